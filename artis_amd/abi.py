@@ -1,0 +1,272 @@
+"""ctypes mirror of include/artis_amd.h (the C-ABI structs), backed by numpy arrays.
+
+This is plumbing for tests and bench.py: it only describes memory that is handed
+to the C-ABI (the HIP engine, or -- from tests -- the CPU oracle). It contains no
+physics.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+NSTATS = 40
+STAT_COUNT = 34
+STAT_X_RPKT_STEPS = 34
+STAT_X_KPKT_STEPS = 35
+STAT_X_LINES_VISITED = 36
+STAT_X_MA_JUMPS = 37
+
+TYPE_RPKT = 11
+TYPE_KPKT = 12
+TYPE_ESCAPE = 32
+TYPE_PRE_KPKT = 120
+EMTYPE_NOTSET = -9999000
+EMTYPE_FREEFREE = -9999999
+
+GRID_SPHERICAL1D = 0
+GRID_CARTESIAN3D = 2
+
+STAT_NAMES = [
+    "MA_STAT_ACTIVATION_COLLEXC", "MA_STAT_ACTIVATION_COLLION", "MA_STAT_ACTIVATION_NTCOLLEXC",
+    "MA_STAT_ACTIVATION_NTCOLLION", "MA_STAT_ACTIVATION_BB", "MA_STAT_ACTIVATION_BF", "MA_STAT_ACTIVATION_FB",
+    "MA_STAT_DEACTIVATION_COLLDEEXC", "MA_STAT_DEACTIVATION_COLLRECOMB", "MA_STAT_DEACTIVATION_BB",
+    "MA_STAT_DEACTIVATION_FB", "MA_STAT_INTERNALUPHIGHER", "MA_STAT_INTERNALUPHIGHERNT",
+    "MA_STAT_INTERNALDOWNLOWER", "K_STAT_TO_MA_COLLEXC", "K_STAT_TO_MA_COLLION", "K_STAT_TO_R_FF", "K_STAT_TO_R_FB",
+    "K_STAT_TO_R_BB", "K_STAT_FROM_FF", "K_STAT_FROM_BF", "NT_STAT_FROM_GAMMA", "NT_STAT_TO_IONISATION",
+    "NT_STAT_TO_EXCITATION", "NT_STAT_TO_KPKT", "K_STAT_FROM_EARLIERDECAY", "INTERACTIONS", "ELECTRON_SCATTERINGS",
+    "RESONANCESCATTERINGS", "CELLCROSSINGS", "UPSCATTER", "DOWNSCATTER", "UPDATECELL", "PKTESCAPES",
+    "X_RPKT_STEPS", "X_KPKT_STEPS", "X_LINES_VISITED", "X_MA_JUMPS", "X_38", "X_39",
+]
+
+# struct artis_packet (include/artis_amd.h), natural C alignment == numpy align=True
+PACKET_DTYPE = np.dtype(
+    [
+        ("rngstate", np.uint32, (4,)),
+        ("prop_time", np.float64),
+        ("pos", np.float64, (3,)),
+        ("dir", np.float64, (3,)),
+        ("nu_cmf", np.float64),
+        ("e_cmf", np.float64),
+        ("nu_rf", np.float64),
+        ("e_rf", np.float64),
+        ("next_trans", np.int32),
+        ("nscatterings", np.int32),
+        ("emissiontype", np.int32),
+        ("em_pos", np.float64, (3,)),
+        ("em_time", np.float32),
+        ("absorptiontype", np.int32),
+        ("absorptionfreq", np.float64),
+        ("stokes_q", np.float64),
+        ("stokes_u", np.float64),
+        ("trueemissiontype", np.int32),
+        ("trueem_pos", np.float64, (3,)),
+        ("trueem_time", np.float32),
+        ("type", np.int32),
+        ("cellindex", np.int32),
+        ("escape_type", np.int32),
+        ("escape_time", np.float32),
+        ("tdecay", np.float64),
+        ("number", np.int32),
+        ("originated_from_particlenotgamma", np.uint8),
+        ("pellet_decaytype", np.int32),
+        ("pellet_nucindex", np.int32),
+    ],
+    align=True,
+)
+
+PACKET_INT_FIELDS = ["next_trans", "nscatterings", "emissiontype", "absorptiontype", "trueemissiontype", "type",
+                     "cellindex", "escape_type", "number"]
+PACKET_FLOAT_FIELDS = ["prop_time", "pos", "dir", "nu_cmf", "e_cmf", "nu_rf", "e_rf", "em_pos", "em_time",
+                       "absorptionfreq", "stokes_q", "stokes_u", "trueem_pos", "trueem_time", "escape_time"]
+
+_I32P = C.POINTER(C.c_int32)
+_F32P = C.POINTER(C.c_float)
+_F64P = C.POINTER(C.c_double)
+_U8P = C.POINTER(C.c_uint8)
+_I64P = C.POINTER(C.c_int64)
+
+# (name, ctype-or-pointer, numpy dtype or None for scalars) in the exact order of struct artis_model
+_MODEL_FIELDS = [
+    ("nelements", C.c_int32, None), ("nions", C.c_int32, None), ("nlevels", C.c_int32, None),
+    ("nlines", C.c_int32, None), ("nalltrans", C.c_int32, None), ("nphixstargets_total", C.c_int32, None),
+    ("nphixslevels", C.c_int32, None), ("nbfcontinua", C.c_int32, None), ("nbfcontinua_ground", C.c_int32, None),
+    ("ncoolingterms", C.c_int32, None), ("nmatransblock", C.c_int32, None), ("NPHIXSPOINTS", C.c_int32, None),
+    ("NPHIXSNUINCREMENT", C.c_double, None),
+    ("elem_nions", _I32P, np.int32), ("elem_uniqueionindexstart", _I32P, np.int32), ("elem_anumber", _I32P, np.int32),
+    ("elem_lowest_ionstage", _I32P, np.int32),
+    ("ion_element", _I32P, np.int32), ("ion_nlevels", _I32P, np.int32), ("ion_nlevels_ionising", _I32P, np.int32),
+    ("ion_maxrecombininglevel", _I32P, np.int32), ("ion_uniquelevelindexstart", _I32P, np.int32),
+    ("ion_coolingoffset", _I32P, np.int32), ("ion_ncoolingterms", _I32P, np.int32),
+    ("level_epsilon", _F64P, np.float64), ("level_statweight", _F32P, np.float32),
+    ("level_alltrans_startdown", _I32P, np.int32), ("level_ndowntrans", _I32P, np.int32),
+    ("level_nuptrans", _I32P, np.int32), ("level_closestgroundlevelcont", _I32P, np.int32),
+    ("level_phixsstart", _I32P, np.int32), ("level_nphixstargets", _I32P, np.int32),
+    ("level_phixstargetstart", _I32P, np.int32), ("level_bflist_start", _I32P, np.int32),
+    ("level_matransblock_start", _I32P, np.int32),
+    ("alltrans_lineindex", _I32P, np.int32), ("alltrans_targetlevelindex", _I32P, np.int32),
+    ("alltrans_einstein_A", _F32P, np.float32), ("alltrans_coll_str", _F32P, np.float32),
+    ("alltrans_osc_strength", _F32P, np.float32), ("alltrans_forbidden", _U8P, np.uint8),
+    ("line_nu", _F64P, np.float64), ("line_elementindex", _I32P, np.int32), ("line_ionindex", _I32P, np.int32),
+    ("line_uniquelevelindex_lower", _I32P, np.int32), ("line_uniquelevelindex_upper", _I32P, np.int32),
+    ("line_B_ul", _F32P, np.float32), ("line_B_lu", _F32P, np.float32),
+    ("allphixs", _F32P, np.float32), ("allphixstargets_levelindex", _I32P, np.int32),
+    ("allphixstargets_probability", _F64P, np.float64),
+    ("allcont_nu_edge", _F64P, np.float64), ("allcont_element", _I32P, np.int32), ("allcont_ion", _I32P, np.int32),
+    ("allcont_level", _I32P, np.int32), ("allcont_phixstargetindex", _I32P, np.int32),
+    ("allcont_upperlevel", _I32P, np.int32), ("allcont_uniquelevelindex", _I32P, np.int32),
+    ("allcont_probability", _F64P, np.float64), ("allcont_groundcontestimindex", _I32P, np.int32),
+    ("groundcont_nu_edge", _F64P, np.float64),
+    ("spontrecombcoeffs", _F64P, np.float64), ("corrphotoioncoeffs", _F64P, np.float64),
+    ("bfcooling_coeffs", _F64P, np.float64),
+    ("coolinglist_type", _U8P, np.uint8), ("coolinglist_level", _I32P, np.int32),
+    ("coolinglist_phixstargetindex", _I32P, np.int32),
+    ("gridtype", C.c_int32, None), ("ncoordgrid", C.c_int32 * 3, "i3"), ("ngrid", C.c_int32, None),
+    ("npts_nonempty", C.c_int32, None), ("tmin", C.c_double, None), ("vmax", C.c_double, None),
+    ("rmax", C.c_double, None), ("coord_pos_min_tmin", _F64P * 3, "p3"), ("propcell_nonemptymgi", _I32P, np.int32),
+]
+
+_CELL_FIELDS = [
+    ("rho", _F32P, np.float32), ("Te", _F32P, np.float32), ("TJ", _F32P, np.float32), ("TR", _F32P, np.float32),
+    ("W", _F32P, np.float32), ("nne", _F32P, np.float32), ("nnetot", _F32P, np.float32),
+    ("kappagrey", _F32P, np.float32), ("thick", _I32P, np.int32), ("clumpfactor", _F32P, np.float32),
+    ("ion_groundlevelpops", _F32P, np.float32), ("ion_partfuncts", _F32P, np.float32),
+    ("elem_massfracs", _F32P, np.float32), ("corrphotoionrenorm", _F64P, np.float64),
+]
+
+
+class CModel(C.Structure):
+    _fields_ = [(n, t) for n, t, _ in _MODEL_FIELDS]
+
+
+class CCellState(C.Structure):
+    _fields_ = [(n, t) for n, t, _ in _CELL_FIELDS]
+
+
+class CTimestep(C.Structure):
+    _fields_ = [("nts", C.c_int32), ("start", C.c_double), ("width", C.c_double), ("mid", C.c_double),
+                ("max_path_step", C.c_double)]
+
+
+class CEstimators(C.Structure):
+    _fields_ = [("J", _F64P), ("nuJ", _F64P), ("ffheatingestimator", _F64P), ("colheatingestimator", _F64P),
+                ("gammaestimator", _F64P), ("bfheatingestimator", _F64P), ("stats", _I64P)]
+
+
+def _as_ptr(arr: np.ndarray, ptype):
+    return arr.ctypes.data_as(ptype)
+
+
+class Model:
+    """Static model: dict of numpy arrays + scalars -> struct artis_model."""
+
+    def __init__(self, d: dict):
+        self.d = {}
+        self.c = CModel()
+        for name, ctype, npdt in _MODEL_FIELDS:
+            v = d[name]
+            if npdt is None:
+                setattr(self.c, name, v)
+                self.d[name] = v
+            elif npdt == "i3":
+                arr = np.ascontiguousarray(v, dtype=np.int32)
+                self.d[name] = arr
+                for k in range(3):
+                    self.c.ncoordgrid[k] = int(arr[k])
+            elif npdt == "p3":
+                arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in v]
+                self.d[name] = arrs
+                for k in range(3):
+                    self.c.coord_pos_min_tmin[k] = _as_ptr(arrs[k], _F64P)
+            else:
+                arr = np.ascontiguousarray(v, dtype=npdt)
+                if arr.size == 0:  # keep a valid pointer for empty tables
+                    arr = np.zeros(1, dtype=npdt)
+                self.d[name] = arr
+                setattr(self.c, name, _as_ptr(arr, ctype))
+
+    def __getitem__(self, k):
+        return self.d[k]
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+class CellState:
+    def __init__(self, d: dict):
+        self.d = {}
+        self.c = CCellState()
+        for name, ctype, npdt in _CELL_FIELDS:
+            arr = np.ascontiguousarray(d[name], dtype=npdt)
+            if arr.size == 0:
+                arr = np.zeros(1, dtype=npdt)
+            self.d[name] = arr
+            setattr(self.c, name, _as_ptr(arr, ctype))
+
+    def __getitem__(self, k):
+        return self.d[k]
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+class Timestep:
+    def __init__(self, nts: int, start: float, width: float, mid: float, max_path_step: float):
+        self.c = CTimestep(nts, start, width, mid, max_path_step)
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+class Estimators:
+    """Host estimator arrays (accumulated into by update_packets)."""
+
+    def __init__(self, npts_nonempty: int, nbfcontinua_ground: int):
+        n, g = npts_nonempty, max(nbfcontinua_ground, 1)
+        self.J = np.zeros(n)
+        self.nuJ = np.zeros(n)
+        self.ffheatingestimator = np.zeros(n)
+        self.colheatingestimator = np.zeros(n)
+        self.gammaestimator = np.zeros(n * g)
+        self.bfheatingestimator = np.zeros(n * g)
+        self.stats = np.zeros(NSTATS, dtype=np.int64)
+        self.c = CEstimators(
+            _as_ptr(self.J, _F64P), _as_ptr(self.nuJ, _F64P), _as_ptr(self.ffheatingestimator, _F64P),
+            _as_ptr(self.colheatingestimator, _F64P), _as_ptr(self.gammaestimator, _F64P),
+            _as_ptr(self.bfheatingestimator, _F64P), _as_ptr(self.stats, _I64P))
+
+    def ref(self):
+        return C.byref(self.c)
+
+    def arrays(self):
+        return {"J": self.J, "nuJ": self.nuJ, "ffheatingestimator": self.ffheatingestimator,
+                "colheatingestimator": self.colheatingestimator, "gammaestimator": self.gammaestimator,
+                "bfheatingestimator": self.bfheatingestimator}
+
+    def stats_dict(self):
+        return {STAT_NAMES[i]: int(self.stats[i]) for i in range(NSTATS)}
+
+
+def packets_ptr(packets: np.ndarray):
+    assert packets.dtype == PACKET_DTYPE and packets.flags["C_CONTIGUOUS"]
+    return packets.ctypes.data_as(C.c_void_p)
+
+
+def seed_packet_rng(packets: np.ndarray, seed_base: int) -> None:
+    """Per-packet Xoshiro128PP seeding: seed = seed_base + n through SplitMix32
+    (reference random.h:32-40, 78-93, 117-123 and input.cc:1912-1916)."""
+    n = len(packets)
+    seed = (np.uint64(seed_base) + np.arange(n, dtype=np.uint64)) & np.uint64(0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        st = seed + np.uint64(0x9E3779B97F4A7C15)
+        st = (st ^ (st >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        st = (st ^ (st >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        sm = ((st ^ (st >> np.uint64(31))) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        out = np.empty((n, 4), dtype=np.uint32)
+        for i in range(4):
+            sm = sm + np.uint32(0x9E3779B9)
+            r = sm.copy()
+            r = (r ^ (r >> np.uint32(16))) * np.uint32(0x21F0AAAD)
+            r = (r ^ (r >> np.uint32(15))) * np.uint32(0x735A2D97)
+            out[:, i] = r ^ (r >> np.uint32(15))
+    packets["rngstate"] = out

@@ -1,0 +1,561 @@
+"""Synthetic atomic data and W7-like ejecta for tests and bench.py.
+
+There is no network in the build or GPU environment, so the reference's atomic
+data release (tests/setup_classicmode_3d.sh downloads atomicdata_classic.tar.xz)
+is not available. This module builds a self-consistent stand-in with the same
+TABLE STRUCTURE the reference's input.cc produces (line list sorted by falling
+frequency, alltrans blocks per level, continua sorted by rising edge frequency,
+ground-continuum estimator indices, cooling list, temperature LUTs) and a
+W7-like exponential-density ejecta mapped on a Cartesian (or 1D spherical) grid.
+
+It is host-side set-up code (the reference does this in input.cc / grid.cc /
+ratecoeff.cc / update_grid.cc, all outside the packet path). Physical fidelity is
+"plausible", not a reproduction of real atomic data; structural rules are cited.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import abi
+
+CLIGHT = 2.99792458e10
+H = 6.6260755e-27
+KB = 1.38064852e-16
+EV = 1.6021772e-12
+ME = 9.1093897e-28
+QE = 4.80325e-10
+MH = 1.67352e-24
+MSUN = 1.98855e33
+DAY = 86400.0
+SAHACONST = 2.0706659e-16
+CLIGHTSQUAREDOVERTWOH = CLIGHT**2 / (2 * H)
+TABLESIZE = 100
+MINTEMP = 3500.0
+MAXTEMP = 140000.0
+MINPOP = 1e-30
+
+# ionisation potentials [eV] of stages I.. (NIST values, rounded); fallback formula otherwise
+_IONPOT = {
+    8: [13.62, 35.12, 54.94, 77.41, 113.9],
+    14: [8.15, 16.35, 33.49, 45.14, 166.8],
+    16: [10.36, 23.34, 34.79, 47.22, 72.59],
+    20: [6.11, 11.87, 50.91, 67.27, 84.5],
+    26: [7.90, 16.20, 30.65, 54.91, 75.0],
+    27: [7.88, 17.08, 33.50, 51.27, 79.5],
+    28: [7.64, 18.17, 35.19, 54.92, 76.06],
+}
+_AMASS = {8: 16.0, 14: 28.09, 16: 32.06, 20: 40.08, 26: 55.85, 27: 58.93, 28: 58.69}
+
+
+def _ionpot_ev(Z: int, stage: int) -> float:
+    tab = _IONPOT.get(Z)
+    if tab is not None and stage - 1 < len(tab):
+        return tab[stage - 1]
+    return 7.5 * stage**1.6
+
+
+def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fraction: float = 0.4,
+                nphixspoints: int = 40, phixsnuincrement: float = 0.1, two_target_fraction: float = 0.25,
+                forbidden_fraction: float = 0.2, collstr_fraction: float = 0.1) -> dict:
+    """Build the atomic part of struct artis_model. `elements` = list of (Z, lowest_ionstage, nions)."""
+    rng = np.random.default_rng(seed)
+    if elements is None:
+        elements = [(14, 1, 4), (26, 1, 5), (27, 1, 5)]
+    nelements = len(elements)
+
+    elem_nions, elem_uiis, elem_anumber, elem_lowest = [], [], [], []
+    ion_element, ion_nlevels, ion_uls = [], [], []
+    level_eps, level_g, level_ion = [], [], []
+    ion_ionpot = []
+    nions_total = 0
+    for e, (Z, lowest, nions) in enumerate(elements):
+        elem_nions.append(nions)
+        elem_uiis.append(nions_total)
+        elem_anumber.append(Z)
+        elem_lowest.append(lowest)
+        eps_ground = 0.0
+        for ion in range(nions):
+            stage = lowest + ion
+            ionpot = _ionpot_ev(Z, stage) * EV
+            top = ion == nions - 1
+            nl = 1 if top else nlevels_per_ion  # SINGLE_LEVEL_TOP_ION (artisoptions_classic.h:28)
+            frac = np.sort(rng.random(nl - 1)) if nl > 1 else np.zeros(0)
+            E = np.concatenate([[0.0], 0.9 * ionpot * (0.04 + 0.96 * frac**0.8)])
+            E = np.sort(E)
+            ion_element.append(e)
+            ion_nlevels.append(nl)
+            ion_uls.append(len(level_eps))
+            ion_ionpot.append(ionpot)
+            for k in range(nl):
+                level_eps.append(eps_ground + E[k])
+                level_g.append(float(rng.integers(1, 11)))
+                level_ion.append(nions_total)
+            eps_ground += ionpot
+            nions_total += 1
+    nlevels = len(level_eps)
+    level_eps = np.array(level_eps)
+    level_g = np.array(level_g, dtype=np.float32)
+    ion_uls = np.array(ion_uls, dtype=np.int32)
+    ion_nlevels = np.array(ion_nlevels, dtype=np.int32)
+    ion_element = np.array(ion_element, dtype=np.int32)
+
+    # ---- bound-bound transitions
+    lines = []  # (nu, ion, lower(level in ion), upper, A, collstr, forbidden)
+    for ui in range(nions_total):
+        nl = ion_nlevels[ui]
+        s = ion_uls[ui]
+        for lo in range(nl):
+            for up in range(lo + 1, nl):
+                if rng.random() >= line_fraction:
+                    continue
+                dE = level_eps[s + up] - level_eps[s + lo]
+                nu = dE / H
+                if nu < 2e13:
+                    continue
+                forb = rng.random() < forbidden_fraction
+                A = 10 ** rng.uniform(-2, 2) if forb else 10 ** rng.uniform(5.0, 8.5) * min(1.0, (dE / (5 * EV)) ** 2)
+                cs = rng.uniform(0.1, 5.0) if rng.random() < collstr_fraction else -1.0
+                lines.append((nu, ui, lo, up, A, cs, forb))
+    # the line list is sorted by falling frequency (input.cc: linelist sort; rpkt.h:179)
+    lines.sort(key=lambda t: -t[0])
+    nlines = len(lines)
+    line_nu = np.array([t[0] for t in lines])
+    # recompute nu exactly as the path does (macroatom.cc:229: nu = epsilon_trans / H)
+    line_ui = np.array([t[1] for t in lines], dtype=np.int32)
+    line_lo = np.array([t[2] for t in lines], dtype=np.int32)
+    line_up = np.array([t[3] for t in lines], dtype=np.int32)
+    line_A = np.array([t[4] for t in lines], dtype=np.float32)
+    line_cs = np.array([t[5] for t in lines], dtype=np.float32)
+    line_forb = np.array([t[6] for t in lines], dtype=np.uint8)
+    line_ul_lower = ion_uls[line_ui] + line_lo
+    line_ul_upper = ion_uls[line_ui] + line_up
+    line_nu = (level_eps[line_ul_upper] - level_eps[line_ul_lower]) / H
+    order = np.argsort(-line_nu, kind="stable")
+    (line_nu, line_ui, line_lo, line_up, line_A, line_cs, line_forb, line_ul_lower, line_ul_upper) = (
+        a[order] for a in (line_nu, line_ui, line_lo, line_up, line_A, line_cs, line_forb, line_ul_lower, line_ul_upper))
+    g_u = level_g[line_ul_upper].astype(np.float64)
+    g_l = level_g[line_ul_lower].astype(np.float64)
+    B_ul = (CLIGHTSQUAREDOVERTWOH / line_nu**3 * line_A.astype(np.float64)).astype(np.float32)
+    B_lu = (g_u / g_l * B_ul.astype(np.float64)).astype(np.float32)
+    f_lu = (g_u / g_l * line_A.astype(np.float64) * ME * CLIGHT**3 / (8 * np.pi**2 * QE**2 * line_nu**2)).astype(np.float32)
+    line_elementindex = ion_element[line_ui]
+    line_ionindex = (line_ui - np.array(elem_uiis, dtype=np.int32)[line_elementindex]).astype(np.int32)
+
+    # alltrans: per level its down transitions, then its up transitions (atomic.h:462-471)
+    downs = [[] for _ in range(nlevels)]
+    ups = [[] for _ in range(nlevels)]
+    for li in range(nlines):
+        downs[line_ul_upper[li]].append((int(line_lo[li]), li))
+        ups[line_ul_lower[li]].append((int(line_up[li]), li))
+    at_line, at_target, at_A, at_cs, at_f, at_forb = [], [], [], [], [], []
+    level_startdown = np.zeros(nlevels, dtype=np.int32)
+    level_ndown = np.zeros(nlevels, dtype=np.int32)
+    level_nup = np.zeros(nlevels, dtype=np.int32)
+    level_mablock = np.zeros(nlevels, dtype=np.int32)
+    mab = 0
+    for ul in range(nlevels):
+        level_startdown[ul] = len(at_line)
+        for lst in (sorted(downs[ul]), sorted(ups[ul])):
+            for target, li in lst:
+                at_line.append(li)
+                at_target.append(target)
+                at_A.append(line_A[li])
+                at_cs.append(line_cs[li])
+                at_f.append(f_lu[li])
+                at_forb.append(line_forb[li])
+        level_ndown[ul] = len(downs[ul])
+        level_nup[ul] = len(ups[ul])
+        level_mablock[ul] = mab  # input.cc:1542
+        mab += 2 * level_ndown[ul] + level_nup[ul]
+
+    # ---- photoionisation: every level of a non-top ion has a table and 1 or 2 targets
+    NP = nphixspoints
+    inc = phixsnuincrement
+    ion_nlevels_ionising = np.zeros(nions_total, dtype=np.int32)
+    ion_maxrecomb = np.full(nions_total, -1, dtype=np.int32)
+    level_phixsstart = np.full(nlevels, -1, dtype=np.int32)
+    level_nphixstargets = np.zeros(nlevels, dtype=np.int32)
+    level_phixstargetstart = np.full(nlevels, -1, dtype=np.int32)
+    level_bflist_start = np.full(nlevels, -1, dtype=np.int32)
+    allphixs = []
+    pt_level, pt_prob = [], []
+    nphixslevels = 0
+    bfl = 0
+    for e, (Z, lowest, nions) in enumerate(elements):
+        for ion in range(nions - 1):
+            ui = elem_uiis[e] + ion
+            nl = ion_nlevels[ui]
+            ion_nlevels_ionising[ui] = nl
+            nl_upper = ion_nlevels[ui + 1]
+            for lev in range(nl):
+                ul = ion_uls[ui] + lev
+                sigma0 = 10 ** rng.uniform(-18.5, -17.3) / (1 + 0.3 * lev)
+                xs = sigma0 * (1.0 + inc * np.arange(NP)) ** -3.0
+                level_phixsstart[ul] = nphixslevels
+                allphixs.append(xs.astype(np.float32))
+                nphixslevels += 1
+                level_phixstargetstart[ul] = len(pt_level)
+                level_bflist_start[ul] = bfl
+                if nl_upper >= 2 and rng.random() < two_target_fraction:
+                    gu0 = float(level_g[ion_uls[ui + 1]])
+                    gu1 = float(level_g[ion_uls[ui + 1] + 1])
+                    p0 = gu0 / (gu0 + gu1)
+                    pt_level += [0, 1]
+                    pt_prob += [p0, 1.0 - p0]
+                    level_nphixstargets[ul] = 2
+                    ion_maxrecomb[ui + 1] = max(ion_maxrecomb[ui + 1], 1)
+                    bfl += 2
+                else:
+                    pt_level += [0]
+                    pt_prob += [1.0]
+                    level_nphixstargets[ul] = 1
+                    ion_maxrecomb[ui + 1] = max(ion_maxrecomb[ui + 1], 0)
+                    bfl += 1
+    nbfcontinua = bfl
+    allphixs = np.concatenate(allphixs) if allphixs else np.zeros(0, dtype=np.float32)
+    pt_level = np.array(pt_level, dtype=np.int32)
+    pt_prob = np.array(pt_prob, dtype=np.float64)
+
+    def threshold(e, ion, lev, t):
+        ul = ion_uls[elem_uiis[e] + ion] + lev
+        upper = pt_level[level_phixstargetstart[ul] + t]
+        return level_eps[ion_uls[elem_uiis[e] + ion + 1] + upper] - level_eps[ul]
+
+    # ground continua, sorted by rising edge (input.cc:785-806)
+    ground = []
+    for e, (Z, lowest, nions) in enumerate(elements):
+        for ion in range(nions - 1):
+            ground.append((threshold(e, ion, 0, 0) / H, e, ion))
+    ground.sort(key=lambda t: t[0])
+    groundcont_nu_edge = np.array([g[0] for g in ground])
+    nbfg = len(ground)
+
+    def search_groundphixslist(nu_edge, e_in, ion_in, lev_in):  # input.cc:703
+        if nbfg <= 0 or nu_edge < groundcont_nu_edge[0]:
+            return -1
+        i = 1
+        while i < nbfg and not (nu_edge < groundcont_nu_edge[i]):
+            i += 1
+        if i == nbfg:
+            return i - 1
+        left = nu_edge - groundcont_nu_edge[i - 1]
+        right = groundcont_nu_edge[i] - nu_edge
+        return i - 1 if left <= right else i
+
+    level_closest = np.full(nlevels, -1, dtype=np.int32)
+    conts = []
+    for e, (Z, lowest, nions) in enumerate(elements):
+        for ion in range(nions - 1):
+            ui = elem_uiis[e] + ion
+            for lev in range(ion_nlevels_ionising[ui]):
+                ul = ion_uls[ui] + lev
+                level_closest[ul] = search_groundphixslist(threshold(e, ion, lev, 0) / H, e, ion, lev)
+                for t in range(level_nphixstargets[ul]):
+                    gci = level_closest[ul] if (lev == 0 and t == 0) else -1
+                    conts.append((threshold(e, ion, lev, t) / H, e, ion, lev, t, int(pt_level[level_phixstargetstart[ul] + t]),
+                                  ul, float(pt_prob[level_phixstargetstart[ul] + t]), gci))
+    conts.sort(key=lambda t: t[0])  # stable sort by nu_edge (input.cc:893)
+    assert len(conts) == nbfcontinua
+
+    # ---- cooling list (kpkt.cc:233 set_ncoolingterms, kpkt.cc:311 setup_coolinglist)
+    ion_coolingoffset = np.zeros(nions_total, dtype=np.int32)
+    ion_ncoolingterms = np.zeros(nions_total, dtype=np.int32)
+    cl_type, cl_level, cl_t = [], [], []
+    for e, (Z, lowest, nions) in enumerate(elements):
+        for ion in range(nions):
+            ui = elem_uiis[e] + ion
+            ion_coolingoffset[ui] = len(cl_type)
+            if lowest + ion - 1 > 0:
+                cl_type.append(0); cl_level.append(-99); cl_t.append(-99)
+            for lev in range(ion_nlevels[ui]):
+                if level_nup[ion_uls[ui] + lev] > 0:
+                    cl_type.append(2); cl_level.append(lev); cl_t.append(-1)
+            if ion < nions - 1:
+                for ctype in (3, 1):  # COLLION block, then FREEBOUND block
+                    for lev in range(ion_nlevels_ionising[ui]):
+                        for t in range(level_nphixstargets[ion_uls[ui] + lev]):
+                            cl_type.append(ctype); cl_level.append(lev); cl_t.append(t)
+            ion_ncoolingterms[ui] = len(cl_type) - ion_coolingoffset[ui]
+
+    # ---- temperature LUTs (ratecoeff.cc:143 precalculate_rate_coefficient_integrals), simple quadrature
+    T_step_log = (np.log(MAXTEMP) - np.log(MINTEMP)) / (TABLESIZE - 1.0)
+    Tgrid = (MINTEMP * np.exp(np.arange(TABLESIZE) * T_step_log)).astype(np.float32).astype(np.float64)
+    spont = np.zeros((nbfcontinua, TABLESIZE))
+    gammac = np.zeros((nbfcontinua, TABLESIZE))
+    bfcool = np.zeros((nbfcontinua, TABLESIZE))
+    nsub = 6
+    for e, (Z, lowest, nions) in enumerate(elements):
+        for ion in range(nions - 1):
+            ui = elem_uiis[e] + ion
+            for lev in range(ion_nlevels_ionising[ui]):
+                ul = ion_uls[ui] + lev
+                xs = allphixs[level_phixsstart[ul] * NP:(level_phixsstart[ul] + 1) * NP].astype(np.float64)
+                for t in range(level_nphixstargets[ul]):
+                    ci = level_bflist_start[ul] + t
+                    nu_thr = threshold(e, ion, lev, t) / H
+                    prob = pt_prob[level_phixstargetstart[ul] + t]
+                    g_low = float(level_g[ul])
+                    g_up = float(level_g[ion_uls[ui + 1] + pt_level[level_phixstargetstart[ul] + t]])
+                    # sample the NP-1 table cells between nu_thr and nu_thr*last_phixs_nuovernuedge
+                    k = np.arange((NP - 1) * nsub)
+                    x = (k + 0.5) / nsub * inc * nu_thr  # nu - nu_edge
+                    dx = inc * nu_thr / nsub
+                    sig = xs[np.minimum((k // nsub), NP - 1)]
+                    nu = nu_thr + x
+                    ex = np.exp(-H * x[None, :] / (KB * Tgrid[:, None]))
+                    saha = SAHACONST * g_low / g_up * Tgrid**-1.5
+                    spont[ci] = 4 * np.pi * saha * prob * np.sum((2 / CLIGHT**2) * sig * nu**2 * ex, axis=1) * dx
+                    bfcool[ci] = 4 * np.pi * saha * prob * np.sum(sig * x * (2 * H / CLIGHT**2) * nu**2 * ex, axis=1) * dx
+                    hnkt = H * nu[None, :] / (KB * Tgrid[:, None])
+                    planck = 2 * H * nu**3 / CLIGHT**2 / np.expm1(hnkt)
+                    gammac[ci] = 4 * np.pi * prob * np.sum(sig / (H * nu) * planck * (1 - np.exp(-hnkt)), axis=1) * dx
+
+    d = dict(
+        nelements=nelements, nions=nions_total, nlevels=nlevels, nlines=nlines, nalltrans=len(at_line),
+        nphixstargets_total=len(pt_level), nphixslevels=nphixslevels, nbfcontinua=nbfcontinua, nbfcontinua_ground=nbfg,
+        ncoolingterms=len(cl_type), nmatransblock=int(mab), NPHIXSPOINTS=NP, NPHIXSNUINCREMENT=float(inc),
+        elem_nions=elem_nions, elem_uniqueionindexstart=elem_uiis, elem_anumber=elem_anumber,
+        elem_lowest_ionstage=elem_lowest,
+        ion_element=ion_element, ion_nlevels=ion_nlevels, ion_nlevels_ionising=ion_nlevels_ionising,
+        ion_maxrecombininglevel=ion_maxrecomb, ion_uniquelevelindexstart=ion_uls,
+        ion_coolingoffset=ion_coolingoffset, ion_ncoolingterms=ion_ncoolingterms,
+        level_epsilon=level_eps, level_statweight=level_g, level_alltrans_startdown=level_startdown,
+        level_ndowntrans=level_ndown, level_nuptrans=level_nup, level_closestgroundlevelcont=level_closest,
+        level_phixsstart=level_phixsstart, level_nphixstargets=level_nphixstargets,
+        level_phixstargetstart=level_phixstargetstart, level_bflist_start=level_bflist_start,
+        level_matransblock_start=level_mablock,
+        alltrans_lineindex=at_line, alltrans_targetlevelindex=at_target, alltrans_einstein_A=at_A,
+        alltrans_coll_str=at_cs, alltrans_osc_strength=at_f, alltrans_forbidden=at_forb,
+        line_nu=line_nu, line_elementindex=line_elementindex, line_ionindex=line_ionindex,
+        line_uniquelevelindex_lower=line_ul_lower, line_uniquelevelindex_upper=line_ul_upper,
+        line_B_ul=B_ul, line_B_lu=B_lu,
+        allphixs=allphixs, allphixstargets_levelindex=pt_level, allphixstargets_probability=pt_prob,
+        allcont_nu_edge=[c[0] for c in conts], allcont_element=[c[1] for c in conts], allcont_ion=[c[2] for c in conts],
+        allcont_level=[c[3] for c in conts], allcont_phixstargetindex=[c[4] for c in conts],
+        allcont_upperlevel=[c[5] for c in conts], allcont_uniquelevelindex=[c[6] for c in conts],
+        allcont_probability=[c[7] for c in conts], allcont_groundcontestimindex=[c[8] for c in conts],
+        groundcont_nu_edge=groundcont_nu_edge,
+        spontrecombcoeffs=spont.ravel(), corrphotoioncoeffs=gammac.ravel(), bfcooling_coeffs=bfcool.ravel(),
+        coolinglist_type=cl_type, coolinglist_level=cl_level, coolinglist_phixstargetindex=cl_t,
+    )
+    d["_elements"] = elements
+    d["_ion_ionpot"] = np.array(ion_ionpot)
+    d["_level_ion"] = np.array(level_ion, dtype=np.int32)
+    return d
+
+
+def _zone_massfracs(elements, v, vmax):
+    """W7-like abundance stratification by velocity: Fe-group core, Co/Ni (decayed 56Ni) zone,
+    Si/S/Ca layer, O-rich outer layer. Elements absent from `elements` are dropped and the rest renormalised."""
+    zones = [
+        (0.12, {26: 0.55, 28: 0.30, 27: 0.10, 14: 0.03, 16: 0.02}),
+        (0.42, {27: 0.55, 26: 0.22, 28: 0.13, 14: 0.05, 16: 0.03, 20: 0.02}),
+        (0.62, {14: 0.55, 16: 0.28, 20: 0.05, 26: 0.06, 27: 0.02, 8: 0.04}),
+        (2.00, {8: 0.70, 14: 0.20, 16: 0.06, 20: 0.01, 26: 0.03, 27: 0.0, 28: 0.0}),
+    ]
+    Zs = [e[0] for e in elements]
+    X = np.zeros((len(v), len(Zs)), dtype=np.float64)
+    x = v / vmax
+    lo = 0.0
+    for hi, comp in zones:
+        sel = (x >= lo) & (x < hi)
+        for j, Z in enumerate(Zs):
+            X[sel, j] = comp.get(Z, 0.0)
+        lo = hi
+    s = X.sum(axis=1, keepdims=True)
+    empty = s[:, 0] <= 0
+    X[empty, :] = 1.0 / len(Zs)
+    s = X.sum(axis=1, keepdims=True)
+    return X / s
+
+
+def make_grid_and_cells(atomic: dict, ncoord: int = 8, gridtype: int = abi.GRID_CARTESIAN3D, t_days: float = 20.0,
+                        tmin_days: float = 2.0, vmax: float = 2.4e9, mass_msun: float = 1.38, ve: float = 2.7e8,
+                        thick_below_v: float = 0.0, seed: int = 7):
+    """W7-like ejecta on an ncoord^3 Cartesian grid (or ncoord radial shells): exponential density profile,
+    stratified composition, Saha ion balance at (T_e, nne). Returns (grid dict, cellstate dict, aux)."""
+    rng = np.random.default_rng(seed)
+    elements = atomic["_elements"]
+    nelements = len(elements)
+    nions = atomic["nions"]
+    tmin = tmin_days * DAY
+    t = t_days * DAY
+    rmax = vmax * tmin
+
+    if gridtype == abi.GRID_CARTESIAN3D:
+        n = ncoord
+        # setup_grid_cartesian_3d grid.cc:1269: coord_pos_min_tmin[axis][i] = -rmax + 2*i*rmax/ncoordgrid
+        cmin = np.array([-rmax + (2 * i * rmax / n) for i in range(n)])
+        centers_v = (cmin + rmax / n) / tmin
+        iz, iy, ix = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+        # cellindex = ix + n*iy + n*n*iz (get_coordcellindexstride grid.cc:200)
+        vx, vy, vz = centers_v[ix.ravel()], centers_v[iy.ravel()], centers_v[iz.ravel()]
+        vr = np.sqrt(vx**2 + vy**2 + vz**2)
+        ngrid = n**3
+        nonempty_mask = vr < vmax
+        ncoordgrid = [n, n, n]
+        coord = [cmin, cmin, cmin]
+        cellvol_tmin = np.full(ngrid, (2 * rmax / n) ** 3)
+    else:
+        n = ncoord
+        vout = vmax * (np.arange(1, n + 1) / n)
+        vin = np.concatenate([[0.0], vout[:-1]])
+        cmin = vin * tmin  # setup_grid_spherical_1d grid.cc:1285
+        vr = 0.5 * (vin + vout)
+        ngrid = n
+        nonempty_mask = np.ones(n, dtype=bool)
+        ncoordgrid = [n, 1, 1]
+        coord = [cmin, np.zeros(1), np.zeros(1)]
+        cellvol_tmin = 4.0 / 3.0 * np.pi * ((vout * tmin) ** 3 - (vin * tmin) ** 3)
+
+    propcell_nonemptymgi = np.full(ngrid, -1, dtype=np.int32)
+    nne_cells = int(nonempty_mask.sum())
+    propcell_nonemptymgi[nonempty_mask] = np.arange(nne_cells, dtype=np.int32)
+    v = vr[nonempty_mask]
+
+    # exponential density: rho(v,t) = M / (8 pi ve^3 t^3) exp(-v/ve)
+    rho = mass_msun * MSUN / (8 * np.pi * ve**3 * t**3) * np.exp(-v / ve)
+    Te = 4000.0 + 12000.0 * np.exp(-v / 1.0e9)
+    TR = Te * (1.0 - 0.05 * rng.random(nne_cells))
+    TJ = Te * (0.92 + 0.05 * rng.random(nne_cells))
+    vph = 0.35 * vmax
+    W = np.where(v < vph, 0.5, 0.5 * (1.0 - np.sqrt(np.clip(1.0 - (vph / np.maximum(v, 1.0)) ** 2, 0.0, 1.0))))
+    W = np.clip(W, 1e-3, 1.0)
+    thick = (v < thick_below_v).astype(np.int32)
+    W = np.where(thick == 1, 1.0, W)
+
+    X = _zone_massfracs(elements, v, vmax)  # [cells, elements]
+    amass = np.array([_AMASS.get(Z, 2.0 * Z) for Z, _, _ in elements])
+    nelem = rho[:, None] * X / (amass[None, :] * MH)  # number density of each element
+
+    # Saha ion balance with partition functions U = sum g exp(-E/kT_J)
+    level_ion = atomic["_level_ion"]
+    eps = np.asarray(atomic["level_epsilon"])
+    g = np.asarray(atomic["level_statweight"], dtype=np.float64)
+    ion_uls = np.asarray(atomic["ion_uniquelevelindexstart"])
+    U = np.zeros((nne_cells, nions))
+    for ul in range(len(eps)):
+        ui = level_ion[ul]
+        U[:, ui] += g[ul] * np.exp(-(eps[ul] - eps[ion_uls[ui]]) / (KB * TJ))
+    ionpot = atomic["_ion_ionpot"]
+    elem_uiis = np.asarray(atomic["elem_uniqueionindexstart"])
+    elem_nions = np.asarray(atomic["elem_nions"])
+    lowest = np.asarray(atomic["elem_lowest_ionstage"])
+    nne = 0.5 * nelem.sum(axis=1) + 1.0
+    nion = np.zeros((nne_cells, nions))
+    for _ in range(60):
+        nne_new = np.zeros(nne_cells)
+        for e in range(nelements):
+            ni = elem_nions[e]
+            s0 = elem_uiis[e]
+            logr = np.zeros((nne_cells, ni))
+            for k in range(1, ni):
+                # n_{k}/n_{k-1} = (2 U_k / U_{k-1}) / (nne * SAHACONST-like) ... Saha
+                phi = (2.0 * U[:, s0 + k] / U[:, s0 + k - 1]) * (2 * np.pi * ME * KB * Te / H**2) ** 1.5 * np.exp(
+                    -ionpot[s0 + k - 1] / (KB * Te))
+                logr[:, k] = logr[:, k - 1] + np.log(np.maximum(phi / nne, 1e-300))
+            logr -= logr.max(axis=1, keepdims=True)
+            f = np.exp(logr)
+            f /= f.sum(axis=1, keepdims=True)
+            nion[:, s0:s0 + ni] = nelem[:, e:e + 1] * f
+            charge = (lowest[e] - 1) + np.arange(ni)
+            nne_new += (nion[:, s0:s0 + ni] * charge[None, :]).sum(axis=1)
+        nne = np.sqrt(nne * np.maximum(nne_new, 1e-3))
+    Zs = np.array([Z for Z, _, _ in elements], dtype=np.float64)
+    nnetot = (nelem * Zs[None, :]).sum(axis=1)
+    g0 = g[ion_uls]
+    groundpops = nion * g0[None, :] / U
+
+    nbfg = atomic["nbfcontinua_ground"]
+    renorm = 0.8 + 0.4 * rng.random((nne_cells, max(nbfg, 1)))
+
+    grid = dict(gridtype=gridtype, ncoordgrid=ncoordgrid, ngrid=int(ngrid), npts_nonempty=nne_cells, tmin=float(tmin),
+                vmax=float(vmax), rmax=float(rmax), coord_pos_min_tmin=coord, propcell_nonemptymgi=propcell_nonemptymgi)
+    cells = dict(rho=rho, Te=Te, TJ=TJ, TR=TR, W=W, nne=nne, nnetot=nnetot, kappagrey=np.full(nne_cells, 0.1),
+                 thick=thick, clumpfactor=np.ones(nne_cells), ion_groundlevelpops=groundpops.ravel(),
+                 ion_partfuncts=U.ravel(), elem_massfracs=X.ravel(), corrphotoionrenorm=renorm.ravel())
+    aux = dict(t=t, v=v, X=X, cellvol_tmin=cellvol_tmin[nonempty_mask], nonempty_cellindex=np.nonzero(nonempty_mask)[0])
+    return grid, cells, aux
+
+
+def make_timestep(t: float, width_frac: float = 0.05, vmax: float = 2.4e9, nts: int = 10) -> abi.Timestep:
+    width = t * width_frac
+    mid = np.sqrt(t * (t + width))  # logarithmic mid time
+    return abi.Timestep(nts, t, width, mid, min(1e35, vmax * mid / 10.0))  # update_grid.cc:753
+
+
+def make_packets(model: abi.Model, aux: dict, npackets: int, seed_base: int = 12345, kpkt_fraction: float = 0.1,
+                 e_total: float = 1e45, seed: int = 99) -> np.ndarray:
+    """Packets at the start of the timestep: thermal energy waiting to be emitted (TYPE_PRE_KPKT -> blackbody
+    r-packet, kpkt.cc:399) or k-packets (kpkt.cc:425), placed in non-empty cells with probability ~ rho * X(Co,Ni,Fe)."""
+    rng = np.random.default_rng(seed)
+    t = aux["t"]
+    d = model.d
+    tmin = d["tmin"]
+    pk = np.zeros(npackets, dtype=abi.PACKET_DTYPE)
+    cells = aux["nonempty_cellindex"]
+    w = aux["cellvol_tmin"] * np.exp(-aux["v"] / 4.0e8)
+    w = w / w.sum()
+    which = rng.choice(len(cells), size=npackets, p=w)
+    cellindex = cells[which]
+    u = 0.02 + 0.96 * rng.random((npackets, 3))
+    if d["gridtype"] == abi.GRID_CARTESIAN3D:
+        n = int(d["ncoordgrid"][0])
+        cmin = d["coord_pos_min_tmin"][0]
+        dx = 2 * d["rmax"] / n
+        ix = cellindex % n
+        iy = (cellindex // n) % n
+        iz = cellindex // (n * n)
+        pos = np.stack([cmin[ix] + u[:, 0] * dx, cmin[iy] + u[:, 1] * dx, cmin[iz] + u[:, 2] * dx], axis=1) * (t / tmin)
+    else:
+        n = int(d["ncoordgrid"][0])
+        cmin = d["coord_pos_min_tmin"][0]
+        cmax = np.concatenate([cmin[1:], [d["rmax"]]])
+        r = (cmin[cellindex] + u[:, 0] * (cmax[cellindex] - cmin[cellindex])) * (t / tmin)
+        mu = 2 * u[:, 1] - 1
+        phi = 2 * np.pi * u[:, 2]
+        s = np.sqrt(1 - mu**2)
+        pos = np.stack([r * s * np.cos(phi), r * s * np.sin(phi), r * mu], axis=1)
+    pk["pos"] = pos
+    pk["prop_time"] = t
+    pk["e_cmf"] = e_total / npackets
+    pk["e_rf"] = e_total / npackets
+    pk["next_trans"] = -1
+    pk["emissiontype"] = abi.EMTYPE_NOTSET
+    pk["em_pos"] = np.nan
+    pk["em_time"] = -1.0
+    pk["trueemissiontype"] = abi.EMTYPE_NOTSET
+    pk["trueem_pos"] = np.nan
+    pk["trueem_time"] = -1.0
+    pk["type"] = np.where(rng.random(npackets) < kpkt_fraction, abi.TYPE_KPKT, abi.TYPE_PRE_KPKT)
+    pk["cellindex"] = cellindex
+    pk["escape_time"] = -1.0
+    pk["tdecay"] = -1.0
+    pk["number"] = np.arange(npackets, dtype=np.int32)
+    pk["pellet_decaytype"] = -1
+    pk["pellet_nucindex"] = -1
+    abi.seed_packet_rng(pk, seed_base)
+    return pk
+
+
+PRESETS = {
+    # name: (elements, nlevels_per_ion, line_fraction, nphixspoints)
+    "tiny": ([(14, 1, 3), (26, 1, 4)], 6, 0.5, 12),
+    "small": ([(14, 1, 4), (26, 1, 5), (27, 1, 5)], 12, 0.4, 40),
+    "w7": ([(8, 1, 4), (14, 1, 5), (16, 1, 5), (20, 1, 4), (26, 1, 5), (27, 1, 5), (28, 1, 5)], 60, 0.3, 100),
+}
+
+
+def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTESIAN3D, seed: int = 1,
+          t_days: float = 20.0, thick_below_v: float = 0.0, width_frac: float = 0.05):
+    """One-call construction of (Model, CellState, Timestep, aux)."""
+    elements, nl, lf, npx = PRESETS[preset]
+    atomic = make_atomic(seed=seed, elements=elements, nlevels_per_ion=nl, line_fraction=lf, nphixspoints=npx)
+    grid, cells, aux = make_grid_and_cells(atomic, ncoord=ncoord, gridtype=gridtype, t_days=t_days,
+                                           thick_below_v=thick_below_v, seed=seed + 100)
+    md = {k: v for k, v in atomic.items() if not k.startswith("_")}
+    md.update(grid)
+    model = abi.Model(md)
+    cs = abi.CellState(cells)
+    ts = make_timestep(aux["t"], width_frac=width_frac, vmax=grid["vmax"])
+    return model, cs, ts, aux

@@ -1,0 +1,360 @@
+/*
+ * artis_amd.h -- C-ABI of the MI355X packet-propagation engine for ARTIS.
+ *
+ * Drop-in boundary: the per-timestep packet update of the reference,
+ *   update_packets(nts, packets)                     update_packets.cc:530
+ *     -> update_packet_cellcache_group()             update_packets.cc:468
+ *        -> do_packet() for TYPE_RPKT / TYPE_KPKT / TYPE_PRE_KPKT
+ *                                                    update_packets.cc:257
+ *           -> do_rpkt() / do_rpkt_step()            rpkt.cc:983 / rpkt.cc:542
+ *           -> kpkt::do_kpkt(), do_kpkt_blackbody()  kpkt.cc:425 / kpkt.cc:399
+ *           -> do_macroatom()                        macroatom.cc:360
+ *     preceded by cellcacheslot_populate()           update_packets.cc:397
+ * and the estimator reduction radfield::reduce_estimators() radfield.cc:988.
+ *
+ * Every struct below is a flat view (plain pointers and sizes) of arrays the
+ * reference already owns; field names follow the reference's globals.
+ * Nothing here depends on torch, HIP types or C++.
+ */
+#ifndef ARTIS_AMD_H
+#define ARTIS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums: values are the reference's, they are written to packets*.out -- */
+/* packet.h:38 enum packet_type */
+enum {
+  ARTIS_TYPE_NONE = 0,
+  ARTIS_TYPE_GAMMA = 10,
+  ARTIS_TYPE_RPKT = 11,
+  ARTIS_TYPE_KPKT = 12,
+  ARTIS_TYPE_MA = 13,
+  ARTIS_TYPE_NTLEPTON_DEPOSITED = 20,
+  ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS = 21,
+  ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS = 22,
+  ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA = 23,
+  ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED = 24,
+  ARTIS_TYPE_ESCAPE = 32,
+  ARTIS_TYPE_RADIOACTIVE_PELLET = 100,
+  ARTIS_TYPE_PRE_KPKT = 120
+};
+
+/* packet.h:85 */
+#define ARTIS_EMTYPE_NOTSET (-9999000)
+#define ARTIS_EMTYPE_FREEFREE (-9999999)
+/* packet.h:89 enum absorption_type */
+#define ARTIS_ABSTYPE_FREEFREE (-1)
+#define ARTIS_ABSTYPE_BOUNDFREE (-2)
+
+/* globals.h:21 enum ma_action */
+enum {
+  ARTIS_MA_ACTION_RADDEEXC = 0,
+  ARTIS_MA_ACTION_COLDEEXC = 1,
+  ARTIS_MA_ACTION_RADRECOMB = 2,
+  ARTIS_MA_ACTION_COLRECOMB = 3,
+  ARTIS_MA_ACTION_INTERNALDOWNSAME = 4,
+  ARTIS_MA_ACTION_INTERNALDOWNLOWER = 5,
+  ARTIS_MA_ACTION_INTERNALUPSAME = 6,
+  ARTIS_MA_ACTION_INTERNALUPHIGHER = 7,
+  ARTIS_MA_ACTION_INTERNALUPHIGHERNT = 8,
+  ARTIS_MA_ACTION_COUNT = 9
+};
+
+/* stats.h:13 enum class Counter (same numbering) */
+enum {
+  ARTIS_STAT_MA_ACTIVATION_COLLEXC = 0,
+  ARTIS_STAT_MA_ACTIVATION_COLLION = 1,
+  ARTIS_STAT_MA_ACTIVATION_NTCOLLEXC = 2,
+  ARTIS_STAT_MA_ACTIVATION_NTCOLLION = 3,
+  ARTIS_STAT_MA_ACTIVATION_BB = 4,
+  ARTIS_STAT_MA_ACTIVATION_BF = 5,
+  ARTIS_STAT_MA_ACTIVATION_FB = 6,
+  ARTIS_STAT_MA_DEACTIVATION_COLLDEEXC = 7,
+  ARTIS_STAT_MA_DEACTIVATION_COLLRECOMB = 8,
+  ARTIS_STAT_MA_DEACTIVATION_BB = 9,
+  ARTIS_STAT_MA_DEACTIVATION_FB = 10,
+  ARTIS_STAT_MA_INTERNALUPHIGHER = 11,
+  ARTIS_STAT_MA_INTERNALUPHIGHERNT = 12,
+  ARTIS_STAT_MA_INTERNALDOWNLOWER = 13,
+  ARTIS_STAT_K_TO_MA_COLLEXC = 14,
+  ARTIS_STAT_K_TO_MA_COLLION = 15,
+  ARTIS_STAT_K_TO_R_FF = 16,
+  ARTIS_STAT_K_TO_R_FB = 17,
+  ARTIS_STAT_K_TO_R_BB = 18,
+  ARTIS_STAT_K_FROM_FF = 19,
+  ARTIS_STAT_K_FROM_BF = 20,
+  ARTIS_STAT_NT_FROM_GAMMA = 21,
+  ARTIS_STAT_NT_TO_IONISATION = 22,
+  ARTIS_STAT_NT_TO_EXCITATION = 23,
+  ARTIS_STAT_NT_TO_KPKT = 24,
+  ARTIS_STAT_K_FROM_EARLIERDECAY = 25,
+  ARTIS_STAT_INTERACTIONS = 26,
+  ARTIS_STAT_ELECTRON_SCATTERINGS = 27,
+  ARTIS_STAT_RESONANCESCATTERINGS = 28,
+  ARTIS_STAT_CELLCROSSINGS = 29,
+  ARTIS_STAT_UPSCATTER = 30,
+  ARTIS_STAT_DOWNSCATTER = 31,
+  ARTIS_STAT_UPDATECELL = 32,
+  ARTIS_STAT_PKTESCAPES = 33,
+  ARTIS_STAT_COUNT = 34,
+  /* extra slots, not in the reference: the unit of the headline metric */
+  ARTIS_STAT_X_RPKT_STEPS = 34, /* calls of do_rpkt_step() rpkt.cc:542 */
+  ARTIS_STAT_X_KPKT_STEPS = 35, /* calls of do_kpkt()/do_kpkt_blackbody() */
+  ARTIS_STAT_X_LINES_VISITED = 36, /* lines walked in get_possible_event() rpkt.cc:121 */
+  ARTIS_STAT_X_MA_JUMPS = 37, /* iterations of the do_macroatom() loop macroatom.cc:385 */
+  ARTIS_NSTATS = 40
+};
+
+/* constants.h:73 GridType */
+enum { ARTIS_GRID_SPHERICAL1D = 0, ARTIS_GRID_CYLINDRICAL2D = 1, ARTIS_GRID_CARTESIAN3D = 2 };
+/* grid.h:29 CellThickness */
+enum { ARTIS_CELL_THIN = 0, ARTIS_CELL_THICK = 1, ARTIS_CELL_THICK_VPKT_ONLY = 2 };
+/* kpkt.cc:42 CoolingType */
+enum { ARTIS_COOLING_FREEFREE = 0, ARTIS_COOLING_FREEBOUND = 1, ARTIS_COOLING_COLLEXC = 2, ARTIS_COOLING_COLLION = 3 };
+
+/* ---- packet: layout of the reference's struct Packet in its GPU_ON form --- */
+/* packet.h:117-169 (rngstate first: packet.h:118-122). Field order and types
+ * are the reference's so a reference-side Packet* can be passed unchanged. */
+typedef struct artis_packet {
+  uint32_t rngstate[4]; /* Xoshiro128PP state, random.h:101 */
+  double prop_time;
+  double pos[3];
+  double dir[3];
+  double nu_cmf;
+  double e_cmf;
+  double nu_rf;
+  double e_rf;
+  int32_t next_trans;
+  int32_t nscatterings;
+  int32_t emissiontype;
+  double em_pos[3];
+  float em_time;
+  int32_t absorptiontype;
+  double absorptionfreq;
+  double stokes_q;
+  double stokes_u;
+  int32_t trueemissiontype;
+  double trueem_pos[3];
+  float trueem_time;
+  int32_t type;
+  int32_t cellindex;
+  int32_t escape_type;
+  float escape_time;
+  double tdecay;
+  int32_t number;
+  uint8_t originated_from_particlenotgamma;
+  int32_t pellet_decaytype;
+  int32_t pellet_nucindex;
+} artis_packet;
+
+/* ---- static model: atomic data + propagation grid (set once per run) ------ */
+typedef struct artis_model {
+  /* sizes */
+  int32_t nelements;
+  int32_t nions;      /* get_includedions() atomic.h:391 */
+  int32_t nlevels;    /* get_includedlevels() atomic.h:37 */
+  int32_t nlines;     /* globals::nlines */
+  int32_t nalltrans;  /* size of globals::alltrans arrays */
+  int32_t nphixstargets_total; /* size of globals::allphixstargets_* */
+  int32_t nphixslevels;        /* number of levels with a phixs table */
+  int32_t nbfcontinua;         /* globals::nbfcontinua */
+  int32_t nbfcontinua_ground;  /* globals::nbfcontinua_ground */
+  int32_t ncoolingterms;       /* kpkt ncoolingterms kpkt.cc:233 */
+  int32_t nmatransblock;       /* sum over levels of 2*ndowntrans+nuptrans input.cc:1542 */
+  int32_t NPHIXSPOINTS;        /* globals::NPHIXSPOINTS */
+  double NPHIXSNUINCREMENT;    /* globals::NPHIXSNUINCREMENT */
+
+  /* per element (globals::elements, globals.h:60) */
+  const int32_t *elem_nions;
+  const int32_t *elem_uniqueionindexstart;
+  const int32_t *elem_anumber;
+  const int32_t *elem_lowest_ionstage;
+
+  /* per ion, indexed by uniqueionindex (struct Ion, globals.h:45) */
+  const int32_t *ion_element;
+  const int32_t *ion_nlevels;
+  const int32_t *ion_nlevels_ionising;
+  const int32_t *ion_maxrecombininglevel;
+  const int32_t *ion_uniquelevelindexstart;
+  const int32_t *ion_coolingoffset;
+  const int32_t *ion_ncoolingterms;
+
+  /* per level, indexed by uniquelevelindex (struct AllLevels, globals.h:181) */
+  const double *level_epsilon;
+  const float *level_statweight;
+  const int32_t *level_alltrans_startdown;
+  const int32_t *level_ndowntrans;
+  const int32_t *level_nuptrans;
+  const int32_t *level_closestgroundlevelcont;
+  const int32_t *level_phixsstart;
+  const int32_t *level_nphixstargets;
+  const int32_t *level_phixstargetstart;
+  const int32_t *level_bflist_start;
+  const int32_t *level_matransblock_start;
+
+  /* globals::alltrans (struct AllTransitions, globals.h:151) */
+  const int32_t *alltrans_lineindex;
+  const int32_t *alltrans_targetlevelindex;
+  const float *alltrans_einstein_A;
+  const float *alltrans_coll_str;
+  const float *alltrans_osc_strength;
+  const uint8_t *alltrans_forbidden;
+
+  /* globals::linelist (struct TransitionLines, globals.h:229), descending nu */
+  const double *line_nu;
+  const int32_t *line_elementindex;
+  const int32_t *line_ionindex;
+  const int32_t *line_uniquelevelindex_lower;
+  const int32_t *line_uniquelevelindex_upper;
+  const float *line_B_ul;
+  const float *line_B_lu;
+
+  /* photoionisation */
+  const float *allphixs;                       /* [nphixslevels*NPHIXSPOINTS] globals.h:149 */
+  const int32_t *allphixstargets_levelindex;   /* globals.h:173 */
+  const double *allphixstargets_probability;   /* globals.h:174 */
+
+  /* globals::allcont (struct AllCont, globals.h:253), ascending nu_edge */
+  const double *allcont_nu_edge;
+  const int32_t *allcont_element;
+  const int32_t *allcont_ion;
+  const int32_t *allcont_level;
+  const int32_t *allcont_phixstargetindex;
+  const int32_t *allcont_upperlevel;
+  const int32_t *allcont_uniquelevelindex;
+  const double *allcont_probability;
+  const int32_t *allcont_groundcontestimindex;
+
+  /* ground-level continua, ascending nu_edge (globals.h:272-274) */
+  const double *groundcont_nu_edge;
+
+  /* temperature LUTs, [nbfcontinua*TABLESIZE], index get_bflutindex() ratecoeff.cc:123 */
+  const double *spontrecombcoeffs;
+  const double *corrphotoioncoeffs;
+  const double *bfcooling_coeffs;
+
+  /* cooling list (kpkt.cc:44-46) */
+  const uint8_t *coolinglist_type;
+  const int32_t *coolinglist_level;
+  const int32_t *coolinglist_phixstargetindex;
+
+  /* propagation grid (grid.cc) */
+  int32_t gridtype;       /* ARTIS_GRID_* */
+  int32_t ncoordgrid[3];  /* grid.cc ncoordgrid */
+  int32_t ngrid;          /* grid::ngrid */
+  int32_t npts_nonempty;  /* grid::get_nonempty_npts_model() */
+  double tmin;            /* globals::tmin */
+  double vmax;            /* globals::vmax */
+  double rmax;            /* globals::rmax */
+  const double *coord_pos_min_tmin[3]; /* grid.cc coord_pos_min_tmin */
+  const int32_t *propcell_nonemptymgi; /* [ngrid] grid::get_propcell_nonemptymgi(), -1 = empty */
+} artis_model;
+
+/* ---- per-timestep cell state written by the reference's update_grid() ----- */
+typedef struct artis_cellstate {
+  /* [npts_nonempty], grid.h:19-37 */
+  const float *rho;
+  const float *Te;
+  const float *TJ;
+  const float *TR;
+  const float *W;
+  const float *nne;
+  const float *nnetot;
+  const float *kappagrey;
+  const int32_t *thick;
+  const float *clumpfactor;
+  /* [npts_nonempty*nions] grid.h:44-45 */
+  const float *ion_groundlevelpops;
+  const float *ion_partfuncts;
+  /* [npts_nonempty*nelements] grid.h:42 */
+  const float *elem_massfracs;
+  /* [npts_nonempty*nbfcontinua_ground] globals.h:126 */
+  const double *corrphotoionrenorm;
+} artis_cellstate;
+
+typedef struct artis_timestep {
+  int32_t nts;          /* timestep number */
+  double start;         /* globals::timesteps[nts].start */
+  double width;         /* globals::timesteps[nts].width */
+  double mid;           /* globals::timesteps[nts].mid */
+  double max_path_step; /* globals::max_path_step update_grid.cc:753 */
+} artis_timestep;
+
+/* ---- estimators: accumulated into, never zeroed, by update_packets -------- */
+typedef struct artis_estimators {
+  double *J;                   /* [npts_nonempty] radfield.cc J */
+  double *nuJ;                 /* [npts_nonempty] radfield.cc nuJ */
+  double *ffheatingestimator;  /* [npts_nonempty] globals.h:133 */
+  double *colheatingestimator; /* [npts_nonempty] globals.h:134 */
+  double *gammaestimator;      /* [npts_nonempty*nbfcontinua_ground] globals.h:128 */
+  double *bfheatingestimator;  /* [npts_nonempty*nbfcontinua_ground] globals.h:131 */
+  int64_t *stats;              /* [ARTIS_NSTATS] stats.cc event counters */
+} artis_estimators;
+
+/* ---- engine ---------------------------------------------------------------- */
+typedef struct artis_amd_engine artis_amd_engine;
+
+/* All functions return 0 on success, a negative ARTIS_ERR_* otherwise;
+ * artis_amd_last_error() gives the message. No function falls back to a CPU
+ * path: without a usable HIP device artis_amd_engine_create() fails. */
+#define ARTIS_OK 0
+#define ARTIS_ERR_NODEVICE (-1)
+#define ARTIS_ERR_HIP (-2)
+#define ARTIS_ERR_ARG (-3)
+#define ARTIS_ERR_UNSUPPORTED (-4)
+#define ARTIS_ERR_NOTCONVERGED (-5)
+
+const char *artis_amd_last_error(void);
+int artis_amd_abi_version(void);
+size_t artis_amd_sizeof_packet(void);
+
+/* Create an engine on HIP device `device` and upload the static model.
+ * Replaces the table set-up the reference's GPU build leaves in unified memory
+ * (MPI_shared_array, mpi_logging.h). */
+int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engine **out);
+void artis_amd_engine_destroy(artis_amd_engine *eng);
+
+/* Upload the cell state of the coming timestep and fill every cell's cache:
+ * cellcacheslot_populate() for all non-empty cells (update_packets.cc:397,
+ * multi-slot form update_packets.cc:551-560) and the per-ion cumulative
+ * cooling of kpkt::calculate_cooling_rates() (kpkt.cc:281). */
+int artis_amd_set_cellstate(artis_amd_engine *eng, const artis_cellstate *cells, const artis_timestep *ts);
+
+/* Host-buffer form of update_packets() (update_packets.cc:530): packets in
+ * TYPE_RPKT / TYPE_KPKT / TYPE_PRE_KPKT are propagated to the end of the
+ * timestep; other types are returned untouched (they stay on the reference's
+ * CPU path). Estimators are ADDED to est (host arrays). */
+int artis_amd_update_packets(artis_amd_engine *eng, artis_packet *packets, int64_t npackets,
+                             artis_estimators *est);
+
+/* Device-resident form, for callers that keep packets in HBM across timesteps:
+ * upload once, step many times, download when needed. */
+int artis_amd_packets_upload(artis_amd_engine *eng, const artis_packet *packets, int64_t npackets);
+int artis_amd_packets_download(artis_amd_engine *eng, artis_packet *packets, int64_t npackets);
+int artis_amd_packets_snapshot(artis_amd_engine *eng); /* save current device packets */
+int artis_amd_packets_restore(artis_amd_engine *eng);  /* restore the snapshot */
+/* Propagate the resident packets through the timestep set by
+ * artis_amd_set_cellstate(). hip_stream is a hipStream_t (NULL = default). */
+int artis_amd_update_packets_device(artis_amd_engine *eng, void *hip_stream);
+int artis_amd_estimators_zero(artis_amd_engine *eng, void *hip_stream);
+int artis_amd_estimators_download(artis_amd_engine *eng, artis_estimators *est_add_into);
+
+/* Device pointers of the estimator block for an in-place RCCL all-reduce
+ * (the reference's radfield::reduce_estimators(), radfield.cc:988, and the
+ * MPI_Allreduce of the heating/gamma estimators in sn3d.cc). The block is one
+ * contiguous array of `*ndoubles` doubles. */
+int artis_amd_estimators_devptr(artis_amd_engine *eng, void **dptr, int64_t *ndoubles);
+
+/* Timing of the dominant kernel inside the last artis_amd_update_packets_device
+ * call, measured with HIP events on the launch stream. */
+int artis_amd_last_kernel_ms(artis_amd_engine *eng, double *propagate_ms, int64_t *nlaunches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARTIS_AMD_H */

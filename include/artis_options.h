@@ -1,0 +1,69 @@
+/*
+ * artis_options.h -- compile-time options of the packet path.
+ *
+ * Mirrors the subset of the reference's artisoptions_*.h presets that the
+ * r-packet / k-packet / macro-atom path reads. The defaults are
+ * artisoptions_classic.h (the preset BASELINE.json's configs[0..2] name).
+ * Like the reference, a different preset means a rebuild: pass -DARTIS_OPT_...
+ * Names are the reference's option names with an ARTIS_OPT_ prefix.
+ */
+#ifndef ARTIS_OPTIONS_H
+#define ARTIS_OPTIONS_H
+
+#ifndef ARTIS_OPT_DIPOLE
+#define ARTIS_OPT_DIPOLE 1 /* artisoptions_classic.h:47 */
+#endif
+#ifndef ARTIS_OPT_POL_ON
+#define ARTIS_OPT_POL_ON 1 /* artisoptions_classic.h:48 */
+#endif
+#ifndef ARTIS_OPT_MINPOP
+#define ARTIS_OPT_MINPOP 1e-30 /* artisoptions_classic.h:53 */
+#endif
+#ifndef ARTIS_OPT_NU_MIN_R
+#define ARTIS_OPT_NU_MIN_R 1e14 /* artisoptions_classic.h:55 */
+#endif
+#ifndef ARTIS_OPT_NU_MAX_R
+#define ARTIS_OPT_NU_MAX_R 5e15 /* artisoptions_classic.h:56 */
+#endif
+#ifndef ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION
+#define ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION 1 /* artisoptions_classic.h:58 */
+#endif
+#ifndef ARTIS_OPT_USE_LUT_PHOTOION
+#define ARTIS_OPT_USE_LUT_PHOTOION 1 /* artisoptions_classic.h:82 */
+#endif
+#ifndef ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
+#define ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS 1 /* artisoptions_classic.h:84 */
+#endif
+#ifndef ARTIS_OPT_LTEPOP_EXCITATION_USE_TJ
+#define ARTIS_OPT_LTEPOP_EXCITATION_USE_TJ 1 /* artisoptions_classic.h:24 */
+#endif
+#ifndef ARTIS_OPT_DIRECT_COL_HEAT
+#define ARTIS_OPT_DIRECT_COL_HEAT 0 /* artisoptions_classic.h:35 */
+#endif
+#ifndef ARTIS_OPT_BFCOOLING_USELEVELPOPNOTIONPOP
+#define ARTIS_OPT_BFCOOLING_USELEVELPOPNOTIONPOP 0 /* artisoptions_classic.h:135 */
+#endif
+#ifndef ARTIS_OPT_TABLESIZE
+#define ARTIS_OPT_TABLESIZE 100 /* artisoptions_classic.h:40 */
+#endif
+#ifndef ARTIS_OPT_MINTEMP
+#define ARTIS_OPT_MINTEMP 3500. /* artisoptions_classic.h:41 */
+#endif
+#ifndef ARTIS_OPT_MAXTEMP
+#define ARTIS_OPT_MAXTEMP 140000. /* artisoptions_classic.h:42 */
+#endif
+
+/* Options of the reference this build does not implement: they must keep the
+ * classic values. (A build that needs them fails here, not at run time.) */
+#define ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT 0  /* artisoptions_classic.h:119 */
+#define ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES 0    /* artisoptions_classic.h:137 */
+#define ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON 0     /* artisoptions_classic.h:74 */
+#define ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON 0       /* artisoptions_classic.h:76 */
+#define ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON 0      /* artisoptions_classic.h:60 */
+#define ARTIS_OPT_NT_ON 0                           /* artisoptions_classic.h:100 */
+#define ARTIS_OPT_VPKT_ON 0                         /* artisoptions_classic.h:50 */
+
+/* kpkt.cc:51 kpktdiffusion_timestep_fraction (a float in the reference) */
+#define ARTIS_KPKTDIFFUSION_TIMESTEP_FRACTION 0.001f
+
+#endif

@@ -1,0 +1,85 @@
+"""ctypes binding of the CPU oracle (oracle/libartis_oracle.so).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module. The artis_amd package never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from artis_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libartis_oracle.so")
+    src = os.path.join(_HERE, "artis_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libartis_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.artis_oracle_update_packets.restype = C.c_int
+        L.artis_oracle_update_packets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.artis_oracle_cellcache.restype = C.c_int
+        L.artis_oracle_rng_next.restype = C.c_uint32
+        L.artis_oracle_rng_uniform.restype = C.c_float
+        L.artis_oracle_doppler.restype = C.c_double
+        L.artis_oracle_get_linedistance.restype = C.c_double
+        L.artis_oracle_get_linedistance.argtypes = [C.c_double, C.c_double, C.c_double]
+        L.artis_oracle_rad_deexcitation_ratecoeff.restype = C.c_double
+        L.artis_oracle_rad_deexcitation_ratecoeff.argtypes = [C.c_double, C.c_float, C.c_double, C.c_double, C.c_double,
+                                                              C.c_double, C.c_double]
+        L.artis_oracle_phixs_fromtable.restype = C.c_float
+        L.artis_oracle_phixs_fromtable.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.artis_oracle_planck.restype = C.c_double
+        L.artis_oracle_planck.argtypes = [C.c_double, C.c_double]
+        L.artis_oracle_closest_transition.restype = C.c_int
+        L.artis_oracle_closest_transition.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
+        L.artis_oracle_sizeof_packet.restype = C.c_size_t
+        L.artis_oracle_seed_packets.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
+        _LIB = L
+    return _LIB
+
+
+def update_packets(model: abi.Model, cells: abi.CellState, ts: abi.Timestep, packets: np.ndarray,
+                   est: abi.Estimators) -> None:
+    rc = lib().artis_oracle_update_packets(C.cast(model.ref(), C.c_void_p), C.cast(cells.ref(), C.c_void_p),
+                                           C.cast(ts.ref(), C.c_void_p), abi.packets_ptr(packets), len(packets),
+                                           C.cast(est.ref(), C.c_void_p))
+    if rc != 0:
+        raise RuntimeError("oracle reported an internal assertion failure")
+
+
+def cellcache(model: abi.Model, cells: abi.CellState, ts: abi.Timestep, nonemptymgi: int) -> dict:
+    d = model.d
+    out = {
+        "levelpops": np.zeros(d["nlevels"]),
+        "maprocessrates": np.zeros(d["nlevels"] * 9),
+        "matrans": np.zeros(max(d["nmatransblock"], 1)),
+        "allcont_nnlevel": np.zeros(max(d["nbfcontinua"], 1)),
+        "allcont_departure": np.zeros(max(d["nbfcontinua"], 1)),
+        "allcont_edgepart": np.zeros(max(d["nbfcontinua"], 1)),
+        "allcont_keepbits": np.zeros((d["nbfcontinua"] + 63) // 64 + 1, dtype=np.uint64),
+        "corrphotoioncoeff": np.zeros(max(d["nphixstargets_total"], 1)),
+        "cooling_contrib": np.zeros(max(d["ncoolingterms"], 1)),
+        "ion_cooling_contribs": np.zeros(d["nions"]),
+    }
+    chi = C.c_double(0.0)
+    args = [C.cast(model.ref(), C.c_void_p), C.cast(cells.ref(), C.c_void_p), C.cast(ts.ref(), C.c_void_p),
+            C.c_int(nonemptymgi)] + [v.ctypes.data_as(C.c_void_p) for v in out.values()] + [C.byref(chi)]
+    rc = lib().artis_oracle_cellcache(*args)
+    if rc != 0:
+        raise RuntimeError("oracle cellcache failed")
+    out["chi_ff_nnionpart"] = chi.value
+    return out

@@ -1,0 +1,233 @@
+"""Pin the CPU oracle against what the reference itself holds for this path.
+
+ 1. tests/golden/rng_reference.json: generator streams produced by the REFERENCE's
+    own random.h, compiled where it lies (tests/golden/make_rng_golden.py).
+ 2. The known-answer / property checks of the reference's unittests.cc that touch the
+    packet path, restated on the oracle's functions with the same seeds and tolerances:
+    test_vector_geometry (unittests.cc:118), test_frame_transform (:199),
+    test_random_sampling (:225), test_rad_deexcitation (:356),
+    test_phixs_table_lookup (:382, classic branch), test_closest_transition_randomised (:435)
+    and the static_asserts next to closest_transition / get_linedistance (rpkt.h:147-186).
+The reference's end-to-end md5 fixtures (tests/*_inputfiles/results_md5_*.txt) need the
+downloaded atomic data release and an MPI build; they cannot be reproduced here.
+"""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+
+from artis_amd import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CLIGHT = 2.99792458e10
+H = 6.6260755e-27
+DAY = 86400.0
+EV = 1.6021772e-12
+PI = math.pi
+
+
+class Rng:
+    def __init__(self, L, seed):
+        self.L = L
+        self.s = (C.c_uint32 * 4)()
+        L.artis_oracle_rng_seed(self.s, C.c_uint32(seed))
+
+    def uniform(self):
+        return float(self.L.artis_oracle_rng_uniform(self.s))
+
+    def raw(self):
+        return int(self.L.artis_oracle_rng_next(self.s))
+
+    def isotropic(self):
+        out = (C.c_double * 3)()
+        self.L.artis_oracle_rand_isotropic_unitvec(self.s, out)
+        return np.array(out[:])
+
+
+def _vec(a):
+    return (C.c_double * 3)(*[float(x) for x in a])
+
+
+def angle_ab(L, d, v):
+    out = (C.c_double * 3)()
+    L.artis_oracle_angle_ab(_vec(d), _vec(v), out)
+    return np.array(out[:])
+
+
+def test_packet_struct_size(oracle):
+    assert oracle.lib().artis_oracle_sizeof_packet() == abi.PACKET_DTYPE.itemsize
+
+
+def test_rng_streams_match_reference_random_h(oracle):
+    L = oracle.lib()
+    with open(os.path.join(HERE, "golden", "rng_reference.json")) as f:
+        gold = json.load(f)
+    for seed, st in gold["streams"].items():
+        r = Rng(L, int(seed))
+        assert [r.raw() for _ in range(gold["count"])] == st["raw_u32"], f"raw stream differs for seed {seed}"
+        r = Rng(L, int(seed))
+        s = (C.c_uint32 * 4)(*r.s)
+        out = np.zeros(gold["count"], dtype=np.float32)
+        L.artis_oracle_rng_fill_uniform(s, C.c_int64(gold["count"]), out.ctypes.data_as(C.c_void_p))
+        assert out.view(np.uint32).tolist() == st["uniform_float_bits"], f"rng_uniform differs for seed {seed}"
+
+
+def test_numpy_seeding_matches_oracle(oracle):
+    pk = np.zeros(1000, dtype=abi.PACKET_DTYPE)
+    abi.seed_packet_rng(pk, 4294967000)  # wraps through 2^32 like the reference's uint32 arithmetic
+    pk2 = pk.copy()
+    oracle.lib().artis_oracle_seed_packets(abi.packets_ptr(pk2), len(pk2), C.c_uint32(4294967000))
+    assert np.array_equal(pk["rngstate"], pk2["rngstate"])
+
+
+def test_vector_geometry_unittests_cc_118(oracle):
+    L = oracle.lib()
+    L.artis_oracle_doppler.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+    r = Rng(L, 81102)
+    # first block of the reference test consumes 100 x 2 isotropic vectors
+    for _ in range(100):
+        a = r.isotropic()
+        b = r.isotropic() * 2.5
+        c = np.cross(a, b)
+        assert abs(c @ a) < 1e-12 and abs(c @ b) < 1e-12
+    for _ in range(100):
+        d1 = r.isotropic()
+        vel = r.isotropic() * (r.uniform() * 0.3 * CLIGHT)
+        d2 = angle_ab(L, d1, vel)
+        back = angle_ab(L, d2, -vel)
+        assert np.all(np.abs(back - d1) < 1e-12)
+    pos = np.array([1.1e14, -2.4e14, 0.8e14])
+    dirv = np.array([0.3, -0.1, 0.9])
+    dirv = dirv / np.sqrt((dirv**2).sum())
+    t = 10.0 * DAY
+    expected = 1.0 - (dirv @ (pos / t)) / CLIGHT
+    got = L.artis_oracle_doppler(_vec(pos), _vec(dirv), C.c_double(t))
+    assert abs(got - expected) <= 1e-14 * max(abs(got), abs(expected))
+    # move_pkt_withtime preserves e_cmf/nu_cmf = e_rf/nu_rf
+    p = _vec(dirv * 2.0e14)
+    tcur = C.c_double(10.0 * DAY)
+    nu_rf, e_rf = 3e15, 4e-12
+    dop = L.artis_oracle_doppler(p, _vec(dirv), tcur)
+    nu_cmf = C.c_double(nu_rf * dop)
+    e_cmf = C.c_double(e_rf * dop)
+    L.artis_oracle_move_pkt_withtime(p, _vec(dirv), C.byref(tcur), C.c_double(nu_rf), C.byref(nu_cmf), C.c_double(e_rf),
+                                     C.byref(e_cmf), C.c_double(3.0e13))
+    a, b = e_cmf.value / nu_cmf.value, e_rf / nu_rf
+    assert abs(a - b) <= 1e-12 * max(abs(a), abs(b))
+
+
+def test_frame_transform_unittests_cc_199(oracle):
+    L = oracle.lib()
+    r = Rng(L, 99001)
+
+    def ft(n, q, u, v):
+        out = (C.c_double * 3)()
+        qq, uu = C.c_double(), C.c_double()
+        L.artis_oracle_frame_transform(_vec(n), C.c_double(q), C.c_double(u), _vec(v), out, C.byref(qq), C.byref(uu))
+        return np.array(out[:]), qq.value, uu.value
+
+    for _ in range(100):
+        n_rf = r.isotropic()
+        pol_p = r.uniform() * 0.9
+        ang = r.uniform() * 2.0 * PI
+        q0, u0 = pol_p * math.cos(ang), pol_p * math.sin(ang)
+        vel = r.isotropic() * (r.uniform() * 0.2 * CLIGHT)
+        n_cmf, q_cmf, u_cmf = ft(n_rf, q0, u0, vel)
+        assert abs(math.sqrt(q_cmf**2 + u_cmf**2) - pol_p) < 1e-10
+        n2, q2, u2 = ft(n_cmf, q_cmf, u_cmf, -vel)
+        assert np.all(np.abs(n2 - n_rf) < 1e-10)
+        assert abs(q2 - q0) < 1e-8 and abs(u2 - u0) < 1e-8
+
+
+def test_random_sampling_unittests_cc_225(oracle):
+    L = oracle.lib()
+    n = 1_000_000
+    r = Rng(L, 31415)
+    z = np.zeros(n, dtype=np.float32)
+    L.artis_oracle_rng_fill_uniform(r.s, C.c_int64(n), z.ctypes.data_as(C.c_void_p))
+    assert z.min() >= 0.0 and z.max() < 1.0
+    assert abs(z.astype(np.float64).mean() - 0.5) < 6.0 / math.sqrt(12.0 * n)
+    d = np.zeros(3 * n)
+    L.artis_oracle_fill_isotropic(r.s, C.c_int64(n), d.ctypes.data_as(C.c_void_p))
+    d = d.reshape(n, 3)
+    assert np.all(np.abs(np.sqrt((d**2).sum(axis=1)) - 1.0) < 1e-6)
+    assert abs(d[:, 2].mean()) < 6.0 / math.sqrt(3.0 * n)
+    assert abs((d[:, 2] ** 2).mean() - 1.0 / 3.0) < 1e-3
+
+
+def test_rad_deexcitation_unittests_cc_356(oracle):
+    L = oracle.lib()
+    eps_trans, A = 2.0 * EV, 1e7
+    gu, gl, t = 3.0, 1.0, 20.0 * DAY
+    assert L.artis_oracle_rad_deexcitation_ratecoeff(eps_trans, A, gu, gl, 0.0, 0.0, t) == np.float32(A)
+    nnu, nnl = 1e5, 1e8
+    nu_trans = eps_trans / H
+    b_ul = CLIGHT**2 / (2 * H) / nu_trans**3 * float(np.float32(A))
+    b_lu = gu / gl * b_ul
+    tau = ((b_lu * nnl) - (b_ul * nnu)) * (H * CLIGHT / (4 * PI)) * t
+    assert tau > 1.0
+    got = L.artis_oracle_rad_deexcitation_ratecoeff(eps_trans, A, gu, gl, nnu, nnl, t)
+    want = float(np.float32(A)) * (-math.expm1(-tau)) / tau
+    assert abs(got - want) <= 1e-12 * max(abs(got), abs(want))
+
+
+def test_phixs_table_lookup_classic_unittests_cc_382(oracle):
+    L = oracle.lib()
+    npts, inc = 10, 0.1
+    xs = np.array([(i + 1) * 1e-18 for i in range(npts)], dtype=np.float32)
+    ptr = xs.ctypes.data_as(C.c_void_p)
+    nu_edge = 3e15
+
+    def f(nu):
+        return np.float32(L.artis_oracle_phixs_fromtable(ptr, npts, inc, nu_edge, nu))
+
+    assert f(nu_edge * 0.99) == 0.0
+    assert f(nu_edge) == xs[0]
+    assert f(nu_edge * 1.25) == xs[2]
+    nu_out = nu_edge * (1 + inc * npts)
+    nu = nu_out * (1.0 - 1e-13)
+    while nu < nu_out:
+        assert f(nu) in xs
+        nu = np.nextafter(nu, nu_out)
+    above = 4.0 * nu_edge
+    want = xs[npts - 1] * (nu_out / above) ** 3
+    got = f(above)
+    assert abs(got - want) <= 1e-6 * max(abs(got), abs(want))
+
+
+def test_closest_transition_randomised_unittests_cc_435(oracle):
+    L = oracle.lib()
+    r = Rng(L, 777)
+    nu = np.array([1e14 + r.uniform() * 1e15 for _ in range(500)])
+    nu = np.sort(nu)[::-1].copy()
+    ptr = nu.ctypes.data_as(C.c_void_p)
+    for _ in range(1000):
+        nu_cmf = 0.5e14 + r.uniform() * 1.2e15
+        expected = -1
+        idx = np.nonzero(nu <= nu_cmf)[0]
+        if len(idx):
+            expected = int(idx[0])
+        assert L.artis_oracle_closest_transition(ptr, 500, nu_cmf, -1) == expected
+
+
+def test_closest_transition_and_linedistance_static_asserts_rpkt_h(oracle):
+    L = oracle.lib()
+    lst = np.array([9.0, 7.0, 5.0, 3.0])
+    p = lst.ctypes.data_as(C.c_void_p)
+    assert L.artis_oracle_closest_transition(p, 4, 10.0, -1) == 0
+    assert L.artis_oracle_closest_transition(p, 4, 8.0, -1) == 1
+    assert L.artis_oracle_closest_transition(p, 4, 5.0, -1) == 2
+    assert L.artis_oracle_closest_transition(p, 4, 2.0, -1) == -1
+    assert L.artis_oracle_closest_transition(p, 4, 8.0, 2) == 2
+    assert L.artis_oracle_closest_transition(p, 4, 8.0, 4) == -1
+    assert L.artis_oracle_get_linedistance(100.0, 1.0, 2.0) == 0.0
+    assert L.artis_oracle_get_linedistance(2.0, 4.0, 2.0) == CLIGHT * 2.0 * 2.0 / 2.0
+
+
+def test_planck_matches_closed_form(oracle):
+    L = oracle.lib()
+    for nu, T in [(1e14, 5000.0), (8e14, 12000.0), (4e15, 3500.0)]:
+        want = 2 * H * nu**3 / CLIGHT**2 / math.expm1(H / 1.38064852e-16 * nu / T)
+        assert abs(L.artis_oracle_planck(nu, T) - want) <= 1e-14 * want
