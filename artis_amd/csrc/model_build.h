@@ -1,0 +1,215 @@
+// model_build.h -- host-side construction of the kernel views (tables.h) from the C-ABI structs.
+// Shared by the HIP engine (which then mirrors every array into HBM) and by the host-emulation
+// test build. No physics here: only pointer plumbing and the three derived tables
+// (temperature grid ratecoeff.cc:39-46, level -> ion map, packed line records).
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "tables.h"
+
+namespace artis {
+
+struct ModelOwned {
+  std::vector<double> temperature_grid;
+  std::vector<int32_t> level_ion;
+  std::vector<LinePack> line_pack;
+};
+
+// X(field, element type, element count) for every array pointer of DevModel
+#define ARTIS_MODEL_ARRAYS(X, m)                                                   \
+  X(temperature_grid, double, (ARTIS_OPT_TABLESIZE + 1))                           \
+  X(elem_nions, int32_t, (m).nelements)                                            \
+  X(elem_uniqueionindexstart, int32_t, (m).nelements)                              \
+  X(elem_lowest_ionstage, int32_t, (m).nelements)                                  \
+  X(ion_element, int32_t, (m).nions)                                               \
+  X(ion_nlevels, int32_t, (m).nions)                                               \
+  X(ion_nlevels_ionising, int32_t, (m).nions)                                      \
+  X(ion_maxrecombininglevel, int32_t, (m).nions)                                   \
+  X(ion_uniquelevelindexstart, int32_t, (m).nions)                                 \
+  X(ion_coolingoffset, int32_t, (m).nions)                                         \
+  X(ion_ncoolingterms, int32_t, (m).nions)                                         \
+  X(level_epsilon, double, (m).nlevels)                                            \
+  X(level_statweight, float, (m).nlevels)                                          \
+  X(level_alltrans_startdown, int32_t, (m).nlevels)                                \
+  X(level_ndowntrans, int32_t, (m).nlevels)                                        \
+  X(level_nuptrans, int32_t, (m).nlevels)                                          \
+  X(level_closestgroundlevelcont, int32_t, (m).nlevels)                            \
+  X(level_phixsstart, int32_t, (m).nlevels)                                        \
+  X(level_nphixstargets, int32_t, (m).nlevels)                                     \
+  X(level_phixstargetstart, int32_t, (m).nlevels)                                  \
+  X(level_bflist_start, int32_t, (m).nlevels)                                      \
+  X(level_matransblock_start, int32_t, (m).nlevels)                                \
+  X(level_ion, int32_t, (m).nlevels)                                               \
+  X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
+  X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
+  X(alltrans_einstein_A, float, (m).nalltrans)                                     \
+  X(alltrans_coll_str, float, (m).nalltrans)                                       \
+  X(alltrans_osc_strength, float, (m).nalltrans)                                   \
+  X(alltrans_forbidden, uint8_t, (m).nalltrans)                                    \
+  X(line_nu, double, (m).nlines)                                                   \
+  X(line_pack, LinePack, (m).nlines)                                               \
+  X(line_elementindex, int32_t, (m).nlines)                                        \
+  X(line_ionindex, int32_t, (m).nlines)                                            \
+  X(allphixs, float, ((int64_t)(m).nphixslevels * (m).NPHIXSPOINTS))               \
+  X(allphixstargets_levelindex, int32_t, (m).nphixstargets_total)                  \
+  X(allphixstargets_probability, double, (m).nphixstargets_total)                  \
+  X(allcont_nu_edge, double, (m).nbfcontinua)                                      \
+  X(allcont_element, int32_t, (m).nbfcontinua)                                     \
+  X(allcont_ion, int32_t, (m).nbfcontinua)                                         \
+  X(allcont_level, int32_t, (m).nbfcontinua)                                       \
+  X(allcont_phixstargetindex, int32_t, (m).nbfcontinua)                            \
+  X(allcont_upperlevel, int32_t, (m).nbfcontinua)                                  \
+  X(allcont_uniquelevelindex, int32_t, (m).nbfcontinua)                            \
+  X(allcont_groundcontestimindex, int32_t, (m).nbfcontinua)                        \
+  X(allcont_probability, double, (m).nbfcontinua)                                  \
+  X(groundcont_nu_edge, double, (m).nbfcontinua_ground)                            \
+  X(spontrecombcoeffs, double, ((int64_t)(m).nbfcontinua * ARTIS_OPT_TABLESIZE))   \
+  X(corrphotoioncoeffs, double, ((int64_t)(m).nbfcontinua * ARTIS_OPT_TABLESIZE))  \
+  X(bfcooling_coeffs, double, ((int64_t)(m).nbfcontinua * ARTIS_OPT_TABLESIZE))    \
+  X(coolinglist_type, uint8_t, (m).ncoolingterms)                                  \
+  X(coolinglist_level, int32_t, (m).ncoolingterms)                                 \
+  X(coolinglist_phixstargetindex, int32_t, (m).ncoolingterms)                      \
+  X(propcell_nonemptymgi, int32_t, (m).ngrid)
+
+// X(field, element type, element count) for every array pointer of DevCells
+#define ARTIS_CELL_ARRAYS(X, m)                                          \
+  X(rho, float, (m).npts_nonempty)                                       \
+  X(Te, float, (m).npts_nonempty)                                        \
+  X(TJ, float, (m).npts_nonempty)                                        \
+  X(TR, float, (m).npts_nonempty)                                        \
+  X(W, float, (m).npts_nonempty)                                         \
+  X(nne, float, (m).npts_nonempty)                                       \
+  X(nnetot, float, (m).npts_nonempty)                                    \
+  X(kappagrey, float, (m).npts_nonempty)                                 \
+  X(clumpfactor, float, (m).npts_nonempty)                               \
+  X(thick, int32_t, (m).npts_nonempty)                                   \
+  X(ion_groundlevelpops, float, ((int64_t)(m).npts_nonempty * (m).nions)) \
+  X(ion_partfuncts, float, ((int64_t)(m).npts_nonempty * (m).nions))     \
+  X(elem_massfracs, float, ((int64_t)(m).npts_nonempty * (m).nelements)) \
+  X(corrphotoionrenorm, double, ((int64_t)(m).npts_nonempty * ((m).nbfcontinua_ground > 0 ? (m).nbfcontinua_ground : 1)))
+
+// X(field, element type, elements per cell) for every array of DevCache
+#define ARTIS_CACHE_ARRAYS(X, m)                                \
+  X(levelpops, double, (m).nlevels)                             \
+  X(maprocessrates, double, ((int64_t)(m).nlevels * 9))         \
+  X(matrans, double, (m).nmatransblock)                         \
+  X(allcont_nnlevel, double, (m).nbfcontinua)                   \
+  X(allcont_departure, double, (m).nbfcontinua)                 \
+  X(allcont_edgepart, double, (m).nbfcontinua)                  \
+  X(allcont_keepbits, uint64_t, (m).nkeepwords)                 \
+  X(corrphotoioncoeff, double, (m).nphixstargets_total)         \
+  X(cooling_contrib, double, (m).ncoolingterms)                 \
+  X(ion_cooling_contribs, double, (m).nions)                    \
+  X(ion_cooling_C, double, (m).nions)                           \
+  X(chi_ff_nnionpart, double, 1)
+
+// Host view of the model: pointers into the caller's arrays plus the derived tables in `own`.
+inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
+  DevModel v;
+  std::memset(&v, 0, sizeof(v));
+  v.nelements = m.nelements; v.nions = m.nions; v.nlevels = m.nlevels; v.nlines = m.nlines; v.nalltrans = m.nalltrans;
+  v.nphixstargets_total = m.nphixstargets_total; v.nphixslevels = m.nphixslevels; v.nbfcontinua = m.nbfcontinua;
+  v.nbfcontinua_ground = m.nbfcontinua_ground; v.ncoolingterms = m.ncoolingterms; v.nmatransblock = m.nmatransblock;
+  v.NPHIXSPOINTS = m.NPHIXSPOINTS;
+  v.nkeepwords = (m.nbfcontinua + 63) / 64;
+  v.NPHIXSNUINCREMENT = m.NPHIXSNUINCREMENT;
+  v.last_phixs_nuovernuedge = (1.0 + (m.NPHIXSNUINCREMENT * (m.NPHIXSPOINTS - 1)));                    // input.cc:310
+  v.T_step_log = (std::log(ARTIS_OPT_MAXTEMP) - std::log(ARTIS_OPT_MINTEMP)) / (ARTIS_OPT_TABLESIZE - 1.);  // ratecoeff.cc:39
+  own.temperature_grid.resize(ARTIS_OPT_TABLESIZE + 1);
+  for (int i = 0; i < ARTIS_OPT_TABLESIZE + 1; i++) own.temperature_grid[i] = ARTIS_OPT_MINTEMP * std::exp(i * v.T_step_log);
+  own.level_ion.assign(m.nlevels, 0);
+  for (int ui = 0; ui < m.nions; ui++)
+    for (int l = 0; l < m.ion_nlevels[ui]; l++) own.level_ion[m.ion_uniquelevelindexstart[ui] + l] = ui;
+  own.line_pack.resize(m.nlines);
+  for (int i = 0; i < m.nlines; i++)
+    own.line_pack[i] = LinePack{m.line_uniquelevelindex_lower[i], m.line_uniquelevelindex_upper[i], m.line_B_ul[i], m.line_B_lu[i]};
+  v.temperature_grid = own.temperature_grid.data();
+  v.level_ion = own.level_ion.data();
+  v.line_pack = own.line_pack.data();
+#define ARTIS_COPY_PTR(f) v.f = m.f;
+  ARTIS_COPY_PTR(elem_nions) ARTIS_COPY_PTR(elem_uniqueionindexstart) ARTIS_COPY_PTR(elem_lowest_ionstage)
+  ARTIS_COPY_PTR(ion_element) ARTIS_COPY_PTR(ion_nlevels) ARTIS_COPY_PTR(ion_nlevels_ionising)
+  ARTIS_COPY_PTR(ion_maxrecombininglevel) ARTIS_COPY_PTR(ion_uniquelevelindexstart) ARTIS_COPY_PTR(ion_coolingoffset)
+  ARTIS_COPY_PTR(ion_ncoolingterms) ARTIS_COPY_PTR(level_epsilon) ARTIS_COPY_PTR(level_statweight)
+  ARTIS_COPY_PTR(level_alltrans_startdown) ARTIS_COPY_PTR(level_ndowntrans) ARTIS_COPY_PTR(level_nuptrans)
+  ARTIS_COPY_PTR(level_closestgroundlevelcont) ARTIS_COPY_PTR(level_phixsstart) ARTIS_COPY_PTR(level_nphixstargets)
+  ARTIS_COPY_PTR(level_phixstargetstart) ARTIS_COPY_PTR(level_bflist_start) ARTIS_COPY_PTR(level_matransblock_start)
+  ARTIS_COPY_PTR(alltrans_lineindex) ARTIS_COPY_PTR(alltrans_targetlevelindex) ARTIS_COPY_PTR(alltrans_einstein_A)
+  ARTIS_COPY_PTR(alltrans_coll_str) ARTIS_COPY_PTR(alltrans_osc_strength) ARTIS_COPY_PTR(alltrans_forbidden)
+  ARTIS_COPY_PTR(line_nu) ARTIS_COPY_PTR(line_elementindex) ARTIS_COPY_PTR(line_ionindex) ARTIS_COPY_PTR(allphixs)
+  ARTIS_COPY_PTR(allphixstargets_levelindex) ARTIS_COPY_PTR(allphixstargets_probability) ARTIS_COPY_PTR(allcont_nu_edge)
+  ARTIS_COPY_PTR(allcont_element) ARTIS_COPY_PTR(allcont_ion) ARTIS_COPY_PTR(allcont_level)
+  ARTIS_COPY_PTR(allcont_phixstargetindex) ARTIS_COPY_PTR(allcont_upperlevel) ARTIS_COPY_PTR(allcont_uniquelevelindex)
+  ARTIS_COPY_PTR(allcont_groundcontestimindex) ARTIS_COPY_PTR(allcont_probability) ARTIS_COPY_PTR(groundcont_nu_edge)
+  ARTIS_COPY_PTR(spontrecombcoeffs) ARTIS_COPY_PTR(corrphotoioncoeffs) ARTIS_COPY_PTR(bfcooling_coeffs)
+  ARTIS_COPY_PTR(coolinglist_type) ARTIS_COPY_PTR(coolinglist_level) ARTIS_COPY_PTR(coolinglist_phixstargetindex)
+  ARTIS_COPY_PTR(propcell_nonemptymgi)
+#undef ARTIS_COPY_PTR
+  v.gridtype = m.gridtype;
+  int stride = 1;
+  for (int a = 0; a < 3; a++) {
+    v.ncoordgrid[a] = m.ncoordgrid[a];
+    v.coordstride[a] = stride;  // get_coordcellindexstride grid.cc:200
+    stride *= m.ncoordgrid[a];
+    v.coord_pos_min_tmin[a] = m.coord_pos_min_tmin[a];
+  }
+  v.ngrid = m.ngrid;
+  v.npts_nonempty = m.npts_nonempty;
+  v.tmin = m.tmin; v.vmax = m.vmax; v.rmax = m.rmax;
+  return v;
+}
+
+inline DevCells make_host_cells_view(const artis_cellstate &c) {
+  DevCells v;
+  v.rho = c.rho; v.Te = c.Te; v.TJ = c.TJ; v.TR = c.TR; v.W = c.W; v.nne = c.nne; v.nnetot = c.nnetot;
+  v.kappagrey = c.kappagrey; v.clumpfactor = c.clumpfactor; v.thick = c.thick;
+  v.ion_groundlevelpops = c.ion_groundlevelpops; v.ion_partfuncts = c.ion_partfuncts; v.elem_massfracs = c.elem_massfracs;
+  v.corrphotoionrenorm = c.corrphotoionrenorm;
+  return v;
+}
+
+inline DevStep make_step(const artis_timestep &t) {
+  DevStep s;
+  s.nts = t.nts; s.start = t.start; s.width = t.width; s.mid = t.mid; s.max_path_step = t.max_path_step;
+  s.ts_end = t.start + t.width;  // update_packets.cc:536
+  return s;
+}
+
+// Carve the SoA columns of n packets out of one allocation of pkt_soa_bytes(n) bytes.
+inline size_t pkt_soa_bytes(int64_t n) {
+  const size_t n8 = ((size_t)n + 1) & ~(size_t)1;  // keep 8-byte columns aligned after 4-byte ones
+  return ((size_t)PKT_NCOL64 * 8 + (size_t)PKT_NCOL32 * 4) * n8;
+}
+inline PktSoA carve_pkt_soa(void *base, int64_t n) {
+  const size_t n8 = ((size_t)n + 1) & ~(size_t)1;
+  PktSoA P;
+  double *d = (double *)base;
+  double **cols64[] = {&P.prop_time, &P.pos_x, &P.pos_y, &P.pos_z, &P.dir_x, &P.dir_y, &P.dir_z, &P.nu_cmf, &P.e_cmf, &P.nu_rf,
+                       &P.e_rf, &P.stokes_q, &P.stokes_u, &P.em_pos_x, &P.em_pos_y, &P.em_pos_z, &P.trueem_pos_x, &P.trueem_pos_y,
+                       &P.trueem_pos_z, &P.absorptionfreq};
+  static_assert(sizeof(cols64) / sizeof(cols64[0]) == PKT_NCOL64, "64-bit column count");
+  for (auto c : cols64) {
+    *c = d;
+    d += n8;
+  }
+  uint32_t *w = (uint32_t *)d;
+  P.rng = w;  // 4 columns, but strided by the true n (see pkt_load)
+  w += 4 * n8;
+  int32_t **cols32[] = {&P.next_trans, &P.nscatterings, &P.type, &P.cellindex, &P.emissiontype, &P.absorptiontype,
+                        &P.trueemissiontype, &P.escape_type};
+  for (auto c : cols32) {
+    *c = (int32_t *)w;
+    w += n8;
+  }
+  float **colsf[] = {&P.em_time, &P.trueem_time, &P.escape_time};
+  for (auto c : colsf) {
+    *c = (float *)w;
+    w += n8;
+  }
+  P.n = n;
+  return P;
+}
+
+}  // namespace artis

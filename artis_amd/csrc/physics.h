@@ -1,0 +1,1831 @@
+// physics.h -- bodies of the packet kernels.
+//
+// Everything a GPU thread does to one packet (or one cell-cache entry) is written here as inline
+// functions over the POD views of tables.h. The HIP engine (artis_engine.hip) wraps them in
+// __global__ kernels; the host-emulation test build (tests/hostemu/emu.cc) compiles the very same
+// bodies with g++ to run differential tests against the CPU oracle on machines without a GPU.
+//
+// Floating-point discipline: build with -ffp-contract=off. The order of operations (including the
+// reference's float/double mixing) follows the reference functions cited at each body, so that a
+// packet history is reproducible field by field.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "tables.h"
+
+#if defined(__HIPCC__) && !defined(ARTIS_HOST_EMU)
+#define AHD __host__ __device__ inline
+#define ANOINLINE static __host__ __device__ __attribute__((noinline))
+#else
+#define AHD inline
+#define ANOINLINE static __attribute__((noinline))
+#endif
+
+namespace artis {
+
+// ---- constants.h of the reference
+constexpr double CLIGHT = 2.99792458e+10;
+constexpr double CLIGHT_PROP = CLIGHT;
+constexpr double HPLANCK = 6.6260755e-27;
+constexpr double PI = 3.14159265358979323846;
+constexpr double EV = 1.6021772e-12;
+constexpr double SIGMA_T = 6.6524e-25;
+constexpr double KB = 1.38064852e-16;
+constexpr double SAHACONST = 2.0706659e-16;
+constexpr double EULERGAMMA = 0.577215664901532860606512090082402431;
+constexpr double CLIGHTSQUARED = CLIGHT * CLIGHT;
+constexpr double CLIGHTSQUAREDOVERTWOH = CLIGHT * CLIGHT / (2 * HPLANCK);
+constexpr double HOVERKB = HPLANCK / KB;
+constexpr double HCLIGHTOVERFOURPI = HPLANCK * CLIGHT / (4 * PI);
+constexpr double H_ionpot = 13.5979996 * EV;
+constexpr double C_0 = 5.465e-11;
+constexpr double DBLMAX = 1.7976931348623157e308;
+constexpr double DBLMIN = 2.2250738585072014e-308;
+constexpr int MA_N = ARTIS_MA_ACTION_COUNT;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned int stat_t;
+#define ARTIS_STAT_ADD(env, i, v) atomicAdd(&(env).stats[(i)], (stat_t)(v))
+#define ARTIS_EST_ADD(ptr, v) unsafeAtomicAdd((ptr), (v))
+#else
+typedef unsigned long long stat_t;
+#define ARTIS_STAT_ADD(env, i, v) ((env).stats[(i)] += (stat_t)(v))
+#define ARTIS_EST_ADD(ptr, v) (*(ptr) += (v))
+#endif
+#define ARTIS_STAT(env, i) ARTIS_STAT_ADD(env, i, 1)
+
+AHD double pow2(double x) { return x * x; }
+AHD double pow3(double x) { return x * x * x; }
+AHD double dmin(double a, double b) { return (b < a) ? b : a; }
+AHD double dmax(double a, double b) { return (a < b) ? b : a; }
+AHD double dclamp(double v, double lo, double hi) { return (v < lo) ? lo : ((hi < v) ? hi : v); }
+
+// Everything a thread needs besides its packet.
+struct Env {
+  DevModel M;
+  DevCells C;
+  DevCache K;
+  DevStep S;
+  DevEst E;
+  PktSoA P;
+  stat_t *stats;       // [ARTIS_NSTATS] LDS on the GPU, plain memory in the emulation
+  double *gamma_ws;    // groundcont_gamma_contr workspace [nbfcontinua_ground][ws_stride]
+  int64_t ws_stride;
+  int32_t *errflag;    // set non-zero when an assert_always of the reference would fire
+};
+
+// Hot packet state, kept in registers.
+struct Pkt {
+  uint32_t s0, s1, s2, s3;
+  double prop_time, px, py, pz, dx, dy, dz, nu_cmf, e_cmf, nu_rf, e_rf, stokes_q, stokes_u;
+  int32_t next_trans, nscatterings, type, cellindex;
+};
+
+// ContinuumOpacity (rpkt.h:70); groundcont_gamma_contr lives in env.gamma_ws
+struct Chi {
+  double nu, chi_escatter, chi_freefree_heat, chi_boundfree;
+  int32_t nonemptymgi;
+};
+
+struct MAState {
+  int32_t element, ion, level, activatingline;
+};
+
+AHD void fail(const Env &env, int code) {
+  if (env.errflag) *env.errflag = code;
+}
+
+// ---------------------------------------------------------------- RNG: random.h:101-136, 141-164, 178-202
+AHD uint32_t rotl32(uint32_t x, unsigned k) { return (x << k) | (x >> (32U - k)); }
+AHD uint32_t rng_next(Pkt &p) {
+  const uint32_t result = rotl32(p.s0 + p.s3, 7U) + p.s0;
+  const uint32_t t = p.s1 << 9U;
+  p.s2 ^= p.s0;
+  p.s3 ^= p.s1;
+  p.s1 ^= p.s2;
+  p.s0 ^= p.s3;
+  p.s2 ^= t;
+  p.s3 = rotl32(p.s3, 11U);
+  return result;
+}
+AHD float rng_uniform(Pkt &p) {
+  while (true) {
+    const float z = (float)(rng_next(p) >> 8U) * 0x1.0p-24F;
+    if (z != 1.) return z;
+  }
+}
+AHD float rng_uniform_pos(Pkt &p) {
+  while (true) {
+    const float z = rng_uniform(p);
+    if (z > 0) return z;
+  }
+}
+
+// ---------------------------------------------------------------- vectors.h
+AHD double vlen(const double v[3]) {
+  double sq = 0.;
+  for (int i = 0; i < 3; i++) sq += pow2(v[i]);
+  return sqrt(sq);
+}
+AHD double vdot(const double x[3], const double y[3]) {
+  double s = 0.;
+  for (int i = 0; i < 3; i++) s += x[i] * y[i];
+  return s;
+}
+AHD void vnorm(const double in[3], double out[3]) {
+  const double m = vlen(in);
+  out[0] = in[0] / m;
+  out[1] = in[1] / m;
+  out[2] = in[2] / m;
+}
+AHD void vcross(const double a[3], const double b[3], double c[3]) {
+  c[0] = (a[1] * b[2]) - (b[1] * a[2]);
+  c[1] = (a[2] * b[0]) - (b[2] * a[0]);
+  c[2] = (a[0] * b[1]) - (b[0] * a[1]);
+}
+// angle_ab vectors.h:70
+AHD void angle_ab(const double dir1[3], const double vel[3], double dir2[3]) {
+  const double vsqr = vdot(vel, vel) / CLIGHTSQUARED;
+  const double gamma_rel = 1. / sqrt(1 - vsqr);
+  const double ndotv = vdot(dir1, vel);
+  const double fact1 = gamma_rel * (1 - (ndotv / CLIGHT));
+  const double fact2 = (gamma_rel - (pow2(gamma_rel) * ndotv / (gamma_rel + 1) / CLIGHT)) / CLIGHT;
+  const double t[3] = {(dir1[0] - (vel[0] * fact2)) / fact1, (dir1[1] - (vel[1] * fact2)) / fact1,
+                       (dir1[2] - (vel[2] * fact2)) / fact1};
+  vnorm(t, dir2);
+}
+// calculate_doppler_nucmf_on_nurf vectors.h:92
+AHD double doppler_at(double px, double py, double pz, double dx, double dy, double dz, double t) {
+  const double vel[3] = {px / t, py / t, pz / t};
+  const double dir[3] = {dx, dy, dz};
+  const double ndotv = vdot(dir, vel);
+  return 1. - (ndotv / CLIGHT);
+}
+AHD double doppler(const Pkt &p) { return doppler_at(p.px, p.py, p.pz, p.dx, p.dy, p.dz, p.prop_time); }
+// move_pkt_withtime vectors.h:119
+AHD void move_raw(double &px, double &py, double &pz, double dx, double dy, double dz, double &prop_time, double nu_rf,
+                  double &nu_cmf, double e_rf, double &e_cmf, double distance) {
+  const double nu_cmf_old = nu_cmf;
+  prop_time += distance / CLIGHT_PROP;
+  px = px + (dx * distance);
+  py = py + (dy * distance);
+  pz = pz + (dz * distance);
+  const double d = doppler_at(px, py, pz, dx, dy, dz, prop_time);
+  nu_cmf = dmin(nu_rf * d, nu_cmf_old);
+  e_cmf = e_rf * d;
+}
+AHD void move_pkt(Pkt &p, double distance) {
+  move_raw(p.px, p.py, p.pz, p.dx, p.dy, p.dz, p.prop_time, p.nu_rf, p.nu_cmf, p.e_rf, p.e_cmf, distance);
+}
+// set_pkt_restframe_from_cmf vectors.h:145
+AHD void set_restframe_from_cmf(Pkt &p) {
+  const double d = doppler(p);
+  p.nu_rf = p.nu_cmf / d;
+  p.e_rf = p.e_cmf / d;
+}
+// get_rand_isotropic_unitvec vectors.h:185
+AHD void rand_isotropic(Pkt &p, double out[3]) {
+  const double u = rng_uniform(p);
+  const double costheta = (2. * u) - 1.;
+  const double sintheta = 2. * sqrt(u * (1. - u));
+  const double phi = rng_uniform(p) * 2 * PI;
+  out[0] = sintheta * cos(phi);
+  out[1] = sintheta * sin(phi);
+  out[2] = costheta;
+}
+// get_rot_angle vectors.h:196
+AHD double rot_angle(const double n1[3], const double n2[3], const double ref1[3], const double ref2[3]) {
+  const double c = vdot(n1, n2);
+  const double u[3] = {(n1[0] * c) - n2[0], (n1[1] * c) - n2[1], (n1[2] * c) - n2[2]};
+  const double len = vlen(u);
+  if (len < 1e-12) return 0.0;
+  const double r[3] = {u[0] / len, u[1] / len, u[2] / len};
+  const double c1 = dclamp(vdot(r, ref1), -1., 1.);
+  const double c2 = vdot(r, ref2);
+  const double a = atan2(c2, c1);
+  return a < 0 ? a + (2 * PI) : a;
+}
+// meridian vectors.h:219
+AHD void meridian(const double dir[3], double ref1[3], double ref2[3]) {
+  const double n_xylen = sqrt(pow2(dir[0]) + pow2(dir[1]));
+  if (n_xylen == 0.) {
+    ref1[0] = 1.; ref1[1] = 0.; ref1[2] = 0.;
+    ref2[0] = 0.; ref2[1] = 1.; ref2[2] = 0.;
+    return;
+  }
+  ref1[0] = -dir[0] * dir[2] / n_xylen;
+  ref1[1] = -dir[1] * dir[2] / n_xylen;
+  ref1[2] = (1 - pow2(dir[2])) / n_xylen;
+  vcross(ref1, dir, ref2);
+}
+// lorentz vectors.h:233
+AHD void lorentz(const double elec_rf[3], const double n_rf[3], const double v[3], double elec_cmf[3]) {
+  const double beta[3] = {v[0] / CLIGHT, v[1] / CLIGHT, v[2] / CLIGHT};
+  const double b2 = vdot(beta, beta);
+  if (b2 == 0.) {
+    elec_cmf[0] = elec_rf[0]; elec_cmf[1] = elec_rf[1]; elec_cmf[2] = elec_rf[2];
+    return;
+  }
+  const double gamma_rel = 1. / sqrt(1 - b2);
+  const double edb = vdot(elec_rf, beta);
+  const double par[3] = {edb * beta[0] / b2, edb * beta[1] / b2, edb * beta[2] / b2};
+  const double perp[3] = {elec_rf[0] - par[0], elec_rf[1] - par[1], elec_rf[2] - par[2]};
+  double b_rf[3], vxb[3];
+  vcross(n_rf, elec_rf, b_rf);
+  vcross(beta, b_rf, vxb);
+  const double t[3] = {par[0] + (gamma_rel * (perp[0] + vxb[0])), par[1] + (gamma_rel * (perp[1] + vxb[1])),
+                       par[2] + (gamma_rel * (perp[2] + vxb[2]))};
+  vnorm(t, elec_cmf);
+}
+// frame_transform vectors.h:266
+ANOINLINE void frame_transform(const double n_rf[3], double q0, double u0, const double v[3], double n_cmf[3], double *q_cmf,
+                               double *u_cmf) {
+  double ref1_rf[3], ref2_rf[3];
+  meridian(n_rf, ref1_rf, ref2_rf);
+  const double pdeg = sqrt(pow2(q0) + pow2(u0));
+  double ra = 0;
+  if (pdeg > 0) {
+    const double pol_angle = atan2(u0, q0);
+    ra = (pol_angle < 0 ? pol_angle + (2. * PI) : pol_angle) / 2.;
+  }
+  const double cr = cos(ra);
+  const double sr = sin(ra);
+  const double elec_rf[3] = {(cr * ref1_rf[0]) - (sr * ref2_rf[0]), (cr * ref1_rf[1]) - (sr * ref2_rf[1]),
+                             (cr * ref1_rf[2]) - (sr * ref2_rf[2])};
+  angle_ab(n_rf, v, n_cmf);
+  double elec_cmf[3];
+  lorentz(elec_rf, n_rf, v, elec_cmf);
+  double ref1_cmf[3], ref2_cmf[3];
+  meridian(n_cmf, ref1_cmf, ref2_cmf);
+  const double c1 = vdot(elec_cmf, ref1_cmf);
+  const double c2 = vdot(elec_cmf, ref2_cmf);
+  double theta = atan2(-c2, c1);
+  if (theta < 0) theta += 2 * PI;
+  *q_cmf = cos(2 * theta) * pdeg;
+  *u_cmf = sin(2 * theta) * pdeg;
+}
+// scatter_polarisation_to_rf vectors.h:325
+ANOINLINE void scatter_polarisation_to_rf(const double old_dir_cmf[3], const double new_dir_cmf[3], double q_i, double u_i,
+                                          const double vel[3], double new_dir_rf[3], double *q_rf, double *u_rf) {
+  double r1o[3], r2o[3];
+  meridian(old_dir_cmf, r1o, r2o);
+  const double i1 = rot_angle(old_dir_cmf, new_dir_cmf, r1o, r2o);
+  const double cos2i1 = cos(2 * i1);
+  const double sin2i1 = sin(2 * i1);
+  const double q_old = (q_i * cos2i1) - (u_i * sin2i1);
+  const double u_old = (q_i * sin2i1) + (u_i * cos2i1);
+  const double mu = vdot(old_dir_cmf, new_dir_cmf);
+  const double mu2 = pow2(mu);
+  const double I_new = 0.75 * ((mu2 + 1.) + (q_old * (mu2 - 1.)));
+  const double q_new = (0.75 * ((mu2 - 1.) + (q_old * (mu2 + 1.)))) / I_new;
+  const double u_new = (1.5 * mu * u_old) / I_new;
+  double r1[3], r2[3];
+  meridian(new_dir_cmf, r1, r2);
+  const double i2 = PI + rot_angle(new_dir_cmf, old_dir_cmf, r1, r2);
+  const double cos2i2 = cos(2 * i2);
+  const double sin2i2 = sin(2 * i2);
+  const double q_cmf = (q_new * cos2i2) + (u_new * sin2i2);
+  const double u_cmf = (-q_new * sin2i2) + (u_new * cos2i2);
+  const double nv[3] = {-vel[0], -vel[1], -vel[2]};
+  frame_transform(new_dir_cmf, q_cmf, u_cmf, nv, new_dir_rf, q_rf, u_rf);
+}
+
+// ---------------------------------------------------------------- atomic.h accessors
+AHD double statw(const DevModel &M, int ul) { return M.level_statweight[ul]; }
+AHD double eps(const DevModel &M, int ul) { return M.level_epsilon[ul]; }
+AHD int uion(const DevModel &M, int element, int ion) { return M.elem_uniqueionindexstart[element] + ion; }
+AHD int lstart(const DevModel &M, int element, int ion) { return M.ion_uniquelevelindexstart[uion(M, element, ion)]; }
+AHD int ionstage(const DevModel &M, int element, int ion) { return M.elem_lowest_ionstage[element] + ion; }
+AHD int phixs_upperlevel(const DevModel &M, int ul, int t) { return M.allphixstargets_levelindex[M.level_phixstargetstart[ul] + t]; }
+AHD double phixs_probability(const DevModel &M, int ul, int t) { return M.allphixstargets_probability[M.level_phixstargetstart[ul] + t]; }
+AHD const float *phixs_table(const DevModel &M, int ul) { return M.allphixs + ((int64_t)M.level_phixsstart[ul] * M.NPHIXSPOINTS); }
+AHD int find_phixstarget(const DevModel &M, int ul, int upperionlevel) {  // atomic.h:493
+  const int n = M.level_nphixstargets[ul];
+  for (int t = 0; t < n; t++)
+    if (upperionlevel == phixs_upperlevel(M, ul, t)) return t;
+  return -1;
+}
+AHD double phixs_threshold(const DevModel &M, int element, int ion, int level, int t) {  // atomic.h:534
+  const int ul = lstart(M, element, ion) + level;
+  return eps(M, lstart(M, element, ion + 1) + phixs_upperlevel(M, ul, t)) - eps(M, ul);
+}
+AHD int emtype_continuum(const DevModel &M, int ul, int t) { return -1 - M.level_bflist_start[ul] - t; }  // atomic.h:508
+// photoionisation_crosssection_fromtable atomic.h:201
+AHD float phixs_fromtable(const DevModel &M, const float *xs, double nu_edge, double nu) {
+  const int NP = M.NPHIXSPOINTS;
+  const double INC = M.NPHIXSNUINCREMENT;
+#if ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION
+  if (nu < nu_edge) return 0.f;
+  if (nu == nu_edge) return xs[0];
+  if (nu < nu_edge * (1 + (INC * NP))) {
+    int i = (int)((nu - nu_edge) / (INC * nu_edge));
+    if (NP - 1 < i) i = NP - 1;
+    return xs[i];
+  }
+  return (float)(xs[NP - 1] * pow(nu_edge * (1 + (INC * NP)) / nu, 3));
+#else
+  const double ireal = ((nu / nu_edge) - 1.0) / INC;
+  const int i = (int)floor(ireal);
+  if (i < 0) return 0.f;
+  if (i < NP - 1) {
+    const double a = xs[i];
+    const double b = xs[i + 1];
+    const double fb = ireal - i;
+    return (float)(((1. - fb) * a) + (fb * b));
+  }
+  const double nu_max_phixs = nu_edge * M.last_phixs_nuovernuedge;
+  return (float)(xs[NP - 1] * pow3(nu_max_phixs / nu));
+#endif
+}
+// std::ranges::upper_bound / lower_bound on a rising double array
+AHD int upper_bound_d(const double *a, int n, double v) {
+  int lo = 0, len = n;
+  while (len > 0) {
+    const int half = len / 2;
+    if (!(v < a[lo + half])) { lo += half + 1; len -= half + 1; } else { len = half; }
+  }
+  return lo;
+}
+AHD int lower_bound_d(const double *a, int n, double v) {
+  int lo = 0, len = n;
+  while (len > 0) {
+    const int half = len / 2;
+    if (a[lo + half] < v) { lo += half + 1; len -= half + 1; } else { len = half; }
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------- grid.cc
+AHD int coordidx(const DevModel &M, int cellindex, int axis) { return (cellindex / M.coordstride[axis]) % M.ncoordgrid[axis]; }
+AHD double coordmin(const DevModel &M, int cellindex, int axis) { return M.coord_pos_min_tmin[axis][coordidx(M, cellindex, axis)]; }
+AHD double coordmax(const DevModel &M, int cellindex, int axis) {
+  const int idx = coordidx(M, cellindex, axis);
+  return idx < M.ncoordgrid[axis] - 1 ? M.coord_pos_min_tmin[axis][idx + 1] : M.rmax;
+}
+AHD double cellbound_tol(double b) { return dmax(10., fabs(b) * 1e-12); }  // grid.cc:1530
+AHD bool overshoot_in_tol(const DevModel &M, bool upper, double pos, double vel, double bpos_tmin, double tstart) {  // grid.cc:1542
+  const double bvel = bpos_tmin / M.tmin;
+  const double bpos = bvel * tstart;
+  const double overshoot = upper ? (pos - bpos) : (bpos - pos);
+  const bool towards = upper ? (vel > bvel) : (vel < bvel);
+  return towards && (overshoot >= 0.) && (overshoot <= cellbound_tol(bpos));
+}
+AHD double dist_cart_boundary(const DevModel &M, double pos, double vel, double bpos, double tstart) {  // grid.cc:1518
+  return CLIGHT_PROP * (pos - (bpos / M.tmin * tstart)) / ((bpos / M.tmin) - vel);
+}
+// expanding_shell_intersection grid.cc:1413 (3-vectors)
+AHD double shell_intersection(bool lower, const double pos[3], const double dir[3], double speed, double rshell, double tstart) {
+  const double a = vdot(dir, dir) - pow2(rshell / tstart / speed);
+  const double b = 2 * (vdot(dir, pos) - (pow2(rshell) / tstart / speed));
+  const double c = vdot(pos, pos) - pow2(rshell);
+  const double disc = pow2(b) - (4 * a * c);
+  if (disc < 0) return -1;
+  if (disc > 0) {
+    double d1 = (-b + sqrt(disc)) / 2 / a;
+    double d2 = (-b - sqrt(disc)) / 2 / a;
+    double pf1[3], pf2[3];
+    for (int d = 0; d < 3; d++) {
+      pf1[d] = pos[d] + (d1 * dir[d]);
+      pf2[d] = pos[d] + (d2 * dir[d]);
+    }
+    const double v_shell = rshell / tstart;
+    const double v1 = vdot(dir, pf1) * speed / vlen(pf1);
+    const double v2 = vdot(dir, pf2) * speed / vlen(pf2);
+    if (lower) {
+      if (v1 > v_shell) d1 = -1;
+      if (v2 > v_shell) d2 = -1;
+    } else {
+      if (v1 < v_shell) d1 = -1;
+      if (v2 < v_shell) d2 = -1;
+    }
+    if (d1 < 0 && d2 < 0) return -1;
+    if (d2 < 0) return d1;
+    if (d1 < 0) return d2;
+    return dmin(d1, d2);
+  }
+  return -1.;
+}
+// boundary_distance grid.cc:2480
+AHD double boundary_distance(const Env &env, const Pkt &p, int *next_cell) {
+  const DevModel &M = env.M;
+  const double tstart = p.prop_time;
+  const int cellindex = p.cellindex;
+  double distance = DBLMAX;
+  int next = -1;
+  const double pos[3] = {p.px, p.py, p.pz};
+  const double dir[3] = {p.dx, p.dy, p.dz};
+  if (M.gridtype == ARTIS_GRID_CARTESIAN3D) {
+    for (int d = 0; d < 3; d++) {
+      const double vel = dir[d] * CLIGHT_PROP;
+      const int idx = coordidx(M, cellindex, d);
+      const double cmin = M.coord_pos_min_tmin[d][idx];
+      const double cmax = idx < M.ncoordgrid[d] - 1 ? M.coord_pos_min_tmin[d][idx + 1] : M.rmax;
+      if (vel > (cmax / M.tmin)) {
+        const double dd = overshoot_in_tol(M, true, pos[d], vel, cmax, tstart) ? 0. : dist_cart_boundary(M, pos[d], vel, cmax, tstart);
+        if ((dd >= 0.) && (dd < distance)) {
+          distance = dd;
+          next = (idx == (M.ncoordgrid[d] - 1)) ? -99 : cellindex + M.coordstride[d];
+        }
+      } else if (vel < (cmin / M.tmin)) {
+        const double dd = overshoot_in_tol(M, false, pos[d], vel, cmin, tstart) ? 0. : dist_cart_boundary(M, pos[d], vel, cmin, tstart);
+        if ((dd >= 0.) && (dd < distance)) {
+          distance = dd;
+          next = (idx == 0) ? -99 : cellindex - M.coordstride[d];
+        }
+      }
+    }
+  } else if (M.gridtype == ARTIS_GRID_SPHERICAL1D) {
+    const double r = vlen(pos);
+    const double vr = vdot(pos, dir) / r * CLIGHT_PROP;
+    const int idx = coordidx(M, cellindex, 0);
+    const double cmin = coordmin(M, cellindex, 0);
+    const double cmax = coordmax(M, cellindex, 0);
+    const double speed = vlen(dir) * CLIGHT_PROP;
+    const double r_outer = cmax * tstart / M.tmin;
+    const double dmaxb = overshoot_in_tol(M, true, r, vr, cmax, tstart) ? 0. : shell_intersection(false, pos, dir, speed, r_outer, tstart);
+    if ((dmaxb >= 0.) && (dmaxb < distance)) {
+      distance = dmaxb;
+      next = (idx == (M.ncoordgrid[0] - 1)) ? -99 : cellindex + M.coordstride[0];
+    }
+    const double r_inner = cmin * tstart / M.tmin;
+    if (r_inner > 0.) {
+      const double dminb = overshoot_in_tol(M, false, r, vr, cmin, tstart) ? 0. : shell_intersection(true, pos, dir, speed, r_inner, tstart);
+      if ((dminb >= 0.) && (dminb < distance)) {
+        distance = dminb;
+        next = (idx == 0) ? -99 : cellindex - M.coordstride[0];
+      }
+    }
+  } else {
+    fail(env, 10);
+  }
+  if (!((next == -99) || ((next >= 0) && (next < M.ngrid))) || !(distance >= 0.)) fail(env, 11);
+  if (distance > env.S.max_path_step) {
+    *next_cell = cellindex;
+    return env.S.max_path_step;
+  }
+  *next_cell = next;
+  return distance;
+}
+// change_cell_or_escape grid.h:118 with snap_pos_to_cell grid.cc:2460
+AHD void change_cell_or_escape(const Env &env, Pkt &p, int64_t pi, int next_cell) {
+  const DevModel &M = env.M;
+  if (next_cell >= 0) {
+    if (next_cell != p.cellindex && M.gridtype == ARTIS_GRID_CARTESIAN3D) {
+      double *pos[3] = {&p.px, &p.py, &p.pz};
+      for (int d = 0; d < 3; d++) {
+        const int idx = coordidx(M, next_cell, d);
+        const double lo = M.coord_pos_min_tmin[d][idx] / M.tmin * p.prop_time;
+        const double hi = (idx < (M.ncoordgrid[d] - 1)) ? M.coord_pos_min_tmin[d][idx + 1] / M.tmin * p.prop_time
+                                                         : M.rmax / M.tmin * p.prop_time;
+        *pos[d] = dclamp(*pos[d], lo, hi);
+      }
+    }
+    p.cellindex = next_cell;
+    ARTIS_STAT(env, ARTIS_STAT_CELLCROSSINGS);
+  } else {
+    env.P.escape_type[pi] = p.type;
+    env.P.escape_time[pi] = (float)p.prop_time;
+    p.type = ARTIS_TYPE_ESCAPE;
+    ARTIS_STAT(env, ARTIS_STAT_PKTESCAPES);
+  }
+}
+
+// ---------------------------------------------------------------- cell state
+AHD float clumpednne(const DevCells &C, int c) { return C.clumpfactor[c] * C.nne[c]; }
+AHD double groundlevelpop(const Env &env, int c, int element, int ion) {  // ltepop.h:74
+  const double nn = env.C.ion_groundlevelpops[((int64_t)c * env.M.nions) + uion(env.M, element, ion)];
+  if (nn < ARTIS_OPT_MINPOP) {
+    if (env.C.elem_massfracs[((int64_t)c * env.M.nelements) + element] > 0) return ARTIS_OPT_MINPOP;
+    return 0.;
+  }
+  return nn;
+}
+AHD double nnion(const Env &env, int c, int element, int ion) {  // ltepop.h:106
+  return groundlevelpop(env, c, element, ion) * env.C.ion_partfuncts[((int64_t)c * env.M.nions) + uion(env.M, element, ion)] /
+         statw(env.M, lstart(env.M, element, ion));
+}
+AHD double planck(double nu, double T) { return 2 * HPLANCK * pow3(nu) / pow2(CLIGHT) / expm1(HOVERKB * nu / T); }  // radfield.h:50
+AHD double radfield(const Env &env, double nu, int c) { return env.C.W[c] * planck(nu, env.C.TR[c]); }              // radfield.cc:786
+
+// ---------------------------------------------------------------- ratecoeff.cc LUTs
+AHD int temperature_upperindex(const DevModel &M, double T) {  // ratecoeff.cc:54
+  const int gridsize = ARTIS_OPT_TABLESIZE + 1;
+  int index = (int)(log(T / ARTIS_OPT_MINTEMP) / M.T_step_log) + 1;
+  if (index < 0) index = 0;
+  if (index > gridsize) index = gridsize;
+  while (index > 0 && M.temperature_grid[index - 1] > T) index--;
+  while (index < gridsize && M.temperature_grid[index] <= T) index++;
+  return index;
+}
+AHD double lerp_or_last(const DevModel &M, const double *table, int ul, int t, float T) {  // ratecoeff.cc:524
+  const double *row = table + ((int64_t)(M.level_bflist_start[ul] + t) * ARTIS_OPT_TABLESIZE);
+  const int up = temperature_upperindex(M, T);
+  if (up == 0) return row[0];
+  if (up < ARTIS_OPT_TABLESIZE) {
+    const double T_lower = M.temperature_grid[up - 1];
+    const double T_upper = M.temperature_grid[up];
+    const double f_lower = row[up - 1];
+    const double f_upper = row[up];
+    return (f_lower + ((f_upper - f_lower) / (T_upper - T_lower) * (T - T_lower)));
+  }
+  return row[ARTIS_OPT_TABLESIZE - 1];
+}
+
+// ---------------------------------------------------------------- macroatom.cc rate coefficients
+AHD double gaunt_factor(int stage) { return stage == 1 ? 0.1 : (stage == 2 ? 0.2 : 0.3); }  // macroatom.cc:327
+AHD double rad_deexc(double epsilon_trans, float A_ul, double gu, double gl, double n_u, double n_l, double t) {  // macroatom.h:61
+  const double nu_trans = epsilon_trans / HPLANCK;
+  const double B_ul = CLIGHTSQUAREDOVERTWOH / pow3(nu_trans) * A_ul;
+  const double B_lu = gu / gl * B_ul;
+  const double tau = ((B_lu * n_l) - (B_ul * n_u)) * HCLIGHTOVERFOURPI * t;
+  if (tau > 1e-100) {
+    const double beta = 1.0 / tau * (-expm1(-tau));
+    return A_ul * beta;
+  }
+  return A_ul;
+}
+AHD double rad_exc(const Env &env, int c, double gu, double A, double epsilon_trans, double n_l, double n_u, double gl, double t) {  // macroatom.cc:611
+  const double nu_trans = epsilon_trans / HPLANCK;
+  const double B_ul = CLIGHTSQUAREDOVERTWOH / pow3(nu_trans) * A;
+  const double B_lu = gu / gl * B_ul;
+  const double tau = ((B_lu * n_l) - (B_ul * n_u)) * HCLIGHTOVERFOURPI * t;
+  if (tau > 1e-100) {
+    const double beta = 1.0 / tau * (-expm1(-tau));
+    const double R_over_J = n_l > 0. ? (B_lu - (B_ul * n_u / n_l)) * beta : B_lu * beta;
+    return R_over_J * radfield(env, nu_trans, c);
+  }
+  return 0.;
+}
+AHD double rad_recomb(const DevModel &M, float T_e, float cnne, int element, int upperion, int lowerlevel, int t) {  // macroatom.cc:646
+  return cnne * lerp_or_last(M, M.spontrecombcoeffs, lstart(M, element, upperion - 1) + lowerlevel, t, T_e);
+}
+AHD double col_recomb(const DevModel &M, float T_e, float cnne, int element, int upperion, int lower, int t, double epsilon_trans) {  // macroatom.cc:660
+  const int ul = lstart(M, element, upperion - 1) + lower;
+  const double gl = statw(M, ul);
+  const double g = gaunt_factor(ionstage(M, element, upperion - 1));
+  const double sigma_bf = (phixs_table(M, ul)[0] * phixs_probability(M, ul, t));
+  const double gu = statw(M, lstart(M, element, upperion) + phixs_upperlevel(M, ul, t));
+  return cnne * cnne * SAHACONST * gl / gu * 1.55e13 * g * sigma_bf * KB / T_e / epsilon_trans;
+}
+AHD double col_ion(const DevModel &M, float T_e, float cnne, int element, int ion, int lower, int t, double epsilon_trans) {  // macroatom.cc:686
+  const int ul = lstart(M, element, ion) + lower;
+  const double g = gaunt_factor(ionstage(M, element, ion));
+  const double fac1 = epsilon_trans / KB / T_e;
+  const double sigma_bf = phixs_table(M, ul)[0] * phixs_probability(M, ul, t);
+  return cnne * 1.55e13 * pow((double)T_e, -0.5) * g * sigma_bf * exp(-fac1) / fac1;
+}
+AHD double col_deexc(const DevModel &M, float T_e, float cnne, double epsilon_trans, double gu, double gl, int ati) {  // macroatom.cc:708
+  const float cs = M.alltrans_coll_str[ati];
+  if (cs < 0) {
+    if (!M.alltrans_forbidden[ati]) {
+      const double f = M.alltrans_osc_strength[ati];
+      const double eoverkt = epsilon_trans / (KB * T_e);
+      const double g_bar = 0.2;
+      const double gauntfac = (eoverkt > 0.33421) ? g_bar : 0.276 * exp(eoverkt) * (-EULERGAMMA - log(eoverkt));
+      const double g_ratio = gl / gu;
+      return C_0 * 14.51039491 * cnne * sqrtf(T_e) * f * pow2(H_ionpot / epsilon_trans) * eoverkt * g_ratio * gauntfac;
+    }
+    return cnne * 8.629e-6 * 0.01 * gl / sqrtf(T_e);
+  }
+  return cnne * 8.629e-6 * (double)cs / gu / sqrtf(T_e);
+}
+AHD double col_exc(const DevModel &M, float T_e, float cnne, double epsilon_trans, double gu, double gl, int ati) {  // macroatom.cc:750
+  const float cs = M.alltrans_coll_str[ati];
+  const double eoverkt = epsilon_trans / (KB * T_e);
+  if (cs < 0) {
+    if (!M.alltrans_forbidden[ati]) {
+      const double f = M.alltrans_osc_strength[ati];
+      const double g_bar = 0.2;
+      const double ex = exp(eoverkt);
+      const double Gamma = dmax(g_bar, 0.276 * ex * (-EULERGAMMA - log(eoverkt)));
+      return C_0 * cnne * sqrtf(T_e) * 14.51039491 * f * pow2(H_ionpot / epsilon_trans) * eoverkt / ex * Gamma;
+    }
+    return cnne * 8.629e-6 * 0.01 * exp(-eoverkt) * gu / sqrtf(T_e);
+  }
+  return cnne * 8.629e-6 * (double)cs * exp(-eoverkt) / gl / sqrtf(T_e);
+}
+
+// ================================================================ cell-cache population
+// (cellcacheslot_populate update_packets.cc:397, multi-slot form; one function per kernel)
+
+// one (cell, level): calculate_levelpop ltepop.cc:412 / calculate_levelpop_boltzmann ltepop.cc:395
+AHD void populate_levelpop(const Env &env, int c, int ul) {
+  const DevModel &M = env.M;
+  const int ui = M.level_ion[ul];
+  const int element = M.ion_element[ui];
+  const int ion = ui - M.elem_uniqueionindexstart[element];
+  const int start = M.ion_uniquelevelindexstart[ui];
+  const double nnground = groundlevelpop(env, c, element, ion);
+  double nn;
+  if (ul == start) {
+    nn = nnground;
+  } else {
+    const float T_exc = ARTIS_OPT_LTEPOP_EXCITATION_USE_TJ ? env.C.TJ[c] : env.C.Te[c];
+    const double E_aboveground = eps(M, ul) - eps(M, start);
+    nn = (nnground * statw(M, ul) / statw(M, start) * exp(-E_aboveground / KB / T_exc));
+  }
+  if (nn < ARTIS_OPT_MINPOP) nn = (env.C.elem_massfracs[((int64_t)c * M.nelements) + element] > 0) ? ARTIS_OPT_MINPOP : 0.;
+  env.K.levelpops[((int64_t)c * M.nlevels) + ul] = nn;
+}
+// one cell: calculate_chi_ffheat_nnionpart rpkt.cc:932
+AHD void populate_chi_ff(const Env &env, int c) {
+  const DevModel &M = env.M;
+  double s = 0.;
+  for (int element = 0; element < M.nelements; element++) {
+    const int nions = M.elem_nions[element];
+    for (int ion = 0; ion < nions; ion++) {
+      const double n = nnion(env, c, element, ion);
+      const int ioncharge = ionstage(M, element, ion) - 1;
+      s += pow2(ioncharge) * 1. * n;
+    }
+  }
+  const float T_e = env.C.Te[c];
+  env.K.chi_ff_nnionpart[c] = s * 3.69255e8 / sqrt((double)T_e);
+}
+// one (cell, continuum): update_packets.cc:430-440 + the slow path of rpkt.cc:853-889. Returns the keep bit.
+AHD bool populate_allcont(const Env &env, int c, int i) {
+  const DevModel &M = env.M;
+  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  const int64_t o = ((int64_t)c * M.nbfcontinua) + i;
+  const double nnlevel = pops[M.allcont_uniquelevelindex[i]];
+  const int element = M.allcont_element[i];
+  const int ion = M.allcont_ion[i];
+  const int level = M.allcont_level[i];
+  const float nnetot = env.C.nnetot[c];
+  const bool keep = nnlevel > 0 && ((nnion(env, c, element, ion) / nnetot > 1.e-6) || (level == 0));  // keep_this_cont rpkt.h:189
+  env.K.allcont_nnlevel[o] = nnlevel;
+  double dep = -1., edge = -1.;
+  if (keep) {
+    const float T_e = env.C.Te[c];
+    const float cnne = env.C.nne[c] * env.C.clumpfactor[c];
+    const double sahapart = SAHACONST * pow((double)T_e, -1.5);
+    const int upper = M.allcont_upperlevel[i];
+    const double nnupper = pops[lstart(M, element, ion + 1) + upper];
+    const double sahafact = sahapart * statw(M, lstart(M, element, ion) + level) / statw(M, lstart(M, element, ion + 1) + upper);
+    dep = nnupper / nnlevel * cnne * sahafact;
+    const double edge_exponent = HOVERKB * M.allcont_nu_edge[i] / T_e;
+    if (edge_exponent < 690.) {
+      const double e = dep * exp(edge_exponent);
+      if (isfinite(e)) edge = e;
+    }
+  }
+  env.K.allcont_departure[o] = dep;
+  env.K.allcont_edgepart[o] = edge;
+  return keep;
+}
+// one (cell, phixs target): get_corrphotoioncoeff ratecoeff.cc:840 (USE_LUT_PHOTOION)
+AHD void populate_corrphotoion(const Env &env, int c, int ul, int t) {
+  const DevModel &M = env.M;
+  const double W = env.C.W[c];
+  const double T_R = env.C.TR[c];
+  double g = W * lerp_or_last(M, M.corrphotoioncoeffs, ul, t, (float)T_R);
+  const int ig = M.level_closestgroundlevelcont[ul];
+  if (ig >= 0) g *= env.C.corrphotoionrenorm[((int64_t)c * M.nbfcontinua_ground) + ig];
+  env.K.corrphotoioncoeff[((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t] = g;
+}
+// one (cell, level): calculate_macroatom_transitionrates macroatom.cc:64
+AHD void populate_macroatom(const Env &env, int c, int ul) {
+  const DevModel &M = env.M;
+  const int ui = M.level_ion[ul];
+  const int element = M.ion_element[ui];
+  const int ion = ui - M.elem_uniqueionindexstart[element];
+  const int start = M.ion_uniquelevelindexstart[ui];
+  const int level = ul - start;
+  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  double *rates = env.K.maprocessrates + (((int64_t)c * M.nlevels + ul) * MA_N);
+  double *block = env.K.matrans + ((int64_t)c * M.nmatransblock) + M.level_matransblock_start[ul];
+  const double t_mid = env.S.mid;
+  const float T_e = env.C.Te[c];
+  const float cnne = clumpednne(env.C, c);
+  const double e_cur = eps(M, ul);
+  const double g_cur = statw(M, ul);
+  const double nnlevel = pops[ul];
+
+  double s_down_same = 0., s_raddeexc = 0., s_coldeexc = 0.;
+  const int startdown = M.level_alltrans_startdown[ul];
+  const int ndown = M.level_ndowntrans[ul];
+  for (int i = 0; i < ndown; i++) {
+    const int ati = startdown + i;
+    const int lul = start + M.alltrans_targetlevelindex[ati];
+    const float A_ul = M.alltrans_einstein_A[ati];
+    const double e_target = eps(M, lul);
+    const double e_trans = e_cur - e_target;
+    const double g_low = statw(M, lul);
+    const double R = rad_deexc(e_trans, A_ul, g_cur, g_low, nnlevel, pops[lul], t_mid);
+    const double Cc = col_deexc(M, T_e, cnne, e_trans, g_cur, g_low, ati);
+    s_raddeexc += R * e_trans;
+    s_coldeexc += Cc * e_trans;
+    s_down_same += (R + Cc) * e_target;
+    block[i] = s_raddeexc;
+    block[ndown + i] = s_down_same;
+  }
+  rates[ARTIS_MA_ACTION_RADDEEXC] = s_raddeexc;
+  rates[ARTIS_MA_ACTION_COLDEEXC] = s_coldeexc;
+  rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = s_down_same;
+
+  double s_up_same = 0.;
+  const int nup = M.level_nuptrans[ul];
+  const int startup = startdown + ndown;
+  for (int ii = 0; ii < nup; ii++) {
+    const int ati = startup + ii;
+    const int uul = start + M.alltrans_targetlevelindex[ati];
+    const double e_trans = eps(M, uul) - e_cur;
+    const double g_up = statw(M, uul);
+    const double R = rad_exc(env, c, g_up, M.alltrans_einstein_A[ati], e_trans, nnlevel, pops[uul], g_cur, t_mid);
+    const double Cc = col_exc(M, T_e, cnne, e_trans, g_up, g_cur, ati);
+    const double NT = 0.;
+    s_up_same += (R + Cc + NT) * e_cur;
+    block[(2 * ndown) + ii] = s_up_same;
+  }
+  rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s_up_same;
+
+  double s_down_lower = 0., s_radrecomb = 0., s_colrecomb = 0.;
+  if (ion > 0 && level <= M.ion_maxrecombininglevel[ui]) {
+    const int nl = M.ion_nlevels_ionising[ui - 1];
+    const int ls = M.ion_uniquelevelindexstart[ui - 1];
+    for (int lower = 0; lower < nl; lower++) {
+      const int t = find_phixstarget(M, ls + lower, level);
+      if (t < 0) continue;
+      const double e_target = eps(M, ls + lower);
+      const double e_trans = e_cur - e_target;
+      const double R = rad_recomb(M, T_e, cnne, element, ion, lower, t);
+      const double Cc = col_recomb(M, T_e, cnne, element, ion, lower, t, e_trans);
+      s_down_lower += (R + Cc) * e_target;
+      s_radrecomb += R * e_trans;
+      s_colrecomb += Cc * e_trans;
+    }
+  }
+  rates[ARTIS_MA_ACTION_INTERNALDOWNLOWER] = s_down_lower;
+  rates[ARTIS_MA_ACTION_RADRECOMB] = s_radrecomb;
+  rates[ARTIS_MA_ACTION_COLRECOMB] = s_colrecomb;
+
+  double s_up_higher = 0.;
+  if (ion < M.elem_nions[element] - 1 && level < M.ion_nlevels_ionising[ui]) {
+    const int nt = M.level_nphixstargets[ul];
+    const double *cpc = env.K.corrphotoioncoeff + ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
+    for (int t = 0; t < nt; t++) {
+      const double e_trans = phixs_threshold(M, element, ion, level, t);
+      const double R = cpc[t];
+      const double Cc = col_ion(M, T_e, cnne, element, ion, level, t, e_trans);
+      s_up_higher += (R + Cc) * e_cur;
+    }
+  }
+  rates[ARTIS_MA_ACTION_INTERNALUPHIGHERNT] = 0.;
+  rates[ARTIS_MA_ACTION_INTERNALUPHIGHER] = s_up_higher;
+}
+// one (cell, ion): calculate_cooling_rates_ion<true> kpkt.cc:57; stores the ion total for the prefix sum of kpkt.cc:281
+AHD void populate_cooling_ion(const Env &env, int c, int ui) {
+  const DevModel &M = env.M;
+  const int element = M.ion_element[ui];
+  const int ion = ui - M.elem_uniqueionindexstart[element];
+  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + M.ion_coolingoffset[ui];
+  const float cnne = clumpednne(env.C, c);
+  const float T_e = env.C.Te[c];
+  double C_ion = 0.;
+  int k = 0;
+  const int nionising = M.ion_nlevels_ionising[ui];
+  const double nncurrention = nnion(env, c, element, ion);
+  const int ioncharge = ionstage(M, element, ion) - 1;
+  if (ioncharge > 0) {
+    const double C_ff_ion = 1.426e-27 * sqrt((double)T_e) * pow2(ioncharge) * nncurrention * cnne;
+    C_ion += C_ff_ion;
+    contribs[k++] = C_ion;
+  }
+  const int start = M.ion_uniquelevelindexstart[ui];
+  const int nlevels = M.ion_nlevels[ui];
+  for (int level = 0; level < nlevels; level++) {
+    const int ul = start + level;
+    const double nnlevel = pops[ul];
+    const double e_cur = eps(M, ul);
+    const double g_cur = statw(M, ul);
+    const int startup = M.level_alltrans_startdown[ul] + M.level_ndowntrans[ul];
+    const int nup = M.level_nuptrans[ul];
+    for (int ati = startup; ati < (startup + nup); ati++) {
+      const int uul = start + M.alltrans_targetlevelindex[ati];
+      const double e_trans = eps(M, uul) - e_cur;
+      const double Cc = nnlevel * col_exc(M, T_e, cnne, e_trans, statw(M, uul), g_cur, ati) * e_trans;
+      C_ion += Cc;
+    }
+    if (nup > 0) contribs[k++] = C_ion;
+  }
+  if (ion < (M.elem_nions[element] - 1) && M.nbfcontinua > 0) {
+    const double nnupperion = nnion(env, c, element, ion + 1);
+    const int ustart = M.ion_uniquelevelindexstart[ui + 1];
+    for (int level = 0; level < nionising; level++) {
+      const int ul = start + level;
+      const double e_cur = eps(M, ul);
+      const double nnlevel = pops[ul];
+      const int nt = M.level_nphixstargets[ul];
+      for (int t = 0; t < nt; t++) {
+        const double e_trans = eps(M, ustart + phixs_upperlevel(M, ul, t)) - e_cur;
+        const double Cc = nnlevel * col_ion(M, T_e, cnne, element, ion, level, t, e_trans) * e_trans;
+        C_ion += Cc;
+        contribs[k++] = C_ion;
+      }
+    }
+    for (int level = 0; level < nionising; level++) {
+      const int ul = start + level;
+      const int nt = M.level_nphixstargets[ul];
+      double wsum = 0.;
+      double E_min = 0.;
+#if !ARTIS_OPT_BFCOOLING_USELEVELPOPNOTIONPOP
+      if (nt > 1) {
+        E_min = DBLMAX;
+        for (int t = 0; t < nt; t++) E_min = dmin(E_min, eps(M, ustart + phixs_upperlevel(M, ul, t)));
+        for (int t = 0; t < nt; t++) {
+          const int up = phixs_upperlevel(M, ul, t);
+          wsum += statw(M, ustart + up) * exp(-(eps(M, ustart + up) - E_min) / KB / T_e);
+        }
+      }
+#endif
+      for (int t = 0; t < nt; t++) {
+        double pop;
+#if ARTIS_OPT_BFCOOLING_USELEVELPOPNOTIONPOP
+        pop = pops[ustart + phixs_upperlevel(M, ul, t)];
+#else
+        if (nt == 1) {
+          pop = nnupperion;
+        } else {
+          const int up = phixs_upperlevel(M, ul, t);
+          const double w = statw(M, ustart + up) * exp(-(eps(M, ustart + up) - E_min) / KB / T_e);
+          pop = nnupperion * w / wsum;
+        }
+#endif
+        const double Cc = lerp_or_last(M, M.bfcooling_coeffs, ul, t, T_e) * pop * cnne;
+        C_ion += Cc;
+        contribs[k++] = C_ion;
+      }
+    }
+  }
+  if (k != M.ion_ncoolingterms[ui]) fail(env, 20);
+  env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] = C_ion;
+}
+// one cell: cumulative cooling over ions, kpkt.cc:288-294
+AHD void populate_cooling_prefix(const Env &env, int c) {
+  double cum = 0.;
+  for (int ui = 0; ui < env.M.nions; ui++) {
+    cum += env.K.ion_cooling_C[((int64_t)c * env.M.nions) + ui];
+    env.K.ion_cooling_contribs[((int64_t)c * env.M.nions) + ui] = cum;
+  }
+}
+
+// ================================================================ r-packet path
+AHD double chi_total(const Chi &x) { return x.chi_escatter + x.chi_boundfree + x.chi_freefree_heat; }  // rpkt.h:100
+
+// calculate_chi_bf_gammacontr<true, SELECT> rpkt.cc:721
+template <bool SELECT>
+AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, double threshold, int *selected) {
+  const DevModel &M = env.M;
+  double sum = 0.;
+  if (!SELECT) {
+    for (int i = 0; i < M.nbfcontinua_ground; i++) env.gamma_ws[(i * env.ws_stride) + slot] = 0.;
+  }
+  const float T_e = env.C.Te[c];
+  const double ex = exp(-HOVERKB * nu / T_e);
+  const bool split_usable = (ex >= DBLMIN);
+  const int cend = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
+  const int cbegin = lower_bound_d(M.allcont_nu_edge, cend, nu / M.last_phixs_nuovernuedge);
+  const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
+  const double *nnl = env.K.allcont_nnlevel + ((int64_t)c * M.nbfcontinua);
+  const double *edgepart = env.K.allcont_edgepart + ((int64_t)c * M.nbfcontinua);
+  const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
+  for (int word = cbegin / 64; word * 64 < cend; word++) {
+    uint64_t bits = keep[word];
+    if (word == (cbegin / 64)) bits &= ~UINT64_C(0) << (unsigned)(cbegin % 64);
+    if (((word + 1) * 64) > cend) bits &= ~UINT64_C(0) >> (unsigned)(64 - (cend % 64));
+    while (bits != 0) {
+      const int i = (word * 64) + __builtin_ctzll(bits);
+      bits &= bits - 1;
+      const double nnlevel = nnl[i];
+      const double nu_edge = M.allcont_nu_edge[i];
+      const double sigma_bf = phixs_fromtable(M, phixs_table(M, M.allcont_uniquelevelindex[i]), nu_edge, nu);
+      const double ep = edgepart[i];
+      double stim;
+      if (ep >= 0. && split_usable) {
+        stim = ep * ex;
+      } else {
+        stim = departure[i] * exp(-HOVERKB * (nu - nu_edge) / T_e);
+      }
+      const double corr = dmax(0., 1 - stim);
+      const double sigma_contr = sigma_bf * M.allcont_probability[i] * corr;
+      if (!SELECT) {
+        const int gi = M.allcont_groundcontestimindex[i];
+        if (gi >= 0) env.gamma_ws[(gi * env.ws_stride) + slot] = sigma_contr;
+      }
+      sum += nnlevel * sigma_contr;
+      if (SELECT && sum > threshold) {
+        *selected = i;
+        return sum;
+      }
+    }
+  }
+  if (SELECT) {
+    *selected = cend - 1;
+    return sum;
+  }
+  if (!isfinite(sum)) fail(env, 30);
+  return sum;
+}
+// calculate_chi_rpkt_cont<true> rpkt.cc:1021 with calculate_chi_ffheating rpkt.cc:697
+AHD void chi_rpkt_cont(const Env &env, double nu_cmf, Chi &x, int c, int64_t slot) {
+  if ((c == x.nonemptymgi) && (fabs((x.nu / nu_cmf) - 1.0) < 1e-4)) return;
+  const float nne = env.C.nne[c];
+  const float cnne = env.C.nne[c] * env.C.clumpfactor[c];
+  const float T_e = env.C.Te[c];
+  x.chi_freefree_heat = env.K.chi_ff_nnionpart[c] / pow3(nu_cmf) * cnne * (1 - exp(-HOVERKB * nu_cmf / T_e));
+  x.chi_escatter = SIGMA_T * nne;
+  x.chi_boundfree = chi_bf_gammacontr<false>(env, c, nu_cmf, slot, 0., nullptr);
+  x.nonemptymgi = c;
+  x.nu = nu_cmf;
+}
+// closest_transition rpkt.h:155
+AHD int closest_transition(const double *nu, int nlines, double nu_cmf, int next_trans) {
+  if (next_trans > (nlines - 1)) return -1;
+  if (nu_cmf < nu[nlines - 1]) return -1;
+  if (next_trans > 0) return next_trans;
+  if (nu_cmf >= nu[0]) return 0;
+  int lo = 0, len = nlines;
+  while (len > 0) {
+    const int half = len / 2;
+    if (nu[lo + half] > nu_cmf) { lo += half + 1; len -= half + 1; } else { len = half; }
+  }
+  return lo;
+}
+AHD double linedistance(double prop_time, double nu_cmf, double nu_trans) {  // rpkt.h:125
+  if (nu_cmf <= nu_trans) return 0.;
+  const double dnu = nu_cmf - nu_trans;
+  return CLIGHT * prop_time * dnu / nu_trans;
+}
+// get_possible_event rpkt.cc:106
+AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAState &ma, double tau_rnd, double abort_dist,
+                          double nu_cmf_abort, double dop, int *next_trans_out, bool *is_bb) {
+  const DevModel &M = env.M;
+  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  double px = p.px, py = p.py, pz = p.pz;
+  double nu_cmf = p.nu_cmf;
+  double e_cmf = p.e_cmf;
+  double prop_time = p.prop_time;
+  int next_trans = p.next_trans;
+  const double chi_cont = chi_total(x) * dop;
+  double tau = 0.;
+  double dist = 0.;
+  int nvisited = 0;
+  double result;
+  while (true) {
+    const int li = closest_transition(M.line_nu, M.nlines, nu_cmf, next_trans);
+    if (li < 0) {
+      const double tau_cont = chi_cont * (abort_dist - dist);
+      if (tau_rnd - tau > tau_cont) {
+        *next_trans_out = next_trans;
+        *is_bb = false;
+        result = DBLMAX;
+        break;
+      }
+      *next_trans_out = M.nlines + 1;
+      *is_bb = false;
+      result = dist + ((tau_rnd - tau) / chi_cont);
+      break;
+    }
+    nvisited++;
+    const double nu_trans = M.line_nu[li];
+    next_trans = li + 1;
+    const double ldist = linedistance(prop_time, nu_cmf, nu_trans);
+    const double tau_cont = chi_cont * ldist;
+    if (tau_rnd - tau > tau_cont) {
+      if (nu_trans < nu_cmf_abort) {
+        *next_trans_out = next_trans - 1;
+        *is_bb = false;
+        result = DBLMAX;
+        break;
+      }
+      // get_tau_sobolev<true> rpkt.cc:75
+      const LinePack lp = M.line_pack[li];
+      const double n_l = pops[lp.lower];
+      const double n_u = pops[lp.upper];
+      const double B_ul = lp.B_ul;
+      const double B_lu = lp.B_lu;
+      const double tau_line = dmax(((B_lu * n_l) - (B_ul * n_u)) * HCLIGHTOVERFOURPI * prop_time, 0.);
+      if ((tau_rnd - tau) <= (tau_cont + tau_line)) {
+        const int element = M.line_elementindex[li];
+        const int ion = M.line_ionindex[li];
+        ma.element = element;
+        ma.ion = ion;
+        ma.level = lp.upper - lstart(M, element, ion);
+        ma.activatingline = li;
+        *next_trans_out = next_trans;
+        *is_bb = true;
+        result = dist + ldist;
+        break;
+      }
+      dist += ldist;
+      tau += tau_cont + tau_line;
+      move_raw(px, py, pz, p.dx, p.dy, p.dz, prop_time, p.nu_rf, nu_cmf, p.e_rf, e_cmf, ldist);
+    } else {
+      *next_trans_out = next_trans - 1;
+      *is_bb = false;
+      result = dist + ((tau_rnd - tau) / chi_cont);
+      break;
+    }
+  }
+  ARTIS_STAT_ADD(env, ARTIS_STAT_X_LINES_VISITED, nvisited);
+  return result;
+}
+
+// emit_rpkt rpkt.cc:991
+AHD void emit_rpkt(const Env &env, Pkt &p, int64_t pi) {
+  p.type = ARTIS_TYPE_RPKT;
+  double dir_cmf[3];
+  rand_isotropic(p, dir_cmf);
+  const double t = -p.prop_time;
+  const double vel[3] = {p.px / t, p.py / t, p.pz / t};
+  double nd[3];
+  angle_ab(dir_cmf, vel, nd);
+  p.dx = nd[0];
+  p.dy = nd[1];
+  p.dz = nd[2];
+  set_restframe_from_cmf(p);
+#if ARTIS_OPT_POL_ON
+  p.stokes_u = 0.;
+  p.stokes_q = 0.;
+#endif
+  env.P.em_pos_x[pi] = p.px;
+  env.P.em_pos_y[pi] = p.py;
+  env.P.em_pos_z[pi] = p.pz;
+  env.P.em_time[pi] = (float)p.prop_time;
+}
+AHD void set_trueem_from_em(const Env &env, int64_t pi) {
+  env.P.trueem_pos_x[pi] = env.P.em_pos_x[pi];
+  env.P.trueem_pos_y[pi] = env.P.em_pos_y[pi];
+  env.P.trueem_pos_z[pi] = env.P.em_pos_z[pi];
+  env.P.trueem_time[pi] = env.P.em_time[pi];
+}
+
+// electron_scatter_rpkt rpkt.cc:331
+ANOINLINE void electron_scatter(Pkt &p) {
+  p.type = ARTIS_TYPE_RPKT;
+  const double vel[3] = {p.px / p.prop_time, p.py / p.prop_time, p.pz / p.prop_time};
+  const double dir[3] = {p.dx, p.dy, p.dz};
+  double old_cmf[3], q_i = 0., u_i = 0.;
+#if ARTIS_OPT_POL_ON
+  frame_transform(dir, p.stokes_q, p.stokes_u, vel, old_cmf, &q_i, &u_i);
+#else
+  angle_ab(dir, vel, old_cmf);
+#endif
+  double Mc = 0., phisc = 0.;
+#if ARTIS_OPT_DIPOLE
+  {
+    double pfn = 0., x = 1.;
+    while (x > pfn) {
+      Mc = (2. * rng_uniform_pos(p)) - 1.;
+      const double mu2 = pow2(Mc);
+      phisc = 2 * PI * rng_uniform(p);
+      pfn = (mu2 + 1) + ((mu2 - 1) * ((cos(2 * phisc) * q_i) + (sin(2 * phisc) * u_i)));
+      x = 2. * rng_uniform(p);
+    }
+  }
+#else
+  Mc = (2. * rng_uniform(p)) - 1.;
+  phisc = 2 * PI * rng_uniform(p);
+#endif
+  double new_cmf[3];
+  const double cos_tsc = Mc;
+  const double sin_tsc = sqrt(1. - pow2(Mc));
+  if (fabs(old_cmf[2]) < 0.99999) {
+    const double sin_polar = sqrt(1. - pow2(old_cmf[2]));
+    const double cf = sin_tsc / sin_polar;
+    const double cph = cos(phisc);
+    const double sph = sin(phisc);
+    new_cmf[0] = (cf * ((old_cmf[1] * sph) - (old_cmf[0] * old_cmf[2] * cph))) + (old_cmf[0] * cos_tsc);
+    new_cmf[1] = (cf * ((-old_cmf[0] * sph) - (old_cmf[1] * old_cmf[2] * cph))) + (old_cmf[1] * cos_tsc);
+    new_cmf[2] = (sin_tsc * cph * sin_polar) + (old_cmf[2] * cos_tsc);
+  } else {
+    new_cmf[0] = sin_tsc * cos(phisc);
+    new_cmf[1] = sin_tsc * sin(phisc);
+    new_cmf[2] = (old_cmf[2] > 0) ? cos_tsc : -cos_tsc;
+  }
+#if ARTIS_OPT_POL_ON
+  {
+    double nd[3], q, u;
+    scatter_polarisation_to_rf(old_cmf, new_cmf, q_i, u_i, vel, nd, &q, &u);
+    p.dx = nd[0]; p.dy = nd[1]; p.dz = nd[2];
+    p.stokes_q = q;
+    p.stokes_u = u;
+  }
+#else
+  {
+    const double nv[3] = {-vel[0], -vel[1], -vel[2]};
+    double nd[3];
+    angle_ab(new_cmf, nv, nd);
+    p.dx = nd[0]; p.dy = nd[1]; p.dz = nd[2];
+  }
+#endif
+  set_restframe_from_cmf(p);
+}
+
+// ---------------------------------------------------------------- Gauss-Kronrod 31 (gausskronrod.h)
+// Abscissae/weights of the 31-point Kronrod rule with its embedded 15-point Gauss rule: the
+// QUADPACK dqk31 constants, stored as in gausskronrod.h:38-90.
+struct GK31 {
+  double x[16];
+  double w[16];
+  double wg[8];
+};
+AHD GK31 gk31_tables() {
+  return GK31{
+      {0.00000000000000000000000000000000000e+00, 1.01142066918717499027074231447392339e-01,
+       2.01194093997434522300628303394596208e-01, 2.99180007153168812166780024266388963e-01,
+       3.94151347077563369897207370981045468e-01, 4.85081863640239680693655740232350613e-01,
+       5.70972172608538847537226737253910641e-01, 6.50996741297416970533735895313274693e-01,
+       7.24417731360170047416186054613938010e-01, 7.90418501442465932967649294817947347e-01,
+       8.48206583410427216200648320774216851e-01, 8.97264532344081900882509656454495883e-01,
+       9.37273392400705904307758947710209471e-01, 9.67739075679139134257347978784337225e-01,
+       9.87992518020485428489565718586612581e-01, 9.98002298693397060285172840152271209e-01},
+      {1.01330007014791549017374792767492547e-01, 1.00769845523875595044946662617569722e-01,
+       9.91735987217919593323931734846031311e-02, 9.66427269836236785051799076275893351e-02,
+       9.31265981708253212254868727473457186e-02, 8.85644430562117706472754436937743032e-02,
+       8.30805028231330210382892472861037896e-02, 7.68496807577203788944327774826590067e-02,
+       6.98541213187282587095200770991474758e-02, 6.20095678006706402851392309608029322e-02,
+       5.34815246909280872653431472394302968e-02, 4.45897513247648766082272993732796902e-02,
+       3.53463607913758462220379484783600481e-02, 2.54608473267153201868740010196533594e-02,
+       1.50079473293161225383747630758072681e-02, 5.37747987292334898779205143012764982e-03},
+      {2.02578241925561272880620199967519315e-01, 1.98431485327111576456118326443839325e-01,
+       1.86161000015562211026800561866422825e-01, 1.66269205816993933553200860481208811e-01,
+       1.39570677926154314447804794511028323e-01, 1.07159220467171935011869546685869303e-01,
+       7.03660474881081247092674164506673385e-02, 3.07532419961172683546283935772044177e-02}};
+}
+struct FbIntegrand {
+  const DevModel *M;
+  const float *xs;
+  double nu_edge;
+  float T_e;
+};
+AHD double fb_integrand(const FbIntegrand &f, double x) {  // alpha_sp_E_integrand ratecoeff.cc:84
+  const double nu = f.nu_edge + x;
+  const float sigma_bf = phixs_fromtable(*f.M, f.xs, f.nu_edge, nu);
+  return (2 / CLIGHTSQUARED) * sigma_bf * pow3(nu) / f.nu_edge * exp(-HOVERKB * x / f.T_e);
+}
+AHD double gk31_unit(const FbIntegrand &f, const GK31 &g, double scale, double mean, double *error) {  // gausskronrod.h:173
+  const double fc = fb_integrand(f, (scale * 0.) + mean);
+  double kr = fc * g.w[0];
+  double gr = 0.;
+  gr += fc * g.wg[0];
+  for (unsigned i = 2; i < 16; i += 2) {
+    const double fp = fb_integrand(f, (scale * g.x[i]) + mean);
+    const double fm = fb_integrand(f, (scale * -g.x[i]) + mean);
+    kr += (fp + fm) * g.w[i];
+    gr += (fp + fm) * g.wg[i / 2];
+  }
+  for (unsigned i = 1; i < 16; i += 2) {
+    const double fp = fb_integrand(f, (scale * g.x[i]) + mean);
+    const double fm = fb_integrand(f, (scale * -g.x[i]) + mean);
+    kr += (fp + fm) * g.w[i];
+  }
+  *error = dmax(fabs(kr - gr), fabs(kr * 2.220446049250313e-16 * 2));
+  return kr;
+}
+// recursive_adaptive_integrate<31> gausskronrod.h:208 as an explicit depth-first walk (no recursion on the GPU).
+// The reference's evaluation order is: node, then left subtree, then right subtree, with
+// estimate = left + right and error accumulated as error_left += error_right at each split.
+AHD double gk31_adaptive(const FbIntegrand &f, const GK31 &g, double tol, double a0, double b0, double *error_out) {
+  constexpr int MAXD = 16;
+  // per depth: interval of the pending RIGHT child, its abs_tol, and the partial sums of the parent
+  double ra[MAXD], rb[MAXD], rtol[MAXD], est_left[MAXD], err_left[MAXD];
+  int state[MAXD];  // 0: left child in progress, 1: right child in progress
+  int depth = 0;
+  double a = a0, b = b0, abs_tol = 0.;
+  unsigned levels = 15;
+  double ret_est = 0., ret_err = 0.;
+  while (true) {
+    // evaluate node (a, b, levels, abs_tol)
+    double err_local = 0.;
+    const double mean = (b + a) / 2;
+    const double scale = (b - a) / 2;
+    const double r1 = gk31_unit(f, g, scale, mean, &err_local);
+    const double estimate = scale * r1;
+    const double abs_tol1 = fabs(estimate * tol);
+    if (abs_tol == 0) abs_tol = abs_tol1;
+    if ((levels != 0) && (abs_tol1 < err_local) && (abs_tol < err_local)) {
+      const double mid = (a + b) / 2;
+      ra[depth] = mid;
+      rb[depth] = b;
+      rtol[depth] = abs_tol / 2;
+      state[depth] = 0;
+      depth++;
+      b = mid;
+      abs_tol = abs_tol / 2;
+      levels--;
+      continue;
+    }
+    ret_est = estimate;
+    ret_err = err_local;
+    // unwind
+    while (true) {
+      if (depth == 0) {
+        *error_out = ret_err;
+        return ret_est;
+      }
+      const int d = depth - 1;
+      if (state[d] == 0) {
+        est_left[d] = ret_est;
+        err_left[d] = ret_err;
+        state[d] = 1;
+        a = ra[d];
+        b = rb[d];
+        abs_tol = rtol[d];
+        levels = 15 - depth;
+        break;  // evaluate the right child
+      }
+      ret_est = est_left[d] + ret_est;
+      ret_err = err_left[d] + ret_err;
+      depth--;
+    }
+  }
+}
+AHD double integrator31(const FbIntegrand &f, const GK31 &g, double a, double b, double epsrel, double *abserr) {  // integrator.h:48
+  if (a == b) return 0.;
+  if (b < a) return -gk31_adaptive(f, g, epsrel, b, a, abserr);
+  return gk31_adaptive(f, g, epsrel, a, b, abserr);
+}
+// select_continuum_nu ratecoeff.cc:563
+ANOINLINE double select_continuum_nu(const Env &env, int element, int lowerion, int lower, int t, float T_e, Pkt &p) {
+  const DevModel &M = env.M;
+  const GK31 g = gk31_tables();
+  const int ul = lstart(M, element, lowerion) + lower;
+  const double E_threshold = phixs_threshold(M, element, lowerion, lower, t);
+  const double nu_threshold = (1. / HPLANCK) * E_threshold;
+  const double nu_max_phixs = nu_threshold * M.last_phixs_nuovernuedge;
+  const int npieces = M.NPHIXSPOINTS;
+  const FbIntegrand f = {&M, phixs_table(M, ul), nu_threshold, T_e};
+  const double zrand = 1. - rng_uniform(p);
+  const double nu_range = nu_max_phixs - nu_threshold;
+  const double deltanu = nu_range / npieces;
+  double error = 0.;
+  const double total = integrator31(f, g, 0., nu_range, 1e-3, &error);
+  if (!(total > 0.) || !isfinite(total)) return nu_threshold;
+  double tail_prev = total;
+  double tail = total;
+  int i = 1;
+  for (; i < npieces; i++) {
+    tail_prev = tail;
+    const double low = i * deltanu;
+    tail = integrator31(f, g, low, nu_range, 1e-3, &error);
+    if (zrand >= tail / total) break;
+  }
+  double nuoffset = 0.;
+  if (i < npieces) {
+    nuoffset = (tail != tail_prev) ? ((total * zrand) - tail_prev) / (tail - tail_prev) * deltanu : 0.;
+  } else if (tail > 0.) {
+    nuoffset = (tail - (total * zrand)) / tail * deltanu;
+  }
+  return nu_threshold + ((i - 1) * deltanu) + nuoffset;
+}
+
+// ---------------------------------------------------------------- do_macroatom macroatom.cc:360
+ANOINLINE void do_macroatom(const Env &env, Pkt &p, int64_t pi, const MAState &mastate) {
+  const DevModel &M = env.M;
+  const int c = M.propcell_nonemptymgi[p.cellindex];
+  const float T_e = env.C.Te[c];
+  const float cnne = clumpednne(env.C, c);
+  const double *cellrates = env.K.maprocessrates + ((int64_t)c * M.nlevels * MA_N);
+  const double *cellblock = env.K.matrans + ((int64_t)c * M.nmatransblock);
+  const int element = mastate.element;
+  int ion = mastate.ion;
+  int level = mastate.level;
+  const int activatingline = mastate.activatingline;
+  int njumps = 0;
+  bool end_packet = false;
+  while (!end_packet) {
+    njumps++;
+    const int ui = uion(M, element, ion);
+    const int start = M.ion_uniquelevelindexstart[ui];
+    const int ul = start + level;
+    const double e_cur = eps(M, ul);
+    const double *rates = cellrates + ((int64_t)ul * MA_N);
+    double cum[MA_N];
+    double total = 0.;
+    {
+      // std::partial_sum macroatom.cc:425
+      cum[0] = rates[0];
+      for (int i = 1; i < MA_N; i++) cum[i] = cum[i - 1] + rates[i];
+      total = cum[MA_N - 1];
+    }
+    if (!(total > 0.)) {
+      fail(env, 40);
+      break;
+    }
+    const double randomrate = rng_uniform(p) * total;
+    int action = 0;  // index_upperbound over 9 entries (sn3d.h:85)
+    while (action < MA_N && !(randomrate < cum[action])) action++;
+    if (action > MA_N - 1) action = MA_N - 1;
+    ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
+    if (action == ARTIS_MA_ACTION_RADDEEXC) {
+      // do_macroatom_raddeexcitation macroatom.cc:204
+      const double targetval = rng_uniform(p) * rates[ARTIS_MA_ACTION_RADDEEXC];
+      const int ndown = M.level_ndowntrans[ul];
+      const double *sums = cellblock + M.level_matransblock_start[ul];
+      const int dti = upper_bound_d(sums, ndown - 1, targetval);
+      const int startdown = M.level_alltrans_startdown[ul];
+      const int lineindex = M.alltrans_lineindex[startdown + dti];
+      if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
+      const int lul = start + M.alltrans_targetlevelindex[startdown + dti];
+      const double e_trans = e_cur - eps(M, lul);
+      const double oldnucmf = p.nu_cmf;
+      p.nu_cmf = e_trans / HPLANCK;
+      if (activatingline >= 0) ARTIS_STAT(env, (oldnucmf < p.nu_cmf) ? ARTIS_STAT_UPSCATTER : ARTIS_STAT_DOWNSCATTER);
+      ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_BB);
+      emit_rpkt(env, p, pi);
+      p.next_trans = lineindex + 1;
+      env.P.emissiontype[pi] = lineindex;
+      p.nscatterings = 0;
+      end_packet = true;
+    } else if (action == ARTIS_MA_ACTION_COLDEEXC || action == ARTIS_MA_ACTION_COLRECOMB) {
+      ARTIS_STAT(env, action == ARTIS_MA_ACTION_COLDEEXC ? ARTIS_STAT_MA_DEACTIVATION_COLLDEEXC : ARTIS_STAT_MA_DEACTIVATION_COLLRECOMB);
+      p.type = ARTIS_TYPE_KPKT;
+      end_packet = true;
+#if !ARTIS_OPT_DIRECT_COL_HEAT
+      ARTIS_EST_ADD(&env.E.colheatingestimator[c], p.e_cmf);
+#endif
+    } else if (action == ARTIS_MA_ACTION_INTERNALDOWNSAME) {
+      const double targetval = rng_uniform(p) * rates[ARTIS_MA_ACTION_INTERNALDOWNSAME];
+      const int ndown = M.level_ndowntrans[ul];
+      const double *sums = cellblock + M.level_matransblock_start[ul] + ndown;
+      const int dti = upper_bound_d(sums, ndown - 1, targetval);
+      level = M.alltrans_targetlevelindex[M.level_alltrans_startdown[ul] + dti];
+    } else if (action == ARTIS_MA_ACTION_RADRECOMB) {
+      // do_macroatom_radrecomb macroatom.cc:248
+      const double targetval = rng_uniform(p) * rates[ARTIS_MA_ACTION_RADRECOMB];
+      double rate = 0;
+      const int nl = M.ion_nlevels_ionising[ui - 1];
+      const int ls = M.ion_uniquelevelindexstart[ui - 1];
+      int lowerlevel = -1, sel_t = -1;
+      for (int l = 0; l < nl; l++) {
+        const int t = find_phixstarget(M, ls + l, level);
+        if (t < 0) continue;
+        const double e_trans = e_cur - eps(M, ls + l);
+        const double R = rad_recomb(M, T_e, cnne, element, ion, l, t);
+        rate += R * e_trans;
+        if (targetval < rate) {
+          lowerlevel = l;
+          sel_t = t;
+          break;
+        }
+      }
+      if (lowerlevel < 0) {
+        fail(env, 41);
+        break;
+      }
+      p.nu_cmf = select_continuum_nu(env, element, ion - 1, lowerlevel, sel_t, T_e, p);
+      ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_FB);
+      emit_rpkt(env, p, pi);
+      p.next_trans = -1;
+      env.P.emissiontype[pi] = emtype_continuum(M, ls + lowerlevel, sel_t);
+      p.nscatterings = 0;
+      level = lowerlevel;
+      ion -= 1;
+      end_packet = true;
+    } else if (action == ARTIS_MA_ACTION_INTERNALDOWNLOWER) {
+      ARTIS_STAT(env, ARTIS_STAT_MA_INTERNALDOWNLOWER);
+      const double targetrate = rng_uniform(p) * rates[ARTIS_MA_ACTION_INTERNALDOWNLOWER];
+      double rate = 0.;
+      const int nl = M.ion_nlevels_ionising[ui - 1];
+      const int ls = M.ion_uniquelevelindexstart[ui - 1];
+      int lower = -1;
+      for (int l = 0; l < nl; l++) {
+        const int t = find_phixstarget(M, ls + l, level);
+        if (t < 0) continue;
+        const double e_target = eps(M, ls + l);
+        const double e_trans = e_cur - e_target;
+        const double R = rad_recomb(M, T_e, cnne, element, ion, l, t);
+        const double Cc = col_recomb(M, T_e, cnne, element, ion, l, t, e_trans);
+        rate += (R + Cc) * e_target;
+        if (rate > targetrate) {
+          lower = l;
+          break;
+        }
+      }
+      if (lower < 0) {
+        fail(env, 42);
+        break;
+      }
+      ion--;
+      level = lower;
+    } else if (action == ARTIS_MA_ACTION_INTERNALUPSAME) {
+      const int ndown = M.level_ndowntrans[ul];
+      const int nup = M.level_nuptrans[ul];
+      const double *sums = cellblock + M.level_matransblock_start[ul] + (2 * ndown);
+      const double targetval = rng_uniform(p) * rates[ARTIS_MA_ACTION_INTERNALUPSAME];
+      const int uti = upper_bound_d(sums, nup - 1, targetval);
+      level = M.alltrans_targetlevelindex[M.level_alltrans_startdown[ul] + ndown + uti];
+    } else if (action == ARTIS_MA_ACTION_INTERNALUPHIGHER) {
+      ARTIS_STAT(env, ARTIS_STAT_MA_INTERNALUPHIGHER);
+      // do_macroatom_ionisation macroatom.cc:298
+      const double targetrate = rng_uniform(p) * rates[ARTIS_MA_ACTION_INTERNALUPHIGHER];
+      double rate = 0.;
+      const int nt = M.level_nphixstargets[ul];
+      const double *cpc = env.K.corrphotoioncoeff + ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
+      int newlevel = -1;
+      for (int t = 0; t < nt; t++) {
+        const double e_trans = phixs_threshold(M, element, ion, level, t);
+        const double R = cpc[t];
+        const double Cc = col_ion(M, T_e, cnne, element, ion, level, t, e_trans);
+        rate += (R + Cc) * e_cur;
+        if (rate > targetrate) {
+          newlevel = phixs_upperlevel(M, ul, t);
+          break;
+        }
+      }
+      if (newlevel < 0) {
+        fail(env, 43);
+        break;
+      }
+      level = newlevel;
+      ion += 1;
+    } else {
+      fail(env, 44);  // MA_ACTION_INTERNALUPHIGHERNT needs NT_ON
+      break;
+    }
+  }
+  ARTIS_STAT_ADD(env, ARTIS_STAT_X_MA_JUMPS, njumps);
+  if (p.type == ARTIS_TYPE_RPKT) {
+    if (env.P.trueemissiontype[pi] == ARTIS_EMTYPE_NOTSET) {
+      env.P.trueemissiontype[pi] = env.P.emissiontype[pi];
+      set_trueem_from_em(env, pi);
+    }
+  } else {
+    env.P.trueemissiontype[pi] = ARTIS_EMTYPE_NOTSET;
+  }
+}
+
+// rpkt_event_continuum rpkt.cc:422
+AHD void rpkt_event_continuum(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) {
+  const DevModel &M = env.M;
+  const double nu = p.nu_cmf;
+  const double dop = doppler(p);
+  const double chi_cont = chi_total(x) * dop;
+  const double chi_es = x.chi_escatter * dop;
+  const double chi_ff = x.chi_freefree_heat * dop;
+  const double chi_bf = x.chi_boundfree * dop;
+  const double chi_rnd = rng_uniform(p) * chi_cont;
+  if (chi_rnd < chi_es) {
+    p.nscatterings++;
+    ARTIS_STAT(env, ARTIS_STAT_ELECTRON_SCATTERINGS);
+    electron_scatter(p);
+    env.P.em_pos_x[pi] = p.px;
+    env.P.em_pos_y[pi] = p.py;
+    env.P.em_pos_z[pi] = p.pz;
+    env.P.em_time[pi] = (float)p.prop_time;
+  } else if (chi_rnd < chi_es + chi_ff) {
+    ARTIS_STAT(env, ARTIS_STAT_K_FROM_FF);
+    p.type = ARTIS_TYPE_KPKT;
+    env.P.absorptiontype[pi] = ARTIS_ABSTYPE_FREEFREE;
+  } else if (chi_rnd < chi_es + chi_ff + chi_bf) {
+    env.P.absorptiontype[pi] = ARTIS_ABSTYPE_BOUNDFREE;
+    const double chi_bf_rand = rng_uniform(p) * x.chi_boundfree;
+    int ci = -1;
+    chi_bf_gammacontr<true>(env, x.nonemptymgi, x.nu, slot, chi_bf_rand, &ci);
+    const double nu_edge = M.allcont_nu_edge[ci];
+    const int element = M.allcont_element[ci];
+    const int ion = M.allcont_ion[ci];
+    const int level = M.allcont_level[ci];
+    const int t = M.allcont_phixstargetindex[ci];
+    if (rng_uniform(p) < nu_edge / nu) {
+      ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_BF);
+      const MAState ma = {element, ion + 1, phixs_upperlevel(M, lstart(M, element, ion) + level, t), -99};
+      do_macroatom(env, p, pi, ma);
+    } else {
+      ARTIS_STAT(env, ARTIS_STAT_K_FROM_BF);
+      p.type = ARTIS_TYPE_KPKT;
+    }
+  } else {
+    fail(env, 50);
+  }
+}
+
+// update_estimators rpkt.cc:502 + radfield::update_estimators radfield.cc:745
+AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double distance, int c, const Chi &x, bool thick, int64_t slot) {
+  const double de = distance * e_cmf;
+  if (de != 0) {
+    ARTIS_EST_ADD(&env.E.J[c], de);
+    ARTIS_EST_ADD(&env.E.nuJ[c], de * nu_cmf);
+  }
+  if (thick) return;
+  ARTIS_EST_ADD(&env.E.ffheatingestimator[c], de * x.chi_freefree_heat);
+#if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
+  const int nbfg = env.M.nbfcontinua_ground;
+  for (int i = 0; i < nbfg; i++) {
+    const double nu_edge = env.M.groundcont_nu_edge[i];
+    if (nu_cmf <= nu_edge) return;
+    const int64_t k = ((int64_t)c * nbfg) + i;
+    const double contr = env.gamma_ws[(i * env.ws_stride) + slot];
+#if ARTIS_OPT_USE_LUT_PHOTOION
+    ARTIS_EST_ADD(&env.E.gammaestimator[k], contr * (de / nu_cmf));
+#endif
+#if ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
+    ARTIS_EST_ADD(&env.E.bfheatingestimator[k], contr * de * (1. - (nu_edge / nu_cmf)));
+#endif
+  }
+#endif
+}
+
+// do_rpkt_step rpkt.cc:542
+AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) {
+  const DevModel &M = env.M;
+  const double t2 = env.S.ts_end;
+  ARTIS_STAT(env, ARTIS_STAT_X_RPKT_STEPS);
+  const int c = M.propcell_nonemptymgi[p.cellindex];
+  MAState ma = {-1, -1, -1, -99};
+  const double tau_rnd = -log((double)rng_uniform_pos(p));
+  int next_cell = -1;
+  const double bdist = boundary_distance(env, p, &next_cell);
+  if (bdist == 0) {
+    change_cell_or_escape(env, p, pi, next_cell);
+    if (p.type != ARTIS_TYPE_RPKT) return false;
+    const int nc = M.propcell_nonemptymgi[p.cellindex];
+    return (nc < 0 || nc == c);
+  }
+  const double tdist = (t2 - p.prop_time) * CLIGHT_PROP;
+  if (!(tdist >= 0)) fail(env, 60);
+  const double abort_dist = dmin(tdist, bdist);
+  double edist = -1;
+  bool is_bb = true;
+  const bool thick = (c >= 0) && (env.C.thick[c] == ARTIS_CELL_THICK);
+  if (c < 0) {
+    edist = DBLMAX;
+    p.next_trans = -1;
+  } else if (thick) {
+    const double chi_grey = env.C.kappagrey[c] * env.C.rho[c] * doppler(p);
+    edist = tau_rnd / chi_grey;
+    p.next_trans = -1;
+  } else {
+    chi_rpkt_cont(env, p.nu_cmf, x, c, slot);
+    // get_nu_cmf_abort rpkt.cc:54
+    const double half = abort_dist / 2.;
+    const double abort_time = p.prop_time + (half / CLIGHT_PROP) + (half / CLIGHT_PROP);
+    const double nu_cmf_abort = p.nu_rf * doppler_at(p.px + (p.dx * half) + (p.dx * half), p.py + (p.dy * half) + (p.dy * half),
+                                                     p.pz + (p.dz * half) + (p.dz * half), p.dx, p.dy, p.dz, abort_time);
+    const double dop = doppler(p);
+    int nt = p.next_trans;
+    edist = possible_event(env, c, p, x, ma, tau_rnd, abort_dist, nu_cmf_abort, dop, &nt, &is_bb);
+    p.next_trans = nt;
+  }
+  if (!(edist >= 0)) fail(env, 61);
+
+  if ((edist < bdist) && (edist <= tdist)) {
+    move_pkt(p, edist / 2.);
+    update_estimators(env, p.e_cmf, p.nu_cmf, edist, c, x, thick, slot);
+    move_pkt(p, edist / 2.);
+    ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
+    if (thick) {
+      p.nscatterings++;
+      ARTIS_STAT(env, ARTIS_STAT_ELECTRON_SCATTERINGS);
+      emit_rpkt(env, p, pi);
+    } else if (!is_bb) {
+      rpkt_event_continuum(env, p, pi, x, slot);
+    } else {
+      ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_BB);
+      env.P.absorptiontype[pi] = ma.activatingline;
+      env.P.absorptionfreq[pi] = p.nu_rf;
+      do_macroatom(env, p, pi, ma);
+    }
+    return (p.type == ARTIS_TYPE_RPKT);
+  }
+  if ((bdist <= tdist) && (bdist <= edist)) {
+    move_pkt(p, bdist / 2.);
+    if (c >= 0) update_estimators(env, p.e_cmf, p.nu_cmf, bdist, c, x, thick, slot);
+    move_pkt(p, bdist / 2.);
+    if (next_cell != p.cellindex) {
+      change_cell_or_escape(env, p, pi, next_cell);
+      if (next_cell < 0) return false;
+      const int nc = M.propcell_nonemptymgi[p.cellindex];
+      return ((nc < 0) || (nc == c));
+    }
+    return true;
+  }
+  if ((tdist < bdist) && (tdist <= edist)) {
+    move_pkt(p, tdist / 2.);
+    if (c >= 0) update_estimators(env, p.e_cmf, p.nu_cmf, tdist, c, x, thick, slot);
+    move_pkt(p, tdist / 2.);
+    p.prop_time = t2;
+    return false;
+  }
+  fail(env, 62);
+  return false;
+}
+
+// ---------------------------------------------------------------- kpkt.cc
+AHD double sample_planck_montecarlo(double T, Pkt &p) {  // kpkt.cc:266
+  const double nu_peak = 5.879e10 * T;
+  const double B_peak = planck(nu_peak, T);
+  while (true) {
+    const double nu = ARTIS_OPT_NU_MIN_R + (rng_uniform(p) * (ARTIS_OPT_NU_MAX_R - ARTIS_OPT_NU_MIN_R));
+    if (rng_uniform(p) * B_peak <= planck(nu, T)) return nu;
+  }
+}
+AHD void thermal_emission_flags(const Env &env, Pkt &p, int64_t pi, int emtype) {
+  p.next_trans = -1;
+  env.P.emissiontype[pi] = emtype;
+  env.P.trueemissiontype[pi] = emtype;
+  set_trueem_from_em(env, pi);
+  p.nscatterings = 0;
+}
+AHD void do_kpkt_blackbody(const Env &env, Pkt &p, int64_t pi) {  // kpkt.cc:399
+  ARTIS_STAT(env, ARTIS_STAT_X_KPKT_STEPS);
+  const int c = env.M.propcell_nonemptymgi[p.cellindex];
+  p.nu_cmf = sample_planck_montecarlo(env.C.Te[c], p);
+  emit_rpkt(env, p, pi);
+  ARTIS_STAT(env, ARTIS_STAT_K_TO_R_BB);
+  ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
+  thermal_emission_flags(env, p, pi, ARTIS_EMTYPE_FREEFREE);
+}
+// do_kpkt kpkt.cc:425
+AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
+  const DevModel &M = env.M;
+  const double t2 = env.S.ts_end;
+  ARTIS_STAT(env, ARTIS_STAT_X_KPKT_STEPS);
+  const double deltat = ARTIS_KPKTDIFFUSION_TIMESTEP_FRACTION * env.S.width;
+  const double t_current = dmin(p.prop_time + deltat, t2);
+  const double sf = t_current / p.prop_time;
+  p.px = p.px * sf;
+  p.py = p.py * sf;
+  p.pz = p.pz * sf;
+  p.e_cmf *= p.prop_time / t_current;
+  p.prop_time = t_current;
+  if (t_current >= t2) return;
+  ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
+  const int c = M.propcell_nonemptymgi[p.cellindex];
+  const double *ioncontribs = env.K.ion_cooling_contribs + ((int64_t)c * M.nions);
+  const double rndcool_ion = rng_uniform(p) * ioncontribs[M.nions - 1];
+  const int ui = upper_bound_d(ioncontribs, M.nions, rndcool_ion);
+  if (!(ui < M.nions)) {
+    fail(env, 70);
+    return;
+  }
+  const int element = M.ion_element[ui];
+  const int ion = ui - M.elem_uniqueionindexstart[element];
+  const int ionstart = M.ion_coolingoffset[ui];
+  const int nterms = M.ion_ncoolingterms[ui];
+  const double *cellcontrib = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
+  const double *contribs = cellcontrib + ionstart;
+  const double rnd_process = rng_uniform(p) * contribs[nterms - 1];
+  const int ionoffset = upper_bound_d(contribs, nterms, rnd_process);
+  if (!(ionoffset < nterms)) {
+    fail(env, 71);
+    return;
+  }
+  const int i = ionstart + ionoffset;
+  const int ctype = M.coolinglist_type[i];
+  const float T_e = env.C.Te[c];
+  if (ctype == ARTIS_COOLING_FREEFREE) {
+    p.nu_cmf = -KB * T_e / HPLANCK * log((double)rng_uniform_pos(p));
+    emit_rpkt(env, p, pi);
+    ARTIS_STAT(env, ARTIS_STAT_K_TO_R_FF);
+    thermal_emission_flags(env, p, pi, ARTIS_EMTYPE_FREEFREE);
+  } else if (ctype == ARTIS_COOLING_FREEBOUND) {
+    const int lowerlevel = M.coolinglist_level[i];
+    const int t = M.coolinglist_phixstargetindex[i];
+    p.nu_cmf = select_continuum_nu(env, element, ion, lowerlevel, t, T_e, p);
+    emit_rpkt(env, p, pi);
+    ARTIS_STAT(env, ARTIS_STAT_K_TO_R_FB);
+    thermal_emission_flags(env, p, pi, emtype_continuum(M, lstart(M, element, ion) + lowerlevel, t));
+  } else if (ctype == ARTIS_COOLING_COLLEXC) {
+    const float cnne = clumpednne(env.C, c);
+    const double contrib_low = (i > ionstart) ? cellcontrib[i - 1] : 0.;
+    double contrib = contrib_low;
+    const int start = M.ion_uniquelevelindexstart[ui];
+    const int ul = start + M.coolinglist_level[i];
+    const double e_cur = eps(M, ul);
+    const double nnlevel = env.K.levelpops[((int64_t)c * M.nlevels) + ul];
+    const double g_cur = statw(M, ul);
+    int upper = -1;
+    const int startup = M.level_alltrans_startdown[ul] + M.level_ndowntrans[ul];
+    const int nup = M.level_nuptrans[ul];
+    for (int ati = startup; ati < (startup + nup); ati++) {
+      const int tmpupper = M.alltrans_targetlevelindex[ati];
+      const int uul = start + tmpupper;
+      const double e_trans = eps(M, uul) - e_cur;
+      const double Cc = nnlevel * col_exc(M, T_e, cnne, e_trans, statw(M, uul), g_cur, ati) * e_trans;
+      contrib += Cc;
+      if (contrib > rnd_process) {
+        upper = tmpupper;
+        break;
+      }
+    }
+    if (!(contrib > rnd_process)) {
+      fail(env, 72);
+      return;
+    }
+    ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_COLLEXC);
+    ARTIS_STAT(env, ARTIS_STAT_K_TO_MA_COLLEXC);
+    env.P.trueemissiontype[pi] = ARTIS_EMTYPE_NOTSET;
+    env.P.trueem_pos_x[pi] = NAN;
+    env.P.trueem_pos_y[pi] = NAN;
+    env.P.trueem_pos_z[pi] = NAN;
+    const MAState ma = {element, ion, upper, -99};
+    do_macroatom(env, p, pi, ma);
+  } else if (ctype == ARTIS_COOLING_COLLION) {
+    const int upper = phixs_upperlevel(M, lstart(M, element, ion) + M.coolinglist_level[i], M.coolinglist_phixstargetindex[i]);
+    ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_COLLION);
+    ARTIS_STAT(env, ARTIS_STAT_K_TO_MA_COLLION);
+    env.P.trueemissiontype[pi] = ARTIS_EMTYPE_NOTSET;
+    env.P.trueem_pos_x[pi] = NAN;
+    env.P.trueem_pos_y[pi] = NAN;
+    env.P.trueem_pos_z[pi] = NAN;
+    const MAState ma = {element, ion + 1, upper, -99};
+    do_macroatom(env, p, pi, ma);
+  } else {
+    fail(env, 73);
+  }
+}
+
+// ---------------------------------------------------------------- packet load/store and the per-thread driver
+AHD bool type_handled(int type) { return type == ARTIS_TYPE_RPKT || type == ARTIS_TYPE_KPKT || type == ARTIS_TYPE_PRE_KPKT; }
+AHD bool pkt_active(const Pkt &p, double ts_end) { return type_handled(p.type) && p.prop_time < ts_end; }  // update_packets.cc:321
+
+AHD void pkt_load(const PktSoA &P, int64_t i, Pkt &p) {
+  p.s0 = P.rng[i];
+  p.s1 = P.rng[P.n + i];
+  p.s2 = P.rng[(2 * P.n) + i];
+  p.s3 = P.rng[(3 * P.n) + i];
+  p.prop_time = P.prop_time[i];
+  p.px = P.pos_x[i]; p.py = P.pos_y[i]; p.pz = P.pos_z[i];
+  p.dx = P.dir_x[i]; p.dy = P.dir_y[i]; p.dz = P.dir_z[i];
+  p.nu_cmf = P.nu_cmf[i]; p.e_cmf = P.e_cmf[i]; p.nu_rf = P.nu_rf[i]; p.e_rf = P.e_rf[i];
+  p.stokes_q = P.stokes_q[i]; p.stokes_u = P.stokes_u[i];
+  p.next_trans = P.next_trans[i]; p.nscatterings = P.nscatterings[i]; p.type = P.type[i]; p.cellindex = P.cellindex[i];
+}
+AHD void pkt_store(const PktSoA &P, int64_t i, const Pkt &p) {
+  P.rng[i] = p.s0;
+  P.rng[P.n + i] = p.s1;
+  P.rng[(2 * P.n) + i] = p.s2;
+  P.rng[(3 * P.n) + i] = p.s3;
+  P.prop_time[i] = p.prop_time;
+  P.pos_x[i] = p.px; P.pos_y[i] = p.py; P.pos_z[i] = p.pz;
+  P.dir_x[i] = p.dx; P.dir_y[i] = p.dy; P.dir_z[i] = p.dz;
+  P.nu_cmf[i] = p.nu_cmf; P.e_cmf[i] = p.e_cmf; P.nu_rf[i] = p.nu_rf; P.e_rf[i] = p.e_rf;
+  P.stokes_q[i] = p.stokes_q; P.stokes_u[i] = p.stokes_u;
+  P.next_trans[i] = p.next_trans; P.nscatterings[i] = p.nscatterings; P.type[i] = p.type; P.cellindex[i] = p.cellindex;
+}
+
+// Advance one packet by at most `budget` calls of do_packet() (update_packets.cc:257). One call is one
+// do_rpkt() (rpkt.cc:983: steps until the packet leaves its model cell, changes type, escapes or reaches
+// the end of the timestep), one do_kpkt() or one do_kpkt_blackbody(). The ContinuumOpacity of the packet
+// is reset on entry of do_rpkt() (see the oracle's header, note 2), so a launch boundary can fall between
+// any two calls without changing the history. Returns true when the packet still needs updating.
+AHD bool advance_packet(const Env &env, Pkt &p, int64_t pi, int64_t slot, int budget) {
+  const double ts_end = env.S.ts_end;
+  int calls = 0;
+  while (calls < budget && pkt_active(p, ts_end)) {
+    calls++;
+    if (p.type == ARTIS_TYPE_RPKT) {
+      Chi x = {-1., 0., 0., 0., -1};
+      while (do_rpkt_step(env, p, pi, x, slot)) {
+      }
+    } else if (p.type == ARTIS_TYPE_PRE_KPKT) {
+      do_kpkt_blackbody(env, p, pi);
+    } else {
+      const int c = env.M.propcell_nonemptymgi[p.cellindex];
+      if (env.C.thick[c] == ARTIS_CELL_THICK) {
+        do_kpkt_blackbody(env, p, pi);
+      } else {
+        do_kpkt(env, p, pi);
+      }
+    }
+  }
+  return pkt_active(p, ts_end);
+}
+
+// AoS (reference struct Packet) <-> SoA, one packet
+AHD void aos_to_soa(const artis_packet &a, const PktSoA &P, int64_t i) {
+  for (int k = 0; k < 4; k++) P.rng[(k * P.n) + i] = a.rngstate[k];
+  P.prop_time[i] = a.prop_time;
+  P.pos_x[i] = a.pos[0]; P.pos_y[i] = a.pos[1]; P.pos_z[i] = a.pos[2];
+  P.dir_x[i] = a.dir[0]; P.dir_y[i] = a.dir[1]; P.dir_z[i] = a.dir[2];
+  P.nu_cmf[i] = a.nu_cmf; P.e_cmf[i] = a.e_cmf; P.nu_rf[i] = a.nu_rf; P.e_rf[i] = a.e_rf;
+  P.stokes_q[i] = a.stokes_q; P.stokes_u[i] = a.stokes_u;
+  P.next_trans[i] = a.next_trans; P.nscatterings[i] = a.nscatterings; P.type[i] = a.type; P.cellindex[i] = a.cellindex;
+  P.emissiontype[i] = a.emissiontype; P.absorptiontype[i] = a.absorptiontype; P.trueemissiontype[i] = a.trueemissiontype;
+  P.escape_type[i] = a.escape_type;
+  P.em_pos_x[i] = a.em_pos[0]; P.em_pos_y[i] = a.em_pos[1]; P.em_pos_z[i] = a.em_pos[2];
+  P.trueem_pos_x[i] = a.trueem_pos[0]; P.trueem_pos_y[i] = a.trueem_pos[1]; P.trueem_pos_z[i] = a.trueem_pos[2];
+  P.absorptionfreq[i] = a.absorptionfreq;
+  P.em_time[i] = a.em_time; P.trueem_time[i] = a.trueem_time; P.escape_time[i] = a.escape_time;
+}
+AHD void soa_to_aos(const PktSoA &P, int64_t i, artis_packet &a) {
+  for (int k = 0; k < 4; k++) a.rngstate[k] = P.rng[(k * P.n) + i];
+  a.prop_time = P.prop_time[i];
+  a.pos[0] = P.pos_x[i]; a.pos[1] = P.pos_y[i]; a.pos[2] = P.pos_z[i];
+  a.dir[0] = P.dir_x[i]; a.dir[1] = P.dir_y[i]; a.dir[2] = P.dir_z[i];
+  a.nu_cmf = P.nu_cmf[i]; a.e_cmf = P.e_cmf[i]; a.nu_rf = P.nu_rf[i]; a.e_rf = P.e_rf[i];
+  a.stokes_q = P.stokes_q[i]; a.stokes_u = P.stokes_u[i];
+  a.next_trans = P.next_trans[i]; a.nscatterings = P.nscatterings[i]; a.type = P.type[i]; a.cellindex = P.cellindex[i];
+  a.emissiontype = P.emissiontype[i]; a.absorptiontype = P.absorptiontype[i]; a.trueemissiontype = P.trueemissiontype[i];
+  a.escape_type = P.escape_type[i];
+  a.em_pos[0] = P.em_pos_x[i]; a.em_pos[1] = P.em_pos_y[i]; a.em_pos[2] = P.em_pos_z[i];
+  a.trueem_pos[0] = P.trueem_pos_x[i]; a.trueem_pos[1] = P.trueem_pos_y[i]; a.trueem_pos[2] = P.trueem_pos_z[i];
+  a.absorptionfreq = P.absorptionfreq[i];
+  a.em_time = P.em_time[i]; a.trueem_time = P.trueem_time[i]; a.escape_time = P.escape_time[i];
+}
+
+}  // namespace artis

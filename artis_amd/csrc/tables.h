@@ -1,0 +1,120 @@
+// tables.h -- plain-old-data views of everything the packet kernels read or write.
+//
+// One struct per lifetime:
+//   DevModel  static atomic data + grid (uploaded once per run)
+//   DevCells  per-timestep cell state (the reference's update_grid() output)
+//   DevCache  per-timestep cell cache (the reference's globals::cellcache, multi-slot form,
+//             globals.h:283 / update_packets.cc:397), one row per non-empty cell
+//   PktSoA    the packet population as structure-of-arrays in HBM
+//   DevEst    estimator accumulators
+// The same structs are used by the host-emulation test build (tests/hostemu), where the
+// pointers are host pointers.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/artis_amd.h"
+#include "../../include/artis_options.h"
+
+namespace artis {
+
+// 16-byte record walked by get_possible_event(): the two level indices and the two Einstein B
+// coefficients of a line (globals::linelist uniquelevelindex_lower/upper, B_ul, B_lu globals.h:234-237)
+struct alignas(16) LinePack {
+  int32_t lower;
+  int32_t upper;
+  float B_ul;
+  float B_lu;
+};
+
+struct DevModel {
+  int32_t nelements, nions, nlevels, nlines, nalltrans, nphixstargets_total, nphixslevels, nbfcontinua, nbfcontinua_ground,
+      ncoolingterms, nmatransblock, NPHIXSPOINTS;
+  int32_t nkeepwords;  // ceil(nbfcontinua/64) (get_allcont_keepwordcount globals.h:401)
+  double NPHIXSNUINCREMENT;
+  double last_phixs_nuovernuedge;  // input.cc:310
+  double T_step_log;               // ratecoeff.cc:39
+  const double *temperature_grid;  // [TABLESIZE+1] ratecoeff.cc:41
+
+  const int32_t *elem_nions, *elem_uniqueionindexstart, *elem_lowest_ionstage;
+  const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
+      *ion_coolingoffset, *ion_ncoolingterms;
+  const double *level_epsilon;
+  const float *level_statweight;
+  const int32_t *level_alltrans_startdown, *level_ndowntrans, *level_nuptrans, *level_closestgroundlevelcont, *level_phixsstart,
+      *level_nphixstargets, *level_phixstargetstart, *level_bflist_start, *level_matransblock_start;
+  const int32_t *level_ion;  // derived: uniqueionindex of each level
+  const int32_t *alltrans_lineindex, *alltrans_targetlevelindex;
+  const float *alltrans_einstein_A, *alltrans_coll_str, *alltrans_osc_strength;
+  const uint8_t *alltrans_forbidden;
+  const double *line_nu;
+  const LinePack *line_pack;
+  const int32_t *line_elementindex, *line_ionindex;
+  const float *allphixs;
+  const int32_t *allphixstargets_levelindex;
+  const double *allphixstargets_probability;
+  const double *allcont_nu_edge;
+  const int32_t *allcont_element, *allcont_ion, *allcont_level, *allcont_phixstargetindex, *allcont_upperlevel,
+      *allcont_uniquelevelindex, *allcont_groundcontestimindex;
+  const double *allcont_probability;
+  const double *groundcont_nu_edge;
+  const double *spontrecombcoeffs, *corrphotoioncoeffs, *bfcooling_coeffs;
+  const uint8_t *coolinglist_type;
+  const int32_t *coolinglist_level, *coolinglist_phixstargetindex;
+
+  int32_t gridtype, ncoordgrid[3], coordstride[3], ngrid, npts_nonempty;
+  double tmin, vmax, rmax;
+  const double *coord_pos_min_tmin[3];
+  const int32_t *propcell_nonemptymgi;
+};
+
+struct DevCells {
+  const float *rho, *Te, *TJ, *TR, *W, *nne, *nnetot, *kappagrey, *clumpfactor;
+  const int32_t *thick;
+  const float *ion_groundlevelpops, *ion_partfuncts, *elem_massfracs;
+  const double *corrphotoionrenorm;
+};
+
+struct DevCache {
+  double *levelpops;             // [cell][nlevels]
+  double *maprocessrates;        // [cell][nlevels*9]
+  double *matrans;               // [cell][nmatransblock]
+  double *allcont_nnlevel;       // [cell][nbfcontinua]
+  double *allcont_departure;     // [cell][nbfcontinua]
+  double *allcont_edgepart;      // [cell][nbfcontinua]
+  uint64_t *allcont_keepbits;    // [cell][nkeepwords]
+  double *corrphotoioncoeff;     // [cell][nphixstargets_total]
+  double *cooling_contrib;       // [cell][ncoolingterms]
+  double *ion_cooling_contribs;  // [cell][nions]
+  double *ion_cooling_C;         // [cell][nions] per-ion totals before the prefix sum
+  double *chi_ff_nnionpart;      // [cell]
+};
+
+struct DevStep {
+  int32_t nts;
+  double start, width, mid, max_path_step, ts_end;
+};
+
+struct DevEst {
+  double *J, *nuJ, *ffheatingestimator, *colheatingestimator, *gammaestimator, *bfheatingestimator;
+};
+
+// Packet population, structure-of-arrays (one array per field of the reference's struct Packet,
+// packet.h:117-169, minus the fields this path never touches: tdecay, number, pellet_*).
+// "hot" fields are loaded into registers for the whole life of a thread; "cold" fields are
+// written through to HBM at the (rare) events that change them.
+struct PktSoA {
+  // hot
+  uint32_t *rng;  // [4][n] Xoshiro128PP words, word-major so that lanes coalesce
+  double *prop_time, *pos_x, *pos_y, *pos_z, *dir_x, *dir_y, *dir_z, *nu_cmf, *e_cmf, *nu_rf, *e_rf, *stokes_q, *stokes_u;
+  int32_t *next_trans, *nscatterings, *type, *cellindex;
+  // cold
+  int32_t *emissiontype, *absorptiontype, *trueemissiontype, *escape_type;
+  double *em_pos_x, *em_pos_y, *em_pos_z, *trueem_pos_x, *trueem_pos_y, *trueem_pos_z, *absorptionfreq;
+  float *em_time, *trueem_time, *escape_time;
+  int64_t n;
+};
+// number of 8-byte and 4-byte columns above (used to carve one allocation)
+constexpr int PKT_NCOL64 = 13 + 7;
+constexpr int PKT_NCOL32 = 4 /*rng*/ + 4 + 4 + 3;
+
+}  // namespace artis

@@ -307,7 +307,8 @@ def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fr
                     spont[ci] = 4 * np.pi * saha * prob * np.sum((2 / CLIGHT**2) * sig * nu**2 * ex, axis=1) * dx
                     bfcool[ci] = 4 * np.pi * saha * prob * np.sum(sig * x * (2 * H / CLIGHT**2) * nu**2 * ex, axis=1) * dx
                     hnkt = H * nu[None, :] / (KB * Tgrid[:, None])
-                    planck = 2 * H * nu**3 / CLIGHT**2 / np.expm1(hnkt)
+                    with np.errstate(over="ignore"):
+                        planck = 2 * H * nu**3 / CLIGHT**2 / np.expm1(hnkt)
                     gammac[ci] = 4 * np.pi * prob * np.sum(sig / (H * nu) * planck * (1 - np.exp(-hnkt)), axis=1) * dx
 
     d = dict(

@@ -1,0 +1,130 @@
+// emu.cc -- TEST HARNESS ONLY (never shipped, never loaded by the artis_amd package).
+//
+// Compiles the kernel bodies of artis_amd/csrc/physics.h for x86 with g++ and runs them in the same
+// order the HIP kernels are launched (populate kernels, then advance_packet() with a launch budget and
+// an active list), so that the engine's logic can be diffed against the CPU oracle on machines without
+// a GPU (the CI container). It is not a CPU fallback: the product library has no such entry point and
+// fails without a HIP device.
+#define ARTIS_HOST_EMU 1
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../artis_amd/csrc/model_build.h"
+#include "../../artis_amd/csrc/physics.h"
+
+using namespace artis;
+
+namespace {
+struct Emu {
+  ModelOwned own;
+  Env env;
+  std::vector<std::vector<uint8_t>> cachebuf;
+  std::vector<stat_t> stats;
+  std::vector<double> ws;
+  int32_t err = 0;
+};
+
+void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_timestep *ts, artis_estimators *est, int64_t nslots) {
+  std::memset(&e.env, 0, sizeof(e.env));
+  e.env.M = make_host_model_view(*m, e.own);
+  e.env.C = make_host_cells_view(*cs);
+  e.env.S = make_step(*ts);
+  if (est) {
+    e.env.E.J = est->J; e.env.E.nuJ = est->nuJ; e.env.E.ffheatingestimator = est->ffheatingestimator;
+    e.env.E.colheatingestimator = est->colheatingestimator; e.env.E.gammaestimator = est->gammaestimator;
+    e.env.E.bfheatingestimator = est->bfheatingestimator;
+  }
+  const DevModel &M = e.env.M;
+  const int64_t ncell = M.npts_nonempty;
+#define ALLOC(f, T, per) { e.cachebuf.emplace_back((size_t)(ncell * (int64_t)(per) + 1) * sizeof(T)); e.env.K.f = (T *)e.cachebuf.back().data(); }
+  ARTIS_CACHE_ARRAYS(ALLOC, M)
+#undef ALLOC
+  e.stats.assign(ARTIS_NSTATS, 0);
+  e.env.stats = e.stats.data();
+  e.ws.assign((size_t)((M.nbfcontinua_ground + 1) * nslots), 0.);
+  e.env.gamma_ws = e.ws.data();
+  e.env.ws_stride = nslots;
+  e.env.errflag = &e.err;
+}
+
+// the populate kernels, in launch order (artis_engine.hip: k_levelpops, k_cell_scalars, k_allcont, k_corrphotoion,
+// k_macroatom, k_cooling_ion, k_cooling_prefix)
+void populate_all(Emu &e) {
+  const DevModel &M = e.env.M;
+  for (int c = 0; c < M.npts_nonempty; c++) {
+    for (int ul = 0; ul < M.nlevels; ul++) populate_levelpop(e.env, c, ul);
+    populate_chi_ff(e.env, c);
+    uint64_t *kb = e.env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
+    for (int w = 0; w < M.nkeepwords; w++) kb[w] = 0;
+    for (int i = 0; i < M.nbfcontinua; i++)
+      if (populate_allcont(e.env, c, i)) kb[i / 64] |= UINT64_C(1) << (unsigned)(i % 64);
+    for (int ul = 0; ul < M.nlevels; ul++)
+      for (int t = 0; t < M.level_nphixstargets[ul]; t++) populate_corrphotoion(e.env, c, ul, t);
+    for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom(e.env, c, ul);
+    for (int ui = 0; ui < M.nions; ui++) populate_cooling_ion(e.env, c, ui);
+    populate_cooling_prefix(e.env, c);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, const artis_timestep *ts, artis_packet *packets,
+                             int64_t npackets, artis_estimators *est, int budget) {
+  Emu e;
+  setup(e, m, cs, ts, est, npackets > 0 ? npackets : 1);
+  populate_all(e);
+  std::vector<uint8_t> soabuf(pkt_soa_bytes(npackets) + 64);
+  e.env.P = carve_pkt_soa(soabuf.data(), npackets);
+  for (int64_t i = 0; i < npackets; i++) aos_to_soa(packets[i], e.env.P, i);
+  // active list + budgeted launches, as in artis_amd_update_packets_device()
+  std::vector<int64_t> active, next;
+  for (int64_t i = 0; i < npackets; i++) {
+    Pkt p;
+    pkt_load(e.env.P, i, p);
+    if (pkt_active(p, e.env.S.ts_end)) active.push_back(i);
+  }
+  while (!active.empty() && !e.err) {
+    next.clear();
+    for (size_t k = 0; k < active.size(); k++) {
+      const int64_t pi = active[k];
+      Pkt p;
+      pkt_load(e.env.P, pi, p);
+      const bool still = advance_packet(e.env, p, pi, /*slot=*/(int64_t)k, budget);
+      pkt_store(e.env.P, pi, p);
+      if (still) next.push_back(pi);
+    }
+    active.swap(next);
+  }
+  for (int64_t i = 0; i < npackets; i++) soa_to_aos(e.env.P, i, packets[i]);
+  if (est && est->stats)
+    for (int i = 0; i < ARTIS_NSTATS; i++) est->stats[i] += (int64_t)e.stats[i];
+  if (est && est->stats) est->stats[ARTIS_STAT_UPDATECELL] += e.env.M.npts_nonempty;
+  return e.err;
+}
+
+int artis_emu_cellcache(const artis_model *m, const artis_cellstate *cs, const artis_timestep *ts, int c, double *levelpops,
+                        double *maprocessrates, double *matrans, double *allcont_nnlevel, double *allcont_departure,
+                        double *allcont_edgepart, uint64_t *allcont_keepbits, double *corrphotoioncoeff, double *cooling_contrib,
+                        double *ion_cooling_contribs, double *chi_ff_nnionpart) {
+  Emu e;
+  setup(e, m, cs, ts, nullptr, 1);
+  populate_all(e);
+  const DevModel &M = e.env.M;
+  const DevCache &K = e.env.K;
+  std::memcpy(levelpops, K.levelpops + (int64_t)c * M.nlevels, sizeof(double) * M.nlevels);
+  std::memcpy(maprocessrates, K.maprocessrates + (int64_t)c * M.nlevels * 9, sizeof(double) * M.nlevels * 9);
+  std::memcpy(matrans, K.matrans + (int64_t)c * M.nmatransblock, sizeof(double) * M.nmatransblock);
+  std::memcpy(allcont_nnlevel, K.allcont_nnlevel + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
+  std::memcpy(allcont_departure, K.allcont_departure + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
+  std::memcpy(allcont_edgepart, K.allcont_edgepart + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
+  std::memcpy(allcont_keepbits, K.allcont_keepbits + (int64_t)c * M.nkeepwords, sizeof(uint64_t) * M.nkeepwords);
+  std::memcpy(corrphotoioncoeff, K.corrphotoioncoeff + (int64_t)c * M.nphixstargets_total, sizeof(double) * M.nphixstargets_total);
+  std::memcpy(cooling_contrib, K.cooling_contrib + (int64_t)c * M.ncoolingterms, sizeof(double) * M.ncoolingterms);
+  std::memcpy(ion_cooling_contribs, K.ion_cooling_contribs + (int64_t)c * M.nions, sizeof(double) * M.nions);
+  *chi_ff_nnionpart = K.chi_ff_nnionpart[c];
+  return e.err;
+}
+}

@@ -1,0 +1,56 @@
+"""Shared comparison helpers for the parity tests (engine or emulated kernel bodies vs the CPU oracle)."""
+from __future__ import annotations
+
+import numpy as np
+
+from artis_amd import abi
+
+# Reference-defined counters must match exactly; so must the step counters this project adds.
+EXACT_STATS = list(range(abi.STAT_COUNT)) + [abi.STAT_X_RPKT_STEPS, abi.STAT_X_KPKT_STEPS, abi.STAT_X_LINES_VISITED,
+                                            abi.STAT_X_MA_JUMPS]
+
+
+def compare_packets(got: np.ndarray, want: np.ndarray, rtol: float, what: str = "") -> dict:
+    """Integer fields (type, cell, line indices, emission/absorption types, scatter counts) and the RNG state
+    must be identical; floating-point fields within rtol (0.0 = bit-exact)."""
+    assert len(got) == len(want)
+    rep = {}
+    for f in abi.PACKET_INT_FIELDS:
+        bad = np.nonzero(got[f] != want[f])[0]
+        assert len(bad) == 0, f"{what}: integer field {f} differs for {len(bad)} packets, first {bad[:5]}: {got[f][bad[:5]]} vs {want[f][bad[:5]]}"
+    assert np.array_equal(got["rngstate"], want["rngstate"]), f"{what}: RNG state differs (a different number of draws was made)"
+    worst = 0.0
+    for f in abi.PACKET_FLOAT_FIELDS:
+        a = np.asarray(got[f], dtype=np.float64)
+        b = np.asarray(want[f], dtype=np.float64)
+        both_nan = np.isnan(a) & np.isnan(b)
+        if rtol == 0.0:
+            same = (a == b) | both_nan
+            assert same.all(), f"{what}: float field {f} not bit-identical for {np.count_nonzero(~same)} values"
+        else:
+            denom = np.maximum(np.abs(a), np.abs(b))
+            denom[denom == 0] = 1.0
+            rel = np.abs(a - b) / denom
+            rel[both_nan] = 0.0
+            assert not np.isnan(rel).any(), f"{what}: NaN mismatch in {f}"
+            worst = max(worst, float(rel.max()))
+            assert rel.max() <= rtol, f"{what}: float field {f} rel diff {rel.max():.3e} > {rtol}"
+    rep["worst_rel"] = worst
+    return rep
+
+
+def compare_estimators(got: abi.Estimators, want: abi.Estimators, rtol: float, what: str = "") -> None:
+    """Estimators are sums of many terms; the GPU adds them with atomics in arbitrary order, so they are compared to a
+    relative tolerance scaled by the largest entry of each array (float sums are not associative)."""
+    for k, a in got.arrays().items():
+        b = want.arrays()[k]
+        scale = max(np.abs(b).max(), 1e-300)
+        err = np.abs(a - b).max() / scale
+        assert err <= rtol, f"{what}: estimator {k} differs by {err:.3e} (rel. to max) > {rtol}"
+
+
+def compare_stats(got: abi.Estimators, want: abi.Estimators, what: str = "", skip=(abi.STAT_NAMES.index("UPDATECELL"),)) -> None:
+    for i in EXACT_STATS:
+        if i in skip:
+            continue
+        assert got.stats[i] == want.stats[i], f"{what}: event counter {abi.STAT_NAMES[i]}: {got.stats[i]} vs {want.stats[i]}"

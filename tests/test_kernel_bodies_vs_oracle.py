@@ -1,0 +1,78 @@
+"""CPU differential tests: the kernel bodies (artis_amd/csrc/physics.h, compiled for x86 by tests/hostemu)
+against the CPU oracle. Both use glibc libm here, so packet histories must be bit-identical; on the GPU the
+same comparison runs through the C-ABI with a tolerance for the device math library (tests/test_gpu_parity.py).
+"""
+import numpy as np
+import pytest
+
+import hostemu_binding as emu
+import parity
+from artis_amd import abi, synth
+
+
+def _run_both(oracle, model, cs, ts, pk0, budget):
+    pa, pb = pk0.copy(), pk0.copy()
+    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+    ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
+    oracle.update_packets(model, cs, ts, pa, ea)
+    emu.update_packets(model, cs, ts, pb, eb, budget=budget)
+    return pa, pb, ea, eb
+
+
+@pytest.mark.parametrize("preset,ncoord,gridtype,thick_v,npk,budget", [
+    ("tiny", 6, abi.GRID_CARTESIAN3D, 0.0, 1500, 1),
+    ("small", 8, abi.GRID_CARTESIAN3D, 0.0, 3000, 4),
+    ("small", 8, abi.GRID_CARTESIAN3D, 6e8, 2000, 1000000),   # optically thick core: grey path + do_kpkt_blackbody
+    ("small", 24, abi.GRID_SPHERICAL1D, 0.0, 2000, 2),        # configs[0]-like: 1D spherical shells
+    ("small", 16, abi.GRID_SPHERICAL1D, 5e8, 1000, 3),
+])
+def test_packets_bit_exact(oracle, preset, ncoord, gridtype, thick_v, npk, budget):
+    model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v)
+    pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=0.2)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, budget)
+    parity.compare_packets(pb, pa, 0.0, "kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, "kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, "kernel bodies vs oracle")
+    assert ea.stats[abi.STAT_X_RPKT_STEPS] > npk  # the run really propagated packets
+    assert np.count_nonzero(pa["type"] == abi.TYPE_ESCAPE) > 0
+
+
+def test_budget_independence(oracle):
+    """A launch boundary may fall between any two do_packet() calls without changing a packet's history."""
+    model, cs, ts, aux = synth.build("tiny", ncoord=6)
+    pk0 = synth.make_packets(model, aux, 800, kpkt_fraction=0.3)
+    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+    outs = []
+    for budget in (1, 2, 7, 10**6):
+        p = pk0.copy()
+        emu.update_packets(model, cs, ts, p, abi.Estimators(n, g), budget=budget)
+        outs.append(p)
+    for p in outs[1:]:
+        parity.compare_packets(p, outs[0], 0.0, "budget independence")
+
+
+def test_cellcache_bit_exact(oracle):
+    model, cs, ts, aux = synth.build("small", ncoord=8, thick_below_v=4e8)
+    for c in (0, 17, model["npts_nonempty"] - 1):
+        a = oracle.cellcache(model, cs, ts, c)
+        b = emu.cellcache(model, cs, ts, c)
+        for k in a:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), f"cell {c}: {k} differs"
+
+
+def test_empty_and_untouched_packets(oracle):
+    """Edge cases: no packets; packets of types this path does not own are returned untouched;
+    packets already at the end of the timestep are not moved."""
+    model, cs, ts, aux = synth.build("tiny", ncoord=6)
+    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+    empty = np.zeros(0, dtype=abi.PACKET_DTYPE)
+    emu.update_packets(model, cs, ts, empty, abi.Estimators(n, g))
+    pk = synth.make_packets(model, aux, 64)
+    pk["type"][:16] = 100  # TYPE_RADIOACTIVE_PELLET
+    pk["type"][16:32] = 10  # TYPE_GAMMA
+    pk["prop_time"][32:48] = ts.c.start + ts.c.width
+    ref = pk.copy()
+    emu.update_packets(model, cs, ts, pk, abi.Estimators(n, g))
+    for f in abi.PACKET_DTYPE.names:  # (padding bytes are not compared)
+        assert pk[f][:48].tobytes() == ref[f][:48].tobytes(), f
+    assert np.all((pk["prop_time"][48:] >= ts.c.start + ts.c.width) | (pk["type"][48:] == abi.TYPE_ESCAPE))
