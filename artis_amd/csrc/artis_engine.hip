@@ -1,0 +1,607 @@
+// artis_engine.hip -- the MI355X packet-propagation engine behind include/artis_amd.h.
+//
+// Layout of the work on the GPU (gfx950, wave64):
+//   * model tables, cell state and the per-cell cache live in HBM for the whole timestep;
+//   * packets are structure-of-arrays columns (tables.h PktSoA), one thread per packet;
+//   * one timestep = populate kernels (cell cache) + repeated k_propagate launches over a compacted
+//     list of packets that still need updating. Each thread advances its packet by at most `budget`
+//     do_packet() calls, then survivors are appended to the next list with a wave ballot;
+//   * estimators are accumulated with hardware f64 atomics, event counters in LDS and flushed per block.
+// There is no CPU path in this library: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "model_build.h"
+#include "physics.h"
+
+using namespace artis;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                            \
+      return ARTIS_ERR_HIP;                                                                        \
+    }                                                                                              \
+  } while (0)
+
+constexpr int BLOCK = 256;
+
+// ------------------------------------------------------------------ populate kernels
+__global__ void __launch_bounds__(BLOCK) k_levelpops(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nlevels;
+  if (i >= total) return;
+  populate_levelpop(env, (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
+}
+__global__ void __launch_bounds__(BLOCK) k_cell_scalars(Env env) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= env.M.npts_nonempty) return;
+  populate_chi_ff(env, c);
+}
+// one wave = one 64-bit word of a cell's keep bitmap: the ballot IS the word (globals.h:296-305)
+__global__ void __launch_bounds__(BLOCK) k_allcont(Env env) {
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = (int64_t)env.M.npts_nonempty * env.M.nkeepwords;
+  if (wave >= nwaves) return;
+  const int c = (int)(wave / env.M.nkeepwords);
+  const int word = (int)(wave % env.M.nkeepwords);
+  const int i = word * 64 + lane;
+  bool keep = false;
+  if (i < env.M.nbfcontinua) keep = populate_allcont(env, c, i);
+  const unsigned long long bits = __ballot(keep);
+  if (lane == 0) env.K.allcont_keepbits[(int64_t)c * env.M.nkeepwords + word] = bits;
+}
+__global__ void __launch_bounds__(BLOCK) k_corrphotoion(Env env, const int32_t *target_level) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nphixstargets_total;
+  if (i >= total) return;
+  const int c = (int)(i / env.M.nphixstargets_total);
+  const int k = (int)(i % env.M.nphixstargets_total);
+  const int ul = target_level[k];
+  populate_corrphotoion(env, c, ul, k - env.M.level_phixstargetstart[ul]);
+}
+__global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nlevels;
+  if (i >= total) return;
+  populate_macroatom(env, (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
+}
+__global__ void __launch_bounds__(BLOCK) k_cooling_ion(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nions;
+  if (i >= total) return;
+  populate_cooling_ion(env, (int)(i / env.M.nions), (int)(i % env.M.nions));
+}
+__global__ void __launch_bounds__(BLOCK) k_cooling_prefix(Env env) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= env.M.npts_nonempty) return;
+  populate_cooling_prefix(env, c);
+}
+
+// ------------------------------------------------------------------ packet layout kernels
+__global__ void __launch_bounds__(BLOCK) k_aos_to_soa(const artis_packet *aos, PktSoA P) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < P.n) aos_to_soa(aos[i], P, i);
+}
+__global__ void __launch_bounds__(BLOCK) k_soa_to_aos(PktSoA P, artis_packet *aos) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < P.n) soa_to_aos(P, i, aos[i]);
+}
+
+// append `pi` of every lane with flag set to list[], one atomic per wave (wave-ballot compaction)
+__device__ inline void wave_append(bool flag, int32_t pi, int32_t *list, int32_t *count) {
+  const unsigned long long mask = __ballot(flag);
+  if (mask == 0) return;
+  const int lane = threadIdx.x & 63;
+  const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+  int base = 0;
+  const int leader = __ffsll((long long)mask) - 1;
+  if (lane == leader) base = atomicAdd(count, __popcll(mask));
+  base = __shfl(base, leader);
+  if (flag) list[base + prefix] = pi;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_build_active(PktSoA P, double ts_end, int32_t *list, int32_t *count) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool act = false;
+  if (i < P.n) act = type_handled(P.type[i]) && P.prop_time[i] < ts_end;
+  wave_append(act, (int32_t)i, list, count);
+}
+
+// ------------------------------------------------------------------ the propagation kernel
+__global__ void __launch_bounds__(BLOCK) k_propagate(Env env, const int32_t *active, int32_t nactive, int32_t *next, int32_t *next_count,
+                                                     unsigned long long *gstats, int budget) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  env.stats = lstats;
+  const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  bool still = false;
+  int32_t pi = 0;
+  if (tid < nactive) {
+    pi = active[tid];
+    Pkt p;
+    pkt_load(env.P, pi, p);
+    still = advance_packet(env, p, pi, tid, budget);
+    pkt_store(env.P, pi, p);
+  }
+  wave_append(still, pi, next, next_count);
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+}
+
+inline int nblocks(int64_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
+
+}  // namespace
+
+// ------------------------------------------------------------------ engine object
+struct artis_amd_engine {
+  int device = 0;
+  ModelOwned own;
+  std::vector<void *> model_allocs;
+  std::vector<void *> cell_allocs;
+  std::vector<void *> cache_allocs;
+  DevModel M{};  // device pointers
+  DevModel Mh{};  // host view (counts)
+  DevCells C{};
+  DevCache K{};
+  DevStep S{};
+  DevEst E{};
+  bool have_cells = false;
+  int32_t *d_target_level = nullptr;
+  double *d_est = nullptr;
+  int64_t est_ndoubles = 0;
+  unsigned long long *d_stats = nullptr;
+  int32_t *d_err = nullptr;
+  // packets
+  int64_t npackets = 0;
+  void *d_soa = nullptr;
+  void *d_soa_snapshot = nullptr;
+  size_t soa_bytes = 0;
+  PktSoA P{};
+  artis_packet *d_aos = nullptr;
+  int64_t aos_capacity = 0;
+  int32_t *d_list[2] = {nullptr, nullptr};
+  int32_t *d_count = nullptr;  // [2]
+  double *d_gamma_ws = nullptr;
+  int64_t ws_capacity = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_propagate_ms = 0.;
+  int64_t last_nlaunches = 0;
+  int budget = 4;
+};
+
+namespace {
+
+template <typename T>
+int upload_array(std::vector<void *> &allocs, const T *host, int64_t count, const T **dev_out) {
+  T *d = nullptr;
+  const size_t bytes = sizeof(T) * (size_t)(count > 0 ? count : 1);
+  HIP_TRY(hipMalloc((void **)&d, bytes));
+  allocs.push_back(d);
+  if (count > 0) HIP_TRY(hipMemcpy(d, host, sizeof(T) * (size_t)count, hipMemcpyHostToDevice));
+  *dev_out = d;
+  return ARTIS_OK;
+}
+
+int free_all(std::vector<void *> &v) {
+  for (void *p : v) (void)hipFree(p);
+  v.clear();
+  return ARTIS_OK;
+}
+
+Env make_env(const artis_amd_engine *e) {
+  Env env;
+  std::memset(&env, 0, sizeof(env));
+  env.M = e->M;
+  env.C = e->C;
+  env.K = e->K;
+  env.S = e->S;
+  env.E = e->E;
+  env.P = e->P;
+  env.stats = nullptr;
+  env.gamma_ws = e->d_gamma_ws;
+  env.ws_stride = e->ws_capacity;
+  env.errflag = e->d_err;
+  return env;
+}
+
+int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
+  if (n == e->npackets && e->d_soa) return ARTIS_OK;
+  if (e->d_soa) (void)hipFree(e->d_soa);
+  if (e->d_soa_snapshot) (void)hipFree(e->d_soa_snapshot);
+  e->d_soa = e->d_soa_snapshot = nullptr;
+  for (int k = 0; k < 2; k++) {
+    if (e->d_list[k]) (void)hipFree(e->d_list[k]);
+    e->d_list[k] = nullptr;
+  }
+  if (e->d_gamma_ws) (void)hipFree(e->d_gamma_ws);
+  e->d_gamma_ws = nullptr;
+  e->npackets = n;
+  e->soa_bytes = pkt_soa_bytes(n) + 64;
+  HIP_TRY(hipMalloc(&e->d_soa, e->soa_bytes));
+  e->P = carve_pkt_soa(e->d_soa, n);
+  const size_t listbytes = sizeof(int32_t) * (size_t)(n > 0 ? n : 1);
+  for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void **)&e->d_list[k], listbytes));
+  e->ws_capacity = n > 0 ? n : 1;
+  const size_t wsbytes = sizeof(double) * (size_t)(e->Mh.nbfcontinua_ground + 1) * (size_t)e->ws_capacity;
+  HIP_TRY(hipMalloc((void **)&e->d_gamma_ws, wsbytes));
+  return ARTIS_OK;
+}
+
+int ensure_aos(artis_amd_engine *e, int64_t n) {
+  if (n <= e->aos_capacity && e->d_aos) return ARTIS_OK;
+  if (e->d_aos) (void)hipFree(e->d_aos);
+  e->d_aos = nullptr;
+  HIP_TRY(hipMalloc((void **)&e->d_aos, sizeof(artis_packet) * (size_t)(n > 0 ? n : 1)));
+  e->aos_capacity = n;
+  return ARTIS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *artis_amd_last_error(void) { return g_last_error.c_str(); }
+int artis_amd_abi_version(void) { return 1; }
+size_t artis_amd_sizeof_packet(void) { return sizeof(artis_packet); }
+
+int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engine **out) {
+  if (!model || !out) {
+    g_last_error = "null argument";
+    return ARTIS_ERR_ARG;
+  }
+  if (model->gridtype != ARTIS_GRID_CARTESIAN3D && model->gridtype != ARTIS_GRID_SPHERICAL1D) {
+    g_last_error = "grid type not supported (CARTESIAN3D and SPHERICAL1D are)";
+    return ARTIS_ERR_UNSUPPORTED;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_last_error = "no HIP device: the artis_amd engine has no CPU path";
+    return ARTIS_ERR_NODEVICE;
+  }
+  HIP_TRY(hipSetDevice(device));
+  artis_amd_engine *e = new artis_amd_engine();
+  e->device = device;
+  e->Mh = make_host_model_view(*model, e->own);
+  e->M = e->Mh;
+  const DevModel &h = e->Mh;
+#define UP(f, T, count)                                                                     \
+  {                                                                                         \
+    int rc = upload_array<T>(e->model_allocs, h.f, (int64_t)(count), (const T **)&e->M.f);  \
+    if (rc != ARTIS_OK) return rc;                                                          \
+  }
+  ARTIS_MODEL_ARRAYS(UP, h)
+#undef UP
+  for (int a = 0; a < 3; a++) {
+    const int64_t cnt = (h.gridtype == ARTIS_GRID_SPHERICAL1D && a > 0) ? 1 : h.ncoordgrid[a];
+    int rc = upload_array<double>(e->model_allocs, h.coord_pos_min_tmin[a], cnt, &e->M.coord_pos_min_tmin[a]);
+    if (rc != ARTIS_OK) return rc;
+  }
+  // allphixstarget index -> level
+  {
+    std::vector<int32_t> tl((size_t)(h.nphixstargets_total > 0 ? h.nphixstargets_total : 1), 0);
+    for (int ul = 0; ul < h.nlevels; ul++)
+      for (int t = 0; t < h.level_nphixstargets[ul]; t++) tl[h.level_phixstargetstart[ul] + t] = ul;
+    const int32_t *d = nullptr;
+    int rc = upload_array<int32_t>(e->model_allocs, tl.data(), h.nphixstargets_total, &d);
+    if (rc != ARTIS_OK) return rc;
+    e->d_target_level = (int32_t *)d;
+  }
+  // per-cell cache
+  const int64_t ncell = h.npts_nonempty;
+#define CA(f, T, per)                                                                       \
+  {                                                                                         \
+    T *d = nullptr;                                                                         \
+    HIP_TRY(hipMalloc((void **)&d, sizeof(T) * (size_t)(ncell * (int64_t)(per) + 1)));    \
+    e->cache_allocs.push_back(d);                                                           \
+    e->K.f = d;                                                                             \
+  }
+  ARTIS_CACHE_ARRAYS(CA, h)
+#undef CA
+  // estimators: one contiguous block [J | nuJ | ff | col | gamma | bfheat]
+  const int64_t g = h.nbfcontinua_ground > 0 ? h.nbfcontinua_ground : 1;
+  e->est_ndoubles = ncell * 4 + 2 * ncell * g;
+  HIP_TRY(hipMalloc((void **)&e->d_est, sizeof(double) * (size_t)e->est_ndoubles));
+  HIP_TRY(hipMemset(e->d_est, 0, sizeof(double) * (size_t)e->est_ndoubles));
+  e->E.J = e->d_est;
+  e->E.nuJ = e->d_est + ncell;
+  e->E.ffheatingestimator = e->d_est + 2 * ncell;
+  e->E.colheatingestimator = e->d_est + 3 * ncell;
+  e->E.gammaestimator = e->d_est + 4 * ncell;
+  e->E.bfheatingestimator = e->d_est + 4 * ncell + ncell * g;
+  HIP_TRY(hipMalloc((void **)&e->d_stats, sizeof(unsigned long long) * ARTIS_NSTATS));
+  HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS));
+  HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
+  HIP_TRY(hipMemset(e->d_err, 0, sizeof(int32_t)));
+  HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 2));
+  HIP_TRY(hipEventCreate(&e->ev0));
+  HIP_TRY(hipEventCreate(&e->ev1));
+  if (const char *b = std::getenv("ARTIS_AMD_BUDGET")) e->budget = std::max(1, std::atoi(b));
+  *out = e;
+  return ARTIS_OK;
+}
+
+void artis_amd_engine_destroy(artis_amd_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  free_all(e->model_allocs);
+  free_all(e->cell_allocs);
+  free_all(e->cache_allocs);
+  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_list[0], e->d_list[1], e->d_count,
+                  e->d_gamma_ws};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  delete e;
+}
+
+int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, const artis_timestep *ts) {
+  if (!e || !cells || !ts) {
+    g_last_error = "null argument";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  free_all(e->cell_allocs);
+  const DevModel &h = e->Mh;
+  const DevCells hc = make_host_cells_view(*cells);
+#define UPC(f, T, count)                                                                   \
+  {                                                                                        \
+    int rc = upload_array<T>(e->cell_allocs, hc.f, (int64_t)(count), (const T **)&e->C.f); \
+    if (rc != ARTIS_OK) return rc;                                                         \
+  }
+  ARTIS_CELL_ARRAYS(UPC, h)
+#undef UPC
+  e->S = make_step(*ts);
+  e->have_cells = true;
+  return artis_amd_populate_cellcache(e, nullptr);
+}
+
+int artis_amd_populate_cellcache(artis_amd_engine *e, void *hip_stream) {
+  if (!e || !e->have_cells) {
+    g_last_error = "no cell state uploaded";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  const DevModel &h = e->Mh;
+  // populate the cell cache of every non-empty cell
+  Env env = make_env(e);
+  const int64_t ncell = h.npts_nonempty;
+  hipStream_t s = (hipStream_t)hip_stream;
+  hipLaunchKernelGGL(k_levelpops, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
+  hipLaunchKernelGGL(k_cell_scalars, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
+  if (h.nbfcontinua > 0) hipLaunchKernelGGL(k_allcont, dim3(nblocks(ncell * h.nkeepwords * 64)), dim3(BLOCK), 0, s, env);
+  if (h.nphixstargets_total > 0)
+    hipLaunchKernelGGL(k_corrphotoion, dim3(nblocks(ncell * h.nphixstargets_total)), dim3(BLOCK), 0, s, env, e->d_target_level);
+  hipLaunchKernelGGL(k_macroatom, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
+  hipLaunchKernelGGL(k_cooling_ion, dim3(nblocks(ncell * h.nions)), dim3(BLOCK), 0, s, env);
+  hipLaunchKernelGGL(k_cooling_prefix, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  // UPDATECELL (stats.h:47): one populate per non-empty cell
+  unsigned long long add = (unsigned long long)ncell, cur = 0;
+  HIP_TRY(hipMemcpy(&cur, e->d_stats + ARTIS_STAT_UPDATECELL, sizeof(cur), hipMemcpyDeviceToHost));
+  cur += add;
+  HIP_TRY(hipMemcpy(e->d_stats + ARTIS_STAT_UPDATECELL, &cur, sizeof(cur), hipMemcpyHostToDevice));
+  int32_t err = 0;
+  HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
+  if (err != 0) {
+    g_last_error = "cell cache population raised error flag " + std::to_string(err);
+    return ARTIS_ERR_NOTCONVERGED;
+  }
+  return ARTIS_OK;
+}
+
+int artis_amd_packets_upload(artis_amd_engine *e, const artis_packet *packets, int64_t npackets) {
+  if (!e || (!packets && npackets > 0) || npackets < 0 || npackets > 2147483000LL) {
+    g_last_error = "bad packet buffer";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = ensure_packet_buffers(e, npackets);
+  if (rc != ARTIS_OK) return rc;
+  rc = ensure_aos(e, npackets);
+  if (rc != ARTIS_OK) return rc;
+  if (npackets > 0) {
+    HIP_TRY(hipMemcpy(e->d_aos, packets, sizeof(artis_packet) * (size_t)npackets, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_aos_to_soa, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->d_aos, e->P);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  return ARTIS_OK;
+}
+
+int artis_amd_packets_download(artis_amd_engine *e, artis_packet *packets, int64_t npackets) {
+  if (!e || npackets != e->npackets || (!packets && npackets > 0)) {
+    g_last_error = "packet count does not match the resident population";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  if (npackets == 0) return ARTIS_OK;
+  int rc = ensure_aos(e, npackets);
+  if (rc != ARTIS_OK) return rc;
+  // start from the caller's structs so that the fields this path never touches keep their values
+  HIP_TRY(hipMemcpy(e->d_aos, packets, sizeof(artis_packet) * (size_t)npackets, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_soa_to_aos, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->P, e->d_aos);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(packets, e->d_aos, sizeof(artis_packet) * (size_t)npackets, hipMemcpyDeviceToHost));
+  return ARTIS_OK;
+}
+
+int artis_amd_packets_snapshot(artis_amd_engine *e) {
+  if (!e || !e->d_soa) {
+    g_last_error = "no resident packets";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->d_soa_snapshot) HIP_TRY(hipMalloc(&e->d_soa_snapshot, e->soa_bytes));
+  HIP_TRY(hipMemcpy(e->d_soa_snapshot, e->d_soa, e->soa_bytes, hipMemcpyDeviceToDevice));
+  return ARTIS_OK;
+}
+
+int artis_amd_packets_restore(artis_amd_engine *e) {
+  if (!e || !e->d_soa || !e->d_soa_snapshot) {
+    g_last_error = "no snapshot";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpy(e->d_soa, e->d_soa_snapshot, e->soa_bytes, hipMemcpyDeviceToDevice));
+  return ARTIS_OK;
+}
+
+int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
+  if (!e || !e->have_cells || !e->d_soa) {
+    g_last_error = "engine needs artis_amd_set_cellstate() and resident packets first";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  hipStream_t s = (hipStream_t)hip_stream;
+  e->last_propagate_ms = 0.;
+  e->last_nlaunches = 0;
+  const int64_t n = e->npackets;
+  if (n == 0) return ARTIS_OK;
+  Env env = make_env(e);
+  int32_t counts[2] = {0, 0};
+  HIP_TRY(hipMemsetAsync(e->d_count, 0, sizeof(int32_t) * 2, s));
+  hipLaunchKernelGGL(k_build_active, dim3(nblocks(n)), dim3(BLOCK), 0, s, e->P, e->S.ts_end, e->d_list[0], e->d_count);
+  HIP_TRY(hipMemcpyAsync(counts, e->d_count, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int cur = 0;
+  int32_t nactive = counts[0];
+  int64_t guard = 0;
+  while (nactive > 0) {
+    const int nxt = 1 - cur;
+    HIP_TRY(hipMemsetAsync(e->d_count + nxt, 0, sizeof(int32_t), s));
+    HIP_TRY(hipEventRecord(e->ev0, s));
+    hipLaunchKernelGGL(k_propagate, dim3(nblocks(nactive)), dim3(BLOCK), 0, s, env, e->d_list[cur], nactive, e->d_list[nxt],
+                       e->d_count + nxt, e->d_stats, e->budget);
+    HIP_TRY(hipEventRecord(e->ev1, s));
+    HIP_TRY(hipMemcpyAsync(counts, e->d_count, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    e->last_propagate_ms += ms;
+    e->last_nlaunches++;
+    nactive = counts[nxt];
+    cur = nxt;
+    if (++guard > 100000000LL) {
+      g_last_error = "packet loop did not terminate";
+      return ARTIS_ERR_NOTCONVERGED;
+    }
+  }
+  int32_t err = 0;
+  HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
+  if (err != 0) {
+    g_last_error = "a kernel raised error flag " + std::to_string(err) + " (an assert_always of the reference would have fired)";
+    return ARTIS_ERR_NOTCONVERGED;
+  }
+  return ARTIS_OK;
+}
+
+int artis_amd_estimators_zero(artis_amd_engine *e, void *hip_stream) {
+  if (!e) return ARTIS_ERR_ARG;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemsetAsync(e->d_est, 0, sizeof(double) * (size_t)e->est_ndoubles, (hipStream_t)hip_stream));
+  HIP_TRY(hipMemsetAsync(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS, (hipStream_t)hip_stream));
+  return ARTIS_OK;
+}
+
+int artis_amd_estimators_download(artis_amd_engine *e, artis_estimators *est) {
+  if (!e || !est) return ARTIS_ERR_ARG;
+  HIP_TRY(hipSetDevice(e->device));
+  std::vector<double> h((size_t)e->est_ndoubles);
+  HIP_TRY(hipMemcpy(h.data(), e->d_est, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+  const int64_t ncell = e->Mh.npts_nonempty;
+  const int64_t g = e->Mh.nbfcontinua_ground > 0 ? e->Mh.nbfcontinua_ground : 1;
+  const double *src = h.data();
+  auto add = [](double *dst, const double *s, int64_t cnt) {
+    if (!dst) return;
+    for (int64_t i = 0; i < cnt; i++) dst[i] += s[i];
+  };
+  add(est->J, src, ncell);
+  add(est->nuJ, src + ncell, ncell);
+  add(est->ffheatingestimator, src + 2 * ncell, ncell);
+  add(est->colheatingestimator, src + 3 * ncell, ncell);
+  add(est->gammaestimator, src + 4 * ncell, ncell * g);
+  add(est->bfheatingestimator, src + 4 * ncell + ncell * g, ncell * g);
+  if (est->stats) {
+    unsigned long long st[ARTIS_NSTATS];
+    HIP_TRY(hipMemcpy(st, e->d_stats, sizeof(st), hipMemcpyDeviceToHost));
+    for (int i = 0; i < ARTIS_NSTATS; i++) est->stats[i] += (int64_t)st[i];
+  }
+  return ARTIS_OK;
+}
+
+int artis_amd_estimators_devptr(artis_amd_engine *e, void **dptr, int64_t *ndoubles) {
+  if (!e || !dptr || !ndoubles) return ARTIS_ERR_ARG;
+  *dptr = e->d_est;
+  *ndoubles = e->est_ndoubles;
+  return ARTIS_OK;
+}
+
+int artis_amd_update_packets(artis_amd_engine *e, artis_packet *packets, int64_t npackets, artis_estimators *est) {
+  int rc = artis_amd_packets_upload(e, packets, npackets);
+  if (rc != ARTIS_OK) return rc;
+  rc = artis_amd_estimators_zero(e, nullptr);
+  if (rc != ARTIS_OK) return rc;
+  {
+    // keep UPDATECELL of the populate that belongs to this timestep
+    unsigned long long ncell = (unsigned long long)e->Mh.npts_nonempty;
+    HIP_TRY(hipMemcpy(e->d_stats + ARTIS_STAT_UPDATECELL, &ncell, sizeof(ncell), hipMemcpyHostToDevice));
+  }
+  rc = artis_amd_update_packets_device(e, nullptr);
+  if (rc != ARTIS_OK) return rc;
+  rc = artis_amd_packets_download(e, packets, npackets);
+  if (rc != ARTIS_OK) return rc;
+  if (est) rc = artis_amd_estimators_download(e, est);
+  return rc;
+}
+
+int artis_amd_last_kernel_ms(artis_amd_engine *e, double *propagate_ms, int64_t *nlaunches) {
+  if (!e) return ARTIS_ERR_ARG;
+  if (propagate_ms) *propagate_ms = e->last_propagate_ms;
+  if (nlaunches) *nlaunches = e->last_nlaunches;
+  return ARTIS_OK;
+}
+
+int artis_amd_debug_cellcache(artis_amd_engine *e, int c, double *levelpops, double *maprocessrates, double *matrans,
+                              double *allcont_nnlevel, double *allcont_departure, double *allcont_edgepart,
+                              uint64_t *allcont_keepbits, double *corrphotoioncoeff, double *cooling_contrib,
+                              double *ion_cooling_contribs, double *chi_ff_nnionpart) {
+  if (!e || !e->have_cells || c < 0 || c >= e->Mh.npts_nonempty) {
+    g_last_error = "bad cell index or no cell state";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  const DevModel &h = e->Mh;
+#define DL(dst, f, T, per)                                                                                            \
+  if (dst && (per) > 0) HIP_TRY(hipMemcpy(dst, e->K.f + (int64_t)c * (per), sizeof(T) * (size_t)(per), hipMemcpyDeviceToHost));
+  DL(levelpops, levelpops, double, h.nlevels)
+  DL(maprocessrates, maprocessrates, double, (int64_t)h.nlevels * 9)
+  DL(matrans, matrans, double, h.nmatransblock)
+  DL(allcont_nnlevel, allcont_nnlevel, double, h.nbfcontinua)
+  DL(allcont_departure, allcont_departure, double, h.nbfcontinua)
+  DL(allcont_edgepart, allcont_edgepart, double, h.nbfcontinua)
+  DL(allcont_keepbits, allcont_keepbits, uint64_t, h.nkeepwords)
+  DL(corrphotoioncoeff, corrphotoioncoeff, double, h.nphixstargets_total)
+  DL(cooling_contrib, cooling_contrib, double, h.ncoolingterms)
+  DL(ion_cooling_contribs, ion_cooling_contribs, double, h.nions)
+  DL(chi_ff_nnionpart, chi_ff_nnionpart, double, 1)
+#undef DL
+  return ARTIS_OK;
+}
+
+}  // extern "C"

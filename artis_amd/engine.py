@@ -1,0 +1,149 @@
+"""Python host side over the C-ABI of libartis_amd.so (ctypes; no torch types cross the boundary).
+
+Mirrors the reference's call sequence for one timestep:
+    update_grid()      -> Engine.set_cellstate(cells, ts)       (cell cache populated on the GPU)
+    update_packets()   -> Engine.update_packets(packets, est)   (host buffers)  or the device-resident
+                          upload_packets / step / download_packets calls used by bench.py
+    reduce_estimators  -> Engine.estimators_devptr() handed to an RCCL all-reduce by the caller
+The library has no CPU path: creating an Engine without a HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .build import SO, build
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def load_library(build_if_missing: bool = False):
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO):
+        if not build_if_missing:
+            raise EngineError(f"{SO} is missing: run `python -m artis_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+        build()
+    L = C.CDLL(SO)
+    L.artis_amd_last_error.restype = C.c_char_p
+    L.artis_amd_abi_version.restype = C.c_int
+    L.artis_amd_sizeof_packet.restype = C.c_size_t
+    L.artis_amd_engine_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.artis_amd_engine_destroy.argtypes = [C.c_void_p]
+    L.artis_amd_engine_destroy.restype = None
+    L.artis_amd_set_cellstate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.artis_amd_populate_cellcache.argtypes = [C.c_void_p, C.c_void_p]
+    L.artis_amd_update_packets.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    L.artis_amd_packets_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.artis_amd_packets_download.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.artis_amd_packets_snapshot.argtypes = [C.c_void_p]
+    L.artis_amd_packets_restore.argtypes = [C.c_void_p]
+    L.artis_amd_update_packets_device.argtypes = [C.c_void_p, C.c_void_p]
+    L.artis_amd_estimators_zero.argtypes = [C.c_void_p, C.c_void_p]
+    L.artis_amd_estimators_download.argtypes = [C.c_void_p, C.c_void_p]
+    L.artis_amd_estimators_devptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.artis_amd_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    assert L.artis_amd_sizeof_packet() == abi.PACKET_DTYPE.itemsize
+    _LIB = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "artis_amd_last_error", "artis_amd_abi_version", "artis_amd_sizeof_packet", "artis_amd_engine_create",
+    "artis_amd_engine_destroy", "artis_amd_set_cellstate", "artis_amd_update_packets", "artis_amd_packets_upload",
+    "artis_amd_packets_download", "artis_amd_packets_snapshot", "artis_amd_packets_restore",
+    "artis_amd_update_packets_device", "artis_amd_estimators_zero", "artis_amd_estimators_download",
+    "artis_amd_estimators_devptr", "artis_amd_last_kernel_ms", "artis_amd_debug_cellcache",
+    "artis_amd_populate_cellcache",
+]
+
+
+class Engine:
+    def __init__(self, model: abi.Model, device: int = 0):
+        self.L = load_library()
+        self.model = model
+        self.h = C.c_void_p()
+        self._check(self.L.artis_amd_engine_create(C.cast(model.ref(), C.c_void_p), device, C.byref(self.h)))
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EngineError(f"artis_amd error {rc}: {self.L.artis_amd_last_error().decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.artis_amd_engine_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_cellstate(self, cells: abi.CellState, ts: abi.Timestep):
+        self._cells, self._ts = cells, ts
+        self._check(self.L.artis_amd_set_cellstate(self.h, C.cast(cells.ref(), C.c_void_p), C.cast(ts.ref(), C.c_void_p)))
+
+    def populate_cellcache(self, stream: int = 0):
+        self._check(self.L.artis_amd_populate_cellcache(self.h, C.c_void_p(stream)))
+
+    def update_packets(self, packets: np.ndarray, est: abi.Estimators):
+        """Host-buffer form of the reference's update_packets() (update_packets.cc:530)."""
+        self._check(self.L.artis_amd_update_packets(self.h, abi.packets_ptr(packets), len(packets), C.cast(est.ref(), C.c_void_p)))
+
+    # device-resident form
+    def upload_packets(self, packets: np.ndarray):
+        self._check(self.L.artis_amd_packets_upload(self.h, abi.packets_ptr(packets), len(packets)))
+
+    def download_packets(self, packets: np.ndarray):
+        self._check(self.L.artis_amd_packets_download(self.h, abi.packets_ptr(packets), len(packets)))
+
+    def snapshot(self):
+        self._check(self.L.artis_amd_packets_snapshot(self.h))
+
+    def restore(self):
+        self._check(self.L.artis_amd_packets_restore(self.h))
+
+    def step(self, stream: int = 0):
+        self._check(self.L.artis_amd_update_packets_device(self.h, C.c_void_p(stream)))
+
+    def zero_estimators(self, stream: int = 0):
+        self._check(self.L.artis_amd_estimators_zero(self.h, C.c_void_p(stream)))
+
+    def download_estimators(self, est: abi.Estimators):
+        self._check(self.L.artis_amd_estimators_download(self.h, C.cast(est.ref(), C.c_void_p)))
+
+    def estimators_devptr(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._check(self.L.artis_amd_estimators_devptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def debug_cellcache(self, c: int) -> dict:
+        d = self.model.d
+        out = {
+            "levelpops": np.zeros(d["nlevels"]), "maprocessrates": np.zeros(d["nlevels"] * 9),
+            "matrans": np.zeros(max(d["nmatransblock"], 1)), "allcont_nnlevel": np.zeros(max(d["nbfcontinua"], 1)),
+            "allcont_departure": np.zeros(max(d["nbfcontinua"], 1)), "allcont_edgepart": np.zeros(max(d["nbfcontinua"], 1)),
+            "allcont_keepbits": np.zeros((d["nbfcontinua"] + 63) // 64 + 1, dtype=np.uint64),
+            "corrphotoioncoeff": np.zeros(max(d["nphixstargets_total"], 1)),
+            "cooling_contrib": np.zeros(max(d["ncoolingterms"], 1)), "ion_cooling_contribs": np.zeros(d["nions"]),
+        }
+        chi = C.c_double(0.0)
+        args = [self.h, C.c_int(c)] + [v.ctypes.data_as(C.c_void_p) for v in out.values()] + [C.byref(chi)]
+        self._check(self.L.artis_amd_debug_cellcache(*args))
+        out["chi_ff_nnionpart"] = chi.value
+        return out
+
+    def last_kernel_ms(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self.L.artis_amd_last_kernel_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

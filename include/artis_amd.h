@@ -325,6 +325,10 @@ void artis_amd_engine_destroy(artis_amd_engine *eng);
  * cooling of kpkt::calculate_cooling_rates() (kpkt.cc:281). */
 int artis_amd_set_cellstate(artis_amd_engine *eng, const artis_cellstate *cells, const artis_timestep *ts);
 
+/* Re-run the cell-cache population for the cell state already uploaded (what update_packets() of the
+ * reference does at its start, update_packets.cc:551-560). hip_stream is a hipStream_t (NULL = default). */
+int artis_amd_populate_cellcache(artis_amd_engine *eng, void *hip_stream);
+
 /* Host-buffer form of update_packets() (update_packets.cc:530): packets in
  * TYPE_RPKT / TYPE_KPKT / TYPE_PRE_KPKT are propagated to the end of the
  * timestep; other types are returned untouched (they stay on the reference's
@@ -353,6 +357,13 @@ int artis_amd_estimators_devptr(artis_amd_engine *eng, void **dptr, int64_t *ndo
 /* Timing of the dominant kernel inside the last artis_amd_update_packets_device
  * call, measured with HIP events on the launch stream. */
 int artis_amd_last_kernel_ms(artis_amd_engine *eng, double *propagate_ms, int64_t *nlaunches);
+
+/* Diagnostics: copy the cell cache of one non-empty cell back to the host (the reference's
+ * globals::cellcache[nonemptymgi] spans, globals.h:283-311). Any pointer may be NULL. */
+int artis_amd_debug_cellcache(artis_amd_engine *eng, int nonemptymgi, double *levelpops, double *maprocessrates,
+                              double *matrans, double *allcont_nnlevel, double *allcont_departure,
+                              double *allcont_edgepart, uint64_t *allcont_keepbits, double *corrphotoioncoeff,
+                              double *cooling_contrib, double *ion_cooling_contribs, double *chi_ff_nnionpart);
 
 #ifdef __cplusplus
 }

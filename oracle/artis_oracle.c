@@ -33,6 +33,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../include/artis_amd.h"
 #include "../include/artis_options.h"
@@ -66,6 +67,7 @@ static inline double dclamp(double v, double lo, double hi) { return (v < lo) ? 
 /* ------------------------------------------------------------------ state */
 typedef struct {
   int populated;
+  int have_ion_cooling;         /* ion_cooling_contribs filled (kpkt.cc:281 is part of update_grid in the reference) */
   double chi_ff_nnionpart;
   double *levelpops;            /* [nlevels] alllevels_pops */
   double *maprocessrates;       /* [nlevels*9] alllevels_maprocessrates */
@@ -89,7 +91,17 @@ typedef struct {
   double T_step_log;
   double last_phixs_nuovernuedge;
   int error;
+  int npopulated;     /* cells currently holding a cache */
+  int cache_cap;      /* evict everything when this many cells are cached (bounds host memory) */
+  double t_populate;  /* seconds spent filling caches */
 } Oracle;
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static double g_last_populate_seconds = 0.;
 
 /* ContinuumOpacity (rpkt.h:70) with its Phixslist (rpkt.h:48) */
 typedef struct {
@@ -955,21 +967,37 @@ static double calculate_cooling_rates_ion(Oracle *o, const CellCache *cc, int c,
   return C_ion;
 }
 
-/* cellcacheslot_populate update_packets.cc:397 (multi-slot form) + kpkt::calculate_cooling_rates kpkt.cc:281 */
+static void cellcache_free_one(CellCache *cc) {
+  free(cc->levelpops); free(cc->maprocessrates); free(cc->matrans); free(cc->allcont_nnlevel);
+  free(cc->allcont_departure); free(cc->allcont_edgepart); free(cc->allcont_keepbits);
+  free(cc->corrphotoioncoeff); free(cc->cooling_contrib); free(cc->ion_cooling_contribs);
+  memset(cc, 0, sizeof(*cc));
+}
+
+/* cellcacheslot_populate update_packets.cc:397. As in the reference's CPU build (cellcache_singleslot,
+ * update_packets.cc:459-463 and :408) the macro-atom rates of a level and the cooling terms of an ion are
+ * left at a negative sentinel here and calculated on first use (macroatom.cc:403, kpkt.cc:459); the values
+ * are the ones the multi-slot form pre-calculates, so results do not depend on which form runs. */
 static void cellcache_populate(Oracle *o, int c) {
   const artis_model *m = o->m;
   CellCache *cc = &o->cache[c];
   if (cc->populated) return;
+  const double t0 = now_s();
+  if (o->cache_cap > 0 && o->npopulated >= o->cache_cap) {
+    for (int k = 0; k < m->npts_nonempty; k++)
+      if (o->cache[k].populated) cellcache_free_one(&o->cache[k]);
+    o->npopulated = 0;
+  }
   cc->levelpops = (double *)malloc(sizeof(double) * (size_t)m->nlevels);
   cc->maprocessrates = (double *)malloc(sizeof(double) * (size_t)m->nlevels * ARTIS_MA_ACTION_COUNT);
-  cc->matrans = (double *)malloc(sizeof(double) * (size_t)(m->nmatransblock > 0 ? m->nmatransblock : 1));
+  cc->matrans = (double *)calloc((size_t)(m->nmatransblock > 0 ? m->nmatransblock : 1), sizeof(double));
   cc->allcont_nnlevel = (double *)malloc(sizeof(double) * (size_t)(m->nbfcontinua + 1));
   cc->allcont_departure = (double *)malloc(sizeof(double) * (size_t)(m->nbfcontinua + 1));
   cc->allcont_edgepart = (double *)malloc(sizeof(double) * (size_t)(m->nbfcontinua + 1));
   const int nwords = (m->nbfcontinua + 63) / 64;
   cc->allcont_keepbits = (uint64_t *)calloc((size_t)(nwords + 1), sizeof(uint64_t));
   cc->corrphotoioncoeff = (double *)malloc(sizeof(double) * (size_t)(m->nphixstargets_total + 1));
-  cc->cooling_contrib = (double *)malloc(sizeof(double) * (size_t)(m->ncoolingterms + 1));
+  cc->cooling_contrib = (double *)calloc((size_t)(m->ncoolingterms + 1), sizeof(double));
   cc->ion_cooling_contribs = (double *)malloc(sizeof(double) * (size_t)m->nions);
   stat_inc(o, ARTIS_STAT_UPDATECELL);
 
@@ -980,6 +1008,7 @@ static void cellcache_populate(Oracle *o, int c) {
       const int nlevels = get_nlevels(o, element, ion);
       const int start = ionlevelstart(o, element, ion);
       for (int level = 0; level < nlevels; level++) cc->levelpops[start + level] = calculate_levelpop(o, c, element, ion, level);
+      cc->cooling_contrib[m->ion_coolingoffset[uniqueion(o, element, ion)]] = -99.; /* update_packets.cc:408 */
     }
   }
   const float T_e = o->cs->Te[c];
@@ -998,7 +1027,7 @@ static void cellcache_populate(Oracle *o, int c) {
     cc->allcont_edgepart[i] = -1.;
     if (keep) {
       cc->allcont_keepbits[i / 64] |= UINT64_C(1) << (unsigned)(i % 64);
-      /* slow path of calculate_chi_bf_gammacontr, rpkt.cc:853-889 */
+      /* slow path of calculate_chi_bf_gammacontr, rpkt.cc:853-889 (header note 3) */
       const int upper = m->allcont_upperlevel[i];
       const double nnupperionlevel = cc->levelpops[ionlevelstart(o, element, ion + 1) + upper];
       const double modified_sahafact = modified_sahafact_statweightpart * stat_weight(o, ionlevelstart(o, element, ion) + level) /
@@ -1015,21 +1044,45 @@ static void cellcache_populate(Oracle *o, int c) {
   for (int ul = 0; ul < m->nlevels; ul++) {
     const int nt = m->level_nphixstargets[ul];
     for (int t = 0; t < nt; t++) cc->corrphotoioncoeff[m->level_phixstargetstart[ul] + t] = calc_corrphotoioncoeff(o, c, ul, t);
+    cc->maprocessrates[(ptrdiff_t)ul * ARTIS_MA_ACTION_COUNT] = -99.; /* update_packets.cc:461 */
   }
-  const double t_mid = o->ts.mid;
-  double cumulative_cooling = 0.;
-  for (int element = 0; element < m->nelements; element++) {
-    const int nions = get_nions(o, element);
-    for (int ion = 0; ion < nions; ion++) {
-      const int nlevels = get_nlevels(o, element, ion);
-      for (int level = 0; level < nlevels; level++) calculate_macroatom_transitionrates(o, cc, c, element, ion, level, t_mid);
-      const int ui = uniqueion(o, element, ion);
-      const double C_ion = calculate_cooling_rates_ion(o, cc, c, element, ion, cc->cooling_contrib + m->ion_coolingoffset[ui]);
-      cumulative_cooling += C_ion;
-      cc->ion_cooling_contribs[ui] = cumulative_cooling;
-    }
-  }
+  cc->have_ion_cooling = 0;
   cc->populated = 1;
+  o->npopulated++;
+  o->t_populate += now_s() - t0;
+}
+
+/* macroatom.cc:403 calc_rates_if_needed */
+static const double *macroatom_levelrates(Oracle *o, int c, int element, int ion, int level) {
+  CellCache *cc = &o->cache[c];
+  const int ul = ionlevelstart(o, element, ion) + level;
+  double *levelrates = cc->maprocessrates + ((ptrdiff_t)ul * ARTIS_MA_ACTION_COUNT);
+  if (levelrates[0] < 0.) calculate_macroatom_transitionrates(o, cc, c, element, ion, level, o->ts.mid);
+  return levelrates;
+}
+/* kpkt.cc:459 calc_cooling_if_needed */
+static const double *cooling_ion_contribs(Oracle *o, int c, int element, int ion) {
+  CellCache *cc = &o->cache[c];
+  const int ui = uniqueion(o, element, ion);
+  double *ion_contribs = cc->cooling_contrib + o->m->ion_coolingoffset[ui];
+  if (ion_contribs[0] < 0.) calculate_cooling_rates_ion(o, cc, c, element, ion, ion_contribs);
+  return ion_contribs;
+}
+/* kpkt::calculate_cooling_rates kpkt.cc:281 (done by update_grid in the reference; here on the first k-packet of a cell) */
+static const double *cell_ion_cooling_contribs(Oracle *o, int c) {
+  CellCache *cc = &o->cache[c];
+  if (!cc->have_ion_cooling) {
+    double cumulative_cooling = 0.;
+    for (int element = 0; element < o->m->nelements; element++) {
+      const int nions = get_nions(o, element);
+      for (int ion = 0; ion < nions; ion++) {
+        cumulative_cooling += calculate_cooling_rates_ion(o, cc, c, element, ion, NULL);
+        cc->ion_cooling_contribs[uniqueion(o, element, ion)] = cumulative_cooling;
+      }
+    }
+    cc->have_ion_cooling = 1;
+  }
+  return cc->ion_cooling_contribs;
 }
 
 /* ------------------------------------------------------------------ rpkt.cc opacities */
@@ -1502,7 +1555,7 @@ static void do_macroatom(Oracle *o, artis_packet *p, const MacroAtomState *ma) {
     const int start = ionlevelstart(o, element, ion);
     const int ul = start + level;
     const double epsilon_current = epsilon(o, ul);
-    const double *levelrates = cc->maprocessrates + ((ptrdiff_t)ul * ARTIS_MA_ACTION_COUNT);
+    const double *levelrates = macroatom_levelrates(o, c, element, ion, level);
     double cumulative[ARTIS_MA_ACTION_COUNT];
     cumulative[0] = levelrates[0];
     for (int i = 1; i < ARTIS_MA_ACTION_COUNT; i++) cumulative[i] = cumulative[i - 1] + levelrates[i]; /* std::partial_sum */
@@ -1812,8 +1865,9 @@ static void do_kpkt(Oracle *o, artis_packet *p, double t2) {
   const int c = propcell_nonemptymgi(o, p->cellindex);
   cellcache_populate(o, c);
   const CellCache *cc = &o->cache[c];
-  const double rndcool_ion = rng_uniform(p->rngstate) * cc->ion_cooling_contribs[m->nions - 1];
-  const int ui = index_upperbound(cc->ion_cooling_contribs, m->nions, rndcool_ion);
+  const double *cell_ion_contribs = cell_ion_cooling_contribs(o, c);
+  const double rndcool_ion = rng_uniform(p->rngstate) * cell_ion_contribs[m->nions - 1];
+  const int ui = index_upperbound(cell_ion_contribs, m->nions, rndcool_ion);
   if (!(ui < m->nions)) {
     ORACLE_FAIL(o, "do_kpkt: uniqueionindex out of range");
     return;
@@ -1822,7 +1876,7 @@ static void do_kpkt(Oracle *o, artis_packet *p, double t2) {
   ion_from_unique(o, ui, &element, &ion);
   const int ionstart = m->ion_coolingoffset[ui];
   const int nterms = m->ion_ncoolingterms[ui];
-  const double *ion_contribs = cc->cooling_contrib + ionstart;
+  const double *ion_contribs = cooling_ion_contribs(o, c, element, ion);
   const double C_ion_procsum = ion_contribs[nterms - 1];
   const double rndcool_ion_process = rng_uniform(p->rngstate) * C_ion_procsum;
   const int ionoffset = index_upperbound(ion_contribs, nterms, rndcool_ion_process);
@@ -1919,16 +1973,17 @@ static void oracle_init(Oracle *o, const artis_model *m, const artis_cellstate *
   o->T_step_log = (log(ARTIS_OPT_MAXTEMP) - log(ARTIS_OPT_MINTEMP)) / (ARTIS_OPT_TABLESIZE - 1.); /* ratecoeff.cc:39 */
   for (int i = 0; i < ARTIS_OPT_TABLESIZE + 1; i++) o->temperature_grid[i] = ARTIS_OPT_MINTEMP * exp(i * o->T_step_log); /* ratecoeff.cc:41 */
   o->last_phixs_nuovernuedge = (1.0 + (m->NPHIXSNUINCREMENT * (m->NPHIXSPOINTS - 1))); /* input.cc:310 */
+  const char *cap = getenv("ARTIS_ORACLE_CACHE_CAP");
+  o->cache_cap = cap ? atoi(cap) : 0;
 }
+double artis_oracle_last_populate_seconds(void) { return g_last_populate_seconds; }
 static void oracle_free(Oracle *o) {
   for (int c = 0; c < o->m->npts_nonempty; c++) {
     CellCache *cc = &o->cache[c];
-    if (!cc->populated) continue;
-    free(cc->levelpops); free(cc->maprocessrates); free(cc->matrans); free(cc->allcont_nnlevel);
-    free(cc->allcont_departure); free(cc->allcont_edgepart); free(cc->allcont_keepbits);
-    free(cc->corrphotoioncoeff); free(cc->cooling_contrib); free(cc->ion_cooling_contribs);
+    if (cc->populated) cellcache_free_one(cc);
   }
   free(o->cache);
+  g_last_populate_seconds = o->t_populate;
 }
 
 /* update_packets update_packets.cc:530 / do_packet update_packets.cc:257 for the r/k-packet types.
@@ -1986,6 +2041,12 @@ int artis_oracle_cellcache(const artis_model *m, const artis_cellstate *cs, cons
   est.stats = stats;
   oracle_init(&o, m, cs, ts, &est);
   cellcache_populate(&o, nonemptymgi);
+  for (int element = 0; element < m->nelements; element++)
+    for (int ion = 0; ion < get_nions(&o, element); ion++) {
+      for (int level = 0; level < get_nlevels(&o, element, ion); level++) (void)macroatom_levelrates(&o, nonemptymgi, element, ion, level);
+      (void)cooling_ion_contribs(&o, nonemptymgi, element, ion);
+    }
+  (void)cell_ion_cooling_contribs(&o, nonemptymgi);
   const CellCache *cc = &o.cache[nonemptymgi];
   memcpy(levelpops, cc->levelpops, sizeof(double) * (size_t)m->nlevels);
   memcpy(maprocessrates, cc->maprocessrates, sizeof(double) * (size_t)m->nlevels * ARTIS_MA_ACTION_COUNT);

@@ -49,8 +49,22 @@ def compare_estimators(got: abi.Estimators, want: abi.Estimators, rtol: float, w
         assert err <= rtol, f"{what}: estimator {k} differs by {err:.3e} (rel. to max) > {rtol}"
 
 
-def compare_stats(got: abi.Estimators, want: abi.Estimators, what: str = "", skip=(abi.STAT_NAMES.index("UPDATECELL"),)) -> None:
+UPDATECELL = abi.STAT_NAMES.index("UPDATECELL")
+UPSCATTER = abi.STAT_NAMES.index("UPSCATTER")
+DOWNSCATTER = abi.STAT_NAMES.index("DOWNSCATTER")
+
+
+def compare_stats(got: abi.Estimators, want: abi.Estimators, what: str = "", same_libm: bool = True) -> None:
+    """Event counters (stats.h:13 of the reference, plus this project's step counters) must be identical.
+    UPDATECELL is skipped: the engine fills the cache of every cell up front, the oracle on first use.
+    With different math libraries (GPU vs glibc) UPSCATTER and DOWNSCATTER are compared as a sum: the
+    reference classifies a line scattering by `oldnucmf < nu_cmf` (macroatom.cc:232), and for a resonance
+    scattering the two frequencies are equal to the last bit or two, so the split is not a property of the
+    algorithm but of the exp/log rounding of the platform."""
     for i in EXACT_STATS:
-        if i in skip:
+        if i == UPDATECELL:
+            continue
+        if not same_libm and i in (UPSCATTER, DOWNSCATTER):
             continue
         assert got.stats[i] == want.stats[i], f"{what}: event counter {abi.STAT_NAMES[i]}: {got.stats[i]} vs {want.stats[i]}"
+    assert got.stats[UPSCATTER] + got.stats[DOWNSCATTER] == want.stats[UPSCATTER] + want.stats[DOWNSCATTER], what
