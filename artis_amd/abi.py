@@ -36,7 +36,7 @@ STAT_NAMES = [
     "K_STAT_TO_R_BB", "K_STAT_FROM_FF", "K_STAT_FROM_BF", "NT_STAT_FROM_GAMMA", "NT_STAT_TO_IONISATION",
     "NT_STAT_TO_EXCITATION", "NT_STAT_TO_KPKT", "K_STAT_FROM_EARLIERDECAY", "INTERACTIONS", "ELECTRON_SCATTERINGS",
     "RESONANCESCATTERINGS", "CELLCROSSINGS", "UPSCATTER", "DOWNSCATTER", "UPDATECELL", "PKTESCAPES",
-    "X_RPKT_STEPS", "X_KPKT_STEPS", "X_LINES_VISITED", "X_MA_JUMPS", "X_38", "X_39",
+    "X_RPKT_STEPS", "X_KPKT_STEPS", "X_LINES_VISITED", "X_MA_JUMPS", "X_CHI_EVALS", "X_CONT_VISITED",
 ]
 
 # struct artis_packet (include/artis_amd.h), natural C alignment == numpy align=True

@@ -112,31 +112,151 @@ __device__ inline void wave_append(bool flag, int32_t pi, int32_t *list, int32_t
   if (flag) list[base + prefix] = pi;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_build_active(PktSoA P, double ts_end, int32_t *list, int32_t *count) {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  bool act = false;
-  if (i < P.n) act = type_handled(P.type[i]) && P.prop_time[i] < ts_end;
-  wave_append(act, (int32_t)i, list, count);
+// Blocks are dealt round-robin over the 8 XCDs (each with its own L2). The work lists are sorted by cell, so give
+// every XCD one contiguous eighth of the list: the per-cell tables its waves read then stay in that XCD's L2.
+// (Bijective remap of blockIdx -> list chunk; placement only changes speed, never results.)
+__device__ inline int64_t xcd_chunk(int64_t b, int64_t nb) {
+  const int64_t q = nb / 8, r = nb % 8, xcd = b % 8;
+  return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
 }
 
-// ------------------------------------------------------------------ the propagation kernel
-__global__ void __launch_bounds__(BLOCK) k_propagate(Env env, const int32_t *active, int32_t nactive, int32_t *next, int32_t *next_count,
-                                                     unsigned long long *gstats, int budget) {
+// the three work lists of a round and their counters: [0] r-packets, [1] thermal, [2] slow path
+struct Lists {
+  int32_t *r, *t, *s;
+  int32_t *counts;
+};
+__device__ inline void append_by_kind(int kind, int32_t pi, const Lists &L) {
+  wave_append(kind == NEXT_RPKT, pi, L.r, L.counts + 0);
+  wave_append(kind == NEXT_THERMAL, pi, L.t, L.counts + 1);
+  wave_append(kind == NEXT_SLOW, pi, L.s, L.counts + 2);
+}
+__global__ void __launch_bounds__(BLOCK) k_classify(PktSoA P, double ts_end, Lists L) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  int kind = NEXT_DONE;
+  if (i < P.n) {
+    const int type = P.type[i];
+    if (P.pend[i] != PEND_NONE) {
+      kind = NEXT_SLOW;
+    } else if (P.ma_level[i] >= 0) {
+      kind = NEXT_THERMAL;
+    } else if (type_handled(type) && P.prop_time[i] < ts_end) {
+      kind = (type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_THERMAL;
+    }
+  }
+  append_by_kind(kind, (int32_t)i, L);
+}
+
+// ---- counting sort of a work list by propagation cell (three tiny kernels)
+__global__ void __launch_bounds__(BLOCK) k_sort_hist(const int32_t *list, int32_t n, const int32_t *cellindex, int32_t *hist) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) atomicAdd(&hist[cellindex[list[i]]], 1);
+}
+__global__ void __launch_bounds__(1024) k_sort_scan(int32_t *hist, int32_t ncells) {
+  __shared__ int32_t part[1024];
+  const int t = threadIdx.x;
+  const int seg = (ncells + 1023) / 1024;
+  const int lo = t * seg;
+  const int hi = min(lo + seg, ncells);
+  int32_t sum = 0;
+  for (int i = lo; i < hi; i++) sum += hist[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    int32_t v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int32_t run = part[t] - sum;  // exclusive prefix of this segment
+  for (int i = lo; i < hi; i++) {
+    const int32_t h = hist[i];
+    hist[i] = run;
+    run += h;
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_sort_scatter(const int32_t *list, int32_t n, const int32_t *cellindex, int32_t *offsets,
+                                                        int32_t *out) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) {
+    const int32_t pi = list[i];
+    out[atomicAdd(&offsets[cellindex[pi]], 1)] = pi;
+  }
+}
+
+// ------------------------------------------------------------------ the propagation kernels
+#ifndef ARTIS_RPKT_WAVES
+#define ARTIS_RPKT_WAVES 2
+#endif
+#ifndef ARTIS_THERMAL_WAVES
+#define ARTIS_THERMAL_WAVES 4
+#endif
+
+// r-packets in flight: boundary distance, continuum opacity, line-by-line Sobolev walk, estimators, events
+__global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const int32_t *list, int32_t n, Lists next,
+                                                                   unsigned long long *gstats, int budget) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  env.stats = lstats;
+  const int64_t nb = gridDim.x;
+  const int64_t tid = xcd_chunk(blockIdx.x, nb) * BLOCK + threadIdx.x;
+  int kind = NEXT_DONE;
+  int32_t pi = 0;
+  if (tid < n) {
+    pi = list[tid];
+    Pkt p;
+    Chi x;
+    pkt_load(env.P, pi, p);
+    chi_load(env.P, pi, x);
+    kind = advance_rpkt(env, p, pi, x, budget);
+    pkt_store(env.P, pi, p);
+    chi_store(env.P, pi, x);
+  }
+  append_by_kind(kind, pi, next);
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+}
+
+// thermal packets: k-packet cooling-channel sampling and the macro-atom random walk
+__global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
+                                                                         unsigned long long *gstats, int budget) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  env.stats = lstats;
+  const int64_t nb = gridDim.x;
+  const int64_t tid = xcd_chunk(blockIdx.x, nb) * BLOCK + threadIdx.x;
+  int kind = NEXT_DONE;
+  int32_t pi = 0;
+  if (tid < n) {
+    pi = list[tid];
+    Pkt p;
+    pkt_load(env.P, pi, p);
+    kind = advance_thermal(env, p, pi, budget);
+    pkt_store(env.P, pi, p);
+  }
+  append_by_kind(kind, pi, next);
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+}
+
+// slow path: the rare bound-free actions (rate coefficients with exp(), adaptive Gauss-Kronrod frequency sampling)
+__global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   __syncthreads();
   env.stats = lstats;
   const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  bool still = false;
+  int kind = NEXT_DONE;
   int32_t pi = 0;
-  if (tid < nactive) {
-    pi = active[tid];
+  if (tid < n) {
+    pi = list[tid];
     Pkt p;
     pkt_load(env.P, pi, p);
-    still = advance_packet(env, p, pi, tid, budget);
+    kind = advance_slow(env, p, pi);
     pkt_store(env.P, pi, p);
   }
-  wave_append(still, pi, next, next_count);
+  append_by_kind(kind, pi, next);
   __syncthreads();
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
 }
@@ -154,6 +274,8 @@ struct artis_amd_engine {
   std::vector<void *> cache_allocs;
   DevModel M{};  // device pointers
   DevModel Mh{};  // host view (counts)
+  artis_model model_copy{};                        // sizes + level_matransblock_start kept for diagnostics
+  std::vector<int32_t> own_matransblock_start;
   DevCells C{};
   DevCache K{};
   DevStep S{};
@@ -172,14 +294,24 @@ struct artis_amd_engine {
   PktSoA P{};
   artis_packet *d_aos = nullptr;
   int64_t aos_capacity = 0;
-  int32_t *d_list[2] = {nullptr, nullptr};
-  int32_t *d_count = nullptr;  // [2]
+  int32_t *d_rlist[2] = {nullptr, nullptr};  // r-packet work lists (ping-pong)
+  int32_t *d_tlist[2] = {nullptr, nullptr};  // thermal work lists (ping-pong)
+  int32_t *d_slist[2] = {nullptr, nullptr};  // slow-path work lists (ping-pong)
+  int32_t *d_sorted = nullptr;                // counting-sort output
+  int32_t *d_hist = nullptr;                  // [ngrid + 1]
+  int32_t *d_count = nullptr;                 // [8]: two sets of (r, thermal, slow, pad)
   double *d_gamma_ws = nullptr;
   int64_t ws_capacity = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   double last_propagate_ms = 0.;
+  double last_rpkt_ms = 0., last_thermal_ms = 0., last_slow_ms = 0.;
+  hipEvent_t ev4 = nullptr, ev5 = nullptr;
   int64_t last_nlaunches = 0;
-  int budget = 4;
+  int64_t last_rpkt_threads = 0, last_thermal_threads = 0;
+  int budget_r = 8;      // do_rpkt_step() calls per thread per launch
+  int budget_t = 512;    // macro-atom transitions / k-packet steps per thread per launch
+  bool sort_lists = true;
+  bool trace = false;
 };
 
 namespace {
@@ -223,9 +355,13 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
   if (e->d_soa_snapshot) (void)hipFree(e->d_soa_snapshot);
   e->d_soa = e->d_soa_snapshot = nullptr;
   for (int k = 0; k < 2; k++) {
-    if (e->d_list[k]) (void)hipFree(e->d_list[k]);
-    e->d_list[k] = nullptr;
+    if (e->d_rlist[k]) (void)hipFree(e->d_rlist[k]);
+    if (e->d_tlist[k]) (void)hipFree(e->d_tlist[k]);
+    if (e->d_slist[k]) (void)hipFree(e->d_slist[k]);
+    e->d_rlist[k] = e->d_tlist[k] = e->d_slist[k] = nullptr;
   }
+  if (e->d_sorted) (void)hipFree(e->d_sorted);
+  e->d_sorted = nullptr;
   if (e->d_gamma_ws) (void)hipFree(e->d_gamma_ws);
   e->d_gamma_ws = nullptr;
   e->npackets = n;
@@ -233,7 +369,12 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
   HIP_TRY(hipMalloc(&e->d_soa, e->soa_bytes));
   e->P = carve_pkt_soa(e->d_soa, n);
   const size_t listbytes = sizeof(int32_t) * (size_t)(n > 0 ? n : 1);
-  for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void **)&e->d_list[k], listbytes));
+  for (int k = 0; k < 2; k++) {
+    HIP_TRY(hipMalloc((void **)&e->d_rlist[k], listbytes));
+    HIP_TRY(hipMalloc((void **)&e->d_tlist[k], listbytes));
+    HIP_TRY(hipMalloc((void **)&e->d_slist[k], listbytes));
+  }
+  HIP_TRY(hipMalloc((void **)&e->d_sorted, listbytes));
   e->ws_capacity = n > 0 ? n : 1;
   const size_t wsbytes = sizeof(double) * (size_t)(e->Mh.nbfcontinua_ground + 1) * (size_t)e->ws_capacity;
   HIP_TRY(hipMalloc((void **)&e->d_gamma_ws, wsbytes));
@@ -275,6 +416,9 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   artis_amd_engine *e = new artis_amd_engine();
   e->device = device;
   e->Mh = make_host_model_view(*model, e->own);
+  e->model_copy = *model;
+  e->own_matransblock_start.assign(model->level_matransblock_start, model->level_matransblock_start + model->nlevels);
+  e->model_copy.level_matransblock_start = e->own_matransblock_start.data();
   e->M = e->Mh;
   const DevModel &h = e->Mh;
 #define UP(f, T, count)                                                                     \
@@ -325,10 +469,22 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
   HIP_TRY(hipMemset(e->d_err, 0, sizeof(int32_t)));
-  HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 2));
+  HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 8));
+  HIP_TRY(hipMalloc((void **)&e->d_hist, sizeof(int32_t) * (size_t)(h.ngrid + 1)));
   HIP_TRY(hipEventCreate(&e->ev0));
   HIP_TRY(hipEventCreate(&e->ev1));
-  if (const char *b = std::getenv("ARTIS_AMD_BUDGET")) e->budget = std::max(1, std::atoi(b));
+  HIP_TRY(hipEventCreate(&e->ev2));
+  HIP_TRY(hipEventCreate(&e->ev3));
+  HIP_TRY(hipEventCreate(&e->ev4));
+  HIP_TRY(hipEventCreate(&e->ev5));
+  if (const char *b = std::getenv("ARTIS_AMD_BUDGET")) {  // tuning / tests: launch budgets never change results
+    e->budget_r = std::max(1, std::atoi(b));
+    e->budget_t = std::max(1, std::atoi(b));
+  }
+  if (const char *b = std::getenv("ARTIS_AMD_BUDGET_R")) e->budget_r = std::max(1, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_BUDGET_T")) e->budget_t = std::max(1, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
+  e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
   *out = e;
   return ARTIS_OK;
 }
@@ -339,12 +495,12 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->model_allocs);
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
-  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_list[0], e->d_list[1], e->d_count,
-                  e->d_gamma_ws};
+  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_rlist[0], e->d_rlist[1],
+                  e->d_tlist[0], e->d_tlist[1], e->d_slist[0], e->d_slist[1], e->d_sorted, e->d_hist, e->d_count, e->d_gamma_ws};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
-  if (e->ev0) (void)hipEventDestroy(e->ev0);
-  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3, e->ev4, e->ev5})
+    if (ev) (void)hipEventDestroy(ev);
   delete e;
 }
 
@@ -461,6 +617,21 @@ int artis_amd_packets_restore(artis_amd_engine *e) {
   return ARTIS_OK;
 }
 
+namespace {
+// sort list[0..n) by propagation cell into e->d_sorted; returns the pointer to launch on
+int sort_by_cell(artis_amd_engine *e, hipStream_t s, int32_t *list, int32_t n, const int32_t **out) {
+  *out = list;
+  if (!e->sort_lists || n < 2 * BLOCK) return ARTIS_OK;
+  const int32_t ngrid = e->Mh.ngrid;
+  HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(ngrid + 1), s));
+  hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, n, e->P.cellindex, e->d_hist);
+  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, e->d_hist, ngrid);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, n, e->P.cellindex, e->d_hist, e->d_sorted);
+  *out = e->d_sorted;
+  return ARTIS_OK;
+}
+}  // namespace
+
 int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   if (!e || !e->have_cells || !e->d_soa) {
     g_last_error = "engine needs artis_amd_set_cellstate() and resident packets first";
@@ -468,40 +639,81 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   }
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = (hipStream_t)hip_stream;
-  e->last_propagate_ms = 0.;
+  e->last_propagate_ms = e->last_rpkt_ms = e->last_thermal_ms = 0.;
   e->last_nlaunches = 0;
+  e->last_rpkt_threads = e->last_thermal_threads = 0;
   const int64_t n = e->npackets;
   if (n == 0) return ARTIS_OK;
   Env env = make_env(e);
-  int32_t counts[2] = {0, 0};
-  HIP_TRY(hipMemsetAsync(e->d_count, 0, sizeof(int32_t) * 2, s));
-  hipLaunchKernelGGL(k_build_active, dim3(nblocks(n)), dim3(BLOCK), 0, s, e->P, e->S.ts_end, e->d_list[0], e->d_count);
-  HIP_TRY(hipMemcpyAsync(counts, e->d_count, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  int32_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int cur = 0;
-  int32_t nactive = counts[0];
+  auto lists_of = [&](int k) { return Lists{e->d_rlist[k], e->d_tlist[k], e->d_slist[k], e->d_count + 4 * k}; };
+  HIP_TRY(hipMemsetAsync(e->d_count, 0, sizeof(int32_t) * 8, s));
+  hipLaunchKernelGGL(k_classify, dim3(nblocks(n)), dim3(BLOCK), 0, s, e->P, e->S.ts_end, lists_of(cur));
+  HIP_TRY(hipMemcpyAsync(counts, e->d_count, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int32_t nr = counts[4 * cur], nt = counts[4 * cur + 1], ns = counts[4 * cur + 2];
+  e->last_slow_ms = 0.;
   int64_t guard = 0;
-  while (nactive > 0) {
+  while (nr > 0 || nt > 0 || ns > 0) {
     const int nxt = 1 - cur;
-    HIP_TRY(hipMemsetAsync(e->d_count + nxt, 0, sizeof(int32_t), s));
-    HIP_TRY(hipEventRecord(e->ev0, s));
-    hipLaunchKernelGGL(k_propagate, dim3(nblocks(nactive)), dim3(BLOCK), 0, s, env, e->d_list[cur], nactive, e->d_list[nxt],
-                       e->d_count + nxt, e->d_stats, e->budget);
-    HIP_TRY(hipEventRecord(e->ev1, s));
-    HIP_TRY(hipMemcpyAsync(counts, e->d_count, sizeof(int32_t) * 2, hipMemcpyDeviceToHost, s));
+    const Lists next = lists_of(nxt);
+    HIP_TRY(hipMemsetAsync(e->d_count + 4 * nxt, 0, sizeof(int32_t) * 4, s));
+    if (nr > 0) {
+      const int32_t *lst = nullptr;
+      int rc = sort_by_cell(e, s, e->d_rlist[cur], nr, &lst);
+      if (rc != ARTIS_OK) return rc;
+      HIP_TRY(hipEventRecord(e->ev0, s));
+      hipLaunchKernelGGL(k_rpkt, dim3(nblocks(nr)), dim3(BLOCK), 0, s, env, lst, nr, next, e->d_stats, e->budget_r);
+      HIP_TRY(hipEventRecord(e->ev1, s));
+    }
+    if (nt > 0) {
+      const int32_t *lst = nullptr;
+      int rc = sort_by_cell(e, s, e->d_tlist[cur], nt, &lst);
+      if (rc != ARTIS_OK) return rc;
+      HIP_TRY(hipEventRecord(e->ev2, s));
+      hipLaunchKernelGGL(k_thermal, dim3(nblocks(nt)), dim3(BLOCK), 0, s, env, lst, nt, next, e->d_stats, e->budget_t);
+      HIP_TRY(hipEventRecord(e->ev3, s));
+    }
+    if (ns > 0) {
+      HIP_TRY(hipEventRecord(e->ev4, s));
+      hipLaunchKernelGGL(k_slow, dim3(nblocks(ns)), dim3(BLOCK), 0, s, env, e->d_slist[cur], ns, next, e->d_stats);
+      HIP_TRY(hipEventRecord(e->ev5, s));
+    }
+    HIP_TRY(hipMemcpyAsync(counts, e->d_count, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-    e->last_propagate_ms += ms;
-    e->last_nlaunches++;
-    nactive = counts[nxt];
+    float ms_r = 0.f, ms_t = 0.f, ms_s = 0.f;
+    if (nr > 0) {
+      HIP_TRY(hipEventElapsedTime(&ms_r, e->ev0, e->ev1));
+      e->last_rpkt_ms += ms_r;
+      e->last_rpkt_threads += nr;
+      e->last_nlaunches++;
+    }
+    if (nt > 0) {
+      HIP_TRY(hipEventElapsedTime(&ms_t, e->ev2, e->ev3));
+      e->last_thermal_ms += ms_t;
+      e->last_thermal_threads += nt;
+      e->last_nlaunches++;
+    }
+    if (ns > 0) {
+      HIP_TRY(hipEventElapsedTime(&ms_s, e->ev4, e->ev5));
+      e->last_slow_ms += ms_s;
+      e->last_nlaunches++;
+    }
+    if (e->trace)
+      fprintf(stderr, "[artis_amd] round %lld: rpkt n=%d %.3f ms | thermal n=%d %.3f ms | slow n=%d %.3f ms\n", (long long)guard, nr,
+              ms_r, nt, ms_t, ns, ms_s);
+    nr = counts[4 * nxt];
+    nt = counts[4 * nxt + 1];
+    ns = counts[4 * nxt + 2];
     cur = nxt;
     if (++guard > 100000000LL) {
       g_last_error = "packet loop did not terminate";
       return ARTIS_ERR_NOTCONVERGED;
     }
   }
+  e->last_propagate_ms = e->last_rpkt_ms + e->last_thermal_ms + e->last_slow_ms;
   int32_t err = 0;
   HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
   if (err != 0) {
@@ -577,6 +789,16 @@ int artis_amd_last_kernel_ms(artis_amd_engine *e, double *propagate_ms, int64_t 
   return ARTIS_OK;
 }
 
+int artis_amd_last_kernel_breakdown(artis_amd_engine *e, double *rpkt_ms, int64_t *rpkt_threads, double *thermal_ms,
+                                    int64_t *thermal_threads) {
+  if (!e) return ARTIS_ERR_ARG;
+  if (rpkt_ms) *rpkt_ms = e->last_rpkt_ms;
+  if (rpkt_threads) *rpkt_threads = e->last_rpkt_threads;
+  if (thermal_ms) *thermal_ms = e->last_thermal_ms;
+  if (thermal_threads) *thermal_threads = e->last_thermal_threads;
+  return ARTIS_OK;
+}
+
 int artis_amd_debug_cellcache(artis_amd_engine *e, int c, double *levelpops, double *maprocessrates, double *matrans,
                               double *allcont_nnlevel, double *allcont_departure, double *allcont_edgepart,
                               uint64_t *allcont_keepbits, double *corrphotoioncoeff, double *cooling_contrib,
@@ -590,8 +812,11 @@ int artis_amd_debug_cellcache(artis_amd_engine *e, int c, double *levelpops, dou
 #define DL(dst, f, T, per)                                                                                            \
   if (dst && (per) > 0) HIP_TRY(hipMemcpy(dst, e->K.f + (int64_t)c * (per), sizeof(T) * (size_t)(per), hipMemcpyDeviceToHost));
   DL(levelpops, levelpops, double, h.nlevels)
-  DL(maprocessrates, maprocessrates, double, (int64_t)h.nlevels * 9)
-  DL(matrans, matrans, double, h.nmatransblock)
+  if (maprocessrates || matrans) {
+    std::vector<double> row((size_t)h.nmacache + 1);
+    HIP_TRY(hipMemcpy(row.data(), e->K.macache + (int64_t)c * h.nmacache, sizeof(double) * (size_t)h.nmacache, hipMemcpyDeviceToHost));
+    unpack_macache_row(h, e->model_copy, row.data(), maprocessrates, matrans);
+  }
   DL(allcont_nnlevel, allcont_nnlevel, double, h.nbfcontinua)
   DL(allcont_departure, allcont_departure, double, h.nbfcontinua)
   DL(allcont_edgepart, allcont_edgepart, double, h.nbfcontinua)

@@ -15,6 +15,7 @@ struct ModelOwned {
   std::vector<double> temperature_grid;
   std::vector<int32_t> level_ion;
   std::vector<LinePack> line_pack;
+  std::vector<LevelPack> level_pack;
 };
 
 // X(field, element type, element count) for every array pointer of DevModel
@@ -42,6 +43,7 @@ struct ModelOwned {
   X(level_bflist_start, int32_t, (m).nlevels)                                      \
   X(level_matransblock_start, int32_t, (m).nlevels)                                \
   X(level_ion, int32_t, (m).nlevels)                                               \
+  X(level_pack, LevelPack, (m).nlevels)                                            \
   X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
   X(alltrans_einstein_A, float, (m).nalltrans)                                     \
@@ -93,8 +95,7 @@ struct ModelOwned {
 // X(field, element type, elements per cell) for every array of DevCache
 #define ARTIS_CACHE_ARRAYS(X, m)                                \
   X(levelpops, double, (m).nlevels)                             \
-  X(maprocessrates, double, ((int64_t)(m).nlevels * 9))         \
-  X(matrans, double, (m).nmatransblock)                         \
+  X(macache, double, (m).nmacache)                              \
   X(allcont_nnlevel, double, (m).nbfcontinua)                   \
   X(allcont_departure, double, (m).nbfcontinua)                 \
   X(allcont_edgepart, double, (m).nbfcontinua)                  \
@@ -128,6 +129,15 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.temperature_grid = own.temperature_grid.data();
   v.level_ion = own.level_ion.data();
   v.line_pack = own.line_pack.data();
+  own.level_pack.resize(m.nlevels);
+  int32_t rec = 0;
+  for (int i = 0; i < m.nlevels; i++) {
+    own.level_pack[i] = LevelPack{rec, m.level_alltrans_startdown[i], m.level_ndowntrans[i], m.level_nuptrans[i]};
+    const int sz = 9 + 2 * m.level_ndowntrans[i] + m.level_nuptrans[i];
+    rec += ((sz + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
+  }
+  v.nmacache = rec;
+  v.level_pack = own.level_pack.data();
 #define ARTIS_COPY_PTR(f) v.f = m.f;
   ARTIS_COPY_PTR(elem_nions) ARTIS_COPY_PTR(elem_uniqueionindexstart) ARTIS_COPY_PTR(elem_lowest_ionstage)
   ARTIS_COPY_PTR(ion_element) ARTIS_COPY_PTR(ion_nlevels) ARTIS_COPY_PTR(ion_nlevels_ionising)
@@ -161,6 +171,27 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   return v;
 }
 
+// Unpack one cell's row of macro-atom records into the reference's two arrays (globals.h:286-287):
+// alllevels_maprocessrates [nlevels*9] and allmacroatomictransitions [nmatransblock] (block order of input.cc:1542:
+// per level: radiative de-excitation sums, internal-down-same sums, internal-up-same sums).
+inline void unpack_macache_row(const DevModel &hostview, const artis_model &m, const double *row, double *maprocessrates,
+                               double *matrans) {
+  for (int ul = 0; ul < m.nlevels; ul++) {
+    const LevelPack lp = hostview.level_pack[ul];
+    const double *rec = row + lp.rec_off;
+    if (maprocessrates)
+      for (int a = 0; a < 9; a++) maprocessrates[(int64_t)ul * 9 + a] = rec[a];
+    if (matrans) {
+      double *blk = matrans + m.level_matransblock_start[ul];
+      for (int i = 0; i < lp.ndown; i++) {
+        blk[i] = rec[9 + lp.ndown + lp.nup + i];
+        blk[lp.ndown + i] = rec[9 + i];
+      }
+      for (int i = 0; i < lp.nup; i++) blk[2 * lp.ndown + i] = rec[9 + lp.ndown + i];
+    }
+  }
+}
+
 inline DevCells make_host_cells_view(const artis_cellstate &c) {
   DevCells v;
   v.rho = c.rho; v.Te = c.Te; v.TJ = c.TJ; v.TR = c.TR; v.W = c.W; v.nne = c.nne; v.nnetot = c.nnetot;
@@ -188,7 +219,7 @@ inline PktSoA carve_pkt_soa(void *base, int64_t n) {
   double *d = (double *)base;
   double **cols64[] = {&P.prop_time, &P.pos_x, &P.pos_y, &P.pos_z, &P.dir_x, &P.dir_y, &P.dir_z, &P.nu_cmf, &P.e_cmf, &P.nu_rf,
                        &P.e_rf, &P.stokes_q, &P.stokes_u, &P.em_pos_x, &P.em_pos_y, &P.em_pos_z, &P.trueem_pos_x, &P.trueem_pos_y,
-                       &P.trueem_pos_z, &P.absorptionfreq};
+                       &P.trueem_pos_z, &P.absorptionfreq, &P.chi_nu, &P.chi_es, &P.chi_ff, &P.chi_bf};
   static_assert(sizeof(cols64) / sizeof(cols64[0]) == PKT_NCOL64, "64-bit column count");
   for (auto c : cols64) {
     *c = d;
@@ -198,7 +229,8 @@ inline PktSoA carve_pkt_soa(void *base, int64_t n) {
   P.rng = w;  // 4 columns, but strided by the true n (see pkt_load)
   w += 4 * n8;
   int32_t **cols32[] = {&P.next_trans, &P.nscatterings, &P.type, &P.cellindex, &P.emissiontype, &P.absorptiontype,
-                        &P.trueemissiontype, &P.escape_type};
+                        &P.trueemissiontype, &P.escape_type, &P.chi_mgi, &P.ma_element, &P.ma_ion, &P.ma_level, &P.ma_line,
+                        &P.ma_origin, &P.pend, &P.pend_arg};
   for (auto c : cols32) {
     *c = (int32_t *)w;
     w += n8;

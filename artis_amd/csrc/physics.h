@@ -80,7 +80,11 @@ struct Pkt {
   uint32_t s0, s1, s2, s3;
   double prop_time, px, py, pz, dx, dy, dz, nu_cmf, e_cmf, nu_rf, e_rf, stokes_q, stokes_u;
   int32_t next_trans, nscatterings, type, cellindex;
+  // an activated macro-atom that has not deactivated yet (ma_level < 0: none); see tables.h PktSoA
+  int32_t ma_element, ma_ion, ma_level, ma_line, ma_origin;
+  int32_t pend, pend_arg;  // see tables.h PktSoA
 };
+enum { PEND_NONE = 0, PEND_MA_ACTION = 2, PEND_KPKT_FB = 3 };
 
 // ContinuumOpacity (rpkt.h:70); groundcont_gamma_contr lives in env.gamma_ws
 struct Chi {
@@ -346,6 +350,23 @@ AHD int upper_bound_d(const double *a, int n, double v) {
     if (!(v < a[lo + half])) { lo += half + 1; len -= half + 1; } else { len = half; }
   }
   return lo;
+}
+// upper_bound on a non-decreasing array as "count the elements <= v", 8 independent loads per round trip instead of
+// one dependent load per bisection step (same result as upper_bound_d for any non-decreasing input)
+AHD int upper_bound_wide(const double *a, int n, double v) {
+  int idx = 0;
+  for (int base = 0; base < n; base += 8) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int i = base + k;
+      const double x = (i < n) ? a[i] : DBLMAX;
+      cnt += (i < n && x <= v) ? 1 : 0;
+    }
+    idx += cnt;
+    if (cnt < 8) break;
+  }
+  return idx;
 }
 AHD int lower_bound_d(const double *a, int n, double v) {
   int lo = 0, len = n;
@@ -693,8 +714,11 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   const int start = M.ion_uniquelevelindexstart[ui];
   const int level = ul - start;
   const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
-  double *rates = env.K.maprocessrates + (((int64_t)c * M.nlevels + ul) * MA_N);
-  double *block = env.K.matrans + ((int64_t)c * M.nmatransblock) + M.level_matransblock_start[ul];
+  const LevelPack lpk = M.level_pack[ul];
+  double *rates = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
+  double *blk_down = rates + MA_N;                       // cumulative internal-down-same
+  double *blk_up = blk_down + lpk.ndown;                 // cumulative internal-up-same
+  double *blk_rad = blk_up + lpk.nup;                    // cumulative radiative de-excitation
   const double t_mid = env.S.mid;
   const float T_e = env.C.Te[c];
   const float cnne = clumpednne(env.C, c);
@@ -717,8 +741,8 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
     s_raddeexc += R * e_trans;
     s_coldeexc += Cc * e_trans;
     s_down_same += (R + Cc) * e_target;
-    block[i] = s_raddeexc;
-    block[ndown + i] = s_down_same;
+    blk_rad[i] = s_raddeexc;
+    blk_down[i] = s_down_same;
   }
   rates[ARTIS_MA_ACTION_RADDEEXC] = s_raddeexc;
   rates[ARTIS_MA_ACTION_COLDEEXC] = s_coldeexc;
@@ -736,7 +760,7 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
     const double Cc = col_exc(M, T_e, cnne, e_trans, g_up, g_cur, ati);
     const double NT = 0.;
     s_up_same += (R + Cc + NT) * e_cur;
-    block[(2 * ndown) + ii] = s_up_same;
+    blk_up[ii] = s_up_same;
   }
   rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s_up_same;
 
@@ -887,6 +911,7 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   const bool split_usable = (ex >= DBLMIN);
   const int cend = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
   const int cbegin = lower_bound_d(M.allcont_nu_edge, cend, nu / M.last_phixs_nuovernuedge);
+  int nvisited = 0;
   const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
   const double *nnl = env.K.allcont_nnlevel + ((int64_t)c * M.nbfcontinua);
   const double *edgepart = env.K.allcont_edgepart + ((int64_t)c * M.nbfcontinua);
@@ -898,6 +923,7 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
     while (bits != 0) {
       const int i = (word * 64) + __builtin_ctzll(bits);
       bits &= bits - 1;
+      nvisited++;
       const double nnlevel = nnl[i];
       const double nu_edge = M.allcont_nu_edge[i];
       const double sigma_bf = phixs_fromtable(M, phixs_table(M, M.allcont_uniquelevelindex[i]), nu_edge, nu);
@@ -920,6 +946,10 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
         return sum;
       }
     }
+  }
+  if (!SELECT) {
+    ARTIS_STAT(env, ARTIS_STAT_X_CHI_EVALS);
+    ARTIS_STAT_ADD(env, ARTIS_STAT_X_CONT_VISITED, nvisited);
   }
   if (SELECT) {
     *selected = cend - 1;
@@ -1063,7 +1093,7 @@ AHD void set_trueem_from_em(const Env &env, int64_t pi) {
 }
 
 // electron_scatter_rpkt rpkt.cc:331
-ANOINLINE void electron_scatter(Pkt &p) {
+AHD void electron_scatter(Pkt &p) {
   p.type = ARTIS_TYPE_RPKT;
   const double vel[3] = {p.px / p.prop_time, p.py / p.prop_time, p.pz / p.prop_time};
   const double dir[3] = {p.dx, p.dy, p.dz};
@@ -1249,8 +1279,12 @@ AHD double integrator31(const FbIntegrand &f, const GK31 &g, double a, double b,
   return gk31_adaptive(f, g, epsrel, a, b, abserr);
 }
 // select_continuum_nu ratecoeff.cc:563
-ANOINLINE double select_continuum_nu(const Env &env, int element, int lowerion, int lower, int t, float T_e, Pkt &p) {
-  const DevModel &M = env.M;
+struct Rng4 {
+  uint32_t s0, s1, s2, s3;
+};
+ANOINLINE double select_continuum_nu_impl(const DevModel &M, int element, int lowerion, int lower, int t, float T_e, Rng4 *rs) {
+  Pkt p;  // only the generator words are used
+  p.s0 = rs->s0; p.s1 = rs->s1; p.s2 = rs->s2; p.s3 = rs->s3;
   const GK31 g = gk31_tables();
   const int ul = lstart(M, element, lowerion) + lower;
   const double E_threshold = phixs_threshold(M, element, lowerion, lower, t);
@@ -1263,7 +1297,10 @@ ANOINLINE double select_continuum_nu(const Env &env, int element, int lowerion, 
   const double deltanu = nu_range / npieces;
   double error = 0.;
   const double total = integrator31(f, g, 0., nu_range, 1e-3, &error);
-  if (!(total > 0.) || !isfinite(total)) return nu_threshold;
+  if (!(total > 0.) || !isfinite(total)) {
+    rs->s0 = p.s0; rs->s1 = p.s1; rs->s2 = p.s2; rs->s3 = p.s3;
+    return nu_threshold;
+  }
   double tail_prev = total;
   double tail = total;
   int i = 1;
@@ -1279,175 +1316,33 @@ ANOINLINE double select_continuum_nu(const Env &env, int element, int lowerion, 
   } else if (tail > 0.) {
     nuoffset = (tail - (total * zrand)) / tail * deltanu;
   }
+  rs->s0 = p.s0; rs->s1 = p.s1; rs->s2 = p.s2; rs->s3 = p.s3;
   return nu_threshold + ((i - 1) * deltanu) + nuoffset;
+}
+AHD double select_continuum_nu(const Env &env, int element, int lowerion, int lower, int t, float T_e, Pkt &p) {
+  Rng4 rs = {p.s0, p.s1, p.s2, p.s3};
+  const double nu = select_continuum_nu_impl(env.M, element, lowerion, lower, t, T_e, &rs);
+  p.s0 = rs.s0; p.s1 = rs.s1; p.s2 = rs.s2; p.s3 = rs.s3;
+  return nu;
 }
 
 // ---------------------------------------------------------------- do_macroatom macroatom.cc:360
-ANOINLINE void do_macroatom(const Env &env, Pkt &p, int64_t pi, const MAState &mastate) {
-  const DevModel &M = env.M;
-  const int c = M.propcell_nonemptymgi[p.cellindex];
-  const float T_e = env.C.Te[c];
-  const float cnne = clumpednne(env.C, c);
-  const double *cellrates = env.K.maprocessrates + ((int64_t)c * M.nlevels * MA_N);
-  const double *cellblock = env.K.matrans + ((int64_t)c * M.nmatransblock);
-  const int element = mastate.element;
-  int ion = mastate.ion;
-  int level = mastate.level;
-  const int activatingline = mastate.activatingline;
-  int njumps = 0;
-  bool end_packet = false;
-  while (!end_packet) {
-    njumps++;
-    const int ui = uion(M, element, ion);
-    const int start = M.ion_uniquelevelindexstart[ui];
-    const int ul = start + level;
-    const double e_cur = eps(M, ul);
-    const double *rates = cellrates + ((int64_t)ul * MA_N);
-    double cum[MA_N];
-    double total = 0.;
-    {
-      // std::partial_sum macroatom.cc:425
-      cum[0] = rates[0];
-      for (int i = 1; i < MA_N; i++) cum[i] = cum[i - 1] + rates[i];
-      total = cum[MA_N - 1];
-    }
-    if (!(total > 0.)) {
-      fail(env, 40);
-      break;
-    }
-    const double randomrate = rng_uniform(p) * total;
-    int action = 0;  // index_upperbound over 9 entries (sn3d.h:85)
-    while (action < MA_N && !(randomrate < cum[action])) action++;
-    if (action > MA_N - 1) action = MA_N - 1;
-    ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
-    if (action == ARTIS_MA_ACTION_RADDEEXC) {
-      // do_macroatom_raddeexcitation macroatom.cc:204
-      const double targetval = rng_uniform(p) * rates[ARTIS_MA_ACTION_RADDEEXC];
-      const int ndown = M.level_ndowntrans[ul];
-      const double *sums = cellblock + M.level_matransblock_start[ul];
-      const int dti = upper_bound_d(sums, ndown - 1, targetval);
-      const int startdown = M.level_alltrans_startdown[ul];
-      const int lineindex = M.alltrans_lineindex[startdown + dti];
-      if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
-      const int lul = start + M.alltrans_targetlevelindex[startdown + dti];
-      const double e_trans = e_cur - eps(M, lul);
-      const double oldnucmf = p.nu_cmf;
-      p.nu_cmf = e_trans / HPLANCK;
-      if (activatingline >= 0) ARTIS_STAT(env, (oldnucmf < p.nu_cmf) ? ARTIS_STAT_UPSCATTER : ARTIS_STAT_DOWNSCATTER);
-      ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_BB);
-      emit_rpkt(env, p, pi);
-      p.next_trans = lineindex + 1;
-      env.P.emissiontype[pi] = lineindex;
-      p.nscatterings = 0;
-      end_packet = true;
-    } else if (action == ARTIS_MA_ACTION_COLDEEXC || action == ARTIS_MA_ACTION_COLRECOMB) {
-      ARTIS_STAT(env, action == ARTIS_MA_ACTION_COLDEEXC ? ARTIS_STAT_MA_DEACTIVATION_COLLDEEXC : ARTIS_STAT_MA_DEACTIVATION_COLLRECOMB);
-      p.type = ARTIS_TYPE_KPKT;
-      end_packet = true;
-#if !ARTIS_OPT_DIRECT_COL_HEAT
-      ARTIS_EST_ADD(&env.E.colheatingestimator[c], p.e_cmf);
-#endif
-    } else if (action == ARTIS_MA_ACTION_INTERNALDOWNSAME) {
-      const double targetval = rng_uniform(p) * rates[ARTIS_MA_ACTION_INTERNALDOWNSAME];
-      const int ndown = M.level_ndowntrans[ul];
-      const double *sums = cellblock + M.level_matransblock_start[ul] + ndown;
-      const int dti = upper_bound_d(sums, ndown - 1, targetval);
-      level = M.alltrans_targetlevelindex[M.level_alltrans_startdown[ul] + dti];
-    } else if (action == ARTIS_MA_ACTION_RADRECOMB) {
-      // do_macroatom_radrecomb macroatom.cc:248
-      const double targetval = rng_uniform(p) * rates[ARTIS_MA_ACTION_RADRECOMB];
-      double rate = 0;
-      const int nl = M.ion_nlevels_ionising[ui - 1];
-      const int ls = M.ion_uniquelevelindexstart[ui - 1];
-      int lowerlevel = -1, sel_t = -1;
-      for (int l = 0; l < nl; l++) {
-        const int t = find_phixstarget(M, ls + l, level);
-        if (t < 0) continue;
-        const double e_trans = e_cur - eps(M, ls + l);
-        const double R = rad_recomb(M, T_e, cnne, element, ion, l, t);
-        rate += R * e_trans;
-        if (targetval < rate) {
-          lowerlevel = l;
-          sel_t = t;
-          break;
-        }
-      }
-      if (lowerlevel < 0) {
-        fail(env, 41);
-        break;
-      }
-      p.nu_cmf = select_continuum_nu(env, element, ion - 1, lowerlevel, sel_t, T_e, p);
-      ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_FB);
-      emit_rpkt(env, p, pi);
-      p.next_trans = -1;
-      env.P.emissiontype[pi] = emtype_continuum(M, ls + lowerlevel, sel_t);
-      p.nscatterings = 0;
-      level = lowerlevel;
-      ion -= 1;
-      end_packet = true;
-    } else if (action == ARTIS_MA_ACTION_INTERNALDOWNLOWER) {
-      ARTIS_STAT(env, ARTIS_STAT_MA_INTERNALDOWNLOWER);
-      const double targetrate = rng_uniform(p) * rates[ARTIS_MA_ACTION_INTERNALDOWNLOWER];
-      double rate = 0.;
-      const int nl = M.ion_nlevels_ionising[ui - 1];
-      const int ls = M.ion_uniquelevelindexstart[ui - 1];
-      int lower = -1;
-      for (int l = 0; l < nl; l++) {
-        const int t = find_phixstarget(M, ls + l, level);
-        if (t < 0) continue;
-        const double e_target = eps(M, ls + l);
-        const double e_trans = e_cur - e_target;
-        const double R = rad_recomb(M, T_e, cnne, element, ion, l, t);
-        const double Cc = col_recomb(M, T_e, cnne, element, ion, l, t, e_trans);
-        rate += (R + Cc) * e_target;
-        if (rate > targetrate) {
-          lower = l;
-          break;
-        }
-      }
-      if (lower < 0) {
-        fail(env, 42);
-        break;
-      }
-      ion--;
-      level = lower;
-    } else if (action == ARTIS_MA_ACTION_INTERNALUPSAME) {
-      const int ndown = M.level_ndowntrans[ul];
-      const int nup = M.level_nuptrans[ul];
-      const double *sums = cellblock + M.level_matransblock_start[ul] + (2 * ndown);
-      const double targetval = rng_uniform(p) * rates[ARTIS_MA_ACTION_INTERNALUPSAME];
-      const int uti = upper_bound_d(sums, nup - 1, targetval);
-      level = M.alltrans_targetlevelindex[M.level_alltrans_startdown[ul] + ndown + uti];
-    } else if (action == ARTIS_MA_ACTION_INTERNALUPHIGHER) {
-      ARTIS_STAT(env, ARTIS_STAT_MA_INTERNALUPHIGHER);
-      // do_macroatom_ionisation macroatom.cc:298
-      const double targetrate = rng_uniform(p) * rates[ARTIS_MA_ACTION_INTERNALUPHIGHER];
-      double rate = 0.;
-      const int nt = M.level_nphixstargets[ul];
-      const double *cpc = env.K.corrphotoioncoeff + ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
-      int newlevel = -1;
-      for (int t = 0; t < nt; t++) {
-        const double e_trans = phixs_threshold(M, element, ion, level, t);
-        const double R = cpc[t];
-        const double Cc = col_ion(M, T_e, cnne, element, ion, level, t, e_trans);
-        rate += (R + Cc) * e_cur;
-        if (rate > targetrate) {
-          newlevel = phixs_upperlevel(M, ul, t);
-          break;
-        }
-      }
-      if (newlevel < 0) {
-        fail(env, 43);
-        break;
-      }
-      level = newlevel;
-      ion += 1;
-    } else {
-      fail(env, 44);  // MA_ACTION_INTERNALUPHIGHERNT needs NT_ON
-      break;
-    }
-  }
-  ARTIS_STAT_ADD(env, ARTIS_STAT_X_MA_JUMPS, njumps);
+// The reference runs a macro-atom to deactivation inside do_macroatom(). Here the activation only records
+// the state in the packet (ma_activate) and the walk is advanced one transition at a time by ma_jump(), so
+// that the thermal kernel can interleave packets at any point of their walk. The sequence of operations on a
+// packet (and so its random numbers) is the reference's.
+AHD void ma_activate(Pkt &p, const MAState &ma, int origin_rpkt) {
+  p.ma_element = ma.element;
+  p.ma_ion = ma.ion;
+  p.ma_level = ma.level;
+  p.ma_line = ma.activatingline;
+  p.ma_origin = origin_rpkt;
+}
+AHD bool ma_pending(const Pkt &p) { return p.ma_level >= 0; }
+
+// end of do_macroatom(), macroatom.cc:579-595
+AHD void ma_finish(const Env &env, Pkt &p, int64_t pi) {
+  p.ma_level = -1;
   if (p.type == ARTIS_TYPE_RPKT) {
     if (env.P.trueemissiontype[pi] == ARTIS_EMTYPE_NOTSET) {
       env.P.trueemissiontype[pi] = env.P.emissiontype[pi];
@@ -1455,6 +1350,215 @@ ANOINLINE void do_macroatom(const Env &env, Pkt &p, int64_t pi, const MAState &m
     }
   } else {
     env.P.trueemissiontype[pi] = ARTIS_EMTYPE_NOTSET;
+  }
+}
+
+// per-launch invariants of a thermal packet (it never changes cell while thermal)
+struct MACtx {
+  int c;                    // non-empty model cell
+  const double *cellma;     // the cell's row of macro-atom records
+  int start_key, start;     // cached get_ionuniquelevelindexstart(element, ion)
+};
+AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
+  MACtx k;
+  k.c = env.M.propcell_nonemptymgi[p.cellindex];
+  k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
+  k.start_key = -1;
+  k.start = 0;
+  return k;
+}
+
+// one iteration of the loop of do_macroatom(), macroatom.cc:385-577
+AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
+  const DevModel &M = env.M;
+  const int c = k.c;
+  const int element = p.ma_element;
+  const int ion = p.ma_ion;
+  const int level = p.ma_level;
+  const int activatingline = p.ma_line;
+  ARTIS_STAT(env, ARTIS_STAT_X_MA_JUMPS);
+  const int key = (element << 8) | ion;
+  if (key != k.start_key) {
+    k.start = M.ion_uniquelevelindexstart[uion(M, element, ion)];
+    k.start_key = key;
+  }
+  const int start = k.start;
+  const int ul = start + level;
+  const LevelPack lp = M.level_pack[ul];
+  const double *rates = k.cellma + lp.rec_off;
+  // std::partial_sum macroatom.cc:425 and index_upperbound sn3d.h:85 over the 9 cumulative rates, kept in
+  // registers (statically indexed): action = number of cumulative values <= randomrate, clamped to the last one
+  double r[MA_N];
+#pragma unroll
+  for (int i = 0; i < MA_N; i++) r[i] = rates[i];
+  double cum[MA_N];
+  cum[0] = r[0];
+#pragma unroll
+  for (int i = 1; i < MA_N; i++) cum[i] = cum[i - 1] + r[i];
+  const double total = cum[MA_N - 1];
+  if (!(total > 0.)) {
+    fail(env, 40);
+    p.ma_level = -1;
+    return;
+  }
+  const double randomrate = rng_uniform(p) * total;
+  int action = 0;
+#pragma unroll
+  for (int i = 0; i < MA_N; i++) action += (cum[i] <= randomrate) ? 1 : 0;  // cum is non-decreasing
+  if (action > MA_N - 1) action = MA_N - 1;
+  double rate_sel = r[0];  // rates[action] without dynamic indexing
+#pragma unroll
+  for (int i = 1; i < MA_N; i++) rate_sel = (action == i) ? r[i] : rate_sel;
+  ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
+  if (action == ARTIS_MA_ACTION_RADDEEXC) {
+    // do_macroatom_raddeexcitation macroatom.cc:204
+    const double targetval = rng_uniform(p) * rate_sel;
+    const int ndown = lp.ndown;
+    const double *sums = rates + MA_N + ndown + lp.nup;
+    const int dti = upper_bound_wide(sums, ndown - 1, targetval);
+    const int startdown = lp.alltrans_startdown;
+    const int lineindex = M.alltrans_lineindex[startdown + dti];
+    if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
+    const int lul = start + M.alltrans_targetlevelindex[startdown + dti];
+    const double e_trans = eps(M, ul) - eps(M, lul);
+    const double oldnucmf = p.nu_cmf;
+    p.nu_cmf = e_trans / HPLANCK;
+    if (activatingline >= 0) ARTIS_STAT(env, (oldnucmf < p.nu_cmf) ? ARTIS_STAT_UPSCATTER : ARTIS_STAT_DOWNSCATTER);
+    ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_BB);
+    emit_rpkt(env, p, pi);
+    p.next_trans = lineindex + 1;
+    env.P.emissiontype[pi] = lineindex;
+    p.nscatterings = 0;
+    ma_finish(env, p, pi);
+  } else if (action == ARTIS_MA_ACTION_COLDEEXC || action == ARTIS_MA_ACTION_COLRECOMB) {
+    ARTIS_STAT(env, action == ARTIS_MA_ACTION_COLDEEXC ? ARTIS_STAT_MA_DEACTIVATION_COLLDEEXC : ARTIS_STAT_MA_DEACTIVATION_COLLRECOMB);
+    p.type = ARTIS_TYPE_KPKT;
+#if !ARTIS_OPT_DIRECT_COL_HEAT
+    ARTIS_EST_ADD(&env.E.colheatingestimator[c], p.e_cmf);
+#endif
+    ma_finish(env, p, pi);
+  } else if (action == ARTIS_MA_ACTION_INTERNALDOWNSAME) {
+    const double targetval = rng_uniform(p) * rate_sel;
+    const int ndown = lp.ndown;
+    const double *sums = rates + MA_N;
+    const int dti = upper_bound_wide(sums, ndown - 1, targetval);
+    p.ma_level = M.alltrans_targetlevelindex[lp.alltrans_startdown + dti];
+  } else if (action == ARTIS_MA_ACTION_INTERNALUPSAME) {
+    const int ndown = lp.ndown;
+    const int nup = lp.nup;
+    const double *sums = rates + MA_N + ndown;
+    const double targetval = rng_uniform(p) * rate_sel;
+    const int uti = upper_bound_wide(sums, nup - 1, targetval);
+    p.ma_level = M.alltrans_targetlevelindex[lp.alltrans_startdown + ndown + uti];
+  } else {
+    // the rare bound-free channels need rate coefficients with exp() and, for a radiative recombination, an adaptive
+    // quadrature: they are executed by the slow-path kernel (ma_slow_action) so that this loop stays small
+    p.pend = PEND_MA_ACTION;
+    p.pend_arg = action;
+  }
+}
+
+// the bound-free transitions of do_macroatom(): macroatom.cc:481-488, 501-533, 552-560
+AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi) {
+  const DevModel &M = env.M;
+  const int c = M.propcell_nonemptymgi[p.cellindex];
+  const int element = p.ma_element;
+  const int ion = p.ma_ion;
+  const int level = p.ma_level;
+  const int action = p.pend_arg;
+  p.pend = PEND_NONE;
+  const int ui = uion(M, element, ion);
+  const int ul = M.ion_uniquelevelindexstart[ui] + level;
+  const double e_cur = eps(M, ul);
+  const double rate_sel = env.K.macache[((int64_t)c * M.nmacache) + M.level_pack[ul].rec_off + action];
+  const float T_e = env.C.Te[c];
+  const float cnne = clumpednne(env.C, c);
+  if (action == ARTIS_MA_ACTION_RADRECOMB) {
+    // do_macroatom_radrecomb macroatom.cc:248
+    const double targetval = rng_uniform(p) * rate_sel;
+    double rate = 0;
+    const int nl = M.ion_nlevels_ionising[ui - 1];
+    const int ls = M.ion_uniquelevelindexstart[ui - 1];
+    int lowerlevel = -1, sel_t = -1;
+    for (int l = 0; l < nl; l++) {
+      const int t = find_phixstarget(M, ls + l, level);
+      if (t < 0) continue;
+      const double e_trans = e_cur - eps(M, ls + l);
+      const double R = rad_recomb(M, T_e, cnne, element, ion, l, t);
+      rate += R * e_trans;
+      if (targetval < rate) {
+        lowerlevel = l;
+        sel_t = t;
+        break;
+      }
+    }
+    if (lowerlevel < 0) {
+      fail(env, 41);
+      p.ma_level = -1;
+      return;
+    }
+    p.nu_cmf = select_continuum_nu(env, element, ion - 1, lowerlevel, sel_t, T_e, p);
+    ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_FB);
+    emit_rpkt(env, p, pi);
+    p.next_trans = -1;
+    env.P.emissiontype[pi] = emtype_continuum(M, ls + lowerlevel, sel_t);
+    p.nscatterings = 0;
+    ma_finish(env, p, pi);
+  } else if (action == ARTIS_MA_ACTION_INTERNALDOWNLOWER) {
+    ARTIS_STAT(env, ARTIS_STAT_MA_INTERNALDOWNLOWER);
+    const double targetrate = rng_uniform(p) * rate_sel;
+    double rate = 0.;
+    const int nl = M.ion_nlevels_ionising[ui - 1];
+    const int ls = M.ion_uniquelevelindexstart[ui - 1];
+    int lower = -1;
+    for (int l = 0; l < nl; l++) {
+      const int t = find_phixstarget(M, ls + l, level);
+      if (t < 0) continue;
+      const double e_target = eps(M, ls + l);
+      const double e_trans = e_cur - e_target;
+      const double R = rad_recomb(M, T_e, cnne, element, ion, l, t);
+      const double Cc = col_recomb(M, T_e, cnne, element, ion, l, t, e_trans);
+      rate += (R + Cc) * e_target;
+      if (rate > targetrate) {
+        lower = l;
+        break;
+      }
+    }
+    if (lower < 0) {
+      fail(env, 42);
+      p.ma_level = -1;
+      return;
+    }
+    p.ma_ion = ion - 1;
+    p.ma_level = lower;
+  } else if (action == ARTIS_MA_ACTION_INTERNALUPHIGHER) {
+    ARTIS_STAT(env, ARTIS_STAT_MA_INTERNALUPHIGHER);
+    // do_macroatom_ionisation macroatom.cc:298
+    const double targetrate = rng_uniform(p) * rate_sel;
+    double rate = 0.;
+    const int nt = M.level_nphixstargets[ul];
+    const double *cpc = env.K.corrphotoioncoeff + ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
+    int newlevel = -1;
+    for (int t = 0; t < nt; t++) {
+      const double e_trans = phixs_threshold(M, element, ion, level, t);
+      const double R = cpc[t];
+      const double Cc = col_ion(M, T_e, cnne, element, ion, level, t, e_trans);
+      rate += (R + Cc) * e_cur;
+      if (rate > targetrate) {
+        newlevel = phixs_upperlevel(M, ul, t);
+        break;
+      }
+    }
+    if (newlevel < 0) {
+      fail(env, 43);
+      p.ma_level = -1;
+      return;
+    }
+    p.ma_level = newlevel;
+    p.ma_ion = ion + 1;
+  } else {
+    fail(env, 44);  // MA_ACTION_INTERNALUPHIGHERNT needs NT_ON
+    p.ma_level = -1;
   }
 }
 
@@ -1493,7 +1597,7 @@ AHD void rpkt_event_continuum(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_
     if (rng_uniform(p) < nu_edge / nu) {
       ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_BF);
       const MAState ma = {element, ion + 1, phixs_upperlevel(M, lstart(M, element, ion) + level, t), -99};
-      do_macroatom(env, p, pi, ma);
+      ma_activate(p, ma, 1);
     } else {
       ARTIS_STAT(env, ARTIS_STAT_K_FROM_BF);
       p.type = ARTIS_TYPE_KPKT;
@@ -1587,7 +1691,7 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
       ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_BB);
       env.P.absorptiontype[pi] = ma.activatingline;
       env.P.absorptionfreq[pi] = p.nu_rf;
-      do_macroatom(env, p, pi, ma);
+      ma_activate(p, ma, 1);
     }
     return (p.type == ARTIS_TYPE_RPKT);
   }
@@ -1683,12 +1787,12 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     ARTIS_STAT(env, ARTIS_STAT_K_TO_R_FF);
     thermal_emission_flags(env, p, pi, ARTIS_EMTYPE_FREEFREE);
   } else if (ctype == ARTIS_COOLING_FREEBOUND) {
-    const int lowerlevel = M.coolinglist_level[i];
-    const int t = M.coolinglist_phixstargetindex[i];
-    p.nu_cmf = select_continuum_nu(env, element, ion, lowerlevel, t, T_e, p);
-    emit_rpkt(env, p, pi);
-    ARTIS_STAT(env, ARTIS_STAT_K_TO_R_FB);
-    thermal_emission_flags(env, p, pi, emtype_continuum(M, lstart(M, element, ion) + lowerlevel, t));
+    // the frequency sampling (an adaptive quadrature) runs in the slow-path kernel: kpkt_fb_emission()
+    p.pend = PEND_KPKT_FB;
+    p.ma_element = element;
+    p.ma_ion = ion;
+    p.ma_line = M.coolinglist_phixstargetindex[i];
+    p.pend_arg = M.coolinglist_level[i];
   } else if (ctype == ARTIS_COOLING_COLLEXC) {
     const float cnne = clumpednne(env.C, c);
     const double contrib_low = (i > ionstart) ? cellcontrib[i - 1] : 0.;
@@ -1723,7 +1827,7 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     env.P.trueem_pos_y[pi] = NAN;
     env.P.trueem_pos_z[pi] = NAN;
     const MAState ma = {element, ion, upper, -99};
-    do_macroatom(env, p, pi, ma);
+    ma_activate(p, ma, 0);
   } else if (ctype == ARTIS_COOLING_COLLION) {
     const int upper = phixs_upperlevel(M, lstart(M, element, ion) + M.coolinglist_level[i], M.coolinglist_phixstargetindex[i]);
     ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_COLLION);
@@ -1733,10 +1837,23 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     env.P.trueem_pos_y[pi] = NAN;
     env.P.trueem_pos_z[pi] = NAN;
     const MAState ma = {element, ion + 1, upper, -99};
-    do_macroatom(env, p, pi, ma);
+    ma_activate(p, ma, 0);
   } else {
     fail(env, 73);
   }
+}
+
+// free-bound emission of a k-packet, kpkt.cc:518-542
+AHD void kpkt_fb_emission(const Env &env, Pkt &p, int64_t pi) {
+  const DevModel &M = env.M;
+  const int c = M.propcell_nonemptymgi[p.cellindex];
+  const int element = p.ma_element, ion = p.ma_ion, lowerlevel = p.pend_arg, t = p.ma_line;
+  p.pend = PEND_NONE;
+  p.ma_line = -99;
+  p.nu_cmf = select_continuum_nu(env, element, ion, lowerlevel, t, env.C.Te[c], p);
+  emit_rpkt(env, p, pi);
+  ARTIS_STAT(env, ARTIS_STAT_K_TO_R_FB);
+  thermal_emission_flags(env, p, pi, emtype_continuum(M, lstart(M, element, ion) + lowerlevel, t));
 }
 
 // ---------------------------------------------------------------- packet load/store and the per-thread driver
@@ -1754,6 +1871,17 @@ AHD void pkt_load(const PktSoA &P, int64_t i, Pkt &p) {
   p.nu_cmf = P.nu_cmf[i]; p.e_cmf = P.e_cmf[i]; p.nu_rf = P.nu_rf[i]; p.e_rf = P.e_rf[i];
   p.stokes_q = P.stokes_q[i]; p.stokes_u = P.stokes_u[i];
   p.next_trans = P.next_trans[i]; p.nscatterings = P.nscatterings[i]; p.type = P.type[i]; p.cellindex = P.cellindex[i];
+  p.ma_element = P.ma_element[i]; p.ma_ion = P.ma_ion[i]; p.ma_level = P.ma_level[i]; p.ma_line = P.ma_line[i];
+  p.ma_origin = P.ma_origin[i];
+  p.pend = P.pend[i]; p.pend_arg = P.pend_arg[i];
+}
+AHD void chi_load(const PktSoA &P, int64_t i, Chi &x) {
+  x.nu = P.chi_nu[i]; x.chi_escatter = P.chi_es[i]; x.chi_freefree_heat = P.chi_ff[i]; x.chi_boundfree = P.chi_bf[i];
+  x.nonemptymgi = P.chi_mgi[i];
+}
+AHD void chi_store(const PktSoA &P, int64_t i, const Chi &x) {
+  P.chi_nu[i] = x.nu; P.chi_es[i] = x.chi_escatter; P.chi_ff[i] = x.chi_freefree_heat; P.chi_bf[i] = x.chi_boundfree;
+  P.chi_mgi[i] = x.nonemptymgi;
 }
 AHD void pkt_store(const PktSoA &P, int64_t i, const Pkt &p) {
   P.rng[i] = p.s0;
@@ -1766,34 +1894,91 @@ AHD void pkt_store(const PktSoA &P, int64_t i, const Pkt &p) {
   P.nu_cmf[i] = p.nu_cmf; P.e_cmf[i] = p.e_cmf; P.nu_rf[i] = p.nu_rf; P.e_rf[i] = p.e_rf;
   P.stokes_q[i] = p.stokes_q; P.stokes_u[i] = p.stokes_u;
   P.next_trans[i] = p.next_trans; P.nscatterings[i] = p.nscatterings; P.type[i] = p.type; P.cellindex[i] = p.cellindex;
+  P.ma_element[i] = p.ma_element; P.ma_ion[i] = p.ma_ion; P.ma_level[i] = p.ma_level; P.ma_line[i] = p.ma_line;
+  P.ma_origin[i] = p.ma_origin;
+  P.pend[i] = p.pend; P.pend_arg[i] = p.pend_arg;
 }
 
-// Advance one packet by at most `budget` calls of do_packet() (update_packets.cc:257). One call is one
-// do_rpkt() (rpkt.cc:983: steps until the packet leaves its model cell, changes type, escapes or reaches
-// the end of the timestep), one do_kpkt() or one do_kpkt_blackbody(). The ContinuumOpacity of the packet
-// is reset on entry of do_rpkt() (see the oracle's header, note 2), so a launch boundary can fall between
-// any two calls without changing the history. Returns true when the packet still needs updating.
-AHD bool advance_packet(const Env &env, Pkt &p, int64_t pi, int64_t slot, int budget) {
+// Work lists: a packet that still needs updating is either "in flight" (an r-packet inside or about to enter
+// do_rpkt(), rpkt.cc:983) or "thermal" (a k-packet, a pre-k-packet, or any packet with an activated macro-atom).
+enum { NEXT_DONE = 0, NEXT_RPKT = 1, NEXT_THERMAL = 2, NEXT_SLOW = 3 };
+AHD int classify(const Pkt &p, double ts_end) {
+  if (p.pend != PEND_NONE) return NEXT_SLOW;
+  if (ma_pending(p)) return NEXT_THERMAL;
+  if (!pkt_active(p, ts_end)) return NEXT_DONE;
+  return (p.type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_THERMAL;
+}
+
+// r-packet kernel body: at most `budget` calls of do_rpkt_step() (rpkt.cc:542). The packet's ContinuumOpacity x is
+// persistent (loaded/stored by the caller); it is invalidated whenever the reference's do_rpkt() loop would be left
+// (do_rpkt_step() returned false: new model cell, type change, escape, end of timestep), which is the same as
+// resetting it on entry of do_rpkt() (oracle header, note 2). A macro-atom activation leaves the loop early with the
+// state recorded in the packet; if the packet is an r-packet again afterwards it continues the same do_rpkt() loop.
+AHD int advance_rpkt(const Env &env, Pkt &p, int64_t pi, Chi &x, int budget) {
   const double ts_end = env.S.ts_end;
-  int calls = 0;
-  while (calls < budget && pkt_active(p, ts_end)) {
-    calls++;
-    if (p.type == ARTIS_TYPE_RPKT) {
-      Chi x = {-1., 0., 0., 0., -1};
-      while (do_rpkt_step(env, p, pi, x, slot)) {
-      }
-    } else if (p.type == ARTIS_TYPE_PRE_KPKT) {
+  int steps = 0;
+  while (steps < budget && !ma_pending(p) && p.type == ARTIS_TYPE_RPKT && p.prop_time < ts_end) {
+    steps++;
+    const bool cont = do_rpkt_step(env, p, pi, x, pi);
+    if (ma_pending(p)) break;
+    if (!cont) x.nonemptymgi = -1;
+  }
+  return classify(p, ts_end);
+}
+
+// a macro-atom has just deactivated: a packet that was an r-packet before and after continues its do_rpkt() loop with
+// its ContinuumOpacity; every other outcome ends or precedes a do_rpkt() call
+AHD void chi_after_ma(const Env &env, const Pkt &p, int64_t pi) {
+  if (!ma_pending(p) && !(p.type == ARTIS_TYPE_RPKT && p.ma_origin == 1)) env.P.chi_mgi[pi] = -1;
+}
+
+// thermal kernel body: at most about `budget` units of work, a unit being one macro-atom transition (ma_jump) or one
+// do_kpkt()/do_kpkt_blackbody() call (update_packets.cc:291-305).
+// The loop alternates two phases so that the lanes of a wave run the same code at the same time: a macro-atom phase
+// of up to MA_PHASE transitions (a small loop of table lookups), then ONE k-packet step for every lane whose
+// macro-atom has deactivated. Without the phases, some lane of the wave is at its (long, branchy) k-packet step in
+// almost every iteration and the whole wave pays for it every time. Phases only order the work of different
+// packets; the sequence of operations on one packet is unchanged.
+#ifndef ARTIS_MA_PHASE
+#define ARTIS_MA_PHASE 64
+#endif
+AHD int advance_thermal(const Env &env, Pkt &p, int64_t pi, int budget) {
+  const double ts_end = env.S.ts_end;
+  int units = 0;
+  MACtx k = ma_ctx(env, p);
+  while (units < budget && p.pend == PEND_NONE) {
+    // phase 1: macro-atom transitions
+    int j = 0;
+    while (j < ARTIS_MA_PHASE && ma_pending(p) && p.pend == PEND_NONE) {
+      ma_jump(env, p, pi, k);
+      j++;
+    }
+    units += j;
+    if (j > 0) chi_after_ma(env, p, pi);
+    if (ma_pending(p) || p.pend != PEND_NONE) continue;  // still walking (next phase) or handed to the slow path
+    // phase 2: one k-packet step
+    if (!pkt_active(p, ts_end) || p.type == ARTIS_TYPE_RPKT) break;
+    if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[k.c] == ARTIS_CELL_THICK) {
       do_kpkt_blackbody(env, p, pi);
     } else {
-      const int c = env.M.propcell_nonemptymgi[p.cellindex];
-      if (env.C.thick[c] == ARTIS_CELL_THICK) {
-        do_kpkt_blackbody(env, p, pi);
-      } else {
-        do_kpkt(env, p, pi);
-      }
+      do_kpkt(env, p, pi);
     }
+    env.P.chi_mgi[pi] = -1;
+    units++;
   }
-  return pkt_active(p, ts_end);
+  return classify(p, ts_end);
+}
+
+// slow-path kernel body: the one deferred action of the packet
+AHD int advance_slow(const Env &env, Pkt &p, int64_t pi) {
+  if (p.pend == PEND_MA_ACTION) {
+    ma_slow_action(env, p, pi);
+    chi_after_ma(env, p, pi);
+  } else if (p.pend == PEND_KPKT_FB) {
+    kpkt_fb_emission(env, p, pi);
+    env.P.chi_mgi[pi] = -1;
+  }
+  return classify(p, env.S.ts_end);
 }
 
 // AoS (reference struct Packet) <-> SoA, one packet
@@ -1811,6 +1996,9 @@ AHD void aos_to_soa(const artis_packet &a, const PktSoA &P, int64_t i) {
   P.trueem_pos_x[i] = a.trueem_pos[0]; P.trueem_pos_y[i] = a.trueem_pos[1]; P.trueem_pos_z[i] = a.trueem_pos[2];
   P.absorptionfreq[i] = a.absorptionfreq;
   P.em_time[i] = a.em_time; P.trueem_time[i] = a.trueem_time; P.escape_time[i] = a.escape_time;
+  P.chi_nu[i] = -1.; P.chi_es[i] = 0.; P.chi_ff[i] = 0.; P.chi_bf[i] = 0.; P.chi_mgi[i] = -1;
+  P.ma_element[i] = -1; P.ma_ion[i] = -1; P.ma_level[i] = -1; P.ma_line[i] = -99; P.ma_origin[i] = 0;
+  P.pend[i] = PEND_NONE; P.pend_arg[i] = 0;
 }
 AHD void soa_to_aos(const PktSoA &P, int64_t i, artis_packet &a) {
   for (int k = 0; k < 4; k++) a.rngstate[k] = P.rng[(k * P.n) + i];

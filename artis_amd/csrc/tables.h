@@ -26,9 +26,26 @@ struct alignas(16) LinePack {
   float B_lu;
 };
 
+// 16-byte record of the static per-level indices a macro-atom transition needs (AllLevels, globals.h:181):
+// alltrans_startdown, ndowntrans, nuptrans, and the offset (in doubles) of the level's macro-atom record inside a
+// cell's macache row (see DevCache::macache)
+struct alignas(16) LevelPack {
+  int32_t rec_off;
+  int32_t alltrans_startdown;
+  int32_t ndown;
+  int32_t nup;
+};
+// macro-atom record of one (cell, level), 128-byte aligned so that a transition touches two adjacent lines:
+//   [0..8]                         the 9 process rates            (alllevels_maprocessrates, globals.h:286)
+//   [9 .. 9+ndown)                 cumulative internal-down-same  (allmacroatomictransitions block 2, macroatom.cc:44)
+//   [9+ndown .. 9+ndown+nup)       cumulative internal-up-same    (block 3, macroatom.cc:51)
+//   [9+ndown+nup .. 9+2ndown+nup)  cumulative radiative deexc.    (block 1, macroatom.cc:58)
+constexpr int MAREC_ALIGN = 16;  // doubles
+
 struct DevModel {
   int32_t nelements, nions, nlevels, nlines, nalltrans, nphixstargets_total, nphixslevels, nbfcontinua, nbfcontinua_ground,
       ncoolingterms, nmatransblock, NPHIXSPOINTS;
+  int32_t nmacache;    // doubles per cell in DevCache::macache
   int32_t nkeepwords;  // ceil(nbfcontinua/64) (get_allcont_keepwordcount globals.h:401)
   double NPHIXSNUINCREMENT;
   double last_phixs_nuovernuedge;  // input.cc:310
@@ -43,6 +60,7 @@ struct DevModel {
   const int32_t *level_alltrans_startdown, *level_ndowntrans, *level_nuptrans, *level_closestgroundlevelcont, *level_phixsstart,
       *level_nphixstargets, *level_phixstargetstart, *level_bflist_start, *level_matransblock_start;
   const int32_t *level_ion;  // derived: uniqueionindex of each level
+  const LevelPack *level_pack;  // derived
   const int32_t *alltrans_lineindex, *alltrans_targetlevelindex;
   const float *alltrans_einstein_A, *alltrans_coll_str, *alltrans_osc_strength;
   const uint8_t *alltrans_forbidden;
@@ -76,8 +94,7 @@ struct DevCells {
 
 struct DevCache {
   double *levelpops;             // [cell][nlevels]
-  double *maprocessrates;        // [cell][nlevels*9]
-  double *matrans;               // [cell][nmatransblock]
+  double *macache;               // [cell][nmacache]: one record per level, see LevelPack
   double *allcont_nnlevel;       // [cell][nbfcontinua]
   double *allcont_departure;     // [cell][nbfcontinua]
   double *allcont_edgepart;      // [cell][nbfcontinua]
@@ -111,10 +128,21 @@ struct PktSoA {
   int32_t *emissiontype, *absorptiontype, *trueemissiontype, *escape_type;
   double *em_pos_x, *em_pos_y, *em_pos_z, *trueem_pos_x, *trueem_pos_y, *trueem_pos_z, *absorptionfreq;
   float *em_time, *trueem_time, *escape_time;
+  // engine-private state that lets a kernel boundary fall anywhere in a packet's history:
+  // the packet's ContinuumOpacity (rpkt.h:70; chi_mgi < 0 = not valid) ...
+  double *chi_nu, *chi_es, *chi_ff, *chi_bf;
+  int32_t *chi_mgi;
+  // ... and an activated macro-atom that has not deactivated yet (MacroAtomState packet.h:103; ma_level < 0 = none).
+  // ma_origin: 1 = activated inside do_rpkt_step() (the packet continues its do_rpkt() loop afterwards), 0 = by a k-packet.
+  int32_t *ma_element, *ma_ion, *ma_level, *ma_line, *ma_origin;
+  // a rare, register-hungry action that was sampled but is executed by the slow-path kernel (pend != 0):
+  // PEND_MA_ACTION: the bound-free macro-atom transition `pend_arg` (an ARTIS_MA_ACTION_*) of the active macro-atom;
+  // PEND_KPKT_FB: free-bound emission of a k-packet into continuum (ma_element, ma_ion, ma_level = lower level, ma_line = target).
+  int32_t *pend, *pend_arg;
   int64_t n;
 };
 // number of 8-byte and 4-byte columns above (used to carve one allocation)
-constexpr int PKT_NCOL64 = 13 + 7;
-constexpr int PKT_NCOL32 = 4 /*rng*/ + 4 + 4 + 3;
+constexpr int PKT_NCOL64 = 13 + 7 + 4;
+constexpr int PKT_NCOL32 = 4 /*rng*/ + 4 + 4 + 3 + 6 + 2;
 
 }  // namespace artis

@@ -29,11 +29,12 @@ def load_library(build_if_missing: bool = False):
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(SO):
+    so = os.environ.get("ARTIS_AMD_SO", SO)  # A/B builds of the same sources (tuning only)
+    if not os.path.exists(so):
         if not build_if_missing:
             raise EngineError(f"{SO} is missing: run `python -m artis_amd.build` (hipcc, gfx950). There is no CPU fallback.")
         build()
-    L = C.CDLL(SO)
+    L = C.CDLL(so)
     L.artis_amd_last_error.restype = C.c_char_p
     L.artis_amd_abi_version.restype = C.c_int
     L.artis_amd_sizeof_packet.restype = C.c_size_t
@@ -64,6 +65,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_update_packets_device", "artis_amd_estimators_zero", "artis_amd_estimators_download",
     "artis_amd_estimators_devptr", "artis_amd_last_kernel_ms", "artis_amd_debug_cellcache",
     "artis_amd_populate_cellcache",
+    "artis_amd_last_kernel_breakdown",
 ]
 
 
@@ -142,6 +144,12 @@ class Engine:
         self._check(self.L.artis_amd_debug_cellcache(*args))
         out["chi_ff_nnionpart"] = chi.value
         return out
+
+    def last_kernel_breakdown(self):
+        a, b, c, d = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
+        self.L.artis_amd_last_kernel_breakdown.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        self._check(self.L.artis_amd_last_kernel_breakdown(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"rpkt_ms": a.value, "rpkt_threads": b.value, "thermal_ms": c.value, "thermal_threads": d.value}
 
     def last_kernel_ms(self):
         ms, n = C.c_double(), C.c_int64()

@@ -212,6 +212,9 @@ def main():
                          "kernel_ms_per_step": k_ms_per_step, "avg_launch_ms": k_ms_per_step / max(launches_per_step, 1),
                          "algorithmic_bytes_per_step": float(alg_bytes)},
         }
+        out["kernel_breakdown_last_step"] = eng.last_kernel_breakdown()
+        if os.environ.get("ARTIS_BENCH_VERBOSE"):
+            print({abi.STAT_NAMES[i]: int(stats[i]) for i in range(abi.NSTATS) if stats[i]}, file=sys.stderr)
         if baseline is not None:
             out["cpu_baseline"] = baseline
             out["gpu_over_cpu_baseline"] = value / baseline["value"]

@@ -107,6 +107,8 @@ enum {
   ARTIS_STAT_X_KPKT_STEPS = 35, /* calls of do_kpkt()/do_kpkt_blackbody() */
   ARTIS_STAT_X_LINES_VISITED = 36, /* lines walked in get_possible_event() rpkt.cc:121 */
   ARTIS_STAT_X_MA_JUMPS = 37, /* iterations of the do_macroatom() loop macroatom.cc:385 */
+  ARTIS_STAT_X_CHI_EVALS = 38, /* continuum opacity evaluations that missed the packet's cache, rpkt.cc:1029 */
+  ARTIS_STAT_X_CONT_VISITED = 39, /* bound-free continua summed in calculate_chi_bf_gammacontr() rpkt.cc:808 */
   ARTIS_NSTATS = 40
 };
 
@@ -357,6 +359,11 @@ int artis_amd_estimators_devptr(artis_amd_engine *eng, void **dptr, int64_t *ndo
 /* Timing of the dominant kernel inside the last artis_amd_update_packets_device
  * call, measured with HIP events on the launch stream. */
 int artis_amd_last_kernel_ms(artis_amd_engine *eng, double *propagate_ms, int64_t *nlaunches);
+
+/* Per-kernel split of the last artis_amd_update_packets_device call: summed launch durations [ms] and summed
+ * thread counts of the r-packet kernel (k_rpkt) and of the thermal kernel (k_thermal). */
+int artis_amd_last_kernel_breakdown(artis_amd_engine *eng, double *rpkt_ms, int64_t *rpkt_threads, double *thermal_ms,
+                                    int64_t *thermal_threads);
 
 /* Diagnostics: copy the cell cache of one non-empty cell back to the host (the reference's
  * globals::cellcache[nonemptymgi] spans, globals.h:283-311). Any pointer may be NULL. */

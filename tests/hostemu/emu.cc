@@ -79,24 +79,52 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
   std::vector<uint8_t> soabuf(pkt_soa_bytes(npackets) + 64);
   e.env.P = carve_pkt_soa(soabuf.data(), npackets);
   for (int64_t i = 0; i < npackets; i++) aos_to_soa(packets[i], e.env.P, i);
-  // active list + budgeted launches, as in artis_amd_update_packets_device()
-  std::vector<int64_t> active, next;
+  // work lists + budgeted launches, as in artis_amd_update_packets_device(): an r-packet list and a thermal list
+  std::vector<int64_t> rl, tl, sl, rn, tn, sn;
+  auto push = [&](int kind, int64_t pi) {
+    if (kind == NEXT_RPKT) rn.push_back(pi);
+    if (kind == NEXT_THERMAL) tn.push_back(pi);
+    if (kind == NEXT_SLOW) sn.push_back(pi);
+  };
   for (int64_t i = 0; i < npackets; i++) {
     Pkt p;
     pkt_load(e.env.P, i, p);
-    if (pkt_active(p, e.env.S.ts_end)) active.push_back(i);
+    push(classify(p, e.env.S.ts_end), i);
   }
-  while (!active.empty() && !e.err) {
-    next.clear();
-    for (size_t k = 0; k < active.size(); k++) {
-      const int64_t pi = active[k];
+  rl.swap(rn);
+  tl.swap(tn);
+  sl.swap(sn);
+  while ((!rl.empty() || !tl.empty() || !sl.empty()) && !e.err) {
+    rn.clear();
+    tn.clear();
+    sn.clear();
+    for (int64_t pi : rl) {  // k_rpkt
+      Pkt p;
+      Chi x;
+      pkt_load(e.env.P, pi, p);
+      chi_load(e.env.P, pi, x);
+      const int kind = advance_rpkt(e.env, p, pi, x, budget);
+      pkt_store(e.env.P, pi, p);
+      chi_store(e.env.P, pi, x);
+      push(kind, pi);
+    }
+    for (int64_t pi : tl) {  // k_thermal
       Pkt p;
       pkt_load(e.env.P, pi, p);
-      const bool still = advance_packet(e.env, p, pi, /*slot=*/(int64_t)k, budget);
+      const int kind = advance_thermal(e.env, p, pi, budget * 8);
       pkt_store(e.env.P, pi, p);
-      if (still) next.push_back(pi);
+      push(kind, pi);
     }
-    active.swap(next);
+    for (int64_t pi : sl) {  // k_slow
+      Pkt p;
+      pkt_load(e.env.P, pi, p);
+      const int kind = advance_slow(e.env, p, pi);
+      pkt_store(e.env.P, pi, p);
+      push(kind, pi);
+    }
+    rl.swap(rn);
+    tl.swap(tn);
+    sl.swap(sn);
   }
   for (int64_t i = 0; i < npackets; i++) soa_to_aos(e.env.P, i, packets[i]);
   if (est && est->stats)
@@ -115,8 +143,7 @@ int artis_emu_cellcache(const artis_model *m, const artis_cellstate *cs, const a
   const DevModel &M = e.env.M;
   const DevCache &K = e.env.K;
   std::memcpy(levelpops, K.levelpops + (int64_t)c * M.nlevels, sizeof(double) * M.nlevels);
-  std::memcpy(maprocessrates, K.maprocessrates + (int64_t)c * M.nlevels * 9, sizeof(double) * M.nlevels * 9);
-  std::memcpy(matrans, K.matrans + (int64_t)c * M.nmatransblock, sizeof(double) * M.nmatransblock);
+  unpack_macache_row(M, *m, K.macache + (int64_t)c * M.nmacache, maprocessrates, matrans);
   std::memcpy(allcont_nnlevel, K.allcont_nnlevel + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
   std::memcpy(allcont_departure, K.allcont_departure + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
   std::memcpy(allcont_edgepart, K.allcont_edgepart + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
