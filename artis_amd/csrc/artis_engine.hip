@@ -12,6 +12,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -184,6 +185,11 @@ __global__ void __launch_bounds__(BLOCK) k_sort_scatter(const int32_t *list, int
 }
 
 // ------------------------------------------------------------------ the propagation kernels
+// Both are PERSISTENT, work-pulling kernels: a lane that has finished with its packet (budget used up, packet handed
+// to another list, escaped, end of timestep) immediately takes the next packet of the work list instead of idling
+// until the slowest lane of its wave is done. The list is sorted by cell and cut into 8 chunks with one cursor each;
+// a block starts on chunk blockIdx % 8 (blocks b and b+8 share an XCD, so each XCD's L2 sees one contiguous range of
+// cells) and moves on to the other chunks when its own is exhausted. Placement only affects speed.
 #ifndef ARTIS_RPKT_WAVES
 #define ARTIS_RPKT_WAVES 2
 #endif
@@ -191,51 +197,132 @@ __global__ void __launch_bounds__(BLOCK) k_sort_scatter(const int32_t *list, int
 #define ARTIS_THERMAL_WAVES 4
 #endif
 
+struct Puller {
+  int chunk, tried;
+  bool exhausted;
+};
+__device__ inline void puller_init(Puller &q) {
+  q.chunk = blockIdx.x & 7;
+  q.tried = 0;
+  q.exhausted = false;
+}
+// Hands list indices to the lanes with need==true. Returns the index for this lane or -1. Wave-uniform control flow.
+__device__ inline int32_t pull(Puller &q, bool need, int32_t n, int32_t *cursors) {
+  int32_t idx = -1;
+  need = need && !q.exhausted;
+  const unsigned long long mask = __ballot(need);
+  if (mask == 0) return -1;
+  const int lane = threadIdx.x & 63;
+  const int cnt = __popcll(mask);
+  const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+  const int leader = __ffsll((long long)mask) - 1;
+  const int64_t cbeg = ((int64_t)n * q.chunk) >> 3;
+  const int64_t cend = ((int64_t)n * (q.chunk + 1)) >> 3;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(&cursors[q.chunk], cnt);
+  base = __shfl(base, leader);
+  const int64_t mine = cbeg + base + prefix;
+  if (need && mine < cend) idx = (int32_t)mine;
+  if (cbeg + base + cnt > cend) {  // this chunk is used up: continue on the next one (the unserved lanes ask again)
+    q.chunk = (q.chunk + 1) & 7;
+    q.tried++;
+    if (q.tried >= 8) q.exhausted = true;
+  }
+  return idx;
+}
+
 // r-packets in flight: boundary distance, continuum opacity, line-by-line Sobolev walk, estimators, events
 __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                   unsigned long long *gstats, int budget) {
+                                                                   unsigned long long *gstats, int budget, int32_t *cursors) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   __syncthreads();
   env.stats = lstats;
-  const int64_t nb = gridDim.x;
-  const int64_t tid = xcd_chunk(blockIdx.x, nb) * BLOCK + threadIdx.x;
-  int kind = NEXT_DONE;
+  const double ts_end = env.S.ts_end;
+  Puller q;
+  puller_init(q);
+  bool have = false;
   int32_t pi = 0;
-  if (tid < n) {
-    pi = list[tid];
-    Pkt p;
-    Chi x;
-    pkt_load(env.P, pi, p);
-    chi_load(env.P, pi, x);
-    kind = advance_rpkt(env, p, pi, x, budget);
-    pkt_store(env.P, pi, p);
-    chi_store(env.P, pi, x);
+  int steps = 0;
+  Pkt p;
+  Chi x;
+  while (true) {
+    const int32_t idx = pull(q, !have, n, cursors);
+    if (idx >= 0) {
+      pi = list[idx];
+      pkt_load(env.P, pi, p);
+      chi_load(env.P, pi, x);
+      steps = 0;
+      have = true;
+    }
+    if (!__any(have)) {
+      if (q.exhausted) break;
+      continue;
+    }
+    int kind = NEXT_DONE;
+    int32_t out_pi = 0;
+    if (have) {
+      bool go = rpkt_can_continue(p, ts_end);
+      if (go) {
+        go = rpkt_iter(env, p, pi, x);
+        steps++;
+      }
+      if (!go || steps >= budget) {
+        pkt_store(env.P, pi, p);
+        chi_store(env.P, pi, x);
+        kind = classify(p, ts_end);
+        out_pi = pi;
+        have = false;
+      }
+    }
+    append_by_kind(kind, out_pi, next);
   }
-  append_by_kind(kind, pi, next);
   __syncthreads();
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
 }
 
 // thermal packets: k-packet cooling-channel sampling and the macro-atom random walk
 __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                         unsigned long long *gstats, int budget) {
+                                                                         unsigned long long *gstats, int budget, int32_t *cursors) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   __syncthreads();
   env.stats = lstats;
-  const int64_t nb = gridDim.x;
-  const int64_t tid = xcd_chunk(blockIdx.x, nb) * BLOCK + threadIdx.x;
-  int kind = NEXT_DONE;
+  const double ts_end = env.S.ts_end;
+  Puller q;
+  puller_init(q);
+  bool have = false;
   int32_t pi = 0;
-  if (tid < n) {
-    pi = list[tid];
-    Pkt p;
-    pkt_load(env.P, pi, p);
-    kind = advance_thermal(env, p, pi, budget);
-    pkt_store(env.P, pi, p);
+  int units = 0;
+  Pkt p;
+  MACtx k;
+  while (true) {
+    const int32_t idx = pull(q, !have, n, cursors);
+    if (idx >= 0) {
+      pi = list[idx];
+      pkt_load(env.P, pi, p);
+      k = ma_ctx(env, p);
+      units = 0;
+      have = true;
+    }
+    if (!__any(have)) {
+      if (q.exhausted) break;
+      continue;
+    }
+    int kind = NEXT_DONE;
+    int32_t out_pi = 0;
+    if (have) {
+      bool go = thermal_can_continue(p, ts_end);
+      if (go) units += thermal_iter(env, p, pi, k, &go);
+      if (!go || units >= budget) {
+        pkt_store(env.P, pi, p);
+        kind = classify(p, ts_end);
+        out_pi = pi;
+        have = false;
+      }
+    }
+    append_by_kind(kind, out_pi, next);
   }
-  append_by_kind(kind, pi, next);
   __syncthreads();
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
 }
@@ -300,6 +387,8 @@ struct artis_amd_engine {
   int32_t *d_sorted = nullptr;                // counting-sort output
   int32_t *d_hist = nullptr;                  // [ngrid + 1]
   int32_t *d_count = nullptr;                 // [8]: two sets of (r, thermal, slow, pad)
+  int32_t *d_cursors = nullptr;               // [16]: 8 chunk cursors for k_rpkt, 8 for k_thermal
+  int ncu = 256;
   double *d_gamma_ws = nullptr;
   int64_t ws_capacity = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
@@ -470,6 +559,12 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
   HIP_TRY(hipMemset(e->d_err, 0, sizeof(int32_t)));
   HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 8));
+  HIP_TRY(hipMalloc((void **)&e->d_cursors, sizeof(int32_t) * 16));
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    e->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
   HIP_TRY(hipMalloc((void **)&e->d_hist, sizeof(int32_t) * (size_t)(h.ngrid + 1)));
   HIP_TRY(hipEventCreate(&e->ev0));
   HIP_TRY(hipEventCreate(&e->ev1));
@@ -496,7 +591,7 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
   void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_rlist[0], e->d_rlist[1],
-                  e->d_tlist[0], e->d_tlist[1], e->d_slist[0], e->d_slist[1], e->d_sorted, e->d_hist, e->d_count, e->d_gamma_ws};
+                  e->d_tlist[0], e->d_tlist[1], e->d_slist[0], e->d_slist[1], e->d_sorted, e->d_hist, e->d_count, e->d_cursors, e->d_gamma_ws};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3, e->ev4, e->ev5})
@@ -659,12 +754,14 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     const int nxt = 1 - cur;
     const Lists next = lists_of(nxt);
     HIP_TRY(hipMemsetAsync(e->d_count + 4 * nxt, 0, sizeof(int32_t) * 4, s));
+    HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * 16, s));
     if (nr > 0) {
       const int32_t *lst = nullptr;
       int rc = sort_by_cell(e, s, e->d_rlist[cur], nr, &lst);
       if (rc != ARTIS_OK) return rc;
       HIP_TRY(hipEventRecord(e->ev0, s));
-      hipLaunchKernelGGL(k_rpkt, dim3(nblocks(nr)), dim3(BLOCK), 0, s, env, lst, nr, next, e->d_stats, e->budget_r);
+      const int grid = std::min(nblocks(nr), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
+      hipLaunchKernelGGL(k_rpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nr, next, e->d_stats, e->budget_r, e->d_cursors);
       HIP_TRY(hipEventRecord(e->ev1, s));
     }
     if (nt > 0) {
@@ -672,7 +769,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       int rc = sort_by_cell(e, s, e->d_tlist[cur], nt, &lst);
       if (rc != ARTIS_OK) return rc;
       HIP_TRY(hipEventRecord(e->ev2, s));
-      hipLaunchKernelGGL(k_thermal, dim3(nblocks(nt)), dim3(BLOCK), 0, s, env, lst, nt, next, e->d_stats, e->budget_t);
+      const int grid = std::min(nblocks(nt), e->ncu * ARTIS_THERMAL_WAVES);
+      hipLaunchKernelGGL(k_thermal, dim3(grid), dim3(BLOCK), 0, s, env, lst, nt, next, e->d_stats, e->budget_t, e->d_cursors + 8);
       HIP_TRY(hipEventRecord(e->ev3, s));
     }
     if (ns > 0) {

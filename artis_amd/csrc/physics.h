@@ -1909,21 +1909,28 @@ AHD int classify(const Pkt &p, double ts_end) {
   return (p.type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_THERMAL;
 }
 
-// r-packet kernel body: at most `budget` calls of do_rpkt_step() (rpkt.cc:542). The packet's ContinuumOpacity x is
+// ---- r-packet kernel body. One iteration = one call of do_rpkt_step() (rpkt.cc:542). The packet's ContinuumOpacity x is
 // persistent (loaded/stored by the caller); it is invalidated whenever the reference's do_rpkt() loop would be left
 // (do_rpkt_step() returned false: new model cell, type change, escape, end of timestep), which is the same as
-// resetting it on entry of do_rpkt() (oracle header, note 2). A macro-atom activation leaves the loop early with the
-// state recorded in the packet; if the packet is an r-packet again afterwards it continues the same do_rpkt() loop.
+// resetting it on entry of do_rpkt() (oracle header, note 2). A macro-atom activation leaves the loop with the state
+// recorded in the packet; if the packet is an r-packet again afterwards it continues the same do_rpkt() loop.
+// Returns true while the packet can take another iteration in the r-packet kernel.
+AHD bool rpkt_can_continue(const Pkt &p, double ts_end) {
+  return !ma_pending(p) && p.pend == PEND_NONE && p.type == ARTIS_TYPE_RPKT && p.prop_time < ts_end;
+}
+AHD bool rpkt_iter(const Env &env, Pkt &p, int64_t pi, Chi &x) {
+  const bool cont = do_rpkt_step(env, p, pi, x, pi);
+  if (!ma_pending(p) && !cont) x.nonemptymgi = -1;
+  return rpkt_can_continue(p, env.S.ts_end);
+}
 AHD int advance_rpkt(const Env &env, Pkt &p, int64_t pi, Chi &x, int budget) {
-  const double ts_end = env.S.ts_end;
   int steps = 0;
-  while (steps < budget && !ma_pending(p) && p.type == ARTIS_TYPE_RPKT && p.prop_time < ts_end) {
+  bool go = rpkt_can_continue(p, env.S.ts_end);
+  while (go && steps < budget) {
+    go = rpkt_iter(env, p, pi, x);
     steps++;
-    const bool cont = do_rpkt_step(env, p, pi, x, pi);
-    if (ma_pending(p)) break;
-    if (!cont) x.nonemptymgi = -1;
   }
-  return classify(p, ts_end);
+  return classify(p, env.S.ts_end);
 }
 
 // a macro-atom has just deactivated: a packet that was an r-packet before and after continues its do_rpkt() loop with
@@ -1932,41 +1939,49 @@ AHD void chi_after_ma(const Env &env, const Pkt &p, int64_t pi) {
   if (!ma_pending(p) && !(p.type == ARTIS_TYPE_RPKT && p.ma_origin == 1)) env.P.chi_mgi[pi] = -1;
 }
 
-// thermal kernel body: at most about `budget` units of work, a unit being one macro-atom transition (ma_jump) or one
-// do_kpkt()/do_kpkt_blackbody() call (update_packets.cc:291-305).
-// The loop alternates two phases so that the lanes of a wave run the same code at the same time: a macro-atom phase
-// of up to MA_PHASE transitions (a small loop of table lookups), then ONE k-packet step for every lane whose
-// macro-atom has deactivated. Without the phases, some lane of the wave is at its (long, branchy) k-packet step in
-// almost every iteration and the whole wave pays for it every time. Phases only order the work of different
-// packets; the sequence of operations on one packet is unchanged.
+// ---- thermal kernel body. A unit of work is one macro-atom transition (ma_jump) or one do_kpkt()/do_kpkt_blackbody()
+// call (update_packets.cc:291-305). One iteration alternates two phases so that the lanes of a wave run the same code
+// at the same time: a macro-atom phase of up to ARTIS_MA_PHASE transitions (a small loop of table lookups), then ONE
+// k-packet step for every lane whose macro-atom has deactivated. Without the phases, some lane of the wave is at its
+// (long, branchy) k-packet step in almost every iteration and the whole wave pays for it every time. Phases only
+// order the work of different packets; the sequence of operations on one packet is unchanged.
 #ifndef ARTIS_MA_PHASE
 #define ARTIS_MA_PHASE 64
 #endif
-AHD int advance_thermal(const Env &env, Pkt &p, int64_t pi, int budget) {
+AHD bool thermal_can_continue(const Pkt &p, double ts_end) {
+  if (p.pend != PEND_NONE) return false;
+  if (ma_pending(p)) return true;
+  return pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT;
+}
+// returns the units of work done; *go = the packet can take another iteration in the thermal kernel
+AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
   const double ts_end = env.S.ts_end;
-  int units = 0;
-  MACtx k = ma_ctx(env, p);
-  while (units < budget && p.pend == PEND_NONE) {
-    // phase 1: macro-atom transitions
-    int j = 0;
-    while (j < ARTIS_MA_PHASE && ma_pending(p) && p.pend == PEND_NONE) {
-      ma_jump(env, p, pi, k);
-      j++;
-    }
-    units += j;
-    if (j > 0) chi_after_ma(env, p, pi);
-    if (ma_pending(p) || p.pend != PEND_NONE) continue;  // still walking (next phase) or handed to the slow path
-    // phase 2: one k-packet step
-    if (!pkt_active(p, ts_end) || p.type == ARTIS_TYPE_RPKT) break;
+  // phase 1: macro-atom transitions
+  int j = 0;
+  while (j < ARTIS_MA_PHASE && ma_pending(p) && p.pend == PEND_NONE) {
+    ma_jump(env, p, pi, k);
+    j++;
+  }
+  if (j > 0) chi_after_ma(env, p, pi);
+  // phase 2: one k-packet step (not for a packet still walking, handed to the slow path, or an r-packet again)
+  if (!ma_pending(p) && p.pend == PEND_NONE && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT) {
     if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[k.c] == ARTIS_CELL_THICK) {
       do_kpkt_blackbody(env, p, pi);
     } else {
       do_kpkt(env, p, pi);
     }
     env.P.chi_mgi[pi] = -1;
-    units++;
+    j++;
   }
-  return classify(p, ts_end);
+  *go = thermal_can_continue(p, ts_end);
+  return j;
+}
+AHD int advance_thermal(const Env &env, Pkt &p, int64_t pi, int budget) {
+  int units = 0;
+  MACtx k = ma_ctx(env, p);
+  bool go = thermal_can_continue(p, env.S.ts_end);
+  while (go && units < budget) units += thermal_iter(env, p, pi, k, &go);
+  return classify(p, env.S.ts_end);
 }
 
 // slow-path kernel body: the one deferred action of the packet
