@@ -147,40 +147,91 @@ __global__ void __launch_bounds__(BLOCK) k_classify(PktSoA P, double ts_end, Lis
   append_by_kind(kind, (int32_t)i, L);
 }
 
-// ---- counting sort of a work list by propagation cell (three tiny kernels)
-__global__ void __launch_bounds__(BLOCK) k_sort_hist(const int32_t *list, int32_t n, const int32_t *cellindex, int32_t *hist) {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < n) atomicAdd(&hist[cellindex[list[i]]], 1);
+// ---- counting sort of a work list by (propagation cell, frequency bin) (three tiny kernels).
+// Within a cell, r-packets are ordered by comoving frequency like the reference's own packet sort
+// (compare_packet_order, update_packets.cc:363): neighbouring lanes then walk the same part of the line list and
+// the same window of bound-free continua. nbins == 1 sorts by cell only (thermal list).
+constexpr int SORT_NUBINS = 16;
+__device__ inline int32_t sort_key(int32_t pi, const int32_t *cellindex, const double *nu_cmf, int nbins) {
+  int32_t key = cellindex[pi] * nbins;
+  if (nbins > 1) {
+    // 16 log-spaced bins over [1e14, 1e16] Hz, bluest first
+    const double lognu = log2(fmax(nu_cmf[pi], 1.0));
+    const double x = (lognu - 46.507) * (nbins / 6.644);  // log2(1e14) = 46.507, log2(100) = 6.644
+    int b = (int)x;
+    b = b < 0 ? 0 : (b > nbins - 1 ? nbins - 1 : b);
+    key += (nbins - 1 - b);
+  }
+  return key;
 }
-__global__ void __launch_bounds__(1024) k_sort_scan(int32_t *hist, int32_t ncells) {
+__global__ void __launch_bounds__(BLOCK) k_sort_hist(const int32_t *list, int32_t n, const int32_t *cellindex, const double *nu_cmf,
+                                                     int nbins, int32_t *hist) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n) atomicAdd(&hist[sort_key(list[i], cellindex, nu_cmf, nbins)], 1);
+}
+// exclusive scan of the key histogram in three steps: per-block scan of SCAN_TILE keys, scan of the block totals
+// (one block), add the block offsets
+constexpr int SCAN_TILE = 8192;  // keys per block of 1024 threads (8 per thread)
+__global__ void __launch_bounds__(1024) k_scan_tiles(int32_t *hist, int32_t nkeys, int32_t *tile_totals) {
   __shared__ int32_t part[1024];
   const int t = threadIdx.x;
-  const int seg = (ncells + 1023) / 1024;
-  const int lo = t * seg;
-  const int hi = min(lo + seg, ncells);
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)t * 8;
+  int32_t v[8];
   int32_t sum = 0;
-  for (int i = lo; i < hi; i++) sum += hist[i];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    v[k] = (base + k < nkeys) ? hist[base + k] : 0;
+    sum += v[k];
+  }
   part[t] = sum;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    int32_t v = (t >= off) ? part[t - off] : 0;
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
+    const int32_t add = (t >= off) ? part[t - off] : 0;
     __syncthreads();
-    part[t] += v;
+    part[t] += add;
     __syncthreads();
   }
-  int32_t run = part[t] - sum;  // exclusive prefix of this segment
-  for (int i = lo; i < hi; i++) {
-    const int32_t h = hist[i];
-    hist[i] = run;
-    run += h;
+  int32_t run = part[t] - sum;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (base + k < nkeys) hist[base + k] = run;
+    run += v[k];
+  }
+  if (t == 1023) tile_totals[blockIdx.x] = part[1023];
+}
+__global__ void __launch_bounds__(1024) k_scan_totals(int32_t *tile_totals, int32_t ntiles) {
+  __shared__ int32_t part[1024];
+  const int t = threadIdx.x;
+  int32_t carry = 0;
+  for (int start = 0; start < ntiles; start += 1024) {
+    const int i = start + t;
+    const int32_t v = (i < ntiles) ? tile_totals[i] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int32_t add = (t >= off) ? part[t - off] : 0;
+      __syncthreads();
+      part[t] += add;
+      __syncthreads();
+    }
+    if (i < ntiles) tile_totals[i] = carry + part[t] - v;
+    carry += part[1023];
+    __syncthreads();
   }
 }
-__global__ void __launch_bounds__(BLOCK) k_sort_scatter(const int32_t *list, int32_t n, const int32_t *cellindex, int32_t *offsets,
-                                                        int32_t *out) {
+__global__ void __launch_bounds__(1024) k_scan_add(int32_t *hist, int32_t nkeys, const int32_t *tile_totals) {
+  const int32_t off = tile_totals[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (base + k < nkeys) hist[base + k] += off;
+}
+__global__ void __launch_bounds__(BLOCK) k_sort_scatter(const int32_t *list, int32_t n, const int32_t *cellindex, const double *nu_cmf,
+                                                        int nbins, int32_t *offsets, int32_t *out) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i < n) {
     const int32_t pi = list[i];
-    out[atomicAdd(&offsets[cellindex[pi]], 1)] = pi;
+    out[atomicAdd(&offsets[sort_key(pi, cellindex, nu_cmf, nbins)], 1)] = pi;
   }
 }
 
@@ -385,7 +436,8 @@ struct artis_amd_engine {
   int32_t *d_tlist[2] = {nullptr, nullptr};  // thermal work lists (ping-pong)
   int32_t *d_slist[2] = {nullptr, nullptr};  // slow-path work lists (ping-pong)
   int32_t *d_sorted = nullptr;                // counting-sort output
-  int32_t *d_hist = nullptr;                  // [ngrid + 1]
+  int32_t *d_hist = nullptr;                  // [ngrid * SORT_NUBINS + 1]
+  int32_t *d_tiles = nullptr;                 // scan tile totals
   int32_t *d_count = nullptr;                 // [8]: two sets of (r, thermal, slow, pad)
   int32_t *d_cursors = nullptr;               // [16]: 8 chunk cursors for k_rpkt, 8 for k_thermal
   int ncu = 256;
@@ -397,9 +449,11 @@ struct artis_amd_engine {
   hipEvent_t ev4 = nullptr, ev5 = nullptr;
   int64_t last_nlaunches = 0;
   int64_t last_rpkt_threads = 0, last_thermal_threads = 0;
+  int64_t last_rpkt_launches = 0, last_thermal_launches = 0;
   int budget_r = 8;      // do_rpkt_step() calls per thread per launch
   int budget_t = 512;    // macro-atom transitions / k-packet steps per thread per launch
   bool sort_lists = true;
+  bool sort_nu = true;
   bool trace = false;
 };
 
@@ -565,7 +619,8 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     e->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  HIP_TRY(hipMalloc((void **)&e->d_hist, sizeof(int32_t) * (size_t)(h.ngrid + 1)));
+  HIP_TRY(hipMalloc((void **)&e->d_hist, sizeof(int32_t) * ((size_t)h.ngrid * SORT_NUBINS + 1)));
+  HIP_TRY(hipMalloc((void **)&e->d_tiles, sizeof(int32_t) * (((size_t)h.ngrid * SORT_NUBINS) / SCAN_TILE + 2)));
   HIP_TRY(hipEventCreate(&e->ev0));
   HIP_TRY(hipEventCreate(&e->ev1));
   HIP_TRY(hipEventCreate(&e->ev2));
@@ -579,6 +634,7 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_R")) e->budget_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_T")) e->budget_t = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
   *out = e;
   return ARTIS_OK;
@@ -591,7 +647,7 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
   void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_rlist[0], e->d_rlist[1],
-                  e->d_tlist[0], e->d_tlist[1], e->d_slist[0], e->d_slist[1], e->d_sorted, e->d_hist, e->d_count, e->d_cursors, e->d_gamma_ws};
+                  e->d_tlist[0], e->d_tlist[1], e->d_slist[0], e->d_slist[1], e->d_sorted, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_gamma_ws};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3, e->ev4, e->ev5})
@@ -714,14 +770,19 @@ int artis_amd_packets_restore(artis_amd_engine *e) {
 
 namespace {
 // sort list[0..n) by propagation cell into e->d_sorted; returns the pointer to launch on
-int sort_by_cell(artis_amd_engine *e, hipStream_t s, int32_t *list, int32_t n, const int32_t **out) {
+int sort_by_cell(artis_amd_engine *e, hipStream_t s, int32_t *list, int32_t n, const int32_t **out, int nbins) {
   *out = list;
   if (!e->sort_lists || n < 2 * BLOCK) return ARTIS_OK;
-  const int32_t ngrid = e->Mh.ngrid;
-  HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(ngrid + 1), s));
-  hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, n, e->P.cellindex, e->d_hist);
-  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, s, e->d_hist, ngrid);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, n, e->P.cellindex, e->d_hist, e->d_sorted);
+  if (!e->sort_nu) nbins = 1;
+  const int32_t nkeys = e->Mh.ngrid * nbins;
+  HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(nkeys + 1), s));
+  hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, n, e->P.cellindex, e->P.nu_cmf, nbins, e->d_hist);
+  const int ntiles = (nkeys + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
+  hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, e->d_tiles, ntiles);
+  hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, n, e->P.cellindex, e->P.nu_cmf, nbins, e->d_hist,
+                     e->d_sorted);
   *out = e->d_sorted;
   return ARTIS_OK;
 }
@@ -737,6 +798,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   e->last_propagate_ms = e->last_rpkt_ms = e->last_thermal_ms = 0.;
   e->last_nlaunches = 0;
   e->last_rpkt_threads = e->last_thermal_threads = 0;
+  e->last_rpkt_launches = e->last_thermal_launches = 0;
   const int64_t n = e->npackets;
   if (n == 0) return ARTIS_OK;
   Env env = make_env(e);
@@ -757,7 +819,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * 16, s));
     if (nr > 0) {
       const int32_t *lst = nullptr;
-      int rc = sort_by_cell(e, s, e->d_rlist[cur], nr, &lst);
+      int rc = sort_by_cell(e, s, e->d_rlist[cur], nr, &lst, SORT_NUBINS);
       if (rc != ARTIS_OK) return rc;
       HIP_TRY(hipEventRecord(e->ev0, s));
       const int grid = std::min(nblocks(nr), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
@@ -766,7 +828,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     }
     if (nt > 0) {
       const int32_t *lst = nullptr;
-      int rc = sort_by_cell(e, s, e->d_tlist[cur], nt, &lst);
+      int rc = sort_by_cell(e, s, e->d_tlist[cur], nt, &lst, 1);
       if (rc != ARTIS_OK) return rc;
       HIP_TRY(hipEventRecord(e->ev2, s));
       const int grid = std::min(nblocks(nt), e->ncu * ARTIS_THERMAL_WAVES);
@@ -786,12 +848,14 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       HIP_TRY(hipEventElapsedTime(&ms_r, e->ev0, e->ev1));
       e->last_rpkt_ms += ms_r;
       e->last_rpkt_threads += nr;
+      e->last_rpkt_launches++;
       e->last_nlaunches++;
     }
     if (nt > 0) {
       HIP_TRY(hipEventElapsedTime(&ms_t, e->ev2, e->ev3));
       e->last_thermal_ms += ms_t;
       e->last_thermal_threads += nt;
+      e->last_thermal_launches++;
       e->last_nlaunches++;
     }
     if (ns > 0) {
@@ -884,6 +948,13 @@ int artis_amd_last_kernel_ms(artis_amd_engine *e, double *propagate_ms, int64_t 
   if (!e) return ARTIS_ERR_ARG;
   if (propagate_ms) *propagate_ms = e->last_propagate_ms;
   if (nlaunches) *nlaunches = e->last_nlaunches;
+  return ARTIS_OK;
+}
+
+int artis_amd_last_kernel_launches(artis_amd_engine *e, int64_t *rpkt_launches, int64_t *thermal_launches) {
+  if (!e) return ARTIS_ERR_ARG;
+  if (rpkt_launches) *rpkt_launches = e->last_rpkt_launches;
+  if (thermal_launches) *thermal_launches = e->last_thermal_launches;
   return ARTIS_OK;
 }
 

@@ -66,6 +66,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_estimators_devptr", "artis_amd_last_kernel_ms", "artis_amd_debug_cellcache",
     "artis_amd_populate_cellcache",
     "artis_amd_last_kernel_breakdown",
+    "artis_amd_last_kernel_launches",
 ]
 
 
@@ -149,7 +150,11 @@ class Engine:
         a, b, c, d = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()
         self.L.artis_amd_last_kernel_breakdown.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         self._check(self.L.artis_amd_last_kernel_breakdown(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return {"rpkt_ms": a.value, "rpkt_threads": b.value, "thermal_ms": c.value, "thermal_threads": d.value}
+        e, f = C.c_int64(), C.c_int64()
+        self.L.artis_amd_last_kernel_launches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._check(self.L.artis_amd_last_kernel_launches(self.h, C.byref(e), C.byref(f)))
+        return {"rpkt_ms": a.value, "rpkt_threads": b.value, "rpkt_launches": e.value, "thermal_ms": c.value,
+                "thermal_threads": d.value, "thermal_launches": f.value}
 
     def last_kernel_ms(self):
         ms, n = C.c_double(), C.c_int64()

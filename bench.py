@@ -38,6 +38,8 @@ B_PER_LINE = 40.0             # line nu (8) + LinePack (16) + two level populati
 B_PER_MA_JUMP = 144.0         # 9 process rates (72) + ~9 probes of a cumulative block (72)
 B_PER_RPKT_STEP = 120.0       # cell scalars (~40) + J, nuJ, ffheating atomics (24) + boundary tables (~56)
 B_PER_KPKT_STEP = 160.0       # ion cumulative cooling probes + per-ion list probes
+B_PER_CONT = 56.0             # one bound-free continuum of the opacity sum: nnlevel, nu_edge, edge part, probability,
+                              # cross-section entry, level index, estimator index
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -185,14 +187,19 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = steps_all / (elapsed / args.steps)
-        # roofline of the dominant kernel k_propagate: algorithmic bytes of one timestep / its summed launch durations
-        thread_launches = None
-        alg_bytes = (B_PER_LINE * stats[abi.STAT_X_LINES_VISITED] + B_PER_MA_JUMP * stats[abi.STAT_X_MA_JUMPS] +
-                     B_PER_RPKT_STEP * stats[abi.STAT_X_RPKT_STEPS] + B_PER_KPKT_STEP * stats[abi.STAT_X_KPKT_STEPS] +
-                     B_PER_THREAD_LAUNCH * (stats[abi.STAT_X_RPKT_STEPS] + stats[abi.STAT_X_KPKT_STEPS]) * 0.5)
-        k_ms_per_step = kern_ms / max(args.steps, 1)
-        launches_per_step = kern_launches / max(args.steps, 1)
+        # roofline of the dominant kernel (k_thermal: macro-atom walk + k-packet steps): algorithmic bytes of its work
+        # in one timestep / its summed launch durations (HIP events on the launch stream, artis_engine.hip)
+        bd = eng.last_kernel_breakdown()
+        alg_thermal = (B_PER_MA_JUMP * stats[abi.STAT_X_MA_JUMPS] + B_PER_KPKT_STEP * stats[abi.STAT_X_KPKT_STEPS] +
+                       B_PER_THREAD_LAUNCH * bd["thermal_threads"])
+        alg_rpkt = (B_PER_LINE * stats[abi.STAT_X_LINES_VISITED] + B_PER_RPKT_STEP * stats[abi.STAT_X_RPKT_STEPS] +
+                    B_PER_CONT * stats[abi.STAT_NAMES.index("X_CONT_VISITED")] + B_PER_THREAD_LAUNCH * bd["rpkt_threads"])
+        dominant = "k_thermal" if bd["thermal_ms"] >= bd["rpkt_ms"] else "k_rpkt"
+        alg_bytes = alg_thermal if dominant == "k_thermal" else alg_rpkt
+        k_ms_per_step = bd["thermal_ms"] if dominant == "k_thermal" else bd["rpkt_ms"]
+        launches_per_step = bd["thermal_launches"] if dominant == "k_thermal" else bd["rpkt_launches"]
         achieved = alg_bytes / (k_ms_per_step * 1e-3) / 1e9 if k_ms_per_step > 0 else 0.0
+        both = (alg_thermal + alg_rpkt) / ((bd["thermal_ms"] + bd["rpkt_ms"]) * 1e-3) / 1e9
         traffic = os.environ.get("ARTIS_BENCH_TRAFFIC_BYTES")
         out = {
             "metric": "packet-steps/sec", "value": value, "unit": "packet-steps/s", "n_gpus": world, "steps": args.steps,
@@ -208,11 +215,12 @@ def main():
                        else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": float(traffic) if traffic else None,
-                         "kernel": "k_propagate", "launches_per_step": launches_per_step,
+                         "kernel": dominant, "launches_per_step": launches_per_step,
                          "kernel_ms_per_step": k_ms_per_step, "avg_launch_ms": k_ms_per_step / max(launches_per_step, 1),
-                         "algorithmic_bytes_per_step": float(alg_bytes)},
+                         "algorithmic_bytes_per_step": float(alg_bytes),
+                         "achieved_both_propagation_kernels": both},
         }
-        out["kernel_breakdown_last_step"] = eng.last_kernel_breakdown()
+        out["kernel_breakdown_last_step"] = bd
         if os.environ.get("ARTIS_BENCH_VERBOSE"):
             print({abi.STAT_NAMES[i]: int(stats[i]) for i in range(abi.NSTATS) if stats[i]}, file=sys.stderr)
         if baseline is not None:

@@ -365,6 +365,8 @@ int artis_amd_last_kernel_ms(artis_amd_engine *eng, double *propagate_ms, int64_
 int artis_amd_last_kernel_breakdown(artis_amd_engine *eng, double *rpkt_ms, int64_t *rpkt_threads, double *thermal_ms,
                                     int64_t *thermal_threads);
 
+int artis_amd_last_kernel_launches(artis_amd_engine *eng, int64_t *rpkt_launches, int64_t *thermal_launches);
+
 /* Diagnostics: copy the cell cache of one non-empty cell back to the host (the reference's
  * globals::cellcache[nonemptymgi] spans, globals.h:283-311). Any pointer may be NULL. */
 int artis_amd_debug_cellcache(artis_amd_engine *eng, int nonemptymgi, double *levelpops, double *maprocessrates,

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc counter_collection.csv files per kernel (sum over dispatches)."""
+import collections, csv, glob, sys
+dirs = sys.argv[1:]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+dur = collections.defaultdict(float)
+ndisp = collections.defaultdict(int)
+for d in dirs:
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        seen = set()
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+            agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+            if row["Dispatch_Id"] not in seen and row["Counter_Name"] in ("FETCH_SIZE", "SQ_WAVES"):
+                seen.add(row["Dispatch_Id"])
+                if row["Counter_Name"] == "FETCH_SIZE":
+                    dur[k] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
+                    ndisp[k] += 1
+for k, v in sorted(agg.items()):
+    if not any(x in k for x in ("k_thermal", "k_rpkt", "k_slow", "k_macroatom")):
+        continue
+    print(f"{k}: {ndisp[k]} dispatches, {dur[k]:.4f} s (in the FETCH_SIZE pass)")
+    for c, val in sorted(v.items()):
+        print(f"   {c:36s} {val:.6g}")
+    if "SQ_THREAD_CYCLES_VALU" in v and "SQ_ACTIVE_INST_VALU" in v and v["SQ_ACTIVE_INST_VALU"]:
+        print(f"   -> VALU lane utilisation           {v['SQ_THREAD_CYCLES_VALU'] / (64 * v['SQ_ACTIVE_INST_VALU']):.3f}")
+    if "TCC_HIT_sum" in v:
+        print(f"   -> L2 hit rate                     {v['TCC_HIT_sum'] / (v['TCC_HIT_sum'] + v['TCC_MISS_sum']):.3f}")
+    if "FETCH_SIZE" in v and dur[k]:
+        print(f"   -> FETCH_SIZE KB/s (x2 per guide)  {v['FETCH_SIZE'] / dur[k]:.4g}  WRITE_SIZE KB/s {v.get('WRITE_SIZE', 0) / dur[k]:.4g}")
