@@ -121,15 +121,23 @@ __device__ inline int64_t xcd_chunk(int64_t b, int64_t nb) {
   return ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
 }
 
-// the three work lists of a round and their counters: [0] r-packets, [1] thermal, [2] slow path
+// Work lists, one per kind of pending work (physics.h NEXT_*). A kernel consumes the whole current list of ITS kind and
+// appends packets to the current lists of the other kinds; packets that stay with the kernel's own kind (launch budget
+// used up) go to that kind's alternate list, which becomes its current list afterwards.
 struct Lists {
-  int32_t *r, *t, *s;
-  int32_t *counts;
+  int32_t *lst[NEXT_NKINDS];  // current list of each kind
+  int32_t *counts;            // [NEXT_NKINDS] fill counts of the current lists
+  int32_t self_kind;          // kind of the running kernel
+  int32_t *self_list;         // its alternate list
+  int32_t *self_count;
 };
 __device__ inline void append_by_kind(int kind, int32_t pi, const Lists &L) {
-  wave_append(kind == NEXT_RPKT, pi, L.r, L.counts + 0);
-  wave_append(kind == NEXT_THERMAL, pi, L.t, L.counts + 1);
-  wave_append(kind == NEXT_SLOW, pi, L.s, L.counts + 2);
+#pragma unroll
+  for (int k = 1; k < NEXT_NKINDS; k++) {
+    int32_t *dst = (k == L.self_kind) ? L.self_list : L.lst[k];
+    int32_t *cnt = (k == L.self_kind) ? L.self_count : (L.counts + k);
+    wave_append(kind == k, pi, dst, cnt);
+  }
 }
 __global__ void __launch_bounds__(BLOCK) k_classify(PktSoA P, double ts_end, Lists L) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -139,9 +147,9 @@ __global__ void __launch_bounds__(BLOCK) k_classify(PktSoA P, double ts_end, Lis
     if (P.pend[i] != PEND_NONE) {
       kind = NEXT_SLOW;
     } else if (P.ma_level[i] >= 0) {
-      kind = NEXT_THERMAL;
+      kind = NEXT_MA;
     } else if (type_handled(type) && P.prop_time[i] < ts_end) {
-      kind = (type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_THERMAL;
+      kind = (type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_KPKT;
     }
   }
   append_by_kind(kind, (int32_t)i, L);
@@ -332,9 +340,13 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
 }
 
-// thermal packets: k-packet cooling-channel sampling and the macro-atom random walk
-__global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                         unsigned long long *gstats, int budget, int32_t *cursors) {
+// macro-atom random walk: every lane walks one macro-atom, one transition per iteration, and takes the next packet of
+// the list as soon as its own walk has ended (deactivation, slow-path action or launch budget)
+#ifndef ARTIS_MA_WAVES
+#define ARTIS_MA_WAVES 4
+#endif
+__global__ void __launch_bounds__(BLOCK, ARTIS_MA_WAVES) k_ma(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats,
+                                                               int budget, int32_t *cursors) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   __syncthreads();
@@ -363,8 +375,11 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
     int kind = NEXT_DONE;
     int32_t out_pi = 0;
     if (have) {
-      bool go = thermal_can_continue(p, ts_end);
-      if (go) units += thermal_iter(env, p, pi, k, &go);
+      bool go = ma_pending(p) && p.pend == PEND_NONE;
+      if (go) {
+        go = ma_iter(env, p, pi, k);
+        units++;
+      }
       if (!go || units >= budget) {
         pkt_store(env.P, pi, p);
         kind = classify(p, ts_end);
@@ -373,6 +388,36 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
       }
     }
     append_by_kind(kind, out_pi, next);
+  }
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+}
+
+// k-packets: every lane performs exactly one k-packet step (cooling-channel sampling), all lanes in step
+#ifndef ARTIS_KPKT_WAVES
+#define ARTIS_KPKT_WAVES 4
+#endif
+__global__ void __launch_bounds__(BLOCK, ARTIS_KPKT_WAVES) k_kpkt(Env env, const int32_t *list, int32_t n, Lists next,
+                                                                   unsigned long long *gstats, int32_t *cursors) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  env.stats = lstats;
+  Puller q;
+  puller_init(q);
+  while (true) {
+    const int32_t idx = pull(q, true, n, cursors);
+    int kind = NEXT_DONE;
+    int32_t pi = 0;
+    if (idx >= 0) {
+      pi = list[idx];
+      Pkt p;
+      pkt_load(env.P, pi, p);
+      kind = advance_kpkt(env, p, pi);
+      pkt_store(env.P, pi, p);
+    }
+    append_by_kind(kind, pi, next);
+    if (q.exhausted && !__any(idx >= 0)) break;
   }
   __syncthreads();
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
@@ -432,28 +477,26 @@ struct artis_amd_engine {
   PktSoA P{};
   artis_packet *d_aos = nullptr;
   int64_t aos_capacity = 0;
-  int32_t *d_rlist[2] = {nullptr, nullptr};  // r-packet work lists (ping-pong)
-  int32_t *d_tlist[2] = {nullptr, nullptr};  // thermal work lists (ping-pong)
-  int32_t *d_slist[2] = {nullptr, nullptr};  // slow-path work lists (ping-pong)
+  int32_t *d_lists[NEXT_NKINDS][2] = {};      // per kind: current and alternate work list
   int32_t *d_sorted = nullptr;                // counting-sort output
   int32_t *d_hist = nullptr;                  // [ngrid * SORT_NUBINS + 1]
   int32_t *d_tiles = nullptr;                 // scan tile totals
-  int32_t *d_count = nullptr;                 // [8]: two sets of (r, thermal, slow, pad)
-  int32_t *d_cursors = nullptr;               // [16]: 8 chunk cursors for k_rpkt, 8 for k_thermal
+  int32_t *d_count = nullptr;                 // [NEXT_NKINDS] current-list counts, [NEXT_NKINDS] alternate-list count
+  int32_t *d_cursors = nullptr;               // [8] chunk cursors of the running pull kernel
   int ncu = 256;
   double *d_gamma_ws = nullptr;
   int64_t ws_capacity = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   double last_propagate_ms = 0.;
-  double last_rpkt_ms = 0., last_thermal_ms = 0., last_slow_ms = 0.;
-  hipEvent_t ev4 = nullptr, ev5 = nullptr;
+  double kms[NEXT_NKINDS] = {};       // summed launch durations per kind of the last update_packets_device call
+  int64_t klaunches[NEXT_NKINDS] = {};
+  int64_t kthreads[NEXT_NKINDS] = {};
   int64_t last_nlaunches = 0;
-  int64_t last_rpkt_threads = 0, last_thermal_threads = 0;
-  int64_t last_rpkt_launches = 0, last_thermal_launches = 0;
-  int budget_r = 8;      // do_rpkt_step() calls per thread per launch
-  int budget_t = 512;    // macro-atom transitions / k-packet steps per thread per launch
+  int budget_r = 8;      // do_rpkt_step() calls per packet per launch
+  int budget_t = 4096;   // macro-atom transitions per packet per launch
   bool sort_lists = true;
   bool sort_nu = true;
+  bool sort_ma = false;
   bool trace = false;
 };
 
@@ -497,12 +540,11 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
   if (e->d_soa) (void)hipFree(e->d_soa);
   if (e->d_soa_snapshot) (void)hipFree(e->d_soa_snapshot);
   e->d_soa = e->d_soa_snapshot = nullptr;
-  for (int k = 0; k < 2; k++) {
-    if (e->d_rlist[k]) (void)hipFree(e->d_rlist[k]);
-    if (e->d_tlist[k]) (void)hipFree(e->d_tlist[k]);
-    if (e->d_slist[k]) (void)hipFree(e->d_slist[k]);
-    e->d_rlist[k] = e->d_tlist[k] = e->d_slist[k] = nullptr;
-  }
+  for (int kind = 0; kind < NEXT_NKINDS; kind++)
+    for (int k = 0; k < 2; k++) {
+      if (e->d_lists[kind][k]) (void)hipFree(e->d_lists[kind][k]);
+      e->d_lists[kind][k] = nullptr;
+    }
   if (e->d_sorted) (void)hipFree(e->d_sorted);
   e->d_sorted = nullptr;
   if (e->d_gamma_ws) (void)hipFree(e->d_gamma_ws);
@@ -512,11 +554,8 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
   HIP_TRY(hipMalloc(&e->d_soa, e->soa_bytes));
   e->P = carve_pkt_soa(e->d_soa, n);
   const size_t listbytes = sizeof(int32_t) * (size_t)(n > 0 ? n : 1);
-  for (int k = 0; k < 2; k++) {
-    HIP_TRY(hipMalloc((void **)&e->d_rlist[k], listbytes));
-    HIP_TRY(hipMalloc((void **)&e->d_tlist[k], listbytes));
-    HIP_TRY(hipMalloc((void **)&e->d_slist[k], listbytes));
-  }
+  for (int kind = 1; kind < NEXT_NKINDS; kind++)
+    for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void **)&e->d_lists[kind][k], listbytes));
   HIP_TRY(hipMalloc((void **)&e->d_sorted, listbytes));
   e->ws_capacity = n > 0 ? n : 1;
   const size_t wsbytes = sizeof(double) * (size_t)(e->Mh.nbfcontinua_ground + 1) * (size_t)e->ws_capacity;
@@ -612,8 +651,8 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
   HIP_TRY(hipMemset(e->d_err, 0, sizeof(int32_t)));
-  HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 8));
-  HIP_TRY(hipMalloc((void **)&e->d_cursors, sizeof(int32_t) * 16));
+  HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 2 * NEXT_NKINDS));
+  HIP_TRY(hipMalloc((void **)&e->d_cursors, sizeof(int32_t) * 8));
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -625,8 +664,6 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   HIP_TRY(hipEventCreate(&e->ev1));
   HIP_TRY(hipEventCreate(&e->ev2));
   HIP_TRY(hipEventCreate(&e->ev3));
-  HIP_TRY(hipEventCreate(&e->ev4));
-  HIP_TRY(hipEventCreate(&e->ev5));
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET")) {  // tuning / tests: launch budgets never change results
     e->budget_r = std::max(1, std::atoi(b));
     e->budget_t = std::max(1, std::atoi(b));
@@ -635,6 +672,7 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_T")) e->budget_t = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
   *out = e;
   return ARTIS_OK;
@@ -646,11 +684,14 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->model_allocs);
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
-  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_rlist[0], e->d_rlist[1],
-                  e->d_tlist[0], e->d_tlist[1], e->d_slist[0], e->d_slist[1], e->d_sorted, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_gamma_ws};
+  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_sorted, e->d_hist, e->d_tiles,
+                  e->d_count, e->d_cursors, e->d_gamma_ws};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
-  for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3, e->ev4, e->ev5})
+  for (int kind = 0; kind < NEXT_NKINDS; kind++)
+    for (int k = 0; k < 2; k++)
+      if (e->d_lists[kind][k]) (void)hipFree(e->d_lists[kind][k]);
+  for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3})
     if (ev) (void)hipEventDestroy(ev);
   delete e;
 }
@@ -795,87 +836,93 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   }
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = (hipStream_t)hip_stream;
-  e->last_propagate_ms = e->last_rpkt_ms = e->last_thermal_ms = 0.;
+  e->last_propagate_ms = 0.;
   e->last_nlaunches = 0;
-  e->last_rpkt_threads = e->last_thermal_threads = 0;
-  e->last_rpkt_launches = e->last_thermal_launches = 0;
+  for (int k = 0; k < NEXT_NKINDS; k++) {
+    e->kms[k] = 0.;
+    e->klaunches[k] = 0;
+    e->kthreads[k] = 0;
+  }
   const int64_t n = e->npackets;
   if (n == 0) return ARTIS_OK;
   Env env = make_env(e);
-  int32_t counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int cur = 0;
-  auto lists_of = [&](int k) { return Lists{e->d_rlist[k], e->d_tlist[k], e->d_slist[k], e->d_count + 4 * k}; };
-  HIP_TRY(hipMemsetAsync(e->d_count, 0, sizeof(int32_t) * 8, s));
-  hipLaunchKernelGGL(k_classify, dim3(nblocks(n)), dim3(BLOCK), 0, s, e->P, e->S.ts_end, lists_of(cur));
-  HIP_TRY(hipMemcpyAsync(counts, e->d_count, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  int32_t nr = counts[4 * cur], nt = counts[4 * cur + 1], ns = counts[4 * cur + 2];
-  e->last_slow_ms = 0.;
-  int64_t guard = 0;
-  while (nr > 0 || nt > 0 || ns > 0) {
-    const int nxt = 1 - cur;
-    const Lists next = lists_of(nxt);
-    HIP_TRY(hipMemsetAsync(e->d_count + 4 * nxt, 0, sizeof(int32_t) * 4, s));
-    HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * 16, s));
-    if (nr > 0) {
-      const int32_t *lst = nullptr;
-      int rc = sort_by_cell(e, s, e->d_rlist[cur], nr, &lst, SORT_NUBINS);
-      if (rc != ARTIS_OK) return rc;
-      HIP_TRY(hipEventRecord(e->ev0, s));
-      const int grid = std::min(nblocks(nr), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
-      hipLaunchKernelGGL(k_rpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nr, next, e->d_stats, e->budget_r, e->d_cursors);
-      HIP_TRY(hipEventRecord(e->ev1, s));
-    }
-    if (nt > 0) {
-      const int32_t *lst = nullptr;
-      int rc = sort_by_cell(e, s, e->d_tlist[cur], nt, &lst, 1);
-      if (rc != ARTIS_OK) return rc;
-      HIP_TRY(hipEventRecord(e->ev2, s));
-      const int grid = std::min(nblocks(nt), e->ncu * ARTIS_THERMAL_WAVES);
-      hipLaunchKernelGGL(k_thermal, dim3(grid), dim3(BLOCK), 0, s, env, lst, nt, next, e->d_stats, e->budget_t, e->d_cursors + 8);
-      HIP_TRY(hipEventRecord(e->ev3, s));
-    }
-    if (ns > 0) {
-      HIP_TRY(hipEventRecord(e->ev4, s));
-      hipLaunchKernelGGL(k_slow, dim3(nblocks(ns)), dim3(BLOCK), 0, s, env, e->d_slist[cur], ns, next, e->d_stats);
-      HIP_TRY(hipEventRecord(e->ev5, s));
-    }
-    HIP_TRY(hipMemcpyAsync(counts, e->d_count, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, s));
+  int cur[NEXT_NKINDS] = {0, 0, 0, 0, 0};             // which of the two buffers is the current list of each kind
+  int32_t cnt[2 * NEXT_NKINDS];                        // host copy of the device counters
+  auto lists_for = [&](int self_kind) {
+    Lists L;
+    for (int k = 0; k < NEXT_NKINDS; k++) L.lst[k] = e->d_lists[k][cur[k]];
+    L.counts = e->d_count;
+    L.self_kind = self_kind;
+    L.self_list = self_kind > 0 ? e->d_lists[self_kind][1 - cur[self_kind]] : nullptr;
+    L.self_count = e->d_count + NEXT_NKINDS;  // one alternate counter: only one kernel runs at a time
+    return L;
+  };
+  auto read_counts = [&]() -> int {
+    HIP_TRY(hipMemcpyAsync(cnt, e->d_count, sizeof(int32_t) * 2 * NEXT_NKINDS, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(hipGetLastError());
-    float ms_r = 0.f, ms_t = 0.f, ms_s = 0.f;
-    if (nr > 0) {
-      HIP_TRY(hipEventElapsedTime(&ms_r, e->ev0, e->ev1));
-      e->last_rpkt_ms += ms_r;
-      e->last_rpkt_threads += nr;
-      e->last_rpkt_launches++;
+    return ARTIS_OK;
+  };
+  HIP_TRY(hipMemsetAsync(e->d_count, 0, sizeof(int32_t) * 2 * NEXT_NKINDS, s));
+  hipLaunchKernelGGL(k_classify, dim3(nblocks(n)), dim3(BLOCK), 0, s, e->P, e->S.ts_end, lists_for(0));
+  int rc = read_counts();
+  if (rc != ARTIS_OK) return rc;
+
+  // one launch = the whole current list of one kind. Order: slow path, k-packets, macro-atoms, r-packets, so that a
+  // k-packet -> macro-atom -> k-packet cycle costs two launches.
+  const int order[4] = {NEXT_SLOW, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
+  int64_t guard = 0;
+  while (cnt[NEXT_RPKT] > 0 || cnt[NEXT_MA] > 0 || cnt[NEXT_SLOW] > 0 || cnt[NEXT_KPKT] > 0) {
+    for (int kind : order) {
+      const int32_t nk = cnt[kind];
+      if (nk <= 0) continue;
+      const Lists next = lists_for(kind);
+      const int32_t *lst = e->d_lists[kind][cur[kind]];
+      if (kind == NEXT_RPKT || (kind == NEXT_MA && e->sort_ma)) {
+        rc = sort_by_cell(e, s, e->d_lists[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? SORT_NUBINS : 1);
+        if (rc != ARTIS_OK) return rc;
+      }
+      // the kernel starts with an empty current list of its own kind: everything it keeps goes to the alternate list
+      HIP_TRY(hipMemsetAsync(e->d_count + kind, 0, sizeof(int32_t), s));
+      HIP_TRY(hipMemsetAsync(e->d_count + NEXT_NKINDS, 0, sizeof(int32_t), s));
+      HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * 8, s));
+      HIP_TRY(hipEventRecord(e->ev0, s));
+      if (kind == NEXT_RPKT) {
+        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
+        hipLaunchKernelGGL(k_rpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors);
+      } else if (kind == NEXT_MA) {
+        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_MA_WAVES);
+        hipLaunchKernelGGL(k_ma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors);
+      } else if (kind == NEXT_KPKT) {
+        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_KPKT_WAVES);
+        hipLaunchKernelGGL(k_kpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->d_cursors);
+      } else {
+        hipLaunchKernelGGL(k_slow, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);
+      }
+      HIP_TRY(hipEventRecord(e->ev1, s));
+      rc = read_counts();
+      if (rc != ARTIS_OK) return rc;
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+      e->kms[kind] += ms;
+      e->klaunches[kind]++;
+      e->kthreads[kind] += nk;
       e->last_nlaunches++;
-    }
-    if (nt > 0) {
-      HIP_TRY(hipEventElapsedTime(&ms_t, e->ev2, e->ev3));
-      e->last_thermal_ms += ms_t;
-      e->last_thermal_threads += nt;
-      e->last_thermal_launches++;
-      e->last_nlaunches++;
-    }
-    if (ns > 0) {
-      HIP_TRY(hipEventElapsedTime(&ms_s, e->ev4, e->ev5));
-      e->last_slow_ms += ms_s;
-      e->last_nlaunches++;
-    }
-    if (e->trace)
-      fprintf(stderr, "[artis_amd] round %lld: rpkt n=%d %.3f ms | thermal n=%d %.3f ms | slow n=%d %.3f ms\n", (long long)guard, nr,
-              ms_r, nt, ms_t, ns, ms_s);
-    nr = counts[4 * nxt];
-    nt = counts[4 * nxt + 1];
-    ns = counts[4 * nxt + 2];
-    cur = nxt;
-    if (++guard > 100000000LL) {
-      g_last_error = "packet loop did not terminate";
-      return ARTIS_ERR_NOTCONVERGED;
+      if (e->trace)
+        fprintf(stderr, "[artis_amd] launch %lld kind %d n=%d %.3f ms -> r %d ma %d slow %d k %d self %d\n", (long long)e->last_nlaunches,
+                kind, nk, ms, cnt[NEXT_RPKT], cnt[NEXT_MA], cnt[NEXT_SLOW], cnt[NEXT_KPKT], cnt[NEXT_NKINDS]);
+      // the alternate list of this kind becomes its current list
+      cur[kind] = 1 - cur[kind];
+      cnt[kind] = cnt[NEXT_NKINDS];
+      HIP_TRY(hipMemcpyAsync(e->d_count + kind, &cnt[kind], sizeof(int32_t), hipMemcpyHostToDevice, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (++guard > 100000000LL) {
+        g_last_error = "packet loop did not terminate";
+        return ARTIS_ERR_NOTCONVERGED;
+      }
     }
   }
-  e->last_propagate_ms = e->last_rpkt_ms + e->last_thermal_ms + e->last_slow_ms;
+  for (int k = 1; k < NEXT_NKINDS; k++) e->last_propagate_ms += e->kms[k];
   int32_t err = 0;
   HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
   if (err != 0) {
@@ -953,18 +1000,29 @@ int artis_amd_last_kernel_ms(artis_amd_engine *e, double *propagate_ms, int64_t 
 
 int artis_amd_last_kernel_launches(artis_amd_engine *e, int64_t *rpkt_launches, int64_t *thermal_launches) {
   if (!e) return ARTIS_ERR_ARG;
-  if (rpkt_launches) *rpkt_launches = e->last_rpkt_launches;
-  if (thermal_launches) *thermal_launches = e->last_thermal_launches;
+  if (rpkt_launches) *rpkt_launches = e->klaunches[NEXT_RPKT];
+  if (thermal_launches) *thermal_launches = e->klaunches[NEXT_MA] + e->klaunches[NEXT_KPKT];
   return ARTIS_OK;
 }
 
 int artis_amd_last_kernel_breakdown(artis_amd_engine *e, double *rpkt_ms, int64_t *rpkt_threads, double *thermal_ms,
                                     int64_t *thermal_threads) {
   if (!e) return ARTIS_ERR_ARG;
-  if (rpkt_ms) *rpkt_ms = e->last_rpkt_ms;
-  if (rpkt_threads) *rpkt_threads = e->last_rpkt_threads;
-  if (thermal_ms) *thermal_ms = e->last_thermal_ms;
-  if (thermal_threads) *thermal_threads = e->last_thermal_threads;
+  if (rpkt_ms) *rpkt_ms = e->kms[NEXT_RPKT];
+  if (rpkt_threads) *rpkt_threads = e->kthreads[NEXT_RPKT];
+  if (thermal_ms) *thermal_ms = e->kms[NEXT_MA] + e->kms[NEXT_KPKT];
+  if (thermal_threads) *thermal_threads = e->kthreads[NEXT_MA] + e->kthreads[NEXT_KPKT];
+  return ARTIS_OK;
+}
+
+int artis_amd_last_kernel_table(artis_amd_engine *e, double ms[4], int64_t launches[4], int64_t packets[4]) {
+  if (!e) return ARTIS_ERR_ARG;
+  const int kinds[4] = {NEXT_RPKT, NEXT_MA, NEXT_KPKT, NEXT_SLOW};
+  for (int i = 0; i < 4; i++) {
+    if (ms) ms[i] = e->kms[kinds[i]];
+    if (launches) launches[i] = e->klaunches[kinds[i]];
+    if (packets) packets[i] = e->kthreads[kinds[i]];
+  }
   return ARTIS_OK;
 }
 

@@ -1899,14 +1899,14 @@ AHD void pkt_store(const PktSoA &P, int64_t i, const Pkt &p) {
   P.pend[i] = p.pend; P.pend_arg[i] = p.pend_arg;
 }
 
-// Work lists: a packet that still needs updating is either "in flight" (an r-packet inside or about to enter
-// do_rpkt(), rpkt.cc:983) or "thermal" (a k-packet, a pre-k-packet, or any packet with an activated macro-atom).
-enum { NEXT_DONE = 0, NEXT_RPKT = 1, NEXT_THERMAL = 2, NEXT_SLOW = 3 };
+// Work lists: a packet that still needs updating is "in flight" (an r-packet inside or about to enter do_rpkt()),
+// walking a macro-atom, a k-packet (or pre-k-packet) due for its next step, or waiting for a slow-path action.
+enum { NEXT_DONE = 0, NEXT_RPKT = 1, NEXT_MA = 2, NEXT_SLOW = 3, NEXT_KPKT = 4, NEXT_NKINDS = 5 };
 AHD int classify(const Pkt &p, double ts_end) {
   if (p.pend != PEND_NONE) return NEXT_SLOW;
-  if (ma_pending(p)) return NEXT_THERMAL;
+  if (ma_pending(p)) return NEXT_MA;
   if (!pkt_active(p, ts_end)) return NEXT_DONE;
-  return (p.type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_THERMAL;
+  return (p.type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_KPKT;
 }
 
 // ---- r-packet kernel body. One iteration = one call of do_rpkt_step() (rpkt.cc:542). The packet's ContinuumOpacity x is
@@ -1939,48 +1939,40 @@ AHD void chi_after_ma(const Env &env, const Pkt &p, int64_t pi) {
   if (!ma_pending(p) && !(p.type == ARTIS_TYPE_RPKT && p.ma_origin == 1)) env.P.chi_mgi[pi] = -1;
 }
 
-// ---- thermal kernel body. A unit of work is one macro-atom transition (ma_jump) or one do_kpkt()/do_kpkt_blackbody()
-// call (update_packets.cc:291-305). One iteration alternates two phases so that the lanes of a wave run the same code
-// at the same time: a macro-atom phase of up to ARTIS_MA_PHASE transitions (a small loop of table lookups), then ONE
-// k-packet step for every lane whose macro-atom has deactivated. Without the phases, some lane of the wave is at its
-// (long, branchy) k-packet step in almost every iteration and the whole wave pays for it every time. Phases only
-// order the work of different packets; the sequence of operations on one packet is unchanged.
-#ifndef ARTIS_MA_PHASE
-#define ARTIS_MA_PHASE 64
-#endif
-AHD bool thermal_can_continue(const Pkt &p, double ts_end) {
-  if (p.pend != PEND_NONE) return false;
-  if (ma_pending(p)) return true;
-  return pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT;
+// ---- macro-atom kernel body: one iteration = one transition of the walk (ma_jump). Returns true while the walk goes on
+// in this kernel (not deactivated, not handed to the slow path).
+AHD bool ma_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
+  ma_jump(env, p, pi, k);
+  const bool go = ma_pending(p) && p.pend == PEND_NONE;
+  if (!ma_pending(p)) chi_after_ma(env, p, pi);
+  return go;
 }
-// returns the units of work done; *go = the packet can take another iteration in the thermal kernel
-AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
-  const double ts_end = env.S.ts_end;
-  // phase 1: macro-atom transitions
-  int j = 0;
-  while (j < ARTIS_MA_PHASE && ma_pending(p) && p.pend == PEND_NONE) {
-    ma_jump(env, p, pi, k);
-    j++;
+AHD int advance_ma(const Env &env, Pkt &p, int64_t pi, int budget) {
+  MACtx k = ma_ctx(env, p);
+  int units = 0;
+  bool go = ma_pending(p) && p.pend == PEND_NONE;
+  while (go && units < budget) {
+    go = ma_iter(env, p, pi, k);
+    units++;
   }
-  if (j > 0) chi_after_ma(env, p, pi);
-  // phase 2: one k-packet step (not for a packet still walking, handed to the slow path, or an r-packet again)
-  if (!ma_pending(p) && p.pend == PEND_NONE && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT) {
-    if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[k.c] == ARTIS_CELL_THICK) {
+  return classify(p, env.S.ts_end);
+}
+
+// ---- k-packet kernel body: ONE do_kpkt()/do_kpkt_blackbody() call (update_packets.cc:291-305); it ends in an emission,
+// a macro-atom activation, a deferred free-bound emission, or at the end of the timestep.
+AHD bool kpkt_eligible(const Pkt &p, double ts_end) {
+  return p.pend == PEND_NONE && !ma_pending(p) && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT;
+}
+AHD int advance_kpkt(const Env &env, Pkt &p, int64_t pi) {
+  if (kpkt_eligible(p, env.S.ts_end)) {
+    const int c = env.M.propcell_nonemptymgi[p.cellindex];
+    if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[c] == ARTIS_CELL_THICK) {
       do_kpkt_blackbody(env, p, pi);
     } else {
       do_kpkt(env, p, pi);
     }
     env.P.chi_mgi[pi] = -1;
-    j++;
   }
-  *go = thermal_can_continue(p, ts_end);
-  return j;
-}
-AHD int advance_thermal(const Env &env, Pkt &p, int64_t pi, int budget) {
-  int units = 0;
-  MACtx k = ma_ctx(env, p);
-  bool go = thermal_can_continue(p, env.S.ts_end);
-  while (go && units < budget) units += thermal_iter(env, p, pi, k, &go);
   return classify(p, env.S.ts_end);
 }
 

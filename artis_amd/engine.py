@@ -67,6 +67,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_populate_cellcache",
     "artis_amd_last_kernel_breakdown",
     "artis_amd_last_kernel_launches",
+    "artis_amd_last_kernel_table",
 ]
 
 
@@ -155,6 +156,13 @@ class Engine:
         self._check(self.L.artis_amd_last_kernel_launches(self.h, C.byref(e), C.byref(f)))
         return {"rpkt_ms": a.value, "rpkt_threads": b.value, "rpkt_launches": e.value, "thermal_ms": c.value,
                 "thermal_threads": d.value, "thermal_launches": f.value}
+
+    def last_kernel_table(self):
+        ms, nl, npk = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_int64 * 4)()
+        self.L.artis_amd_last_kernel_table.argtypes = [C.c_void_p] * 4
+        self._check(self.L.artis_amd_last_kernel_table(self.h, ms, nl, npk))
+        names = ["k_rpkt", "k_ma", "k_kpkt", "k_slow"]
+        return {n: {"ms": ms[i], "launches": nl[i], "packets": npk[i]} for i, n in enumerate(names)}
 
     def last_kernel_ms(self):
         ms, n = C.c_double(), C.c_int64()

@@ -361,11 +361,13 @@ int artis_amd_estimators_devptr(artis_amd_engine *eng, void **dptr, int64_t *ndo
 int artis_amd_last_kernel_ms(artis_amd_engine *eng, double *propagate_ms, int64_t *nlaunches);
 
 /* Per-kernel split of the last artis_amd_update_packets_device call: summed launch durations [ms] and summed
- * thread counts of the r-packet kernel (k_rpkt) and of the thermal kernel (k_thermal). */
+ * packet counts of the r-packet kernel (k_rpkt) and of the thermal kernels (k_ma + k_kpkt). */
 int artis_amd_last_kernel_breakdown(artis_amd_engine *eng, double *rpkt_ms, int64_t *rpkt_threads, double *thermal_ms,
                                     int64_t *thermal_threads);
 
 int artis_amd_last_kernel_launches(artis_amd_engine *eng, int64_t *rpkt_launches, int64_t *thermal_launches);
+/* The same for each kernel: index 0 k_rpkt, 1 k_ma, 2 k_kpkt, 3 k_slow. */
+int artis_amd_last_kernel_table(artis_amd_engine *eng, double ms[4], int64_t launches[4], int64_t packets[4]);
 
 /* Diagnostics: copy the cell cache of one non-empty cell back to the host (the reference's
  * globals::cellcache[nonemptymgi] spans, globals.h:283-311). Any pointer may be NULL. */

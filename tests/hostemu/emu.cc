@@ -79,52 +79,46 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
   std::vector<uint8_t> soabuf(pkt_soa_bytes(npackets) + 64);
   e.env.P = carve_pkt_soa(soabuf.data(), npackets);
   for (int64_t i = 0; i < npackets; i++) aos_to_soa(packets[i], e.env.P, i);
-  // work lists + budgeted launches, as in artis_amd_update_packets_device(): an r-packet list and a thermal list
-  std::vector<int64_t> rl, tl, sl, rn, tn, sn;
-  auto push = [&](int kind, int64_t pi) {
-    if (kind == NEXT_RPKT) rn.push_back(pi);
-    if (kind == NEXT_THERMAL) tn.push_back(pi);
-    if (kind == NEXT_SLOW) sn.push_back(pi);
-  };
+  // work lists + budgeted launches, as in artis_amd_update_packets_device(): one list per kind of pending work;
+  // a launch consumes the whole current list of its kind and appends to the lists of the other kinds
+  std::vector<int64_t> lists[NEXT_NKINDS], self;
   for (int64_t i = 0; i < npackets; i++) {
     Pkt p;
     pkt_load(e.env.P, i, p);
-    push(classify(p, e.env.S.ts_end), i);
+    const int kind = classify(p, e.env.S.ts_end);
+    if (kind != NEXT_DONE) lists[kind].push_back(i);
   }
-  rl.swap(rn);
-  tl.swap(tn);
-  sl.swap(sn);
-  while ((!rl.empty() || !tl.empty() || !sl.empty()) && !e.err) {
-    rn.clear();
-    tn.clear();
-    sn.clear();
-    for (int64_t pi : rl) {  // k_rpkt
-      Pkt p;
-      Chi x;
-      pkt_load(e.env.P, pi, p);
-      chi_load(e.env.P, pi, x);
-      const int kind = advance_rpkt(e.env, p, pi, x, budget);
-      pkt_store(e.env.P, pi, p);
-      chi_store(e.env.P, pi, x);
-      push(kind, pi);
+  auto any = [&] {
+    for (int k = 1; k < NEXT_NKINDS; k++)
+      if (!lists[k].empty()) return true;
+    return false;
+  };
+  const int order[4] = {NEXT_SLOW, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
+  while (any() && !e.err) {
+    for (int kind : order) {
+      if (lists[kind].empty()) continue;
+      std::vector<int64_t> cur;
+      cur.swap(lists[kind]);
+      for (int64_t pi : cur) {
+        Pkt p;
+        pkt_load(e.env.P, pi, p);
+        int next = NEXT_DONE;
+        if (kind == NEXT_RPKT) {
+          Chi x;
+          chi_load(e.env.P, pi, x);
+          next = advance_rpkt(e.env, p, pi, x, budget);
+          chi_store(e.env.P, pi, x);
+        } else if (kind == NEXT_MA) {
+          next = advance_ma(e.env, p, pi, budget * 8);
+        } else if (kind == NEXT_KPKT) {
+          next = advance_kpkt(e.env, p, pi);
+        } else {
+          next = advance_slow(e.env, p, pi);
+        }
+        pkt_store(e.env.P, pi, p);
+        if (next != NEXT_DONE) lists[next].push_back(pi);
+      }
     }
-    for (int64_t pi : tl) {  // k_thermal
-      Pkt p;
-      pkt_load(e.env.P, pi, p);
-      const int kind = advance_thermal(e.env, p, pi, budget * 8);
-      pkt_store(e.env.P, pi, p);
-      push(kind, pi);
-    }
-    for (int64_t pi : sl) {  // k_slow
-      Pkt p;
-      pkt_load(e.env.P, pi, p);
-      const int kind = advance_slow(e.env, p, pi);
-      pkt_store(e.env.P, pi, p);
-      push(kind, pi);
-    }
-    rl.swap(rn);
-    tl.swap(tn);
-    sl.swap(sn);
   }
   for (int64_t i = 0; i < npackets; i++) soa_to_aos(e.env.P, i, packets[i]);
   if (est && est->stats)
