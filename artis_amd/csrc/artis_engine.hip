@@ -130,13 +130,16 @@ struct Lists {
   int32_t self_kind;          // kind of the running kernel
   int32_t *self_list;         // its alternate list
   int32_t *self_count;
+  int32_t kpkt_slot;          // list that takes k-packets: NEXT_KPKT, or NEXT_MA when k-packets and macro-atoms share the
+                              // fused thermal kernel
 };
 __device__ inline void append_by_kind(int kind, int32_t pi, const Lists &L) {
+  const int slot = (kind == NEXT_KPKT) ? L.kpkt_slot : kind;
 #pragma unroll
   for (int k = 1; k < NEXT_NKINDS; k++) {
     int32_t *dst = (k == L.self_kind) ? L.self_list : L.lst[k];
     int32_t *cnt = (k == L.self_kind) ? L.self_count : (L.counts + k);
-    wave_append(kind == k, pi, dst, cnt);
+    wave_append(slot == k, pi, dst, cnt);
   }
 }
 __global__ void __launch_bounds__(BLOCK) k_classify(PktSoA P, double ts_end, Lists L) {
@@ -423,6 +426,135 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_KPKT_WAVES) k_kpkt(Env env, const
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
 }
 
+// Fused thermal kernel: k-packets and macro-atoms in one persistent kernel, so that the k-packet -> macro-atom ->
+// k-packet cycle (about a thousand times per k-packet and timestep, kpkt.cc:51) needs no kernel boundary. Divergence is
+// tamed with a wave ballot: in every round the wave either runs a burst of macro-atom transitions for the lanes that are
+// walking, or -- once enough lanes are waiting for it -- ONE k-packet step for all of those lanes together. A lane whose
+// packet leaves (r-packet again, slow path, end of timestep, budget) takes the next packet of the list at once.
+#ifndef ARTIS_THERMAL_WAVES
+#define ARTIS_THERMAL_WAVES 4
+#endif
+#ifndef ARTIS_MA_BURST
+#define ARTIS_MA_BURST 8
+#endif
+__global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
+                                                                         unsigned long long *gstats, int budget, int32_t *cursors,
+                                                                         int kthresh) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  env.stats = lstats;
+  const double ts_end = env.S.ts_end;
+  Puller q;
+  puller_init(q);
+  bool have = false;
+  int32_t pi = 0;
+  int units = 0;
+  Pkt p;
+  MACtx k;
+  while (true) {
+    const int32_t idx = pull(q, !have, n, cursors);
+    if (idx >= 0) {
+      pi = list[idx];
+      pkt_load(env.P, pi, p);
+      k = ma_ctx(env, p);
+      units = 0;
+      have = true;
+    }
+    if (!__any(have)) {
+      if (q.exhausted) break;
+      continue;
+    }
+    const bool wantM = have && ma_pending(p) && p.pend == PEND_NONE && units < budget;
+    const bool wantK = have && !wantM && kpkt_eligible(p, ts_end) && units < budget;
+    const int nM = __popcll(__ballot(wantM));
+    const int nK = __popcll(__ballot(wantK));
+    if (nK > 0 && (nM == 0 || nK >= kthresh)) {
+      if (wantK) {  // one k-packet step for every waiting lane
+        if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[k.c] == ARTIS_CELL_THICK) {
+          do_kpkt_blackbody(env, p, pi);
+        } else {
+          do_kpkt(env, p, pi);
+        }
+        env.P.chi_mgi[pi] = -1;
+        units++;
+      }
+    } else if (nM > 0) {
+      if (wantM) {  // a burst of macro-atom transitions
+        bool go = true;
+        for (int j = 0; j < ARTIS_MA_BURST && go; j++) {
+          go = ma_iter(env, p, pi, k);
+          units++;
+        }
+      }
+    }
+    // lanes whose packet can do nothing more in this kernel hand it on
+    int kind = NEXT_DONE;
+    int32_t out_pi = 0;
+    if (have) {
+      const bool stayM = ma_pending(p) && p.pend == PEND_NONE;
+      const bool stayK = !stayM && kpkt_eligible(p, ts_end);
+      if (!(stayM || stayK) || units >= budget) {
+        pkt_store(env.P, pi, p);
+        kind = classify(p, ts_end);
+        out_pi = pi;
+        have = false;
+      }
+    }
+    append_by_kind(kind, out_pi, next);
+  }
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+}
+
+// Fused thermal kernel, phase form (physics.h thermal_iter): up to ARTIS_MA_PHASE macro-atom transitions, then one
+// k-packet step, per iteration; lanes take a new packet between iterations.
+__global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal_phase(Env env, const int32_t *list, int32_t n, Lists next,
+                                                                               unsigned long long *gstats, int budget,
+                                                                               int32_t *cursors) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  env.stats = lstats;
+  const double ts_end = env.S.ts_end;
+  Puller q;
+  puller_init(q);
+  bool have = false;
+  int32_t pi = 0;
+  int units = 0;
+  Pkt p;
+  MACtx k;
+  while (true) {
+    const int32_t idx = pull(q, !have, n, cursors);
+    if (idx >= 0) {
+      pi = list[idx];
+      pkt_load(env.P, pi, p);
+      k = ma_ctx(env, p);
+      units = 0;
+      have = true;
+    }
+    if (!__any(have)) {
+      if (q.exhausted) break;
+      continue;
+    }
+    int kind = NEXT_DONE;
+    int32_t out_pi = 0;
+    if (have) {
+      bool go = thermal_can_continue(p, ts_end);
+      if (go) units += thermal_iter(env, p, pi, k, &go);
+      if (!go || units >= budget) {
+        pkt_store(env.P, pi, p);
+        kind = classify(p, ts_end);
+        out_pi = pi;
+        have = false;
+      }
+    }
+    append_by_kind(kind, out_pi, next);
+  }
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+}
+
 // slow path: the rare bound-free actions (rate coefficients with exp(), adaptive Gauss-Kronrod frequency sampling)
 __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
@@ -493,10 +625,12 @@ struct artis_amd_engine {
   int64_t kthreads[NEXT_NKINDS] = {};
   int64_t last_nlaunches = 0;
   int budget_r = 8;      // do_rpkt_step() calls per packet per launch
-  int budget_t = 4096;   // macro-atom transitions per packet per launch
+  int budget_t = 2048;   // macro-atom transitions / k-packet steps per packet per launch
   bool sort_lists = true;
   bool sort_nu = true;
-  bool sort_ma = false;
+  bool sort_ma = true;
+  bool fused_thermal = true;  // k-packets and macro-atoms in one kernel (k_thermal); false: k_kpkt + k_ma
+  int kthresh = 0;            // 0: phase form (k_thermal_phase); >0: ballot form (k_thermal) with this many waiting lanes
   bool trace = false;
 };
 
@@ -673,6 +807,8 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_FUSED")) e->fused_thermal = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_KTHRESH")) e->kthresh = std::max(0, std::atoi(b));
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
   *out = e;
   return ARTIS_OK;
@@ -855,6 +991,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     L.self_kind = self_kind;
     L.self_list = self_kind > 0 ? e->d_lists[self_kind][1 - cur[self_kind]] : nullptr;
     L.self_count = e->d_count + NEXT_NKINDS;  // one alternate counter: only one kernel runs at a time
+    L.kpkt_slot = e->fused_thermal ? NEXT_MA : NEXT_KPKT;
     return L;
   };
   auto read_counts = [&]() -> int {
@@ -890,6 +1027,15 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       if (kind == NEXT_RPKT) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
         hipLaunchKernelGGL(k_rpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors);
+      } else if (kind == NEXT_MA && e->fused_thermal) {
+        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_THERMAL_WAVES);
+        if (e->kthresh > 0) {
+          hipLaunchKernelGGL(k_thermal, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors,
+                             e->kthresh);
+        } else {
+          hipLaunchKernelGGL(k_thermal_phase, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
+                             e->d_cursors);
+        }
       } else if (kind == NEXT_MA) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_MA_WAVES);
         hipLaunchKernelGGL(k_ma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors);

@@ -1958,6 +1958,40 @@ AHD int advance_ma(const Env &env, Pkt &p, int64_t pi, int budget) {
   return classify(p, env.S.ts_end);
 }
 
+// ---- fused thermal body, phase form: one iteration = a macro-atom phase of up to ARTIS_MA_PHASE transitions, then ONE
+// k-packet step for every lane whose macro-atom has deactivated. The phases make the lanes of a wave run the same code
+// at the same time; they only order the work of different packets.
+#ifndef ARTIS_MA_PHASE
+#define ARTIS_MA_PHASE 64
+#endif
+AHD bool kpkt_eligible(const Pkt &p, double ts_end);
+AHD bool thermal_can_continue(const Pkt &p, double ts_end) {
+  if (p.pend != PEND_NONE) return false;
+  if (ma_pending(p)) return true;
+  return pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT;
+}
+// returns the units of work done (transitions + k-packet steps); *go = the packet can take another iteration
+AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
+  const double ts_end = env.S.ts_end;
+  int j = 0;
+  while (j < ARTIS_MA_PHASE && ma_pending(p) && p.pend == PEND_NONE) {
+    ma_jump(env, p, pi, k);
+    j++;
+  }
+  if (j > 0) chi_after_ma(env, p, pi);
+  if (!ma_pending(p) && p.pend == PEND_NONE && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT) {
+    if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[k.c] == ARTIS_CELL_THICK) {
+      do_kpkt_blackbody(env, p, pi);
+    } else {
+      do_kpkt(env, p, pi);
+    }
+    env.P.chi_mgi[pi] = -1;
+    j++;
+  }
+  *go = thermal_can_continue(p, ts_end);
+  return j;
+}
+
 // ---- k-packet kernel body: ONE do_kpkt()/do_kpkt_blackbody() call (update_packets.cc:291-305); it ends in an emission,
 // a macro-atom activation, a deferred free-bound emission, or at the end of the timestep.
 AHD bool kpkt_eligible(const Pkt &p, double ts_end) {
