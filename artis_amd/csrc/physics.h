@@ -1368,24 +1368,25 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   return k;
 }
 
-// one iteration of the loop of do_macroatom(), macroatom.cc:385-577
-AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
-  const DevModel &M = env.M;
-  const int c = k.c;
-  const int element = p.ma_element;
-  const int ion = p.ma_ion;
-  const int level = p.ma_level;
-  const int activatingline = p.ma_line;
-  ARTIS_STAT(env, ARTIS_STAT_X_MA_JUMPS);
-  const int key = (element << 8) | ion;
+// one iteration of the loop of do_macroatom(), macroatom.cc:385-577.
+// ma_locate() finds the level's unique index; ma_jump_core() performs the transition given the level's macro-atom
+// record `rates` (tables.h LevelPack layout) and its list of target levels `targets` (alltrans.targetlevelindex of the
+// level: down targets, then up targets). Both pointers may refer to HBM or to an LDS copy of the same values.
+AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
+  const int key = (p.ma_element << 8) | p.ma_ion;
   if (key != k.start_key) {
-    k.start = M.ion_uniquelevelindexstart[uion(M, element, ion)];
+    k.start = env.M.ion_uniquelevelindexstart[uion(env.M, p.ma_element, p.ma_ion)];
     k.start_key = key;
   }
+  return k.start + p.ma_level;
+}
+AHD void ma_jump_core(const Env &env, Pkt &p, int64_t pi, const MACtx &k, int ul, const LevelPack lp, const double *rates,
+                      const int32_t *targets) {
+  const DevModel &M = env.M;
+  const int c = k.c;
   const int start = k.start;
-  const int ul = start + level;
-  const LevelPack lp = M.level_pack[ul];
-  const double *rates = k.cellma + lp.rec_off;
+  const int activatingline = p.ma_line;
+  ARTIS_STAT(env, ARTIS_STAT_X_MA_JUMPS);
   // std::partial_sum macroatom.cc:425 and index_upperbound sn3d.h:85 over the 9 cumulative rates, kept in
   // registers (statically indexed): action = number of cumulative values <= randomrate, clamped to the last one
   double r[MA_N];
@@ -1419,7 +1420,7 @@ AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
     const int startdown = lp.alltrans_startdown;
     const int lineindex = M.alltrans_lineindex[startdown + dti];
     if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
-    const int lul = start + M.alltrans_targetlevelindex[startdown + dti];
+    const int lul = start + targets[dti];
     const double e_trans = eps(M, ul) - eps(M, lul);
     const double oldnucmf = p.nu_cmf;
     p.nu_cmf = e_trans / HPLANCK;
@@ -1442,20 +1443,25 @@ AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
     const int ndown = lp.ndown;
     const double *sums = rates + MA_N;
     const int dti = upper_bound_wide(sums, ndown - 1, targetval);
-    p.ma_level = M.alltrans_targetlevelindex[lp.alltrans_startdown + dti];
+    p.ma_level = targets[dti];
   } else if (action == ARTIS_MA_ACTION_INTERNALUPSAME) {
     const int ndown = lp.ndown;
     const int nup = lp.nup;
     const double *sums = rates + MA_N + ndown;
     const double targetval = rng_uniform(p) * rate_sel;
     const int uti = upper_bound_wide(sums, nup - 1, targetval);
-    p.ma_level = M.alltrans_targetlevelindex[lp.alltrans_startdown + ndown + uti];
+    p.ma_level = targets[ndown + uti];
   } else {
     // the rare bound-free channels need rate coefficients with exp() and, for a radiative recombination, an adaptive
     // quadrature: they are executed by the slow-path kernel (ma_slow_action) so that this loop stays small
     p.pend = PEND_MA_ACTION;
     p.pend_arg = action;
   }
+}
+AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
+  const int ul = ma_locate(env, p, k);
+  const LevelPack lp = env.M.level_pack[ul];
+  ma_jump_core(env, p, pi, k, ul, lp, k.cellma + lp.rec_off, env.M.alltrans_targetlevelindex + lp.alltrans_startdown);
 }
 
 // the bound-free transitions of do_macroatom(): macroatom.cc:481-488, 501-533, 552-560
@@ -1970,12 +1976,14 @@ AHD bool thermal_can_continue(const Pkt &p, double ts_end) {
   if (ma_pending(p)) return true;
   return pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT;
 }
-// returns the units of work done (transitions + k-packet steps); *go = the packet can take another iteration
-AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
+// returns the units of work done (transitions + k-packet steps); *go = the packet can take another iteration.
+// `jump` performs one transition (ma_jump, or the engine's LDS-cached form of it).
+template <class JumpFn>
+AHD int thermal_iter_with(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go, JumpFn jump) {
   const double ts_end = env.S.ts_end;
   int j = 0;
   while (j < ARTIS_MA_PHASE && ma_pending(p) && p.pend == PEND_NONE) {
-    ma_jump(env, p, pi, k);
+    jump(p, k);
     j++;
   }
   if (j > 0) chi_after_ma(env, p, pi);
@@ -1990,6 +1998,9 @@ AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
   }
   *go = thermal_can_continue(p, ts_end);
   return j;
+}
+AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
+  return thermal_iter_with(env, p, pi, k, go, [&](Pkt &pp, MACtx &kk) { ma_jump(env, pp, pi, kk); });
 }
 
 // ---- k-packet kernel body: ONE do_kpkt()/do_kpkt_blackbody() call (update_packets.cc:291-305); it ends in an emission,

@@ -109,7 +109,9 @@ enum {
   ARTIS_STAT_X_MA_JUMPS = 37, /* iterations of the do_macroatom() loop macroatom.cc:385 */
   ARTIS_STAT_X_CHI_EVALS = 38, /* continuum opacity evaluations that missed the packet's cache, rpkt.cc:1029 */
   ARTIS_STAT_X_CONT_VISITED = 39, /* bound-free continua summed in calculate_chi_bf_gammacontr() rpkt.cc:808 */
-  ARTIS_NSTATS = 40
+  ARTIS_STAT_X_MC_HIT = 40, /* macro-atom transitions served from the LDS record cache (k_thermal_lds) */
+  ARTIS_STAT_X_MC_MISS = 41, /* ... and from HBM */
+  ARTIS_NSTATS = 48
 };
 
 /* constants.h:73 GridType */

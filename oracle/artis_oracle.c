@@ -102,6 +102,8 @@ static double now_s(void) {
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 static double g_last_populate_seconds = 0.;
+static int64_t *g_visit_hist = NULL; /* diagnostics: macro-atom visits per (cell, level), set by artis_oracle_set_visit_hist */
+static int g_visit_nlevels = 0;
 
 /* ContinuumOpacity (rpkt.h:70) with its Phixslist (rpkt.h:48) */
 typedef struct {
@@ -1554,6 +1556,7 @@ static void do_macroatom(Oracle *o, artis_packet *p, const MacroAtomState *ma) {
     o->est.stats[ARTIS_STAT_X_MA_JUMPS]++;
     const int start = ionlevelstart(o, element, ion);
     const int ul = start + level;
+    if (g_visit_hist) g_visit_hist[(int64_t)c * g_visit_nlevels + ul]++;
     const double epsilon_current = epsilon(o, ul);
     const double *levelrates = macroatom_levelrates(o, c, element, ion, level);
     double cumulative[ARTIS_MA_ACTION_COUNT];
@@ -1977,6 +1980,7 @@ static void oracle_init(Oracle *o, const artis_model *m, const artis_cellstate *
   o->cache_cap = cap ? atoi(cap) : 0;
 }
 double artis_oracle_last_populate_seconds(void) { return g_last_populate_seconds; }
+void artis_oracle_set_visit_hist(int64_t *hist, int nlevels) { g_visit_hist = hist; g_visit_nlevels = nlevels; }
 static void oracle_free(Oracle *o) {
   for (int c = 0; c < o->m->npts_nonempty; c++) {
     CellCache *cc = &o->cache[c];
