@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-NSTATS = 48
+NSTATS = 64
 STAT_COUNT = 34
 STAT_X_RPKT_STEPS = 34
 STAT_X_KPKT_STEPS = 35
@@ -37,8 +37,8 @@ STAT_NAMES = [
     "NT_STAT_TO_EXCITATION", "NT_STAT_TO_KPKT", "K_STAT_FROM_EARLIERDECAY", "INTERACTIONS", "ELECTRON_SCATTERINGS",
     "RESONANCESCATTERINGS", "CELLCROSSINGS", "UPSCATTER", "DOWNSCATTER", "UPDATECELL", "PKTESCAPES",
     "X_RPKT_STEPS", "X_KPKT_STEPS", "X_LINES_VISITED", "X_MA_JUMPS", "X_CHI_EVALS", "X_CONT_VISITED",
-    "X_MC_HIT", "X_MC_MISS", "X_42", "X_43", "X_44", "X_45", "X_46", "X_47",
-]
+    "X_MC_HIT", "X_MC_MISS",
+] + [f"X_{i}" for i in range(42, 64)]
 
 # struct artis_packet (include/artis_amd.h), natural C alignment == numpy align=True
 PACKET_DTYPE = np.dtype(

@@ -308,6 +308,9 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
   int steps = 0;
   Pkt p;
   Chi x;
+#ifdef ARTIS_PROFILE
+  long long tprev = clock64();
+#endif
   while (true) {
     const int32_t idx = pull(q, !have, n, cursors);
     if (idx >= 0) {
@@ -323,6 +326,16 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
     }
     int kind = NEXT_DONE;
     int32_t out_pi = 0;
+#ifdef ARTIS_PROFILE
+    {  // slot 53: everything outside do_rpkt_step (pull, load, store, append), 54: inside; 55: wave iterations
+      const long long now = clock64();
+      if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&lstats[53], (stat_t)((now - tprev) >> 4));
+        atomicAdd(&lstats[55], 1u);
+      }
+      tprev = now;
+    }
+#endif
     if (have) {
       bool go = rpkt_can_continue(p, ts_end);
       if (go) {
@@ -337,6 +350,13 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
         have = false;
       }
     }
+#ifdef ARTIS_PROFILE
+    {
+      const long long now = clock64();
+      if ((threadIdx.x & 63) == 0) atomicAdd(&lstats[54], (stat_t)((now - tprev) >> 4));
+      tprev = now;
+    }
+#endif
     append_by_kind(kind, out_pi, next);
   }
   __syncthreads();
@@ -434,6 +454,9 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_KPKT_WAVES) k_kpkt(Env env, const
 #ifndef ARTIS_THERMAL_WAVES
 #define ARTIS_THERMAL_WAVES 4
 #endif
+#ifndef ARTIS_TV
+#define ARTIS_TV 0
+#endif
 #ifndef ARTIS_MA_BURST
 #define ARTIS_MA_BURST 8
 #endif
@@ -524,6 +547,13 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal_phase(En
   int units = 0;
   Pkt p;
   MACtx k;
+#ifdef ARTIS_PROFILE
+#define PROF_ADD(slot, dt) \
+  do {                     \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&lstats[slot], (stat_t)((dt) >> 4)); \
+  } while (0)
+  long long tprev = clock64();
+#endif
   while (true) {
     const int32_t idx = pull(q, !have, n, cursors);
     if (idx >= 0) {
@@ -539,17 +569,64 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal_phase(En
     }
     int kind = NEXT_DONE;
     int32_t out_pi = 0;
-    if (have) {
-      bool go = thermal_can_continue(p, ts_end);
-      if (go) units += thermal_iter(env, p, pi, k, &go);
-      if (!go || units >= budget) {
-        pkt_store(env.P, pi, p);
-        kind = classify(p, ts_end);
-        out_pi = pi;
-        have = false;
+    // the two phases of thermal_iter() (physics.h), spelled out so that the wave reconverges between them
+#ifdef ARTIS_PROFILE
+    // wave-cycle accounting (units of 16 clocks) in the spare stats slots 42..47: pull+load | macro-atom phase |
+    // k-packet phase | store+append, and the wave-level iteration counts of the two phases
+    const long long t0 = clock64();
+    PROF_ADD(42, t0 - tprev);
+#endif
+    bool go = have && thermal_can_continue(p, ts_end);
+    if (go) {
+      int j = 0;
+      while (j < ARTIS_MA_PHASE && ma_pending(p) && p.pend == PEND_NONE) {
+#if defined(ARTIS_PROFILE) || ARTIS_TV == 1
+        if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 46);
+#endif
+        ma_jump(env, p, pi, k);
+        j++;
       }
+      if (j > 0) chi_after_ma(env, p, pi);
+      units += j;
+    }
+#ifdef ARTIS_PROFILE
+    const long long t1 = clock64();
+    PROF_ADD(43, t1 - t0);
+#elif ARTIS_TV == 2
+    __builtin_amdgcn_wave_barrier();
+#elif ARTIS_TV == 3
+    __builtin_amdgcn_s_barrier();
+#endif
+    if (go) {
+      if (!ma_pending(p) && p.pend == PEND_NONE && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT) {
+#ifdef ARTIS_PROFILE
+        if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 47);
+#endif
+        if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[k.c] == ARTIS_CELL_THICK) {
+          do_kpkt_blackbody(env, p, pi);
+        } else {
+          do_kpkt(env, p, pi);
+        }
+        env.P.chi_mgi[pi] = -1;
+        units++;
+      }
+      go = thermal_can_continue(p, ts_end);
+    }
+#ifdef ARTIS_PROFILE
+    const long long t2 = clock64();
+    PROF_ADD(44, t2 - t1);
+#endif
+    if (have && (!go || units >= budget)) {
+      pkt_store(env.P, pi, p);
+      kind = classify(p, ts_end);
+      out_pi = pi;
+      have = false;
     }
     append_by_kind(kind, out_pi, next);
+#ifdef ARTIS_PROFILE
+    tprev = clock64();
+    PROF_ADD(45, tprev - t2);
+#endif
   }
   __syncthreads();
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
@@ -760,7 +837,9 @@ struct artis_amd_engine {
   int32_t *d_count = nullptr;                 // [NEXT_NKINDS] current-list counts, [NEXT_NKINDS] alternate-list count
   int32_t *d_cursors = nullptr;               // [8] chunk cursors of the running pull kernel
   int ncu = 256;
-  double *d_gamma_ws = nullptr;
+  double *d_gamma_ws = nullptr;   // per-packet groundcont_gamma_contr lists (physics.h Env)
+  int32_t *d_gamma_gi = nullptr;
+  int32_t *d_gamma_n = nullptr;
   int64_t ws_capacity = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   double last_propagate_ms = 0.;
@@ -809,7 +888,8 @@ Env make_env(const artis_amd_engine *e) {
   env.P = e->P;
   env.stats = nullptr;
   env.gamma_ws = e->d_gamma_ws;
-  env.ws_stride = e->ws_capacity;
+  env.gamma_gi = e->d_gamma_gi;
+  env.gamma_n = e->d_gamma_n;
   env.errflag = e->d_err;
   return env;
 }
@@ -827,7 +907,11 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
   if (e->d_sorted) (void)hipFree(e->d_sorted);
   e->d_sorted = nullptr;
   if (e->d_gamma_ws) (void)hipFree(e->d_gamma_ws);
+  if (e->d_gamma_gi) (void)hipFree(e->d_gamma_gi);
+  if (e->d_gamma_n) (void)hipFree(e->d_gamma_n);
   e->d_gamma_ws = nullptr;
+  e->d_gamma_gi = nullptr;
+  e->d_gamma_n = nullptr;
   e->npackets = n;
   e->soa_bytes = pkt_soa_bytes(n) + 64;
   HIP_TRY(hipMalloc(&e->d_soa, e->soa_bytes));
@@ -839,6 +923,9 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
   e->ws_capacity = n > 0 ? n : 1;
   const size_t wsbytes = sizeof(double) * (size_t)(e->Mh.nbfcontinua_ground + 1) * (size_t)e->ws_capacity;
   HIP_TRY(hipMalloc((void **)&e->d_gamma_ws, wsbytes));
+  HIP_TRY(hipMalloc((void **)&e->d_gamma_gi, wsbytes / 2));
+  HIP_TRY(hipMalloc((void **)&e->d_gamma_n, sizeof(int32_t) * (size_t)e->ws_capacity));
+  HIP_TRY(hipMemset(e->d_gamma_n, 0, sizeof(int32_t) * (size_t)e->ws_capacity));
   return ARTIS_OK;
 }
 
@@ -867,6 +954,24 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   if (model->gridtype != ARTIS_GRID_CARTESIAN3D && model->gridtype != ARTIS_GRID_SPHERICAL1D) {
     g_last_error = "grid type not supported (CARTESIAN3D and SPHERICAL1D are)";
     return ARTIS_ERR_UNSUPPORTED;
+  }
+  // the per-packet list of ground-continuum contributions (physics.h chi_bf_gammacontr) relies on the order the
+  // reference builds these tables in: groundcont_nu_edge rising (input.cc:802) and, with allcont sorted by nu_edge
+  // (input.cc:892), a non-decreasing nearest-edge index (input.cc:703)
+  for (int i = 1; i < model->nbfcontinua_ground; i++) {
+    if (model->groundcont_nu_edge[i] < model->groundcont_nu_edge[i - 1]) {
+      g_last_error = "groundcont_nu_edge is not in ascending order";
+      return ARTIS_ERR_ARG;
+    }
+  }
+  for (int i = 0, last = -1; i < model->nbfcontinua; i++) {
+    const int gi = model->allcont_groundcontestimindex[i];
+    if (gi < 0) continue;
+    if (gi < last || gi >= model->nbfcontinua_ground) {
+      g_last_error = "allcont_groundcontestimindex does not rise with nu_edge";
+      return ARTIS_ERR_ARG;
+    }
+    last = gi;
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -967,7 +1072,7 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
   void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_sorted, e->d_hist, e->d_tiles,
-                  e->d_count, e->d_cursors, e->d_gamma_ws};
+                  e->d_count, e->d_cursors, e->d_gamma_ws, e->d_gamma_gi, e->d_gamma_n};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (int kind = 0; kind < NEXT_NKINDS; kind++)

@@ -16,6 +16,7 @@ struct ModelOwned {
   std::vector<int32_t> level_ion;
   std::vector<LinePack> line_pack;
   std::vector<LevelPack> level_pack;
+  std::vector<ContPack> cont_pack;
 };
 
 // X(field, element type, element count) for every array pointer of DevModel
@@ -52,6 +53,7 @@ struct ModelOwned {
   X(alltrans_forbidden, uint8_t, (m).nalltrans)                                    \
   X(line_nu, double, (m).nlines)                                                   \
   X(line_pack, LinePack, (m).nlines)                                               \
+  X(cont_pack, ContPack, (m).nbfcontinua)                                          \
   X(line_elementindex, int32_t, (m).nlines)                                        \
   X(line_ionindex, int32_t, (m).nlines)                                            \
   X(allphixs, float, ((int64_t)(m).nphixslevels * (m).NPHIXSPOINTS))               \
@@ -138,6 +140,12 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   }
   v.nmacache = rec;
   v.level_pack = own.level_pack.data();
+  own.cont_pack.resize(m.nbfcontinua);
+  for (int i = 0; i < m.nbfcontinua; i++)
+    own.cont_pack[i] = ContPack{m.allcont_nu_edge[i], m.allcont_probability[i],
+                                m.level_phixsstart[m.allcont_uniquelevelindex[i]] * m.NPHIXSPOINTS,
+                                m.allcont_groundcontestimindex[i], {0, 0}};
+  v.cont_pack = own.cont_pack.data();
 #define ARTIS_COPY_PTR(f) v.f = m.f;
   ARTIS_COPY_PTR(elem_nions) ARTIS_COPY_PTR(elem_uniqueionindexstart) ARTIS_COPY_PTR(elem_lowest_ionstage)
   ARTIS_COPY_PTR(ion_element) ARTIS_COPY_PTR(ion_nlevels) ARTIS_COPY_PTR(ion_nlevels_ionising)

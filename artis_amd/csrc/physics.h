@@ -54,6 +54,21 @@ typedef unsigned long long stat_t;
 #define ARTIS_EST_ADD(ptr, v) (*(ptr) += (v))
 #endif
 #define ARTIS_STAT(env, i) ARTIS_STAT_ADD(env, i, 1)
+// -DARTIS_PROFILE (device only): wave-cycle accounting into the spare stats slots, units of 16 clocks, charged by
+// the first active lane of the wave for the code between two marks
+#if defined(ARTIS_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define PROF_BEGIN() long long prof_t = clock64()
+#define PROF_MARK(env, slot)                                                                   \
+  do {                                                                                         \
+    const long long prof_now = clock64();                                                      \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1)                         \
+      atomicAdd(&(env).stats[(slot)], (stat_t)((prof_now - prof_t) >> 4));                     \
+    prof_t = prof_now;                                                                         \
+  } while (0)
+#else
+#define PROF_BEGIN() ((void)0)
+#define PROF_MARK(env, slot) ((void)0)
+#endif
 
 AHD double pow2(double x) { return x * x; }
 AHD double pow3(double x) { return x * x * x; }
@@ -70,8 +85,11 @@ struct Env {
   DevEst E;
   PktSoA P;
   stat_t *stats;       // [ARTIS_NSTATS] LDS on the GPU, plain memory in the emulation
-  double *gamma_ws;    // groundcont_gamma_contr workspace [nbfcontinua_ground][ws_stride]
-  int64_t ws_stride;
+  // groundcont_gamma_contr (rpkt.h:63) of every packet as a compact list of its non-zero entries, packet-major:
+  // gamma_n[slot] entries (gamma_gi[slot*nbfg + j], gamma_ws[slot*nbfg + j]), j ascending in ground-continuum index
+  double *gamma_ws;
+  int32_t *gamma_gi;
+  int32_t *gamma_n;
   int32_t *errflag;    // set non-zero when an assert_always of the reference would fire
 };
 
@@ -898,13 +916,103 @@ AHD void populate_cooling_prefix(const Env &env, int c) {
 // ================================================================ r-packet path
 AHD double chi_total(const Chi &x) { return x.chi_escatter + x.chi_boundfree + x.chi_freefree_heat; }  // rpkt.h:100
 
-// calculate_chi_bf_gammacontr<true, SELECT> rpkt.cc:721
+// photoionisation_crosssection_fromtable (atomic.h:201) in two halves, so that the table reads of several continua can
+// be in flight together: phixs_lookup() decides which table entries are needed and reads them, phixs_finish() is the
+// arithmetic. phixs_finish(phixs_lookup()) == phixs_fromtable() bit for bit.
+struct PhixsRead {
+  float a, b;
+  int i;
+};
+AHD PhixsRead phixs_lookup(const DevModel &M, const float *xs, double nu_edge, double nu) {
+  const int NP = M.NPHIXSPOINTS;
+  const double INC = M.NPHIXSNUINCREMENT;
+  PhixsRead r = {0.f, 0.f, -1};
+#if ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION
+  if (nu < nu_edge) return r;
+  int i = 0;
+  if (nu == nu_edge) {
+    i = 0;
+  } else if (nu < nu_edge * (1 + (INC * NP))) {
+    i = (int)((nu - nu_edge) / (INC * nu_edge));
+    if (NP - 1 < i) i = NP - 1;
+  } else {
+    i = NP;  // beyond the table: extrapolate from the last point
+  }
+  r.i = i;
+  r.a = xs[(i < NP) ? i : NP - 1];
+#else
+  const double ireal = ((nu / nu_edge) - 1.0) / INC;
+  const int i = (int)floor(ireal);
+  if (i < 0) return r;
+  r.i = i;
+  if (i < NP - 1) {
+    r.a = xs[i];
+    r.b = xs[i + 1];
+  } else {
+    r.a = xs[NP - 1];
+  }
+#endif
+  return r;
+}
+AHD float phixs_finish(const DevModel &M, const PhixsRead r, double nu_edge, double nu) {
+  const int NP = M.NPHIXSPOINTS;
+  const double INC = M.NPHIXSNUINCREMENT;
+  if (r.i < 0) return 0.f;
+#if ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION
+  if (r.i < NP) return r.a;
+  return (float)(r.a * pow(nu_edge * (1 + (INC * NP)) / nu, 3));
+#else
+  if (r.i < NP - 1) {
+    const double a = r.a;
+    const double b = r.b;
+    const double ireal = ((nu / nu_edge) - 1.0) / INC;
+    const double fb = ireal - r.i;
+    return (float)(((1. - fb) * a) + (fb * b));
+  }
+  const double nu_max_phixs = nu_edge * M.last_phixs_nuovernuedge;
+  return (float)(r.a * pow3(nu_max_phixs / nu));
+#endif
+}
+
+// calculate_chi_bf_gammacontr<true, SELECT> rpkt.cc:721. The continua that contribute (keep bitmap of the cell) are
+// taken CHI_BATCH at a time: all reads of a batch are issued before any of its arithmetic, the sum is accumulated in
+// the reference's order.
+#ifndef ARTIS_CHI_BATCH
+#define ARTIS_CHI_BATCH 4
+#endif
+struct KeepIter {
+  const uint64_t *keep;
+  int word, cbegin, cend;
+  uint64_t bits;
+};
+AHD uint64_t keep_masked(const KeepIter &it) {
+  uint64_t bits = it.keep[it.word];
+  if (it.word == (it.cbegin / 64)) bits &= ~UINT64_C(0) << (unsigned)(it.cbegin % 64);
+  if (((it.word + 1) * 64) > it.cend) bits &= ~UINT64_C(0) >> (unsigned)(64 - (it.cend % 64));
+  return bits;
+}
+AHD int keep_next(KeepIter &it) {
+  while (it.bits == 0) {
+    it.word++;
+    if (it.word * 64 >= it.cend) return -1;
+    it.bits = keep_masked(it);
+  }
+  const int i = (it.word * 64) + __builtin_ctzll(it.bits);
+  it.bits &= it.bits - 1;
+  return i;
+}
 template <bool SELECT>
 AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, double threshold, int *selected) {
   const DevModel &M = env.M;
   double sum = 0.;
+  // std::ranges::fill(groundcont_gamma_contr, 0.) rpkt.cc:728: the list starts empty. The ground-continuum index of
+  // the continua rises with nu_edge (nearest-edge map of a sorted list, input.cc:703), so equal indices are adjacent.
+  int ng = 0, lastgi = -1;
+  double *wsv = nullptr;
+  int32_t *wsi = nullptr;
   if (!SELECT) {
-    for (int i = 0; i < M.nbfcontinua_ground; i++) env.gamma_ws[(i * env.ws_stride) + slot] = 0.;
+    wsv = env.gamma_ws + (slot * M.nbfcontinua_ground);
+    wsi = env.gamma_gi + (slot * M.nbfcontinua_ground);
   }
   const float T_e = env.C.Te[c];
   const double ex = exp(-HOVERKB * nu / T_e);
@@ -912,42 +1020,74 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   const int cend = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
   const int cbegin = lower_bound_d(M.allcont_nu_edge, cend, nu / M.last_phixs_nuovernuedge);
   int nvisited = 0;
-  const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
   const double *nnl = env.K.allcont_nnlevel + ((int64_t)c * M.nbfcontinua);
   const double *edgepart = env.K.allcont_edgepart + ((int64_t)c * M.nbfcontinua);
   const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
-  for (int word = cbegin / 64; word * 64 < cend; word++) {
-    uint64_t bits = keep[word];
-    if (word == (cbegin / 64)) bits &= ~UINT64_C(0) << (unsigned)(cbegin % 64);
-    if (((word + 1) * 64) > cend) bits &= ~UINT64_C(0) >> (unsigned)(64 - (cend % 64));
-    while (bits != 0) {
-      const int i = (word * 64) + __builtin_ctzll(bits);
-      bits &= bits - 1;
-      nvisited++;
-      const double nnlevel = nnl[i];
-      const double nu_edge = M.allcont_nu_edge[i];
-      const double sigma_bf = phixs_fromtable(M, phixs_table(M, M.allcont_uniquelevelindex[i]), nu_edge, nu);
-      const double ep = edgepart[i];
-      double stim;
-      if (ep >= 0. && split_usable) {
-        stim = ep * ex;
-      } else {
-        stim = departure[i] * exp(-HOVERKB * (nu - nu_edge) / T_e);
-      }
-      const double corr = dmax(0., 1 - stim);
-      const double sigma_contr = sigma_bf * M.allcont_probability[i] * corr;
-      if (!SELECT) {
-        const int gi = M.allcont_groundcontestimindex[i];
-        if (gi >= 0) env.gamma_ws[(gi * env.ws_stride) + slot] = sigma_contr;
-      }
-      sum += nnlevel * sigma_contr;
-      if (SELECT && sum > threshold) {
-        *selected = i;
-        return sum;
+  KeepIter it;
+  it.keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
+  it.cbegin = cbegin;
+  it.cend = cend;
+  it.word = cbegin / 64;
+  it.bits = (it.word * 64 < cend) ? keep_masked(it) : 0;
+  bool more = (it.word * 64 < cend);
+  while (more) {
+    int idx[ARTIS_CHI_BATCH];
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
+      idx[k] = more ? keep_next(it) : -1;
+      if (idx[k] < 0) more = false;
+    }
+    if (idx[0] < 0) break;
+    ContPack cp[ARTIS_CHI_BATCH];
+    double nn[ARTIS_CHI_BATCH], ep[ARTIS_CHI_BATCH];
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
+      const int i = (idx[k] >= 0) ? idx[k] : idx[0];
+      cp[k] = M.cont_pack[i];
+      nn[k] = nnl[i];
+      ep[k] = edgepart[i];
+    }
+    PhixsRead xr[ARTIS_CHI_BATCH];
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) xr[k] = phixs_lookup(M, M.allphixs + cp[k].xs_off, cp[k].nu_edge, nu);
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
+      if (idx[k] >= 0) {
+        const int i = idx[k];
+        nvisited++;
+        const double nu_edge = cp[k].nu_edge;
+        const double sigma_bf = phixs_finish(M, xr[k], nu_edge, nu);
+        double stim;
+        if (ep[k] >= 0. && split_usable) {
+          stim = ep[k] * ex;
+        } else {
+          stim = departure[i] * exp(-HOVERKB * (nu - nu_edge) / T_e);
+        }
+        const double corr = dmax(0., 1 - stim);
+        const double sigma_contr = sigma_bf * cp[k].probability * corr;
+        if (!SELECT) {
+          const int gi = cp[k].gi;
+          if (gi >= 0) {
+            if (gi == lastgi) {
+              wsv[ng - 1] = sigma_contr;
+            } else {
+              wsv[ng] = sigma_contr;
+              wsi[ng] = gi;
+              ng++;
+              lastgi = gi;
+            }
+          }
+        }
+        sum += nn[k] * sigma_contr;
+        if (SELECT && sum > threshold) {
+          *selected = i;
+          return sum;
+        }
       }
     }
   }
   if (!SELECT) {
+    env.gamma_n[slot] = ng;
     ARTIS_STAT(env, ARTIS_STAT_X_CHI_EVALS);
     ARTIS_STAT_ADD(env, ARTIS_STAT_X_CONT_VISITED, nvisited);
   }
@@ -1623,12 +1763,18 @@ AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double d
   if (thick) return;
   ARTIS_EST_ADD(&env.E.ffheatingestimator[c], de * x.chi_freefree_heat);
 #if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
+  // update_bfestimators rpkt.cc:519: the loop runs over the ground continua in rising nu_edge until nu_cmf <= nu_edge;
+  // entries whose groundcont_gamma_contr is zero add nothing and are not in the packet's list
   const int nbfg = env.M.nbfcontinua_ground;
-  for (int i = 0; i < nbfg; i++) {
+  const int ng = env.gamma_n[slot];
+  const double *wsv = env.gamma_ws + (slot * nbfg);
+  const int32_t *wsi = env.gamma_gi + (slot * nbfg);
+  for (int j = 0; j < ng; j++) {
+    const int i = wsi[j];
     const double nu_edge = env.M.groundcont_nu_edge[i];
     if (nu_cmf <= nu_edge) return;
     const int64_t k = ((int64_t)c * nbfg) + i;
-    const double contr = env.gamma_ws[(i * env.ws_stride) + slot];
+    const double contr = wsv[j];
 #if ARTIS_OPT_USE_LUT_PHOTOION
     ARTIS_EST_ADD(&env.E.gammaestimator[k], contr * (de / nu_cmf));
 #endif
@@ -1644,11 +1790,13 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
   const DevModel &M = env.M;
   const double t2 = env.S.ts_end;
   ARTIS_STAT(env, ARTIS_STAT_X_RPKT_STEPS);
+  PROF_BEGIN();
   const int c = M.propcell_nonemptymgi[p.cellindex];
   MAState ma = {-1, -1, -1, -99};
   const double tau_rnd = -log((double)rng_uniform_pos(p));
   int next_cell = -1;
   const double bdist = boundary_distance(env, p, &next_cell);
+  PROF_MARK(env, 48);
   if (bdist == 0) {
     change_cell_or_escape(env, p, pi, next_cell);
     if (p.type != ARTIS_TYPE_RPKT) return false;
@@ -1670,6 +1818,7 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
     p.next_trans = -1;
   } else {
     chi_rpkt_cont(env, p.nu_cmf, x, c, slot);
+    PROF_MARK(env, 49);
     // get_nu_cmf_abort rpkt.cc:54
     const double half = abort_dist / 2.;
     const double abort_time = p.prop_time + (half / CLIGHT_PROP) + (half / CLIGHT_PROP);
@@ -1679,6 +1828,7 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
     int nt = p.next_trans;
     edist = possible_event(env, c, p, x, ma, tau_rnd, abort_dist, nu_cmf_abort, dop, &nt, &is_bb);
     p.next_trans = nt;
+    PROF_MARK(env, 50);
   }
   if (!(edist >= 0)) fail(env, 61);
 
@@ -1686,6 +1836,7 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
     move_pkt(p, edist / 2.);
     update_estimators(env, p.e_cmf, p.nu_cmf, edist, c, x, thick, slot);
     move_pkt(p, edist / 2.);
+    PROF_MARK(env, 51);
     ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
     if (thick) {
       p.nscatterings++;
@@ -1699,12 +1850,14 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
       env.P.absorptionfreq[pi] = p.nu_rf;
       ma_activate(p, ma, 1);
     }
+    PROF_MARK(env, 52);
     return (p.type == ARTIS_TYPE_RPKT);
   }
   if ((bdist <= tdist) && (bdist <= edist)) {
     move_pkt(p, bdist / 2.);
     if (c >= 0) update_estimators(env, p.e_cmf, p.nu_cmf, bdist, c, x, thick, slot);
     move_pkt(p, bdist / 2.);
+    PROF_MARK(env, 51);
     if (next_cell != p.cellindex) {
       change_cell_or_escape(env, p, pi, next_cell);
       if (next_cell < 0) return false;

@@ -35,6 +35,16 @@ struct alignas(16) LevelPack {
   int32_t ndown;
   int32_t nup;
 };
+// 32-byte record of the static data of one bound-free continuum that calculate_chi_bf_gammacontr() needs
+// (globals::allcont nu_edge, probability, groundcontestimindex globals.h:253-263; xs_off = offset of the lower level's
+// photoionisation table in allphixs, i.e. level_phixsstart * NPHIXSPOINTS)
+struct alignas(32) ContPack {
+  double nu_edge;
+  double probability;
+  int32_t xs_off;
+  int32_t gi;
+  int32_t pad[2];
+};
 // macro-atom record of one (cell, level), 128-byte aligned so that a transition touches two adjacent lines:
 //   [0..8]                         the 9 process rates            (alllevels_maprocessrates, globals.h:286)
 //   [9 .. 9+ndown)                 cumulative internal-down-same  (allmacroatomictransitions block 2, macroatom.cc:44)
@@ -66,6 +76,7 @@ struct DevModel {
   const uint8_t *alltrans_forbidden;
   const double *line_nu;
   const LinePack *line_pack;
+  const ContPack *cont_pack;  // derived
   const int32_t *line_elementindex, *line_ionindex;
   const float *allphixs;
   const int32_t *allphixstargets_levelindex;

@@ -111,7 +111,8 @@ enum {
   ARTIS_STAT_X_CONT_VISITED = 39, /* bound-free continua summed in calculate_chi_bf_gammacontr() rpkt.cc:808 */
   ARTIS_STAT_X_MC_HIT = 40, /* macro-atom transitions served from the LDS record cache (k_thermal_lds) */
   ARTIS_STAT_X_MC_MISS = 41, /* ... and from HBM */
-  ARTIS_NSTATS = 48
+  /* 42..63: free for profiling builds (-DARTIS_PROFILE: wave-cycle accounting, units of 16 clocks) */
+  ARTIS_NSTATS = 64
 };
 
 /* constants.h:73 GridType */

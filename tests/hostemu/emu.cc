@@ -23,6 +23,7 @@ struct Emu {
   std::vector<std::vector<uint8_t>> cachebuf;
   std::vector<stat_t> stats;
   std::vector<double> ws;
+  std::vector<int32_t> ws_gi, ws_n;
   int32_t err = 0;
 };
 
@@ -45,7 +46,10 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   e.env.stats = e.stats.data();
   e.ws.assign((size_t)((M.nbfcontinua_ground + 1) * nslots), 0.);
   e.env.gamma_ws = e.ws.data();
-  e.env.ws_stride = nslots;
+  e.ws_gi.assign((size_t)((M.nbfcontinua_ground + 1) * nslots), 0);
+  e.ws_n.assign((size_t)nslots + 1, 0);
+  e.env.gamma_gi = e.ws_gi.data();
+  e.env.gamma_n = e.ws_n.data();
   e.env.errflag = &e.err;
 }
 
