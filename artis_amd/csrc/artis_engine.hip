@@ -363,176 +363,14 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
 }
 
-// macro-atom random walk: every lane walks one macro-atom, one transition per iteration, and takes the next packet of
-// the list as soon as its own walk has ended (deactivation, slow-path action or launch budget)
-#ifndef ARTIS_MA_WAVES
-#define ARTIS_MA_WAVES 4
-#endif
-__global__ void __launch_bounds__(BLOCK, ARTIS_MA_WAVES) k_ma(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats,
-                                                               int budget, int32_t *cursors) {
-  __shared__ stat_t lstats[ARTIS_NSTATS];
-  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
-  __syncthreads();
-  env.stats = lstats;
-  const double ts_end = env.S.ts_end;
-  Puller q;
-  puller_init(q);
-  bool have = false;
-  int32_t pi = 0;
-  int units = 0;
-  Pkt p;
-  MACtx k;
-  while (true) {
-    const int32_t idx = pull(q, !have, n, cursors);
-    if (idx >= 0) {
-      pi = list[idx];
-      pkt_load(env.P, pi, p);
-      k = ma_ctx(env, p);
-      units = 0;
-      have = true;
-    }
-    if (!__any(have)) {
-      if (q.exhausted) break;
-      continue;
-    }
-    int kind = NEXT_DONE;
-    int32_t out_pi = 0;
-    if (have) {
-      bool go = ma_pending(p) && p.pend == PEND_NONE;
-      if (go) {
-        go = ma_iter(env, p, pi, k);
-        units++;
-      }
-      if (!go || units >= budget) {
-        pkt_store(env.P, pi, p);
-        kind = classify(p, ts_end);
-        out_pi = pi;
-        have = false;
-      }
-    }
-    append_by_kind(kind, out_pi, next);
-  }
-  __syncthreads();
-  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
-}
-
-// k-packets: every lane performs exactly one k-packet step (cooling-channel sampling), all lanes in step
-#ifndef ARTIS_KPKT_WAVES
-#define ARTIS_KPKT_WAVES 4
-#endif
-__global__ void __launch_bounds__(BLOCK, ARTIS_KPKT_WAVES) k_kpkt(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                   unsigned long long *gstats, int32_t *cursors) {
-  __shared__ stat_t lstats[ARTIS_NSTATS];
-  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
-  __syncthreads();
-  env.stats = lstats;
-  Puller q;
-  puller_init(q);
-  while (true) {
-    const int32_t idx = pull(q, true, n, cursors);
-    int kind = NEXT_DONE;
-    int32_t pi = 0;
-    if (idx >= 0) {
-      pi = list[idx];
-      Pkt p;
-      pkt_load(env.P, pi, p);
-      kind = advance_kpkt(env, p, pi);
-      pkt_store(env.P, pi, p);
-    }
-    append_by_kind(kind, pi, next);
-    if (q.exhausted && !__any(idx >= 0)) break;
-  }
-  __syncthreads();
-  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
-}
-
-// Fused thermal kernel: k-packets and macro-atoms in one persistent kernel, so that the k-packet -> macro-atom ->
-// k-packet cycle (about a thousand times per k-packet and timestep, kpkt.cc:51) needs no kernel boundary. Divergence is
-// tamed with a wave ballot: in every round the wave either runs a burst of macro-atom transitions for the lanes that are
-// walking, or -- once enough lanes are waiting for it -- ONE k-packet step for all of those lanes together. A lane whose
-// packet leaves (r-packet again, slow path, end of timestep, budget) takes the next packet of the list at once.
+// Thermal packets (k-packets and walking macro-atoms) are advanced by ONE persistent kernel, so that the k-packet ->
+// macro-atom -> k-packet cycle (tens of times per packet and timestep, kpkt.cc:51) needs no kernel boundary.
 #ifndef ARTIS_THERMAL_WAVES
 #define ARTIS_THERMAL_WAVES 4
 #endif
-#ifndef ARTIS_TV
-#define ARTIS_TV 0
-#endif
-#ifndef ARTIS_MA_BURST
-#define ARTIS_MA_BURST 8
-#endif
-__global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                         unsigned long long *gstats, int budget, int32_t *cursors,
-                                                                         int kthresh) {
-  __shared__ stat_t lstats[ARTIS_NSTATS];
-  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
-  __syncthreads();
-  env.stats = lstats;
-  const double ts_end = env.S.ts_end;
-  Puller q;
-  puller_init(q);
-  bool have = false;
-  int32_t pi = 0;
-  int units = 0;
-  Pkt p;
-  MACtx k;
-  while (true) {
-    const int32_t idx = pull(q, !have, n, cursors);
-    if (idx >= 0) {
-      pi = list[idx];
-      pkt_load(env.P, pi, p);
-      k = ma_ctx(env, p);
-      units = 0;
-      have = true;
-    }
-    if (!__any(have)) {
-      if (q.exhausted) break;
-      continue;
-    }
-    const bool wantM = have && ma_pending(p) && p.pend == PEND_NONE && units < budget;
-    const bool wantK = have && !wantM && kpkt_eligible(p, ts_end) && units < budget;
-    const int nM = __popcll(__ballot(wantM));
-    const int nK = __popcll(__ballot(wantK));
-    if (nK > 0 && (nM == 0 || nK >= kthresh)) {
-      if (wantK) {  // one k-packet step for every waiting lane
-        if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[k.c] == ARTIS_CELL_THICK) {
-          do_kpkt_blackbody(env, p, pi);
-        } else {
-          do_kpkt(env, p, pi);
-        }
-        env.P.chi_mgi[pi] = -1;
-        units++;
-      }
-    } else if (nM > 0) {
-      if (wantM) {  // a burst of macro-atom transitions
-        bool go = true;
-        for (int j = 0; j < ARTIS_MA_BURST && go; j++) {
-          go = ma_iter(env, p, pi, k);
-          units++;
-        }
-      }
-    }
-    // lanes whose packet can do nothing more in this kernel hand it on
-    int kind = NEXT_DONE;
-    int32_t out_pi = 0;
-    if (have) {
-      const bool stayM = ma_pending(p) && p.pend == PEND_NONE;
-      const bool stayK = !stayM && kpkt_eligible(p, ts_end);
-      if (!(stayM || stayK) || units >= budget) {
-        pkt_store(env.P, pi, p);
-        kind = classify(p, ts_end);
-        out_pi = pi;
-        have = false;
-      }
-    }
-    append_by_kind(kind, out_pi, next);
-  }
-  __syncthreads();
-  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
-}
-
 // Fused thermal kernel, phase form (physics.h thermal_iter): up to ARTIS_MA_PHASE macro-atom transitions, then one
 // k-packet step, per iteration; lanes take a new packet between iterations.
-__global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal_phase(Env env, const int32_t *list, int32_t n, Lists next,
+__global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                                unsigned long long *gstats, int budget,
                                                                                int32_t *cursors) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
@@ -580,7 +418,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal_phase(En
     if (go) {
       int j = 0;
       while (j < ARTIS_MA_PHASE && ma_pending(p) && p.pend == PEND_NONE) {
-#if defined(ARTIS_PROFILE) || ARTIS_TV == 1
+#ifdef ARTIS_PROFILE
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 46);
 #endif
         ma_jump(env, p, pi, k);
@@ -592,10 +430,6 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal_phase(En
 #ifdef ARTIS_PROFILE
     const long long t1 = clock64();
     PROF_ADD(43, t1 - t0);
-#elif ARTIS_TV == 2
-    __builtin_amdgcn_wave_barrier();
-#elif ARTIS_TV == 3
-    __builtin_amdgcn_s_barrier();
 #endif
     if (go) {
       if (!ma_pending(p) && p.pend == PEND_NONE && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT) {
@@ -632,149 +466,6 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal_phase(En
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
 }
 
-// ------------------------------------------------------------------ thermal kernel with an LDS cache of macro-atom records
-// One wave per workgroup. The wave takes TILES of consecutive entries of the cell-sorted list, so its 64 packets sit in
-// the same few cells, and it keeps the macro-atom records those packets visit in LDS: a direct-mapped cache keyed by
-// (cell, level) holding the record (process rates + cumulative sums), the level's static indices and its target levels.
-// A k-packet makes ~4e4 transitions per timestep over a few dozen levels of its cell, so after warm-up nearly every
-// transition is served from LDS instead of two HBM lines plus two L2 lookups. Cached values are bit copies; a miss
-// (or a record too long for a slot) takes the HBM path of ma_jump().
-constexpr int MC_BLOCK = 64;
-constexpr int MC_SLOTS = 64;   // direct-mapped slots
-constexpr int MC_RECW = 48;    // doubles per slot for rates + sums
-constexpr int MC_TW = 40;      // target levels per slot
-constexpr int MC_TILE = 256;   // list entries a wave takes at a time
-#ifndef ARTIS_MC_WAVES
-#define ARTIS_MC_WAVES 1       // waves per SIMD the register allocator may assume (LDS limits residency anyway)
-#endif
-
-struct TilePuller {
-  int chunk, tried;
-  bool exhausted;
-  int32_t t_next, t_end;
-};
-__device__ inline int32_t pull_tiled(TilePuller &q, bool need, int32_t n, int32_t *cursors) {
-  int32_t idx = -1;
-  for (int attempt = 0; attempt < 10; attempt++) {
-    const unsigned long long mask = __ballot(need && idx < 0);
-    if (mask == 0) break;
-    if (q.t_next >= q.t_end) {  // take a new tile (wave-uniform)
-      if (q.exhausted) break;
-      const int64_t cbeg = ((int64_t)n * q.chunk) >> 3;
-      const int64_t cend = ((int64_t)n * (q.chunk + 1)) >> 3;
-      int base = 0;
-      if ((threadIdx.x & 63) == 0) base = atomicAdd(&cursors[q.chunk], MC_TILE);
-      base = __shfl(base, 0);
-      const int64_t start = cbeg + base;
-      if (start >= cend) {
-        q.chunk = (q.chunk + 1) & 7;
-        q.tried++;
-        if (q.tried >= 8) q.exhausted = true;
-        continue;
-      }
-      q.t_next = (int32_t)start;
-      q.t_end = (int32_t)((start + MC_TILE < cend) ? start + MC_TILE : cend);
-    }
-    const int lane = threadIdx.x & 63;
-    const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    const int cnt = __popcll(mask);
-    const int32_t mine = q.t_next + prefix;
-    if (need && idx < 0 && mine < q.t_end) idx = mine;
-    q.t_next = (q.t_next + cnt < q.t_end) ? q.t_next + cnt : q.t_end;
-  }
-  return idx;
-}
-
-__global__ void __launch_bounds__(MC_BLOCK, ARTIS_MC_WAVES) k_thermal_lds(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                           unsigned long long *gstats, int budget,
-                                                                           int32_t *cursors) {
-  __shared__ stat_t lstats[ARTIS_NSTATS];
-  __shared__ double mc_data[MC_SLOTS * MC_RECW];
-  __shared__ int32_t mc_targets[MC_SLOTS * MC_TW];
-  __shared__ LevelPack mc_pack[MC_SLOTS];
-  __shared__ int32_t mc_tag[MC_SLOTS];
-  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
-  for (int i = threadIdx.x; i < MC_SLOTS; i += MC_BLOCK) mc_tag[i] = -1;
-  __syncthreads();
-  env.stats = lstats;
-  const double ts_end = env.S.ts_end;
-  const bool cacheable = env.M.nlevels <= 2048 && env.M.npts_nonempty <= (1 << 20);
-  TilePuller q;
-  q.chunk = blockIdx.x & 7;
-  q.tried = 0;
-  q.exhausted = false;
-  q.t_next = q.t_end = 0;
-  bool have = false;
-  int32_t pi = 0;
-  int units = 0;
-  Pkt p;
-  MACtx k;
-
-  // one macro-atom transition through the cache
-  auto jump = [&](Pkt &pp, MACtx &kk) {
-    const int ul = ma_locate(env, pp, kk);
-    const int32_t tag = (kk.c << 11) | ul;
-    const int slot = (ul + kk.c * 13) & (MC_SLOTS - 1);
-    const bool hit = cacheable && mc_tag[slot] == tag;
-    ARTIS_STAT(env, hit ? ARTIS_STAT_X_MC_HIT : ARTIS_STAT_X_MC_MISS);
-    if (hit) {
-      ma_jump_core(env, pp, pi, kk, ul, mc_pack[slot], mc_data + slot * MC_RECW, mc_targets + slot * MC_TW);
-    } else {
-      const LevelPack lp = env.M.level_pack[ul];
-      const double *rec = kk.cellma + lp.rec_off;
-      const int32_t *tg = env.M.alltrans_targetlevelindex + lp.alltrans_startdown;
-      ma_jump_core(env, pp, pi, kk, ul, lp, rec, tg);
-      // Fill the slot if it is EMPTY (claimed with a compare-and-swap on the tag). A valid slot is never overwritten
-      // here: the two sides of this if/else run one after the other in an order the compiler chooses, so lanes that hit
-      // may read their slot after this code has run. Slots are only invalidated at the wave-uniform point where the wave
-      // takes a new tile (below).
-      const int nrec = MA_N + 2 * lp.ndown + lp.nup;
-      const int ntg = lp.ndown + lp.nup;
-      if (cacheable && nrec <= MC_RECW && ntg <= MC_TW && atomicCAS(&mc_tag[slot], -1, -2) == -1) {
-        for (int i = 0; i < nrec; i++) mc_data[slot * MC_RECW + i] = rec[i];
-        for (int i = 0; i < ntg; i++) mc_targets[slot * MC_TW + i] = tg[i];
-        mc_pack[slot] = lp;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        mc_tag[slot] = tag;
-      }
-    }
-  };
-
-  while (true) {
-    const int32_t tile_before = q.t_end;
-    const int32_t idx = pull_tiled(q, !have, n, cursors);
-    if (q.t_end != tile_before) {  // new tile, new cells: start with an empty cache (all lanes are here, none is reading)
-      for (int i = threadIdx.x; i < MC_SLOTS; i += MC_BLOCK) mc_tag[i] = -1;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    }
-    if (idx >= 0) {
-      pi = list[idx];
-      pkt_load(env.P, pi, p);
-      k = ma_ctx(env, p);
-      units = 0;
-      have = true;
-    }
-    if (!__any(have)) {
-      if (q.exhausted && q.t_next >= q.t_end) break;
-      continue;
-    }
-    int kind = NEXT_DONE;
-    int32_t out_pi = 0;
-    if (have) {
-      bool go = thermal_can_continue(p, ts_end);
-      if (go) units += thermal_iter_with(env, p, pi, k, &go, jump);
-      if (!go || units >= budget) {
-        pkt_store(env.P, pi, p);
-        kind = classify(p, ts_end);
-        out_pi = pi;
-        have = false;
-      }
-    }
-    append_by_kind(kind, out_pi, next);
-  }
-  __syncthreads();
-  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
-}
 
 // slow path: the rare bound-free actions (rate coefficients with exp(), adaptive Gauss-Kronrod frequency sampling)
 __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats) {
@@ -852,9 +543,6 @@ struct artis_amd_engine {
   bool sort_lists = true;
   bool sort_nu = true;
   bool sort_ma = true;
-  bool fused_thermal = true;  // k-packets and macro-atoms in one kernel (k_thermal); false: k_kpkt + k_ma
-  int kthresh = 0;            // 0: phase form (k_thermal_phase); >0: ballot form (k_thermal) with this many waiting lanes
-  bool lds_cache = false;     // ARTIS_AMD_LDS=1: thermal kernel with an LDS cache of macro-atom records (k_thermal_lds); measured slower
   bool trace = false;
 };
 
@@ -1057,9 +745,6 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
-  if (const char *b = std::getenv("ARTIS_AMD_FUSED")) e->fused_thermal = std::atoi(b) != 0;
-  if (const char *b = std::getenv("ARTIS_AMD_KTHRESH")) e->kthresh = std::max(0, std::atoi(b));
-  if (const char *b = std::getenv("ARTIS_AMD_LDS")) e->lds_cache = std::atoi(b) != 0;
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
   *out = e;
   return ARTIS_OK;
@@ -1242,7 +927,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     L.self_kind = self_kind;
     L.self_list = self_kind > 0 ? e->d_lists[self_kind][1 - cur[self_kind]] : nullptr;
     L.self_count = e->d_count + NEXT_NKINDS;  // one alternate counter: only one kernel runs at a time
-    L.kpkt_slot = e->fused_thermal ? NEXT_MA : NEXT_KPKT;
+    L.kpkt_slot = NEXT_MA;  // k-packets travel in the thermal list
     return L;
   };
   int32_t errflag = 0;
@@ -1285,26 +970,9 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       if (kind == NEXT_RPKT) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
         hipLaunchKernelGGL(k_rpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors);
-      } else if (kind == NEXT_MA && e->fused_thermal) {
-        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_THERMAL_WAVES);
-        if (e->lds_cache && e->kthresh == 0) {
-          // one wave per workgroup, LDS-limited residency: about 160 KB / 38 KB = 4 workgroups per CU
-          const int wgrid = std::min((int)((nk + MC_BLOCK - 1) / MC_BLOCK), e->ncu * 4);
-          hipLaunchKernelGGL(k_thermal_lds, dim3(wgrid), dim3(MC_BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
-                             e->d_cursors);
-        } else if (e->kthresh > 0) {
-          hipLaunchKernelGGL(k_thermal, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors,
-                             e->kthresh);
-        } else {
-          hipLaunchKernelGGL(k_thermal_phase, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
-                             e->d_cursors);
-        }
       } else if (kind == NEXT_MA) {
-        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_MA_WAVES);
-        hipLaunchKernelGGL(k_ma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors);
-      } else if (kind == NEXT_KPKT) {
-        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_KPKT_WAVES);
-        hipLaunchKernelGGL(k_kpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->d_cursors);
+        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_THERMAL_WAVES);
+        hipLaunchKernelGGL(k_thermal, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors);
       } else {
         hipLaunchKernelGGL(k_slow, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);
       }
@@ -1456,7 +1124,9 @@ int artis_amd_debug_cellcache(artis_amd_engine *e, int c, double *levelpops, dou
   DL(allcont_nnlevel, allcont_nnlevel, double, h.nbfcontinua)
   DL(allcont_departure, allcont_departure, double, h.nbfcontinua)
   DL(allcont_edgepart, allcont_edgepart, double, h.nbfcontinua)
-  DL(allcont_keepbits, allcont_keepbits, uint64_t, h.nkeepwords)
+  if (allcont_keepbits && h.nbfcontinua > 0)  // rows are padded to nkeepwords; the caller's buffer holds ceil(nbfcontinua/64) words
+    HIP_TRY(hipMemcpy(allcont_keepbits, e->K.allcont_keepbits + (int64_t)c * h.nkeepwords, sizeof(uint64_t) * (size_t)((h.nbfcontinua + 63) / 64),
+                      hipMemcpyDeviceToHost));
   DL(corrphotoioncoeff, corrphotoioncoeff, double, h.nphixstargets_total)
   DL(cooling_contrib, cooling_contrib, double, h.ncoolingterms)
   DL(ion_cooling_contribs, ion_cooling_contribs, double, h.nions)

@@ -17,6 +17,7 @@ struct ModelOwned {
   std::vector<LinePack> line_pack;
   std::vector<LevelPack> level_pack;
   std::vector<ContPack> cont_pack;
+  std::vector<TargetPack> target_pack;
 };
 
 // X(field, element type, element count) for every array pointer of DevModel
@@ -45,6 +46,7 @@ struct ModelOwned {
   X(level_matransblock_start, int32_t, (m).nlevels)                                \
   X(level_ion, int32_t, (m).nlevels)                                               \
   X(level_pack, LevelPack, (m).nlevels)                                            \
+  X(target_pack, TargetPack, (m).nalltrans)                                        \
   X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
   X(alltrans_einstein_A, float, (m).nalltrans)                                     \
@@ -116,7 +118,7 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.nphixstargets_total = m.nphixstargets_total; v.nphixslevels = m.nphixslevels; v.nbfcontinua = m.nbfcontinua;
   v.nbfcontinua_ground = m.nbfcontinua_ground; v.ncoolingterms = m.ncoolingterms; v.nmatransblock = m.nmatransblock;
   v.NPHIXSPOINTS = m.NPHIXSPOINTS;
-  v.nkeepwords = (m.nbfcontinua + 63) / 64;
+  v.nkeepwords = (((m.nbfcontinua + 63) / 64) + 3) & ~3;  // rows padded to whole 4-word chunks (physics.h KeepIter)
   v.NPHIXSNUINCREMENT = m.NPHIXSNUINCREMENT;
   v.last_phixs_nuovernuedge = (1.0 + (m.NPHIXSNUINCREMENT * (m.NPHIXSPOINTS - 1)));                    // input.cc:310
   v.T_step_log = (std::log(ARTIS_OPT_MAXTEMP) - std::log(ARTIS_OPT_MINTEMP)) / (ARTIS_OPT_TABLESIZE - 1.);  // ratecoeff.cc:39
@@ -135,11 +137,23 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   int32_t rec = 0;
   for (int i = 0; i < m.nlevels; i++) {
     own.level_pack[i] = LevelPack{rec, m.level_alltrans_startdown[i], m.level_ndowntrans[i], m.level_nuptrans[i]};
-    const int sz = 9 + 2 * m.level_ndowntrans[i] + m.level_nuptrans[i];
+    const int sz = marec_size(m.level_ndowntrans[i], m.level_nuptrans[i]);
     rec += ((sz + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
   }
   v.nmacache = rec;
   v.level_pack = own.level_pack.data();
+  own.target_pack.resize(m.nalltrans > 0 ? m.nalltrans : 1);
+  for (int ul = 0; ul < m.nlevels; ul++) {
+    const int ui = own.level_ion[ul];
+    const int ntrans = m.level_ndowntrans[ul] + m.level_nuptrans[ul];
+    for (int t = 0; t < ntrans; t++) {
+      const int ati = m.level_alltrans_startdown[ul] + t;
+      const int target = m.alltrans_targetlevelindex[ati];
+      const LevelPack &tl = own.level_pack[m.ion_uniquelevelindexstart[ui] + target];
+      own.target_pack[ati] = TargetPack{tl.rec_off, tl.alltrans_startdown, (uint16_t)tl.ndown, (uint16_t)tl.nup, target};
+    }
+  }
+  v.target_pack = own.target_pack.data();
   own.cont_pack.resize(m.nbfcontinua);
   for (int i = 0; i < m.nbfcontinua; i++)
     own.cont_pack[i] = ContPack{m.allcont_nu_edge[i], m.allcont_probability[i],
@@ -192,10 +206,10 @@ inline void unpack_macache_row(const DevModel &hostview, const artis_model &m, c
     if (matrans) {
       double *blk = matrans + m.level_matransblock_start[ul];
       for (int i = 0; i < lp.ndown; i++) {
-        blk[i] = rec[9 + lp.ndown + lp.nup + i];
-        blk[lp.ndown + i] = rec[9 + i];
+        blk[i] = rec[marec_rad(lp.ndown, lp.nup) + i];
+        blk[lp.ndown + i] = rec[marec_down + i];
       }
-      for (int i = 0; i < lp.nup; i++) blk[2 * lp.ndown + i] = rec[9 + lp.ndown + i];
+      for (int i = 0; i < lp.nup; i++) blk[2 * lp.ndown + i] = rec[marec_up(lp.ndown) + i];
     }
   }
 }

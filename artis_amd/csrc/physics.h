@@ -360,14 +360,68 @@ AHD float phixs_fromtable(const DevModel &M, const float *xs, double nu_edge, do
   return (float)(xs[NP - 1] * pow3(nu_max_phixs / nu));
 #endif
 }
+// Partition point of a[0..n) for a predicate that is true on a prefix and false on the rest: the index of the first
+// element for which it is false (n if none), i.e. what std::ranges::upper_bound / lower_bound / partition_point return.
+// 8-ary instead of binary: the 7 probes of a round are independent reads, so an array of n elements costs
+// ceil(log8 n) memory round trips instead of log2 n; the result is the same for any partitioned input.
+template <class Pred>
+AHD int partition_point8(const double *a, int n, Pred pred) {
+  int lo = 0, len = n;  // the answer lies in [lo, lo + len]
+  while (len > 8) {
+    const int step = (len + 7) / 8;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 1; k < 8; k++) {
+      const int pidx = lo + (k * step) - 1;
+      const bool valid = pidx < lo + len;
+      const double x = a[valid ? pidx : lo];
+      cnt += (valid && pred(x)) ? 1 : 0;
+    }
+    const int nlo = lo + (cnt * step);
+    const int upper = lo + ((cnt + 1) * step) - 1;  // probe cnt+1: known to be false if it was made
+    const int end = lo + len;
+    len = ((cnt < 7 && upper < end) ? upper : end) - nlo;
+    lo = nlo;
+  }
+  int cnt = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const bool valid = k < len;
+    const double x = a[valid ? lo + k : lo];
+    cnt += (valid && pred(x)) ? 1 : 0;
+  }
+  return lo + cnt;
+}
 // std::ranges::upper_bound / lower_bound on a rising double array
-AHD int upper_bound_d(const double *a, int n, double v) {
+// measured on MI355X: the propagation kernels are bound by the number of memory instructions, not by their latency,
+// so the binary search (fewest reads) is the default
+#ifndef ARTIS_KARY
+#define ARTIS_KARY 0
+#endif
+template <class Pred>
+AHD int partition_point2(const double *a, int n, Pred pred) {
   int lo = 0, len = n;
   while (len > 0) {
     const int half = len / 2;
-    if (!(v < a[lo + half])) { lo += half + 1; len -= half + 1; } else { len = half; }
+    if (pred(a[lo + half])) { lo += half + 1; len -= half + 1; } else { len = half; }
   }
   return lo;
+}
+template <class Pred>
+AHD int partition_point_d(const double *a, int n, Pred pred) {
+#if ARTIS_KARY
+  return partition_point8(a, n, pred);
+#else
+  return partition_point2(a, n, pred);
+#endif
+}
+AHD int upper_bound_d(const double *a, int n, double v) {
+  if (n <= 0) return 0;
+  return partition_point_d(a, n, [v](double x) { return !(v < x); });
+}
+AHD int lower_bound_d(const double *a, int n, double v) {
+  if (n <= 0) return 0;
+  return partition_point_d(a, n, [v](double x) { return x < v; });
 }
 // upper_bound on a non-decreasing array as "count the elements <= v", 8 independent loads per round trip instead of
 // one dependent load per bisection step (same result as upper_bound_d for any non-decreasing input)
@@ -385,14 +439,6 @@ AHD int upper_bound_wide(const double *a, int n, double v) {
     if (cnt < 8) break;
   }
   return idx;
-}
-AHD int lower_bound_d(const double *a, int n, double v) {
-  int lo = 0, len = n;
-  while (len > 0) {
-    const int half = len / 2;
-    if (a[lo + half] < v) { lo += half + 1; len -= half + 1; } else { len = half; }
-  }
-  return lo;
 }
 
 // ---------------------------------------------------------------- grid.cc
@@ -629,12 +675,25 @@ AHD double col_deexc(const DevModel &M, float T_e, float cnne, double epsilon_tr
   }
   return cnne * 8.629e-6 * (double)cs / gu / sqrtf(T_e);
 }
-AHD double col_exc(const DevModel &M, float T_e, float cnne, double epsilon_trans, double gu, double gl, int ati) {  // macroatom.cc:750
-  const float cs = M.alltrans_coll_str[ati];
+// col_exc_ratecoeff macroatom.cc:750, with the transition's three constants read by the caller (col_exc_read) so that
+// a loop over transitions can have the reads of several of them in flight
+struct ColRead {
+  float cs, f;
+  bool forbidden;
+};
+AHD ColRead col_exc_read(const DevModel &M, int ati) {
+  ColRead r;
+  r.cs = M.alltrans_coll_str[ati];
+  r.forbidden = M.alltrans_forbidden[ati] != 0;
+  r.f = M.alltrans_osc_strength[ati];
+  return r;
+}
+AHD double col_exc_from(const ColRead r, float T_e, float cnne, double epsilon_trans, double gu, double gl) {
+  const float cs = r.cs;
   const double eoverkt = epsilon_trans / (KB * T_e);
   if (cs < 0) {
-    if (!M.alltrans_forbidden[ati]) {
-      const double f = M.alltrans_osc_strength[ati];
+    if (!r.forbidden) {
+      const double f = r.f;
       const double g_bar = 0.2;
       const double ex = exp(eoverkt);
       const double Gamma = dmax(g_bar, 0.276 * ex * (-EULERGAMMA - log(eoverkt)));
@@ -643,6 +702,9 @@ AHD double col_exc(const DevModel &M, float T_e, float cnne, double epsilon_tran
     return cnne * 8.629e-6 * 0.01 * exp(-eoverkt) * gu / sqrtf(T_e);
   }
   return cnne * 8.629e-6 * (double)cs * exp(-eoverkt) / gl / sqrtf(T_e);
+}
+AHD double col_exc(const DevModel &M, float T_e, float cnne, double epsilon_trans, double gu, double gl, int ati) {
+  return col_exc_from(col_exc_read(M, ati), T_e, cnne, epsilon_trans, gu, gl);
 }
 
 // ================================================================ cell-cache population
@@ -734,9 +796,9 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
   const LevelPack lpk = M.level_pack[ul];
   double *rates = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
-  double *blk_down = rates + MA_N;                       // cumulative internal-down-same
-  double *blk_up = blk_down + lpk.ndown;                 // cumulative internal-up-same
-  double *blk_rad = blk_up + lpk.nup;                    // cumulative radiative de-excitation
+  double *blk_down = rates + marec_down;                      // cumulative internal-down-same
+  double *blk_up = rates + marec_up(lpk.ndown);               // cumulative internal-up-same
+  double *blk_rad = rates + marec_rad(lpk.ndown, lpk.nup);    // cumulative radiative de-excitation
   const double t_mid = env.S.mid;
   const float T_e = env.C.Te[c];
   const float cnne = clumpednne(env.C, c);
@@ -980,13 +1042,34 @@ AHD float phixs_finish(const DevModel &M, const PhixsRead r, double nu_edge, dou
 #ifndef ARTIS_CHI_BATCH
 #define ARTIS_CHI_BATCH 4
 #endif
+// iterator over the set bits of a cell's keep bitmap inside [cbegin, cend); the bitmap is read four words (32 bytes)
+// at a time so that a sparse stretch costs one memory round trip per 256 continua
+#ifndef ARTIS_KEEPCHUNK
+#define ARTIS_KEEPCHUNK 0
+#endif
 struct KeepIter {
   const uint64_t *keep;
-  int word, cbegin, cend;
-  uint64_t bits;
+  int word, cbegin, cend, chunk;
+  uint64_t bits, w0, w1, w2, w3;
 };
-AHD uint64_t keep_masked(const KeepIter &it) {
-  uint64_t bits = it.keep[it.word];
+AHD uint64_t keep_masked(KeepIter &it) {
+#if !ARTIS_KEEPCHUNK
+  uint64_t bits1 = it.keep[it.word];
+  if (it.word == (it.cbegin / 64)) bits1 &= ~UINT64_C(0) << (unsigned)(it.cbegin % 64);
+  if (((it.word + 1) * 64) > it.cend) bits1 &= ~UINT64_C(0) >> (unsigned)(64 - (it.cend % 64));
+  return bits1;
+#endif
+  const int chunk = it.word >> 2;
+  if (chunk != it.chunk) {
+    const uint64_t *q = it.keep + (chunk * 4);
+    it.w0 = q[0];
+    it.w1 = q[1];
+    it.w2 = q[2];
+    it.w3 = q[3];
+    it.chunk = chunk;
+  }
+  const int sel = it.word & 3;
+  uint64_t bits = (sel == 0) ? it.w0 : ((sel == 1) ? it.w1 : ((sel == 2) ? it.w2 : it.w3));
   if (it.word == (it.cbegin / 64)) bits &= ~UINT64_C(0) << (unsigned)(it.cbegin % 64);
   if (((it.word + 1) * 64) > it.cend) bits &= ~UINT64_C(0) >> (unsigned)(64 - (it.cend % 64));
   return bits;
@@ -1028,6 +1111,8 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   it.cbegin = cbegin;
   it.cend = cend;
   it.word = cbegin / 64;
+  it.chunk = -1;
+  it.w0 = it.w1 = it.w2 = it.w3 = 0;
   it.bits = (it.word * 64 < cend) ? keep_masked(it) : 0;
   bool more = (it.word * 64 < cend);
   while (more) {
@@ -1116,12 +1201,7 @@ AHD int closest_transition(const double *nu, int nlines, double nu_cmf, int next
   if (nu_cmf < nu[nlines - 1]) return -1;
   if (next_trans > 0) return next_trans;
   if (nu_cmf >= nu[0]) return 0;
-  int lo = 0, len = nlines;
-  while (len > 0) {
-    const int half = len / 2;
-    if (nu[lo + half] > nu_cmf) { lo += half + 1; len -= half + 1; } else { len = half; }
-  }
-  return lo;
+  return partition_point_d(nu, nlines, [nu_cmf](double x) { return x > nu_cmf; });
 }
 AHD double linedistance(double prop_time, double nu_cmf, double nu_trans) {  // rpkt.h:125
   if (nu_cmf <= nu_trans) return 0.;
@@ -1493,11 +1573,14 @@ AHD void ma_finish(const Env &env, Pkt &p, int64_t pi) {
   }
 }
 
-// per-launch invariants of a thermal packet (it never changes cell while thermal)
+// per-launch invariants of a thermal packet (it never changes cell while thermal) and the static indices of the level
+// its macro-atom is in
 struct MACtx {
   int c;                    // non-empty model cell
   const double *cellma;     // the cell's row of macro-atom records
   int start_key, start;     // cached get_ionuniquelevelindexstart(element, ion)
+  int lp_key, lp_level;     // (element, ion), level that `lp` belongs to
+  LevelPack lp;
 };
 AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   MACtx k;
@@ -1505,13 +1588,52 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
   k.start_key = -1;
   k.start = 0;
+  k.lp_key = -1;
+  k.lp_level = -1;
+  k.lp = LevelPack{0, 0, 0, 0};
   return k;
 }
 
+// upper_bound over the cumulative sums of one block of a macro-atom record (16-byte aligned, non-decreasing):
+// index of the first element > v, at most n
+#ifndef ARTIS_MA_SEARCH
+#define ARTIS_MA_SEARCH 1
+#endif
+struct alignas(16) D2 {
+  double x, y;
+};
+AHD int ma_search(const double *a, int n, double v) {
+#if ARTIS_MA_SEARCH == 0
+  if (n <= 0) return 0;
+  return partition_point2(a, n, [v](double x) { return !(v < x); });
+#elif ARTIS_MA_SEARCH == 1
+  return upper_bound_wide(a, n, v);
+#else
+  // eight elements per round as four 16-byte reads
+  int idx = 0;
+  for (int base = 0; base < n; base += 8) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const int i = base + k;
+      if (i < n) {
+        const D2 q = *(const D2 *)(a + i);
+        cnt += (q.x <= v) ? 1 : 0;
+        cnt += (i + 1 < n && q.y <= v) ? 1 : 0;
+      }
+    }
+    idx += cnt;
+    if (cnt < 8) break;
+  }
+  return idx;
+#endif
+}
+
 // one iteration of the loop of do_macroatom(), macroatom.cc:385-577.
-// ma_locate() finds the level's unique index; ma_jump_core() performs the transition given the level's macro-atom
-// record `rates` (tables.h LevelPack layout) and its list of target levels `targets` (alltrans.targetlevelindex of the
-// level: down targets, then up targets). Both pointers may refer to HBM or to an LDS copy of the same values.
+// ma_jump() makes sure the static indices of the current level are at hand (they come with the transition that led
+// here, tables.h TargetPack; only the first transition of a walk has to look them up) and ma_jump_core() performs the
+// transition given the level's macro-atom record `rates` (tables.h layout) and its transition targets `targets`
+// (down targets, then up targets).
 AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
   const int key = (p.ma_element << 8) | p.ma_ion;
   if (key != k.start_key) {
@@ -1520,11 +1642,26 @@ AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
   }
   return k.start + p.ma_level;
 }
-AHD void ma_jump_core(const Env &env, Pkt &p, int64_t pi, const MACtx &k, int ul, const LevelPack lp, const double *rates,
-                      const int32_t *targets) {
+#ifndef ARTIS_MA_TARGETPACK
+#define ARTIS_MA_TARGETPACK 0  // 1: carry the static indices of the next level with the transition (TargetPack)
+#endif
+#if ARTIS_MA_TARGETPACK
+typedef TargetPack ma_target_t;
+AHD int ma_target_level(const TargetPack &tp) { return tp.level; }
+AHD void ma_set_level(Pkt &p, MACtx &k, const TargetPack tp) {
+  p.ma_level = tp.level;
+  k.lp = LevelPack{tp.rec_off, tp.alltrans_startdown, tp.ndown, tp.nup};
+  k.lp_level = tp.level;
+}
+#else
+typedef int32_t ma_target_t;
+AHD int ma_target_level(int32_t level) { return level; }
+AHD void ma_set_level(Pkt &p, MACtx &, int32_t level) { p.ma_level = level; }
+#endif
+AHD void ma_jump_core(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double *rates, const ma_target_t *targets) {
   const DevModel &M = env.M;
   const int c = k.c;
-  const int start = k.start;
+  const LevelPack lp = k.lp;
   const int activatingline = p.ma_line;
   ARTIS_STAT(env, ARTIS_STAT_X_MA_JUMPS);
   // std::partial_sum macroatom.cc:425 and index_upperbound sn3d.h:85 over the 9 cumulative rates, kept in
@@ -1555,12 +1692,13 @@ AHD void ma_jump_core(const Env &env, Pkt &p, int64_t pi, const MACtx &k, int ul
     // do_macroatom_raddeexcitation macroatom.cc:204
     const double targetval = rng_uniform(p) * rate_sel;
     const int ndown = lp.ndown;
-    const double *sums = rates + MA_N + ndown + lp.nup;
-    const int dti = upper_bound_wide(sums, ndown - 1, targetval);
+    const double *sums = rates + marec_rad(ndown, lp.nup);
+    const int dti = ma_search(sums, ndown - 1, targetval);
     const int startdown = lp.alltrans_startdown;
     const int lineindex = M.alltrans_lineindex[startdown + dti];
     if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
-    const int lul = start + targets[dti];
+    const int ul = ma_locate(env, p, k);
+    const int lul = k.start + ma_target_level(targets[dti]);
     const double e_trans = eps(M, ul) - eps(M, lul);
     const double oldnucmf = p.nu_cmf;
     p.nu_cmf = e_trans / HPLANCK;
@@ -1581,16 +1719,16 @@ AHD void ma_jump_core(const Env &env, Pkt &p, int64_t pi, const MACtx &k, int ul
   } else if (action == ARTIS_MA_ACTION_INTERNALDOWNSAME) {
     const double targetval = rng_uniform(p) * rate_sel;
     const int ndown = lp.ndown;
-    const double *sums = rates + MA_N;
-    const int dti = upper_bound_wide(sums, ndown - 1, targetval);
-    p.ma_level = targets[dti];
+    const double *sums = rates + marec_down;
+    const int dti = ma_search(sums, ndown - 1, targetval);
+    ma_set_level(p, k, targets[dti]);
   } else if (action == ARTIS_MA_ACTION_INTERNALUPSAME) {
     const int ndown = lp.ndown;
     const int nup = lp.nup;
-    const double *sums = rates + MA_N + ndown;
+    const double *sums = rates + marec_up(ndown);
     const double targetval = rng_uniform(p) * rate_sel;
-    const int uti = upper_bound_wide(sums, nup - 1, targetval);
-    p.ma_level = targets[ndown + uti];
+    const int uti = ma_search(sums, nup - 1, targetval);
+    ma_set_level(p, k, targets[ndown + uti]);
   } else {
     // the rare bound-free channels need rate coefficients with exp() and, for a radiative recombination, an adaptive
     // quadrature: they are executed by the slow-path kernel (ma_slow_action) so that this loop stays small
@@ -1599,9 +1737,17 @@ AHD void ma_jump_core(const Env &env, Pkt &p, int64_t pi, const MACtx &k, int ul
   }
 }
 AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
-  const int ul = ma_locate(env, p, k);
-  const LevelPack lp = env.M.level_pack[ul];
-  ma_jump_core(env, p, pi, k, ul, lp, k.cellma + lp.rec_off, env.M.alltrans_targetlevelindex + lp.alltrans_startdown);
+  const int key = (p.ma_element << 8) | p.ma_ion;
+  if (!ARTIS_MA_TARGETPACK || key != k.lp_key || p.ma_level != k.lp_level) {
+    k.lp = env.M.level_pack[ma_locate(env, p, k)];
+    k.lp_key = key;
+    k.lp_level = p.ma_level;
+  }
+#if ARTIS_MA_TARGETPACK
+  ma_jump_core(env, p, pi, k, k.cellma + k.lp.rec_off, env.M.target_pack + k.lp.alltrans_startdown);
+#else
+  ma_jump_core(env, p, pi, k, k.cellma + k.lp.rec_off, env.M.alltrans_targetlevelindex + k.lp.alltrans_startdown);
+#endif
 }
 
 // the bound-free transitions of do_macroatom(): macroatom.cc:481-488, 501-533, 552-560
@@ -1964,15 +2110,35 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     int upper = -1;
     const int startup = M.level_alltrans_startdown[ul] + M.level_ndowntrans[ul];
     const int nup = M.level_nuptrans[ul];
-    for (int ati = startup; ati < (startup + nup); ati++) {
-      const int tmpupper = M.alltrans_targetlevelindex[ati];
-      const int uul = start + tmpupper;
-      const double e_trans = eps(M, uul) - e_cur;
-      const double Cc = nnlevel * col_exc(M, T_e, cnne, e_trans, statw(M, uul), g_cur, ati) * e_trans;
-      contrib += Cc;
-      if (contrib > rnd_process) {
-        upper = tmpupper;
-        break;
+    // kpkt.cc:461-476, the level's upward transitions four at a time: reads first, then the sums in order
+#ifndef ARTIS_COLLEXC_BATCH
+#define ARTIS_COLLEXC_BATCH 1
+#endif
+    constexpr int CB = ARTIS_COLLEXC_BATCH;
+    for (int base = startup; base < (startup + nup) && upper < 0; base += CB) {
+      int tmpupper[CB];
+      ColRead cr[CB];
+      double e_up[CB];
+      float g_up[CB];
+#pragma unroll
+      for (int k = 0; k < CB; k++) {
+        const int ati = (base + k < startup + nup) ? base + k : base;
+        tmpupper[k] = M.alltrans_targetlevelindex[ati];
+        cr[k] = col_exc_read(M, ati);
+      }
+#pragma unroll
+      for (int k = 0; k < CB; k++) {
+        e_up[k] = eps(M, start + tmpupper[k]);
+        g_up[k] = M.level_statweight[start + tmpupper[k]];
+      }
+#pragma unroll
+      for (int k = 0; k < CB; k++) {
+        if (upper < 0 && base + k < startup + nup) {
+          const double e_trans = e_up[k] - e_cur;
+          const double Cc = nnlevel * col_exc_from(cr[k], T_e, cnne, e_trans, g_up[k], g_cur) * e_trans;
+          contrib += Cc;
+          if (contrib > rnd_process) upper = tmpupper[k];
+        }
       }
     }
     if (!(contrib > rnd_process)) {
@@ -2130,13 +2296,12 @@ AHD bool thermal_can_continue(const Pkt &p, double ts_end) {
   return pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT;
 }
 // returns the units of work done (transitions + k-packet steps); *go = the packet can take another iteration.
-// `jump` performs one transition (ma_jump, or the engine's LDS-cached form of it).
-template <class JumpFn>
-AHD int thermal_iter_with(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go, JumpFn jump) {
+// (artis_engine.hip k_thermal spells the two phases out so that the wave reconverges between them.)
+AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
   const double ts_end = env.S.ts_end;
   int j = 0;
   while (j < ARTIS_MA_PHASE && ma_pending(p) && p.pend == PEND_NONE) {
-    jump(p, k);
+    ma_jump(env, p, pi, k);
     j++;
   }
   if (j > 0) chi_after_ma(env, p, pi);
@@ -2151,9 +2316,6 @@ AHD int thermal_iter_with(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go
   }
   *go = thermal_can_continue(p, ts_end);
   return j;
-}
-AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
-  return thermal_iter_with(env, p, pi, k, go, [&](Pkt &pp, MACtx &kk) { ma_jump(env, pp, pi, kk); });
 }
 
 // ---- k-packet kernel body: ONE do_kpkt()/do_kpkt_blackbody() call (update_packets.cc:291-305); it ends in an emission,

@@ -75,6 +75,14 @@ void populate_all(Emu &e) {
 
 extern "C" {
 
+// search helpers of physics.h, for tests/test_kernel_bodies_vs_oracle.py
+int artis_emu_upper_bound(const double *a, int n, double v) { return artis::upper_bound_d(a, n, v); }
+int artis_emu_lower_bound(const double *a, int n, double v) { return artis::lower_bound_d(a, n, v); }
+int artis_emu_upper_bound_wide(const double *a, int n, double v) { return artis::upper_bound_wide(a, n, v); }
+int artis_emu_closest_transition(const double *nu, int nlines, double nu_cmf, int next_trans) {
+  return artis::closest_transition(nu, nlines, nu_cmf, next_trans);
+}
+
 int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, const artis_timestep *ts, artis_packet *packets,
                              int64_t npackets, artis_estimators *est, int budget) {
   Emu e;
@@ -145,7 +153,7 @@ int artis_emu_cellcache(const artis_model *m, const artis_cellstate *cs, const a
   std::memcpy(allcont_nnlevel, K.allcont_nnlevel + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
   std::memcpy(allcont_departure, K.allcont_departure + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
   std::memcpy(allcont_edgepart, K.allcont_edgepart + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
-  std::memcpy(allcont_keepbits, K.allcont_keepbits + (int64_t)c * M.nkeepwords, sizeof(uint64_t) * M.nkeepwords);
+  std::memcpy(allcont_keepbits, K.allcont_keepbits + (int64_t)c * M.nkeepwords, sizeof(uint64_t) * ((M.nbfcontinua + 63) / 64));
   std::memcpy(corrphotoioncoeff, K.corrphotoioncoeff + (int64_t)c * M.nphixstargets_total, sizeof(double) * M.nphixstargets_total);
   std::memcpy(cooling_contrib, K.cooling_contrib + (int64_t)c * M.ncoolingterms, sizeof(double) * M.ncoolingterms);
   std::memcpy(ion_cooling_contribs, K.ion_cooling_contribs + (int64_t)c * M.nions, sizeof(double) * M.nions);

@@ -76,3 +76,29 @@ def test_empty_and_untouched_packets(oracle):
     for f in abi.PACKET_DTYPE.names:  # (padding bytes are not compared)
         assert pk[f][:48].tobytes() == ref[f][:48].tobytes(), f
     assert np.all((pk["prop_time"][48:] >= ts.c.start + ts.c.width) | (pk["type"][48:] == abi.TYPE_ESCAPE))
+
+
+def test_search_helpers_match_numpy():
+    """partition_point8 / upper_bound_wide (physics.h) against numpy.searchsorted on arrays with ties and at the edges"""
+    import ctypes as C
+    L = emu.lib()
+    for f in (L.artis_emu_upper_bound, L.artis_emu_lower_bound, L.artis_emu_upper_bound_wide):
+        f.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        f.restype = C.c_int
+    L.artis_emu_closest_transition.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
+    L.artis_emu_closest_transition.restype = C.c_int
+    rng = np.random.default_rng(5)
+    for n in [1, 2, 7, 8, 9, 15, 16, 17, 63, 64, 65, 100, 511, 512, 513, 1851, 13619]:
+        a = np.sort(rng.integers(0, max(2, n // 2), n).astype(np.float64))  # many ties
+        probes = np.concatenate([a[:: max(1, n // 50)], a[:: max(1, n // 50)] + 0.5, [-1.0, a[-1] + 1.0]])
+        for v in probes:
+            assert L.artis_emu_upper_bound(a.ctypes.data, n, v) == np.searchsorted(a, v, side="right")
+            assert L.artis_emu_lower_bound(a.ctypes.data, n, v) == np.searchsorted(a, v, side="left")
+            assert L.artis_emu_upper_bound_wide(a.ctypes.data, n, v) == np.searchsorted(a, v, side="right")
+        d = np.ascontiguousarray(a[::-1])  # line list: falling frequencies (rpkt.h:155)
+        for v in probes:
+            got = L.artis_emu_closest_transition(d.ctypes.data, n, v, 0)
+            if v < d[-1]:
+                assert got == -1
+            else:
+                assert got == int(np.sum(d > v))

@@ -1,24 +1,21 @@
 #!/bin/bash
-# Collect PMC counters for the propagation kernels (separate passes, kernel-trace only), 1e6-packet bench.
+# Collect PMC counters for the propagation kernels: separate rocprofv3 passes (kernel-trace + pmc only).
+# usage (on the GPU box): bash tools_pmc.sh [packets]   -> gpurun_out/pmc/<pass>/..., gpurun_out/pmc_<pass>.log
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS SQ_INSTS_SMEM" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
-  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc/$tag -- python3 $R/bench.py --packets ${PMC_PACKETS:-1000000} --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc_$tag.log 2>&1
-  echo "pass $tag rc=$?"
+P=${1:-10000000}
+i=0
+for set in \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU" \
+  "SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA" \
+  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
+  "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum" \
+  "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
+  "FETCH_SIZE GRBM_GUI_ACTIVE" \
+  "WRITE_SIZE TCC_EA0_RDREQ_32B_sum"; do
+  i=$((i+1))
+  tag=pass$i
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc/$tag -- python3 $R/bench.py --packets $P --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc_$tag.log 2>&1
+  echo "$tag rc=$? : $set"
 done
-python3 - <<'PY'
-import csv, glob, os, collections
-root=os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/pmc"
-agg=collections.defaultdict(lambda: collections.defaultdict(float))
-for f in glob.glob(root+"/*/*/*counter_collection.csv"):
-    for row in csv.DictReader(open(f)):
-        k=row["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::","")
-        agg[k][row["Counter_Name"]]+=float(row["Counter_Value"])
-with open(root+"/summary.txt","w") as out:
-    for k,v in sorted(agg.items()):
-        if not any(x in k for x in ("k_thermal","k_rpkt","k_slow","k_macroatom")): continue
-        out.write(k+"\n")
-        for c,val in sorted(v.items()): out.write(f"   {c:40s} {val:.6g}\n")
-print(open(root+"/summary.txt").read())
-PY
