@@ -416,14 +416,19 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
 #endif
     bool go = have && thermal_can_continue(p, ts_end);
     if (go) {
+      // the loop makes the internal transitions; the process that ends a walk is carried out after it, once per phase
       int j = 0;
-      while (j < ARTIS_MA_PHASE && ma_pending(p) && p.pend == PEND_NONE) {
+      int exit_action = -1;
+      double exit_rate = 0.;
+      while (j < ARTIS_MA_PHASE && exit_action < 0 && ma_pending(p) && p.pend == PEND_NONE) {
 #ifdef ARTIS_PROFILE
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 46);
 #endif
-        ma_jump(env, p, pi, k);
+        ma_prepare(env, p, k);
+        exit_action = ma_jump_internal(env, p, k, k.cellma + k.lp.rec_off, ma_targets(env, k), &exit_rate);
         j++;
       }
+      if (exit_action >= 0) ma_jump_exit(env, p, pi, k, k.cellma + k.lp.rec_off, ma_targets(env, k), exit_action, exit_rate);
       if (j > 0) chi_after_ma(env, p, pi);
       units += j;
     }

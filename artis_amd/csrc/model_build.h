@@ -16,6 +16,7 @@ struct ModelOwned {
   std::vector<int32_t> level_ion;
   std::vector<LinePack> line_pack;
   std::vector<LevelPack> level_pack;
+  std::vector<int32_t> level_upcum_start;
   std::vector<ContPack> cont_pack;
   std::vector<TargetPack> target_pack;
 };
@@ -46,6 +47,7 @@ struct ModelOwned {
   X(level_matransblock_start, int32_t, (m).nlevels)                                \
   X(level_ion, int32_t, (m).nlevels)                                               \
   X(level_pack, LevelPack, (m).nlevels)                                            \
+  X(level_upcum_start, int32_t, (m).nlevels)                                       \
   X(target_pack, TargetPack, (m).nalltrans)                                        \
   X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
@@ -106,6 +108,7 @@ struct ModelOwned {
   X(allcont_keepbits, uint64_t, (m).nkeepwords)                 \
   X(corrphotoioncoeff, double, (m).nphixstargets_total)         \
   X(cooling_contrib, double, (m).ncoolingterms)                 \
+  X(collexc_cum, double, (m).nupcum)                            \
   X(ion_cooling_contribs, double, (m).nions)                    \
   X(ion_cooling_C, double, (m).nions)                           \
   X(chi_ff_nnionpart, double, 1)
@@ -142,6 +145,14 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   }
   v.nmacache = rec;
   v.level_pack = own.level_pack.data();
+  own.level_upcum_start.resize(m.nlevels);
+  int32_t nupcum = 0;
+  for (int i = 0; i < m.nlevels; i++) {
+    own.level_upcum_start[i] = nupcum;
+    nupcum += m.level_nuptrans[i];
+  }
+  v.nupcum = nupcum;
+  v.level_upcum_start = own.level_upcum_start.data();
   own.target_pack.resize(m.nalltrans > 0 ? m.nalltrans : 1);
   for (int ul = 0; ul < m.nlevels; ul++) {
     const int ui = own.level_ion[ul];

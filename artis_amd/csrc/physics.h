@@ -906,11 +906,15 @@ AHD void populate_cooling_ion(const Env &env, int c, int ui) {
     const double g_cur = statw(M, ul);
     const int startup = M.level_alltrans_startdown[ul] + M.level_ndowntrans[ul];
     const int nup = M.level_nuptrans[ul];
+    // the running sum after every transition is kept: do_kpkt() (kpkt.cc:461-476) re-adds exactly these terms, in this
+    // order and from the same starting value, to pick the transition, and reads the sums here instead
+    double *upcum = env.K.collexc_cum + ((int64_t)c * M.nupcum) + M.level_upcum_start[ul];
     for (int ati = startup; ati < (startup + nup); ati++) {
       const int uul = start + M.alltrans_targetlevelindex[ati];
       const double e_trans = eps(M, uul) - e_cur;
       const double Cc = nnlevel * col_exc(M, T_e, cnne, e_trans, statw(M, uul), g_cur, ati) * e_trans;
       C_ion += Cc;
+      upcum[ati - startup] = C_ion;
     }
     if (nup > 0) contribs[k++] = C_ion;
   }
@@ -1608,6 +1612,21 @@ AHD int ma_search(const double *a, int n, double v) {
   return partition_point2(a, n, [v](double x) { return !(v < x); });
 #elif ARTIS_MA_SEARCH == 1
   return upper_bound_wide(a, n, v);
+#elif ARTIS_MA_SEARCH == 3
+  // eight elements per round, no branches: reads past the end are redirected to the last element
+  int idx = 0;
+  for (int base = 0; base < n; base += 8) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int i = base + k;
+      const double x = a[(i < n) ? i : n - 1];
+      cnt += (i < n && x <= v) ? 1 : 0;
+    }
+    idx += cnt;
+    if (cnt < 8) break;
+  }
+  return idx;
 #else
   // eight elements per round as four 16-byte reads
   int idx = 0;
@@ -1658,11 +1677,13 @@ typedef int32_t ma_target_t;
 AHD int ma_target_level(int32_t level) { return level; }
 AHD void ma_set_level(Pkt &p, MACtx &, int32_t level) { p.ma_level = level; }
 #endif
-AHD void ma_jump_core(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double *rates, const ma_target_t *targets) {
-  const DevModel &M = env.M;
-  const int c = k.c;
+// First half of a transition: draw the process (macroatom.cc:425-431); an internal transition inside the ion is made
+// at once and -1 is returned. Every other process ends the walk in this kernel (deactivation, or a bound-free process
+// for the slow path): its index is returned with its rate, and ma_jump_exit() carries it out. The split lets a kernel
+// keep the rare, long deactivation code out of its transition loop.
+constexpr int MA_EXIT_FAILED = 99;
+AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rates, const ma_target_t *targets, double *rate_out) {
   const LevelPack lp = k.lp;
-  const int activatingline = p.ma_line;
   ARTIS_STAT(env, ARTIS_STAT_X_MA_JUMPS);
   // std::partial_sum macroatom.cc:425 and index_upperbound sn3d.h:85 over the 9 cumulative rates, kept in
   // registers (statically indexed): action = number of cumulative values <= randomrate, clamped to the last one
@@ -1677,7 +1698,7 @@ AHD void ma_jump_core(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double
   if (!(total > 0.)) {
     fail(env, 40);
     p.ma_level = -1;
-    return;
+    return MA_EXIT_FAILED;
   }
   const double randomrate = rng_uniform(p) * total;
   int action = 0;
@@ -1688,6 +1709,32 @@ AHD void ma_jump_core(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double
 #pragma unroll
   for (int i = 1; i < MA_N; i++) rate_sel = (action == i) ? r[i] : rate_sel;
   ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
+  if (action == ARTIS_MA_ACTION_INTERNALDOWNSAME) {
+    const double targetval = rng_uniform(p) * rate_sel;
+    const int ndown = lp.ndown;
+    const double *sums = rates + marec_down;
+    const int dti = ma_search(sums, ndown - 1, targetval);
+    ma_set_level(p, k, targets[dti]);
+    return -1;
+  }
+  if (action == ARTIS_MA_ACTION_INTERNALUPSAME) {
+    const int ndown = lp.ndown;
+    const int nup = lp.nup;
+    const double *sums = rates + marec_up(ndown);
+    const double targetval = rng_uniform(p) * rate_sel;
+    const int uti = ma_search(sums, nup - 1, targetval);
+    ma_set_level(p, k, targets[ndown + uti]);
+    return -1;
+  }
+  *rate_out = rate_sel;
+  return action;
+}
+AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double *rates, const ma_target_t *targets, int action,
+                      double rate_sel) {
+  const DevModel &M = env.M;
+  const int c = k.c;
+  const LevelPack lp = k.lp;
+  const int activatingline = p.ma_line;
   if (action == ARTIS_MA_ACTION_RADDEEXC) {
     // do_macroatom_raddeexcitation macroatom.cc:204
     const double targetval = rng_uniform(p) * rate_sel;
@@ -1716,38 +1763,37 @@ AHD void ma_jump_core(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double
     ARTIS_EST_ADD(&env.E.colheatingestimator[c], p.e_cmf);
 #endif
     ma_finish(env, p, pi);
-  } else if (action == ARTIS_MA_ACTION_INTERNALDOWNSAME) {
-    const double targetval = rng_uniform(p) * rate_sel;
-    const int ndown = lp.ndown;
-    const double *sums = rates + marec_down;
-    const int dti = ma_search(sums, ndown - 1, targetval);
-    ma_set_level(p, k, targets[dti]);
-  } else if (action == ARTIS_MA_ACTION_INTERNALUPSAME) {
-    const int ndown = lp.ndown;
-    const int nup = lp.nup;
-    const double *sums = rates + marec_up(ndown);
-    const double targetval = rng_uniform(p) * rate_sel;
-    const int uti = ma_search(sums, nup - 1, targetval);
-    ma_set_level(p, k, targets[ndown + uti]);
-  } else {
+  } else if (action != MA_EXIT_FAILED) {
     // the rare bound-free channels need rate coefficients with exp() and, for a radiative recombination, an adaptive
     // quadrature: they are executed by the slow-path kernel (ma_slow_action) so that this loop stays small
     p.pend = PEND_MA_ACTION;
     p.pend_arg = action;
   }
 }
-AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
+// make sure k.lp describes the packet's current level (only the first transition of a walk has to look it up when the
+// TargetPack form is compiled in)
+AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) {
   const int key = (p.ma_element << 8) | p.ma_ion;
   if (!ARTIS_MA_TARGETPACK || key != k.lp_key || p.ma_level != k.lp_level) {
     k.lp = env.M.level_pack[ma_locate(env, p, k)];
     k.lp_key = key;
     k.lp_level = p.ma_level;
   }
+}
+AHD const ma_target_t *ma_targets(const Env &env, const MACtx &k) {
 #if ARTIS_MA_TARGETPACK
-  ma_jump_core(env, p, pi, k, k.cellma + k.lp.rec_off, env.M.target_pack + k.lp.alltrans_startdown);
+  return env.M.target_pack + k.lp.alltrans_startdown;
 #else
-  ma_jump_core(env, p, pi, k, k.cellma + k.lp.rec_off, env.M.alltrans_targetlevelindex + k.lp.alltrans_startdown);
+  return env.M.alltrans_targetlevelindex + k.lp.alltrans_startdown;
 #endif
+}
+AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
+  ma_prepare(env, p, k);
+  const double *rates = k.cellma + k.lp.rec_off;
+  const ma_target_t *targets = ma_targets(env, k);
+  double rate_sel = 0.;
+  const int action = ma_jump_internal(env, p, k, rates, targets, &rate_sel);
+  if (action >= 0) ma_jump_exit(env, p, pi, k, rates, targets, action, rate_sel);
 }
 
 // the bound-free transitions of do_macroatom(): macroatom.cc:481-488, 501-533, 552-560
@@ -2099,52 +2145,26 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     p.ma_line = M.coolinglist_phixstargetindex[i];
     p.pend_arg = M.coolinglist_level[i];
   } else if (ctype == ARTIS_COOLING_COLLEXC) {
-    const float cnne = clumpednne(env.C, c);
-    const double contrib_low = (i > ionstart) ? cellcontrib[i - 1] : 0.;
-    double contrib = contrib_low;
+    // kpkt.cc:455-476: the reference adds the level's collisional-excitation terms to contrib_low one by one until the
+    // sum exceeds rnd_process; those running sums are the cell cache's collexc_cum (populate_cooling_ion)
     const int start = M.ion_uniquelevelindexstart[ui];
     const int ul = start + M.coolinglist_level[i];
-    const double e_cur = eps(M, ul);
-    const double nnlevel = env.K.levelpops[((int64_t)c * M.nlevels) + ul];
-    const double g_cur = statw(M, ul);
-    int upper = -1;
-    const int startup = M.level_alltrans_startdown[ul] + M.level_ndowntrans[ul];
     const int nup = M.level_nuptrans[ul];
-    // kpkt.cc:461-476, the level's upward transitions four at a time: reads first, then the sums in order
-#ifndef ARTIS_COLLEXC_BATCH
-#define ARTIS_COLLEXC_BATCH 1
-#endif
-    constexpr int CB = ARTIS_COLLEXC_BATCH;
-    for (int base = startup; base < (startup + nup) && upper < 0; base += CB) {
-      int tmpupper[CB];
-      ColRead cr[CB];
-      double e_up[CB];
-      float g_up[CB];
+    const double *upcum = env.K.collexc_cum + ((int64_t)c * M.nupcum) + M.level_upcum_start[ul];
+    int first = nup;  // first transition whose running sum is greater than rnd_process
+    for (int base = 0; base < nup && first == nup; base += 8) {
 #pragma unroll
-      for (int k = 0; k < CB; k++) {
-        const int ati = (base + k < startup + nup) ? base + k : base;
-        tmpupper[k] = M.alltrans_targetlevelindex[ati];
-        cr[k] = col_exc_read(M, ati);
-      }
-#pragma unroll
-      for (int k = 0; k < CB; k++) {
-        e_up[k] = eps(M, start + tmpupper[k]);
-        g_up[k] = M.level_statweight[start + tmpupper[k]];
-      }
-#pragma unroll
-      for (int k = 0; k < CB; k++) {
-        if (upper < 0 && base + k < startup + nup) {
-          const double e_trans = e_up[k] - e_cur;
-          const double Cc = nnlevel * col_exc_from(cr[k], T_e, cnne, e_trans, g_up[k], g_cur) * e_trans;
-          contrib += Cc;
-          if (contrib > rnd_process) upper = tmpupper[k];
-        }
+      for (int k = 7; k >= 0; k--) {
+        const int j = base + k;
+        if (j < nup && upcum[j] > rnd_process) first = j;
       }
     }
-    if (!(contrib > rnd_process)) {
+    if (first == nup) {
       fail(env, 72);
       return;
     }
+    const int startup = M.level_alltrans_startdown[ul] + M.level_ndowntrans[ul];
+    const int upper = M.alltrans_targetlevelindex[startup + first];
     ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_COLLEXC);
     ARTIS_STAT(env, ARTIS_STAT_K_TO_MA_COLLEXC);
     env.P.trueemissiontype[pi] = ARTIS_EMTYPE_NOTSET;

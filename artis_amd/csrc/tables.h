@@ -73,6 +73,7 @@ struct DevModel {
   int32_t nelements, nions, nlevels, nlines, nalltrans, nphixstargets_total, nphixslevels, nbfcontinua, nbfcontinua_ground,
       ncoolingterms, nmatransblock, NPHIXSPOINTS;
   int32_t nmacache;    // doubles per cell in DevCache::macache
+  int32_t nupcum;      // doubles per cell in DevCache::collexc_cum (= number of upward transitions = nlines)
   int32_t nkeepwords;  // ceil(nbfcontinua/64) (get_allcont_keepwordcount globals.h:401) rounded up to a multiple of 4
   double NPHIXSNUINCREMENT;
   double last_phixs_nuovernuedge;  // input.cc:310
@@ -88,6 +89,7 @@ struct DevModel {
       *level_nphixstargets, *level_phixstargetstart, *level_bflist_start, *level_matransblock_start;
   const int32_t *level_ion;  // derived: uniqueionindex of each level
   const LevelPack *level_pack;  // derived
+  const int32_t *level_upcum_start;  // derived: offset of the level's upward transitions in DevCache::collexc_cum
   const TargetPack *target_pack;  // derived, [nalltrans]
   const int32_t *alltrans_lineindex, *alltrans_targetlevelindex;
   const float *alltrans_einstein_A, *alltrans_coll_str, *alltrans_osc_strength;
@@ -128,6 +130,7 @@ struct DevCache {
   double *allcont_departure;     // [cell][nbfcontinua]
   double *allcont_edgepart;      // [cell][nbfcontinua]
   uint64_t *allcont_keepbits;    // [cell][nkeepwords]
+  double *collexc_cum;           // [cell][nupcum]: running cooling sum after each upward transition of each level (kpkt.cc:461-476)
   double *corrphotoioncoeff;     // [cell][nphixstargets_total]
   double *cooling_contrib;       // [cell][ncoolingterms]
   double *ion_cooling_contribs;  // [cell][nions]
