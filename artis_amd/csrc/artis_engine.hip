@@ -44,6 +44,12 @@ __global__ void __launch_bounds__(BLOCK) k_levelpops(Env env) {
   if (i >= total) return;
   populate_levelpop(env, (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
+__global__ void __launch_bounds__(BLOCK) k_line_dpop(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nlines;
+  if (i >= total) return;
+  populate_line_dpop(env, (int)(i / env.M.nlines), (int)(i % env.M.nlines));
+}
 __global__ void __launch_bounds__(BLOCK) k_cell_scalars(Env env) {
   const int c = blockIdx.x * BLOCK + threadIdx.x;
   if (c >= env.M.npts_nonempty) return;
@@ -806,6 +812,7 @@ int artis_amd_populate_cellcache(artis_amd_engine *e, void *hip_stream) {
   const int64_t ncell = h.npts_nonempty;
   hipStream_t s = (hipStream_t)hip_stream;
   hipLaunchKernelGGL(k_levelpops, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
+  if (h.nlines > 0) hipLaunchKernelGGL(k_line_dpop, dim3(nblocks(ncell * h.nlines)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cell_scalars, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
   if (h.nbfcontinua > 0) hipLaunchKernelGGL(k_allcont, dim3(nblocks(ncell * h.nkeepwords * 64)), dim3(BLOCK), 0, s, env);
   if (h.nphixstargets_total > 0)

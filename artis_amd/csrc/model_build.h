@@ -105,10 +105,12 @@ struct ModelOwned {
   X(allcont_nnlevel, double, (m).nbfcontinua)                   \
   X(allcont_departure, double, (m).nbfcontinua)                 \
   X(allcont_edgepart, double, (m).nbfcontinua)                  \
+  X(allcont_pair, D2, (m).nbfcontinua)                          \
   X(allcont_keepbits, uint64_t, (m).nkeepwords)                 \
   X(corrphotoioncoeff, double, (m).nphixstargets_total)         \
   X(cooling_contrib, double, (m).ncoolingterms)                 \
   X(collexc_cum, double, (m).nupcum)                            \
+  X(line_dpop, double, (m).nlines)                              \
   X(ion_cooling_contribs, double, (m).nions)                    \
   X(ion_cooling_C, double, (m).nions)                           \
   X(chi_ff_nnionpart, double, 1)

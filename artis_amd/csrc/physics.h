@@ -47,7 +47,11 @@ constexpr int MA_N = ARTIS_MA_ACTION_COUNT;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned int stat_t;
 #define ARTIS_STAT_ADD(env, i, v) atomicAdd(&(env).stats[(i)], (stat_t)(v))
+#ifdef ARTIS_EXPERIMENT_NO_ESTIMATORS  // timing experiment only: results are wrong
+#define ARTIS_EST_ADD(ptr, v) ((void)(ptr), (void)(v))
+#else
 #define ARTIS_EST_ADD(ptr, v) unsafeAtomicAdd((ptr), (v))
+#endif
 #else
 typedef unsigned long long stat_t;
 #define ARTIS_STAT_ADD(env, i, v) ((env).stats[(i)] += (stat_t)(v))
@@ -729,6 +733,18 @@ AHD void populate_levelpop(const Env &env, int c, int ul) {
   if (nn < ARTIS_OPT_MINPOP) nn = (env.C.elem_massfracs[((int64_t)c * M.nelements) + element] > 0) ? ARTIS_OPT_MINPOP : 0.;
   env.K.levelpops[((int64_t)c * M.nlevels) + ul] = nn;
 }
+// one (cell, line): the level-population factor of get_tau_sobolev<true>() (rpkt.cc:75), evaluated once per timestep so
+// that the line walk reads one value per line instead of the line record and two level populations
+AHD void populate_line_dpop(const Env &env, int c, int li) {
+  const DevModel &M = env.M;
+  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  const LinePack lp = M.line_pack[li];
+  const double n_l = pops[lp.lower];
+  const double n_u = pops[lp.upper];
+  const double B_ul = lp.B_ul;
+  const double B_lu = lp.B_lu;
+  env.K.line_dpop[((int64_t)c * M.nlines) + li] = (B_lu * n_l) - (B_ul * n_u);
+}
 // one cell: calculate_chi_ffheat_nnionpart rpkt.cc:932
 AHD void populate_chi_ff(const Env &env, int c) {
   const DevModel &M = env.M;
@@ -773,6 +789,7 @@ AHD bool populate_allcont(const Env &env, int c, int i) {
   }
   env.K.allcont_departure[o] = dep;
   env.K.allcont_edgepart[o] = edge;
+  env.K.allcont_pair[o] = D2{nnlevel, edge};
   return keep;
 }
 // one (cell, phixs target): get_corrphotoioncoeff ratecoeff.cc:840 (USE_LUT_PHOTOION)
@@ -1107,8 +1124,7 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   const int cend = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
   const int cbegin = lower_bound_d(M.allcont_nu_edge, cend, nu / M.last_phixs_nuovernuedge);
   int nvisited = 0;
-  const double *nnl = env.K.allcont_nnlevel + ((int64_t)c * M.nbfcontinua);
-  const double *edgepart = env.K.allcont_edgepart + ((int64_t)c * M.nbfcontinua);
+  const D2 *pairs = env.K.allcont_pair + ((int64_t)c * M.nbfcontinua);  // {nnlevel, edgepart}
   const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
   KeepIter it;
   it.keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
@@ -1133,8 +1149,9 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
     for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
       const int i = (idx[k] >= 0) ? idx[k] : idx[0];
       cp[k] = M.cont_pack[i];
-      nn[k] = nnl[i];
-      ep[k] = edgepart[i];
+      const D2 pr = pairs[i];
+      nn[k] = pr.x;
+      ep[k] = pr.y;
     }
     PhixsRead xr[ARTIS_CHI_BATCH];
 #pragma unroll
@@ -1216,7 +1233,7 @@ AHD double linedistance(double prop_time, double nu_cmf, double nu_trans) {  // 
 AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAState &ma, double tau_rnd, double abort_dist,
                           double nu_cmf_abort, double dop, int *next_trans_out, bool *is_bb) {
   const DevModel &M = env.M;
-  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  const double *dpop = env.K.line_dpop + ((int64_t)c * M.nlines);
   double px = p.px, py = p.py, pz = p.pz;
   double nu_cmf = p.nu_cmf;
   double e_cmf = p.e_cmf;
@@ -1254,14 +1271,10 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
         result = DBLMAX;
         break;
       }
-      // get_tau_sobolev<true> rpkt.cc:75
-      const LinePack lp = M.line_pack[li];
-      const double n_l = pops[lp.lower];
-      const double n_u = pops[lp.upper];
-      const double B_ul = lp.B_ul;
-      const double B_lu = lp.B_lu;
-      const double tau_line = dmax(((B_lu * n_l) - (B_ul * n_u)) * HCLIGHTOVERFOURPI * prop_time, 0.);
+      // get_tau_sobolev<true> rpkt.cc:75 with the cell cache's (B_lu n_l - B_ul n_u)
+      const double tau_line = dmax(dpop[li] * HCLIGHTOVERFOURPI * prop_time, 0.);
       if ((tau_rnd - tau) <= (tau_cont + tau_line)) {
+        const LinePack lp = M.line_pack[li];
         const int element = M.line_elementindex[li];
         const int ion = M.line_ionindex[li];
         ma.element = element;
@@ -1603,9 +1616,6 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
 #ifndef ARTIS_MA_SEARCH
 #define ARTIS_MA_SEARCH 1
 #endif
-struct alignas(16) D2 {
-  double x, y;
-};
 AHD int ma_search(const double *a, int n, double v) {
 #if ARTIS_MA_SEARCH == 0
   if (n <= 0) return 0;

@@ -69,6 +69,10 @@ constexpr int marec_rad(int ndown, int nup) { return marec_up(ndown) + marec_eve
 constexpr int marec_size(int ndown, int nup) { return marec_rad(ndown, nup) + marec_even(ndown); }
 constexpr int MAREC_ALIGN = 16;  // doubles
 
+struct alignas(16) D2 {
+  double x, y;
+};
+
 struct DevModel {
   int32_t nelements, nions, nlevels, nlines, nalltrans, nphixstargets_total, nphixslevels, nbfcontinua, nbfcontinua_ground,
       ncoolingterms, nmatransblock, NPHIXSPOINTS;
@@ -129,7 +133,9 @@ struct DevCache {
   double *allcont_nnlevel;       // [cell][nbfcontinua]
   double *allcont_departure;     // [cell][nbfcontinua]
   double *allcont_edgepart;      // [cell][nbfcontinua]
+  D2 *allcont_pair;              // [cell][nbfcontinua] {nnlevel, edgepart} as one 16-byte read for calculate_chi_bf_gammacontr
   uint64_t *allcont_keepbits;    // [cell][nkeepwords]
+  double *line_dpop;             // [cell][nlines]: B_lu n_l - B_ul n_u of every line, the population factor of get_tau_sobolev() (rpkt.cc:75)
   double *collexc_cum;           // [cell][nupcum]: running cooling sum after each upward transition of each level (kpkt.cc:461-476)
   double *corrphotoioncoeff;     // [cell][nphixstargets_total]
   double *cooling_contrib;       // [cell][ncoolingterms]

@@ -53,12 +53,13 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   e.env.errflag = &e.err;
 }
 
-// the populate kernels, in launch order (artis_engine.hip: k_levelpops, k_cell_scalars, k_allcont, k_corrphotoion,
+// the populate kernels, in launch order (artis_engine.hip: k_levelpops, k_line_dpop, k_cell_scalars, k_allcont, k_corrphotoion,
 // k_macroatom, k_cooling_ion, k_cooling_prefix)
 void populate_all(Emu &e) {
   const DevModel &M = e.env.M;
   for (int c = 0; c < M.npts_nonempty; c++) {
     for (int ul = 0; ul < M.nlevels; ul++) populate_levelpop(e.env, c, ul);
+    for (int li = 0; li < M.nlines; li++) populate_line_dpop(e.env, c, li);
     populate_chi_ff(e.env, c);
     uint64_t *kb = e.env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
     for (int w = 0; w < M.nkeepwords; w++) kb[w] = 0;
