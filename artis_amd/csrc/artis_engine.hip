@@ -434,6 +434,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
         exit_action = ma_jump_internal(env, p, k, k.cellma + k.lp.rec_off, ma_targets(env, k), &exit_rate);
         j++;
       }
+      ma_flush_stats(env, k);
       if (exit_action >= 0) ma_jump_exit(env, p, pi, k, k.cellma + k.lp.rec_off, ma_targets(env, k), exit_action, exit_rate);
       if (j > 0) chi_after_ma(env, p, pi);
       units += j;

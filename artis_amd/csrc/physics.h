@@ -1598,6 +1598,7 @@ struct MACtx {
   int start_key, start;     // cached get_ionuniquelevelindexstart(element, ion)
   int lp_key, lp_level;     // (element, ion), level that `lp` belongs to
   LevelPack lp;
+  int njumps;               // transitions made since the last ma_flush_stats()
 };
 AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   MACtx k;
@@ -1608,6 +1609,7 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   k.lp_key = -1;
   k.lp_level = -1;
   k.lp = LevelPack{0, 0, 0, 0};
+  k.njumps = 0;
   return k;
 }
 
@@ -1694,7 +1696,6 @@ AHD void ma_set_level(Pkt &p, MACtx &, int32_t level) { p.ma_level = level; }
 constexpr int MA_EXIT_FAILED = 99;
 AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rates, const ma_target_t *targets, double *rate_out) {
   const LevelPack lp = k.lp;
-  ARTIS_STAT(env, ARTIS_STAT_X_MA_JUMPS);
   // std::partial_sum macroatom.cc:425 and index_upperbound sn3d.h:85 over the 9 cumulative rates, kept in
   // registers (statically indexed): action = number of cumulative values <= randomrate, clamped to the last one
   double r[MA_N];
@@ -1708,6 +1709,7 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rates, 
   if (!(total > 0.)) {
     fail(env, 40);
     p.ma_level = -1;
+    ARTIS_STAT(env, ARTIS_STAT_X_MA_JUMPS);
     return MA_EXIT_FAILED;
   }
   const double randomrate = rng_uniform(p) * total;
@@ -1718,22 +1720,17 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rates, 
   double rate_sel = r[0];  // rates[action] without dynamic indexing
 #pragma unroll
   for (int i = 1; i < MA_N; i++) rate_sel = (action == i) ? r[i] : rate_sel;
-  ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
-  if (action == ARTIS_MA_ACTION_INTERNALDOWNSAME) {
-    const double targetval = rng_uniform(p) * rate_sel;
+  k.njumps++;  // stats::increment(INTERACTIONS) macroatom.cc:430 and the engine's transition counter: ma_flush_stats()
+  const bool down = (action == ARTIS_MA_ACTION_INTERNALDOWNSAME);
+  if (down || action == ARTIS_MA_ACTION_INTERNALUPSAME) {
+    // macroatom.cc:433-447 and 536-550: one search for both directions, so that a wave runs it once
     const int ndown = lp.ndown;
-    const double *sums = rates + marec_down;
-    const int dti = ma_search(sums, ndown - 1, targetval);
-    ma_set_level(p, k, targets[dti]);
-    return -1;
-  }
-  if (action == ARTIS_MA_ACTION_INTERNALUPSAME) {
-    const int ndown = lp.ndown;
-    const int nup = lp.nup;
-    const double *sums = rates + marec_up(ndown);
+    const int nsel = down ? ndown : lp.nup;
+    const int first = down ? 0 : ndown;                       // first target of the direction
+    const double *sums = rates + (down ? marec_down : marec_up(ndown));
     const double targetval = rng_uniform(p) * rate_sel;
-    const int uti = ma_search(sums, nup - 1, targetval);
-    ma_set_level(p, k, targets[ndown + uti]);
+    const int ti = ma_search(sums, nsel - 1, targetval);
+    ma_set_level(p, k, targets[first + ti]);
     return -1;
   }
   *rate_out = rate_sel;
@@ -1797,6 +1794,13 @@ AHD const ma_target_t *ma_targets(const Env &env, const MACtx &k) {
   return env.M.alltrans_targetlevelindex + k.lp.alltrans_startdown;
 #endif
 }
+AHD void ma_flush_stats(const Env &env, MACtx &k) {
+  if (k.njumps != 0) {
+    ARTIS_STAT_ADD(env, ARTIS_STAT_X_MA_JUMPS, k.njumps);
+    ARTIS_STAT_ADD(env, ARTIS_STAT_INTERACTIONS, k.njumps);
+    k.njumps = 0;
+  }
+}
 AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
   ma_prepare(env, p, k);
   const double *rates = k.cellma + k.lp.rec_off;
@@ -1804,6 +1808,7 @@ AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
   double rate_sel = 0.;
   const int action = ma_jump_internal(env, p, k, rates, targets, &rate_sel);
   if (action >= 0) ma_jump_exit(env, p, pi, k, rates, targets, action, rate_sel);
+  ma_flush_stats(env, k);
 }
 
 // the bound-free transitions of do_macroatom(): macroatom.cc:481-488, 501-533, 552-560
@@ -2317,7 +2322,7 @@ AHD int advance_ma(const Env &env, Pkt &p, int64_t pi, int budget) {
 // k-packet step for every lane whose macro-atom has deactivated. The phases make the lanes of a wave run the same code
 // at the same time; they only order the work of different packets.
 #ifndef ARTIS_MA_PHASE
-#define ARTIS_MA_PHASE 64
+#define ARTIS_MA_PHASE 24  // measured optimum on MI355X (12..64 tried): short enough to keep the lanes busy, long enough to amortise the k-packet phase
 #endif
 AHD bool kpkt_eligible(const Pkt &p, double ts_end);
 AHD bool thermal_can_continue(const Pkt &p, double ts_end) {
