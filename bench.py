@@ -32,14 +32,14 @@ sys.path.insert(0, ROOT)
 
 from artis_amd import abi, synth  # noqa: E402
 
-# Algorithmic bytes per unit of work of k_propagate (DESIGN.md "Kernels and rooflines"):
-B_PER_THREAD_LAUNCH = 272.0   # hot packet state loaded + stored once per thread per launch (2 x 136 B)
-B_PER_LINE = 40.0             # line nu (8) + LinePack (16) + two level populations (16)
-B_PER_MA_JUMP = 144.0         # 9 process rates (72) + ~9 probes of a cumulative block (72)
-B_PER_RPKT_STEP = 120.0       # cell scalars (~40) + J, nuJ, ffheating atomics (24) + boundary tables (~56)
-B_PER_KPKT_STEP = 160.0       # ion cumulative cooling probes + per-ion list probes
-B_PER_CONT = 56.0             # one bound-free continuum of the opacity sum: nnlevel, nu_edge, edge part, probability,
-                              # cross-section entry, level index, estimator index
+# Algorithmic bytes per unit of work ("Algorithmic bytes per unit"): what the kernels read and write
+# by design for one unit, wherever the cache hierarchy then serves it from.
+B_PER_THREAD_LAUNCH = 272.0   # packet state loaded + stored once per packet per launch (2 x 136 B)
+B_PER_MA_JUMP = 140.0         # LevelPack 16 + 9 process rates 72 + ~6 cumulative sums 48 + target level 4
+B_PER_KPKT_STEP = 200.0       # ~6 ion sums 48 + ~7 cooling-list sums 56 + ~6 collisional-excitation sums 48 + indices/flags 48
+B_PER_RPKT_STEP = 120.0       # cell scalars ~40 + boundary tables ~56 + J, nuJ, ffheating atomics 24
+B_PER_LINE = 16.0             # line frequency 8 + the cell's population factor of the line 8
+B_PER_CONT = 52.0             # ContPack 32 + {nnlevel, edge part} 16 + cross-section entry 4
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -200,7 +200,17 @@ def main():
         launches_per_step = bd["thermal_launches"] if dominant == "k_thermal" else bd["rpkt_launches"]
         achieved = alg_bytes / (k_ms_per_step * 1e-3) / 1e9 if k_ms_per_step > 0 else 0.0
         both = (alg_thermal + alg_rpkt) / ((bd["thermal_ms"] + bd["rpkt_ms"]) * 1e-3) / 1e9
-        traffic = os.environ.get("ARTIS_BENCH_TRAFFIC_BYTES")
+        # HBM traffic of the dominant kernel per launch: from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/<round>/pmc_traffic.json, written by tools_pmc_summary.py; FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950). None when the workload is not the profiled one.
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+        if os.path.exists(tfile) and args.packets == 10_000_000 and args.ncoord == 50 and args.preset == "w7" and world == 1:
+            with open(tfile) as f:
+                tj = json.load(f)
+            if dominant in tj:
+                traffic = tj[dominant]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/r01/pmc_traffic.json"
         out = {
             "metric": "packet-steps/sec", "value": value, "unit": "packet-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -214,10 +224,11 @@ def main():
                        "parallelism": f"packets sharded over {world} GPU(s); estimator all-reduce over RCCL" if world > 1
                        else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": float(traffic) if traffic else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": dominant, "launches_per_step": launches_per_step,
                          "kernel_ms_per_step": k_ms_per_step, "avg_launch_ms": k_ms_per_step / max(launches_per_step, 1),
                          "algorithmic_bytes_per_step": float(alg_bytes),
+                         "algorithmic_bytes_per_launch": float(alg_bytes) / max(launches_per_step, 1),
                          "achieved_both_propagation_kernels": both},
         }
         out["kernel_breakdown_last_step"] = bd

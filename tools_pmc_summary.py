@@ -28,3 +28,16 @@ for k, v in sorted(agg.items()):
         print(f"   -> L2 hit rate                     {v['TCC_HIT_sum'] / (v['TCC_HIT_sum'] + v['TCC_MISS_sum']):.3f}")
     if "FETCH_SIZE" in v and dur[k]:
         print(f"   -> FETCH_SIZE KB/s (x2 per guide)  {v['FETCH_SIZE'] / dur[k]:.4g}  WRITE_SIZE KB/s {v.get('WRITE_SIZE', 0) / dur[k]:.4g}")
+
+# per-launch HBM traffic of the propagation kernels for bench.py's roofline.traffic (FETCH_SIZE and WRITE_SIZE are in KB;
+# FETCH_SIZE is doubled on gfx950, MI355X_MICROARCH.md "HBM")
+import json, os
+out = {}
+for k, v in agg.items():
+    if k in ("k_thermal", "k_rpkt") and "FETCH_SIZE" in v and "WRITE_SIZE" in v and ndisp[k]:
+        out[k] = {"fetch_size_kb": v["FETCH_SIZE"], "write_size_kb": v["WRITE_SIZE"], "dispatches": ndisp[k],
+                  "hbm_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / ndisp[k]}
+if out and os.environ.get("PMC_TRAFFIC_JSON"):
+    with open(os.environ["PMC_TRAFFIC_JSON"], "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", os.environ["PMC_TRAFFIC_JSON"])
