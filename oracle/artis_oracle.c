@@ -26,7 +26,14 @@
  *  (4) The cell cache is the multi-slot form (cellcache_singleslot == false,
  *      constants.h:84-88): all rates pre-calculated (update_packets.cc:442-458).
  *
- * Parity pinning: see oracle/README.md and tests/test_oracle_reference_props.py.
+ * Parity pinning (tests/test_oracle_reference_props.py): PARTIAL.
+ *  - pinned bit for bit against reference code compiled where it lies (oracle/Makefile target `ref`, binaries in
+ *    oracle/_ref/): random.h (generator streams and rng_uniform, tests/golden/rng_reference.json) and gausskronrod.h
+ *    (the adaptive integrator behind select_continuum_nu, tests/golden/gk31_reference.json);
+ *  - pinned against the known answers and properties of the reference's unittests.cc for the pieces of this path
+ *    (vector/Doppler/frame transforms, move_pkt_withtime, closest_transition, line distance, rate-coefficient helpers);
+ *  - the transport loop as a whole is UNPINNED: the reference binary cannot be built in this image (it needs <print>
+ *    and <mdspan>, MPI and a downloaded atomic data set), so no end-to-end output of it exists to compare with.
  */
 #include <math.h>
 #include <stdint.h>
@@ -1369,9 +1376,20 @@ typedef struct {
   const float *xs;
   double nu_edge;
   float T_e;
+  int testmode;   /* != 0: one of the analytic integrands of artis_oracle_gk31_test() (pins the integrator only) */
+  double p0, p1;
 } FbIntegrand;
+
+/* Analytic integrands used only to pin this file's Gauss-Kronrod restatement against the reference's own
+ * gausskronrod.h (oracle/ref_harness/ref_gk31_main.cc holds the same three formulas). */
+static double gk31_test_integrand(int mode, double p0, double p1, double x) {
+  if (mode == 1) return exp(-p0 * x) * (1. + floor(x * p1)); /* steps: deep recursion */
+  if (mode == 2) return x * x * exp(-p0 * x) / (1. + (p1 * x * x * x));
+  return sqrt(fabs(x - p0)) + p1; /* kink */
+}
 /* alpha_sp_E_integrand ratecoeff.cc:84 */
 static double alpha_sp_E_integrand(const FbIntegrand *f, double nu_minus_nu_edge) {
+  if (f->testmode != 0) return gk31_test_integrand(f->testmode, f->p0, f->p1, nu_minus_nu_edge);
   const double nu = f->nu_edge + nu_minus_nu_edge;
   const float sigma_bf = photoionisation_crosssection_fromtable(f->o, f->xs, f->nu_edge, nu);
   return (2 / CLIGHTSQUARED) * sigma_bf * pow3(nu) / f->nu_edge * exp(-HOVERKB * nu_minus_nu_edge / f->T_e);
@@ -1424,6 +1442,15 @@ static double integrator31(const FbIntegrand *f, double a, double b, double epsr
   return gk31_recursive(f, epsrel, a, b, 15, 0., abserr);
 }
 
+/* gauss_kronrod_integrate<31>(f, a, b, 15, tol, &error) of this restatement on an analytic integrand */
+double artis_oracle_gk31_test(int mode, double p0, double p1, double a, double b, double tol, double *error) {
+  FbIntegrand f = {NULL, NULL, 0., 0.f, mode, p0, p1};
+  double err = 0.;
+  const double r = integrator31(&f, a, b, tol, &err);
+  if (error) *error = err;
+  return r;
+}
+
 /* select_continuum_nu ratecoeff.cc:563 */
 static double select_continuum_nu(Oracle *o, int element, int lowerion, int lower, int t, float T_e, uint32_t rng[4]) {
   const int ul = ionlevelstart(o, element, lowerion) + lower;
@@ -1431,7 +1458,7 @@ static double select_continuum_nu(Oracle *o, int element, int lowerion, int lowe
   const double nu_threshold = (1. / H_PLANCK) * E_threshold;
   const double nu_max_phixs = nu_threshold * o->last_phixs_nuovernuedge;
   const int npieces = o->m->NPHIXSPOINTS;
-  FbIntegrand f = {o, get_phixs_table(o, ul), nu_threshold, T_e};
+  FbIntegrand f = {o, get_phixs_table(o, ul), nu_threshold, T_e, 0, 0., 0.};
   const double zrand = 1. - rng_uniform(rng);
   const double nu_range = nu_max_phixs - nu_threshold;
   const double deltanu = nu_range / npieces;

@@ -231,3 +231,25 @@ def test_planck_matches_closed_form(oracle):
     for nu, T in [(1e14, 5000.0), (8e14, 12000.0), (4e15, 3500.0)]:
         want = 2 * H * nu**3 / CLIGHT**2 / math.expm1(H / 1.38064852e-16 * nu / T)
         assert abs(L.artis_oracle_planck(nu, T) - want) <= 1e-14 * want
+
+
+def test_gauss_kronrod_matches_reference_golden(oracle):
+    """The oracle's restatement of gauss_kronrod_integrate<31> (gausskronrod.h:244: Boost tables, summation order,
+    adaptive bisection with inherited tolerances) against results of the reference's own header, bit for bit.
+    Golden file: tests/golden/gk31_reference.json (tests/golden/make_gk31_golden.py)."""
+    import ctypes as C
+    L = oracle.lib()
+    L.artis_oracle_gk31_test.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    L.artis_oracle_gk31_test.restype = C.c_double
+    with open(os.path.join(os.path.dirname(__file__), "golden", "gk31_reference.json")) as f:
+        gold = json.load(f)
+    assert len(gold["cases"]) >= 20
+    ndeep = 0
+    for case in gold["cases"]:
+        err = C.c_double(0.)
+        res = L.artis_oracle_gk31_test(case["mode"], case["p0"], case["p1"], case["a"], case["b"], case["tol"], C.byref(err))
+        assert float(res).hex() == float.fromhex(case["result"]).hex(), case
+        if case["a"] != case["b"]:
+            assert float(err.value).hex() == float.fromhex(case["error"]).hex(), case
+        ndeep += 1
+    assert ndeep == len(gold["cases"])
