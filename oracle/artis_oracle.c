@@ -28,8 +28,9 @@
  *
  * Parity pinning (tests/test_oracle_reference_props.py): PARTIAL.
  *  - pinned bit for bit against reference code compiled where it lies (oracle/Makefile target `ref`, binaries in
- *    oracle/_ref/): random.h (generator streams and rng_uniform, tests/golden/rng_reference.json) and gausskronrod.h
- *    (the adaptive integrator behind select_continuum_nu, tests/golden/gk31_reference.json);
+ *    oracle/_ref/): random.h (generator streams and rng_uniform, tests/golden/rng_reference.json), gausskronrod.h
+ *    (the adaptive integrator behind select_continuum_nu, tests/golden/gk31_reference.json) and macroatom.h
+ *    (rad_deexcitation_ratecoeff, tests/golden/macroatom_reference.json);
  *  - pinned against the known answers and properties of the reference's unittests.cc for the pieces of this path
  *    (vector/Doppler/frame transforms, move_pkt_withtime, closest_transition, line distance, rate-coefficient helpers);
  *  - the transport loop as a whole is UNPINNED: the reference binary cannot be built in this image (it needs <print>

@@ -59,3 +59,38 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle_py" not in txt and "libartis_oracle" not in txt and "hostemu" not in txt.replace(
                     "host-emulation", "").replace("tests/hostemu", ""), f
+
+
+def test_packet_struct_matches_reference_layout():
+    """artis_packet (include/artis_amd.h, mirrored by abi.PACKET_DTYPE) against offsetof/sizeof of the reference's own
+    struct Packet compiled with -DGPU_ON (tests/golden/packet_layout_reference.json, made by
+    tests/golden/make_packet_layout_golden.py from /root/reference/packet.h): a reference build can hand its
+    std::span<Packet> to artis_amd_update_packets() as it is."""
+    import json
+    from artis_amd import abi
+    with open(os.path.join(os.path.dirname(__file__), "golden", "packet_layout_reference.json")) as f:
+        gold = json.load(f)
+    dt = abi.PACKET_DTYPE
+    assert dt.itemsize == gold["sizeof"] == 256
+    assert set(dt.names) == set(gold["fields"])
+    for name, ref in gold["fields"].items():
+        field_dtype, offset = dt.fields[name][:2]
+        assert offset == ref["offset"], name
+        assert field_dtype.itemsize == ref["size"], name
+    # the C header itself (not only the numpy mirror): compile-time layout of struct artis_packet
+    import subprocess, tempfile
+    fields = list(gold["fields"])
+    src = '#include <stddef.h>\n#include <stdio.h>\n#include "artis_amd.h"\nint main(void){' + "".join(
+        f'printf("{n} %zu\\n", offsetof(artis_packet, {n}));' for n in fields) + 'printf("sizeof %zu\\n", sizeof(artis_packet));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "t.c"), "w") as f:
+            f.write(src)
+        inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+        subprocess.check_call(["gcc", "-I", inc, "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        got = dict(line.split() for line in subprocess.check_output([os.path.join(d, "t")], text=True).strip().splitlines())
+    assert int(got["sizeof"]) == gold["sizeof"]
+    for name, ref in gold["fields"].items():
+        assert int(got[name]) == ref["offset"], name
+    e = gold["enums"]
+    assert (abi.TYPE_RPKT, abi.TYPE_KPKT, abi.TYPE_PRE_KPKT, abi.TYPE_ESCAPE) == (e["TYPE_RPKT"], e["TYPE_KPKT"], e["TYPE_PRE_KPKT"], e["TYPE_ESCAPE"])
+    assert (abi.EMTYPE_NOTSET, abi.EMTYPE_FREEFREE) == (e["EMTYPE_NOTSET"], e["EMTYPE_FREEFREE"])

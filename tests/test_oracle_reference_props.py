@@ -253,3 +253,20 @@ def test_gauss_kronrod_matches_reference_golden(oracle):
             assert float(err.value).hex() == float.fromhex(case["error"]).hex(), case
         ndeep += 1
     assert ndeep == len(gold["cases"])
+
+
+def test_rad_deexcitation_matches_reference_golden(oracle):
+    """rad_deexcitation_ratecoeff() of the oracle against the reference's macroatom.h:61 compiled in place, bit for bit
+    (tests/golden/macroatom_reference.json, tests/golden/make_macroatom_golden.py)."""
+    L = oracle.lib()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "macroatom_reference.json")) as f:
+        gold = json.load(f)
+    assert len(gold["cases"]) >= 200
+    kinds = set()
+    for c in gold["cases"]:
+        got = L.artis_oracle_rad_deexcitation_ratecoeff(c["epsilon_trans"], c["A_ul"], c["g_upper"], c["g_lower"], c["nn_upper"],
+                                                        c["nn_lower"], c["t_current"])
+        want = float.fromhex(c["result"])
+        assert float(got).hex() == want.hex(), c
+        kinds.add("thin" if want == float(np.float32(c["A_ul"])) else "escape")
+    assert kinds == {"thin", "escape"}
