@@ -25,6 +25,7 @@ EMTYPE_NOTSET = -9999000
 EMTYPE_FREEFREE = -9999999
 
 GRID_SPHERICAL1D = 0
+GRID_CYLINDRICAL2D = 1
 GRID_CARTESIAN3D = 2
 
 STAT_NAMES = [

@@ -651,8 +651,9 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
     g_last_error = "null argument";
     return ARTIS_ERR_ARG;
   }
-  if (model->gridtype != ARTIS_GRID_CARTESIAN3D && model->gridtype != ARTIS_GRID_SPHERICAL1D) {
-    g_last_error = "grid type not supported (CARTESIAN3D and SPHERICAL1D are)";
+  if (model->gridtype != ARTIS_GRID_CARTESIAN3D && model->gridtype != ARTIS_GRID_SPHERICAL1D &&
+      model->gridtype != ARTIS_GRID_CYLINDRICAL2D) {
+    g_last_error = "unknown grid type";
     return ARTIS_ERR_UNSUPPORTED;
   }
   // the per-packet list of ground-continuum contributions (physics.h chi_bf_gammacontr) relies on the order the
@@ -695,7 +696,8 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   ARTIS_MODEL_ARRAYS(UP, h)
 #undef UP
   for (int a = 0; a < 3; a++) {
-    const int64_t cnt = (h.gridtype == ARTIS_GRID_SPHERICAL1D && a > 0) ? 1 : h.ncoordgrid[a];
+    const int ndim = (h.gridtype == ARTIS_GRID_SPHERICAL1D) ? 1 : ((h.gridtype == ARTIS_GRID_CYLINDRICAL2D) ? 2 : 3);  // get_ndim grid.cc:120
+    const int64_t cnt = (a >= ndim) ? 1 : h.ncoordgrid[a];
     int rc = upload_array<double>(e->model_allocs, h.coord_pos_min_tmin[a], cnt, &e->M.coord_pos_min_tmin[a]);
     if (rc != ARTIS_OK) return rc;
   }

@@ -545,6 +545,71 @@ AHD double boundary_distance(const Env &env, const Pkt &p, int *next_cell) {
         next = (idx == 0) ? -99 : cellindex - M.coordstride[0];
       }
     }
+  } else if (M.gridtype == ARTIS_GRID_CYLINDRICAL2D) {
+    // grid.cc:2602-2695: coordinate 0 is the cylindrical radius, coordinate 1 is z. The reference's 2-vectors are
+    // passed as 3-vectors with a zero third component, which changes no sum of shell_intersection().
+    const double posnoz[3] = {pos[0], pos[1], 0.};
+    const double rc = sqrt(pow2(pos[0]) + pow2(pos[1]));                                    // grid.cc:1377
+    const double vrc = ((pos[0] * dir[0]) + (pos[1] * dir[1])) / rc * CLIGHT_PROP;          // grid.cc:1394
+    const int idx0 = coordidx(M, cellindex, 0);
+    const double cmin0 = coordmin(M, cellindex, 0);
+    const double cmax0 = coordmax(M, cellindex, 0);
+    const double dirxylen = sqrt(pow2(dir[0]) + pow2(dir[1]));
+    const double xyspeed = dirxylen * CLIGHT_PROP;
+    if (dirxylen > 0.) {
+      const double dirnoz[3] = {dir[0] / dirxylen, dir[1] / dirxylen, 0.};
+      const double r_outer = cmax0 * tstart / M.tmin;
+      const double d_rcyl_max =
+          overshoot_in_tol(M, true, rc, vrc, cmax0, tstart) ? 0. : shell_intersection(false, posnoz, dirnoz, xyspeed, r_outer, tstart);
+      if (d_rcyl_max >= 0.) {
+        const double d_z = d_rcyl_max / xyspeed * dir[2] * CLIGHT_PROP;
+        const double dd = sqrt(pow2(d_rcyl_max) + pow2(d_z));
+        if ((dd >= 0.) && (dd < distance)) {
+          distance = dd;
+          next = (idx0 == (M.ncoordgrid[0] - 1)) ? -99 : cellindex + M.coordstride[0];
+        }
+      }
+      const double r_inner = cmin0 * tstart / M.tmin;
+      if (r_inner > 0) {
+        const double d_rcyl_min =
+            overshoot_in_tol(M, false, rc, vrc, cmin0, tstart) ? 0. : shell_intersection(true, posnoz, dirnoz, xyspeed, r_inner, tstart);
+        if (d_rcyl_min >= 0.) {
+          const double d_z = d_rcyl_min / xyspeed * dir[2] * CLIGHT_PROP;
+          const double dd = sqrt(pow2(d_rcyl_min) + pow2(d_z));
+          if ((dd >= 0.) && (dd < distance)) {
+            distance = dd;
+            next = (idx0 == 0) ? -99 : cellindex - M.coordstride[0];
+          }
+        }
+      }
+    } else if (cmin0 > 0.) {
+      // moving exactly along z: only the expanding inner r_cyl boundary can catch up with the packet (grid.cc:2654)
+      const double dd = overshoot_in_tol(M, false, rc, vrc, cmin0, tstart) ? 0. : ((rc * M.tmin / cmin0) - tstart) * CLIGHT_PROP;
+      if ((dd >= 0.) && (dd < distance)) {
+        distance = dd;
+        next = (idx0 == 0) ? -99 : cellindex - M.coordstride[0];
+      }
+    }
+    {  // z boundaries are Cartesian (grid.cc:2671)
+      const int d = 1;
+      const double vel = dir[2] * CLIGHT_PROP;
+      const int idx = coordidx(M, cellindex, d);
+      const double cmin = coordmin(M, cellindex, d);
+      const double cmax = coordmax(M, cellindex, d);
+      if (vel > (cmax / M.tmin)) {
+        const double dd = overshoot_in_tol(M, true, pos[2], vel, cmax, tstart) ? 0. : dist_cart_boundary(M, pos[2], vel, cmax, tstart);
+        if ((dd >= 0.) && (dd < distance)) {
+          distance = dd;
+          next = (idx == (M.ncoordgrid[d] - 1)) ? -99 : cellindex + M.coordstride[d];
+        }
+      } else if (vel < (cmin / M.tmin)) {
+        const double dd = overshoot_in_tol(M, false, pos[2], vel, cmin, tstart) ? 0. : dist_cart_boundary(M, pos[2], vel, cmin, tstart);
+        if ((dd >= 0.) && (dd < distance)) {
+          distance = dd;
+          next = (idx == 0) ? -99 : cellindex - M.coordstride[d];
+        }
+      }
+    }
   } else {
     fail(env, 10);
   }

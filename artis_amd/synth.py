@@ -397,6 +397,23 @@ def make_grid_and_cells(atomic: dict, ncoord: int = 8, gridtype: int = abi.GRID_
         ncoordgrid = [n, n, n]
         coord = [cmin, cmin, cmin]
         cellvol_tmin = np.full(ngrid, (2 * rmax / n) ** 3)
+    elif gridtype == abi.GRID_CYLINDRICAL2D:
+        # setup_grid_cylindrical_2d grid.cc:1290: ncoord cells in r_cyl over [0, rmax], 2*ncoord cells in z over [-rmax, rmax]
+        nr, nz = ncoord, 2 * ncoord
+        rmin = np.array([i * rmax / nr for i in range(nr)])
+        zmin = np.array([rmax * (-1 + (i * 2.0 / nz)) for i in range(nz)])
+        rout = np.concatenate([rmin[1:], [rmax]])
+        zout = np.concatenate([zmin[1:], [rmax]])
+        iz, ir = np.meshgrid(np.arange(nz), np.arange(nr), indexing="ij")  # cellindex = ir + nr*iz
+        ir, iz = ir.ravel(), iz.ravel()
+        vrc = 0.5 * (rmin[ir] + rout[ir]) / tmin
+        vz = 0.5 * (zmin[iz] + zout[iz]) / tmin
+        vr = np.sqrt(vrc**2 + vz**2)
+        ngrid = nr * nz
+        nonempty_mask = vr < vmax
+        ncoordgrid = [nr, nz, 1]
+        coord = [rmin, zmin, np.zeros(1)]
+        cellvol_tmin = np.pi * (rout[ir] ** 2 - rmin[ir] ** 2) * (zout[iz] - zmin[iz])
     else:
         n = ncoord
         vout = vmax * (np.arange(1, n + 1) / n)
@@ -508,6 +525,16 @@ def make_packets(model: abi.Model, aux: dict, npackets: int, seed_base: int = 12
         iy = (cellindex // n) % n
         iz = cellindex // (n * n)
         pos = np.stack([cmin[ix] + u[:, 0] * dx, cmin[iy] + u[:, 1] * dx, cmin[iz] + u[:, 2] * dx], axis=1) * (t / tmin)
+    elif d["gridtype"] == abi.GRID_CYLINDRICAL2D:
+        nr = int(d["ncoordgrid"][0])
+        rmin, zmin = d["coord_pos_min_tmin"][0], d["coord_pos_min_tmin"][1]
+        rout = np.concatenate([rmin[1:], [d["rmax"]]])
+        zout = np.concatenate([zmin[1:], [d["rmax"]]])
+        ir, iz = cellindex % nr, cellindex // nr
+        rc = np.sqrt(rmin[ir] ** 2 + u[:, 0] * (rout[ir] ** 2 - rmin[ir] ** 2)) * (t / tmin)
+        phi = 2 * np.pi * u[:, 1]
+        z = (zmin[iz] + u[:, 2] * (zout[iz] - zmin[iz])) * (t / tmin)
+        pos = np.stack([rc * np.cos(phi), rc * np.sin(phi), z], axis=1)
     else:
         n = int(d["ncoordgrid"][0])
         cmin = d["coord_pos_min_tmin"][0]

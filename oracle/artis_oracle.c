@@ -563,6 +563,82 @@ static double boundary_distance(Oracle *o, const double dir[3], const double pos
         }
       }
     }
+  } else if (m->gridtype == ARTIS_GRID_CYLINDRICAL2D) {
+    /* grid.cc:2602-2695: coordinate 0 is the cylindrical radius, coordinate 1 is z */
+    const double posnoz[3] = {pos[0], pos[1], 0.}; /* the reference's 2-vectors; a zero third component changes no sum */
+    const double pktpos0 = sqrt(pow2(pos[0]) + pow2(pos[1]));                                   /* grid.cc:1377 */
+    const double pktvel0 = ((pos[0] * dir[0]) + (pos[1] * dir[1])) / pktpos0 * CLIGHT_PROP;     /* grid.cc:1394 */
+    const double pktpos1 = pos[2];
+    const double pktvel1 = dir[2] * CLIGHT_PROP;
+    const int idx0 = cellcoordindex(o, cellindex, 0);
+    const double cmin0 = cellcoordmin(o, cellindex, 0);
+    const double cmax0 = cellcoordmax(o, cellindex, 0);
+    const double dirxylen = sqrt(pow2(dir[0]) + pow2(dir[1]));
+    const double xyspeed = dirxylen * CLIGHT_PROP;
+    if (dirxylen > 0.) {
+      const double dirnoz[3] = {dir[0] / dirxylen, dir[1] / dirxylen, 0.};
+      const double r_outer = cmax0 * tstart / tmin;
+      const double d_rcyl_max = overshoot_within_tol(o, 1, pktpos0, pktvel0, cmax0, tstart)
+                                    ? 0.
+                                    : expanding_shell_intersection(0, posnoz, dirnoz, xyspeed, r_outer, tstart);
+      if (d_rcyl_max >= 0.) {
+        const double d_z = d_rcyl_max / xyspeed * dir[2] * CLIGHT_PROP;
+        const double dd = sqrt(pow2(d_rcyl_max) + pow2(d_z));
+        if ((dd >= 0.) && (dd < distance)) {
+          distance = dd;
+          next_cellindex = (idx0 == (m->ncoordgrid[0] - 1)) ? -99 : cellindex + coordstride(o, 0);
+        }
+      }
+      const double r_inner = cmin0 * tstart / tmin;
+      if (r_inner > 0) {
+        const double d_rcyl_min = overshoot_within_tol(o, 0, pktpos0, pktvel0, cmin0, tstart)
+                                      ? 0.
+                                      : expanding_shell_intersection(1, posnoz, dirnoz, xyspeed, r_inner, tstart);
+        if (d_rcyl_min >= 0.) {
+          const double d_z = d_rcyl_min / xyspeed * dir[2] * CLIGHT_PROP;
+          const double dd = sqrt(pow2(d_rcyl_min) + pow2(d_z));
+          if ((dd >= 0.) && (dd < distance)) {
+            distance = dd;
+            next_cellindex = (idx0 == 0) ? -99 : cellindex - coordstride(o, 0);
+          }
+        }
+      }
+    } else {
+      /* moving exactly along z: only the expanding inner r_cyl boundary can catch up with the packet (grid.cc:2654) */
+      const double rcyl_inner_tmin = cmin0;
+      if (rcyl_inner_tmin > 0.) {
+        const double dd = overshoot_within_tol(o, 0, pktpos0, pktvel0, cmin0, tstart)
+                              ? 0.
+                              : ((pktpos0 * tmin / rcyl_inner_tmin) - tstart) * CLIGHT_PROP;
+        if ((dd >= 0.) && (dd < distance)) {
+          distance = dd;
+          next_cellindex = (idx0 == 0) ? -99 : cellindex - coordstride(o, 0);
+        }
+      }
+    }
+    { /* z boundaries are Cartesian (grid.cc:2671) */
+      const int d = 1;
+      const int idx = cellcoordindex(o, cellindex, d);
+      const double cmin = cellcoordmin(o, cellindex, d);
+      const double cmax = cellcoordmax(o, cellindex, d);
+      if (pktvel1 > (cmax / tmin)) {
+        const double dd = overshoot_within_tol(o, 1, pktpos1, pktvel1, cmax, tstart)
+                              ? 0.
+                              : distance_cartesian_boundary(o, pktpos1, pktvel1, cmax, tstart);
+        if ((dd >= 0.) && (dd < distance)) {
+          distance = dd;
+          next_cellindex = (idx == (m->ncoordgrid[d] - 1)) ? -99 : cellindex + coordstride(o, d);
+        }
+      } else if (pktvel1 < (cmin / tmin)) {
+        const double dd = overshoot_within_tol(o, 0, pktpos1, pktvel1, cmin, tstart)
+                              ? 0.
+                              : distance_cartesian_boundary(o, pktpos1, pktvel1, cmin, tstart);
+        if ((dd >= 0.) && (dd < distance)) {
+          distance = dd;
+          next_cellindex = (idx == 0) ? -99 : cellindex - coordstride(o, d);
+        }
+      }
+    }
   } else {
     ORACLE_FAIL(o, "gridtype not supported by the oracle");
   }

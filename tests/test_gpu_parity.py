@@ -51,6 +51,8 @@ def _run_case(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk, kfrac=
     ("small", 8, abi.GRID_CARTESIAN3D, 6e8, 8000),
     ("small", 24, abi.GRID_SPHERICAL1D, 0.0, 8000),
     ("small", 16, abi.GRID_SPHERICAL1D, 5e8, 4000),
+    ("small", 8, abi.GRID_CYLINDRICAL2D, 0.0, 10000),
+    ("tiny", 6, abi.GRID_CYLINDRICAL2D, 5e8, 4000),
 ])
 def test_engine_matches_oracle(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk):
     model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk)

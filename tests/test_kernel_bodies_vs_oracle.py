@@ -25,6 +25,8 @@ def _run_both(oracle, model, cs, ts, pk0, budget):
     ("small", 8, abi.GRID_CARTESIAN3D, 6e8, 2000, 1000000),   # optically thick core: grey path + do_kpkt_blackbody
     ("small", 24, abi.GRID_SPHERICAL1D, 0.0, 2000, 2),        # configs[0]-like: 1D spherical shells
     ("small", 16, abi.GRID_SPHERICAL1D, 5e8, 1000, 3),
+    ("small", 8, abi.GRID_CYLINDRICAL2D, 0.0, 2500, 2),       # 2D cylindrical (r_cyl, z) grid, grid.cc:2602
+    ("tiny", 6, abi.GRID_CYLINDRICAL2D, 5e8, 1500, 5),
 ])
 def test_packets_bit_exact(oracle, preset, ncoord, gridtype, thick_v, npk, budget):
     model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v)

@@ -17,6 +17,7 @@ import math
 import os
 
 import numpy as np
+import pytest
 
 from artis_amd import abi
 
@@ -270,3 +271,42 @@ def test_rad_deexcitation_matches_reference_golden(oracle):
         assert float(got).hex() == want.hex(), c
         kinds.add("thin" if want == float(np.float32(c["A_ul"])) else "escape")
     assert kinds == {"thin", "escape"}
+
+
+@pytest.mark.parametrize("gridtype,ncoord", [(abi.GRID_SPHERICAL1D, 16), (abi.GRID_CYLINDRICAL2D, 8), (abi.GRID_CARTESIAN3D, 8)])
+def test_packets_stay_inside_their_cells(oracle, gridtype, ncoord):
+    """Geometric invariant of boundary_distance()/change_cell_or_escape() (grid.cc:2480, grid.h:118) on every grid type:
+    after a timestep each packet that has not escaped lies inside the homologously expanded bounds of the cell it says
+    it is in (to the reference's boundary tolerance, grid.cc cellbound_tolerance = 1e-7 relative), escaped packets
+    left through the outer surface, and energy only changes through the Doppler factor (e_rf stays positive)."""
+    from artis_amd import synth
+    model, cs, ts, aux = synth.build("tiny", ncoord=ncoord, gridtype=gridtype)
+    pk = synth.make_packets(model, aux, 3000, kpkt_fraction=0.1)
+    est = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
+    oracle.update_packets(model, cs, ts, pk, est)
+    d = model.d
+    tmin, rmax = d["tmin"], d["rmax"]
+    alive = pk["type"] != abi.TYPE_ESCAPE
+    assert alive.sum() > 1000 and (~alive).sum() > 10
+    pos = pk["pos"][alive] * (tmin / pk["prop_time"][alive])[:, None]   # scaled back to tmin
+    ci = pk["cellindex"][alive]
+    if gridtype == abi.GRID_SPHERICAL1D:
+        coords = [np.sqrt((pos ** 2).sum(axis=1))]
+    elif gridtype == abi.GRID_CYLINDRICAL2D:
+        coords = [np.sqrt(pos[:, 0] ** 2 + pos[:, 1] ** 2), pos[:, 2]]
+    else:
+        coords = [pos[:, 0], pos[:, 1], pos[:, 2]]
+    stride = 1
+    for axis, x in enumerate(coords):
+        n = int(d["ncoordgrid"][axis])
+        lo_edges = np.asarray(d["coord_pos_min_tmin"][axis], dtype=np.float64)
+        hi_edges = np.concatenate([lo_edges[1:], [rmax]])
+        idx = (ci // stride) % n
+        stride *= n
+        tol = 1e-6 * rmax
+        assert np.all(x >= lo_edges[idx] - tol), (axis, float((lo_edges[idx] - x).max()))
+        assert np.all(x <= hi_edges[idx] + tol), (axis, float((x - hi_edges[idx]).max()))
+    esc = pk[~alive]
+    r_esc = np.sqrt((esc["pos"] ** 2).sum(axis=1)) * (tmin / esc["prop_time"])
+    assert np.all(r_esc >= 0.7 * rmax)   # left through the outer surface (a face of the cube / cylinder / the sphere)
+    assert np.all(pk["e_rf"] > 0) and np.all(np.isfinite(pk["pos"]))
