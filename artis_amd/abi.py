@@ -11,14 +11,18 @@ import ctypes as C
 import numpy as np
 
 NSTATS = 64
+NSCALARS = 2  # ARTIS_SCALAR_GAMMA_DEP_DISCRETE, ARTIS_SCALAR_NT_ENERGY_DEPOSITED
 STAT_COUNT = 34
 STAT_X_RPKT_STEPS = 34
 STAT_X_KPKT_STEPS = 35
 STAT_X_LINES_VISITED = 36
 STAT_X_MA_JUMPS = 37
+STAT_X_GAMMA_STEPS = 40
 
+TYPE_GAMMA = 10
 TYPE_RPKT = 11
 TYPE_KPKT = 12
+TYPE_NTLEPTON_DEPOSITED = 20
 TYPE_ESCAPE = 32
 TYPE_PRE_KPKT = 120
 EMTYPE_NOTSET = -9999000
@@ -38,8 +42,8 @@ STAT_NAMES = [
     "NT_STAT_TO_EXCITATION", "NT_STAT_TO_KPKT", "K_STAT_FROM_EARLIERDECAY", "INTERACTIONS", "ELECTRON_SCATTERINGS",
     "RESONANCESCATTERINGS", "CELLCROSSINGS", "UPSCATTER", "DOWNSCATTER", "UPDATECELL", "PKTESCAPES",
     "X_RPKT_STEPS", "X_KPKT_STEPS", "X_LINES_VISITED", "X_MA_JUMPS", "X_CHI_EVALS", "X_CONT_VISITED",
-    "X_MC_HIT", "X_MC_MISS",
-] + [f"X_{i}" for i in range(42, 64)]
+    "X_GAMMA_STEPS",
+] + [f"X_{i}" for i in range(41, 64)]
 
 # struct artis_packet (include/artis_amd.h), natural C alignment == numpy align=True
 PACKET_DTYPE = np.dtype(
@@ -134,6 +138,7 @@ _CELL_FIELDS = [
     ("kappagrey", _F32P, np.float32), ("thick", _I32P, np.int32), ("clumpfactor", _F32P, np.float32),
     ("ion_groundlevelpops", _F32P, np.float32), ("ion_partfuncts", _F32P, np.float32),
     ("elem_massfracs", _F32P, np.float32), ("corrphotoionrenorm", _F64P, np.float64),
+    ("ffegrp", _F32P, np.float32),
 ]
 
 
@@ -152,7 +157,8 @@ class CTimestep(C.Structure):
 
 class CEstimators(C.Structure):
     _fields_ = [("J", _F64P), ("nuJ", _F64P), ("ffheatingestimator", _F64P), ("colheatingestimator", _F64P),
-                ("gammaestimator", _F64P), ("bfheatingestimator", _F64P), ("stats", _I64P)]
+                ("gammaestimator", _F64P), ("bfheatingestimator", _F64P), ("stats", _I64P),
+                ("dep_estimator_gamma", _F64P), ("scalars", _F64P)]
 
 
 def _as_ptr(arr: np.ndarray, ptype):
@@ -232,10 +238,13 @@ class Estimators:
         self.gammaestimator = np.zeros(n * g)
         self.bfheatingestimator = np.zeros(n * g)
         self.stats = np.zeros(NSTATS, dtype=np.int64)
+        self.dep_estimator_gamma = np.zeros(n)
+        self.scalars = np.zeros(NSCALARS)
         self.c = CEstimators(
             _as_ptr(self.J, _F64P), _as_ptr(self.nuJ, _F64P), _as_ptr(self.ffheatingestimator, _F64P),
             _as_ptr(self.colheatingestimator, _F64P), _as_ptr(self.gammaestimator, _F64P),
-            _as_ptr(self.bfheatingestimator, _F64P), _as_ptr(self.stats, _I64P))
+            _as_ptr(self.bfheatingestimator, _F64P), _as_ptr(self.stats, _I64P),
+            _as_ptr(self.dep_estimator_gamma, _F64P), _as_ptr(self.scalars, _F64P))
 
     def ref(self):
         return C.byref(self.c)
@@ -243,7 +252,8 @@ class Estimators:
     def arrays(self):
         return {"J": self.J, "nuJ": self.nuJ, "ffheatingestimator": self.ffheatingestimator,
                 "colheatingestimator": self.colheatingestimator, "gammaestimator": self.gammaestimator,
-                "bfheatingestimator": self.bfheatingestimator}
+                "bfheatingestimator": self.bfheatingestimator, "dep_estimator_gamma": self.dep_estimator_gamma,
+                "scalars": self.scalars}
 
     def stats_dict(self):
         return {STAT_NAMES[i]: int(self.stats[i]) for i in range(NSTATS)}

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(BLOCK) k_classify(PktSoA P, double ts_end, Lis
     } else if (P.ma_level[i] >= 0) {
       kind = NEXT_MA;
     } else if (type_handled(type) && P.prop_time[i] < ts_end) {
-      kind = (type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_KPKT;
+      kind = type_gamma(type) ? NEXT_GAMMA : ((type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_KPKT);
     }
   }
   append_by_kind(kind, (int32_t)i, L);
@@ -369,6 +369,57 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
 }
 
+// gamma packets (and the non-thermal deposits they end in): one do_gamma() call per iteration, same persistent
+// work-pulling form as k_rpkt; a packet that has thermalised leaves as a k-packet for the thermal list
+#ifndef ARTIS_GAMMA_WAVES
+#define ARTIS_GAMMA_WAVES 2
+#endif
+__global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, const int32_t *list, int32_t n, Lists next,
+                                                                     unsigned long long *gstats, int budget, int32_t *cursors) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  env.stats = lstats;
+  const double ts_end = env.S.ts_end;
+  Puller q;
+  puller_init(q);
+  bool have = false;
+  int32_t pi = 0;
+  int steps = 0;
+  Pkt p;
+  while (true) {
+    const int32_t idx = pull(q, !have, n, cursors);
+    if (idx >= 0) {
+      pi = list[idx];
+      pkt_load(env.P, pi, p);
+      steps = 0;
+      have = true;
+    }
+    if (!__any(have)) {
+      if (q.exhausted) break;
+      continue;
+    }
+    int kind = NEXT_DONE;
+    int32_t out_pi = 0;
+    if (have) {
+      bool go = gamma_can_continue(p, ts_end);
+      if (go) {
+        go = gamma_iter(env, p, pi);
+        steps++;
+      }
+      if (!go || steps >= budget) {
+        pkt_store(env.P, pi, p);
+        kind = classify(p, ts_end);
+        out_pi = pi;
+        have = false;
+      }
+    }
+    append_by_kind(kind, out_pi, next);
+  }
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+}
+
 // Thermal packets (k-packets and walking macro-atoms) are advanced by ONE persistent kernel, so that the k-packet ->
 // macro-atom -> k-packet cycle (tens of times per packet and timestep, kpkt.cc:51) needs no kernel boundary.
 #ifndef ARTIS_THERMAL_WAVES
@@ -444,7 +495,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
     PROF_ADD(43, t1 - t0);
 #endif
     if (go) {
-      if (!ma_pending(p) && p.pend == PEND_NONE && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT) {
+      if (kpkt_eligible(p, ts_end)) {
 #ifdef ARTIS_PROFILE
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 47);
 #endif
@@ -722,9 +773,9 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   }
   ARTIS_CACHE_ARRAYS(CA, h)
 #undef CA
-  // estimators: one contiguous block [J | nuJ | ff | col | gamma | bfheat]
+  // estimators: one contiguous block [J | nuJ | ff | col | gamma | bfheat | dep_gamma | scalars]
   const int64_t g = h.nbfcontinua_ground > 0 ? h.nbfcontinua_ground : 1;
-  e->est_ndoubles = ncell * 4 + 2 * ncell * g;
+  e->est_ndoubles = ncell * 5 + 2 * ncell * g + ARTIS_NSCALARS;  // ... | dep_estimator_gamma | scalars]
   HIP_TRY(hipMalloc((void **)&e->d_est, sizeof(double) * (size_t)e->est_ndoubles));
   HIP_TRY(hipMemset(e->d_est, 0, sizeof(double) * (size_t)e->est_ndoubles));
   e->E.J = e->d_est;
@@ -733,6 +784,8 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   e->E.colheatingestimator = e->d_est + 3 * ncell;
   e->E.gammaestimator = e->d_est + 4 * ncell;
   e->E.bfheatingestimator = e->d_est + 4 * ncell + ncell * g;
+  e->E.dep_estimator_gamma = e->d_est + 4 * ncell + 2 * ncell * g;
+  e->E.scalars = e->d_est + 5 * ncell + 2 * ncell * g;
   HIP_TRY(hipMalloc((void **)&e->d_stats, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
@@ -790,7 +843,12 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
   HIP_TRY(hipSetDevice(e->device));
   free_all(e->cell_allocs);
   const DevModel &h = e->Mh;
-  const DevCells hc = make_host_cells_view(*cells);
+  DevCells hc = make_host_cells_view(*cells);
+  std::vector<float> zero_ffegrp;
+  if (!hc.ffegrp) {  // no gamma packets will be handed over: the opacities of gammapkt.cc are never evaluated
+    zero_ffegrp.assign((size_t)(h.npts_nonempty > 0 ? h.npts_nonempty : 1), 0.f);
+    hc.ffegrp = zero_ffegrp.data();
+  }
 #define UPC(f, T, count)                                                                   \
   {                                                                                        \
     int rc = upload_array<T>(e->cell_allocs, hc.f, (int64_t)(count), (const T **)&e->C.f); \
@@ -933,7 +991,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   const int64_t n = e->npackets;
   if (n == 0) return ARTIS_OK;
   Env env = make_env(e);
-  int cur[NEXT_NKINDS] = {0, 0, 0, 0, 0};             // which of the two buffers is the current list of each kind
+  int cur[NEXT_NKINDS] = {};             // which of the two buffers is the current list of each kind
   int32_t cnt[2 * NEXT_NKINDS];                        // host copy of the device counters
   auto lists_for = [&](int self_kind) {
     Lists L;
@@ -965,15 +1023,15 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
 
   // one launch = the whole current list of one kind. Order: slow path, k-packets, macro-atoms, r-packets, so that a
   // k-packet -> macro-atom -> k-packet cycle costs two launches.
-  const int order[4] = {NEXT_SLOW, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
+  const int order[5] = {NEXT_SLOW, NEXT_GAMMA, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
   int64_t guard = 0;
-  while (cnt[NEXT_RPKT] > 0 || cnt[NEXT_MA] > 0 || cnt[NEXT_SLOW] > 0 || cnt[NEXT_KPKT] > 0) {
+  while (cnt[NEXT_RPKT] > 0 || cnt[NEXT_MA] > 0 || cnt[NEXT_SLOW] > 0 || cnt[NEXT_KPKT] > 0 || cnt[NEXT_GAMMA] > 0) {
     for (int kind : order) {
       const int32_t nk = cnt[kind];
       if (nk <= 0) continue;
       const Lists next = lists_for(kind);
       const int32_t *lst = e->d_lists[kind][cur[kind]];
-      if (kind == NEXT_RPKT || (kind == NEXT_MA && e->sort_ma)) {
+      if (kind == NEXT_RPKT || kind == NEXT_GAMMA || (kind == NEXT_MA && e->sort_ma)) {
         rc = sort_by_cell(e, s, e->d_lists[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? SORT_NUBINS : 1);
         if (rc != ARTIS_OK) return rc;
       }
@@ -985,6 +1043,9 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       if (kind == NEXT_RPKT) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
         hipLaunchKernelGGL(k_rpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors);
+      } else if (kind == NEXT_GAMMA) {
+        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_GAMMA_WAVES);
+        hipLaunchKernelGGL(k_gamma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r * 8, e->d_cursors);
       } else if (kind == NEXT_MA) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_THERMAL_WAVES);
         hipLaunchKernelGGL(k_thermal, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors);
@@ -1050,6 +1111,8 @@ int artis_amd_estimators_download(artis_amd_engine *e, artis_estimators *est) {
   add(est->colheatingestimator, src + 3 * ncell, ncell);
   add(est->gammaestimator, src + 4 * ncell, ncell * g);
   add(est->bfheatingestimator, src + 4 * ncell + ncell * g, ncell * g);
+  add(est->dep_estimator_gamma, src + 4 * ncell + 2 * ncell * g, ncell);
+  add(est->scalars, src + 5 * ncell + 2 * ncell * g, ARTIS_NSCALARS);
   if (est->stats) {
     unsigned long long st[ARTIS_NSTATS];
     HIP_TRY(hipMemcpy(st, e->d_stats, sizeof(st), hipMemcpyDeviceToHost));

@@ -96,7 +96,8 @@ struct ModelOwned {
   X(ion_groundlevelpops, float, ((int64_t)(m).npts_nonempty * (m).nions)) \
   X(ion_partfuncts, float, ((int64_t)(m).npts_nonempty * (m).nions))     \
   X(elem_massfracs, float, ((int64_t)(m).npts_nonempty * (m).nelements)) \
-  X(corrphotoionrenorm, double, ((int64_t)(m).npts_nonempty * ((m).nbfcontinua_ground > 0 ? (m).nbfcontinua_ground : 1)))
+  X(corrphotoionrenorm, double, ((int64_t)(m).npts_nonempty * ((m).nbfcontinua_ground > 0 ? (m).nbfcontinua_ground : 1))) \
+  X(ffegrp, float, (m).npts_nonempty)
 
 // X(field, element type, elements per cell) for every array of DevCache
 #define ARTIS_CACHE_ARRAYS(X, m)                                \
@@ -233,6 +234,7 @@ inline DevCells make_host_cells_view(const artis_cellstate &c) {
   v.kappagrey = c.kappagrey; v.clumpfactor = c.clumpfactor; v.thick = c.thick;
   v.ion_groundlevelpops = c.ion_groundlevelpops; v.ion_partfuncts = c.ion_partfuncts; v.elem_massfracs = c.elem_massfracs;
   v.corrphotoionrenorm = c.corrphotoionrenorm;
+  v.ffegrp = c.ffegrp;
   return v;
 }
 

@@ -31,6 +31,11 @@ constexpr double HPLANCK = 6.6260755e-27;
 constexpr double PI = 3.14159265358979323846;
 constexpr double EV = 1.6021772e-12;
 constexpr double SIGMA_T = 6.6524e-25;
+constexpr double ME = 9.1093897e-28;
+constexpr double MH = 1.67352e-24;
+constexpr double MEV = 1.6021772e-6;
+constexpr double THOMSON_LIMIT = 1e-2;  // constants.h:38
+constexpr double NU_100KEV = 2.41326e+19, NU_1MEV = 2.41326e+20, NU_1P022MEV = 2.46636e+20, NU_1P5MEV = 3.61990e+20;  // constants.h:64-67
 constexpr double KB = 1.38064852e-16;
 constexpr double SAHACONST = 2.0706659e-16;
 constexpr double EULERGAMMA = 0.577215664901532860606512090082402431;
@@ -2281,8 +2286,247 @@ AHD void kpkt_fb_emission(const Env &env, Pkt &p, int64_t pi) {
   thermal_emission_flags(env, p, pi, emtype_continuum(M, lstart(M, element, ion) + lowerlevel, t));
 }
 
+// ---------------------------------------------------------------- gammapkt.cc / gammapkt.h, classic preset:
+// GAMMA_THERMALISATION_SCHEME FREQUENCYDEPENDENT, no grey opacity, USE_XCOM_GAMMAPHOTOION off,
+// PARTICLE_THERMALISATION_SCHEME INSTANTFULLDEPOSITION (artisoptions_classic.h:144-150)
+AHD double sigma_compton_partial(double x, double f_max) {  // gammapkt.h:28
+  const double term1 = ((x * x) - (2 * x) - 2) * log(f_max) / x / x;
+  const double term2 = (((f_max * f_max) - 1) / (f_max * f_max)) / 2;
+  const double term3 = ((f_max - 1) / x) * ((1 / x) + (2 / f_max) + (1 / (x * f_max)));
+  return (3 * SIGMA_T * (term1 + term2 + term3) / (8 * x));
+}
+AHD double choose_f(double xx, double zrand) {  // gammapkt.h:38
+  double f_max = 1 + (2 * xx);
+  double f_min = 1;
+  const double norm = zrand * sigma_compton_partial(xx, f_max);
+  int count = 0;
+  double err = 1e20;
+  double ftry = (f_max + f_min) / 2;
+  while ((err > 1.e-4) && (count < 1000)) {
+    ftry = (f_max + f_min) / 2;
+    const double sigma_try = sigma_compton_partial(xx, ftry);
+    if (sigma_try > norm) {
+      f_max = ftry;
+      err = (sigma_try - norm) / norm;
+    } else {
+      f_min = ftry;
+      err = (norm - sigma_try) / norm;
+    }
+    count++;
+  }
+  return ftry;
+}
+AHD double meanf_sigma(double x) {  // gammapkt.h:68
+  if (x < THOMSON_LIMIT) {
+    double series = -409088. / 165.;  // Horner evaluation of the eight Taylor coefficients, highest order first
+    series = (14588. / 15.) + (x * series);
+    series = (-2584. / 7.) + (x * series);
+    series = (940. / 7.) + (x * series);
+    series = (-1616. / 35.) + (x * series);
+    series = (147. / 10.) + (x * series);
+    series = (-21. / 5.) + (x * series);
+    series = 1. + (x * series);
+    return SIGMA_T * x * series;
+  }
+  const double f = 1 + (2 * x);
+  const double term0 = 2 / x;
+  const double term1 = (1 - (2 / x) - (3 / (x * x))) * log(f);
+  const double term2 = ((4 / x) + (3 / (x * x)) - 1) * 2 * x / f;
+  const double term3 = (1 - (2 / x) - (1 / (x * x))) * 2 * x * (1 + x) / f / f;
+  const double term4 = -2. * x * ((4 * x * x) + (6 * x) + 3) / 3 / f / f / f;
+  return 3 * SIGMA_T * (term0 + term1 + term2 + term3 + term4) / (8 * x);
+}
+AHD double chi_compton_cmf(const Env &env, int c, double nu_cmf) {  // gammapkt.cc:265
+  const double xx = HPLANCK * nu_cmf / ME / CLIGHT / CLIGHT;
+  const double sigma_cmf = (xx < THOMSON_LIMIT) ? SIGMA_T : sigma_compton_partial(xx, 1 + (2 * xx));
+  return sigma_cmf * env.C.nnetot[c];
+}
+AHD double chi_photo_electric_cmf(const Env &env, int c, double ffegrp, double nu_cmf) {  // gammapkt.cc:416 (Veigele fit)
+  const double rho = env.C.rho[c];
+  const double hnu_over_100kev = nu_cmf / NU_100KEV;
+  const double sigma_cmf_si = 1.16e-24 * pow(hnu_over_100kev, -3.13);
+  const double sigma_cmf_fe = 25.7e-24 * pow(hnu_over_100kev, -3.0);
+  const double chi_cmf_si = sigma_cmf_si * (rho / MH / 28);
+  const double chi_cmf_fe = sigma_cmf_fe * (rho / MH / 56);
+  return (chi_cmf_fe * ffegrp) + (chi_cmf_si * (1. - ffegrp));
+}
+AHD double sigma_pair_prod_factor(double nu_cmf) {  // gammapkt.cc:501
+  const double hnu_over_1MeV = nu_cmf / NU_1MEV;
+  if (nu_cmf > NU_1P5MEV) return 0.0481 + (0.301 * (hnu_over_1MeV - 1.5));
+  return 0.10063 * (hnu_over_1MeV - 1.022);
+}
+AHD double chi_pair_prod_cmf(const Env &env, int c, double ffegrp, double nu_cmf) {  // gammapkt.cc:516
+  const double rho = env.C.rho[c];
+  if (nu_cmf <= NU_1P022MEV) return 0.;
+  const double sigma_factor = sigma_pair_prod_factor(nu_cmf);
+  const double sigma_cmf_si = sigma_factor * 196.e-27;
+  const double sigma_cmf_fe = sigma_factor * 784.e-27;
+  const double chi_cmf_si = sigma_cmf_si * (rho / MH / 28);
+  const double chi_cmf_fe = sigma_cmf_fe * (rho / MH / 56);
+  return dmax((chi_cmf_fe * ffegrp) + (chi_cmf_si * (1. - ffegrp)), 0.);
+}
+AHD double chi_cmf_loss_weighted(const Env &env, int c, double nu_cmf) {  // gammapkt.cc:548
+  const double ffegrp = env.C.ffegrp[c];
+  const double chi_pe = chi_photo_electric_cmf(env, c, ffegrp, nu_cmf);
+  const double xx = HPLANCK * nu_cmf / ME / CLIGHT / CLIGHT;
+  const double chi_pp = chi_pair_prod_cmf(env, c, ffegrp, nu_cmf);
+  return ((meanf_sigma(xx) * env.C.nnetot[c]) + chi_pe + (chi_pp * (1. - (NU_1P022MEV / nu_cmf))));
+}
+AHD void update_gamma_dep(const Env &env, const Pkt &p, int c, double dist) {  // gammapkt.cc:568
+  if (!(dist > 0)) return;
+  if (c < 0) return;
+  const double doppler_sq = pow2(doppler(p));
+  const double heating_cont = chi_cmf_loss_weighted(env, c, p.nu_cmf) * p.e_rf * dist * doppler_sq;
+  ARTIS_EST_ADD(&env.E.dep_estimator_gamma[c], heating_cont);
+}
+AHD double thomson_angle(Pkt &p) {  // gammapkt.cc:284
+  const double B_coeff = (8. * rng_uniform(p)) - 4.;
+  const double t_coeff = cbrt((sqrt(pow2(B_coeff) + 4) - B_coeff) / 2);
+  return (1 / t_coeff) - t_coeff;
+}
+AHD void scatter_dir(const double dir_in[3], double cos_theta, Pkt &p, double dir_out[3]) {  // gammapkt.cc:297
+  const double phi = rng_uniform(p) * 2 * PI;
+  const double sin_theta_sq = 1. - pow2(cos_theta);
+  const double sin_theta = sqrt(sin_theta_sq);
+  const double zprime = cos_theta;
+  const double xprime = sin_theta * cos(phi);
+  const double yprime = sin_theta * sin(phi);
+  if (fabs(dir_in[2]) > 0.999999999) {
+    dir_out[0] = xprime;
+    dir_out[1] = yprime;
+    dir_out[2] = (dir_in[2] > 0) ? zprime : -zprime;
+    return;
+  }
+  const double norm1 = 1. / sqrt(pow2(dir_in[0]) + pow2(dir_in[1]));
+  const double norm2 = 1. / vlen(dir_in);
+  const double r11 = dir_in[1] * norm1;
+  const double r12 = -dir_in[0] * norm1;
+  const double r13 = 0.;
+  const double r21 = dir_in[0] * dir_in[2] * norm1 * norm2;
+  const double r22 = dir_in[1] * dir_in[2] * norm1 * norm2;
+  const double r23 = -norm2 / norm1;
+  const double r31 = dir_in[0] * norm2;
+  const double r32 = dir_in[1] * norm2;
+  const double r33 = dir_in[2] * norm2;
+  dir_out[0] = (r11 * xprime) + (r21 * yprime) + (r31 * zprime);
+  dir_out[1] = (r12 * xprime) + (r22 * yprime) + (r32 * zprime);
+  dir_out[2] = (r13 * xprime) + (r23 * yprime) + (r33 * zprime);
+}
+AHD void compton_scatter(const Env &env, Pkt &p, int64_t pi) {  // gammapkt.cc:346
+  const double xx = HPLANCK * p.nu_cmf / ME / CLIGHT / CLIGHT;
+  double f = 1.;
+  bool stay_gamma = true;
+  if (xx >= THOMSON_LIMIT) {
+    f = choose_f(xx, rng_uniform(p));
+    const double prob_gamma = 1. / f;
+    stay_gamma = (rng_uniform(p) < prob_gamma);
+  }
+  if (stay_gamma) {
+    p.nu_cmf = p.nu_cmf / f;
+    const double pos[3] = {p.px, p.py, p.pz};
+    const double dir[3] = {p.dx, p.dy, p.dz};
+    const double vel_vec[3] = {pos[0] / p.prop_time, pos[1] / p.prop_time, pos[2] / p.prop_time};  // get_velocity vectors.h:50
+    double cmf_dir[3], new_dir[3], out[3];
+    angle_ab(dir, vel_vec, cmf_dir);
+    const double cos_theta = (xx < THOMSON_LIMIT) ? thomson_angle(p) : 1. - ((f - 1) / xx);
+    scatter_dir(cmf_dir, cos_theta, p, new_dir);
+    const double negvel[3] = {vel_vec[0] * -1., vel_vec[1] * -1., vel_vec[2] * -1.};
+    angle_ab(new_dir, negvel, out);
+    p.dx = out[0];
+    p.dy = out[1];
+    p.dz = out[2];
+    set_restframe_from_cmf(p);
+  } else {
+    p.type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+    env.P.absorptiontype[pi] = ARTIS_ABSTYPE_GAMMA_COMPTON;
+    ARTIS_STAT(env, ARTIS_STAT_NT_FROM_GAMMA);
+  }
+}
+AHD void emit_gamma_isotropic(Pkt &p) {  // gammapkt.cc:603
+  double dir_cmf[3], out[3];
+  rand_isotropic(p, dir_cmf);
+  const double mt = -p.prop_time;
+  const double vel_vec[3] = {p.px / mt, p.py / mt, p.pz / mt};
+  angle_ab(dir_cmf, vel_vec, out);
+  p.dx = out[0];
+  p.dy = out[1];
+  p.dz = out[2];
+  set_restframe_from_cmf(p);
+  p.type = ARTIS_TYPE_GAMMA;
+}
+AHD void pair_production(const Env &env, Pkt &p, int64_t pi) {  // gammapkt.cc:618
+  const double pair_rest_mass_energy = 1.022 * MEV;
+  const double gamma_energy = HPLANCK * p.nu_cmf;
+  const double prob_gamma = pair_rest_mass_energy / gamma_energy;
+  if (rng_uniform(p) > prob_gamma) {
+    p.type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+    env.P.absorptiontype[pi] = ARTIS_ABSTYPE_GAMMA_PAIRPRODUCTION;
+    ARTIS_STAT(env, ARTIS_STAT_NT_FROM_GAMMA);
+  } else {
+    p.nu_cmf = 0.511 * MEV / HPLANCK;
+    emit_gamma_isotropic(p);
+  }
+}
+// transport_gamma gammapkt.cc:655 + do_gamma gammapkt.cc:911
+AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
+  const double t2 = env.S.ts_end;
+  ARTIS_STAT(env, ARTIS_STAT_X_GAMMA_STEPS);
+  const double tau_next = -log((double)rng_uniform_pos(p));
+  int next_cell = -1;
+  const double boundarydist = boundary_distance(env, p, &next_cell);
+  const int c = env.M.propcell_nonemptymgi[p.cellindex];
+  const double dop = doppler(p);
+  const double ffegrp = (c >= 0) ? (double)env.C.ffegrp[c] : 0.;
+  const double chi_compton = (c >= 0) ? chi_compton_cmf(env, c, p.nu_cmf) * dop : 0.;
+  const double chi_pe = (c >= 0) ? chi_photo_electric_cmf(env, c, ffegrp, p.nu_cmf) * dop : 0.;
+  const double chi_pp = (c >= 0) ? chi_pair_prod_cmf(env, c, ffegrp, p.nu_cmf) * dop : 0.;
+  const double chi_tot = chi_compton + chi_pe + chi_pp;
+  const double edist = chi_tot > 0. ? tau_next / chi_tot : DBLMAX;
+  if (!(edist >= 0)) fail(env, 80);
+  const double tdist = (t2 - p.prop_time) * CLIGHT_PROP;
+  if (!(tdist >= 0)) fail(env, 81);
+  if ((boundarydist <= tdist) && (boundarydist <= edist)) {
+    move_pkt(p, boundarydist / 2.);
+    if (chi_tot > 0) update_gamma_dep(env, p, c, boundarydist);
+    move_pkt(p, boundarydist / 2.);
+    if (next_cell != p.cellindex) change_cell_or_escape(env, p, pi, next_cell);
+  } else if ((tdist < boundarydist) && (tdist <= edist)) {
+    move_pkt(p, tdist / 2.);
+    if (chi_tot > 0) update_gamma_dep(env, p, c, tdist);
+    move_pkt(p, tdist / 2.);
+    p.prop_time = t2;
+  } else if ((edist < boundarydist) && (edist <= tdist)) {
+    move_pkt(p, edist / 2.);
+    if (chi_tot > 0) update_gamma_dep(env, p, c, edist);
+    move_pkt(p, edist / 2.);
+    const double chi_rnd = rng_uniform(p) * chi_tot;
+    if (chi_compton > chi_rnd) {
+      compton_scatter(env, p, pi);
+    } else if ((chi_compton + chi_pe) > chi_rnd) {
+      p.type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+      env.P.absorptiontype[pi] = ARTIS_ABSTYPE_GAMMA_PHOTOELECTRIC;
+      ARTIS_STAT(env, ARTIS_STAT_NT_FROM_GAMMA);
+    } else {
+      pair_production(env, p, pi);
+    }
+  } else {
+    fail(env, 82);
+  }
+  if (p.type != ARTIS_TYPE_GAMMA && p.type != ARTIS_TYPE_ESCAPE)
+    ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE], p.e_cmf);  // gammapkt.cc:926
+}
+// nonthermal::do_ntlepton_deposit nonthermal.cc:2529 with NT_ON == false (artisoptions_classic.h:95)
+AHD void do_ntlepton_deposit(const Env &env, Pkt &p) {
+  ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_NT_ENERGY_DEPOSITED], p.e_cmf);
+  p.type = ARTIS_TYPE_KPKT;
+  ARTIS_STAT(env, ARTIS_STAT_NT_TO_KPKT);
+}
+
 // ---------------------------------------------------------------- packet load/store and the per-thread driver
-AHD bool type_handled(int type) { return type == ARTIS_TYPE_RPKT || type == ARTIS_TYPE_KPKT || type == ARTIS_TYPE_PRE_KPKT; }
+AHD bool type_gamma(int type) { return type == ARTIS_TYPE_GAMMA || type == ARTIS_TYPE_NTLEPTON_DEPOSITED; }
+AHD bool type_handled(int type) {
+  return type == ARTIS_TYPE_RPKT || type == ARTIS_TYPE_KPKT || type == ARTIS_TYPE_PRE_KPKT || type_gamma(type);
+}
 AHD bool pkt_active(const Pkt &p, double ts_end) { return type_handled(p.type) && p.prop_time < ts_end; }  // update_packets.cc:321
 
 AHD void pkt_load(const PktSoA &P, int64_t i, Pkt &p) {
@@ -2326,11 +2570,12 @@ AHD void pkt_store(const PktSoA &P, int64_t i, const Pkt &p) {
 
 // Work lists: a packet that still needs updating is "in flight" (an r-packet inside or about to enter do_rpkt()),
 // walking a macro-atom, a k-packet (or pre-k-packet) due for its next step, or waiting for a slow-path action.
-enum { NEXT_DONE = 0, NEXT_RPKT = 1, NEXT_MA = 2, NEXT_SLOW = 3, NEXT_KPKT = 4, NEXT_NKINDS = 5 };
+enum { NEXT_DONE = 0, NEXT_RPKT = 1, NEXT_MA = 2, NEXT_SLOW = 3, NEXT_KPKT = 4, NEXT_GAMMA = 5, NEXT_NKINDS = 6 };
 AHD int classify(const Pkt &p, double ts_end) {
   if (p.pend != PEND_NONE) return NEXT_SLOW;
   if (ma_pending(p)) return NEXT_MA;
   if (!pkt_active(p, ts_end)) return NEXT_DONE;
+  if (type_gamma(p.type)) return NEXT_GAMMA;
   return (p.type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_KPKT;
 }
 
@@ -2393,7 +2638,7 @@ AHD bool kpkt_eligible(const Pkt &p, double ts_end);
 AHD bool thermal_can_continue(const Pkt &p, double ts_end) {
   if (p.pend != PEND_NONE) return false;
   if (ma_pending(p)) return true;
-  return pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT;
+  return pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT && !type_gamma(p.type);
 }
 // returns the units of work done (transitions + k-packet steps); *go = the packet can take another iteration.
 // (artis_engine.hip k_thermal spells the two phases out so that the wave reconverges between them.)
@@ -2421,7 +2666,7 @@ AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
 // ---- k-packet kernel body: ONE do_kpkt()/do_kpkt_blackbody() call (update_packets.cc:291-305); it ends in an emission,
 // a macro-atom activation, a deferred free-bound emission, or at the end of the timestep.
 AHD bool kpkt_eligible(const Pkt &p, double ts_end) {
-  return p.pend == PEND_NONE && !ma_pending(p) && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT;
+  return p.pend == PEND_NONE && !ma_pending(p) && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT && !type_gamma(p.type);
 }
 AHD int advance_kpkt(const Env &env, Pkt &p, int64_t pi) {
   if (kpkt_eligible(p, env.S.ts_end)) {
@@ -2432,6 +2677,28 @@ AHD int advance_kpkt(const Env &env, Pkt &p, int64_t pi) {
       do_kpkt(env, p, pi);
     }
     env.P.chi_mgi[pi] = -1;
+  }
+  return classify(p, env.S.ts_end);
+}
+
+// ---- gamma kernel body: one iteration = one do_packet() call for TYPE_GAMMA (do_gamma) or TYPE_NTLEPTON_DEPOSITED
+// (update_packets.cc:264, :283). Returns true while the packet stays with this kernel.
+AHD bool gamma_can_continue(const Pkt &p, double ts_end) { return type_gamma(p.type) && p.prop_time < ts_end; }
+AHD bool gamma_iter(const Env &env, Pkt &p, int64_t pi) {
+  if (p.type == ARTIS_TYPE_GAMMA) {
+    do_gamma(env, p, pi);
+  } else {
+    do_ntlepton_deposit(env, p);
+    env.P.chi_mgi[pi] = -1;
+  }
+  return gamma_can_continue(p, env.S.ts_end);
+}
+AHD int advance_gamma(const Env &env, Pkt &p, int64_t pi, int budget) {
+  int steps = 0;
+  bool go = gamma_can_continue(p, env.S.ts_end);
+  while (go && steps < budget) {
+    go = gamma_iter(env, p, pi);
+    steps++;
   }
   return classify(p, env.S.ts_end);
 }

@@ -125,6 +125,7 @@ struct DevCells {
   const int32_t *thick;
   const float *ion_groundlevelpops, *ion_partfuncts, *elem_massfracs;
   const double *corrphotoionrenorm;
+  const float *ffegrp;  // may be null on the host view (then the engine uploads zeros)
 };
 
 struct DevCache {
@@ -151,6 +152,8 @@ struct DevStep {
 
 struct DevEst {
   double *J, *nuJ, *ffheatingestimator, *colheatingestimator, *gammaestimator, *bfheatingestimator;
+  double *dep_estimator_gamma;  // [cell] gammapkt.cc:568
+  double *scalars;              // [ARTIS_NSCALARS]
 };
 
 // Packet population, structure-of-arrays (one array per field of the reference's struct Packet,

@@ -36,6 +36,7 @@ def allreduce_estimators(block, dist=None):
 
 
 def flatten_estimators(est) -> np.ndarray:
-    """Host estimators in the engine's block order [J | nuJ | ffheating | colheating | gamma | bfheating]."""
+    """Host estimators in the engine's block order
+    [J | nuJ | ffheating | colheating | gamma | bfheating | dep_estimator_gamma | scalars]."""
     return np.concatenate([est.J, est.nuJ, est.ffheatingestimator, est.colheatingestimator, est.gammaestimator,
-                           est.bfheatingestimator])
+                           est.bfheatingestimator, est.dep_estimator_gamma, est.scalars])

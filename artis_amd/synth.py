@@ -491,7 +491,9 @@ def make_grid_and_cells(atomic: dict, ncoord: int = 8, gridtype: int = abi.GRID_
                 vmax=float(vmax), rmax=float(rmax), coord_pos_min_tmin=coord, propcell_nonemptymgi=propcell_nonemptymgi)
     cells = dict(rho=rho, Te=Te, TJ=TJ, TR=TR, W=W, nne=nne, nnetot=nnetot, kappagrey=np.full(nne_cells, 0.1),
                  thick=thick, clumpfactor=np.ones(nne_cells), ion_groundlevelpops=groundpops.ravel(),
-                 ion_partfuncts=U.ravel(), elem_massfracs=X.ravel(), corrphotoionrenorm=renorm.ravel())
+                 ion_partfuncts=U.ravel(), elem_massfracs=X.ravel(), corrphotoionrenorm=renorm.ravel(),
+                 ffegrp=X[:, [k for k, (Z, _, _) in enumerate(elements) if 21 <= Z <= 28]].sum(axis=1) if any(
+                     21 <= Z <= 28 for Z, _, _ in elements) else np.zeros(nne_cells))
     aux = dict(t=t, v=v, X=X, cellvol_tmin=cellvol_tmin[nonempty_mask], nonempty_cellindex=np.nonzero(nonempty_mask)[0])
     return grid, cells, aux
 
@@ -503,7 +505,7 @@ def make_timestep(t: float, width_frac: float = 0.05, vmax: float = 2.4e9, nts: 
 
 
 def make_packets(model: abi.Model, aux: dict, npackets: int, seed_base: int = 12345, kpkt_fraction: float = 0.1,
-                 e_total: float = 1e45, seed: int = 99) -> np.ndarray:
+                 e_total: float = 1e45, seed: int = 99, gamma_fraction: float = 0.0) -> np.ndarray:
     """Packets at the start of the timestep: thermal energy waiting to be emitted (TYPE_PRE_KPKT -> blackbody
     r-packet, kpkt.cc:399) or k-packets (kpkt.cc:425), placed in non-empty cells with probability ~ rho * X(Co,Ni,Fe)."""
     rng = np.random.default_rng(seed)
@@ -557,6 +559,28 @@ def make_packets(model: abi.Model, aux: dict, npackets: int, seed_base: int = 12
     pk["trueem_time"] = -1.0
     pk["type"] = np.where(rng.random(npackets) < kpkt_fraction, abi.TYPE_KPKT, abi.TYPE_PRE_KPKT)
     pk["cellindex"] = cellindex
+    if gamma_fraction > 0:
+        # gamma packets as pellet_gamma_decay() leaves them (gammapkt.cc:894): a line of the 56Ni/56Co decay spectra (a few
+        # below the Thomson limit of the Compton treatment and above the pair-production threshold included), isotropic
+        # direction; rest-frame quantities from the Doppler factor of the homologous flow
+        isg = rng.random(npackets) < gamma_fraction
+        lines_mev = np.array([0.004, 0.158, 0.27, 0.48, 0.75, 0.812, 0.847, 1.238, 1.771, 2.598, 3.253])
+        e_mev = lines_mev[rng.integers(0, len(lines_mev), npackets)]
+        mu = 2 * rng.random(npackets) - 1
+        ph = 2 * np.pi * rng.random(npackets)
+        sth = np.sqrt(1 - mu**2)
+        gdir = np.stack([sth * np.cos(ph), sth * np.sin(ph), mu], axis=1)
+        clight = 2.99792458e10
+        vel = pos / t
+        ndotv = (gdir * vel).sum(axis=1)
+        gamma_rel = 1.0 / np.sqrt(1.0 - (vel**2).sum(axis=1) / clight**2)
+        doppler = gamma_rel * (1.0 - ndotv / clight)  # nu_cmf / nu_rf
+        nu_cmf = e_mev * 1.0e6 * 1.6021772e-12 / 6.6260755e-27
+        pk["type"] = np.where(isg, abi.TYPE_GAMMA, pk["type"])
+        pk["dir"] = np.where(isg[:, None], gdir, pk["dir"])
+        pk["nu_cmf"] = np.where(isg, nu_cmf, pk["nu_cmf"])
+        pk["nu_rf"] = np.where(isg, nu_cmf / doppler, pk["nu_rf"])
+        pk["e_rf"] = np.where(isg, pk["e_cmf"] / doppler, pk["e_rf"])
     pk["escape_time"] = -1.0
     pk["tdecay"] = -1.0
     pk["number"] = np.arange(npackets, dtype=np.int32)

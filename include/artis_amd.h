@@ -50,6 +50,9 @@ enum {
 /* packet.h:89 enum absorption_type */
 #define ARTIS_ABSTYPE_FREEFREE (-1)
 #define ARTIS_ABSTYPE_BOUNDFREE (-2)
+#define ARTIS_ABSTYPE_GAMMA_COMPTON (-3)
+#define ARTIS_ABSTYPE_GAMMA_PHOTOELECTRIC (-4)
+#define ARTIS_ABSTYPE_GAMMA_PAIRPRODUCTION (-5)
 
 /* globals.h:21 enum ma_action */
 enum {
@@ -109,8 +112,7 @@ enum {
   ARTIS_STAT_X_MA_JUMPS = 37, /* iterations of the do_macroatom() loop macroatom.cc:385 */
   ARTIS_STAT_X_CHI_EVALS = 38, /* continuum opacity evaluations that missed the packet's cache, rpkt.cc:1029 */
   ARTIS_STAT_X_CONT_VISITED = 39, /* bound-free continua summed in calculate_chi_bf_gammacontr() rpkt.cc:808 */
-  ARTIS_STAT_X_MC_HIT = 40, /* macro-atom transitions served from the LDS record cache (k_thermal_lds) */
-  ARTIS_STAT_X_MC_MISS = 41, /* ... and from HBM */
+  ARTIS_STAT_X_GAMMA_STEPS = 40, /* calls of gammapkt::do_gamma() gammapkt.cc:911 */
   /* 42..63: free for profiling builds (-DARTIS_PROFILE: wave-cycle accounting, units of 16 clocks) */
   ARTIS_NSTATS = 64
 };
@@ -280,6 +282,9 @@ typedef struct artis_cellstate {
   const float *elem_massfracs;
   /* [npts_nonempty*nbfcontinua_ground] globals.h:126 */
   const double *corrphotoionrenorm;
+  /* [npts_nonempty] grid::get_ffegrp(mgi): iron-group mass fraction, read by the gamma-ray opacities
+   * (gammapkt.cc:416, :516). May be NULL when no TYPE_GAMMA packet is handed over (treated as 0). */
+  const float *ffegrp;
 } artis_cellstate;
 
 typedef struct artis_timestep {
@@ -299,7 +304,14 @@ typedef struct artis_estimators {
   double *gammaestimator;      /* [npts_nonempty*nbfcontinua_ground] globals.h:128 */
   double *bfheatingestimator;  /* [npts_nonempty*nbfcontinua_ground] globals.h:131 */
   int64_t *stats;              /* [ARTIS_NSTATS] stats.cc event counters */
+  double *dep_estimator_gamma; /* [npts_nonempty] globals::dep_estimator_gamma (gammapkt.cc:568); may be NULL */
+  double *scalars;             /* [ARTIS_NSCALARS] per-timestep sums, see ARTIS_SCALAR_*; may be NULL */
 } artis_estimators;
+enum {
+  ARTIS_SCALAR_GAMMA_DEP_DISCRETE = 0,   /* globals::timesteps[nts].gamma_dep_discrete gammapkt.cc:926 */
+  ARTIS_SCALAR_NT_ENERGY_DEPOSITED = 1,  /* nonthermal.cc nt_energy_deposited (do_ntlepton_deposit :2530) */
+  ARTIS_NSCALARS = 2
+};
 
 /* ---- engine ---------------------------------------------------------------- */
 typedef struct artis_amd_engine artis_amd_engine;

@@ -51,6 +51,13 @@
 #define CLIGHT_PROP CLIGHT
 #define H_PLANCK 6.6260755e-27
 #define ME 9.1093897e-28
+#define MH 1.67352e-24
+#define MEV 1.6021772e-6
+#define THOMSON_LIMIT 1e-2 /* constants.h:38 */
+#define NU_100KEV 2.41326e+19 /* constants.h:64-67 */
+#define NU_1MEV 2.41326e+20
+#define NU_1P022MEV 2.46636e+20
+#define NU_1P5MEV 3.61990e+20
 #define PI 3.14159265358979323846
 #define EV 1.6021772e-12
 #define SIGMA_T 6.6524e-25
@@ -2066,9 +2073,254 @@ static void do_kpkt(Oracle *o, artis_packet *p, double t2) {
   }
 }
 
+/* ------------------------------------------------------------------ gammapkt.cc / gammapkt.h (classic preset:
+ * GAMMA_THERMALISATION_SCHEME FREQUENCYDEPENDENT, no grey opacity, USE_XCOM_GAMMAPHOTOION off,
+ * PARTICLE_THERMALISATION_SCHEME INSTANTFULLDEPOSITION; artisoptions_classic.h:144-150) */
+/* sigma_compton_partial gammapkt.h:28 */
+static double sigma_compton_partial(double x, double f_max) {
+  const double term1 = ((x * x) - (2 * x) - 2) * log(f_max) / x / x;
+  const double term2 = (((f_max * f_max) - 1) / (f_max * f_max)) / 2;
+  const double term3 = ((f_max - 1) / x) * ((1 / x) + (2 / f_max) + (1 / (x * f_max)));
+  return (3 * SIGMA_T * (term1 + term2 + term3) / (8 * x));
+}
+/* choose_f gammapkt.h:38 */
+static double choose_f(double xx, double zrand) {
+  double f_max = 1 + (2 * xx);
+  double f_min = 1;
+  const double norm = zrand * sigma_compton_partial(xx, f_max);
+  int count = 0;
+  double err = 1e20;
+  double ftry = (f_max + f_min) / 2;
+  while ((err > 1.e-4) && (count < 1000)) {
+    ftry = (f_max + f_min) / 2;
+    const double sigma_try = sigma_compton_partial(xx, ftry);
+    if (sigma_try > norm) {
+      f_max = ftry;
+      err = (sigma_try - norm) / norm;
+    } else {
+      f_min = ftry;
+      err = (norm - sigma_try) / norm;
+    }
+    count++;
+  }
+  return ftry;
+}
+/* meanf_sigma gammapkt.h:68 */
+static double meanf_sigma(double x) {
+  if (x < THOMSON_LIMIT) {
+    static const double taylor_coeffs[8] = {1., -21. / 5., 147. / 10., -1616. / 35., 940. / 7., -2584. / 7., 14588. / 15., -409088. / 165.};
+    double series = taylor_coeffs[7];
+    for (int i = 6; i >= 0; i--) series = taylor_coeffs[i] + (x * series);
+    return SIGMA_T * x * series;
+  }
+  const double f = 1 + (2 * x);
+  const double term0 = 2 / x;
+  const double term1 = (1 - (2 / x) - (3 / (x * x))) * log(f);
+  const double term2 = ((4 / x) + (3 / (x * x)) - 1) * 2 * x / f;
+  const double term3 = (1 - (2 / x) - (1 / (x * x))) * 2 * x * (1 + x) / f / f;
+  const double term4 = -2. * x * ((4 * x * x) + (6 * x) + 3) / 3 / f / f / f;
+  return 3 * SIGMA_T * (term0 + term1 + term2 + term3 + term4) / (8 * x);
+}
+/* get_chi_compton_cmf gammapkt.cc:265 */
+static double get_chi_compton_cmf(const Oracle *o, int c, double nu_cmf) {
+  const double xx = H_PLANCK * nu_cmf / ME / CLIGHT / CLIGHT;
+  const double sigma_cmf = (xx < THOMSON_LIMIT) ? SIGMA_T : sigma_compton_partial(xx, 1 + (2 * xx));
+  return sigma_cmf * o->cs->nnetot[c];
+}
+/* get_chi_photo_electric_cmf gammapkt.cc:416 (Veigele fit, no XCOM tables) */
+static double get_chi_photo_electric_cmf(const Oracle *o, int c, double ffegrp, double nu_cmf) {
+  const double rho = o->cs->rho[c];
+  const double hnu_over_100kev = nu_cmf / NU_100KEV;
+  const double sigma_cmf_si = 1.16e-24 * pow(hnu_over_100kev, -3.13);
+  const double sigma_cmf_fe = 25.7e-24 * pow(hnu_over_100kev, -3.0);
+  const double chi_cmf_si = sigma_cmf_si * (rho / MH / 28);
+  const double chi_cmf_fe = sigma_cmf_fe * (rho / MH / 56);
+  return (chi_cmf_fe * ffegrp) + (chi_cmf_si * (1. - ffegrp));
+}
+/* get_sigma_pair_prod_factor gammapkt.cc:501 */
+static double get_sigma_pair_prod_factor(double nu_cmf) {
+  const double hnu_over_1MeV = nu_cmf / NU_1MEV;
+  if (nu_cmf > NU_1P5MEV) return 0.0481 + (0.301 * (hnu_over_1MeV - 1.5));
+  return 0.10063 * (hnu_over_1MeV - 1.022);
+}
+/* get_chi_pair_prod_cmf gammapkt.cc:516 */
+static double get_chi_pair_prod_cmf(const Oracle *o, int c, double ffegrp, double nu_cmf) {
+  const double rho = o->cs->rho[c];
+  if (nu_cmf <= NU_1P022MEV) return 0.;
+  const double sigma_factor = get_sigma_pair_prod_factor(nu_cmf);
+  const double sigma_cmf_si = sigma_factor * 196.e-27;
+  const double sigma_cmf_fe = sigma_factor * 784.e-27;
+  const double chi_cmf_si = sigma_cmf_si * (rho / MH / 28);
+  const double chi_cmf_fe = sigma_cmf_fe * (rho / MH / 56);
+  const double chi_cmf = (chi_cmf_fe * ffegrp) + (chi_cmf_si * (1. - ffegrp));
+  return dmax(chi_cmf, 0.);
+}
+static inline double cell_ffegrp(const Oracle *o, int c) { return o->cs->ffegrp ? o->cs->ffegrp[c] : 0.; } /* grid::get_ffegrp */
+/* get_chi_cmf_loss_weighted gammapkt.cc:548 */
+static double get_chi_cmf_loss_weighted(const Oracle *o, int c, double nu_cmf) {
+  const double ffegrp = cell_ffegrp(o, c);
+  const double chi_photo_electric_cmf = get_chi_photo_electric_cmf(o, c, ffegrp, nu_cmf);
+  const double xx = H_PLANCK * nu_cmf / ME / CLIGHT / CLIGHT;
+  const double chi_pair_prod_cmf = get_chi_pair_prod_cmf(o, c, ffegrp, nu_cmf);
+  return ((meanf_sigma(xx) * o->cs->nnetot[c]) + chi_photo_electric_cmf + (chi_pair_prod_cmf * (1. - (NU_1P022MEV / nu_cmf))));
+}
+/* update_gamma_dep gammapkt.cc:568 */
+static void update_gamma_dep(Oracle *o, const artis_packet *p, int c, double dist) {
+  if (!(dist > 0)) return;
+  if (c < 0) return;
+  const double doppler_sq = pow2(doppler_nucmf_on_nurf(p->pos, p->dir, p->prop_time));
+  const double heating_cont = get_chi_cmf_loss_weighted(o, c, p->nu_cmf) * p->e_rf * dist * doppler_sq;
+  if (o->est.dep_estimator_gamma) o->est.dep_estimator_gamma[c] += heating_cont;
+}
+/* thomson_angle gammapkt.cc:284 */
+static double thomson_angle(uint32_t rng[4]) {
+  const double B_coeff = (8. * rng_uniform(rng)) - 4.;
+  const double t_coeff = cbrt((sqrt(pow2(B_coeff) + 4) - B_coeff) / 2);
+  return (1 / t_coeff) - t_coeff;
+}
+/* scatter_dir gammapkt.cc:297 */
+static void scatter_dir(const double dir_in[3], double cos_theta, uint32_t rng[4], double dir_out[3]) {
+  const double phi = rng_uniform(rng) * 2 * PI;
+  const double sin_theta_sq = 1. - pow2(cos_theta);
+  const double sin_theta = sqrt(sin_theta_sq);
+  const double zprime = cos_theta;
+  const double xprime = sin_theta * cos(phi);
+  const double yprime = sin_theta * sin(phi);
+  if (fabs(dir_in[2]) > 0.999999999) {
+    dir_out[0] = xprime;
+    dir_out[1] = yprime;
+    dir_out[2] = (dir_in[2] > 0) ? zprime : -zprime;
+    return;
+  }
+  const double norm1 = 1. / sqrt(pow2(dir_in[0]) + pow2(dir_in[1]));
+  const double norm2 = 1. / vec_len3(dir_in);
+  const double r11 = dir_in[1] * norm1;
+  const double r12 = -dir_in[0] * norm1;
+  const double r13 = 0.;
+  const double r21 = dir_in[0] * dir_in[2] * norm1 * norm2;
+  const double r22 = dir_in[1] * dir_in[2] * norm1 * norm2;
+  const double r23 = -norm2 / norm1;
+  const double r31 = dir_in[0] * norm2;
+  const double r32 = dir_in[1] * norm2;
+  const double r33 = dir_in[2] * norm2;
+  dir_out[0] = (r11 * xprime) + (r21 * yprime) + (r31 * zprime);
+  dir_out[1] = (r12 * xprime) + (r22 * yprime) + (r32 * zprime);
+  dir_out[2] = (r13 * xprime) + (r23 * yprime) + (r33 * zprime);
+}
+/* compton_scatter gammapkt.cc:346 */
+static void compton_scatter(Oracle *o, artis_packet *p) {
+  const double xx = H_PLANCK * p->nu_cmf / ME / CLIGHT / CLIGHT;
+  double f = 1.;
+  int stay_gamma = 1;
+  if (xx >= THOMSON_LIMIT) {
+    f = choose_f(xx, rng_uniform(p->rngstate));
+    const double prob_gamma = 1. / f;
+    stay_gamma = (rng_uniform(p->rngstate) < prob_gamma);
+  }
+  if (stay_gamma) {
+    p->nu_cmf = p->nu_cmf / f;
+    double vel_vec[3], cmf_dir[3], new_dir[3];
+    get_velocity(p->pos, p->prop_time, vel_vec);
+    angle_ab(p->dir, vel_vec, cmf_dir);
+    const double cos_theta = (xx < THOMSON_LIMIT) ? thomson_angle(p->rngstate) : 1. - ((f - 1) / xx);
+    scatter_dir(cmf_dir, cos_theta, p->rngstate, new_dir);
+    const double negvel[3] = {vel_vec[0] * -1., vel_vec[1] * -1., vel_vec[2] * -1.}; /* vec_scale(vel_vec, -1.) */
+    angle_ab(new_dir, negvel, p->dir);
+    set_pkt_restframe_from_cmf(p);
+  } else {
+    p->type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+    p->absorptiontype = ARTIS_ABSTYPE_GAMMA_COMPTON;
+    stat_inc(o, ARTIS_STAT_NT_FROM_GAMMA);
+  }
+}
+/* emit_gamma_isotropic gammapkt.cc:603 */
+static void emit_gamma_isotropic(artis_packet *p) {
+  double dir_cmf[3], vel_vec[3];
+  get_rand_isotropic_unitvec(p->rngstate, dir_cmf);
+  get_velocity(p->pos, -p->prop_time, vel_vec);
+  angle_ab(dir_cmf, vel_vec, p->dir);
+  set_pkt_restframe_from_cmf(p);
+  p->type = ARTIS_TYPE_GAMMA;
+}
+/* pair_production gammapkt.cc:618 */
+static void pair_production(Oracle *o, artis_packet *p) {
+  const double pair_rest_mass_energy = 1.022 * MEV;
+  const double gamma_energy = H_PLANCK * p->nu_cmf;
+  const double prob_gamma = pair_rest_mass_energy / gamma_energy;
+  if (rng_uniform(p->rngstate) > prob_gamma) {
+    p->type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+    p->absorptiontype = ARTIS_ABSTYPE_GAMMA_PAIRPRODUCTION;
+    stat_inc(o, ARTIS_STAT_NT_FROM_GAMMA);
+  } else {
+    p->nu_cmf = 0.511 * MEV / H_PLANCK;
+    emit_gamma_isotropic(p);
+  }
+}
+/* transport_gamma gammapkt.cc:655 */
+static void transport_gamma(Oracle *o, artis_packet *p, double t2) {
+  const double tau_next = -log((double)rng_uniform_pos(p->rngstate));
+  int next_cellindex = -1;
+  const double boundarydist = boundary_distance(o, p->dir, p->pos, p->prop_time, p->cellindex, &next_cellindex);
+  const int c = propcell_nonemptymgi(o, p->cellindex);
+  const double doppler = doppler_nucmf_on_nurf(p->pos, p->dir, p->prop_time);
+  const double ffegrp = (c >= 0) ? cell_ffegrp(o, c) : 0.;
+  const double chi_compton = (c >= 0) ? get_chi_compton_cmf(o, c, p->nu_cmf) * doppler : 0.;
+  const double chi_photo_electric = (c >= 0) ? get_chi_photo_electric_cmf(o, c, ffegrp, p->nu_cmf) * doppler : 0.;
+  const double chi_pair_prod = (c >= 0) ? get_chi_pair_prod_cmf(o, c, ffegrp, p->nu_cmf) * doppler : 0.;
+  const double chi_tot = chi_compton + chi_photo_electric + chi_pair_prod;
+  const double edist = chi_tot > 0. ? tau_next / chi_tot : DBL_MAXV;
+  if (!(edist >= 0)) ORACLE_FAIL(o, "transport_gamma: negative edist");
+  const double tdist = (t2 - p->prop_time) * CLIGHT_PROP;
+  if (!(tdist >= 0)) ORACLE_FAIL(o, "transport_gamma: negative tdist");
+  if ((boundarydist <= tdist) && (boundarydist <= edist)) {
+    move_pkt_withtime(p, boundarydist / 2.);
+    if (chi_tot > 0) update_gamma_dep(o, p, c, boundarydist);
+    move_pkt_withtime(p, boundarydist / 2.);
+    if (next_cellindex != p->cellindex) change_cell_or_escape(o, p, next_cellindex);
+  } else if ((tdist < boundarydist) && (tdist <= edist)) {
+    move_pkt_withtime(p, tdist / 2.);
+    if (chi_tot > 0) update_gamma_dep(o, p, c, tdist);
+    move_pkt_withtime(p, tdist / 2.);
+    p->prop_time = t2;
+  } else if ((edist < boundarydist) && (edist <= tdist)) {
+    move_pkt_withtime(p, edist / 2.);
+    if (chi_tot > 0) update_gamma_dep(o, p, c, edist);
+    move_pkt_withtime(p, edist / 2.);
+    const double chi_rnd = rng_uniform(p->rngstate) * chi_tot;
+    if (chi_compton > chi_rnd) {
+      compton_scatter(o, p);
+    } else if ((chi_compton + chi_photo_electric) > chi_rnd) {
+      p->type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+      p->absorptiontype = ARTIS_ABSTYPE_GAMMA_PHOTOELECTRIC;
+      stat_inc(o, ARTIS_STAT_NT_FROM_GAMMA);
+    } else {
+      pair_production(o, p);
+    }
+  } else {
+    ORACLE_FAIL(o, "transport_gamma: no branch");
+  }
+}
+/* do_gamma gammapkt.cc:911 */
+static void do_gamma(Oracle *o, artis_packet *p, double t2) {
+  stat_inc(o, ARTIS_STAT_X_GAMMA_STEPS);
+  transport_gamma(o, p, t2);
+  if (p->type != ARTIS_TYPE_GAMMA && p->type != ARTIS_TYPE_ESCAPE) {
+    if (o->est.scalars) o->est.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE] += p->e_cmf;
+  }
+}
+/* nonthermal::do_ntlepton_deposit nonthermal.cc:2529 with NT_ON == false (artisoptions_classic.h:95) */
+static void do_ntlepton_deposit(Oracle *o, artis_packet *p) {
+  if (o->est.scalars) o->est.scalars[ARTIS_SCALAR_NT_ENERGY_DEPOSITED] += p->e_cmf;
+  p->type = ARTIS_TYPE_KPKT;
+  stat_inc(o, ARTIS_STAT_NT_TO_KPKT);
+}
+
 /* ------------------------------------------------------------------ driver */
 /* packetprop_update_required update_packets.cc:321, restricted to the types this path owns */
-static int handled_type(int type) { return type == ARTIS_TYPE_RPKT || type == ARTIS_TYPE_KPKT || type == ARTIS_TYPE_PRE_KPKT; }
+static int handled_type(int type) {
+  return type == ARTIS_TYPE_RPKT || type == ARTIS_TYPE_KPKT || type == ARTIS_TYPE_PRE_KPKT || type == ARTIS_TYPE_GAMMA ||
+         type == ARTIS_TYPE_NTLEPTON_DEPOSITED;
+}
 
 static void oracle_init(Oracle *o, const artis_model *m, const artis_cellstate *cs, const artis_timestep *ts, artis_estimators *est) {
   memset(o, 0, sizeof(*o));
@@ -2112,6 +2364,12 @@ int artis_oracle_update_packets(const artis_model *m, const artis_cellstate *cs,
           chi.nu = -1.; chi.chi_escatter = 0.; chi.chi_freefree_heat = 0.; chi.chi_boundfree = 0.; chi.nonemptymgi = -1;
           while (do_rpkt_step(&o, p, ts_end, &chi) && !o.error) {
           }
+          break;
+        case ARTIS_TYPE_GAMMA:
+          do_gamma(&o, p, ts_end);
+          break;
+        case ARTIS_TYPE_NTLEPTON_DEPOSITED:
+          do_ntlepton_deposit(&o, p);
           break;
         case ARTIS_TYPE_PRE_KPKT:
           do_kpkt_blackbody(&o, p);

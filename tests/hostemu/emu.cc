@@ -36,6 +36,8 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
     e.env.E.J = est->J; e.env.E.nuJ = est->nuJ; e.env.E.ffheatingestimator = est->ffheatingestimator;
     e.env.E.colheatingestimator = est->colheatingestimator; e.env.E.gammaestimator = est->gammaestimator;
     e.env.E.bfheatingestimator = est->bfheatingestimator;
+    e.env.E.dep_estimator_gamma = est->dep_estimator_gamma;
+    e.env.E.scalars = est->scalars;
   }
   const DevModel &M = e.env.M;
   const int64_t ncell = M.npts_nonempty;
@@ -106,7 +108,7 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
       if (!lists[k].empty()) return true;
     return false;
   };
-  const int order[4] = {NEXT_SLOW, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
+  const int order[5] = {NEXT_SLOW, NEXT_GAMMA, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
   while (any() && !e.err) {
     for (int kind : order) {
       if (lists[kind].empty()) continue;
@@ -125,6 +127,8 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
           next = advance_ma(e.env, p, pi, budget * 8);
         } else if (kind == NEXT_KPKT) {
           next = advance_kpkt(e.env, p, pi);
+        } else if (kind == NEXT_GAMMA) {
+          next = advance_gamma(e.env, p, pi, budget);
         } else {
           next = advance_slow(e.env, p, pi);
         }

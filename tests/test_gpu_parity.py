@@ -32,9 +32,9 @@ def engine_mod():
     return engine
 
 
-def _run_case(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk, kfrac=0.2):
+def _run_case(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk, kfrac=0.2, gfrac=0.0):
     model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v)
-    pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=kfrac)
+    pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=kfrac, gamma_fraction=gfrac)
     n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
     pa, pb = pk0.copy(), pk0.copy()
     ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
@@ -61,6 +61,25 @@ def test_engine_matches_oracle(engine_mod, oracle, preset, ncoord, gridtype, thi
     parity.compare_estimators(eb, ea, EST_RTOL, "HIP engine vs oracle")
     assert ea.stats[abi.STAT_X_RPKT_STEPS] > npk
     print(f"worst float rel diff {rep['worst_rel']:.3e}; packet-steps {ea.stats[34] + ea.stats[35]}")
+    eng.close()
+
+
+@pytest.mark.parametrize("preset,ncoord,gridtype,npk", [
+    ("small", 8, abi.GRID_CARTESIAN3D, 20000),
+    ("tiny", 16, abi.GRID_SPHERICAL1D, 8000),
+    ("tiny", 6, abi.GRID_CYLINDRICAL2D, 8000),
+])
+def test_engine_matches_oracle_gamma_packets(engine_mod, oracle, preset, ncoord, gridtype, npk):
+    """gamma packets (k_gamma: gammapkt.cc transport, Compton / photoelectric / pair production) mixed with r- and
+    k-packets; thermalised gamma packets continue as k-packets in the same call"""
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, preset, ncoord, gridtype, 0.0, npk, gfrac=0.6)
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, "gamma: HIP engine vs oracle")
+    parity.compare_stats(eb, ea, "gamma: HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, "gamma: HIP engine vs oracle")
+    st = eb.stats_dict()
+    assert st["X_GAMMA_STEPS"] > 0.6 * npk and st["NT_STAT_FROM_GAMMA"] > 0.1 * npk
+    assert eb.scalars[0] > 0 and eb.dep_estimator_gamma.sum() > 0
+    print(f"worst float rel diff {rep['worst_rel']:.3e}; gamma steps {st['X_GAMMA_STEPS']}")
     eng.close()
 
 
@@ -158,7 +177,7 @@ def test_edge_cases(engine_mod):
     eng.update_packets(np.zeros(0, dtype=abi.PACKET_DTYPE), abi.Estimators(n, g))  # empty population
     pk = synth.make_packets(model, aux, 64)
     pk["type"][:16] = 100
-    pk["type"][16:32] = 10
+    pk["type"][16:32] = 21  # TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS
     pk["prop_time"][32:48] = ts.c.start + ts.c.width
     ref = pk.copy()
     eng.update_packets(pk, abi.Estimators(n, g))

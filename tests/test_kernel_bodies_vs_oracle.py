@@ -39,6 +39,30 @@ def test_packets_bit_exact(oracle, preset, ncoord, gridtype, thick_v, npk, budge
     assert np.count_nonzero(pa["type"] == abi.TYPE_ESCAPE) > 0
 
 
+@pytest.mark.parametrize("preset,ncoord,gridtype,npk,budget", [
+    ("small", 8, abi.GRID_CARTESIAN3D, 3000, 3),
+    ("tiny", 16, abi.GRID_SPHERICAL1D, 2000, 1),
+    ("tiny", 6, abi.GRID_CYLINDRICAL2D, 2000, 1000000),
+])
+def test_gamma_packets_bit_exact(oracle, preset, ncoord, gridtype, npk, budget):
+    """TYPE_GAMMA packets (transport_gamma gammapkt.cc:655: Compton scattering incl. the Thomson limit, photoelectric
+    absorption, pair production) and their hand-over to the thermal pool (do_ntlepton_deposit -> k-packet) in one
+    population with r- and k-packets."""
+    model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype)
+    pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=0.2, gamma_fraction=0.6)
+    ngamma = np.count_nonzero(pk0["type"] == abi.TYPE_GAMMA)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, budget)
+    parity.compare_packets(pb, pa, 0.0, "gamma: kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, "gamma: kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, "gamma: kernel bodies vs oracle")
+    st = ea.stats_dict()
+    assert st["X_GAMMA_STEPS"] > ngamma and st["NT_STAT_FROM_GAMMA"] > 0.2 * ngamma and st["NT_STAT_TO_KPKT"] == st["NT_STAT_FROM_GAMMA"]
+    assert ea.scalars[0] > 0 and ea.scalars[0] == ea.scalars[1]          # every deposit became a k-packet at once
+    assert abs(ea.dep_estimator_gamma.sum() / ea.scalars[0] - 1) < 0.2   # path estimator ~ discrete deposition
+    assert np.count_nonzero(pa["type"] == abi.TYPE_NTLEPTON_DEPOSITED) == 0
+    assert np.count_nonzero((pa["type"] == abi.TYPE_ESCAPE) & (pa["escape_type"] == abi.TYPE_GAMMA)) > 0
+
+
 def test_budget_independence(oracle):
     """A launch boundary may fall between any two do_packet() calls without changing a packet's history."""
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
@@ -71,7 +95,7 @@ def test_empty_and_untouched_packets(oracle):
     emu.update_packets(model, cs, ts, empty, abi.Estimators(n, g))
     pk = synth.make_packets(model, aux, 64)
     pk["type"][:16] = 100  # TYPE_RADIOACTIVE_PELLET
-    pk["type"][16:32] = 10  # TYPE_GAMMA
+    pk["type"][16:32] = 21  # TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS
     pk["prop_time"][32:48] = ts.c.start + ts.c.width
     ref = pk.copy()
     emu.update_packets(model, cs, ts, pk, abi.Estimators(n, g))
