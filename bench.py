@@ -201,7 +201,7 @@ def main():
         achieved = alg_bytes / (k_ms_per_step * 1e-3) / 1e9 if k_ms_per_step > 0 else 0.0
         both = (alg_thermal + alg_rpkt) / ((bd["thermal_ms"] + bd["rpkt_ms"]) * 1e-3) / 1e9
         # HBM traffic of the dominant kernel per launch: from the committed rocprofv3 --pmc passes of this same command
-        # (profiles/<round>/pmc_traffic.json, written by tools_pmc_summary.py; FETCH_SIZE doubled as
+        # (profiles/<round>/pmc_traffic.json, written by tools/pmc_summary.py; FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950). None when the workload is not the profiled one.
         traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect PMC counters for the propagation kernels: separate rocprofv3 passes (kernel-trace + pmc only).
 # (A pass with TA_* counters did not finish within 300 s on this pool and is left out.)
-# usage (on the GPU box): bash tools_pmc.sh [packets]   -> gpurun_out/pmc/<pass>/..., gpurun_out/pmc_<pass>.log
+# usage (on the GPU box): bash tools/pmc_collect.sh [packets]   -> gpurun_out/pmc/<pass>/..., gpurun_out/pmc_<pass>.log
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 P=${1:-10000000}
