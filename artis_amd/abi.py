@@ -11,7 +11,10 @@ import ctypes as C
 import numpy as np
 
 NSTATS = 64
-NSCALARS = 2  # ARTIS_SCALAR_GAMMA_DEP_DISCRETE, ARTIS_SCALAR_NT_ENERGY_DEPOSITED
+NSCALARS = 11  # ARTIS_SCALAR_* of include/artis_amd.h
+SCALAR_NAMES = ["gamma_dep_discrete", "nt_energy_deposited", "pellet_decays", "gamma_emission", "positron_emission",
+                "electron_emission", "alpha_emission", "spfission_dep_discrete", "electron_dep_discrete",
+                "positron_dep_discrete", "alpha_dep_discrete"]
 STAT_COUNT = 34
 STAT_X_RPKT_STEPS = 34
 STAT_X_KPKT_STEPS = 35
@@ -23,6 +26,11 @@ TYPE_GAMMA = 10
 TYPE_RPKT = 11
 TYPE_KPKT = 12
 TYPE_NTLEPTON_DEPOSITED = 20
+TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS = 21
+TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS = 22
+TYPE_NONTHERMAL_PREDEPOSIT_ALPHA = 23
+TYPE_NTALPHA_FISPROD_DEPOSITED = 24
+TYPE_RADIOACTIVE_PELLET = 100
 TYPE_ESCAPE = 32
 TYPE_PRE_KPKT = 120
 EMTYPE_NOTSET = -9999000
@@ -158,7 +166,8 @@ class CTimestep(C.Structure):
 class CEstimators(C.Structure):
     _fields_ = [("J", _F64P), ("nuJ", _F64P), ("ffheatingestimator", _F64P), ("colheatingestimator", _F64P),
                 ("gammaestimator", _F64P), ("bfheatingestimator", _F64P), ("stats", _I64P),
-                ("dep_estimator_gamma", _F64P), ("scalars", _F64P)]
+                ("dep_estimator_gamma", _F64P), ("scalars", _F64P), ("dep_estimator_electron", _F64P),
+                ("dep_estimator_positron", _F64P), ("dep_estimator_alpha", _F64P)]
 
 
 def _as_ptr(arr: np.ndarray, ptype):
@@ -240,11 +249,16 @@ class Estimators:
         self.stats = np.zeros(NSTATS, dtype=np.int64)
         self.dep_estimator_gamma = np.zeros(n)
         self.scalars = np.zeros(NSCALARS)
+        self.dep_estimator_electron = np.zeros(n)
+        self.dep_estimator_positron = np.zeros(n)
+        self.dep_estimator_alpha = np.zeros(n)
         self.c = CEstimators(
             _as_ptr(self.J, _F64P), _as_ptr(self.nuJ, _F64P), _as_ptr(self.ffheatingestimator, _F64P),
             _as_ptr(self.colheatingestimator, _F64P), _as_ptr(self.gammaestimator, _F64P),
             _as_ptr(self.bfheatingestimator, _F64P), _as_ptr(self.stats, _I64P),
-            _as_ptr(self.dep_estimator_gamma, _F64P), _as_ptr(self.scalars, _F64P))
+            _as_ptr(self.dep_estimator_gamma, _F64P), _as_ptr(self.scalars, _F64P),
+            _as_ptr(self.dep_estimator_electron, _F64P), _as_ptr(self.dep_estimator_positron, _F64P),
+            _as_ptr(self.dep_estimator_alpha, _F64P))
 
     def ref(self):
         return C.byref(self.c)
@@ -253,7 +267,8 @@ class Estimators:
         return {"J": self.J, "nuJ": self.nuJ, "ffheatingestimator": self.ffheatingestimator,
                 "colheatingestimator": self.colheatingestimator, "gammaestimator": self.gammaestimator,
                 "bfheatingestimator": self.bfheatingestimator, "dep_estimator_gamma": self.dep_estimator_gamma,
-                "scalars": self.scalars}
+                "scalars": self.scalars, "dep_estimator_electron": self.dep_estimator_electron,
+                "dep_estimator_positron": self.dep_estimator_positron, "dep_estimator_alpha": self.dep_estimator_alpha}
 
     def stats_dict(self):
         return {STAT_NAMES[i]: int(self.stats[i]) for i in range(NSTATS)}

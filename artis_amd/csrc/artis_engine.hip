@@ -773,9 +773,9 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   }
   ARTIS_CACHE_ARRAYS(CA, h)
 #undef CA
-  // estimators: one contiguous block [J | nuJ | ff | col | gamma | bfheat | dep_gamma | scalars]
+  // estimators: one contiguous block [J | nuJ | ff | col | gamma | bfheat | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars]
   const int64_t g = h.nbfcontinua_ground > 0 ? h.nbfcontinua_ground : 1;
-  e->est_ndoubles = ncell * 5 + 2 * ncell * g + ARTIS_NSCALARS;  // ... | dep_estimator_gamma | scalars]
+  e->est_ndoubles = ncell * 8 + 2 * ncell * g + ARTIS_NSCALARS;  // ... | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars]
   HIP_TRY(hipMalloc((void **)&e->d_est, sizeof(double) * (size_t)e->est_ndoubles));
   HIP_TRY(hipMemset(e->d_est, 0, sizeof(double) * (size_t)e->est_ndoubles));
   e->E.J = e->d_est;
@@ -785,7 +785,10 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   e->E.gammaestimator = e->d_est + 4 * ncell;
   e->E.bfheatingestimator = e->d_est + 4 * ncell + ncell * g;
   e->E.dep_estimator_gamma = e->d_est + 4 * ncell + 2 * ncell * g;
-  e->E.scalars = e->d_est + 5 * ncell + 2 * ncell * g;
+  e->E.dep_estimator_electron = e->d_est + 5 * ncell + 2 * ncell * g;
+  e->E.dep_estimator_positron = e->d_est + 6 * ncell + 2 * ncell * g;
+  e->E.dep_estimator_alpha = e->d_est + 7 * ncell + 2 * ncell * g;
+  e->E.scalars = e->d_est + 8 * ncell + 2 * ncell * g;
   HIP_TRY(hipMalloc((void **)&e->d_stats, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
@@ -1112,7 +1115,10 @@ int artis_amd_estimators_download(artis_amd_engine *e, artis_estimators *est) {
   add(est->gammaestimator, src + 4 * ncell, ncell * g);
   add(est->bfheatingestimator, src + 4 * ncell + ncell * g, ncell * g);
   add(est->dep_estimator_gamma, src + 4 * ncell + 2 * ncell * g, ncell);
-  add(est->scalars, src + 5 * ncell + 2 * ncell * g, ARTIS_NSCALARS);
+  add(est->dep_estimator_electron, src + 5 * ncell + 2 * ncell * g, ncell);
+  add(est->dep_estimator_positron, src + 6 * ncell + 2 * ncell * g, ncell);
+  add(est->dep_estimator_alpha, src + 7 * ncell + 2 * ncell * g, ncell);
+  add(est->scalars, src + 8 * ncell + 2 * ncell * g, ARTIS_NSCALARS);
   if (est->stats) {
     unsigned long long st[ARTIS_NSTATS];
     HIP_TRY(hipMemcpy(st, e->d_stats, sizeof(st), hipMemcpyDeviceToHost));

@@ -256,7 +256,7 @@ inline PktSoA carve_pkt_soa(void *base, int64_t n) {
   double *d = (double *)base;
   double **cols64[] = {&P.prop_time, &P.pos_x, &P.pos_y, &P.pos_z, &P.dir_x, &P.dir_y, &P.dir_z, &P.nu_cmf, &P.e_cmf, &P.nu_rf,
                        &P.e_rf, &P.stokes_q, &P.stokes_u, &P.em_pos_x, &P.em_pos_y, &P.em_pos_z, &P.trueem_pos_x, &P.trueem_pos_y,
-                       &P.trueem_pos_z, &P.absorptionfreq, &P.chi_nu, &P.chi_es, &P.chi_ff, &P.chi_bf};
+                       &P.trueem_pos_z, &P.absorptionfreq, &P.chi_nu, &P.chi_es, &P.chi_ff, &P.chi_bf, &P.tdecay};
   static_assert(sizeof(cols64) / sizeof(cols64[0]) == PKT_NCOL64, "64-bit column count");
   for (auto c : cols64) {
     *c = d;
@@ -267,7 +267,7 @@ inline PktSoA carve_pkt_soa(void *base, int64_t n) {
   w += 4 * n8;
   int32_t **cols32[] = {&P.next_trans, &P.nscatterings, &P.type, &P.cellindex, &P.emissiontype, &P.absorptiontype,
                         &P.trueemissiontype, &P.escape_type, &P.chi_mgi, &P.ma_element, &P.ma_ion, &P.ma_level, &P.ma_line,
-                        &P.ma_origin, &P.pend, &P.pend_arg};
+                        &P.ma_origin, &P.pend, &P.pend_arg, &P.pellet_decaytype, &P.originated_particle};
   for (auto c : cols32) {
     *c = (int32_t *)w;
     w += n8;

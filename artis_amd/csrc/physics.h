@@ -2522,8 +2522,98 @@ AHD void do_ntlepton_deposit(const Env &env, Pkt &p) {
   ARTIS_STAT(env, ARTIS_STAT_NT_TO_KPKT);
 }
 
+// nonthermal::do_ntalpha_fisprod_deposit nonthermal.cc:2520
+AHD void do_ntalpha_fisprod_deposit(const Env &env, Pkt &p) {
+  ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_NT_ENERGY_DEPOSITED], p.e_cmf);
+  p.type = ARTIS_TYPE_KPKT;
+  ARTIS_STAT(env, ARTIS_STAT_NT_TO_KPKT);
+}
+// do_nonthermal_predeposit update_packets.cc:42 with PARTICLE_THERMALISATION_SCHEME == INSTANTFULLDEPOSITION
+AHD void do_nonthermal_predeposit(const Env &env, Pkt &p, int64_t pi) {
+  const double e_cmf_deposited = p.e_cmf;
+  const int c = env.M.propcell_nonemptymgi[p.cellindex];
+  const int priortype = p.type;
+  p.type = (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED : ARTIS_TYPE_NTLEPTON_DEPOSITED;
+  if (env.P.originated_particle[pi] != 0) {
+    if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS) {
+      ARTIS_EST_ADD(&env.E.dep_estimator_electron[c], e_cmf_deposited);
+      ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ELECTRON_DEP_DISCRETE], p.e_cmf);
+    } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS) {
+      ARTIS_EST_ADD(&env.E.dep_estimator_positron[c], e_cmf_deposited);
+      ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_POSITRON_DEP_DISCRETE], p.e_cmf);
+    } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) {
+      ARTIS_EST_ADD(&env.E.dep_estimator_alpha[c], e_cmf_deposited);
+      ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ALPHA_DEP_DISCRETE], p.e_cmf);
+    }
+  }
+}
+// update_pellet update_packets.cc:185 with pellet_gamma_decay gammapkt.cc:894
+AHD void update_pellet(const Env &env, Pkt &p, int64_t pi) {
+  const double t2 = env.S.ts_end;
+  const double ts = p.prop_time;
+  const double tdecay = env.P.tdecay[pi];
+  if (tdecay > t2) {
+    const double scale = t2 / ts;
+    p.px = p.px * scale;
+    p.py = p.py * scale;
+    p.pz = p.pz * scale;
+    p.prop_time = t2;
+  } else if (tdecay > ts) {
+    ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_PELLET_DECAYS], 1.);
+    p.prop_time = tdecay;
+    const double scale = tdecay / ts;
+    p.px = p.px * scale;
+    p.py = p.py * scale;
+    p.pz = p.pz * scale;
+    if (env.P.originated_particle[pi] != 0) {
+      const int decaytype = env.P.pellet_decaytype[pi];
+      if (decaytype == ARTIS_DECAYTYPE_BETAPLUS) {
+        p.type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS;
+        ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_POSITRON_EMISSION], p.e_cmf);
+      } else if (decaytype == ARTIS_DECAYTYPE_BETAMINUS) {
+        p.type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS;
+        ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ELECTRON_EMISSION], p.e_cmf);
+      } else if (decaytype == ARTIS_DECAYTYPE_ALPHA) {
+        ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ALPHA_EMISSION], p.e_cmf);
+        p.type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA;
+      } else if (decaytype == ARTIS_DECAYTYPE_SPONTFISSION) {
+        ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_SPFISSION_DEP_DISCRETE], p.e_cmf);
+        p.type = ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED;
+      } else {
+        fail(env, 90);
+        p.type = ARTIS_TYPE_ESCAPE;  // leave the work lists
+        return;
+      }
+      env.P.em_time[pi] = (float)p.prop_time;
+      env.P.absorptiontype[pi] = ARTIS_ABSTYPE_PELLET_PARTICLEDECAY;
+    } else {
+      ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_EMISSION], p.e_cmf);
+      if (p.nu_cmf < 0) {  // no gamma spectrum known for the nuclide: straight to a k-packet
+        p.type = ARTIS_TYPE_KPKT;
+        env.P.absorptiontype[pi] = ARTIS_ABSTYPE_PELLET_NOGAMMASPEC;
+      } else {
+        emit_gamma_isotropic(p);
+      }
+    }
+  } else if ((tdecay > 0) && (env.S.nts == 0)) {
+    p.e_cmf *= tdecay / env.M.tmin;
+    p.type = ARTIS_TYPE_PRE_KPKT;
+    env.P.absorptiontype[pi] = ARTIS_ABSTYPE_PELLET_BEFORESIMSTART;
+    ARTIS_STAT(env, ARTIS_STAT_K_FROM_EARLIERDECAY);
+    p.prop_time = env.M.tmin;
+  } else {
+    fail(env, 91);
+    p.type = ARTIS_TYPE_ESCAPE;
+  }
+}
+
 // ---------------------------------------------------------------- packet load/store and the per-thread driver
-AHD bool type_gamma(int type) { return type == ARTIS_TYPE_GAMMA || type == ARTIS_TYPE_NTLEPTON_DEPOSITED; }
+// the packet types that do not use the cell cache (get_packet_cellcachegroupid update_packets.cc:340): handled by k_gamma
+AHD bool type_gamma(int type) {
+  return type == ARTIS_TYPE_GAMMA || type == ARTIS_TYPE_NTLEPTON_DEPOSITED || type == ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED ||
+         type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS || type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS ||
+         type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA || type == ARTIS_TYPE_RADIOACTIVE_PELLET;
+}
 AHD bool type_handled(int type) {
   return type == ARTIS_TYPE_RPKT || type == ARTIS_TYPE_KPKT || type == ARTIS_TYPE_PRE_KPKT || type_gamma(type);
 }
@@ -2681,16 +2771,22 @@ AHD int advance_kpkt(const Env &env, Pkt &p, int64_t pi) {
   return classify(p, env.S.ts_end);
 }
 
-// ---- gamma kernel body: one iteration = one do_packet() call for TYPE_GAMMA (do_gamma) or TYPE_NTLEPTON_DEPOSITED
-// (update_packets.cc:264, :283). Returns true while the packet stays with this kernel.
+// ---- gamma kernel body: one iteration = one do_packet() call (update_packets.cc:257) for a type that does not use the
+// cell cache: pellet, gamma packet, non-thermal pre-deposit and deposit types. Returns true while the packet stays with this kernel.
 AHD bool gamma_can_continue(const Pkt &p, double ts_end) { return type_gamma(p.type) && p.prop_time < ts_end; }
 AHD bool gamma_iter(const Env &env, Pkt &p, int64_t pi) {
   if (p.type == ARTIS_TYPE_GAMMA) {
     do_gamma(env, p, pi);
-  } else {
+  } else if (p.type == ARTIS_TYPE_RADIOACTIVE_PELLET) {
+    update_pellet(env, p, pi);
+  } else if (p.type == ARTIS_TYPE_NTLEPTON_DEPOSITED) {
     do_ntlepton_deposit(env, p);
-    env.P.chi_mgi[pi] = -1;
+  } else if (p.type == ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED) {
+    do_ntalpha_fisprod_deposit(env, p);
+  } else {
+    do_nonthermal_predeposit(env, p, pi);
   }
+  env.P.chi_mgi[pi] = -1;
   return gamma_can_continue(p, env.S.ts_end);
 }
 AHD int advance_gamma(const Env &env, Pkt &p, int64_t pi, int budget) {
@@ -2729,6 +2825,9 @@ AHD void aos_to_soa(const artis_packet &a, const PktSoA &P, int64_t i) {
   P.em_pos_x[i] = a.em_pos[0]; P.em_pos_y[i] = a.em_pos[1]; P.em_pos_z[i] = a.em_pos[2];
   P.trueem_pos_x[i] = a.trueem_pos[0]; P.trueem_pos_y[i] = a.trueem_pos[1]; P.trueem_pos_z[i] = a.trueem_pos[2];
   P.absorptionfreq[i] = a.absorptionfreq;
+  P.tdecay[i] = a.tdecay;
+  P.pellet_decaytype[i] = a.pellet_decaytype;
+  P.originated_particle[i] = a.originated_from_particlenotgamma ? 1 : 0;
   P.em_time[i] = a.em_time; P.trueem_time[i] = a.trueem_time; P.escape_time[i] = a.escape_time;
   P.chi_nu[i] = -1.; P.chi_es[i] = 0.; P.chi_ff[i] = 0.; P.chi_bf[i] = 0.; P.chi_mgi[i] = -1;
   P.ma_element[i] = -1; P.ma_ion[i] = -1; P.ma_level[i] = -1; P.ma_line[i] = -99; P.ma_origin[i] = 0;

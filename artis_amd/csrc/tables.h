@@ -153,11 +153,12 @@ struct DevStep {
 struct DevEst {
   double *J, *nuJ, *ffheatingestimator, *colheatingestimator, *gammaestimator, *bfheatingestimator;
   double *dep_estimator_gamma;  // [cell] gammapkt.cc:568
+  double *dep_estimator_electron, *dep_estimator_positron, *dep_estimator_alpha;  // [cell] update_packets.cc:160-173
   double *scalars;              // [ARTIS_NSCALARS]
 };
 
 // Packet population, structure-of-arrays (one array per field of the reference's struct Packet,
-// packet.h:117-169, minus the fields this path never touches: tdecay, number, pellet_*).
+// packet.h:117-169, minus the fields this path never touches: number, pellet_nucindex).
 // "hot" fields are loaded into registers for the whole life of a thread; "cold" fields are
 // written through to HBM at the (rare) events that change them.
 struct PktSoA {
@@ -169,6 +170,9 @@ struct PktSoA {
   int32_t *emissiontype, *absorptiontype, *trueemissiontype, *escape_type;
   double *em_pos_x, *em_pos_y, *em_pos_z, *trueem_pos_x, *trueem_pos_y, *trueem_pos_z, *absorptionfreq;
   float *em_time, *trueem_time, *escape_time;
+  // read-only here, used by update_pellet() (update_packets.cc:185)
+  double *tdecay;
+  int32_t *pellet_decaytype, *originated_particle;
   // engine-private state that lets a kernel boundary fall anywhere in a packet's history:
   // the packet's ContinuumOpacity (rpkt.h:70; chi_mgi < 0 = not valid) ...
   double *chi_nu, *chi_es, *chi_ff, *chi_bf;
@@ -183,7 +187,7 @@ struct PktSoA {
   int64_t n;
 };
 // number of 8-byte and 4-byte columns above (used to carve one allocation)
-constexpr int PKT_NCOL64 = 13 + 7 + 4;
-constexpr int PKT_NCOL32 = 4 /*rng*/ + 4 + 4 + 3 + 6 + 2;
+constexpr int PKT_NCOL64 = 13 + 7 + 4 + 1;
+constexpr int PKT_NCOL32 = 4 /*rng*/ + 4 + 4 + 3 + 6 + 2 + 2;
 
 }  // namespace artis

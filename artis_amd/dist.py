@@ -37,6 +37,7 @@ def allreduce_estimators(block, dist=None):
 
 def flatten_estimators(est) -> np.ndarray:
     """Host estimators in the engine's block order
-    [J | nuJ | ffheating | colheating | gamma | bfheating | dep_estimator_gamma | scalars]."""
+    [J | nuJ | ffheating | colheating | gamma | bfheating | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars]."""
     return np.concatenate([est.J, est.nuJ, est.ffheatingestimator, est.colheatingestimator, est.gammaestimator,
-                           est.bfheatingestimator, est.dep_estimator_gamma, est.scalars])
+                           est.bfheatingestimator, est.dep_estimator_gamma, est.dep_estimator_electron,
+                           est.dep_estimator_positron, est.dep_estimator_alpha, est.scalars])

@@ -505,7 +505,8 @@ def make_timestep(t: float, width_frac: float = 0.05, vmax: float = 2.4e9, nts: 
 
 
 def make_packets(model: abi.Model, aux: dict, npackets: int, seed_base: int = 12345, kpkt_fraction: float = 0.1,
-                 e_total: float = 1e45, seed: int = 99, gamma_fraction: float = 0.0) -> np.ndarray:
+                 e_total: float = 1e45, seed: int = 99, gamma_fraction: float = 0.0, pellet_fraction: float = 0.0,
+                 ts_width_frac: float = 0.05, early_pellets: bool = False) -> np.ndarray:
     """Packets at the start of the timestep: thermal energy waiting to be emitted (TYPE_PRE_KPKT -> blackbody
     r-packet, kpkt.cc:399) or k-packets (kpkt.cc:425), placed in non-empty cells with probability ~ rho * X(Co,Ni,Fe)."""
     rng = np.random.default_rng(seed)
@@ -583,8 +584,26 @@ def make_packets(model: abi.Model, aux: dict, npackets: int, seed_base: int = 12
         pk["e_rf"] = np.where(isg, pk["e_cmf"] / doppler, pk["e_rf"])
     pk["escape_time"] = -1.0
     pk["tdecay"] = -1.0
-    pk["number"] = np.arange(npackets, dtype=np.int32)
     pk["pellet_decaytype"] = -1
+    if pellet_fraction > 0:
+        # pellets as packet_init() leaves them (packet.cc): a decay time, the gamma line already chosen (nu_cmf, or -1 for
+        # a nuclide without a gamma spectrum), or marked as a particle-emitting decay with its decay type
+        isp = (rng.random(npackets) < pellet_fraction) & (pk["type"] != abi.TYPE_GAMMA)
+        width = t * ts_width_frac
+        tdec = t + rng.random(npackets) * 3.0 * width          # about a third decays within the timestep
+        if early_pellets:                                      # nts == 0 only: some decayed before the simulation start
+            tdec = np.where(rng.random(npackets) < 0.3, t * (0.2 + 0.7 * rng.random(npackets)), tdec)
+        particle = rng.random(npackets) < 0.35
+        dtype = rng.choice([0, 2, 3, 5], size=npackets)        # alpha, beta+, beta-, spontaneous fission (decay.h:21)
+        lines_mev = np.array([0.158, 0.48, 0.75, 0.812, 0.847, 1.238, 1.771, 2.598])
+        nu_line = lines_mev[rng.integers(0, len(lines_mev), npackets)] * 1.0e6 * 1.6021772e-12 / 6.6260755e-27
+        nu_line = np.where(rng.random(npackets) < 0.05, -1.0, nu_line)
+        pk["type"] = np.where(isp, abi.TYPE_RADIOACTIVE_PELLET, pk["type"])
+        pk["tdecay"] = np.where(isp, tdec, pk["tdecay"])
+        pk["originated_from_particlenotgamma"] = np.where(isp & particle, 1, 0)
+        pk["pellet_decaytype"] = np.where(isp, np.where(particle, dtype, 1), -1)
+        pk["nu_cmf"] = np.where(isp, nu_line, pk["nu_cmf"])
+    pk["number"] = np.arange(npackets, dtype=np.int32)
     pk["pellet_nucindex"] = -1
     abi.seed_packet_rng(pk, seed_base)
     return pk
@@ -599,15 +618,15 @@ PRESETS = {
 
 
 def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTESIAN3D, seed: int = 1,
-          t_days: float = 20.0, thick_below_v: float = 0.0, width_frac: float = 0.05):
+          t_days: float = 20.0, thick_below_v: float = 0.0, width_frac: float = 0.05, nts: int = 10, tmin_days: float = 2.0):
     """One-call construction of (Model, CellState, Timestep, aux)."""
     elements, nl, lf, npx = PRESETS[preset]
     atomic = make_atomic(seed=seed, elements=elements, nlevels_per_ion=nl, line_fraction=lf, nphixspoints=npx)
-    grid, cells, aux = make_grid_and_cells(atomic, ncoord=ncoord, gridtype=gridtype, t_days=t_days,
+    grid, cells, aux = make_grid_and_cells(atomic, ncoord=ncoord, gridtype=gridtype, t_days=t_days, tmin_days=tmin_days,
                                            thick_below_v=thick_below_v, seed=seed + 100)
     md = {k: v for k, v in atomic.items() if not k.startswith("_")}
     md.update(grid)
     model = abi.Model(md)
     cs = abi.CellState(cells)
-    ts = make_timestep(aux["t"], width_frac=width_frac, vmax=grid["vmax"])
+    ts = make_timestep(aux["t"], width_frac=width_frac, vmax=grid["vmax"], nts=nts)
     return model, cs, ts, aux

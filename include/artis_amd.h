@@ -53,6 +53,9 @@ enum {
 #define ARTIS_ABSTYPE_GAMMA_COMPTON (-3)
 #define ARTIS_ABSTYPE_GAMMA_PHOTOELECTRIC (-4)
 #define ARTIS_ABSTYPE_GAMMA_PAIRPRODUCTION (-5)
+#define ARTIS_ABSTYPE_PELLET_NOGAMMASPEC (-6)
+#define ARTIS_ABSTYPE_PELLET_BEFORESIMSTART (-7)
+#define ARTIS_ABSTYPE_PELLET_PARTICLEDECAY (-10)
 
 /* globals.h:21 enum ma_action */
 enum {
@@ -306,12 +309,30 @@ typedef struct artis_estimators {
   int64_t *stats;              /* [ARTIS_NSTATS] stats.cc event counters */
   double *dep_estimator_gamma; /* [npts_nonempty] globals::dep_estimator_gamma (gammapkt.cc:568); may be NULL */
   double *scalars;             /* [ARTIS_NSCALARS] per-timestep sums, see ARTIS_SCALAR_*; may be NULL */
+  /* [npts_nonempty] globals::dep_estimator_electron / _positron / _alpha (update_packets.cc:160-173); may be NULL */
+  double *dep_estimator_electron;
+  double *dep_estimator_positron;
+  double *dep_estimator_alpha;
 } artis_estimators;
 enum {
   ARTIS_SCALAR_GAMMA_DEP_DISCRETE = 0,   /* globals::timesteps[nts].gamma_dep_discrete gammapkt.cc:926 */
-  ARTIS_SCALAR_NT_ENERGY_DEPOSITED = 1,  /* nonthermal.cc nt_energy_deposited (do_ntlepton_deposit :2530) */
-  ARTIS_NSCALARS = 2
+  ARTIS_SCALAR_NT_ENERGY_DEPOSITED = 1,  /* nonthermal.cc nt_energy_deposited (:2524, :2530) */
+  /* globals::timesteps[nts].* written by update_pellet() (update_packets.cc:199-231) ... */
+  ARTIS_SCALAR_PELLET_DECAYS = 2,
+  ARTIS_SCALAR_GAMMA_EMISSION = 3,
+  ARTIS_SCALAR_POSITRON_EMISSION = 4,
+  ARTIS_SCALAR_ELECTRON_EMISSION = 5,
+  ARTIS_SCALAR_ALPHA_EMISSION = 6,
+  ARTIS_SCALAR_SPFISSION_DEP_DISCRETE = 7,
+  /* ... and by do_nonthermal_predeposit() (update_packets.cc:162-172) */
+  ARTIS_SCALAR_ELECTRON_DEP_DISCRETE = 8,
+  ARTIS_SCALAR_POSITRON_DEP_DISCRETE = 9,
+  ARTIS_SCALAR_ALPHA_DEP_DISCRETE = 10,
+  ARTIS_NSCALARS = 11
 };
+/* decay::DecayType values read from Packet::pellet_decaytype (decay.h:21-26) */
+enum { ARTIS_DECAYTYPE_ALPHA = 0, ARTIS_DECAYTYPE_ELECTRONCAPTURE = 1, ARTIS_DECAYTYPE_BETAPLUS = 2, ARTIS_DECAYTYPE_BETAMINUS = 3,
+       ARTIS_DECAYTYPE_NONE = 4, ARTIS_DECAYTYPE_SPONTFISSION = 5 };
 
 /* ---- engine ---------------------------------------------------------------- */
 typedef struct artis_amd_engine artis_amd_engine;

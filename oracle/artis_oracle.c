@@ -2315,11 +2315,99 @@ static void do_ntlepton_deposit(Oracle *o, artis_packet *p) {
   stat_inc(o, ARTIS_STAT_NT_TO_KPKT);
 }
 
+/* nonthermal::do_ntalpha_fisprod_deposit nonthermal.cc:2520 */
+static void do_ntalpha_fisprod_deposit(Oracle *o, artis_packet *p) {
+  if (o->est.scalars) o->est.scalars[ARTIS_SCALAR_NT_ENERGY_DEPOSITED] += p->e_cmf;
+  p->type = ARTIS_TYPE_KPKT;
+  stat_inc(o, ARTIS_STAT_NT_TO_KPKT);
+}
+static inline void scalar_add(Oracle *o, int i, double v) {
+  if (o->est.scalars) o->est.scalars[i] += v;
+}
+/* do_nonthermal_predeposit update_packets.cc:42 with PARTICLE_THERMALISATION_SCHEME == INSTANTFULLDEPOSITION */
+static void do_nonthermal_predeposit(Oracle *o, artis_packet *p) {
+  const double e_cmf_deposited = p->e_cmf;
+  const int c = propcell_nonemptymgi(o, p->cellindex);
+  const int priortype = p->type;
+  const int deposit_type = (p->type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED : ARTIS_TYPE_NTLEPTON_DEPOSITED;
+  p->type = deposit_type; /* absorption happens */
+  if (p->originated_from_particlenotgamma) {
+    if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS) {
+      if (o->est.dep_estimator_electron) o->est.dep_estimator_electron[c] += e_cmf_deposited;
+      scalar_add(o, ARTIS_SCALAR_ELECTRON_DEP_DISCRETE, p->e_cmf);
+    } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS) {
+      if (o->est.dep_estimator_positron) o->est.dep_estimator_positron[c] += e_cmf_deposited;
+      scalar_add(o, ARTIS_SCALAR_POSITRON_DEP_DISCRETE, p->e_cmf);
+    } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) {
+      if (o->est.dep_estimator_alpha) o->est.dep_estimator_alpha[c] += e_cmf_deposited;
+      scalar_add(o, ARTIS_SCALAR_ALPHA_DEP_DISCRETE, p->e_cmf);
+    }
+  }
+}
+/* pellet_gamma_decay gammapkt.cc:894 */
+static void pellet_gamma_decay(artis_packet *p) {
+  if (p->nu_cmf < 0) {
+    p->type = ARTIS_TYPE_KPKT;
+    p->absorptiontype = ARTIS_ABSTYPE_PELLET_NOGAMMASPEC;
+    return;
+  }
+  emit_gamma_isotropic(p);
+}
+/* update_pellet update_packets.cc:185 */
+static void update_pellet(Oracle *o, artis_packet *p, double t2) {
+  const double ts = p->prop_time;
+  const double tdecay = p->tdecay;
+  if (tdecay > t2) {
+    const double scale = t2 / ts; /* vec_scale(pkt.pos, t2 / ts) */
+    p->pos[0] = p->pos[0] * scale; p->pos[1] = p->pos[1] * scale; p->pos[2] = p->pos[2] * scale;
+    p->prop_time = t2;
+  } else if (tdecay > ts) {
+    scalar_add(o, ARTIS_SCALAR_PELLET_DECAYS, 1.);
+    p->prop_time = tdecay;
+    const double scale = tdecay / ts;
+    p->pos[0] = p->pos[0] * scale; p->pos[1] = p->pos[1] * scale; p->pos[2] = p->pos[2] * scale;
+    if (p->originated_from_particlenotgamma) {
+      if (p->pellet_decaytype == ARTIS_DECAYTYPE_BETAPLUS) {
+        p->type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS;
+        scalar_add(o, ARTIS_SCALAR_POSITRON_EMISSION, p->e_cmf);
+      } else if (p->pellet_decaytype == ARTIS_DECAYTYPE_BETAMINUS) {
+        p->type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS;
+        scalar_add(o, ARTIS_SCALAR_ELECTRON_EMISSION, p->e_cmf);
+      } else if (p->pellet_decaytype == ARTIS_DECAYTYPE_ALPHA) {
+        scalar_add(o, ARTIS_SCALAR_ALPHA_EMISSION, p->e_cmf);
+        p->type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA;
+      } else if (p->pellet_decaytype == ARTIS_DECAYTYPE_SPONTFISSION) {
+        scalar_add(o, ARTIS_SCALAR_SPFISSION_DEP_DISCRETE, p->e_cmf);
+        p->type = ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED;
+      } else {
+        ORACLE_FAIL(o, "update_pellet: particle pellet with a decay type that emits no particle");
+        return;
+      }
+      p->em_time = (float)p->prop_time;
+      p->absorptiontype = ARTIS_ABSTYPE_PELLET_PARTICLEDECAY;
+    } else {
+      scalar_add(o, ARTIS_SCALAR_GAMMA_EMISSION, p->e_cmf);
+      pellet_gamma_decay(p);
+    }
+  } else if ((tdecay > 0) && (o->ts.nts == 0)) {
+    p->e_cmf *= tdecay / o->m->tmin;
+    p->type = ARTIS_TYPE_PRE_KPKT;
+    p->absorptiontype = ARTIS_ABSTYPE_PELLET_BEFORESIMSTART;
+    stat_inc(o, ARTIS_STAT_K_FROM_EARLIERDECAY);
+    p->prop_time = o->m->tmin;
+  } else {
+    ORACLE_FAIL(o, "update_pellet: decay time before the start of the timestep");
+  }
+}
+
 /* ------------------------------------------------------------------ driver */
 /* packetprop_update_required update_packets.cc:321, restricted to the types this path owns */
 static int handled_type(int type) {
+  /* every type of do_packet()'s switch (update_packets.cc:258-300) */
   return type == ARTIS_TYPE_RPKT || type == ARTIS_TYPE_KPKT || type == ARTIS_TYPE_PRE_KPKT || type == ARTIS_TYPE_GAMMA ||
-         type == ARTIS_TYPE_NTLEPTON_DEPOSITED;
+         type == ARTIS_TYPE_NTLEPTON_DEPOSITED || type == ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED ||
+         type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS || type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS ||
+         type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA || type == ARTIS_TYPE_RADIOACTIVE_PELLET;
 }
 
 static void oracle_init(Oracle *o, const artis_model *m, const artis_cellstate *cs, const artis_timestep *ts, artis_estimators *est) {
@@ -2370,6 +2458,17 @@ int artis_oracle_update_packets(const artis_model *m, const artis_cellstate *cs,
           break;
         case ARTIS_TYPE_NTLEPTON_DEPOSITED:
           do_ntlepton_deposit(&o, p);
+          break;
+        case ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED:
+          do_ntalpha_fisprod_deposit(&o, p);
+          break;
+        case ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA:
+        case ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS:
+        case ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS:
+          do_nonthermal_predeposit(&o, p);
+          break;
+        case ARTIS_TYPE_RADIOACTIVE_PELLET:
+          update_pellet(&o, p, ts_end);
           break;
         case ARTIS_TYPE_PRE_KPKT:
           do_kpkt_blackbody(&o, p);

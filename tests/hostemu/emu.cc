@@ -37,6 +37,9 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
     e.env.E.colheatingestimator = est->colheatingestimator; e.env.E.gammaestimator = est->gammaestimator;
     e.env.E.bfheatingestimator = est->bfheatingestimator;
     e.env.E.dep_estimator_gamma = est->dep_estimator_gamma;
+    e.env.E.dep_estimator_electron = est->dep_estimator_electron;
+    e.env.E.dep_estimator_positron = est->dep_estimator_positron;
+    e.env.E.dep_estimator_alpha = est->dep_estimator_alpha;
     e.env.E.scalars = est->scalars;
   }
   const DevModel &M = e.env.M;

@@ -32,9 +32,9 @@ def engine_mod():
     return engine
 
 
-def _run_case(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk, kfrac=0.2, gfrac=0.0):
-    model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v)
-    pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=kfrac, gamma_fraction=gfrac)
+def _run_case(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk, kfrac=0.2, gfrac=0.0, pfrac=0.0, bkw=None, pkw=None):
+    model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v, **(bkw or {}))
+    pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=kfrac, gamma_fraction=gfrac, pellet_fraction=pfrac, **(pkw or {}))
     n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
     pa, pb = pk0.copy(), pk0.copy()
     ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
@@ -80,6 +80,21 @@ def test_engine_matches_oracle_gamma_packets(engine_mod, oracle, preset, ncoord,
     assert st["X_GAMMA_STEPS"] > 0.6 * npk and st["NT_STAT_FROM_GAMMA"] > 0.1 * npk
     assert eb.scalars[0] > 0 and eb.dep_estimator_gamma.sum() > 0
     print(f"worst float rel diff {rep['worst_rel']:.3e}; gamma steps {st['X_GAMMA_STEPS']}")
+    eng.close()
+
+
+@pytest.mark.parametrize("gridtype,ncoord,bkw,pkw", [
+    (abi.GRID_CARTESIAN3D, 8, {}, {}),
+    (abi.GRID_CYLINDRICAL2D, 6, {"nts": 0, "t_days": 2.0, "tmin_days": 2.0}, {"early_pellets": True}),
+])
+def test_engine_matches_oracle_all_packet_types(engine_mod, oracle, gridtype, ncoord, bkw, pkw):
+    """pellets, gamma packets, non-thermal particles and deposits together with r-/k-packets: every type of do_packet()"""
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", ncoord, gridtype, 0.0, 16000, kfrac=0.1, gfrac=0.2,
+                                                    pfrac=0.6, bkw=bkw, pkw=pkw)
+    parity.compare_packets(pb, pa, FLOAT_RTOL, "all types: HIP engine vs oracle")
+    parity.compare_stats(eb, ea, "all types: HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, "all types: HIP engine vs oracle")
+    assert eb.scalars[2] > 1000 and eb.dep_estimator_alpha.sum() > 0   # pellet decays, alpha deposition
     eng.close()
 
 
@@ -176,8 +191,8 @@ def test_edge_cases(engine_mod):
     eng.set_cellstate(cs, ts)
     eng.update_packets(np.zeros(0, dtype=abi.PACKET_DTYPE), abi.Estimators(n, g))  # empty population
     pk = synth.make_packets(model, aux, 64)
-    pk["type"][:16] = 100
-    pk["type"][16:32] = 21  # TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS
+    pk["type"][:16] = 0   # TYPE_NONE
+    pk["type"][16:32] = 13  # TYPE_MA: types outside do_packet()'s switch are returned untouched
     pk["prop_time"][32:48] = ts.c.start + ts.c.width
     ref = pk.copy()
     eng.update_packets(pk, abi.Estimators(n, g))

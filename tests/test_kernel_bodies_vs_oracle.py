@@ -63,6 +63,37 @@ def test_gamma_packets_bit_exact(oracle, preset, ncoord, gridtype, npk, budget):
     assert np.count_nonzero((pa["type"] == abi.TYPE_ESCAPE) & (pa["escape_type"] == abi.TYPE_GAMMA)) > 0
 
 
+@pytest.mark.parametrize("gridtype,ncoord,kw,pkw", [
+    (abi.GRID_CARTESIAN3D, 8, {}, {}),
+    (abi.GRID_SPHERICAL1D, 16, {}, {}),
+    (abi.GRID_CYLINDRICAL2D, 6, {"nts": 0, "t_days": 2.0, "tmin_days": 2.0}, {"early_pellets": True}),  # first timestep
+])
+def test_all_packet_types_bit_exact(oracle, gridtype, ncoord, kw, pkw):
+    """Every packet type of do_packet() (update_packets.cc:257) in one population: pellets (update_pellet: carried with
+    the flow, decaying to gamma packets / k-packets / non-thermal particles, or -- in timestep 0 -- already decayed),
+    gamma packets, non-thermal pre-deposits and deposits, r-, k- and pre-k-packets."""
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, **kw)
+    pk0 = synth.make_packets(model, aux, 4000, kpkt_fraction=0.1, gamma_fraction=0.2, pellet_fraction=0.6, **pkw)
+    npellets = np.count_nonzero(pk0["type"] == abi.TYPE_RADIOACTIVE_PELLET)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3)
+    parity.compare_packets(pb, pa, 0.0, "all types: kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, "all types: kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, "all types: kernel bodies vs oracle")
+    sc = dict(zip(abi.SCALAR_NAMES, ea.scalars))
+    e_pkt = pk0["e_cmf"][0]
+    ndecayed = npellets - np.count_nonzero(pa["type"] == abi.TYPE_RADIOACTIVE_PELLET) - ea.stats_dict()["K_STAT_FROM_EARLIERDECAY"]
+    assert sc["pellet_decays"] == ndecayed > 100
+    emitted = sc["gamma_emission"] + sc["positron_emission"] + sc["electron_emission"] + sc["alpha_emission"] + sc["spfission_dep_discrete"]
+    assert abs(emitted / (ndecayed * e_pkt) - 1) < 1e-12                      # every decay is counted in exactly one channel
+    assert sc["electron_dep_discrete"] == sc["electron_emission"] and sc["alpha_dep_discrete"] == sc["alpha_emission"]
+    assert ea.dep_estimator_electron.sum() > 0 and ea.dep_estimator_positron.sum() > 0 and ea.dep_estimator_alpha.sum() > 0
+    if kw.get("nts") == 0:
+        assert ea.stats_dict()["K_STAT_FROM_EARLIERDECAY"] > 100
+    still = pa[pa["type"] == abi.TYPE_RADIOACTIVE_PELLET]
+    assert np.all(still["tdecay"] > ts.c.start + ts.c.width) and np.all(still["prop_time"] == ts.c.start + ts.c.width)
+    assert not np.any(np.isin(pa["type"], [20, 21, 22, 23, 24]))               # no deposit type survives a call
+
+
 def test_budget_independence(oracle):
     """A launch boundary may fall between any two do_packet() calls without changing a packet's history."""
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
@@ -87,15 +118,15 @@ def test_cellcache_bit_exact(oracle):
 
 
 def test_empty_and_untouched_packets(oracle):
-    """Edge cases: no packets; packets of types this path does not own are returned untouched;
+    """Edge cases: no packets; packets of types outside do_packet()'s switch are returned untouched;
     packets already at the end of the timestep are not moved."""
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
     n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
     empty = np.zeros(0, dtype=abi.PACKET_DTYPE)
     emu.update_packets(model, cs, ts, empty, abi.Estimators(n, g))
     pk = synth.make_packets(model, aux, 64)
-    pk["type"][:16] = 100  # TYPE_RADIOACTIVE_PELLET
-    pk["type"][16:32] = 21  # TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS
+    pk["type"][:16] = 0  # TYPE_NONE
+    pk["type"][16:32] = 13  # TYPE_MA: not a state a packet is handed over in
     pk["prop_time"][32:48] = ts.c.start + ts.c.width
     ref = pk.copy()
     emu.update_packets(model, cs, ts, pk, abi.Estimators(n, g))
