@@ -367,10 +367,12 @@ int artis_amd_set_cellstate(artis_amd_engine *eng, const artis_cellstate *cells,
  * reference does at its start, update_packets.cc:551-560). hip_stream is a hipStream_t (NULL = default). */
 int artis_amd_populate_cellcache(artis_amd_engine *eng, void *hip_stream);
 
-/* Host-buffer form of update_packets() (update_packets.cc:530): packets in
- * TYPE_RPKT / TYPE_KPKT / TYPE_PRE_KPKT are propagated to the end of the
- * timestep; other types are returned untouched (they stay on the reference's
- * CPU path). Estimators are ADDED to est (host arrays). */
+/* Host-buffer form of update_packets() (update_packets.cc:530): every packet
+ * whose type is in do_packet()'s switch (update_packets.cc:257: pellets, gamma
+ * packets, non-thermal pre-deposits and deposits, r-, k- and pre-k-packets) is
+ * advanced to the end of the timestep with the physics of the classic preset
+ * (include/artis_options.h); packets of any other type are returned untouched.
+ * Estimators are ADDED to est (host arrays; NULL members are skipped). */
 int artis_amd_update_packets(artis_amd_engine *eng, artis_packet *packets, int64_t npackets,
                              artis_estimators *est);
 

@@ -62,6 +62,11 @@
 #define ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON 0      /* artisoptions_classic.h:60 */
 #define ARTIS_OPT_NT_ON 0                           /* artisoptions_classic.h:100 */
 #define ARTIS_OPT_VPKT_ON 0                         /* artisoptions_classic.h:50 */
+/* gamma packets and non-thermal particles: the classic choices (artisoptions_classic.h:144-150) are the ones built */
+#define ARTIS_OPT_USE_XCOM_GAMMAPHOTOION 0            /* Veigele fit for the photoelectric opacity */
+#define ARTIS_OPT_GAMMA_USE_KAPPA_GREY 0             /* std::nullopt in the reference: frequency-dependent transport */
+#define ARTIS_OPT_GAMMA_THERMALISATION_FREQUENCYDEPENDENT 1
+#define ARTIS_OPT_PARTICLE_THERMALISATION_INSTANTFULLDEPOSITION 1
 
 /* kpkt.cc:51 kpktdiffusion_timestep_fraction (a float in the reference) */
 #define ARTIS_KPKTDIFFUSION_TIMESTEP_FRACTION 0.001f
