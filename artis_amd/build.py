@@ -14,23 +14,38 @@ SOURCES = ["artis_engine.hip", "physics.h", "tables.h", "model_build.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-munsafe-fp-atomics"]
 
 
-def needs_build() -> bool:
-    if not os.path.exists(SO):
+PRESETS = ("classic", "kilonova_lte")  # options presets of include/artis_options.h (the reference's artisoptions_*.h)
+
+
+def so_path(preset: str = "classic") -> str:
+    return SO if preset == "classic" else os.path.join(HERE, f"libartis_amd_{preset}.so")
+
+
+def needs_build(preset: str = "classic") -> bool:
+    so = so_path(preset)
+    if not os.path.exists(so):
         return True
-    t = os.path.getmtime(SO)
+    t = os.path.getmtime(so)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", h)
                                                         for h in ("artis_amd.h", "artis_options.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, extra_flags=()) -> str:
-    if not force and not needs_build():
-        return SO
+def build(force: bool = False, extra_flags=(), preset: str = "classic") -> str:
+    """One library per options preset, like one sn3d binary per artisoptions.h in the reference."""
+    so = so_path(preset)
+    if not force and not needs_build(preset):
+        return so
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, *FLAGS, *extra_flags, "-o", SO, os.path.join(CSRC, "artis_engine.hip")]
+    pflags = [] if preset == "classic" else [f"-DARTIS_PRESET_{preset.upper()}"]
+    cmd = [hipcc, *FLAGS, *pflags, *extra_flags, "-o", so, os.path.join(CSRC, "artis_engine.hip")]
     subprocess.check_call(cmd)
-    return SO
+    return so
+
+
+def build_all(force: bool = False):
+    return [build(force=force, preset=p) for p in PRESETS]
 
 
 if __name__ == "__main__":
-    print(build(force=True))
+    print(build_all(force=True))

@@ -694,7 +694,14 @@ int ensure_aos(artis_amd_engine *e, int64_t n) {
 extern "C" {
 
 const char *artis_amd_last_error(void) { return g_last_error.c_str(); }
-int artis_amd_abi_version(void) { return 1; }
+int artis_amd_abi_version(void) { return 2; }
+const char *artis_amd_options_preset(void) {
+#ifdef ARTIS_PRESET_KILONOVA_LTE
+  return "kilonova_lte";
+#else
+  return "classic";
+#endif
+}
 size_t artis_amd_sizeof_packet(void) { return sizeof(artis_packet); }
 
 int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engine **out) {

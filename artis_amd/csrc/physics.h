@@ -191,7 +191,12 @@ AHD double doppler_at(double px, double py, double pz, double dx, double dy, dou
   const double vel[3] = {px / t, py / t, pz / t};
   const double dir[3] = {dx, dy, dz};
   const double ndotv = vdot(dir, vel);
-  return 1. - (ndotv / CLIGHT);
+  double dopplerfactor = 1. - (ndotv / CLIGHT);
+#if ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
+  const double betasq = vdot(vel, vel) / CLIGHTSQUARED;
+  dopplerfactor = dopplerfactor / sqrt(1 - betasq);
+#endif
+  return dopplerfactor;
 }
 AHD double doppler(const Pkt &p) { return doppler_at(p.px, p.py, p.pz, p.dx, p.dy, p.dz, p.prop_time); }
 // move_pkt_withtime vectors.h:119
@@ -1294,14 +1299,20 @@ AHD int closest_transition(const double *nu, int nlines, double nu_cmf, int next
   if (nu_cmf >= nu[0]) return 0;
   return partition_point_d(nu, nlines, [nu_cmf](double x) { return x > nu_cmf; });
 }
-AHD double linedistance(double prop_time, double nu_cmf, double nu_trans) {  // rpkt.h:125
+AHD double linedistance(double prop_time, double nu_cmf, double nu_trans, double dnu_on_dl) {  // rpkt.h:117
   if (nu_cmf <= nu_trans) return 0.;
   const double dnu = nu_cmf - nu_trans;
+#if ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
+  (void)prop_time;
+  return -dnu / dnu_on_dl;  // linear interpolation of the frequency along the path, rpkt.h:126-132
+#else
+  (void)dnu_on_dl;
   return CLIGHT * prop_time * dnu / nu_trans;
+#endif
 }
 // get_possible_event rpkt.cc:106
 AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAState &ma, double tau_rnd, double abort_dist,
-                          double nu_cmf_abort, double dop, int *next_trans_out, bool *is_bb) {
+                          double nu_cmf_abort, double dnu_on_dl, double dop, int *next_trans_out, bool *is_bb) {
   const DevModel &M = env.M;
   const double *dpop = env.K.line_dpop + ((int64_t)c * M.nlines);
   double px = p.px, py = p.py, pz = p.pz;
@@ -1332,7 +1343,7 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
     nvisited++;
     const double nu_trans = M.line_nu[li];
     next_trans = li + 1;
-    const double ldist = linedistance(prop_time, nu_cmf, nu_trans);
+    const double ldist = linedistance(prop_time, nu_cmf, nu_trans, dnu_on_dl);
     const double tau_cont = chi_cont * ldist;
     if (tau_rnd - tau > tau_cont) {
       if (nu_trans < nu_cmf_abort) {
@@ -1358,7 +1369,17 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
       }
       dist += ldist;
       tau += tau_cont + tau_line;
+#if !ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
       move_raw(px, py, pz, p.dx, p.dy, p.dz, prop_time, p.nu_rf, nu_cmf, p.e_rf, e_cmf, ldist);
+#else
+      // rpkt.cc:190-196: the linear approximation instead of the Doppler formula
+      px += (p.dx * ldist);
+      py += (p.dy * ldist);
+      pz += (p.dz * ldist);
+      prop_time += ldist / CLIGHT_PROP;
+      nu_cmf = p.nu_cmf + (dnu_on_dl * dist);
+      (void)e_cmf;
+#endif
     } else {
       *next_trans_out = next_trans - 1;
       *is_bb = false;
@@ -2103,7 +2124,8 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
                                                      p.pz + (p.dz * half) + (p.dz * half), p.dx, p.dy, p.dz, abort_time);
     const double dop = doppler(p);
     int nt = p.next_trans;
-    edist = possible_event(env, c, p, x, ma, tau_rnd, abort_dist, nu_cmf_abort, dop, &nt, &is_bb);
+    const double dnu_on_dl = (nu_cmf_abort - p.nu_cmf) / abort_dist;  // rpkt.cc:591
+    edist = possible_event(env, c, p, x, ma, tau_rnd, abort_dist, nu_cmf_abort, dnu_on_dl, dop, &nt, &is_bb);
     p.next_trans = nt;
     PROF_MARK(env, 50);
   }
@@ -2528,22 +2550,53 @@ AHD void do_ntalpha_fisprod_deposit(const Env &env, Pkt &p) {
   p.type = ARTIS_TYPE_KPKT;
   ARTIS_STAT(env, ARTIS_STAT_NT_TO_KPKT);
 }
-// do_nonthermal_predeposit update_packets.cc:42 with PARTICLE_THERMALISATION_SCHEME == INSTANTFULLDEPOSITION
+// do_nonthermal_predeposit update_packets.cc:42 (INSTANTFULLDEPOSITION, TIMEDEPENDENT, TIMEDEPENDENT_WITH_ADIABATIC_LOSS)
 AHD void do_nonthermal_predeposit(const Env &env, Pkt &p, int64_t pi) {
-  const double e_cmf_deposited = p.e_cmf;
+  double e_cmf_deposited = p.e_cmf;
   const int c = env.M.propcell_nonemptymgi[p.cellindex];
   const int priortype = p.type;
-  p.type = (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED : ARTIS_TYPE_NTLEPTON_DEPOSITED;
+  const int deposit_type = (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED : ARTIS_TYPE_NTLEPTON_DEPOSITED;
+#if ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_INSTANTFULLDEPOSITION
+  p.type = deposit_type;  // absorption happens
+#else
+  {  // local time-dependent absorption, update_packets.cc:90-150
+    const double ts = p.prop_time;
+    const double ts_end = env.S.ts_end;
+    const double rho = env.C.rho[c];
+    const double particle_en = HPLANCK * p.nu_cmf;
+    const double endot_collisional = (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? 5.e11 * MEV * rho : 4.e10 * MEV * rho;
+    const double endot_adiabatic =
+        (ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_TIMEDEPENDENT_WITH_ADIABATIC_LOSS) ? particle_en / ts : 0.;
+    const double endot = endot_collisional + endot_adiabatic;
+    e_cmf_deposited = p.e_cmf * endot_collisional * dmin(ts_end - ts, particle_en / endot) / particle_en;
+    const double rnd_en_absorb = rng_uniform(p) * particle_en;
+    const double t_absorb = ts + (rnd_en_absorb / endot);
+    const double t_new = dmin(t_absorb, ts_end);
+    const bool absorbed = (t_absorb <= ts_end);
+    if (absorbed) {
+      p.type = deposit_type;
+    } else {
+      p.nu_cmf -= (endot * (ts_end - ts)) / HPLANCK;
+    }
+    const double scale = t_new / ts;
+    p.px = p.px * scale;
+    p.py = p.py * scale;
+    p.pz = p.pz * scale;
+    p.prop_time = t_new;
+    if (ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_TIMEDEPENDENT_WITH_ADIABATIC_LOSS && absorbed)
+      p.e_cmf *= endot_collisional / endot;
+  }
+#endif
   if (env.P.originated_particle[pi] != 0) {
     if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS) {
       ARTIS_EST_ADD(&env.E.dep_estimator_electron[c], e_cmf_deposited);
-      ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ELECTRON_DEP_DISCRETE], p.e_cmf);
+      if (p.type == deposit_type) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ELECTRON_DEP_DISCRETE], p.e_cmf);
     } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS) {
       ARTIS_EST_ADD(&env.E.dep_estimator_positron[c], e_cmf_deposited);
-      ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_POSITRON_DEP_DISCRETE], p.e_cmf);
+      if (p.type == deposit_type) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_POSITRON_DEP_DISCRETE], p.e_cmf);
     } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) {
       ARTIS_EST_ADD(&env.E.dep_estimator_alpha[c], e_cmf_deposited);
-      ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ALPHA_DEP_DISCRETE], p.e_cmf);
+      if (p.type == deposit_type) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ALPHA_DEP_DISCRETE], p.e_cmf);
     }
   }
 }

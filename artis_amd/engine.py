@@ -15,25 +15,27 @@ import os
 import numpy as np
 
 from . import abi
-from .build import SO, build
+from .build import SO, build, so_path
 
 
 class EngineError(RuntimeError):
     pass
 
 
-_LIB = None
+_LIBS = {}
 
 
-def load_library(build_if_missing: bool = False):
-    global _LIB
-    if _LIB is not None:
-        return _LIB
-    so = os.environ.get("ARTIS_AMD_SO", SO)  # A/B builds of the same sources (tuning only)
+def load_library(build_if_missing: bool = False, preset: str = "classic"):
+    """Load the engine built for an options preset (include/artis_options.h). One library per preset."""
+    if preset in _LIBS:
+        return _LIBS[preset]
+    so = so_path(preset)
+    if preset == "classic":
+        so = os.environ.get("ARTIS_AMD_SO", so)  # A/B builds of the same sources (tuning only)
     if not os.path.exists(so):
         if not build_if_missing:
-            raise EngineError(f"{SO} is missing: run `python -m artis_amd.build` (hipcc, gfx950). There is no CPU fallback.")
-        build()
+            raise EngineError(f"{so} is missing: run `python -m artis_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+        build(preset=preset)
     L = C.CDLL(so)
     L.artis_amd_last_error.restype = C.c_char_p
     L.artis_amd_abi_version.restype = C.c_int
@@ -54,7 +56,9 @@ def load_library(build_if_missing: bool = False):
     L.artis_amd_estimators_devptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.artis_amd_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     assert L.artis_amd_sizeof_packet() == abi.PACKET_DTYPE.itemsize
-    _LIB = L
+    L.artis_amd_options_preset.restype = C.c_char_p
+    assert L.artis_amd_options_preset().decode() == preset, (L.artis_amd_options_preset(), preset)
+    _LIBS[preset] = L
     return L
 
 
@@ -68,12 +72,13 @@ EXPORTED_SYMBOLS = [
     "artis_amd_last_kernel_breakdown",
     "artis_amd_last_kernel_launches",
     "artis_amd_last_kernel_table",
+    "artis_amd_options_preset",
 ]
 
 
 class Engine:
-    def __init__(self, model: abi.Model, device: int = 0):
-        self.L = load_library()
+    def __init__(self, model: abi.Model, device: int = 0, preset: str = "classic"):
+        self.L = load_library(preset=preset)
         self.model = model
         self.h = C.c_void_p()
         self._check(self.L.artis_amd_engine_create(C.cast(model.ref(), C.c_void_p), device, C.byref(self.h)))

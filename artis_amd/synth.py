@@ -54,9 +54,13 @@ def _ionpot_ev(Z: int, stage: int) -> float:
     return 7.5 * stage**1.6
 
 
+# rate-coefficient table grids of the options presets (include/artis_options.h: TABLESIZE, MINTEMP, MAXTEMP)
+OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0, 150000.0)}
+
+
 def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fraction: float = 0.4,
                 nphixspoints: int = 40, phixsnuincrement: float = 0.1, two_target_fraction: float = 0.25,
-                forbidden_fraction: float = 0.2, collstr_fraction: float = 0.1) -> dict:
+                forbidden_fraction: float = 0.2, collstr_fraction: float = 0.1, options: str = "classic") -> dict:
     """Build the atomic part of struct artis_model. `elements` = list of (Z, lowest_ionstage, nions)."""
     rng = np.random.default_rng(seed)
     if elements is None:
@@ -278,6 +282,7 @@ def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fr
             ion_ncoolingterms[ui] = len(cl_type) - ion_coolingoffset[ui]
 
     # ---- temperature LUTs (ratecoeff.cc:143 precalculate_rate_coefficient_integrals), simple quadrature
+    TABLESIZE, MINTEMP, MAXTEMP = OPTION_TABLES[options]
     T_step_log = (np.log(MAXTEMP) - np.log(MINTEMP)) / (TABLESIZE - 1.0)
     Tgrid = (MINTEMP * np.exp(np.arange(TABLESIZE) * T_step_log)).astype(np.float32).astype(np.float64)
     spont = np.zeros((nbfcontinua, TABLESIZE))
@@ -598,6 +603,9 @@ def make_packets(model: abi.Model, aux: dict, npackets: int, seed_base: int = 12
         lines_mev = np.array([0.158, 0.48, 0.75, 0.812, 0.847, 1.238, 1.771, 2.598])
         nu_line = lines_mev[rng.integers(0, len(lines_mev), npackets)] * 1.0e6 * 1.6021772e-12 / 6.6260755e-27
         nu_line = np.where(rng.random(npackets) < 0.05, -1.0, nu_line)
+        # a particle-emitting pellet carries the kinetic energy of its particles instead (0.3 .. 5 MeV), which the
+        # time-dependent thermalisation schemes read (update_packets.cc:93)
+        nu_line = np.where(particle, (0.3 + 4.7 * rng.random(npackets)) * 1.0e6 * 1.6021772e-12 / 6.6260755e-27, nu_line)
         pk["type"] = np.where(isp, abi.TYPE_RADIOACTIVE_PELLET, pk["type"])
         pk["tdecay"] = np.where(isp, tdec, pk["tdecay"])
         pk["originated_from_particlenotgamma"] = np.where(isp & particle, 1, 0)
@@ -618,10 +626,11 @@ PRESETS = {
 
 
 def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTESIAN3D, seed: int = 1,
-          t_days: float = 20.0, thick_below_v: float = 0.0, width_frac: float = 0.05, nts: int = 10, tmin_days: float = 2.0):
+          t_days: float = 20.0, thick_below_v: float = 0.0, width_frac: float = 0.05, nts: int = 10, tmin_days: float = 2.0,
+          options: str = "classic"):
     """One-call construction of (Model, CellState, Timestep, aux)."""
     elements, nl, lf, npx = PRESETS[preset]
-    atomic = make_atomic(seed=seed, elements=elements, nlevels_per_ion=nl, line_fraction=lf, nphixspoints=npx)
+    atomic = make_atomic(seed=seed, elements=elements, nlevels_per_ion=nl, line_fraction=lf, nphixspoints=npx, options=options)
     grid, cells, aux = make_grid_and_cells(atomic, ncoord=ncoord, gridtype=gridtype, t_days=t_days, tmin_days=tmin_days,
                                            thick_below_v=thick_below_v, seed=seed + 100)
     md = {k: v for k, v in atomic.items() if not k.startswith("_")}

@@ -349,6 +349,9 @@ typedef struct artis_amd_engine artis_amd_engine;
 
 const char *artis_amd_last_error(void);
 int artis_amd_abi_version(void);
+/* Name of the options preset the library was compiled with (include/artis_options.h): "classic" or "kilonova_lte".
+ * Like the reference, one binary per artisoptions.h. */
+const char *artis_amd_options_preset(void);
 size_t artis_amd_sizeof_packet(void);
 
 /* Create an engine on HIP device `device` and upload the static model.

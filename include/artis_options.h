@@ -10,6 +10,23 @@
 #ifndef ARTIS_OPTIONS_H
 #define ARTIS_OPTIONS_H
 
+/* -DARTIS_PRESET_KILONOVA_LTE: the packet-path options of artisoptions_kilonova_lte.h (BASELINE.json configs[3]);
+ * every value below is the one of that file where it differs from artisoptions_classic.h. */
+#ifdef ARTIS_PRESET_KILONOVA_LTE
+#define ARTIS_OPT_DIPOLE 0                            /* artisoptions_kilonova_lte.h:48 */
+#define ARTIS_OPT_POL_ON 0                            /* :49 */
+#define ARTIS_OPT_MINPOP 1e-40                        /* :54 */
+#define ARTIS_OPT_NU_MIN_R 1e13                       /* :56 */
+#define ARTIS_OPT_NU_MAX_R 5e16                       /* :57 */
+#define ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION 0    /* :59 */
+#define ARTIS_OPT_DIRECT_COL_HEAT 1                   /* :37 */
+#define ARTIS_OPT_TABLESIZE 200                       /* :42 */
+#define ARTIS_OPT_MINTEMP 500.                        /* :43 */
+#define ARTIS_OPT_MAXTEMP 150000.                     /* :44 */
+#define ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT 1    /* :118 */
+#define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME 3    /* :146 TIMEDEPENDENT */
+#endif
+
 #ifndef ARTIS_OPT_DIPOLE
 #define ARTIS_OPT_DIPOLE 1 /* artisoptions_classic.h:47 */
 #endif
@@ -53,20 +70,30 @@
 #define ARTIS_OPT_MAXTEMP 140000. /* artisoptions_classic.h:42 */
 #endif
 
+#ifndef ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
+#define ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT 0 /* artisoptions_classic.h:118 */
+#endif
+/* PARTICLE_THERMALISATION_SCHEME (artisoptions_classic.h:146): 0 = INSTANTFULLDEPOSITION, 3 = TIMEDEPENDENT,
+ * 4 = TIMEDEPENDENT_WITH_ADIABATIC_LOSS. (BARNES and WOLLAEGER read whole-ejecta sums of the host; not built.) */
+#define ARTIS_PARTICLE_INSTANTFULLDEPOSITION 0
+#define ARTIS_PARTICLE_TIMEDEPENDENT 3
+#define ARTIS_PARTICLE_TIMEDEPENDENT_WITH_ADIABATIC_LOSS 4
+#ifndef ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME
+#define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_INSTANTFULLDEPOSITION
+#endif
+
 /* Options of the reference this build does not implement: they must keep the
  * classic values. (A build that needs them fails here, not at run time.) */
-#define ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT 0  /* artisoptions_classic.h:119 */
 #define ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES 0    /* artisoptions_classic.h:137 */
 #define ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON 0     /* artisoptions_classic.h:74 */
 #define ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON 0       /* artisoptions_classic.h:76 */
 #define ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON 0      /* artisoptions_classic.h:60 */
 #define ARTIS_OPT_NT_ON 0                           /* artisoptions_classic.h:100 */
 #define ARTIS_OPT_VPKT_ON 0                         /* artisoptions_classic.h:50 */
-/* gamma packets and non-thermal particles: the classic choices (artisoptions_classic.h:144-150) are the ones built */
+/* gamma packets: the classic choices (artisoptions_classic.h:144-150) are the ones built */
 #define ARTIS_OPT_USE_XCOM_GAMMAPHOTOION 0            /* Veigele fit for the photoelectric opacity */
 #define ARTIS_OPT_GAMMA_USE_KAPPA_GREY 0             /* std::nullopt in the reference: frequency-dependent transport */
 #define ARTIS_OPT_GAMMA_THERMALISATION_FREQUENCYDEPENDENT 1
-#define ARTIS_OPT_PARTICLE_THERMALISATION_INSTANTFULLDEPOSITION 1
 
 /* kpkt.cc:51 kpktdiffusion_timestep_fraction (a float in the reference) */
 #define ARTIS_KPKTDIFFUSION_TIMESTEP_FRACTION 0.001f

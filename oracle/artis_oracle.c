@@ -220,12 +220,17 @@ static void angle_ab(const double dir1[3], const double vel[3], double dir2[3]) 
                          (dir1[2] - (vel[2] * fact2)) / fact1};
   vec_norm3(tmp, dir2);
 }
-/* calculate_doppler_nucmf_on_nurf vectors.h:92 (USE_RELATIVISTIC_DOPPLER_SHIFT false) */
+/* calculate_doppler_nucmf_on_nurf vectors.h:92 */
 static inline double doppler_nucmf_on_nurf(const double pos[3], const double dir[3], double prop_time) {
   double vel[3];
   get_velocity(pos, prop_time, vel);
   const double ndotv = dot3(dir, vel);
-  return 1. - (ndotv / CLIGHT);
+  double dopplerfactor = 1. - (ndotv / CLIGHT);
+#if ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
+  const double betasq = dot3(vel, vel) / CLIGHTSQUARED;
+  dopplerfactor = dopplerfactor / sqrt(1 - betasq);
+#endif
+  return dopplerfactor;
 }
 /* move_pkt_withtime vectors.h:119 */
 static void move_pkt_withtime_raw(double pos[3], const double dir[3], double *prop_time, double nu_rf, double *nu_cmf,
@@ -1266,10 +1271,16 @@ static int closest_transition(const double *linelistnu, int nlines, double nu_cm
   return lo;
 }
 /* get_linedistance rpkt.h:125 (non-relativistic) */
-static inline double get_linedistance(double prop_time, double nu_cmf, double nu_trans) {
+static inline double get_linedistance(double prop_time, double nu_cmf, double nu_trans, double dnu_on_dl) {
   if (nu_cmf <= nu_trans) return 0.;
   const double delta_nu = nu_cmf - nu_trans;
+#if ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
+  (void)prop_time;
+  return -delta_nu / dnu_on_dl; /* linear interpolation of the frequency along the path, rpkt.h:126-132 */
+#else
+  (void)dnu_on_dl;
   return CLIGHT * prop_time * delta_nu / nu_trans;
+#endif
 }
 /* get_tau_sobolev<true> rpkt.cc:75 */
 static inline double get_tau_sobolev(const Oracle *o, const CellCache *cc, int lineindex, double t_current) {
@@ -1291,7 +1302,7 @@ static double get_nu_cmf_abort(const double pos[3], const double dir[3], double 
 /* get_possible_event rpkt.cc:106. Returns edist; *next_trans_out, *is_bb set. */
 static double get_possible_event(Oracle *o, const CellCache *cc, const artis_packet *pkt, const ContOpacity *chi,
                                  MacroAtomState *mastate, double tau_rnd, double abort_dist, double nu_cmf_abort,
-                                 double doppler, int *next_trans_out, int *is_bb) {
+                                 double dnu_on_dl, double doppler, int *next_trans_out, int *is_bb) {
   const artis_model *m = o->m;
   double pos[3] = {pkt->pos[0], pkt->pos[1], pkt->pos[2]};
   double nu_cmf = pkt->nu_cmf;
@@ -1317,7 +1328,7 @@ static double get_possible_event(Oracle *o, const CellCache *cc, const artis_pac
     o->est.stats[ARTIS_STAT_X_LINES_VISITED]++;
     const double nu_trans = m->line_nu[lineindex];
     next_trans = lineindex + 1;
-    const double ldist = get_linedistance(prop_time, nu_cmf, nu_trans);
+    const double ldist = get_linedistance(prop_time, nu_cmf, nu_trans, dnu_on_dl);
     const double tau_cont = chi_cont * ldist;
     if (tau_rnd - tau > tau_cont) {
       if (nu_trans < nu_cmf_abort) {
@@ -1340,7 +1351,17 @@ static double get_possible_event(Oracle *o, const CellCache *cc, const artis_pac
       }
       dist += ldist;
       tau += tau_cont + tau_line;
+#if !ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
       move_pkt_withtime_raw(pos, pkt->dir, &prop_time, pkt->nu_rf, &nu_cmf, pkt->e_rf, &e_cmf, ldist);
+#else
+      /* rpkt.cc:190-196: the linear approximation instead of the Doppler formula */
+      pos[0] += (pkt->dir[0] * ldist);
+      pos[1] += (pkt->dir[1] * ldist);
+      pos[2] += (pkt->dir[2] * ldist);
+      prop_time += ldist / CLIGHT_PROP;
+      nu_cmf = pkt->nu_cmf + (dnu_on_dl * dist);
+      (void)e_cmf;
+#endif
     } else {
       *next_trans_out = next_trans - 1;
       *is_bb = 0;
@@ -1883,7 +1904,8 @@ static int do_rpkt_step(Oracle *o, artis_packet *p, double t2, ContOpacity *chi)
     const double nu_cmf_abort = get_nu_cmf_abort(p->pos, p->dir, p->prop_time, p->nu_rf, abort_dist);
     const double doppler = doppler_nucmf_on_nurf(p->pos, p->dir, p->prop_time);
     int nt = p->next_trans;
-    edist = get_possible_event(o, cc, p, chi, &pktmastate, tau_rnd, abort_dist, nu_cmf_abort, doppler, &nt, &event_is_boundbound);
+    const double dnu_on_dl = (nu_cmf_abort - p->nu_cmf) / abort_dist; /* rpkt.cc:591 */
+    edist = get_possible_event(o, cc, p, chi, &pktmastate, tau_rnd, abort_dist, nu_cmf_abort, dnu_on_dl, doppler, &nt, &event_is_boundbound);
     p->next_trans = nt;
   }
   if (!(edist >= 0)) ORACLE_FAIL(o, "edist < 0");
@@ -2324,23 +2346,51 @@ static void do_ntalpha_fisprod_deposit(Oracle *o, artis_packet *p) {
 static inline void scalar_add(Oracle *o, int i, double v) {
   if (o->est.scalars) o->est.scalars[i] += v;
 }
-/* do_nonthermal_predeposit update_packets.cc:42 with PARTICLE_THERMALISATION_SCHEME == INSTANTFULLDEPOSITION */
-static void do_nonthermal_predeposit(Oracle *o, artis_packet *p) {
-  const double e_cmf_deposited = p->e_cmf;
+/* do_nonthermal_predeposit update_packets.cc:42 (INSTANTFULLDEPOSITION, TIMEDEPENDENT, TIMEDEPENDENT_WITH_ADIABATIC_LOSS) */
+static void do_nonthermal_predeposit(Oracle *o, artis_packet *p, double ts_end) {
+  double e_cmf_deposited = p->e_cmf;
   const int c = propcell_nonemptymgi(o, p->cellindex);
   const int priortype = p->type;
+  const double ts = p->prop_time;
   const int deposit_type = (p->type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED : ARTIS_TYPE_NTLEPTON_DEPOSITED;
+#if ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_INSTANTFULLDEPOSITION
+  (void)ts; (void)ts_end;
   p->type = deposit_type; /* absorption happens */
+#else
+  { /* local time-dependent absorption, update_packets.cc:90-150 */
+    const double rho = o->cs->rho[c];
+    const double particle_en = H_PLANCK * p->nu_cmf;
+    const double endot_collisional = (p->type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? 5.e11 * MEV * rho : 4.e10 * MEV * rho;
+    const double endot_adiabatic =
+        (ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_TIMEDEPENDENT_WITH_ADIABATIC_LOSS) ? particle_en / ts : 0.;
+    const double endot = endot_collisional + endot_adiabatic;
+    e_cmf_deposited = p->e_cmf * endot_collisional * dmin(ts_end - ts, particle_en / endot) / particle_en;
+    const double rnd_en_absorb = rng_uniform(p->rngstate) * particle_en;
+    const double t_absorb = ts + (rnd_en_absorb / endot);
+    const double t_new = dmin(t_absorb, ts_end);
+    const int absorbed = (t_absorb <= ts_end);
+    if (absorbed) {
+      p->type = deposit_type;
+    } else {
+      p->nu_cmf -= (endot * (ts_end - ts)) / H_PLANCK;
+    }
+    const double scale = t_new / ts;
+    p->pos[0] = p->pos[0] * scale; p->pos[1] = p->pos[1] * scale; p->pos[2] = p->pos[2] * scale;
+    p->prop_time = t_new;
+    if (ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_TIMEDEPENDENT_WITH_ADIABATIC_LOSS && absorbed)
+      p->e_cmf *= endot_collisional / endot;
+  }
+#endif
   if (p->originated_from_particlenotgamma) {
     if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS) {
       if (o->est.dep_estimator_electron) o->est.dep_estimator_electron[c] += e_cmf_deposited;
-      scalar_add(o, ARTIS_SCALAR_ELECTRON_DEP_DISCRETE, p->e_cmf);
+      if (p->type == deposit_type) scalar_add(o, ARTIS_SCALAR_ELECTRON_DEP_DISCRETE, p->e_cmf);
     } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS) {
       if (o->est.dep_estimator_positron) o->est.dep_estimator_positron[c] += e_cmf_deposited;
-      scalar_add(o, ARTIS_SCALAR_POSITRON_DEP_DISCRETE, p->e_cmf);
+      if (p->type == deposit_type) scalar_add(o, ARTIS_SCALAR_POSITRON_DEP_DISCRETE, p->e_cmf);
     } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) {
       if (o->est.dep_estimator_alpha) o->est.dep_estimator_alpha[c] += e_cmf_deposited;
-      scalar_add(o, ARTIS_SCALAR_ALPHA_DEP_DISCRETE, p->e_cmf);
+      if (p->type == deposit_type) scalar_add(o, ARTIS_SCALAR_ALPHA_DEP_DISCRETE, p->e_cmf);
     }
   }
 }
@@ -2465,7 +2515,7 @@ int artis_oracle_update_packets(const artis_model *m, const artis_cellstate *cs,
         case ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA:
         case ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS:
         case ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS:
-          do_nonthermal_predeposit(&o, p);
+          do_nonthermal_predeposit(&o, p, ts_end);
           break;
         case ARTIS_TYPE_RADIOACTIVE_PELLET:
           update_pellet(&o, p, ts_end);
@@ -2546,7 +2596,7 @@ void artis_oracle_frame_transform(const double n_rf[3], double q0, double u0, co
 int artis_oracle_closest_transition(const double *linelistnu, int nlines, double nu_cmf, int next_trans) {
   return closest_transition(linelistnu, nlines, nu_cmf, next_trans);
 }
-double artis_oracle_get_linedistance(double prop_time, double nu_cmf, double nu_trans) { return get_linedistance(prop_time, nu_cmf, nu_trans); }
+double artis_oracle_get_linedistance(double prop_time, double nu_cmf, double nu_trans) { return get_linedistance(prop_time, nu_cmf, nu_trans, -1.); }
 double artis_oracle_rad_deexcitation_ratecoeff(double epsilon_trans, float A_ul, double gu, double gl, double nu_, double nl_, double t) {
   return rad_deexcitation_ratecoeff(epsilon_trans, A_ul, gu, gl, nu_, nl_, t);
 }

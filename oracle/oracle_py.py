@@ -14,21 +14,26 @@ import numpy as np
 from artis_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
+_LIBS = {}
+PRESETS = ("classic", "kilonova_lte")  # options presets of include/artis_options.h the oracle is built for
 
 
-def build(force: bool = False) -> str:
-    so = os.path.join(_HERE, "libartis_oracle.so")
-    src = os.path.join(_HERE, "artis_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "libartis_oracle.so"], stdout=subprocess.DEVNULL)
+def _soname(preset: str) -> str:
+    return "libartis_oracle.so" if preset == "classic" else f"libartis_oracle_{preset}.so"
+
+
+def build(force: bool = False, preset: str = "classic") -> str:
+    so = os.path.join(_HERE, _soname(preset))
+    deps = [os.path.join(_HERE, "artis_oracle.c"), os.path.join(_HERE, "..", "include", "artis_options.h"),
+            os.path.join(_HERE, "..", "include", "artis_amd.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["make", "-C", _HERE, _soname(preset)], stdout=subprocess.DEVNULL)
     return so
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        L = C.CDLL(build())
+def lib(preset: str = "classic"):
+    if preset not in _LIBS:
+        L = C.CDLL(build(preset=preset))
         L.artis_oracle_update_packets.restype = C.c_int
         L.artis_oracle_update_packets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.artis_oracle_cellcache.restype = C.c_int
@@ -48,13 +53,13 @@ def lib():
         L.artis_oracle_closest_transition.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
         L.artis_oracle_sizeof_packet.restype = C.c_size_t
         L.artis_oracle_seed_packets.argtypes = [C.c_void_p, C.c_int64, C.c_uint32]
-        _LIB = L
-    return _LIB
+        _LIBS[preset] = L
+    return _LIBS[preset]
 
 
 def update_packets(model: abi.Model, cells: abi.CellState, ts: abi.Timestep, packets: np.ndarray,
-                   est: abi.Estimators) -> None:
-    rc = lib().artis_oracle_update_packets(C.cast(model.ref(), C.c_void_p), C.cast(cells.ref(), C.c_void_p),
+                   est: abi.Estimators, preset: str = "classic") -> None:
+    rc = lib(preset).artis_oracle_update_packets(C.cast(model.ref(), C.c_void_p), C.cast(cells.ref(), C.c_void_p),
                                            C.cast(ts.ref(), C.c_void_p), abi.packets_ptr(packets), len(packets),
                                            C.cast(est.ref(), C.c_void_p))
     if rc != 0:

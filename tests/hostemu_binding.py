@@ -8,23 +8,22 @@ import numpy as np
 from artis_amd import abi
 
 _HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostemu")
-_LIB = None
+_LIBS = {}
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
+def lib(preset: str = "classic"):
+    if preset not in _LIBS:
         subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
-        L = C.CDLL(os.path.join(_HERE, "libartis_hostemu.so"))
+        L = C.CDLL(os.path.join(_HERE, "libartis_hostemu.so" if preset == "classic" else f"libartis_hostemu_{preset}.so"))
         L.artis_emu_update_packets.restype = C.c_int
         L.artis_emu_update_packets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         L.artis_emu_cellcache.restype = C.c_int
-        _LIB = L
-    return _LIB
+        _LIBS[preset] = L
+    return _LIBS[preset]
 
 
-def update_packets(model, cells, ts, packets, est, budget=4):
-    rc = lib().artis_emu_update_packets(C.cast(model.ref(), C.c_void_p), C.cast(cells.ref(), C.c_void_p),
+def update_packets(model, cells, ts, packets, est, budget=4, preset="classic"):
+    rc = lib(preset).artis_emu_update_packets(C.cast(model.ref(), C.c_void_p), C.cast(cells.ref(), C.c_void_p),
                                         C.cast(ts.ref(), C.c_void_p), abi.packets_ptr(packets), len(packets),
                                         C.cast(est.ref(), C.c_void_p), budget)
     if rc != 0:

@@ -32,7 +32,7 @@ def test_exports_every_declared_symbol(lib):
 def test_packet_layout_matches_header(lib):
     lib.artis_amd_sizeof_packet.restype = C.c_size_t
     assert lib.artis_amd_sizeof_packet() == abi.PACKET_DTYPE.itemsize == 256
-    assert lib.artis_amd_abi_version() == 1
+    assert lib.artis_amd_abi_version() == 2
 
 
 def test_no_cpu_fallback(lib):
@@ -94,3 +94,18 @@ def test_packet_struct_matches_reference_layout():
     e = gold["enums"]
     assert (abi.TYPE_RPKT, abi.TYPE_KPKT, abi.TYPE_PRE_KPKT, abi.TYPE_ESCAPE) == (e["TYPE_RPKT"], e["TYPE_KPKT"], e["TYPE_PRE_KPKT"], e["TYPE_ESCAPE"])
     assert (abi.EMTYPE_NOTSET, abi.EMTYPE_FREEFREE) == (e["EMTYPE_NOTSET"], e["EMTYPE_FREEFREE"])
+
+
+def test_one_library_per_options_preset():
+    """Like the reference (one sn3d per artisoptions.h), every options preset of include/artis_options.h is its own
+    library; each reports the preset it was compiled with and exports the same C-ABI."""
+    from artis_amd.build import PRESETS, build as build_preset, so_path
+    from artis_amd.engine import EXPORTED_SYMBOLS
+    assert set(PRESETS) == {"classic", "kilonova_lte"}
+    for preset in PRESETS:
+        L = C.CDLL(build_preset(preset=preset))
+        assert os.path.samefile(build_preset(preset=preset), so_path(preset))
+        L.artis_amd_options_preset.restype = C.c_char_p
+        assert L.artis_amd_options_preset().decode() == preset
+        for name in EXPORTED_SYMBOLS:
+            assert hasattr(L, name), (preset, name)

@@ -32,14 +32,15 @@ def engine_mod():
     return engine
 
 
-def _run_case(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk, kfrac=0.2, gfrac=0.0, pfrac=0.0, bkw=None, pkw=None):
-    model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v, **(bkw or {}))
+def _run_case(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk, kfrac=0.2, gfrac=0.0, pfrac=0.0, bkw=None, pkw=None,
+              options="classic"):
+    model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v, options=options, **(bkw or {}))
     pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=kfrac, gamma_fraction=gfrac, pellet_fraction=pfrac, **(pkw or {}))
     n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
     pa, pb = pk0.copy(), pk0.copy()
     ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
-    oracle.update_packets(model, cs, ts, pa, ea)
-    eng = engine_mod.Engine(model)
+    oracle.update_packets(model, cs, ts, pa, ea, preset=options)
+    eng = engine_mod.Engine(model, preset=options)
     eng.set_cellstate(cs, ts)
     eng.update_packets(pb, eb)
     return model, cs, ts, eng, pa, pb, ea, eb
@@ -95,6 +96,20 @@ def test_engine_matches_oracle_all_packet_types(engine_mod, oracle, gridtype, nc
     parity.compare_stats(eb, ea, "all types: HIP engine vs oracle", same_libm=False)
     parity.compare_estimators(eb, ea, EST_RTOL, "all types: HIP engine vs oracle")
     assert eb.scalars[2] > 1000 and eb.dep_estimator_alpha.sum() > 0   # pellet decays, alpha deposition
+    eng.close()
+
+
+@pytest.mark.parametrize("gridtype,ncoord", [(abi.GRID_CARTESIAN3D, 8), (abi.GRID_SPHERICAL1D, 16)])
+def test_engine_matches_oracle_kilonova_lte_preset(engine_mod, oracle, gridtype, ncoord):
+    """the engine built with the packet-path options of artisoptions_kilonova_lte.h (libartis_amd_kilonova_lte.so)
+    against the oracle built with the same options; all packet types"""
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", ncoord, gridtype, 0.0, 16000, kfrac=0.15, gfrac=0.15,
+                                                    pfrac=0.4, options="kilonova_lte")
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, "kilonova_lte: HIP engine vs oracle")
+    parity.compare_stats(eb, ea, "kilonova_lte: HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, "kilonova_lte: HIP engine vs oracle")
+    assert eb.stats[abi.STAT_X_RPKT_STEPS] > 16000 and eb.colheatingestimator.sum() == 0
+    print(f"worst float rel diff {rep['worst_rel']:.3e}")
     eng.close()
 
 

@@ -10,12 +10,12 @@ import parity
 from artis_amd import abi, synth
 
 
-def _run_both(oracle, model, cs, ts, pk0, budget):
+def _run_both(oracle, model, cs, ts, pk0, budget, options="classic"):
     pa, pb = pk0.copy(), pk0.copy()
     n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
     ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
-    oracle.update_packets(model, cs, ts, pa, ea)
-    emu.update_packets(model, cs, ts, pb, eb, budget=budget)
+    oracle.update_packets(model, cs, ts, pa, ea, preset=options)
+    emu.update_packets(model, cs, ts, pb, eb, budget=budget, preset=options)
     return pa, pb, ea, eb
 
 
@@ -92,6 +92,36 @@ def test_all_packet_types_bit_exact(oracle, gridtype, ncoord, kw, pkw):
     still = pa[pa["type"] == abi.TYPE_RADIOACTIVE_PELLET]
     assert np.all(still["tdecay"] > ts.c.start + ts.c.width) and np.all(still["prop_time"] == ts.c.start + ts.c.width)
     assert not np.any(np.isin(pa["type"], [20, 21, 22, 23, 24]))               # no deposit type survives a call
+
+
+@pytest.mark.parametrize("gridtype,ncoord,thick_v", [
+    (abi.GRID_CARTESIAN3D, 8, 0.0),
+    (abi.GRID_SPHERICAL1D, 16, 5e8),
+    (abi.GRID_CYLINDRICAL2D, 6, 0.0),
+])
+def test_kilonova_lte_options_preset_bit_exact(oracle, gridtype, ncoord, thick_v):
+    """The packet-path options of artisoptions_kilonova_lte.h (BASELINE.json configs[3]) as a second build of the same
+    sources (-DARTIS_PRESET_KILONOVA_LTE, include/artis_options.h): isotropic electron scattering without polarisation,
+    DIRECT_COL_HEAT, interpolated photoionisation cross sections, relativistic Doppler factor with the linear frequency
+    approximation in the line walk (rpkt.cc:188), 200-point rate-coefficient tables from 500 K, and the time-dependent
+    thermalisation of non-thermal particles (update_packets.cc:90). All packet types in one population."""
+    P = "kilonova_lte"
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v, options=P)
+    pk0 = synth.make_packets(model, aux, 4000, kpkt_fraction=0.15, gamma_fraction=0.15, pellet_fraction=0.4)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=P)
+    parity.compare_packets(pb, pa, 0.0, "kilonova_lte: kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, "kilonova_lte: kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, "kilonova_lte: kernel bodies vs oracle")
+    st = ea.stats_dict()
+    assert st["X_RPKT_STEPS"] > 4000 and st["ELECTRON_SCATTERINGS"] > 100 and st["X_MA_JUMPS"] > 10000
+    assert np.all(pa["stokes_q"] == 0) and np.all(pa["stokes_u"] == 0)       # POL_ON off: never touched
+    assert ea.colheatingestimator.sum() == 0                                   # DIRECT_COL_HEAT: estimator unused
+    assert np.count_nonzero(np.isin(pa["type"], [21, 22, 23])) > 0             # particles still slowing down at t_end
+    # the options matter: the classic build gives another history for the same input
+    pc, ec = pk0.copy(), abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
+    model_c, cs_c, ts_c, aux_c = synth.build("small", ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v)
+    oracle.update_packets(model_c, cs_c, ts_c, pc, ec)
+    assert not np.array_equal(pc["nu_cmf"], pa["nu_cmf"])
 
 
 def test_budget_independence(oracle):
