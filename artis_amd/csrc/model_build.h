@@ -18,7 +18,6 @@ struct ModelOwned {
   std::vector<LevelPack> level_pack;
   std::vector<int32_t> level_upcum_start;
   std::vector<ContPack> cont_pack;
-  std::vector<TargetPack> target_pack;
 };
 
 // X(field, element type, element count) for every array pointer of DevModel
@@ -48,7 +47,6 @@ struct ModelOwned {
   X(level_ion, int32_t, (m).nlevels)                                               \
   X(level_pack, LevelPack, (m).nlevels)                                            \
   X(level_upcum_start, int32_t, (m).nlevels)                                       \
-  X(target_pack, TargetPack, (m).nalltrans)                                        \
   X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
   X(alltrans_einstein_A, float, (m).nalltrans)                                     \
@@ -156,18 +154,6 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   }
   v.nupcum = nupcum;
   v.level_upcum_start = own.level_upcum_start.data();
-  own.target_pack.resize(m.nalltrans > 0 ? m.nalltrans : 1);
-  for (int ul = 0; ul < m.nlevels; ul++) {
-    const int ui = own.level_ion[ul];
-    const int ntrans = m.level_ndowntrans[ul] + m.level_nuptrans[ul];
-    for (int t = 0; t < ntrans; t++) {
-      const int ati = m.level_alltrans_startdown[ul] + t;
-      const int target = m.alltrans_targetlevelindex[ati];
-      const LevelPack &tl = own.level_pack[m.ion_uniquelevelindexstart[ui] + target];
-      own.target_pack[ati] = TargetPack{tl.rec_off, tl.alltrans_startdown, (uint16_t)tl.ndown, (uint16_t)tl.nup, target};
-    }
-  }
-  v.target_pack = own.target_pack.data();
   own.cont_pack.resize(m.nbfcontinua);
   for (int i = 0; i < m.nbfcontinua; i++)
     own.cont_pack[i] = ContPack{m.allcont_nu_edge[i], m.allcont_probability[i],

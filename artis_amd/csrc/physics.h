@@ -52,11 +52,7 @@ constexpr int MA_N = ARTIS_MA_ACTION_COUNT;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned int stat_t;
 #define ARTIS_STAT_ADD(env, i, v) atomicAdd(&(env).stats[(i)], (stat_t)(v))
-#ifdef ARTIS_EXPERIMENT_NO_ESTIMATORS  // timing experiment only: results are wrong
-#define ARTIS_EST_ADD(ptr, v) ((void)(ptr), (void)(v))
-#else
 #define ARTIS_EST_ADD(ptr, v) unsafeAtomicAdd((ptr), (v))
-#endif
 #else
 typedef unsigned long long stat_t;
 #define ARTIS_STAT_ADD(env, i, v) ((env).stats[(i)] += (stat_t)(v))
@@ -376,44 +372,10 @@ AHD float phixs_fromtable(const DevModel &M, const float *xs, double nu_edge, do
 }
 // Partition point of a[0..n) for a predicate that is true on a prefix and false on the rest: the index of the first
 // element for which it is false (n if none), i.e. what std::ranges::upper_bound / lower_bound / partition_point return.
-// 8-ary instead of binary: the 7 probes of a round are independent reads, so an array of n elements costs
-// ceil(log8 n) memory round trips instead of log2 n; the result is the same for any partitioned input.
+// (An 8-ary variant with 7 independent probes per round was measured slower on MI355X: the kernels are bound by the
+// number of memory instructions, not by their latency.)
 template <class Pred>
-AHD int partition_point8(const double *a, int n, Pred pred) {
-  int lo = 0, len = n;  // the answer lies in [lo, lo + len]
-  while (len > 8) {
-    const int step = (len + 7) / 8;
-    int cnt = 0;
-#pragma unroll
-    for (int k = 1; k < 8; k++) {
-      const int pidx = lo + (k * step) - 1;
-      const bool valid = pidx < lo + len;
-      const double x = a[valid ? pidx : lo];
-      cnt += (valid && pred(x)) ? 1 : 0;
-    }
-    const int nlo = lo + (cnt * step);
-    const int upper = lo + ((cnt + 1) * step) - 1;  // probe cnt+1: known to be false if it was made
-    const int end = lo + len;
-    len = ((cnt < 7 && upper < end) ? upper : end) - nlo;
-    lo = nlo;
-  }
-  int cnt = 0;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const bool valid = k < len;
-    const double x = a[valid ? lo + k : lo];
-    cnt += (valid && pred(x)) ? 1 : 0;
-  }
-  return lo + cnt;
-}
-// std::ranges::upper_bound / lower_bound on a rising double array
-// measured on MI355X: the propagation kernels are bound by the number of memory instructions, not by their latency,
-// so the binary search (fewest reads) is the default
-#ifndef ARTIS_KARY
-#define ARTIS_KARY 0
-#endif
-template <class Pred>
-AHD int partition_point2(const double *a, int n, Pred pred) {
+AHD int partition_point_d(const double *a, int n, Pred pred) {
   int lo = 0, len = n;
   while (len > 0) {
     const int half = len / 2;
@@ -421,14 +383,7 @@ AHD int partition_point2(const double *a, int n, Pred pred) {
   }
   return lo;
 }
-template <class Pred>
-AHD int partition_point_d(const double *a, int n, Pred pred) {
-#if ARTIS_KARY
-  return partition_point8(a, n, pred);
-#else
-  return partition_point2(a, n, pred);
-#endif
-}
+// std::ranges::upper_bound / lower_bound on a rising double array
 AHD int upper_bound_d(const double *a, int n, double v) {
   if (n <= 0) return 0;
   return partition_point_d(a, n, [v](double x) { return !(v < x); });
@@ -754,25 +709,12 @@ AHD double col_deexc(const DevModel &M, float T_e, float cnne, double epsilon_tr
   }
   return cnne * 8.629e-6 * (double)cs / gu / sqrtf(T_e);
 }
-// col_exc_ratecoeff macroatom.cc:750, with the transition's three constants read by the caller (col_exc_read) so that
-// a loop over transitions can have the reads of several of them in flight
-struct ColRead {
-  float cs, f;
-  bool forbidden;
-};
-AHD ColRead col_exc_read(const DevModel &M, int ati) {
-  ColRead r;
-  r.cs = M.alltrans_coll_str[ati];
-  r.forbidden = M.alltrans_forbidden[ati] != 0;
-  r.f = M.alltrans_osc_strength[ati];
-  return r;
-}
-AHD double col_exc_from(const ColRead r, float T_e, float cnne, double epsilon_trans, double gu, double gl) {
-  const float cs = r.cs;
+AHD double col_exc(const DevModel &M, float T_e, float cnne, double epsilon_trans, double gu, double gl, int ati) {  // macroatom.cc:750
+  const float cs = M.alltrans_coll_str[ati];
   const double eoverkt = epsilon_trans / (KB * T_e);
   if (cs < 0) {
-    if (!r.forbidden) {
-      const double f = r.f;
+    if (!M.alltrans_forbidden[ati]) {
+      const double f = M.alltrans_osc_strength[ati];
       const double g_bar = 0.2;
       const double ex = exp(eoverkt);
       const double Gamma = dmax(g_bar, 0.276 * ex * (-EULERGAMMA - log(eoverkt)));
@@ -781,9 +723,6 @@ AHD double col_exc_from(const ColRead r, float T_e, float cnne, double epsilon_t
     return cnne * 8.629e-6 * 0.01 * exp(-eoverkt) * gu / sqrtf(T_e);
   }
   return cnne * 8.629e-6 * (double)cs * exp(-eoverkt) / gl / sqrtf(T_e);
-}
-AHD double col_exc(const DevModel &M, float T_e, float cnne, double epsilon_trans, double gu, double gl, int ati) {
-  return col_exc_from(col_exc_read(M, ati), T_e, cnne, epsilon_trans, gu, gl);
 }
 
 // ================================================================ cell-cache population
@@ -1138,34 +1077,14 @@ AHD float phixs_finish(const DevModel &M, const PhixsRead r, double nu_edge, dou
 #ifndef ARTIS_CHI_BATCH
 #define ARTIS_CHI_BATCH 4
 #endif
-// iterator over the set bits of a cell's keep bitmap inside [cbegin, cend); the bitmap is read four words (32 bytes)
-// at a time so that a sparse stretch costs one memory round trip per 256 continua
-#ifndef ARTIS_KEEPCHUNK
-#define ARTIS_KEEPCHUNK 0
-#endif
+// iterator over the set bits of a cell's keep bitmap inside [cbegin, cend), one 64-bit word per read
 struct KeepIter {
   const uint64_t *keep;
-  int word, cbegin, cend, chunk;
-  uint64_t bits, w0, w1, w2, w3;
+  int word, cbegin, cend;
+  uint64_t bits;
 };
 AHD uint64_t keep_masked(KeepIter &it) {
-#if !ARTIS_KEEPCHUNK
-  uint64_t bits1 = it.keep[it.word];
-  if (it.word == (it.cbegin / 64)) bits1 &= ~UINT64_C(0) << (unsigned)(it.cbegin % 64);
-  if (((it.word + 1) * 64) > it.cend) bits1 &= ~UINT64_C(0) >> (unsigned)(64 - (it.cend % 64));
-  return bits1;
-#endif
-  const int chunk = it.word >> 2;
-  if (chunk != it.chunk) {
-    const uint64_t *q = it.keep + (chunk * 4);
-    it.w0 = q[0];
-    it.w1 = q[1];
-    it.w2 = q[2];
-    it.w3 = q[3];
-    it.chunk = chunk;
-  }
-  const int sel = it.word & 3;
-  uint64_t bits = (sel == 0) ? it.w0 : ((sel == 1) ? it.w1 : ((sel == 2) ? it.w2 : it.w3));
+  uint64_t bits = it.keep[it.word];
   if (it.word == (it.cbegin / 64)) bits &= ~UINT64_C(0) << (unsigned)(it.cbegin % 64);
   if (((it.word + 1) * 64) > it.cend) bits &= ~UINT64_C(0) >> (unsigned)(64 - (it.cend % 64));
   return bits;
@@ -1206,8 +1125,6 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   it.cbegin = cbegin;
   it.cend = cend;
   it.word = cbegin / 64;
-  it.chunk = -1;
-  it.w0 = it.w1 = it.w2 = it.w3 = 0;
   it.bits = (it.word * 64 < cend) ? keep_masked(it) : 0;
   bool more = (it.word * 64 < cend);
   while (more) {
@@ -1687,8 +1604,7 @@ struct MACtx {
   int c;                    // non-empty model cell
   const double *cellma;     // the cell's row of macro-atom records
   int start_key, start;     // cached get_ionuniquelevelindexstart(element, ion)
-  int lp_key, lp_level;     // (element, ion), level that `lp` belongs to
-  LevelPack lp;
+  LevelPack lp;             // static indices of the current level (ma_prepare)
   int njumps;               // transitions made since the last ma_flush_stats()
 };
 AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
@@ -1697,65 +1613,20 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
   k.start_key = -1;
   k.start = 0;
-  k.lp_key = -1;
-  k.lp_level = -1;
   k.lp = LevelPack{0, 0, 0, 0};
   k.njumps = 0;
   return k;
 }
 
-// upper_bound over the cumulative sums of one block of a macro-atom record (16-byte aligned, non-decreasing):
-// index of the first element > v, at most n
-#ifndef ARTIS_MA_SEARCH
-#define ARTIS_MA_SEARCH 1
-#endif
-AHD int ma_search(const double *a, int n, double v) {
-#if ARTIS_MA_SEARCH == 0
-  if (n <= 0) return 0;
-  return partition_point2(a, n, [v](double x) { return !(v < x); });
-#elif ARTIS_MA_SEARCH == 1
-  return upper_bound_wide(a, n, v);
-#elif ARTIS_MA_SEARCH == 3
-  // eight elements per round, no branches: reads past the end are redirected to the last element
-  int idx = 0;
-  for (int base = 0; base < n; base += 8) {
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int i = base + k;
-      const double x = a[(i < n) ? i : n - 1];
-      cnt += (i < n && x <= v) ? 1 : 0;
-    }
-    idx += cnt;
-    if (cnt < 8) break;
-  }
-  return idx;
-#else
-  // eight elements per round as four 16-byte reads
-  int idx = 0;
-  for (int base = 0; base < n; base += 8) {
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k += 2) {
-      const int i = base + k;
-      if (i < n) {
-        const D2 q = *(const D2 *)(a + i);
-        cnt += (q.x <= v) ? 1 : 0;
-        cnt += (i + 1 < n && q.y <= v) ? 1 : 0;
-      }
-    }
-    idx += cnt;
-    if (cnt < 8) break;
-  }
-  return idx;
-#endif
-}
+// upper_bound over the cumulative sums of one block of a macro-atom record (non-decreasing): index of the first
+// element > v, at most n. Eight independent reads per round (upper_bound_wide). Measured alternatives, all slower on
+// MI355X: bisection (dependent reads), branch-free reads clamped to the last element (more memory instructions),
+// 16-byte paired reads of a padded record.
+AHD int ma_search(const double *a, int n, double v) { return upper_bound_wide(a, n, v); }
 
-// one iteration of the loop of do_macroatom(), macroatom.cc:385-577.
-// ma_jump() makes sure the static indices of the current level are at hand (they come with the transition that led
-// here, tables.h TargetPack; only the first transition of a walk has to look them up) and ma_jump_core() performs the
-// transition given the level's macro-atom record `rates` (tables.h layout) and its transition targets `targets`
-// (down targets, then up targets).
+// one iteration of the loop of do_macroatom(), macroatom.cc:385-577. ma_prepare() looks up the static indices of the
+// current level; ma_jump_internal() / ma_jump_exit() perform the transition given the level's macro-atom record
+// `rates` (tables.h layout) and its transition targets `targets` (down targets, then up targets).
 AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
   const int key = (p.ma_element << 8) | p.ma_ion;
   if (key != k.start_key) {
@@ -1764,22 +1635,8 @@ AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
   }
   return k.start + p.ma_level;
 }
-#ifndef ARTIS_MA_TARGETPACK
-#define ARTIS_MA_TARGETPACK 0  // 1: carry the static indices of the next level with the transition (TargetPack)
-#endif
-#if ARTIS_MA_TARGETPACK
-typedef TargetPack ma_target_t;
-AHD int ma_target_level(const TargetPack &tp) { return tp.level; }
-AHD void ma_set_level(Pkt &p, MACtx &k, const TargetPack tp) {
-  p.ma_level = tp.level;
-  k.lp = LevelPack{tp.rec_off, tp.alltrans_startdown, tp.ndown, tp.nup};
-  k.lp_level = tp.level;
-}
-#else
-typedef int32_t ma_target_t;
-AHD int ma_target_level(int32_t level) { return level; }
-AHD void ma_set_level(Pkt &p, MACtx &, int32_t level) { p.ma_level = level; }
-#endif
+typedef int32_t ma_target_t;  // alltrans.targetlevelindex: the level a transition leads to, within the ion
+AHD void ma_set_level(Pkt &p, int32_t level) { p.ma_level = level; }
 // First half of a transition: draw the process (macroatom.cc:425-431); an internal transition inside the ion is made
 // at once and -1 is returned. Every other process ends the walk in this kernel (deactivation, or a bound-free process
 // for the slow path): its index is returned with its rate, and ma_jump_exit() carries it out. The split lets a kernel
@@ -1821,7 +1678,7 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rates, 
     const double *sums = rates + (down ? marec_down : marec_up(ndown));
     const double targetval = rng_uniform(p) * rate_sel;
     const int ti = ma_search(sums, nsel - 1, targetval);
-    ma_set_level(p, k, targets[first + ti]);
+    ma_set_level(p, targets[first + ti]);
     return -1;
   }
   *rate_out = rate_sel;
@@ -1843,7 +1700,7 @@ AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double
     const int lineindex = M.alltrans_lineindex[startdown + dti];
     if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
     const int ul = ma_locate(env, p, k);
-    const int lul = k.start + ma_target_level(targets[dti]);
+    const int lul = k.start + targets[dti];
     const double e_trans = eps(M, ul) - eps(M, lul);
     const double oldnucmf = p.nu_cmf;
     p.nu_cmf = e_trans / HPLANCK;
@@ -1868,22 +1725,12 @@ AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double
     p.pend_arg = action;
   }
 }
-// make sure k.lp describes the packet's current level (only the first transition of a walk has to look it up when the
-// TargetPack form is compiled in)
-AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) {
-  const int key = (p.ma_element << 8) | p.ma_ion;
-  if (!ARTIS_MA_TARGETPACK || key != k.lp_key || p.ma_level != k.lp_level) {
-    k.lp = env.M.level_pack[ma_locate(env, p, k)];
-    k.lp_key = key;
-    k.lp_level = p.ma_level;
-  }
-}
+// k.lp = the static indices of the packet's current level. (Carrying them with the transition that leads to a level --
+// a 16-byte record per transition instead of the 4-byte level index -- saves this read but was measured 12 % slower: the
+// larger table falls out of L1.)
+AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) { k.lp = env.M.level_pack[ma_locate(env, p, k)]; }
 AHD const ma_target_t *ma_targets(const Env &env, const MACtx &k) {
-#if ARTIS_MA_TARGETPACK
-  return env.M.target_pack + k.lp.alltrans_startdown;
-#else
   return env.M.alltrans_targetlevelindex + k.lp.alltrans_startdown;
-#endif
 }
 AHD void ma_flush_stats(const Env &env, MACtx &k) {
   if (k.njumps != 0) {

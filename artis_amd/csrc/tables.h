@@ -45,28 +45,15 @@ struct alignas(32) ContPack {
   int32_t gi;
   int32_t pad[2];
 };
-// 16-byte record of one entry of globals::alltrans (globals.h:151) as the macro-atom walk needs it: the level the
-// transition leads to (index within the ion) together with THAT level's LevelPack, so that the next transition of
-// the walk can start reading its record without another lookup
-struct alignas(16) TargetPack {
-  int32_t rec_off;
-  int32_t alltrans_startdown;
-  uint16_t ndown, nup;
-  int32_t level;
-};
 // macro-atom record of one (cell, level), 128-byte aligned:
 //   [0..8]               the 9 process rates            (alllevels_maprocessrates, globals.h:286)
 //   [marec_down ..)      cumulative internal-down-same  (allmacroatomictransitions block 2, macroatom.cc:44)
 //   [marec_up(ndown) ..) cumulative internal-up-same    (block 3, macroatom.cc:51)
 //   [marec_rad(ndown, nup) ..) cumulative radiative deexc. (block 1, macroatom.cc:58)
-#ifndef ARTIS_MAREC_PAD
-#define ARTIS_MAREC_PAD 0  // 1: blocks padded to 16-byte boundaries (needed by ARTIS_MA_SEARCH 2)
-#endif
-constexpr int marec_even(int n) { return ARTIS_MAREC_PAD ? ((n + 1) & ~1) : n; }
-constexpr int marec_down = ARTIS_MAREC_PAD ? 10 : 9;
-constexpr int marec_up(int ndown) { return marec_down + marec_even(ndown); }
-constexpr int marec_rad(int ndown, int nup) { return marec_up(ndown) + marec_even(nup); }
-constexpr int marec_size(int ndown, int nup) { return marec_rad(ndown, nup) + marec_even(ndown); }
+constexpr int marec_down = 9;
+constexpr int marec_up(int ndown) { return marec_down + ndown; }
+constexpr int marec_rad(int ndown, int nup) { return marec_up(ndown) + nup; }
+constexpr int marec_size(int ndown, int nup) { return marec_rad(ndown, nup) + ndown; }
 constexpr int MAREC_ALIGN = 16;  // doubles
 
 struct alignas(16) D2 {
@@ -94,7 +81,6 @@ struct DevModel {
   const int32_t *level_ion;  // derived: uniqueionindex of each level
   const LevelPack *level_pack;  // derived
   const int32_t *level_upcum_start;  // derived: offset of the level's upward transitions in DevCache::collexc_cum
-  const TargetPack *target_pack;  // derived, [nalltrans]
   const int32_t *alltrans_lineindex, *alltrans_targetlevelindex;
   const float *alltrans_einstein_A, *alltrans_coll_str, *alltrans_osc_strength;
   const uint8_t *alltrans_forbidden;
