@@ -216,3 +216,66 @@ def test_edge_cases(engine_mod):
     for f in ("tdecay", "number", "pellet_decaytype", "pellet_nucindex", "originated_from_particlenotgamma"):
         assert np.array_equal(pk[f], ref[f])  # fields the path never touches survive the round trip
     eng.close()
+
+
+def test_full_size_properties_50cubed_1e7_packets(engine_mod):
+    """BASELINE.json's bench configuration itself (50^3 cells, w7 atomic data, 1e7 packets) through properties that do not
+    need the oracle: (1) two runs from the same device snapshot are bit-identical (packets and event counters);
+    (2) every packet ends escaped or exactly at the end of the timestep, with finite positive state; (3) packets are
+    independent, so the event counters of the whole population equal the sum over its two halves run separately --
+    exactly -- and the estimators agree to the accuracy of float summation (a checksum of checksums)."""
+    npk = 10_000_000
+    model, cs, ts, aux = synth.build("w7", ncoord=50)
+    pk0 = synth.make_packets(model, aux, npk, seed_base=1281360349, kpkt_fraction=0.02)
+    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+    t_end = ts.c.start + ts.c.width
+    eng = engine_mod.Engine(model)
+    eng.set_cellstate(cs, ts)
+    eng.upload_packets(pk0)
+    eng.snapshot()
+
+    def run():
+        eng.restore()
+        eng.zero_estimators()
+        eng.step()
+        est = abi.Estimators(n, g)
+        eng.download_estimators(est)
+        out = np.empty_like(pk0)
+        out[:] = pk0
+        eng.download_packets(out)
+        return out, est
+
+    p1, e1 = run()
+    p2, e2 = run()
+    assert np.array_equal(e1.stats, e2.stats)
+    for f in abi.PACKET_DTYPE.names:
+        assert np.array_equal(p1[f], p2[f], equal_nan=True), f      # (1) determinism, field by field
+    del p2
+    esc = p1["type"] == abi.TYPE_ESCAPE
+    assert 1000 < esc.sum() < npk
+    assert np.all(p1["prop_time"][~esc] == t_end)                     # (2)
+    assert np.all(np.isin(p1["type"][~esc], [abi.TYPE_RPKT, abi.TYPE_KPKT]))
+    for f in ("pos", "dir", "nu_cmf", "nu_rf", "e_cmf", "e_rf"):
+        assert np.all(np.isfinite(p1[f])), f
+    assert np.all(p1["e_rf"] > 0) and np.all(p1["nu_rf"][p1["type"] == abi.TYPE_RPKT] > 0)
+    assert np.all(np.abs(np.sqrt((p1["dir"] ** 2).sum(axis=1)) - 1) < 1e-9)
+    r_esc = np.sqrt((p1["pos"][esc] ** 2).sum(axis=1)) * (model["tmin"] / p1["prop_time"][esc])
+    assert np.all(r_esc > 0.7 * model["rmax"])
+    steps = int(e1.stats[abi.STAT_X_RPKT_STEPS] + e1.stats[abi.STAT_X_KPKT_STEPS])
+    assert steps > 5e8 and e1.stats_dict()["PKTESCAPES"] == int(esc.sum())
+    assert np.all(e1.J >= 0) and e1.J.sum() > 0 and np.all(np.isfinite(e1.gammaestimator))
+    del p1
+
+    half = npk // 2                                                    # (3) additivity over a split of the population
+    ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
+    pa, pb = pk0[:half].copy(), pk0[half:].copy()
+    eng.update_packets(pa, ea)
+    eng.update_packets(pb, eb)
+    skip = abi.STAT_NAMES.index("UPDATECELL")
+    mask = np.arange(abi.NSTATS) != skip
+    assert np.array_equal((ea.stats + eb.stats)[mask], e1.stats[mask])
+    for k, whole in e1.arrays().items():
+        parts = ea.arrays()[k] + eb.arrays()[k]
+        scale = max(np.abs(whole).max(), 1e-300)
+        assert np.abs(parts - whole).max() / scale < 1e-9, k
+    eng.close()
