@@ -1399,6 +1399,8 @@ static void electron_scatter_rpkt(artis_packet *p) {
   frame_transform(p->dir, p->stokes_q, p->stokes_u, vel_vec, old_dir_cmf, &q_i_cmf, &u_i_cmf);
 #else
   angle_ab(p->dir, vel_vec, old_dir_cmf);
+  (void)q_i_cmf;
+  (void)u_i_cmf;
 #endif
   double M = 0., phisc = 0.;
 #if ARTIS_OPT_DIPOLE
