@@ -97,13 +97,24 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_prefix(Env env) {
 }
 
 // ------------------------------------------------------------------ packet layout kernels
-__global__ void __launch_bounds__(BLOCK) k_aos_to_soa(const artis_packet *aos, PktSoA P) {
+// The SoA slot of a packet is not its index in the caller's array: slots are handed out in the order of the packets'
+// propagation cells at upload (perm[slot] = index in the caller's array), so that the lanes of a wave -- whose work list
+// is sorted by cell -- read and write neighbouring slots. Thermal packets never leave their cell, r-packets drift away
+// from this order only gradually. perm == nullptr: identity.
+__global__ void __launch_bounds__(BLOCK) k_aos_to_soa(const artis_packet *aos, PktSoA P, const int32_t *perm) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < P.n) aos_to_soa(aos[i], P, i);
+  if (i < P.n) aos_to_soa(aos[perm ? perm[i] : i], P, i);
 }
-__global__ void __launch_bounds__(BLOCK) k_soa_to_aos(PktSoA P, artis_packet *aos) {
+__global__ void __launch_bounds__(BLOCK) k_soa_to_aos(PktSoA P, artis_packet *aos, const int32_t *perm) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < P.n) soa_to_aos(P, i, aos[i]);
+  if (i < P.n) soa_to_aos(P, i, aos[perm ? perm[i] : i]);
+}
+__global__ void __launch_bounds__(BLOCK) k_aos_cellkeys(const artis_packet *aos, int64_t n, int32_t ngrid, int32_t *ident, int32_t *keys) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  ident[i] = (int32_t)i;
+  const int32_t c = aos[i].cellindex;
+  keys[i] = (c >= 0 && c < ngrid) ? c : 0;  // a packet of a type this path does not own may carry any cell index
 }
 
 // append `pi` of every lane with flag set to list[], one atomic per wave (wave-ballot compaction)
@@ -586,6 +597,9 @@ struct artis_amd_engine {
   int64_t aos_capacity = 0;
   int32_t *d_lists[NEXT_NKINDS][2] = {};      // per kind: current and alternate work list
   int32_t *d_sorted = nullptr;                // counting-sort output
+  int32_t *d_perm = nullptr;                  // SoA slot -> index in the caller's packet array (k_aos_to_soa)
+  bool use_perm = false;                      // d_perm describes the resident population
+  bool slot_order_by_cell = true;             // ARTIS_AMD_SLOTSORT=0: slots in the caller's order
   int32_t *d_hist = nullptr;                  // [ngrid * SORT_NUBINS + 1]
   int32_t *d_tiles = nullptr;                 // scan tile totals
   int32_t *d_count = nullptr;                 // [NEXT_NKINDS] current-list counts, [NEXT_NKINDS] alternate-list count
@@ -656,7 +670,9 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
       e->d_lists[kind][k] = nullptr;
     }
   if (e->d_sorted) (void)hipFree(e->d_sorted);
+  if (e->d_perm) (void)hipFree(e->d_perm);
   e->d_sorted = nullptr;
+  e->d_perm = nullptr;
   if (e->d_gamma_ws) (void)hipFree(e->d_gamma_ws);
   if (e->d_gamma_gi) (void)hipFree(e->d_gamma_gi);
   if (e->d_gamma_n) (void)hipFree(e->d_gamma_n);
@@ -671,6 +687,7 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
   for (int kind = 1; kind < NEXT_NKINDS; kind++)
     for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void **)&e->d_lists[kind][k], listbytes));
   HIP_TRY(hipMalloc((void **)&e->d_sorted, listbytes));
+  HIP_TRY(hipMalloc((void **)&e->d_perm, listbytes));
   e->ws_capacity = n > 0 ? n : 1;
   const size_t wsbytes = sizeof(double) * (size_t)(e->Mh.nbfcontinua_ground + 1) * (size_t)e->ws_capacity;
   HIP_TRY(hipMalloc((void **)&e->d_gamma_ws, wsbytes));
@@ -819,6 +836,7 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   }
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_R")) e->budget_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_T")) e->budget_t = std::max(1, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_SLOTSORT")) e->slot_order_by_cell = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
@@ -833,7 +851,7 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->model_allocs);
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
-  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_sorted, e->d_hist, e->d_tiles,
+  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_sorted, e->d_perm, e->d_hist, e->d_tiles,
                   e->d_count, e->d_cursors, e->d_gamma_ws, e->d_gamma_gi, e->d_gamma_n};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -919,7 +937,25 @@ int artis_amd_packets_upload(artis_amd_engine *e, const artis_packet *packets, i
   if (rc != ARTIS_OK) return rc;
   if (npackets > 0) {
     HIP_TRY(hipMemcpy(e->d_aos, packets, sizeof(artis_packet) * (size_t)npackets, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_aos_to_soa, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->d_aos, e->P);
+    e->use_perm = false;
+    if (e->slot_order_by_cell && e->sort_lists && npackets >= 2 * BLOCK) {
+      // counting sort of the packet indices by propagation cell (the work-list sort kernels; the lists are free now)
+      int32_t *ident = e->d_lists[NEXT_RPKT][0], *keys = e->d_lists[NEXT_RPKT][1];
+      const int32_t n32 = (int32_t)npackets;
+      const int32_t nkeys = e->Mh.ngrid;
+      hipStream_t s = nullptr;
+      hipLaunchKernelGGL(k_aos_cellkeys, dim3(nblocks(npackets)), dim3(BLOCK), 0, s, e->d_aos, npackets, nkeys, ident, keys);
+      HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(nkeys + 1), s));
+      hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n32)), dim3(BLOCK), 0, s, ident, n32, keys, (const double *)nullptr, 1, e->d_hist);
+      const int ntiles = (nkeys + SCAN_TILE - 1) / SCAN_TILE;
+      hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
+      hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, e->d_tiles, ntiles);
+      hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
+      hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n32)), dim3(BLOCK), 0, s, ident, n32, keys, (const double *)nullptr, 1, e->d_hist,
+                         e->d_perm);
+      e->use_perm = true;
+    }
+    hipLaunchKernelGGL(k_aos_to_soa, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->d_aos, e->P, e->use_perm ? e->d_perm : nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
   }
@@ -937,7 +973,7 @@ int artis_amd_packets_download(artis_amd_engine *e, artis_packet *packets, int64
   if (rc != ARTIS_OK) return rc;
   // start from the caller's structs so that the fields this path never touches keep their values
   HIP_TRY(hipMemcpy(e->d_aos, packets, sizeof(artis_packet) * (size_t)npackets, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_soa_to_aos, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->P, e->d_aos);
+  hipLaunchKernelGGL(k_soa_to_aos, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->P, e->d_aos, e->use_perm ? e->d_perm : nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(packets, e->d_aos, sizeof(artis_packet) * (size_t)npackets, hipMemcpyDeviceToHost));
   return ARTIS_OK;
