@@ -12,7 +12,7 @@ EXACT_STATS = list(range(abi.STAT_COUNT)) + [abi.STAT_X_RPKT_STEPS, abi.STAT_X_K
 
 def compare_packets(got: np.ndarray, want: np.ndarray, rtol: float, what: str = "") -> dict:
     """Integer fields (type, cell, line indices, emission/absorption types, scatter counts) and the RNG state
-    must be identical; floating-point fields within rtol (0.0 = bit-exact)."""
+    must be identical; floating-point fields within rtol (0.0 = bit-exact), vectors relative to their length."""
     assert len(got) == len(want)
     rep = {}
     for f in abi.PACKET_INT_FIELDS:
@@ -28,8 +28,12 @@ def compare_packets(got: np.ndarray, want: np.ndarray, rtol: float, what: str = 
             same = (a == b) | both_nan
             assert same.all(), f"{what}: float field {f} not bit-identical for {np.count_nonzero(~same)} values"
         else:
-            denom = np.maximum(np.abs(a), np.abs(b))
-            denom[denom == 0] = 1.0
+            if a.ndim == 2:  # 3-vectors (pos, dir, em_pos, trueem_pos): error relative to the length of the vector,
+                # not to each component (a component that happens to be ~0 carries the absolute rounding of the others)
+                denom = np.broadcast_to(np.sqrt(np.nansum(b * b, axis=1))[:, None], a.shape).copy()
+            else:
+                denom = np.maximum(np.abs(a), np.abs(b))
+            denom[~(denom > 0)] = 1.0
             rel = np.abs(a - b) / denom
             rel[both_nan] = 0.0
             assert not np.isnan(rel).any(), f"{what}: NaN mismatch in {f}"
