@@ -113,6 +113,31 @@ def test_engine_matches_oracle_kilonova_lte_preset(engine_mod, oracle, gridtype,
     eng.close()
 
 
+def test_consecutive_timesteps_match_oracle(engine_mod, oracle):
+    """three consecutive timesteps, with the packets resident on the device in between (upload once, set the next
+    timestep, step, ... download once) against the oracle called once per timestep"""
+    model, cs, ts, aux = synth.build("small", ncoord=8)
+    pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.2, gamma_fraction=0.1, pellet_fraction=0.3)
+    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+    pa, pb = pk0.copy(), pk0.copy()
+    ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
+    eng = engine_mod.Engine(model)
+    eng.upload_packets(pb)
+    t = aux["t"]
+    for step in range(3):
+        tsn = synth.make_timestep(t, width_frac=0.05, vmax=model["vmax"], nts=10 + step)
+        oracle.update_packets(model, cs, tsn, pa, ea)
+        eng.set_cellstate(cs, tsn)
+        eng.step()
+        t = tsn.c.start + tsn.c.width
+    eng.download_packets(pb)
+    eng.download_estimators(eb)
+    parity.compare_packets(pb, pa, FLOAT_RTOL, "3 timesteps: HIP engine vs oracle")
+    parity.compare_stats(eb, ea, "3 timesteps: HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, "3 timesteps: HIP engine vs oracle")
+    eng.close()
+
+
 def test_engine_matches_oracle_w7_atomic_data(engine_mod, oracle):
     """The benchmark's atomic data set (7 elements, 33 ions, ~1.4e4 lines) on a small grid."""
     model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "w7", 10, abi.GRID_CARTESIAN3D, 0.0, 6000, kfrac=0.05)

@@ -124,6 +124,28 @@ def test_kilonova_lte_options_preset_bit_exact(oracle, gridtype, ncoord, thick_v
     assert not np.array_equal(pc["nu_cmf"], pa["nu_cmf"])
 
 
+def test_consecutive_timesteps_bit_exact(oracle):
+    """Three consecutive timesteps on the same population (the reference's timestep loop calls update_packets() once per
+    timestep): packets that end a timestep in flight, as k-packets or as undecayed pellets continue in the next one."""
+    model, cs, ts, aux = synth.build("small", ncoord=8)
+    pk0 = synth.make_packets(model, aux, 2500, kpkt_fraction=0.2, gamma_fraction=0.1, pellet_fraction=0.3)
+    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+    pa, pb = pk0.copy(), pk0.copy()
+    t = aux["t"]
+    for step in range(3):
+        tsn = synth.make_timestep(t, width_frac=0.05, vmax=model["vmax"], nts=10 + step)
+        ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
+        oracle.update_packets(model, cs, tsn, pa, ea)
+        emu.update_packets(model, cs, tsn, pb, eb, budget=3)
+        parity.compare_packets(pb, pa, 0.0, f"timestep {step}")
+        parity.compare_stats(eb, ea, f"timestep {step}")
+        parity.compare_estimators(eb, ea, 1e-11, f"timestep {step}")
+        t = tsn.c.start + tsn.c.width
+        alive = pa["type"] != abi.TYPE_ESCAPE
+        assert np.all(pa["prop_time"][alive] == t)
+    assert np.count_nonzero(pa["type"] == abi.TYPE_RADIOACTIVE_PELLET) < np.count_nonzero(pk0["type"] == abi.TYPE_RADIOACTIVE_PELLET)
+
+
 def test_budget_independence(oracle):
     """A launch boundary may fall between any two do_packet() calls without changing a packet's history."""
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
