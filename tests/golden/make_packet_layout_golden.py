@@ -1,4 +1,4 @@
-"""Regenerate tests/golden/packet_layout_reference.json from the REFERENCE's own packet.h (GPU_ON build).
+"""Regenerate tests/golden/packet_layout_reference.json from the REFERENCE's own packet.h (GPU_ON build) and stats.h.
 
 Needs /root/reference (this container only). `make -C oracle ref` compiles oracle/ref_harness/ref_packet_layout_main.cc
 against /root/reference/packet.h (included where it lies, never copied); the harness prints offsetof/sizeof of every
@@ -21,6 +21,11 @@ for line in txt.strip().splitlines():
         out["enums"][parts[1]] = int(parts[2])
     else:
         out["fields"][parts[0]] = {"offset": int(parts[1]), "size": int(parts[2])}
+# event counters: stats::Counter of the reference's stats.h
+out["stats_counters"] = {}
+for line in subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "ref_stats_enum")], text=True).strip().splitlines():
+    name, val = line.split()
+    out["stats_counters"][name] = int(val)
 with open(os.path.join(HERE, "packet_layout_reference.json"), "w") as f:
     json.dump(out, f, indent=1)
 print("wrote packet_layout_reference.json:", len(out["fields"]), "fields, sizeof", out["sizeof"])

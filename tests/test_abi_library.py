@@ -96,6 +96,25 @@ def test_packet_struct_matches_reference_layout():
     assert (abi.EMTYPE_NOTSET, abi.EMTYPE_FREEFREE) == (e["EMTYPE_NOTSET"], e["EMTYPE_FREEFREE"])
 
 
+def test_event_counters_match_reference_enum():
+    """ARTIS_STAT_* (include/artis_amd.h) and abi.STAT_NAMES against stats::Counter of the reference's stats.h compiled in
+    place (tests/golden/packet_layout_reference.json): artis_estimators.stats is indexed exactly like the reference's
+    event counters."""
+    import json
+    from artis_amd import abi
+    with open(os.path.join(os.path.dirname(__file__), "golden", "packet_layout_reference.json")) as f:
+        gold = json.load(f)["stats_counters"]
+    assert gold["COUNT"] == abi.STAT_COUNT == 34
+    for name, val in gold.items():
+        if name != "COUNT":
+            assert abi.STAT_NAMES[val] == name, (name, val)
+    hdr = open(os.path.join(ROOT, "include", "artis_amd.h")).read()
+    for name, val in gold.items():
+        cname = name.replace("_STAT_", "_", 1)  # MA_STAT_ACTIVATION_BB -> ARTIS_STAT_MA_ACTIVATION_BB
+        m = re.search(r"ARTIS_STAT_%s = (\d+)" % re.escape(cname), hdr)
+        assert m and int(m.group(1)) == val, name
+
+
 def test_one_library_per_options_preset():
     """Like the reference (one sn3d per artisoptions.h), every options preset of include/artis_options.h is its own
     library; each reports the preset it was compiled with and exports the same C-ABI."""
