@@ -35,7 +35,7 @@ constexpr double ME = 9.1093897e-28;
 constexpr double MH = 1.67352e-24;
 constexpr double MEV = 1.6021772e-6;
 constexpr double THOMSON_LIMIT = 1e-2;  // constants.h:38
-constexpr double NU_100KEV = 2.41326e+19, NU_1MEV = 2.41326e+20, NU_1P022MEV = 2.46636e+20, NU_1P5MEV = 3.61990e+20;  // constants.h:64-67
+constexpr double NU_100KEV = 2.41326e+19, NU_1MEV = 2.41326e+20, NU_1P022MEV = 2.46636e+20, NU_1P5MEV = 3.61990e+20;  // gammapkt.cc:64-67
 constexpr double KB = 1.38064852e-16;
 constexpr double SAHACONST = 2.0706659e-16;
 constexpr double EULERGAMMA = 0.577215664901532860606512090082402431;

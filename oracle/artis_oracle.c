@@ -54,7 +54,7 @@
 #define MH 1.67352e-24
 #define MEV 1.6021772e-6
 #define THOMSON_LIMIT 1e-2 /* constants.h:38 */
-#define NU_100KEV 2.41326e+19 /* constants.h:64-67 */
+#define NU_100KEV 2.41326e+19 /* gammapkt.cc:64-67 */
 #define NU_1MEV 2.41326e+20
 #define NU_1P022MEV 2.46636e+20
 #define NU_1P5MEV 3.61990e+20
@@ -2476,6 +2476,19 @@ static void oracle_init(Oracle *o, const artis_model *m, const artis_cellstate *
   o->cache_cap = cap ? atoi(cap) : 0;
 }
 double artis_oracle_last_populate_seconds(void) { return g_last_populate_seconds; }
+/* the constants of constants.h as restated at the top of this file, for tests/test_oracle_reference_props.py */
+int artis_oracle_constants(const char **names, double *values, int maxn) {
+  static const char *N[] = {"CLIGHT", "CLIGHT_PROP", "H", "MH", "ME", "PI", "EV", "MEV", "SIGMA_T", "THOMSON_LIMIT", "KB", "SAHACONST",
+                            "EULERGAMMA", "CLIGHTSQUARED", "CLIGHTSQUAREDOVERTWOH", "HOVERKB", "HCLIGHTOVERFOURPI", "H_ionpot", "C_0"};
+  const double V[] = {CLIGHT, CLIGHT_PROP, H_PLANCK, MH, ME, PI, EV, MEV, SIGMA_T, THOMSON_LIMIT, KB, SAHACONST,
+                      EULERGAMMA, CLIGHTSQUARED, CLIGHTSQUAREDOVERTWOH, HOVERKB, HCLIGHTOVERFOURPI, H_ionpot, C_0};
+  const int n = (int)(sizeof(V) / sizeof(V[0]));
+  for (int i = 0; i < n && i < maxn; i++) {
+    names[i] = N[i];
+    values[i] = V[i];
+  }
+  return n;
+}
 void artis_oracle_set_visit_hist(int64_t *hist, int nlevels) { g_visit_hist = hist; g_visit_nlevels = nlevels; }
 static void oracle_free(Oracle *o) {
   for (int c = 0; c < o->m->npts_nonempty; c++) {

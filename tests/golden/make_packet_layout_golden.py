@@ -26,6 +26,11 @@ out["stats_counters"] = {}
 for line in subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "ref_stats_enum")], text=True).strip().splitlines():
     name, val = line.split()
     out["stats_counters"][name] = int(val)
+# physical constants of the reference's constants.h, as hex floats
+out["constants"] = {}
+for line in subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "ref_constants")], text=True).strip().splitlines():
+    name, val = line.split()
+    out["constants"][name] = val
 with open(os.path.join(HERE, "packet_layout_reference.json"), "w") as f:
     json.dump(out, f, indent=1)
 print("wrote packet_layout_reference.json:", len(out["fields"]), "fields, sizeof", out["sizeof"])

@@ -81,6 +81,20 @@ void populate_all(Emu &e) {
 
 extern "C" {
 
+// the constants of constants.h as restated in physics.h, for tests/test_oracle_reference_props.py
+int artis_emu_constants(const char **names, double *values, int maxn) {
+  using namespace artis;
+  static const char *N[] = {"CLIGHT", "CLIGHT_PROP", "H", "MH", "ME", "PI", "EV", "MEV", "SIGMA_T", "THOMSON_LIMIT", "KB", "SAHACONST",
+                            "EULERGAMMA", "CLIGHTSQUARED", "CLIGHTSQUAREDOVERTWOH", "HOVERKB", "HCLIGHTOVERFOURPI", "H_ionpot", "C_0"};
+  const double V[] = {CLIGHT, CLIGHT_PROP, HPLANCK, MH, ME, PI, EV, MEV, SIGMA_T, THOMSON_LIMIT, KB, SAHACONST,
+                      EULERGAMMA, CLIGHTSQUARED, CLIGHTSQUAREDOVERTWOH, HOVERKB, HCLIGHTOVERFOURPI, H_ionpot, C_0};
+  const int n = (int)(sizeof(V) / sizeof(V[0]));
+  for (int i = 0; i < n && i < maxn; i++) {
+    names[i] = N[i];
+    values[i] = V[i];
+  }
+  return n;
+}
 // search helpers of physics.h, for tests/test_kernel_bodies_vs_oracle.py
 int artis_emu_upper_bound(const double *a, int n, double v) { return artis::upper_bound_d(a, n, v); }
 int artis_emu_lower_bound(const double *a, int n, double v) { return artis::lower_bound_d(a, n, v); }

@@ -310,3 +310,21 @@ def test_packets_stay_inside_their_cells(oracle, gridtype, ncoord):
     r_esc = np.sqrt((esc["pos"] ** 2).sum(axis=1)) * (tmin / esc["prop_time"])
     assert np.all(r_esc >= 0.7 * rmax)   # left through the outer surface (a face of the cube / cylinder / the sphere)
     assert np.all(pk["e_rf"] > 0) and np.all(np.isfinite(pk["pos"]))
+
+
+def test_physical_constants_match_reference_constants_h(oracle):
+    """The constants restated in oracle/artis_oracle.c and in artis_amd/csrc/physics.h against the reference's constants.h
+    compiled in place (tests/golden/packet_layout_reference.json), bit for bit."""
+    import hostemu_binding
+    with open(os.path.join(os.path.dirname(__file__), "golden", "packet_layout_reference.json")) as f:
+        gold = json.load(f)["constants"]
+    for L, fn in ((oracle.lib(), "artis_oracle_constants"), (hostemu_binding.lib(), "artis_emu_constants")):
+        names = (C.c_char_p * 64)()
+        vals = (C.c_double * 64)()
+        f = getattr(L, fn)
+        f.restype = C.c_int
+        n = f(names, vals, 64)
+        assert n == len(gold) == 19
+        for i in range(n):
+            name = names[i].decode()
+            assert float(vals[i]).hex() == float.fromhex(gold[name]).hex(), (fn, name)
