@@ -1210,6 +1210,7 @@ AHD void chi_rpkt_cont(const Env &env, double nu_cmf, Chi &x, int c, int64_t slo
 }
 // closest_transition rpkt.h:155
 AHD int closest_transition(const double *nu, int nlines, double nu_cmf, int next_trans) {
+  if (nlines <= 0) return -1;  // an empty line list (the reference would read linelist.nu.back() of an empty span)
   if (next_trans > (nlines - 1)) return -1;
   if (nu_cmf < nu[nlines - 1]) return -1;
   if (next_trans > 0) return next_trans;

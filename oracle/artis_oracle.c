@@ -1258,6 +1258,7 @@ static inline double chi_total(const ContOpacity *chi) { /* rpkt.h:100 */
 
 /* closest_transition rpkt.h:155 */
 static int closest_transition(const double *linelistnu, int nlines, double nu_cmf, int next_trans) {
+  if (nlines <= 0) return -1; /* an empty line list: the reference would read linelist.nu.back() of an empty span */
   if (next_trans > (nlines - 1)) return -1;
   if (nu_cmf < linelistnu[nlines - 1]) return -1;
   if (next_trans > 0) return next_trans;

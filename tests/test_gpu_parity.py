@@ -113,6 +113,17 @@ def test_engine_matches_oracle_kilonova_lte_preset(engine_mod, oracle, gridtype,
     eng.close()
 
 
+@pytest.mark.parametrize("name,spec", [("oneion", ([(26, 2, 1)], 8, 0.5, 10)), ("twoel", ([(14, 1, 2), (26, 1, 1)], 5, 0.6, 8))])
+def test_degenerate_atomic_data(engine_mod, oracle, name, spec):
+    """zero lines / zero bound-free continua / a single cooling term through the C-ABI (zero-length tables are legal)"""
+    synth.PRESETS[name] = spec
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, name, 5, abi.GRID_CARTESIAN3D, 0.0, 6000, kfrac=0.3, gfrac=0.1)
+    parity.compare_packets(pb, pa, FLOAT_RTOL, name)
+    parity.compare_stats(eb, ea, name, same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, name)
+    eng.close()
+
+
 def test_consecutive_timesteps_match_oracle(engine_mod, oracle):
     """three consecutive timesteps, with the packets resident on the device in between (upload once, set the next
     timestep, step, ... download once) against the oracle called once per timestep"""

@@ -146,6 +146,25 @@ def test_consecutive_timesteps_bit_exact(oracle):
     assert np.count_nonzero(pa["type"] == abi.TYPE_RADIOACTIVE_PELLET) < np.count_nonzero(pk0["type"] == abi.TYPE_RADIOACTIVE_PELLET)
 
 
+DEGENERATE = {"oneion": ([(26, 2, 1)], 8, 0.5, 10),            # one ion, one level: no lines, no continua at all
+              "twoel": ([(14, 1, 2), (26, 1, 1)], 5, 0.6, 8)}    # a handful of levels, one ground continuum
+
+
+@pytest.mark.parametrize("name", sorted(DEGENERATE))
+def test_degenerate_atomic_data_bit_exact(oracle, name):
+    """Empty and nearly empty tables (zero lines, zero bound-free continua, a single cooling term): the paths that loop
+    over them must simply do nothing."""
+    synth.PRESETS[name] = DEGENERATE[name]
+    model, cs, ts, aux = synth.build(name, ncoord=5)
+    assert model["nlines"] == (0 if name == "oneion" else model["nlines"])
+    pk0 = synth.make_packets(model, aux, 1500, kpkt_fraction=0.3, gamma_fraction=0.1)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3)
+    parity.compare_packets(pb, pa, 0.0, name)
+    parity.compare_stats(eb, ea, name)
+    parity.compare_estimators(eb, ea, 1e-11, name)
+    assert ea.stats[abi.STAT_X_RPKT_STEPS] > 1500
+
+
 def test_budget_independence(oracle):
     """A launch boundary may fall between any two do_packet() calls without changing a packet's history."""
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
