@@ -124,6 +124,25 @@ def test_degenerate_atomic_data(engine_mod, oracle, name, spec):
     eng.close()
 
 
+def test_population_sizes_around_wave_and_sort_boundaries(engine_mod, oracle):
+    """ragged populations: 1 .. 1025 packets (below / at / above a wavefront, a workgroup and the list-sort threshold), all
+    packet types, one engine reused for all sizes (buffers grow and shrink)"""
+    model, cs, ts, aux = synth.build("tiny", ncoord=6)
+    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+    eng = engine_mod.Engine(model)
+    eng.set_cellstate(cs, ts)
+    for npk in (1025, 1, 2, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1024):
+        pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=0.3, gamma_fraction=0.1, pellet_fraction=0.2, seed=npk)
+        pa, pb = pk0.copy(), pk0.copy()
+        ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
+        oracle.update_packets(model, cs, ts, pa, ea)
+        eng.update_packets(pb, eb)
+        parity.compare_packets(pb, pa, FLOAT_RTOL, f"{npk} packets")
+        parity.compare_stats(eb, ea, f"{npk} packets", same_libm=False)
+        parity.compare_estimators(eb, ea, EST_RTOL, f"{npk} packets")
+    eng.close()
+
+
 def test_consecutive_timesteps_match_oracle(engine_mod, oracle):
     """three consecutive timesteps, with the packets resident on the device in between (upload once, set the next
     timestep, step, ... download once) against the oracle called once per timestep"""
