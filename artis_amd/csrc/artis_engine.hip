@@ -2,7 +2,7 @@
 //
 // Layout of the work on the GPU (gfx950, wave64):
 //   * model tables, cell state and the per-cell cache live in HBM for the whole timestep;
-//   * packets are structure-of-arrays columns (tables.h PktSoA), one thread per packet;
+//   * packets are three arrays of cache-line records (tables.h PktStore: hot / flight / cold), one lane per packet;
 //   * one timestep = populate kernels (cell cache) + repeated k_propagate launches over a compacted
 //     list of packets that still need updating. Each thread advances its packet by at most `budget`
 //     do_packet() calls, then survivors are appended to the next list with a wave ballot;
@@ -97,17 +97,17 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_prefix(Env env) {
 }
 
 // ------------------------------------------------------------------ packet layout kernels
-// The SoA slot of a packet is not its index in the caller's array: slots are handed out in the order of the packets'
+// The slot of a packet is not its index in the caller's array: slots are handed out in the order of the packets'
 // propagation cells at upload (perm[slot] = index in the caller's array), so that the lanes of a wave -- whose work list
-// is sorted by cell -- read and write neighbouring slots. Thermal packets never leave their cell, r-packets drift away
+// is sorted by cell -- read and write neighbouring records. Thermal packets never leave their cell, r-packets drift away
 // from this order only gradually. perm == nullptr: identity.
-__global__ void __launch_bounds__(BLOCK) k_aos_to_soa(const artis_packet *aos, PktSoA P, const int32_t *perm) {
+__global__ void __launch_bounds__(BLOCK) k_aos_to_rec(const artis_packet *aos, PktStore P, const int32_t *perm) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < P.n) aos_to_soa(aos[perm ? perm[i] : i], P, i);
+  if (i < P.n) aos_to_rec(aos[perm ? perm[i] : i], P, i);
 }
-__global__ void __launch_bounds__(BLOCK) k_soa_to_aos(PktSoA P, artis_packet *aos, const int32_t *perm) {
+__global__ void __launch_bounds__(BLOCK) k_rec_to_aos(PktStore P, artis_packet *aos, const int32_t *perm) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < P.n) soa_to_aos(P, i, aos[perm ? perm[i] : i]);
+  if (i < P.n) rec_to_aos(P, i, aos[perm ? perm[i] : i]);
 }
 __global__ void __launch_bounds__(BLOCK) k_aos_cellkeys(const artis_packet *aos, int64_t n, int32_t ngrid, int32_t *ident, int32_t *keys) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -117,8 +117,8 @@ __global__ void __launch_bounds__(BLOCK) k_aos_cellkeys(const artis_packet *aos,
   keys[i] = (c >= 0 && c < ngrid) ? c : 0;  // a packet of a type this path does not own may carry any cell index
 }
 
-// append `pi` of every lane with flag set to list[], one atomic per wave (wave-ballot compaction)
-__device__ inline void wave_append(bool flag, int32_t pi, int32_t *list, int32_t *count) {
+// append (pi, key) of every lane with flag set to list[] / keys[], one atomic per wave (wave-ballot compaction)
+__device__ inline void wave_append(bool flag, int32_t pi, int32_t key, int32_t *list, int32_t *keys, int32_t *count) {
   const unsigned long long mask = __ballot(flag);
   if (mask == 0) return;
   const int lane = threadIdx.x & 63;
@@ -127,7 +127,10 @@ __device__ inline void wave_append(bool flag, int32_t pi, int32_t *list, int32_t
   const int leader = __ffsll((long long)mask) - 1;
   if (lane == leader) base = atomicAdd(count, __popcll(mask));
   base = __shfl(base, leader);
-  if (flag) list[base + prefix] = pi;
+  if (flag) {
+    list[base + prefix] = pi;
+    keys[base + prefix] = key;
+  }
 }
 
 // Blocks are dealt round-robin over the 8 XCDs (each with its own L2). The work lists are sorted by cell, so give
@@ -140,62 +143,69 @@ __device__ inline int64_t xcd_chunk(int64_t b, int64_t nb) {
 
 // Work lists, one per kind of pending work (physics.h NEXT_*). A kernel consumes the whole current list of ITS kind and
 // appends packets to the current lists of the other kinds; packets that stay with the kernel's own kind (launch budget
-// used up) go to that kind's alternate list, which becomes its current list afterwards.
+// used up) go to that kind's alternate list, which becomes its current list afterwards. Every entry carries its sort
+// key (physics.h list_sort_key), written by the lane that still has the packet in registers, so that sorting a list
+// never touches the packet records.
 struct Lists {
   int32_t *lst[NEXT_NKINDS];  // current list of each kind
+  int32_t *key[NEXT_NKINDS];  // ... and the sort keys of its entries
   int32_t *counts;            // [NEXT_NKINDS] fill counts of the current lists
   int32_t self_kind;          // kind of the running kernel
   int32_t *self_list;         // its alternate list
+  int32_t *self_key;
   int32_t *self_count;
   int32_t kpkt_slot;          // list that takes k-packets: NEXT_KPKT, or NEXT_MA when k-packets and macro-atoms share the
                               // fused thermal kernel
+  int32_t nubins;             // frequency bins of the r-packet list's keys (1 = sort by cell only)
 };
-__device__ inline void append_by_kind(int kind, int32_t pi, const Lists &L) {
+__device__ inline void append_by_kind(int kind, int32_t pi, int32_t cellindex, double nu_cmf, const Lists &L) {
   const int slot = (kind == NEXT_KPKT) ? L.kpkt_slot : kind;
+  const int32_t key = list_sort_key(cellindex, nu_cmf, (slot == NEXT_RPKT) ? L.nubins : 1);
 #pragma unroll
   for (int k = 1; k < NEXT_NKINDS; k++) {
     int32_t *dst = (k == L.self_kind) ? L.self_list : L.lst[k];
+    int32_t *dkey = (k == L.self_kind) ? L.self_key : L.key[k];
     int32_t *cnt = (k == L.self_kind) ? L.self_count : (L.counts + k);
-    wave_append(slot == k, pi, dst, cnt);
+    wave_append(slot == k, pi, key, dst, dkey, cnt);
   }
 }
-__global__ void __launch_bounds__(BLOCK) k_classify(PktSoA P, double ts_end, Lists L) {
+// start of update_packets(): every resident packet is put on the list of its kind. A ContinuumOpacity never survives
+// into another call (rpkt.cc:1023 compares globals::timestep; the cell state may have changed in between).
+__global__ void __launch_bounds__(BLOCK) k_classify(Env env, Lists L) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   int kind = NEXT_DONE;
-  if (i < P.n) {
-    const int type = P.type[i];
-    if (P.pend[i] != PEND_NONE) {
+  int32_t cellindex = 0;
+  double nu_cmf = 0.;
+  if (i < env.P.n) {
+    PktHot &h = env.P.hot[i];
+    const int type = h.type;
+    cellindex = h.cellindex;
+    nu_cmf = h.nu_cmf;
+    if (h.chi_mgi >= 0) h.chi_mgi = -1;
+    if (h.pend != PEND_NONE) {
       kind = NEXT_SLOW;
-    } else if (P.ma_level[i] >= 0) {
+    } else if (h.ma_level >= 0) {
       kind = NEXT_MA;
-    } else if (type_handled(type) && P.prop_time[i] < ts_end) {
-      kind = type_gamma(type) ? NEXT_GAMMA : ((type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_KPKT);
+    } else if (type_handled(type) && h.prop_time < env.S.ts_end) {
+      if (type_gamma(type)) {
+        kind = NEXT_GAMMA;
+      } else if (type == ARTIS_TYPE_RPKT) {
+        kind = NEXT_RPKT;
+      } else {
+        kind = kpkt_blackbody_case(env, type, cellindex) ? NEXT_BB : NEXT_KPKT;
+      }
     }
   }
-  append_by_kind(kind, (int32_t)i, L);
+  append_by_kind(kind, (int32_t)i, cellindex, nu_cmf, L);
 }
 
-// ---- counting sort of a work list by (propagation cell, frequency bin) (three tiny kernels).
+// ---- counting sort of a work list by its entries' keys (propagation cell, frequency bin): three tiny kernels.
 // Within a cell, r-packets are ordered by comoving frequency like the reference's own packet sort
 // (compare_packet_order, update_packets.cc:363): neighbouring lanes then walk the same part of the line list and
-// the same window of bound-free continua. nbins == 1 sorts by cell only (thermal list).
-constexpr int SORT_NUBINS = 16;
-__device__ inline int32_t sort_key(int32_t pi, const int32_t *cellindex, const double *nu_cmf, int nbins) {
-  int32_t key = cellindex[pi] * nbins;
-  if (nbins > 1) {
-    // 16 log-spaced bins over [1e14, 1e16] Hz, bluest first
-    const double lognu = log2(fmax(nu_cmf[pi], 1.0));
-    const double x = (lognu - 46.507) * (nbins / 6.644);  // log2(1e14) = 46.507, log2(100) = 6.644
-    int b = (int)x;
-    b = b < 0 ? 0 : (b > nbins - 1 ? nbins - 1 : b);
-    key += (nbins - 1 - b);
-  }
-  return key;
-}
-__global__ void __launch_bounds__(BLOCK) k_sort_hist(const int32_t *list, int32_t n, const int32_t *cellindex, const double *nu_cmf,
-                                                     int nbins, int32_t *hist) {
+// the same window of bound-free continua.
+__global__ void __launch_bounds__(BLOCK) k_sort_hist(const int32_t *keys, int32_t n, int32_t *hist) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < n) atomicAdd(&hist[sort_key(list[i], cellindex, nu_cmf, nbins)], 1);
+  if (i < n) atomicAdd(&hist[keys[i]], 1);
 }
 // exclusive scan of the key histogram in three steps: per-block scan of SCAN_TILE keys, scan of the block totals
 // (one block), add the block offsets
@@ -254,13 +264,9 @@ __global__ void __launch_bounds__(1024) k_scan_add(int32_t *hist, int32_t nkeys,
   for (int k = 0; k < 8; k++)
     if (base + k < nkeys) hist[base + k] += off;
 }
-__global__ void __launch_bounds__(BLOCK) k_sort_scatter(const int32_t *list, int32_t n, const int32_t *cellindex, const double *nu_cmf,
-                                                        int nbins, int32_t *offsets, int32_t *out) {
+__global__ void __launch_bounds__(BLOCK) k_sort_scatter(const int32_t *list, const int32_t *keys, int32_t n, int32_t *offsets, int32_t *out) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i < n) {
-    const int32_t pi = list[i];
-    out[atomicAdd(&offsets[sort_key(pi, cellindex, nu_cmf, nbins)], 1)] = pi;
-  }
+  if (i < n) out[atomicAdd(&offsets[keys[i]], 1)] = list[i];
 }
 
 // ------------------------------------------------------------------ the propagation kernels
@@ -333,7 +339,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
     if (idx >= 0) {
       pi = list[idx];
       pkt_load(env.P, pi, p);
-      chi_load(env.P, pi, x);
+      chi_load(env.P, pi, p, x);
       steps = 0;
       have = true;
     }
@@ -348,7 +354,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
       const long long now = clock64();
       if ((threadIdx.x & 63) == 0) {
         atomicAdd(&lstats[53], (stat_t)((now - tprev) >> 4));
-        atomicAdd(&lstats[55], 1u);
+        atomicAdd(&lstats[55], (stat_t)1);
       }
       tprev = now;
     }
@@ -360,9 +366,9 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
         steps++;
       }
       if (!go || steps >= budget) {
+        chi_store(env.P, pi, p, x);
         pkt_store(env.P, pi, p);
-        chi_store(env.P, pi, x);
-        kind = classify(p, ts_end);
+        kind = classify(env, p, ts_end);
         out_pi = pi;
         have = false;
       }
@@ -374,10 +380,10 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
       tprev = now;
     }
 #endif
-    append_by_kind(kind, out_pi, next);
+    append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
   }
   __syncthreads();
-  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
 // gamma packets (and the non-thermal deposits they end in): one do_gamma() call per iteration, same persistent
@@ -420,15 +426,15 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
       }
       if (!go || steps >= budget) {
         pkt_store(env.P, pi, p);
-        kind = classify(p, ts_end);
+        kind = classify(env, p, ts_end);
         out_pi = pi;
         have = false;
       }
     }
-    append_by_kind(kind, out_pi, next);
+    append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
   }
   __syncthreads();
-  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
 // Thermal packets (k-packets and walking macro-atoms) are advanced by ONE persistent kernel, so that the k-packet ->
@@ -464,7 +470,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
     const int32_t idx = pull(q, !have, n, cursors);
     if (idx >= 0) {
       pi = list[idx];
-      pkt_load(env.P, pi, p);
+      pkt_load_thermal(env.P, pi, p);  // the hot line only
       k = ma_ctx(env, p);
       units = 0;
       have = true;
@@ -498,7 +504,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
       }
       ma_flush_stats(env, k);
       if (exit_action >= 0) ma_jump_exit(env, p, pi, k, k.cellma + k.lp.rec_off, ma_targets(env, k), exit_action, exit_rate);
-      if (j > 0) chi_after_ma(env, p, pi);
+      if (j > 0) chi_after_ma(p);
       units += j;
     }
 #ifdef ARTIS_PROFILE
@@ -506,38 +512,37 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
     PROF_ADD(43, t1 - t0);
 #endif
     if (go) {
-      if (kpkt_eligible(p, ts_end)) {
+      // a pre-k-packet, or a k-packet in a grey cell, leaves for the blackbody kernel (classify() below)
+      const bool blackbody = (p.type == ARTIS_TYPE_PRE_KPKT) || k.thick;
+      if (kpkt_eligible(p, ts_end) && !blackbody) {
 #ifdef ARTIS_PROFILE
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 47);
 #endif
-        if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[k.c] == ARTIS_CELL_THICK) {
-          do_kpkt_blackbody(env, p, pi);
-        } else {
-          do_kpkt(env, p, pi);
-        }
-        env.P.chi_mgi[pi] = -1;
+        do_kpkt(env, p, pi);
+        p.chi_mgi = -1;
         units++;
       }
-      go = thermal_can_continue(p, ts_end);
+      go = thermal_can_continue(p, ts_end) && !(blackbody && kpkt_eligible(p, ts_end));
     }
 #ifdef ARTIS_PROFILE
     const long long t2 = clock64();
     PROF_ADD(44, t2 - t1);
 #endif
     if (have && (!go || units >= budget)) {
-      pkt_store(env.P, pi, p);
-      kind = classify(p, ts_end);
+      pkt_store_thermal(env.P, pi, p);  // the hot line; the flight line only if an r-packet was emitted
+      kind = classify(env, p, ts_end);
       out_pi = pi;
       have = false;
     }
-    append_by_kind(kind, out_pi, next);
+    append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
+    pkt_clear_flight(p);  // a thermal packet never reads them: no live range across iterations
 #ifdef ARTIS_PROFILE
     tprev = clock64();
     PROF_ADD(45, tprev - t2);
 #endif
   }
   __syncthreads();
-  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
 
@@ -549,17 +554,44 @@ __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, in
   env.stats = lstats;
   const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   int kind = NEXT_DONE;
-  int32_t pi = 0;
+  int32_t pi = 0, cellindex = 0;
+  double nu_cmf = 0.;
   if (tid < n) {
     pi = list[tid];
     Pkt p;
     pkt_load(env.P, pi, p);
     kind = advance_slow(env, p, pi);
     pkt_store(env.P, pi, p);
+    cellindex = p.cellindex;
+    nu_cmf = p.nu_cmf;
   }
-  append_by_kind(kind, pi, next);
+  append_by_kind(kind, pi, cellindex, nu_cmf, next);
   __syncthreads();
-  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], (unsigned long long)lstats[threadIdx.x]);
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
+}
+
+// blackbody emission of pre-k-packets and of k-packets in grey cells: one do_kpkt_blackbody() per packet
+__global__ void __launch_bounds__(BLOCK) k_blackbody(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  env.stats = lstats;
+  const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  int kind = NEXT_DONE;
+  int32_t pi = 0, cellindex = 0;
+  double nu_cmf = 0.;
+  if (tid < n) {
+    pi = list[tid];
+    Pkt p;
+    pkt_load_thermal(env.P, pi, p);
+    kind = advance_blackbody(env, p, pi);
+    pkt_store_thermal(env.P, pi, p);
+    cellindex = p.cellindex;
+    nu_cmf = p.nu_cmf;
+  }
+  append_by_kind(kind, pi, cellindex, nu_cmf, next);
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
 inline int nblocks(int64_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
@@ -588,16 +620,17 @@ struct artis_amd_engine {
   unsigned long long *d_stats = nullptr;
   int32_t *d_err = nullptr;
   // packets
-  int64_t npackets = 0;
-  void *d_soa = nullptr;
-  void *d_soa_snapshot = nullptr;
-  size_t soa_bytes = 0;
-  PktSoA P{};
+  int64_t npackets = -1;           // -1: no resident population
+  void *d_pkt = nullptr;           // the three record arrays of the resident population (tables.h PktStore)
+  void *d_pkt_snapshot = nullptr;
+  size_t pkt_bytes = 0;
+  PktStore P{};
   artis_packet *d_aos = nullptr;
   int64_t aos_capacity = 0;
   int32_t *d_lists[NEXT_NKINDS][2] = {};      // per kind: current and alternate work list
+  int32_t *d_keys[NEXT_NKINDS][2] = {};       // ... and the sort keys of their entries
   int32_t *d_sorted = nullptr;                // counting-sort output
-  int32_t *d_perm = nullptr;                  // SoA slot -> index in the caller's packet array (k_aos_to_soa)
+  int32_t *d_perm = nullptr;                  // record slot -> index in the caller's packet array (k_aos_to_rec)
   bool use_perm = false;                      // d_perm describes the resident population
   bool slot_order_by_cell = true;             // ARTIS_AMD_SLOTSORT=0: slots in the caller's order
   int32_t *d_hist = nullptr;                  // [ngrid * SORT_NUBINS + 1]
@@ -659,33 +692,36 @@ Env make_env(const artis_amd_engine *e) {
   return env;
 }
 
-int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
-  if (n == e->npackets && e->d_soa) return ARTIS_OK;
-  if (e->d_soa) (void)hipFree(e->d_soa);
-  if (e->d_soa_snapshot) (void)hipFree(e->d_soa_snapshot);
-  e->d_soa = e->d_soa_snapshot = nullptr;
+void free_packet_buffers(artis_amd_engine *e) {
+  void **singles[] = {&e->d_pkt, &e->d_pkt_snapshot, (void **)&e->d_sorted, (void **)&e->d_perm, (void **)&e->d_gamma_ws,
+                      (void **)&e->d_gamma_gi, (void **)&e->d_gamma_n};
+  for (void **q : singles) {
+    if (*q) (void)hipFree(*q);
+    *q = nullptr;
+  }
   for (int kind = 0; kind < NEXT_NKINDS; kind++)
     for (int k = 0; k < 2; k++) {
       if (e->d_lists[kind][k]) (void)hipFree(e->d_lists[kind][k]);
+      if (e->d_keys[kind][k]) (void)hipFree(e->d_keys[kind][k]);
       e->d_lists[kind][k] = nullptr;
+      e->d_keys[kind][k] = nullptr;
     }
-  if (e->d_sorted) (void)hipFree(e->d_sorted);
-  if (e->d_perm) (void)hipFree(e->d_perm);
-  e->d_sorted = nullptr;
-  e->d_perm = nullptr;
-  if (e->d_gamma_ws) (void)hipFree(e->d_gamma_ws);
-  if (e->d_gamma_gi) (void)hipFree(e->d_gamma_gi);
-  if (e->d_gamma_n) (void)hipFree(e->d_gamma_n);
-  e->d_gamma_ws = nullptr;
-  e->d_gamma_gi = nullptr;
-  e->d_gamma_n = nullptr;
-  e->npackets = n;
-  e->soa_bytes = pkt_soa_bytes(n) + 64;
-  HIP_TRY(hipMalloc(&e->d_soa, e->soa_bytes));
-  e->P = carve_pkt_soa(e->d_soa, n);
+  e->npackets = -1;  // nothing resident
+  e->use_perm = false;
+}
+
+int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
+  if (n == e->npackets && e->d_pkt) return ARTIS_OK;
+  free_packet_buffers(e);
+  e->pkt_bytes = pkt_store_bytes(n);
+  HIP_TRY(hipMalloc(&e->d_pkt, e->pkt_bytes));
+  e->P = carve_pkt_store(e->d_pkt, n);
   const size_t listbytes = sizeof(int32_t) * (size_t)(n > 0 ? n : 1);
   for (int kind = 1; kind < NEXT_NKINDS; kind++)
-    for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void **)&e->d_lists[kind][k], listbytes));
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(hipMalloc((void **)&e->d_lists[kind][k], listbytes));
+      HIP_TRY(hipMalloc((void **)&e->d_keys[kind][k], listbytes));
+    }
   HIP_TRY(hipMalloc((void **)&e->d_sorted, listbytes));
   HIP_TRY(hipMalloc((void **)&e->d_perm, listbytes));
   e->ws_capacity = n > 0 ? n : 1;
@@ -694,6 +730,7 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
   HIP_TRY(hipMalloc((void **)&e->d_gamma_gi, wsbytes / 2));
   HIP_TRY(hipMalloc((void **)&e->d_gamma_n, sizeof(int32_t) * (size_t)e->ws_capacity));
   HIP_TRY(hipMemset(e->d_gamma_n, 0, sizeof(int32_t) * (size_t)e->ws_capacity));
+  e->npackets = n;  // committed only now: a failed allocation above leaves "nothing resident" (npackets == -1)
   return ARTIS_OK;
 }
 
@@ -707,6 +744,10 @@ int ensure_aos(artis_amd_engine *e, int64_t n) {
 }
 
 }  // namespace
+
+namespace {
+int engine_fill(artis_amd_engine *e, const artis_model *model);
+}
 
 extern "C" {
 
@@ -757,6 +798,20 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   HIP_TRY(hipSetDevice(device));
   artis_amd_engine *e = new artis_amd_engine();
   e->device = device;
+  const int rc = engine_fill(e, model);
+  if (rc != ARTIS_OK) {  // release whatever was allocated before the failing call (g_last_error is already set)
+    artis_amd_engine_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return ARTIS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+int engine_fill(artis_amd_engine *e, const artis_model *model) {
+  const int device = e->device;
   e->Mh = make_host_model_view(*model, e->own);
   e->model_copy = *model;
   e->own_matransblock_start.assign(model->level_matransblock_start, model->level_matransblock_start + model->nlevels);
@@ -841,9 +896,11 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
-  *out = e;
   return ARTIS_OK;
 }
+}  // namespace
+
+extern "C" {
 
 void artis_amd_engine_destroy(artis_amd_engine *e) {
   if (!e) return;
@@ -851,13 +908,10 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->model_allocs);
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
-  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_soa, e->d_soa_snapshot, e->d_aos, e->d_sorted, e->d_perm, e->d_hist, e->d_tiles,
-                  e->d_count, e->d_cursors, e->d_gamma_ws, e->d_gamma_gi, e->d_gamma_n};
+  free_packet_buffers(e);
+  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
-  for (int kind = 0; kind < NEXT_NKINDS; kind++)
-    for (int k = 0; k < 2; k++)
-      if (e->d_lists[kind][k]) (void)hipFree(e->d_lists[kind][k]);
   for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3})
     if (ev) (void)hipEventDestroy(ev);
   delete e;
@@ -869,6 +923,7 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
     return ARTIS_ERR_ARG;
   }
   HIP_TRY(hipSetDevice(e->device));
+  e->have_cells = false;  // until every array of the new state is resident
   free_all(e->cell_allocs);
   const DevModel &h = e->Mh;
   DevCells hc = make_host_cells_view(*cells);
@@ -935,6 +990,9 @@ int artis_amd_packets_upload(artis_amd_engine *e, const artis_packet *packets, i
   if (rc != ARTIS_OK) return rc;
   rc = ensure_aos(e, npackets);
   if (rc != ARTIS_OK) return rc;
+  // a snapshot belongs to the population (and slot permutation) it was taken of
+  if (e->d_pkt_snapshot) (void)hipFree(e->d_pkt_snapshot);
+  e->d_pkt_snapshot = nullptr;
   if (npackets > 0) {
     HIP_TRY(hipMemcpy(e->d_aos, packets, sizeof(artis_packet) * (size_t)npackets, hipMemcpyHostToDevice));
     e->use_perm = false;
@@ -946,16 +1004,15 @@ int artis_amd_packets_upload(artis_amd_engine *e, const artis_packet *packets, i
       hipStream_t s = nullptr;
       hipLaunchKernelGGL(k_aos_cellkeys, dim3(nblocks(npackets)), dim3(BLOCK), 0, s, e->d_aos, npackets, nkeys, ident, keys);
       HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(nkeys + 1), s));
-      hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n32)), dim3(BLOCK), 0, s, ident, n32, keys, (const double *)nullptr, 1, e->d_hist);
+      hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n32)), dim3(BLOCK), 0, s, keys, n32, e->d_hist);
       const int ntiles = (nkeys + SCAN_TILE - 1) / SCAN_TILE;
       hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
       hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, e->d_tiles, ntiles);
       hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
-      hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n32)), dim3(BLOCK), 0, s, ident, n32, keys, (const double *)nullptr, 1, e->d_hist,
-                         e->d_perm);
+      hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n32)), dim3(BLOCK), 0, s, ident, keys, n32, e->d_hist, e->d_perm);
       e->use_perm = true;
     }
-    hipLaunchKernelGGL(k_aos_to_soa, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->d_aos, e->P, e->use_perm ? e->d_perm : nullptr);
+    hipLaunchKernelGGL(k_aos_to_rec, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->d_aos, e->P, e->use_perm ? e->d_perm : nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
   }
@@ -973,55 +1030,53 @@ int artis_amd_packets_download(artis_amd_engine *e, artis_packet *packets, int64
   if (rc != ARTIS_OK) return rc;
   // start from the caller's structs so that the fields this path never touches keep their values
   HIP_TRY(hipMemcpy(e->d_aos, packets, sizeof(artis_packet) * (size_t)npackets, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_soa_to_aos, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->P, e->d_aos, e->use_perm ? e->d_perm : nullptr);
+  hipLaunchKernelGGL(k_rec_to_aos, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->P, e->d_aos, e->use_perm ? e->d_perm : nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(packets, e->d_aos, sizeof(artis_packet) * (size_t)npackets, hipMemcpyDeviceToHost));
   return ARTIS_OK;
 }
 
 int artis_amd_packets_snapshot(artis_amd_engine *e) {
-  if (!e || !e->d_soa) {
+  if (!e || !e->d_pkt) {
     g_last_error = "no resident packets";
     return ARTIS_ERR_ARG;
   }
   HIP_TRY(hipSetDevice(e->device));
-  if (!e->d_soa_snapshot) HIP_TRY(hipMalloc(&e->d_soa_snapshot, e->soa_bytes));
-  HIP_TRY(hipMemcpy(e->d_soa_snapshot, e->d_soa, e->soa_bytes, hipMemcpyDeviceToDevice));
+  if (!e->d_pkt_snapshot) HIP_TRY(hipMalloc(&e->d_pkt_snapshot, e->pkt_bytes));
+  HIP_TRY(hipMemcpy(e->d_pkt_snapshot, e->d_pkt, e->pkt_bytes, hipMemcpyDeviceToDevice));
   return ARTIS_OK;
 }
 
 int artis_amd_packets_restore(artis_amd_engine *e) {
-  if (!e || !e->d_soa || !e->d_soa_snapshot) {
+  if (!e || !e->d_pkt || !e->d_pkt_snapshot) {
     g_last_error = "no snapshot";
     return ARTIS_ERR_ARG;
   }
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipMemcpy(e->d_soa, e->d_soa_snapshot, e->soa_bytes, hipMemcpyDeviceToDevice));
+  HIP_TRY(hipMemcpy(e->d_pkt, e->d_pkt_snapshot, e->pkt_bytes, hipMemcpyDeviceToDevice));
   return ARTIS_OK;
 }
 
 namespace {
-// sort list[0..n) by propagation cell into e->d_sorted; returns the pointer to launch on
-int sort_by_cell(artis_amd_engine *e, hipStream_t s, int32_t *list, int32_t n, const int32_t **out, int nbins) {
+// counting sort of list[0..n) by its entries' keys into e->d_sorted; *out = the list to launch on
+int sort_by_key(artis_amd_engine *e, hipStream_t s, const int32_t *list, const int32_t *keys, int32_t n, const int32_t **out, int nbins) {
   *out = list;
   if (!e->sort_lists || n < 2 * BLOCK) return ARTIS_OK;
-  if (!e->sort_nu) nbins = 1;
   const int32_t nkeys = e->Mh.ngrid * nbins;
   HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(nkeys + 1), s));
-  hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, n, e->P.cellindex, e->P.nu_cmf, nbins, e->d_hist);
+  hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n)), dim3(BLOCK), 0, s, keys, n, e->d_hist);
   const int ntiles = (nkeys + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
   hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, e->d_tiles, ntiles);
   hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, n, e->P.cellindex, e->P.nu_cmf, nbins, e->d_hist,
-                     e->d_sorted);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, keys, n, e->d_hist, e->d_sorted);
   *out = e->d_sorted;
   return ARTIS_OK;
 }
 }  // namespace
 
 int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
-  if (!e || !e->have_cells || !e->d_soa) {
+  if (!e || !e->have_cells || !e->d_pkt) {
     g_last_error = "engine needs artis_amd_set_cellstate() and resident packets first";
     return ARTIS_ERR_ARG;
   }
@@ -1038,15 +1093,21 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   if (n == 0) return ARTIS_OK;
   Env env = make_env(e);
   int cur[NEXT_NKINDS] = {};             // which of the two buffers is the current list of each kind
+  const int r_nubins = e->sort_nu ? SORT_NUBINS : 1;  // frequency bins in the keys of the r-packet list
   int32_t cnt[2 * NEXT_NKINDS];                        // host copy of the device counters
   auto lists_for = [&](int self_kind) {
     Lists L;
-    for (int k = 0; k < NEXT_NKINDS; k++) L.lst[k] = e->d_lists[k][cur[k]];
+    for (int k = 0; k < NEXT_NKINDS; k++) {
+      L.lst[k] = e->d_lists[k][cur[k]];
+      L.key[k] = e->d_keys[k][cur[k]];
+    }
     L.counts = e->d_count;
     L.self_kind = self_kind;
     L.self_list = self_kind > 0 ? e->d_lists[self_kind][1 - cur[self_kind]] : nullptr;
+    L.self_key = self_kind > 0 ? e->d_keys[self_kind][1 - cur[self_kind]] : nullptr;
     L.self_count = e->d_count + NEXT_NKINDS;  // one alternate counter: only one kernel runs at a time
     L.kpkt_slot = NEXT_MA;  // k-packets travel in the thermal list
+    L.nubins = r_nubins;
     return L;
   };
   int32_t errflag = 0;
@@ -1063,22 +1124,22 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     return ARTIS_OK;
   };
   HIP_TRY(hipMemsetAsync(e->d_count, 0, sizeof(int32_t) * 2 * NEXT_NKINDS, s));
-  hipLaunchKernelGGL(k_classify, dim3(nblocks(n)), dim3(BLOCK), 0, s, e->P, e->S.ts_end, lists_for(0));
+  hipLaunchKernelGGL(k_classify, dim3(nblocks(n)), dim3(BLOCK), 0, s, env, lists_for(0));
   int rc = read_counts();
   if (rc != ARTIS_OK) return rc;
 
   // one launch = the whole current list of one kind. Order: slow path, k-packets, macro-atoms, r-packets, so that a
   // k-packet -> macro-atom -> k-packet cycle costs two launches.
-  const int order[5] = {NEXT_SLOW, NEXT_GAMMA, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
+  const int order[6] = {NEXT_SLOW, NEXT_GAMMA, NEXT_BB, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
   int64_t guard = 0;
-  while (cnt[NEXT_RPKT] > 0 || cnt[NEXT_MA] > 0 || cnt[NEXT_SLOW] > 0 || cnt[NEXT_KPKT] > 0 || cnt[NEXT_GAMMA] > 0) {
+  while (cnt[NEXT_RPKT] > 0 || cnt[NEXT_MA] > 0 || cnt[NEXT_SLOW] > 0 || cnt[NEXT_KPKT] > 0 || cnt[NEXT_GAMMA] > 0 || cnt[NEXT_BB] > 0) {
     for (int kind : order) {
       const int32_t nk = cnt[kind];
       if (nk <= 0) continue;
       const Lists next = lists_for(kind);
       const int32_t *lst = e->d_lists[kind][cur[kind]];
       if (kind == NEXT_RPKT || kind == NEXT_GAMMA || (kind == NEXT_MA && e->sort_ma)) {
-        rc = sort_by_cell(e, s, e->d_lists[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? SORT_NUBINS : 1);
+        rc = sort_by_key(e, s, e->d_lists[kind][cur[kind]], e->d_keys[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? r_nubins : 1);
         if (rc != ARTIS_OK) return rc;
       }
       // the kernel starts with an empty current list of its own kind: everything it keeps goes to the alternate list
@@ -1095,6 +1156,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       } else if (kind == NEXT_MA) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_THERMAL_WAVES);
         hipLaunchKernelGGL(k_thermal, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors);
+      } else if (kind == NEXT_BB) {
+        hipLaunchKernelGGL(k_blackbody, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);
       } else {
         hipLaunchKernelGGL(k_slow, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);
       }
@@ -1110,11 +1173,10 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       if (e->trace)
         fprintf(stderr, "[artis_amd] launch %lld kind %d n=%d %.3f ms -> r %d ma %d slow %d k %d self %d\n", (long long)e->last_nlaunches,
                 kind, nk, ms, cnt[NEXT_RPKT], cnt[NEXT_MA], cnt[NEXT_SLOW], cnt[NEXT_KPKT], cnt[NEXT_NKINDS]);
-      // the alternate list of this kind becomes its current list
+      // the alternate list of this kind becomes its current list (its count moves on the device: no second sync)
       cur[kind] = 1 - cur[kind];
       cnt[kind] = cnt[NEXT_NKINDS];
-      HIP_TRY(hipMemcpyAsync(e->d_count + kind, &cnt[kind], sizeof(int32_t), hipMemcpyHostToDevice, s));
-      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipMemcpyAsync(e->d_count + kind, e->d_count + NEXT_NKINDS, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
       if (++guard > 2000000LL) {
         g_last_error = "packet loop did not terminate";
         return ARTIS_ERR_NOTCONVERGED;

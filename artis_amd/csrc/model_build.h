@@ -231,38 +231,14 @@ inline DevStep make_step(const artis_timestep &t) {
   return s;
 }
 
-// Carve the SoA columns of n packets out of one allocation of pkt_soa_bytes(n) bytes.
-inline size_t pkt_soa_bytes(int64_t n) {
-  const size_t n8 = ((size_t)n + 1) & ~(size_t)1;  // keep 8-byte columns aligned after 4-byte ones
-  return ((size_t)PKT_NCOL64 * 8 + (size_t)PKT_NCOL32 * 4) * n8;
-}
-inline PktSoA carve_pkt_soa(void *base, int64_t n) {
-  const size_t n8 = ((size_t)n + 1) & ~(size_t)1;
-  PktSoA P;
-  double *d = (double *)base;
-  double **cols64[] = {&P.prop_time, &P.pos_x, &P.pos_y, &P.pos_z, &P.dir_x, &P.dir_y, &P.dir_z, &P.nu_cmf, &P.e_cmf, &P.nu_rf,
-                       &P.e_rf, &P.stokes_q, &P.stokes_u, &P.em_pos_x, &P.em_pos_y, &P.em_pos_z, &P.trueem_pos_x, &P.trueem_pos_y,
-                       &P.trueem_pos_z, &P.absorptionfreq, &P.chi_nu, &P.chi_es, &P.chi_ff, &P.chi_bf, &P.tdecay};
-  static_assert(sizeof(cols64) / sizeof(cols64[0]) == PKT_NCOL64, "64-bit column count");
-  for (auto c : cols64) {
-    *c = d;
-    d += n8;
-  }
-  uint32_t *w = (uint32_t *)d;
-  P.rng = w;  // 4 columns, but strided by the true n (see pkt_load)
-  w += 4 * n8;
-  int32_t **cols32[] = {&P.next_trans, &P.nscatterings, &P.type, &P.cellindex, &P.emissiontype, &P.absorptiontype,
-                        &P.trueemissiontype, &P.escape_type, &P.chi_mgi, &P.ma_element, &P.ma_ion, &P.ma_level, &P.ma_line,
-                        &P.ma_origin, &P.pend, &P.pend_arg, &P.pellet_decaytype, &P.originated_particle};
-  for (auto c : cols32) {
-    *c = (int32_t *)w;
-    w += n8;
-  }
-  float **colsf[] = {&P.em_time, &P.trueem_time, &P.escape_time};
-  for (auto c : colsf) {
-    *c = (float *)w;
-    w += n8;
-  }
+// Carve the three record arrays of n packets out of one allocation of pkt_store_bytes(n) bytes (base aligned to 128 B).
+inline size_t pkt_store_bytes(int64_t n) { return PKT_BYTES_PER_PACKET * (size_t)(n > 0 ? n : 1); }
+inline PktStore carve_pkt_store(void *base, int64_t n) {
+  const size_t m = (size_t)(n > 0 ? n : 1);
+  PktStore P;
+  P.hot = (PktHot *)base;
+  P.flight = (PktFlight *)((char *)base + sizeof(PktHot) * m);
+  P.cold = (PktCold *)((char *)base + (sizeof(PktHot) + sizeof(PktFlight)) * m);
   P.n = n;
   return P;
 }

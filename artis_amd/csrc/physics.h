@@ -50,7 +50,7 @@ constexpr double DBLMIN = 2.2250738585072014e-308;
 constexpr int MA_N = ARTIS_MA_ACTION_COUNT;
 
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef unsigned int stat_t;
+typedef unsigned long long stat_t;  // per-block LDS counters (ds_add_u64): X_MA_JUMPS alone passes 2^32 at realistic sizes
 #define ARTIS_STAT_ADD(env, i, v) atomicAdd(&(env).stats[(i)], (stat_t)(v))
 #define ARTIS_EST_ADD(ptr, v) unsafeAtomicAdd((ptr), (v))
 #else
@@ -88,7 +88,7 @@ struct Env {
   DevCache K;
   DevStep S;
   DevEst E;
-  PktSoA P;
+  PktStore P;
   stat_t *stats;       // [ARTIS_NSTATS] LDS on the GPU, plain memory in the emulation
   // groundcont_gamma_contr (rpkt.h:63) of every packet as a compact list of its non-zero entries, packet-major:
   // gamma_n[slot] entries (gamma_gi[slot*nbfg + j], gamma_ws[slot*nbfg + j]), j ascending in ground-continuum index
@@ -103,9 +103,12 @@ struct Pkt {
   uint32_t s0, s1, s2, s3;
   double prop_time, px, py, pz, dx, dy, dz, nu_cmf, e_cmf, nu_rf, e_rf, stokes_q, stokes_u;
   int32_t next_trans, nscatterings, type, cellindex;
-  // an activated macro-atom that has not deactivated yet (ma_level < 0: none); see tables.h PktSoA
+  // an activated macro-atom that has not deactivated yet (ma_level < 0: none); see tables.h PktHot
   int32_t ma_element, ma_ion, ma_level, ma_line, ma_origin;
-  int32_t pend, pend_arg;  // see tables.h PktSoA
+  int32_t pend, pend_arg;  // see tables.h PktHot
+  int32_t chi_mgi;         // cell of the packet's ContinuumOpacity, < 0 = not valid (the r-packet kernel keeps it in Chi)
+  int32_t emissiontype, trueemissiontype, absorptiontype;
+  int32_t flags;           // PKT_FLAG_*
 };
 enum { PEND_NONE = 0, PEND_MA_ACTION = 2, PEND_KPKT_FB = 3 };
 
@@ -603,8 +606,8 @@ AHD void change_cell_or_escape(const Env &env, Pkt &p, int64_t pi, int next_cell
     p.cellindex = next_cell;
     ARTIS_STAT(env, ARTIS_STAT_CELLCROSSINGS);
   } else {
-    env.P.escape_type[pi] = p.type;
-    env.P.escape_time[pi] = (float)p.prop_time;
+    env.P.cold[pi].escape_type = p.type;
+    env.P.cold[pi].escape_time = (float)p.prop_time;
     p.type = ARTIS_TYPE_ESCAPE;
     ARTIS_STAT(env, ARTIS_STAT_PKTESCAPES);
   }
@@ -1309,6 +1312,14 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
   return result;
 }
 
+// em_pos = pos, em_time = prop_time (rpkt.cc:1012, rpkt.cc:449): straight to the flight line
+AHD void set_em_here(const Env &env, const Pkt &p, int64_t pi) {
+  PktFlight &fl = env.P.flight[pi];
+  fl.em_pos_x = p.px;
+  fl.em_pos_y = p.py;
+  fl.em_pos_z = p.pz;
+  fl.em_time = (float)p.prop_time;
+}
 // emit_rpkt rpkt.cc:991
 AHD void emit_rpkt(const Env &env, Pkt &p, int64_t pi) {
   p.type = ARTIS_TYPE_RPKT;
@@ -1326,16 +1337,18 @@ AHD void emit_rpkt(const Env &env, Pkt &p, int64_t pi) {
   p.stokes_u = 0.;
   p.stokes_q = 0.;
 #endif
-  env.P.em_pos_x[pi] = p.px;
-  env.P.em_pos_y[pi] = p.py;
-  env.P.em_pos_z[pi] = p.pz;
-  env.P.em_time[pi] = (float)p.prop_time;
+  set_em_here(env, p, pi);
+  p.flags |= PKT_FLAG_EMITTED;  // the new direction and rest-frame quantities have to reach the packet's flight line
 }
-AHD void set_trueem_from_em(const Env &env, int64_t pi) {
-  env.P.trueem_pos_x[pi] = env.P.em_pos_x[pi];
-  env.P.trueem_pos_y[pi] = env.P.em_pos_y[pi];
-  env.P.trueem_pos_z[pi] = env.P.em_pos_z[pi];
-  env.P.trueem_time[pi] = env.P.em_time[pi];
+// trueem_pos = em_pos, trueem_time = em_time (macroatom.cc:588, kpkt.cc:512). Every caller has just run emit_rpkt() on the
+// unchanged packet, so em_pos is the packet's position and em_time its time: no read-back of the flight line.
+AHD void set_trueem_from_em(const Env &env, Pkt &p, int64_t pi) {
+  PktCold &cold = env.P.cold[pi];
+  cold.trueem_pos_x = p.px;
+  cold.trueem_pos_y = p.py;
+  cold.trueem_pos_z = p.pz;
+  cold.trueem_time = (float)p.prop_time;
+  p.flags &= ~PKT_FLAG_TRUEEM_NAN;
 }
 
 // electron_scatter_rpkt rpkt.cc:331
@@ -1590,12 +1603,12 @@ AHD bool ma_pending(const Pkt &p) { return p.ma_level >= 0; }
 AHD void ma_finish(const Env &env, Pkt &p, int64_t pi) {
   p.ma_level = -1;
   if (p.type == ARTIS_TYPE_RPKT) {
-    if (env.P.trueemissiontype[pi] == ARTIS_EMTYPE_NOTSET) {
-      env.P.trueemissiontype[pi] = env.P.emissiontype[pi];
-      set_trueem_from_em(env, pi);
+    if (p.trueemissiontype == ARTIS_EMTYPE_NOTSET) {
+      p.trueemissiontype = p.emissiontype;
+      set_trueem_from_em(env, p, pi);
     }
   } else {
-    env.P.trueemissiontype[pi] = ARTIS_EMTYPE_NOTSET;
+    p.trueemissiontype = ARTIS_EMTYPE_NOTSET;
   }
 }
 
@@ -1603,6 +1616,7 @@ AHD void ma_finish(const Env &env, Pkt &p, int64_t pi) {
 // its macro-atom is in
 struct MACtx {
   int c;                    // non-empty model cell
+  bool thick;               // the cell is optically thick (grey): its k-packets go to do_kpkt_blackbody()
   const double *cellma;     // the cell's row of macro-atom records
   int start_key, start;     // cached get_ionuniquelevelindexstart(element, ion)
   LevelPack lp;             // static indices of the current level (ma_prepare)
@@ -1611,6 +1625,7 @@ struct MACtx {
 AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   MACtx k;
   k.c = env.M.propcell_nonemptymgi[p.cellindex];
+  k.thick = (k.c >= 0) && (env.C.thick[k.c] == ARTIS_CELL_THICK);
   k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
   k.start_key = -1;
   k.start = 0;
@@ -1709,7 +1724,7 @@ AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double
     ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_BB);
     emit_rpkt(env, p, pi);
     p.next_trans = lineindex + 1;
-    env.P.emissiontype[pi] = lineindex;
+    p.emissiontype = lineindex;
     p.nscatterings = 0;
     ma_finish(env, p, pi);
   } else if (action == ARTIS_MA_ACTION_COLDEEXC || action == ARTIS_MA_ACTION_COLRECOMB) {
@@ -1793,7 +1808,7 @@ AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi) {
     ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_FB);
     emit_rpkt(env, p, pi);
     p.next_trans = -1;
-    env.P.emissiontype[pi] = emtype_continuum(M, ls + lowerlevel, sel_t);
+    p.emissiontype = emtype_continuum(M, ls + lowerlevel, sel_t);
     p.nscatterings = 0;
     ma_finish(env, p, pi);
   } else if (action == ARTIS_MA_ACTION_INTERNALDOWNLOWER) {
@@ -1868,16 +1883,13 @@ AHD void rpkt_event_continuum(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_
     p.nscatterings++;
     ARTIS_STAT(env, ARTIS_STAT_ELECTRON_SCATTERINGS);
     electron_scatter(p);
-    env.P.em_pos_x[pi] = p.px;
-    env.P.em_pos_y[pi] = p.py;
-    env.P.em_pos_z[pi] = p.pz;
-    env.P.em_time[pi] = (float)p.prop_time;
+    set_em_here(env, p, pi);
   } else if (chi_rnd < chi_es + chi_ff) {
     ARTIS_STAT(env, ARTIS_STAT_K_FROM_FF);
     p.type = ARTIS_TYPE_KPKT;
-    env.P.absorptiontype[pi] = ARTIS_ABSTYPE_FREEFREE;
+    p.absorptiontype = ARTIS_ABSTYPE_FREEFREE;
   } else if (chi_rnd < chi_es + chi_ff + chi_bf) {
-    env.P.absorptiontype[pi] = ARTIS_ABSTYPE_BOUNDFREE;
+    p.absorptiontype = ARTIS_ABSTYPE_BOUNDFREE;
     const double chi_bf_rand = rng_uniform(p) * x.chi_boundfree;
     int ci = -1;
     chi_bf_gammacontr<true>(env, x.nonemptymgi, x.nu, slot, chi_bf_rand, &ci);
@@ -1993,8 +2005,8 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
       rpkt_event_continuum(env, p, pi, x, slot);
     } else {
       ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_BB);
-      env.P.absorptiontype[pi] = ma.activatingline;
-      env.P.absorptionfreq[pi] = p.nu_rf;
+      p.absorptiontype = ma.activatingline;
+      env.P.flight[pi].absorptionfreq = p.nu_rf;
       ma_activate(p, ma, 1);
     }
     PROF_MARK(env, 52);
@@ -2035,9 +2047,9 @@ AHD double sample_planck_montecarlo(double T, Pkt &p) {  // kpkt.cc:266
 }
 AHD void thermal_emission_flags(const Env &env, Pkt &p, int64_t pi, int emtype) {
   p.next_trans = -1;
-  env.P.emissiontype[pi] = emtype;
-  env.P.trueemissiontype[pi] = emtype;
-  set_trueem_from_em(env, pi);
+  p.emissiontype = emtype;
+  p.trueemissiontype = emtype;
+  set_trueem_from_em(env, p, pi);
   p.nscatterings = 0;
 }
 AHD void do_kpkt_blackbody(const Env &env, Pkt &p, int64_t pi) {  // kpkt.cc:399
@@ -2122,20 +2134,16 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     const int upper = M.alltrans_targetlevelindex[startup + first];
     ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_COLLEXC);
     ARTIS_STAT(env, ARTIS_STAT_K_TO_MA_COLLEXC);
-    env.P.trueemissiontype[pi] = ARTIS_EMTYPE_NOTSET;
-    env.P.trueem_pos_x[pi] = NAN;
-    env.P.trueem_pos_y[pi] = NAN;
-    env.P.trueem_pos_z[pi] = NAN;
+    p.trueemissiontype = ARTIS_EMTYPE_NOTSET;
+    p.flags |= PKT_FLAG_TRUEEM_NAN;  // trueem_pos = NaN (kpkt.cc:483)
     const MAState ma = {element, ion, upper, -99};
     ma_activate(p, ma, 0);
   } else if (ctype == ARTIS_COOLING_COLLION) {
     const int upper = phixs_upperlevel(M, lstart(M, element, ion) + M.coolinglist_level[i], M.coolinglist_phixstargetindex[i]);
     ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_COLLION);
     ARTIS_STAT(env, ARTIS_STAT_K_TO_MA_COLLION);
-    env.P.trueemissiontype[pi] = ARTIS_EMTYPE_NOTSET;
-    env.P.trueem_pos_x[pi] = NAN;
-    env.P.trueem_pos_y[pi] = NAN;
-    env.P.trueem_pos_z[pi] = NAN;
+    p.trueemissiontype = ARTIS_EMTYPE_NOTSET;
+    p.flags |= PKT_FLAG_TRUEEM_NAN;  // trueem_pos = NaN (kpkt.cc:483)
     const MAState ma = {element, ion + 1, upper, -99};
     ma_activate(p, ma, 0);
   } else {
@@ -2308,7 +2316,7 @@ AHD void compton_scatter(const Env &env, Pkt &p, int64_t pi) {  // gammapkt.cc:3
     set_restframe_from_cmf(p);
   } else {
     p.type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
-    env.P.absorptiontype[pi] = ARTIS_ABSTYPE_GAMMA_COMPTON;
+    p.absorptiontype = ARTIS_ABSTYPE_GAMMA_COMPTON;
     ARTIS_STAT(env, ARTIS_STAT_NT_FROM_GAMMA);
   }
 }
@@ -2330,7 +2338,7 @@ AHD void pair_production(const Env &env, Pkt &p, int64_t pi) {  // gammapkt.cc:6
   const double prob_gamma = pair_rest_mass_energy / gamma_energy;
   if (rng_uniform(p) > prob_gamma) {
     p.type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
-    env.P.absorptiontype[pi] = ARTIS_ABSTYPE_GAMMA_PAIRPRODUCTION;
+    p.absorptiontype = ARTIS_ABSTYPE_GAMMA_PAIRPRODUCTION;
     ARTIS_STAT(env, ARTIS_STAT_NT_FROM_GAMMA);
   } else {
     p.nu_cmf = 0.511 * MEV / HPLANCK;
@@ -2374,7 +2382,7 @@ AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
       compton_scatter(env, p, pi);
     } else if ((chi_compton + chi_pe) > chi_rnd) {
       p.type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
-      env.P.absorptiontype[pi] = ARTIS_ABSTYPE_GAMMA_PHOTOELECTRIC;
+      p.absorptiontype = ARTIS_ABSTYPE_GAMMA_PHOTOELECTRIC;
       ARTIS_STAT(env, ARTIS_STAT_NT_FROM_GAMMA);
     } else {
       pair_production(env, p, pi);
@@ -2435,7 +2443,7 @@ AHD void do_nonthermal_predeposit(const Env &env, Pkt &p, int64_t pi) {
       p.e_cmf *= endot_collisional / endot;
   }
 #endif
-  if (env.P.originated_particle[pi] != 0) {
+  if (env.P.cold[pi].originated_particle != 0) {
     if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS) {
       ARTIS_EST_ADD(&env.E.dep_estimator_electron[c], e_cmf_deposited);
       if (p.type == deposit_type) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ELECTRON_DEP_DISCRETE], p.e_cmf);
@@ -2452,7 +2460,7 @@ AHD void do_nonthermal_predeposit(const Env &env, Pkt &p, int64_t pi) {
 AHD void update_pellet(const Env &env, Pkt &p, int64_t pi) {
   const double t2 = env.S.ts_end;
   const double ts = p.prop_time;
-  const double tdecay = env.P.tdecay[pi];
+  const double tdecay = env.P.cold[pi].tdecay;
   if (tdecay > t2) {
     const double scale = t2 / ts;
     p.px = p.px * scale;
@@ -2466,8 +2474,8 @@ AHD void update_pellet(const Env &env, Pkt &p, int64_t pi) {
     p.px = p.px * scale;
     p.py = p.py * scale;
     p.pz = p.pz * scale;
-    if (env.P.originated_particle[pi] != 0) {
-      const int decaytype = env.P.pellet_decaytype[pi];
+    if (env.P.cold[pi].originated_particle != 0) {
+      const int decaytype = env.P.cold[pi].pellet_decaytype;
       if (decaytype == ARTIS_DECAYTYPE_BETAPLUS) {
         p.type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS;
         ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_POSITRON_EMISSION], p.e_cmf);
@@ -2485,13 +2493,13 @@ AHD void update_pellet(const Env &env, Pkt &p, int64_t pi) {
         p.type = ARTIS_TYPE_ESCAPE;  // leave the work lists
         return;
       }
-      env.P.em_time[pi] = (float)p.prop_time;
-      env.P.absorptiontype[pi] = ARTIS_ABSTYPE_PELLET_PARTICLEDECAY;
+      env.P.flight[pi].em_time = (float)p.prop_time;
+      p.absorptiontype = ARTIS_ABSTYPE_PELLET_PARTICLEDECAY;
     } else {
       ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_EMISSION], p.e_cmf);
       if (p.nu_cmf < 0) {  // no gamma spectrum known for the nuclide: straight to a k-packet
         p.type = ARTIS_TYPE_KPKT;
-        env.P.absorptiontype[pi] = ARTIS_ABSTYPE_PELLET_NOGAMMASPEC;
+        p.absorptiontype = ARTIS_ABSTYPE_PELLET_NOGAMMASPEC;
       } else {
         emit_gamma_isotropic(p);
       }
@@ -2499,7 +2507,7 @@ AHD void update_pellet(const Env &env, Pkt &p, int64_t pi) {
   } else if ((tdecay > 0) && (env.S.nts == 0)) {
     p.e_cmf *= tdecay / env.M.tmin;
     p.type = ARTIS_TYPE_PRE_KPKT;
-    env.P.absorptiontype[pi] = ARTIS_ABSTYPE_PELLET_BEFORESIMSTART;
+    p.absorptiontype = ARTIS_ABSTYPE_PELLET_BEFORESIMSTART;
     ARTIS_STAT(env, ARTIS_STAT_K_FROM_EARLIERDECAY);
     p.prop_time = env.M.tmin;
   } else {
@@ -2520,54 +2528,110 @@ AHD bool type_handled(int type) {
 }
 AHD bool pkt_active(const Pkt &p, double ts_end) { return type_handled(p.type) && p.prop_time < ts_end; }  // update_packets.cc:321
 
-AHD void pkt_load(const PktSoA &P, int64_t i, Pkt &p) {
-  p.s0 = P.rng[i];
-  p.s1 = P.rng[P.n + i];
-  p.s2 = P.rng[(2 * P.n) + i];
-  p.s3 = P.rng[(3 * P.n) + i];
-  p.prop_time = P.prop_time[i];
-  p.px = P.pos_x[i]; p.py = P.pos_y[i]; p.pz = P.pos_z[i];
-  p.dx = P.dir_x[i]; p.dy = P.dir_y[i]; p.dz = P.dir_z[i];
-  p.nu_cmf = P.nu_cmf[i]; p.e_cmf = P.e_cmf[i]; p.nu_rf = P.nu_rf[i]; p.e_rf = P.e_rf[i];
-  p.stokes_q = P.stokes_q[i]; p.stokes_u = P.stokes_u[i];
-  p.next_trans = P.next_trans[i]; p.nscatterings = P.nscatterings[i]; p.type = P.type[i]; p.cellindex = P.cellindex[i];
-  p.ma_element = P.ma_element[i]; p.ma_ion = P.ma_ion[i]; p.ma_level = P.ma_level[i]; p.ma_line = P.ma_line[i];
-  p.ma_origin = P.ma_origin[i];
-  p.pend = P.pend[i]; p.pend_arg = P.pend_arg[i];
+// Hot line <-> registers: everything a thermal packet needs; 128 B, one cache line, eight 16-byte accesses.
+AHD void pkt_load_hot(const PktStore &P, int64_t i, Pkt &p) {
+  const PktHot h = P.hot[i];
+  p.s0 = h.rng[0]; p.s1 = h.rng[1]; p.s2 = h.rng[2]; p.s3 = h.rng[3];
+  p.prop_time = h.prop_time;
+  p.px = h.pos_x; p.py = h.pos_y; p.pz = h.pos_z;
+  p.e_cmf = h.e_cmf; p.nu_cmf = h.nu_cmf;
+  p.type = h.type; p.cellindex = h.cellindex; p.next_trans = h.next_trans; p.nscatterings = h.nscatterings;
+  p.ma_element = h.ma_element; p.ma_ion = h.ma_ion; p.ma_level = h.ma_level; p.ma_line = h.ma_line;
+  p.ma_origin = h.ma_origin; p.pend = h.pend; p.pend_arg = h.pend_arg; p.chi_mgi = h.chi_mgi;
+  p.emissiontype = h.emissiontype; p.trueemissiontype = h.trueemissiontype; p.absorptiontype = h.absorptiontype;
+  p.flags = h.flags;
 }
-AHD void chi_load(const PktSoA &P, int64_t i, Chi &x) {
-  x.nu = P.chi_nu[i]; x.chi_escatter = P.chi_es[i]; x.chi_freefree_heat = P.chi_ff[i]; x.chi_boundfree = P.chi_bf[i];
-  x.nonemptymgi = P.chi_mgi[i];
+AHD void pkt_store_hot(const PktStore &P, int64_t i, const Pkt &p) {
+  PktHot h;
+  h.rng[0] = p.s0; h.rng[1] = p.s1; h.rng[2] = p.s2; h.rng[3] = p.s3;
+  h.prop_time = p.prop_time;
+  h.pos_x = p.px; h.pos_y = p.py; h.pos_z = p.pz;
+  h.e_cmf = p.e_cmf; h.nu_cmf = p.nu_cmf;
+  h.type = p.type; h.cellindex = p.cellindex; h.next_trans = p.next_trans; h.nscatterings = p.nscatterings;
+  h.ma_element = p.ma_element; h.ma_ion = p.ma_ion; h.ma_level = p.ma_level; h.ma_line = p.ma_line;
+  h.ma_origin = p.ma_origin; h.pend = p.pend; h.pend_arg = p.pend_arg; h.chi_mgi = p.chi_mgi;
+  h.emissiontype = p.emissiontype; h.trueemissiontype = p.trueemissiontype; h.absorptiontype = p.absorptiontype;
+  h.flags = p.flags & ~PKT_FLAG_EMITTED;
+  P.hot[i] = h;
 }
-AHD void chi_store(const PktSoA &P, int64_t i, const Chi &x) {
-  P.chi_nu[i] = x.nu; P.chi_es[i] = x.chi_escatter; P.chi_ff[i] = x.chi_freefree_heat; P.chi_bf[i] = x.chi_boundfree;
-  P.chi_mgi[i] = x.nonemptymgi;
+// Flight line: direction, rest-frame quantities, polarisation ...
+AHD void pkt_load_flight(const PktStore &P, int64_t i, Pkt &p) {
+  const PktFlight &f = P.flight[i];
+  p.dx = f.dir_x; p.dy = f.dir_y; p.dz = f.dir_z;
+  p.nu_rf = f.nu_rf; p.e_rf = f.e_rf;
+  p.stokes_q = f.stokes_q; p.stokes_u = f.stokes_u;
 }
-AHD void pkt_store(const PktSoA &P, int64_t i, const Pkt &p) {
-  P.rng[i] = p.s0;
-  P.rng[P.n + i] = p.s1;
-  P.rng[(2 * P.n) + i] = p.s2;
-  P.rng[(3 * P.n) + i] = p.s3;
-  P.prop_time[i] = p.prop_time;
-  P.pos_x[i] = p.px; P.pos_y[i] = p.py; P.pos_z[i] = p.pz;
-  P.dir_x[i] = p.dx; P.dir_y[i] = p.dy; P.dir_z[i] = p.dz;
-  P.nu_cmf[i] = p.nu_cmf; P.e_cmf[i] = p.e_cmf; P.nu_rf[i] = p.nu_rf; P.e_rf[i] = p.e_rf;
-  P.stokes_q[i] = p.stokes_q; P.stokes_u[i] = p.stokes_u;
-  P.next_trans[i] = p.next_trans; P.nscatterings[i] = p.nscatterings; P.type[i] = p.type; P.cellindex[i] = p.cellindex;
-  P.ma_element[i] = p.ma_element; P.ma_ion[i] = p.ma_ion; P.ma_level[i] = p.ma_level; P.ma_line[i] = p.ma_line;
-  P.ma_origin[i] = p.ma_origin;
-  P.pend[i] = p.pend; P.pend_arg[i] = p.pend_arg;
+AHD void pkt_store_flight(const PktStore &P, int64_t i, const Pkt &p) {
+  PktFlight &f = P.flight[i];
+  f.dir_x = p.dx; f.dir_y = p.dy; f.dir_z = p.dz;
+  f.nu_rf = p.nu_rf; f.e_rf = p.e_rf;
+  f.stokes_q = p.stokes_q; f.stokes_u = p.stokes_u;
+}
+// ... and the packet's ContinuumOpacity (its cell index travels in the hot line)
+AHD void chi_load(const PktStore &P, int64_t i, const Pkt &p, Chi &x) {
+  const PktFlight &f = P.flight[i];
+  x.nu = f.chi_nu; x.chi_escatter = f.chi_es; x.chi_freefree_heat = f.chi_ff; x.chi_boundfree = f.chi_bf;
+  x.nonemptymgi = p.chi_mgi;
+}
+AHD void chi_store(const PktStore &P, int64_t i, Pkt &p, const Chi &x) {
+  PktFlight &f = P.flight[i];
+  f.chi_nu = x.nu; f.chi_es = x.chi_escatter; f.chi_ff = x.chi_freefree_heat; f.chi_bf = x.chi_boundfree;
+  p.chi_mgi = x.nonemptymgi;
+}
+// all register state of a packet (r-packet, gamma and slow-path kernels)
+AHD void pkt_load(const PktStore &P, int64_t i, Pkt &p) {
+  pkt_load_hot(P, i, p);
+  pkt_load_flight(P, i, p);
+}
+AHD void pkt_store(const PktStore &P, int64_t i, const Pkt &p) {
+  pkt_store_flight(P, i, p);
+  pkt_store_hot(P, i, p);
+}
+// Thermal kernel: only the hot line is loaded. The flight fields of the register struct are written by emit_rpkt() when
+// a k-packet or macro-atom ends in an r-packet (the only way they change here), and then -- and only then -- stored.
+AHD void pkt_clear_flight(Pkt &p) {
+  p.dx = 0.; p.dy = 0.; p.dz = 0.; p.nu_rf = 0.; p.e_rf = 0.; p.stokes_q = 0.; p.stokes_u = 0.;
+}
+AHD void pkt_load_thermal(const PktStore &P, int64_t i, Pkt &p) {
+  pkt_load_hot(P, i, p);
+  pkt_clear_flight(p);
+}
+AHD void pkt_store_thermal(const PktStore &P, int64_t i, Pkt &p) {
+  if (p.flags & PKT_FLAG_EMITTED) pkt_store_flight(P, i, p);
+  pkt_store_hot(P, i, p);
+  p.flags &= ~PKT_FLAG_EMITTED;
 }
 
 // Work lists: a packet that still needs updating is "in flight" (an r-packet inside or about to enter do_rpkt()),
 // walking a macro-atom, a k-packet (or pre-k-packet) due for its next step, or waiting for a slow-path action.
-enum { NEXT_DONE = 0, NEXT_RPKT = 1, NEXT_MA = 2, NEXT_SLOW = 3, NEXT_KPKT = 4, NEXT_GAMMA = 5, NEXT_NKINDS = 6 };
-AHD int classify(const Pkt &p, double ts_end) {
+// NEXT_BB: a (pre-)k-packet whose next step is do_kpkt_blackbody() (update_packets.cc:291-300) -- it always ends in an
+// r-packet, so it gets a small kernel of its own instead of widening the thermal kernel's register footprint.
+enum { NEXT_DONE = 0, NEXT_RPKT = 1, NEXT_MA = 2, NEXT_SLOW = 3, NEXT_KPKT = 4, NEXT_GAMMA = 5, NEXT_BB = 6, NEXT_NKINDS = 7 };
+// Sort key of a work-list entry: the packet's propagation cell and, for r-packets, a coarse comoving-frequency bin
+// (two per octave over 2^46 .. 2^54 Hz = 7e13 .. 1.8e16 Hz, bluest first, like the reference's own packet order
+// compare_packet_order update_packets.cc:363). Read off the exponent and top mantissa bit: placement only, never results.
+constexpr int SORT_NUBINS = 16;
+AHD int32_t list_sort_key(int32_t cellindex, double nu_cmf, int nbins) {
+  if (nbins <= 1) return cellindex;
+  union { double d; uint64_t u; } v;
+  v.d = nu_cmf;
+  const int e2 = (int)((v.u >> 51) & 0xFFF) - (2 * (1023 + 46));  // 2 * (exponent - 46) + top mantissa bit
+  const int b = (nu_cmf > 0.) ? (e2 < 0 ? 0 : (e2 > SORT_NUBINS - 1 ? SORT_NUBINS - 1 : e2)) : 0;
+  return (cellindex * SORT_NUBINS) + (SORT_NUBINS - 1 - b);
+}
+// do_packet() sends a pre-k-packet, and a k-packet in an optically thick cell, to do_kpkt_blackbody() (update_packets.cc:291-300)
+AHD bool kpkt_blackbody_case(const Env &env, int type, int cellindex) {
+  if (type == ARTIS_TYPE_PRE_KPKT) return true;
+  const int c = env.M.propcell_nonemptymgi[cellindex];
+  return c >= 0 && env.C.thick[c] == ARTIS_CELL_THICK;
+}
+AHD int classify(const Env &env, const Pkt &p, double ts_end) {
   if (p.pend != PEND_NONE) return NEXT_SLOW;
   if (ma_pending(p)) return NEXT_MA;
   if (!pkt_active(p, ts_end)) return NEXT_DONE;
   if (type_gamma(p.type)) return NEXT_GAMMA;
-  return (p.type == ARTIS_TYPE_RPKT) ? NEXT_RPKT : NEXT_KPKT;
+  if (p.type == ARTIS_TYPE_RPKT) return NEXT_RPKT;
+  return kpkt_blackbody_case(env, p.type, p.cellindex) ? NEXT_BB : NEXT_KPKT;
 }
 
 // ---- r-packet kernel body. One iteration = one call of do_rpkt_step() (rpkt.cc:542). The packet's ContinuumOpacity x is
@@ -2591,13 +2655,13 @@ AHD int advance_rpkt(const Env &env, Pkt &p, int64_t pi, Chi &x, int budget) {
     go = rpkt_iter(env, p, pi, x);
     steps++;
   }
-  return classify(p, env.S.ts_end);
+  return classify(env, p, env.S.ts_end);
 }
 
 // a macro-atom has just deactivated: a packet that was an r-packet before and after continues its do_rpkt() loop with
 // its ContinuumOpacity; every other outcome ends or precedes a do_rpkt() call
-AHD void chi_after_ma(const Env &env, const Pkt &p, int64_t pi) {
-  if (!ma_pending(p) && !(p.type == ARTIS_TYPE_RPKT && p.ma_origin == 1)) env.P.chi_mgi[pi] = -1;
+AHD void chi_after_ma(Pkt &p) {
+  if (!ma_pending(p) && !(p.type == ARTIS_TYPE_RPKT && p.ma_origin == 1)) p.chi_mgi = -1;
 }
 
 // ---- macro-atom kernel body: one iteration = one transition of the walk (ma_jump). Returns true while the walk goes on
@@ -2605,7 +2669,7 @@ AHD void chi_after_ma(const Env &env, const Pkt &p, int64_t pi) {
 AHD bool ma_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
   ma_jump(env, p, pi, k);
   const bool go = ma_pending(p) && p.pend == PEND_NONE;
-  if (!ma_pending(p)) chi_after_ma(env, p, pi);
+  if (!ma_pending(p)) chi_after_ma(p);
   return go;
 }
 AHD int advance_ma(const Env &env, Pkt &p, int64_t pi, int budget) {
@@ -2616,7 +2680,7 @@ AHD int advance_ma(const Env &env, Pkt &p, int64_t pi, int budget) {
     go = ma_iter(env, p, pi, k);
     units++;
   }
-  return classify(p, env.S.ts_end);
+  return classify(env, p, env.S.ts_end);
 }
 
 // ---- fused thermal body, phase form: one iteration = a macro-atom phase of up to ARTIS_MA_PHASE transitions, then ONE
@@ -2640,17 +2704,13 @@ AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
     ma_jump(env, p, pi, k);
     j++;
   }
-  if (j > 0) chi_after_ma(env, p, pi);
-  if (!ma_pending(p) && p.pend == PEND_NONE && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT) {
-    if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[k.c] == ARTIS_CELL_THICK) {
-      do_kpkt_blackbody(env, p, pi);
-    } else {
-      do_kpkt(env, p, pi);
-    }
-    env.P.chi_mgi[pi] = -1;
+  if (j > 0) chi_after_ma(p);
+  if (kpkt_eligible(p, ts_end) && !kpkt_blackbody_case(env, p.type, p.cellindex)) {
+    do_kpkt(env, p, pi);
+    p.chi_mgi = -1;
     j++;
   }
-  *go = thermal_can_continue(p, ts_end);
+  *go = thermal_can_continue(p, ts_end) && !(kpkt_eligible(p, ts_end) && kpkt_blackbody_case(env, p.type, p.cellindex));
   return j;
 }
 
@@ -2660,16 +2720,19 @@ AHD bool kpkt_eligible(const Pkt &p, double ts_end) {
   return p.pend == PEND_NONE && !ma_pending(p) && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT && !type_gamma(p.type);
 }
 AHD int advance_kpkt(const Env &env, Pkt &p, int64_t pi) {
-  if (kpkt_eligible(p, env.S.ts_end)) {
-    const int c = env.M.propcell_nonemptymgi[p.cellindex];
-    if (p.type == ARTIS_TYPE_PRE_KPKT || env.C.thick[c] == ARTIS_CELL_THICK) {
-      do_kpkt_blackbody(env, p, pi);
-    } else {
-      do_kpkt(env, p, pi);
-    }
-    env.P.chi_mgi[pi] = -1;
+  if (kpkt_eligible(p, env.S.ts_end) && !kpkt_blackbody_case(env, p.type, p.cellindex)) {
+    do_kpkt(env, p, pi);
+    p.chi_mgi = -1;
   }
-  return classify(p, env.S.ts_end);
+  return classify(env, p, env.S.ts_end);
+}
+// ---- blackbody kernel body: ONE do_kpkt_blackbody() call; the packet leaves as an r-packet
+AHD int advance_blackbody(const Env &env, Pkt &p, int64_t pi) {
+  if (kpkt_eligible(p, env.S.ts_end) && kpkt_blackbody_case(env, p.type, p.cellindex)) {
+    do_kpkt_blackbody(env, p, pi);
+    p.chi_mgi = -1;
+  }
+  return classify(env, p, env.S.ts_end);
 }
 
 // ---- gamma kernel body: one iteration = one do_packet() call (update_packets.cc:257) for a type that does not use the
@@ -2687,7 +2750,7 @@ AHD bool gamma_iter(const Env &env, Pkt &p, int64_t pi) {
   } else {
     do_nonthermal_predeposit(env, p, pi);
   }
-  env.P.chi_mgi[pi] = -1;
+  p.chi_mgi = -1;
   return gamma_can_continue(p, env.S.ts_end);
 }
 AHD int advance_gamma(const Env &env, Pkt &p, int64_t pi, int budget) {
@@ -2697,57 +2760,71 @@ AHD int advance_gamma(const Env &env, Pkt &p, int64_t pi, int budget) {
     go = gamma_iter(env, p, pi);
     steps++;
   }
-  return classify(p, env.S.ts_end);
+  return classify(env, p, env.S.ts_end);
 }
 
 // slow-path kernel body: the one deferred action of the packet
 AHD int advance_slow(const Env &env, Pkt &p, int64_t pi) {
   if (p.pend == PEND_MA_ACTION) {
     ma_slow_action(env, p, pi);
-    chi_after_ma(env, p, pi);
+    chi_after_ma(p);
   } else if (p.pend == PEND_KPKT_FB) {
     kpkt_fb_emission(env, p, pi);
-    env.P.chi_mgi[pi] = -1;
+    p.chi_mgi = -1;
   }
-  return classify(p, env.S.ts_end);
+  return classify(env, p, env.S.ts_end);
 }
 
-// AoS (reference struct Packet) <-> SoA, one packet
-AHD void aos_to_soa(const artis_packet &a, const PktSoA &P, int64_t i) {
-  for (int k = 0; k < 4; k++) P.rng[(k * P.n) + i] = a.rngstate[k];
-  P.prop_time[i] = a.prop_time;
-  P.pos_x[i] = a.pos[0]; P.pos_y[i] = a.pos[1]; P.pos_z[i] = a.pos[2];
-  P.dir_x[i] = a.dir[0]; P.dir_y[i] = a.dir[1]; P.dir_z[i] = a.dir[2];
-  P.nu_cmf[i] = a.nu_cmf; P.e_cmf[i] = a.e_cmf; P.nu_rf[i] = a.nu_rf; P.e_rf[i] = a.e_rf;
-  P.stokes_q[i] = a.stokes_q; P.stokes_u[i] = a.stokes_u;
-  P.next_trans[i] = a.next_trans; P.nscatterings[i] = a.nscatterings; P.type[i] = a.type; P.cellindex[i] = a.cellindex;
-  P.emissiontype[i] = a.emissiontype; P.absorptiontype[i] = a.absorptiontype; P.trueemissiontype[i] = a.trueemissiontype;
-  P.escape_type[i] = a.escape_type;
-  P.em_pos_x[i] = a.em_pos[0]; P.em_pos_y[i] = a.em_pos[1]; P.em_pos_z[i] = a.em_pos[2];
-  P.trueem_pos_x[i] = a.trueem_pos[0]; P.trueem_pos_y[i] = a.trueem_pos[1]; P.trueem_pos_z[i] = a.trueem_pos[2];
-  P.absorptionfreq[i] = a.absorptionfreq;
-  P.tdecay[i] = a.tdecay;
-  P.pellet_decaytype[i] = a.pellet_decaytype;
-  P.originated_particle[i] = a.originated_from_particlenotgamma ? 1 : 0;
-  P.em_time[i] = a.em_time; P.trueem_time[i] = a.trueem_time; P.escape_time[i] = a.escape_time;
-  P.chi_nu[i] = -1.; P.chi_es[i] = 0.; P.chi_ff[i] = 0.; P.chi_bf[i] = 0.; P.chi_mgi[i] = -1;
-  P.ma_element[i] = -1; P.ma_ion[i] = -1; P.ma_level[i] = -1; P.ma_line[i] = -99; P.ma_origin[i] = 0;
-  P.pend[i] = PEND_NONE; P.pend_arg[i] = 0;
+// caller's array (reference struct Packet) <-> resident records, one packet
+AHD void aos_to_rec(const artis_packet &a, const PktStore &P, int64_t i) {
+  PktHot h;
+  for (int k = 0; k < 4; k++) h.rng[k] = a.rngstate[k];
+  h.prop_time = a.prop_time;
+  h.pos_x = a.pos[0]; h.pos_y = a.pos[1]; h.pos_z = a.pos[2];
+  h.e_cmf = a.e_cmf; h.nu_cmf = a.nu_cmf;
+  h.type = a.type; h.cellindex = a.cellindex; h.next_trans = a.next_trans; h.nscatterings = a.nscatterings;
+  h.ma_element = -1; h.ma_ion = -1; h.ma_level = -1; h.ma_line = -99;
+  h.ma_origin = 0; h.pend = PEND_NONE; h.pend_arg = 0; h.chi_mgi = -1;
+  h.emissiontype = a.emissiontype; h.trueemissiontype = a.trueemissiontype; h.absorptiontype = a.absorptiontype;
+  h.flags = 0;
+  P.hot[i] = h;
+  PktFlight f;
+  f.dir_x = a.dir[0]; f.dir_y = a.dir[1]; f.dir_z = a.dir[2];
+  f.nu_rf = a.nu_rf; f.e_rf = a.e_rf; f.stokes_q = a.stokes_q; f.stokes_u = a.stokes_u;
+  f.absorptionfreq = a.absorptionfreq;
+  f.chi_nu = -1.; f.chi_es = 0.; f.chi_ff = 0.; f.chi_bf = 0.;
+  f.em_pos_x = a.em_pos[0]; f.em_pos_y = a.em_pos[1]; f.em_pos_z = a.em_pos[2];
+  f.em_time = a.em_time; f.pad0 = 0.f;
+  P.flight[i] = f;
+  PktCold c;
+  c.trueem_pos_x = a.trueem_pos[0]; c.trueem_pos_y = a.trueem_pos[1]; c.trueem_pos_z = a.trueem_pos[2];
+  c.tdecay = a.tdecay;
+  c.escape_time = a.escape_time; c.trueem_time = a.trueem_time;
+  c.escape_type = a.escape_type; c.pellet_decaytype = a.pellet_decaytype;
+  c.originated_particle = a.originated_from_particlenotgamma ? 1 : 0;
+  c.pad[0] = c.pad[1] = c.pad[2] = 0;
+  P.cold[i] = c;
 }
-AHD void soa_to_aos(const PktSoA &P, int64_t i, artis_packet &a) {
-  for (int k = 0; k < 4; k++) a.rngstate[k] = P.rng[(k * P.n) + i];
-  a.prop_time = P.prop_time[i];
-  a.pos[0] = P.pos_x[i]; a.pos[1] = P.pos_y[i]; a.pos[2] = P.pos_z[i];
-  a.dir[0] = P.dir_x[i]; a.dir[1] = P.dir_y[i]; a.dir[2] = P.dir_z[i];
-  a.nu_cmf = P.nu_cmf[i]; a.e_cmf = P.e_cmf[i]; a.nu_rf = P.nu_rf[i]; a.e_rf = P.e_rf[i];
-  a.stokes_q = P.stokes_q[i]; a.stokes_u = P.stokes_u[i];
-  a.next_trans = P.next_trans[i]; a.nscatterings = P.nscatterings[i]; a.type = P.type[i]; a.cellindex = P.cellindex[i];
-  a.emissiontype = P.emissiontype[i]; a.absorptiontype = P.absorptiontype[i]; a.trueemissiontype = P.trueemissiontype[i];
-  a.escape_type = P.escape_type[i];
-  a.em_pos[0] = P.em_pos_x[i]; a.em_pos[1] = P.em_pos_y[i]; a.em_pos[2] = P.em_pos_z[i];
-  a.trueem_pos[0] = P.trueem_pos_x[i]; a.trueem_pos[1] = P.trueem_pos_y[i]; a.trueem_pos[2] = P.trueem_pos_z[i];
-  a.absorptionfreq = P.absorptionfreq[i];
-  a.em_time = P.em_time[i]; a.trueem_time = P.trueem_time[i]; a.escape_time = P.escape_time[i];
+AHD void rec_to_aos(const PktStore &P, int64_t i, artis_packet &a) {
+  const PktHot h = P.hot[i];
+  const PktFlight f = P.flight[i];
+  const PktCold c = P.cold[i];
+  for (int k = 0; k < 4; k++) a.rngstate[k] = h.rng[k];
+  a.prop_time = h.prop_time;
+  a.pos[0] = h.pos_x; a.pos[1] = h.pos_y; a.pos[2] = h.pos_z;
+  a.dir[0] = f.dir_x; a.dir[1] = f.dir_y; a.dir[2] = f.dir_z;
+  a.nu_cmf = h.nu_cmf; a.e_cmf = h.e_cmf; a.nu_rf = f.nu_rf; a.e_rf = f.e_rf;
+  a.stokes_q = f.stokes_q; a.stokes_u = f.stokes_u;
+  a.next_trans = h.next_trans; a.nscatterings = h.nscatterings; a.type = h.type; a.cellindex = h.cellindex;
+  a.emissiontype = h.emissiontype; a.absorptiontype = h.absorptiontype; a.trueemissiontype = h.trueemissiontype;
+  a.escape_type = c.escape_type;
+  a.em_pos[0] = f.em_pos_x; a.em_pos[1] = f.em_pos_y; a.em_pos[2] = f.em_pos_z;
+  const bool nan_trueem = (h.flags & PKT_FLAG_TRUEEM_NAN) != 0;  // kpkt.cc:483, recorded as a flag
+  a.trueem_pos[0] = nan_trueem ? NAN : c.trueem_pos_x;
+  a.trueem_pos[1] = nan_trueem ? NAN : c.trueem_pos_y;
+  a.trueem_pos[2] = nan_trueem ? NAN : c.trueem_pos_z;
+  a.absorptionfreq = f.absorptionfreq;
+  a.em_time = f.em_time; a.trueem_time = c.trueem_time; a.escape_time = c.escape_time;
 }
 
 }  // namespace artis

@@ -5,7 +5,7 @@
 //   DevCells  per-timestep cell state (the reference's update_grid() output)
 //   DevCache  per-timestep cell cache (the reference's globals::cellcache, multi-slot form,
 //             globals.h:283 / update_packets.cc:397), one row per non-empty cell
-//   PktSoA    the packet population as structure-of-arrays in HBM
+//   PktStore  the packet population in HBM (three arrays of cache-line records)
 //   DevEst    estimator accumulators
 // The same structs are used by the host-emulation test build (tests/hostemu), where the
 // pointers are host pointers.
@@ -143,37 +143,60 @@ struct DevEst {
   double *scalars;              // [ARTIS_NSCALARS]
 };
 
-// Packet population, structure-of-arrays (one array per field of the reference's struct Packet,
-// packet.h:117-169, minus the fields this path never touches: number, pellet_nucindex).
-// "hot" fields are loaded into registers for the whole life of a thread; "cold" fields are
-// written through to HBM at the (rare) events that change them.
-struct PktSoA {
-  // hot
-  uint32_t *rng;  // [4][n] Xoshiro128PP words, word-major so that lanes coalesce
-  double *prop_time, *pos_x, *pos_y, *pos_z, *dir_x, *dir_y, *dir_z, *nu_cmf, *e_cmf, *nu_rf, *e_rf, *stokes_q, *stokes_u;
-  int32_t *next_trans, *nscatterings, *type, *cellindex;
-  // cold
-  int32_t *emissiontype, *absorptiontype, *trueemissiontype, *escape_type;
-  double *em_pos_x, *em_pos_y, *em_pos_z, *trueem_pos_x, *trueem_pos_y, *trueem_pos_z, *absorptionfreq;
-  float *em_time, *trueem_time, *escape_time;
-  // read-only here, used by update_pellet() (update_packets.cc:185)
-  double *tdecay;
-  int32_t *pellet_decaytype, *originated_particle;
-  // engine-private state that lets a kernel boundary fall anywhere in a packet's history:
-  // the packet's ContinuumOpacity (rpkt.h:70; chi_mgi < 0 = not valid) ...
-  double *chi_nu, *chi_es, *chi_ff, *chi_bf;
-  int32_t *chi_mgi;
-  // ... and an activated macro-atom that has not deactivated yet (MacroAtomState packet.h:103; ma_level < 0 = none).
+// Packet population in HBM: three arrays of cache-line records, slot-major ("structure of lines").
+// The propagation kernels are persistent and work-pulling: a lane retires its packet and takes the next one on its own,
+// so a packet is loaded and stored by ONE lane at a time. With one array per field that lane would touch ~40 cache
+// lines and dirty a few bytes of each; here it reads and writes whole lines:
+//   PktHot    everything a thermal packet (k-packet, walking macro-atom) needs and changes, and the dispatch fields
+//   PktFlight what only an r-packet / gamma packet in flight needs: direction, rest-frame quantities, its ContinuumOpacity
+//   PktCold   written at rare events, read at download
+// Fields are those of the reference's struct Packet (packet.h:117-169; number and pellet_nucindex never leave the
+// caller's array) plus engine-private state that makes any kernel boundary legal.
+constexpr int32_t PKT_FLAG_TRUEEM_NAN = 1;  // trueem_pos is NaN (kpkt.cc:483): materialised at download, not stored per event
+constexpr int32_t PKT_FLAG_EMITTED = 2;     // transient, inside a kernel: emit_rpkt() ran, the flight line has to be written
+
+struct alignas(128) PktHot {
+  uint32_t rng[4];                        // Xoshiro128PP words
+  double prop_time, pos_x;
+  double pos_y, pos_z;
+  double e_cmf, nu_cmf;
+  int32_t type, cellindex, next_trans, nscatterings;
+  // an activated macro-atom that has not deactivated yet (MacroAtomState packet.h:103; ma_level < 0 = none).
   // ma_origin: 1 = activated inside do_rpkt_step() (the packet continues its do_rpkt() loop afterwards), 0 = by a k-packet.
-  int32_t *ma_element, *ma_ion, *ma_level, *ma_line, *ma_origin;
-  // a rare, register-hungry action that was sampled but is executed by the slow-path kernel (pend != 0):
-  // PEND_MA_ACTION: the bound-free macro-atom transition `pend_arg` (an ARTIS_MA_ACTION_*) of the active macro-atom;
-  // PEND_KPKT_FB: free-bound emission of a k-packet into continuum (ma_element, ma_ion, ma_level = lower level, ma_line = target).
-  int32_t *pend, *pend_arg;
+  int32_t ma_element, ma_ion, ma_level, ma_line;
+  // pend != 0: a rare, register-hungry action that was sampled but is executed by the slow-path kernel
+  //   PEND_MA_ACTION: the bound-free macro-atom transition `pend_arg` (an ARTIS_MA_ACTION_*) of the active macro-atom;
+  //   PEND_KPKT_FB: free-bound emission of a k-packet into continuum (ma_element, ma_ion, pend_arg = lower level, ma_line = target).
+  // chi_mgi: cell of the packet's ContinuumOpacity (rpkt.h:70; < 0 = not valid)
+  int32_t ma_origin, pend, pend_arg, chi_mgi;
+  int32_t emissiontype, trueemissiontype, absorptiontype, flags;
+};
+struct alignas(128) PktFlight {
+  double dir_x, dir_y;
+  double dir_z, nu_rf;
+  double e_rf, stokes_q;
+  double stokes_u, absorptionfreq;
+  double chi_nu, chi_es;                  // ContinuumOpacity: nu, chi_escatter, chi_freefree_heat, chi_boundfree
+  double chi_ff, chi_bf;
+  double em_pos_x, em_pos_y;
+  double em_pos_z;
+  float em_time, pad0;
+};
+struct alignas(64) PktCold {
+  double trueem_pos_x, trueem_pos_y;
+  double trueem_pos_z, tdecay;            // tdecay, pellet_decaytype, originated_particle: read-only here (update_pellet)
+  float escape_time, trueem_time;
+  int32_t escape_type, pellet_decaytype;
+  int32_t originated_particle, pad[3];
+};
+static_assert(sizeof(PktHot) == 128 && sizeof(PktFlight) == 128 && sizeof(PktCold) == 64, "packet records are whole cache lines");
+
+struct PktStore {
+  PktHot *hot;
+  PktFlight *flight;
+  PktCold *cold;
   int64_t n;
 };
-// number of 8-byte and 4-byte columns above (used to carve one allocation)
-constexpr int PKT_NCOL64 = 13 + 7 + 4 + 1;
-constexpr int PKT_NCOL32 = 4 /*rng*/ + 4 + 4 + 3 + 6 + 2 + 2;
+constexpr size_t PKT_BYTES_PER_PACKET = sizeof(PktHot) + sizeof(PktFlight) + sizeof(PktCold);
 
 }  // namespace artis

@@ -108,16 +108,18 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
   Emu e;
   setup(e, m, cs, ts, est, npackets > 0 ? npackets : 1);
   populate_all(e);
-  std::vector<uint8_t> soabuf(pkt_soa_bytes(npackets) + 64);
-  e.env.P = carve_pkt_soa(soabuf.data(), npackets);
-  for (int64_t i = 0; i < npackets; i++) aos_to_soa(packets[i], e.env.P, i);
+  std::vector<uint8_t> recbuf(pkt_store_bytes(npackets) + 128);
+  void *recbase = (void *)(((uintptr_t)recbuf.data() + 127) & ~(uintptr_t)127);
+  e.env.P = carve_pkt_store(recbase, npackets);
+  for (int64_t i = 0; i < npackets; i++) aos_to_rec(packets[i], e.env.P, i);
   // work lists + budgeted launches, as in artis_amd_update_packets_device(): one list per kind of pending work;
   // a launch consumes the whole current list of its kind and appends to the lists of the other kinds
   std::vector<int64_t> lists[NEXT_NKINDS], self;
   for (int64_t i = 0; i < npackets; i++) {
     Pkt p;
     pkt_load(e.env.P, i, p);
-    const int kind = classify(p, e.env.S.ts_end);
+    const int kind = classify(e.env, p, e.env.S.ts_end);
+    e.env.P.hot[i].chi_mgi = -1;  // k_classify: a ContinuumOpacity never survives into another update_packets() call
     if (kind != NEXT_DONE) lists[kind].push_back(i);
   }
   auto any = [&] {
@@ -125,7 +127,7 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
       if (!lists[k].empty()) return true;
     return false;
   };
-  const int order[5] = {NEXT_SLOW, NEXT_GAMMA, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
+  const int order[6] = {NEXT_SLOW, NEXT_GAMMA, NEXT_BB, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
   while (any() && !e.err) {
     for (int kind : order) {
       if (lists[kind].empty()) continue;
@@ -133,28 +135,33 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
       cur.swap(lists[kind]);
       for (int64_t pi : cur) {
         Pkt p;
-        pkt_load(e.env.P, pi, p);
         int next = NEXT_DONE;
-        if (kind == NEXT_RPKT) {
-          Chi x;
-          chi_load(e.env.P, pi, x);
-          next = advance_rpkt(e.env, p, pi, x, budget);
-          chi_store(e.env.P, pi, x);
-        } else if (kind == NEXT_MA) {
-          next = advance_ma(e.env, p, pi, budget * 8);
-        } else if (kind == NEXT_KPKT) {
-          next = advance_kpkt(e.env, p, pi);
-        } else if (kind == NEXT_GAMMA) {
-          next = advance_gamma(e.env, p, pi, budget);
+        if (kind == NEXT_MA || kind == NEXT_KPKT || kind == NEXT_BB) {
+          // as k_thermal / k_blackbody do: only the hot line is loaded, the flight line is written when (and only when) an
+          // r-packet was emitted
+          pkt_load_thermal(e.env.P, pi, p);
+          next = (kind == NEXT_MA) ? advance_ma(e.env, p, pi, budget * 8)
+                                   : ((kind == NEXT_KPKT) ? advance_kpkt(e.env, p, pi) : advance_blackbody(e.env, p, pi));
+          pkt_store_thermal(e.env.P, pi, p);
         } else {
-          next = advance_slow(e.env, p, pi);
+          pkt_load(e.env.P, pi, p);
+          if (kind == NEXT_RPKT) {
+            Chi x;
+            chi_load(e.env.P, pi, p, x);
+            next = advance_rpkt(e.env, p, pi, x, budget);
+            chi_store(e.env.P, pi, p, x);
+          } else if (kind == NEXT_GAMMA) {
+            next = advance_gamma(e.env, p, pi, budget);
+          } else {
+            next = advance_slow(e.env, p, pi);
+          }
+          pkt_store(e.env.P, pi, p);
         }
-        pkt_store(e.env.P, pi, p);
         if (next != NEXT_DONE) lists[next].push_back(pi);
       }
     }
   }
-  for (int64_t i = 0; i < npackets; i++) soa_to_aos(e.env.P, i, packets[i]);
+  for (int64_t i = 0; i < npackets; i++) rec_to_aos(e.env.P, i, packets[i]);
   if (est && est->stats)
     for (int i = 0; i < ARTIS_NSTATS; i++) est->stats[i] += (int64_t)e.stats[i];
   if (est && est->stats) est->stats[ARTIS_STAT_UPDATECELL] += e.env.M.npts_nonempty;
