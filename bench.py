@@ -14,6 +14,12 @@ physics (line-by-line Sobolev + macro-atom + k-packets), 1e7 packets per GPU, sy
 A packet-step is one call of do_rpkt_step() (rpkt.cc:542) or of do_kpkt()/do_kpkt_blackbody() (kpkt.cc:425/399);
 the count comes from the engine's own event counters and is identical to the CPU oracle's on the same input.
 
+`python bench.py --gpus N` (N > 1) without a torchrun environment starts the N ranks itself: it spawns
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a child process BEFORE anything
+touches the GPU and exits with the child's code; under torchrun (RANK/WORLD_SIZE set) it runs as one rank.
+`--options kilonova_lte` runs the same workload on the engine built with the packet-path options of
+artisoptions_kilonova_lte.h (libartis_amd_kilonova_lte.so; BASELINE.json configs[3]).
+
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definitions of roofline and cpu_baseline).
 """
 from __future__ import annotations
@@ -34,13 +40,22 @@ from artis_amd import abi, synth  # noqa: E402
 
 # Algorithmic bytes per unit of work ("Algorithmic bytes per unit"): what the kernels read and write
 # by design for one unit, wherever the cache hierarchy then serves it from.
-B_PER_THREAD_LAUNCH = 272.0   # packet state loaded + stored once per packet per launch (2 x 136 B)
+B_PER_THERMAL_VISIT = 256.0   # hot line (128 B) loaded + stored once per packet per k_thermal launch
+B_PER_RPKT_VISIT = 448.0      # hot + flight line (96 of 128 B used) loaded + stored once per packet per k_rpkt launch
+B_PER_EMISSION = 120.0        # flight line direction/rest-frame part 56 + em_pos/em_time 28 + trueem 36
 B_PER_MA_JUMP = 140.0         # LevelPack 16 + 9 process rates 72 + ~6 cumulative sums 48 + target level 4
 B_PER_KPKT_STEP = 200.0       # ~6 ion sums 48 + ~7 cooling-list sums 56 + ~6 collisional-excitation sums 48 + indices/flags 48
 B_PER_RPKT_STEP = 120.0       # cell scalars ~40 + boundary tables ~56 + J, nuJ, ffheating atomics 24
 B_PER_LINE = 16.0             # line frequency 8 + the cell's population factor of the line 8
 B_PER_CONT = 52.0             # ContPack 32 + {nnlevel, edge part} 16 + cross-section entry 4
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# bytes a kernel HAS to write by design (for write_amplification = measured WRITE_SIZE / this)
+W_PER_THERMAL_VISIT = 128.0   # hot line
+W_PER_RPKT_VISIT = 224.0      # hot line + 96 B of the flight line
+W_PER_EMISSION = 120.0
+W_PER_ATOMIC = 8.0            # one f64 estimator add
+W_PER_LIST_ENTRY = 8.0        # (slot, key) appended to a work list
+PROFILE_ROUND = "r02"
 
 
 class _CudaArrayView:
@@ -58,14 +73,14 @@ def _cpu_worker(args):
     sub = pk[lo:hi].copy()
     est = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
     t0 = time.perf_counter()
-    oracle_py.update_packets(model, cs, ts, sub, est)
+    oracle_py.update_packets(model, cs, ts, sub, est, preset=_cpu_worker.options)
     wall = time.perf_counter() - t0
-    oracle_py.lib().artis_oracle_last_populate_seconds.restype = __import__("ctypes").c_double
-    tpop = oracle_py.lib().artis_oracle_last_populate_seconds()
+    oracle_py.lib(_cpu_worker.options).artis_oracle_last_populate_seconds.restype = __import__("ctypes").c_double
+    tpop = oracle_py.lib(_cpu_worker.options).artis_oracle_last_populate_seconds()
     return int(est.stats[abi.STAT_X_RPKT_STEPS] + est.stats[abi.STAT_X_KPKT_STEPS]), wall, tpop
 
 
-def cpu_baseline(model, cs, ts, pk, sample: int, cores: int):
+def cpu_baseline(model, cs, ts, pk, sample: int, cores: int, options: str = "classic"):
     """The CPU oracle (a scalar port of the reference's path) on the first `sample` packets of the same population,
     one process per core. Cell-cache filling is lazy as in the reference's CPU build and its time is excluded
     (at full scale it is amortised over ~150 packets per cell; in a small sample it would dominate)."""
@@ -73,6 +88,7 @@ def cpu_baseline(model, cs, ts, pk, sample: int, cores: int):
     sample = min(sample, len(pk))
     bounds = [(sample * i // cores, sample * (i + 1) // cores) for i in range(cores)]
     _cpu_worker.shared = (model, cs, ts, pk)
+    _cpu_worker.options = options
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:
@@ -97,15 +113,29 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=160_000)
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--options", default="classic", choices=("classic", "kilonova_lte"),
+                    help="options preset of include/artis_options.h (the reference's artisoptions_*.h)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the ranks ourselves: fresh child processes, nothing in this process has touched the GPU
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.call(cmd))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N>1"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
 
     t_setup = time.perf_counter()
-    model, cs, ts, aux = synth.build(args.preset, ncoord=args.ncoord)
+    model, cs, ts, aux = synth.build(args.preset, ncoord=args.ncoord, options=args.options)
     # packet seeds: the reference's per-rank spacing (input.cc:1912: rank_seed_base = seed + rank * npackets)
     seed_base = (1281360349 + rank * args.packets) & 0xFFFFFFFF
     pk = synth.make_packets(model, aux, args.packets, seed_base=seed_base, kpkt_fraction=0.02, seed=99 + rank)
@@ -113,7 +143,7 @@ def main():
     baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = args.cpu_cores or min(os.cpu_count() or 1, 16)
-        baseline = cpu_baseline(model, cs, ts, pk, args.cpu_sample, cores)  # before any GPU initialisation (fork)
+        baseline = cpu_baseline(model, cs, ts, pk, args.cpu_sample, cores, args.options)  # before any GPU initialisation (fork)
 
     import torch
     import torch.distributed as dist
@@ -126,7 +156,7 @@ def main():
 
     from artis_amd import engine
 
-    eng = engine.Engine(model, device=local_rank)
+    eng = engine.Engine(model, device=local_rank, preset=args.options)
     eng.set_cellstate(cs, ts)
     eng.upload_packets(pk)
     eng.snapshot()
@@ -190,46 +220,81 @@ def main():
         # roofline of the dominant kernel (k_thermal: macro-atom walk + k-packet steps): algorithmic bytes of its work
         # in one timestep / its summed launch durations (HIP events on the launch stream, artis_engine.hip)
         bd = eng.last_kernel_breakdown()
-        alg_thermal = (B_PER_MA_JUMP * stats[abi.STAT_X_MA_JUMPS] + B_PER_KPKT_STEP * stats[abi.STAT_X_KPKT_STEPS] +
-                       B_PER_THREAD_LAUNCH * bd["thermal_threads"])
-        alg_rpkt = (B_PER_LINE * stats[abi.STAT_X_LINES_VISITED] + B_PER_RPKT_STEP * stats[abi.STAT_X_RPKT_STEPS] +
-                    B_PER_CONT * stats[abi.STAT_NAMES.index("X_CONT_VISITED")] + B_PER_THREAD_LAUNCH * bd["rpkt_threads"])
-        dominant = "k_thermal" if bd["thermal_ms"] >= bd["rpkt_ms"] else "k_rpkt"
-        alg_bytes = alg_thermal if dominant == "k_thermal" else alg_rpkt
-        k_ms_per_step = bd["thermal_ms"] if dominant == "k_thermal" else bd["rpkt_ms"]
-        launches_per_step = bd["thermal_launches"] if dominant == "k_thermal" else bd["rpkt_launches"]
-        achieved = alg_bytes / (k_ms_per_step * 1e-3) / 1e9 if k_ms_per_step > 0 else 0.0
-        both = (alg_thermal + alg_rpkt) / ((bd["thermal_ms"] + bd["rpkt_ms"]) * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel per launch: from the committed rocprofv3 --pmc passes of this same command
+        S = lambda name: float(stats[abi.STAT_NAMES.index(name)])  # noqa: E731
+        emissions = (S("K_STAT_TO_R_FF") + S("K_STAT_TO_R_FB") + S("K_STAT_TO_R_BB") + S("MA_STAT_DEACTIVATION_BB") +
+                     S("MA_STAT_DEACTIVATION_FB"))
+        alg = {
+            "k_thermal": (B_PER_MA_JUMP * S("X_MA_JUMPS") + B_PER_KPKT_STEP * S("X_KPKT_STEPS") +
+                          B_PER_THERMAL_VISIT * bd["thermal_threads"] + B_PER_EMISSION * emissions),
+            "k_rpkt": (B_PER_LINE * S("X_LINES_VISITED") + B_PER_RPKT_STEP * S("X_RPKT_STEPS") +
+                       B_PER_CONT * S("X_CONT_VISITED") + B_PER_RPKT_VISIT * bd["rpkt_threads"]),
+        }
+        # bytes the kernels have to write by design: packet lines at retire, list entries, estimator atomics
+        wr = {
+            "k_thermal": (W_PER_THERMAL_VISIT + W_PER_LIST_ENTRY) * bd["thermal_threads"] + W_PER_EMISSION * emissions +
+                         W_PER_ATOMIC * (S("MA_STAT_DEACTIVATION_COLLDEEXC") + S("MA_STAT_DEACTIVATION_COLLRECOMB")),
+            "k_rpkt": (W_PER_RPKT_VISIT + W_PER_LIST_ENTRY) * bd["rpkt_threads"] + 3 * W_PER_ATOMIC * S("X_RPKT_STEPS") +
+                      32.0 * S("X_CHI_EVALS"),
+        }
+        kms = {"k_thermal": bd["thermal_ms"], "k_rpkt": bd["rpkt_ms"]}
+        kl = {"k_thermal": bd["thermal_launches"], "k_rpkt": bd["rpkt_launches"]}
+        dominant = "k_thermal" if kms["k_thermal"] >= kms["k_rpkt"] else "k_rpkt"
+        # HBM traffic per launch: from the committed rocprofv3 --pmc passes of this same command
         # (profiles/<round>/pmc_traffic.json, written by tools/pmc_summary.py; FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950). None when the workload is not the profiled one.
-        traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-        if os.path.exists(tfile) and args.packets == 10_000_000 and args.ncoord == 50 and args.preset == "w7" and world == 1:
+        tj, traffic_src = {}, None
+        tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic.json")
+        if (os.path.exists(tfile) and args.packets == 10_000_000 and args.ncoord == 50 and args.preset == "w7" and world == 1
+                and args.options == "classic"):
             with open(tfile) as f:
                 tj = json.load(f)
-            if dominant in tj:
-                traffic = tj[dominant]["hbm_bytes_per_launch"]
-                traffic_src = "profiles/r01/pmc_traffic.json"
+            traffic_src = f"profiles/{PROFILE_ROUND}/pmc_traffic.json"
+
+        def kernel_roofline(k):
+            ms = kms[k]
+            nl = max(kl[k], 1)
+            r = {"kernel_ms_per_step": ms, "launches_per_step": kl[k], "avg_launch_ms": ms / nl,
+                 "algorithmic_bytes_per_launch": alg[k] / nl,
+                 "algorithmic_gbs": alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                 "hbm_bytes_per_launch_measured": None, "hbm_gbs_measured": None, "hbm_frac_measured": None,
+                 "write_amplification": None}
+            if k in tj and ms > 0:
+                t = tj[k]
+                r["hbm_bytes_per_launch_measured"] = t["hbm_bytes_per_launch"]
+                # the PMC passes have their own launch count (one step): scale by bytes per launch
+                gbs = t["hbm_bytes_per_launch"] * nl / (ms * 1e-3) / 1e9
+                r["hbm_gbs_measured"] = gbs
+                r["hbm_frac_measured"] = gbs / HBM_PEAK_GBS
+                r["write_amplification"] = t["write_size_kb"] * 1024.0 / t["dispatches"] * nl / wr[k] if wr[k] > 0 else None
+            return r
+
+        per_kernel = {k: kernel_roofline(k) for k in ("k_thermal", "k_rpkt")}
+        d = per_kernel[dominant]
         out = {
             "metric": "packet-steps/sec", "value": value, "unit": "packet-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.ncoord}^3 Cartesian W7-like ejecta, artisoptions_classic physics "
+            "config": {"workload": f"{args.ncoord}^3 Cartesian W7-like ejecta, artisoptions_{args.options} physics "
                                    f"(line-by-line Sobolev + macro-atom + k-packets), {args.packets} packets per GPU, "
                                    f"synthetic atomic data '{args.preset}' ({model['nlines']} lines, {model['nlevels']} levels, "
                                    f"{model['nions']} ions), one timestep at t=20 d (dt/t=0.05)",
+                       "options": args.options,
                        "packets_per_gpu": args.packets, "nonempty_cells": int(model["npts_nonempty"]),
                        "packet_steps_per_step": steps_all, "setup_s": round(setup_s, 1),
                        "parallelism": f"packets sharded over {world} GPU(s); estimator all-reduce over RCCL" if world > 1
                        else "1 GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": dominant, "launches_per_step": launches_per_step,
-                         "kernel_ms_per_step": k_ms_per_step, "avg_launch_ms": k_ms_per_step / max(launches_per_step, 1),
-                         "algorithmic_bytes_per_step": float(alg_bytes),
-                         "algorithmic_bytes_per_launch": float(alg_bytes) / max(launches_per_step, 1),
-                         "achieved_both_propagation_kernels": both},
+            # achieved/frac: ALGORITHMIC bytes (requested by design, cache-served re-reads included) over the kernel's launch
+            # time; hbm_frac_measured: bytes that reached HBM by the rocprofv3 counters over the same time -- the number
+            # north_star's ">= 30 % of HBM roofline" is about
+            "roofline": {"bound": "hbm", "achieved": d["algorithmic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": d["algorithmic_gbs"] / HBM_PEAK_GBS, "traffic": d["hbm_bytes_per_launch_measured"],
+                         "traffic_source": traffic_src, "kernel": dominant,
+                         "hbm_gbs_measured": d["hbm_gbs_measured"], "hbm_frac_measured": d["hbm_frac_measured"],
+                         "write_amplification": d["write_amplification"],
+                         "launches_per_step": d["launches_per_step"], "kernel_ms_per_step": d["kernel_ms_per_step"],
+                         "avg_launch_ms": d["avg_launch_ms"],
+                         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                         "kernels": per_kernel},
         }
         out["kernel_breakdown_last_step"] = bd
         if os.environ.get("ARTIS_BENCH_VERBOSE"):
