@@ -11,7 +11,7 @@ SO = os.path.join(HERE, "libartis_amd.so")
 SOURCES = ["artis_engine.hip", "physics.h", "tables.h", "model_build.h"]
 # -ffp-contract=off: the operation order of physics.h is part of the parity contract (no FMA contraction).
 # -munsafe-fp-atomics: estimator adds become global_atomic_add_f64, not compare-and-swap loops.
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-munsafe-fp-atomics"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-munsafe-fp-atomics", "-ldl"]
 
 
 PRESETS = ("classic", "kilonova_lte")  # options presets of include/artis_options.h (the reference's artisoptions_*.h)

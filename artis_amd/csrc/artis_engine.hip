@@ -9,6 +9,9 @@
 //   * estimators are accumulated with hardware f64 atomics, event counters in LDS and flushed per block.
 // There is no CPU path in this library: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is bound at run time (rccl_api below)
+
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -494,16 +497,16 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
       int j = 0;
       int exit_action = -1;
       double exit_rate = 0.;
+      if (ma_pending(p) && p.pend == PEND_NONE) ma_prepare(env, p, k);  // the record of the current level; the walk carries it on
       while (j < ARTIS_MA_PHASE && exit_action < 0 && ma_pending(p) && p.pend == PEND_NONE) {
 #ifdef ARTIS_PROFILE
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 46);
 #endif
-        ma_prepare(env, p, k);
-        exit_action = ma_jump_internal(env, p, k, k.cellma + k.lp.rec_off, ma_targets(env, k), &exit_rate);
+        exit_action = ma_jump_internal(env, p, k, &exit_rate);
         j++;
       }
       ma_flush_stats(env, k);
-      if (exit_action >= 0) ma_jump_exit(env, p, pi, k, k.cellma + k.lp.rec_off, ma_targets(env, k), exit_action, exit_rate);
+      if (exit_action >= 0) ma_jump_exit(env, p, pi, k, exit_action, exit_rate);
       if (j > 0) chi_after_ma(p);
       units += j;
     }
@@ -654,6 +657,7 @@ struct artis_amd_engine {
   bool sort_nu = true;
   bool sort_ma = true;
   bool trace = false;
+  ncclComm_t comm = nullptr;  // created by artis_amd_comm_init(), owned by the engine
 };
 
 namespace {
@@ -747,7 +751,51 @@ int ensure_aos(artis_amd_engine *e, int64_t n) {
 
 namespace {
 int engine_fill(artis_amd_engine *e, const artis_model *model);
+
+// RCCL entry points, resolved at run time from the librccl the process already has (a host that links RCCL itself, or
+// torch's own copy in bench.py) or else from the ROCm installation: the engine library itself carries no link-time
+// dependency on a particular librccl, and a communicator handed in by the caller is used with the library it came from.
+struct RcclApi {
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+const RcclApi &rccl_api() {
+  static RcclApi api = [] {
+    RcclApi a;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+      if (h) break;
+    }
+    if (!h)
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+      }
+    if (!h) return a;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
+    return a;
+  }();
+  return api;
 }
+#define RCCL_TRY(expr)                                                                             \
+  do {                                                                                             \
+    ncclResult_t _r = (expr);                                                                      \
+    if (_r != ncclSuccess) {                                                                       \
+      g_last_error = std::string(#expr) + ": " + rccl_api().GetErrorString(_r);                    \
+      return ARTIS_ERR_RCCL;                                                                       \
+    }                                                                                              \
+  } while (0)
+}  // namespace
 
 extern "C" {
 
@@ -846,7 +894,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
 #define CA(f, T, per)                                                                       \
   {                                                                                         \
     T *d = nullptr;                                                                         \
-    HIP_TRY(hipMalloc((void **)&d, sizeof(T) * (size_t)(ncell * (int64_t)(per) + 1)));    \
+    HIP_TRY(hipMalloc((void **)&d, sizeof(T) * (size_t)(ncell * (int64_t)(per) + MAREC_SLACK)));    \
     e->cache_allocs.push_back(d);                                                           \
     e->K.f = d;                                                                             \
   }
@@ -905,6 +953,7 @@ extern "C" {
 void artis_amd_engine_destroy(artis_amd_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  if (e->comm && rccl_api().ok) (void)rccl_api().CommDestroy(e->comm);
   free_all(e->model_allocs);
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
@@ -1236,6 +1285,55 @@ int artis_amd_estimators_devptr(artis_amd_engine *e, void **dptr, int64_t *ndoub
   if (!e || !dptr || !ndoubles) return ARTIS_ERR_ARG;
   *dptr = e->d_est;
   *ndoubles = e->est_ndoubles;
+  return ARTIS_OK;
+}
+
+int artis_amd_comm_unique_id(void *id_out) {
+  if (!id_out) return ARTIS_ERR_ARG;
+  if (!rccl_api().ok) {
+    g_last_error = "librccl could not be loaded";
+    return ARTIS_ERR_RCCL;
+  }
+  ncclUniqueId id;
+  RCCL_TRY(rccl_api().GetUniqueId(&id));
+  std::memcpy(id_out, id.internal, ARTIS_AMD_COMM_ID_BYTES);
+  return ARTIS_OK;
+}
+
+int artis_amd_comm_init(artis_amd_engine *e, int nranks, int rank, const void *id_bytes) {
+  if (!e || !id_bytes || nranks < 1 || rank < 0 || rank >= nranks) {
+    g_last_error = "bad communicator arguments";
+    return ARTIS_ERR_ARG;
+  }
+  if (!rccl_api().ok) {
+    g_last_error = "librccl could not be loaded";
+    return ARTIS_ERR_RCCL;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->comm) {
+    (void)rccl_api().CommDestroy(e->comm);
+    e->comm = nullptr;
+  }
+  ncclUniqueId id;
+  std::memcpy(id.internal, id_bytes, ARTIS_AMD_COMM_ID_BYTES);
+  RCCL_TRY(rccl_api().CommInitRank(&e->comm, nranks, id, rank));
+  return ARTIS_OK;
+}
+
+int artis_amd_allreduce_estimators(artis_amd_engine *e, void *nccl_comm, void *hip_stream) {
+  if (!e) return ARTIS_ERR_ARG;
+  ncclComm_t comm = nccl_comm ? (ncclComm_t)nccl_comm : e->comm;
+  if (!comm) {
+    g_last_error = "no communicator: pass an ncclComm_t or call artis_amd_comm_init() first";
+    return ARTIS_ERR_ARG;
+  }
+  if (!rccl_api().ok) {
+    g_last_error = "librccl could not be loaded";
+    return ARTIS_ERR_RCCL;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  // one in-place sum over the whole block [J | nuJ | ffheat | colheat | gamma | bfheat | dep_* | scalars]
+  RCCL_TRY(rccl_api().AllReduce(e->d_est, e->d_est, (size_t)e->est_ndoubles, ncclDouble, ncclSum, comm, (hipStream_t)hip_stream));
   return ARTIS_OK;
 }
 

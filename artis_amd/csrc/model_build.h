@@ -202,7 +202,7 @@ inline void unpack_macache_row(const DevModel &hostview, const artis_model &m, c
     const LevelPack lp = hostview.level_pack[ul];
     const double *rec = row + lp.rec_off;
     if (maprocessrates)
-      for (int a = 0; a < 9; a++) maprocessrates[(int64_t)ul * 9 + a] = rec[a];
+      for (int a = 0; a < 9; a++) maprocessrates[(int64_t)ul * 9 + a] = rec[marec_rates + a];
     if (matrans) {
       double *blk = matrans + m.level_matransblock_start[ul];
       for (int i = 0; i < lp.ndown; i++) {

@@ -829,10 +829,20 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   const int level = ul - start;
   const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
   const LevelPack lpk = M.level_pack[ul];
-  double *rates = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
-  double *blk_down = rates + marec_down;                      // cumulative internal-down-same
-  double *blk_up = rates + marec_up(lpk.ndown);               // cumulative internal-up-same
-  double *blk_rad = rates + marec_rad(lpk.ndown, lpk.nup);    // cumulative radiative de-excitation
+  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
+  double *rates = rec + marec_rates;
+  double *blk_down = rec + marec_down;                        // cumulative internal-down-same
+  double *blk_up = rec + marec_up(lpk.ndown);                 // cumulative internal-up-same
+  double *blk_rad = rec + marec_rad(lpk.ndown, lpk.nup);      // cumulative radiative de-excitation
+  {  // the static part of the record: header and transition targets (tables.h)
+    *(MaHeader *)rec = MaHeader{lpk.ndown, lpk.nup, ul, lpk.alltrans_startdown};
+    MaTarget *tgt = (MaTarget *)(rec + marec_tgt(lpk.ndown, lpk.nup));
+    const int ntrans = lpk.ndown + lpk.nup;
+    for (int i = 0; i < ntrans; i++) {
+      const int tl = M.alltrans_targetlevelindex[lpk.alltrans_startdown + i];
+      tgt[i] = MaTarget{M.level_pack[start + tl].rec_off, tl};
+    }
+  }
   const double t_mid = env.S.mid;
   const float T_e = env.C.Te[c];
   const float cnne = clumpednne(env.C, c);
@@ -1619,7 +1629,8 @@ struct MACtx {
   bool thick;               // the cell is optically thick (grey): its k-packets go to do_kpkt_blackbody()
   const double *cellma;     // the cell's row of macro-atom records
   int start_key, start;     // cached get_ionuniquelevelindexstart(element, ion)
-  LevelPack lp;             // static indices of the current level (ma_prepare)
+  int rec;                  // offset of the current level's record in the cell's row (ma_prepare, then carried by the walk)
+  MaHeader hd;              // header of the record the last transition was drawn from
   int njumps;               // transitions made since the last ma_flush_stats()
 };
 AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
@@ -1629,20 +1640,34 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
   k.start_key = -1;
   k.start = 0;
-  k.lp = LevelPack{0, 0, 0, 0};
+  k.rec = 0;
+  k.hd = MaHeader{0, 0, 0, 0};
   k.njumps = 0;
   return k;
 }
 
 // upper_bound over the cumulative sums of one block of a macro-atom record (non-decreasing): index of the first
-// element > v, at most n. Eight independent reads per round (upper_bound_wide). Measured alternatives, all slower on
-// MI355X: bisection (dependent reads), branch-free reads clamped to the last element (more memory instructions),
-// 16-byte paired reads of a padded record.
-AHD int ma_search(const double *a, int n, double v) { return upper_bound_wide(a, n, v); }
+// element > v, at most n. Eight independent reads per round, issued without bounds checks as four 16-byte loads (a
+// block is 16-byte aligned and reading past its end stays inside the row, tables.h); entries at or beyond n are never
+// counted. Measured alternatives, all slower on MI355X: bisection (dependent reads), reads clamped to the last element.
+AHD int ma_search(const double *a, int n, double v) {
+  int idx = 0;
+  for (int base = 0; base < n; base += 8) {
+    const D2 q0 = *(const D2 *)(a + base), q1 = *(const D2 *)(a + base + 2), q2 = *(const D2 *)(a + base + 4),
+             q3 = *(const D2 *)(a + base + 6);
+    const double x[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) cnt += ((base + k < n) && (x[k] <= v)) ? 1 : 0;
+    idx += cnt;
+    if (cnt < 8) break;
+  }
+  return idx;
+}
 
-// one iteration of the loop of do_macroatom(), macroatom.cc:385-577. ma_prepare() looks up the static indices of the
-// current level; ma_jump_internal() / ma_jump_exit() perform the transition given the level's macro-atom record
-// `rates` (tables.h layout) and its transition targets `targets` (down targets, then up targets).
+// one iteration of the loop of do_macroatom(), macroatom.cc:385-577. ma_prepare() finds the record of the packet's
+// current level (once per phase of the walk: afterwards every transition hands over the record of its target);
+// ma_jump_internal() / ma_jump_exit() perform the transition from the record at k.rec.
 AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
   const int key = (p.ma_element << 8) | p.ma_ion;
   if (key != k.start_key) {
@@ -1651,20 +1676,24 @@ AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
   }
   return k.start + p.ma_level;
 }
-typedef int32_t ma_target_t;  // alltrans.targetlevelindex: the level a transition leads to, within the ion
-AHD void ma_set_level(Pkt &p, int32_t level) { p.ma_level = level; }
+AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) { k.rec = env.M.level_pack[ma_locate(env, p, k)].rec_off; }
 // First half of a transition: draw the process (macroatom.cc:425-431); an internal transition inside the ion is made
 // at once and -1 is returned. Every other process ends the walk in this kernel (deactivation, or a bound-free process
 // for the slow path): its index is returned with its rate, and ma_jump_exit() carries it out. The split lets a kernel
 // keep the rare, long deactivation code out of its transition loop.
 constexpr int MA_EXIT_FAILED = 99;
-AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rates, const ma_target_t *targets, double *rate_out) {
-  const LevelPack lp = k.lp;
+AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, double *rate_out) {
+  const double *rec = k.cellma + k.rec;
+  const MaHeader hd = *(const MaHeader *)rec;
+  k.hd = hd;
   // std::partial_sum macroatom.cc:425 and index_upperbound sn3d.h:85 over the 9 cumulative rates, kept in
   // registers (statically indexed): action = number of cumulative values <= randomrate, clamped to the last one
   double r[MA_N];
-#pragma unroll
-  for (int i = 0; i < MA_N; i++) r[i] = rates[i];
+  {
+    const D2 q0 = *(const D2 *)(rec + 2), q1 = *(const D2 *)(rec + 4), q2 = *(const D2 *)(rec + 6), q3 = *(const D2 *)(rec + 8);
+    r[0] = q0.x; r[1] = q0.y; r[2] = q1.x; r[3] = q1.y; r[4] = q2.x; r[5] = q2.y; r[6] = q3.x; r[7] = q3.y;
+    r[8] = rec[10];
+  }
   double cum[MA_N];
   cum[0] = r[0];
 #pragma unroll
@@ -1688,35 +1717,37 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rates, 
   const bool down = (action == ARTIS_MA_ACTION_INTERNALDOWNSAME);
   if (down || action == ARTIS_MA_ACTION_INTERNALUPSAME) {
     // macroatom.cc:433-447 and 536-550: one search for both directions, so that a wave runs it once
-    const int ndown = lp.ndown;
-    const int nsel = down ? ndown : lp.nup;
+    const int ndown = hd.ndown;
+    const int nsel = down ? ndown : hd.nup;
     const int first = down ? 0 : ndown;                       // first target of the direction
-    const double *sums = rates + (down ? marec_down : marec_up(ndown));
+    const double *sums = rec + (down ? marec_down : marec_up(ndown));
     const double targetval = rng_uniform(p) * rate_sel;
     const int ti = ma_search(sums, nsel - 1, targetval);
-    ma_set_level(p, targets[first + ti]);
+    const MaTarget tg = ((const MaTarget *)(rec + marec_tgt(ndown, hd.nup)))[first + ti];
+    p.ma_level = tg.level;
+    k.rec = tg.rec_off;
     return -1;
   }
   *rate_out = rate_sel;
   return action;
 }
-AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double *rates, const ma_target_t *targets, int action,
-                      double rate_sel) {
+AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, int action, double rate_sel) {
   const DevModel &M = env.M;
   const int c = k.c;
-  const LevelPack lp = k.lp;
+  const MaHeader hd = k.hd;  // of the record the action was drawn from: the packet's current level
+  const double *rec = k.cellma + k.rec;
   const int activatingline = p.ma_line;
   if (action == ARTIS_MA_ACTION_RADDEEXC) {
     // do_macroatom_raddeexcitation macroatom.cc:204
     const double targetval = rng_uniform(p) * rate_sel;
-    const int ndown = lp.ndown;
-    const double *sums = rates + marec_rad(ndown, lp.nup);
+    const int ndown = hd.ndown;
+    const double *sums = rec + marec_rad(ndown, hd.nup);
     const int dti = ma_search(sums, ndown - 1, targetval);
-    const int startdown = lp.alltrans_startdown;
-    const int lineindex = M.alltrans_lineindex[startdown + dti];
+    const int lineindex = M.alltrans_lineindex[hd.alltrans_startdown + dti];
     if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
-    const int ul = ma_locate(env, p, k);
-    const int lul = k.start + targets[dti];
+    const int ul = hd.ul;
+    const MaTarget tg = ((const MaTarget *)(rec + marec_tgt(ndown, hd.nup)))[dti];
+    const int lul = (ul - p.ma_level) + tg.level;
     const double e_trans = eps(M, ul) - eps(M, lul);
     const double oldnucmf = p.nu_cmf;
     p.nu_cmf = e_trans / HPLANCK;
@@ -1741,13 +1772,6 @@ AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double
     p.pend_arg = action;
   }
 }
-// k.lp = the static indices of the packet's current level. (Carrying them with the transition that leads to a level --
-// a 16-byte record per transition instead of the 4-byte level index -- saves this read but was measured 12 % slower: the
-// larger table falls out of L1.)
-AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) { k.lp = env.M.level_pack[ma_locate(env, p, k)]; }
-AHD const ma_target_t *ma_targets(const Env &env, const MACtx &k) {
-  return env.M.alltrans_targetlevelindex + k.lp.alltrans_startdown;
-}
 AHD void ma_flush_stats(const Env &env, MACtx &k) {
   if (k.njumps != 0) {
     ARTIS_STAT_ADD(env, ARTIS_STAT_X_MA_JUMPS, k.njumps);
@@ -1757,11 +1781,9 @@ AHD void ma_flush_stats(const Env &env, MACtx &k) {
 }
 AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
   ma_prepare(env, p, k);
-  const double *rates = k.cellma + k.lp.rec_off;
-  const ma_target_t *targets = ma_targets(env, k);
   double rate_sel = 0.;
-  const int action = ma_jump_internal(env, p, k, rates, targets, &rate_sel);
-  if (action >= 0) ma_jump_exit(env, p, pi, k, rates, targets, action, rate_sel);
+  const int action = ma_jump_internal(env, p, k, &rate_sel);
+  if (action >= 0) ma_jump_exit(env, p, pi, k, action, rate_sel);
   ma_flush_stats(env, k);
 }
 
@@ -1777,7 +1799,7 @@ AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi) {
   const int ui = uion(M, element, ion);
   const int ul = M.ion_uniquelevelindexstart[ui] + level;
   const double e_cur = eps(M, ul);
-  const double rate_sel = env.K.macache[((int64_t)c * M.nmacache) + M.level_pack[ul].rec_off + action];
+  const double rate_sel = env.K.macache[((int64_t)c * M.nmacache) + M.level_pack[ul].rec_off + marec_rates + action];
   const float T_e = env.C.Te[c];
   const float cnne = clumpednne(env.C, c);
   if (action == ARTIS_MA_ACTION_RADRECOMB) {

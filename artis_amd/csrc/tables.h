@@ -45,16 +45,36 @@ struct alignas(32) ContPack {
   int32_t gi;
   int32_t pad[2];
 };
-// macro-atom record of one (cell, level), 128-byte aligned:
-//   [0..8]               the 9 process rates            (alllevels_maprocessrates, globals.h:286)
-//   [marec_down ..)      cumulative internal-down-same  (allmacroatomictransitions block 2, macroatom.cc:44)
-//   [marec_up(ndown) ..) cumulative internal-up-same    (block 3, macroatom.cc:51)
-//   [marec_rad(ndown, nup) ..) cumulative radiative deexc. (block 1, macroatom.cc:58)
-constexpr int marec_down = 9;
-constexpr int marec_up(int ndown) { return marec_down + ndown; }
-constexpr int marec_rad(int ndown, int nup) { return marec_up(ndown) + nup; }
-constexpr int marec_size(int ndown, int nup) { return marec_rad(ndown, nup) + ndown; }
+// Macro-atom record of one (cell, level), 128-byte aligned and SELF-CONTAINED: one transition of the walk
+// (macroatom.cc:385-577) reads this record and nothing else -- no level table, no transition table -- so the chain of
+// dependent reads per transition is record -> cumulative sums -> target, all inside a few adjacent cache lines.
+// In doubles:
+//   [0..1]                 MaHeader (16 B): ndown, nup, unique level index, alltrans_startdown
+//   [2..10]                the 9 process rates              (alllevels_maprocessrates, globals.h:286)
+//   [marec_down ..)        cumulative internal-down-same    (allmacroatomictransitions block 2, macroatom.cc:44)
+//   [marec_up(ndown) ..)   cumulative internal-up-same      (block 3, macroatom.cc:51)
+//   [marec_rad(..) ..)     cumulative radiative deexc.      (block 1, macroatom.cc:58)
+//   [marec_tgt(..) ..)     MaTarget (8 B) of every transition, down targets then up targets: the target level and the
+//                          offset of ITS record in the cell's row (static data, repeated per cell so that it sits next to
+//                          the sums that select it)
+// Every block starts 16-byte aligned (counts rounded up to even); a search may read up to 7 doubles past a block's end
+// (it never uses them), which stays inside the row (+ MAREC_SLACK at the end of the allocation).
+struct alignas(16) MaHeader {
+  int32_t ndown, nup, ul, alltrans_startdown;
+};
+struct alignas(8) MaTarget {
+  int32_t rec_off;  // offset (in doubles) of the target level's record in a cell's macache row
+  int32_t level;    // the target level's index within its ion (alltrans.targetlevelindex)
+};
+constexpr int marec_even(int n) { return (n + 1) & ~1; }
+constexpr int marec_rates = 2;
+constexpr int marec_down = 12;
+constexpr int marec_up(int ndown) { return marec_down + marec_even(ndown); }
+constexpr int marec_rad(int ndown, int nup) { return marec_up(ndown) + marec_even(nup); }
+constexpr int marec_tgt(int ndown, int nup) { return marec_rad(ndown, nup) + marec_even(ndown); }
+constexpr int marec_size(int ndown, int nup) { return marec_tgt(ndown, nup) + ndown + nup; }
 constexpr int MAREC_ALIGN = 16;  // doubles
+constexpr int MAREC_SLACK = 16;  // doubles past the last row that a padded search may touch
 
 struct alignas(16) D2 {
   double x, y;

@@ -73,6 +73,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_last_kernel_launches",
     "artis_amd_last_kernel_table",
     "artis_amd_options_preset",
+    "artis_amd_allreduce_estimators", "artis_amd_comm_unique_id", "artis_amd_comm_init",
 ]
 
 
@@ -151,6 +152,24 @@ class Engine:
         self._check(self.L.artis_amd_debug_cellcache(*args))
         out["chi_ff_nnionpart"] = chi.value
         return out
+
+    # estimator reduction in the C++ host layer (RCCL)
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(self.COMM_ID_BYTES)
+        self.L.artis_amd_comm_unique_id.argtypes = [C.c_void_p]
+        self._check(self.L.artis_amd_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, id_bytes: bytes):
+        assert len(id_bytes) == self.COMM_ID_BYTES
+        self.L.artis_amd_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        self._check(self.L.artis_amd_comm_init(self.h, nranks, rank, id_bytes))
+
+    def allreduce_estimators(self, stream: int = 0, comm: int = 0):
+        self.L.artis_amd_allreduce_estimators.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self._check(self.L.artis_amd_allreduce_estimators(self.h, C.c_void_p(comm), C.c_void_p(stream)))
 
     def last_kernel_breakdown(self):
         a, b, c, d = C.c_double(), C.c_int64(), C.c_double(), C.c_int64()

@@ -346,6 +346,7 @@ typedef struct artis_amd_engine artis_amd_engine;
 #define ARTIS_ERR_ARG (-3)
 #define ARTIS_ERR_UNSUPPORTED (-4)
 #define ARTIS_ERR_NOTCONVERGED (-5)
+#define ARTIS_ERR_RCCL (-6)
 
 const char *artis_amd_last_error(void);
 int artis_amd_abi_version(void);
@@ -396,6 +397,20 @@ int artis_amd_estimators_download(artis_amd_engine *eng, artis_estimators *est_a
  * MPI_Allreduce of the heating/gamma estimators in sn3d.cc). The block is one
  * contiguous array of `*ndoubles` doubles. */
 int artis_amd_estimators_devptr(artis_amd_engine *eng, void **dptr, int64_t *ndoubles);
+
+/* The estimator reduction at the end of a timestep in the host layer: ONE in-place RCCL all-reduce (sum, f64) of the
+ * whole estimator block over the ranks' GPUs, enqueued on hip_stream. Replaces radfield::reduce_estimators()
+ * (radfield.cc:988) and the MPI_Allreduce calls on the heating / photoionisation estimators in the timestep loop
+ * (sn3d.cc:565-590). nccl_comm is the caller's ncclComm_t, or NULL to use the communicator made by
+ * artis_amd_comm_init(). RCCL is bound at run time (the librccl already in the process, else ROCm's). */
+#define ARTIS_AMD_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+int artis_amd_allreduce_estimators(artis_amd_engine *eng, void *nccl_comm, void *hip_stream);
+/* Communicator set-up for hosts that do not hold an ncclComm_t yet: rank 0 draws an id (ncclGetUniqueId) and hands its
+ * 128 bytes to the other ranks by whatever the host already has (MPI_Bcast in the reference, globals::my_rank /
+ * nprocs); every rank then calls artis_amd_comm_init (ncclCommInitRank on the engine's device; collective). The
+ * engine owns the communicator and destroys it with itself. */
+int artis_amd_comm_unique_id(void *id_out /* ARTIS_AMD_COMM_ID_BYTES */);
+int artis_amd_comm_init(artis_amd_engine *eng, int nranks, int rank, const void *id_bytes);
 
 /* Timing of the dominant kernel inside the last artis_amd_update_packets_device
  * call, measured with HIP events on the launch stream. */

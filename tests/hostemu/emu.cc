@@ -44,7 +44,7 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   }
   const DevModel &M = e.env.M;
   const int64_t ncell = M.npts_nonempty;
-#define ALLOC(f, T, per) { e.cachebuf.emplace_back((size_t)(ncell * (int64_t)(per) + 1) * sizeof(T)); e.env.K.f = (T *)e.cachebuf.back().data(); }
+#define ALLOC(f, T, per) { e.cachebuf.emplace_back((size_t)(ncell * (int64_t)(per) + MAREC_SLACK) * sizeof(T)); e.env.K.f = (T *)e.cachebuf.back().data(); }
   ARTIS_CACHE_ARRAYS(ALLOC, M)
 #undef ALLOC
   e.stats.assign(ARTIS_NSTATS, 0);
