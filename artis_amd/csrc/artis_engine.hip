@@ -273,26 +273,42 @@ __global__ void __launch_bounds__(BLOCK) k_sort_scatter(const int32_t *list, con
 }
 
 // ------------------------------------------------------------------ the propagation kernels
-// Both are PERSISTENT, work-pulling kernels: a lane that has finished with its packet (budget used up, packet handed
+// They are PERSISTENT, work-pulling kernels: a lane that has finished with its packet (budget used up, packet handed
 // to another list, escaped, end of timestep) immediately takes the next packet of the work list instead of idling
-// until the slowest lane of its wave is done. The list is sorted by cell and cut into 8 chunks with one cursor each;
-// a block starts on chunk blockIdx % 8 (blocks b and b+8 share an XCD, so each XCD's L2 sees one contiguous range of
-// cells) and moves on to the other chunks when its own is exhausted. Placement only affects speed.
+// until the slowest lane of its wave is done. The list is sorted by cell and cut into `nchunks` contiguous chunks with
+// one cursor each -- one chunk per WAVE when the list is long enough: a wave then walks its own run of cells, so at any
+// time its lanes sit in one or two cells and read the same cell-cache lines. The chunks of the waves of one XCD are
+// adjacent (blocks b and b+8 share an XCD, so each XCD's L2 sees one contiguous range of cells). A wave whose chunk is
+// used up steals from the other chunks, its own XCD's first. Placement only affects speed, never results.
 #ifndef ARTIS_RPKT_WAVES
 #define ARTIS_RPKT_WAVES 2
 #endif
 #ifndef ARTIS_THERMAL_WAVES
 #define ARTIS_THERMAL_WAVES 4
 #endif
+constexpr int MAX_CHUNKS = 8192;  // >= 256 CUs x 4 waves/SIMD x 4 SIMDs, a multiple of 8
 
 struct Puller {
-  int chunk, tried;
+  int chunk;     // current chunk
+  int home, cx;  // first position of the search order: (XCD, local index); chunks per XCD
+  int nchunks;
   bool exhausted;
 };
-__device__ inline void puller_init(Puller &q) {
-  q.chunk = blockIdx.x & 7;
-  q.tried = 0;
+__device__ inline void puller_init(Puller &q, int nchunks) {
+  const int xcd = blockIdx.x & 7;
+  const int local = (int)(blockIdx.x >> 3) * (BLOCK / 64) + (int)(threadIdx.x >> 6);  // wave index within its XCD
+  q.nchunks = nchunks;
+  q.cx = nchunks >> 3;
+  q.home = xcd * q.cx + (local % q.cx);
+  q.chunk = q.home;
   q.exhausted = false;
+}
+__device__ inline int64_t chunk_begin(int32_t n, int c, int nchunks) { return ((int64_t)n * c) / nchunks; }
+// position v of a wave's search order -> chunk: its own XCD's chunks first (from its home chunk, wrapping), then the rest
+__device__ inline int chunk_at(const Puller &q, int v) {
+  const int x0 = (q.home / q.cx) * q.cx;
+  if (v < q.cx) return x0 + ((q.home - x0 + v) % q.cx);
+  return (x0 + v) % q.nchunks;
 }
 // Hands list indices to the lanes with need==true. Returns the index for this lane or -1. Wave-uniform control flow.
 __device__ inline int32_t pull(Puller &q, bool need, int32_t n, int32_t *cursors) {
@@ -304,31 +320,53 @@ __device__ inline int32_t pull(Puller &q, bool need, int32_t n, int32_t *cursors
   const int cnt = __popcll(mask);
   const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
   const int leader = __ffsll((long long)mask) - 1;
-  const int64_t cbeg = ((int64_t)n * q.chunk) >> 3;
-  const int64_t cend = ((int64_t)n * (q.chunk + 1)) >> 3;
+  const int64_t cbeg = chunk_begin(n, q.chunk, q.nchunks);
+  const int64_t cend = chunk_begin(n, q.chunk + 1, q.nchunks);
   int base = 0;
   if (lane == leader) base = atomicAdd(&cursors[q.chunk], cnt);
   base = __shfl(base, leader);
   const int64_t mine = cbeg + base + prefix;
   if (need && mine < cend) idx = (int32_t)mine;
-  if (cbeg + base + cnt > cend) {  // this chunk is used up: continue on the next one (the unserved lanes ask again)
-    q.chunk = (q.chunk + 1) & 7;
-    q.tried++;
-    if (q.tried >= 8) q.exhausted = true;
+  if (cbeg + base + cnt > cend) {
+    // this chunk is used up: look for one that still has entries, 64 candidates at a time (the unserved lanes ask again).
+    // A cursor only grows, so a stale read can only make a chunk look fuller than it is: the next pull finds out.
+    bool found = false;
+    for (int v0 = 1; v0 < q.nchunks && !found; v0 += 64) {
+      const int v = v0 + lane;
+      bool has = false;
+      int c = 0;
+      if (v < q.nchunks) {
+        c = chunk_at(q, v);
+        const int32_t used = __hip_atomic_load(&cursors[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        has = chunk_begin(n, c, q.nchunks) + used < chunk_begin(n, c + 1, q.nchunks);
+      }
+      const unsigned long long hm = __ballot(has);
+      if (hm != 0) {
+        q.chunk = __shfl(c, __ffsll((long long)hm) - 1);
+        found = true;
+      }
+    }
+    if (!found) q.exhausted = true;
   }
   return idx;
+}
+// chunks for a list of n entries consumed by `nwaves` waves: one per wave, fewer when the list is short
+inline int chunks_for(int64_t n, int nwaves) {
+  int64_t c = std::min<int64_t>(nwaves, n / 128);
+  c = std::max<int64_t>(8, (c / 8) * 8);
+  return (int)std::min<int64_t>(c, MAX_CHUNKS);
 }
 
 // r-packets in flight: boundary distance, continuum opacity, line-by-line Sobolev walk, estimators, events
 __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                   unsigned long long *gstats, int budget, int32_t *cursors) {
+                                                                   unsigned long long *gstats, int budget, int32_t *cursors, int nchunks) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   __syncthreads();
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
   Puller q;
-  puller_init(q);
+  puller_init(q, nchunks);
   bool have = false;
   int32_t pi = 0;
   int steps = 0;
@@ -395,14 +433,14 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
 #define ARTIS_GAMMA_WAVES 2
 #endif
 __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                     unsigned long long *gstats, int budget, int32_t *cursors) {
+                                                                     unsigned long long *gstats, int budget, int32_t *cursors, int nchunks) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   __syncthreads();
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
   Puller q;
-  puller_init(q);
+  puller_init(q, nchunks);
   bool have = false;
   int32_t pi = 0;
   int steps = 0;
@@ -449,14 +487,14 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
 // k-packet step, per iteration; lanes take a new packet between iterations.
 __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                                unsigned long long *gstats, int budget,
-                                                                               int32_t *cursors) {
+                                                                               int32_t *cursors, int nchunks) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   __syncthreads();
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
   Puller q;
-  puller_init(q);
+  puller_init(q, nchunks);
   bool have = false;
   int32_t pi = 0;
   int units = 0;
@@ -639,7 +677,7 @@ struct artis_amd_engine {
   int32_t *d_hist = nullptr;                  // [ngrid * SORT_NUBINS + 1]
   int32_t *d_tiles = nullptr;                 // scan tile totals
   int32_t *d_count = nullptr;                 // [NEXT_NKINDS] current-list counts, [NEXT_NKINDS] alternate-list count
-  int32_t *d_cursors = nullptr;               // [8] chunk cursors of the running pull kernel
+  int32_t *d_cursors = nullptr;               // [MAX_CHUNKS] chunk cursors of the running pull kernel
   int ncu = 256;
   double *d_gamma_ws = nullptr;   // per-packet groundcont_gamma_contr lists (physics.h Env)
   int32_t *d_gamma_gi = nullptr;
@@ -656,6 +694,11 @@ struct artis_amd_engine {
   bool sort_lists = true;
   bool sort_nu = true;
   bool sort_ma = true;
+  // one list chunk per wave instead of one per XCD (artis_engine.hip pull): measured on MI355X, 1e7 packets: k_rpkt -4 %
+  // (a wave's lanes share continuum windows and line ranges), k_thermal +30 % (every wave then has its own cells in
+  // flight and the L2 working set of macro-atom records triples)
+  bool wave_chunks_r = true, wave_chunks_t = false;
+  int thermal_blocks_per_cu = ARTIS_THERMAL_WAVES;  // tuning: resident k_thermal blocks per CU
   bool trace = false;
   ncclComm_t comm = nullptr;  // created by artis_amd_comm_init(), owned by the engine
 };
@@ -921,7 +964,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
   HIP_TRY(hipMemset(e->d_err, 0, sizeof(int32_t)));
   HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 2 * NEXT_NKINDS));
-  HIP_TRY(hipMalloc((void **)&e->d_cursors, sizeof(int32_t) * 8));
+  HIP_TRY(hipMalloc((void **)&e->d_cursors, sizeof(int32_t) * MAX_CHUNKS));
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -943,6 +986,9 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_R")) e->wave_chunks_r = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_T")) e->wave_chunks_t = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_THERMAL_BLOCKS")) e->thermal_blocks_per_cu = std::max(1, std::min(ARTIS_THERMAL_WAVES, std::atoi(b)));
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
   return ARTIS_OK;
 }
@@ -1194,17 +1240,20 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       // the kernel starts with an empty current list of its own kind: everything it keeps goes to the alternate list
       HIP_TRY(hipMemsetAsync(e->d_count + kind, 0, sizeof(int32_t), s));
       HIP_TRY(hipMemsetAsync(e->d_count + NEXT_NKINDS, 0, sizeof(int32_t), s));
-      HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * 8, s));
+      HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * MAX_CHUNKS, s));
       HIP_TRY(hipEventRecord(e->ev0, s));
       if (kind == NEXT_RPKT) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
-        hipLaunchKernelGGL(k_rpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors);
+        hipLaunchKernelGGL(k_rpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors,
+                           e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
       } else if (kind == NEXT_GAMMA) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_GAMMA_WAVES);
-        hipLaunchKernelGGL(k_gamma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r * 8, e->d_cursors);
+        hipLaunchKernelGGL(k_gamma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r * 8, e->d_cursors,
+                           e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
       } else if (kind == NEXT_MA) {
-        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_THERMAL_WAVES);
-        hipLaunchKernelGGL(k_thermal, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors);
+        const int grid = std::min(nblocks(nk), e->ncu * e->thermal_blocks_per_cu);
+        hipLaunchKernelGGL(k_thermal, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors,
+                           e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
       } else if (kind == NEXT_BB) {
         hipLaunchKernelGGL(k_blackbody, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);
       } else {
