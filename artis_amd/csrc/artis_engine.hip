@@ -87,6 +87,55 @@ __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   if (i >= total) return;
   populate_macroatom(env, (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
+// hot levels of every cell (physics.h populate_hotselect: the same rule, the levels spread over the lanes of one wave)
+__global__ void __launch_bounds__(BLOCK) k_hotselect(Env env) {
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= env.M.npts_nonempty) return;
+  const int c = (int)wave;
+  const int nl = env.M.nlevels;
+  const int per = (nl + 63) / 64;
+  const int l0 = lane * per < nl ? lane * per : nl;
+  const int l1 = l0 + per < nl ? l0 + per : nl;
+  auto fits = [&](uint32_t t) {
+    int u = hot_units_at(env, c, l0, l1, t);
+    for (int o = 32; o > 0; o >>= 1) u += __shfl_xor(u, o);
+    return u <= HOT_UNITS;
+  };
+  uint32_t lo = 1u, hi = 0xFFFFFFFFu;
+  if (fits(lo)) {
+    hi = lo;
+  } else {
+    while (hi - lo > 1u) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (fits(mid)) hi = mid; else lo = mid;
+    }
+  }
+  // places: exclusive prefix sum of the selected levels' sizes in level order
+  const int mine = hot_units_at(env, c, l0, l1, hi);
+  int incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  int u = incl - mine;
+  const float *hn = env.K.hotness + ((int64_t)c * nl);
+  int16_t *off = env.K.hotoff + ((int64_t)c * nl);
+  for (int l = l0; l < l1; l++) {
+    if (hot_key(hn[l]) >= hi) {
+      off[l] = (int16_t)u;
+      u += marec_units(env.M.level_pack[l]);
+    } else {
+      off[l] = -1;
+    }
+  }
+}
+__global__ void __launch_bounds__(BLOCK) k_hotfill(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nlevels;
+  if (i >= total) return;
+  populate_hotfill(env, (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
+}
 __global__ void __launch_bounds__(BLOCK) k_cooling_ion(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nions;
@@ -294,9 +343,10 @@ struct Puller {
   int nchunks;
   bool exhausted;
 };
-__device__ inline void puller_init(Puller &q, int nchunks) {
+__device__ inline void puller_init(Puller &q, int nchunks, bool per_block = false) {
   const int xcd = blockIdx.x & 7;
-  const int local = (int)(blockIdx.x >> 3) * (BLOCK / 64) + (int)(threadIdx.x >> 6);  // wave index within its XCD
+  // wave (or workgroup) index within its XCD
+  const int local = per_block ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
   q.nchunks = nchunks;
   q.cx = nchunks >> 3;
   q.home = xcd * q.cx + (local % q.cx);
@@ -480,24 +530,109 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
 
 // Thermal packets (k-packets and walking macro-atoms) are advanced by ONE persistent kernel, so that the k-packet ->
 // macro-atom -> k-packet cycle (tens of times per packet and timestep, kpkt.cc:51) needs no kernel boundary.
+//
+// LDS staging of the macro-atom tables. The kernel is bound by the rate at which a CU's vector L1 takes the scattered
+// record reads of the walk (rocprof: ~0.6 tag look-ups per cycle and CU; 3 and 4 waves/SIMD run at the same speed). The
+// work list is sorted by cell and a workgroup pulls one contiguous run of it, so its lanes sit in a handful of cells at
+// any time. For each of those cells the workgroup keeps the cell's HOT BLOCK (tables.h: bit-identical copies of the
+// records of its hottest levels, ~90 % of all transitions) in one of ARTIS_HOT_SLOTS slots of LDS: the first wave that
+// pulls a packet of a new cell claims a free slot and copies the block in (12 KB, coalesced); a slot is free again when
+// the last packet of its cell has retired. A transition reads its record through a generic pointer -- the LDS copy when
+// the level is hot and the slot is ready, the block in HBM or the cell's full row otherwise -- so hot and cold lanes of
+// a wave share one instruction stream and only the cold ones go through L1/L2.
 #ifndef ARTIS_THERMAL_WAVES
 #define ARTIS_THERMAL_WAVES 4
 #endif
+#ifndef ARTIS_THERMAL_BLOCK
+#define ARTIS_THERMAL_BLOCK 512
+#endif
+#ifndef ARTIS_HOT_SLOTS
+#define ARTIS_HOT_SLOTS 18
+#endif
+constexpr int TBLOCK = ARTIS_THERMAL_BLOCK;
+constexpr int NSLOT = ARTIS_HOT_SLOTS;
+static_assert((size_t)NSLOT * HOT_DOUBLES * 8 * (1024 * ARTIS_THERMAL_WAVES / 4 / TBLOCK) <= 156 * 1024, "hot slots exceed the CU's LDS");
+struct HotSlots {
+  int cell[NSLOT];   // non-empty cell whose hot block the slot holds (-1: never used)
+  int ref[NSLOT];    // packets of that cell held by lanes of this workgroup that were given the slot
+  int ready[NSLOT];  // the copy is complete
+  int lock;
+};
+// The lanes with isnew==true have just pulled a packet of non-empty cell c (thermal packets never change cell): give
+// each of them the slot of its cell, claiming and filling a free one for a cell that has none. Returns the slot or -1
+// (every slot is held by a cell with packets in flight: those lanes read the block in HBM). Wave-uniform control flow.
+__device__ inline int hot_acquire(HotSlots &hs, double *hot_lds, const Env &env, bool isnew, int c) {
+  volatile int *vcell = hs.cell, *vref = hs.ref, *vready = hs.ready;
+  const int lane = threadIdx.x & 63;
+  int myslot = -1;
+  unsigned long long todo = __ballot(isnew && c >= 0);
+  while (todo != 0) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int cc = __shfl(c, leader);
+    const unsigned long long same = __ballot(isnew && c == cc) & todo;
+    const int nn = __popcll(same);
+    int s = -1, stage = 0;
+    if (lane == leader) {
+      while (atomicCAS(&hs.lock, 0, 1) != 0) {}
+      for (int i = 0; i < NSLOT; i++)
+        if (vcell[i] == cc) s = i;
+      if (s < 0) {
+        for (int i = 0; i < NSLOT && s < 0; i++)
+          if (vref[i] == 0) s = i;
+        if (s >= 0) {
+          vcell[s] = cc;
+          vready[s] = 0;
+          stage = 1;
+        }
+      }
+      if (s >= 0) vref[s] = vref[s] + nn;
+      __threadfence_block();
+      atomicExch(&hs.lock, 0);
+    }
+    s = __shfl(s, leader);
+    stage = __shfl(stage, leader);
+    if (stage) {  // this wave copies the cell's hot block into the slot: 16 bytes per lane and round
+      const D2 *src = (const D2 *)(env.K.hotblk + ((int64_t)cc * HOT_DOUBLES));
+      D2 *dst = (D2 *)(hot_lds + (s * HOT_DOUBLES));
+      for (int i = lane; i < HOT_DOUBLES / 2; i += 64) dst[i] = src[i];
+      __threadfence_block();
+      if (lane == leader) vready[s] = 1;
+    }
+    if ((same >> lane) & 1ull) myslot = s;
+    todo &= ~same;
+  }
+  return myslot;
+}
 // Fused thermal kernel, phase form (physics.h thermal_iter): up to ARTIS_MA_PHASE macro-atom transitions, then one
-// k-packet step, per iteration; lanes take a new packet between iterations.
-__global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                               unsigned long long *gstats, int budget,
-                                                                               int32_t *cursors, int nchunks) {
+// k-packet step, per iteration; lanes take a new packet between iterations. USE_LDS: with the hot-block slots above
+// (workgroups of TBLOCK threads, one list chunk per workgroup); otherwise workgroups of BLOCK threads on the XCD chunks,
+// every record read from HBM (a hot level from the cell's compact hot block there).
+template <bool USE_LDS, int TB>
+__global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
+                                                                     unsigned long long *gstats, int budget, int32_t *cursors,
+                                                                     int nchunks) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
+  __shared__ HotSlots hs;
+  __shared__ double __attribute__((aligned(16))) hot_lds[USE_LDS ? NSLOT * HOT_DOUBLES : 2];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  if (USE_LDS) {
+    if (threadIdx.x < NSLOT) {
+      hs.cell[threadIdx.x] = -1;
+      hs.ref[threadIdx.x] = 0;
+      hs.ready[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) hs.lock = 0;
+  }
   __syncthreads();
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
   Puller q;
-  puller_init(q, nchunks);
+  puller_init(q, nchunks, /*per_block=*/USE_LDS);
   bool have = false;
   int32_t pi = 0;
   int units = 0;
+  int myslot = -1;       // LDS slot of this lane's cell
+  bool slot_ok = false;  // ... and its copy is complete
   Pkt p;
   MACtx k;
 #ifdef ARTIS_PROFILE
@@ -515,6 +650,13 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
       k = ma_ctx(env, p);
       units = 0;
       have = true;
+    }
+    if (USE_LDS) {
+      const int s = hot_acquire(hs, hot_lds, env, idx >= 0, k.c);
+      if (idx >= 0) {
+        myslot = s;
+        slot_ok = false;
+      }
     }
     if (!__any(have)) {
       if (q.exhausted) break;
@@ -535,16 +677,27 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
       int j = 0;
       int exit_action = -1;
       double exit_rate = 0.;
-      if (ma_pending(p) && p.pend == PEND_NONE) ma_prepare(env, p, k);  // the record of the current level; the walk carries it on
+      const double *rec = nullptr;
+      if (ma_pending(p) && p.pend == PEND_NONE) {
+        ma_prepare(env, p, k);  // the record of the current level; the walk carries it on
+        if (USE_LDS) {
+          if (myslot >= 0 && !slot_ok) slot_ok = ((volatile int *)hs.ready)[myslot] != 0;
+          if (slot_ok) k.hotbase = hot_lds + (myslot * HOT_DOUBLES);  // generic pointer into LDS
+        }
+      }
       while (j < ARTIS_MA_PHASE && exit_action < 0 && ma_pending(p) && p.pend == PEND_NONE) {
 #ifdef ARTIS_PROFILE
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 46);
+        if (k.hot >= 0 && slot_ok) ARTIS_STAT(env, 56);  // transitions read from LDS
+        if (k.hot >= 0) ARTIS_STAT(env, 57);             // transitions from a hot level
+        if (myslot >= 0) ARTIS_STAT(env, 58);            // transitions of a packet whose cell has a slot
 #endif
-        exit_action = ma_jump_internal(env, p, k, &exit_rate);
+        rec = ma_record(k);
+        exit_action = ma_jump_internal(env, p, k, rec, &exit_rate);
         j++;
       }
       ma_flush_stats(env, k);
-      if (exit_action >= 0) ma_jump_exit(env, p, pi, k, exit_action, exit_rate);
+      if (exit_action >= 0) ma_jump_exit(env, p, pi, k, rec, exit_action, exit_rate);
       if (j > 0) chi_after_ma(p);
       units += j;
     }
@@ -574,6 +727,11 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal(Env env,
       kind = classify(env, p, ts_end);
       out_pi = pi;
       have = false;
+      if (USE_LDS) {
+        if (myslot >= 0) atomicSub(&hs.ref[myslot], 1);  // the slot is free again when its cell's last packet has retired
+        myslot = -1;
+        slot_ok = false;
+      }
     }
     append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
     pkt_clear_flight(p);  // a thermal packet never reads them: no live range across iterations
@@ -698,6 +856,10 @@ struct artis_amd_engine {
   // (a wave's lanes share continuum windows and line ranges), k_thermal +30 % (every wave then has its own cells in
   // flight and the L2 working set of macro-atom records triples)
   bool wave_chunks_r = true, wave_chunks_t = false;
+  // ARTIS_AMD_HOTLDS=1: the cells' hot blocks of macro-atom records are staged in LDS (k_thermal<true>). Parity-tested;
+  // measured slower than reading them from HBM on MI355X (profiles/r02/lds_staging.md), so it is off by default.
+  bool hot_lds = false;
+  bool hot_blocks = true;  // ARTIS_AMD_HOTBLOCKS=0: no per-cell hot blocks at all (A/B)
   int thermal_blocks_per_cu = ARTIS_THERMAL_WAVES;  // tuning: resident k_thermal blocks per CU
   bool trace = false;
   ncclComm_t comm = nullptr;  // created by artis_amd_comm_init(), owned by the engine
@@ -988,6 +1150,8 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_R")) e->wave_chunks_r = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_T")) e->wave_chunks_t = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_HOTLDS")) e->hot_lds = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_HOTBLOCKS")) e->hot_blocks = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_THERMAL_BLOCKS")) e->thermal_blocks_per_cu = std::max(1, std::min(ARTIS_THERMAL_WAVES, std::atoi(b)));
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
   return ARTIS_OK;
@@ -1057,6 +1221,12 @@ int artis_amd_populate_cellcache(artis_amd_engine *e, void *hip_stream) {
   if (h.nphixstargets_total > 0)
     hipLaunchKernelGGL(k_corrphotoion, dim3(nblocks(ncell * h.nphixstargets_total)), dim3(BLOCK), 0, s, env, e->d_target_level);
   hipLaunchKernelGGL(k_macroatom, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
+  if (e->hot_blocks) {
+    hipLaunchKernelGGL(k_hotselect, dim3(nblocks(ncell * 64)), dim3(BLOCK), 0, s, env);
+  } else {  // no hot blocks: every record is read from its cell's full row
+    HIP_TRY(hipMemsetAsync(e->K.hotoff, 0xFF, sizeof(int16_t) * (size_t)(ncell * h.nlevels), s));
+  }
+  hipLaunchKernelGGL(k_hotfill, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_ion, dim3(nblocks(ncell * h.nions)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_prefix, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
   HIP_TRY(hipGetLastError());
@@ -1251,9 +1421,17 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
         hipLaunchKernelGGL(k_gamma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r * 8, e->d_cursors,
                            e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
       } else if (kind == NEXT_MA) {
-        const int grid = std::min(nblocks(nk), e->ncu * e->thermal_blocks_per_cu);
-        hipLaunchKernelGGL(k_thermal, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t, e->d_cursors,
-                           e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
+        // persistent: every workgroup resident (ARTIS_THERMAL_WAVES waves per SIMD)
+        if (e->hot_lds) {  // hot blocks staged in LDS: one list chunk per workgroup
+          const int per_cu = std::max(1, e->thermal_blocks_per_cu * BLOCK / TBLOCK);
+          const int grid = std::min((int)((nk + TBLOCK - 1) / TBLOCK), e->ncu * per_cu);
+          hipLaunchKernelGGL((k_thermal<true, TBLOCK>), dim3(grid), dim3(TBLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
+                             e->d_cursors, chunks_for(nk, grid));
+        } else {
+          const int grid = std::min(nblocks(nk), e->ncu * e->thermal_blocks_per_cu);
+          hipLaunchKernelGGL((k_thermal<false, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
+                             e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
+        }
       } else if (kind == NEXT_BB) {
         hipLaunchKernelGGL(k_blackbody, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);
       } else {

@@ -101,6 +101,9 @@ struct ModelOwned {
 #define ARTIS_CACHE_ARRAYS(X, m)                                \
   X(levelpops, double, (m).nlevels)                             \
   X(macache, double, (m).nmacache)                              \
+  X(hotblk, double, HOT_DOUBLES)                                \
+  X(hotness, float, (m).nlevels)                                \
+  X(hotoff, int16_t, (m).nlevels)                               \
   X(allcont_nnlevel, double, (m).nbfcontinua)                   \
   X(allcont_departure, double, (m).nbfcontinua)                 \
   X(allcont_edgepart, double, (m).nbfcontinua)                  \

@@ -834,15 +834,7 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   double *blk_down = rec + marec_down;                        // cumulative internal-down-same
   double *blk_up = rec + marec_up(lpk.ndown);                 // cumulative internal-up-same
   double *blk_rad = rec + marec_rad(lpk.ndown, lpk.nup);      // cumulative radiative de-excitation
-  {  // the static part of the record: header and transition targets (tables.h)
-    *(MaHeader *)rec = MaHeader{lpk.ndown, lpk.nup, ul, lpk.alltrans_startdown};
-    MaTarget *tgt = (MaTarget *)(rec + marec_tgt(lpk.ndown, lpk.nup));
-    const int ntrans = lpk.ndown + lpk.nup;
-    for (int i = 0; i < ntrans; i++) {
-      const int tl = M.alltrans_targetlevelindex[lpk.alltrans_startdown + i];
-      tgt[i] = MaTarget{M.level_pack[start + tl].rec_off, tl};
-    }
-  }
+  // (the record's header and transition targets are written by populate_hotfill(), once the cell's hot levels are known)
   const double t_mid = env.S.mid;
   const float T_e = env.C.Te[c];
   const float cnne = clumpednne(env.C, c);
@@ -921,6 +913,75 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   }
   rates[ARTIS_MA_ACTION_INTERNALUPHIGHERNT] = 0.;
   rates[ARTIS_MA_ACTION_INTERNALUPHIGHER] = s_up_higher;
+  // flow through the level ~ population x total rate: the hotness that ranks the levels of a cell for its hot block
+  // (tables.h). A heuristic: it decides only where the thermal kernel reads a record from.
+  double total = 0.;
+  for (int a = 0; a < MA_N; a++) total += rates[a];
+  const float h = (float)(nnlevel * total);
+  env.K.hotness[((int64_t)c * M.nlevels) + ul] = (h > 0.f && h <= 3.0e38f) ? h : 0.f;
+}
+// ---- hot block of a cell (tables.h): which levels, where, and the copies
+AHD int marec_units(const LevelPack &lp) { return (marec_size(lp.ndown, lp.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN; }
+constexpr int HOT_UNITS = HOT_DOUBLES / MAREC_ALIGN;
+AHD uint32_t hot_key(float h) {  // positive floats order like their bit patterns
+  union { float f; uint32_t u; } v;
+  v.f = h;
+  return (h > 0.f) ? v.u : 0u;
+}
+// units taken by the levels [l0, l1) of cell c whose key is >= t
+AHD int hot_units_at(const Env &env, int c, int l0, int l1, uint32_t t) {
+  const float *hn = env.K.hotness + ((int64_t)c * env.M.nlevels);
+  int u = 0;
+  for (int l = l0; l < l1; l++)
+    if (hot_key(hn[l]) >= t) u += marec_units(env.M.level_pack[l]);
+  return u;
+}
+// Selection rule: the hot levels of a cell are those with key >= T, T the smallest threshold whose levels fit in
+// HOT_UNITS (bisection on the 32-bit key). The sequential form; the GPU kernel (artis_engine.hip k_hotselect) runs the
+// same rule with the levels spread over the lanes of a wave.
+AHD void populate_hotselect(const Env &env, int c) {
+  const DevModel &M = env.M;
+  uint32_t lo = 1u, hi = 0xFFFFFFFFu;  // invariant: units(hi) fit; units(lo - 1) do not, or lo == 1
+  if (hot_units_at(env, c, 0, M.nlevels, lo) <= HOT_UNITS) {
+    hi = lo;
+  } else {
+    while (hi - lo > 1u) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (hot_units_at(env, c, 0, M.nlevels, mid) <= HOT_UNITS) hi = mid; else lo = mid;
+    }
+  }
+  const float *hn = env.K.hotness + ((int64_t)c * M.nlevels);
+  int16_t *off = env.K.hotoff + ((int64_t)c * M.nlevels);
+  int u = 0;
+  for (int l = 0; l < M.nlevels; l++) {
+    if (hot_key(hn[l]) >= hi) {
+      off[l] = (int16_t)u;
+      u += marec_units(M.level_pack[l]);
+    } else {
+      off[l] = -1;
+    }
+  }
+}
+// one (cell, level): the static part of the level's record -- header and transition targets, each with the place of
+// the level it leads to in the cell's hot block -- and, for a hot level, the copy of the whole record
+AHD void populate_hotfill(const Env &env, int c, int ul) {
+  const DevModel &M = env.M;
+  const LevelPack lpk = M.level_pack[ul];
+  const int start = M.ion_uniquelevelindexstart[M.level_ion[ul]];
+  const int16_t *off = env.K.hotoff + ((int64_t)c * M.nlevels);
+  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
+  *(MaHeader *)rec = MaHeader{(int16_t)lpk.ndown, (int16_t)lpk.nup, ul, lpk.alltrans_startdown, off[ul], 0};
+  MaTarget *tgt = (MaTarget *)(rec + marec_tgt(lpk.ndown, lpk.nup));
+  const int ntrans = lpk.ndown + lpk.nup;
+  for (int i = 0; i < ntrans; i++) {
+    const int tl = M.alltrans_targetlevelindex[lpk.alltrans_startdown + i];
+    tgt[i] = MaTarget{M.level_pack[start + tl].rec_off, (uint16_t)tl, off[start + tl]};
+  }
+  if (off[ul] >= 0) {
+    double *dst = env.K.hotblk + ((int64_t)c * HOT_DOUBLES) + ((int)off[ul] * MAREC_ALIGN);
+    const int n = marec_units(lpk) * MAREC_ALIGN;
+    for (int i = 0; i < n; i++) dst[i] = rec[i];
+  }
 }
 // one (cell, ion): calculate_cooling_rates_ion<true> kpkt.cc:57; stores the ion total for the prefix sum of kpkt.cc:281
 AHD void populate_cooling_ion(const Env &env, int c, int ui) {
@@ -1630,6 +1691,8 @@ struct MACtx {
   const double *cellma;     // the cell's row of macro-atom records
   int start_key, start;     // cached get_ionuniquelevelindexstart(element, ion)
   int rec;                  // offset of the current level's record in the cell's row (ma_prepare, then carried by the walk)
+  int hot;                  // ... and its place in the cell's hot block (units of MAREC_ALIGN doubles), or -1
+  const double *hotbase;    // where the cell's hot block is read from: its LDS copy (k_thermal) or the block in HBM
   MaHeader hd;              // header of the record the last transition was drawn from
   int njumps;               // transitions made since the last ma_flush_stats()
 };
@@ -1638,10 +1701,12 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   k.c = env.M.propcell_nonemptymgi[p.cellindex];
   k.thick = (k.c >= 0) && (env.C.thick[k.c] == ARTIS_CELL_THICK);
   k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
+  k.hotbase = env.K.hotblk + ((int64_t)k.c * HOT_DOUBLES);  // in HBM; k_thermal points it at its LDS copy
   k.start_key = -1;
   k.start = 0;
   k.rec = 0;
-  k.hd = MaHeader{0, 0, 0, 0};
+  k.hot = -1;
+  k.hd = MaHeader{0, 0, 0, 0, -1, 0};
   k.njumps = 0;
   return k;
 }
@@ -1676,14 +1741,21 @@ AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
   }
   return k.start + p.ma_level;
 }
-AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) { k.rec = env.M.level_pack[ma_locate(env, p, k)].rec_off; }
+AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) {
+  const int ul = ma_locate(env, p, k);
+  k.rec = env.M.level_pack[ul].rec_off;
+  k.hot = env.K.hotoff[((int64_t)k.c * env.M.nlevels) + ul];
+}
+// the current level's record: its copy in the hot block when there is one and the block is readable, else the cell's row
+AHD const double *ma_record(const MACtx &k) {
+  return (k.hot >= 0 && k.hotbase != nullptr) ? k.hotbase + (k.hot * MAREC_ALIGN) : k.cellma + k.rec;
+}
 // First half of a transition: draw the process (macroatom.cc:425-431); an internal transition inside the ion is made
 // at once and -1 is returned. Every other process ends the walk in this kernel (deactivation, or a bound-free process
 // for the slow path): its index is returned with its rate, and ma_jump_exit() carries it out. The split lets a kernel
 // keep the rare, long deactivation code out of its transition loop.
 constexpr int MA_EXIT_FAILED = 99;
-AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, double *rate_out) {
-  const double *rec = k.cellma + k.rec;
+AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, double *rate_out) {
   const MaHeader hd = *(const MaHeader *)rec;
   k.hd = hd;
   // std::partial_sum macroatom.cc:425 and index_upperbound sn3d.h:85 over the 9 cumulative rates, kept in
@@ -1726,16 +1798,16 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, double *rate_out) {
     const MaTarget tg = ((const MaTarget *)(rec + marec_tgt(ndown, hd.nup)))[first + ti];
     p.ma_level = tg.level;
     k.rec = tg.rec_off;
+    k.hot = tg.hot;
     return -1;
   }
   *rate_out = rate_sel;
   return action;
 }
-AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, int action, double rate_sel) {
+AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double *rec, int action, double rate_sel) {
   const DevModel &M = env.M;
   const int c = k.c;
   const MaHeader hd = k.hd;  // of the record the action was drawn from: the packet's current level
-  const double *rec = k.cellma + k.rec;
   const int activatingline = p.ma_line;
   if (action == ARTIS_MA_ACTION_RADDEEXC) {
     // do_macroatom_raddeexcitation macroatom.cc:204
@@ -1781,9 +1853,10 @@ AHD void ma_flush_stats(const Env &env, MACtx &k) {
 }
 AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
   ma_prepare(env, p, k);
+  const double *rec = ma_record(k);
   double rate_sel = 0.;
-  const int action = ma_jump_internal(env, p, k, &rate_sel);
-  if (action >= 0) ma_jump_exit(env, p, pi, k, action, rate_sel);
+  const int action = ma_jump_internal(env, p, k, rec, &rate_sel);
+  if (action >= 0) ma_jump_exit(env, p, pi, k, rec, action, rate_sel);
   ma_flush_stats(env, k);
 }
 

@@ -49,7 +49,7 @@ struct alignas(32) ContPack {
 // (macroatom.cc:385-577) reads this record and nothing else -- no level table, no transition table -- so the chain of
 // dependent reads per transition is record -> cumulative sums -> target, all inside a few adjacent cache lines.
 // In doubles:
-//   [0..1]                 MaHeader (16 B): ndown, nup, unique level index, alltrans_startdown
+//   [0..1]                 MaHeader (16 B): ndown, nup, unique level index, alltrans_startdown, place in the hot block
 //   [2..10]                the 9 process rates              (alllevels_maprocessrates, globals.h:286)
 //   [marec_down ..)        cumulative internal-down-same    (allmacroatomictransitions block 2, macroatom.cc:44)
 //   [marec_up(ndown) ..)   cumulative internal-up-same      (block 3, macroatom.cc:51)
@@ -59,13 +59,27 @@ struct alignas(32) ContPack {
 //                          the sums that select it)
 // Every block starts 16-byte aligned (counts rounded up to even); a search may read up to 7 doubles past a block's end
 // (it never uses them), which stays inside the row (+ MAREC_SLACK at the end of the allocation).
+//
+// HOT BLOCK. A walk spends ~90 % of its transitions in a few dozen levels of its cell. At population time the records of
+// the cell's hottest levels (by level population x total rate, i.e. the flow through the level) are copied, bit for bit,
+// into a compact per-cell block of HOT_DOUBLES doubles, which the thermal kernel stages in LDS for the cells its
+// workgroup is working on. `hot` (header: of this level; target: of the target level) is the place of a level's copy in
+// that block in units of MAREC_ALIGN doubles, or -1. Which levels are hot only decides where a record is read from.
 struct alignas(16) MaHeader {
-  int32_t ndown, nup, ul, alltrans_startdown;
+  int16_t ndown, nup;
+  int32_t ul, alltrans_startdown;
+  int16_t hot, pad;
 };
 struct alignas(8) MaTarget {
   int32_t rec_off;  // offset (in doubles) of the target level's record in a cell's macache row
-  int32_t level;    // the target level's index within its ion (alltrans.targetlevelindex)
+  uint16_t level;   // the target level's index within its ion (alltrans.targetlevelindex)
+  int16_t hot;      // place of the target level's copy in the cell's hot block, or -1
 };
+static_assert(sizeof(MaHeader) == 16 && sizeof(MaTarget) == 8, "record header and target sizes");
+#ifndef ARTIS_HOT_DOUBLES
+#define ARTIS_HOT_DOUBLES 512  // 4 KB per cell
+#endif
+constexpr int HOT_DOUBLES = ARTIS_HOT_DOUBLES;
 constexpr int marec_even(int n) { return (n + 1) & ~1; }
 constexpr int marec_rates = 2;
 constexpr int marec_down = 12;
@@ -137,6 +151,9 @@ struct DevCells {
 struct DevCache {
   double *levelpops;             // [cell][nlevels]
   double *macache;               // [cell][nmacache]: one record per level, see LevelPack
+  double *hotblk;                // [cell][HOT_DOUBLES]: copies of the records of the cell's hottest levels (MaHeader::hot)
+  float *hotness;                // [cell][nlevels]: level population x total macro-atom rate (populate_macroatom)
+  int16_t *hotoff;               // [cell][nlevels]: place of each level's copy in the hot block, or -1
   double *allcont_nnlevel;       // [cell][nbfcontinua]
   double *allcont_departure;     // [cell][nbfcontinua]
   double *allcont_edgepart;      // [cell][nbfcontinua]

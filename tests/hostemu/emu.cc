@@ -73,6 +73,8 @@ void populate_all(Emu &e) {
     for (int ul = 0; ul < M.nlevels; ul++)
       for (int t = 0; t < M.level_nphixstargets[ul]; t++) populate_corrphotoion(e.env, c, ul, t);
     for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom(e.env, c, ul);
+    populate_hotselect(e.env, c);
+    for (int ul = 0; ul < M.nlevels; ul++) populate_hotfill(e.env, c, ul);
     for (int ui = 0; ui < M.nions; ui++) populate_cooling_ion(e.env, c, ui);
     populate_cooling_prefix(e.env, c);
   }
