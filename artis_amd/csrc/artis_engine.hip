@@ -81,6 +81,12 @@ __global__ void __launch_bounds__(BLOCK) k_corrphotoion(Env env, const int32_t *
   const int ul = target_level[k];
   populate_corrphotoion(env, c, ul, k - env.M.level_phixstargetstart[ul]);
 }
+__global__ void __launch_bounds__(BLOCK) k_matrans(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nalltrans;
+  if (i >= total) return;
+  populate_matrans(env, (int)(i / env.M.nalltrans), (int)(i % env.M.nalltrans));
+}
 __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nlevels;
@@ -859,7 +865,9 @@ struct artis_amd_engine {
   // ARTIS_AMD_HOTLDS=1: the cells' hot blocks of macro-atom records are staged in LDS (k_thermal<true>). Parity-tested;
   // measured slower than reading them from HBM on MI355X (profiles/r02/lds_staging.md), so it is off by default.
   bool hot_lds = false;
-  bool hot_blocks = true;  // ARTIS_AMD_HOTBLOCKS=0: no per-cell hot blocks at all (A/B)
+  // per-cell hot blocks (tables.h) are built when the LDS staging is on; ARTIS_AMD_HOTBLOCKS=1 builds and reads them in
+  // HBM without it (measured: k_thermal -3.5 %, populate +25 ms: no net gain)
+  bool hot_blocks = false;
   int thermal_blocks_per_cu = ARTIS_THERMAL_WAVES;  // tuning: resident k_thermal blocks per CU
   bool trace = false;
   ncclComm_t comm = nullptr;  // created by artis_amd_comm_init(), owned by the engine
@@ -1152,6 +1160,17 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_T")) e->wave_chunks_t = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_HOTLDS")) e->hot_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_HOTBLOCKS")) e->hot_blocks = std::atoi(b) != 0;
+  e->hot_blocks = e->hot_blocks || e->hot_lds;
+  {
+    // the static part of every macro-atom record (header, transition targets) is written once; without hot blocks no
+    // level has a place in one
+    const int64_t ncell_ = e->Mh.npts_nonempty;
+    HIP_TRY(hipMemset(e->K.hotoff, 0xFF, sizeof(int16_t) * (size_t)(ncell_ * e->Mh.nlevels)));
+    Env env0 = make_env(e);
+    hipLaunchKernelGGL(k_hotfill, dim3(nblocks(ncell_ * e->Mh.nlevels)), dim3(BLOCK), 0, nullptr, env0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+  }
   if (const char *b = std::getenv("ARTIS_AMD_THERMAL_BLOCKS")) e->thermal_blocks_per_cu = std::max(1, std::min(ARTIS_THERMAL_WAVES, std::atoi(b)));
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
   return ARTIS_OK;
@@ -1220,13 +1239,12 @@ int artis_amd_populate_cellcache(artis_amd_engine *e, void *hip_stream) {
   if (h.nbfcontinua > 0) hipLaunchKernelGGL(k_allcont, dim3(nblocks(ncell * h.nkeepwords * 64)), dim3(BLOCK), 0, s, env);
   if (h.nphixstargets_total > 0)
     hipLaunchKernelGGL(k_corrphotoion, dim3(nblocks(ncell * h.nphixstargets_total)), dim3(BLOCK), 0, s, env, e->d_target_level);
+  if (h.nalltrans > 0) hipLaunchKernelGGL(k_matrans, dim3(nblocks(ncell * h.nalltrans)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_macroatom, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
-  if (e->hot_blocks) {
+  if (e->hot_blocks) {  // per-cell hot blocks: which levels are hot depends on the cell state
     hipLaunchKernelGGL(k_hotselect, dim3(nblocks(ncell * 64)), dim3(BLOCK), 0, s, env);
-  } else {  // no hot blocks: every record is read from its cell's full row
-    HIP_TRY(hipMemsetAsync(e->K.hotoff, 0xFF, sizeof(int16_t) * (size_t)(ncell * h.nlevels), s));
+    hipLaunchKernelGGL(k_hotfill, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   }
-  hipLaunchKernelGGL(k_hotfill, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_ion, dim3(nblocks(ncell * h.nions)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_prefix, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
   HIP_TRY(hipGetLastError());

@@ -17,6 +17,7 @@ struct ModelOwned {
   std::vector<LinePack> line_pack;
   std::vector<LevelPack> level_pack;
   std::vector<int32_t> level_upcum_start;
+  std::vector<int32_t> alltrans_owner;
   std::vector<ContPack> cont_pack;
 };
 
@@ -49,6 +50,7 @@ struct ModelOwned {
   X(level_upcum_start, int32_t, (m).nlevels)                                       \
   X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
+  X(alltrans_owner, int32_t, (m).nalltrans)                                        \
   X(alltrans_einstein_A, float, (m).nalltrans)                                     \
   X(alltrans_coll_str, float, (m).nalltrans)                                       \
   X(alltrans_osc_strength, float, (m).nalltrans)                                   \
@@ -110,6 +112,10 @@ struct ModelOwned {
   X(allcont_pair, D2, (m).nbfcontinua)                          \
   X(allcont_keepbits, uint64_t, (m).nkeepwords)                 \
   X(corrphotoioncoeff, double, (m).nphixstargets_total)         \
+  X(bf_radrecomb, double, (m).nphixstargets_total)              \
+  X(bf_colrecomb, double, (m).nphixstargets_total)              \
+  X(bf_colion, double, (m).nphixstargets_total)                 \
+  X(bf_cooling, double, (m).nphixstargets_total)                \
   X(cooling_contrib, double, (m).ncoolingterms)                 \
   X(collexc_cum, double, (m).nupcum)                            \
   X(line_dpop, double, (m).nlines)                              \
@@ -156,6 +162,10 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
     nupcum += m.level_nuptrans[i];
   }
   v.nupcum = nupcum;
+  own.alltrans_owner.assign((size_t)(m.nalltrans > 0 ? m.nalltrans : 1), 0);
+  for (int i = 0; i < m.nlevels; i++)
+    for (int t = 0; t < m.level_ndowntrans[i] + m.level_nuptrans[i]; t++) own.alltrans_owner[m.level_alltrans_startdown[i] + t] = i;
+  v.alltrans_owner = own.alltrans_owner.data();
   v.level_upcum_start = own.level_upcum_start.data();
   own.cont_pack.resize(m.nbfcontinua);
   for (int i = 0; i < m.nbfcontinua; i++)

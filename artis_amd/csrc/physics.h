@@ -810,6 +810,11 @@ AHD bool populate_allcont(const Env &env, int c, int i) {
   return keep;
 }
 // one (cell, phixs target): get_corrphotoioncoeff ratecoeff.cc:840 (USE_LUT_PHOTOION)
+// ... and the other rate coefficients of the same bound-free pair (level ul of an ion -> target t in the next ion), which
+// the per-level and per-ion stages below only have to combine: rad_recomb / col_recomb (macroatom.cc:646, :660),
+// col_ion (macroatom.cc:686) and the bound-free cooling coefficient (kpkt.cc:165). Each is the value the
+// reference's loop computes for this pair, evaluated once here instead of inside a loop over levels that only a few
+// lanes of a wave would run.
 AHD void populate_corrphotoion(const Env &env, int c, int ul, int t) {
   const DevModel &M = env.M;
   const double W = env.C.W[c];
@@ -817,9 +822,60 @@ AHD void populate_corrphotoion(const Env &env, int c, int ul, int t) {
   double g = W * lerp_or_last(M, M.corrphotoioncoeffs, ul, t, (float)T_R);
   const int ig = M.level_closestgroundlevelcont[ul];
   if (ig >= 0) g *= env.C.corrphotoionrenorm[((int64_t)c * M.nbfcontinua_ground) + ig];
-  env.K.corrphotoioncoeff[((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t] = g;
+  const int64_t o = ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t;
+  env.K.corrphotoioncoeff[o] = g;
+  const int ui = M.level_ion[ul];
+  const int element = M.ion_element[ui];
+  const int ion = ui - M.elem_uniqueionindexstart[element];
+  const int level = ul - M.ion_uniquelevelindexstart[ui];
+  const float T_e = env.C.Te[c];
+  const float cnne = clumpednne(env.C, c);
+  const double e_trans = phixs_threshold(M, element, ion, level, t);  // epsilon(upper) - epsilon(ul)
+  env.K.bf_radrecomb[o] = rad_recomb(M, T_e, cnne, element, ion + 1, level, t);
+  env.K.bf_colrecomb[o] = col_recomb(M, T_e, cnne, element, ion + 1, level, t, e_trans);
+  env.K.bf_colion[o] = col_ion(M, T_e, cnne, element, ion, level, t, e_trans);
+  env.K.bf_cooling[o] = lerp_or_last(M, M.bfcooling_coeffs, ul, t, T_e);
 }
-// one (cell, level): calculate_macroatom_transitionrates macroatom.cc:64
+// one (cell, entry of alltrans): the rate coefficients of ONE bound-bound transition of
+// calculate_macroatom_transitionrates() (macroatom.cc:64-140) and its term of calculate_cooling_rates_ion()
+// (kpkt.cc:108-121), written where the per-level / per-ion stages below turn them into running sums. Splitting the work
+// this way keeps every lane busy (levels have 0..60 transitions each) and evaluates each collisional-excitation
+// coefficient once instead of twice. The later stages form the same products and add them in the same order: same bits.
+AHD void populate_matrans(const Env &env, int c, int ati) {
+  const DevModel &M = env.M;
+  const int ul = M.alltrans_owner[ati];
+  const LevelPack lpk = M.level_pack[ul];
+  const int start = M.ion_uniquelevelindexstart[M.level_ion[ul]];
+  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
+  const float T_e = env.C.Te[c];
+  const float cnne = clumpednne(env.C, c);
+  const double e_cur = eps(M, ul);
+  const double g_cur = statw(M, ul);
+  const double nnlevel = pops[ul];
+  const int i = ati - lpk.alltrans_startdown;
+  const int tul = start + M.alltrans_targetlevelindex[ati];
+  if (i < lpk.ndown) {
+    const float A_ul = M.alltrans_einstein_A[ati];
+    const double e_trans = e_cur - eps(M, tul);
+    const double g_low = statw(M, tul);
+    const double R = rad_deexc(e_trans, A_ul, g_cur, g_low, nnlevel, pops[tul], env.S.mid);
+    const double Cc = col_deexc(M, T_e, cnne, e_trans, g_cur, g_low, ati);
+    rec[marec_rad(lpk.ndown, lpk.nup) + i] = R;
+    rec[marec_down + i] = Cc;
+  } else {
+    const int ii = i - lpk.ndown;
+    const double e_trans = eps(M, tul) - e_cur;
+    const double g_up = statw(M, tul);
+    const double R = rad_exc(env, c, g_up, M.alltrans_einstein_A[ati], e_trans, nnlevel, pops[tul], g_cur, env.S.mid);
+    const double Cc = col_exc(M, T_e, cnne, e_trans, g_up, g_cur, ati);
+    const double NT = 0.;
+    rec[marec_up(lpk.ndown) + ii] = (R + Cc + NT) * e_cur;
+    env.K.collexc_cum[((int64_t)c * M.nupcum) + M.level_upcum_start[ul] + ii] = nnlevel * Cc * e_trans;
+  }
+}
+// one (cell, level): the running sums of calculate_macroatom_transitionrates macroatom.cc:64 over the terms of
+// populate_matrans(), and the bound-free channels
 AHD void populate_macroatom(const Env &env, int c, int ul) {
   const DevModel &M = env.M;
   const int ui = M.level_ion[ul];
@@ -843,17 +899,12 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   const double nnlevel = pops[ul];
 
   double s_down_same = 0., s_raddeexc = 0., s_coldeexc = 0.;
-  const int startdown = M.level_alltrans_startdown[ul];
-  const int ndown = M.level_ndowntrans[ul];
+  const int ndown = lpk.ndown;
   for (int i = 0; i < ndown; i++) {
-    const int ati = startdown + i;
-    const int lul = start + M.alltrans_targetlevelindex[ati];
-    const float A_ul = M.alltrans_einstein_A[ati];
-    const double e_target = eps(M, lul);
+    const double R = blk_rad[i];   // rad_deexcitation_ratecoeff and col_deexcitation_ratecoeff of the transition,
+    const double Cc = blk_down[i];  // left there by populate_matrans()
+    const double e_target = eps(M, start + M.alltrans_targetlevelindex[lpk.alltrans_startdown + i]);
     const double e_trans = e_cur - e_target;
-    const double g_low = statw(M, lul);
-    const double R = rad_deexc(e_trans, A_ul, g_cur, g_low, nnlevel, pops[lul], t_mid);
-    const double Cc = col_deexc(M, T_e, cnne, e_trans, g_cur, g_low, ati);
     s_raddeexc += R * e_trans;
     s_coldeexc += Cc * e_trans;
     s_down_same += (R + Cc) * e_target;
@@ -865,17 +916,9 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = s_down_same;
 
   double s_up_same = 0.;
-  const int nup = M.level_nuptrans[ul];
-  const int startup = startdown + ndown;
+  const int nup = lpk.nup;
   for (int ii = 0; ii < nup; ii++) {
-    const int ati = startup + ii;
-    const int uul = start + M.alltrans_targetlevelindex[ati];
-    const double e_trans = eps(M, uul) - e_cur;
-    const double g_up = statw(M, uul);
-    const double R = rad_exc(env, c, g_up, M.alltrans_einstein_A[ati], e_trans, nnlevel, pops[uul], g_cur, t_mid);
-    const double Cc = col_exc(M, T_e, cnne, e_trans, g_up, g_cur, ati);
-    const double NT = 0.;
-    s_up_same += (R + Cc + NT) * e_cur;
+    s_up_same += blk_up[ii];
     blk_up[ii] = s_up_same;
   }
   rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s_up_same;
@@ -884,13 +927,15 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   if (ion > 0 && level <= M.ion_maxrecombininglevel[ui]) {
     const int nl = M.ion_nlevels_ionising[ui - 1];
     const int ls = M.ion_uniquelevelindexstart[ui - 1];
+    const int64_t cb = (int64_t)c * M.nphixstargets_total;
     for (int lower = 0; lower < nl; lower++) {
       const int t = find_phixstarget(M, ls + lower, level);
       if (t < 0) continue;
       const double e_target = eps(M, ls + lower);
       const double e_trans = e_cur - e_target;
-      const double R = rad_recomb(M, T_e, cnne, element, ion, lower, t);
-      const double Cc = col_recomb(M, T_e, cnne, element, ion, lower, t, e_trans);
+      const int64_t o = cb + M.level_phixstargetstart[ls + lower] + t;
+      const double R = env.K.bf_radrecomb[o];   // rad_recomb_ratecoeff / col_recomb_ratecoeff of the pair
+      const double Cc = env.K.bf_colrecomb[o];  // (populate_corrphotoion)
       s_down_lower += (R + Cc) * e_target;
       s_radrecomb += R * e_trans;
       s_colrecomb += Cc * e_trans;
@@ -903,11 +948,10 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   double s_up_higher = 0.;
   if (ion < M.elem_nions[element] - 1 && level < M.ion_nlevels_ionising[ui]) {
     const int nt = M.level_nphixstargets[ul];
-    const double *cpc = env.K.corrphotoioncoeff + ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
+    const int64_t o = ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
     for (int t = 0; t < nt; t++) {
-      const double e_trans = phixs_threshold(M, element, ion, level, t);
-      const double R = cpc[t];
-      const double Cc = col_ion(M, T_e, cnne, element, ion, level, t, e_trans);
+      const double R = env.K.corrphotoioncoeff[o + t];
+      const double Cc = env.K.bf_colion[o + t];  // col_ionization_ratecoeff of the pair (populate_corrphotoion)
       s_up_higher += (R + Cc) * e_cur;
     }
   }
@@ -1013,12 +1057,10 @@ AHD void populate_cooling_ion(const Env &env, int c, int ui) {
     const int nup = M.level_nuptrans[ul];
     // the running sum after every transition is kept: do_kpkt() (kpkt.cc:461-476) re-adds exactly these terms, in this
     // order and from the same starting value, to pick the transition, and reads the sums here instead
+    // (the terms nnlevel * C * e_trans were left there by populate_matrans())
     double *upcum = env.K.collexc_cum + ((int64_t)c * M.nupcum) + M.level_upcum_start[ul];
     for (int ati = startup; ati < (startup + nup); ati++) {
-      const int uul = start + M.alltrans_targetlevelindex[ati];
-      const double e_trans = eps(M, uul) - e_cur;
-      const double Cc = nnlevel * col_exc(M, T_e, cnne, e_trans, statw(M, uul), g_cur, ati) * e_trans;
-      C_ion += Cc;
+      C_ion += upcum[ati - startup];
       upcum[ati - startup] = C_ion;
     }
     if (nup > 0) contribs[k++] = C_ion;
@@ -1031,9 +1073,10 @@ AHD void populate_cooling_ion(const Env &env, int c, int ui) {
       const double e_cur = eps(M, ul);
       const double nnlevel = pops[ul];
       const int nt = M.level_nphixstargets[ul];
+      const int64_t o = ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
       for (int t = 0; t < nt; t++) {
         const double e_trans = eps(M, ustart + phixs_upperlevel(M, ul, t)) - e_cur;
-        const double Cc = nnlevel * col_ion(M, T_e, cnne, element, ion, level, t, e_trans) * e_trans;
+        const double Cc = nnlevel * env.K.bf_colion[o + t] * e_trans;  // col_ionization_ratecoeff: populate_corrphotoion
         C_ion += Cc;
         contribs[k++] = C_ion;
       }
@@ -1066,7 +1109,7 @@ AHD void populate_cooling_ion(const Env &env, int c, int ui) {
           pop = nnupperion * w / wsum;
         }
 #endif
-        const double Cc = lerp_or_last(M, M.bfcooling_coeffs, ul, t, T_e) * pop * cnne;
+        const double Cc = env.K.bf_cooling[((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t] * pop * cnne;
         C_ion += Cc;
         contribs[k++] = C_ion;
       }

@@ -116,6 +116,7 @@ struct DevModel {
   const LevelPack *level_pack;  // derived
   const int32_t *level_upcum_start;  // derived: offset of the level's upward transitions in DevCache::collexc_cum
   const int32_t *alltrans_lineindex, *alltrans_targetlevelindex;
+  const int32_t *alltrans_owner;  // derived: the level whose block of alltrans an entry belongs to
   const float *alltrans_einstein_A, *alltrans_coll_str, *alltrans_osc_strength;
   const uint8_t *alltrans_forbidden;
   const double *line_nu;
@@ -162,6 +163,9 @@ struct DevCache {
   double *line_dpop;             // [cell][nlines]: B_lu n_l - B_ul n_u of every line, the population factor of get_tau_sobolev() (rpkt.cc:75)
   double *collexc_cum;           // [cell][nupcum]: running cooling sum after each upward transition of each level (kpkt.cc:461-476)
   double *corrphotoioncoeff;     // [cell][nphixstargets_total]
+  // [cell][nphixstargets_total] the other coefficients of each bound-free pair (populate_corrphotoion): radiative and
+  // collisional recombination, collisional ionisation, bound-free cooling
+  double *bf_radrecomb, *bf_colrecomb, *bf_colion, *bf_cooling;
   double *cooling_contrib;       // [cell][ncoolingterms]
   double *ion_cooling_contribs;  // [cell][nions]
   double *ion_cooling_C;         // [cell][nions] per-ion totals before the prefix sum

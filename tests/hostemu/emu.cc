@@ -72,6 +72,7 @@ void populate_all(Emu &e) {
       if (populate_allcont(e.env, c, i)) kb[i / 64] |= UINT64_C(1) << (unsigned)(i % 64);
     for (int ul = 0; ul < M.nlevels; ul++)
       for (int t = 0; t < M.level_nphixstargets[ul]; t++) populate_corrphotoion(e.env, c, ul, t);
+    for (int ati = 0; ati < M.nalltrans; ati++) populate_matrans(e.env, c, ati);
     for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom(e.env, c, ul);
     populate_hotselect(e.env, c);
     for (int ul = 0; ul < M.nlevels; ul++) populate_hotfill(e.env, c, ul);
