@@ -511,7 +511,7 @@ def make_timestep(t: float, width_frac: float = 0.05, vmax: float = 2.4e9, nts: 
 
 def make_packets(model: abi.Model, aux: dict, npackets: int, seed_base: int = 12345, kpkt_fraction: float = 0.1,
                  e_total: float = 1e45, seed: int = 99, gamma_fraction: float = 0.0, pellet_fraction: float = 0.0,
-                 ts_width_frac: float = 0.05, early_pellets: bool = False) -> np.ndarray:
+                 ts_width_frac: float = 0.05, early_pellets: bool = False, cells_only=None) -> np.ndarray:
     """Packets at the start of the timestep: thermal energy waiting to be emitted (TYPE_PRE_KPKT -> blackbody
     r-packet, kpkt.cc:399) or k-packets (kpkt.cc:425), placed in non-empty cells with probability ~ rho * X(Co,Ni,Fe)."""
     rng = np.random.default_rng(seed)
@@ -521,6 +521,10 @@ def make_packets(model: abi.Model, aux: dict, npackets: int, seed_base: int = 12
     pk = np.zeros(npackets, dtype=abi.PACKET_DTYPE)
     cells = aux["nonempty_cellindex"]
     w = aux["cellvol_tmin"] * np.exp(-aux["v"] / 4.0e8)
+    if cells_only is not None:  # start every packet in this subset of the non-empty cells (dense sampling of a few cells)
+        mask = np.zeros(len(w), dtype=bool)
+        mask[np.asarray(cells_only)] = True
+        w = np.where(mask, w, 0.0)
     w = w / w.sum()
     which = rng.choice(len(cells), size=npackets, p=w)
     cellindex = cells[which]

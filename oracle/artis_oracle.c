@@ -2628,6 +2628,10 @@ float artis_oracle_phixs_fromtable(const float *xs, int npoints, double nuincrem
   return photoionisation_crosssection_fromtable(&o, xs, nu_edge, nu);
 }
 double artis_oracle_planck(double nu, double T) { return planck(nu, T); }
+/* gammapkt.h:28, :38, :68 -- for the restatement of unittests.cc:323 test_compton */
+double artis_oracle_sigma_compton_partial(double x, double f_max) { return sigma_compton_partial(x, f_max); }
+double artis_oracle_choose_f(double xx, double zrand) { return choose_f(xx, zrand); }
+double artis_oracle_meanf_sigma(double x) { return meanf_sigma(x); }
 void artis_oracle_seed_packets(artis_packet *packets, int64_t npackets, uint32_t seed_base) {
   /* input.cc:1912-1916: packet n gets seed rank_seed_base + n */
   for (int64_t n = 0; n < npackets; n++) rng_seed(packets[n].rngstate, seed_base + (uint32_t)n);

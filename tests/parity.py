@@ -72,3 +72,35 @@ def compare_stats(got: abi.Estimators, want: abi.Estimators, what: str = "", sam
             continue
         assert got.stats[i] == want.stats[i], f"{what}: event counter {abi.STAT_NAMES[i]}: {got.stats[i]} vs {want.stats[i]}"
     assert got.stats[UPSCATTER] + got.stats[DOWNSCATTER] == want.stats[UPSCATTER] + want.stats[DOWNSCATTER], what
+
+
+def _oracle_slice(args):
+    lo, hi = args
+    from oracle import oracle_py
+
+    model, cs, ts, pk, preset = _oracle_slice.shared
+    sub = pk[lo:hi].copy()
+    est = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
+    oracle_py.update_packets(model, cs, ts, sub, est, preset=preset)
+    return sub, est.arrays(), np.array(est.stats)
+
+
+def oracle_parallel(model, cs, ts, pk, est: abi.Estimators, preset: str = "classic", nproc: int = 0) -> None:
+    """The CPU oracle on slices of the population in forked worker processes (packets are independent: per-packet
+    generator, per-packet opacity cache), results written back into pk and added into est. Event counters add exactly;
+    estimators are float sums whose order differs from a single call, which the comparison tolerance covers.
+    Call before anything in the process has touched the GPU (fork)."""
+    import multiprocessing as mp
+    import os
+
+    nproc = nproc or min(os.cpu_count() or 1, 16)
+    n = len(pk)
+    bounds = [(n * i // nproc, n * (i + 1) // nproc) for i in range(nproc)]
+    _oracle_slice.shared = (model, cs, ts, pk, preset)
+    with mp.get_context("fork").Pool(nproc) as pool:
+        res = pool.map(_oracle_slice, bounds)
+    for (lo, hi), (sub, arrs, stats) in zip(bounds, res):
+        pk[lo:hi] = sub
+        for k, a in est.arrays().items():
+            a += arrs[k]
+        est.stats[:] = np.asarray(est.stats) + stats

@@ -21,8 +21,40 @@ FLOAT_RTOL = 1e-9
 EST_RTOL = 1e-9
 
 
+BIG_CASES = {
+    # BASELINE.json configs[0] as written: 1D spherical grid, the bench's atomic data ("w7": 7 elements, 33 ions, 1.4e4
+    # lines), artisoptions_classic physics, 1e5 packets
+    "w7_1d_1e5": dict(build=dict(preset="w7", ncoord=50, gridtype=abi.GRID_SPHERICAL1D), npk=100_000,
+                      pkw=dict(kpkt_fraction=0.05), dense_cells=0),
+    # the bench grid itself (50^3 Cartesian, w7 data) sampled densely: 2e5 packets started in the 1500 heaviest cells
+    # (>= 100 packets per cell as in the 1e7-packet bench, where a cell holds ~150), so that the per-cell paths the
+    # bench exercises -- many packets of one cell in a wave, sorted lists, chunked work pulling -- meet the oracle
+    "w7_50cubed_dense_2e5": dict(build=dict(preset="w7", ncoord=50), npk=200_000, pkw=dict(kpkt_fraction=0.02),
+                                 dense_cells=1500),
+}
+
+
 @pytest.fixture(scope="module")
-def engine_mod():
+def oracle_big(oracle):
+    """The oracle's answers for the large cases, computed in forked worker processes BEFORE this process touches the GPU."""
+    os.environ.setdefault("ARTIS_ORACLE_CACHE_CAP", "2500")
+    out = {}
+    for name, c in BIG_CASES.items():
+        model, cs, ts, aux = synth.build(**c["build"])
+        pkw = dict(c["pkw"])
+        if c["dense_cells"]:
+            w = aux["cellvol_tmin"] * np.exp(-aux["v"] / 4.0e8)
+            pkw["cells_only"] = np.argsort(w)[-c["dense_cells"]:]
+        pk0 = synth.make_packets(model, aux, c["npk"], **pkw)
+        pa = pk0.copy()
+        ea = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
+        parity.oracle_parallel(model, cs, ts, pa, ea)
+        out[name] = (model, cs, ts, pk0, pa, ea)
+    return out
+
+
+@pytest.fixture(scope="module")
+def engine_mod(oracle_big):
     import torch
 
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
@@ -177,6 +209,38 @@ def test_engine_matches_oracle_w7_atomic_data(engine_mod, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("name", list(BIG_CASES))
+def test_engine_matches_oracle_large_cases(engine_mod, oracle_big, name):
+    """configs[0] at its stated size and a dense cut of the bench grid (see BIG_CASES), same bars as the small cases"""
+    model, cs, ts, pk0, pa, ea = oracle_big[name]
+    pb = pk0.copy()
+    eb = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
+    eng = engine_mod.Engine(model)
+    eng.set_cellstate(cs, ts)
+    eng.update_packets(pb, eb)
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, f"{name}: HIP engine vs oracle")
+    parity.compare_stats(eb, ea, f"{name}: HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, f"{name}: HIP engine vs oracle")
+    steps = int(ea.stats[abi.STAT_X_RPKT_STEPS] + ea.stats[abi.STAT_X_KPKT_STEPS])
+    assert steps > 20 * len(pk0)
+    if BIG_CASES[name]["dense_cells"]:
+        counts = np.bincount(pk0["cellindex"])
+        assert np.median(counts[counts > 0]) >= 100
+    print(f"{name}: {len(pk0)} packets, {steps} packet-steps, {int(ea.stats[abi.STAT_X_MA_JUMPS])} transitions, "
+          f"worst float rel diff {rep['worst_rel']:.3e}")
+    eng.close()
+
+
+def test_lds_staging_option_matches_oracle(engine_mod, oracle, monkeypatch):
+    """ARTIS_AMD_HOTLDS=1: hot macro-atom blocks staged in LDS (k_thermal<true>); only where records are read from changes"""
+    monkeypatch.setenv("ARTIS_AMD_HOTLDS", "1")
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", 8, abi.GRID_CARTESIAN3D, 0.0, 30000, kfrac=0.3)
+    parity.compare_packets(pb, pa, FLOAT_RTOL, "LDS staging: HIP engine vs oracle")
+    parity.compare_stats(eb, ea, "LDS staging: HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, "LDS staging: HIP engine vs oracle")
+    eng.close()
+
+
 def test_cellcache_matches_oracle(engine_mod, oracle):
     model, cs, ts, aux = synth.build("small", ncoord=8, thick_below_v=4e8)
     eng = engine_mod.Engine(model)
@@ -273,18 +337,20 @@ def test_edge_cases(engine_mod):
     eng.close()
 
 
-def test_full_size_properties_50cubed_1e7_packets(engine_mod):
-    """BASELINE.json's bench configuration itself (50^3 cells, w7 atomic data, 1e7 packets) through properties that do not
+@pytest.mark.parametrize("options", ["classic", "kilonova_lte"])
+def test_full_size_properties_50cubed_1e7_packets(engine_mod, options):
+    """BASELINE.json's bench configuration itself (50^3 cells, w7 atomic data, 1e7 packets; configs[1] with the classic
+    options, configs[3]'s packet-path options with libartis_amd_kilonova_lte.so) through properties that do not
     need the oracle: (1) two runs from the same device snapshot are bit-identical (packets and event counters);
     (2) every packet ends escaped or exactly at the end of the timestep, with finite positive state; (3) packets are
     independent, so the event counters of the whole population equal the sum over its two halves run separately --
     exactly -- and the estimators agree to the accuracy of float summation (a checksum of checksums)."""
     npk = 10_000_000
-    model, cs, ts, aux = synth.build("w7", ncoord=50)
+    model, cs, ts, aux = synth.build("w7", ncoord=50, options=options)
     pk0 = synth.make_packets(model, aux, npk, seed_base=1281360349, kpkt_fraction=0.02)
     n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
     t_end = ts.c.start + ts.c.width
-    eng = engine_mod.Engine(model)
+    eng = engine_mod.Engine(model, preset=options)
     eng.set_cellstate(cs, ts)
     eng.upload_packets(pk0)
     eng.snapshot()

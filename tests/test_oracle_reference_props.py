@@ -328,3 +328,75 @@ def test_physical_constants_match_reference_constants_h(oracle):
         for i in range(n):
             name = names[i].decode()
             assert float(vals[i]).hex() == float.fromhex(gold[name]).hex(), (fn, name)
+
+
+def _compton_functions(oracle):
+    """(name, sigma_compton_partial, choose_f, meanf_sigma) of the oracle and of the kernel bodies (physics.h on x86)"""
+    import ctypes as C
+
+    import hostemu_binding
+
+    out = []
+    for name, L, prefix in (("oracle", oracle.lib(), "artis_oracle_"), ("kernel bodies", hostemu_binding.lib(), "artis_emu_")):
+        fs = []
+        for fn, nargs in (("sigma_compton_partial", 2), ("choose_f", 2), ("meanf_sigma", 1)):
+            f = getattr(L, prefix + fn)
+            f.restype = C.c_double
+            f.argtypes = [C.c_double] * nargs
+            fs.append(f)
+        out.append((name, *fs))
+    return out
+
+
+def test_compton_cross_sections_unittests_cc_323(oracle):
+    """unittests.cc:323 test_compton, on the oracle's and the kernels' restatements of gammapkt.h:28-90: the partial
+    Compton cross section over the full energy-loss range is the Klein-Nishina total; choose_f() inverts it to the
+    solver tolerance; meanf_sigma() is continuous across the Taylor-series / closed-form crossover."""
+    SIGMA_T, THOMSON_LIMIT = 6.6524e-25, 1e-2
+
+    def kn_total(x):
+        return 0.75 * SIGMA_T * ((((1. + x) / x**3) * (((2. * x * (1. + x)) / (1. + (2. * x))) - np.log1p(2. * x))) +
+                                 (np.log1p(2. * x) / (2. * x)) - ((1. + (3. * x)) / (1. + (2. * x))**2))
+
+    for name, partial, choose_f, meanf in _compton_functions(oracle):
+        for x in (0.05, 0.2, 1., 5.):
+            assert abs(partial(x, 1. + 2. * x) - kn_total(x)) <= 1e-10 * kn_total(x), (name, x)
+        for x in (0.05, 1., 5.):
+            for z in (0.1, 0.5, 0.9):
+                f = choose_f(x, z)
+                assert abs(partial(x, f) / partial(x, 1. + 2. * x) - z) < 2e-4, (name, x, z)
+        a, b = meanf(THOMSON_LIMIT * (1. - 1e-6)), meanf(THOMSON_LIMIT * (1. + 1e-6))
+        assert abs(a - b) <= 1e-5 * max(abs(a), abs(b)), name
+    # and the two restatements agree bit for bit with each other
+    (_, p0, c0, m0), (_, p1, c1, m1) = _compton_functions(oracle)
+    for x in np.geomspace(1e-3, 30., 40):
+        assert p0(x, 1. + 2. * x) == p1(x, 1. + 2. * x) and m0(x) == m1(x)
+        for z in (0.03, 0.4, 0.97):
+            assert c0(x, z) == c1(x, z)
+
+
+def test_planck_function_integrals_unittests_cc_254(oracle):
+    """unittests.cc:254 test_planck checks radfield::calculate_planck_integral (a host-side routine outside the packet
+    path) against the Stefan-Boltzmann law and the mean frequency 4 zeta(5)/zeta(4) kT/h. The packet path only has the
+    Planck function itself (radfield.h:50 dbb(), used by sample_planck_montecarlo kpkt.cc:266 and radfield()): the same
+    two laws are checked on it by numerical quadrature, for the oracle and for the kernel bodies."""
+    import ctypes as C
+
+    import hostemu_binding
+
+    H, KB, CLIGHT, STEBO = 6.6260755e-27, 1.38064852e-16, 2.99792458e10, 5.670400e-5
+    T = 6000.
+    x = np.geomspace(1e-6, 80., 400001)  # h nu / k T
+    nu = x * KB * T / H
+    for name, L, fn in (("oracle", oracle.lib(), "artis_oracle_planck"), ("kernel bodies", hostemu_binding.lib(), "artis_emu_planck")):
+        f = getattr(L, fn)
+        f.restype = C.c_double
+        f.argtypes = [C.c_double, C.c_double]
+        B = np.array([f(v, T) for v in nu[::40]])
+        n = nu[::40]
+        total = np.trapezoid(B, n)
+        assert abs(total - STEBO * T**4 / np.pi) <= 1e-3 * total, name
+        nubar = np.trapezoid(B * n, n) / total
+        assert abs(nubar - KB * T / H * 4. * 1.03692775514337 / 1.08232323371114) <= 1e-4 * nubar, name
+        # Wien peak of B_nu: x = 2.821439...
+        assert abs(n[np.argmax(B)] * H / (KB * T) - 2.8214393721) < 2e-3, name
