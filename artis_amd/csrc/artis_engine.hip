@@ -43,28 +43,28 @@ constexpr int BLOCK = 256;
 // ------------------------------------------------------------------ populate kernels
 __global__ void __launch_bounds__(BLOCK) k_levelpops(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nlevels;
+  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nlevels;
   if (i >= total) return;
-  populate_levelpop(env, (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
+  populate_levelpop(env, env.tile_lo + (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
 __global__ void __launch_bounds__(BLOCK) k_line_dpop(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nlines;
+  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nlines;
   if (i >= total) return;
-  populate_line_dpop(env, (int)(i / env.M.nlines), (int)(i % env.M.nlines));
+  populate_line_dpop(env, env.tile_lo + (int)(i / env.M.nlines), (int)(i % env.M.nlines));
 }
 __global__ void __launch_bounds__(BLOCK) k_cell_scalars(Env env) {
-  const int c = blockIdx.x * BLOCK + threadIdx.x;
-  if (c >= env.M.npts_nonempty) return;
+  const int c = env.tile_lo + blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= env.tile_hi) return;
   populate_chi_ff(env, c);
 }
 // one wave = one 64-bit word of a cell's keep bitmap: the ballot IS the word (globals.h:296-305)
 __global__ void __launch_bounds__(BLOCK) k_allcont(Env env) {
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  const int64_t nwaves = (int64_t)env.M.npts_nonempty * env.M.nkeepwords;
+  const int64_t nwaves = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nkeepwords;
   if (wave >= nwaves) return;
-  const int c = (int)(wave / env.M.nkeepwords);
+  const int c = env.tile_lo + (int)(wave / env.M.nkeepwords);
   const int word = (int)(wave % env.M.nkeepwords);
   const int i = word * 64 + lane;
   bool keep = false;
@@ -74,31 +74,31 @@ __global__ void __launch_bounds__(BLOCK) k_allcont(Env env) {
 }
 __global__ void __launch_bounds__(BLOCK) k_corrphotoion(Env env, const int32_t *target_level) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nphixstargets_total;
+  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nphixstargets_total;
   if (i >= total) return;
-  const int c = (int)(i / env.M.nphixstargets_total);
+  const int c = env.tile_lo + (int)(i / env.M.nphixstargets_total);
   const int k = (int)(i % env.M.nphixstargets_total);
   const int ul = target_level[k];
   populate_corrphotoion(env, c, ul, k - env.M.level_phixstargetstart[ul]);
 }
 __global__ void __launch_bounds__(BLOCK) k_matrans(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nalltrans;
+  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nalltrans;
   if (i >= total) return;
-  populate_matrans(env, (int)(i / env.M.nalltrans), (int)(i % env.M.nalltrans));
+  populate_matrans(env, env.tile_lo + (int)(i / env.M.nalltrans), (int)(i % env.M.nalltrans));
 }
 __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nlevels;
+  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nlevels;
   if (i >= total) return;
-  populate_macroatom(env, (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
+  populate_macroatom(env, env.tile_lo + (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
 // hot levels of every cell (physics.h populate_hotselect: the same rule, the levels spread over the lanes of one wave)
 __global__ void __launch_bounds__(BLOCK) k_hotselect(Env env) {
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (wave >= env.M.npts_nonempty) return;
-  const int c = (int)wave;
+  if (wave >= env.tile_hi - env.tile_lo) return;
+  const int c = env.tile_lo + (int)wave;
   const int nl = env.M.nlevels;
   const int per = (nl + 63) / 64;
   const int l0 = lane * per < nl ? lane * per : nl;
@@ -138,19 +138,19 @@ __global__ void __launch_bounds__(BLOCK) k_hotselect(Env env) {
 }
 __global__ void __launch_bounds__(BLOCK) k_hotfill(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nlevels;
+  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nlevels;
   if (i >= total) return;
-  populate_hotfill(env, (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
+  populate_hotfill(env, env.tile_lo + (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
 __global__ void __launch_bounds__(BLOCK) k_cooling_ion(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)env.M.npts_nonempty * env.M.nions;
+  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nions;
   if (i >= total) return;
-  populate_cooling_ion(env, (int)(i / env.M.nions), (int)(i % env.M.nions));
+  populate_cooling_ion(env, env.tile_lo + (int)(i / env.M.nions), (int)(i % env.M.nions));
 }
 __global__ void __launch_bounds__(BLOCK) k_cooling_prefix(Env env) {
-  const int c = blockIdx.x * BLOCK + threadIdx.x;
-  if (c >= env.M.npts_nonempty) return;
+  const int c = env.tile_lo + blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= env.tile_hi) return;
   populate_cooling_prefix(env, c);
 }
 
@@ -229,7 +229,8 @@ __device__ inline void append_by_kind(int kind, int32_t pi, int32_t cellindex, d
 }
 // start of update_packets(): every resident packet is put on the list of its kind. A ContinuumOpacity never survives
 // into another call (rpkt.cc:1023 compares globals::timestep; the cell state may have changed in between).
-__global__ void __launch_bounds__(BLOCK) k_classify(Env env, Lists L) {
+// (Called once per cell-cache tile: only the packets whose cell is in the resident tile are listed, physics.h classify().)
+__global__ void __launch_bounds__(BLOCK) k_classify(Env env, Lists L, int reset_chi) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   int kind = NEXT_DONE;
   int32_t cellindex = 0;
@@ -239,14 +240,16 @@ __global__ void __launch_bounds__(BLOCK) k_classify(Env env, Lists L) {
     const int type = h.type;
     cellindex = h.cellindex;
     nu_cmf = h.nu_cmf;
-    if (h.chi_mgi >= 0) h.chi_mgi = -1;
-    if (h.pend != PEND_NONE) {
-      kind = NEXT_SLOW;
-    } else if (h.ma_level >= 0) {
-      kind = NEXT_MA;
-    } else if (type_handled(type) && h.prop_time < env.S.ts_end) {
-      if (type_gamma(type)) {
-        kind = NEXT_GAMMA;
+    if (reset_chi && h.chi_mgi >= 0) h.chi_mgi = -1;
+    const bool active = type_handled(type) && h.prop_time < env.S.ts_end;
+    const bool waiting = h.pend != PEND_NONE || h.ma_level >= 0;
+    if (active && type_gamma(type) && !waiting) {
+      kind = NEXT_GAMMA;
+    } else if ((waiting || active) && in_tile(env, cellindex)) {
+      if (h.pend != PEND_NONE) {
+        kind = NEXT_SLOW;
+      } else if (h.ma_level >= 0) {
+        kind = NEXT_MA;
       } else if (type == ARTIS_TYPE_RPKT) {
         kind = NEXT_RPKT;
       } else {
@@ -819,6 +822,15 @@ struct artis_amd_engine {
   DevStep S{};
   DevEst E{};
   bool have_cells = false;
+  // Cell-cache tiling: the cache rows of `tile_cells` non-empty cells are resident at a time (all of them when they fit
+  // the budget: ntiles == 1). With more tiles, update_packets sweeps over them -- populate a tile, advance every packet
+  // that sits in one of its cells until it leaves the tile or is done -- until no packet is left (what the reference's
+  // single-slot cell cache does cell by cell, update_packets.cc:397-460, 551-621).
+  int64_t tile_cells = 0;
+  int ntiles = 1;
+  int tile_lo = 0, tile_hi = 0;   // the tile the biased cache pointers refer to
+  int tile_valid_lo = -1;         // first cell of the tile whose cache is populated for the current cell state (-1: none)
+  size_t cache_bytes_per_cell = 0;
   int32_t *d_target_level = nullptr;
   double *d_est = nullptr;
   int64_t est_ndoubles = 0;
@@ -898,6 +910,15 @@ Env make_env(const artis_amd_engine *e) {
   env.M = e->M;
   env.C = e->C;
   env.K = e->K;
+  {  // bias the cache pointers by the first cell of the resident tile: rows are addressed by absolute cell number
+    const DevModel &h = e->Mh;
+    const int64_t lo = e->tile_lo;
+#define BIAS(f, T, per) env.K.f = e->K.f - (lo * (int64_t)(per));
+    ARTIS_CACHE_ARRAYS(BIAS, h)
+#undef BIAS
+  }
+  env.tile_lo = e->tile_lo;
+  env.tile_hi = e->tile_hi;
   env.S = e->S;
   env.E = e->E;
   env.P = e->P;
@@ -1102,18 +1123,37 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
     if (rc != ARTIS_OK) return rc;
     e->d_target_level = (int32_t *)d;
   }
-  // per-cell cache
-  const int64_t ncell = h.npts_nonempty;
+  // per-cell cache: all cells if that fits the budget, else one tile of cells at a time
+  const int64_t ncell_all = h.npts_nonempty;
+  {
+    size_t per_cell = 0;
+#define SZ(f, T, per) per_cell += sizeof(T) * (size_t)(per);
+    ARTIS_CACHE_ARRAYS(SZ, h)
+#undef SZ
+    e->cache_bytes_per_cell = per_cell;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    double budget = 0.6 * (double)free_b;  // the packets, their lists and the caller's buffers need room too
+    if (const char *b = std::getenv("ARTIS_AMD_CACHE_BUDGET_MB")) budget = std::atof(b) * 1048576.0;
+    int64_t fit = (int64_t)(budget / (double)(per_cell > 0 ? per_cell : 1));
+    e->tile_cells = std::max<int64_t>(1, std::min<int64_t>(ncell_all > 0 ? ncell_all : 1, fit));
+    e->ntiles = (int)((ncell_all + e->tile_cells - 1) / e->tile_cells);
+    if (e->ntiles < 1) e->ntiles = 1;
+    e->tile_lo = 0;
+    e->tile_hi = (int)std::min<int64_t>(ncell_all, e->tile_cells);
+  }
+  const int64_t nrows = e->tile_cells;  // rows allocated
 #define CA(f, T, per)                                                                       \
   {                                                                                         \
     T *d = nullptr;                                                                         \
-    HIP_TRY(hipMalloc((void **)&d, sizeof(T) * (size_t)(ncell * (int64_t)(per) + MAREC_SLACK)));    \
+    HIP_TRY(hipMalloc((void **)&d, sizeof(T) * (size_t)(nrows * (int64_t)(per) + MAREC_SLACK)));    \
     e->cache_allocs.push_back(d);                                                           \
     e->K.f = d;                                                                             \
   }
   ARTIS_CACHE_ARRAYS(CA, h)
 #undef CA
   // estimators: one contiguous block [J | nuJ | ff | col | gamma | bfheat | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars]
+  const int64_t ncell = ncell_all;  // estimators cover every cell
   const int64_t g = h.nbfcontinua_ground > 0 ? h.nbfcontinua_ground : 1;
   e->est_ndoubles = ncell * 8 + 2 * ncell * g + ARTIS_NSCALARS;  // ... | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars]
   HIP_TRY(hipMalloc((void **)&e->d_est, sizeof(double) * (size_t)e->est_ndoubles));
@@ -1164,10 +1204,13 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   {
     // the static part of every macro-atom record (header, transition targets) is written once; without hot blocks no
     // level has a place in one
-    const int64_t ncell_ = e->Mh.npts_nonempty;
-    HIP_TRY(hipMemset(e->K.hotoff, 0xFF, sizeof(int16_t) * (size_t)(ncell_ * e->Mh.nlevels)));
+    const int64_t nrows_ = e->tile_cells;  // every resident row; the static parts do not depend on the cell
+    HIP_TRY(hipMemset(e->K.hotoff, 0xFF, sizeof(int16_t) * (size_t)(nrows_ * e->Mh.nlevels)));
     Env env0 = make_env(e);
-    hipLaunchKernelGGL(k_hotfill, dim3(nblocks(ncell_ * e->Mh.nlevels)), dim3(BLOCK), 0, nullptr, env0);
+    env0.tile_lo = 0;
+    env0.tile_hi = (int)nrows_;
+    env0.K = e->K;
+    hipLaunchKernelGGL(k_hotfill, dim3(nblocks(nrows_ * e->Mh.nlevels)), dim3(BLOCK), 0, nullptr, env0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
   }
@@ -1222,17 +1265,18 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
   return artis_amd_populate_cellcache(e, nullptr);
 }
 
-int artis_amd_populate_cellcache(artis_amd_engine *e, void *hip_stream) {
-  if (!e || !e->have_cells) {
-    g_last_error = "no cell state uploaded";
-    return ARTIS_ERR_ARG;
-  }
-  HIP_TRY(hipSetDevice(e->device));
+}  // extern "C"
+
+namespace {
+// populate the cell cache of the non-empty cells [lo, hi) (at most tile_cells of them) into the resident rows
+int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s) {
   const DevModel &h = e->Mh;
-  // populate the cell cache of every non-empty cell
+  e->tile_lo = lo;
+  e->tile_hi = hi;
+  e->tile_valid_lo = -1;
   Env env = make_env(e);
-  const int64_t ncell = h.npts_nonempty;
-  hipStream_t s = (hipStream_t)hip_stream;
+  const int64_t ncell = hi - lo;
+  if (ncell <= 0) return ARTIS_OK;
   hipLaunchKernelGGL(k_levelpops, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   if (h.nlines > 0) hipLaunchKernelGGL(k_line_dpop, dim3(nblocks(ncell * h.nlines)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cell_scalars, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
@@ -1249,7 +1293,7 @@ int artis_amd_populate_cellcache(artis_amd_engine *e, void *hip_stream) {
   hipLaunchKernelGGL(k_cooling_prefix, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
-  // UPDATECELL (stats.h:47): one populate per non-empty cell
+  // UPDATECELL (stats.h:47): one populate per cell
   unsigned long long add = (unsigned long long)ncell, cur = 0;
   HIP_TRY(hipMemcpy(&cur, e->d_stats + ARTIS_STAT_UPDATECELL, sizeof(cur), hipMemcpyDeviceToHost));
   cur += add;
@@ -1260,6 +1304,31 @@ int artis_amd_populate_cellcache(artis_amd_engine *e, void *hip_stream) {
     g_last_error = "cell cache population raised error flag " + std::to_string(err);
     return ARTIS_ERR_NOTCONVERGED;
   }
+  e->tile_valid_lo = lo;
+  return ARTIS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int artis_amd_populate_cellcache(artis_amd_engine *e, void *hip_stream) {
+  if (!e || !e->have_cells) {
+    g_last_error = "no cell state uploaded";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  e->tile_valid_lo = -1;
+  // with one tile the whole cache is filled now; with several, artis_amd_update_packets_device() fills each tile when
+  // its turn comes
+  if (e->ntiles == 1) return populate_tile(e, 0, e->Mh.npts_nonempty, (hipStream_t)hip_stream);
+  return ARTIS_OK;
+}
+
+int artis_amd_cache_tiles(artis_amd_engine *e, int32_t *ntiles, int64_t *cells_per_tile, int64_t *bytes_per_cell) {
+  if (!e) return ARTIS_ERR_ARG;
+  if (ntiles) *ntiles = e->ntiles;
+  if (cells_per_tile) *cells_per_tile = e->tile_cells;
+  if (bytes_per_cell) *bytes_per_cell = (int64_t)e->cache_bytes_per_cell;
   return ARTIS_OK;
 }
 
@@ -1406,15 +1475,43 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     }
     return ARTIS_OK;
   };
+  int rc = ARTIS_OK;
+  const int order[6] = {NEXT_SLOW, NEXT_GAMMA, NEXT_BB, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
+  int64_t guard = 0;
+  const int64_t ncell_all = e->Mh.npts_nonempty;
+  bool first_pass = true;
+  // Sweeps over the cell-cache tiles (one tile, one sweep when the whole cache is resident): list the packets that sit
+  // in the tile, fill the tile's cache if any do, advance them until they leave the tile or are done; repeat until a
+  // sweep finds no packet left to advance.
+  for (int sweep = 0;; sweep++) {
+  bool any_active = false;
+  for (int tile = 0; tile < e->ntiles; tile++) {
+  const int lo = (int)(tile * e->tile_cells);
+  const int hi = (int)std::min<int64_t>(ncell_all, lo + e->tile_cells);
+  if (e->tile_lo != lo || e->tile_hi != hi) {
+    e->tile_lo = lo;
+    e->tile_hi = hi;
+    e->tile_valid_lo = -1;
+  }
+  env = make_env(e);
+  for (int k = 0; k < NEXT_NKINDS; k++) cur[k] = 0;
   HIP_TRY(hipMemsetAsync(e->d_count, 0, sizeof(int32_t) * 2 * NEXT_NKINDS, s));
-  hipLaunchKernelGGL(k_classify, dim3(nblocks(n)), dim3(BLOCK), 0, s, env, lists_for(0));
-  int rc = read_counts();
+  hipLaunchKernelGGL(k_classify, dim3(nblocks(n)), dim3(BLOCK), 0, s, env, lists_for(0), first_pass ? 1 : 0);
+  first_pass = false;
+  rc = read_counts();
   if (rc != ARTIS_OK) return rc;
+  bool tile_active = false;
+  for (int k = 1; k < NEXT_NKINDS; k++) tile_active = tile_active || cnt[k] > 0;
+  if (!tile_active) continue;
+  any_active = true;
+  if (e->tile_valid_lo != lo) {
+    rc = populate_tile(e, lo, hi, s);
+    if (rc != ARTIS_OK) return rc;
+    env = make_env(e);
+  }
 
   // one launch = the whole current list of one kind. Order: slow path, k-packets, macro-atoms, r-packets, so that a
   // k-packet -> macro-atom -> k-packet cycle costs two launches.
-  const int order[6] = {NEXT_SLOW, NEXT_GAMMA, NEXT_BB, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
-  int64_t guard = 0;
   while (cnt[NEXT_RPKT] > 0 || cnt[NEXT_MA] > 0 || cnt[NEXT_SLOW] > 0 || cnt[NEXT_KPKT] > 0 || cnt[NEXT_GAMMA] > 0 || cnt[NEXT_BB] > 0) {
     for (int kind : order) {
       const int32_t nk = cnt[kind];
@@ -1477,6 +1574,9 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       }
     }
   }
+  }  // tiles
+  if (e->ntiles == 1 || !any_active) break;
+  }  // sweeps
   for (int k = 1; k < NEXT_NKINDS; k++) e->last_propagate_ms += e->kms[k];
   int32_t err = 0;
   HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
@@ -1588,8 +1688,9 @@ int artis_amd_update_packets(artis_amd_engine *e, artis_packet *packets, int64_t
   rc = artis_amd_estimators_zero(e, nullptr);
   if (rc != ARTIS_OK) return rc;
   {
-    // keep UPDATECELL of the populate that belongs to this timestep
-    unsigned long long ncell = (unsigned long long)e->Mh.npts_nonempty;
+    // keep UPDATECELL of the populate that belongs to this timestep (with several cache tiles the populates happen
+    // inside the update and count themselves)
+    unsigned long long ncell = (e->ntiles == 1) ? (unsigned long long)e->Mh.npts_nonempty : 0ull;
     HIP_TRY(hipMemcpy(e->d_stats + ARTIS_STAT_UPDATECELL, &ncell, sizeof(ncell), hipMemcpyHostToDevice));
   }
   rc = artis_amd_update_packets_device(e, nullptr);
@@ -1645,6 +1746,15 @@ int artis_amd_debug_cellcache(artis_amd_engine *e, int c, double *levelpops, dou
   }
   HIP_TRY(hipSetDevice(e->device));
   const DevModel &h = e->Mh;
+  {  // the tile that holds cell c has to be resident and filled
+    const int lo = (int)((c / e->tile_cells) * e->tile_cells);
+    const int hi = (int)std::min<int64_t>(h.npts_nonempty, lo + e->tile_cells);
+    if (e->tile_valid_lo != lo) {
+      int rc = populate_tile(e, lo, hi, nullptr);
+      if (rc != ARTIS_OK) return rc;
+    }
+    c -= lo;  // row within the resident tile
+  }
 #define DL(dst, f, T, per)                                                                                            \
   if (dst && (per) > 0) HIP_TRY(hipMemcpy(dst, e->K.f + (int64_t)c * (per), sizeof(T) * (size_t)(per), hipMemcpyDeviceToHost));
   DL(levelpops, levelpops, double, h.nlevels)

@@ -96,7 +96,16 @@ struct Env {
   int32_t *gamma_gi;
   int32_t *gamma_n;
   int32_t *errflag;    // set non-zero when an assert_always of the reference would fire
+  // Cell-cache tile: the non-empty cells [tile_lo, tile_hi) are the ones whose cache rows are resident (the DevCache
+  // pointers are biased so that they are indexed by the absolute cell number). A packet that needs the cache of another
+  // cell waits for that cell's tile (classify()). One tile = all cells unless the cache would not fit in HBM.
+  int32_t tile_lo, tile_hi;
 };
+// the packet's cell is empty (no cache needed) or its cache row is resident
+AHD bool in_tile(const Env &env, int cellindex) {
+  const int c = env.M.propcell_nonemptymgi[cellindex];
+  return c < 0 || (c >= env.tile_lo && c < env.tile_hi);
+}
 
 // Hot packet state, kept in registers.
 struct Pkt {
@@ -2764,10 +2773,12 @@ AHD bool kpkt_blackbody_case(const Env &env, int type, int cellindex) {
   return c >= 0 && env.C.thick[c] == ARTIS_CELL_THICK;
 }
 AHD int classify(const Env &env, const Pkt &p, double ts_end) {
+  const bool active = pkt_active(p, ts_end);
+  if (active && type_gamma(p.type) && p.pend == PEND_NONE && !ma_pending(p)) return NEXT_GAMMA;  // no cell cache needed
+  if ((p.pend != PEND_NONE || ma_pending(p) || active) && !in_tile(env, p.cellindex)) return NEXT_DONE;  // waits for its tile
   if (p.pend != PEND_NONE) return NEXT_SLOW;
   if (ma_pending(p)) return NEXT_MA;
-  if (!pkt_active(p, ts_end)) return NEXT_DONE;
-  if (type_gamma(p.type)) return NEXT_GAMMA;
+  if (!active) return NEXT_DONE;
   if (p.type == ARTIS_TYPE_RPKT) return NEXT_RPKT;
   return kpkt_blackbody_case(env, p.type, p.cellindex) ? NEXT_BB : NEXT_KPKT;
 }
@@ -2784,11 +2795,11 @@ AHD bool rpkt_can_continue(const Pkt &p, double ts_end) {
 AHD bool rpkt_iter(const Env &env, Pkt &p, int64_t pi, Chi &x) {
   const bool cont = do_rpkt_step(env, p, pi, x, pi);
   if (!ma_pending(p) && !cont) x.nonemptymgi = -1;
-  return rpkt_can_continue(p, env.S.ts_end);
+  return rpkt_can_continue(p, env.S.ts_end) && in_tile(env, p.cellindex);  // a new cell may belong to another tile
 }
 AHD int advance_rpkt(const Env &env, Pkt &p, int64_t pi, Chi &x, int budget) {
   int steps = 0;
-  bool go = rpkt_can_continue(p, env.S.ts_end);
+  bool go = rpkt_can_continue(p, env.S.ts_end) && in_tile(env, p.cellindex);
   while (go && steps < budget) {
     go = rpkt_iter(env, p, pi, x);
     steps++;

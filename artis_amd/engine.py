@@ -74,6 +74,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_last_kernel_table",
     "artis_amd_options_preset",
     "artis_amd_allreduce_estimators", "artis_amd_comm_unique_id", "artis_amd_comm_init",
+    "artis_amd_cache_tiles",
 ]
 
 
@@ -152,6 +153,13 @@ class Engine:
         self._check(self.L.artis_amd_debug_cellcache(*args))
         out["chi_ff_nnionpart"] = chi.value
         return out
+
+    def cache_tiles(self):
+        """(number of cell-cache tiles, cells per tile, cache bytes per cell)"""
+        nt, cells, bpc = C.c_int32(), C.c_int64(), C.c_int64()
+        self.L.artis_amd_cache_tiles.argtypes = [C.c_void_p] * 4
+        self._check(self.L.artis_amd_cache_tiles(self.h, C.byref(nt), C.byref(cells), C.byref(bpc)))
+        return nt.value, cells.value, bpc.value
 
     # estimator reduction in the C++ host layer (RCCL)
     COMM_ID_BYTES = 128

@@ -371,6 +371,13 @@ int artis_amd_set_cellstate(artis_amd_engine *eng, const artis_cellstate *cells,
  * reference does at its start, update_packets.cc:551-560). hip_stream is a hipStream_t (NULL = default). */
 int artis_amd_populate_cellcache(artis_amd_engine *eng, void *hip_stream);
 
+/* Cell-cache tiling. The cache of every non-empty cell is resident when it fits the budget (60 % of the free HBM at
+ * engine creation, or ARTIS_AMD_CACHE_BUDGET_MB); otherwise the cells are cut into `*ntiles` ranges of `*cells_per_tile`
+ * and artis_amd_update_packets*() sweeps over them (fill a range, advance the packets that sit in it until they leave it
+ * or are done, next range, ... until no packet is left): the reference's single-slot cell cache (update_packets.cc:397-460,
+ * :551-621) with a tile instead of a cell. Packet histories do not depend on the tiling. */
+int artis_amd_cache_tiles(artis_amd_engine *eng, int32_t *ntiles, int64_t *cells_per_tile, int64_t *bytes_per_cell);
+
 /* Host-buffer form of update_packets() (update_packets.cc:530): every packet
  * whose type is in do_packet()'s switch (update_packets.cc:257: pellets, gamma
  * packets, non-thermal pre-deposits and deposits, r-, k- and pre-k-packets) is

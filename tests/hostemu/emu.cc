@@ -56,6 +56,8 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   e.env.gamma_gi = e.ws_gi.data();
   e.env.gamma_n = e.ws_n.data();
   e.env.errflag = &e.err;
+  e.env.tile_lo = 0;
+  e.env.tile_hi = M.npts_nonempty;
 }
 
 // the populate kernels, in launch order (artis_engine.hip: k_levelpops, k_line_dpop, k_cell_scalars, k_allcont, k_corrphotoion,

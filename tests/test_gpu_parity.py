@@ -241,6 +241,56 @@ def test_lds_staging_option_matches_oracle(engine_mod, oracle, monkeypatch):
     eng.close()
 
 
+def test_cell_cache_tiling_gives_identical_packets(engine_mod, oracle, monkeypatch):
+    """the cell cache cut into tiles that do not fit together (ARTIS_AMD_CACHE_BUDGET_MB): the engine sweeps over the
+    tiles, parking packets that enter a cell of another tile; packet histories must not depend on it. Compared with the
+    untiled engine bit for bit, and with the oracle to the usual bars; all packet types, two consecutive timesteps."""
+    model, cs, ts, aux = synth.build("small", ncoord=8)
+    pk0 = synth.make_packets(model, aux, 30000, kpkt_fraction=0.2, gamma_fraction=0.1, pellet_fraction=0.2)
+    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+
+    def run(budget_mb):
+        if budget_mb is None:
+            monkeypatch.delenv("ARTIS_AMD_CACHE_BUDGET_MB", raising=False)
+        else:
+            monkeypatch.setenv("ARTIS_AMD_CACHE_BUDGET_MB", str(budget_mb))
+        eng = engine_mod.Engine(model)
+        tiles = eng.cache_tiles()
+        p, est = pk0.copy(), abi.Estimators(n, g)
+        eng.upload_packets(p)
+        t = aux["t"]
+        for step in range(2):
+            tsn = synth.make_timestep(t, width_frac=0.05, vmax=model["vmax"], nts=10 + step)
+            eng.set_cellstate(cs, tsn)
+            eng.step()
+            t = tsn.c.start + tsn.c.width
+        eng.download_packets(p)
+        eng.download_estimators(est)
+        if budget_mb is not None:  # the diagnostics copy of a cell of the LAST tile comes from a refilled tile
+            a, b = oracle.cellcache(model, cs, tsn, n - 1), eng.debug_cellcache(n - 1)
+            assert np.allclose(a["levelpops"], b["levelpops"], rtol=1e-12) and np.allclose(a["cooling_contrib"], b["cooling_contrib"], rtol=1e-12)
+        eng.close()
+        return p, est, tiles
+
+    p1, e1, t1 = run(None)
+    bytes_per_cell = t1[2]
+    p3, e3, t3 = run(bytes_per_cell * (n // 3 + 1) / 1048576.0 + 0.01)
+    assert t1[0] == 1 and t3[0] == 3, (t1, t3)
+    parity.compare_packets(p3, p1, 0.0, "3 cache tiles vs 1")
+    skip = abi.STAT_NAMES.index("UPDATECELL")
+    mask = np.arange(abi.NSTATS) != skip
+    assert np.array_equal(e3.stats[mask], e1.stats[mask])
+    assert e3.stats[skip] > e1.stats[skip]  # tiles were refilled
+    parity.compare_estimators(e3, e1, EST_RTOL, "3 cache tiles vs 1")
+    pa, ea = pk0.copy(), abi.Estimators(n, g)
+    t = aux["t"]
+    for step in range(2):
+        tsn = synth.make_timestep(t, width_frac=0.05, vmax=model["vmax"], nts=10 + step)
+        oracle.update_packets(model, cs, tsn, pa, ea)
+        t = tsn.c.start + tsn.c.width
+    parity.compare_packets(p3, pa, FLOAT_RTOL, "3 cache tiles vs oracle")
+
+
 def test_cellcache_matches_oracle(engine_mod, oracle):
     model, cs, ts, aux = synth.build("small", ncoord=8, thick_below_v=4e8)
     eng = engine_mod.Engine(model)
