@@ -347,12 +347,14 @@ __global__ void __launch_bounds__(BLOCK) k_sort_scatter(const int32_t *list, con
 constexpr int MAX_CHUNKS = 8192;  // >= 256 CUs x 4 waves/SIMD x 4 SIMDs, a multiple of 8
 
 struct Puller {
-  int chunk;     // current chunk
-  int home, cx;  // first position of the search order: (XCD, local index); chunks per XCD
+  int chunk;           // current chunk
+  int32_t cbeg, cend;  // ... and its range of the list (kept: the bounds cost two 64-bit divisions)
+  int home, cx;        // first position of the search order: (XCD, local index); chunks per XCD
   int nchunks;
   bool exhausted;
 };
-__device__ inline void puller_init(Puller &q, int nchunks, bool per_block = false) {
+__device__ inline int64_t chunk_begin(int32_t n, int c, int nchunks) { return ((int64_t)n * c) / nchunks; }
+__device__ inline void puller_init(Puller &q, int32_t n, int nchunks, bool per_block = false) {
   const int xcd = blockIdx.x & 7;
   // wave (or workgroup) index within its XCD
   const int local = per_block ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
@@ -360,9 +362,10 @@ __device__ inline void puller_init(Puller &q, int nchunks, bool per_block = fals
   q.cx = nchunks >> 3;
   q.home = xcd * q.cx + (local % q.cx);
   q.chunk = q.home;
+  q.cbeg = (int32_t)chunk_begin(n, q.chunk, nchunks);
+  q.cend = (int32_t)chunk_begin(n, q.chunk + 1, nchunks);
   q.exhausted = false;
 }
-__device__ inline int64_t chunk_begin(int32_t n, int c, int nchunks) { return ((int64_t)n * c) / nchunks; }
 // position v of a wave's search order -> chunk: its own XCD's chunks first (from its home chunk, wrapping), then the rest
 __device__ inline int chunk_at(const Puller &q, int v) {
   const int x0 = (q.home / q.cx) * q.cx;
@@ -379,8 +382,7 @@ __device__ inline int32_t pull(Puller &q, bool need, int32_t n, int32_t *cursors
   const int cnt = __popcll(mask);
   const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
   const int leader = __ffsll((long long)mask) - 1;
-  const int64_t cbeg = chunk_begin(n, q.chunk, q.nchunks);
-  const int64_t cend = chunk_begin(n, q.chunk + 1, q.nchunks);
+  const int64_t cbeg = q.cbeg, cend = q.cend;
   int base = 0;
   if (lane == leader) base = atomicAdd(&cursors[q.chunk], cnt);
   base = __shfl(base, leader);
@@ -402,6 +404,8 @@ __device__ inline int32_t pull(Puller &q, bool need, int32_t n, int32_t *cursors
       const unsigned long long hm = __ballot(has);
       if (hm != 0) {
         q.chunk = __shfl(c, __ffsll((long long)hm) - 1);
+        q.cbeg = (int32_t)chunk_begin(n, q.chunk, q.nchunks);
+        q.cend = (int32_t)chunk_begin(n, q.chunk + 1, q.nchunks);
         found = true;
       }
     }
@@ -425,7 +429,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
   Puller q;
-  puller_init(q, nchunks);
+  puller_init(q, n, nchunks);
   bool have = false;
   int32_t pi = 0;
   int steps = 0;
@@ -499,7 +503,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
   Puller q;
-  puller_init(q, nchunks);
+  puller_init(q, n, nchunks);
   bool have = false;
   int32_t pi = 0;
   int steps = 0;
@@ -636,7 +640,7 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
   Puller q;
-  puller_init(q, nchunks, /*per_block=*/USE_LDS);
+  puller_init(q, n, nchunks, /*per_block=*/USE_LDS);
   bool have = false;
   int32_t pi = 0;
   int units = 0;
@@ -688,7 +692,7 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
       double exit_rate = 0.;
       const double *rec = nullptr;
       if (ma_pending(p) && p.pend == PEND_NONE) {
-        ma_prepare(env, p, k);  // the record of the current level; the walk carries it on
+        ma_prepare<USE_LDS>(env, p, k);  // the record of the current level; the walk carries it on
         if (USE_LDS) {
           if (myslot >= 0 && !slot_ok) slot_ok = ((volatile int *)hs.ready)[myslot] != 0;
           if (slot_ok) k.hotbase = hot_lds + (myslot * HOT_DOUBLES);  // generic pointer into LDS
@@ -701,7 +705,7 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
         if (k.hot >= 0) ARTIS_STAT(env, 57);             // transitions from a hot level
         if (myslot >= 0) ARTIS_STAT(env, 58);            // transitions of a packet whose cell has a slot
 #endif
-        rec = ma_record(k);
+        rec = ma_record<USE_LDS>(k);
         exit_action = ma_jump_internal(env, p, k, rec, &exit_rate);
         j++;
       }
@@ -919,6 +923,7 @@ Env make_env(const artis_amd_engine *e) {
   }
   env.tile_lo = e->tile_lo;
   env.tile_hi = e->tile_hi;
+  env.tile_all = (e->tile_lo == 0 && e->tile_hi >= e->Mh.npts_nonempty) ? 1 : 0;
   env.S = e->S;
   env.E = e->E;
   env.P = e->P;
@@ -1537,12 +1542,15 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
                            e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
       } else if (kind == NEXT_MA) {
         // persistent: every workgroup resident (ARTIS_THERMAL_WAVES waves per SIMD)
+#ifndef ARTIS_NO_LDS_VARIANT
         if (e->hot_lds) {  // hot blocks staged in LDS: one list chunk per workgroup
           const int per_cu = std::max(1, e->thermal_blocks_per_cu * BLOCK / TBLOCK);
           const int grid = std::min((int)((nk + TBLOCK - 1) / TBLOCK), e->ncu * per_cu);
           hipLaunchKernelGGL((k_thermal<true, TBLOCK>), dim3(grid), dim3(TBLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
                              e->d_cursors, chunks_for(nk, grid));
-        } else {
+        } else
+#endif
+        {
           const int grid = std::min(nblocks(nk), e->ncu * e->thermal_blocks_per_cu);
           hipLaunchKernelGGL((k_thermal<false, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
                              e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8);

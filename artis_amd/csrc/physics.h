@@ -100,9 +100,11 @@ struct Env {
   // pointers are biased so that they are indexed by the absolute cell number). A packet that needs the cache of another
   // cell waits for that cell's tile (classify()). One tile = all cells unless the cache would not fit in HBM.
   int32_t tile_lo, tile_hi;
+  int32_t tile_all;  // the tile covers every cell (the usual case): in_tile() needs no look-up
 };
 // the packet's cell is empty (no cache needed) or its cache row is resident
 AHD bool in_tile(const Env &env, int cellindex) {
+  if (env.tile_all) return true;
   const int c = env.M.propcell_nonemptymgi[cellindex];
   return c < 0 || (c >= env.tile_lo && c < env.tile_hi);
 }
@@ -1793,13 +1795,17 @@ AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
   }
   return k.start + p.ma_level;
 }
+// HOT = false: the caller never uses hot blocks (the thermal kernel without LDS staging): nothing about them is read
+template <bool HOT = true>
 AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) {
   const int ul = ma_locate(env, p, k);
   k.rec = env.M.level_pack[ul].rec_off;
-  k.hot = env.K.hotoff[((int64_t)k.c * env.M.nlevels) + ul];
+  k.hot = HOT ? (int)env.K.hotoff[((int64_t)k.c * env.M.nlevels) + ul] : -1;
 }
 // the current level's record: its copy in the hot block when there is one and the block is readable, else the cell's row
+template <bool HOT = true>
 AHD const double *ma_record(const MACtx &k) {
+  if (!HOT) return k.cellma + k.rec;
   return (k.hot >= 0 && k.hotbase != nullptr) ? k.hotbase + (k.hot * MAREC_ALIGN) : k.cellma + k.rec;
 }
 // First half of a transition: draw the process (macroatom.cc:425-431); an internal transition inside the ion is made

@@ -163,6 +163,30 @@ def main():
     ptr, ndoubles = eng.estimators_devptr()
     est_view = torch.as_tensor(_CudaArrayView(ptr, ndoubles), device=torch.device("cuda", local_rank))
     stream = torch.cuda.current_stream().cuda_stream
+    # N > 1: the estimator all-reduce is the library's (artis_amd_allreduce_estimators: one in-place ncclAllReduce over
+    # RCCL in the C++ host layer). torch.distributed only carries the 128 bytes of the communicator id, as MPI would in
+    # the reference. Should the library's communicator fail to come up, the same reduction is done by torch's RCCL
+    # binding on the same device block, and the JSON line says so.
+    reduce_via = None
+    if world > 1:
+        ids = [None]
+        if rank == 0:
+            try:
+                ids = [eng.comm_unique_id()]
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] librccl not reachable from the engine library ({exc})", file=sys.stderr)
+        dist.broadcast_object_list(ids, src=0)
+        reduce_via = "torch.distributed.all_reduce (RCCL)"
+        if ids[0] is not None:
+            try:
+                eng.comm_init(world, rank, ids[0])
+                reduce_via = "artis_amd_allreduce_estimators (RCCL, C-ABI)"
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] rank {rank}: C-ABI communicator not available ({exc})", file=sys.stderr)
+        allv = [None] * world
+        dist.all_gather_object(allv, reduce_via)
+        if any(v != "artis_amd_allreduce_estimators (RCCL, C-ABI)" for v in allv):
+            reduce_via = "torch.distributed.all_reduce (RCCL)"  # every rank must take the same path
     setup_s = time.perf_counter() - t_setup
 
     kern_ms, kern_launches = 0.0, 0
@@ -173,8 +197,11 @@ def main():
         eng.zero_estimators(stream)
         eng.populate_cellcache(stream)
         eng.step(stream)
-        if world > 1:
-            dist.all_reduce(est_view)  # RCCL all-reduce of [J | nuJ | ffheat | colheat | gamma | bfheat]
+        if world > 1:  # [J | nuJ | ffheat | colheat | gamma | bfheat | dep_* | scalars], one in-place sum over the ranks
+            if reduce_via.startswith("artis_amd"):
+                eng.allreduce_estimators(stream)
+            else:
+                dist.all_reduce(est_view)
         if timed:
             ms, nl = eng.last_kernel_ms()
             kern_ms += ms
@@ -281,7 +308,7 @@ def main():
                        "options": args.options,
                        "packets_per_gpu": args.packets, "nonempty_cells": int(model["npts_nonempty"]),
                        "packet_steps_per_step": steps_all, "setup_s": round(setup_s, 1),
-                       "parallelism": f"packets sharded over {world} GPU(s); estimator all-reduce over RCCL" if world > 1
+                       "parallelism": f"packets sharded over {world} GPU(s); estimator all-reduce: {reduce_via}" if world > 1
                        else "1 GPU"},
             # achieved/frac: ALGORITHMIC bytes (requested by design, cache-served re-reads included) over the kernel's launch
             # time; hbm_frac_measured: bytes that reached HBM by the rocprofv3 counters over the same time -- the number

@@ -58,6 +58,7 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   e.env.errflag = &e.err;
   e.env.tile_lo = 0;
   e.env.tile_hi = M.npts_nonempty;
+  e.env.tile_all = 1;
 }
 
 // the populate kernels, in launch order (artis_engine.hip: k_levelpops, k_line_dpop, k_cell_scalars, k_allcont, k_corrphotoion,

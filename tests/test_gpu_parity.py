@@ -291,6 +291,34 @@ def test_cell_cache_tiling_gives_identical_packets(engine_mod, oracle, monkeypat
     parity.compare_packets(p3, pa, FLOAT_RTOL, "3 cache tiles vs oracle")
 
 
+def test_estimator_allreduce_through_the_c_abi(engine_mod):
+    """artis_amd_comm_unique_id / artis_amd_comm_init / artis_amd_allreduce_estimators on a one-rank communicator (the GPU
+    box has one device): RCCL is found at run time, the communicator comes up, the in-place sum leaves the block as is"""
+    model, cs, ts, aux = synth.build("tiny", ncoord=6)
+    pk = synth.make_packets(model, aux, 4000, kpkt_fraction=0.3)
+    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+    eng = engine_mod.Engine(model)
+    eng.set_cellstate(cs, ts)
+    eng.upload_packets(pk)
+    eng.zero_estimators()
+    eng.step()
+    before = abi.Estimators(n, g)
+    eng.download_estimators(before)
+    ident = eng.comm_unique_id()
+    assert len(ident) == 128 and any(ident)
+    eng.comm_init(1, 0, ident)
+    eng.allreduce_estimators()
+    import torch
+
+    torch.cuda.synchronize()
+    after = abi.Estimators(n, g)
+    eng.download_estimators(after)
+    for k, a in before.arrays().items():
+        assert np.array_equal(a, after.arrays()[k]), k
+    assert before.J.sum() > 0
+    eng.close()
+
+
 def test_cellcache_matches_oracle(engine_mod, oracle):
     model, cs, ts, aux = synth.build("small", ncoord=8, thick_below_v=4e8)
     eng = engine_mod.Engine(model)

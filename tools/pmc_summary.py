@@ -10,6 +10,7 @@ for d in dirs:
         seen = set()
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+            k = k.replace("void ", "").split("<")[0].strip()  # template instantiations (k_thermal<false, 256>) by base name
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
             if row["Dispatch_Id"] not in seen and row["Counter_Name"] in ("FETCH_SIZE", "SQ_WAVES"):
                 seen.add(row["Dispatch_Id"])
