@@ -81,11 +81,80 @@ __global__ void __launch_bounds__(BLOCK) k_corrphotoion(Env env, const int32_t *
   const int ul = target_level[k];
   populate_corrphotoion(env, c, ul, k - env.M.level_phixstargetstart[ul]);
 }
+// Bound-bound part of a cell's macro-atom records: one WAVE per (cell, run of alltrans entries). Each lane evaluates
+// the rate coefficients of one transition (every lane busy, whatever the levels' transition counts), then the wave forms
+// the running sums of macroatom.cc:64-140 with an ORDER-PRESERVING scan: in step k the lanes that are k entries into
+// their (level, direction) segment add their term to the sum of the lane before them -- the additions of the
+// reference's loop, in its order, so the sums carry the same bits as the sequential form (physics.h
+// populate_macroatom_sums) -- while loads and stores stay coalesced (round 2's per-level loop ran at ~1 TB/s on strided
+// 8-byte accesses). A segment that crosses a 64-entry chunk hands its partial sums to the next chunk.
+// the value of the lane below (lane 0: 0), as two DPP wave-shift moves: the scan's steps are a serial chain, and a DPP
+// move costs a few cycles where ds_bpermute (what __shfl_up compiles to) costs an LDS round trip
+__device__ inline double wave_shr1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 __global__ void __launch_bounds__(BLOCK) k_matrans(Env env) {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nalltrans;
-  if (i >= total) return;
-  populate_matrans(env, env.tile_lo + (int)(i / env.M.nalltrans), (int)(i % env.M.nalltrans));
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int nblk = env.M.nscanblk;
+  if (wave >= (int64_t)(env.tile_hi - env.tile_lo) * nblk) return;
+  const int c = env.tile_lo + (int)(wave / nblk);
+  const int blk = (int)(wave % nblk);
+  const int a0 = env.M.scanblk_start[blk], a1 = env.M.scanblk_start[blk + 1];
+  double *row = env.K.macache + ((int64_t)c * env.M.nmacache);
+  double c0 = 0., c1 = 0., c2 = 0.;  // sums carried into the chunk by a segment that began before it
+  for (int base = a0; base < a1; base += 64) {
+    const int ati = base + lane;
+    const bool valid = ati < a1;
+    MaTransTerms t;
+    t.v0 = t.v1 = t.v2 = t.kterm = 0.;
+    t.i = 0;
+    t.isdown = false;
+    t.ul = 0;
+    t.lpk = LevelPack{0, 0, 0, 0};
+    if (valid) t = matrans_terms(env, c, ati);
+    // distance to the first entry of the lane's segment inside this chunk (a segment = one level, one direction)
+    const int off = valid ? (t.i < lane ? t.i : lane) : 0;
+    const bool continues = valid && t.i > lane;  // the segment began in the previous chunk: lane 0 takes the carry
+    double s0 = (continues ? c0 : 0.) + t.v0, s1 = (continues ? c1 : 0.) + t.v1, s2 = (continues ? c2 : 0.) + t.v2;
+    int maxoff = off;
+    for (int o = 32; o > 0; o >>= 1) {
+      const int v = __shfl_xor(maxoff, o);
+      maxoff = v > maxoff ? v : maxoff;
+    }
+    for (int k = 1; k <= maxoff; k++) {
+      const double p0 = wave_shr1(s0), p1 = wave_shr1(s1), p2 = wave_shr1(s2);
+      if (off == k) {
+        s0 = p0 + t.v0;
+        s1 = p1 + t.v1;
+        s2 = p2 + t.v2;
+      }
+    }
+    if (valid) {
+      double *rec = row + t.lpk.rec_off;
+      const int seglen = t.isdown ? t.lpk.ndown : t.lpk.nup;
+      if (t.isdown) {
+        rec[marec_rad(t.lpk.ndown, t.lpk.nup) + t.i] = s0;
+        rec[marec_down + t.i] = s2;
+        if (t.i == seglen - 1) {
+          rec[marec_rates + ARTIS_MA_ACTION_RADDEEXC] = s0;
+          rec[marec_rates + ARTIS_MA_ACTION_COLDEEXC] = s1;
+          rec[marec_rates + ARTIS_MA_ACTION_INTERNALDOWNSAME] = s2;
+        }
+      } else {
+        rec[marec_up(t.lpk.ndown) + t.i] = s0;
+        env.K.collexc_cum[((int64_t)c * env.M.nupcum) + env.M.level_upcum_start[t.ul] + t.i] = t.kterm;
+        if (t.i == seglen - 1) rec[marec_rates + ARTIS_MA_ACTION_INTERNALUPSAME] = s0;
+      }
+    }
+    // the last lane's sums go on if its segment does (the run ends at a level boundary, so only inside the run)
+    c0 = __shfl(s0, 63);
+    c1 = __shfl(s1, 63);
+    c2 = __shfl(s2, 63);
+  }
 }
 __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1288,7 +1357,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s) {
   if (h.nbfcontinua > 0) hipLaunchKernelGGL(k_allcont, dim3(nblocks(ncell * h.nkeepwords * 64)), dim3(BLOCK), 0, s, env);
   if (h.nphixstargets_total > 0)
     hipLaunchKernelGGL(k_corrphotoion, dim3(nblocks(ncell * h.nphixstargets_total)), dim3(BLOCK), 0, s, env, e->d_target_level);
-  if (h.nalltrans > 0) hipLaunchKernelGGL(k_matrans, dim3(nblocks(ncell * h.nalltrans)), dim3(BLOCK), 0, s, env);
+  if (h.nalltrans > 0) hipLaunchKernelGGL(k_matrans, dim3(nblocks(ncell * h.nscanblk * 64)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_macroatom, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   if (e->hot_blocks) {  // per-cell hot blocks: which levels are hot depends on the cell state
     hipLaunchKernelGGL(k_hotselect, dim3(nblocks(ncell * 64)), dim3(BLOCK), 0, s, env);

@@ -18,6 +18,7 @@ struct ModelOwned {
   std::vector<LevelPack> level_pack;
   std::vector<int32_t> level_upcum_start;
   std::vector<int32_t> alltrans_owner;
+  std::vector<int32_t> scanblk_start;
   std::vector<ContPack> cont_pack;
 };
 
@@ -51,6 +52,7 @@ struct ModelOwned {
   X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
   X(alltrans_owner, int32_t, (m).nalltrans)                                        \
+  X(scanblk_start, int32_t, ((m).nscanblk + 1))                                    \
   X(alltrans_einstein_A, float, (m).nalltrans)                                     \
   X(alltrans_coll_str, float, (m).nalltrans)                                       \
   X(alltrans_osc_strength, float, (m).nalltrans)                                   \
@@ -166,6 +168,18 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   for (int i = 0; i < m.nlevels; i++)
     for (int t = 0; t < m.level_ndowntrans[i] + m.level_nuptrans[i]; t++) own.alltrans_owner[m.level_alltrans_startdown[i] + t] = i;
   v.alltrans_owner = own.alltrans_owner.data();
+  own.scanblk_start.assign(1, 0);
+  for (int i = 0, run = 0; i < m.nlevels; i++) {
+    const int nt = m.level_ndowntrans[i] + m.level_nuptrans[i];
+    if (run > 0 && run + nt > 256) {
+      own.scanblk_start.push_back(m.level_alltrans_startdown[i]);
+      run = 0;
+    }
+    run += nt;
+  }
+  own.scanblk_start.push_back(m.nalltrans);
+  v.nscanblk = (int32_t)own.scanblk_start.size() - 1;
+  v.scanblk_start = own.scanblk_start.data();
   v.level_upcum_start = own.level_upcum_start.data();
   own.cont_pack.resize(m.nbfcontinua);
   for (int i = 0; i < m.nbfcontinua; i++)

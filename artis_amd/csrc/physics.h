@@ -852,41 +852,103 @@ AHD void populate_corrphotoion(const Env &env, int c, int ul, int t) {
 // (kpkt.cc:108-121), written where the per-level / per-ion stages below turn them into running sums. Splitting the work
 // this way keeps every lane busy (levels have 0..60 transitions each) and evaluates each collisional-excitation
 // coefficient once instead of twice. The later stages form the same products and add them in the same order: same bits.
-AHD void populate_matrans(const Env &env, int c, int ati) {
+// the terms one entry of alltrans adds to the running sums of its level: for a downward transition {R e_trans, C e_trans,
+// (R + C) e_target}, for an upward one {(R + C + NT) e_cur, -, -} plus its k-packet cooling term n C e_trans
+struct MaTransTerms {
+  int ul, i;        // owner level; index within its down (isdown) or up block
+  bool isdown;
+  LevelPack lpk;
+  double v0, v1, v2;
+  double kterm;
+};
+AHD MaTransTerms matrans_terms(const Env &env, int c, int ati) {
   const DevModel &M = env.M;
-  const int ul = M.alltrans_owner[ati];
-  const LevelPack lpk = M.level_pack[ul];
+  MaTransTerms r;
+  r.ul = M.alltrans_owner[ati];
+  r.lpk = M.level_pack[r.ul];
+  const int ul = r.ul;
   const int start = M.ion_uniquelevelindexstart[M.level_ion[ul]];
   const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
-  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
   const float T_e = env.C.Te[c];
   const float cnne = clumpednne(env.C, c);
   const double e_cur = eps(M, ul);
   const double g_cur = statw(M, ul);
   const double nnlevel = pops[ul];
-  const int i = ati - lpk.alltrans_startdown;
+  const int i = ati - r.lpk.alltrans_startdown;
   const int tul = start + M.alltrans_targetlevelindex[ati];
-  if (i < lpk.ndown) {
+  r.isdown = i < r.lpk.ndown;
+  r.kterm = 0.;
+  if (r.isdown) {
+    r.i = i;
     const float A_ul = M.alltrans_einstein_A[ati];
-    const double e_trans = e_cur - eps(M, tul);
+    const double e_target = eps(M, tul);
+    const double e_trans = e_cur - e_target;
     const double g_low = statw(M, tul);
     const double R = rad_deexc(e_trans, A_ul, g_cur, g_low, nnlevel, pops[tul], env.S.mid);
     const double Cc = col_deexc(M, T_e, cnne, e_trans, g_cur, g_low, ati);
-    rec[marec_rad(lpk.ndown, lpk.nup) + i] = R;
-    rec[marec_down + i] = Cc;
+    r.v0 = R * e_trans;
+    r.v1 = Cc * e_trans;
+    r.v2 = (R + Cc) * e_target;
   } else {
-    const int ii = i - lpk.ndown;
+    r.i = i - r.lpk.ndown;
     const double e_trans = eps(M, tul) - e_cur;
     const double g_up = statw(M, tul);
     const double R = rad_exc(env, c, g_up, M.alltrans_einstein_A[ati], e_trans, nnlevel, pops[tul], g_cur, env.S.mid);
     const double Cc = col_exc(M, T_e, cnne, e_trans, g_up, g_cur, ati);
     const double NT = 0.;
-    rec[marec_up(lpk.ndown) + ii] = (R + Cc + NT) * e_cur;
-    env.K.collexc_cum[((int64_t)c * M.nupcum) + M.level_upcum_start[ul] + ii] = nnlevel * Cc * e_trans;
+    r.v0 = (R + Cc + NT) * e_cur;
+    r.v1 = 0.;
+    r.v2 = 0.;
+    r.kterm = nnlevel * Cc * e_trans;
+  }
+  return r;
+}
+// sequential form (test emulation): the terms are stored in the blocks the sums go to (the collisional de-excitation
+// term, which has no block, in the target area until populate_hotfill() writes the targets)
+AHD void populate_matrans(const Env &env, int c, int ati) {
+  const DevModel &M = env.M;
+  const MaTransTerms t = matrans_terms(env, c, ati);
+  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + t.lpk.rec_off;
+  if (t.isdown) {
+    rec[marec_rad(t.lpk.ndown, t.lpk.nup) + t.i] = t.v0;
+    rec[marec_tgt(t.lpk.ndown, t.lpk.nup) + t.i] = t.v1;
+    rec[marec_down + t.i] = t.v2;
+  } else {
+    rec[marec_up(t.lpk.ndown) + t.i] = t.v0;
+    env.K.collexc_cum[((int64_t)c * M.nupcum) + M.level_upcum_start[t.ul] + t.i] = t.kterm;
   }
 }
-// one (cell, level): the running sums of calculate_macroatom_transitionrates macroatom.cc:64 over the terms of
-// populate_matrans(), and the bound-free channels
+// sequential form: the running sums of one level over the terms left by populate_matrans(), in the reference's order
+// (macroatom.cc:64-140). The GPU does the same additions in the same order inside k_matrans (a wave scan).
+AHD void populate_macroatom_sums(const Env &env, int c, int ul) {
+  const DevModel &M = env.M;
+  const LevelPack lpk = M.level_pack[ul];
+  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
+  double *rates = rec + marec_rates;
+  double *blk_down = rec + marec_down;
+  double *blk_up = rec + marec_up(lpk.ndown);
+  double *blk_rad = rec + marec_rad(lpk.ndown, lpk.nup);
+  const double *parked = rec + marec_tgt(lpk.ndown, lpk.nup);
+  double s_down_same = 0., s_raddeexc = 0., s_coldeexc = 0.;
+  for (int i = 0; i < lpk.ndown; i++) {
+    s_raddeexc += blk_rad[i];
+    s_coldeexc += parked[i];
+    s_down_same += blk_down[i];
+    blk_rad[i] = s_raddeexc;
+    blk_down[i] = s_down_same;
+  }
+  rates[ARTIS_MA_ACTION_RADDEEXC] = s_raddeexc;
+  rates[ARTIS_MA_ACTION_COLDEEXC] = s_coldeexc;
+  rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = s_down_same;
+  double s_up_same = 0.;
+  for (int ii = 0; ii < lpk.nup; ii++) {
+    s_up_same += blk_up[ii];
+    blk_up[ii] = s_up_same;
+  }
+  rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s_up_same;
+}
+// one (cell, level): the bound-free channels of calculate_macroatom_transitionrates macroatom.cc:141-190 (the four
+// bound-bound rates are already in the record: populate_macroatom_sums() / k_matrans), and the level's hotness
 AHD void populate_macroatom(const Env &env, int c, int ul) {
   const DevModel &M = env.M;
   const int ui = M.level_ion[ul];
@@ -909,31 +971,9 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   const double g_cur = statw(M, ul);
   const double nnlevel = pops[ul];
 
-  double s_down_same = 0., s_raddeexc = 0., s_coldeexc = 0.;
-  const int ndown = lpk.ndown;
-  for (int i = 0; i < ndown; i++) {
-    const double R = blk_rad[i];   // rad_deexcitation_ratecoeff and col_deexcitation_ratecoeff of the transition,
-    const double Cc = blk_down[i];  // left there by populate_matrans()
-    const double e_target = eps(M, start + M.alltrans_targetlevelindex[lpk.alltrans_startdown + i]);
-    const double e_trans = e_cur - e_target;
-    s_raddeexc += R * e_trans;
-    s_coldeexc += Cc * e_trans;
-    s_down_same += (R + Cc) * e_target;
-    blk_rad[i] = s_raddeexc;
-    blk_down[i] = s_down_same;
-  }
-  rates[ARTIS_MA_ACTION_RADDEEXC] = s_raddeexc;
-  rates[ARTIS_MA_ACTION_COLDEEXC] = s_coldeexc;
-  rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = s_down_same;
-
-  double s_up_same = 0.;
-  const int nup = lpk.nup;
-  for (int ii = 0; ii < nup; ii++) {
-    s_up_same += blk_up[ii];
-    blk_up[ii] = s_up_same;
-  }
-  rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s_up_same;
-
+  // a level without downward (upward) transitions has no segment that would have written its bound-bound rates
+  if (lpk.ndown == 0) rates[ARTIS_MA_ACTION_RADDEEXC] = rates[ARTIS_MA_ACTION_COLDEEXC] = rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = 0.;
+  if (lpk.nup == 0) rates[ARTIS_MA_ACTION_INTERNALUPSAME] = 0.;
   double s_down_lower = 0., s_radrecomb = 0., s_colrecomb = 0.;
   if (ion > 0 && level <= M.ion_maxrecombininglevel[ui]) {
     const int nl = M.ion_nlevels_ionising[ui - 1];

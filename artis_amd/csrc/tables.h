@@ -117,6 +117,10 @@ struct DevModel {
   const int32_t *level_upcum_start;  // derived: offset of the level's upward transitions in DevCache::collexc_cum
   const int32_t *alltrans_lineindex, *alltrans_targetlevelindex;
   const int32_t *alltrans_owner;  // derived: the level whose block of alltrans an entry belongs to
+  // derived: alltrans cut at level boundaries into runs of at most ~256 entries, [nscanblk + 1] start indices: one wave
+  // of k_matrans forms the running sums of one run
+  const int32_t *scanblk_start;
+  int32_t nscanblk;
   const float *alltrans_einstein_A, *alltrans_coll_str, *alltrans_osc_strength;
   const uint8_t *alltrans_forbidden;
   const double *line_nu;

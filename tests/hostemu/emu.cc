@@ -76,6 +76,7 @@ void populate_all(Emu &e) {
     for (int ul = 0; ul < M.nlevels; ul++)
       for (int t = 0; t < M.level_nphixstargets[ul]; t++) populate_corrphotoion(e.env, c, ul, t);
     for (int ati = 0; ati < M.nalltrans; ati++) populate_matrans(e.env, c, ati);
+    for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom_sums(e.env, c, ul);
     for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom(e.env, c, ul);
     populate_hotselect(e.env, c);
     for (int ul = 0; ul < M.nlevels; ul++) populate_hotfill(e.env, c, ul);
