@@ -106,6 +106,8 @@ int artis_emu_constants(const char **names, double *values, int maxn) {
 int artis_emu_upper_bound(const double *a, int n, double v) { return artis::upper_bound_d(a, n, v); }
 int artis_emu_lower_bound(const double *a, int n, double v) { return artis::lower_bound_d(a, n, v); }
 int artis_emu_upper_bound_wide(const double *a, int n, double v) { return artis::upper_bound_wide(a, n, v); }
+int artis_emu_upper_bound_blocked6(const double *a, int n, double v) { return artis::upper_bound_blocked<6>(a, n, v); }
+int artis_emu_upper_bound_blocked16(const double *a, int n, double v) { return artis::upper_bound_blocked<16>(a, n, v); }
 // Compton cross-section helpers of physics.h (gammapkt.h:28, :38, :68), for the restatement of unittests.cc:323
 double artis_emu_sigma_compton_partial(double x, double f_max) { return artis::sigma_compton_partial(x, f_max); }
 double artis_emu_choose_f(double xx, double zrand) { return artis::choose_f(xx, zrand); }

@@ -210,7 +210,8 @@ def test_search_helpers_match_numpy():
     """partition_point8 / upper_bound_wide (physics.h) against numpy.searchsorted on arrays with ties and at the edges"""
     import ctypes as C
     L = emu.lib()
-    for f in (L.artis_emu_upper_bound, L.artis_emu_lower_bound, L.artis_emu_upper_bound_wide):
+    for f in (L.artis_emu_upper_bound, L.artis_emu_lower_bound, L.artis_emu_upper_bound_wide, L.artis_emu_upper_bound_blocked6,
+              L.artis_emu_upper_bound_blocked16):
         f.argtypes = [C.c_void_p, C.c_int, C.c_double]
         f.restype = C.c_int
     L.artis_emu_closest_transition.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
@@ -223,6 +224,8 @@ def test_search_helpers_match_numpy():
             assert L.artis_emu_upper_bound(a.ctypes.data, n, v) == np.searchsorted(a, v, side="right")
             assert L.artis_emu_lower_bound(a.ctypes.data, n, v) == np.searchsorted(a, v, side="left")
             assert L.artis_emu_upper_bound_wide(a.ctypes.data, n, v) == np.searchsorted(a, v, side="right")
+            assert L.artis_emu_upper_bound_blocked6(a.ctypes.data, n, v) == np.searchsorted(a, v, side="right")
+            assert L.artis_emu_upper_bound_blocked16(a.ctypes.data, n, v) == np.searchsorted(a, v, side="right")
         d = np.ascontiguousarray(a[::-1])  # line list: falling frequencies (rpkt.h:155)
         for v in probes:
             got = L.artis_emu_closest_transition(d.ctypes.data, n, v, 0)
