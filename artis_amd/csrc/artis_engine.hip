@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
         if (myslot >= 0) ARTIS_STAT(env, 58);            // transitions of a packet whose cell has a slot
 #endif
         rec = ma_record<USE_LDS>(k);
-        exit_action = ma_jump_internal(env, p, k, rec, &exit_rate);
+        exit_action = ma_jump_internal<USE_LDS>(env, p, k, rec, &exit_rate);
         j++;
       }
       ma_flush_stats(env, k);
@@ -1146,6 +1146,18 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
     }
     last = gi;
   }
+  for (int i = 0; i < model->nlevels; i++) {  // what a packed macro-atom transition target can hold (tables.h MaTarget)
+    if (model->level_ndowntrans[i] >= MATGT_MAX_NTRANS || model->level_nuptrans[i] >= MATGT_MAX_NTRANS) {
+      g_last_error = "a level has more transitions than a packed transition target can describe";
+      return ARTIS_ERR_UNSUPPORTED;
+    }
+  }
+  for (int i = 0; i < model->nions; i++) {
+    if (model->ion_nlevels[i] >= MATGT_MAX_LEVEL) {
+      g_last_error = "an ion has more levels than a packed transition target can describe";
+      return ARTIS_ERR_UNSUPPORTED;
+    }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_last_error = "no HIP device: the artis_amd engine has no CPU path";
@@ -1169,6 +1181,10 @@ namespace {
 int engine_fill(artis_amd_engine *e, const artis_model *model) {
   const int device = e->device;
   e->Mh = make_host_model_view(*model, e->own);
+  if ((int64_t)e->Mh.nmacache / MAREC_ALIGN >= MATGT_MAX_RECUNITS) {
+    g_last_error = "a cell's macro-atom row is larger than a packed transition target can address";
+    return ARTIS_ERR_UNSUPPORTED;
+  }
   e->model_copy = *model;
   e->own_matransblock_start.assign(model->level_matransblock_start, model->level_matransblock_start + model->nlevels);
   e->model_copy.level_matransblock_start = e->own_matransblock_start.data();

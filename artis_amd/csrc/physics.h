@@ -1049,6 +1049,10 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   env.K.hotness[((int64_t)c * M.nlevels) + ul] = (h > 0.f && h <= 3.0e38f) ? h : 0.f;
 }
 // ---- hot block of a cell (tables.h): which levels, where, and the copies
+AHD MaTarget matgt_pack(const LevelPack &target, int level) {
+  return MaTarget{(uint64_t)(target.rec_off / MAREC_ALIGN) | ((uint64_t)level << 20) | ((uint64_t)target.ndown << 36) |
+                  ((uint64_t)target.nup << 50)};
+}
 AHD int marec_units(const LevelPack &lp) { return (marec_size(lp.ndown, lp.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN; }
 constexpr int HOT_UNITS = HOT_DOUBLES / MAREC_ALIGN;
 AHD uint32_t hot_key(float h) {  // positive floats order like their bit patterns
@@ -1103,7 +1107,7 @@ AHD void populate_hotfill(const Env &env, int c, int ul) {
   const int ntrans = lpk.ndown + lpk.nup;
   for (int i = 0; i < ntrans; i++) {
     const int tl = M.alltrans_targetlevelindex[lpk.alltrans_startdown + i];
-    tgt[i] = MaTarget{M.level_pack[start + tl].rec_off, (uint16_t)tl, off[start + tl]};
+    tgt[i] = matgt_pack(M.level_pack[start + tl], tl);
   }
   if (off[ul] >= 0) {
     double *dst = env.K.hotblk + ((int64_t)c * HOT_DOUBLES) + ((int)off[ul] * MAREC_ALIGN);
@@ -1818,9 +1822,9 @@ struct MACtx {
   const double *cellma;     // the cell's row of macro-atom records
   int start_key, start;     // cached get_ionuniquelevelindexstart(element, ion)
   int rec;                  // offset of the current level's record in the cell's row (ma_prepare, then carried by the walk)
+  int nd, nu;               // ... and its numbers of downward / upward transitions (where the record's blocks begin)
   int hot;                  // ... and its place in the cell's hot block (units of MAREC_ALIGN doubles), or -1
   const double *hotbase;    // where the cell's hot block is read from: its LDS copy (k_thermal) or the block in HBM
-  MaHeader hd;              // header of the record the last transition was drawn from
   int njumps;               // transitions made since the last ma_flush_stats()
 };
 AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
@@ -1832,8 +1836,8 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   k.start_key = -1;
   k.start = 0;
   k.rec = 0;
+  k.nd = k.nu = 0;
   k.hot = -1;
-  k.hd = MaHeader{0, 0, 0, 0, -1, 0};
   k.njumps = 0;
   return k;
 }
@@ -1872,7 +1876,10 @@ AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
 template <bool HOT = true>
 AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) {
   const int ul = ma_locate(env, p, k);
-  k.rec = env.M.level_pack[ul].rec_off;
+  const LevelPack lp = env.M.level_pack[ul];
+  k.rec = lp.rec_off;
+  k.nd = lp.ndown;
+  k.nu = lp.nup;
   k.hot = HOT ? (int)env.K.hotoff[((int64_t)k.c * env.M.nlevels) + ul] : -1;
 }
 // the current level's record: its copy in the hot block when there is one and the block is readable, else the cell's row
@@ -1886,16 +1893,16 @@ AHD const double *ma_record(const MACtx &k) {
 // for the slow path): its index is returned with its rate, and ma_jump_exit() carries it out. The split lets a kernel
 // keep the rare, long deactivation code out of its transition loop.
 constexpr int MA_EXIT_FAILED = 99;
+template <bool HOT = true>
 AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, double *rate_out) {
-  const MaHeader hd = *(const MaHeader *)rec;
-  k.hd = hd;
   // std::partial_sum macroatom.cc:425 and index_upperbound sn3d.h:85 over the 9 cumulative rates, kept in
   // registers (statically indexed): action = number of cumulative values <= randomrate, clamped to the last one
   double r[MA_N];
   {
     const D2 q0 = *(const D2 *)(rec + 2), q1 = *(const D2 *)(rec + 4), q2 = *(const D2 *)(rec + 6), q3 = *(const D2 *)(rec + 8);
     r[0] = q0.x; r[1] = q0.y; r[2] = q1.x; r[3] = q1.y; r[4] = q2.x; r[5] = q2.y; r[6] = q3.x; r[7] = q3.y;
-    r[8] = rec[10];
+    // MA_ACTION_INTERNALUPHIGHERNT: only NT_ON puts anything there (macroatom.cc:171); adding the 0 leaves cum[8] = cum[7]
+    r[8] = ARTIS_OPT_NT_ON ? rec[10] : 0.;
   }
   double cum[MA_N];
   cum[0] = r[0];
@@ -1920,16 +1927,19 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
   const bool down = (action == ARTIS_MA_ACTION_INTERNALDOWNSAME);
   if (down || action == ARTIS_MA_ACTION_INTERNALUPSAME) {
     // macroatom.cc:433-447 and 536-550: one search for both directions, so that a wave runs it once
-    const int ndown = hd.ndown;
-    const int nsel = down ? ndown : hd.nup;
+    const int ndown = k.nd;
+    const int nsel = down ? ndown : k.nu;
     const int first = down ? 0 : ndown;                       // first target of the direction
     const double *sums = rec + (down ? marec_down : marec_up(ndown));
     const double targetval = rng_uniform(p) * rate_sel;
     const int ti = ma_search(sums, nsel - 1, targetval);
-    const MaTarget tg = ((const MaTarget *)(rec + marec_tgt(ndown, hd.nup)))[first + ti];
-    p.ma_level = tg.level;
-    k.rec = tg.rec_off;
-    k.hot = tg.hot;
+    const uint64_t tg = ((const MaTarget *)(rec + marec_tgt(ndown, k.nu)))[first + ti].bits;
+    p.ma_level = (int)((tg >> 20) & 0xFFFF);
+    k.rec = (int)(tg & 0xFFFFF) * MAREC_ALIGN;
+    k.nd = (int)((tg >> 36) & 0x3FFF);
+    k.nu = (int)(tg >> 50);
+    // (only the LDS option asks where the target's copy sits in the cell's hot block)
+    k.hot = HOT ? (int)env.K.hotoff[((int64_t)k.c * env.M.nlevels) + (k.start + p.ma_level)] : -1;
     return -1;
   }
   *rate_out = rate_sel;
@@ -1938,7 +1948,7 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
 AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double *rec, int action, double rate_sel) {
   const DevModel &M = env.M;
   const int c = k.c;
-  const MaHeader hd = k.hd;  // of the record the action was drawn from: the packet's current level
+  const MaHeader hd = *(const MaHeader *)rec;  // of the record the action was drawn from: the packet's current level
   const int activatingline = p.ma_line;
   if (action == ARTIS_MA_ACTION_RADDEEXC) {
     // do_macroatom_raddeexcitation macroatom.cc:204
@@ -1949,8 +1959,8 @@ AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double
     const int lineindex = M.alltrans_lineindex[hd.alltrans_startdown + dti];
     if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
     const int ul = hd.ul;
-    const MaTarget tg = ((const MaTarget *)(rec + marec_tgt(ndown, hd.nup)))[dti];
-    const int lul = (ul - p.ma_level) + tg.level;
+    const uint64_t tg = ((const MaTarget *)(rec + marec_tgt(ndown, hd.nup)))[dti].bits;
+    const int lul = (ul - p.ma_level) + (int)((tg >> 20) & 0xFFFF);
     const double e_trans = eps(M, ul) - eps(M, lul);
     const double oldnucmf = p.nu_cmf;
     p.nu_cmf = e_trans / HPLANCK;

@@ -70,16 +70,20 @@ struct alignas(16) MaHeader {
   int32_t ul, alltrans_startdown;
   int16_t hot, pad;
 };
-struct alignas(8) MaTarget {
-  int32_t rec_off;  // offset (in doubles) of the target level's record in a cell's macache row
-  uint16_t level;   // the target level's index within its ion (alltrans.targetlevelindex)
-  int16_t hot;      // place of the target level's copy in the cell's hot block, or -1
+// What a transition needs to know about the level it leads to, in 8 bytes, so that the NEXT transition reads neither a
+// level table nor the target record's header: where the target's record is, which level it is, and how many downward
+// and upward transitions it has (= where the blocks of its record begin).
+struct MaTarget {
+  uint64_t bits;  // [0..20) record offset / MAREC_ALIGN   [20..36) level within its ion   [36..50) ndown   [50..64) nup
 };
+constexpr int64_t MATGT_MAX_RECUNITS = 1 << 20;  // rows up to 128 MB
+constexpr int MATGT_MAX_LEVEL = 1 << 16, MATGT_MAX_NTRANS = 1 << 14;
 static_assert(sizeof(MaHeader) == 16 && sizeof(MaTarget) == 8, "record header and target sizes");
 #ifndef ARTIS_HOT_DOUBLES
 #define ARTIS_HOT_DOUBLES 512  // 4 KB per cell
 #endif
 constexpr int HOT_DOUBLES = ARTIS_HOT_DOUBLES;
+constexpr int MAREC_ALIGN = 16;  // doubles
 constexpr int marec_even(int n) { return (n + 1) & ~1; }
 constexpr int marec_rates = 2;
 constexpr int marec_down = 12;
@@ -87,7 +91,6 @@ constexpr int marec_up(int ndown) { return marec_down + marec_even(ndown); }
 constexpr int marec_rad(int ndown, int nup) { return marec_up(ndown) + marec_even(nup); }
 constexpr int marec_tgt(int ndown, int nup) { return marec_rad(ndown, nup) + marec_even(ndown); }
 constexpr int marec_size(int ndown, int nup) { return marec_tgt(ndown, nup) + ndown + nup; }
-constexpr int MAREC_ALIGN = 16;  // doubles
 constexpr int MAREC_SLACK = 16;  // doubles past the last row that a padded search may touch
 
 struct alignas(16) D2 {
