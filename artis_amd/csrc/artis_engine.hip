@@ -423,10 +423,20 @@ struct Puller {
   bool exhausted;
 };
 __device__ inline int64_t chunk_begin(int32_t n, int c, int nchunks) { return ((int64_t)n * c) / nchunks; }
-__device__ inline void puller_init(Puller &q, int32_t n, int nchunks, bool per_block = false) {
-  const int xcd = blockIdx.x & 7;
-  // wave (or workgroup) index within its XCD
-  const int local = per_block ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+// chunk_mode: 0 = one chunk per wave (or fewer, shared in order), 1 = per workgroup, 2 = per COMPUTE UNIT (nchunks == 256):
+// the workgroups that the hardware placed on one CU walk one run of cells together, so the CU's L1 sees a handful of
+// cells. The CU is read from HW_REG_HW_ID (MI355X: 8 XCDs x 4 shader engines x 8 CUs, CU_ID 0..7 or 1..8).
+__device__ inline void puller_init(Puller &q, int32_t n, int nchunks, int chunk_mode = 0) {
+  int xcd = blockIdx.x & 7;
+  // wave / workgroup / CU index within its XCD
+  int local = (chunk_mode == 1) ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3) * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+  if (chunk_mode == 2) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcd = (int)(xcc & 7u);
+    local = (int)(((hwid >> 13) & 3u) * 8u + ((hwid >> 8) & 7u));
+  }
   q.nchunks = nchunks;
   q.cx = nchunks >> 3;
   q.home = xcd * q.cx + (local % q.cx);
@@ -489,11 +499,23 @@ inline int chunks_for(int64_t n, int nwaves) {
   return (int)std::min<int64_t>(c, MAX_CHUNKS);
 }
 
-// r-packets in flight: boundary distance, continuum opacity, line-by-line Sobolev walk, estimators, events
+// r-packets in flight: boundary distance, continuum opacity, line-by-line Sobolev walk, estimators, events.
+// CONT_LDS: the static table of bound-free continua (ContPack: edge frequency, target probability, cross-section table,
+// ground-continuum index; 32 B per continuum) is copied into LDS once per workgroup and every read of it in the opacity
+// sum (rpkt.cc:721, two of the ~five reads per continuum visited) is a ds_read that does not touch the vector L1.
+constexpr int CONT_LDS_MAX = 2048;  // continua (64 KB per workgroup, two workgroups per CU)
+template <bool CONT_LDS>
 __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const int32_t *list, int32_t n, Lists next,
                                                                    unsigned long long *gstats, int budget, int32_t *cursors, int nchunks) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
+  __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  if (CONT_LDS) {
+    const D2 *src = (const D2 *)env.M.cont_pack;
+    D2 *dst = (D2 *)lds_cont;
+    for (int i = threadIdx.x; i < env.M.nbfcontinua * 2; i += BLOCK) dst[i] = src[i];
+    env.M.cont_pack = lds_cont;
+  }
   __syncthreads();
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
@@ -692,7 +714,7 @@ __device__ inline int hot_acquire(HotSlots &hs, double *hot_lds, const Env &env,
 template <bool USE_LDS, int TB>
 __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                      unsigned long long *gstats, int budget, int32_t *cursors,
-                                                                     int nchunks) {
+                                                                     int nchunks, int chunk_mode) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ HotSlots hs;
   __shared__ double __attribute__((aligned(16))) hot_lds[USE_LDS ? NSLOT * HOT_DOUBLES : 2];
@@ -709,7 +731,7 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
   Puller q;
-  puller_init(q, n, nchunks, /*per_block=*/USE_LDS);
+  puller_init(q, n, nchunks, USE_LDS ? 1 : chunk_mode);
   bool have = false;
   int32_t pi = 0;
   int units = 0;
@@ -947,6 +969,9 @@ struct artis_amd_engine {
   // (a wave's lanes share continuum windows and line ranges), k_thermal +30 % (every wave then has its own cells in
   // flight and the L2 working set of macro-atom records triples)
   bool wave_chunks_r = true, wave_chunks_t = false;
+  bool cu_chunks_t = false;  // ARTIS_AMD_CUCHUNKS_T=1: k_thermal takes one list chunk per compute unit (HW_REG_HW_ID);
+                             // measured +7 %: like every finer chunking it puts more cells in flight per XCD
+  bool cont_lds = true;      // k_rpkt keeps the static continuum table (ContPack) in LDS when it fits (ARTIS_AMD_CONTLDS=0: HBM)
   // ARTIS_AMD_HOTLDS=1: the cells' hot blocks of macro-atom records are staged in LDS (k_thermal<true>). Parity-tested;
   // measured slower than reading them from HBM on MI355X (profiles/r02/lds_staging.md), so it is off by default.
   bool hot_lds = false;
@@ -1288,6 +1313,8 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_R")) e->wave_chunks_r = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_T")) e->wave_chunks_t = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_CUCHUNKS_T")) e->cu_chunks_t = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_CONTLDS")) e->cont_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_HOTLDS")) e->hot_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_HOTBLOCKS")) e->hot_blocks = std::atoi(b) != 0;
   e->hot_blocks = e->hot_blocks || e->hot_lds;
@@ -1619,8 +1646,11 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       HIP_TRY(hipEventRecord(e->ev0, s));
       if (kind == NEXT_RPKT) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
-        hipLaunchKernelGGL(k_rpkt, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors,
-                           e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
+        const int nch = e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8;
+        if (e->cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0)
+          hipLaunchKernelGGL((k_rpkt<true>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch);
+        else
+          hipLaunchKernelGGL((k_rpkt<false>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch);
       } else if (kind == NEXT_GAMMA) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_GAMMA_WAVES);
         hipLaunchKernelGGL(k_gamma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r * 8, e->d_cursors,
@@ -1632,13 +1662,14 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
           const int per_cu = std::max(1, e->thermal_blocks_per_cu * BLOCK / TBLOCK);
           const int grid = std::min((int)((nk + TBLOCK - 1) / TBLOCK), e->ncu * per_cu);
           hipLaunchKernelGGL((k_thermal<true, TBLOCK>), dim3(grid), dim3(TBLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
-                             e->d_cursors, chunks_for(nk, grid));
+                             e->d_cursors, chunks_for(nk, grid), 1);
         } else
 #endif
         {
           const int grid = std::min(nblocks(nk), e->ncu * e->thermal_blocks_per_cu);
+          const bool per_cu = e->cu_chunks_t && nk >= 256 * 1024;
           hipLaunchKernelGGL((k_thermal<false, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
-                             e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
+                             e->d_cursors, per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8), per_cu ? 2 : 0);
         }
       } else if (kind == NEXT_BB) {
         hipLaunchKernelGGL(k_blackbody, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);
