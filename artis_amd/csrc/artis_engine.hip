@@ -515,6 +515,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
     D2 *dst = (D2 *)lds_cont;
     for (int i = threadIdx.x; i < env.M.nbfcontinua * 2; i += BLOCK) dst[i] = src[i];
     env.M.cont_pack = lds_cont;
+    env.cont_in_lds = 1;
   }
   __syncthreads();
   env.stats = lstats;

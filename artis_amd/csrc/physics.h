@@ -101,6 +101,7 @@ struct Env {
   // cell waits for that cell's tile (classify()). One tile = all cells unless the cache would not fit in HBM.
   int32_t tile_lo, tile_hi;
   int32_t tile_all;  // the tile covers every cell (the usual case): in_tile() needs no look-up
+  int32_t cont_in_lds;  // M.cont_pack points into LDS (k_rpkt<true>)
 };
 // the packet's cell is empty (no cache needed) or its cache row is resident
 AHD bool in_tile(const Env &env, int cellindex) {
@@ -394,6 +395,16 @@ AHD int partition_point_d(const double *a, int n, Pred pred) {
   while (len > 0) {
     const int half = len / 2;
     if (pred(a[lo + half])) { lo += half + 1; len -= half + 1; } else { len = half; }
+  }
+  return lo;
+}
+// the same over an index range [0, n) with the predicate given the index
+template <class Pred>
+AHD int partition_point_f(int n, Pred pred) {
+  int lo = 0, len = n;
+  while (len > 0) {
+    const int half = len / 2;
+    if (pred(lo + half)) { lo += half + 1; len -= half + 1; } else { len = half; }
   }
   return lo;
 }
@@ -1320,8 +1331,18 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   const float T_e = env.C.Te[c];
   const double ex = exp(-HOVERKB * nu / T_e);
   const bool split_usable = (ex >= DBLMIN);
-  const int cend = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
-  const int cbegin = lower_bound_d(M.allcont_nu_edge, cend, nu / M.last_phixs_nuovernuedge);
+  // the window of continua whose edge lies in (nu / last_phixs_nuovernuedge, nu] (rpkt.cc:745-760). With the continuum
+  // table in LDS (k_rpkt) the two bisections read the edges from it (stride 32 B) instead of from the dense array in HBM.
+  int cend, cbegin;
+  if (env.cont_in_lds) {
+    const double nu_lo = nu / M.last_phixs_nuovernuedge;
+    const ContPack *cpk = M.cont_pack;
+    cend = partition_point_f(M.nbfcontinua, [cpk, nu](int i) { return !(nu < cpk[i].nu_edge); });
+    cbegin = partition_point_f(cend, [cpk, nu_lo](int i) { return cpk[i].nu_edge < nu_lo; });
+  } else {
+    cend = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
+    cbegin = lower_bound_d(M.allcont_nu_edge, cend, nu / M.last_phixs_nuovernuedge);
+  }
   int nvisited = 0;
   const D2 *pairs = env.K.allcont_pair + ((int64_t)c * M.nbfcontinua);  // {nnlevel, edgepart}
   const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
