@@ -147,7 +147,12 @@ _CELL_FIELDS = [
     ("ion_groundlevelpops", _F32P, np.float32), ("ion_partfuncts", _F32P, np.float32),
     ("elem_massfracs", _F32P, np.float32), ("corrphotoionrenorm", _F64P, np.float64),
     ("ffegrp", _F32P, np.float32),
+    # optional (NULL when absent from the dict): host level populations, host photoionisation coefficients, multibin field
+    ("levelpops", _F64P, np.float64), ("corrphotoioncoeff", _F64P, np.float64),
+    ("radfieldbin_W", _F32P, np.float32), ("radfieldbin_T_R", _F32P, np.float32),
 ]
+_CELL_OPTIONAL = ("levelpops", "corrphotoioncoeff", "radfieldbin_W", "radfieldbin_T_R")
+RADFIELDBINCOUNT = 256
 
 
 class CModel(C.Structure):
@@ -167,7 +172,8 @@ class CEstimators(C.Structure):
     _fields_ = [("J", _F64P), ("nuJ", _F64P), ("ffheatingestimator", _F64P), ("colheatingestimator", _F64P),
                 ("gammaestimator", _F64P), ("bfheatingestimator", _F64P), ("stats", _I64P),
                 ("dep_estimator_gamma", _F64P), ("scalars", _F64P), ("dep_estimator_electron", _F64P),
-                ("dep_estimator_positron", _F64P), ("dep_estimator_alpha", _F64P)]
+                ("dep_estimator_positron", _F64P), ("dep_estimator_alpha", _F64P),
+                ("radfieldbin_J", _F64P), ("radfieldbin_nuJ", _F64P), ("bfrate_raw", _F64P)]
 
 
 def _as_ptr(arr: np.ndarray, ptype):
@@ -214,6 +220,8 @@ class CellState:
         self.d = {}
         self.c = CCellState()
         for name, ctype, npdt in _CELL_FIELDS:
+            if name in _CELL_OPTIONAL and d.get(name) is None:
+                continue  # stays a NULL pointer
             arr = np.ascontiguousarray(d[name], dtype=npdt)
             if arr.size == 0:
                 arr = np.zeros(1, dtype=npdt)
@@ -238,8 +246,13 @@ class Timestep:
 class Estimators:
     """Host estimator arrays (accumulated into by update_packets)."""
 
-    def __init__(self, npts_nonempty: int, nbfcontinua_ground: int):
+    def __init__(self, npts_nonempty: int, nbfcontinua_ground: int, nbfcontinua: int = 0):
+        """nbfcontinua > 0: also the estimators of the nltenebular options (radiation-field bins, detailed bound-free)"""
         n, g = npts_nonempty, max(nbfcontinua_ground, 1)
+        self.radfieldbin_J = np.zeros(n * RADFIELDBINCOUNT if nbfcontinua > 0 else 1)
+        self.radfieldbin_nuJ = np.zeros(n * RADFIELDBINCOUNT if nbfcontinua > 0 else 1)
+        self.bfrate_raw = np.zeros(n * nbfcontinua if nbfcontinua > 0 else 1)
+        self.extended = nbfcontinua > 0
         self.J = np.zeros(n)
         self.nuJ = np.zeros(n)
         self.ffheatingestimator = np.zeros(n)
@@ -258,13 +271,18 @@ class Estimators:
             _as_ptr(self.bfheatingestimator, _F64P), _as_ptr(self.stats, _I64P),
             _as_ptr(self.dep_estimator_gamma, _F64P), _as_ptr(self.scalars, _F64P),
             _as_ptr(self.dep_estimator_electron, _F64P), _as_ptr(self.dep_estimator_positron, _F64P),
-            _as_ptr(self.dep_estimator_alpha, _F64P))
+            _as_ptr(self.dep_estimator_alpha, _F64P),
+            _as_ptr(self.radfieldbin_J, _F64P) if self.extended else None,
+            _as_ptr(self.radfieldbin_nuJ, _F64P) if self.extended else None,
+            _as_ptr(self.bfrate_raw, _F64P) if self.extended else None)
 
     def ref(self):
         return C.byref(self.c)
 
     def arrays(self):
-        return {"J": self.J, "nuJ": self.nuJ, "ffheatingestimator": self.ffheatingestimator,
+        ext = {"radfieldbin_J": self.radfieldbin_J, "radfieldbin_nuJ": self.radfieldbin_nuJ,
+               "bfrate_raw": self.bfrate_raw} if self.extended else {}
+        return {**ext, "J": self.J, "nuJ": self.nuJ, "ffheatingestimator": self.ffheatingestimator,
                 "colheatingestimator": self.colheatingestimator, "gammaestimator": self.gammaestimator,
                 "bfheatingestimator": self.bfheatingestimator, "dep_estimator_gamma": self.dep_estimator_gamma,
                 "scalars": self.scalars, "dep_estimator_electron": self.dep_estimator_electron,
@@ -272,6 +290,12 @@ class Estimators:
 
     def stats_dict(self):
         return {STAT_NAMES[i]: int(self.stats[i]) for i in range(NSTATS)}
+
+
+def estimators_for(model, options: str = "classic") -> Estimators:
+    """Estimator arrays sized for a model under an options preset (nltenebular adds the bin and bound-free arrays)"""
+    ext = model["nbfcontinua"] if options == "nltenebular" else 0
+    return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"], ext)
 
 
 def packets_ptr(packets: np.ndarray):

@@ -14,7 +14,7 @@ SOURCES = ["artis_engine.hip", "physics.h", "tables.h", "model_build.h"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-munsafe-fp-atomics", "-ldl"]
 
 
-PRESETS = ("classic", "kilonova_lte")  # options presets of include/artis_options.h (the reference's artisoptions_*.h)
+PRESETS = ("classic", "kilonova_lte", "nltenebular")  # options presets of include/artis_options.h (the reference's artisoptions_*.h)
 
 
 def so_path(preset: str = "classic") -> str:

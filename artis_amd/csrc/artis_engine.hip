@@ -1134,9 +1134,11 @@ const RcclApi &rccl_api() {
 extern "C" {
 
 const char *artis_amd_last_error(void) { return g_last_error.c_str(); }
-int artis_amd_abi_version(void) { return 2; }
+int artis_amd_abi_version(void) { return 3; }
 const char *artis_amd_options_preset(void) {
-#ifdef ARTIS_PRESET_KILONOVA_LTE
+#if defined(ARTIS_PRESET_NLTENEBULAR)
+  return "nltenebular";
+#elif defined(ARTIS_PRESET_KILONOVA_LTE)
   return "kilonova_lte";
 #else
   return "classic";
@@ -1271,7 +1273,10 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   // estimators: one contiguous block [J | nuJ | ff | col | gamma | bfheat | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars]
   const int64_t ncell = ncell_all;  // estimators cover every cell
   const int64_t g = h.nbfcontinua_ground > 0 ? h.nbfcontinua_ground : 1;
-  e->est_ndoubles = ncell * 8 + 2 * ncell * g + ARTIS_NSCALARS;  // ... | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars]
+  // ... | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars | (radfieldbin_J | radfieldbin_nuJ) | (bfrate_raw)]
+  const int64_t nbinest = ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON ? ncell * ARTIS_OPT_RADFIELDBINCOUNT : 0;
+  const int64_t nbfest = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? ncell * (int64_t)h.nbfcontinua : 0;
+  e->est_ndoubles = ncell * 8 + 2 * ncell * g + ARTIS_NSCALARS + 2 * nbinest + nbfest;
   HIP_TRY(hipMalloc((void **)&e->d_est, sizeof(double) * (size_t)e->est_ndoubles));
   HIP_TRY(hipMemset(e->d_est, 0, sizeof(double) * (size_t)e->est_ndoubles));
   e->E.J = e->d_est;
@@ -1285,6 +1290,9 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   e->E.dep_estimator_positron = e->d_est + 6 * ncell + 2 * ncell * g;
   e->E.dep_estimator_alpha = e->d_est + 7 * ncell + 2 * ncell * g;
   e->E.scalars = e->d_est + 8 * ncell + 2 * ncell * g;
+  e->E.radfieldbin_J = nbinest ? e->E.scalars + ARTIS_NSCALARS : nullptr;
+  e->E.radfieldbin_nuJ = nbinest ? e->E.radfieldbin_J + nbinest : nullptr;
+  e->E.bfrate_raw = nbfest ? e->E.scalars + ARTIS_NSCALARS + 2 * nbinest : nullptr;
   HIP_TRY(hipMalloc((void **)&e->d_stats, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
@@ -1378,6 +1386,25 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
   }
   ARTIS_CELL_ARRAYS(UPC, h)
 #undef UPC
+#define UPO(f, T, count)                                                                     \
+  {                                                                                          \
+    e->C.f = nullptr;                                                                        \
+    if (hc.f) {                                                                              \
+      int rc = upload_array<T>(e->cell_allocs, hc.f, (int64_t)(count), (const T **)&e->C.f); \
+      if (rc != ARTIS_OK) return rc;                                                         \
+    }                                                                                        \
+  }
+  ARTIS_CELL_OPTIONAL_ARRAYS(UPO, h)
+#undef UPO
+  // what the options this library was built with need from the host
+  if (!ARTIS_OPT_USE_LUT_PHOTOION && h.nphixstargets_total > 0 && !e->C.corrphotoioncoeff) {
+    g_last_error = "this build has USE_LUT_PHOTOION off: artis_cellstate.corrphotoioncoeff is required";
+    return ARTIS_ERR_ARG;
+  }
+  if (ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON && (!e->C.radfieldbin_W || !e->C.radfieldbin_T_R)) {
+    g_last_error = "this build has the multibin radiation field on: artis_cellstate.radfieldbin_W / _T_R are required";
+    return ARTIS_ERR_ARG;
+  }
   e->S = make_step(*ts);
   e->have_cells = true;
   return artis_amd_populate_cellcache(e, nullptr);
@@ -1743,6 +1770,16 @@ int artis_amd_estimators_download(artis_amd_engine *e, artis_estimators *est) {
   add(est->dep_estimator_positron, src + 6 * ncell + 2 * ncell * g, ncell);
   add(est->dep_estimator_alpha, src + 7 * ncell + 2 * ncell * g, ncell);
   add(est->scalars, src + 8 * ncell + 2 * ncell * g, ARTIS_NSCALARS);
+  {
+    const int64_t nbinest = ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON ? ncell * ARTIS_OPT_RADFIELDBINCOUNT : 0;
+    const int64_t nbfest = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? ncell * (int64_t)e->Mh.nbfcontinua : 0;
+    const double *ext = src + 8 * ncell + 2 * ncell * g + ARTIS_NSCALARS;
+    if (nbinest) {
+      add(est->radfieldbin_J, ext, nbinest);
+      add(est->radfieldbin_nuJ, ext + nbinest, nbinest);
+    }
+    if (nbfest) add(est->bfrate_raw, ext + 2 * nbinest, nbfest);
+  }
   if (est->stats) {
     unsigned long long st[ARTIS_NSTATS];
     HIP_TRY(hipMemcpy(st, e->d_stats, sizeof(st), hipMemcpyDeviceToHost));

@@ -101,6 +101,13 @@ struct ModelOwned {
   X(corrphotoionrenorm, double, ((int64_t)(m).npts_nonempty * ((m).nbfcontinua_ground > 0 ? (m).nbfcontinua_ground : 1))) \
   X(ffegrp, float, (m).npts_nonempty)
 
+// the optional arrays of DevCells (uploaded only when the caller hands them over)
+#define ARTIS_CELL_OPTIONAL_ARRAYS(X, m)                                                            \
+  X(levelpops, double, ((int64_t)(m).npts_nonempty * (m).nlevels))                                  \
+  X(corrphotoioncoeff, double, ((int64_t)(m).npts_nonempty * (m).nphixstargets_total))              \
+  X(radfieldbin_W, float, ((int64_t)(m).npts_nonempty * ARTIS_OPT_RADFIELDBINCOUNT))                \
+  X(radfieldbin_T_R, float, ((int64_t)(m).npts_nonempty * ARTIS_OPT_RADFIELDBINCOUNT))
+
 // X(field, element type, elements per cell) for every array of DevCache
 #define ARTIS_CACHE_ARRAYS(X, m)                                \
   X(levelpops, double, (m).nlevels)                             \
@@ -248,6 +255,10 @@ inline DevCells make_host_cells_view(const artis_cellstate &c) {
   v.ion_groundlevelpops = c.ion_groundlevelpops; v.ion_partfuncts = c.ion_partfuncts; v.elem_massfracs = c.elem_massfracs;
   v.corrphotoionrenorm = c.corrphotoionrenorm;
   v.ffegrp = c.ffegrp;
+  v.levelpops = c.levelpops;
+  v.corrphotoioncoeff = c.corrphotoioncoeff;
+  v.radfieldbin_W = c.radfieldbin_W;
+  v.radfieldbin_T_R = c.radfieldbin_T_R;
   return v;
 }
 

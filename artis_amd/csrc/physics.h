@@ -683,7 +683,36 @@ AHD double nnion(const Env &env, int c, int element, int ion) {  // ltepop.h:106
          statw(env.M, lstart(env.M, element, ion));
 }
 AHD double planck(double nu, double T) { return 2 * HPLANCK * pow3(nu) / pow2(CLIGHT) / expm1(HOVERKB * nu / T); }  // radfield.h:50
-AHD double radfield(const Env &env, double nu, int c) { return env.C.W[c] * planck(nu, env.C.TR[c]); }              // radfield.cc:786
+// multibin radiation field model: bins radfield.cc:118-161 (RADFIELDBINCOUNT - 1 bins of equal width from NU_MIN to
+// NU_MAX, then the "T_e superbin" up to SUPERBIN_NU_MAX)
+constexpr double RADBIN_DELTA_NU = (ARTIS_OPT_RADFIELDBINS_NU_MAX - ARTIS_OPT_RADFIELDBINS_NU_MIN) / (ARTIS_OPT_RADFIELDBINCOUNT - 1);  // radfield.cc:73
+AHD double radbin_nu_upper(int b) {  // get_bin_nu_upper radfield.cc:118
+  if (b == ARTIS_OPT_RADFIELDBINCOUNT - 1) return ARTIS_OPT_RADFIELDBINS_T_E_SUPERBIN_NU_MAX;
+  return ARTIS_OPT_RADFIELDBINS_NU_MIN + ((b + 1) * RADBIN_DELTA_NU);
+}
+AHD int radbin_select(double nu) {  // select_bin radfield.cc:138 (get_linearbinindex sn3d.h:115)
+  if (nu < ARTIS_OPT_RADFIELDBINS_NU_MIN) return -2;
+  if (nu >= ARTIS_OPT_RADFIELDBINS_T_E_SUPERBIN_NU_MAX) return -1;
+  if (nu >= ARTIS_OPT_RADFIELDBINS_NU_MAX) return ARTIS_OPT_RADFIELDBINCOUNT - 1;
+  const double fracindex = (nu - ARTIS_OPT_RADFIELDBINS_NU_MIN) / RADBIN_DELTA_NU;
+  const int64_t truncated = (int64_t)fracindex;
+  const int b = (int)((fracindex < (double)truncated) ? truncated - 1 : truncated);
+  if (nu == radbin_nu_upper(b)) return b + 1;
+  return b;
+}
+AHD double radfield(const Env &env, double nu, int c) {  // radfield.cc:786
+#if ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON
+  if (env.S.nts >= ARTIS_OPT_FIRST_NLTE_RADFIELD_TIMESTEP) {
+    const int b = radbin_select(nu);
+    if (b >= 0) {
+      const float W = env.C.radfieldbin_W[((int64_t)c * ARTIS_OPT_RADFIELDBINCOUNT) + b];
+      if (W >= 0.) return W * planck(nu, env.C.radfieldbin_T_R[((int64_t)c * ARTIS_OPT_RADFIELDBINCOUNT) + b]);
+    }
+    return 0.;
+  }
+#endif
+  return env.C.W[c] * planck(nu, env.C.TR[c]);
+}
 
 // ---------------------------------------------------------------- ratecoeff.cc LUTs
 AHD int temperature_upperindex(const DevModel &M, double T) {  // ratecoeff.cc:54
@@ -789,6 +818,10 @@ AHD double col_exc(const DevModel &M, float T_e, float cnne, double epsilon_tran
 // one (cell, level): calculate_levelpop ltepop.cc:412 / calculate_levelpop_boltzmann ltepop.cc:395
 AHD void populate_levelpop(const Env &env, int c, int ul) {
   const DevModel &M = env.M;
+  if (env.C.levelpops) {  // the host's NLTE / LTE solution (get_levelpop ltepop.cc:169)
+    env.K.levelpops[((int64_t)c * M.nlevels) + ul] = env.C.levelpops[((int64_t)c * M.nlevels) + ul];
+    return;
+  }
   const int ui = M.level_ion[ul];
   const int element = M.ion_element[ui];
   const int ion = ui - M.elem_uniqueionindexstart[element];
@@ -874,10 +907,17 @@ AHD void populate_corrphotoion(const Env &env, int c, int ul, int t) {
   const DevModel &M = env.M;
   const double W = env.C.W[c];
   const double T_R = env.C.TR[c];
+  const int64_t o = ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t;
+#if ARTIS_OPT_USE_LUT_PHOTOION
   double g = W * lerp_or_last(M, M.corrphotoioncoeffs, ul, t, (float)T_R);
   const int ig = M.level_closestgroundlevelcont[ul];
   if (ig >= 0) g *= env.C.corrphotoionrenorm[((int64_t)c * M.nbfcontinua_ground) + ig];
-  const int64_t o = ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t;
+#else
+  // the estimator-based / integrated coefficient of get_corrphotoioncoeff() (ratecoeff.cc:840) comes from the host
+  (void)W;
+  (void)T_R;
+  const double g = env.C.corrphotoioncoeff[o];
+#endif
   env.K.corrphotoioncoeff[o] = g;
   const int ui = M.level_ion[ul];
   const int element = M.ion_element[ui];
@@ -1422,6 +1462,52 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   if (!isfinite(sum)) fail(env, 30);
   return sum;
 }
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+// radfield::update_bfestimators radfield.cc:215. The reference keeps, per packet, the contribution sigma_contr of every
+// continuum of the window that calculate_chi_bf_gammacontr() walked at the frequency x.nu (Phixslist::gamma_contr), and
+// adds it to bfrate_raw for the continua that are still in the window at the packet's present frequency. Here the
+// contributions are not kept (nbfcontinua doubles per packet) but recomputed: same cell, same x.nu, same arithmetic as
+// in chi_bf_gammacontr(), so the same bits. Every continuum has an estimator (LEVEL_HAS_BFEST true), so the estimator
+// index is the continuum index.
+AHD void update_bfestimators(const Env &env, int c, double de, double nu_cmf, const Chi &x) {
+  const DevModel &M = env.M;
+  const double de_over_nu = de / nu_cmf;
+  const double nu = x.nu;  // the frequency the contributions belong to
+  // the window stored with the opacity (rpkt.cc:762-768) ...
+  const int end_s = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
+  const int begin_s = lower_bound_d(M.allcont_nu_edge, end_s, nu / M.last_phixs_nuovernuedge);
+  // ... narrowed to the packet's present frequency (radfield.cc:229-244)
+  const int end_n = upper_bound_d(M.allcont_nu_edge, end_s, nu_cmf);
+  const int b0 = begin_s < end_n ? begin_s : end_n;
+  const int begin_n = b0 + lower_bound_d(M.allcont_nu_edge + b0, end_n - b0, nu_cmf / M.last_phixs_nuovernuedge);
+  if (begin_n >= end_n) return;
+  const float T_e = env.C.Te[c];
+  const double ex = exp(-HOVERKB * nu / T_e);
+  const bool split_usable = (ex >= DBLMIN);
+  const D2 *pairs = env.K.allcont_pair + ((int64_t)c * M.nbfcontinua);
+  const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
+  KeepIter it;
+  it.keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
+  it.cbegin = begin_n;
+  it.cend = end_n;
+  it.word = begin_n / 64;
+  it.bits = keep_masked(it);
+  for (int i = keep_next(it); i >= 0; i = keep_next(it)) {
+    const ContPack cp = M.cont_pack[i];
+    const double sigma_bf = phixs_fromtable(M, M.allphixs + cp.xs_off, cp.nu_edge, nu);
+    const double ep = pairs[i].y;
+    double stim;
+    if (ep >= 0. && split_usable) {
+      stim = ep * ex;
+    } else {
+      stim = departure[i] * exp(-HOVERKB * (nu - cp.nu_edge) / T_e);
+    }
+    const double corr = dmax(0., 1 - stim);
+    const double sigma_contr = sigma_bf * cp.probability * corr;
+    ARTIS_EST_ADD(&env.E.bfrate_raw[((int64_t)c * M.nbfcontinua) + i], sigma_contr * de_over_nu);
+  }
+}
+#endif
 // calculate_chi_rpkt_cont<true> rpkt.cc:1021 with calculate_chi_ffheating rpkt.cc:697
 AHD void chi_rpkt_cont(const Env &env, double nu_cmf, Chi &x, int c, int64_t slot) {
   if ((c == x.nonemptymgi) && (fabs((x.nu / nu_cmf) - 1.0) < 1e-4)) return;
@@ -2176,6 +2262,19 @@ AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double d
     ARTIS_EST_ADD(&env.E.nuJ[c], de * nu_cmf);
   }
   if (thick) return;
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+  if (de != 0) update_bfestimators(env, c, de, nu_cmf, x);
+#endif
+#if ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON
+  if (de != 0) {  // radfield.cc:762-770
+    const int b = radbin_select(nu_cmf);
+    if (b >= 0) {
+      const int64_t k = ((int64_t)c * ARTIS_OPT_RADFIELDBINCOUNT) + b;
+      ARTIS_EST_ADD(&env.E.radfieldbin_J[k], de);
+      ARTIS_EST_ADD(&env.E.radfieldbin_nuJ[k], de * nu_cmf);
+    }
+  }
+#endif
   ARTIS_EST_ADD(&env.E.ffheatingestimator[c], de * x.chi_freefree_heat);
 #if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
   // update_bfestimators rpkt.cc:519: the loop runs over the ground continua in rising nu_edge until nu_cmf <= nu_edge;

@@ -154,6 +154,10 @@ struct DevCells {
   const float *ion_groundlevelpops, *ion_partfuncts, *elem_massfracs;
   const double *corrphotoionrenorm;
   const float *ffegrp;  // may be null on the host view (then the engine uploads zeros)
+  // optional / option-dependent (include/artis_amd.h artis_cellstate): null when not handed over
+  const double *levelpops;           // [cell][nlevels] host level populations
+  const double *corrphotoioncoeff;   // [cell][nphixstargets_total] host photoionisation coefficients (USE_LUT_PHOTOION off)
+  const float *radfieldbin_W, *radfieldbin_T_R;  // [cell][RADFIELDBINCOUNT] multibin radiation field
 };
 
 struct DevCache {
@@ -189,6 +193,9 @@ struct DevEst {
   double *dep_estimator_gamma;  // [cell] gammapkt.cc:568
   double *dep_estimator_electron, *dep_estimator_positron, *dep_estimator_alpha;  // [cell] update_packets.cc:160-173
   double *scalars;              // [ARTIS_NSCALARS]
+  // builds with the multibin radiation field / detailed bound-free estimators (else null)
+  double *radfieldbin_J, *radfieldbin_nuJ;  // [cell][RADFIELDBINCOUNT] radfield.cc:745-790
+  double *bfrate_raw;                       // [cell][nbfcontinua] radfield.cc:215
 };
 
 // Packet population in HBM: three arrays of cache-line records, slot-major ("structure of lines").

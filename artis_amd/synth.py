@@ -55,7 +55,8 @@ def _ionpot_ev(Z: int, stage: int) -> float:
 
 
 # rate-coefficient table grids of the options presets (include/artis_options.h: TABLESIZE, MINTEMP, MAXTEMP)
-OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0, 150000.0)}
+OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0, 150000.0),
+                 "nltenebular": (100, 1000.0, 30000.0)}
 
 
 def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fraction: float = 0.4,
@@ -640,6 +641,35 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     md = {k: v for k, v in atomic.items() if not k.startswith("_")}
     md.update(grid)
     model = abi.Model(md)
+    if options == "nltenebular":
+        cells.update(nebular_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 200))
     cs = abi.CellState(cells)
     ts = make_timestep(aux["t"], width_frac=width_frac, vmax=grid["vmax"], nts=nts)
     return model, cs, ts, aux
+
+
+def nebular_cellstate(atomic: dict, cells: dict, ncell: int, seed: int = 201) -> dict:
+    """What the host's NLTE / radiation-field solvers hand to the packet path under artisoptions_nltenebular.h
+    (include/artis_amd.h artis_cellstate): level populations with departures from LTE, photoionisation coefficients of
+    every bound-free pair, and W, T_R of the 256 radiation-field bins (a few bins without a solution: W = -1)."""
+    rng = np.random.default_rng(seed)
+    eps = np.asarray(atomic["level_epsilon"])
+    g = np.asarray(atomic["level_statweight"], dtype=np.float64)
+    level_ion = atomic["_level_ion"]
+    ion_uls = np.asarray(atomic["ion_uniquelevelindexstart"])
+    nlevels, nions = len(eps), atomic["nions"]
+    Te = np.asarray(cells["Te"], dtype=np.float64)
+    ground = np.asarray(cells["ion_groundlevelpops"], dtype=np.float64).reshape(ncell, nions)
+    start = ion_uls[level_ion]
+    # Boltzmann at T_e times a departure coefficient (ground levels keep the ion's ground population)
+    boltz = g[None, :] / g[start][None, :] * np.exp(-(eps - eps[start])[None, :] / (KB * Te[:, None]))
+    dep = np.exp(rng.normal(0.0, 0.5, size=(ncell, nlevels)))
+    dep[:, ion_uls] = 1.0
+    pops = np.maximum(ground[:, level_ion] * boltz * dep, 1e-40)
+    npt = atomic["nphixstargets_total"]
+    corr = 10 ** rng.uniform(-4.0, 1.0, size=(ncell, max(npt, 1))) * np.asarray(cells["W"], dtype=np.float64)[:, None]
+    nb = abi.RADFIELDBINCOUNT
+    W = np.asarray(cells["W"], dtype=np.float64)[:, None] * rng.uniform(0.3, 1.7, size=(ncell, nb))
+    W[rng.random((ncell, nb)) < 0.05] = -1.0
+    TR = np.asarray(cells["TR"], dtype=np.float64)[:, None] * rng.uniform(0.7, 1.3, size=(ncell, nb))
+    return dict(levelpops=pops.ravel(), corrphotoioncoeff=corr.ravel(), radfieldbin_W=W.ravel(), radfieldbin_T_R=TR.ravel())

@@ -71,7 +71,7 @@ def _cpu_worker(args):
     from oracle import oracle_py
 
     sub = pk[lo:hi].copy()
-    est = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
+    est = abi.estimators_for(model, _cpu_worker.options)
     t0 = time.perf_counter()
     oracle_py.update_packets(model, cs, ts, sub, est, preset=_cpu_worker.options)
     wall = time.perf_counter() - t0
@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=160_000)
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--options", default="classic", choices=("classic", "kilonova_lte"),
+    ap.add_argument("--options", default="classic", choices=("classic", "kilonova_lte", "nltenebular"),
                     help="options preset of include/artis_options.h (the reference's artisoptions_*.h)")
     args = ap.parse_args()
 
@@ -141,7 +141,7 @@ def main():
     pk = synth.make_packets(model, aux, args.packets, seed_base=seed_base, kpkt_fraction=0.02, seed=99 + rank)
 
     baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
         cores = args.cpu_cores or min(os.cpu_count() or 1, 16)
         baseline = cpu_baseline(model, cs, ts, pk, args.cpu_sample, cores, args.options)  # before any GPU initialisation (fork)
 
@@ -226,7 +226,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    est = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
+    est = abi.estimators_for(model, args.options)
     # counters of the last step (identical every step: packet histories are deterministic)
     # the all-reduced estimator block is not needed here; only the per-rank event counters
     import ctypes as C

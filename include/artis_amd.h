@@ -288,6 +288,17 @@ typedef struct artis_cellstate {
   /* [npts_nonempty] grid::get_ffegrp(mgi): iron-group mass fraction, read by the gamma-ray opacities
    * (gammapkt.cc:416, :516). May be NULL when no TYPE_GAMMA packet is handed over (treated as 0). */
   const float *ffegrp;
+  /* [npts_nonempty*nlevels] level populations from the host's NLTE / LTE solution (ltepop.cc:169-180 get_levelpop); NULL:
+   * the engine evaluates the LTE populations itself (calculate_levelpop_lte ltepop.cc:395) */
+  const double *levelpops;
+  /* [npts_nonempty*nphixstargets_total] corrected photoionisation coefficient of every bound-free pair, what
+   * get_corrphotoioncoeff() (ratecoeff.cc:840) returns when USE_LUT_PHOTOION is off (the normalised bound-free estimators of
+   * the previous timestep, or the radiation-field integral): required by builds with ARTIS_OPT_USE_LUT_PHOTOION == 0 */
+  const double *corrphotoioncoeff;
+  /* [npts_nonempty*RADFIELDBINCOUNT] W and T_R of the multibin radiation field (radfield.cc:208-214; W < 0: bin without a
+   * solution): required by builds with ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON */
+  const float *radfieldbin_W;
+  const float *radfieldbin_T_R;
 } artis_cellstate;
 
 typedef struct artis_timestep {
@@ -313,6 +324,12 @@ typedef struct artis_estimators {
   double *dep_estimator_electron;
   double *dep_estimator_positron;
   double *dep_estimator_alpha;
+  /* multibin radiation field estimators radfieldbins.J_raw / nuJ_raw [npts_nonempty*RADFIELDBINCOUNT] (radfield.cc:745-790)
+   * and detailed bound-free estimators bfrate_raw [npts_nonempty*nbfcontinua] (radfield.cc:215; every continuum has one, as
+   * with LEVEL_HAS_BFEST == true). Written by builds with the corresponding options; may be NULL. */
+  double *radfieldbin_J;
+  double *radfieldbin_nuJ;
+  double *bfrate_raw;
 } artis_estimators;
 enum {
   ARTIS_SCALAR_GAMMA_DEP_DISCRETE = 0,   /* globals::timesteps[nts].gamma_dep_discrete gammapkt.cc:926 */
@@ -349,7 +366,7 @@ typedef struct artis_amd_engine artis_amd_engine;
 #define ARTIS_ERR_RCCL (-6)
 
 const char *artis_amd_last_error(void);
-int artis_amd_abi_version(void);
+int artis_amd_abi_version(void); /* 3: cell state and estimators of the nltenebular options appended */
 /* Name of the options preset the library was compiled with (include/artis_options.h): "classic" or "kilonova_lte".
  * Like the reference, one binary per artisoptions.h. */
 const char *artis_amd_options_preset(void);

@@ -27,6 +27,33 @@
 #define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME 3    /* :146 TIMEDEPENDENT */
 #endif
 
+/* -DARTIS_PRESET_NLTENEBULAR: the packet-path options of artisoptions_nltenebular.h (BASELINE.json configs[4]): level
+ * populations and photoionisation coefficients come from the host (NLTE solver, USE_LUT_PHOTOION off), the radiation
+ * field is the multibin model (estimators per frequency bin, binned J_nu in the radiative excitation rates), every
+ * continuum has a detailed bound-free estimator. NOT covered: NT_ON (Spencer-Fano channels of do_ntlepton_deposit() and
+ * the non-thermal macro-atom rates, artisoptions_nltenebular.h:102) -- this build keeps NT_ON = 0. */
+#ifdef ARTIS_PRESET_NLTENEBULAR
+#define ARTIS_OPT_DIPOLE 0                            /* artisoptions_nltenebular.h:48 */
+#define ARTIS_OPT_POL_ON 0                            /* :49 */
+#define ARTIS_OPT_MINPOP 1e-40                        /* :54 */
+#define ARTIS_OPT_NU_MIN_R 1e13                       /* :56 */
+#define ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION 0    /* :59 */
+#define ARTIS_OPT_DIRECT_COL_HEAT 1                   /* :36 */
+#define ARTIS_OPT_MINTEMP 1000.                       /* :42 */
+#define ARTIS_OPT_MAXTEMP 30000.                      /* :43 */
+#define ARTIS_OPT_LTEPOP_EXCITATION_USE_TJ 0          /* :24 */
+#define ARTIS_OPT_USE_LUT_PHOTOION 0                  /* :84 */
+#define ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS 0      /* :86 */
+#define ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON 1        /* :61 */
+#define ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON 1         /* :78 (LEVEL_HAS_BFEST is true for every level, :80) */
+#endif
+/* multibin radiation field model (artisoptions_nltenebular.h:62-70) */
+#define ARTIS_OPT_RADFIELDBINCOUNT 256
+#define ARTIS_OPT_FIRST_NLTE_RADFIELD_TIMESTEP 12
+#define ARTIS_OPT_RADFIELDBINS_NU_MIN (2.99792458e+10 / 40000e-8)
+#define ARTIS_OPT_RADFIELDBINS_NU_MAX (2.99792458e+10 / 1085e-8)
+#define ARTIS_OPT_RADFIELDBINS_T_E_SUPERBIN_NU_MAX (2.99792458e+10 / 10e-8)
+
 #ifndef ARTIS_OPT_DIPOLE
 #define ARTIS_OPT_DIPOLE 1 /* artisoptions_classic.h:47 */
 #endif
@@ -86,8 +113,12 @@
  * classic values. (A build that needs them fails here, not at run time.) */
 #define ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES 0    /* artisoptions_classic.h:137 */
 #define ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON 0     /* artisoptions_classic.h:74 */
+#ifndef ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
 #define ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON 0       /* artisoptions_classic.h:76 */
+#endif
+#ifndef ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON
 #define ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON 0      /* artisoptions_classic.h:60 */
+#endif
 #define ARTIS_OPT_NT_ON 0                           /* artisoptions_classic.h:100 */
 #define ARTIS_OPT_VPKT_ON 0                         /* artisoptions_classic.h:50 */
 /* gamma packets: the classic choices (artisoptions_classic.h:144-150) are the ones built */

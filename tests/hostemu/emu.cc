@@ -41,6 +41,9 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
     e.env.E.dep_estimator_positron = est->dep_estimator_positron;
     e.env.E.dep_estimator_alpha = est->dep_estimator_alpha;
     e.env.E.scalars = est->scalars;
+    e.env.E.radfieldbin_J = est->radfieldbin_J;
+    e.env.E.radfieldbin_nuJ = est->radfieldbin_nuJ;
+    e.env.E.bfrate_raw = est->bfrate_raw;
   }
   const DevModel &M = e.env.M;
   const int64_t ncell = M.npts_nonempty;

@@ -80,7 +80,7 @@ def _oracle_slice(args):
 
     model, cs, ts, pk, preset = _oracle_slice.shared
     sub = pk[lo:hi].copy()
-    est = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
+    est = abi.estimators_for(model, preset)
     oracle_py.update_packets(model, cs, ts, sub, est, preset=preset)
     return sub, est.arrays(), np.array(est.stats)
 

@@ -32,7 +32,7 @@ def test_exports_every_declared_symbol(lib):
 def test_packet_layout_matches_header(lib):
     lib.artis_amd_sizeof_packet.restype = C.c_size_t
     assert lib.artis_amd_sizeof_packet() == abi.PACKET_DTYPE.itemsize == 256
-    assert lib.artis_amd_abi_version() == 2
+    assert lib.artis_amd_abi_version() == 3
 
 
 def test_no_cpu_fallback(lib):
@@ -120,7 +120,7 @@ def test_one_library_per_options_preset():
     library; each reports the preset it was compiled with and exports the same C-ABI."""
     from artis_amd.build import PRESETS, build as build_preset, so_path
     from artis_amd.engine import EXPORTED_SYMBOLS
-    assert set(PRESETS) == {"classic", "kilonova_lte"}
+    assert set(PRESETS) == {"classic", "kilonova_lte", "nltenebular"}
     for preset in PRESETS:
         L = C.CDLL(build_preset(preset=preset))
         assert os.path.samefile(build_preset(preset=preset), so_path(preset))

@@ -68,9 +68,8 @@ def _run_case(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk, kfrac=
               options="classic"):
     model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v, options=options, **(bkw or {}))
     pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=kfrac, gamma_fraction=gfrac, pellet_fraction=pfrac, **(pkw or {}))
-    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
     pa, pb = pk0.copy(), pk0.copy()
-    ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
+    ea, eb = abi.estimators_for(model, options), abi.estimators_for(model, options)
     oracle.update_packets(model, cs, ts, pa, ea, preset=options)
     eng = engine_mod.Engine(model, preset=options)
     eng.set_cellstate(cs, ts)
@@ -412,6 +411,28 @@ def test_edge_cases(engine_mod):
         assert pk[f][:48].tobytes() == ref[f][:48].tobytes(), f
     for f in ("tdecay", "number", "pellet_decaytype", "pellet_nucindex", "originated_from_particlenotgamma"):
         assert np.array_equal(pk[f], ref[f])  # fields the path never touches survive the round trip
+    eng.close()
+
+
+@pytest.mark.parametrize("gridtype,ncoord,nts", [(abi.GRID_CARTESIAN3D, 8, 13), (abi.GRID_SPHERICAL1D, 16, 13),
+                                                  (abi.GRID_CARTESIAN3D, 8, 10)])
+def test_engine_matches_oracle_nltenebular_preset(engine_mod, oracle, gridtype, ncoord, nts):
+    """the engine built with the packet-path options of artisoptions_nltenebular.h (libartis_amd_nltenebular.so;
+    BASELINE.json configs[2] without the NT_ON channels): host level populations and photoionisation coefficients,
+    the binned radiation field (read past FIRST_NLTE_RADFIELD_TIMESTEP, accumulated always) and the detailed
+    bound-free estimators, against the oracle built with the same options"""
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", ncoord, gridtype, 0.0, 16000, kfrac=0.15, gfrac=0.15,
+                                                    pfrac=0.3, options="nltenebular", bkw=dict(nts=nts))
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, "nltenebular: HIP engine vs oracle")
+    parity.compare_stats(eb, ea, "nltenebular: HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, "nltenebular: HIP engine vs oracle")
+    assert eb.stats[abi.STAT_X_RPKT_STEPS] > 16000 and eb.gammaestimator.sum() == 0
+    assert np.count_nonzero(eb.bfrate_raw) > 100 and eb.radfieldbin_J.sum() > 0.5 * eb.J.sum()
+    # a cell state without the solver's arrays is refused, not silently replaced by LTE values
+    bare = abi.CellState({k: v for k, v in cs.d.items() if k not in ("levelpops", "corrphotoioncoeff")})
+    with pytest.raises(engine_mod.EngineError):
+        eng.set_cellstate(bare, ts)
+    print(f"worst float rel diff {rep['worst_rel']:.3e}")
     eng.close()
 
 
