@@ -138,7 +138,10 @@ _MODEL_FIELDS = [
     ("gridtype", C.c_int32, None), ("ncoordgrid", C.c_int32 * 3, "i3"), ("ngrid", C.c_int32, None),
     ("npts_nonempty", C.c_int32, None), ("tmin", C.c_double, None), ("vmax", C.c_double, None),
     ("rmax", C.c_double, None), ("coord_pos_min_tmin", _F64P * 3, "p3"), ("propcell_nonemptymgi", _I32P, np.int32),
+    # optional (NULL when absent): static inputs of the non-thermal channels
+    ("elem_meannucmass", _F32P, np.float32), ("ion_nt_sum_q_over_binding", _F64P, np.float64),
 ]
+_MODEL_OPTIONAL = ("elem_meannucmass", "ion_nt_sum_q_over_binding")
 
 _CELL_FIELDS = [
     ("rho", _F32P, np.float32), ("Te", _F32P, np.float32), ("TJ", _F32P, np.float32), ("TR", _F32P, np.float32),
@@ -150,8 +153,19 @@ _CELL_FIELDS = [
     # optional (NULL when absent from the dict): host level populations, host photoionisation coefficients, multibin field
     ("levelpops", _F64P, np.float64), ("corrphotoioncoeff", _F64P, np.float64),
     ("radfieldbin_W", _F32P, np.float32), ("radfieldbin_T_R", _F32P, np.float32),
+    # optional: the Spencer-Fano solution (builds with NT_ON)
+    ("nt_frac_ionisation", _F32P, np.float32), ("nt_frac_excitation", _F32P, np.float32),
+    ("nt_deposition_rate_density", _F64P, np.float64), ("nt_eff_ionpot", _F32P, np.float32),
+    ("nt_prob_num_auger", _F32P, np.float32), ("nt_ionenfrac_num_auger", _F32P, np.float32),
+    ("nt_exc_count", _I32P, np.int32), ("nt_exc_frac_deposition", _F64P, np.float64),
+    ("nt_exc_ratecoeffperdeposition", _F64P, np.float64), ("nt_exc_alltransindex", _I32P, np.int32),
+    ("nt_excitations_stored", C.c_int32, None),
 ]
-_CELL_OPTIONAL = ("levelpops", "corrphotoioncoeff", "radfieldbin_W", "radfieldbin_T_R")
+_CELL_OPTIONAL = ("levelpops", "corrphotoioncoeff", "radfieldbin_W", "radfieldbin_T_R", "nt_frac_ionisation",
+                  "nt_frac_excitation", "nt_deposition_rate_density", "nt_eff_ionpot", "nt_prob_num_auger",
+                  "nt_ionenfrac_num_auger", "nt_exc_count", "nt_exc_frac_deposition", "nt_exc_ratecoeffperdeposition",
+                  "nt_exc_alltransindex", "nt_excitations_stored")
+NT_NAUGER = 3  # NT_MAX_AUGER_ELECTRONS + 1
 RADFIELDBINCOUNT = 256
 
 
@@ -187,6 +201,8 @@ class Model:
         self.d = {}
         self.c = CModel()
         for name, ctype, npdt in _MODEL_FIELDS:
+            if name in _MODEL_OPTIONAL and d.get(name) is None:
+                continue  # stays a NULL pointer
             v = d[name]
             if npdt is None:
                 setattr(self.c, name, v)
@@ -222,6 +238,10 @@ class CellState:
         for name, ctype, npdt in _CELL_FIELDS:
             if name in _CELL_OPTIONAL and d.get(name) is None:
                 continue  # stays a NULL pointer
+            if npdt is None:
+                setattr(self.c, name, int(d[name]))
+                self.d[name] = int(d[name])
+                continue
             arr = np.ascontiguousarray(d[name], dtype=npdt)
             if arr.size == 0:
                 arr = np.zeros(1, dtype=npdt)

@@ -11,7 +11,13 @@ SO = os.path.join(HERE, "libartis_amd.so")
 SOURCES = ["artis_engine.hip", "physics.h", "tables.h", "model_build.h"]
 # -ffp-contract=off: the operation order of physics.h is part of the parity contract (no FMA contraction).
 # -munsafe-fp-atomics: estimator adds become global_atomic_add_f64, not compare-and-swap loops.
-FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-munsafe-fp-atomics", "-ldl"]
+# -fno-slp-vectorize: with SLP vectorisation on, hipcc 7.2 packs the four int32 of a packet's hot line that follow each other
+#   (emissiontype, trueemissiontype, absorptiontype, flags) into one vector in k_gamma and, on the path through the NT_ON
+#   branch of do_ntlepton_deposit(), stores the vector it loaded instead of the updated absorptiontype (GPU parity test
+#   test_engine_matches_oracle_nltenebular_preset caught it; -O1, noinline or this flag all give the right answer). The
+#   kernels compute in f64 and their loads/stores are merged by the separate load/store vectoriser: no measured cost.
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-munsafe-fp-atomics",
+         "-fno-slp-vectorize", "-ldl"]
 
 
 PRESETS = ("classic", "kilonova_lte", "nltenebular")  # options presets of include/artis_options.h (the reference's artisoptions_*.h)

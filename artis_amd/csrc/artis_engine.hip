@@ -53,6 +53,14 @@ __global__ void __launch_bounds__(BLOCK) k_line_dpop(Env env) {
   if (i >= total) return;
   populate_line_dpop(env, env.tile_lo + (int)(i / env.M.nlines), (int)(i % env.M.nlines));
 }
+#if ARTIS_OPT_NT_ON
+// every cell of the model (not a tile): the non-thermal ionisation rate coefficients and energy-rate sums
+__global__ void __launch_bounds__(BLOCK) k_nt_cells(Env env, int ncell) {
+  const int c = blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= ncell) return;
+  if (!populate_nt_cell(env, c)) fail(env, 90);
+}
+#endif
 __global__ void __launch_bounds__(BLOCK) k_cell_scalars(Env env) {
   const int c = env.tile_lo + blockIdx.x * BLOCK + threadIdx.x;
   if (c >= env.tile_hi) return;
@@ -1225,6 +1233,20 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   }
   ARTIS_MODEL_ARRAYS(UP, h)
 #undef UP
+#define UPMO(f, T, count)                                                                     \
+  {                                                                                           \
+    e->M.f = nullptr;                                                                         \
+    if (h.f) {                                                                                \
+      int rc = upload_array<T>(e->model_allocs, h.f, (int64_t)(count), (const T **)&e->M.f);  \
+      if (rc != ARTIS_OK) return rc;                                                          \
+    }                                                                                         \
+  }
+  ARTIS_MODEL_OPTIONAL_ARRAYS(UPMO, h)
+#undef UPMO
+  if (ARTIS_OPT_NT_ON && (!e->M.elem_meannucmass || !e->M.ion_nt_sum_q_over_binding)) {
+    g_last_error = "this build has NT_ON: artis_model.elem_meannucmass and ion_nt_sum_q_over_binding are required";
+    return ARTIS_ERR_ARG;
+  }
   for (int a = 0; a < 3; a++) {
     const int ndim = (h.gridtype == ARTIS_GRID_SPHERICAL1D) ? 1 : ((h.gridtype == ARTIS_GRID_CYLINDRICAL2D) ? 2 : 3);  // get_ndim grid.cc:120
     const int64_t cnt = (a >= ndim) ? 1 : h.ncoordgrid[a];
@@ -1394,8 +1416,12 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
       if (rc != ARTIS_OK) return rc;                                                         \
     }                                                                                        \
   }
+  const int64_t nt_stored = (hc.nt_exc_count && hc.nt_excitations_stored > 0) ? hc.nt_excitations_stored : 0;
   ARTIS_CELL_OPTIONAL_ARRAYS(UPO, h)
 #undef UPO
+  e->C.nt_excitations_stored = (int32_t)nt_stored;
+  e->C.nt_ionratecoeff = nullptr;
+  e->C.nt_ionenrate_cum = nullptr;
   // what the options this library was built with need from the host
   if (!ARTIS_OPT_USE_LUT_PHOTOION && h.nphixstargets_total > 0 && !e->C.corrphotoioncoeff) {
     g_last_error = "this build has USE_LUT_PHOTOION off: artis_cellstate.corrphotoioncoeff is required";
@@ -1406,6 +1432,34 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
     return ARTIS_ERR_ARG;
   }
   e->S = make_step(*ts);
+#if ARTIS_OPT_NT_ON
+  if (!e->C.nt_frac_ionisation || !e->C.nt_frac_excitation || !e->C.nt_deposition_rate_density || !e->C.nt_eff_ionpot ||
+      !e->C.nt_prob_num_auger || !e->C.nt_ionenfrac_num_auger || !e->C.nt_exc_count ||
+      (nt_stored > 0 && (!e->C.nt_exc_frac_deposition || !e->C.nt_exc_ratecoeffperdeposition || !e->C.nt_exc_alltransindex))) {
+    g_last_error = "this build has NT_ON: the Spencer-Fano solution (artis_cellstate.nt_*) is required";
+    return ARTIS_ERR_ARG;
+  }
+  {
+    const size_t bytes = sizeof(double) * (size_t)(h.npts_nonempty > 0 ? h.npts_nonempty : 1) * (size_t)h.nions;
+    HIP_TRY(hipMalloc((void **)&e->C.nt_ionratecoeff, bytes));
+    e->cell_allocs.push_back(e->C.nt_ionratecoeff);
+    HIP_TRY(hipMalloc((void **)&e->C.nt_ionenrate_cum, bytes));
+    e->cell_allocs.push_back(e->C.nt_ionenrate_cum);
+    if (h.npts_nonempty > 0) {
+      const Env env = make_env(e);
+      hipLaunchKernelGGL(k_nt_cells, dim3((h.npts_nonempty + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, nullptr, env, h.npts_nonempty);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipDeviceSynchronize());
+      int32_t err = 0;
+      HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
+      if (err != 0) {
+        (void)hipMemset(e->d_err, 0, sizeof(int32_t));
+        g_last_error = "the Spencer-Fano solution is inconsistent (Auger probabilities do not sum to one): error flag " + std::to_string(err);
+        return ARTIS_ERR_ARG;
+      }
+    }
+  }
+#endif
   e->have_cells = true;
   return artis_amd_populate_cellcache(e, nullptr);
 }
@@ -1446,6 +1500,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s) {
   int32_t err = 0;
   HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
   if (err != 0) {
+    (void)hipMemset(e->d_err, 0, sizeof(int32_t));  // the flag is reported once; the next call starts clean
     g_last_error = "cell cache population raised error flag " + std::to_string(err);
     return ARTIS_ERR_NOTCONVERGED;
   }

@@ -28,6 +28,7 @@ struct ModelOwned {
   X(elem_nions, int32_t, (m).nelements)                                            \
   X(elem_uniqueionindexstart, int32_t, (m).nelements)                              \
   X(elem_lowest_ionstage, int32_t, (m).nelements)                                  \
+  X(elem_anumber, int32_t, (m).nelements)                                          \
   X(ion_element, int32_t, (m).nions)                                               \
   X(ion_nlevels, int32_t, (m).nions)                                               \
   X(ion_nlevels_ionising, int32_t, (m).nions)                                      \
@@ -83,6 +84,11 @@ struct ModelOwned {
   X(coolinglist_phixstargetindex, int32_t, (m).ncoolingterms)                      \
   X(propcell_nonemptymgi, int32_t, (m).ngrid)
 
+// arrays of DevModel that may be absent (null) on the host
+#define ARTIS_MODEL_OPTIONAL_ARRAYS(X, m)      \
+  X(elem_meannucmass, float, (m).nelements)    \
+  X(ion_nt_sum_q_over_binding, double, (m).nions)
+
 // X(field, element type, element count) for every array pointer of DevCells
 #define ARTIS_CELL_ARRAYS(X, m)                                          \
   X(rho, float, (m).npts_nonempty)                                       \
@@ -106,7 +112,17 @@ struct ModelOwned {
   X(levelpops, double, ((int64_t)(m).npts_nonempty * (m).nlevels))                                  \
   X(corrphotoioncoeff, double, ((int64_t)(m).npts_nonempty * (m).nphixstargets_total))              \
   X(radfieldbin_W, float, ((int64_t)(m).npts_nonempty * ARTIS_OPT_RADFIELDBINCOUNT))                \
-  X(radfieldbin_T_R, float, ((int64_t)(m).npts_nonempty * ARTIS_OPT_RADFIELDBINCOUNT))
+  X(radfieldbin_T_R, float, ((int64_t)(m).npts_nonempty * ARTIS_OPT_RADFIELDBINCOUNT))                \
+  X(nt_frac_ionisation, float, (m).npts_nonempty)                                                   \
+  X(nt_frac_excitation, float, (m).npts_nonempty)                                                   \
+  X(nt_deposition_rate_density, double, (m).npts_nonempty)                                          \
+  X(nt_eff_ionpot, float, ((int64_t)(m).npts_nonempty * (m).nions))                                 \
+  X(nt_prob_num_auger, float, ((int64_t)(m).npts_nonempty * (m).nions * (ARTIS_OPT_NT_MAX_AUGER_ELECTRONS + 1)))      \
+  X(nt_ionenfrac_num_auger, float, ((int64_t)(m).npts_nonempty * (m).nions * (ARTIS_OPT_NT_MAX_AUGER_ELECTRONS + 1))) \
+  X(nt_exc_count, int32_t, (m).npts_nonempty)                                                       \
+  X(nt_exc_frac_deposition, double, ((int64_t)(m).npts_nonempty * (nt_stored)))                     \
+  X(nt_exc_ratecoeffperdeposition, double, ((int64_t)(m).npts_nonempty * (nt_stored)))              \
+  X(nt_exc_alltransindex, int32_t, ((int64_t)(m).npts_nonempty * (nt_stored)))
 
 // X(field, element type, elements per cell) for every array of DevCache
 #define ARTIS_CACHE_ARRAYS(X, m)                                \
@@ -196,6 +212,7 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.cont_pack = own.cont_pack.data();
 #define ARTIS_COPY_PTR(f) v.f = m.f;
   ARTIS_COPY_PTR(elem_nions) ARTIS_COPY_PTR(elem_uniqueionindexstart) ARTIS_COPY_PTR(elem_lowest_ionstage)
+  ARTIS_COPY_PTR(elem_anumber) ARTIS_COPY_PTR(elem_meannucmass) ARTIS_COPY_PTR(ion_nt_sum_q_over_binding)
   ARTIS_COPY_PTR(ion_element) ARTIS_COPY_PTR(ion_nlevels) ARTIS_COPY_PTR(ion_nlevels_ionising)
   ARTIS_COPY_PTR(ion_maxrecombininglevel) ARTIS_COPY_PTR(ion_uniquelevelindexstart) ARTIS_COPY_PTR(ion_coolingoffset)
   ARTIS_COPY_PTR(ion_ncoolingterms) ARTIS_COPY_PTR(level_epsilon) ARTIS_COPY_PTR(level_statweight)
@@ -259,6 +276,13 @@ inline DevCells make_host_cells_view(const artis_cellstate &c) {
   v.corrphotoioncoeff = c.corrphotoioncoeff;
   v.radfieldbin_W = c.radfieldbin_W;
   v.radfieldbin_T_R = c.radfieldbin_T_R;
+  v.nt_frac_ionisation = c.nt_frac_ionisation; v.nt_frac_excitation = c.nt_frac_excitation;
+  v.nt_deposition_rate_density = c.nt_deposition_rate_density; v.nt_eff_ionpot = c.nt_eff_ionpot;
+  v.nt_prob_num_auger = c.nt_prob_num_auger; v.nt_ionenfrac_num_auger = c.nt_ionenfrac_num_auger;
+  v.nt_exc_count = c.nt_exc_count; v.nt_exc_frac_deposition = c.nt_exc_frac_deposition;
+  v.nt_exc_ratecoeffperdeposition = c.nt_exc_ratecoeffperdeposition; v.nt_exc_alltransindex = c.nt_exc_alltransindex;
+  v.nt_excitations_stored = c.nt_excitations_stored;
+  v.nt_ionratecoeff = nullptr; v.nt_ionenrate_cum = nullptr;
   return v;
 }
 

@@ -931,6 +931,110 @@ AHD void populate_corrphotoion(const Env &env, int c, int ul, int t) {
   env.K.bf_colion[o] = col_ion(M, T_e, cnne, element, ion, level, t, e_trans);
   env.K.bf_cooling[o] = lerp_or_last(M, M.bfcooling_coeffs, ul, t, T_e);
 }
+#if ARTIS_OPT_NT_ON
+// ---------------------------------------------------------------- non-thermal channels (nonthermal.cc)
+// The Spencer-Fano solution comes from the host (DevCells nt_*); the packet path only reads it.
+constexpr int NT_NAUGER = ARTIS_OPT_NT_MAX_AUGER_ELECTRONS + 1;
+constexpr double QE = 4.80325E-10;  // constants.h:31
+AHD double elem_numberdens(const DevModel &M, const DevCells &C, int c, int element) {  // grid.cc:1693
+  return C.elem_massfracs[((int64_t)c * M.nelements) + element] / (double)M.elem_meannucmass[element] * C.rho[c];
+}
+AHD int nt_maxupperion(const DevModel &M, int element, int lowerion) {  // nt_ionisation_maxupperion nonthermal.cc:2435
+  const int nions = M.elem_nions[element];
+  const int maxupper = lowerion + 1 + ARTIS_OPT_NT_MAX_AUGER_ELECTRONS;
+  return (nions - 1 < maxupper) ? nions - 1 : maxupper;
+}
+// nt_ionisation_upperion_probability nonthermal.cc:2398; *bad is set where the reference asserts
+AHD double nt_upperion_probability(const DevModel &M, const DevCells &C, int c, int element, int lowerion, int upperion,
+                                   bool energyweighted, bool *bad) {
+  const int numaugerelec = upperion - lowerion - 1;
+  const float *prob = (energyweighted ? C.nt_ionenfrac_num_auger : C.nt_prob_num_auger) +
+                      ((((int64_t)c * M.nions) + uion(M, element, lowerion)) * NT_NAUGER);
+  if (numaugerelec < ARTIS_OPT_NT_MAX_AUGER_ELECTRONS) return prob[numaugerelec];
+  if (numaugerelec == ARTIS_OPT_NT_MAX_AUGER_ELECTRONS) {
+    double prob_remaining = 1.;
+    for (int a = 0; a < ARTIS_OPT_NT_MAX_AUGER_ELECTRONS; a++) prob_remaining -= prob[a];
+    if (!(fabs(prob_remaining - prob[numaugerelec]) < 0.001)) *bad = true;
+    return prob_remaining;
+  }
+  return 0.;
+}
+AHD int nt_random_upperion(const Env &env, Pkt &p, int c, int element, int lowerion, bool energyweighted) {  // nonthermal.cc:2450
+  const double zrand = rng_uniform(p);
+  double prob_sum = 0.;
+  bool bad = false;
+  const int maxupper = nt_maxupperion(env.M, element, lowerion);
+  for (int upperion = lowerion + 1; upperion <= maxupper; upperion++) {
+    prob_sum += nt_upperion_probability(env.M, env.C, c, element, lowerion, upperion, energyweighted, &bad);
+    if (bad) fail(env, 91);
+    if (zrand < prob_sum) return upperion;
+  }
+  if (!(prob_sum > 0.99)) fail(env, 92);
+  return maxupper;
+}
+// one cell: nt_ionisation_ratecoeff() (nonthermal.cc:2478, with _sf :1420 and the Axelrod fallback _wfapprox :1251,
+// get_oneoverw_approx_axelrod :1207) of every ion that has a higher stage, and the running sum of ion_ntion_energyrate()
+// (:1509) in the order select_nt_ionisation() (:1537) adds them (an ion without a higher stage repeats the sum so far).
+// Returns false where the reference would assert (Auger probabilities that do not sum to one).
+AHD bool populate_nt_cell(const Env &env, int c) {
+  const DevModel &M = env.M;
+  const DevCells &C = env.C;
+  double nntot = 0., Zbar = 0.;
+  for (int e = 0; e < M.nelements; e++) {  // get_nnion_tot atomic.h:51 and the mean atomic number of :1214
+    const double nnelement = elem_numberdens(M, C, c, e);
+    Zbar += nnelement * M.elem_anumber[e];
+    nntot += nnelement;
+  }
+  if (nntot > 0) Zbar /= nntot;
+  const double dep = C.nt_deposition_rate_density[c];
+  double ratesum = 0.;
+  bool bad = false;
+  for (int e = 0; e < M.nelements; e++) {
+    const int nions = M.elem_nions[e];
+    for (int ion = 0; ion < nions; ion++) {
+      const int64_t o = ((int64_t)c * M.nions) + uion(M, e, ion);
+      double Y_nt = 0.;
+      if (ion < nions - 1) {
+        if (dep > 0.) Y_nt = dep / nntot / C.nt_eff_ionpot[o];
+        if (!isfinite(Y_nt)) {
+          constexpr double Aconst = 1.33e-14 * EV * EV;
+          const double oneoverw = Aconst * M.ion_nt_sum_q_over_binding[uion(M, e, ion)] / Zbar / (2 * PI * (pow2(QE) * pow2(QE)));
+          Y_nt = dep / nntot * oneoverw;
+        }
+        const double nnlowerion = nnion(env, c, e, ion);
+        double enrate = 0.;
+        const int maxupper = nt_maxupperion(M, e, ion);
+        for (int upperion = ion + 1; upperion <= maxupper; upperion++) {
+          const double frac = nt_upperion_probability(M, C, c, e, ion, upperion, false, &bad);
+          const double e_trans = eps(M, lstart(M, e, upperion)) - eps(M, lstart(M, e, ion));
+          enrate += nnlowerion * frac * e_trans;
+        }
+        ratesum += Y_nt * enrate;
+      }
+      C.nt_ionratecoeff[o] = Y_nt;
+      C.nt_ionenrate_cum[o] = ratesum;
+    }
+  }
+  return !bad;
+}
+// nt_excitation_ratecoeff nonthermal.cc:2496 (lowerlevel, upperlevel: indices within the ion)
+AHD double nt_excitation_ratecoeff(const DevCells &C, int c, int lowerlevel, int upperlevel, int alltransindex) {
+  if (!ARTIS_OPT_NT_EXCITATION_ON) return 0.;
+  if (lowerlevel >= ARTIS_OPT_NTEXCITATION_MAXNLEVELS_LOWER) return 0.;
+  if (upperlevel >= ARTIS_OPT_NTEXCITATION_MAXNLEVELS_UPPER) return 0.;
+  const int64_t base = (int64_t)c * C.nt_excitations_stored;
+  const int32_t *ati = C.nt_exc_alltransindex + base;
+  const int n = C.nt_exc_count[c];
+  int lo = 0, hi = n;  // std::ranges::lower_bound
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) / 2);
+    if (ati[mid] < alltransindex) lo = mid + 1; else hi = mid;
+  }
+  if (lo == n || ati[lo] != alltransindex) return 0.;
+  return C.nt_exc_ratecoeffperdeposition[base + lo] * C.nt_deposition_rate_density[c];
+}
+#endif
+
 // one (cell, entry of alltrans): the rate coefficients of ONE bound-bound transition of
 // calculate_macroatom_transitionrates() (macroatom.cc:64-140) and its term of calculate_cooling_rates_ion()
 // (kpkt.cc:108-121), written where the per-level / per-ion stages below turn them into running sums. Splitting the work
@@ -979,7 +1083,11 @@ AHD MaTransTerms matrans_terms(const Env &env, int c, int ati) {
     const double g_up = statw(M, tul);
     const double R = rad_exc(env, c, g_up, M.alltrans_einstein_A[ati], e_trans, nnlevel, pops[tul], g_cur, env.S.mid);
     const double Cc = col_exc(M, T_e, cnne, e_trans, g_up, g_cur, ati);
+#if ARTIS_OPT_NT_ON
+    const double NT = nt_excitation_ratecoeff(env.C, c, ul - start, M.alltrans_targetlevelindex[ati], ati);  // macroatom.cc:133
+#else
     const double NT = 0.;
+#endif
     r.v0 = (R + Cc + NT) * e_cur;
     r.v1 = 0.;
     r.v2 = 0.;
@@ -1090,7 +1198,12 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
       s_up_higher += (R + Cc) * e_cur;
     }
   }
-  rates[ARTIS_MA_ACTION_INTERNALUPHIGHERNT] = 0.;
+  double s_up_highernt = 0.;
+#if ARTIS_OPT_NT_ON
+  if (ion < M.elem_nions[element] - 1 && level < M.ion_nlevels_ionising[ui])
+    s_up_highernt = env.C.nt_ionratecoeff[((int64_t)c * M.nions) + ui] * e_cur;  // macroatom.cc:181
+#endif
+  rates[ARTIS_MA_ACTION_INTERNALUPHIGHERNT] = s_up_highernt;
   rates[ARTIS_MA_ACTION_INTERNALUPHIGHER] = s_up_higher;
   // flow through the level ~ population x total rate: the hotness that ranks the levels of a cell for its hot block
   // (tables.h). A heuristic: it decides only where the thermal kernel reads a record from.
@@ -2206,6 +2319,12 @@ AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi) {
     }
     p.ma_level = newlevel;
     p.ma_ion = ion + 1;
+#if ARTIS_OPT_NT_ON
+  } else if (action == ARTIS_MA_ACTION_INTERNALUPHIGHERNT) {  // macroatom.cc:562
+    p.ma_ion = nt_random_upperion(env, p, c, element, ion, false);
+    p.ma_level = 0;
+    ARTIS_STAT(env, ARTIS_STAT_MA_INTERNALUPHIGHERNT);
+#endif
   } else {
     fail(env, 44);  // MA_ACTION_INTERNALUPHIGHERNT needs NT_ON
     p.ma_level = -1;
@@ -2755,9 +2874,78 @@ AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
   if (p.type != ARTIS_TYPE_GAMMA && p.type != ARTIS_TYPE_ESCAPE)
     ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE], p.e_cmf);  // gammapkt.cc:926
 }
-// nonthermal::do_ntlepton_deposit nonthermal.cc:2529 with NT_ON == false (artisoptions_classic.h:95)
+// nonthermal::do_ntlepton_deposit nonthermal.cc:2529. NT_ON == false (artisoptions_classic.h:95): every deposit is heat.
+// NT_ON with a Spencer-Fano solution (artisoptions_nltenebular.h:102-104): the deposit ionises or excites a macro-atom
+// with the solution's fractions; the activation is recorded in the packet (ma_activate) and the walk runs in the thermal
+// kernel, the packet keeping its deposit type until the macro-atom deactivates (as in the reference's do_macroatom()).
 AHD void do_ntlepton_deposit(const Env &env, Pkt &p) {
   ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_NT_ENERGY_DEPOSITED], p.e_cmf);
+#if ARTIS_OPT_NT_ON
+  const DevModel &M = env.M;
+  const int c = M.propcell_nonemptymgi[p.cellindex];
+  if (env.C.thick[c] != ARTIS_CELL_THICK) {
+    double zrand = rng_uniform(p);
+    const double frac_ionisation = env.C.nt_frac_ionisation[c];
+    if (zrand < frac_ionisation) {
+      // select_nt_ionisation nonthermal.cc:1537 over the running sums of populate_nt_cell()
+      const double *cum = env.C.nt_ionenrate_cum + ((int64_t)c * M.nions);
+      const double ratetotal = cum[M.nions - 1];
+      if (ratetotal > 0.) {
+        const double target = rng_uniform(p) * ratetotal;
+        int element = -1, lowerion = -1;
+        for (int e = 0; e < M.nelements && element < 0; e++) {
+          for (int ion = 0; ion < M.elem_nions[e] - 1; ion++) {
+            if (cum[uion(M, e, ion)] > target) {
+              element = e;
+              lowerion = ion;
+              break;
+            }
+          }
+        }
+        if (element < 0) {
+          fail(env, 93);
+          return;
+        }
+        const int upperion = nt_random_upperion(env, p, c, element, lowerion, true);
+        ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_NTCOLLION);
+        ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
+        p.trueemissiontype = ARTIS_EMTYPE_NOTSET;
+        p.flags |= PKT_FLAG_TRUEEM_NAN;
+        ARTIS_STAT(env, ARTIS_STAT_NT_TO_IONISATION);
+        const MAState ma = {element, upperion, 0, -99};
+        ma_activate(p, ma, 0);
+        return;
+      }
+      p.type = ARTIS_TYPE_KPKT;
+      ARTIS_STAT(env, ARTIS_STAT_NT_TO_KPKT);
+      return;
+    }
+    const double frac_excitation = ARTIS_OPT_NT_EXCITATION_ON ? env.C.nt_frac_excitation[c] : 0.;
+    if (zrand < (frac_ionisation + frac_excitation)) {
+      zrand -= frac_ionisation;
+      const int64_t base = (int64_t)c * env.C.nt_excitations_stored;
+      const int n = env.C.nt_exc_count[c];
+      for (int i = 0; i < n; i++) {
+        const double frac_deposition_exc = env.C.nt_exc_frac_deposition[base + i];
+        if (zrand < frac_deposition_exc) {
+          const int lineindex = M.alltrans_lineindex[env.C.nt_exc_alltransindex[base + i]];
+          const int element = M.line_elementindex[lineindex];
+          const int ion = M.line_ionindex[lineindex];
+          const int upper = M.line_pack[lineindex].upper - lstart(M, element, ion);  // get_levelfromuniquelevelindex
+          ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_NTCOLLEXC);
+          ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
+          p.trueemissiontype = ARTIS_EMTYPE_NOTSET;
+          p.flags |= PKT_FLAG_TRUEEM_NAN;
+          ARTIS_STAT(env, ARTIS_STAT_NT_TO_EXCITATION);
+          const MAState ma = {element, ion, upper, -99};
+          ma_activate(p, ma, 0);
+          return;
+        }
+        zrand -= frac_deposition_exc;
+      }
+    }
+  }
+#endif
   p.type = ARTIS_TYPE_KPKT;
   ARTIS_STAT(env, ARTIS_STAT_NT_TO_KPKT);
 }
@@ -3101,7 +3289,9 @@ AHD int advance_blackbody(const Env &env, Pkt &p, int64_t pi) {
 
 // ---- gamma kernel body: one iteration = one do_packet() call (update_packets.cc:257) for a type that does not use the
 // cell cache: pellet, gamma packet, non-thermal pre-deposit and deposit types. Returns true while the packet stays with this kernel.
-AHD bool gamma_can_continue(const Pkt &p, double ts_end) { return type_gamma(p.type) && p.prop_time < ts_end; }
+AHD bool gamma_can_continue(const Pkt &p, double ts_end) {
+  return type_gamma(p.type) && p.prop_time < ts_end && !ma_pending(p);  // (a deposit may have activated a macro-atom)
+}
 AHD bool gamma_iter(const Env &env, Pkt &p, int64_t pi) {
   if (p.type == ARTIS_TYPE_GAMMA) {
     do_gamma(env, p, pi);

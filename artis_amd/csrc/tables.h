@@ -108,7 +108,9 @@ struct DevModel {
   double T_step_log;               // ratecoeff.cc:39
   const double *temperature_grid;  // [TABLESIZE+1] ratecoeff.cc:41
 
-  const int32_t *elem_nions, *elem_uniqueionindexstart, *elem_lowest_ionstage;
+  const int32_t *elem_nions, *elem_uniqueionindexstart, *elem_lowest_ionstage, *elem_anumber;
+  const float *elem_meannucmass;             // optional (NT_ON builds)
+  const double *ion_nt_sum_q_over_binding;   // optional (NT_ON builds)
   const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
       *ion_coolingoffset, *ion_ncoolingterms;
   const double *level_epsilon;
@@ -158,6 +160,19 @@ struct DevCells {
   const double *levelpops;           // [cell][nlevels] host level populations
   const double *corrphotoioncoeff;   // [cell][nphixstargets_total] host photoionisation coefficients (USE_LUT_PHOTOION off)
   const float *radfieldbin_W, *radfieldbin_T_R;  // [cell][RADFIELDBINCOUNT] multibin radiation field
+  // Spencer-Fano solution of the host (NT_ON builds; include/artis_amd.h artis_cellstate)
+  const float *nt_frac_ionisation, *nt_frac_excitation;          // [cell]
+  const double *nt_deposition_rate_density;                      // [cell]
+  const float *nt_eff_ionpot;                                    // [cell][nions]
+  const float *nt_prob_num_auger, *nt_ionenfrac_num_auger;       // [cell][nions][NT_MAX_AUGER_ELECTRONS + 1]
+  const int32_t *nt_exc_count;                                   // [cell]
+  const double *nt_exc_frac_deposition, *nt_exc_ratecoeffperdeposition;  // [cell][nt_excitations_stored]
+  const int32_t *nt_exc_alltransindex;                           // [cell][nt_excitations_stored], ascending
+  int32_t nt_excitations_stored;
+  // derived once per cell state (populate_nt_cell): nt_ionisation_ratecoeff() of every ion and the running sum of
+  // ion_ntion_energyrate() in select_nt_ionisation()'s order. Not part of the tiled cell cache: a deposit reads them in
+  // whichever cell the particle stops.
+  double *nt_ionratecoeff, *nt_ionenrate_cum;                    // [cell][nions]
 };
 
 struct DevCache {

@@ -30,8 +30,7 @@ def load_library(build_if_missing: bool = False, preset: str = "classic"):
     if preset in _LIBS:
         return _LIBS[preset]
     so = so_path(preset)
-    if preset == "classic":
-        so = os.environ.get("ARTIS_AMD_SO", so)  # A/B builds of the same sources (tuning only)
+    so = os.environ.get("ARTIS_AMD_SO" if preset == "classic" else f"ARTIS_AMD_SO_{preset.upper()}", so)  # A/B builds (tuning only)
     if not os.path.exists(so):
         if not build_if_missing:
             raise EngineError(f"{so} is missing: run `python -m artis_amd.build` (hipcc, gfx950). There is no CPU fallback.")

@@ -643,9 +643,87 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     model = abi.Model(md)
     if options == "nltenebular":
         cells.update(nebular_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 200))
+        cells.update(nonthermal_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 300))
+        md.update(nonthermal_model_inputs(atomic))
+        model = abi.Model(md)
     cs = abi.CellState(cells)
     ts = make_timestep(aux["t"], width_frac=width_frac, vmax=grid["vmax"], nts=nts)
     return model, cs, ts, aux
+
+
+def nonthermal_model_inputs(atomic: dict) -> dict:
+    """Static inputs of the non-thermal channels (include/artis_amd.h artis_model): mean nuclear mass of each element and
+    the sum over shells of occupancy / binding energy of each ion (nonthermal.cc:553; here one valence-like term)."""
+    elements = atomic["_elements"]
+    amass = np.array([_AMASS.get(Z, 2.0 * Z) for Z, _, _ in elements]) * MH
+    ionpot = np.asarray(atomic["_ion_ionpot"], dtype=np.float64)
+    elem_uiis = np.asarray(atomic["elem_uniqueionindexstart"])
+    lowest = np.asarray(atomic["elem_lowest_ionstage"])
+    binding = np.zeros(atomic["nions"])
+    for e, (Z, _, _) in enumerate(elements):
+        for k in range(int(atomic["elem_nions"][e])):
+            nbound = Z - (int(lowest[e]) - 1 + k)
+            binding[elem_uiis[e] + k] = max(nbound, 0) / max(ionpot[elem_uiis[e] + k], 1e-12)
+    return dict(elem_meannucmass=amass, ion_nt_sum_q_over_binding=binding)
+
+
+def nonthermal_cellstate(atomic: dict, cells: dict, ncell: int, seed: int = 301, stored: int = 48) -> dict:
+    """A Spencer-Fano solution per cell as the host's solver stores it (nonthermal.cc:215-245): deposition fractions,
+    effective ionisation potentials (a few zero: no cross-section data, the Axelrod work-function fallback), Auger
+    probabilities that sum to one in float, and a truncated list of excitation transitions sorted by alltransindex.
+    Some cells have no deposition at all (rate density 0: select_nt_ionisation() finds no ion)."""
+    rng = np.random.default_rng(seed)
+    nions = atomic["nions"]
+    ionpot = np.asarray(atomic["_ion_ionpot"], dtype=np.float64)
+    rho = np.asarray(cells["rho"], dtype=np.float64)
+    dep = rho * 1e8 * rng.uniform(0.5, 1.5, ncell)
+    dep[rng.random(ncell) < 0.08] = 0.0
+    frac_ion = rng.uniform(0.02, 0.3, ncell).astype(np.float32)
+    frac_exc = rng.uniform(0.02, 0.2, ncell).astype(np.float32)
+    eff = (ionpot[None, :] * rng.uniform(1.5, 4.0, (ncell, nions))).astype(np.float32)
+    eff[rng.random((ncell, nions)) < 0.05] = 0.0
+
+    # number of ions above each ion: an ionisation cannot eject more Auger electrons than there are stages left
+    elem_nions = np.asarray(atomic["elem_nions"])
+    elem_uiis = np.asarray(atomic["elem_uniqueionindexstart"])
+    nabove = np.concatenate([np.arange(n - 1, -1, -1) for n in elem_nions])
+    assert len(nabove) == nions and elem_uiis[-1] + elem_nions[-1] == nions
+
+    def auger():
+        p = np.zeros((ncell, nions, abi.NT_NAUGER), dtype=np.float32)
+        p[:, :, 1] = rng.uniform(0.0, 0.2, (ncell, nions)) * (nabove >= 2)[None, :]
+        p[:, :, 2] = rng.uniform(0.0, 0.05, (ncell, nions)) * (nabove >= 3)[None, :]
+        p[:, :, 0] = np.float32(1.0) - p[:, :, 1] - p[:, :, 2]
+        return p
+
+    # candidate excitations: the upward transitions of the lowest levels of every ion
+    level_ion = np.asarray(atomic["_level_ion"])
+    ion_uls = np.asarray(atomic["ion_uniquelevelindexstart"])
+    startdown = np.asarray(atomic["level_alltrans_startdown"])
+    ndown = np.asarray(atomic["level_ndowntrans"])
+    nup = np.asarray(atomic["level_nuptrans"])
+    cand = []
+    for ul in range(len(level_ion)):
+        if ul - ion_uls[level_ion[ul]] < 5:
+            cand.extend(range(int(startdown[ul] + ndown[ul]), int(startdown[ul] + ndown[ul] + nup[ul])))
+    cand = np.array(cand, dtype=np.int32)
+    count = np.zeros(ncell, dtype=np.int32)
+    fdep = np.zeros((ncell, stored))
+    rcoeff = np.zeros((ncell, stored))
+    ati = np.zeros((ncell, stored), dtype=np.int32)
+    for c in range(ncell):
+        n = int(min(len(cand), rng.integers(0, stored + 1)))
+        count[c] = n
+        if n == 0:
+            continue
+        ati[c, :n] = np.sort(rng.choice(cand, size=n, replace=False))
+        w = rng.random(n) + 0.05
+        fdep[c, :n] = w / w.sum() * 0.8 * float(frac_exc[c])
+        rcoeff[c, :n] = 10 ** rng.uniform(-1.0, 3.0, n)
+    return dict(nt_frac_ionisation=frac_ion, nt_frac_excitation=frac_exc, nt_deposition_rate_density=dep,
+                nt_eff_ionpot=eff.ravel(), nt_prob_num_auger=auger().ravel(), nt_ionenfrac_num_auger=auger().ravel(),
+                nt_exc_count=count, nt_exc_frac_deposition=fdep.ravel(), nt_exc_ratecoeffperdeposition=rcoeff.ravel(),
+                nt_exc_alltransindex=ati.ravel(), nt_excitations_stored=stored)
 
 
 def nebular_cellstate(atomic: dict, cells: dict, ncell: int, seed: int = 201) -> dict:

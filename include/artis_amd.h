@@ -263,6 +263,12 @@ typedef struct artis_model {
   double rmax;            /* globals::rmax */
   const double *coord_pos_min_tmin[3]; /* grid.cc coord_pos_min_tmin */
   const int32_t *propcell_nonemptymgi; /* [ngrid] grid::get_propcell_nonemptymgi(), -1 = empty */
+
+  /* static inputs of the non-thermal channels, required by builds with ARTIS_OPT_NT_ON (else may be NULL):
+   * [nelements] globals::elements[].initstablemeannucmass (grid.cc:1515, USE_CALCULATED_MEANATOMICWEIGHT off) and
+   * [nions] nonthermal get_sum_q_over_binding_energy(element, ion) (nonthermal.cc:553; from the host's binding-energy data) */
+  const float *elem_meannucmass;
+  const double *ion_nt_sum_q_over_binding;
 } artis_model;
 
 /* ---- per-timestep cell state written by the reference's update_grid() ----- */
@@ -299,6 +305,25 @@ typedef struct artis_cellstate {
    * solution): required by builds with ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON */
   const float *radfieldbin_W;
   const float *radfieldbin_T_R;
+  /* Solution of the host's Spencer-Fano solver, read by the non-thermal channels of do_ntlepton_deposit() and of the
+   * macro-atom (nonthermal.cc:215-250): required by builds with ARTIS_OPT_NT_ON.
+   *   nt_frac_ionisation / nt_frac_excitation [npts_nonempty]  NonThermalCellSolution::frac_ionisation / frac_excitation
+   *   nt_deposition_rate_density [npts_nonempty]               ntlepton_deposition_rate_density_all_cells
+   *   nt_eff_ionpot [npts_nonempty*nions]                      NonThermalSolutionIon::eff_ionpot
+   *   nt_prob_num_auger, nt_ionenfrac_num_auger [npts_nonempty*nions*(NT_MAX_AUGER_ELECTRONS+1)]
+   *   nt_exc_count [npts_nonempty]                             NonThermalCellSolution::frac_excitations_list_size
+   *   nt_exc_* [npts_nonempty*nt_excitations_stored]           the cell's NonThermalExcitation list, ascending alltransindex */
+  const float *nt_frac_ionisation;
+  const float *nt_frac_excitation;
+  const double *nt_deposition_rate_density;
+  const float *nt_eff_ionpot;
+  const float *nt_prob_num_auger;
+  const float *nt_ionenfrac_num_auger;
+  const int32_t *nt_exc_count;
+  const double *nt_exc_frac_deposition;
+  const double *nt_exc_ratecoeffperdeposition;
+  const int32_t *nt_exc_alltransindex;
+  int32_t nt_excitations_stored; /* nonthermal.cc nt_excitations_stored: stride of the nt_exc_* lists */
 } artis_cellstate;
 
 typedef struct artis_timestep {

@@ -30,8 +30,8 @@
 /* -DARTIS_PRESET_NLTENEBULAR: the packet-path options of artisoptions_nltenebular.h (BASELINE.json configs[4]): level
  * populations and photoionisation coefficients come from the host (NLTE solver, USE_LUT_PHOTOION off), the radiation
  * field is the multibin model (estimators per frequency bin, binned J_nu in the radiative excitation rates), every
- * continuum has a detailed bound-free estimator. NOT covered: NT_ON (Spencer-Fano channels of do_ntlepton_deposit() and
- * the non-thermal macro-atom rates, artisoptions_nltenebular.h:102) -- this build keeps NT_ON = 0. */
+ * continuum has a detailed bound-free estimator, and the non-thermal channels are on (NT_ON with a Spencer-Fano solution
+ * from the host: ionisation / excitation branches of do_ntlepton_deposit(), non-thermal macro-atom rates). */
 #ifdef ARTIS_PRESET_NLTENEBULAR
 #define ARTIS_OPT_DIPOLE 0                            /* artisoptions_nltenebular.h:48 */
 #define ARTIS_OPT_POL_ON 0                            /* :49 */
@@ -46,7 +46,13 @@
 #define ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS 0      /* :86 */
 #define ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON 1        /* :61 */
 #define ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON 1         /* :78 (LEVEL_HAS_BFEST is true for every level, :80) */
+#define ARTIS_OPT_NT_ON 1                             /* :102 with NT_SOLVE_SPENCERFANO :104 */
 #endif
+/* non-thermal options (artisoptions_nltenebular.h:110-119; NT_EXCITATION_ON only has a meaning with NT_ON) */
+#define ARTIS_OPT_NT_EXCITATION_ON 1
+#define ARTIS_OPT_NTEXCITATION_MAXNLEVELS_LOWER 5
+#define ARTIS_OPT_NTEXCITATION_MAXNLEVELS_UPPER 250
+#define ARTIS_OPT_NT_MAX_AUGER_ELECTRONS 2
 /* multibin radiation field model (artisoptions_nltenebular.h:62-70) */
 #define ARTIS_OPT_RADFIELDBINCOUNT 256
 #define ARTIS_OPT_FIRST_NLTE_RADFIELD_TIMESTEP 12
@@ -119,7 +125,9 @@
 #ifndef ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON
 #define ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON 0      /* artisoptions_classic.h:60 */
 #endif
+#ifndef ARTIS_OPT_NT_ON
 #define ARTIS_OPT_NT_ON 0                           /* artisoptions_classic.h:100 */
+#endif
 #define ARTIS_OPT_VPKT_ON 0                         /* artisoptions_classic.h:50 */
 /* gamma packets: the classic choices (artisoptions_classic.h:144-150) are the ones built */
 #define ARTIS_OPT_USE_XCOM_GAMMAPHOTOION 0            /* Veigele fit for the photoelectric opacity */

@@ -714,6 +714,127 @@ static double get_nnion(const Oracle *o, int c, int element, int ion) {
          o->cs->ion_partfuncts[((ptrdiff_t)c * o->m->nions) + uniqueion(o, element, ion)] /
          stat_weight(o, ionlevelstart(o, element, ion));
 }
+#if ARTIS_OPT_NT_ON
+/* ---- non-thermal channels (nonthermal.cc), read from the Spencer-Fano solution the host hands over ---- */
+#define QE 4.80325E-10 /* constants.h:31 */
+#define NT_NAUGER (ARTIS_OPT_NT_MAX_AUGER_ELECTRONS + 1)
+/* grid::get_elem_numberdens grid.cc:1693 (float mass fraction / double(float mean weight) * float rho) */
+static double get_elem_numberdens(const Oracle *o, int c, int element) {
+  return o->cs->elem_massfracs[((ptrdiff_t)c * o->m->nelements) + element] / (double)o->m->elem_meannucmass[element] * o->cs->rho[c];
+}
+/* get_nnion_tot atomic.h:51 */
+static double get_nnion_tot(const Oracle *o, int c) {
+  double nntot = 0.;
+  for (int element = 0; element < o->m->nelements; element++) nntot += get_elem_numberdens(o, c, element);
+  return nntot;
+}
+/* nt_ionisation_maxupperion nonthermal.cc:2435 (NT_SOLVE_SPENCERFANO) */
+static int nt_ionisation_maxupperion(const Oracle *o, int element, int lowerion) {
+  const int nions = get_nions(o, element);
+  int maxupper = lowerion + 1 + ARTIS_OPT_NT_MAX_AUGER_ELECTRONS;
+  if (nions - 1 < maxupper) maxupper = nions - 1;
+  return maxupper;
+}
+/* nt_ionisation_upperion_probability nonthermal.cc:2398 */
+static double nt_ionisation_upperion_probability(Oracle *o, int c, int element, int lowerion, int upperion, int energyweighted) {
+  const int numaugerelec = upperion - lowerion - 1;
+  const float *prob = (energyweighted ? o->cs->nt_ionenfrac_num_auger : o->cs->nt_prob_num_auger) +
+                      ((((ptrdiff_t)c * o->m->nions) + uniqueion(o, element, lowerion)) * NT_NAUGER);
+  if (numaugerelec < ARTIS_OPT_NT_MAX_AUGER_ELECTRONS) return prob[numaugerelec];
+  if (numaugerelec == ARTIS_OPT_NT_MAX_AUGER_ELECTRONS) {
+    double prob_remaining = 1.;
+    for (int a = 0; a < ARTIS_OPT_NT_MAX_AUGER_ELECTRONS; a++) prob_remaining -= prob[a];
+    if (!(fabs(prob_remaining - prob[numaugerelec]) < 0.001)) ORACLE_FAIL(o, "Auger probabilities do not sum to one");
+    return prob_remaining;
+  }
+  return 0.;
+}
+/* nt_random_upperion nonthermal.cc:2450 */
+static int nt_random_upperion(Oracle *o, int c, int element, int lowerion, int energyweighted, uint32_t *rngstate) {
+  const double zrand = rng_uniform(rngstate);
+  double prob_sum = 0.;
+  const int maxupper = nt_ionisation_maxupperion(o, element, lowerion);
+  for (int upperion = lowerion + 1; upperion <= maxupper; upperion++) {
+    prob_sum += nt_ionisation_upperion_probability(o, c, element, lowerion, upperion, energyweighted);
+    if (zrand < prob_sum) return upperion;
+  }
+  if (!(prob_sum > 0.99)) ORACLE_FAIL(o, "nt_random_upperion: probabilities sum below 0.99");
+  return maxupper;
+}
+/* get_oneoverw_approx_axelrod nonthermal.cc:1207 */
+static double get_oneoverw_approx_axelrod(const Oracle *o, int element, int ion, int c) {
+  double nntot = 0., Zbar = 0.;
+  for (int ielement = 0; ielement < o->m->nelements; ielement++) {
+    const double nnelement = get_elem_numberdens(o, c, ielement);
+    Zbar += nnelement * o->m->elem_anumber[ielement];
+    nntot += nnelement;
+  }
+  if (nntot > 0) Zbar /= nntot;
+  const double binding = o->m->ion_nt_sum_q_over_binding[uniqueion(o, element, ion)];
+  const double Aconst = 1.33e-14 * EV * EV;
+  return Aconst * binding / Zbar / (2 * PI * (pow2(QE) * pow2(QE)));
+}
+/* nt_ionisation_ratecoeff nonthermal.cc:2478 with nt_ionisation_ratecoeff_sf :1420 and _wfapprox :1251 */
+static double nt_ionisation_ratecoeff(const Oracle *o, int c, int element, int ion) {
+  const double deposition_rate_density = o->cs->nt_deposition_rate_density[c];
+  double Y_nt = 0.;
+  if (deposition_rate_density > 0.)
+    Y_nt = deposition_rate_density / get_nnion_tot(o, c) / o->cs->nt_eff_ionpot[((ptrdiff_t)c * o->m->nions) + uniqueion(o, element, ion)];
+  if (!isfinite(Y_nt)) return deposition_rate_density / get_nnion_tot(o, c) * get_oneoverw_approx_axelrod(o, element, ion, c);
+  return Y_nt;
+}
+/* nt_excitation_ratecoeff nonthermal.cc:2496 */
+static double nt_excitation_ratecoeff(const Oracle *o, int c, int lowerlevel, int upperlevel, int alltransindex) {
+  if (!ARTIS_OPT_NT_EXCITATION_ON) return 0.;
+  if (lowerlevel >= ARTIS_OPT_NTEXCITATION_MAXNLEVELS_LOWER) return 0.;
+  if (upperlevel >= ARTIS_OPT_NTEXCITATION_MAXNLEVELS_UPPER) return 0.;
+  const ptrdiff_t base = (ptrdiff_t)c * o->cs->nt_excitations_stored;
+  const int32_t *ati = o->cs->nt_exc_alltransindex + base;
+  int lo = 0, hi = o->cs->nt_exc_count[c]; /* std::ranges::lower_bound */
+  const int n = hi;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) / 2);
+    if (ati[mid] < alltransindex) lo = mid + 1; else hi = mid;
+  }
+  if (lo == n || ati[lo] != alltransindex) return 0.;
+  return o->cs->nt_exc_ratecoeffperdeposition[base + lo] * o->cs->nt_deposition_rate_density[c];
+}
+static double get_nnion(const Oracle *o, int c, int element, int ion);
+/* ion_ntion_energyrate nonthermal.cc:1509 */
+static double ion_ntion_energyrate(Oracle *o, int c, int element, int lowerion) {
+  const double nnlowerion = get_nnion(o, c, element, lowerion);
+  double enrate = 0.;
+  const int maxupperion = nt_ionisation_maxupperion(o, element, lowerion);
+  for (int upperion = lowerion + 1; upperion <= maxupperion; upperion++) {
+    const double upperionprobfrac = nt_ionisation_upperion_probability(o, c, element, lowerion, upperion, 0);
+    const double epsilon_trans = epsilon(o, ionlevelstart(o, element, upperion)) - epsilon(o, ionlevelstart(o, element, lowerion));
+    enrate += nnlowerion * upperionprobfrac * epsilon_trans;
+  }
+  return nt_ionisation_ratecoeff(o, c, element, lowerion) * enrate;
+}
+/* select_nt_ionisation nonthermal.cc:1537 with get_ntion_energyrate :1524; returns 0 when no ion can be selected */
+static int select_nt_ionisation(Oracle *o, int c, uint32_t *rngstate, int *element_out, int *lowerion_out) {
+  double ratetotal = 0.;
+  for (int ielement = 0; ielement < o->m->nelements; ielement++)
+    for (int ilowerion = 0; ilowerion < get_nions(o, ielement) - 1; ilowerion++) ratetotal += ion_ntion_energyrate(o, c, ielement, ilowerion);
+  if (!(ratetotal > 0.)) return 0;
+  const double zrand = rng_uniform(rngstate);
+  double ratesum = 0.;
+  for (int ielement = 0; ielement < o->m->nelements; ielement++) {
+    for (int ilowerion = 0; ilowerion < get_nions(o, ielement) - 1; ilowerion++) {
+      ratesum += ion_ntion_energyrate(o, c, ielement, ilowerion);
+      if (ratesum > zrand * ratetotal) {
+        *element_out = ielement;
+        *lowerion_out = ilowerion;
+        return 1;
+      }
+    }
+  }
+  ORACLE_FAIL(o, "select_nt_ionisation: nothing selected");
+  return 0;
+}
+#endif
+
 /* calculate_levelpop ltepop.cc:412 via calculate_levelpop_nominpop ltepop.cc:170 (no NLTE levels in classic)
  * and calculate_levelpop_boltzmann ltepop.cc:395 */
 static double calculate_levelpop(const Oracle *o, int c, int element, int ion, int level) {
@@ -972,7 +1093,11 @@ static void calculate_macroatom_transitionrates(Oracle *o, CellCache *cc, int c,
     const double R = rad_excitation_ratecoeff(o, c, upper_statweight, m->alltrans_einstein_A[ati], epsilon_trans, nnlevel,
                                               cc->levelpops[uul], statweight, t_mid);
     const double C = col_excitation_ratecoeff(o, T_e, clumpednne, epsilon_trans, upper_statweight, statweight, ati);
+#if ARTIS_OPT_NT_ON
+    const double NT = nt_excitation_ratecoeff(o, c, level, upper, ati);
+#else
     const double NT = 0.; /* nonthermal::nt_excitation_ratecoeff with NT_ON false */
+#endif
     sum_internal_up_same += (R + C + NT) * epsilon_current;
     transblock[blockstart + (2 * ndowntrans) + ii] = sum_internal_up_same;
   }
@@ -1001,6 +1126,9 @@ static void calculate_macroatom_transitionrates(Oracle *o, CellCache *cc, int c,
   double sum_up_highernt = 0., sum_up_higher = 0.;
   const int ionisinglevels = get_nlevels_ionising(o, element, ion);
   if (ion < get_nions(o, element) - 1 && level < ionisinglevels) {
+#if ARTIS_OPT_NT_ON
+    sum_up_highernt = nt_ionisation_ratecoeff(o, c, element, ion) * epsilon_current; /* macroatom.cc:181 */
+#endif
     const int nt = m->level_nphixstargets[ul];
     for (int t = 0; t < nt; t++) {
       const double epsilon_trans = get_phixs_threshold(o, element, ion, level, t);
@@ -1832,6 +1960,13 @@ static void do_macroatom(Oracle *o, artis_packet *p, const MacroAtomState *ma) {
                                         p->rngstate);
         ion += 1;
         break;
+#if ARTIS_OPT_NT_ON
+      case ARTIS_MA_ACTION_INTERNALUPHIGHERNT: /* macroatom.cc:562 */
+        ion = nt_random_upperion(o, c, element, ion, 0, p->rngstate);
+        level = 0;
+        stat_inc(o, ARTIS_STAT_MA_INTERNALUPHIGHERNT);
+        break;
+#endif
       default: /* MA_ACTION_INTERNALUPHIGHERNT needs NT_ON */
         ORACLE_FAIL(o, "do_macroatom: non-thermal action selected with NT_ON false");
         return;
@@ -2403,9 +2538,58 @@ static void do_gamma(Oracle *o, artis_packet *p, double t2) {
     if (o->est.scalars) o->est.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE] += p->e_cmf;
   }
 }
-/* nonthermal::do_ntlepton_deposit nonthermal.cc:2529 with NT_ON == false (artisoptions_classic.h:95) */
+/* nonthermal::do_ntlepton_deposit nonthermal.cc:2529 (NT_ON false in artisoptions_classic.h:95; NT_ON with
+ * NT_SOLVE_SPENCERFANO in artisoptions_nltenebular.h:102-104) */
 static void do_ntlepton_deposit(Oracle *o, artis_packet *p) {
   if (o->est.scalars) o->est.scalars[ARTIS_SCALAR_NT_ENERGY_DEPOSITED] += p->e_cmf;
+#if ARTIS_OPT_NT_ON
+  const int c = propcell_nonemptymgi(o, p->cellindex);
+  if (o->cs->thick[c] != ARTIS_CELL_THICK) { /* macroatom should not be activated in thick cells */
+    cellcache_populate(o, c); /* TYPE_NTLEPTON_DEPOSITED is a cell-cache type: get_packet_cellcachegroupid update_packets.cc:333 */
+    double zrand = rng_uniform(p->rngstate);
+    const double frac_ionisation = o->cs->nt_frac_ionisation[c];
+    if (zrand < frac_ionisation) {
+      int element = -1, lowerion = -1;
+      if (select_nt_ionisation(o, c, p->rngstate, &element, &lowerion)) {
+        const int upperion = nt_random_upperion(o, c, element, lowerion, 1, p->rngstate);
+        stat_inc(o, ARTIS_STAT_MA_ACTIVATION_NTCOLLION);
+        stat_inc(o, ARTIS_STAT_INTERACTIONS);
+        p->trueemissiontype = ARTIS_EMTYPE_NOTSET;
+        p->trueem_pos[0] = p->trueem_pos[1] = p->trueem_pos[2] = NAN;
+        stat_inc(o, ARTIS_STAT_NT_TO_IONISATION);
+        const MacroAtomState ma = {element, upperion, 0, -99};
+        do_macroatom(o, p, &ma);
+        return;
+      }
+      p->type = ARTIS_TYPE_KPKT;
+      stat_inc(o, ARTIS_STAT_NT_TO_KPKT);
+      return;
+    }
+    const double frac_excitation = ARTIS_OPT_NT_EXCITATION_ON ? o->cs->nt_frac_excitation[c] : 0.;
+    if (zrand < (frac_ionisation + frac_excitation)) {
+      zrand -= frac_ionisation;
+      const ptrdiff_t base = (ptrdiff_t)c * o->cs->nt_excitations_stored;
+      for (int i = 0; i < o->cs->nt_exc_count[c]; i++) {
+        const double frac_deposition_exc = o->cs->nt_exc_frac_deposition[base + i];
+        if (zrand < frac_deposition_exc) {
+          const int lineindex = o->m->alltrans_lineindex[o->cs->nt_exc_alltransindex[base + i]];
+          const int element = o->m->line_elementindex[lineindex];
+          const int ion = o->m->line_ionindex[lineindex];
+          const int upper = o->m->line_uniquelevelindex_upper[lineindex] - ionlevelstart(o, element, ion); /* get_levelfromuniquelevelindex */
+          stat_inc(o, ARTIS_STAT_MA_ACTIVATION_NTCOLLEXC);
+          stat_inc(o, ARTIS_STAT_INTERACTIONS);
+          p->trueemissiontype = ARTIS_EMTYPE_NOTSET;
+          p->trueem_pos[0] = p->trueem_pos[1] = p->trueem_pos[2] = NAN;
+          stat_inc(o, ARTIS_STAT_NT_TO_EXCITATION);
+          const MacroAtomState ma = {element, ion, upper, -99};
+          do_macroatom(o, p, &ma);
+          return;
+        }
+        zrand -= frac_deposition_exc;
+      }
+    }
+  }
+#endif
   p->type = ARTIS_TYPE_KPKT;
   stat_inc(o, ARTIS_STAT_NT_TO_KPKT);
 }

@@ -24,6 +24,7 @@ struct Emu {
   std::vector<stat_t> stats;
   std::vector<double> ws;
   std::vector<int32_t> ws_gi, ws_n;
+  std::vector<double> nt_ionratecoeff, nt_ionenrate_cum;
   int32_t err = 0;
 };
 
@@ -62,6 +63,15 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   e.env.tile_lo = 0;
   e.env.tile_hi = M.npts_nonempty;
   e.env.tile_all = 1;
+#if ARTIS_OPT_NT_ON
+  // k_nt_cells (artis_amd_set_cellstate): derived non-thermal arrays of every cell
+  e.nt_ionratecoeff.assign((size_t)(ncell * M.nions) + 1, 0.);
+  e.nt_ionenrate_cum.assign((size_t)(ncell * M.nions) + 1, 0.);
+  e.env.C.nt_ionratecoeff = e.nt_ionratecoeff.data();
+  e.env.C.nt_ionenrate_cum = e.nt_ionenrate_cum.data();
+  for (int c = 0; c < ncell; c++)
+    if (!populate_nt_cell(e.env, c)) e.err = 90;
+#endif
 }
 
 // the populate kernels, in launch order (artis_engine.hip: k_levelpops, k_line_dpop, k_cell_scalars, k_allcont, k_corrphotoion,

@@ -417,10 +417,10 @@ def test_edge_cases(engine_mod):
 @pytest.mark.parametrize("gridtype,ncoord,nts", [(abi.GRID_CARTESIAN3D, 8, 13), (abi.GRID_SPHERICAL1D, 16, 13),
                                                   (abi.GRID_CARTESIAN3D, 8, 10)])
 def test_engine_matches_oracle_nltenebular_preset(engine_mod, oracle, gridtype, ncoord, nts):
-    """the engine built with the packet-path options of artisoptions_nltenebular.h (libartis_amd_nltenebular.so;
-    BASELINE.json configs[2] without the NT_ON channels): host level populations and photoionisation coefficients,
-    the binned radiation field (read past FIRST_NLTE_RADFIELD_TIMESTEP, accumulated always) and the detailed
-    bound-free estimators, against the oracle built with the same options"""
+    """the engine built with the packet-path options of artisoptions_nltenebular.h (libartis_amd_nltenebular.so):
+    host level populations and photoionisation coefficients, the binned radiation field (read past
+    FIRST_NLTE_RADFIELD_TIMESTEP, accumulated always), the detailed bound-free estimators and the NT_ON channels
+    (Spencer-Fano fractions from the host), against the oracle built with the same options"""
     model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", ncoord, gridtype, 0.0, 16000, kfrac=0.15, gfrac=0.15,
                                                     pfrac=0.3, options="nltenebular", bkw=dict(nts=nts))
     rep = parity.compare_packets(pb, pa, FLOAT_RTOL, "nltenebular: HIP engine vs oracle")
@@ -428,10 +428,13 @@ def test_engine_matches_oracle_nltenebular_preset(engine_mod, oracle, gridtype, 
     parity.compare_estimators(eb, ea, EST_RTOL, "nltenebular: HIP engine vs oracle")
     assert eb.stats[abi.STAT_X_RPKT_STEPS] > 16000 and eb.gammaestimator.sum() == 0
     assert np.count_nonzero(eb.bfrate_raw) > 100 and eb.radfieldbin_J.sum() > 0.5 * eb.J.sum()
+    st = eb.stats_dict()
+    assert st["NT_STAT_TO_IONISATION"] > 100 and st["NT_STAT_TO_EXCITATION"] > 30 and st["MA_STAT_INTERNALUPHIGHERNT"] > 50
     # a cell state without the solver's arrays is refused, not silently replaced by LTE values
-    bare = abi.CellState({k: v for k, v in cs.d.items() if k not in ("levelpops", "corrphotoioncoeff")})
-    with pytest.raises(engine_mod.EngineError):
-        eng.set_cellstate(bare, ts)
+    for missing in (("levelpops", "corrphotoioncoeff"), ("nt_frac_ionisation",), ("nt_exc_alltransindex",)):
+        bare = abi.CellState({k: v for k, v in cs.d.items() if k not in missing})
+        with pytest.raises(engine_mod.EngineError):
+            eng.set_cellstate(bare, ts)
     print(f"worst float rel diff {rep['worst_rel']:.3e}")
     eng.close()
 

@@ -243,9 +243,10 @@ def test_nltenebular_options_preset_bit_exact(oracle, gridtype, ncoord, nts):
     """The packet-path options of artisoptions_nltenebular.h (BASELINE.json configs[2]) as a third build of the same
     sources (-DARTIS_PRESET_NLTENEBULAR): level populations and photoionisation coefficients handed over by the host's
     NLTE solver instead of computed from (T_e, T_R, W) (USE_LUT_PHOTOION off, atomic.h / ltepop.cc:get_levelpop),
-    the 256-bin radiation field in radfield() and its J / nuJ bin estimators (radfield.cc:update_estimators), and the
-    detailed bound-free rate estimators (radfield.cc:update_bfestimators). NT_ON channels are not part of this build
-    (include/artis_options.h)."""
+    the 256-bin radiation field in radfield() and its J / nuJ bin estimators (radfield.cc:update_estimators), the
+    detailed bound-free rate estimators (radfield.cc:update_bfestimators), and the NT_ON channels read from the host's
+    Spencer-Fano solution: ionisation / excitation branches of do_ntlepton_deposit() (nonthermal.cc:2529), non-thermal
+    excitation and ionisation rates of the macro-atom (macroatom.cc:133, :181, :562) with Auger multi-ionisation."""
     P = "nltenebular"
     model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=P, nts=nts)
     pk0 = synth.make_packets(model, aux, 4000, kpkt_fraction=0.15, gamma_fraction=0.15, pellet_fraction=0.3)
@@ -255,6 +256,8 @@ def test_nltenebular_options_preset_bit_exact(oracle, gridtype, ncoord, nts):
     parity.compare_estimators(eb, ea, 1e-11, "nltenebular: kernel bodies vs oracle")
     st = ea.stats_dict()
     assert st["X_RPKT_STEPS"] > 4000 and st["X_MA_JUMPS"] > 10000
+    assert st["NT_STAT_TO_IONISATION"] > 30 and st["NT_STAT_TO_EXCITATION"] > 10 and st["NT_STAT_TO_KPKT"] > 100
+    assert st["MA_STAT_ACTIVATION_NTCOLLION"] == st["NT_STAT_TO_IONISATION"] and st["MA_STAT_INTERNALUPHIGHERNT"] > 20
     assert ea.gammaestimator.sum() == 0 and ea.bfheatingestimator.sum() == 0   # LUT estimators are not kept
     nb = abi.RADFIELDBINCOUNT
     binJ = ea.radfieldbin_J.reshape(-1, nb)
