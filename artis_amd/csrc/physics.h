@@ -128,6 +128,11 @@ enum { PEND_NONE = 0, PEND_MA_ACTION = 2, PEND_KPKT_FB = 3 };
 struct Chi {
   double nu, chi_escatter, chi_freefree_heat, chi_boundfree;
   int32_t nonemptymgi;
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+  // the window of continua [bf_begin, bf_end) that calculate_chi_bf_gammacontr() walked at nu (Phixslist::allcontbegin /
+  // allcontend, rpkt.cc:762-768), kept while the opacity stays in registers; bf_end < 0: not known (loaded with the packet)
+  int32_t bf_begin, bf_end;
+#endif
 };
 
 struct MAState {
@@ -1469,18 +1474,21 @@ AHD int keep_next(KeepIter &it) {
   return i;
 }
 template <bool SELECT>
-AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, double threshold, int *selected) {
+AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, double threshold, int *selected, Chi *keep = nullptr) {
   const DevModel &M = env.M;
   double sum = 0.;
   // std::ranges::fill(groundcont_gamma_contr, 0.) rpkt.cc:728: the list starts empty. The ground-continuum index of
   // the continua rises with nu_edge (nearest-edge map of a sorted list, input.cc:703), so equal indices are adjacent.
-  int ng = 0, lastgi = -1;
+  int ng = 0;
+#if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
+  int lastgi = -1;
   double *wsv = nullptr;
   int32_t *wsi = nullptr;
   if (!SELECT) {
     wsv = env.gamma_ws + (slot * M.nbfcontinua_ground);
     wsi = env.gamma_gi + (slot * M.nbfcontinua_ground);
   }
+#endif
   const float T_e = env.C.Te[c];
   const double ex = exp(-HOVERKB * nu / T_e);
   const bool split_usable = (ex >= DBLMIN);
@@ -1496,6 +1504,12 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
     cend = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
     cbegin = lower_bound_d(M.allcont_nu_edge, cend, nu / M.last_phixs_nuovernuedge);
   }
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+  if (!SELECT && keep != nullptr) {
+    keep->bf_begin = cbegin;
+    keep->bf_end = cend;
+  }
+#endif
   int nvisited = 0;
   const D2 *pairs = env.K.allcont_pair + ((int64_t)c * M.nbfcontinua);  // {nnlevel, edgepart}
   const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
@@ -1542,6 +1556,7 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
         }
         const double corr = dmax(0., 1 - stim);
         const double sigma_contr = sigma_bf * cp[k].probability * corr;
+#if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
         if (!SELECT) {
           const int gi = cp[k].gi;
           if (gi >= 0) {
@@ -1555,6 +1570,7 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
             }
           }
         }
+#endif
         sum += nn[k] * sigma_contr;
         if (SELECT && sum > threshold) {
           *selected = i;
@@ -1587,37 +1603,71 @@ AHD void update_bfestimators(const Env &env, int c, double de, double nu_cmf, co
   const double de_over_nu = de / nu_cmf;
   const double nu = x.nu;  // the frequency the contributions belong to
   // the window stored with the opacity (rpkt.cc:762-768) ...
-  const int end_s = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
-  const int begin_s = lower_bound_d(M.allcont_nu_edge, end_s, nu / M.last_phixs_nuovernuedge);
-  // ... narrowed to the packet's present frequency (radfield.cc:229-244)
-  const int end_n = upper_bound_d(M.allcont_nu_edge, end_s, nu_cmf);
-  const int b0 = begin_s < end_n ? begin_s : end_n;
-  const int begin_n = b0 + lower_bound_d(M.allcont_nu_edge + b0, end_n - b0, nu_cmf / M.last_phixs_nuovernuedge);
+  int begin_n, end_n;
+  if (x.bf_end >= 0) {
+    begin_n = x.bf_begin;
+    end_n = x.bf_end;
+  } else {
+    end_n = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
+    begin_n = lower_bound_d(M.allcont_nu_edge, end_n, nu / M.last_phixs_nuovernuedge);
+  }
+  // ... narrowed to the packet's present frequency (radfield.cc:229-244); nearly every step has just evaluated its
+  // opacity at that very frequency
+  if (nu_cmf != nu) {
+    end_n = upper_bound_d(M.allcont_nu_edge, end_n, nu_cmf);
+    const int b0 = begin_n < end_n ? begin_n : end_n;
+    begin_n = b0 + lower_bound_d(M.allcont_nu_edge + b0, end_n - b0, nu_cmf / M.last_phixs_nuovernuedge);
+  }
   if (begin_n >= end_n) return;
   const float T_e = env.C.Te[c];
   const double ex = exp(-HOVERKB * nu / T_e);
   const bool split_usable = (ex >= DBLMIN);
   const D2 *pairs = env.K.allcont_pair + ((int64_t)c * M.nbfcontinua);
   const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
+  // the same batched walk as chi_bf_gammacontr(): the reads of a few continua are in flight together
   KeepIter it;
   it.keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
   it.cbegin = begin_n;
   it.cend = end_n;
   it.word = begin_n / 64;
   it.bits = keep_masked(it);
-  for (int i = keep_next(it); i >= 0; i = keep_next(it)) {
-    const ContPack cp = M.cont_pack[i];
-    const double sigma_bf = phixs_fromtable(M, M.allphixs + cp.xs_off, cp.nu_edge, nu);
-    const double ep = pairs[i].y;
-    double stim;
-    if (ep >= 0. && split_usable) {
-      stim = ep * ex;
-    } else {
-      stim = departure[i] * exp(-HOVERKB * (nu - cp.nu_edge) / T_e);
+  double *dst = env.E.bfrate_raw + ((int64_t)c * M.nbfcontinua);
+  bool more = true;
+  while (more) {
+    int idx[ARTIS_CHI_BATCH];
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
+      idx[k] = more ? keep_next(it) : -1;
+      if (idx[k] < 0) more = false;
     }
-    const double corr = dmax(0., 1 - stim);
-    const double sigma_contr = sigma_bf * cp.probability * corr;
-    ARTIS_EST_ADD(&env.E.bfrate_raw[((int64_t)c * M.nbfcontinua) + i], sigma_contr * de_over_nu);
+    if (idx[0] < 0) break;
+    ContPack cp[ARTIS_CHI_BATCH];
+    double ep[ARTIS_CHI_BATCH];
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
+      const int i = (idx[k] >= 0) ? idx[k] : idx[0];
+      cp[k] = M.cont_pack[i];
+      ep[k] = pairs[i].y;
+    }
+    PhixsRead xr[ARTIS_CHI_BATCH];
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) xr[k] = phixs_lookup(M, M.allphixs + cp[k].xs_off, cp[k].nu_edge, nu);
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
+      if (idx[k] >= 0) {
+        const int i = idx[k];
+        const double sigma_bf = phixs_finish(M, xr[k], cp[k].nu_edge, nu);
+        double stim;
+        if (ep[k] >= 0. && split_usable) {
+          stim = ep[k] * ex;
+        } else {
+          stim = departure[i] * exp(-HOVERKB * (nu - cp[k].nu_edge) / T_e);
+        }
+        const double corr = dmax(0., 1 - stim);
+        const double sigma_contr = sigma_bf * cp[k].probability * corr;
+        ARTIS_EST_ADD(&dst[i], sigma_contr * de_over_nu);
+      }
+    }
   }
 }
 #endif
@@ -1629,7 +1679,7 @@ AHD void chi_rpkt_cont(const Env &env, double nu_cmf, Chi &x, int c, int64_t slo
   const float T_e = env.C.Te[c];
   x.chi_freefree_heat = env.K.chi_ff_nnionpart[c] / pow3(nu_cmf) * cnne * (1 - exp(-HOVERKB * nu_cmf / T_e));
   x.chi_escatter = SIGMA_T * nne;
-  x.chi_boundfree = chi_bf_gammacontr<false>(env, c, nu_cmf, slot, 0., nullptr);
+  x.chi_boundfree = chi_bf_gammacontr<false>(env, c, nu_cmf, slot, 0., nullptr, &x);
   x.nonemptymgi = c;
   x.nu = nu_cmf;
 }
@@ -3122,6 +3172,10 @@ AHD void chi_load(const PktStore &P, int64_t i, const Pkt &p, Chi &x) {
   const PktFlight &f = P.flight[i];
   x.nu = f.chi_nu; x.chi_escatter = f.chi_es; x.chi_freefree_heat = f.chi_ff; x.chi_boundfree = f.chi_bf;
   x.nonemptymgi = p.chi_mgi;
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+  x.bf_end = -1;
+  x.bf_begin = 0;
+#endif
 }
 AHD void chi_store(const PktStore &P, int64_t i, Pkt &p, const Chi &x) {
   PktFlight &f = P.flight[i];
