@@ -1611,9 +1611,13 @@ AHD void update_bfestimators(const Env &env, int c, double de, double nu_cmf, co
     end_n = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
     begin_n = lower_bound_d(M.allcont_nu_edge, end_n, nu / M.last_phixs_nuovernuedge);
   }
-  // ... narrowed to the packet's present frequency (radfield.cc:229-244); nearly every step has just evaluated its
-  // opacity at that very frequency
-  if (nu_cmf != nu) {
+  // ... narrowed to the packet's present frequency (radfield.cc:229-244). The estimators are taken at the middle of
+  // the step, where the comoving frequency is a little below the one the opacity was evaluated at: the lower end of the
+  // window stays (its bound only moves down) and the upper end drops by the few edges in between, found by stepping
+  // down instead of bisecting the whole table. (upper_bound: first edge > nu_cmf.)
+  if (nu_cmf < nu) {
+    while (end_n > begin_n && M.allcont_nu_edge[end_n - 1] > nu_cmf) end_n--;
+  } else if (nu_cmf > nu) {
     end_n = upper_bound_d(M.allcont_nu_edge, end_n, nu_cmf);
     const int b0 = begin_n < end_n ? begin_n : end_n;
     begin_n = b0 + lower_bound_d(M.allcont_nu_edge + b0, end_n - b0, nu_cmf / M.last_phixs_nuovernuedge);

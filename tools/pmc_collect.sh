@@ -1,11 +1,14 @@
 #!/bin/bash
 # Collect PMC counters for the propagation kernels: separate rocprofv3 passes (kernel-trace + pmc only).
 # (A pass with TA_* counters did not finish within 300 s on this pool and is left out.)
-# usage (on the GPU box): bash tools/pmc_collect.sh [packets] [tag]  -> gpurun_out/pmc_<tag>/<pass>/..., gpurun_out/pmc_<tag>_<pass>.log
+# usage (on the GPU box): bash tools/pmc_collect.sh [packets] [tag] [options preset] [passes, e.g. "1 2 4"]
+#   -> gpurun_out/pmc_<tag>/<pass>/..., gpurun_out/pmc_<tag>_<pass>.log
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 P=${1:-10000000}
 T=${2:-r02}
+O=${3:-classic}
+ONLY=${4:-}
 i=0
 for set in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU" \
@@ -17,6 +20,7 @@ for set in \
   "WRITE_SIZE TCC_EA0_RDREQ_32B_sum"; do
   i=$((i+1))
   tag=pass$i
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_$T/$tag -- python3 $R/bench.py --packets $P --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/pmc_${T}_$tag.log 2>&1
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $i "; then continue; fi
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_$T/$tag -- python3 $R/bench.py --packets $P --steps 1 --warmup 0 --no-cpu-baseline --options $O > $R/gpurun_out/pmc_${T}_$tag.log 2>&1
   echo "$tag rc=$? : $set"
 done
