@@ -140,8 +140,9 @@ _MODEL_FIELDS = [
     ("rmax", C.c_double, None), ("coord_pos_min_tmin", _F64P * 3, "p3"), ("propcell_nonemptymgi", _I32P, np.int32),
     # optional (NULL when absent): static inputs of the non-thermal channels
     ("elem_meannucmass", _F32P, np.float32), ("ion_nt_sum_q_over_binding", _F64P, np.float64),
+    ("ejecta_kinetic_energy", C.c_double, None), ("mtot_input", C.c_double, None),
 ]
-_MODEL_OPTIONAL = ("elem_meannucmass", "ion_nt_sum_q_over_binding")
+_MODEL_OPTIONAL = ("elem_meannucmass", "ion_nt_sum_q_over_binding", "ejecta_kinetic_energy", "mtot_input")
 
 _CELL_FIELDS = [
     ("rho", _F32P, np.float32), ("Te", _F32P, np.float32), ("TJ", _F32P, np.float32), ("TR", _F32P, np.float32),

@@ -1146,6 +1146,10 @@ int artis_amd_abi_version(void) { return 3; }
 const char *artis_amd_options_preset(void) {
 #if defined(ARTIS_PRESET_NLTENEBULAR)
   return "nltenebular";
+#elif defined(ARTIS_PRESET_KILONOVA_BARNES)
+  return "kilonova_barnes";
+#elif defined(ARTIS_PRESET_KILONOVA_WOLLAEGER)
+  return "kilonova_wollaeger";
 #elif defined(ARTIS_PRESET_KILONOVA_LTE)
   return "kilonova_lte";
 #else

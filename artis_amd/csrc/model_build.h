@@ -241,6 +241,7 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.ngrid = m.ngrid;
   v.npts_nonempty = m.npts_nonempty;
   v.tmin = m.tmin; v.vmax = m.vmax; v.rmax = m.rmax;
+  v.ejecta_kinetic_energy = m.ejecta_kinetic_energy; v.mtot_input = m.mtot_input;
   return v;
 }
 

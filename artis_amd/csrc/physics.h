@@ -34,6 +34,8 @@ constexpr double SIGMA_T = 6.6524e-25;
 constexpr double ME = 9.1093897e-28;
 constexpr double MH = 1.67352e-24;
 constexpr double MEV = 1.6021772e-6;
+constexpr double MSUN = 1.98855e+33;  // constants.h:27
+constexpr double DAY = 86400.;        // constants.h:35
 constexpr double THOMSON_LIMIT = 1e-2;  // constants.h:38
 constexpr double NU_100KEV = 2.41326e+19, NU_1MEV = 2.41326e+20, NU_1P022MEV = 2.46636e+20, NU_1P5MEV = 3.61990e+20;  // gammapkt.cc:64-67
 constexpr double KB = 1.38064852e-16;
@@ -3018,6 +3020,29 @@ AHD void do_nonthermal_predeposit(const Env &env, Pkt &p, int64_t pi) {
   const int deposit_type = (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED : ARTIS_TYPE_NTLEPTON_DEPOSITED;
 #if ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_INSTANTFULLDEPOSITION
   p.type = deposit_type;  // absorption happens
+#elif ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_BARNES || ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_WOLLAEGER
+  {  // analytic thermalisation efficiency f_p: deposit with probability f_p, else the particle escapes (update_packets.cc:53-88)
+    const double ts = p.prop_time;
+    double f_p;
+    if (ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_BARNES) {
+      const double E_kin = env.M.ejecta_kinetic_energy;
+      const double v_ej = sqrt(E_kin * 2 / env.M.mtot_input);
+      const double prefactor = (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? 7.74 : 7.4;
+      const double tau_ineff = prefactor * DAY * sqrt(env.M.mtot_input / (5.e-3 * MSUN)) * pow((0.2 * CLIGHT) / v_ej, 3. / 2.);
+      f_p = log1p(2. * ts * ts / tau_ineff / tau_ineff) / (2. * ts * ts / tau_ineff / tau_ineff);
+    } else {
+      const double A = (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? 1.2 * 1.e-11 : 1.3 * 1.e-11;
+      const double aux_term = 2 * A / (ts * env.C.rho[c]);
+      f_p = log1p(aux_term) / aux_term;
+    }
+    if (!(f_p >= 0.) || !(f_p <= 1.)) fail(env, 94);
+    if (rng_uniform(p) < f_p) {
+      p.type = deposit_type;
+    } else {
+      e_cmf_deposited = 0.;
+      change_cell_or_escape(env, p, pi, -99);  // escape_type keeps the particle type (grid.h:130)
+    }
+  }
 #else
   {  // local time-dependent absorption, update_packets.cc:90-150
     const double ts = p.prop_time;

@@ -111,6 +111,7 @@ struct DevModel {
   const int32_t *elem_nions, *elem_uniqueionindexstart, *elem_lowest_ionstage, *elem_anumber;
   const float *elem_meannucmass;             // optional (NT_ON builds)
   const double *ion_nt_sum_q_over_binding;   // optional (NT_ON builds)
+  double ejecta_kinetic_energy, mtot_input;  // Barnes thermalisation scheme only
   const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
       *ion_coolingoffset, *ion_ncoolingterms;
   const double *level_epsilon;

@@ -56,7 +56,8 @@ def _ionpot_ev(Z: int, stage: int) -> float:
 
 # rate-coefficient table grids of the options presets (include/artis_options.h: TABLESIZE, MINTEMP, MAXTEMP)
 OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0, 150000.0),
-                 "nltenebular": (100, 1000.0, 30000.0)}
+                 "nltenebular": (100, 1000.0, 30000.0), "kilonova_barnes": (200, 500.0, 150000.0),
+                 "kilonova_wollaeger": (200, 500.0, 150000.0)}
 
 
 def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fraction: float = 0.4,
@@ -640,6 +641,10 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
                                            thick_below_v=thick_below_v, seed=seed + 100)
     md = {k: v for k, v in atomic.items() if not k.startswith("_")}
     md.update(grid)
+    # whole-ejecta scalars of the Barnes thermalisation scheme (grid.h:139 get_ejecta_kinetic_energy, grid.h:40 mtot_input)
+    m_cell = np.asarray(cells["rho"], dtype=np.float64) * (aux["t"] / grid["tmin"]) ** 3 * aux["cellvol_tmin"]
+    md["mtot_input"] = float(m_cell.sum())
+    md["ejecta_kinetic_energy"] = float((0.5 * m_cell * aux["v"] ** 2).sum())
     model = abi.Model(md)
     if options == "nltenebular":
         cells.update(nebular_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 200))

@@ -269,6 +269,11 @@ typedef struct artis_model {
    * [nions] nonthermal get_sum_q_over_binding_energy(element, ion) (nonthermal.cc:553; from the host's binding-energy data) */
   const float *elem_meannucmass;
   const double *ion_nt_sum_q_over_binding;
+
+  /* whole-ejecta scalars of the Barnes thermalisation efficiency (update_packets.cc:69-77): grid::get_ejecta_kinetic_energy()
+   * (grid.h:139) and grid::mtot_input (grid.h:40). Read only by builds with that scheme; 0 elsewhere. */
+  double ejecta_kinetic_energy;
+  double mtot_input;
 } artis_model;
 
 /* ---- per-timestep cell state written by the reference's update_grid() ----- */

@@ -10,6 +10,25 @@
 #ifndef ARTIS_OPTIONS_H
 #define ARTIS_OPTIONS_H
 
+/* PARTICLE_THERMALISATION_SCHEME (constants.h:78-87, artisoptions_classic.h:146) */
+#define ARTIS_PARTICLE_INSTANTFULLDEPOSITION 0
+#define ARTIS_PARTICLE_BARNES 1
+#define ARTIS_PARTICLE_WOLLAEGER 2
+#define ARTIS_PARTICLE_TIMEDEPENDENT 3
+#define ARTIS_PARTICLE_TIMEDEPENDENT_WITH_ADIABATIC_LOSS 4
+
+/* -DARTIS_PRESET_KILONOVA_BARNES / _WOLLAEGER: artisoptions_kilonova_lte.h with the analytic thermalisation efficiency of
+ * Barnes et al. (2016) or Wollaeger et al. (2018) instead of the local time-dependent scheme (update_packets.cc:69-88).
+ * No options file of the reference selects them; built so that every branch of do_nonthermal_predeposit() is covered. */
+#ifdef ARTIS_PRESET_KILONOVA_BARNES
+#define ARTIS_PRESET_KILONOVA_LTE
+#define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_BARNES
+#endif
+#ifdef ARTIS_PRESET_KILONOVA_WOLLAEGER
+#define ARTIS_PRESET_KILONOVA_LTE
+#define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_WOLLAEGER
+#endif
+
 /* -DARTIS_PRESET_KILONOVA_LTE: the packet-path options of artisoptions_kilonova_lte.h (BASELINE.json configs[3]);
  * every value below is the one of that file where it differs from artisoptions_classic.h. */
 #ifdef ARTIS_PRESET_KILONOVA_LTE
@@ -24,7 +43,9 @@
 #define ARTIS_OPT_MINTEMP 500.                        /* :43 */
 #define ARTIS_OPT_MAXTEMP 150000.                     /* :44 */
 #define ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT 1    /* :118 */
-#define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME 3    /* :146 TIMEDEPENDENT */
+#ifndef ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME
+#define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_TIMEDEPENDENT /* :146 */
+#endif
 #endif
 
 /* -DARTIS_PRESET_NLTENEBULAR: the packet-path options of artisoptions_nltenebular.h (BASELINE.json configs[4]): level
@@ -106,11 +127,6 @@
 #ifndef ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
 #define ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT 0 /* artisoptions_classic.h:118 */
 #endif
-/* PARTICLE_THERMALISATION_SCHEME (artisoptions_classic.h:146): 0 = INSTANTFULLDEPOSITION, 3 = TIMEDEPENDENT,
- * 4 = TIMEDEPENDENT_WITH_ADIABATIC_LOSS. (BARNES and WOLLAEGER read whole-ejecta sums of the host; not built.) */
-#define ARTIS_PARTICLE_INSTANTFULLDEPOSITION 0
-#define ARTIS_PARTICLE_TIMEDEPENDENT 3
-#define ARTIS_PARTICLE_TIMEDEPENDENT_WITH_ADIABATIC_LOSS 4
 #ifndef ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME
 #define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_INSTANTFULLDEPOSITION
 #endif

@@ -53,6 +53,8 @@
 #define ME 9.1093897e-28
 #define MH 1.67352e-24
 #define MEV 1.6021772e-6
+#define MSUN 1.98855e+33 /* constants.h:27 */
+#define DAY 86400.      /* constants.h:35 */
 #define THOMSON_LIMIT 1e-2 /* constants.h:38 */
 #define NU_100KEV 2.41326e+19 /* gammapkt.cc:64-67 */
 #define NU_1MEV 2.41326e+20
@@ -2613,6 +2615,29 @@ static void do_nonthermal_predeposit(Oracle *o, artis_packet *p, double ts_end) 
 #if ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_INSTANTFULLDEPOSITION
   (void)ts; (void)ts_end;
   p->type = deposit_type; /* absorption happens */
+#elif ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_BARNES || ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_WOLLAEGER
+  { /* update_packets.cc:53-88: deposit with probability f_p, otherwise discard the deposited energy and let the particle escape */
+    (void)ts_end;
+    double f_p;
+    if (ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_BARNES) { /* :69 */
+      const double E_kin = o->m->ejecta_kinetic_energy;
+      const double v_ej = sqrt(E_kin * 2 / o->m->mtot_input);
+      const double prefactor = (p->type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? 7.74 : 7.4;
+      const double tau_ineff = prefactor * DAY * sqrt(o->m->mtot_input / (5.e-3 * MSUN)) * pow((0.2 * CLIGHT) / v_ej, 3. / 2.);
+      f_p = log1p(2. * ts * ts / tau_ineff / tau_ineff) / (2. * ts * ts / tau_ineff / tau_ineff);
+    } else { /* :78 Wollaeger et al. 2018 */
+      const double A = (p->type == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) ? 1.2 * 1.e-11 : 1.3 * 1.e-11;
+      const double aux_term = 2 * A / (ts * o->cs->rho[c]);
+      f_p = log1p(aux_term) / aux_term;
+    }
+    if (!(f_p >= 0.) || !(f_p <= 1.)) ORACLE_FAIL(o, "thermalisation efficiency outside [0, 1]");
+    if (rng_uniform(p->rngstate) < f_p) {
+      p->type = deposit_type;
+    } else {
+      e_cmf_deposited = 0.;
+      change_cell_or_escape(o, p, -99);
+    }
+  }
 #else
   { /* local time-dependent absorption, update_packets.cc:90-150 */
     const double rho = o->cs->rho[c];

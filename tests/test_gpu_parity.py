@@ -65,8 +65,12 @@ def engine_mod(oracle_big):
 
 
 def _run_case(engine_mod, oracle, preset, ncoord, gridtype, thick_v, npk, kfrac=0.2, gfrac=0.0, pfrac=0.0, bkw=None, pkw=None,
-              options="classic"):
+              options="classic", model_override=None, rho_scale=None):
     model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, thick_below_v=thick_v, options=options, **(bkw or {}))
+    if model_override:
+        model = abi.Model({**model.d, **model_override})
+    if rho_scale:
+        cs = abi.CellState({**cs.d, "rho": cs.d["rho"] * rho_scale})
     pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=kfrac, gamma_fraction=gfrac, pellet_fraction=pfrac, **(pkw or {}))
     pa, pb = pk0.copy(), pk0.copy()
     ea, eb = abi.estimators_for(model, options), abi.estimators_for(model, options)
@@ -411,6 +415,22 @@ def test_edge_cases(engine_mod):
         assert pk[f][:48].tobytes() == ref[f][:48].tobytes(), f
     for f in ("tdecay", "number", "pellet_decaytype", "pellet_nucindex", "originated_from_particlenotgamma"):
         assert np.array_equal(pk[f], ref[f])  # fields the path never touches survive the round trip
+    eng.close()
+
+
+@pytest.mark.parametrize("options", ["kilonova_barnes", "kilonova_wollaeger"])
+def test_engine_matches_oracle_analytic_thermalisation(engine_mod, oracle, options):
+    """the Barnes / Wollaeger particle thermalisation builds (update_packets.cc:53-88) against the oracle built alike"""
+    mtot = 5.0e-3 * 1.98855e33  # a 0.005 Msun, 0.2 c kilonova: Barnes' f_p(20 d) ~ 0.2
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", 8, abi.GRID_CARTESIAN3D, 0.0, 16000, kfrac=0.1, gfrac=0.1,
+                                                    pfrac=0.7, options=options, rho_scale=1e-4,
+                                                    model_override={"mtot_input": mtot, "ejecta_kinetic_energy": 0.5 * mtot * (0.2 * 2.99792458e10) ** 2})
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, options + ": HIP engine vs oracle")
+    parity.compare_stats(eb, ea, options + ": HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, options + ": HIP engine vs oracle")
+    esc = pb[pb["type"] == abi.TYPE_ESCAPE]
+    assert np.count_nonzero(np.isin(esc["escape_type"], [21, 22, 23])) > 100 and eb.stats_dict()["NT_STAT_TO_KPKT"] > 100
+    print(f"worst float rel diff {rep['worst_rel']:.3e}")
     eng.close()
 
 

@@ -270,3 +270,39 @@ def test_nltenebular_options_preset_bit_exact(oracle, gridtype, ncoord, nts):
     pc, ec = pk0.copy(), abi.estimators_for(model, P)
     oracle.update_packets(model, abi.CellState(cs2_cells), ts, pc, ec, preset=P)
     assert not np.array_equal(pc["nu_cmf"], pa["nu_cmf"])
+
+
+def kilonova_like_ejecta(model):
+    """the same model with the whole-ejecta scalars of a 0.005 Msun, 0.2 c kilonova: Barnes' inefficiency time scale is
+    then 7.4 d and f_p(20 d) ~ 0.2 (with the 1.4 Msun of the synthetic supernova every particle would thermalise)"""
+    mtot = 5.0e-3 * 1.98855e33
+    return abi.Model({**model.d, "mtot_input": mtot, "ejecta_kinetic_energy": 0.5 * mtot * (0.2 * 2.99792458e10) ** 2})
+
+
+@pytest.mark.parametrize("options", ["kilonova_barnes", "kilonova_wollaeger"])
+def test_analytic_thermalisation_schemes_bit_exact(oracle, options):
+    """PARTICLE_THERMALISATION_SCHEME BARNES and WOLLAEGER (update_packets.cc:53-88): a non-thermal particle deposits with
+    the analytic efficiency f_p(t) (Barnes et al. 2016: from the ejecta's mass and kinetic energy; Wollaeger et al. 2018:
+    from the local density) or leaves the grid with its particle type recorded as escape_type. Built on the kilonova_lte
+    options; no options file of the reference selects these schemes."""
+    model, cs, ts, aux = synth.build("small", ncoord=8, options=options)
+    model = kilonova_like_ejecta(model)
+    cs = abi.CellState({**cs.d, "rho": cs.d["rho"] * 1e-4})   # kilonova-like densities: Wollaeger's f_p(rho t) well below 1
+    pk0 = synth.make_packets(model, aux, 6000, kpkt_fraction=0.1, gamma_fraction=0.1, pellet_fraction=0.7)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, options + ": kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, options + ": kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, options + ": kernel bodies vs oracle")
+    esc = pa[pa["type"] == abi.TYPE_ESCAPE]
+    nescaped_particles = np.count_nonzero(np.isin(esc["escape_type"], [21, 22, 23]))   # TYPE_NONTHERMAL_PREDEPOSIT_*
+    ndeposited = ea.stats_dict()["NT_STAT_TO_KPKT"]
+    assert nescaped_particles > 50 and ndeposited > 50
+    sc = dict(zip(abi.SCALAR_NAMES, ea.scalars))
+    # the escaped particles deposit nothing: the discrete deposition is below the emission by their share
+    emitted = sc["electron_emission"] + sc["positron_emission"] + sc["alpha_emission"]
+    deposited = sc["electron_dep_discrete"] + sc["positron_dep_discrete"] + sc["alpha_dep_discrete"]
+    assert 0.05 < deposited / emitted < 0.98
+    # the scheme matters: the time-dependent kilonova_lte build gives another history
+    pc, ec = pk0.copy(), abi.estimators_for(model, "kilonova_lte")
+    oracle.update_packets(model, cs, ts, pc, ec, preset="kilonova_lte")
+    assert not np.array_equal(pc["type"], pa["type"])
