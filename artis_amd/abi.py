@@ -161,11 +161,13 @@ _CELL_FIELDS = [
     ("nt_exc_count", _I32P, np.int32), ("nt_exc_frac_deposition", _F64P, np.float64),
     ("nt_exc_ratecoeffperdeposition", _F64P, np.float64), ("nt_exc_alltransindex", _I32P, np.int32),
     ("nt_excitations_stored", C.c_int32, None),
+    ("expansionopacities", _F32P, np.float32), ("expansionopacity_planck_cumulative", _F64P, np.float64),
 ]
+EXPOPAC_NBINS = 1997
 _CELL_OPTIONAL = ("levelpops", "corrphotoioncoeff", "radfieldbin_W", "radfieldbin_T_R", "nt_frac_ionisation",
                   "nt_frac_excitation", "nt_deposition_rate_density", "nt_eff_ionpot", "nt_prob_num_auger",
                   "nt_ionenfrac_num_auger", "nt_exc_count", "nt_exc_frac_deposition", "nt_exc_ratecoeffperdeposition",
-                  "nt_exc_alltransindex", "nt_excitations_stored")
+                  "nt_exc_alltransindex", "nt_excitations_stored", "expansionopacities", "expansionopacity_planck_cumulative")
 NT_NAUGER = 3  # NT_MAX_AUGER_ELECTRONS + 1
 RADFIELDBINCOUNT = 256
 

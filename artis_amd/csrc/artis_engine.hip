@@ -1146,6 +1146,10 @@ int artis_amd_abi_version(void) { return 3; }
 const char *artis_amd_options_preset(void) {
 #if defined(ARTIS_PRESET_NLTENEBULAR)
   return "nltenebular";
+#elif defined(ARTIS_PRESET_KILONOVA_EXPOPAC)
+  return "kilonova_expopac";
+#elif defined(ARTIS_PRESET_CLASSIC_EXPOPAC_THERM)
+  return "classic_expopac_therm";
 #elif defined(ARTIS_PRESET_KILONOVA_BARNES)
   return "kilonova_barnes";
 #elif defined(ARTIS_PRESET_KILONOVA_WOLLAEGER)
@@ -1433,6 +1437,14 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
   }
   if (ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON && (!e->C.radfieldbin_W || !e->C.radfieldbin_T_R)) {
     g_last_error = "this build has the multibin radiation field on: artis_cellstate.radfieldbin_W / _T_R are required";
+    return ARTIS_ERR_ARG;
+  }
+  if (ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES && !e->C.expansionopacities) {
+    g_last_error = "this build has RPKT_USE_EXPANSION_OPACITIES: artis_cellstate.expansionopacities is required";
+    return ARTIS_ERR_ARG;
+  }
+  if (ARTIS_OPT_RPKT_BB_THERMALISATION && !e->C.expansionopacity_planck_cumulative) {
+    g_last_error = "this build has RPKT_BOUNDBOUND_THERMALISATION_PROBABILITY: artis_cellstate.expansionopacity_planck_cumulative is required";
     return ARTIS_ERR_ARG;
   }
   e->S = make_step(*ts);

@@ -122,7 +122,9 @@ struct ModelOwned {
   X(nt_exc_count, int32_t, (m).npts_nonempty)                                                       \
   X(nt_exc_frac_deposition, double, ((int64_t)(m).npts_nonempty * (nt_stored)))                     \
   X(nt_exc_ratecoeffperdeposition, double, ((int64_t)(m).npts_nonempty * (nt_stored)))              \
-  X(nt_exc_alltransindex, int32_t, ((int64_t)(m).npts_nonempty * (nt_stored)))
+  X(nt_exc_alltransindex, int32_t, ((int64_t)(m).npts_nonempty * (nt_stored)))                      \
+  X(expansionopacities, float, ((int64_t)(m).npts_nonempty * ARTIS_EXPOPAC_NBINS))                  \
+  X(expansionopacity_planck_cumulative, double, ((int64_t)(m).npts_nonempty * ARTIS_EXPOPAC_NBINS))
 
 // X(field, element type, elements per cell) for every array of DevCache
 #define ARTIS_CACHE_ARRAYS(X, m)                                \
@@ -284,6 +286,8 @@ inline DevCells make_host_cells_view(const artis_cellstate &c) {
   v.nt_exc_ratecoeffperdeposition = c.nt_exc_ratecoeffperdeposition; v.nt_exc_alltransindex = c.nt_exc_alltransindex;
   v.nt_excitations_stored = c.nt_excitations_stored;
   v.nt_ionratecoeff = nullptr; v.nt_ionenrate_cum = nullptr;
+  v.expansionopacities = c.expansionopacities;
+  v.expansionopacity_planck_cumulative = c.expansionopacity_planck_cumulative;
   return v;
 }
 

@@ -1790,6 +1790,94 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
   return result;
 }
 
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+// wavelength bins in ascending wavelength (descending frequency), rpkt.h:30-40
+AHD double expopac_bin_nu_upper(int64_t b) { return 1e8 * CLIGHT / (ARTIS_EXPOPAC_LAMBDAMIN + ((double)b * ARTIS_EXPOPAC_DELTALAMBDA)); }
+AHD double expopac_bin_nu_lower(int64_t b) { return 1e8 * CLIGHT / (ARTIS_EXPOPAC_LAMBDAMIN + ((double)(b + 1) * ARTIS_EXPOPAC_DELTALAMBDA)); }
+AHD int64_t linearbinindex(double value, double minvalue, double binwidth) {  // get_linearbinindex sn3d.h:115
+  const double fracindex = (value - minvalue) / binwidth;
+  const int64_t truncated = (int64_t)fracindex;
+  return (fracindex < (double)truncated) ? truncated - 1 : truncated;
+}
+#endif
+#if ARTIS_OPT_RPKT_BB_THERMALISATION
+// sample_planck_times_expansion_opacity rpkt.cc:964
+AHD double sample_planck_times_expopac(const Env &env, int c, Pkt &p) {
+  const double *cum = env.C.expansionopacity_planck_cumulative + ((int64_t)c * ARTIS_EXPOPAC_NBINS);
+  const double last = cum[ARTIS_EXPOPAC_NBINS - 1];
+  if (!(last > 0)) fail(env, 95);
+  const double rnd_integral = rng_uniform(p) * last;
+  int b = upper_bound_d(cum, ARTIS_EXPOPAC_NBINS, rnd_integral);  // index_upperbound sn3d.h:85
+  if (b > ARTIS_EXPOPAC_NBINS - 1) b = ARTIS_EXPOPAC_NBINS - 1;
+  const double bin_nu_lower = expopac_bin_nu_lower(b);
+  const double delta_nu = expopac_bin_nu_upper(b) - bin_nu_lower;
+  const double nuoffset = rng_uniform(p) * delta_nu;
+  return bin_nu_lower + nuoffset;
+}
+#endif
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES
+// get_possible_event_expansion_opacity rpkt.cc:221: the packet walks the wavelength bins of the cell's expansion
+// opacity instead of the line list. With a thermalisation probability the event is placed inside the bin; without, the
+// bin is re-traced line by line (possible_event() on a copy of the packet at the bin's start and the timestep's mid time).
+AHD double possible_event_expopac(const Env &env, int c, Pkt &p, const Chi &x, MAState &ma, double tau_rnd, double nu_cmf_abort,
+                                  double dnu_on_dl, double dop, bool *is_bb) {
+  double px = p.px, py = p.py, pz = p.pz;
+  double nu_cmf = p.nu_cmf;
+  double e_cmf = p.e_cmf;
+  double prop_time = p.prop_time;
+  double dist = 0.;
+  double tau = 0.;
+  int64_t b0 = linearbinindex(1e8 * CLIGHT / nu_cmf, ARTIS_EXPOPAC_LAMBDAMIN, ARTIS_EXPOPAC_DELTALAMBDA);
+  if (b0 < -1) b0 = -1;
+  const float *kappa_bins = env.C.expansionopacities + ((int64_t)c * ARTIS_EXPOPAC_NBINS);
+  const float rho = env.C.rho[c];
+  const double chi_cont = chi_total(x) * dop;
+  for (int64_t b = b0; b < ARTIS_EXPOPAC_NBINS; b++) {
+    const double next_bin_edge_nu = (b < 0) ? expopac_bin_nu_upper(0) : expopac_bin_nu_lower(b);
+    const double binedgedist = linedistance(prop_time, nu_cmf, next_bin_edge_nu, dnu_on_dl);
+    double chi_bb = 0.;
+    if (b >= 0) chi_bb = kappa_bins[b] * rho;  // float product (both are floats in the reference)
+    const double chi_tot = chi_cont + chi_bb;
+    if (chi_tot * binedgedist > tau_rnd - tau) {
+#if ARTIS_OPT_RPKT_BB_THERMALISATION
+      (void)ma;
+      const double edist = dmax(dist + ((tau_rnd - tau) / chi_tot), 0.);
+      *is_bb = rng_uniform(p) < chi_bb / chi_tot;
+      return edist;
+#else
+      Pkt q = p;
+      q.px = px; q.py = py; q.pz = pz;
+      q.nu_cmf = nu_cmf;
+      q.e_cmf = e_cmf;
+      q.prop_time = env.S.mid;  // the expansion opacity was calculated at t_mid
+      q.next_trans = -1;
+      int nt = -1;
+      const double edist_after_bin = possible_event(env, c, q, x, ma, tau_rnd - tau, DBLMAX, 0., dnu_on_dl, dop, &nt, is_bb);
+      return dist + edist_after_bin;
+#endif
+    }
+    tau += chi_tot * binedgedist;
+    dist += binedgedist;
+#if !ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
+    move_raw(px, py, pz, p.dx, p.dy, p.dz, prop_time, p.nu_rf, nu_cmf, p.e_rf, e_cmf, binedgedist);
+#else
+    px += (p.dx * binedgedist);
+    py += (p.dy * binedgedist);
+    pz += (p.dz * binedgedist);
+    prop_time += binedgedist / CLIGHT_PROP;
+    nu_cmf = p.nu_cmf + (dnu_on_dl * dist);
+#endif
+    if (nu_cmf <= nu_cmf_abort) {
+      *is_bb = false;
+      return DBLMAX;
+    }
+  }
+  *is_bb = false;
+  if (chi_cont > 0.) return dist + ((tau_rnd - tau) / chi_cont);
+  return DBLMAX;
+}
+#endif
+
 // em_pos = pos, em_time = prop_time (rpkt.cc:1012, rpkt.cc:449): straight to the flight line
 AHD void set_em_here(const Env &env, const Pkt &p, int64_t pi) {
   PktFlight &fl = env.P.flight[pi];
@@ -2514,10 +2602,14 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
     const double nu_cmf_abort = p.nu_rf * doppler_at(p.px + (p.dx * half) + (p.dx * half), p.py + (p.dy * half) + (p.dy * half),
                                                      p.pz + (p.dz * half) + (p.dz * half), p.dx, p.dy, p.dz, abort_time);
     const double dop = doppler(p);
-    int nt = p.next_trans;
     const double dnu_on_dl = (nu_cmf_abort - p.nu_cmf) / abort_dist;  // rpkt.cc:591
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES
+    edist = possible_event_expopac(env, c, p, x, ma, tau_rnd, nu_cmf_abort, dnu_on_dl, dop, &is_bb);  // rpkt.cc:594
+#else
+    int nt = p.next_trans;
     edist = possible_event(env, c, p, x, ma, tau_rnd, abort_dist, nu_cmf_abort, dnu_on_dl, dop, &nt, &is_bb);
     p.next_trans = nt;
+#endif
     PROF_MARK(env, 50);
   }
   if (!(edist >= 0)) fail(env, 61);
@@ -2535,10 +2627,29 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
     } else if (!is_bb) {
       rpkt_event_continuum(env, p, pi, x, slot);
     } else {
+#if !ARTIS_OPT_RPKT_BB_THERMALISATION
       ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_BB);
       p.absorptiontype = ma.activatingline;
       env.P.flight[pi].absorptionfreq = p.nu_rf;
       ma_activate(p, ma, 1);
+#else
+      // probability-based thermalisation (redistribution of the packet's frequency) or scattering, rpkt.cc:624-648
+      if (ARTIS_OPT_RPKT_BB_THERMALISATION_PROBABILITY >= 1. || rng_uniform(p) < ARTIS_OPT_RPKT_BB_THERMALISATION_PROBABILITY) {
+        p.absorptiontype = ma.activatingline;
+        env.P.flight[pi].absorptionfreq = p.nu_rf;
+        p.nu_cmf = sample_planck_times_expopac(env, c, p);
+        p.next_trans = -1;
+        p.emissiontype = ARTIS_EMTYPE_NOTSET;
+        p.trueemissiontype = ARTIS_EMTYPE_NOTSET;
+        p.flags |= PKT_FLAG_TRUEEM_NAN;
+        env.P.cold[pi].trueem_time = -1.f;
+        p.nscatterings = 0;
+      } else {
+        p.nscatterings++;
+        ARTIS_STAT(env, ARTIS_STAT_ELECTRON_SCATTERINGS);
+      }
+      emit_rpkt(env, p, pi);
+#endif
     }
     PROF_MARK(env, 52);
     return (p.type == ARTIS_TYPE_RPKT);
@@ -2590,6 +2701,11 @@ AHD void thermal_emission_flags(const Env &env, Pkt &p, int64_t pi, int emtype) 
 AHD void do_kpkt_blackbody(const Env &env, Pkt &p, int64_t pi) {  // kpkt.cc:399
   ARTIS_STAT(env, ARTIS_STAT_X_KPKT_STEPS);
   const int c = env.M.propcell_nonemptymgi[p.cellindex];
+#if ARTIS_OPT_RPKT_BB_THERMALISATION
+  if (env.C.thick[c] != ARTIS_CELL_THICK) {  // kpkt.cc:402
+    p.nu_cmf = sample_planck_times_expopac(env, c, p);
+  } else
+#endif
   p.nu_cmf = sample_planck_montecarlo(env.C.Te[c], p);
   emit_rpkt(env, p, pi);
   ARTIS_STAT(env, ARTIS_STAT_K_TO_R_BB);

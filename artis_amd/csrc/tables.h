@@ -174,6 +174,9 @@ struct DevCells {
   // ion_ntion_energyrate() in select_nt_ionisation()'s order. Not part of the tiled cell cache: a deposit reads them in
   // whichever cell the particle stops.
   double *nt_ionratecoeff, *nt_ionenrate_cum;                    // [cell][nions]
+  // [cell][ARTIS_EXPOPAC_NBINS] binned line opacity and its Planck-weighted running integral (expansion-opacity builds)
+  const float *expansionopacities;
+  const double *expansionopacity_planck_cumulative;
 };
 
 struct DevCache {

@@ -57,7 +57,8 @@ def _ionpot_ev(Z: int, stage: int) -> float:
 # rate-coefficient table grids of the options presets (include/artis_options.h: TABLESIZE, MINTEMP, MAXTEMP)
 OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0, 150000.0),
                  "nltenebular": (100, 1000.0, 30000.0), "kilonova_barnes": (200, 500.0, 150000.0),
-                 "kilonova_wollaeger": (200, 500.0, 150000.0)}
+                 "kilonova_wollaeger": (200, 500.0, 150000.0), "kilonova_expopac": (200, 500.0, 150000.0),
+                 "classic_expopac_therm": (100, 3500.0, 140000.0)}
 
 
 def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fraction: float = 0.4,
@@ -646,6 +647,8 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     md["mtot_input"] = float(m_cell.sum())
     md["ejecta_kinetic_energy"] = float((0.5 * m_cell * aux["v"] ** 2).sum())
     model = abi.Model(md)
+    if "expopac" in options:
+        cells.update(expansion_opacity_cellstate(cells, grid["npts_nonempty"], seed=seed + 400))
     if options == "nltenebular":
         cells.update(nebular_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 200))
         cells.update(nonthermal_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 300))
@@ -654,6 +657,28 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     cs = abi.CellState(cells)
     ts = make_timestep(aux["t"], width_frac=width_frac, vmax=grid["vmax"], nts=nts)
     return model, cs, ts, aux
+
+
+def expansion_opacity_cellstate(cells: dict, ncell: int, seed: int = 401) -> dict:
+    """What calculate_expansion_opacities() (rpkt.cc:1071) leaves per cell: a binned line opacity kappa(lambda) [cm^2/g]
+    on the 20 A grid from 60 A to 40000 A (a forest that thins out to the red, with bins and whole stretches without
+    lines), and the running integral over the bins of (kappa + a continuum share) * B_nu(T_e) * delta_nu."""
+    rng = np.random.default_rng(seed)
+    nb = abi.EXPOPAC_NBINS
+    lam_lo = 60.0 + 20.0 * np.arange(nb)
+    nu_upper = 1e8 * CLIGHT / lam_lo
+    nu_lower = 1e8 * CLIGHT / (lam_lo + 20.0)
+    nu_mid = 0.5 * (nu_upper + nu_lower)
+    envelope = 10.0 ** (1.0 - 2.5 * (lam_lo / 40000.0))                       # ~10 cm^2/g in the UV, ~0.03 in the IR
+    kappa = envelope[None, :] * 10.0 ** rng.normal(0.0, 0.6, (ncell, nb))
+    kappa[rng.random((ncell, nb)) < 0.15] = 0.0
+    kappa[:, lam_lo > 30000.0] = 0.0
+    kappa = kappa.astype(np.float32)
+    Te = np.asarray(cells["Te"], dtype=np.float64)
+    x = H * nu_mid[None, :] / (KB * Te[:, None])
+    planck = 2 * H * nu_mid[None, :] ** 3 / CLIGHT ** 2 / np.expm1(np.minimum(x, 700.0))
+    cum = np.cumsum((kappa.astype(np.float64) + 1e-3) * planck * (nu_upper - nu_lower)[None, :], axis=1)
+    return dict(expansionopacities=kappa.ravel(), expansionopacity_planck_cumulative=cum.ravel())
 
 
 def nonthermal_model_inputs(atomic: dict) -> dict:

@@ -29,6 +29,23 @@
 #define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_WOLLAEGER
 #endif
 
+/* RPKT_USE_EXPANSION_OPACITIES = true (artisoptions_*.h:136; binned expansion opacities instead of the line-by-line walk,
+ * rpkt.cc:221), which every options file of the reference leaves off, in its two forms:
+ * -DARTIS_PRESET_KILONOVA_EXPOPAC: artisoptions_kilonova_lte.h + expansion opacities; the bin in which the event falls is
+ *   re-traced line by line and a bound-bound event activates a macro-atom (relativistic Doppler branch of the bin walk);
+ * -DARTIS_PRESET_CLASSIC_EXPOPAC_THERM: artisoptions_classic.h + expansion opacities +
+ *   RPKT_BOUNDBOUND_THERMALISATION_PROBABILITY (:140; here 0.9): a bound-bound event thermalises or scatters instead of
+ *   activating a macro-atom (rpkt.cc:624-648), k-packets in grey-free cells emit from kappa * B_nu (kpkt.cc:402). */
+#ifdef ARTIS_PRESET_KILONOVA_EXPOPAC
+#define ARTIS_PRESET_KILONOVA_LTE
+#define ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES 1
+#endif
+#ifdef ARTIS_PRESET_CLASSIC_EXPOPAC_THERM
+#define ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES 1
+#define ARTIS_OPT_RPKT_BB_THERMALISATION 1
+#define ARTIS_OPT_RPKT_BB_THERMALISATION_PROBABILITY 0.9f
+#endif
+
 /* -DARTIS_PRESET_KILONOVA_LTE: the packet-path options of artisoptions_kilonova_lte.h (BASELINE.json configs[3]);
  * every value below is the one of that file where it differs from artisoptions_classic.h. */
 #ifdef ARTIS_PRESET_KILONOVA_LTE
@@ -133,7 +150,18 @@
 
 /* Options of the reference this build does not implement: they must keep the
  * classic values. (A build that needs them fails here, not at run time.) */
-#define ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES 0    /* artisoptions_classic.h:137 */
+#ifndef ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES
+#define ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES 0    /* artisoptions_classic.h:136 */
+#endif
+#ifndef ARTIS_OPT_RPKT_BB_THERMALISATION
+#define ARTIS_OPT_RPKT_BB_THERMALISATION 0          /* RPKT_BOUNDBOUND_THERMALISATION_PROBABILITY.has_value(), :140 */
+#define ARTIS_OPT_RPKT_BB_THERMALISATION_PROBABILITY 0.f
+#endif
+/* wavelength grid of the expansion opacities, rpkt.h:23-26 */
+#define ARTIS_EXPOPAC_LAMBDAMIN 60.
+#define ARTIS_EXPOPAC_LAMBDAMAX 40000.
+#define ARTIS_EXPOPAC_DELTALAMBDA 20.
+#define ARTIS_EXPOPAC_NBINS 1997 /* (lambdamax - lambdamin) / deltalambda */
 #define ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON 0     /* artisoptions_classic.h:74 */
 #ifndef ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
 #define ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON 0       /* artisoptions_classic.h:76 */

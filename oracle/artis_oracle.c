@@ -1550,6 +1550,107 @@ static double get_possible_event(Oracle *o, const CellCache *cc, const artis_pac
 }
 
 /* emit_rpkt rpkt.cc:991 */
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+/* wavelength bins in ascending wavelength (descending frequency), rpkt.h:30-40 */
+static inline double get_expopac_bin_nu_upper(ptrdiff_t binindex) {
+  return 1e8 * CLIGHT / (ARTIS_EXPOPAC_LAMBDAMIN + ((double)binindex * ARTIS_EXPOPAC_DELTALAMBDA));
+}
+static inline double get_expopac_bin_nu_lower(ptrdiff_t binindex) {
+  return 1e8 * CLIGHT / (ARTIS_EXPOPAC_LAMBDAMIN + ((double)(binindex + 1) * ARTIS_EXPOPAC_DELTALAMBDA));
+}
+/* get_linearbinindex sn3d.h:115 */
+static inline ptrdiff_t get_linearbinindex(double value, double minvalue, double binwidth) {
+  const double fracindex = (value - minvalue) / binwidth;
+  const ptrdiff_t truncated = (ptrdiff_t)fracindex;
+  return (fracindex < (double)truncated) ? truncated - 1 : truncated;
+}
+#endif
+#if ARTIS_OPT_RPKT_BB_THERMALISATION
+/* sample_planck_times_expansion_opacity rpkt.cc:964 */
+static double sample_planck_times_expansion_opacity(Oracle *o, int c, uint32_t *rngstate) {
+  const double *kappa_planck_bins = o->cs->expansionopacity_planck_cumulative + ((ptrdiff_t)c * ARTIS_EXPOPAC_NBINS);
+  if (!(kappa_planck_bins[ARTIS_EXPOPAC_NBINS - 1] > 0)) ORACLE_FAIL(o, "sample_planck_times_expansion_opacity: empty integral");
+  const double rnd_integral = rng_uniform(rngstate) * kappa_planck_bins[ARTIS_EXPOPAC_NBINS - 1];
+  int binindex = upper_bound_d(kappa_planck_bins, ARTIS_EXPOPAC_NBINS, rnd_integral); /* index_upperbound sn3d.h:85 */
+  if (binindex > ARTIS_EXPOPAC_NBINS - 1) binindex = ARTIS_EXPOPAC_NBINS - 1;
+  const double bin_nu_lower = get_expopac_bin_nu_lower(binindex);
+  const double delta_nu = get_expopac_bin_nu_upper(binindex) - bin_nu_lower;
+  const double nuoffset = rng_uniform(rngstate) * delta_nu;
+  return bin_nu_lower + nuoffset;
+}
+#endif
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES
+/* get_possible_event_expansion_opacity rpkt.cc:221 */
+static double get_possible_event_expansion_opacity(Oracle *o, const CellCache *cc, int c, artis_packet *pkt, const ContOpacity *chi,
+                                                   MacroAtomState *mastate, double tau_rnd, double nu_cmf_abort, double dnu_on_dl,
+                                                   double doppler, int *is_bb) {
+  double pos[3] = {pkt->pos[0], pkt->pos[1], pkt->pos[2]};
+  const double nu_rf = pkt->nu_rf;
+  double nu_cmf = pkt->nu_cmf;
+  const double e_rf = pkt->e_rf;
+  double e_cmf = pkt->e_cmf;
+  double prop_time = pkt->prop_time;
+  (void)nu_rf; (void)e_rf; (void)e_cmf;
+  double dist = 0.;
+  double tau = 0.;
+  ptrdiff_t binindex_start = get_linearbinindex(1e8 * CLIGHT / nu_cmf, ARTIS_EXPOPAC_LAMBDAMIN, ARTIS_EXPOPAC_DELTALAMBDA);
+  if (binindex_start < -1) binindex_start = -1;
+  for (ptrdiff_t binindex = binindex_start; binindex < ARTIS_EXPOPAC_NBINS; binindex++) {
+    const double next_bin_edge_nu = (binindex < 0) ? get_expopac_bin_nu_upper(0) : get_expopac_bin_nu_lower(binindex);
+    const double binedgedist = get_linedistance(prop_time, nu_cmf, next_bin_edge_nu, dnu_on_dl);
+    const double chi_cont = chi_total(chi) * doppler;
+    double chi_bb_expansionopac = 0.;
+    if (binindex >= 0) {
+      const float kappa = o->cs->expansionopacities[((ptrdiff_t)c * ARTIS_EXPOPAC_NBINS) + binindex];
+      chi_bb_expansionopac = kappa * o->cs->rho[c]; /* float product: kappa and get_rho() are floats */
+    }
+    const double chi_tot = chi_cont + chi_bb_expansionopac;
+    if (chi_tot * binedgedist > tau_rnd - tau) {
+#if ARTIS_OPT_RPKT_BB_THERMALISATION
+      (void)cc; (void)mastate;
+      const double edist = dmax(dist + ((tau_rnd - tau) / chi_tot), 0.);
+      *is_bb = rng_uniform(pkt->rngstate) < chi_bb_expansionopac / chi_tot;
+      return edist;
+#else
+      /* re-trace this bin line by line */
+      artis_packet pkt_bin_start = *pkt;
+      pkt_bin_start.pos[0] = pos[0]; pkt_bin_start.pos[1] = pos[1]; pkt_bin_start.pos[2] = pos[2];
+      pkt_bin_start.nu_rf = nu_rf;
+      pkt_bin_start.nu_cmf = nu_cmf;
+      pkt_bin_start.e_rf = e_rf;
+      pkt_bin_start.e_cmf = e_cmf;
+      pkt_bin_start.prop_time = o->ts.mid; /* expansion opacity was calculated at t_mid, so match it */
+      pkt_bin_start.next_trans = -1;
+      int next_trans = -1;
+      const double edist_after_bin = get_possible_event(o, cc, &pkt_bin_start, chi, mastate, tau_rnd - tau, DBL_MAXV, 0., dnu_on_dl,
+                                                        doppler, &next_trans, is_bb);
+      dist = dist + edist_after_bin;
+      return dist;
+#endif
+    }
+    tau += chi_tot * binedgedist;
+    dist += binedgedist;
+#if !ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
+    move_pkt_withtime_raw(pos, pkt->dir, &prop_time, nu_rf, &nu_cmf, e_rf, &e_cmf, binedgedist);
+#else
+    pos[0] += (pkt->dir[0] * binedgedist);
+    pos[1] += (pkt->dir[1] * binedgedist);
+    pos[2] += (pkt->dir[2] * binedgedist);
+    prop_time += binedgedist / CLIGHT_PROP;
+    nu_cmf = pkt->nu_cmf + (dnu_on_dl * dist);
+#endif
+    if (nu_cmf <= nu_cmf_abort) {
+      *is_bb = 0;
+      return DBL_MAXV;
+    }
+  }
+  const double chi_cont = chi_total(chi) * doppler;
+  *is_bb = 0;
+  if (chi_cont > 0.) return dist + ((tau_rnd - tau) / chi_cont);
+  return DBL_MAXV;
+}
+#endif
+
 static void emit_rpkt(artis_packet *p) {
   p->type = ARTIS_TYPE_RPKT;
   double dir_cmf[3];
@@ -2113,10 +2214,15 @@ static int do_rpkt_step(Oracle *o, artis_packet *p, double t2, ContOpacity *chi)
     calculate_chi_rpkt_cont(o, cc, p->nu_cmf, chi, c);
     const double nu_cmf_abort = get_nu_cmf_abort(p->pos, p->dir, p->prop_time, p->nu_rf, abort_dist);
     const double doppler = doppler_nucmf_on_nurf(p->pos, p->dir, p->prop_time);
-    int nt = p->next_trans;
     const double dnu_on_dl = (nu_cmf_abort - p->nu_cmf) / abort_dist; /* rpkt.cc:591 */
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES
+    edist = get_possible_event_expansion_opacity(o, cc, c, p, chi, &pktmastate, tau_rnd, nu_cmf_abort, dnu_on_dl, doppler,
+                                                 &event_is_boundbound); /* rpkt.cc:594 */
+#else
+    int nt = p->next_trans;
     edist = get_possible_event(o, cc, p, chi, &pktmastate, tau_rnd, abort_dist, nu_cmf_abort, dnu_on_dl, doppler, &nt, &event_is_boundbound);
     p->next_trans = nt;
+#endif
   }
   if (!(edist >= 0)) ORACLE_FAIL(o, "edist < 0");
 
@@ -2132,10 +2238,29 @@ static int do_rpkt_step(Oracle *o, artis_packet *p, double t2, ContOpacity *chi)
     } else if (!event_is_boundbound) {
       rpkt_event_continuum(o, cc, p, chi);
     } else {
+#if !ARTIS_OPT_RPKT_BB_THERMALISATION
       stat_inc(o, ARTIS_STAT_MA_ACTIVATION_BB);
       p->absorptiontype = pktmastate.activatingline;
       p->absorptionfreq = p->nu_rf;
       do_macroatom(o, p, &pktmastate);
+#else
+      /* probability based thermalisation (redistribution of the packet frequency) or scattering, rpkt.cc:624-648 */
+      if (ARTIS_OPT_RPKT_BB_THERMALISATION_PROBABILITY >= 1. || rng_uniform(p->rngstate) < ARTIS_OPT_RPKT_BB_THERMALISATION_PROBABILITY) {
+        p->absorptiontype = pktmastate.activatingline;
+        p->absorptionfreq = p->nu_rf;
+        p->nu_cmf = sample_planck_times_expansion_opacity(o, c, p->rngstate);
+        p->next_trans = -1;
+        p->emissiontype = ARTIS_EMTYPE_NOTSET;
+        p->trueemissiontype = ARTIS_EMTYPE_NOTSET;
+        p->trueem_pos[0] = p->trueem_pos[1] = p->trueem_pos[2] = NAN;
+        p->trueem_time = -1.;
+        p->nscatterings = 0;
+      } else {
+        p->nscatterings++;
+        stat_inc(o, ARTIS_STAT_ELECTRON_SCATTERINGS);
+      }
+      emit_rpkt(p);
+#endif
     }
     return (p->type == ARTIS_TYPE_RPKT);
   }
@@ -2176,6 +2301,11 @@ static double sample_planck_montecarlo(double T, uint32_t rng[4]) {
 static void do_kpkt_blackbody(Oracle *o, artis_packet *p) {
   o->est.stats[ARTIS_STAT_X_KPKT_STEPS]++;
   const int c = propcell_nonemptymgi(o, p->cellindex);
+#if ARTIS_OPT_RPKT_BB_THERMALISATION
+  if (o->cs->thick[c] != ARTIS_CELL_THICK) { /* kpkt.cc:402 */
+    p->nu_cmf = sample_planck_times_expansion_opacity(o, c, p->rngstate);
+  } else
+#endif
   p->nu_cmf = sample_planck_montecarlo(o->cs->Te[c], p->rngstate);
   emit_rpkt(p);
   p->next_trans = -1;

@@ -120,7 +120,8 @@ def test_one_library_per_options_preset():
     library; each reports the preset it was compiled with and exports the same C-ABI."""
     from artis_amd.build import PRESETS, build as build_preset, so_path
     from artis_amd.engine import EXPORTED_SYMBOLS
-    assert set(PRESETS) == {"classic", "kilonova_lte", "nltenebular", "kilonova_barnes", "kilonova_wollaeger"}
+    assert set(PRESETS) == {"classic", "kilonova_lte", "nltenebular", "kilonova_barnes", "kilonova_wollaeger", "kilonova_expopac",
+                            "classic_expopac_therm"}
     for preset in PRESETS:
         L = C.CDLL(build_preset(preset=preset))
         assert os.path.samefile(build_preset(preset=preset), so_path(preset))

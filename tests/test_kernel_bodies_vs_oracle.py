@@ -306,3 +306,37 @@ def test_analytic_thermalisation_schemes_bit_exact(oracle, options):
     pc, ec = pk0.copy(), abi.estimators_for(model, "kilonova_lte")
     oracle.update_packets(model, cs, ts, pc, ec, preset="kilonova_lte")
     assert not np.array_equal(pc["type"], pa["type"])
+
+
+@pytest.mark.parametrize("options,gridtype,ncoord", [
+    ("kilonova_expopac", abi.GRID_CARTESIAN3D, 8),
+    ("kilonova_expopac", abi.GRID_SPHERICAL1D, 16),
+    ("classic_expopac_therm", abi.GRID_CARTESIAN3D, 8),
+    ("classic_expopac_therm", abi.GRID_CYLINDRICAL2D, 6),
+])
+def test_expansion_opacity_builds_bit_exact(oracle, options, gridtype, ncoord):
+    """RPKT_USE_EXPANSION_OPACITIES (rpkt.cc:221): r-packets walk the 20 A bins of the cell's expansion opacity instead of
+    the line list. kilonova_expopac: the bin of the event is re-traced line by line and a bound-bound event activates a
+    macro-atom (relativistic Doppler branch). classic_expopac_therm: with RPKT_BOUNDBOUND_THERMALISATION_PROBABILITY = 0.9
+    a bound-bound event redistributes the frequency over kappa * B_nu (sample_planck_times_expansion_opacity rpkt.cc:964)
+    or scatters, and pre-k-packets emit from the same distribution (kpkt.cc:402)."""
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options, thick_below_v=4e8 if "therm" in options else 0.0)
+    pk0 = synth.make_packets(model, aux, 4000, kpkt_fraction=0.15, gamma_fraction=0.1, pellet_fraction=0.2)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, options + ": kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, options + ": kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, options + ": kernel bodies vs oracle")
+    st = ea.stats_dict()
+    assert st["X_RPKT_STEPS"] > 4000
+    if "therm" in options:
+        assert st["MA_STAT_ACTIVATION_BB"] == 0                        # a bound-bound event never activates a macro-atom
+        rp = pa[pa["type"] == abi.TYPE_RPKT]
+        assert np.count_nonzero(rp["trueem_time"] == -1.0) > 100       # thermal redistributions (rpkt.cc:641)
+        assert st["ELECTRON_SCATTERINGS"] > 100
+    else:
+        assert st["MA_STAT_ACTIVATION_BB"] > 100 and st["X_LINES_VISITED"] > 1000   # the re-trace walked lines
+    # the options matter: the same input through the line-by-line build gives another history
+    base = "kilonova_lte" if options.startswith("kilonova") else "classic"
+    pc, ec = pk0.copy(), abi.estimators_for(model, base)
+    oracle.update_packets(model, cs, ts, pc, ec, preset=base)
+    assert not np.array_equal(pc["nu_cmf"], pa["nu_cmf"])
