@@ -1150,6 +1150,8 @@ const char *artis_amd_options_preset(void) {
   return "kilonova_expopac";
 #elif defined(ARTIS_PRESET_CLASSIC_EXPOPAC_THERM)
   return "classic_expopac_therm";
+#elif defined(ARTIS_PRESET_KILONOVA_GAMMAPRODUCTS)
+  return "kilonova_gammaproducts";
 #elif defined(ARTIS_PRESET_KILONOVA_BARNES)
   return "kilonova_barnes";
 #elif defined(ARTIS_PRESET_KILONOVA_WOLLAEGER)

@@ -2905,6 +2905,7 @@ AHD double chi_cmf_loss_weighted(const Env &env, int c, double nu_cmf) {  // gam
 }
 AHD void update_gamma_dep(const Env &env, const Pkt &p, int c, double dist) {  // gammapkt.cc:568
   if (!(dist > 0)) return;
+  if (ARTIS_GAMMAPRODUCTS) return;  // the particles the gamma rays produce deposit instead, gammapkt.cc:572
   if (c < 0) return;
   const double doppler_sq = pow2(doppler(p));
   const double heating_cont = chi_cmf_loss_weighted(env, c, p.nu_cmf) * p.e_rf * dist * doppler_sq;
@@ -2968,7 +2969,12 @@ AHD void compton_scatter(const Env &env, Pkt &p, int64_t pi) {  // gammapkt.cc:3
     p.dz = out[2];
     set_restframe_from_cmf(p);
   } else {
+#if ARTIS_GAMMAPRODUCTS
+    p.nu_cmf = p.nu_cmf * (1 - (1 / f));  // the gamma's energy loss is the electron's energy, gammapkt.cc:404
+    p.type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS;
+#else
     p.type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+#endif
     p.absorptiontype = ARTIS_ABSTYPE_GAMMA_COMPTON;
     ARTIS_STAT(env, ARTIS_STAT_NT_FROM_GAMMA);
   }
@@ -2990,7 +2996,13 @@ AHD void pair_production(const Env &env, Pkt &p, int64_t pi) {  // gammapkt.cc:6
   const double gamma_energy = HPLANCK * p.nu_cmf;
   const double prob_gamma = pair_rest_mass_energy / gamma_energy;
   if (rng_uniform(p) > prob_gamma) {
+#if ARTIS_GAMMAPRODUCTS
+    const double particle_kinetic_energy = (gamma_energy - pair_rest_mass_energy) / 2;  // gammapkt.cc:630
+    p.nu_cmf = particle_kinetic_energy / HPLANCK;
+    p.type = (rng_uniform(p) > 0.5) ? ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS : ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS;
+#else
     p.type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+#endif
     p.absorptiontype = ARTIS_ABSTYPE_GAMMA_PAIRPRODUCTION;
     ARTIS_STAT(env, ARTIS_STAT_NT_FROM_GAMMA);
   } else {
@@ -3034,7 +3046,7 @@ AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
     if (chi_compton > chi_rnd) {
       compton_scatter(env, p, pi);
     } else if ((chi_compton + chi_pe) > chi_rnd) {
-      p.type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+      p.type = ARTIS_GAMMAPRODUCTS ? ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS : ARTIS_TYPE_NTLEPTON_DEPOSITED;  // gammapkt.cc:734
       p.absorptiontype = ARTIS_ABSTYPE_GAMMA_PHOTOELECTRIC;
       ARTIS_STAT(env, ARTIS_STAT_NT_FROM_GAMMA);
     } else {
@@ -3043,7 +3055,7 @@ AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
   } else {
     fail(env, 82);
   }
-  if (p.type != ARTIS_TYPE_GAMMA && p.type != ARTIS_TYPE_ESCAPE)
+  if (p.type != ARTIS_TYPE_GAMMA && p.type != ARTIS_TYPE_ESCAPE && !ARTIS_GAMMAPRODUCTS)
     ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE], p.e_cmf);  // gammapkt.cc:926
 }
 // nonthermal::do_ntlepton_deposit nonthermal.cc:2529. NT_ON == false (artisoptions_classic.h:95): every deposit is heat.
@@ -3199,6 +3211,9 @@ AHD void do_nonthermal_predeposit(const Env &env, Pkt &p, int64_t pi) {
       ARTIS_EST_ADD(&env.E.dep_estimator_alpha[c], e_cmf_deposited);
       if (p.type == deposit_type) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ALPHA_DEP_DISCRETE], p.e_cmf);
     }
+  } else if (ARTIS_GAMMAPRODUCTS) {  // update_packets.cc:174: products of gamma rays count as gamma deposition
+    ARTIS_EST_ADD(&env.E.dep_estimator_gamma[c], e_cmf_deposited);
+    if (p.type == ARTIS_TYPE_NTLEPTON_DEPOSITED) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE], p.e_cmf);
   }
 }
 // update_pellet update_packets.cc:185 with pellet_gamma_decay gammapkt.cc:894

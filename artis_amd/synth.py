@@ -58,6 +58,7 @@ def _ionpot_ev(Z: int, stage: int) -> float:
 OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0, 150000.0),
                  "nltenebular": (100, 1000.0, 30000.0), "kilonova_barnes": (200, 500.0, 150000.0),
                  "kilonova_wollaeger": (200, 500.0, 150000.0), "kilonova_expopac": (200, 500.0, 150000.0),
+                 "kilonova_gammaproducts": (200, 500.0, 150000.0),
                  "classic_expopac_therm": (100, 3500.0, 140000.0)}
 
 

@@ -16,6 +16,7 @@
 #define ARTIS_PARTICLE_WOLLAEGER 2
 #define ARTIS_PARTICLE_TIMEDEPENDENT 3
 #define ARTIS_PARTICLE_TIMEDEPENDENT_WITH_ADIABATIC_LOSS 4
+#define ARTIS_PARTICLE_TIMEDEPENDENTWITHGAMMAPRODUCTS 5
 
 /* -DARTIS_PRESET_KILONOVA_BARNES / _WOLLAEGER: artisoptions_kilonova_lte.h with the analytic thermalisation efficiency of
  * Barnes et al. (2016) or Wollaeger et al. (2018) instead of the local time-dependent scheme (update_packets.cc:69-88).
@@ -27,6 +28,13 @@
 #ifdef ARTIS_PRESET_KILONOVA_WOLLAEGER
 #define ARTIS_PRESET_KILONOVA_LTE
 #define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_WOLLAEGER
+#endif
+/* -DARTIS_PRESET_KILONOVA_GAMMAPRODUCTS: TIMEDEPENDENTWITHGAMMAPRODUCTS (constants.h:86): a gamma-ray interaction hands its
+ * energy to an electron / positron that thermalises with the local time-dependent scheme instead of depositing at once
+ * (gammapkt.cc:404, :572, :630, :734, :925; update_packets.cc:174) */
+#ifdef ARTIS_PRESET_KILONOVA_GAMMAPRODUCTS
+#define ARTIS_PRESET_KILONOVA_LTE
+#define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_TIMEDEPENDENTWITHGAMMAPRODUCTS
 #endif
 
 /* RPKT_USE_EXPANSION_OPACITIES = true (artisoptions_*.h:136; binned expansion opacities instead of the line-by-line walk,
@@ -147,6 +155,7 @@
 #ifndef ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME
 #define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_INSTANTFULLDEPOSITION
 #endif
+#define ARTIS_GAMMAPRODUCTS (ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_TIMEDEPENDENTWITHGAMMAPRODUCTS)
 
 /* Options of the reference this build does not implement: they must keep the
  * classic values. (A build that needs them fails here, not at run time.) */

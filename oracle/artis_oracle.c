@@ -2529,6 +2529,7 @@ static double get_chi_cmf_loss_weighted(const Oracle *o, int c, double nu_cmf) {
 /* update_gamma_dep gammapkt.cc:568 */
 static void update_gamma_dep(Oracle *o, const artis_packet *p, int c, double dist) {
   if (!(dist > 0)) return;
+  if (ARTIS_GAMMAPRODUCTS) return; /* the particles the gamma rays produce deposit instead, gammapkt.cc:572 */
   if (c < 0) return;
   const double doppler_sq = pow2(doppler_nucmf_on_nurf(p->pos, p->dir, p->prop_time));
   const double heating_cont = get_chi_cmf_loss_weighted(o, c, p->nu_cmf) * p->e_rf * dist * doppler_sq;
@@ -2590,7 +2591,12 @@ static void compton_scatter(Oracle *o, artis_packet *p) {
     angle_ab(new_dir, negvel, p->dir);
     set_pkt_restframe_from_cmf(p);
   } else {
+#if ARTIS_GAMMAPRODUCTS
+    p->nu_cmf = p->nu_cmf * (1 - (1 / f)); /* the gamma's energy loss is the electron's energy, gammapkt.cc:404 */
+    p->type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS;
+#else
     p->type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+#endif
     p->absorptiontype = ARTIS_ABSTYPE_GAMMA_COMPTON;
     stat_inc(o, ARTIS_STAT_NT_FROM_GAMMA);
   }
@@ -2610,7 +2616,13 @@ static void pair_production(Oracle *o, artis_packet *p) {
   const double gamma_energy = H_PLANCK * p->nu_cmf;
   const double prob_gamma = pair_rest_mass_energy / gamma_energy;
   if (rng_uniform(p->rngstate) > prob_gamma) {
+#if ARTIS_GAMMAPRODUCTS
+    const double particle_kinetic_energy = (gamma_energy - pair_rest_mass_energy) / 2; /* gammapkt.cc:630 */
+    p->nu_cmf = particle_kinetic_energy / H_PLANCK;
+    p->type = (rng_uniform(p->rngstate) > 0.5) ? ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS : ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS;
+#else
     p->type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+#endif
     p->absorptiontype = ARTIS_ABSTYPE_GAMMA_PAIRPRODUCTION;
     stat_inc(o, ARTIS_STAT_NT_FROM_GAMMA);
   } else {
@@ -2652,7 +2664,7 @@ static void transport_gamma(Oracle *o, artis_packet *p, double t2) {
     if (chi_compton > chi_rnd) {
       compton_scatter(o, p);
     } else if ((chi_compton + chi_photo_electric) > chi_rnd) {
-      p->type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+      p->type = ARTIS_GAMMAPRODUCTS ? ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS : ARTIS_TYPE_NTLEPTON_DEPOSITED; /* gammapkt.cc:734 */
       p->absorptiontype = ARTIS_ABSTYPE_GAMMA_PHOTOELECTRIC;
       stat_inc(o, ARTIS_STAT_NT_FROM_GAMMA);
     } else {
@@ -2666,7 +2678,7 @@ static void transport_gamma(Oracle *o, artis_packet *p, double t2) {
 static void do_gamma(Oracle *o, artis_packet *p, double t2) {
   stat_inc(o, ARTIS_STAT_X_GAMMA_STEPS);
   transport_gamma(o, p, t2);
-  if (p->type != ARTIS_TYPE_GAMMA && p->type != ARTIS_TYPE_ESCAPE) {
+  if (p->type != ARTIS_TYPE_GAMMA && p->type != ARTIS_TYPE_ESCAPE && !ARTIS_GAMMAPRODUCTS) { /* gammapkt.cc:925 */
     if (o->est.scalars) o->est.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE] += p->e_cmf;
   }
 }
@@ -2804,6 +2816,9 @@ static void do_nonthermal_predeposit(Oracle *o, artis_packet *p, double ts_end) 
       if (o->est.dep_estimator_alpha) o->est.dep_estimator_alpha[c] += e_cmf_deposited;
       if (p->type == deposit_type) scalar_add(o, ARTIS_SCALAR_ALPHA_DEP_DISCRETE, p->e_cmf);
     }
+  } else if (ARTIS_GAMMAPRODUCTS) { /* update_packets.cc:174: products of gamma rays count as gamma deposition */
+    if (o->est.dep_estimator_gamma) o->est.dep_estimator_gamma[c] += e_cmf_deposited;
+    if (p->type == ARTIS_TYPE_NTLEPTON_DEPOSITED) scalar_add(o, ARTIS_SCALAR_GAMMA_DEP_DISCRETE, p->e_cmf);
   }
 }
 /* pellet_gamma_decay gammapkt.cc:894 */

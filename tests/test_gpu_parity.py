@@ -438,6 +438,19 @@ def test_engine_matches_oracle_expansion_opacities(engine_mod, oracle, options, 
     eng.close()
 
 
+def test_engine_matches_oracle_gamma_products(engine_mod, oracle):
+    """the TIMEDEPENDENTWITHGAMMAPRODUCTS build (gammapkt.cc:404, :572, :630, :734, :925) against the oracle built alike"""
+    P = "kilonova_gammaproducts"
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", 8, abi.GRID_CARTESIAN3D, 0.0, 16000, kfrac=0.1, gfrac=0.7,
+                                                    pfrac=0.1, options=P)
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, P + ": HIP engine vs oracle")
+    parity.compare_stats(eb, ea, P + ": HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, P + ": HIP engine vs oracle")
+    assert eb.stats_dict()["NT_STAT_FROM_GAMMA"] > 1000 and eb.dep_estimator_gamma.sum() > 0
+    print(f"worst float rel diff {rep['worst_rel']:.3e}")
+    eng.close()
+
+
 @pytest.mark.parametrize("options", ["kilonova_barnes", "kilonova_wollaeger"])
 def test_engine_matches_oracle_analytic_thermalisation(engine_mod, oracle, options):
     """the Barnes / Wollaeger particle thermalisation builds (update_packets.cc:53-88) against the oracle built alike"""

@@ -340,3 +340,24 @@ def test_expansion_opacity_builds_bit_exact(oracle, options, gridtype, ncoord):
     pc, ec = pk0.copy(), abi.estimators_for(model, base)
     oracle.update_packets(model, cs, ts, pc, ec, preset=base)
     assert not np.array_equal(pc["nu_cmf"], pa["nu_cmf"])
+
+
+def test_gamma_products_thermalisation_bit_exact(oracle):
+    """TIMEDEPENDENTWITHGAMMAPRODUCTS (constants.h:86): Compton scattering, photoelectric absorption and pair production
+    hand the gamma ray's energy to an electron or positron (gammapkt.cc:404, :630, :734) that slows down with the local
+    time-dependent scheme; its deposition counts as gamma deposition (update_packets.cc:174) and the path estimator of the
+    gamma rays themselves is off (gammapkt.cc:572)."""
+    P = "kilonova_gammaproducts"
+    model, cs, ts, aux = synth.build("small", ncoord=8, options=P)
+    pk0 = synth.make_packets(model, aux, 5000, kpkt_fraction=0.1, gamma_fraction=0.7, pellet_fraction=0.1)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=P)
+    parity.compare_packets(pb, pa, 0.0, P + ": kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, P + ": kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, P + ": kernel bodies vs oracle")
+    st, sc = ea.stats_dict(), dict(zip(abi.SCALAR_NAMES, ea.scalars))
+    assert st["NT_STAT_FROM_GAMMA"] > 300
+    assert ea.dep_estimator_gamma.sum() > 0 and sc["gamma_dep_discrete"] > 0    # deposited by the products, not by the gamma rays
+    # with the plain time-dependent scheme the same gamma rays deposit at once
+    pc, ec = pk0.copy(), abi.estimators_for(model, "kilonova_lte")
+    oracle.update_packets(model, cs, ts, pc, ec, preset="kilonova_lte")
+    assert ec.scalars[abi.SCALAR_NAMES.index("gamma_dep_discrete")] > sc["gamma_dep_discrete"]
