@@ -53,6 +53,22 @@ __global__ void __launch_bounds__(BLOCK) k_line_dpop(Env env) {
   if (i >= total) return;
   populate_line_dpop(env, env.tile_lo + (int)(i / env.M.nlines), (int)(i % env.M.nlines));
 }
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+// calculate_expansion_opacities() for the cells of the resident tile, when the host did not hand the tables over
+__global__ void __launch_bounds__(BLOCK) k_expopac(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * ARTIS_EXPOPAC_NBINS;
+  if (i >= total) return;
+  const int c = env.tile_lo + (int)(i / ARTIS_EXPOPAC_NBINS);
+  if (env.C.thick[c] == ARTIS_CELL_THICK) return;  // update_grid.cc:657
+  populate_expopac_bin(env, c, (int)(i % ARTIS_EXPOPAC_NBINS));
+}
+__global__ void __launch_bounds__(BLOCK) k_expopac_planck(Env env) {
+  const int c = env.tile_lo + blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= env.tile_hi || env.C.thick[c] == ARTIS_CELL_THICK) return;
+  populate_expopac_planck(env, c);
+}
+#endif
 #if ARTIS_OPT_NT_ON
 // every cell of the model (not a tile): the non-thermal ionisation rate coefficients and energy-rate sums
 __global__ void __launch_bounds__(BLOCK) k_nt_cells(Env env, int ncell) {
@@ -926,6 +942,7 @@ struct artis_amd_engine {
   DevStep S{};
   DevEst E{};
   bool have_cells = false;
+  bool expopac_own = false;  // the expansion-opacity tables are the engine's (calculated at cell-cache population)
   // Cell-cache tiling: the cache rows of `tile_cells` non-empty cells are resident at a time (all of them when they fit
   // the budget: ntiles == 1). With more tiles, update_packets sweeps over them -- populate a tile, advance every packet
   // that sits in one of its cells until it leaves the tile or is done -- until no packet is left (what the reference's
@@ -1441,13 +1458,28 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
     g_last_error = "this build has the multibin radiation field on: artis_cellstate.radfieldbin_W / _T_R are required";
     return ARTIS_ERR_ARG;
   }
-  if (ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES && !e->C.expansionopacities) {
-    g_last_error = "this build has RPKT_USE_EXPANSION_OPACITIES: artis_cellstate.expansionopacities is required";
-    return ARTIS_ERR_ARG;
-  }
-  if (ARTIS_OPT_RPKT_BB_THERMALISATION && !e->C.expansionopacity_planck_cumulative) {
-    g_last_error = "this build has RPKT_BOUNDBOUND_THERMALISATION_PROBABILITY: artis_cellstate.expansionopacity_planck_cumulative is required";
-    return ARTIS_ERR_ARG;
+  e->expopac_own = false;
+  if (ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION) {
+    // the tables of calculate_expansion_opacities(): the host's, or (both NULL) made by the engine at cell-cache population
+    const bool need_planck = ARTIS_OPT_RPKT_BB_THERMALISATION;
+    if (!e->C.expansionopacities && !e->C.expansionopacity_planck_cumulative) {
+      const size_t cnt = (size_t)(h.npts_nonempty > 0 ? h.npts_nonempty : 1) * ARTIS_EXPOPAC_NBINS;
+      float *dk = nullptr;
+      double *dp = nullptr;
+      HIP_TRY(hipMalloc((void **)&dk, sizeof(float) * cnt));
+      e->cell_allocs.push_back(dk);
+      HIP_TRY(hipMemset(dk, 0, sizeof(float) * cnt));
+      HIP_TRY(hipMalloc((void **)&dp, sizeof(double) * cnt));
+      e->cell_allocs.push_back(dp);
+      HIP_TRY(hipMemset(dp, 0, sizeof(double) * cnt));
+      e->C.expansionopacities = dk;
+      e->C.expansionopacity_planck_cumulative = dp;
+      e->expopac_own = true;
+    } else if (!e->C.expansionopacities || (need_planck && !e->C.expansionopacity_planck_cumulative)) {
+      g_last_error = "expansion-opacity build: hand over both artis_cellstate.expansionopacities and (with a thermalisation "
+                     "probability) .expansionopacity_planck_cumulative, or neither (the engine then calculates them)";
+      return ARTIS_ERR_ARG;
+    }
   }
   e->S = make_step(*ts);
 #if ARTIS_OPT_NT_ON
@@ -1506,6 +1538,12 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s) {
     hipLaunchKernelGGL(k_hotselect, dim3(nblocks(ncell * 64)), dim3(BLOCK), 0, s, env);
     hipLaunchKernelGGL(k_hotfill, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   }
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+  if (e->expopac_own) {  // needs line_dpop and chi_ff_nnionpart of the tile's cells (k_line_dpop, k_cell_scalars above)
+    hipLaunchKernelGGL(k_expopac, dim3(nblocks((int64_t)ncell * ARTIS_EXPOPAC_NBINS)), dim3(BLOCK), 0, s, env);
+    if (ARTIS_OPT_RPKT_BB_THERMALISATION) hipLaunchKernelGGL(k_expopac_planck, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
+  }
+#endif
   hipLaunchKernelGGL(k_cooling_ion, dim3(nblocks(ncell * h.nions)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_prefix, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
   HIP_TRY(hipGetLastError());

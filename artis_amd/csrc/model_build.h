@@ -20,6 +20,7 @@ struct ModelOwned {
   std::vector<int32_t> alltrans_owner;
   std::vector<int32_t> scanblk_start;
   std::vector<ContPack> cont_pack;
+  std::vector<int32_t> expopac_linestart;
 };
 
 // X(field, element type, element count) for every array pointer of DevModel
@@ -82,6 +83,7 @@ struct ModelOwned {
   X(coolinglist_type, uint8_t, (m).ncoolingterms)                                  \
   X(coolinglist_level, int32_t, (m).ncoolingterms)                                 \
   X(coolinglist_phixstargetindex, int32_t, (m).ncoolingterms)                      \
+  X(expopac_linestart, int32_t, (ARTIS_EXPOPAC_NBINS + 1))                         \
   X(propcell_nonemptymgi, int32_t, (m).ngrid)
 
 // arrays of DevModel that may be absent (null) on the host
@@ -212,6 +214,21 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
                                 m.level_phixsstart[m.allcont_uniquelevelindex[i]] * m.NPHIXSPOINTS,
                                 m.allcont_groundcontestimindex[i], {0, 0}};
   v.cont_pack = own.cont_pack.data();
+  // which lines calculate_expansion_opacities() (rpkt.cc:1083-1097) adds into which wavelength bin: the walk starts at the
+  // first line with nu <= nu_upper(0) and bin b takes lines while nu >= nu_lower(b)
+  own.expopac_linestart.assign(ARTIS_EXPOPAC_NBINS + 1, m.nlines);
+  {
+    int li = 0;
+    const double nu0 = 1e8 * 2.99792458e+10 / ARTIS_EXPOPAC_LAMBDAMIN;
+    while (li < m.nlines && m.line_nu[li] > nu0) li++;
+    for (int b = 0; b < ARTIS_EXPOPAC_NBINS; b++) {
+      own.expopac_linestart[b] = li;
+      const double nu_lower = 1e8 * 2.99792458e+10 / (ARTIS_EXPOPAC_LAMBDAMIN + ((double)(b + 1) * ARTIS_EXPOPAC_DELTALAMBDA));
+      while (li < m.nlines && m.line_nu[li] >= nu_lower) li++;
+    }
+    own.expopac_linestart[ARTIS_EXPOPAC_NBINS] = li;
+  }
+  v.expopac_linestart = own.expopac_linestart.data();
 #define ARTIS_COPY_PTR(f) v.f = m.f;
   ARTIS_COPY_PTR(elem_nions) ARTIS_COPY_PTR(elem_uniqueionindexstart) ARTIS_COPY_PTR(elem_lowest_ionstage)
   ARTIS_COPY_PTR(elem_anumber) ARTIS_COPY_PTR(elem_meannucmass) ARTIS_COPY_PTR(ion_nt_sum_q_over_binding)

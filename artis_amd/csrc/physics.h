@@ -1800,6 +1800,45 @@ AHD int64_t linearbinindex(double value, double minvalue, double binwidth) {  //
   return (fracindex < (double)truncated) ? truncated - 1 : truncated;
 }
 #endif
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+// calculate_expansion_opacities rpkt.cc:1071, run by the engine when the host does not hand the tables over (they are a
+// product of update_grid() in the reference, update_grid.cc:655). One (cell, bin): the lines of the bin in list order.
+AHD void populate_expopac_bin(const Env &env, int c, int b) {
+  const DevModel &M = env.M;
+  const double *dpop = env.K.line_dpop + ((int64_t)c * M.nlines);
+  const double t_mid = env.S.mid;
+  double bin_linesum = 0.;
+  const int l1 = M.expopac_linestart[b + 1];
+  for (int li = M.expopac_linestart[b]; li < l1; li++) {
+    const double tau_line = dmax(dpop[li] * HCLIGHTOVERFOURPI * t_mid, 0.);  // get_tau_sobolev rpkt.cc:75
+    const double linelambda = 1e8 * CLIGHT / M.line_nu[li];
+    bin_linesum += (linelambda / ARTIS_EXPOPAC_DELTALAMBDA) * -expm1(-tau_line);
+  }
+  const float kappa = (float)(1. / (CLIGHT * t_mid * env.C.rho[c]) * bin_linesum);
+  if (!isfinite(kappa)) fail(env, 96);
+  const_cast<float *>(env.C.expansionopacities)[((int64_t)c * ARTIS_EXPOPAC_NBINS) + b] = kappa;
+}
+// ... and one cell: the running integral of (kappa + free-free) * B_nu(T_e) over the bins (rpkt.cc:1102-1118)
+AHD void populate_expopac_planck(const Env &env, int c) {
+  const float *kappa = env.C.expansionopacities + ((int64_t)c * ARTIS_EXPOPAC_NBINS);
+  double *cum = const_cast<double *>(env.C.expansionopacity_planck_cumulative) + ((int64_t)c * ARTIS_EXPOPAC_NBINS);
+  const float rho = env.C.rho[c];
+  const float T_e = env.C.Te[c];
+  const float cnne = env.C.nne[c] * env.C.clumpfactor[c];
+  double kappa_planck_cumulative = 0.;
+  for (int b = 0; b < ARTIS_EXPOPAC_NBINS; b++) {
+    const double nu_lower = expopac_bin_nu_lower(b);
+    const double nu_upper = expopac_bin_nu_upper(b);
+    const double nu_mid = (nu_upper + nu_lower) / 2.;
+    const double chi_ff = env.K.chi_ff_nnionpart[c] / pow3(nu_mid) * cnne * (1 - exp(-HOVERKB * nu_mid / T_e));  // rpkt.cc:697
+    const double bin_kappa_cont = chi_ff / rho;
+    const double kappa_planck = (kappa[b] + bin_kappa_cont) * planck(nu_mid, T_e);
+    const double delta_nu = nu_upper - nu_lower;
+    kappa_planck_cumulative += kappa_planck * delta_nu;
+    cum[b] = kappa_planck_cumulative;
+  }
+}
+#endif
 #if ARTIS_OPT_RPKT_BB_THERMALISATION
 // sample_planck_times_expansion_opacity rpkt.cc:964
 AHD double sample_planck_times_expopac(const Env &env, int c, Pkt &p) {

@@ -112,6 +112,9 @@ struct DevModel {
   const float *elem_meannucmass;             // optional (NT_ON builds)
   const double *ion_nt_sum_q_over_binding;   // optional (NT_ON builds)
   double ejecta_kinetic_energy, mtot_input;  // Barnes thermalisation scheme only
+  // [ARTIS_EXPOPAC_NBINS + 1] first line of each wavelength bin of the expansion opacities (lines in falling frequency:
+  // bin b holds the lines [start[b], start[b+1])); derived on the host, model_build.h
+  const int32_t *expopac_linestart;
   const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
       *ion_coolingoffset, *ion_ncoolingterms;
   const double *level_epsilon;

@@ -635,8 +635,9 @@ PRESETS = {
 
 def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTESIAN3D, seed: int = 1,
           t_days: float = 20.0, thick_below_v: float = 0.0, width_frac: float = 0.05, nts: int = 10, tmin_days: float = 2.0,
-          options: str = "classic"):
-    """One-call construction of (Model, CellState, Timestep, aux)."""
+          options: str = "classic", host_expopac: bool = False):
+    """One-call construction of (Model, CellState, Timestep, aux). host_expopac: hand synthetic expansion-opacity tables
+    over with the cell state (expansion-opacity builds; otherwise the engine calculates them from the line list)."""
     elements, nl, lf, npx = PRESETS[preset]
     atomic = make_atomic(seed=seed, elements=elements, nlevels_per_ion=nl, line_fraction=lf, nphixspoints=npx, options=options)
     grid, cells, aux = make_grid_and_cells(atomic, ncoord=ncoord, gridtype=gridtype, t_days=t_days, tmin_days=tmin_days,
@@ -648,7 +649,7 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     md["mtot_input"] = float(m_cell.sum())
     md["ejecta_kinetic_energy"] = float((0.5 * m_cell * aux["v"] ** 2).sum())
     model = abi.Model(md)
-    if "expopac" in options:
+    if "expopac" in options and host_expopac:
         cells.update(expansion_opacity_cellstate(cells, grid["npts_nonempty"], seed=seed + 400))
     if options == "nltenebular":
         cells.update(nebular_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 200))

@@ -330,8 +330,9 @@ typedef struct artis_cellstate {
   const int32_t *nt_exc_alltransindex;
   int32_t nt_excitations_stored; /* nonthermal.cc nt_excitations_stored: stride of the nt_exc_* lists */
   /* [npts_nonempty*ARTIS_EXPOPAC_NBINS] what calculate_expansion_opacities() (rpkt.cc:1071, called from update_grid.cc:655)
-   * leaves per cell: the binned line opacity kappa [cm^2/g] (required by builds with RPKT_USE_EXPANSION_OPACITIES) and the
-   * running integral of kappa * B_nu(T_e) over the bins (required with RPKT_BOUNDBOUND_THERMALISATION_PROBABILITY) */
+   * leaves per cell: the binned line opacity kappa [cm^2/g] (read by builds with RPKT_USE_EXPANSION_OPACITIES) and the
+   * running integral of kappa * B_nu(T_e) over the bins (read with RPKT_BOUNDBOUND_THERMALISATION_PROBABILITY).
+   * Both NULL: the engine calculates them itself when it populates the cell cache. */
   const float *expansionopacities;
   const double *expansionopacity_planck_cumulative;
 } artis_cellstate;

@@ -84,6 +84,8 @@ static inline double dclamp(double v, double lo, double hi) { return (v < lo) ? 
 /* ------------------------------------------------------------------ state */
 typedef struct {
   int populated;
+  float *expansionopacities;                  /* [ARTIS_EXPOPAC_NBINS] when the host did not hand the tables over */
+  double *expansionopacity_planck_cumulative; /* [ARTIS_EXPOPAC_NBINS] */
   int have_ion_cooling;         /* ion_cooling_contribs filled (kpkt.cc:281 is part of update_grid in the reference) */
   double chi_ff_nnionpart;
   double *levelpops;            /* [nlevels] alllevels_pops */
@@ -1237,9 +1239,13 @@ static void cellcache_free_one(CellCache *cc) {
   free(cc->levelpops); free(cc->maprocessrates); free(cc->matrans); free(cc->allcont_nnlevel);
   free(cc->allcont_departure); free(cc->allcont_edgepart); free(cc->allcont_keepbits);
   free(cc->corrphotoioncoeff); free(cc->cooling_contrib); free(cc->ion_cooling_contribs);
+  free(cc->expansionopacities); free(cc->expansionopacity_planck_cumulative);
   memset(cc, 0, sizeof(*cc));
 }
 
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+static void calculate_expansion_opacities(Oracle *o, CellCache *cc, int c);
+#endif
 /* cellcacheslot_populate update_packets.cc:397. As in the reference's CPU build (cellcache_singleslot,
  * update_packets.cc:459-463 and :408) the macro-atom rates of a level and the cooling terms of an ion are
  * left at a negative sentinel here and calculated on first use (macroatom.cc:403, kpkt.cc:459); the values
@@ -1312,6 +1318,9 @@ static void cellcache_populate(Oracle *o, int c) {
     for (int t = 0; t < nt; t++) cc->corrphotoioncoeff[m->level_phixstargetstart[ul] + t] = calc_corrphotoioncoeff(o, c, ul, t);
     cc->maprocessrates[(ptrdiff_t)ul * ARTIS_MA_ACTION_COUNT] = -99.; /* update_packets.cc:461 */
   }
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+  if (!o->cs->expansionopacities && o->cs->thick[c] != ARTIS_CELL_THICK) calculate_expansion_opacities(o, cc, c); /* update_grid.cc:655 */
+#endif
   cc->have_ion_cooling = 0;
   cc->populated = 1;
   o->npopulated++;
@@ -1564,11 +1573,67 @@ static inline ptrdiff_t get_linearbinindex(double value, double minvalue, double
   const ptrdiff_t truncated = (ptrdiff_t)fracindex;
   return (fracindex < (double)truncated) ? truncated - 1 : truncated;
 }
+/* calculate_expansion_opacities rpkt.cc:1071 (get_tau_sobolev<false> evaluates the populations the cell cache holds) */
+static void calculate_expansion_opacities(Oracle *o, CellCache *cc, int c) {
+  const artis_model *m = o->m;
+  const float rho = o->cs->rho[c];
+  const float temperature = o->cs->Te[c];
+  const double t_mid = o->ts.mid;
+  if (!cc->expansionopacities) cc->expansionopacities = (float *)calloc(ARTIS_EXPOPAC_NBINS, sizeof(float));
+  if (!cc->expansionopacity_planck_cumulative) cc->expansionopacity_planck_cumulative = (double *)calloc(ARTIS_EXPOPAC_NBINS, sizeof(double));
+  /* the first line with nu below the upper limit of the first bin: lower_bound(linelist.nu, nu_upper(0), greater) */
+  int lineindex = 0;
+  {
+    const double nu0 = get_expopac_bin_nu_upper(0);
+    int lo = 0, len = m->nlines;
+    while (len > 0) {
+      const int half = len / 2;
+      if (m->line_nu[lo + half] > nu0) { lo += half + 1; len -= half + 1; } else { len = half; }
+    }
+    lineindex = lo;
+  }
+  double kappa_planck_cumulative = 0.;
+  for (ptrdiff_t binindex = 0; binindex < ARTIS_EXPOPAC_NBINS; binindex++) {
+    double bin_linesum = 0.;
+    const double nu_lower = get_expopac_bin_nu_lower(binindex);
+    while (lineindex < m->nlines && m->line_nu[lineindex] >= nu_lower) {
+      const double tau_line = get_tau_sobolev(o, cc, lineindex, t_mid);
+      const double linelambda = 1e8 * CLIGHT / m->line_nu[lineindex];
+      bin_linesum += (linelambda / ARTIS_EXPOPAC_DELTALAMBDA) * -expm1(-tau_line);
+      lineindex++;
+    }
+    const float bin_kappa_bb = (float)(1. / (CLIGHT * t_mid * rho) * bin_linesum);
+    if (!isfinite(bin_kappa_bb)) ORACLE_FAIL(o, "calculate_expansion_opacities: kappa not finite");
+    cc->expansionopacities[binindex] = bin_kappa_bb;
+#if ARTIS_OPT_RPKT_BB_THERMALISATION
+    const double nu_upper = get_expopac_bin_nu_upper(binindex);
+    const double nu_mid = (nu_upper + nu_lower) / 2.;
+    const double bin_kappa_cont = calculate_chi_ffheating(o, cc, c, nu_mid) / rho;
+    const double planck_val = 2 * H_PLANCK * pow3(nu_mid) / pow2(CLIGHT) / expm1(HOVERKB * nu_mid / temperature); /* radfield.h:50 */
+    const double kappa_planck = (bin_kappa_bb + bin_kappa_cont) * planck_val;
+    const double delta_nu = nu_upper - nu_lower;
+    kappa_planck_cumulative += kappa_planck * delta_nu;
+    cc->expansionopacity_planck_cumulative[binindex] = kappa_planck_cumulative;
+#else
+    (void)temperature; (void)kappa_planck_cumulative;
+#endif
+  }
+}
+#endif
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+/* the cell's tables: the host's (artis_cellstate) or the ones calculate_expansion_opacities() below made at population */
+static const float *cell_expansionopacities(const Oracle *o, int c) {
+  return o->cs->expansionopacities ? o->cs->expansionopacities + ((ptrdiff_t)c * ARTIS_EXPOPAC_NBINS) : o->cache[c].expansionopacities;
+}
+static const double *cell_expopac_planck_cumulative(const Oracle *o, int c) {
+  return o->cs->expansionopacity_planck_cumulative ? o->cs->expansionopacity_planck_cumulative + ((ptrdiff_t)c * ARTIS_EXPOPAC_NBINS)
+                                                   : o->cache[c].expansionopacity_planck_cumulative;
+}
 #endif
 #if ARTIS_OPT_RPKT_BB_THERMALISATION
 /* sample_planck_times_expansion_opacity rpkt.cc:964 */
 static double sample_planck_times_expansion_opacity(Oracle *o, int c, uint32_t *rngstate) {
-  const double *kappa_planck_bins = o->cs->expansionopacity_planck_cumulative + ((ptrdiff_t)c * ARTIS_EXPOPAC_NBINS);
+  const double *kappa_planck_bins = cell_expopac_planck_cumulative(o, c);
   if (!(kappa_planck_bins[ARTIS_EXPOPAC_NBINS - 1] > 0)) ORACLE_FAIL(o, "sample_planck_times_expansion_opacity: empty integral");
   const double rnd_integral = rng_uniform(rngstate) * kappa_planck_bins[ARTIS_EXPOPAC_NBINS - 1];
   int binindex = upper_bound_d(kappa_planck_bins, ARTIS_EXPOPAC_NBINS, rnd_integral); /* index_upperbound sn3d.h:85 */
@@ -1601,7 +1666,7 @@ static double get_possible_event_expansion_opacity(Oracle *o, const CellCache *c
     const double chi_cont = chi_total(chi) * doppler;
     double chi_bb_expansionopac = 0.;
     if (binindex >= 0) {
-      const float kappa = o->cs->expansionopacities[((ptrdiff_t)c * ARTIS_EXPOPAC_NBINS) + binindex];
+      const float kappa = cell_expansionopacities(o, c)[binindex];
       chi_bb_expansionopac = kappa * o->cs->rho[c]; /* float product: kappa and get_rho() are floats */
     }
     const double chi_tot = chi_cont + chi_bb_expansionopac;
@@ -2303,6 +2368,8 @@ static void do_kpkt_blackbody(Oracle *o, artis_packet *p) {
   const int c = propcell_nonemptymgi(o, p->cellindex);
 #if ARTIS_OPT_RPKT_BB_THERMALISATION
   if (o->cs->thick[c] != ARTIS_CELL_THICK) { /* kpkt.cc:402 */
+    /* (the reference's tables exist for every cell after update_grid(); this oracle makes a cell's tables with its cache) */
+    if (!o->cs->expansionopacity_planck_cumulative) cellcache_populate(o, c);
     p->nu_cmf = sample_planck_times_expansion_opacity(o, c, p->rngstate);
   } else
 #endif

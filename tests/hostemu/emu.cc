@@ -25,6 +25,9 @@ struct Emu {
   std::vector<double> ws;
   std::vector<int32_t> ws_gi, ws_n;
   std::vector<double> nt_ionratecoeff, nt_ionenrate_cum;
+  std::vector<float> expopac_kappa;
+  std::vector<double> expopac_planck;
+  bool expopac_own = false;
   int32_t err = 0;
 };
 
@@ -63,6 +66,15 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   e.env.tile_lo = 0;
   e.env.tile_hi = M.npts_nonempty;
   e.env.tile_all = 1;
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+  if (!e.env.C.expansionopacities) {  // the engine's own tables (artis_amd_set_cellstate), filled in populate_all()
+    e.expopac_kappa.assign((size_t)(ncell * ARTIS_EXPOPAC_NBINS) + 1, 0.f);
+    e.expopac_planck.assign((size_t)(ncell * ARTIS_EXPOPAC_NBINS) + 1, 0.);
+    e.env.C.expansionopacities = e.expopac_kappa.data();
+    e.env.C.expansionopacity_planck_cumulative = e.expopac_planck.data();
+    e.expopac_own = true;
+  }
+#endif
 #if ARTIS_OPT_NT_ON
   // k_nt_cells (artis_amd_set_cellstate): derived non-thermal arrays of every cell
   e.nt_ionratecoeff.assign((size_t)(ncell * M.nions) + 1, 0.);
@@ -93,6 +105,12 @@ void populate_all(Emu &e) {
     for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom(e.env, c, ul);
     populate_hotselect(e.env, c);
     for (int ul = 0; ul < M.nlevels; ul++) populate_hotfill(e.env, c, ul);
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+    if (e.expopac_own && e.env.C.thick[c] != ARTIS_CELL_THICK) {  // k_expopac, k_expopac_planck
+      for (int b = 0; b < ARTIS_EXPOPAC_NBINS; b++) populate_expopac_bin(e.env, c, b);
+      if (ARTIS_OPT_RPKT_BB_THERMALISATION) populate_expopac_planck(e.env, c);
+    }
+#endif
     for (int ui = 0; ui < M.nions; ui++) populate_cooling_ion(e.env, c, ui);
     populate_cooling_prefix(e.env, c);
   }

@@ -418,22 +418,26 @@ def test_edge_cases(engine_mod):
     eng.close()
 
 
-@pytest.mark.parametrize("options,gridtype,ncoord", [("kilonova_expopac", abi.GRID_CARTESIAN3D, 8),
-                                                     ("kilonova_expopac", abi.GRID_SPHERICAL1D, 16),
-                                                     ("classic_expopac_therm", abi.GRID_CARTESIAN3D, 8)])
-def test_engine_matches_oracle_expansion_opacities(engine_mod, oracle, options, gridtype, ncoord):
+@pytest.mark.parametrize("options,gridtype,ncoord,host_tables", [("kilonova_expopac", abi.GRID_CARTESIAN3D, 8, False),
+                                                                 ("kilonova_expopac", abi.GRID_SPHERICAL1D, 16, True),
+                                                                 ("classic_expopac_therm", abi.GRID_CARTESIAN3D, 8, False),
+                                                                 ("classic_expopac_therm", abi.GRID_CARTESIAN3D, 8, True)])
+def test_engine_matches_oracle_expansion_opacities(engine_mod, oracle, options, gridtype, ncoord, host_tables):
     """the expansion-opacity builds (rpkt.cc:221-330; with the bin re-trace, and with the thermalisation probability of
-    rpkt.cc:624-648 and kpkt.cc:402) against the oracle built alike; a cell state without the opacities is refused"""
+    rpkt.cc:624-648 and kpkt.cc:402) against the oracle built alike, with the tables of calculate_expansion_opacities()
+    (rpkt.cc:1071) made by the engine's own kernels or handed over by the host; half a set of tables is refused"""
     model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", ncoord, gridtype, 4e8 if "therm" in options else 0.0,
-                                                    16000, kfrac=0.15, gfrac=0.1, pfrac=0.2, options=options)
+                                                    16000, kfrac=0.15, gfrac=0.1, pfrac=0.2, options=options,
+                                                    bkw=dict(host_expopac=host_tables))
     rep = parity.compare_packets(pb, pa, FLOAT_RTOL, options + ": HIP engine vs oracle")
     parity.compare_stats(eb, ea, options + ": HIP engine vs oracle", same_libm=False)
     parity.compare_estimators(eb, ea, EST_RTOL, options + ": HIP engine vs oracle")
     st = eb.stats_dict()
     assert st["X_RPKT_STEPS"] > 16000 and ((st["MA_STAT_ACTIVATION_BB"] == 0) == ("therm" in options))
-    bare = abi.CellState({k: v for k, v in cs.d.items() if not k.startswith("expansionopacit")})
-    with pytest.raises(engine_mod.EngineError):
-        eng.set_cellstate(bare, ts)
+    if host_tables and "therm" in options:
+        bare = abi.CellState({k: v for k, v in cs.d.items() if k != "expansionopacity_planck_cumulative"})
+        with pytest.raises(engine_mod.EngineError):
+            eng.set_cellstate(bare, ts)
     print(f"worst float rel diff {rep['worst_rel']:.3e}")
     eng.close()
 

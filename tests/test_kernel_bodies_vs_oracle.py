@@ -308,19 +308,22 @@ def test_analytic_thermalisation_schemes_bit_exact(oracle, options):
     assert not np.array_equal(pc["type"], pa["type"])
 
 
-@pytest.mark.parametrize("options,gridtype,ncoord", [
-    ("kilonova_expopac", abi.GRID_CARTESIAN3D, 8),
-    ("kilonova_expopac", abi.GRID_SPHERICAL1D, 16),
-    ("classic_expopac_therm", abi.GRID_CARTESIAN3D, 8),
-    ("classic_expopac_therm", abi.GRID_CYLINDRICAL2D, 6),
+@pytest.mark.parametrize("options,gridtype,ncoord,host_tables", [
+    ("kilonova_expopac", abi.GRID_CARTESIAN3D, 8, False),
+    ("kilonova_expopac", abi.GRID_SPHERICAL1D, 16, True),
+    ("classic_expopac_therm", abi.GRID_CARTESIAN3D, 8, False),
+    ("classic_expopac_therm", abi.GRID_CYLINDRICAL2D, 6, True),
 ])
-def test_expansion_opacity_builds_bit_exact(oracle, options, gridtype, ncoord):
+def test_expansion_opacity_builds_bit_exact(oracle, options, gridtype, ncoord, host_tables):
     """RPKT_USE_EXPANSION_OPACITIES (rpkt.cc:221): r-packets walk the 20 A bins of the cell's expansion opacity instead of
     the line list. kilonova_expopac: the bin of the event is re-traced line by line and a bound-bound event activates a
     macro-atom (relativistic Doppler branch). classic_expopac_therm: with RPKT_BOUNDBOUND_THERMALISATION_PROBABILITY = 0.9
     a bound-bound event redistributes the frequency over kappa * B_nu (sample_planck_times_expansion_opacity rpkt.cc:964)
-    or scatters, and pre-k-packets emit from the same distribution (kpkt.cc:402)."""
-    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options, thick_below_v=4e8 if "therm" in options else 0.0)
+    or scatters, and pre-k-packets emit from the same distribution (kpkt.cc:402). The per-cell tables are those of
+    calculate_expansion_opacities() (rpkt.cc:1071) evaluated by oracle and kernel bodies from the cell's level populations,
+    or (host_tables) arbitrary ones handed over with the cell state."""
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options, thick_below_v=4e8 if "therm" in options else 0.0,
+                                     host_expopac=host_tables)
     pk0 = synth.make_packets(model, aux, 4000, kpkt_fraction=0.15, gamma_fraction=0.1, pellet_fraction=0.2)
     pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
     parity.compare_packets(pb, pa, 0.0, options + ": kernel bodies vs oracle")
