@@ -10,13 +10,14 @@
 #ifndef ARTIS_OPTIONS_H
 #define ARTIS_OPTIONS_H
 
-/* PARTICLE_THERMALISATION_SCHEME (constants.h:78-87, artisoptions_classic.h:146) */
+/* PARTICLE_THERMALISATION_SCHEME (artisoptions_classic.h:146), numbered like enum class ParticleThermalisationScheme
+ * (constants.h:82-89) */
 #define ARTIS_PARTICLE_INSTANTFULLDEPOSITION 0
-#define ARTIS_PARTICLE_BARNES 1
-#define ARTIS_PARTICLE_WOLLAEGER 2
-#define ARTIS_PARTICLE_TIMEDEPENDENT 3
-#define ARTIS_PARTICLE_TIMEDEPENDENT_WITH_ADIABATIC_LOSS 4
-#define ARTIS_PARTICLE_TIMEDEPENDENTWITHGAMMAPRODUCTS 5
+#define ARTIS_PARTICLE_TIMEDEPENDENT 1
+#define ARTIS_PARTICLE_TIMEDEPENDENT_WITH_ADIABATIC_LOSS 2
+#define ARTIS_PARTICLE_TIMEDEPENDENTWITHGAMMAPRODUCTS 3
+#define ARTIS_PARTICLE_BARNES 4
+#define ARTIS_PARTICLE_WOLLAEGER 5
 
 /* -DARTIS_PRESET_KILONOVA_BARNES / _WOLLAEGER: artisoptions_kilonova_lte.h with the analytic thermalisation efficiency of
  * Barnes et al. (2016) or Wollaeger et al. (2018) instead of the local time-dependent scheme (update_packets.cc:69-88).
@@ -68,6 +69,8 @@
 #define ARTIS_OPT_MINTEMP 500.                        /* :43 */
 #define ARTIS_OPT_MAXTEMP 150000.                     /* :44 */
 #define ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT 1    /* :118 */
+#define ARTIS_OPT_USE_CALCULATED_MEANATOMICWEIGHT 1   /* :120 (on the packet path only the XCOM opacities and the NT_ON
+                                                       * channels read element number densities; this preset has neither) */
 #ifndef ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME
 #define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_TIMEDEPENDENT /* :146 */
 #endif
@@ -156,6 +159,9 @@
 #define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_INSTANTFULLDEPOSITION
 #endif
 #define ARTIS_GAMMAPRODUCTS (ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_TIMEDEPENDENTWITHGAMMAPRODUCTS)
+#ifndef ARTIS_OPT_USE_CALCULATED_MEANATOMICWEIGHT
+#define ARTIS_OPT_USE_CALCULATED_MEANATOMICWEIGHT 0 /* artisoptions_classic.h:120 */
+#endif
 
 /* Options of the reference this build does not implement: they must keep the
  * classic values. (A build that needs them fails here, not at run time.) */
@@ -189,5 +195,9 @@
 
 /* kpkt.cc:51 kpktdiffusion_timestep_fraction (a float in the reference) */
 #define ARTIS_KPKTDIFFUSION_TIMESTEP_FRACTION 0.001f
+
+#if ARTIS_OPT_NT_ON && ARTIS_OPT_USE_CALCULATED_MEANATOMICWEIGHT
+#error "NT_ON reads element number densities from the static mean nuclear masses (artis_model.elem_meannucmass); per-cell mean atomic weights are not in the ABI"
+#endif
 
 #endif
