@@ -3122,6 +3122,10 @@ float artis_oracle_phixs_fromtable(const float *xs, int npoints, double nuincrem
   return photoionisation_crosssection_fromtable(&o, xs, nu_edge, nu);
 }
 double artis_oracle_planck(double nu, double T) { return planck(nu, T); }
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+long long artis_oracle_linearbinindex(double value, double minvalue, double binwidth) { return get_linearbinindex(value, minvalue, binwidth); }
+double artis_oracle_expopac_bin_nu(long long b, int upper) { return upper ? get_expopac_bin_nu_upper(b) : get_expopac_bin_nu_lower(b); }
+#endif
 /* gammapkt.h:28, :38, :68 -- for the restatement of unittests.cc:323 test_compton */
 double artis_oracle_sigma_compton_partial(double x, double f_max) { return sigma_compton_partial(x, f_max); }
 double artis_oracle_choose_f(double xx, double zrand) { return choose_f(xx, zrand); }

@@ -144,6 +144,11 @@ double artis_emu_sigma_compton_partial(double x, double f_max) { return artis::s
 double artis_emu_choose_f(double xx, double zrand) { return artis::choose_f(xx, zrand); }
 double artis_emu_meanf_sigma(double x) { return artis::meanf_sigma(x); }
 double artis_emu_planck(double nu, double T) { return artis::planck(nu, T); }
+#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+// the wavelength-bin helpers of the expansion opacities (sn3d.h:115, rpkt.h:30-40), for tests/test_oracle_reference_props.py
+long long artis_emu_linearbinindex(double value, double minvalue, double binwidth) { return artis::linearbinindex(value, minvalue, binwidth); }
+double artis_emu_expopac_bin_nu(long long b, int upper) { return upper ? artis::expopac_bin_nu_upper(b) : artis::expopac_bin_nu_lower(b); }
+#endif
 int artis_emu_closest_transition(const double *nu, int nlines, double nu_cmf, int next_trans) {
   return artis::closest_transition(nu, nlines, nu_cmf, next_trans);
 }

@@ -421,3 +421,28 @@ def test_options_presets_match_reference_option_files(preset, tmp_path):
     assert len(want) >= 37 and set(got) == set(want)
     for name, val in want.items():
         assert got[name] == val, f"{preset}: {name} = {got[name]}, reference {val}"
+
+
+def test_expansion_opacity_bin_helpers_static_asserts(oracle):
+    """The compile-time checks the reference keeps beside its bin helpers, restated on oracle and kernel bodies (the
+    expansion-opacity builds): get_linearbinindex floors, is left-closed and signed (sn3d.h:124-128); the 20 A wavelength
+    bins are contiguous and ordered (rpkt.h:42-44); there are (40000 - 60) / 20 of them (rpkt.h:26)."""
+    import ctypes as C
+
+    import hostemu_binding
+
+    P = "kilonova_expopac"
+    for L, pre in ((oracle.lib(P), "artis_oracle_"), (hostemu_binding.lib(P), "artis_emu_")):
+        idx = getattr(L, pre + "linearbinindex")
+        idx.restype, idx.argtypes = C.c_longlong, [C.c_double] * 3
+        nu = getattr(L, pre + "expopac_bin_nu")
+        nu.restype, nu.argtypes = C.c_double, [C.c_longlong, C.c_int]
+        assert idx(1.5, 1., 1.) == 0 and idx(3., 1., 1.) == 2 and idx(1., 1., 1.) == 0
+        assert idx(0.5, 1., 1.) == -1 and idx(-5., 1., 2.) == -3
+        assert nu(0, 0) == nu(1, 1) and nu(0, 0) < nu(0, 1)
+        assert nu(abi.EXPOPAC_NBINS - 1, 1) > nu(abi.EXPOPAC_NBINS - 1, 0)
+        assert nu(0, 1) == 1e8 * 2.99792458e10 / 60. and abs(nu(abi.EXPOPAC_NBINS - 1, 0) / (1e8 * 2.99792458e10 / 40000.) - 1) < 1e-15
+        # a packet at 5000 A sits in the bin whose edges bracket it
+        b = idx(5000., 60., 20.)
+        assert nu(b, 0) < 1e8 * 2.99792458e10 / 5000. <= nu(b, 1)
+    assert abi.EXPOPAC_NBINS == int((40000. - 60.) / 20.)
