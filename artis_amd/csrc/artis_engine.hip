@@ -120,7 +120,7 @@ __device__ inline double wave_shr1(double x) {
   hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
-__global__ void __launch_bounds__(BLOCK) k_matrans(Env env) {
+__global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {  // 128 VGPR without spills: 4 waves/SIMD (-6 ms per step)
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int nblk = env.M.nscanblk;
@@ -235,11 +235,80 @@ __global__ void __launch_bounds__(BLOCK) k_hotfill(Env env) {
   if (i >= total) return;
   populate_hotfill(env, env.tile_lo + (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
-__global__ void __launch_bounds__(BLOCK) k_cooling_ion(Env env) {
+// The cooling list of a (cell, ion) is one running sum over hundreds of terms (kpkt.cc:57-190): a free-free term, the
+// collisional-excitation terms k_matrans left in collexc_cum (most of them), and the bound-free tail. Three kernels:
+// head and tail with a lane per (cell, ion) -- 64 chains side by side, each short -- and the long middle with a ROW OF
+// 16 LANES per (cell, ion): it reads 16 terms (one cache line) at a time, forms the running sum with the sequential
+// additions of the reference's loop (lane k adds its term to lane k-1's finished sum: DPP row shifts, same order, same
+// bits), writes it back and drops the level totals into the cooling list through the static slot table. (A lane per
+// chain walked the terms with strided 8-byte accesses: 35 ms per step for the three parts, now 15.) The running sum
+// travels between the kernels in ion_cooling_C.
+__global__ void __launch_bounds__(BLOCK) k_cooling_head(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nions;
   if (i >= total) return;
-  populate_cooling_ion(env, env.tile_lo + (int)(i / env.M.nions), (int)(i % env.M.nions));
+  const int c = env.tile_lo + (int)(i / env.M.nions);
+  const int ui = (int)(i % env.M.nions);
+  int k = 0;
+  env.K.ion_cooling_C[((int64_t)c * env.M.nions) + ui] = cooling_ion_head(env, c, ui, &k);
+}
+// the value of the lane below within a row of 16 lanes (the row's first lane: 0)
+__device__ inline double row_shr1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// Four chains per wave, one per row of 16 lanes: a row reads 16 terms (one 128-byte line) at a time and needs 15 serial
+// steps for them; four independent chains keep the wave's issue slots four times as busy as one chain of 64 would.
+__global__ void __launch_bounds__(BLOCK) k_cooling_chain(Env env) {
+  const int64_t row_id = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4;
+  const int r = threadIdx.x & 15;
+  const DevModel &M = env.M;
+  const int64_t nchains = (int64_t)(env.tile_hi - env.tile_lo) * M.nions;
+  const bool valid = row_id < nchains;
+  const int c = env.tile_lo + (int)((valid ? row_id : 0) / M.nions);
+  const int ui = (int)((valid ? row_id : 0) % M.nions);
+  const int start = M.ion_uniquelevelindexstart[ui];
+  const int nlevels = M.ion_nlevels[ui];
+  const int j0 = (valid && nlevels > 0) ? M.level_upcum_start[start] : 0;
+  const int j1 = (valid && nlevels > 0) ? M.level_upcum_start[start + nlevels - 1] + M.level_nuptrans[start + nlevels - 1] : 0;
+  double carry = valid ? env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] : 0.;
+  double *upcum = env.K.collexc_cum + ((int64_t)c * M.nupcum);
+  double *cool = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
+  for (int j = j0; __any(j < j1); j += 16) {  // rows with shorter chains idle through the longer ones' chunks
+    const bool in = (j + r) < j1;
+    const double x = in ? upcum[j + r] : 0.;
+    double acc = (r == 0) ? carry + x : x;
+#pragma unroll
+    for (int s = 1; s < 16; s++) {
+      const double prev = row_shr1(acc);  // lane s-1 of the row holds its finished sum
+      if (r == s) acc = prev + x;
+    }
+    if (in) {
+      upcum[j + r] = acc;
+      const int slot = M.upcum_coolslot[j + r];
+      if (slot >= 0) cool[slot] = acc;
+    }
+    // the sum after the row's last term, broadcast to the row (lanes past the end added 0. to it: x + 0. == x exactly)
+    const int src = ((threadIdx.x & 63) | 15) << 2;
+    carry = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(acc)), __builtin_amdgcn_ds_bpermute(src, __double2loint(acc)));
+  }
+  if (valid && r == 0 && j1 > j0) env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] = carry;
+}
+__global__ void __launch_bounds__(BLOCK) k_cooling_tail(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const DevModel &M = env.M;
+  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * M.nions;
+  if (i >= total) return;
+  const int c = env.tile_lo + (int)(i / M.nions);
+  const int ui = (int)(i % M.nions);
+  // the entries written so far: the free-free one and one per level with upward transitions
+  const int element = M.ion_element[ui];
+  int k = ((ionstage(M, element, ui - M.elem_uniqueionindexstart[element]) - 1) > 0) ? 1 : 0;
+  const int start = M.ion_uniquelevelindexstart[ui];
+  for (int l = 0; l < M.ion_nlevels[ui]; l++) k += (M.level_nuptrans[start + l] > 0) ? 1 : 0;
+  cooling_ion_tail(env, c, ui, env.K.ion_cooling_C[((int64_t)c * M.nions) + ui], k);
 }
 __global__ void __launch_bounds__(BLOCK) k_cooling_prefix(Env env) {
   const int c = env.tile_lo + blockIdx.x * BLOCK + threadIdx.x;
@@ -1544,7 +1613,9 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s) {
     if (ARTIS_OPT_RPKT_BB_THERMALISATION) hipLaunchKernelGGL(k_expopac_planck, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
   }
 #endif
-  hipLaunchKernelGGL(k_cooling_ion, dim3(nblocks(ncell * h.nions)), dim3(BLOCK), 0, s, env);
+  hipLaunchKernelGGL(k_cooling_head, dim3(nblocks((int64_t)ncell * h.nions)), dim3(BLOCK), 0, s, env);
+  hipLaunchKernelGGL(k_cooling_chain, dim3(nblocks((int64_t)ncell * h.nions * 16)), dim3(BLOCK), 0, s, env);
+  hipLaunchKernelGGL(k_cooling_tail, dim3(nblocks((int64_t)ncell * h.nions)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_prefix, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));

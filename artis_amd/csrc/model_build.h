@@ -21,6 +21,7 @@ struct ModelOwned {
   std::vector<int32_t> scanblk_start;
   std::vector<ContPack> cont_pack;
   std::vector<int32_t> expopac_linestart;
+  std::vector<int32_t> upcum_coolslot;
 };
 
 // X(field, element type, element count) for every array pointer of DevModel
@@ -84,6 +85,7 @@ struct ModelOwned {
   X(coolinglist_level, int32_t, (m).ncoolingterms)                                 \
   X(coolinglist_phixstargetindex, int32_t, (m).ncoolingterms)                      \
   X(expopac_linestart, int32_t, (ARTIS_EXPOPAC_NBINS + 1))                         \
+  X(upcum_coolslot, int32_t, (m).nupcum)                                           \
   X(propcell_nonemptymgi, int32_t, (m).ngrid)
 
 // arrays of DevModel that may be absent (null) on the host
@@ -229,6 +231,17 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
     own.expopac_linestart[ARTIS_EXPOPAC_NBINS] = li;
   }
   v.expopac_linestart = own.expopac_linestart.data();
+  own.upcum_coolslot.assign((size_t)(nupcum > 0 ? nupcum : 1), -1);
+  for (int e = 0; e < m.nelements; e++)
+    for (int ion = 0; ion < m.elem_nions[e]; ion++) {
+      const int ui = m.elem_uniqueionindexstart[e] + ion;
+      int k = ((m.elem_lowest_ionstage[e] + ion - 1) > 0) ? 1 : 0;  // the free-free entry comes first (kpkt.cc:75)
+      for (int l = 0; l < m.ion_nlevels[ui]; l++) {
+        const int ul = m.ion_uniquelevelindexstart[ui] + l;
+        if (m.level_nuptrans[ul] > 0) own.upcum_coolslot[own.level_upcum_start[ul] + m.level_nuptrans[ul] - 1] = m.ion_coolingoffset[ui] + k++;
+      }
+    }
+  v.upcum_coolslot = own.upcum_coolslot.data();
 #define ARTIS_COPY_PTR(f) v.f = m.f;
   ARTIS_COPY_PTR(elem_nions) ARTIS_COPY_PTR(elem_uniqueionindexstart) ARTIS_COPY_PTR(elem_lowest_ionstage)
   ARTIS_COPY_PTR(elem_anumber) ARTIS_COPY_PTR(elem_meannucmass) ARTIS_COPY_PTR(ion_nt_sum_q_over_binding)

@@ -1286,18 +1286,19 @@ AHD void populate_hotfill(const Env &env, int c, int ul) {
     for (int i = 0; i < n; i++) dst[i] = rec[i];
   }
 }
-// one (cell, ion): calculate_cooling_rates_ion<true> kpkt.cc:57; stores the ion total for the prefix sum of kpkt.cc:281
-AHD void populate_cooling_ion(const Env &env, int c, int ui) {
+// one (cell, ion): calculate_cooling_rates_ion<true> kpkt.cc:57 in three parts, so that the GPU can form the long middle
+// part -- the running sum over the ion's collisional-excitation terms -- with rows of 16 lanes (k_cooling_chain) while the
+// test emulation runs it as the plain loop; same additions in the same order either way.
+// head: the free-free term (kpkt.cc:75-86). Returns the running sum and the number of list entries written so far.
+AHD double cooling_ion_head(const Env &env, int c, int ui, int *k_out) {
   const DevModel &M = env.M;
   const int element = M.ion_element[ui];
   const int ion = ui - M.elem_uniqueionindexstart[element];
-  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
   double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + M.ion_coolingoffset[ui];
   const float cnne = clumpednne(env.C, c);
   const float T_e = env.C.Te[c];
   double C_ion = 0.;
   int k = 0;
-  const int nionising = M.ion_nlevels_ionising[ui];
   const double nncurrention = nnion(env, c, element, ion);
   const int ioncharge = ionstage(M, element, ion) - 1;
   if (ioncharge > 0) {
@@ -1305,25 +1306,43 @@ AHD void populate_cooling_ion(const Env &env, int c, int ui) {
     C_ion += C_ff_ion;
     contribs[k++] = C_ion;
   }
+  *k_out = k;
+  return C_ion;
+}
+// middle, sequential form: the running sum after every upward transition is kept: do_kpkt() (kpkt.cc:461-476) re-adds
+// exactly these terms, in this order and from the same starting value, to pick the transition, and reads the sums here
+// instead (the terms nnlevel * C * e_trans were left there by populate_matrans()); one list entry per level that has
+// upward transitions (kpkt.cc:108-121)
+AHD double cooling_ion_collexc_chain(const Env &env, int c, int ui, double C_ion, int *k_inout) {
+  const DevModel &M = env.M;
+  double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + M.ion_coolingoffset[ui];
+  int k = *k_inout;
   const int start = M.ion_uniquelevelindexstart[ui];
   const int nlevels = M.ion_nlevels[ui];
   for (int level = 0; level < nlevels; level++) {
     const int ul = start + level;
-    const double nnlevel = pops[ul];
-    const double e_cur = eps(M, ul);
-    const double g_cur = statw(M, ul);
-    const int startup = M.level_alltrans_startdown[ul] + M.level_ndowntrans[ul];
     const int nup = M.level_nuptrans[ul];
-    // the running sum after every transition is kept: do_kpkt() (kpkt.cc:461-476) re-adds exactly these terms, in this
-    // order and from the same starting value, to pick the transition, and reads the sums here instead
-    // (the terms nnlevel * C * e_trans were left there by populate_matrans())
     double *upcum = env.K.collexc_cum + ((int64_t)c * M.nupcum) + M.level_upcum_start[ul];
-    for (int ati = startup; ati < (startup + nup); ati++) {
-      C_ion += upcum[ati - startup];
-      upcum[ati - startup] = C_ion;
+    for (int i = 0; i < nup; i++) {
+      C_ion += upcum[i];
+      upcum[i] = C_ion;
     }
     if (nup > 0) contribs[k++] = C_ion;
   }
+  *k_inout = k;
+  return C_ion;
+}
+// tail: collisional ionisation and bound-free cooling (kpkt.cc:123-190), then the ion total for the prefix sum of kpkt.cc:281
+AHD void cooling_ion_tail(const Env &env, int c, int ui, double C_ion, int k) {
+  const DevModel &M = env.M;
+  const int element = M.ion_element[ui];
+  const int ion = ui - M.elem_uniqueionindexstart[element];
+  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + M.ion_coolingoffset[ui];
+  const float cnne = clumpednne(env.C, c);
+  const float T_e = env.C.Te[c];
+  const int nionising = M.ion_nlevels_ionising[ui];
+  const int start = M.ion_uniquelevelindexstart[ui];
   if (ion < (M.elem_nions[element] - 1) && M.nbfcontinua > 0) {
     const double nnupperion = nnion(env, c, element, ion + 1);
     const int ustart = M.ion_uniquelevelindexstart[ui + 1];
@@ -1376,6 +1395,12 @@ AHD void populate_cooling_ion(const Env &env, int c, int ui) {
   }
   if (k != M.ion_ncoolingterms[ui]) fail(env, 20);
   env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] = C_ion;
+}
+AHD void populate_cooling_ion(const Env &env, int c, int ui) {
+  int k = 0;
+  double C_ion = cooling_ion_head(env, c, ui, &k);
+  C_ion = cooling_ion_collexc_chain(env, c, ui, C_ion, &k);
+  cooling_ion_tail(env, c, ui, C_ion, k);
 }
 // one cell: cumulative cooling over ions, kpkt.cc:288-294
 AHD void populate_cooling_prefix(const Env &env, int c) {

@@ -115,6 +115,9 @@ struct DevModel {
   // [ARTIS_EXPOPAC_NBINS + 1] first line of each wavelength bin of the expansion opacities (lines in falling frequency:
   // bin b holds the lines [start[b], start[b+1])); derived on the host, model_build.h
   const int32_t *expopac_linestart;
+  // [nupcum] for the LAST upward transition of a level: the entry of the cell's cooling list that holds the running
+  // sum after that level (calculate_cooling_rates_ion kpkt.cc:108-121); -1 for every other transition. Static.
+  const int32_t *upcum_coolslot;
   const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
       *ion_coolingoffset, *ion_ncoolingterms;
   const double *level_epsilon;

@@ -87,7 +87,7 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
 }
 
 // the populate kernels, in launch order (artis_engine.hip: k_levelpops, k_line_dpop, k_cell_scalars, k_allcont, k_corrphotoion,
-// k_macroatom, k_cooling_ion, k_cooling_prefix)
+// k_macroatom, k_cooling_head / _chain / _tail, k_cooling_prefix)
 void populate_all(Emu &e) {
   const DevModel &M = e.env.M;
   for (int c = 0; c < M.npts_nonempty; c++) {
