@@ -22,6 +22,7 @@ struct ModelOwned {
   std::vector<ContPack> cont_pack;
   std::vector<int32_t> expopac_linestart;
   std::vector<int32_t> upcum_coolslot;
+  std::vector<int32_t> level_recomb_start, recomb_lower, recomb_target;
 };
 
 // X(field, element type, element count) for every array pointer of DevModel
@@ -86,6 +87,9 @@ struct ModelOwned {
   X(coolinglist_phixstargetindex, int32_t, (m).ncoolingterms)                      \
   X(expopac_linestart, int32_t, (ARTIS_EXPOPAC_NBINS + 1))                         \
   X(upcum_coolslot, int32_t, (m).nupcum)                                           \
+  X(level_recomb_start, int32_t, ((m).nlevels + 1))                                \
+  X(recomb_lower, int32_t, (m).nrecomb)                                            \
+  X(recomb_target, int32_t, (m).nrecomb)                                           \
   X(propcell_nonemptymgi, int32_t, (m).ngrid)
 
 // arrays of DevModel that may be absent (null) on the host
@@ -242,6 +246,34 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
       }
     }
   v.upcum_coolslot = own.upcum_coolslot.data();
+  // recombination lists: for every level of ion i > 0, the levels of ion i-1 with a photoionisation target equal to it
+  // (the first such target, like find_phixstargetindex atomic.h:493), lower level rising
+  own.level_recomb_start.assign((size_t)m.nlevels + 1, 0);
+  own.recomb_lower.clear();
+  own.recomb_target.clear();
+  for (int e = 0; e < m.nelements; e++)
+    for (int ion = 0; ion < m.elem_nions[e]; ion++) {
+      const int ui = m.elem_uniqueionindexstart[e] + ion;
+      for (int l = 0; l < m.ion_nlevels[ui]; l++) {
+        const int ul = m.ion_uniquelevelindexstart[ui] + l;
+        own.level_recomb_start[ul] = (int32_t)own.recomb_lower.size();
+        if (ion == 0) continue;
+        const int ls = m.ion_uniquelevelindexstart[ui - 1];
+        for (int lower = 0; lower < m.ion_nlevels_ionising[ui - 1]; lower++)
+          for (int t = 0; t < m.level_nphixstargets[ls + lower]; t++)
+            if (m.allphixstargets_levelindex[m.level_phixstargetstart[ls + lower] + t] == l) {
+              own.recomb_lower.push_back(lower);
+              own.recomb_target.push_back(t);
+              break;
+            }
+      }
+    }
+  own.level_recomb_start[m.nlevels] = (int32_t)own.recomb_lower.size();
+  v.nrecomb = (int32_t)own.recomb_lower.size();
+  if (own.recomb_lower.empty()) { own.recomb_lower.push_back(0); own.recomb_target.push_back(0); }
+  v.level_recomb_start = own.level_recomb_start.data();
+  v.recomb_lower = own.recomb_lower.data();
+  v.recomb_target = own.recomb_target.data();
 #define ARTIS_COPY_PTR(f) v.f = m.f;
   ARTIS_COPY_PTR(elem_nions) ARTIS_COPY_PTR(elem_uniqueionindexstart) ARTIS_COPY_PTR(elem_lowest_ionstage)
   ARTIS_COPY_PTR(elem_anumber) ARTIS_COPY_PTR(elem_meannucmass) ARTIS_COPY_PTR(ion_nt_sum_q_over_binding)

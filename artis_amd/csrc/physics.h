@@ -1175,12 +1175,12 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   if (lpk.nup == 0) rates[ARTIS_MA_ACTION_INTERNALUPSAME] = 0.;
   double s_down_lower = 0., s_radrecomb = 0., s_colrecomb = 0.;
   if (ion > 0 && level <= M.ion_maxrecombininglevel[ui]) {
-    const int nl = M.ion_nlevels_ionising[ui - 1];
     const int ls = M.ion_uniquelevelindexstart[ui - 1];
     const int64_t cb = (int64_t)c * M.nphixstargets_total;
-    for (int lower = 0; lower < nl; lower++) {
-      const int t = find_phixstarget(M, ls + lower, level);
-      if (t < 0) continue;
+    // the levels of the ion below that ionise into this one (find_phixstargetindex() >= 0), from the static list
+    for (int r = M.level_recomb_start[ul]; r < M.level_recomb_start[ul + 1]; r++) {
+      const int lower = M.recomb_lower[r];
+      const int t = M.recomb_target[r];
       const double e_target = eps(M, ls + lower);
       const double e_trans = e_cur - e_target;
       const int64_t o = cb + M.level_phixstargetstart[ls + lower] + t;
@@ -2448,12 +2448,11 @@ AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi) {
     // do_macroatom_radrecomb macroatom.cc:248
     const double targetval = rng_uniform(p) * rate_sel;
     double rate = 0;
-    const int nl = M.ion_nlevels_ionising[ui - 1];
     const int ls = M.ion_uniquelevelindexstart[ui - 1];
     int lowerlevel = -1, sel_t = -1;
-    for (int l = 0; l < nl; l++) {
-      const int t = find_phixstarget(M, ls + l, level);
-      if (t < 0) continue;
+    for (int r = M.level_recomb_start[ul]; r < M.level_recomb_start[ul + 1]; r++) {
+      const int l = M.recomb_lower[r];
+      const int t = M.recomb_target[r];
       const double e_trans = e_cur - eps(M, ls + l);
       const double R = rad_recomb(M, T_e, cnne, element, ion, l, t);
       rate += R * e_trans;
@@ -2479,12 +2478,11 @@ AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi) {
     ARTIS_STAT(env, ARTIS_STAT_MA_INTERNALDOWNLOWER);
     const double targetrate = rng_uniform(p) * rate_sel;
     double rate = 0.;
-    const int nl = M.ion_nlevels_ionising[ui - 1];
     const int ls = M.ion_uniquelevelindexstart[ui - 1];
     int lower = -1;
-    for (int l = 0; l < nl; l++) {
-      const int t = find_phixstarget(M, ls + l, level);
-      if (t < 0) continue;
+    for (int r = M.level_recomb_start[ul]; r < M.level_recomb_start[ul + 1]; r++) {
+      const int l = M.recomb_lower[r];
+      const int t = M.recomb_target[r];
       const double e_target = eps(M, ls + l);
       const double e_trans = e_cur - e_target;
       const double R = rad_recomb(M, T_e, cnne, element, ion, l, t);

@@ -118,6 +118,13 @@ struct DevModel {
   // [nupcum] for the LAST upward transition of a level: the entry of the cell's cooling list that holds the running
   // sum after that level (calculate_cooling_rates_ion kpkt.cc:108-121); -1 for every other transition. Static.
   const int32_t *upcum_coolslot;
+  // recombination list of every level (static): the (level of the ion below, photoionisation target) pairs that ionise
+  // INTO this level, in rising lower level -- what the loops of macroatom.cc:147-168 find with find_phixstargetindex()
+  // for every level of the lower ion. Entries [level_recomb_start[ul], level_recomb_start[ul+1]).
+  const int32_t *level_recomb_start;   // [nlevels + 1]
+  const int32_t *recomb_lower;         // [nrecomb] level index within the lower ion
+  const int32_t *recomb_target;        // [nrecomb] its phixstargetindex
+  int32_t nrecomb;
   const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
       *ion_coolingoffset, *ion_ncoolingterms;
   const double *level_epsilon;
