@@ -37,7 +37,11 @@ def allreduce_estimators(block, dist=None):
 
 def flatten_estimators(est) -> np.ndarray:
     """Host estimators in the engine's block order
-    [J | nuJ | ffheating | colheating | gamma | bfheating | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars]."""
-    return np.concatenate([est.J, est.nuJ, est.ffheatingestimator, est.colheatingestimator, est.gammaestimator,
-                           est.bfheatingestimator, est.dep_estimator_gamma, est.dep_estimator_electron,
-                           est.dep_estimator_positron, est.dep_estimator_alpha, est.scalars])
+    [J | nuJ | ffheating | colheating | gamma | bfheating | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars],
+    followed in nltenebular builds by [radfieldbin_J | radfieldbin_nuJ | bfrate_raw]."""
+    parts = [est.J, est.nuJ, est.ffheatingestimator, est.colheatingestimator, est.gammaestimator,
+             est.bfheatingestimator, est.dep_estimator_gamma, est.dep_estimator_electron,
+             est.dep_estimator_positron, est.dep_estimator_alpha, est.scalars]
+    if getattr(est, "extended", False):
+        parts += [est.radfieldbin_J, est.radfieldbin_nuJ, est.bfrate_raw]
+    return np.concatenate(parts)

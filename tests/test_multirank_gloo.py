@@ -23,14 +23,14 @@ def _population(model, aux, start, count):
     return pk[start:start + count].copy()
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, options):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    model, cs, ts, aux = synth.build("tiny", ncoord=6)
+    model, cs, ts, aux = synth.build("tiny", ncoord=6, options=options)
     start, count = adist.packet_shard(NPK, world, rank)
     pk = _population(model, aux, start, count)
-    est = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
-    emu.update_packets(model, cs, ts, pk, est)
+    est = abi.estimators_for(model, options)
+    emu.update_packets(model, cs, ts, pk, est, preset=options)
     block = torch.from_numpy(adist.flatten_estimators(est))
     adist.allreduce_estimators(block, dist)
     counters = torch.from_numpy(est.stats.copy())
@@ -43,15 +43,19 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("options", ["classic", "nltenebular"])   # nltenebular: the block carries the bin and bound-free estimators too
+def test_two_ranks_equal_one(tmp_path, options):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    model, cs, ts, aux = synth.build("tiny", ncoord=6)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), options), nprocs=2, join=True)
+    model, cs, ts, aux = synth.build("tiny", ncoord=6, options=options)
     pk = _population(model, aux, 0, NPK)
-    est = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
-    emu.update_packets(model, cs, ts, pk, est)
+    est = abi.estimators_for(model, options)
+    emu.update_packets(model, cs, ts, pk, est, preset=options)
     block = np.load(tmp_path / "block.npy")
     want = adist.flatten_estimators(est)
     assert np.allclose(block, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
