@@ -675,6 +675,84 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+// The deferred updates of the detailed bound-free estimators (radfield.cc:215), one WAVE per record: the lanes share the
+// record's cell, frequency and window and take one kept continuum each (rank -> continuum through the cell's keep
+// bitmap: prefix sums of the words' bit counts, then the k-th set bit of a word), so every lane of the wave is busy
+// however long the window is. The contributions are the ones update_bfestimators() would have added in place (same
+// arithmetic); only the order of the f64 atomic additions differs.
+__device__ inline int select_kth_bit(unsigned long long x, int k) {  // position of the k-th (0-based) set bit of x
+  int pos = 0;
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) {
+    const unsigned long long lowmask = (1ull << sh) - 1ull;
+    const int cnt = __popcll(x & lowmask);
+    if (k >= cnt) {
+      k -= cnt;
+      x >>= sh;
+      pos += sh;
+    } else {
+      x &= lowmask;
+    }
+  }
+  return pos;
+}
+// (Keeping a cell's sums in LDS across a run of records of the same cell -- per wave, or per workgroup with ds_add_f64 --
+// was measured and lost, 651 / 427 ms against 364 ms: the kernel is bound by the latency of a record's chain of reads,
+// not by the HBM atomics, and LDS costs resident waves.)
+__global__ void __launch_bounds__(BLOCK) k_bfest_dense(Env env) {
+  const DevModel &M = env.M;
+  const int n = min(*env.bfev_count, env.bfev_cap);
+  const int lane = threadIdx.x & 63;
+  const int nwaves = gridDim.x * (BLOCK / 64);
+  for (int ei = (blockIdx.x * BLOCK + threadIdx.x) >> 6; ei < n; ei += nwaves) {
+    const BfEvent ev = env.bfev[ei];
+    const int c = ev.c;
+    const double nu = ev.nu;
+    const float T_e = env.C.Te[c];
+    const double ex = exp(-HOVERKB * nu / T_e);
+    const bool split_usable = (ex >= DBLMIN);
+    const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
+    double *dst = env.E.bfrate_raw + ((int64_t)c * M.nbfcontinua);
+    const int wfirst = ev.begin / 64, wlast = (ev.end - 1) / 64;
+    for (int wb = wfirst; wb <= wlast; wb += 64) {  // 64 bitmap words (4096 continua) at a time
+      const int j = wb + lane;
+      unsigned long long word = (j <= wlast) ? keep[j] : 0ull;
+      if (j == wfirst) word &= ~0ull << (ev.begin % 64);
+      if (j == wlast && (ev.end % 64) != 0) word &= (1ull << (ev.end % 64)) - 1ull;
+      const int pc = __popcll(word);
+      int incl = pc;  // inclusive prefix sum over the lanes
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      const int total = __shfl(incl, 63);
+      const int wlo = (int)(word & 0xFFFFFFFFull), whi = (int)(word >> 32);
+      for (int s0 = 0; s0 < total; s0 += 64) {  // every lane runs the shuffles; the last round may have idle lanes
+        const int s = s0 + lane;
+        const bool valid = s < total;
+        const int sq = valid ? s : total - 1;
+        int lo = 0, hi = 63;  // first lane whose inclusive count exceeds sq
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+          const int mid = (lo + hi) >> 1;
+          const int v = __shfl(incl, mid);
+          if (v > sq) hi = mid; else lo = mid + 1;
+        }
+        const int src = lo;
+        const int before = __shfl(incl, src) - __shfl(pc, src);
+        const unsigned long long w64 = ((unsigned long long)(unsigned int)__shfl(whi, src) << 32) | (unsigned int)__shfl(wlo, src);
+        if (valid) {
+          const int i = ((wb + src) * 64) + select_kth_bit(w64, sq - before);
+          ARTIS_EST_ADD(&dst[i], bf_sigma_contr(env, c, i, nu, T_e, ex, split_usable) * ev.w);
+        }
+      }
+    }
+  }
+}
+#endif
+
 // gamma packets (and the non-thermal deposits they end in): one do_gamma() call per iteration, same persistent
 // work-pulling form as k_rpkt; a packet that has thermalised leaves as a k-packet for the thermal list
 #ifndef ARTIS_GAMMA_WAVES
@@ -1012,6 +1090,10 @@ struct artis_amd_engine {
   DevEst E{};
   bool have_cells = false;
   bool expopac_own = false;  // the expansion-opacity tables are the engine's (calculated at cell-cache population)
+  BfEvent *d_bfev = nullptr;     // deferred bound-free estimator updates of one k_rpkt launch (DETAILED_BF builds)
+  int32_t *d_bfev_count = nullptr;
+  int32_t bfev_cap = 0;
+  bool bf_defer = true;          // ARTIS_AMD_BFDEFER=0: add in place inside k_rpkt
   // Cell-cache tiling: the cache rows of `tile_cells` non-empty cells are resident at a time (all of them when they fit
   // the budget: ntiles == 1). With more tiles, update_packets sweeps over them -- populate a tile, advance every packet
   // that sits in one of its cells until it leaves the tile or is done -- until no packet is left (what the reference's
@@ -1118,6 +1200,9 @@ Env make_env(const artis_amd_engine *e) {
   env.P = e->P;
   env.stats = nullptr;
   env.gamma_ws = e->d_gamma_ws;
+  env.bfev = e->bf_defer ? e->d_bfev : nullptr;
+  env.bfev_count = e->d_bfev_count;
+  env.bfev_cap = e->bfev_cap;
   env.gamma_gi = e->d_gamma_gi;
   env.gamma_n = e->d_gamma_n;
   env.errflag = e->d_err;
@@ -1126,7 +1211,8 @@ Env make_env(const artis_amd_engine *e) {
 
 void free_packet_buffers(artis_amd_engine *e) {
   void **singles[] = {&e->d_pkt, &e->d_pkt_snapshot, (void **)&e->d_sorted, (void **)&e->d_perm, (void **)&e->d_gamma_ws,
-                      (void **)&e->d_gamma_gi, (void **)&e->d_gamma_n};
+                      (void **)&e->d_gamma_gi, (void **)&e->d_gamma_n, (void **)&e->d_bfev, (void **)&e->d_bfev_count};
+  e->bfev_cap = 0;
   for (void **q : singles) {
     if (*q) (void)hipFree(*q);
     *q = nullptr;
@@ -1162,6 +1248,15 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
   HIP_TRY(hipMalloc((void **)&e->d_gamma_gi, wsbytes / 2));
   HIP_TRY(hipMalloc((void **)&e->d_gamma_n, sizeof(int32_t) * (size_t)e->ws_capacity));
   HIP_TRY(hipMemset(e->d_gamma_n, 0, sizeof(int32_t) * (size_t)e->ws_capacity));
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+  if (e->Mh.nbfcontinua > 0) {  // one k_rpkt launch records at most budget_r updates per packet on its list
+    const int64_t cap = std::min<int64_t>((int64_t)(n > 0 ? n : 1) * e->budget_r, 0x7FFFFFF0LL);
+    HIP_TRY(hipMalloc((void **)&e->d_bfev, sizeof(BfEvent) * (size_t)cap));
+    HIP_TRY(hipMalloc((void **)&e->d_bfev_count, sizeof(int32_t)));
+    HIP_TRY(hipMemset(e->d_bfev_count, 0, sizeof(int32_t)));
+    e->bfev_cap = (int32_t)cap;
+  }
+#endif
   e->npackets = n;  // committed only now: a failed allocation above leaves "nothing resident" (npackets == -1)
   return ARTIS_OK;
 }
@@ -1435,6 +1530,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_R")) e->budget_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_T")) e->budget_t = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_SLOTSORT")) e->slot_order_by_cell = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_BFDEFER")) e->bf_defer = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
@@ -1861,6 +1957,12 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
           hipLaunchKernelGGL((k_rpkt<true>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch);
         else
           hipLaunchKernelGGL((k_rpkt<false>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch);
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+        if (env.bfev != nullptr) {  // the estimator updates the launch recorded (the cells' cache rows are still resident)
+          hipLaunchKernelGGL(k_bfest_dense, dim3(e->ncu * 8), dim3(BLOCK), 0, s, env);
+          HIP_TRY(hipMemsetAsync(e->d_bfev_count, 0, sizeof(int32_t), s));
+        }
+#endif
       } else if (kind == NEXT_GAMMA) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_GAMMA_WAVES);
         hipLaunchKernelGGL(k_gamma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r * 8, e->d_cursors,

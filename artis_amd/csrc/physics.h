@@ -104,6 +104,10 @@ struct Env {
   int32_t tile_lo, tile_hi;
   int32_t tile_all;  // the tile covers every cell (the usual case): in_tile() needs no look-up
   int32_t cont_in_lds;  // M.cont_pack points into LDS (k_rpkt<true>)
+  // deferred detailed bound-free estimator updates (DETAILED_BF builds on the GPU; null: added in place)
+  BfEvent *bfev;
+  int32_t *bfev_count;
+  int32_t bfev_cap;
 };
 // the packet's cell is empty (no cache needed) or its cache row is resident
 AHD bool in_tile(const Env &env, int cellindex) {
@@ -1619,6 +1623,22 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   return sum;
 }
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+// the contribution of continuum i at frequency nu in cell c: sigma_bf * probability * stimulated-emission correction, the
+// arithmetic of calculate_chi_bf_gammacontr() (rpkt.cc:770-798) for one continuum
+AHD double bf_sigma_contr(const Env &env, int c, int i, double nu, float T_e, double ex, bool split_usable) {
+  const DevModel &M = env.M;
+  const ContPack cp = M.cont_pack[i];
+  const double sigma_bf = phixs_fromtable(M, M.allphixs + cp.xs_off, cp.nu_edge, nu);
+  const double ep = env.K.allcont_pair[((int64_t)c * M.nbfcontinua) + i].y;
+  double stim;
+  if (ep >= 0. && split_usable) {
+    stim = ep * ex;
+  } else {
+    stim = env.K.allcont_departure[((int64_t)c * M.nbfcontinua) + i] * exp(-HOVERKB * (nu - cp.nu_edge) / T_e);
+  }
+  const double corr = dmax(0., 1 - stim);
+  return sigma_bf * cp.probability * corr;
+}
 // radfield::update_bfestimators radfield.cc:215. The reference keeps, per packet, the contribution sigma_contr of every
 // continuum of the window that calculate_chi_bf_gammacontr() walked at the frequency x.nu (Phixslist::gamma_contr), and
 // adds it to bfrate_raw for the continua that are still in the window at the packet's present frequency. Here the
@@ -1650,6 +1670,23 @@ AHD void update_bfestimators(const Env &env, int c, double de, double nu_cmf, co
     begin_n = b0 + lower_bound_d(M.allcont_nu_edge + b0, end_n - b0, nu_cmf / M.last_phixs_nuovernuedge);
   }
   if (begin_n >= end_n) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // On the GPU the additions themselves are deferred: lanes of a wave are at windows of very different lengths (0 to
+  // more than a hundred continua), so a lane-per-packet loop runs at a fraction of the lanes (17 % measured). The update
+  // is recorded (one atomic per wave for the space) and k_bfest_dense gives every record a whole wave.
+  if (env.bfev != nullptr) {
+    const unsigned long long active = __ballot(1);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == __ffsll((long long)active) - 1) base = atomicAdd(env.bfev_count, __popcll(active));
+    base = __builtin_amdgcn_readfirstlane(base);  // the first active lane is the one that reserved the space
+    const int idx = base + __popcll(active & ((1ull << lane) - 1ull));
+    if (idx < env.bfev_cap) {
+      env.bfev[idx] = BfEvent{nu, de_over_nu, c, begin_n, end_n, 0};
+      return;
+    }
+  }
+#endif
   const float T_e = env.C.Te[c];
   const double ex = exp(-HOVERKB * nu / T_e);
   const bool split_usable = (ex >= DBLMIN);

@@ -215,6 +215,14 @@ struct DevCache {
   double *chi_ff_nnionpart;      // [cell]
 };
 
+// One deferred update of the detailed bound-free estimators (physics.h update_bfestimators): the opacity's frequency, the
+// weight distance * e_cmf / nu_cmf, the cell and the window of continua [begin, end) still in range at the packet's
+// frequency. k_rpkt records them; k_bfest_dense adds the contributions with a whole wave per record.
+struct alignas(16) BfEvent {
+  double nu, w;
+  int32_t c, begin, end, pad;
+};
+
 struct DevStep {
   int32_t nts;
   double start, width, mid, max_path_step, ts_end;

@@ -499,6 +499,29 @@ def test_engine_matches_oracle_nltenebular_preset(engine_mod, oracle, gridtype, 
     eng.close()
 
 
+def test_deferred_bound_free_estimators_equal_in_place(engine_mod, monkeypatch):
+    """nltenebular build: the detailed bound-free estimator updates recorded by k_rpkt and added by k_bfest_dense (a wave
+    per update) against the same build adding them in place (ARTIS_AMD_BFDEFER=0): identical packets and counters, the
+    estimators to the accuracy of float summation order. w7 atomic data (1851 continua: windows longer than a wave)."""
+    P = "nltenebular"
+    model, cs, ts, aux = synth.build("w7", ncoord=10, options=P, nts=13)
+    pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.05)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("ARTIS_AMD_BFDEFER", mode)
+        eng = engine_mod.Engine(model, preset=P)
+        eng.set_cellstate(cs, ts)
+        p, est = pk0.copy(), abi.estimators_for(model, P)
+        eng.update_packets(p, est)
+        eng.close()
+        out[mode] = (p, est)
+    (p1, e1), (p0, e0) = out["1"], out["0"]
+    parity.compare_packets(p1, p0, 0.0, "deferred vs in-place bound-free estimators")
+    assert np.array_equal(e1.stats, e0.stats)
+    assert np.count_nonzero(e0.bfrate_raw) > 10000 and np.array_equal(e1.bfrate_raw != 0, e0.bfrate_raw != 0)
+    parity.compare_estimators(e1, e0, 1e-11, "deferred vs in-place bound-free estimators")
+
+
 @pytest.mark.parametrize("options", ["classic", "kilonova_lte", "nltenebular"])
 def test_full_size_properties_50cubed_1e7_packets(engine_mod, options):
     """BASELINE.json's bench configuration itself (50^3 cells, w7 atomic data, 1e7 packets; configs[1] with the classic
