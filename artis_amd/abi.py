@@ -141,8 +141,10 @@ _MODEL_FIELDS = [
     # optional (NULL when absent): static inputs of the non-thermal channels
     ("elem_meannucmass", _F32P, np.float32), ("ion_nt_sum_q_over_binding", _F64P, np.float64),
     ("ejecta_kinetic_energy", C.c_double, None), ("mtot_input", C.c_double, None),
+    ("allcont_bfestimindex", _I32P, np.int32), ("nbfestim", C.c_int32, None),
 ]
-_MODEL_OPTIONAL = ("elem_meannucmass", "ion_nt_sum_q_over_binding", "ejecta_kinetic_energy", "mtot_input")
+_MODEL_OPTIONAL = ("elem_meannucmass", "ion_nt_sum_q_over_binding", "ejecta_kinetic_energy", "mtot_input",
+                   "allcont_bfestimindex", "nbfestim")
 
 _CELL_FIELDS = [
     ("rho", _F32P, np.float32), ("Te", _F32P, np.float32), ("TJ", _F32P, np.float32), ("TR", _F32P, np.float32),
@@ -170,6 +172,9 @@ _CELL_OPTIONAL = ("levelpops", "corrphotoioncoeff", "radfieldbin_W", "radfieldbi
                   "nt_exc_alltransindex", "nt_excitations_stored", "expansionopacities", "expansionopacity_planck_cumulative")
 NT_NAUGER = 3  # NT_MAX_AUGER_ELECTRONS + 1
 RADFIELDBINCOUNT = 256
+# options presets with the multibin radiation field and the detailed bound-free estimators (artisoptions_nltenebular.h and
+# the three files that differ from it in constants): RADFIELDBINCOUNT of each
+NEBULAR_FAMILY = {"nltenebular": 256, "christinenonthermal": 64, "nltephotospheric": 256, "nltewithoutnonthermal": 512}
 
 
 class CModel(C.Structure):
@@ -269,11 +274,12 @@ class Timestep:
 class Estimators:
     """Host estimator arrays (accumulated into by update_packets)."""
 
-    def __init__(self, npts_nonempty: int, nbfcontinua_ground: int, nbfcontinua: int = 0):
-        """nbfcontinua > 0: also the estimators of the nltenebular options (radiation-field bins, detailed bound-free)"""
+    def __init__(self, npts_nonempty: int, nbfcontinua_ground: int, nbfcontinua: int = 0, nbins: int = RADFIELDBINCOUNT):
+        """nbfcontinua > 0: also the estimators of the nltenebular options (radiation-field bins, detailed bound-free;
+        nbfcontinua = the number of bound-free estimators, nbins = RADFIELDBINCOUNT of the options preset)"""
         n, g = npts_nonempty, max(nbfcontinua_ground, 1)
-        self.radfieldbin_J = np.zeros(n * RADFIELDBINCOUNT if nbfcontinua > 0 else 1)
-        self.radfieldbin_nuJ = np.zeros(n * RADFIELDBINCOUNT if nbfcontinua > 0 else 1)
+        self.radfieldbin_J = np.zeros(n * nbins if nbfcontinua > 0 else 1)
+        self.radfieldbin_nuJ = np.zeros(n * nbins if nbfcontinua > 0 else 1)
         self.bfrate_raw = np.zeros(n * nbfcontinua if nbfcontinua > 0 else 1)
         self.extended = nbfcontinua > 0
         self.J = np.zeros(n)
@@ -317,8 +323,10 @@ class Estimators:
 
 def estimators_for(model, options: str = "classic") -> Estimators:
     """Estimator arrays sized for a model under an options preset (nltenebular adds the bin and bound-free arrays)"""
-    ext = model["nbfcontinua"] if options == "nltenebular" else 0
-    return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"], ext)
+    if options not in NEBULAR_FAMILY:
+        return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
+    nest = model.d.get("nbfestim") or model["nbfcontinua"]
+    return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"], nest, NEBULAR_FAMILY[options])
 
 
 def packets_ptr(packets: np.ndarray):

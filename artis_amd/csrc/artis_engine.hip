@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(BLOCK) k_bfest_dense(Env env) {
     const double ex = exp(-HOVERKB * nu / T_e);
     const bool split_usable = (ex >= DBLMIN);
     const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
-    double *dst = env.E.bfrate_raw + ((int64_t)c * M.nbfcontinua);
+    double *dst = env.E.bfrate_raw + ((int64_t)c * M.nbfestim);
     const int wfirst = ev.begin / 64, wlast = (ev.end - 1) / 64;
     for (int wb = wfirst; wb <= wlast; wb += 64) {  // 64 bitmap words (4096 continua) at a time
       const int j = wb + lane;
@@ -745,7 +745,8 @@ __global__ void __launch_bounds__(BLOCK) k_bfest_dense(Env env) {
         const unsigned long long w64 = ((unsigned long long)(unsigned int)__shfl(whi, src) << 32) | (unsigned int)__shfl(wlo, src);
         if (valid) {
           const int i = ((wb + src) * 64) + select_kth_bit(w64, sq - before);
-          ARTIS_EST_ADD(&dst[i], bf_sigma_contr(env, c, i, nu, T_e, ex, split_usable) * ev.w);
+          const int bi = bfestimindex(M, i);
+          if (bi >= 0) ARTIS_EST_ADD(&dst[bi], bf_sigma_contr(env, c, i, nu, T_e, ex, split_usable) * ev.w);
         }
       }
     }
@@ -1325,7 +1326,13 @@ extern "C" {
 const char *artis_amd_last_error(void) { return g_last_error.c_str(); }
 int artis_amd_abi_version(void) { return 3; }
 const char *artis_amd_options_preset(void) {
-#if defined(ARTIS_PRESET_NLTENEBULAR)
+#if defined(ARTIS_PRESET_CHRISTINENONTHERMAL)
+  return "christinenonthermal";
+#elif defined(ARTIS_PRESET_NLTEPHOTOSPHERIC)
+  return "nltephotospheric";
+#elif defined(ARTIS_PRESET_NLTEWITHOUTNONTHERMAL)
+  return "nltewithoutnonthermal";
+#elif defined(ARTIS_PRESET_NLTENEBULAR)
   return "nltenebular";
 #elif defined(ARTIS_PRESET_KILONOVA_EXPOPAC)
   return "kilonova_expopac";
@@ -1434,6 +1441,10 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   }
   ARTIS_MODEL_OPTIONAL_ARRAYS(UPMO, h)
 #undef UPMO
+  if (ARTIS_OPT_BFEST_SUBSET && !e->M.allcont_bfestimindex) {
+    g_last_error = "this build keeps bound-free estimators for a subset of the continua: artis_model.allcont_bfestimindex / nbfestim are required";
+    return ARTIS_ERR_ARG;
+  }
   if (ARTIS_OPT_NT_ON && (!e->M.elem_meannucmass || !e->M.ion_nt_sum_q_over_binding)) {
     g_last_error = "this build has NT_ON: artis_model.elem_meannucmass and ion_nt_sum_q_over_binding are required";
     return ARTIS_ERR_ARG;
@@ -1488,7 +1499,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   const int64_t g = h.nbfcontinua_ground > 0 ? h.nbfcontinua_ground : 1;
   // ... | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars | (radfieldbin_J | radfieldbin_nuJ) | (bfrate_raw)]
   const int64_t nbinest = ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON ? ncell * ARTIS_OPT_RADFIELDBINCOUNT : 0;
-  const int64_t nbfest = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? ncell * (int64_t)h.nbfcontinua : 0;
+  const int64_t nbfest = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? ncell * (int64_t)h.nbfestim : 0;
   e->est_ndoubles = ncell * 8 + 2 * ncell * g + ARTIS_NSCALARS + 2 * nbinest + nbfest;
   HIP_TRY(hipMalloc((void **)&e->d_est, sizeof(double) * (size_t)e->est_ndoubles));
   HIP_TRY(hipMemset(e->d_est, 0, sizeof(double) * (size_t)e->est_ndoubles));
@@ -2056,7 +2067,7 @@ int artis_amd_estimators_download(artis_amd_engine *e, artis_estimators *est) {
   add(est->scalars, src + 8 * ncell + 2 * ncell * g, ARTIS_NSCALARS);
   {
     const int64_t nbinest = ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON ? ncell * ARTIS_OPT_RADFIELDBINCOUNT : 0;
-    const int64_t nbfest = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? ncell * (int64_t)e->Mh.nbfcontinua : 0;
+    const int64_t nbfest = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? ncell * (int64_t)e->Mh.nbfestim : 0;
     const double *ext = src + 8 * ncell + 2 * ncell * g + ARTIS_NSCALARS;
     if (nbinest) {
       add(est->radfieldbin_J, ext, nbinest);

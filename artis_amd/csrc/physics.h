@@ -1623,6 +1623,8 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   return sum;
 }
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+// globals::allcont.bfestimindex (input.cc:932): the estimator of continuum i, -1 if LEVEL_HAS_BFEST() is false for its level
+AHD int bfestimindex(const DevModel &M, int i) { return M.allcont_bfestimindex ? M.allcont_bfestimindex[i] : i; }
 // the contribution of continuum i at frequency nu in cell c: sigma_bf * probability * stimulated-emission correction, the
 // arithmetic of calculate_chi_bf_gammacontr() (rpkt.cc:770-798) for one continuum
 AHD double bf_sigma_contr(const Env &env, int c, int i, double nu, float T_e, double ex, bool split_usable) {
@@ -1699,7 +1701,7 @@ AHD void update_bfestimators(const Env &env, int c, double de, double nu_cmf, co
   it.cend = end_n;
   it.word = begin_n / 64;
   it.bits = keep_masked(it);
-  double *dst = env.E.bfrate_raw + ((int64_t)c * M.nbfcontinua);
+  double *dst = env.E.bfrate_raw + ((int64_t)c * M.nbfestim);
   bool more = true;
   while (more) {
     int idx[ARTIS_CHI_BATCH];
@@ -1733,7 +1735,8 @@ AHD void update_bfestimators(const Env &env, int c, double de, double nu_cmf, co
         }
         const double corr = dmax(0., 1 - stim);
         const double sigma_contr = sigma_bf * cp[k].probability * corr;
-        ARTIS_EST_ADD(&dst[i], sigma_contr * de_over_nu);
+        const int bi = bfestimindex(M, i);  // Phixslist::gamma_contr is indexed by estimator (rpkt.cc:905)
+        if (bi >= 0) ARTIS_EST_ADD(&dst[bi], sigma_contr * de_over_nu);
       }
     }
   }

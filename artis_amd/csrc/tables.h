@@ -125,6 +125,9 @@ struct DevModel {
   const int32_t *recomb_lower;         // [nrecomb] level index within the lower ion
   const int32_t *recomb_target;        // [nrecomb] its phixstargetindex
   int32_t nrecomb;
+  // detailed bound-free estimators: estimator index of every continuum (-1: none) or null = identity; their number
+  const int32_t *allcont_bfestimindex;
+  int32_t nbfestim;
   const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
       *ion_coolingoffset, *ion_ncoolingterms;
   const double *level_epsilon;

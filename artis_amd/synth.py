@@ -56,7 +56,9 @@ def _ionpot_ev(Z: int, stage: int) -> float:
 
 # rate-coefficient table grids of the options presets (include/artis_options.h: TABLESIZE, MINTEMP, MAXTEMP)
 OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0, 150000.0),
-                 "nltenebular": (100, 1000.0, 30000.0), "kilonova_barnes": (200, 500.0, 150000.0),
+                 "nltenebular": (100, 1000.0, 30000.0), "christinenonthermal": (100, 3000.0, 140000.0),
+                 "nltephotospheric": (100, 3500.0, 140000.0), "nltewithoutnonthermal": (200, 4000.0, 140000.0),
+                 "kilonova_barnes": (200, 500.0, 150000.0),
                  "kilonova_wollaeger": (200, 500.0, 150000.0), "kilonova_expopac": (200, 500.0, 150000.0),
                  "kilonova_gammaproducts": (200, 500.0, 150000.0),
                  "classic_expopac_therm": (100, 3500.0, 140000.0)}
@@ -651,10 +653,16 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     model = abi.Model(md)
     if "expopac" in options and host_expopac:
         cells.update(expansion_opacity_cellstate(cells, grid["npts_nonempty"], seed=seed + 400))
-    if options == "nltenebular":
-        cells.update(nebular_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 200))
+    if options in abi.NEBULAR_FAMILY:
+        cells.update(nebular_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 200, nbins=abi.NEBULAR_FAMILY[options]))
         cells.update(nonthermal_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 300))
         md.update(nonthermal_model_inputs(atomic))
+        if options == "nltephotospheric":
+            # LEVEL_HAS_BFEST (artisoptions_nltephotospheric_dynamic_ion_range.h:80): estimators for the lowest levels only;
+            # globals::allcont.bfestimindex is the running count over the continua that have one (input.cc:932-947)
+            has = np.asarray(atomic["allcont_level"]) <= 3
+            idx = np.where(has, np.cumsum(has) - 1, -1).astype(np.int32)
+            md.update(allcont_bfestimindex=idx, nbfestim=int(has.sum()))
         model = abi.Model(md)
     cs = abi.CellState(cells)
     ts = make_timestep(aux["t"], width_frac=width_frac, vmax=grid["vmax"], nts=nts)
@@ -758,7 +766,7 @@ def nonthermal_cellstate(atomic: dict, cells: dict, ncell: int, seed: int = 301,
                 nt_exc_alltransindex=ati.ravel(), nt_excitations_stored=stored)
 
 
-def nebular_cellstate(atomic: dict, cells: dict, ncell: int, seed: int = 201) -> dict:
+def nebular_cellstate(atomic: dict, cells: dict, ncell: int, seed: int = 201, nbins: int = 256) -> dict:
     """What the host's NLTE / radiation-field solvers hand to the packet path under artisoptions_nltenebular.h
     (include/artis_amd.h artis_cellstate): level populations with departures from LTE, photoionisation coefficients of
     every bound-free pair, and W, T_R of the 256 radiation-field bins (a few bins without a solution: W = -1)."""
@@ -778,7 +786,7 @@ def nebular_cellstate(atomic: dict, cells: dict, ncell: int, seed: int = 201) ->
     pops = np.maximum(ground[:, level_ion] * boltz * dep, 1e-40)
     npt = atomic["nphixstargets_total"]
     corr = 10 ** rng.uniform(-4.0, 1.0, size=(ncell, max(npt, 1))) * np.asarray(cells["W"], dtype=np.float64)[:, None]
-    nb = abi.RADFIELDBINCOUNT
+    nb = nbins
     W = np.asarray(cells["W"], dtype=np.float64)[:, None] * rng.uniform(0.3, 1.7, size=(ncell, nb))
     W[rng.random((ncell, nb)) < 0.05] = -1.0
     TR = np.asarray(cells["TR"], dtype=np.float64)[:, None] * rng.uniform(0.7, 1.3, size=(ncell, nb))

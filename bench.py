@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=160_000)
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--options", default="classic", choices=("classic", "kilonova_lte", "nltenebular"),
+    ap.add_argument("--options", default="classic", choices=("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal"),
                     help="options preset of include/artis_options.h (the reference's artisoptions_*.h)")
     args = ap.parse_args()
 

@@ -274,6 +274,12 @@ typedef struct artis_model {
    * (grid.h:139) and grid::mtot_input (grid.h:40). Read only by builds with that scheme; 0 elsewhere. */
   double ejecta_kinetic_energy;
   double mtot_input;
+
+  /* [nbfcontinua] globals::allcont.bfestimindex (input.cc:932-947): index of the continuum's detailed bound-free estimator,
+   * -1 where LEVEL_HAS_BFEST() is false; nbfestim = number of estimators (globals::bfestim_nu_edge.size()). NULL / 0: every
+   * continuum has one (artisoptions_nltenebular.h:82), the estimator index is the continuum index. */
+  const int32_t *allcont_bfestimindex;
+  int32_t nbfestim;
 } artis_model;
 
 /* ---- per-timestep cell state written by the reference's update_grid() ----- */
@@ -361,8 +367,8 @@ typedef struct artis_estimators {
   double *dep_estimator_positron;
   double *dep_estimator_alpha;
   /* multibin radiation field estimators radfieldbins.J_raw / nuJ_raw [npts_nonempty*RADFIELDBINCOUNT] (radfield.cc:745-790)
-   * and detailed bound-free estimators bfrate_raw [npts_nonempty*nbfcontinua] (radfield.cc:215; every continuum has one, as
-   * with LEVEL_HAS_BFEST == true). Written by builds with the corresponding options; may be NULL. */
+   * and detailed bound-free estimators bfrate_raw [npts_nonempty*nbfestim] (radfield.cc:215; nbfestim = nbfcontinua unless
+   * artis_model.allcont_bfestimindex selects a subset). Written by builds with the corresponding options; may be NULL. */
   double *radfieldbin_J;
   double *radfieldbin_nuJ;
   double *bfrate_raw;

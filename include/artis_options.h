@@ -81,15 +81,57 @@
  * field is the multibin model (estimators per frequency bin, binned J_nu in the radiative excitation rates), every
  * continuum has a detailed bound-free estimator, and the non-thermal channels are on (NT_ON with a Spencer-Fano solution
  * from the host: ionisation / excitation branches of do_ntlepton_deposit(), non-thermal macro-atom rates). */
+/* The reference's other three options files differ from artisoptions_nltenebular.h, on the packet path, in the values
+ * below only (tests/golden/options_reference.json pins all six files):
+ * -DARTIS_PRESET_CHRISTINENONTHERMAL   artisoptions_christinenonthermal.h
+ * -DARTIS_PRESET_NLTEPHOTOSPHERIC      artisoptions_nltephotospheric_dynamic_ion_range.h (bound-free estimators for the NLTE
+ *                                      levels only: LEVEL_HAS_BFEST :80, artis_model.allcont_bfestimindex)
+ * -DARTIS_PRESET_NLTEWITHOUTNONTHERMAL artisoptions_nltewithoutnonthermal.h */
+#ifdef ARTIS_PRESET_CHRISTINENONTHERMAL
+#define ARTIS_PRESET_NLTENEBULAR
+#define ARTIS_OPT_MINTEMP 3000.                       /* artisoptions_christinenonthermal.h:48 */
+#define ARTIS_OPT_MAXTEMP 140000.                     /* :49 */
+#define ARTIS_OPT_NU_MAX_R 5e16                       /* :62 */
+#define ARTIS_OPT_RADFIELDBINCOUNT 64                 /* :68 */
+#define ARTIS_OPT_RADFIELDBINS_NU_MAX (2.99792458e+10 / 500e-8)            /* :73 */
+#define ARTIS_OPT_RADFIELDBINS_T_E_SUPERBIN_NU_MAX (2.99792458e+10 / 50e-8) /* :74 */
+#define ARTIS_OPT_NT_EXCITATION_ON 0                  /* :113 */
+#endif
+#ifdef ARTIS_PRESET_NLTEPHOTOSPHERIC
+#define ARTIS_PRESET_NLTENEBULAR
+#define ARTIS_OPT_MINTEMP 3500.                       /* artisoptions_nltephotospheric_dynamic_ion_range.h:46 */
+#define ARTIS_OPT_MAXTEMP 140000.                     /* :47 */
+#define ARTIS_OPT_BFEST_SUBSET 1                      /* :80 LEVEL_HAS_BFEST: only some continua have an estimator */
+#endif
+#ifdef ARTIS_PRESET_NLTEWITHOUTNONTHERMAL
+#define ARTIS_PRESET_NLTENEBULAR
+#define ARTIS_OPT_DIPOLE 1                            /* artisoptions_nltewithoutnonthermal.h:51 */
+#define ARTIS_OPT_POL_ON 1                            /* :52 */
+#define ARTIS_OPT_NU_MIN_R 1e14                       /* :59 */
+#define ARTIS_OPT_NU_MAX_R 5e16                       /* :60 */
+#define ARTIS_OPT_TABLESIZE 200                       /* :45 */
+#define ARTIS_OPT_MINTEMP 4000.                       /* :46 */
+#define ARTIS_OPT_MAXTEMP 140000.                     /* :47 */
+#define ARTIS_OPT_RADFIELDBINCOUNT 512                /* :66 */
+#define ARTIS_OPT_RADFIELDBINS_NU_MAX (2.99792458e+10 / 100e-8)            /* :71 */
+#define ARTIS_OPT_NT_EXCITATION_ON 0                  /* :111 */
+#define ARTIS_OPT_BFCOOLING_USELEVELPOPNOTIONPOP 1    /* :137 */
+#endif
 #ifdef ARTIS_PRESET_NLTENEBULAR
+#ifndef ARTIS_OPT_DIPOLE
 #define ARTIS_OPT_DIPOLE 0                            /* artisoptions_nltenebular.h:48 */
 #define ARTIS_OPT_POL_ON 0                            /* :49 */
+#endif
 #define ARTIS_OPT_MINPOP 1e-40                        /* :54 */
+#ifndef ARTIS_OPT_NU_MIN_R
 #define ARTIS_OPT_NU_MIN_R 1e13                       /* :56 */
+#endif
 #define ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION 0    /* :59 */
 #define ARTIS_OPT_DIRECT_COL_HEAT 1                   /* :36 */
+#ifndef ARTIS_OPT_MINTEMP
 #define ARTIS_OPT_MINTEMP 1000.                       /* :42 */
 #define ARTIS_OPT_MAXTEMP 30000.                      /* :43 */
+#endif
 #define ARTIS_OPT_LTEPOP_EXCITATION_USE_TJ 0          /* :24 */
 #define ARTIS_OPT_USE_LUT_PHOTOION 0                  /* :84 */
 #define ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS 0      /* :86 */
@@ -98,16 +140,27 @@
 #define ARTIS_OPT_NT_ON 1                             /* :102 with NT_SOLVE_SPENCERFANO :104 */
 #endif
 /* non-thermal options (artisoptions_nltenebular.h:110-119; NT_EXCITATION_ON only has a meaning with NT_ON) */
+#ifndef ARTIS_OPT_NT_EXCITATION_ON
 #define ARTIS_OPT_NT_EXCITATION_ON 1
+#endif
 #define ARTIS_OPT_NTEXCITATION_MAXNLEVELS_LOWER 5
 #define ARTIS_OPT_NTEXCITATION_MAXNLEVELS_UPPER 250
 #define ARTIS_OPT_NT_MAX_AUGER_ELECTRONS 2
 /* multibin radiation field model (artisoptions_nltenebular.h:62-70) */
+#ifndef ARTIS_OPT_RADFIELDBINCOUNT
 #define ARTIS_OPT_RADFIELDBINCOUNT 256
+#endif
 #define ARTIS_OPT_FIRST_NLTE_RADFIELD_TIMESTEP 12
 #define ARTIS_OPT_RADFIELDBINS_NU_MIN (2.99792458e+10 / 40000e-8)
+#ifndef ARTIS_OPT_RADFIELDBINS_NU_MAX
 #define ARTIS_OPT_RADFIELDBINS_NU_MAX (2.99792458e+10 / 1085e-8)
+#endif
+#ifndef ARTIS_OPT_RADFIELDBINS_T_E_SUPERBIN_NU_MAX
 #define ARTIS_OPT_RADFIELDBINS_T_E_SUPERBIN_NU_MAX (2.99792458e+10 / 10e-8)
+#endif
+#ifndef ARTIS_OPT_BFEST_SUBSET
+#define ARTIS_OPT_BFEST_SUBSET 0 /* LEVEL_HAS_BFEST is true for every level (nltenebular.h:82) or the estimators are off */
+#endif
 
 #ifndef ARTIS_OPT_DIPOLE
 #define ARTIS_OPT_DIPOLE 1 /* artisoptions_classic.h:47 */

@@ -112,6 +112,11 @@ typedef struct {
   int error;
   int npopulated;     /* cells currently holding a cache */
   int cache_cap;      /* evict everything when this many cells are cached (bounds host memory) */
+  /* detailed bound-free estimators (input.cc:932-955): the estimator of every continuum (-1: none), their number and
+   * their edge frequencies in rising order (globals::allcont.bfestimindex, globals::bfestim_nu_edge) */
+  int32_t *allcont_bfestimindex;
+  double *bfestim_nu_edge;
+  int nbfestim;
   double t_populate;  /* seconds spent filling caches */
 } Oracle;
 
@@ -1202,6 +1207,7 @@ static double calculate_cooling_rates_ion(Oracle *o, const CellCache *cc, int c,
       const int nt = m->level_nphixstargets[ul];
       double targetweight_sum = 0.;
       double E_target_min = 0.;
+      (void)targetweight_sum; (void)E_target_min; (void)nnupperion;
 #if !ARTIS_OPT_BFCOOLING_USELEVELPOPNOTIONPOP
       if (nt > 1) {
         E_target_min = DBL_MAXV;
@@ -1382,10 +1388,11 @@ static double calculate_chi_bf_gammacontr(Oracle *o, const CellCache *cc, int c,
   const int allcontend = upper_bound_d(m->allcont_nu_edge, m->nbfcontinua, nu);
   const int allcontbegin = lower_bound_d(m->allcont_nu_edge, allcontend, nu / o->last_phixs_nuovernuedge);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
-  if (!selectcontinuum && phixslist) { /* rpkt.cc:762-775 (bfestim_nu_edge is allcont_nu_edge here) */
-    phixslist->bfestimend = allcontend;
-    phixslist->bfestimbegin = allcontbegin;
-    for (int i = allcontbegin; i < allcontend; i++) phixslist->gamma_contr[i] = 0.;
+  if (!selectcontinuum && phixslist) {
+    /* rpkt.cc:762-776: the window in estimator indices, cleared (only contributing continua write below) */
+    phixslist->bfestimend = upper_bound_d(o->bfestim_nu_edge, o->nbfestim, nu);
+    phixslist->bfestimbegin = lower_bound_d(o->bfestim_nu_edge, phixslist->bfestimend, nu / o->last_phixs_nuovernuedge);
+    for (int i = phixslist->bfestimbegin; i < phixslist->bfestimend; i++) phixslist->gamma_contr[i] = 0.;
   }
 #endif
 
@@ -1412,7 +1419,8 @@ static double calculate_chi_bf_gammacontr(Oracle *o, const CellCache *cc, int c,
         if (m->allcont_groundcontestimindex[i] >= 0) groundcont_gamma_contr[m->allcont_groundcontestimindex[i]] = sigma_contr;
       }
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
-      if (!selectcontinuum && phixslist) phixslist->gamma_contr[i] = sigma_contr; /* rpkt.cc:905 */
+      if (!selectcontinuum && phixslist && o->allcont_bfestimindex[i] >= 0)
+        phixslist->gamma_contr[o->allcont_bfestimindex[i]] = sigma_contr; /* rpkt.cc:905 */
 #endif
       chi_bf_sum += nnlevel * sigma_contr;
       if (selectcontinuum && chi_bf_sum > threshold) {
@@ -2211,12 +2219,13 @@ static void update_estimators(Oracle *o, double e_cmf, double nu_cmf, double dis
   if (distance_e_cmf != 0 && o->est.bfrate_raw) { /* radfield::update_bfestimators radfield.cc:215 */
     const artis_model *m = o->m;
     const double distance_e_cmf_over_nu = distance_e_cmf / nu_cmf;
-    const int bfestimend = upper_bound_d(m->allcont_nu_edge, chi->bfestimend, nu_cmf);
+    (void)m;
+    const int bfestimend = upper_bound_d(o->bfestim_nu_edge, chi->bfestimend, nu_cmf);
     const int bfestimbegin_stored = chi->bfestimbegin < bfestimend ? chi->bfestimbegin : bfestimend;
-    const int bfestimbegin = bfestimbegin_stored + lower_bound_d(m->allcont_nu_edge + bfestimbegin_stored, bfestimend - bfestimbegin_stored,
+    const int bfestimbegin = bfestimbegin_stored + lower_bound_d(o->bfestim_nu_edge + bfestimbegin_stored, bfestimend - bfestimbegin_stored,
                                                                  nu_cmf / o->last_phixs_nuovernuedge);
     for (int i = bfestimbegin; i < bfestimend; i++)
-      o->est.bfrate_raw[((ptrdiff_t)c * m->nbfcontinua) + i] += chi->gamma_contr[i] * distance_e_cmf_over_nu;
+      o->est.bfrate_raw[((ptrdiff_t)c * o->nbfestim) + i] += chi->gamma_contr[i] * distance_e_cmf_over_nu;
   }
 #endif
 #if ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON
@@ -2966,6 +2975,24 @@ static void oracle_init(Oracle *o, const artis_model *m, const artis_cellstate *
   o->last_phixs_nuovernuedge = (1.0 + (m->NPHIXSNUINCREMENT * (m->NPHIXSPOINTS - 1))); /* input.cc:310 */
   const char *cap = getenv("ARTIS_ORACLE_CACHE_CAP");
   o->cache_cap = cap ? atoi(cap) : 0;
+  /* input.cc:932-955: estimator index of every continuum and the estimators' edge frequencies */
+  o->allcont_bfestimindex = (int32_t *)calloc((size_t)m->nbfcontinua + 1, sizeof(int32_t));
+  o->bfestim_nu_edge = (double *)calloc((size_t)m->nbfcontinua + 1, sizeof(double));
+  o->nbfestim = 0;
+  for (int i = 0; i < m->nbfcontinua; i++) {
+    const int has = m->allcont_bfestimindex ? (m->allcont_bfestimindex[i] >= 0) : 1;
+    if (has) {
+      o->allcont_bfestimindex[i] = o->nbfestim;
+      o->bfestim_nu_edge[o->nbfestim++] = m->allcont_nu_edge[i];
+    } else {
+      o->allcont_bfestimindex[i] = -1;
+    }
+  }
+  if (m->allcont_bfestimindex) {
+    if (o->nbfestim != m->nbfestim) ORACLE_FAIL(o, "artis_model.nbfestim does not match allcont_bfestimindex");
+    for (int i = 0; i < m->nbfcontinua; i++)
+      if (m->allcont_bfestimindex[i] != o->allcont_bfestimindex[i]) ORACLE_FAIL(o, "allcont_bfestimindex is not the running count of input.cc:940");
+  }
 }
 double artis_oracle_last_populate_seconds(void) { return g_last_populate_seconds; }
 /* the constants of constants.h as restated at the top of this file, for tests/test_oracle_reference_props.py */
@@ -2988,6 +3015,8 @@ static void oracle_free(Oracle *o) {
     if (cc->populated) cellcache_free_one(cc);
   }
   free(o->cache);
+  free(o->allcont_bfestimindex);
+  free(o->bfestim_nu_edge);
   g_last_populate_seconds = o->t_populate;
 }
 

@@ -499,6 +499,24 @@ def test_engine_matches_oracle_nltenebular_preset(engine_mod, oracle, gridtype, 
     eng.close()
 
 
+@pytest.mark.parametrize("options", ["christinenonthermal", "nltephotospheric", "nltewithoutnonthermal"])
+def test_engine_matches_oracle_remaining_option_files(engine_mod, oracle, options):
+    """the builds for the reference's other three options files (64 / 256 / 512 radiation-field bins, estimators for a
+    subset of the continua, polarisation with the non-thermal channels, level-population bound-free cooling) against the
+    oracle built alike; all packet types"""
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", 8, abi.GRID_CARTESIAN3D, 0.0, 16000, kfrac=0.15, gfrac=0.15,
+                                                    pfrac=0.3, options=options, bkw=dict(nts=13))
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, options + ": HIP engine vs oracle")
+    parity.compare_stats(eb, ea, options + ": HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, options + ": HIP engine vs oracle")
+    assert eb.stats[abi.STAT_X_RPKT_STEPS] > 16000 and np.count_nonzero(eb.bfrate_raw) > 100
+    if options == "nltephotospheric":   # a model without the estimator map is refused by this build
+        with pytest.raises(engine_mod.EngineError):
+            engine_mod.Engine(abi.Model({k: v for k, v in model.d.items() if k not in ("allcont_bfestimindex", "nbfestim")}), preset=options)
+    print(f"worst float rel diff {rep['worst_rel']:.3e}")
+    eng.close()
+
+
 def test_deferred_bound_free_estimators_equal_in_place(engine_mod, monkeypatch):
     """nltenebular build: the detailed bound-free estimator updates recorded by k_rpkt and added by k_bfest_dense (a wave
     per update) against the same build adding them in place (ARTIS_AMD_BFDEFER=0): identical packets and counters, the

@@ -364,3 +364,30 @@ def test_gamma_products_thermalisation_bit_exact(oracle):
     pc, ec = pk0.copy(), abi.estimators_for(model, "kilonova_lte")
     oracle.update_packets(model, cs, ts, pc, ec, preset="kilonova_lte")
     assert ec.scalars[abi.SCALAR_NAMES.index("gamma_dep_discrete")] > sc["gamma_dep_discrete"]
+
+
+@pytest.mark.parametrize("options", ["christinenonthermal", "nltephotospheric", "nltewithoutnonthermal"])
+def test_remaining_reference_option_files_bit_exact(oracle, options):
+    """The reference's other three options files (artisoptions_christinenonthermal.h,
+    artisoptions_nltephotospheric_dynamic_ion_range.h, artisoptions_nltewithoutnonthermal.h): the nltenebular packet path
+    with other table grids and frequency limits, 64 / 256 / 512 radiation-field bins, NT_EXCITATION_ON off, bound-free
+    estimators for a subset of the continua (LEVEL_HAS_BFEST: estimator index != continuum index, input.cc:932-947),
+    dipole scattering with polarisation together with the non-thermal channels, and bound-free cooling weighted by level
+    populations (BFCOOLING_USELEVELPOPNOTIONPOP, kpkt.cc:191). All packet types."""
+    model, cs, ts, aux = synth.build("small", ncoord=8, options=options, nts=13)
+    pk0 = synth.make_packets(model, aux, 4000, kpkt_fraction=0.15, gamma_fraction=0.15, pellet_fraction=0.3)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, options + ": kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, options + ": kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, options + ": kernel bodies vs oracle")
+    st = ea.stats_dict()
+    nb = abi.NEBULAR_FAMILY[options]
+    assert ea.radfieldbin_J.size == model["npts_nonempty"] * nb and ea.radfieldbin_J.sum() > 0
+    assert st["X_RPKT_STEPS"] > 4000 and st["NT_STAT_TO_IONISATION"] > 30
+    assert (st["NT_STAT_TO_EXCITATION"] > 0) == (options == "nltephotospheric")          # NT_EXCITATION_ON
+    if options == "nltephotospheric":
+        nest = model["nbfestim"]
+        assert 0 < nest < model["nbfcontinua"] and ea.bfrate_raw.size == model["npts_nonempty"] * nest
+        assert np.count_nonzero(ea.bfrate_raw) > 100
+    if options == "nltewithoutnonthermal":
+        assert np.any(pa["stokes_q"] != 0)                                                  # POL_ON

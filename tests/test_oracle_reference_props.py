@@ -402,10 +402,11 @@ def test_planck_function_integrals_unittests_cc_254(oracle):
         assert abs(n[np.argmax(B)] * H / (KB * T) - 2.8214393721) < 2e-3, name
 
 
-@pytest.mark.parametrize("preset", ["classic", "kilonova_lte", "nltenebular"])
+@pytest.mark.parametrize("preset", ["classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric",
+                                    "nltewithoutnonthermal"])
 def test_options_presets_match_reference_option_files(preset, tmp_path):
-    """include/artis_options.h against the reference's own artisoptions_<preset>.h: every compile-time option the packet
-    path reads (37 of them: grids of the rate-coefficient tables, frequency limits, scattering and polarisation switches,
+    """include/artis_options.h against the reference's own artisoptions_<preset>.h, all six files: every compile-time
+    option the packet path reads (39 of them: grids of the rate-coefficient tables, frequency limits, scattering and polarisation switches,
     estimator and radiation-field model switches, non-thermal switches, thermalisation schemes with the reference's enum
     numbering, expansion opacities ...) has the value the reference's file gives it. Golden file:
     tests/golden/options_reference.json, printed by the reference's headers compiled where they lie
@@ -418,7 +419,7 @@ def test_options_presets_match_reference_option_files(preset, tmp_path):
     flags = [] if preset == "classic" else [f"-DARTIS_PRESET_{preset.upper()}"]
     subprocess.check_call(["gcc", *flags, "-o", exe, os.path.join(HERE, "options_printer.c")], cwd=root)
     got = dict(line.split() for line in subprocess.check_output([exe], text=True).strip().splitlines())
-    assert len(want) >= 37 and set(got) == set(want)
+    assert len(want) >= 39 and set(got) == set(want)
     for name, val in want.items():
         assert got[name] == val, f"{preset}: {name} = {got[name]}, reference {val}"
 
