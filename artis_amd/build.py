@@ -50,8 +50,13 @@ def build(force: bool = False, extra_flags=(), preset: str = "classic") -> str:
     return so
 
 
-def build_all(force: bool = False):
-    return [build(force=force, preset=p) for p in PRESETS]
+def build_all(force: bool = False, jobs: int = 0):
+    """Every preset's library; the hipcc runs are independent, so a few go side by side (each takes ~12 s and ~1 GB)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    jobs = jobs or min(4, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        return list(pool.map(lambda p: build(force=force, preset=p), PRESETS))
 
 
 if __name__ == "__main__":
