@@ -142,9 +142,10 @@ _MODEL_FIELDS = [
     ("elem_meannucmass", _F32P, np.float32), ("ion_nt_sum_q_over_binding", _F64P, np.float64),
     ("ejecta_kinetic_energy", C.c_double, None), ("mtot_input", C.c_double, None),
     ("allcont_bfestimindex", _I32P, np.int32), ("nbfestim", C.c_int32, None),
+    ("rho_tmin", _F32P, np.float32),
 ]
 _MODEL_OPTIONAL = ("elem_meannucmass", "ion_nt_sum_q_over_binding", "ejecta_kinetic_energy", "mtot_input",
-                   "allcont_bfestimindex", "nbfestim")
+                   "allcont_bfestimindex", "nbfestim", "rho_tmin")
 
 _CELL_FIELDS = [
     ("rho", _F32P, np.float32), ("Te", _F32P, np.float32), ("TJ", _F32P, np.float32), ("TR", _F32P, np.float32),

@@ -1338,6 +1338,12 @@ const char *artis_amd_options_preset(void) {
   return "kilonova_expopac";
 #elif defined(ARTIS_PRESET_CLASSIC_EXPOPAC_THERM)
   return "classic_expopac_therm";
+#elif defined(ARTIS_PRESET_KILONOVA_GAMMA_BARNES)
+  return "kilonova_gamma_barnes";
+#elif defined(ARTIS_PRESET_KILONOVA_GAMMA_WOLLAEGER)
+  return "kilonova_gamma_wollaeger";
+#elif defined(ARTIS_PRESET_KILONOVA_GAMMA_GUTTMAN)
+  return "kilonova_gamma_guttman";
 #elif defined(ARTIS_PRESET_KILONOVA_GAMMAPRODUCTS)
   return "kilonova_gammaproducts";
 #elif defined(ARTIS_PRESET_KILONOVA_BARNES)
@@ -1441,6 +1447,16 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   }
   ARTIS_MODEL_OPTIONAL_ARRAYS(UPMO, h)
 #undef UPMO
+  if ((ARTIS_OPT_GAMMA_THERMALISATION_SCHEME == ARTIS_GAMMA_WOLLAEGER || ARTIS_OPT_GAMMA_THERMALISATION_SCHEME == ARTIS_GAMMA_GUTTMAN) &&
+      !e->M.rho_tmin) {
+    g_last_error = "this build integrates gamma-ray column densities: artis_model.rho_tmin is required";
+    return ARTIS_ERR_ARG;
+  }
+  if ((ARTIS_OPT_GAMMA_THERMALISATION_SCHEME == ARTIS_GAMMA_BARNES || ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_BARNES) &&
+      !(h.mtot_input > 0. && h.ejecta_kinetic_energy > 0.)) {
+    g_last_error = "this build uses a Barnes thermalisation efficiency: artis_model.mtot_input and ejecta_kinetic_energy are required";
+    return ARTIS_ERR_ARG;
+  }
   if (ARTIS_OPT_BFEST_SUBSET && !e->M.allcont_bfestimindex) {
     g_last_error = "this build keeps bound-free estimators for a subset of the continua: artis_model.allcont_bfestimindex / nbfestim are required";
     return ARTIS_ERR_ARG;

@@ -96,7 +96,8 @@ struct ModelOwned {
 #define ARTIS_MODEL_OPTIONAL_ARRAYS(X, m)      \
   X(elem_meannucmass, float, (m).nelements)    \
   X(ion_nt_sum_q_over_binding, double, (m).nions) \
-  X(allcont_bfestimindex, int32_t, (m).nbfcontinua)
+  X(allcont_bfestimindex, int32_t, (m).nbfcontinua) \
+  X(rho_tmin, float, (m).npts_nonempty)
 
 // X(field, element type, element count) for every array pointer of DevCells
 #define ARTIS_CELL_ARRAYS(X, m)                                          \
@@ -308,6 +309,7 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.tmin = m.tmin; v.vmax = m.vmax; v.rmax = m.rmax;
   v.ejecta_kinetic_energy = m.ejecta_kinetic_energy; v.mtot_input = m.mtot_input;
   v.allcont_bfestimindex = m.allcont_bfestimindex;
+  v.rho_tmin = m.rho_tmin;
   v.nbfestim = (m.allcont_bfestimindex && m.nbfestim > 0) ? m.nbfestim : m.nbfcontinua;
   return v;
 }

@@ -3113,6 +3113,97 @@ AHD void pair_production(const Env &env, Pkt &p, int64_t pi) {  // gammapkt.cc:6
   }
 }
 // transport_gamma gammapkt.cc:655 + do_gamma gammapkt.cc:911
+#if ARTIS_OPT_GAMMA_THERMALISATION_SCHEME != ARTIS_GAMMA_FREQUENCYDEPENDENT
+// column density times kappa along the ray of q (a copy of the packet) out of the grid: the loop of
+// wollaeger_thermalisation() / guttman_thermalisation() (gammapkt.cc:805-828, :846-858)
+AHD double gamma_ray_tau(const Env &env, Pkt q, double mean_gamma_opac) {
+  const DevModel &M = env.M;
+  double tau = 0.;
+  int guard = 0;
+  while (q.type != ARTIS_TYPE_ESCAPE) {
+    int next_cell = -1;
+    const double boundarydist = boundary_distance(env, q, &next_cell);
+    const int c = M.propcell_nonemptymgi[q.cellindex];
+    if (c >= 0) {
+      const double rho = M.rho_tmin[c] * pow3(M.tmin / q.prop_time);  // the density when the ray reaches the cell
+      tau += mean_gamma_opac * rho * boundarydist;
+    }
+    move_pkt(q, boundarydist);
+    // change_cell_or_escape(pkt_copy, next_cellindex, false): no counters, nothing recorded
+    if (next_cell >= 0) {
+      if (next_cell != q.cellindex && M.gridtype == ARTIS_GRID_CARTESIAN3D) {
+        double *pos[3] = {&q.px, &q.py, &q.pz};
+        for (int d = 0; d < 3; d++) {
+          const int idx = coordidx(M, next_cell, d);
+          const double lo = M.coord_pos_min_tmin[d][idx] / M.tmin * q.prop_time;
+          const double hi = (idx < (M.ncoordgrid[d] - 1)) ? M.coord_pos_min_tmin[d][idx + 1] / M.tmin * q.prop_time
+                                                           : M.rmax / M.tmin * q.prop_time;
+          *pos[d] = dclamp(*pos[d], lo, hi);
+        }
+      }
+      q.cellindex = next_cell;
+    } else {
+      q.type = ARTIS_TYPE_ESCAPE;
+    }
+    if (++guard > 1000000) {
+      fail(env, 97);
+      break;
+    }
+  }
+  return tau;
+}
+// do_gamma gammapkt.cc:911 with a parameterised thermalisation scheme: no transport, the packet is absorbed where it is
+// with the scheme's probability (absorb_or_escape_gamma :754) or leaves the grid
+AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
+  ARTIS_STAT(env, ARTIS_STAT_X_GAMMA_STEPS);
+  double f_gamma;
+#if ARTIS_OPT_GAMMA_THERMALISATION_SCHEME == ARTIS_GAMMA_BARNES
+  {  // barnes_thermalisation gammapkt.cc:779
+    const double E_kin = env.M.ejecta_kinetic_energy;
+    const double v_ej = sqrt(E_kin * 2 / env.M.mtot_input);
+    const double t_ineff = 1.4 * DAY * sqrt(env.M.mtot_input / (5.e-3 * MSUN)) * ((0.2 * CLIGHT) / v_ej);
+    const double tau = pow2(t_ineff / p.prop_time);
+    f_gamma = 1. - exp(-tau);
+  }
+#elif ARTIS_OPT_GAMMA_THERMALISATION_SCHEME == ARTIS_GAMMA_WOLLAEGER
+  {  // wollaeger_thermalisation gammapkt.cc:797: the optical depth radially outwards
+    Pkt q = p;
+    const double pos[3] = {p.px, p.py, p.pz};
+    const double mag = vlen(pos);
+    q.dx = pos[0] / mag;  // vec_norm vectors.h:31
+    q.dy = pos[1] / mag;
+    q.dz = pos[2] / mag;
+    f_gamma = 1. - exp(-gamma_ray_tau(env, q, 0.1));
+  }
+#else
+  {  // guttman_thermalisation gammapkt.cc:831: the deposition probability averaged over 100 random directions
+    double deposition_probability_sum = 0.;
+    for (int i = 0; i < 100; i++) {
+      Pkt q = p;
+      double dir[3];
+      rand_isotropic(p, dir);  // drawn from the packet's own generator
+      q.dx = dir[0];
+      q.dy = dir[1];
+      q.dz = dir[2];
+      deposition_probability_sum -= expm1(-gamma_ray_tau(env, q, 0.03));
+    }
+    f_gamma = deposition_probability_sum / 100;
+  }
+#endif
+  if (!(f_gamma >= 0.) || !(f_gamma <= 1.)) fail(env, 98);
+  if (rng_uniform(p) < f_gamma) {
+    p.type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+    p.absorptiontype = ARTIS_ABSTYPE_GAMMA_PHOTOELECTRIC;  // the schemes do not resolve the process (gammapkt.cc:761)
+  } else {
+    change_cell_or_escape(env, p, pi, -99);  // escape_type stays TYPE_GAMMA
+  }
+  if (p.type != ARTIS_TYPE_GAMMA && p.type != ARTIS_TYPE_ESCAPE) {
+    if (!ARTIS_GAMMAPRODUCTS) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE], p.e_cmf);
+    const int c = env.M.propcell_nonemptymgi[p.cellindex];  // no transport: the path estimator is fed here (gammapkt.cc:930)
+    if (c >= 0) ARTIS_EST_ADD(&env.E.dep_estimator_gamma[c], p.e_cmf);
+  }
+}
+#else
 AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
   const double t2 = env.S.ts_end;
   ARTIS_STAT(env, ARTIS_STAT_X_GAMMA_STEPS);
@@ -3160,6 +3251,7 @@ AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
   if (p.type != ARTIS_TYPE_GAMMA && p.type != ARTIS_TYPE_ESCAPE && !ARTIS_GAMMAPRODUCTS)
     ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE], p.e_cmf);  // gammapkt.cc:926
 }
+#endif
 // nonthermal::do_ntlepton_deposit nonthermal.cc:2529. NT_ON == false (artisoptions_classic.h:95): every deposit is heat.
 // NT_ON with a Spencer-Fano solution (artisoptions_nltenebular.h:102-104): the deposit ionises or excites a macro-atom
 // with the solution's fractions; the activation is recorded in the packet (ma_activate) and the walk runs in the thermal

@@ -128,6 +128,7 @@ struct DevModel {
   // detailed bound-free estimators: estimator index of every continuum (-1: none) or null = identity; their number
   const int32_t *allcont_bfestimindex;
   int32_t nbfestim;
+  const float *rho_tmin;  // [npts_nonempty] optional: column densities of the Wollaeger / Guttman gamma-ray schemes
   const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
       *ion_coolingoffset, *ion_ncoolingterms;
   const double *level_epsilon;

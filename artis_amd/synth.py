@@ -60,7 +60,8 @@ OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0
                  "nltephotospheric": (100, 3500.0, 140000.0), "nltewithoutnonthermal": (200, 4000.0, 140000.0),
                  "kilonova_barnes": (200, 500.0, 150000.0),
                  "kilonova_wollaeger": (200, 500.0, 150000.0), "kilonova_expopac": (200, 500.0, 150000.0),
-                 "kilonova_gammaproducts": (200, 500.0, 150000.0),
+                 "kilonova_gammaproducts": (200, 500.0, 150000.0), "kilonova_gamma_barnes": (200, 500.0, 150000.0),
+                 "kilonova_gamma_wollaeger": (200, 500.0, 150000.0), "kilonova_gamma_guttman": (200, 500.0, 150000.0),
                  "classic_expopac_therm": (100, 3500.0, 140000.0)}
 
 
@@ -648,6 +649,7 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     md.update(grid)
     # whole-ejecta scalars of the Barnes thermalisation scheme (grid.h:139 get_ejecta_kinetic_energy, grid.h:40 mtot_input)
     m_cell = np.asarray(cells["rho"], dtype=np.float64) * (aux["t"] / grid["tmin"]) ** 3 * aux["cellvol_tmin"]
+    md["rho_tmin"] = (np.asarray(cells["rho"], dtype=np.float64) * (aux["t"] / grid["tmin"]) ** 3).astype(np.float32)  # grid::get_rho_tmin
     md["mtot_input"] = float(m_cell.sum())
     md["ejecta_kinetic_energy"] = float((0.5 * m_cell * aux["v"] ** 2).sum())
     model = abi.Model(md)

@@ -280,6 +280,10 @@ typedef struct artis_model {
    * continuum has one (artisoptions_nltenebular.h:82), the estimator index is the continuum index. */
   const int32_t *allcont_bfestimindex;
   int32_t nbfestim;
+
+  /* [npts_nonempty] grid::get_rho_tmin(mgi): the density at tmin, read by the Wollaeger and Guttman gamma-ray
+   * thermalisation schemes (gammapkt.cc:819, :853) for the column density along a ray; NULL elsewhere */
+  const float *rho_tmin;
 } artis_model;
 
 /* ---- per-timestep cell state written by the reference's update_grid() ----- */

@@ -30,6 +30,21 @@
 #define ARTIS_PRESET_KILONOVA_LTE
 #define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_WOLLAEGER
 #endif
+/* -DARTIS_PRESET_KILONOVA_GAMMA_BARNES / _WOLLAEGER / _GUTTMAN: artisoptions_kilonova_lte.h with one of the parameterised
+ * gamma-ray thermalisation schemes instead of gamma-ray transport (gammapkt.cc:775-866): a gamma packet is absorbed where
+ * it is born with the scheme's deposition probability, or escapes. No options file of the reference selects them. */
+#ifdef ARTIS_PRESET_KILONOVA_GAMMA_BARNES
+#define ARTIS_PRESET_KILONOVA_LTE
+#define ARTIS_OPT_GAMMA_THERMALISATION_SCHEME 1
+#endif
+#ifdef ARTIS_PRESET_KILONOVA_GAMMA_WOLLAEGER
+#define ARTIS_PRESET_KILONOVA_LTE
+#define ARTIS_OPT_GAMMA_THERMALISATION_SCHEME 2
+#endif
+#ifdef ARTIS_PRESET_KILONOVA_GAMMA_GUTTMAN
+#define ARTIS_PRESET_KILONOVA_LTE
+#define ARTIS_OPT_GAMMA_THERMALISATION_SCHEME 3
+#endif
 /* -DARTIS_PRESET_KILONOVA_GAMMAPRODUCTS: TIMEDEPENDENTWITHGAMMAPRODUCTS (constants.h:86): a gamma-ray interaction hands its
  * energy to an electron / positron that thermalises with the local time-dependent scheme instead of depositing at once
  * (gammapkt.cc:404, :572, :630, :734, :925; update_packets.cc:174) */
@@ -244,7 +259,15 @@
 /* gamma packets: the classic choices (artisoptions_classic.h:144-150) are the ones built */
 #define ARTIS_OPT_USE_XCOM_GAMMAPHOTOION 0            /* Veigele fit for the photoelectric opacity */
 #define ARTIS_OPT_GAMMA_USE_KAPPA_GREY 0             /* std::nullopt in the reference: frequency-dependent transport */
-#define ARTIS_OPT_GAMMA_THERMALISATION_FREQUENCYDEPENDENT 1
+/* GAMMA_THERMALISATION_SCHEME (artisoptions_classic.h:148), numbered like enum class GammaThermalisationScheme
+ * (constants.h:81): 0 = FREQUENCYDEPENDENT (transport), 1 = BARNES, 2 = WOLLAEGER, 3 = GUTTMAN (gammapkt.cc:775-866) */
+#define ARTIS_GAMMA_FREQUENCYDEPENDENT 0
+#define ARTIS_GAMMA_BARNES 1
+#define ARTIS_GAMMA_WOLLAEGER 2
+#define ARTIS_GAMMA_GUTTMAN 3
+#ifndef ARTIS_OPT_GAMMA_THERMALISATION_SCHEME
+#define ARTIS_OPT_GAMMA_THERMALISATION_SCHEME ARTIS_GAMMA_FREQUENCYDEPENDENT
+#endif
 
 /* kpkt.cc:51 kpktdiffusion_timestep_fraction (a float in the reference) */
 #define ARTIS_KPKTDIFFUSION_TIMESTEP_FRACTION 0.001f

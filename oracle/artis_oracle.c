@@ -2750,12 +2750,81 @@ static void transport_gamma(Oracle *o, artis_packet *p, double t2) {
     ORACLE_FAIL(o, "transport_gamma: no branch");
   }
 }
+#if ARTIS_OPT_GAMMA_THERMALISATION_SCHEME != ARTIS_GAMMA_FREQUENCYDEPENDENT
+/* absorb_or_escape_gamma gammapkt.cc:754 */
+static void absorb_or_escape_gamma(Oracle *o, artis_packet *p, double f_gamma) {
+  if (!(f_gamma >= 0.) || !(f_gamma <= 1.)) ORACLE_FAIL(o, "gamma thermalisation: f_gamma outside [0, 1]");
+  if (rng_uniform(p->rngstate) < f_gamma) {
+    p->type = ARTIS_TYPE_NTLEPTON_DEPOSITED;
+    p->absorptiontype = ARTIS_ABSTYPE_GAMMA_PHOTOELECTRIC;
+  } else {
+    change_cell_or_escape(o, p, -99);
+  }
+}
+/* the ray integration shared by wollaeger_thermalisation() and guttman_thermalisation() (gammapkt.cc:805-828, :846-858):
+ * a copy of the packet is moved cell by cell out of the grid, change_cell_or_escape(.., tally_stats = false) */
+static double gamma_ray_tau(Oracle *o, artis_packet pkt_copy, double mean_gamma_opac) {
+  double tau = 0.;
+  while (pkt_copy.type != ARTIS_TYPE_ESCAPE) {
+    int next_cellindex = -1;
+    const double boundarydist = boundary_distance(o, pkt_copy.dir, pkt_copy.pos, pkt_copy.prop_time, pkt_copy.cellindex, &next_cellindex);
+    const int c = propcell_nonemptymgi(o, pkt_copy.cellindex);
+    if (c >= 0) {
+      const double rho = o->m->rho_tmin[c] * pow3(o->m->tmin / pkt_copy.prop_time);
+      tau += mean_gamma_opac * rho * boundarydist;
+    }
+    move_pkt_withtime(&pkt_copy, boundarydist);
+    if (next_cellindex >= 0) {
+      if (next_cellindex != pkt_copy.cellindex) snap_pos_to_cell(o, pkt_copy.pos, pkt_copy.prop_time, next_cellindex);
+      pkt_copy.cellindex = next_cellindex;
+    } else {
+      pkt_copy.type = ARTIS_TYPE_ESCAPE;
+    }
+    if (o->error) break;
+  }
+  return tau;
+}
+#endif
 /* do_gamma gammapkt.cc:911 */
 static void do_gamma(Oracle *o, artis_packet *p, double t2) {
   stat_inc(o, ARTIS_STAT_X_GAMMA_STEPS);
+#if ARTIS_OPT_GAMMA_THERMALISATION_SCHEME == ARTIS_GAMMA_FREQUENCYDEPENDENT
   transport_gamma(o, p, t2);
-  if (p->type != ARTIS_TYPE_GAMMA && p->type != ARTIS_TYPE_ESCAPE && !ARTIS_GAMMAPRODUCTS) { /* gammapkt.cc:925 */
-    if (o->est.scalars) o->est.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE] += p->e_cmf;
+#elif ARTIS_OPT_GAMMA_THERMALISATION_SCHEME == ARTIS_GAMMA_BARNES
+  { /* barnes_thermalisation gammapkt.cc:779 */
+    (void)t2;
+    const double E_kin = o->m->ejecta_kinetic_energy;
+    const double v_ej = sqrt(E_kin * 2 / o->m->mtot_input);
+    const double t_ineff = 1.4 * DAY * sqrt(o->m->mtot_input / (5.e-3 * MSUN)) * ((0.2 * CLIGHT) / v_ej);
+    const double tau = pow2(t_ineff / p->prop_time);
+    absorb_or_escape_gamma(o, p, 1. - exp(-tau));
+  }
+#elif ARTIS_OPT_GAMMA_THERMALISATION_SCHEME == ARTIS_GAMMA_WOLLAEGER
+  { /* wollaeger_thermalisation gammapkt.cc:797 */
+    (void)t2;
+    artis_packet pkt_copy = *p;
+    vec_norm3(p->pos, pkt_copy.dir); /* integrate the optical depth radially outwards */
+    const double tau = gamma_ray_tau(o, pkt_copy, 0.1);
+    absorb_or_escape_gamma(o, p, 1. - exp(-tau));
+  }
+#else
+  { /* guttman_thermalisation gammapkt.cc:831 */
+    (void)t2;
+    double deposition_probability_sum = 0.;
+    for (int i = 0; i < 100; i++) {
+      artis_packet pkt_copy = *p;
+      get_rand_isotropic_unitvec(p->rngstate, pkt_copy.dir);
+      deposition_probability_sum -= expm1(-gamma_ray_tau(o, pkt_copy, 0.03));
+    }
+    absorb_or_escape_gamma(o, p, deposition_probability_sum / 100);
+  }
+#endif
+  if (p->type != ARTIS_TYPE_GAMMA && p->type != ARTIS_TYPE_ESCAPE) { /* gammapkt.cc:924-936 */
+    if (!ARTIS_GAMMAPRODUCTS && o->est.scalars) o->est.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE] += p->e_cmf;
+#if ARTIS_OPT_GAMMA_THERMALISATION_SCHEME != ARTIS_GAMMA_FREQUENCYDEPENDENT
+    const int c = propcell_nonemptymgi(o, p->cellindex); /* no transport: the path-based estimator is fed here */
+    if (c >= 0 && o->est.dep_estimator_gamma) o->est.dep_estimator_gamma[c] += p->e_cmf;
+#endif
   }
 }
 /* nonthermal::do_ntlepton_deposit nonthermal.cc:2529 (NT_ON false in artisoptions_classic.h:95; NT_ON with

@@ -445,6 +445,24 @@ def test_engine_matches_oracle_expansion_opacities(engine_mod, oracle, options, 
     eng.close()
 
 
+@pytest.mark.parametrize("options", ["kilonova_gamma_barnes", "kilonova_gamma_wollaeger", "kilonova_gamma_guttman"])
+def test_engine_matches_oracle_parameterised_gamma_thermalisation(engine_mod, oracle, options):
+    """the Barnes / Wollaeger / Guttman gamma-ray thermalisation builds (gammapkt.cc:775-866) against the oracle built alike"""
+    mtot = 0.5 * 1.98855e33   # Barnes: t_ineff = 14 d, f_gamma(20 d) ~ 0.4
+    base = synth.build("small", ncoord=8, options=options)[0]
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", 8, abi.GRID_CARTESIAN3D, 0.0, 12000, kfrac=0.1, gfrac=0.7,
+                                                    pfrac=0.1, options=options,
+                                                    model_override={"mtot_input": mtot, "ejecta_kinetic_energy": 0.5 * mtot * (0.2 * 2.99792458e10) ** 2,
+                                                                    "rho_tmin": base.d["rho_tmin"] * 0.5})
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, options + ": HIP engine vs oracle")
+    parity.compare_stats(eb, ea, options + ": HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, options + ": HIP engine vs oracle")
+    esc = pb[pb["type"] == abi.TYPE_ESCAPE]
+    assert np.count_nonzero(esc["escape_type"] == abi.TYPE_GAMMA) > 200 and eb.dep_estimator_gamma.sum() > 0
+    print(f"worst float rel diff {rep['worst_rel']:.3e}")
+    eng.close()
+
+
 def test_engine_matches_oracle_gamma_products(engine_mod, oracle):
     """the TIMEDEPENDENTWITHGAMMAPRODUCTS build (gammapkt.cc:404, :572, :630, :734, :925) against the oracle built alike"""
     P = "kilonova_gammaproducts"

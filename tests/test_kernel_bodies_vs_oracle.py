@@ -391,3 +391,33 @@ def test_remaining_reference_option_files_bit_exact(oracle, options):
         assert np.count_nonzero(ea.bfrate_raw) > 100
     if options == "nltewithoutnonthermal":
         assert np.any(pa["stokes_q"] != 0)                                                  # POL_ON
+
+
+@pytest.mark.parametrize("options,gridtype,ncoord", [
+    ("kilonova_gamma_barnes", abi.GRID_CARTESIAN3D, 8),
+    ("kilonova_gamma_wollaeger", abi.GRID_CARTESIAN3D, 8),
+    ("kilonova_gamma_wollaeger", abi.GRID_SPHERICAL1D, 16),
+    ("kilonova_gamma_guttman", abi.GRID_CARTESIAN3D, 8),
+    ("kilonova_gamma_guttman", abi.GRID_CYLINDRICAL2D, 6),
+])
+def test_parameterised_gamma_thermalisation_bit_exact(oracle, options, gridtype, ncoord):
+    """GAMMA_THERMALISATION_SCHEME BARNES, WOLLAEGER, GUTTMAN (gammapkt.cc:775-866): no gamma-ray transport; a gamma packet
+    is absorbed where it is born with the scheme's deposition probability -- from the ejecta's mass and kinetic energy
+    (Barnes), from the column density of a radial ray through the grid (Wollaeger), or averaged over 100 random rays
+    (Guttman) -- or leaves the grid as a gamma packet. Built on the kilonova_lte options with kilonova-like ejecta."""
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options)
+    mtot = 0.5 * 1.98855e33   # Barnes: t_ineff = 1.4 d sqrt(M / 0.005 Msun) (0.2 c / v_ej) = 14 d, f_gamma(20 d) ~ 0.4
+    model = abi.Model({**model.d, "mtot_input": mtot, "ejecta_kinetic_energy": 0.5 * mtot * (0.2 * 2.99792458e10) ** 2,
+                       "rho_tmin": model.d["rho_tmin"] * 0.5})                                   # rays of optical depth ~1
+    pk0 = synth.make_packets(model, aux, 3000, kpkt_fraction=0.1, gamma_fraction=0.7, pellet_fraction=0.1)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, options + ": kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, options + ": kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, options + ": kernel bodies vs oracle")
+    esc = pa[pa["type"] == abi.TYPE_ESCAPE]
+    nesc_gamma = np.count_nonzero(esc["escape_type"] == abi.TYPE_GAMMA)
+    ngamma = np.count_nonzero(pk0["type"] == abi.TYPE_GAMMA)
+    assert 0.05 * ngamma < nesc_gamma < 0.95 * ngamma                      # both outcomes occur
+    assert np.count_nonzero(pa["type"] == abi.TYPE_GAMMA) == 0              # no gamma packet is left to transport
+    sc = dict(zip(abi.SCALAR_NAMES, ea.scalars))
+    assert sc["gamma_dep_discrete"] > 0 and abs(ea.dep_estimator_gamma.sum() / sc["gamma_dep_discrete"] - 1) < 1e-12
