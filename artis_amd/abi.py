@@ -143,9 +143,10 @@ _MODEL_FIELDS = [
     ("ejecta_kinetic_energy", C.c_double, None), ("mtot_input", C.c_double, None),
     ("allcont_bfestimindex", _I32P, np.int32), ("nbfestim", C.c_int32, None),
     ("rho_tmin", _F32P, np.float32),
+    ("xcom_elem_start", _I32P, np.int32), ("xcom_energy", _F64P, np.float64), ("xcom_sigma", _F64P, np.float64),
 ]
 _MODEL_OPTIONAL = ("elem_meannucmass", "ion_nt_sum_q_over_binding", "ejecta_kinetic_energy", "mtot_input",
-                   "allcont_bfestimindex", "nbfestim", "rho_tmin")
+                   "allcont_bfestimindex", "nbfestim", "rho_tmin", "xcom_elem_start", "xcom_energy", "xcom_sigma")
 
 _CELL_FIELDS = [
     ("rho", _F32P, np.float32), ("Te", _F32P, np.float32), ("TJ", _F32P, np.float32), ("TR", _F32P, np.float32),

@@ -1338,6 +1338,10 @@ const char *artis_amd_options_preset(void) {
   return "kilonova_expopac";
 #elif defined(ARTIS_PRESET_CLASSIC_EXPOPAC_THERM)
   return "classic_expopac_therm";
+#elif defined(ARTIS_PRESET_KILONOVA_GAMMA_GREY)
+  return "kilonova_gamma_grey";
+#elif defined(ARTIS_PRESET_CLASSIC_GAMMA_XCOM)
+  return "classic_gamma_xcom";
 #elif defined(ARTIS_PRESET_KILONOVA_GAMMA_BARNES)
   return "kilonova_gamma_barnes";
 #elif defined(ARTIS_PRESET_KILONOVA_GAMMA_WOLLAEGER)
@@ -1455,6 +1459,10 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if ((ARTIS_OPT_GAMMA_THERMALISATION_SCHEME == ARTIS_GAMMA_BARNES || ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME == ARTIS_PARTICLE_BARNES) &&
       !(h.mtot_input > 0. && h.ejecta_kinetic_energy > 0.)) {
     g_last_error = "this build uses a Barnes thermalisation efficiency: artis_model.mtot_input and ejecta_kinetic_energy are required";
+    return ARTIS_ERR_ARG;
+  }
+  if (ARTIS_OPT_USE_XCOM_GAMMAPHOTOION && (!e->M.xcom_elem_start || !e->M.xcom_energy || !e->M.xcom_sigma || !e->M.elem_meannucmass)) {
+    g_last_error = "this build has USE_XCOM_GAMMAPHOTOION: artis_model.xcom_elem_start / xcom_energy / xcom_sigma and elem_meannucmass are required";
     return ARTIS_ERR_ARG;
   }
   if (ARTIS_OPT_BFEST_SUBSET && !e->M.allcont_bfestimindex) {

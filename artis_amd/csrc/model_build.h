@@ -97,7 +97,10 @@ struct ModelOwned {
   X(elem_meannucmass, float, (m).nelements)    \
   X(ion_nt_sum_q_over_binding, double, (m).nions) \
   X(allcont_bfestimindex, int32_t, (m).nbfcontinua) \
-  X(rho_tmin, float, (m).npts_nonempty)
+  X(rho_tmin, float, (m).npts_nonempty) \
+  X(xcom_elem_start, int32_t, ((m).nelements + 1)) \
+  X(xcom_energy, double, (m).nxcom) \
+  X(xcom_sigma, double, (m).nxcom)
 
 // X(field, element type, element count) for every array pointer of DevCells
 #define ARTIS_CELL_ARRAYS(X, m)                                          \
@@ -310,6 +313,8 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.ejecta_kinetic_energy = m.ejecta_kinetic_energy; v.mtot_input = m.mtot_input;
   v.allcont_bfestimindex = m.allcont_bfestimindex;
   v.rho_tmin = m.rho_tmin;
+  v.xcom_elem_start = m.xcom_elem_start; v.xcom_energy = m.xcom_energy; v.xcom_sigma = m.xcom_sigma;
+  v.nxcom = m.xcom_elem_start ? m.xcom_elem_start[m.nelements] : 0;
   v.nbfestim = (m.allcont_bfestimindex && m.nbfestim > 0) ? m.nbfestim : m.nbfcontinua;
   return v;
 }

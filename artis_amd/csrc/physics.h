@@ -942,14 +942,16 @@ AHD void populate_corrphotoion(const Env &env, int c, int ul, int t) {
   env.K.bf_colion[o] = col_ion(M, T_e, cnne, element, ion, level, t, e_trans);
   env.K.bf_cooling[o] = lerp_or_last(M, M.bfcooling_coeffs, ul, t, T_e);
 }
+#if ARTIS_OPT_NT_ON || ARTIS_OPT_USE_XCOM_GAMMAPHOTOION
+AHD double elem_numberdens(const DevModel &M, const DevCells &C, int c, int element) {  // grid.cc:1693
+  return C.elem_massfracs[((int64_t)c * M.nelements) + element] / (double)M.elem_meannucmass[element] * C.rho[c];
+}
+#endif
 #if ARTIS_OPT_NT_ON
 // ---------------------------------------------------------------- non-thermal channels (nonthermal.cc)
 // The Spencer-Fano solution comes from the host (DevCells nt_*); the packet path only reads it.
 constexpr int NT_NAUGER = ARTIS_OPT_NT_MAX_AUGER_ELECTRONS + 1;
 constexpr double QE = 4.80325E-10;  // constants.h:31
-AHD double elem_numberdens(const DevModel &M, const DevCells &C, int c, int element) {  // grid.cc:1693
-  return C.elem_massfracs[((int64_t)c * M.nelements) + element] / (double)M.elem_meannucmass[element] * C.rho[c];
-}
 AHD int nt_maxupperion(const DevModel &M, int element, int lowerion) {  // nt_ionisation_maxupperion nonthermal.cc:2435
   const int nions = M.elem_nions[element];
   const int maxupper = lowerion + 1 + ARTIS_OPT_NT_MAX_AUGER_ELECTRONS;
@@ -2970,12 +2972,56 @@ AHD double meanf_sigma(double x) {  // gammapkt.h:68
   return 3 * SIGMA_T * (term0 + term1 + term2 + term3 + term4) / (8 * x);
 }
 AHD double chi_compton_cmf(const Env &env, int c, double nu_cmf) {  // gammapkt.cc:265
+  if (ARTIS_OPT_GAMMA_USE_KAPPA_GREY) return 0.;
   const double xx = HPLANCK * nu_cmf / ME / CLIGHT / CLIGHT;
   const double sigma_cmf = (xx < THOMSON_LIMIT) ? SIGMA_T : sigma_compton_partial(xx, 1 + (2 * xx));
   return sigma_cmf * env.C.nnetot[c];
 }
-AHD double chi_photo_electric_cmf(const Env &env, int c, double ffegrp, double nu_cmf) {  // gammapkt.cc:416 (Veigele fit)
+AHD double chi_photo_electric_cmf(const Env &env, int c, double ffegrp, double nu_cmf) {  // gammapkt.cc:416
   const double rho = env.C.rho[c];
+  if (ARTIS_OPT_GAMMA_USE_KAPPA_GREY) return ARTIS_OPT_GAMMA_KAPPA_GREY * rho;
+#if ARTIS_OPT_USE_XCOM_GAMMAPHOTOION
+  {  // gammapkt.cc:443-495: the tabulated XCOM cross sections of every element, linear in log10-log10
+    (void)ffegrp;
+    const DevModel &M = env.M;
+    const double hnu_over_1MeV = nu_cmf / NU_1MEV;
+    const double log10_hnu_over_1MeV = log10(hnu_over_1MeV);
+    double chi_cmf = 0.;
+    for (int e = 0; e < M.nelements; e++) {
+      const int s0 = M.xcom_elem_start[e], numb_energies = M.xcom_elem_start[e + 1] - s0;
+      if (numb_energies == 0) continue;
+      const double n_i = elem_numberdens(M, env.C, c, e);
+      if (n_i == 0) continue;
+      const double *E = M.xcom_energy + s0;
+      const double *S = M.xcom_sigma + s0;
+      int idx_above = -1;
+      for (int j = 0; j < numb_energies; j++) {
+        if (E[j] > hnu_over_1MeV) {
+          idx_above = j;
+          break;
+        }
+      }
+      if (idx_above == 0) {
+        chi_cmf += S[0] * n_i;
+        continue;
+      }
+      if (idx_above == -1) {
+        chi_cmf += S[numb_energies - 1] * n_i;
+        continue;
+      }
+      const int idx_below = idx_above - 1;
+      const double log10_E_above = log10(E[idx_above]);
+      const double log10_E_below = log10(E[idx_below]);
+      const double log10_sigma_below = log10(S[idx_below]);
+      const double log10_sigma_above = log10(S[idx_above]);
+      const double log10_sigma_interp =
+          log10_sigma_below + ((log10_sigma_above - log10_sigma_below) / (log10_E_above - log10_E_below) * (log10_hnu_over_1MeV - log10_E_below));
+      const double sigma_interp = pow(10., log10_sigma_interp);
+      chi_cmf += sigma_interp * n_i;
+    }
+    return chi_cmf;
+  }
+#endif
   const double hnu_over_100kev = nu_cmf / NU_100KEV;
   const double sigma_cmf_si = 1.16e-24 * pow(hnu_over_100kev, -3.13);
   const double sigma_cmf_fe = 25.7e-24 * pow(hnu_over_100kev, -3.0);
@@ -2989,6 +3035,7 @@ AHD double sigma_pair_prod_factor(double nu_cmf) {  // gammapkt.cc:501
   return 0.10063 * (hnu_over_1MeV - 1.022);
 }
 AHD double chi_pair_prod_cmf(const Env &env, int c, double ffegrp, double nu_cmf) {  // gammapkt.cc:516
+  if (ARTIS_OPT_GAMMA_USE_KAPPA_GREY) return 0.;
   const double rho = env.C.rho[c];
   if (nu_cmf <= NU_1P022MEV) return 0.;
   const double sigma_factor = sigma_pair_prod_factor(nu_cmf);
@@ -3001,6 +3048,7 @@ AHD double chi_pair_prod_cmf(const Env &env, int c, double ffegrp, double nu_cmf
 AHD double chi_cmf_loss_weighted(const Env &env, int c, double nu_cmf) {  // gammapkt.cc:548
   const double ffegrp = env.C.ffegrp[c];
   const double chi_pe = chi_photo_electric_cmf(env, c, ffegrp, nu_cmf);
+  if (ARTIS_OPT_GAMMA_USE_KAPPA_GREY) return chi_pe;  // every interaction deposits the whole packet, gammapkt.cc:553
   const double xx = HPLANCK * nu_cmf / ME / CLIGHT / CLIGHT;
   const double chi_pp = chi_pair_prod_cmf(env, c, ffegrp, nu_cmf);
   return ((meanf_sigma(xx) * env.C.nnetot[c]) + chi_pe + (chi_pp * (1. - (NU_1P022MEV / nu_cmf))));

@@ -129,6 +129,10 @@ struct DevModel {
   const int32_t *allcont_bfestimindex;
   int32_t nbfestim;
   const float *rho_tmin;  // [npts_nonempty] optional: column densities of the Wollaeger / Guttman gamma-ray schemes
+  // optional (USE_XCOM_GAMMAPHOTOION builds): XCOM photoionisation points of every element of the model
+  const int32_t *xcom_elem_start;  // [nelements + 1]
+  const double *xcom_energy, *xcom_sigma;
+  int32_t nxcom;
   const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
       *ion_coolingoffset, *ion_ncoolingterms;
   const double *level_epsilon;

@@ -62,6 +62,7 @@ OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0
                  "kilonova_wollaeger": (200, 500.0, 150000.0), "kilonova_expopac": (200, 500.0, 150000.0),
                  "kilonova_gammaproducts": (200, 500.0, 150000.0), "kilonova_gamma_barnes": (200, 500.0, 150000.0),
                  "kilonova_gamma_wollaeger": (200, 500.0, 150000.0), "kilonova_gamma_guttman": (200, 500.0, 150000.0),
+                 "kilonova_gamma_grey": (200, 500.0, 150000.0), "classic_gamma_xcom": (100, 3500.0, 140000.0),
                  "classic_expopac_therm": (100, 3500.0, 140000.0)}
 
 
@@ -652,6 +653,9 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     md["rho_tmin"] = (np.asarray(cells["rho"], dtype=np.float64) * (aux["t"] / grid["tmin"]) ** 3).astype(np.float32)  # grid::get_rho_tmin
     md["mtot_input"] = float(m_cell.sum())
     md["ejecta_kinetic_energy"] = float((0.5 * m_cell * aux["v"] ** 2).sum())
+    if options == "classic_gamma_xcom":
+        md.update(nonthermal_model_inputs(atomic))     # element masses for the number densities
+        md.update(xcom_tables(atomic))
     model = abi.Model(md)
     if "expopac" in options and host_expopac:
         cells.update(expansion_opacity_cellstate(cells, grid["npts_nonempty"], seed=seed + 400))
@@ -691,6 +695,26 @@ def expansion_opacity_cellstate(cells: dict, ncell: int, seed: int = 401) -> dic
     planck = 2 * H * nu_mid[None, :] ** 3 / CLIGHT ** 2 / np.expm1(np.minimum(x, 700.0))
     cum = np.cumsum((kappa.astype(np.float64) + 1e-3) * planck * (nu_upper - nu_lower)[None, :], axis=1)
     return dict(expansionopacities=kappa.ravel(), expansionopacity_planck_cumulative=cum.ravel())
+
+
+def xcom_tables(atomic: dict) -> dict:
+    """XCOM-like photoionisation cross sections per element of the model (gammapkt.cc:244: energy [MeV] rising, sigma [cm^2]):
+    sigma ~ Z^4.5 E^-3 with K-edge-like steps, 30-60 points from 1 keV to 100 MeV; the last element has no data."""
+    rng = np.random.default_rng(77)
+    start, en, sg = [0], [], []
+    elements = atomic["_elements"]
+    for k, (Z, _, _) in enumerate(elements):
+        if k == len(elements) - 1 and len(elements) > 1:
+            start.append(start[-1])
+            continue
+        n = int(rng.integers(30, 61))
+        E = np.sort(10 ** rng.uniform(-3.0, 2.0, n))
+        edge = 1e-5 * Z ** 2.2                                  # MeV
+        sigma = 3e-29 * Z ** 4.5 * E ** -3.0 * np.where(E > edge, 1.0, 0.12) + 1e-30
+        en.extend(E)
+        sg.extend(sigma)
+        start.append(start[-1] + n)
+    return dict(xcom_elem_start=np.array(start, dtype=np.int32), xcom_energy=np.array(en), xcom_sigma=np.array(sg))
 
 
 def nonthermal_model_inputs(atomic: dict) -> dict:

@@ -284,6 +284,14 @@ typedef struct artis_model {
   /* [npts_nonempty] grid::get_rho_tmin(mgi): the density at tmin, read by the Wollaeger and Guttman gamma-ray
    * thermalisation schemes (gammapkt.cc:819, :853) for the column density along a ray; NULL elsewhere */
   const float *rho_tmin;
+
+  /* XCOM photoionisation cross sections (gammapkt.cc:244-261 photoion_data, read from xcom_photoion_data.txt), per element
+   * of the model: element e has the points [xcom_elem_start[e], xcom_elem_start[e+1]) of xcom_energy [MeV, rising] and
+   * xcom_sigma [cm^2]; an element beyond the table or without data has none. Builds with USE_XCOM_GAMMAPHOTOION (which also
+   * read elem_meannucmass for the element number densities); NULL elsewhere. */
+  const int32_t *xcom_elem_start; /* [nelements + 1] */
+  const double *xcom_energy;
+  const double *xcom_sigma;
 } artis_model;
 
 /* ---- per-timestep cell state written by the reference's update_grid() ----- */

@@ -45,6 +45,18 @@
 #define ARTIS_PRESET_KILONOVA_LTE
 #define ARTIS_OPT_GAMMA_THERMALISATION_SCHEME 3
 #endif
+/* -DARTIS_PRESET_KILONOVA_GAMMA_GREY: gamma-ray transport with one grey absorption opacity (GAMMA_USE_KAPPA_GREY = 0.06 cm^2/g:
+ * no Compton scattering, no pair production, gammapkt.cc:266, :420, :517, :553).
+ * -DARTIS_PRESET_CLASSIC_GAMMA_XCOM: artisoptions_classic.h with USE_XCOM_GAMMAPHOTOION: the photoelectric opacity from the
+ * tabulated XCOM cross sections of every element, log-log interpolated (gammapkt.cc:443-495; artis_model.xcom_*). */
+#ifdef ARTIS_PRESET_KILONOVA_GAMMA_GREY
+#define ARTIS_PRESET_KILONOVA_LTE
+#define ARTIS_OPT_GAMMA_USE_KAPPA_GREY 1
+#define ARTIS_OPT_GAMMA_KAPPA_GREY 0.06
+#endif
+#ifdef ARTIS_PRESET_CLASSIC_GAMMA_XCOM
+#define ARTIS_OPT_USE_XCOM_GAMMAPHOTOION 1
+#endif
 /* -DARTIS_PRESET_KILONOVA_GAMMAPRODUCTS: TIMEDEPENDENTWITHGAMMAPRODUCTS (constants.h:86): a gamma-ray interaction hands its
  * energy to an electron / positron that thermalises with the local time-dependent scheme instead of depositing at once
  * (gammapkt.cc:404, :572, :630, :734, :925; update_packets.cc:174) */
@@ -257,8 +269,13 @@
 #endif
 #define ARTIS_OPT_VPKT_ON 0                         /* artisoptions_classic.h:50 */
 /* gamma packets: the classic choices (artisoptions_classic.h:144-150) are the ones built */
-#define ARTIS_OPT_USE_XCOM_GAMMAPHOTOION 0            /* Veigele fit for the photoelectric opacity */
-#define ARTIS_OPT_GAMMA_USE_KAPPA_GREY 0             /* std::nullopt in the reference: frequency-dependent transport */
+#ifndef ARTIS_OPT_USE_XCOM_GAMMAPHOTOION
+#define ARTIS_OPT_USE_XCOM_GAMMAPHOTOION 0            /* artisoptions_classic.h:144: Veigele fit for the photoelectric opacity */
+#endif
+#ifndef ARTIS_OPT_GAMMA_USE_KAPPA_GREY
+#define ARTIS_OPT_GAMMA_USE_KAPPA_GREY 0             /* :150 std::nullopt: frequency-dependent opacities */
+#define ARTIS_OPT_GAMMA_KAPPA_GREY 0.
+#endif
 /* GAMMA_THERMALISATION_SCHEME (artisoptions_classic.h:148), numbered like enum class GammaThermalisationScheme
  * (constants.h:81): 0 = FREQUENCYDEPENDENT (transport), 1 = BARNES, 2 = WOLLAEGER, 3 = GUTTMAN (gammapkt.cc:775-866) */
 #define ARTIS_GAMMA_FREQUENCYDEPENDENT 0

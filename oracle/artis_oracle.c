@@ -723,14 +723,16 @@ static double get_nnion(const Oracle *o, int c, int element, int ion) {
          o->cs->ion_partfuncts[((ptrdiff_t)c * o->m->nions) + uniqueion(o, element, ion)] /
          stat_weight(o, ionlevelstart(o, element, ion));
 }
-#if ARTIS_OPT_NT_ON
-/* ---- non-thermal channels (nonthermal.cc), read from the Spencer-Fano solution the host hands over ---- */
-#define QE 4.80325E-10 /* constants.h:31 */
-#define NT_NAUGER (ARTIS_OPT_NT_MAX_AUGER_ELECTRONS + 1)
+#if ARTIS_OPT_NT_ON || ARTIS_OPT_USE_XCOM_GAMMAPHOTOION
 /* grid::get_elem_numberdens grid.cc:1693 (float mass fraction / double(float mean weight) * float rho) */
 static double get_elem_numberdens(const Oracle *o, int c, int element) {
   return o->cs->elem_massfracs[((ptrdiff_t)c * o->m->nelements) + element] / (double)o->m->elem_meannucmass[element] * o->cs->rho[c];
 }
+#endif
+#if ARTIS_OPT_NT_ON
+/* ---- non-thermal channels (nonthermal.cc), read from the Spencer-Fano solution the host hands over ---- */
+#define QE 4.80325E-10 /* constants.h:31 */
+#define NT_NAUGER (ARTIS_OPT_NT_MAX_AUGER_ELECTRONS + 1)
 /* get_nnion_tot atomic.h:51 */
 static double get_nnion_tot(const Oracle *o, int c) {
   double nntot = 0.;
@@ -2561,6 +2563,7 @@ static double meanf_sigma(double x) {
 }
 /* get_chi_compton_cmf gammapkt.cc:265 */
 static double get_chi_compton_cmf(const Oracle *o, int c, double nu_cmf) {
+  if (ARTIS_OPT_GAMMA_USE_KAPPA_GREY) return 0.; /* gammapkt.cc:266 */
   const double xx = H_PLANCK * nu_cmf / ME / CLIGHT / CLIGHT;
   const double sigma_cmf = (xx < THOMSON_LIMIT) ? SIGMA_T : sigma_compton_partial(xx, 1 + (2 * xx));
   return sigma_cmf * o->cs->nnetot[c];
@@ -2568,6 +2571,52 @@ static double get_chi_compton_cmf(const Oracle *o, int c, double nu_cmf) {
 /* get_chi_photo_electric_cmf gammapkt.cc:416 (Veigele fit, no XCOM tables) */
 static double get_chi_photo_electric_cmf(const Oracle *o, int c, double ffegrp, double nu_cmf) {
   const double rho = o->cs->rho[c];
+  if (ARTIS_OPT_GAMMA_USE_KAPPA_GREY) return ARTIS_OPT_GAMMA_KAPPA_GREY * rho; /* gammapkt.cc:420 */
+#if ARTIS_OPT_USE_XCOM_GAMMAPHOTOION
+  { /* gammapkt.cc:443-495 */
+    (void)ffegrp;
+    const artis_model *m = o->m;
+    const double hnu_over_1MeV = nu_cmf / NU_1MEV;
+    const double log10_hnu_over_1MeV = log10(hnu_over_1MeV);
+    double chi_cmf = 0.;
+    for (int i = 0; i < m->nelements; i++) {
+      const int s0 = m->xcom_elem_start[i];
+      const int numb_energies = m->xcom_elem_start[i + 1] - s0; /* none beyond the table (Z > xcom_max_atomic_number) or without data */
+      if (numb_energies == 0) continue;
+      const double n_i = get_elem_numberdens(o, c, i);
+      if (n_i == 0) continue;
+      const double *energy = m->xcom_energy + s0;
+      const double *sigma_xcom = m->xcom_sigma + s0;
+      int idx_above = -1;
+      for (int j = 0; j < numb_energies; j++) {
+        if (energy[j] > hnu_over_1MeV) {
+          idx_above = j;
+          break;
+        }
+      }
+      if (idx_above == 0) {
+        chi_cmf += sigma_xcom[0] * n_i;
+        continue;
+      }
+      if (idx_above == -1) {
+        chi_cmf += sigma_xcom[numb_energies - 1] * n_i;
+        continue;
+      }
+      const int idx_below = idx_above - 1;
+      const double log10_E = log10_hnu_over_1MeV;
+      const double log10_E_above = log10(energy[idx_above]);
+      const double log10_E_below = log10(energy[idx_below]);
+      const double log10_sigma_below = log10(sigma_xcom[idx_below]);
+      const double log10_sigma_above = log10(sigma_xcom[idx_above]);
+      const double log10_sigma_interp =
+          log10_sigma_below + ((log10_sigma_above - log10_sigma_below) / (log10_E_above - log10_E_below) * (log10_E - log10_E_below));
+      const double sigma_interp = pow(10., log10_sigma_interp);
+      if (!(sigma_interp >= 0.)) ORACLE_FAIL((Oracle *)o, "XCOM: negative cross section");
+      chi_cmf += sigma_interp * n_i;
+    }
+    return chi_cmf;
+  }
+#endif
   const double hnu_over_100kev = nu_cmf / NU_100KEV;
   const double sigma_cmf_si = 1.16e-24 * pow(hnu_over_100kev, -3.13);
   const double sigma_cmf_fe = 25.7e-24 * pow(hnu_over_100kev, -3.0);
@@ -2583,6 +2632,7 @@ static double get_sigma_pair_prod_factor(double nu_cmf) {
 }
 /* get_chi_pair_prod_cmf gammapkt.cc:516 */
 static double get_chi_pair_prod_cmf(const Oracle *o, int c, double ffegrp, double nu_cmf) {
+  if (ARTIS_OPT_GAMMA_USE_KAPPA_GREY) return 0.; /* gammapkt.cc:517 */
   const double rho = o->cs->rho[c];
   if (nu_cmf <= NU_1P022MEV) return 0.;
   const double sigma_factor = get_sigma_pair_prod_factor(nu_cmf);
@@ -2598,6 +2648,7 @@ static inline double cell_ffegrp(const Oracle *o, int c) { return o->cs->ffegrp 
 static double get_chi_cmf_loss_weighted(const Oracle *o, int c, double nu_cmf) {
   const double ffegrp = cell_ffegrp(o, c);
   const double chi_photo_electric_cmf = get_chi_photo_electric_cmf(o, c, ffegrp, nu_cmf);
+  if (ARTIS_OPT_GAMMA_USE_KAPPA_GREY) return chi_photo_electric_cmf; /* gammapkt.cc:553 */
   const double xx = H_PLANCK * nu_cmf / ME / CLIGHT / CLIGHT;
   const double chi_pair_prod_cmf = get_chi_pair_prod_cmf(o, c, ffegrp, nu_cmf);
   return ((meanf_sigma(xx) * o->cs->nnetot[c]) + chi_photo_electric_cmf + (chi_pair_prod_cmf * (1. - (NU_1P022MEV / nu_cmf))));

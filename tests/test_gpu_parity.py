@@ -463,6 +463,19 @@ def test_engine_matches_oracle_parameterised_gamma_thermalisation(engine_mod, or
     eng.close()
 
 
+@pytest.mark.parametrize("options", ["kilonova_gamma_grey", "classic_gamma_xcom"])
+def test_engine_matches_oracle_gamma_opacity_options(engine_mod, oracle, options):
+    """the grey-opacity and XCOM gamma-ray builds (gammapkt.cc:266-553) against the oracle built alike"""
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", 8, abi.GRID_CARTESIAN3D, 0.0, 16000, kfrac=0.1, gfrac=0.7,
+                                                    pfrac=0.1, options=options)
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, options + ": HIP engine vs oracle")
+    parity.compare_stats(eb, ea, options + ": HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, options + ": HIP engine vs oracle")
+    assert eb.stats_dict()["NT_STAT_FROM_GAMMA"] > 1000 and eb.dep_estimator_gamma.sum() > 0
+    print(f"worst float rel diff {rep['worst_rel']:.3e}")
+    eng.close()
+
+
 def test_engine_matches_oracle_gamma_products(engine_mod, oracle):
     """the TIMEDEPENDENTWITHGAMMAPRODUCTS build (gammapkt.cc:404, :572, :630, :734, :925) against the oracle built alike"""
     P = "kilonova_gammaproducts"

@@ -421,3 +421,27 @@ def test_parameterised_gamma_thermalisation_bit_exact(oracle, options, gridtype,
     assert np.count_nonzero(pa["type"] == abi.TYPE_GAMMA) == 0              # no gamma packet is left to transport
     sc = dict(zip(abi.SCALAR_NAMES, ea.scalars))
     assert sc["gamma_dep_discrete"] > 0 and abs(ea.dep_estimator_gamma.sum() / sc["gamma_dep_discrete"] - 1) < 1e-12
+
+
+@pytest.mark.parametrize("options,gridtype,ncoord", [("kilonova_gamma_grey", abi.GRID_CARTESIAN3D, 8),
+                                                     ("classic_gamma_xcom", abi.GRID_CARTESIAN3D, 8),
+                                                     ("classic_gamma_xcom", abi.GRID_SPHERICAL1D, 16)])
+def test_gamma_opacity_options_bit_exact(oracle, options, gridtype, ncoord):
+    """GAMMA_USE_KAPPA_GREY (gammapkt.cc:266, :420, :517, :553: one grey absorption opacity, every interaction deposits the
+    packet) and USE_XCOM_GAMMAPHOTOION (:443-495: the photoelectric opacity summed over the elements from tabulated cross
+    sections, log-log interpolated, clamped beyond the table, elements without data skipped)."""
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options)
+    pk0 = synth.make_packets(model, aux, 4000, kpkt_fraction=0.1, gamma_fraction=0.7, pellet_fraction=0.1)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, options + ": kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, options + ": kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, options + ": kernel bodies vs oracle")
+    st = ea.stats_dict()
+    assert st["X_GAMMA_STEPS"] > 3000 and st["NT_STAT_FROM_GAMMA"] > 200 and ea.dep_estimator_gamma.sum() > 0
+    absorbed = pa[np.isin(pa["absorptiontype"], [-3, -4, -5])]
+    if "grey" in options:
+        assert np.all(absorbed["absorptiontype"] == -4)       # only the grey "photoelectric" channel exists
+    base = "kilonova_lte" if options.startswith("kilonova") else "classic"
+    pc, ec = pk0.copy(), abi.estimators_for(model, base)
+    oracle.update_packets(model, cs, ts, pc, ec, preset=base)
+    assert not np.array_equal(pc["type"], pa["type"]) or not np.array_equal(pc["prop_time"], pa["prop_time"])
