@@ -144,9 +144,11 @@ _MODEL_FIELDS = [
     ("allcont_bfestimindex", _I32P, np.int32), ("nbfestim", C.c_int32, None),
     ("rho_tmin", _F32P, np.float32),
     ("xcom_elem_start", _I32P, np.int32), ("xcom_energy", _F64P, np.float64), ("xcom_sigma", _F64P, np.float64),
+    ("detailed_lineindices", _I32P, np.int32), ("detailed_linecount", C.c_int32, None),
 ]
 _MODEL_OPTIONAL = ("elem_meannucmass", "ion_nt_sum_q_over_binding", "ejecta_kinetic_energy", "mtot_input",
-                   "allcont_bfestimindex", "nbfestim", "rho_tmin", "xcom_elem_start", "xcom_energy", "xcom_sigma")
+                   "allcont_bfestimindex", "nbfestim", "rho_tmin", "xcom_elem_start", "xcom_energy", "xcom_sigma",
+                   "detailed_lineindices", "detailed_linecount")
 
 _CELL_FIELDS = [
     ("rho", _F32P, np.float32), ("Te", _F32P, np.float32), ("TJ", _F32P, np.float32), ("TR", _F32P, np.float32),
@@ -166,17 +168,19 @@ _CELL_FIELDS = [
     ("nt_exc_ratecoeffperdeposition", _F64P, np.float64), ("nt_exc_alltransindex", _I32P, np.int32),
     ("nt_excitations_stored", C.c_int32, None),
     ("expansionopacities", _F32P, np.float32), ("expansionopacity_planck_cumulative", _F64P, np.float64),
+    ("Jb_lu_normed", _F64P, np.float64),
 ]
 EXPOPAC_NBINS = 1997
 _CELL_OPTIONAL = ("levelpops", "corrphotoioncoeff", "radfieldbin_W", "radfieldbin_T_R", "nt_frac_ionisation",
                   "nt_frac_excitation", "nt_deposition_rate_density", "nt_eff_ionpot", "nt_prob_num_auger",
                   "nt_ionenfrac_num_auger", "nt_exc_count", "nt_exc_frac_deposition", "nt_exc_ratecoeffperdeposition",
-                  "nt_exc_alltransindex", "nt_excitations_stored", "expansionopacities", "expansionopacity_planck_cumulative")
+                  "nt_exc_alltransindex", "nt_excitations_stored", "expansionopacities", "expansionopacity_planck_cumulative", "Jb_lu_normed")
 NT_NAUGER = 3  # NT_MAX_AUGER_ELECTRONS + 1
 RADFIELDBINCOUNT = 256
 # options presets with the multibin radiation field and the detailed bound-free estimators (artisoptions_nltenebular.h and
 # the three files that differ from it in constants): RADFIELDBINCOUNT of each
-NEBULAR_FAMILY = {"nltenebular": 256, "christinenonthermal": 64, "nltephotospheric": 256, "nltewithoutnonthermal": 512}
+NEBULAR_FAMILY = {"nltenebular": 256, "christinenonthermal": 64, "nltephotospheric": 256, "nltewithoutnonthermal": 512,
+                  "nltenebular_lineest": 256}
 
 
 class CModel(C.Structure):
@@ -197,7 +201,8 @@ class CEstimators(C.Structure):
                 ("gammaestimator", _F64P), ("bfheatingestimator", _F64P), ("stats", _I64P),
                 ("dep_estimator_gamma", _F64P), ("scalars", _F64P), ("dep_estimator_electron", _F64P),
                 ("dep_estimator_positron", _F64P), ("dep_estimator_alpha", _F64P),
-                ("radfieldbin_J", _F64P), ("radfieldbin_nuJ", _F64P), ("bfrate_raw", _F64P)]
+                ("radfieldbin_J", _F64P), ("radfieldbin_nuJ", _F64P), ("bfrate_raw", _F64P),
+                ("Jb_lu_raw", _F64P), ("Jb_lu_contribcount", _I64P)]
 
 
 def _as_ptr(arr: np.ndarray, ptype):
@@ -276,13 +281,17 @@ class Timestep:
 class Estimators:
     """Host estimator arrays (accumulated into by update_packets)."""
 
-    def __init__(self, npts_nonempty: int, nbfcontinua_ground: int, nbfcontinua: int = 0, nbins: int = RADFIELDBINCOUNT):
+    def __init__(self, npts_nonempty: int, nbfcontinua_ground: int, nbfcontinua: int = 0, nbins: int = RADFIELDBINCOUNT,
+                 ndetailedlines: int = 0):
         """nbfcontinua > 0: also the estimators of the nltenebular options (radiation-field bins, detailed bound-free;
         nbfcontinua = the number of bound-free estimators, nbins = RADFIELDBINCOUNT of the options preset)"""
         n, g = npts_nonempty, max(nbfcontinua_ground, 1)
         self.radfieldbin_J = np.zeros(n * nbins if nbfcontinua > 0 else 1)
         self.radfieldbin_nuJ = np.zeros(n * nbins if nbfcontinua > 0 else 1)
         self.bfrate_raw = np.zeros(n * nbfcontinua if nbfcontinua > 0 else 1)
+        self.Jb_lu_raw = np.zeros(max(n * ndetailedlines, 1))
+        self.Jb_lu_contribcount = np.zeros(max(n * ndetailedlines, 1), dtype=np.int64)
+        self.lineest = ndetailedlines > 0
         self.extended = nbfcontinua > 0
         self.J = np.zeros(n)
         self.nuJ = np.zeros(n)
@@ -305,7 +314,9 @@ class Estimators:
             _as_ptr(self.dep_estimator_alpha, _F64P),
             _as_ptr(self.radfieldbin_J, _F64P) if self.extended else None,
             _as_ptr(self.radfieldbin_nuJ, _F64P) if self.extended else None,
-            _as_ptr(self.bfrate_raw, _F64P) if self.extended else None)
+            _as_ptr(self.bfrate_raw, _F64P) if self.extended else None,
+            _as_ptr(self.Jb_lu_raw, _F64P) if self.lineest else None,
+            _as_ptr(self.Jb_lu_contribcount, _I64P) if self.lineest else None)
 
     def ref(self):
         return C.byref(self.c)
@@ -313,6 +324,8 @@ class Estimators:
     def arrays(self):
         ext = {"radfieldbin_J": self.radfieldbin_J, "radfieldbin_nuJ": self.radfieldbin_nuJ,
                "bfrate_raw": self.bfrate_raw} if self.extended else {}
+        if self.lineest:
+            ext = {**ext, "Jb_lu_raw": self.Jb_lu_raw, "Jb_lu_contribcount": self.Jb_lu_contribcount}
         return {**ext, "J": self.J, "nuJ": self.nuJ, "ffheatingestimator": self.ffheatingestimator,
                 "colheatingestimator": self.colheatingestimator, "gammaestimator": self.gammaestimator,
                 "bfheatingestimator": self.bfheatingestimator, "dep_estimator_gamma": self.dep_estimator_gamma,
@@ -328,7 +341,8 @@ def estimators_for(model, options: str = "classic") -> Estimators:
     if options not in NEBULAR_FAMILY:
         return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
     nest = model.d.get("nbfestim") or model["nbfcontinua"]
-    return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"], nest, NEBULAR_FAMILY[options])
+    nlines = (model.d.get("detailed_linecount") or 0) if options.endswith("_lineest") else 0
+    return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"], nest, NEBULAR_FAMILY[options], nlines)
 
 
 def packets_ptr(packets: np.ndarray):

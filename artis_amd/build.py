@@ -20,7 +20,7 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fno-slp-vectorize", "-ldl"]
 
 
-PRESETS = ("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal", "kilonova_barnes", "kilonova_wollaeger", "kilonova_gammaproducts",
+PRESETS = ("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal", "nltenebular_lineest", "kilonova_barnes", "kilonova_wollaeger", "kilonova_gammaproducts",
            "kilonova_gamma_barnes", "kilonova_gamma_wollaeger", "kilonova_gamma_guttman", "kilonova_gamma_grey", "classic_gamma_xcom",
            "kilonova_expopac", "classic_expopac_therm")  # options presets of include/artis_options.h (the reference's artisoptions_*.h)
 

@@ -1326,7 +1326,9 @@ extern "C" {
 const char *artis_amd_last_error(void) { return g_last_error.c_str(); }
 int artis_amd_abi_version(void) { return 3; }
 const char *artis_amd_options_preset(void) {
-#if defined(ARTIS_PRESET_CHRISTINENONTHERMAL)
+#if defined(ARTIS_PRESET_NLTENEBULAR_LINEEST)
+  return "nltenebular_lineest";
+#elif defined(ARTIS_PRESET_CHRISTINENONTHERMAL)
   return "christinenonthermal";
 #elif defined(ARTIS_PRESET_NLTEPHOTOSPHERIC)
   return "nltephotospheric";
@@ -1465,6 +1467,10 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
     g_last_error = "this build has USE_XCOM_GAMMAPHOTOION: artis_model.xcom_elem_start / xcom_energy / xcom_sigma and elem_meannucmass are required";
     return ARTIS_ERR_ARG;
   }
+  if (ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON && (!e->M.detailed_lineindices || h.detailed_linecount <= 0)) {
+    g_last_error = "this build has DETAILED_LINE_ESTIMATORS_ON: artis_model.detailed_lineindices / detailed_linecount are required";
+    return ARTIS_ERR_ARG;
+  }
   if (ARTIS_OPT_BFEST_SUBSET && !e->M.allcont_bfestimindex) {
     g_last_error = "this build keeps bound-free estimators for a subset of the continua: artis_model.allcont_bfestimindex / nbfestim are required";
     return ARTIS_ERR_ARG;
@@ -1524,7 +1530,8 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   // ... | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars | (radfieldbin_J | radfieldbin_nuJ) | (bfrate_raw)]
   const int64_t nbinest = ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON ? ncell * ARTIS_OPT_RADFIELDBINCOUNT : 0;
   const int64_t nbfest = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? ncell * (int64_t)h.nbfestim : 0;
-  e->est_ndoubles = ncell * 8 + 2 * ncell * g + ARTIS_NSCALARS + 2 * nbinest + nbfest;
+  const int64_t nlineest = ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON ? ncell * (int64_t)h.detailed_linecount : 0;
+  e->est_ndoubles = ncell * 8 + 2 * ncell * g + ARTIS_NSCALARS + 2 * nbinest + nbfest + 2 * nlineest;
   HIP_TRY(hipMalloc((void **)&e->d_est, sizeof(double) * (size_t)e->est_ndoubles));
   HIP_TRY(hipMemset(e->d_est, 0, sizeof(double) * (size_t)e->est_ndoubles));
   e->E.J = e->d_est;
@@ -1541,6 +1548,8 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   e->E.radfieldbin_J = nbinest ? e->E.scalars + ARTIS_NSCALARS : nullptr;
   e->E.radfieldbin_nuJ = nbinest ? e->E.radfieldbin_J + nbinest : nullptr;
   e->E.bfrate_raw = nbfest ? e->E.scalars + ARTIS_NSCALARS + 2 * nbinest : nullptr;
+  e->E.Jb_lu_raw = nlineest ? e->E.scalars + ARTIS_NSCALARS + 2 * nbinest + nbfest : nullptr;
+  e->E.Jb_lu_contribcount = nlineest ? e->E.Jb_lu_raw + nlineest : nullptr;
   HIP_TRY(hipMalloc((void **)&e->d_stats, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
@@ -1659,6 +1668,10 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
     return ARTIS_ERR_ARG;
   }
   e->expopac_own = false;
+  if (ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON && !e->C.Jb_lu_normed) {
+    g_last_error = "this build has DETAILED_LINE_ESTIMATORS_ON: artis_cellstate.Jb_lu_normed is required";
+    return ARTIS_ERR_ARG;
+  }
   if (ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION) {
     // the tables of calculate_expansion_opacities(): the host's, or (both NULL) made by the engine at cell-cache population
     const bool need_planck = ARTIS_OPT_RPKT_BB_THERMALISATION;
@@ -2098,6 +2111,12 @@ int artis_amd_estimators_download(artis_amd_engine *e, artis_estimators *est) {
       add(est->radfieldbin_nuJ, ext + nbinest, nbinest);
     }
     if (nbfest) add(est->bfrate_raw, ext + 2 * nbinest, nbfest);
+    const int64_t nlineest = ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON ? ncell * (int64_t)e->Mh.detailed_linecount : 0;
+    if (nlineest) {
+      add(est->Jb_lu_raw, ext + 2 * nbinest + nbfest, nlineest);
+      if (est->Jb_lu_contribcount)
+        for (int64_t i = 0; i < nlineest; i++) est->Jb_lu_contribcount[i] += (int64_t)ext[2 * nbinest + nbfest + nlineest + i];
+    }
   }
   if (est->stats) {
     unsigned long long st[ARTIS_NSTATS];

@@ -100,7 +100,8 @@ struct ModelOwned {
   X(rho_tmin, float, (m).npts_nonempty) \
   X(xcom_elem_start, int32_t, ((m).nelements + 1)) \
   X(xcom_energy, double, (m).nxcom) \
-  X(xcom_sigma, double, (m).nxcom)
+  X(xcom_sigma, double, (m).nxcom) \
+  X(detailed_lineindices, int32_t, (m).detailed_linecount)
 
 // X(field, element type, element count) for every array pointer of DevCells
 #define ARTIS_CELL_ARRAYS(X, m)                                          \
@@ -137,7 +138,8 @@ struct ModelOwned {
   X(nt_exc_ratecoeffperdeposition, double, ((int64_t)(m).npts_nonempty * (nt_stored)))              \
   X(nt_exc_alltransindex, int32_t, ((int64_t)(m).npts_nonempty * (nt_stored)))                      \
   X(expansionopacities, float, ((int64_t)(m).npts_nonempty * ARTIS_EXPOPAC_NBINS))                  \
-  X(expansionopacity_planck_cumulative, double, ((int64_t)(m).npts_nonempty * ARTIS_EXPOPAC_NBINS))
+  X(expansionopacity_planck_cumulative, double, ((int64_t)(m).npts_nonempty * ARTIS_EXPOPAC_NBINS)) \
+  X(Jb_lu_normed, double, ((int64_t)(m).npts_nonempty * (m).detailed_linecount))
 
 // X(field, element type, elements per cell) for every array of DevCache
 #define ARTIS_CACHE_ARRAYS(X, m)                                \
@@ -315,6 +317,8 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.rho_tmin = m.rho_tmin;
   v.xcom_elem_start = m.xcom_elem_start; v.xcom_energy = m.xcom_energy; v.xcom_sigma = m.xcom_sigma;
   v.nxcom = m.xcom_elem_start ? m.xcom_elem_start[m.nelements] : 0;
+  v.detailed_lineindices = m.detailed_lineindices;
+  v.detailed_linecount = m.detailed_lineindices ? m.detailed_linecount : 0;
   v.nbfestim = (m.allcont_bfestimindex && m.nbfestim > 0) ? m.nbfestim : m.nbfcontinua;
   return v;
 }
@@ -360,6 +364,7 @@ inline DevCells make_host_cells_view(const artis_cellstate &c) {
   v.nt_ionratecoeff = nullptr; v.nt_ionenrate_cum = nullptr;
   v.expansionopacities = c.expansionopacities;
   v.expansionopacity_planck_cumulative = c.expansionopacity_planck_cumulative;
+  v.Jb_lu_normed = c.Jb_lu_normed;
   return v;
 }
 

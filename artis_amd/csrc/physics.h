@@ -762,7 +762,32 @@ AHD double rad_deexc(double epsilon_trans, float A_ul, double gu, double gl, dou
   }
   return A_ul;
 }
-AHD double rad_exc(const Env &env, int c, double gu, double A, double epsilon_trans, double n_l, double n_u, double gl, double t) {  // macroatom.cc:611
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+// radfield::get_Jblueindex radfield.cc:695: place of the line among the detailed lines, -1 if it has no estimator
+AHD int jblueindex(const DevModel &M, int lineindex) {
+  int low = 0, high = M.detailed_linecount - 1;
+  while (low <= high) {
+    const int mid = low + ((high - low) / 2);
+    if (M.detailed_lineindices[mid] < lineindex) low = mid + 1;
+    else if (M.detailed_lineindices[mid] > lineindex) high = mid - 1;
+    else return mid;
+  }
+  return -1;
+}
+// radfield::update_lineestimator radfield.cc:773
+AHD void update_lineestimator(const Env &env, int c, int lineindex, double increment) {
+  const int jb = jblueindex(env.M, lineindex);
+  if (jb >= 0) {
+    const int64_t o = ((int64_t)c * env.M.detailed_linecount) + jb;
+    ARTIS_EST_ADD(&env.E.Jb_lu_raw[o], increment);
+    ARTIS_EST_ADD(&env.E.Jb_lu_contribcount[o], 1.);
+  }
+}
+#endif
+// alltransindex: only read by builds with detailed line estimators (macroatom.cc:628; globals::lte_iteration is false while
+// packets propagate)
+AHD double rad_exc(const Env &env, int c, double gu, double A, double epsilon_trans, double n_l, double n_u, double gl, double t,
+                   int alltransindex = -1) {  // macroatom.cc:611
   const double nu_trans = epsilon_trans / HPLANCK;
   const double B_ul = CLIGHTSQUAREDOVERTWOH / pow3(nu_trans) * A;
   const double B_lu = gu / gl * B_ul;
@@ -770,6 +795,12 @@ AHD double rad_exc(const Env &env, int c, double gu, double A, double epsilon_tr
   if (tau > 1e-100) {
     const double beta = 1.0 / tau * (-expm1(-tau));
     const double R_over_J = n_l > 0. ? (B_lu - (B_ul * n_u / n_l)) * beta : B_lu * beta;
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+    if (alltransindex >= 0) {
+      const int jb = jblueindex(env.M, env.M.alltrans_lineindex[alltransindex]);
+      if (jb >= 0) return R_over_J * env.C.Jb_lu_normed[((int64_t)c * env.M.detailed_linecount) + jb];  // get_Jb_lu radfield.cc:718
+    }
+#endif
     return R_over_J * radfield(env, nu_trans, c);
   }
   return 0.;
@@ -1094,7 +1125,7 @@ AHD MaTransTerms matrans_terms(const Env &env, int c, int ati) {
     r.i = i - r.lpk.ndown;
     const double e_trans = eps(M, tul) - e_cur;
     const double g_up = statw(M, tul);
-    const double R = rad_exc(env, c, g_up, M.alltrans_einstein_A[ati], e_trans, nnlevel, pops[tul], g_cur, env.S.mid);
+    const double R = rad_exc(env, c, g_up, M.alltrans_einstein_A[ati], e_trans, nnlevel, pops[tul], g_cur, env.S.mid, ati);
     const double Cc = col_exc(M, T_e, cnne, e_trans, g_up, g_cur, ati);
 #if ARTIS_OPT_NT_ON
     const double NT = nt_excitation_ratecoeff(env.C, c, ul - start, M.alltrans_targetlevelindex[ati], ati);  // macroatom.cc:133
@@ -1828,6 +1859,10 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
         ma.ion = ion;
         ma.level = lp.upper - lstart(M, element, ion);
         ma.activatingline = li;
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+        move_raw(px, py, pz, p.dx, p.dy, p.dz, prop_time, p.nu_rf, nu_cmf, p.e_rf, e_cmf, ldist);  // rpkt.cc:173-176
+        update_lineestimator(env, c, li, prop_time * CLIGHT * e_cmf / nu_cmf);
+#endif
         *next_trans_out = next_trans;
         *is_bb = true;
         result = dist + ldist;
@@ -1844,7 +1879,14 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
       pz += (p.dz * ldist);
       prop_time += ldist / CLIGHT_PROP;
       nu_cmf = p.nu_cmf + (dnu_on_dl * dist);
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+      e_cmf = nu_cmf * p.e_rf / p.nu_rf;  // consistent with the linearly approximated nu_cmf, rpkt.cc:199-203
+#else
       (void)e_cmf;
+#endif
+#endif
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+      update_lineestimator(env, c, li, prop_time * CLIGHT * e_cmf / nu_cmf);  // rpkt.cc:206
 #endif
     } else {
       *next_trans_out = next_trans - 1;

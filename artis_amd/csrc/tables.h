@@ -133,6 +133,9 @@ struct DevModel {
   const int32_t *xcom_elem_start;  // [nelements + 1]
   const double *xcom_energy, *xcom_sigma;
   int32_t nxcom;
+  // optional (DETAILED_LINE_ESTIMATORS_ON builds): the lines with their own intensity estimator, rising line index
+  const int32_t *detailed_lineindices;
+  int32_t detailed_linecount;
   const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
       *ion_coolingoffset, *ion_ncoolingterms;
   const double *level_epsilon;
@@ -198,6 +201,7 @@ struct DevCells {
   // [cell][ARTIS_EXPOPAC_NBINS] binned line opacity and its Planck-weighted running integral (expansion-opacity builds)
   const float *expansionopacities;
   const double *expansionopacity_planck_cumulative;
+  const double *Jb_lu_normed;  // [cell][detailed_linecount] normalised line intensities of the previous timestep
 };
 
 struct DevCache {
@@ -243,7 +247,8 @@ struct DevEst {
   double *scalars;              // [ARTIS_NSCALARS]
   // builds with the multibin radiation field / detailed bound-free estimators (else null)
   double *radfieldbin_J, *radfieldbin_nuJ;  // [cell][RADFIELDBINCOUNT] radfield.cc:745-790
-  double *bfrate_raw;                       // [cell][nbfcontinua] radfield.cc:215
+  double *bfrate_raw;                       // [cell][nbfestim] radfield.cc:215
+  double *Jb_lu_raw, *Jb_lu_contribcount;   // [cell][detailed_linecount] radfield.cc:773 (the count kept as f64: one block, one all-reduce)
 };
 
 // Packet population in HBM: three arrays of cache-line records, slot-major ("structure of lines").

@@ -58,6 +58,7 @@ def _ionpot_ev(Z: int, stage: int) -> float:
 OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0, 150000.0),
                  "nltenebular": (100, 1000.0, 30000.0), "christinenonthermal": (100, 3000.0, 140000.0),
                  "nltephotospheric": (100, 3500.0, 140000.0), "nltewithoutnonthermal": (200, 4000.0, 140000.0),
+                 "nltenebular_lineest": (100, 1000.0, 30000.0),
                  "kilonova_barnes": (200, 500.0, 150000.0),
                  "kilonova_wollaeger": (200, 500.0, 150000.0), "kilonova_expopac": (200, 500.0, 150000.0),
                  "kilonova_gammaproducts": (200, 500.0, 150000.0), "kilonova_gamma_barnes": (200, 500.0, 150000.0),
@@ -663,6 +664,18 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
         cells.update(nebular_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 200, nbins=abi.NEBULAR_FAMILY[options]))
         cells.update(nonthermal_cellstate(atomic, cells, grid["npts_nonempty"], seed=seed + 300))
         md.update(nonthermal_model_inputs(atomic))
+        if options == "nltenebular_lineest":
+            # radfield.cc detailed_lineindices: every seventh line has its own intensity estimator; the normalised
+            # intensities of the previous timestep scatter around the dilute blackbody
+            rng = np.random.default_rng(seed + 500)
+            idx = np.arange(3, atomic["nlines"], 7, dtype=np.int32)
+            nu = np.asarray(atomic["line_nu"], dtype=np.float64)[idx]
+            TR = np.asarray(cells["TR"], dtype=np.float64)[:, None]
+            Wd = np.asarray(cells["W"], dtype=np.float64)[:, None]
+            jb = Wd * 2 * H * nu[None, :] ** 3 / CLIGHT ** 2 / np.expm1(np.minimum(H * nu[None, :] / (KB * TR), 700.0))
+            jb *= rng.uniform(0.3, 3.0, jb.shape)
+            md.update(detailed_lineindices=idx, detailed_linecount=len(idx))
+            cells["Jb_lu_normed"] = jb.ravel()
         if options == "nltephotospheric":
             # LEVEL_HAS_BFEST (artisoptions_nltephotospheric_dynamic_ion_range.h:80): estimators for the lowest levels only;
             # globals::allcont.bfestimindex is the running count over the continua that have one (input.cc:932-947)

@@ -292,6 +292,11 @@ typedef struct artis_model {
   const int32_t *xcom_elem_start; /* [nelements + 1] */
   const double *xcom_energy;
   const double *xcom_sigma;
+
+  /* [detailed_linecount] radfield.cc detailed_lineindices: the lines with their own intensity estimator, rising line index
+   * (builds with DETAILED_LINE_ESTIMATORS_ON; NULL / 0 elsewhere) */
+  const int32_t *detailed_lineindices;
+  int32_t detailed_linecount;
 } artis_model;
 
 /* ---- per-timestep cell state written by the reference's update_grid() ----- */
@@ -353,6 +358,9 @@ typedef struct artis_cellstate {
    * Both NULL: the engine calculates them itself when it populates the cell cache. */
   const float *expansionopacities;
   const double *expansionopacity_planck_cumulative;
+  /* [npts_nonempty*detailed_linecount] radfield.cc prev_Jb_lu_normed[].value: the normalised line intensities of the previous
+   * timestep, what get_Jb_lu() returns (builds with DETAILED_LINE_ESTIMATORS_ON) */
+  const double *Jb_lu_normed;
 } artis_cellstate;
 
 typedef struct artis_timestep {
@@ -384,6 +392,10 @@ typedef struct artis_estimators {
   double *radfieldbin_J;
   double *radfieldbin_nuJ;
   double *bfrate_raw;
+  /* detailed line estimators Jb_lu_raw[][].value and .contribcount [npts_nonempty*detailed_linecount] (radfield.cc:773
+   * update_lineestimator). Builds with DETAILED_LINE_ESTIMATORS_ON; may be NULL. */
+  double *Jb_lu_raw;
+  int64_t *Jb_lu_contribcount;
 } artis_estimators;
 enum {
   ARTIS_SCALAR_GAMMA_DEP_DISCRETE = 0,   /* globals::timesteps[nts].gamma_dep_discrete gammapkt.cc:926 */

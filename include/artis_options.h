@@ -114,6 +114,14 @@
  * -DARTIS_PRESET_NLTEPHOTOSPHERIC      artisoptions_nltephotospheric_dynamic_ion_range.h (bound-free estimators for the NLTE
  *                                      levels only: LEVEL_HAS_BFEST :80, artis_model.allcont_bfestimindex)
  * -DARTIS_PRESET_NLTEWITHOUTNONTHERMAL artisoptions_nltewithoutnonthermal.h */
+/* -DARTIS_PRESET_NLTENEBULAR_LINEEST: artisoptions_nltenebular.h + DETAILED_LINE_ESTIMATORS_ON (:78, off in every options
+ * file of the reference): selected lines get their own intensity estimator, updated by every packet that redshifts
+ * through them (radfield.cc:773, rpkt.cc:173-207) and used instead of the binned field in the radiative excitation rate
+ * (macroatom.cc:628). artis_model.detailed_lineindices, artis_cellstate.Jb_lu_normed, artis_estimators.Jb_lu_*. */
+#ifdef ARTIS_PRESET_NLTENEBULAR_LINEEST
+#define ARTIS_PRESET_NLTENEBULAR
+#define ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON 1
+#endif
 #ifdef ARTIS_PRESET_CHRISTINENONTHERMAL
 #define ARTIS_PRESET_NLTENEBULAR
 #define ARTIS_OPT_MINTEMP 3000.                       /* artisoptions_christinenonthermal.h:48 */
@@ -257,7 +265,9 @@
 #define ARTIS_EXPOPAC_LAMBDAMAX 40000.
 #define ARTIS_EXPOPAC_DELTALAMBDA 20.
 #define ARTIS_EXPOPAC_NBINS 1997 /* (lambdamax - lambdamin) / deltalambda */
-#define ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON 0     /* artisoptions_classic.h:74 */
+#ifndef ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+#define ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON 0     /* artisoptions_classic.h:71 */
+#endif
 #ifndef ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
 #define ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON 0       /* artisoptions_classic.h:76 */
 #endif

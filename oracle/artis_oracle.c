@@ -963,8 +963,31 @@ static double rad_deexcitation_ratecoeff(double epsilon_trans, float A_ul, doubl
   return A_ul;
 }
 /* rad_excitation_ratecoeff macroatom.cc:611 */
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+/* radfield::get_Jblueindex radfield.cc:695 */
+static int get_Jblueindex(const Oracle *o, int lineindex) {
+  int low = 0, high = o->m->detailed_linecount - 1;
+  while (low <= high) {
+    const int mid = low + ((high - low) / 2);
+    if (o->m->detailed_lineindices[mid] < lineindex) low = mid + 1;
+    else if (o->m->detailed_lineindices[mid] > lineindex) high = mid - 1;
+    else return mid;
+  }
+  return -1;
+}
+/* radfield::update_lineestimator radfield.cc:773 */
+static void update_lineestimator(Oracle *o, int c, int lineindex, double increment) {
+  const int jblueindex = get_Jblueindex(o, lineindex);
+  if (jblueindex >= 0 && o->est.Jb_lu_raw) {
+    const ptrdiff_t k = ((ptrdiff_t)c * o->m->detailed_linecount) + jblueindex;
+    o->est.Jb_lu_raw[k] += increment;
+    if (o->est.Jb_lu_contribcount) o->est.Jb_lu_contribcount[k] += 1;
+  }
+}
+#endif
 static double rad_excitation_ratecoeff(const Oracle *o, int c, double upper_statweight, double einstein_A, double epsilon_trans,
-                                       double nnlevel_lower, double nnlevel_upper, double statweight_lower, double t_current) {
+                                       double nnlevel_lower, double nnlevel_upper, double statweight_lower, double t_current,
+                                       int alltransindex) {
   const double nu_trans = epsilon_trans / H_PLANCK;
   const double B_ul = CLIGHTSQUAREDOVERTWOH / pow3(nu_trans) * einstein_A;
   const double B_lu = upper_statweight / statweight_lower * B_ul;
@@ -972,6 +995,14 @@ static double rad_excitation_ratecoeff(const Oracle *o, int c, double upper_stat
   if (tau_sobolev > 1e-100) {
     const double beta = 1.0 / tau_sobolev * (-expm1(-tau_sobolev));
     const double R_over_J_nu = nnlevel_lower > 0. ? (B_lu - (B_ul * nnlevel_upper / nnlevel_lower)) * beta : B_lu * beta;
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+    { /* macroatom.cc:628 (globals::lte_iteration is false while packets propagate) */
+      const int jblueindex = get_Jblueindex(o, o->m->alltrans_lineindex[alltransindex]);
+      if (jblueindex >= 0) return R_over_J_nu * o->cs->Jb_lu_normed[((ptrdiff_t)c * o->m->detailed_linecount) + jblueindex]; /* get_Jb_lu */
+    }
+#else
+    (void)alltransindex;
+#endif
     return R_over_J_nu * radfield(o, nu_trans, c);
   }
   return 0.;
@@ -1102,7 +1133,7 @@ static void calculate_macroatom_transitionrates(Oracle *o, CellCache *cc, int c,
     const double epsilon_trans = epsilon(o, uul) - epsilon_current;
     const double upper_statweight = stat_weight(o, uul);
     const double R = rad_excitation_ratecoeff(o, c, upper_statweight, m->alltrans_einstein_A[ati], epsilon_trans, nnlevel,
-                                              cc->levelpops[uul], statweight, t_mid);
+                                              cc->levelpops[uul], statweight, t_mid, ati);
     const double C = col_excitation_ratecoeff(o, T_e, clumpednne, epsilon_trans, upper_statweight, statweight, ati);
 #if ARTIS_OPT_NT_ON
     const double NT = nt_excitation_ratecoeff(o, c, level, upper, ati);
@@ -1543,6 +1574,10 @@ static double get_possible_event(Oracle *o, const CellCache *cc, const artis_pac
         mastate->ion = ion;
         mastate->level = upper;
         mastate->activatingline = lineindex;
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+        move_pkt_withtime_raw(pos, pkt->dir, &prop_time, pkt->nu_rf, &nu_cmf, pkt->e_rf, &e_cmf, ldist); /* rpkt.cc:173-176 */
+        update_lineestimator(o, (int)(cc - o->cache), lineindex, prop_time * CLIGHT * e_cmf / nu_cmf);
+#endif
         *next_trans_out = next_trans;
         *is_bb = 1;
         return dist + ldist;
@@ -1558,7 +1593,14 @@ static double get_possible_event(Oracle *o, const CellCache *cc, const artis_pac
       pos[2] += (pkt->dir[2] * ldist);
       prop_time += ldist / CLIGHT_PROP;
       nu_cmf = pkt->nu_cmf + (dnu_on_dl * dist);
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+      e_cmf = nu_cmf * pkt->e_rf / pkt->nu_rf; /* rpkt.cc:199-203 */
+#else
       (void)e_cmf;
+#endif
+#endif
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+      update_lineestimator(o, (int)(cc - o->cache), lineindex, prop_time * CLIGHT * e_cmf / nu_cmf); /* rpkt.cc:206 */
 #endif
     } else {
       *next_trans_out = next_trans - 1;

@@ -15,7 +15,7 @@ from artis_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
-PRESETS = ("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal", "kilonova_barnes", "kilonova_wollaeger", "kilonova_gammaproducts",
+PRESETS = ("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal", "nltenebular_lineest", "kilonova_barnes", "kilonova_wollaeger", "kilonova_gammaproducts",
            "kilonova_gamma_barnes", "kilonova_gamma_wollaeger", "kilonova_gamma_guttman", "kilonova_gamma_grey", "classic_gamma_xcom",
            "kilonova_expopac", "classic_expopac_therm")  # options presets of include/artis_options.h the oracle is built for
 

@@ -25,6 +25,7 @@ struct Emu {
   std::vector<double> ws;
   std::vector<int32_t> ws_gi, ws_n;
   std::vector<double> nt_ionratecoeff, nt_ionenrate_cum;
+  std::vector<double> lineest_count;  // Jb_lu contribution counts as f64
   std::vector<float> expopac_kappa;
   std::vector<double> expopac_planck;
   bool expopac_own = false;
@@ -48,6 +49,11 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
     e.env.E.radfieldbin_J = est->radfieldbin_J;
     e.env.E.radfieldbin_nuJ = est->radfieldbin_nuJ;
     e.env.E.bfrate_raw = est->bfrate_raw;
+    e.env.E.Jb_lu_raw = est->Jb_lu_raw;
+    if (est->Jb_lu_raw) {  // counted as f64 here (like the engine's block) and handed back as integers at the end
+      e.lineest_count.assign((size_t)((int64_t)m->npts_nonempty * m->detailed_linecount) + 1, 0.);
+      e.env.E.Jb_lu_contribcount = e.lineest_count.data();
+    }
   }
   const DevModel &M = e.env.M;
   const int64_t ncell = M.npts_nonempty;
@@ -215,6 +221,8 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
   if (est && est->stats)
     for (int i = 0; i < ARTIS_NSTATS; i++) est->stats[i] += (int64_t)e.stats[i];
   if (est && est->stats) est->stats[ARTIS_STAT_UPDATECELL] += e.env.M.npts_nonempty;
+  if (est && est->Jb_lu_contribcount)
+    for (size_t i = 0; i + 1 < e.lineest_count.size(); i++) est->Jb_lu_contribcount[i] += (int64_t)e.lineest_count[i];
   return e.err;
 }
 

@@ -548,6 +548,20 @@ def test_engine_matches_oracle_remaining_option_files(engine_mod, oracle, option
     eng.close()
 
 
+def test_engine_matches_oracle_detailed_line_estimators(engine_mod, oracle):
+    """the DETAILED_LINE_ESTIMATORS_ON build (radfield.cc:773, rpkt.cc:173-207, macroatom.cc:628) against the oracle built
+    alike: contribution counts identical, intensities to the estimator tolerance"""
+    P = "nltenebular_lineest"
+    model, cs, ts, eng, pa, pb, ea, eb = _run_case(engine_mod, oracle, "small", 8, abi.GRID_CARTESIAN3D, 0.0, 16000, kfrac=0.15, gfrac=0.1,
+                                                    pfrac=0.2, options=P, bkw=dict(nts=13))
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, P + ": HIP engine vs oracle")
+    parity.compare_stats(eb, ea, P + ": HIP engine vs oracle", same_libm=False)
+    assert np.array_equal(ea.Jb_lu_contribcount, eb.Jb_lu_contribcount) and eb.Jb_lu_contribcount.sum() > 5000
+    parity.compare_estimators(eb, ea, EST_RTOL, P + ": HIP engine vs oracle")
+    print(f"worst float rel diff {rep['worst_rel']:.3e}")
+    eng.close()
+
+
 def test_deferred_bound_free_estimators_equal_in_place(engine_mod, monkeypatch):
     """nltenebular build: the detailed bound-free estimator updates recorded by k_rpkt and added by k_bfest_dense (a wave
     per update) against the same build adding them in place (ARTIS_AMD_BFDEFER=0): identical packets and counters, the

@@ -445,3 +445,29 @@ def test_gamma_opacity_options_bit_exact(oracle, options, gridtype, ncoord):
     pc, ec = pk0.copy(), abi.estimators_for(model, base)
     oracle.update_packets(model, cs, ts, pc, ec, preset=base)
     assert not np.array_equal(pc["type"], pa["type"]) or not np.array_equal(pc["prop_time"], pa["prop_time"])
+
+
+@pytest.mark.parametrize("gridtype,ncoord", [(abi.GRID_CARTESIAN3D, 8), (abi.GRID_SPHERICAL1D, 16)])
+def test_detailed_line_estimators_bit_exact(oracle, gridtype, ncoord):
+    """DETAILED_LINE_ESTIMATORS_ON on top of the nltenebular options: every packet that redshifts through a line with its
+    own estimator adds prop_time * c * e_cmf / nu_cmf to it and counts itself (radfield.cc:773; rpkt.cc:173-207: also at
+    the line it is absorbed in), and the radiative excitation rate of such a line uses the host's normalised intensity
+    instead of the binned field (macroatom.cc:628)."""
+    P = "nltenebular_lineest"
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=P, nts=13)
+    pk0 = synth.make_packets(model, aux, 4000, kpkt_fraction=0.15, gamma_fraction=0.1, pellet_fraction=0.2)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=P)
+    parity.compare_packets(pb, pa, 0.0, P + ": kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, P + ": kernel bodies vs oracle")
+    assert np.array_equal(ea.Jb_lu_contribcount, eb.Jb_lu_contribcount)
+    parity.compare_estimators(eb, ea, 1e-11, P + ": kernel bodies vs oracle")
+    nl = model["detailed_linecount"]
+    assert ea.Jb_lu_raw.size == model["npts_nonempty"] * nl and ea.Jb_lu_contribcount.sum() > 1000
+    assert np.array_equal(ea.Jb_lu_raw > 0, ea.Jb_lu_contribcount > 0)
+    # a seventh of the lines have an estimator; a line counts when the packet reaches it (not when the walk ends before it)
+    frac = ea.Jb_lu_contribcount.sum() / ea.stats_dict()["X_LINES_VISITED"]
+    assert 0.01 < frac < 0.3
+    # the host's line intensities matter: the same input through the plain nltenebular build gives another history
+    pc, ec = pk0.copy(), abi.estimators_for(model, "nltenebular")
+    oracle.update_packets(model, cs, ts, pc, ec, preset="nltenebular")
+    assert not np.array_equal(pc["nu_cmf"], pa["nu_cmf"])
