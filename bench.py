@@ -17,8 +17,9 @@ the count comes from the engine's own event counters and is identical to the CPU
 `python bench.py --gpus N` (N > 1) without a torchrun environment starts the N ranks itself: it spawns
 `python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a child process BEFORE anything
 touches the GPU and exits with the child's code; under torchrun (RANK/WORLD_SIZE set) it runs as one rank.
-`--options kilonova_lte` runs the same workload on the engine built with the packet-path options of
-artisoptions_kilonova_lte.h (libartis_amd_kilonova_lte.so; BASELINE.json configs[3]).
+`--options <preset>` runs the same workload on the engine built for another options file of the reference (one library
+per artisoptions_*.h: kilonova_lte = BASELINE.json configs[3], nltenebular = configs[4], ...); the headline line is the
+classic build.
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the definitions of roofline and cpu_baseline).
 """
