@@ -562,10 +562,11 @@ def test_engine_matches_oracle_detailed_line_estimators(engine_mod, oracle):
     eng.close()
 
 
-def test_deferred_bound_free_estimators_equal_in_place(engine_mod, monkeypatch):
+def test_deferred_bound_free_estimators_equal_in_place(engine_mod, oracle, monkeypatch):
     """nltenebular build: the detailed bound-free estimator updates recorded by k_rpkt and added by k_bfest_dense (a wave
     per update) against the same build adding them in place (ARTIS_AMD_BFDEFER=0): identical packets and counters, the
-    estimators to the accuracy of float summation order. w7 atomic data (1851 continua: windows longer than a wave)."""
+    estimators to the accuracy of float summation order. w7 atomic data (1851 continua: windows longer than a wave); and
+    both against the oracle on the bench's atomic data."""
     P = "nltenebular"
     model, cs, ts, aux = synth.build("w7", ncoord=10, options=P, nts=13)
     pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.05)
@@ -583,6 +584,11 @@ def test_deferred_bound_free_estimators_equal_in_place(engine_mod, monkeypatch):
     assert np.array_equal(e1.stats, e0.stats)
     assert np.count_nonzero(e0.bfrate_raw) > 10000 and np.array_equal(e1.bfrate_raw != 0, e0.bfrate_raw != 0)
     parity.compare_estimators(e1, e0, 1e-11, "deferred vs in-place bound-free estimators")
+    pa, ea = pk0.copy(), abi.estimators_for(model, P)
+    oracle.update_packets(model, cs, ts, pa, ea, preset=P)
+    parity.compare_packets(p1, pa, FLOAT_RTOL, "nltenebular, w7 atomic data: HIP engine vs oracle")
+    parity.compare_stats(e1, ea, "nltenebular, w7 atomic data: HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(e1, ea, EST_RTOL, "nltenebular, w7 atomic data: HIP engine vs oracle")
 
 
 @pytest.mark.parametrize("options", ["classic", "kilonova_lte", "nltenebular"])
