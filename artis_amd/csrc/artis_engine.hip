@@ -162,14 +162,14 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {  // 128 VGPR wi
       const int seglen = t.isdown ? t.lpk.ndown : t.lpk.nup;
       if (t.isdown) {
         rec[marec_rad(t.lpk.ndown, t.lpk.nup) + t.i] = s0;
-        rec[marec_down + t.i] = s2;
+        rec[marec_sum(marec_down, t.i)] = s2;
         if (t.i == seglen - 1) {
           rec[marec_rates + ARTIS_MA_ACTION_RADDEEXC] = s0;
           rec[marec_rates + ARTIS_MA_ACTION_COLDEEXC] = s1;
           rec[marec_rates + ARTIS_MA_ACTION_INTERNALDOWNSAME] = s2;
         }
       } else {
-        rec[marec_up(t.lpk.ndown) + t.i] = s0;
+        rec[marec_sum(marec_up(t.lpk.ndown), t.i)] = s0;
         env.K.collexc_cum[((int64_t)c * env.M.nupcum) + env.M.level_upcum_start[t.ul] + t.i] = t.kterm;
         if (t.i == seglen - 1) rec[marec_rates + ARTIS_MA_ACTION_INTERNALUPSAME] = s0;
       }

@@ -337,9 +337,9 @@ inline void unpack_macache_row(const DevModel &hostview, const artis_model &m, c
       double *blk = matrans + m.level_matransblock_start[ul];
       for (int i = 0; i < lp.ndown; i++) {
         blk[i] = rec[marec_rad(lp.ndown, lp.nup) + i];
-        blk[lp.ndown + i] = rec[marec_down + i];
+        blk[lp.ndown + i] = rec[marec_sum(marec_down, i)];
       }
-      for (int i = 0; i < lp.nup; i++) blk[2 * lp.ndown + i] = rec[marec_up(lp.ndown) + i];
+      for (int i = 0; i < lp.nup; i++) blk[2 * lp.ndown + i] = rec[marec_sum(marec_up(lp.ndown), i)];
     }
   }
 }

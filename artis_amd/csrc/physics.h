@@ -1147,10 +1147,10 @@ AHD void populate_matrans(const Env &env, int c, int ati) {
   double *rec = env.K.macache + ((int64_t)c * M.nmacache) + t.lpk.rec_off;
   if (t.isdown) {
     rec[marec_rad(t.lpk.ndown, t.lpk.nup) + t.i] = t.v0;
-    rec[marec_tgt(t.lpk.ndown, t.lpk.nup) + t.i] = t.v1;
-    rec[marec_down + t.i] = t.v2;
+    rec[marec_tgt(marec_down, t.i)] = t.v1;
+    rec[marec_sum(marec_down, t.i)] = t.v2;
   } else {
-    rec[marec_up(t.lpk.ndown) + t.i] = t.v0;
+    rec[marec_sum(marec_up(t.lpk.ndown), t.i)] = t.v0;
     env.K.collexc_cum[((int64_t)c * M.nupcum) + M.level_upcum_start[t.ul] + t.i] = t.kterm;
   }
 }
@@ -1161,25 +1161,23 @@ AHD void populate_macroatom_sums(const Env &env, int c, int ul) {
   const LevelPack lpk = M.level_pack[ul];
   double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
   double *rates = rec + marec_rates;
-  double *blk_down = rec + marec_down;
-  double *blk_up = rec + marec_up(lpk.ndown);
   double *blk_rad = rec + marec_rad(lpk.ndown, lpk.nup);
-  const double *parked = rec + marec_tgt(lpk.ndown, lpk.nup);
   double s_down_same = 0., s_raddeexc = 0., s_coldeexc = 0.;
   for (int i = 0; i < lpk.ndown; i++) {
     s_raddeexc += blk_rad[i];
-    s_coldeexc += parked[i];
-    s_down_same += blk_down[i];
+    s_coldeexc += rec[marec_tgt(marec_down, i)];  // parked there by populate_matrans()
+    s_down_same += rec[marec_sum(marec_down, i)];
     blk_rad[i] = s_raddeexc;
-    blk_down[i] = s_down_same;
+    rec[marec_sum(marec_down, i)] = s_down_same;
   }
   rates[ARTIS_MA_ACTION_RADDEEXC] = s_raddeexc;
   rates[ARTIS_MA_ACTION_COLDEEXC] = s_coldeexc;
   rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = s_down_same;
   double s_up_same = 0.;
+  const int up = marec_up(lpk.ndown);
   for (int ii = 0; ii < lpk.nup; ii++) {
-    s_up_same += blk_up[ii];
-    blk_up[ii] = s_up_same;
+    s_up_same += rec[marec_sum(up, ii)];
+    rec[marec_sum(up, ii)] = s_up_same;
   }
   rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s_up_same;
 }
@@ -1196,9 +1194,6 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   const LevelPack lpk = M.level_pack[ul];
   double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
   double *rates = rec + marec_rates;
-  double *blk_down = rec + marec_down;                        // cumulative internal-down-same
-  double *blk_up = rec + marec_up(lpk.ndown);                 // cumulative internal-up-same
-  double *blk_rad = rec + marec_rad(lpk.ndown, lpk.nup);      // cumulative radiative de-excitation
   // (the record's header and transition targets are written by populate_hotfill(), once the cell's hot levels are known)
   const double t_mid = env.S.mid;
   const float T_e = env.C.Te[c];
@@ -1311,11 +1306,16 @@ AHD void populate_hotfill(const Env &env, int c, int ul) {
   const int16_t *off = env.K.hotoff + ((int64_t)c * M.nlevels);
   double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
   *(MaHeader *)rec = MaHeader{(int16_t)lpk.ndown, (int16_t)lpk.nup, ul, lpk.alltrans_startdown, off[ul], 0};
-  MaTarget *tgt = (MaTarget *)(rec + marec_tgt(lpk.ndown, lpk.nup));
+  MaTarget *tgt = (MaTarget *)rec;
   const int ntrans = lpk.ndown + lpk.nup;
+  tgt[marec_tgt0] = tgt[marec_tgt0 + 1] = MaTarget{0};
   for (int i = 0; i < ntrans; i++) {
     const int tl = M.alltrans_targetlevelindex[lpk.alltrans_startdown + i];
-    tgt[i] = matgt_pack(M.level_pack[start + tl], tl);
+    const MaTarget tg = matgt_pack(M.level_pack[start + tl], tl);
+    const bool down = i < lpk.ndown;
+    const int j = down ? i : i - lpk.ndown;
+    tgt[marec_tgt(down ? marec_down : marec_up(lpk.ndown), j)] = tg;
+    if (j == 0) tgt[marec_tgt0 + (down ? 0 : 1)] = tg;
   }
   if (off[ul] >= 0) {
     double *dst = env.K.hotblk + ((int64_t)c * HOT_DOUBLES) + ((int)off[ul] * MAREC_ALIGN);
@@ -2358,11 +2358,12 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
 // element > v, at most n. Eight independent reads per round, issued without bounds checks as four 16-byte loads (a
 // block is 16-byte aligned and reading past its end stays inside the row, tables.h); entries at or beyond n are never
 // counted. Measured alternatives, all slower on MI355X: bisection (dependent reads), reads clamped to the last element.
+// STRIDE: doubles between the starts of consecutive groups of 8 sums (8: contiguous; MAREC_LINE: a direction's lines).
+template <int STRIDE = 8>
 AHD int ma_search(const double *a, int n, double v) {
   int idx = 0;
-  for (int base = 0; base < n; base += 8) {
-    const D2 q0 = *(const D2 *)(a + base), q1 = *(const D2 *)(a + base + 2), q2 = *(const D2 *)(a + base + 4),
-             q3 = *(const D2 *)(a + base + 6);
+  for (int base = 0; base < n; base += 8, a += STRIDE) {
+    const D2 q0 = *(const D2 *)(a), q1 = *(const D2 *)(a + 2), q2 = *(const D2 *)(a + 4), q3 = *(const D2 *)(a + 6);
     const double x[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
     int cnt = 0;
 #pragma unroll
@@ -2441,11 +2442,11 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
     // macroatom.cc:433-447 and 536-550: one search for both directions, so that a wave runs it once
     const int ndown = k.nd;
     const int nsel = down ? ndown : k.nu;
-    const int first = down ? 0 : ndown;                       // first target of the direction
-    const double *sums = rec + (down ? marec_down : marec_up(ndown));
+    const int base = down ? marec_down : marec_up(ndown);      // the direction's lines (sums + targets)
     const double targetval = rng_uniform(p) * rate_sel;
-    const int ti = ma_search(sums, nsel - 1, targetval);
-    const uint64_t tg = ((const MaTarget *)(rec + marec_tgt(ndown, k.nu)))[first + ti].bits;
+    const int ti = ma_search<MAREC_LINE>(rec + base, nsel - 1, targetval);
+    // the first transition's target is also in line 0: a direction with one transition reads nothing else
+    const uint64_t tg = ((const MaTarget *)rec)[ti == 0 ? marec_tgt0 + (down ? 0 : 1) : marec_tgt(base, ti)].bits;
     p.ma_level = (int)((tg >> 20) & 0xFFFF);
     k.rec = (int)(tg & 0xFFFFF) * MAREC_ALIGN;
     k.nd = (int)((tg >> 36) & 0x3FFF);
@@ -2471,7 +2472,7 @@ AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double
     const int lineindex = M.alltrans_lineindex[hd.alltrans_startdown + dti];
     if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
     const int ul = hd.ul;
-    const uint64_t tg = ((const MaTarget *)(rec + marec_tgt(ndown, hd.nup)))[dti].bits;
+    const uint64_t tg = ((const MaTarget *)rec)[marec_tgt(marec_down, dti)].bits;
     const int lul = (ul - p.ma_level) + (int)((tg >> 20) & 0xFFFF);
     const double e_trans = eps(M, ul) - eps(M, lul);
     const double oldnucmf = p.nu_cmf;

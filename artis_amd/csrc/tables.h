@@ -48,17 +48,19 @@ struct alignas(32) ContPack {
 // Macro-atom record of one (cell, level), 128-byte aligned and SELF-CONTAINED: one transition of the walk
 // (macroatom.cc:385-577) reads this record and nothing else -- no level table, no transition table -- so the chain of
 // dependent reads per transition is record -> cumulative sums -> target, all inside a few adjacent cache lines.
-// In doubles:
-//   [0..1]                 MaHeader (16 B): ndown, nup, unique level index, alltrans_startdown, place in the hot block
-//   [2..10]                the 9 process rates              (alllevels_maprocessrates, globals.h:286)
-//   [marec_down ..)        cumulative internal-down-same    (allmacroatomictransitions block 2, macroatom.cc:44)
-//   [marec_up(ndown) ..)   cumulative internal-up-same      (block 3, macroatom.cc:51)
-//   [marec_rad(..) ..)     cumulative radiative deexc.      (block 1, macroatom.cc:58)
-//   [marec_tgt(..) ..)     MaTarget (8 B) of every transition, down targets then up targets: the target level and the
-//                          offset of ITS record in the cell's row (static data, repeated per cell so that it sits next to
-//                          the sums that select it)
-// Every block starts 16-byte aligned (counts rounded up to even); a search may read up to 7 doubles past a block's end
-// (it never uses them), which stays inside the row (+ MAREC_SLACK at the end of the allocation).
+// The unit of the layout is the 128-byte line: a transition touches line 0 and one line of its direction. In doubles:
+//   line 0   [0..1]        MaHeader (16 B): ndown, nup, unique level index, alltrans_startdown, place in the hot block
+//            [2..10]       the 9 process rates              (alllevels_maprocessrates, globals.h:286)
+//            [12], [13]    copies of the MaTarget of the first downward and of the first upward transition (a direction
+//                          with one transition, a third of all searches, reads no other line)
+//   then one line per 8 transitions of a direction, downward lines first (marec_down), then upward (marec_up(ndown)):
+//            [0..8)        cumulative internal-down-same / internal-up-same (allmacroatomictransitions blocks 2 and 3,
+//                          macroatom.cc:44, :51) of transitions 8b .. 8b+7
+//            [8..16)       their MaTarget (8 B each): the target level and the offset of ITS record in the cell's row
+//                          (static data, repeated per cell so that it sits in the line of the sums that select it)
+//   [marec_rad(..) ..)     cumulative radiative deexc.      (block 1, macroatom.cc:58), contiguous (read once per walk)
+// A search reads whole lines of sums (entries beyond the count are never used); the rad block may be read up to 7 doubles
+// past its end, which stays inside the row (+ MAREC_SLACK at the end of the allocation).
 //
 // HOT BLOCK. A walk spends ~90 % of its transitions in a few dozen levels of its cell. At population time the records of
 // the cell's hottest levels (by level population x total rate, i.e. the flow through the level) are copied, bit for bit,
@@ -86,11 +88,16 @@ constexpr int HOT_DOUBLES = ARTIS_HOT_DOUBLES;
 constexpr int MAREC_ALIGN = 16;  // doubles
 constexpr int marec_even(int n) { return (n + 1) & ~1; }
 constexpr int marec_rates = 2;
-constexpr int marec_down = 12;
-constexpr int marec_up(int ndown) { return marec_down + marec_even(ndown); }
-constexpr int marec_rad(int ndown, int nup) { return marec_up(ndown) + marec_even(nup); }
-constexpr int marec_tgt(int ndown, int nup) { return marec_rad(ndown, nup) + marec_even(ndown); }
-constexpr int marec_size(int ndown, int nup) { return marec_tgt(ndown, nup) + ndown + nup; }
+constexpr int marec_tgt0 = 12;   // [12] first downward target, [13] first upward target
+constexpr int MAREC_LINE = 16;   // doubles per line of a direction: 8 sums, 8 targets
+constexpr int marec_lines(int n) { return (n + 7) >> 3; }
+constexpr int marec_down = 16;
+constexpr int marec_up(int ndown) { return marec_down + (marec_lines(ndown) * MAREC_LINE); }
+constexpr int marec_rad(int ndown, int nup) { return marec_up(ndown) + (marec_lines(nup) * MAREC_LINE); }
+constexpr int marec_size(int ndown, int nup) { return marec_rad(ndown, nup) + marec_even(ndown); }
+// entry i of a direction whose lines begin at `base`: its cumulative sum, its target
+constexpr int marec_sum(int base, int i) { return base + ((i >> 3) * MAREC_LINE) + (i & 7); }
+constexpr int marec_tgt(int base, int i) { return marec_sum(base, i) + 8; }
 constexpr int MAREC_SLACK = 16;  // doubles past the last row that a padded search may touch
 
 struct alignas(16) D2 {

@@ -324,6 +324,7 @@ def main():
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                          "kernels": per_kernel},
         }
+        bd.update(ma_transitions=int(S("X_MA_JUMPS")), kpkt_steps=int(S("X_KPKT_STEPS")), rpkt_steps=int(S("X_RPKT_STEPS")))
         out["kernel_breakdown_last_step"] = bd
         if os.environ.get("ARTIS_BENCH_VERBOSE"):
             print({abi.STAT_NAMES[i]: int(stats[i]) for i in range(abi.NSTATS) if stats[i]}, file=sys.stderr)
