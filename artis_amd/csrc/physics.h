@@ -1317,6 +1317,9 @@ AHD void populate_hotfill(const Env &env, int c, int ul) {
     tgt[marec_tgt(down ? marec_down : marec_up(lpk.ndown), j)] = tg;
     if (j == 0) tgt[marec_tgt0 + (down ? 0 : 1)] = tg;
   }
+  // the sum slots after each direction's last entry: +inf, so that ma_search_lines() needs no bounds checks
+  for (int j = lpk.ndown; j < marec_lines(lpk.ndown) * 8; j++) rec[marec_sum(marec_down, j)] = __builtin_inf();
+  for (int j = lpk.nup; j < marec_lines(lpk.nup) * 8; j++) rec[marec_sum(marec_up(lpk.ndown), j)] = __builtin_inf();
   if (off[ul] >= 0) {
     double *dst = env.K.hotblk + ((int64_t)c * HOT_DOUBLES) + ((int)off[ul] * MAREC_ALIGN);
     const int n = marec_units(lpk) * MAREC_ALIGN;
@@ -2358,11 +2361,9 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
 // element > v, at most n. Eight independent reads per round, issued without bounds checks as four 16-byte loads (a
 // block is 16-byte aligned and reading past its end stays inside the row, tables.h); entries at or beyond n are never
 // counted. Measured alternatives, all slower on MI355X: bisection (dependent reads), reads clamped to the last element.
-// STRIDE: doubles between the starts of consecutive groups of 8 sums (8: contiguous; MAREC_LINE: a direction's lines).
-template <int STRIDE = 8>
 AHD int ma_search(const double *a, int n, double v) {
   int idx = 0;
-  for (int base = 0; base < n; base += 8, a += STRIDE) {
+  for (int base = 0; base < n; base += 8, a += 8) {
     const D2 q0 = *(const D2 *)(a), q1 = *(const D2 *)(a + 2), q2 = *(const D2 *)(a + 4), q3 = *(const D2 *)(a + 6);
     const double x[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
     int cnt = 0;
@@ -2372,6 +2373,23 @@ AHD int ma_search(const double *a, int n, double v) {
     if (cnt < 8) break;
   }
   return idx;
+}
+
+// The same over the first n sums of a direction's lines (tables.h). The slots after a direction's last sum hold +inf
+// (populate_hotfill), so no entry needs a bounds check; the direction's last sum itself (entry n, never searched by the
+// reference: it is the whole rate, >= v) can only be counted when v rounds up to it, hence the final clamp.
+AHD int ma_search_lines(const double *a, int n, double v) {
+  int idx = 0;
+  for (int base = 0; base < n; base += 8, a += MAREC_LINE) {
+    const D2 q0 = *(const D2 *)(a), q1 = *(const D2 *)(a + 2), q2 = *(const D2 *)(a + 4), q3 = *(const D2 *)(a + 6);
+    const double x[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) cnt += (x[k] <= v) ? 1 : 0;
+    idx += cnt;
+    if (cnt < 8) break;
+  }
+  return idx < n ? idx : n;
 }
 
 // one iteration of the loop of do_macroatom(), macroatom.cc:385-577. ma_prepare() finds the record of the packet's
@@ -2433,9 +2451,6 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
 #pragma unroll
   for (int i = 0; i < MA_N; i++) action += (cum[i] <= randomrate) ? 1 : 0;  // cum is non-decreasing
   if (action > MA_N - 1) action = MA_N - 1;
-  double rate_sel = r[0];  // rates[action] without dynamic indexing
-#pragma unroll
-  for (int i = 1; i < MA_N; i++) rate_sel = (action == i) ? r[i] : rate_sel;
   k.njumps++;  // stats::increment(INTERACTIONS) macroatom.cc:430 and the engine's transition counter: ma_flush_stats()
   const bool down = (action == ARTIS_MA_ACTION_INTERNALDOWNSAME);
   if (down || action == ARTIS_MA_ACTION_INTERNALUPSAME) {
@@ -2443,8 +2458,8 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
     const int ndown = k.nd;
     const int nsel = down ? ndown : k.nu;
     const int base = down ? marec_down : marec_up(ndown);      // the direction's lines (sums + targets)
-    const double targetval = rng_uniform(p) * rate_sel;
-    const int ti = ma_search<MAREC_LINE>(rec + base, nsel - 1, targetval);
+    const double targetval = rng_uniform(p) * (down ? r[ARTIS_MA_ACTION_INTERNALDOWNSAME] : r[ARTIS_MA_ACTION_INTERNALUPSAME]);
+    const int ti = ma_search_lines(rec + base, nsel - 1, targetval);
     // the first transition's target is also in line 0: a direction with one transition reads nothing else
     const uint64_t tg = ((const MaTarget *)rec)[ti == 0 ? marec_tgt0 + (down ? 0 : 1) : marec_tgt(base, ti)].bits;
     p.ma_level = (int)((tg >> 20) & 0xFFFF);
@@ -2455,7 +2470,7 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
     k.hot = HOT ? (int)env.K.hotoff[((int64_t)k.c * env.M.nlevels) + (k.start + p.ma_level)] : -1;
     return -1;
   }
-  *rate_out = rate_sel;
+  *rate_out = rec[marec_rates + action];  // once per walk: not worth a select chain in the loop
   return action;
 }
 AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double *rec, int action, double rate_sel) {
