@@ -77,6 +77,25 @@ typedef unsigned long long stat_t;
 #define PROF_MARK(env, slot) ((void)0)
 #endif
 
+// -DARTIS_PROFILE_MA (device only): wave clocks of the stages of one macro-atom transition (ma_jump_internal) into the
+// stats slots 59..62, wave-rounds into 63: rates read | process drawn | direction searched | target read. Each read
+// stage ends in an explicit wait, so the stage's clocks are its memory latency as the wave sees it.
+#if defined(ARTIS_PROFILE_MA) && defined(__HIP_DEVICE_COMPILE__)
+#define MA_PROF_BEGIN() long long ma_prof_t = clock64()
+#define MA_PROF_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MA_PROF_MARK(env, slot)                                                                \
+  do {                                                                                         \
+    const long long prof_now = clock64();                                                      \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1)                         \
+      atomicAdd(&(env).stats[(slot)], (stat_t)(prof_now - ma_prof_t));                         \
+    ma_prof_t = prof_now;                                                                      \
+  } while (0)
+#else
+#define MA_PROF_BEGIN() ((void)0)
+#define MA_PROF_WAIT() ((void)0)
+#define MA_PROF_MARK(env, slot) ((void)0)
+#endif
+
 AHD double pow2(double x) { return x * x; }
 AHD double pow3(double x) { return x * x * x; }
 AHD double dmin(double a, double b) { return (b < a) ? b : a; }
@@ -2429,8 +2448,12 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
   // std::partial_sum macroatom.cc:425 and index_upperbound sn3d.h:85 over the 9 cumulative rates, kept in
   // registers (statically indexed): action = number of cumulative values <= randomrate, clamped to the last one
   double r[MA_N];
+  MA_PROF_BEGIN();
+  MA_PROF_MARK(env, 63);  // (clocks between the marks themselves: the cost of one mark)
   {
     const D2 q0 = *(const D2 *)(rec + 2), q1 = *(const D2 *)(rec + 4), q2 = *(const D2 *)(rec + 6), q3 = *(const D2 *)(rec + 8);
+    MA_PROF_WAIT();
+    MA_PROF_MARK(env, 59);
     r[0] = q0.x; r[1] = q0.y; r[2] = q1.x; r[3] = q1.y; r[4] = q2.x; r[5] = q2.y; r[6] = q3.x; r[7] = q3.y;
     // MA_ACTION_INTERNALUPHIGHERNT: only NT_ON puts anything there (macroatom.cc:171); adding the 0 leaves cum[8] = cum[7]
     r[8] = ARTIS_OPT_NT_ON ? rec[10] : 0.;
@@ -2459,9 +2482,13 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
     const int nsel = down ? ndown : k.nu;
     const int base = down ? marec_down : marec_up(ndown);      // the direction's lines (sums + targets)
     const double targetval = rng_uniform(p) * (down ? r[ARTIS_MA_ACTION_INTERNALDOWNSAME] : r[ARTIS_MA_ACTION_INTERNALUPSAME]);
+    MA_PROF_MARK(env, 60);
     const int ti = ma_search_lines(rec + base, nsel - 1, targetval);
+    MA_PROF_MARK(env, 61);
     // the first transition's target is also in line 0: a direction with one transition reads nothing else
     const uint64_t tg = ((const MaTarget *)rec)[ti == 0 ? marec_tgt0 + (down ? 0 : 1) : marec_tgt(base, ti)].bits;
+    MA_PROF_WAIT();
+    MA_PROF_MARK(env, 62);
     p.ma_level = (int)((tg >> 20) & 0xFFFF);
     k.rec = (int)(tg & 0xFFFFF) * MAREC_ALIGN;
     k.nd = (int)((tg >> 36) & 0x3FFF);
