@@ -181,12 +181,10 @@ AHD uint32_t rng_next(Pkt &p) {
   p.s3 = rotl32(p.s3, 11U);
   return result;
 }
-AHD float rng_uniform(Pkt &p) {
-  while (true) {
-    const float z = (float)(rng_next(p) >> 8U) * 0x1.0p-24F;
-    if (z != 1.) return z;
-  }
-}
+// random.h:49 rng_uniform() redraws while the value is 1. It never is: the 24-bit integer is at most 2^24 - 1, exact as a
+// float, and the product with 2^-24 is exact, so the largest value is 1 - 2^-24. Without the (dead) loop a draw is
+// straight-line code that the compiler can schedule under the latency of loads in flight.
+AHD float rng_uniform(Pkt &p) { return (float)(rng_next(p) >> 8U) * 0x1.0p-24F; }
 AHD float rng_uniform_pos(Pkt &p) {
   while (true) {
     const float z = rng_uniform(p);
