@@ -491,6 +491,41 @@ __global__ void __launch_bounds__(BLOCK) k_sort_scatter(const int32_t *list, con
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i < n) out[atomicAdd(&offsets[keys[i]], 1)] = list[i];
 }
+// The same two steps for FEW keys (1D and 2D models, small 3D grids: a few hundred cells). With one global atomic per
+// entry the entries of a cell serialise on its counter (measured on a 6^3 grid with 1e7 packets: 7 ms per sort kernel,
+// 36 % of the GPU time of a step, against 0.2 ms on the 50^3 grid). Here a workgroup counts its contiguous chunk of the
+// list in LDS and touches each global counter once.
+constexpr int SORT_LDS_KEYS = 8192;
+constexpr int SORT_LDS_GRID = 2048;
+__global__ void __launch_bounds__(BLOCK) k_sort_hist_lds(const int32_t *keys, int32_t n, int32_t *hist, int32_t nkeys) {
+  __shared__ int32_t h[SORT_LDS_KEYS];
+  for (int k = threadIdx.x; k < nkeys; k += BLOCK) h[k] = 0;
+  __syncthreads();
+  const int64_t chunk = ((int64_t)n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = chunk * blockIdx.x, hi = (lo + chunk < n) ? lo + chunk : n;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += BLOCK) atomicAdd(&h[keys[i]], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < nkeys; k += BLOCK)
+    if (h[k] != 0) atomicAdd(&hist[k], h[k]);
+}
+__global__ void __launch_bounds__(BLOCK) k_sort_scatter_lds(const int32_t *list, const int32_t *keys, int32_t n, int32_t *offsets, int32_t *out,
+                                                            int32_t nkeys) {
+  __shared__ int32_t h[SORT_LDS_KEYS];
+  for (int k = threadIdx.x; k < nkeys; k += BLOCK) h[k] = 0;
+  __syncthreads();
+  const int64_t chunk = ((int64_t)n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = chunk * blockIdx.x, hi = (lo + chunk < n) ? lo + chunk : n;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += BLOCK) atomicAdd(&h[keys[i]], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < nkeys; k += BLOCK)  // the workgroup's range of each key's output
+    if (h[k] != 0) h[k] = atomicAdd(&offsets[k], h[k]);
+  __syncthreads();
+  for (int64_t i = lo + threadIdx.x; i < hi; i += BLOCK) out[atomicAdd(&h[keys[i]], 1)] = list[i];
+}
+inline int sort_lds_grid(int64_t n) {
+  const int64_t b = (n + BLOCK - 1) / BLOCK;
+  return (int)(b < SORT_LDS_GRID ? b : SORT_LDS_GRID);
+}
 
 // ------------------------------------------------------------------ the propagation kernels
 // They are PERSISTENT, work-pulling kernels: a lane that has finished with its packet (budget used up, packet handed
@@ -1143,6 +1178,11 @@ struct artis_amd_engine {
   bool sort_lists = true;
   bool sort_nu = true;
   bool sort_ma = true;
+  // lists with more entries per cell of the tile than this are not sorted (sort_by_key); measured crossovers with 1e7
+  // packets: r-packet lists between 6^3 and 12^3 cells (46 000 / 5 800 per cell), thermal lists between 20^3 and 30^3
+  // (1 250 / 370 per cell). ARTIS_AMD_SORT_MAXPC_R / _T.
+  int sort_maxpc_r = 20000;
+  int sort_maxpc_t = 600;
   // one list chunk per wave instead of one per XCD (artis_engine.hip pull): measured on MI355X, 1e7 packets: k_rpkt -4 %
   // (a wave's lanes share continuum windows and line ranges), k_thermal +30 % (every wave then has its own cells in
   // flight and the L2 working set of macro-atom records triples)
@@ -1578,6 +1618,8 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_R")) e->sort_maxpc_r = std::max(1, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_T")) e->sort_maxpc_t = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_R")) e->wave_chunks_r = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_T")) e->wave_chunks_t = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_CUCHUNKS_T")) e->cu_chunks_t = std::atoi(b) != 0;
@@ -1827,12 +1869,18 @@ int artis_amd_packets_upload(artis_amd_engine *e, const artis_packet *packets, i
       hipStream_t s = nullptr;
       hipLaunchKernelGGL(k_aos_cellkeys, dim3(nblocks(npackets)), dim3(BLOCK), 0, s, e->d_aos, npackets, nkeys, ident, keys);
       HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(nkeys + 1), s));
-      hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n32)), dim3(BLOCK), 0, s, keys, n32, e->d_hist);
+      if (nkeys <= SORT_LDS_KEYS)
+        hipLaunchKernelGGL(k_sort_hist_lds, dim3(sort_lds_grid(n32)), dim3(BLOCK), 0, s, keys, n32, e->d_hist, nkeys);
+      else
+        hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n32)), dim3(BLOCK), 0, s, keys, n32, e->d_hist);
       const int ntiles = (nkeys + SCAN_TILE - 1) / SCAN_TILE;
       hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
       hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, e->d_tiles, ntiles);
       hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
-      hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n32)), dim3(BLOCK), 0, s, ident, keys, n32, e->d_hist, e->d_perm);
+      if (nkeys <= SORT_LDS_KEYS)
+        hipLaunchKernelGGL(k_sort_scatter_lds, dim3(sort_lds_grid(n32)), dim3(BLOCK), 0, s, ident, keys, n32, e->d_hist, e->d_perm, nkeys);
+      else
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n32)), dim3(BLOCK), 0, s, ident, keys, n32, e->d_hist, e->d_perm);
       e->use_perm = true;
     }
     hipLaunchKernelGGL(k_aos_to_rec, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->d_aos, e->P, e->use_perm ? e->d_perm : nullptr);
@@ -1882,17 +1930,30 @@ int artis_amd_packets_restore(artis_amd_engine *e) {
 
 namespace {
 // counting sort of list[0..n) by its entries' keys into e->d_sorted; *out = the list to launch on
-int sort_by_key(artis_amd_engine *e, hipStream_t s, const int32_t *list, const int32_t *keys, int32_t n, const int32_t **out, int nbins) {
+// max_per_cell: a list with more entries per cell than this stays in the order it was appended in. A cell-sorted list puts
+// every lane that is running on an XCD into the same few cells when the cells are few and full (1D / 2D models, small
+// grids): their reads then collide on the same cache lines (measured on 6^3 cells with 1e7 packets: mean L1->L2 read
+// latency 937 clocks against 190 on the 50^3 grid, the L1 stalled on pending lines 4x as long, k_thermal 1192 ms sorted
+// against 736 ms unsorted), while the locality the sort buys is not needed because the cells' tables fit in the caches.
+int sort_by_key(artis_amd_engine *e, hipStream_t s, const int32_t *list, const int32_t *keys, int32_t n, const int32_t **out, int nbins,
+                int64_t ncells, int max_per_cell) {
   *out = list;
   if (!e->sort_lists || n < 2 * BLOCK) return ARTIS_OK;
+  if ((int64_t)n > (int64_t)max_per_cell * (ncells > 0 ? ncells : 1)) return ARTIS_OK;
   const int32_t nkeys = e->Mh.ngrid * nbins;
   HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(nkeys + 1), s));
-  hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n)), dim3(BLOCK), 0, s, keys, n, e->d_hist);
+  if (nkeys <= SORT_LDS_KEYS)
+    hipLaunchKernelGGL(k_sort_hist_lds, dim3(sort_lds_grid(n)), dim3(BLOCK), 0, s, keys, n, e->d_hist, nkeys);
+  else
+    hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n)), dim3(BLOCK), 0, s, keys, n, e->d_hist);
   const int ntiles = (nkeys + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
   hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, e->d_tiles, ntiles);
   hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, keys, n, e->d_hist, e->d_sorted);
+  if (nkeys <= SORT_LDS_KEYS)
+    hipLaunchKernelGGL(k_sort_scatter_lds, dim3(sort_lds_grid(n)), dim3(BLOCK), 0, s, list, keys, n, e->d_hist, e->d_sorted, nkeys);
+  else
+    hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, keys, n, e->d_hist, e->d_sorted);
   *out = e->d_sorted;
   return ARTIS_OK;
 }
@@ -1990,7 +2051,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       const Lists next = lists_for(kind);
       const int32_t *lst = e->d_lists[kind][cur[kind]];
       if (kind == NEXT_RPKT || kind == NEXT_GAMMA || (kind == NEXT_MA && e->sort_ma)) {
-        rc = sort_by_key(e, s, e->d_lists[kind][cur[kind]], e->d_keys[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? r_nubins : 1);
+        rc = sort_by_key(e, s, e->d_lists[kind][cur[kind]], e->d_keys[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? r_nubins : 1,
+                         hi - lo, kind == NEXT_MA ? e->sort_maxpc_t : e->sort_maxpc_r);
         if (rc != ARTIS_OK) return rc;
       }
       // the kernel starts with an empty current list of its own kind: everything it keeps goes to the alternate list

@@ -386,6 +386,35 @@ def test_device_runs_are_deterministic_and_idempotent(engine_mod):
     eng.close()
 
 
+@pytest.mark.parametrize("gridtype,ncoord", [(abi.GRID_SPHERICAL1D, 12), (abi.GRID_CARTESIAN3D, 6)])
+def test_work_list_order_does_not_change_packets(engine_mod, oracle, monkeypatch, gridtype, ncoord):
+    """The work lists are counting-sorted by cell (few cells: the LDS form of the sort kernels) unless they hold more
+    entries per cell than a threshold (few, full cells: 1D models). Never sorted, always sorted and the default policy
+    (here: r-packet lists sorted, thermal lists not) give the same packets and counters, and the oracle's."""
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype)
+    pk0 = synth.make_packets(model, aux, 60000, kpkt_fraction=0.2)
+    outs = []
+    for maxpc in (None, "1", "1000000000"):
+        for v in ("ARTIS_AMD_SORT_MAXPC_R", "ARTIS_AMD_SORT_MAXPC_T"):
+            if maxpc is None:
+                monkeypatch.delenv(v, raising=False)
+            else:
+                monkeypatch.setenv(v, maxpc)
+        eng = engine_mod.Engine(model)
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, "classic")
+        eng.update_packets(p, e)
+        eng.close()
+        outs.append((p, e))
+    for p, e in outs[1:]:
+        parity.compare_packets(p, outs[0][0], 0.0, "work-list order")
+        parity.compare_stats(e, outs[0][1], "work-list order")
+        parity.compare_estimators(e, outs[0][1], 1e-11, "work-list order")
+    pa, ea = pk0[:6000].copy(), abi.estimators_for(model, "classic")
+    oracle.update_packets(model, cs, ts, pa, ea)
+    parity.compare_packets(outs[0][0][:6000], pa, FLOAT_RTOL, "default list policy vs oracle")
+
+
 def test_budget_independence_on_device(engine_mod, monkeypatch):
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
     pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.3)

@@ -10,7 +10,7 @@ import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["ARTIS_AMD_SO"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scratch", "libprof.so")
 from artis_amd import abi, synth, engine
-model, cs, ts, aux = synth.build("w7", ncoord=50)
+model, cs, ts, aux = synth.build("w7", ncoord=int(sys.argv[1]) if len(sys.argv) > 1 else 50)
 pk = synth.make_packets(model, aux, 10000000, kpkt_fraction=0.02)
 est = abi.estimators_for(model, "classic")
 eng = engine.Engine(model)
