@@ -632,12 +632,29 @@ inline int chunks_for(int64_t n, int nwaves) {
 // ground-continuum index; 32 B per continuum) is copied into LDS once per workgroup and every read of it in the opacity
 // sum (rpkt.cc:721, two of the ~five reads per continuum visited) is a ds_read that does not touch the vector L1.
 constexpr int CONT_LDS_MAX = 2048;  // continua (64 KB per workgroup, two workgroups per CU)
+// LDS accumulators of per-cell estimators for models with few cells (physics.h Env::cellest_lds)
+constexpr int RPKT_CELLEST_CAP = 512;      // cells: 3 estimators x 8 B x 512 = 12 KB per workgroup (next to the 64 KB above)
+constexpr int THERMAL_CELLEST_CAP = 4096;  // cells: 32 KB per workgroup, four workgroups per CU
+__device__ inline void cellest_begin(Env &env, double *lds, int n, int nkinds, int nthreads) {
+  for (int i = threadIdx.x; i < n * nkinds; i += nthreads) lds[i] = 0.;
+  env.cellest_lds = lds;
+  env.cellest_n = n;
+}
+// call after a __syncthreads(): the workgroup's sums of one estimator go to the global array
+__device__ inline void cellest_flush(const Env &env, int kind, double *global_array, int nthreads) {
+  for (int c = threadIdx.x; c < env.cellest_n; c += nthreads) {
+    const double v = env.cellest_lds[(kind * env.cellest_n) + c];
+    if (v != 0.) unsafeAtomicAdd(&global_array[c], v);
+  }
+}
 template <bool CONT_LDS>
 __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const int32_t *list, int32_t n, Lists next,
                                                                    unsigned long long *gstats, int budget, int32_t *cursors, int nchunks) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
+  __shared__ double lds_cellest[3 * RPKT_CELLEST_CAP];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  cellest_begin(env, lds_cellest, env.cellest_n_r, 3, BLOCK);
   if (CONT_LDS) {
     const D2 *src = (const D2 *)env.M.cont_pack;
     D2 *dst = (D2 *)lds_cont;
@@ -707,6 +724,9 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
     append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
   }
   __syncthreads();
+  cellest_flush(env, CELLEST_J, env.E.J, BLOCK);
+  cellest_flush(env, CELLEST_NUJ, env.E.nuJ, BLOCK);
+  cellest_flush(env, CELLEST_FFHEAT, env.E.ffheatingestimator, BLOCK);
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
@@ -926,7 +946,9 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ HotSlots hs;
   __shared__ double __attribute__((aligned(16))) hot_lds[USE_LDS ? NSLOT * HOT_DOUBLES : 2];
+  __shared__ double lds_cellest[USE_LDS ? 1 : THERMAL_CELLEST_CAP];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  cellest_begin(env, lds_cellest, USE_LDS ? 0 : env.cellest_n_t, 1, TB);
   if (USE_LDS) {
     if (threadIdx.x < NSLOT) {
       hs.cell[threadIdx.x] = -1;
@@ -1053,6 +1075,7 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
 #endif
   }
   __syncthreads();
+  cellest_flush(env, CELLEST_COLHEAT, env.E.colheatingestimator, TB);
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
@@ -1178,9 +1201,10 @@ struct artis_amd_engine {
   bool sort_lists = true;
   bool sort_nu = true;
   bool sort_ma = true;
-  // lists with more entries per cell of the tile than this are not sorted (sort_by_key); measured crossovers with 1e7
-  // packets: r-packet lists between 6^3 and 12^3 cells (46 000 / 5 800 per cell), thermal lists between 20^3 and 30^3
+  // lists with more entries per cell of the tile than this are not sorted (sort_by_key) unless the kernel accumulates its
+  // per-cell estimators in LDS; measured crossover of the thermal lists with 1e7 packets: between 20^3 and 30^3 cells
   // (1 250 / 370 per cell). ARTIS_AMD_SORT_MAXPC_R / _T.
+  bool cellest_in_lds = true;  // ARTIS_AMD_CELLEST_LDS=0: every estimator add is a global atomic
   int sort_maxpc_r = 20000;
   int sort_maxpc_t = 600;
   // one list chunk per wave instead of one per XCD (artis_engine.hip pull): measured on MI355X, 1e7 packets: k_rpkt -4 %
@@ -1236,6 +1260,11 @@ Env make_env(const artis_amd_engine *e) {
   env.tile_lo = e->tile_lo;
   env.tile_hi = e->tile_hi;
   env.tile_all = (e->tile_lo == 0 && e->tile_hi >= e->Mh.npts_nonempty) ? 1 : 0;
+  {  // few cells: per-cell estimators accumulate in LDS (physics.h Env::cellest_lds)
+    const int nc = e->Mh.npts_nonempty;
+    env.cellest_n_t = (e->cellest_in_lds && nc <= THERMAL_CELLEST_CAP) ? nc : 0;
+    env.cellest_n_r = (e->cellest_in_lds && nc <= RPKT_CELLEST_CAP) ? nc : 0;
+  }
   env.S = e->S;
   env.E = e->E;
   env.P = e->P;
@@ -1618,6 +1647,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_CELLEST_LDS")) e->cellest_in_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_R")) e->sort_maxpc_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_T")) e->sort_maxpc_t = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_R")) e->wave_chunks_r = std::atoi(b) != 0;
@@ -1931,10 +1961,11 @@ int artis_amd_packets_restore(artis_amd_engine *e) {
 namespace {
 // counting sort of list[0..n) by its entries' keys into e->d_sorted; *out = the list to launch on
 // max_per_cell: a list with more entries per cell than this stays in the order it was appended in. A cell-sorted list puts
-// every lane that is running on an XCD into the same few cells when the cells are few and full (1D / 2D models, small
-// grids): their reads then collide on the same cache lines (measured on 6^3 cells with 1e7 packets: mean L1->L2 read
-// latency 937 clocks against 190 on the 50^3 grid, the L1 stalled on pending lines 4x as long, k_thermal 1192 ms sorted
-// against 736 ms unsorted), while the locality the sort buys is not needed because the cells' tables fit in the caches.
+// every lane that is running on an XCD into the same few cells when the cells are few and full, and their estimator
+// atomics then hit the same few addresses at the same time (device-wide atomics on one address are serialised in memory:
+// 20^3 cells, 1e7 packets: k_thermal 907 ms sorted, 725 ms unsorted), while the locality the sort buys matters less
+// because fewer cells' tables compete for the caches. Models with so few cells that the kernels accumulate their per-cell
+// estimators in LDS (Env::cellest_lds) have no such atomics and are always sorted (6^3 cells: 494 ms sorted, 593 unsorted).
 int sort_by_key(artis_amd_engine *e, hipStream_t s, const int32_t *list, const int32_t *keys, int32_t n, const int32_t **out, int nbins,
                 int64_t ncells, int max_per_cell) {
   *out = list;
@@ -2052,7 +2083,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       const int32_t *lst = e->d_lists[kind][cur[kind]];
       if (kind == NEXT_RPKT || kind == NEXT_GAMMA || (kind == NEXT_MA && e->sort_ma)) {
         rc = sort_by_key(e, s, e->d_lists[kind][cur[kind]], e->d_keys[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? r_nubins : 1,
-                         hi - lo, kind == NEXT_MA ? e->sort_maxpc_t : e->sort_maxpc_r);
+                         hi - lo, kind == NEXT_MA ? (env.cellest_n_t > 0 ? INT32_MAX : e->sort_maxpc_t)
+                                                  : (env.cellest_n_r > 0 ? INT32_MAX : e->sort_maxpc_r));
         if (rc != ARTIS_OK) return rc;
       }
       // the kernel starts with an empty current list of its own kind: everything it keeps goes to the alternate list

@@ -96,6 +96,20 @@ typedef unsigned long long stat_t;
 #define MA_PROF_MARK(env, slot) ((void)0)
 #endif
 
+// add to a per-cell estimator: the workgroup's LDS accumulator when the kernel keeps one for this cell (Env::cellest_lds)
+enum { CELLEST_COLHEAT = 0, CELLEST_J = 0, CELLEST_NUJ = 1, CELLEST_FFHEAT = 2 };
+template <typename EnvT>
+AHD void cellest_add(const EnvT &env, double *global_array, int kind, int c, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (c < env.cellest_n) {
+    __hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(env.cellest_lds + (kind * env.cellest_n) + c), v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+#endif
+  ARTIS_EST_ADD(&global_array[c], v);
+}
+
 AHD double pow2(double x) { return x * x; }
 AHD double pow3(double x) { return x * x * x; }
 AHD double dmin(double a, double b) { return (b < a) ? b : a; }
@@ -123,6 +137,13 @@ struct Env {
   int32_t tile_lo, tile_hi;
   int32_t tile_all;  // the tile covers every cell (the usual case): in_tile() needs no look-up
   int32_t cont_in_lds;  // M.cont_pack points into LDS (k_rpkt<true>)
+  // Per-cell estimators of a model with FEW cells (1D / 2D models, small grids): every packet of the launch adds to one of
+  // a few addresses, and device-wide atomics on one address are serialised in memory (measured, 30 shells, 1e7 packets:
+  // k_thermal 2330 ms with its one atomic per walk on colheatingestimator[cell], 590 ms without it). A workgroup then
+  // accumulates in LDS, cellest_lds[kind * cellest_n + cell] for cell < cellest_n, and adds its sums to the global
+  // arrays once, when the kernel ends. cellest_n_t / cellest_n_r: set by the host for k_thermal / k_rpkt (0 = off).
+  double *cellest_lds;
+  int32_t cellest_n, cellest_n_t, cellest_n_r;
   // deferred detailed bound-free estimator updates (DETAILED_BF builds on the GPU; null: added in place)
   BfEvent *bfev;
   int32_t *bfev_count;
@@ -2528,7 +2549,7 @@ AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double
     ARTIS_STAT(env, action == ARTIS_MA_ACTION_COLDEEXC ? ARTIS_STAT_MA_DEACTIVATION_COLLDEEXC : ARTIS_STAT_MA_DEACTIVATION_COLLRECOMB);
     p.type = ARTIS_TYPE_KPKT;
 #if !ARTIS_OPT_DIRECT_COL_HEAT
-    ARTIS_EST_ADD(&env.E.colheatingestimator[c], p.e_cmf);
+    cellest_add(env, env.E.colheatingestimator, CELLEST_COLHEAT, c, p.e_cmf);
 #endif
     ma_finish(env, p, pi);
   } else if (action != MA_EXIT_FAILED) {
@@ -2708,8 +2729,8 @@ AHD void rpkt_event_continuum(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_
 AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double distance, int c, const Chi &x, bool thick, int64_t slot) {
   const double de = distance * e_cmf;
   if (de != 0) {
-    ARTIS_EST_ADD(&env.E.J[c], de);
-    ARTIS_EST_ADD(&env.E.nuJ[c], de * nu_cmf);
+    cellest_add(env, env.E.J, CELLEST_J, c, de);
+    cellest_add(env, env.E.nuJ, CELLEST_NUJ, c, de * nu_cmf);
   }
   if (thick) return;
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
@@ -2725,7 +2746,7 @@ AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double d
     }
   }
 #endif
-  ARTIS_EST_ADD(&env.E.ffheatingestimator[c], de * x.chi_freefree_heat);
+  cellest_add(env, env.E.ffheatingestimator, CELLEST_FFHEAT, c, de * x.chi_freefree_heat);
 #if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
   // update_bfestimators rpkt.cc:519: the loop runs over the ground continua in rising nu_edge until nu_cmf <= nu_edge;
   // entries whose groundcont_gamma_contr is zero add nothing and are not in the packet's list

@@ -111,6 +111,8 @@ def main():
     ap.add_argument("--packets", type=int, default=10_000_000, help="packets per GPU")
     ap.add_argument("--ncoord", type=int, default=50)
     ap.add_argument("--preset", default="w7")
+    ap.add_argument("--grid", default="3d", choices=("1d", "2d", "3d"),
+                    help="grid geometry (GridType of the reference): 3d = the headline workload; 1d / 2d = --ncoord shells / (r, z) cells")
     ap.add_argument("--cpu-sample", type=int, default=160_000)
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -136,7 +138,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
 
     t_setup = time.perf_counter()
-    model, cs, ts, aux = synth.build(args.preset, ncoord=args.ncoord, options=args.options)
+    gridtype = {"1d": abi.GRID_SPHERICAL1D, "2d": abi.GRID_CYLINDRICAL2D, "3d": abi.GRID_CARTESIAN3D}[args.grid]
+    model, cs, ts, aux = synth.build(args.preset, ncoord=args.ncoord, gridtype=gridtype, options=args.options)
     # packet seeds: the reference's per-rank spacing (input.cc:1912: rank_seed_base = seed + rank * npackets)
     seed_base = (1281360349 + rank * args.packets) & 0xFFFFFFFF
     pk = synth.make_packets(model, aux, args.packets, seed_base=seed_base, kpkt_fraction=0.02, seed=99 + rank)
@@ -243,6 +246,8 @@ def main():
         steps_all = int(tsum.item())
 
     if rank == 0:
+        geometry = {"3d": f"{args.ncoord}^3 Cartesian", "2d": f"{args.ncoord} x {2 * args.ncoord} cylindrical (r, z)",
+                    "1d": f"{args.ncoord}-shell spherical 1D"}[args.grid]
         ms_per_step = 1e3 * elapsed / args.steps
         value = steps_all / (elapsed / args.steps)
         # roofline of the dominant kernel (k_thermal: macro-atom walk + k-packet steps): algorithmic bytes of its work
@@ -302,7 +307,7 @@ def main():
             "metric": "packet-steps/sec", "value": value, "unit": "packet-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.ncoord}^3 Cartesian W7-like ejecta, artisoptions_{args.options} physics "
+            "config": {"workload": f"{geometry} W7-like ejecta, artisoptions_{args.options} physics "
                                    f"(line-by-line Sobolev + macro-atom + k-packets), {args.packets} packets per GPU, "
                                    f"synthetic atomic data '{args.preset}' ({model['nlines']} lines, {model['nlevels']} levels, "
                                    f"{model['nions']} ions), one timestep at t=20 d (dt/t=0.05)",

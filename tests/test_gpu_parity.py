@@ -388,18 +388,19 @@ def test_device_runs_are_deterministic_and_idempotent(engine_mod):
 
 @pytest.mark.parametrize("gridtype,ncoord", [(abi.GRID_SPHERICAL1D, 12), (abi.GRID_CARTESIAN3D, 6)])
 def test_work_list_order_does_not_change_packets(engine_mod, oracle, monkeypatch, gridtype, ncoord):
-    """The work lists are counting-sorted by cell (few cells: the LDS form of the sort kernels) unless they hold more
-    entries per cell than a threshold (few, full cells: 1D models). Never sorted, always sorted and the default policy
-    (here: r-packet lists sorted, thermal lists not) give the same packets and counters, and the oracle's."""
+    """Models with few cells: the kernels accumulate the per-cell estimators (J, nuJ, ffheating, colheating) in LDS and add
+    a workgroup's sums to the global arrays once, and the work lists are counting-sorted by cell with the LDS form of the
+    sort kernels. Against the same run with every estimator add a global atomic, lists never sorted / always sorted:
+    same packets and counters, estimators equal to summation order; and the oracle's packets."""
     model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype)
     pk0 = synth.make_packets(model, aux, 60000, kpkt_fraction=0.2)
     outs = []
     for maxpc in (None, "1", "1000000000"):
-        for v in ("ARTIS_AMD_SORT_MAXPC_R", "ARTIS_AMD_SORT_MAXPC_T"):
+        for v in ("ARTIS_AMD_SORT_MAXPC_R", "ARTIS_AMD_SORT_MAXPC_T", "ARTIS_AMD_CELLEST_LDS"):
             if maxpc is None:
                 monkeypatch.delenv(v, raising=False)
             else:
-                monkeypatch.setenv(v, maxpc)
+                monkeypatch.setenv(v, "0" if v == "ARTIS_AMD_CELLEST_LDS" else maxpc)
         eng = engine_mod.Engine(model)
         eng.set_cellstate(cs, ts)
         p, e = pk0.copy(), abi.estimators_for(model, "classic")
