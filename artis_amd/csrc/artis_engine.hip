@@ -634,11 +634,17 @@ inline int chunks_for(int64_t n, int nwaves) {
 constexpr int CONT_LDS_MAX = 2048;  // continua (64 KB per workgroup, two workgroups per CU)
 // LDS accumulators of per-cell estimators for models with few cells (physics.h Env::cellest_lds)
 constexpr int RPKT_CELLEST_CAP = 512;      // cells: 3 estimators x 8 B x 512 = 12 KB per workgroup (next to the 64 KB above)
+constexpr int GAMMA_CELLEST_CAP = 2048;    // cells: 16 KB per workgroup
 constexpr int THERMAL_CELLEST_CAP = 4096;  // cells: 32 KB per workgroup, four workgroups per CU
-__device__ inline void cellest_begin(Env &env, double *lds, int n, int nkinds, int nthreads) {
+__device__ inline void cellest_begin(Env &env, double *lds, int n, int nthreads, const double *a0, const double *a1 = nullptr,
+                                     const double *a2 = nullptr) {
+  const int nkinds = a2 ? 3 : (a1 ? 2 : 1);
   for (int i = threadIdx.x; i < n * nkinds; i += nthreads) lds[i] = 0.;
   env.cellest_lds = lds;
   env.cellest_n = n;
+  env.cellest_owner[0] = a0;
+  env.cellest_owner[1] = a1;
+  env.cellest_owner[2] = a2;
 }
 // call after a __syncthreads(): the workgroup's sums of one estimator go to the global array
 __device__ inline void cellest_flush(const Env &env, int kind, double *global_array, int nthreads) {
@@ -654,7 +660,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
   __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
   __shared__ double lds_cellest[3 * RPKT_CELLEST_CAP];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
-  cellest_begin(env, lds_cellest, env.cellest_n_r, 3, BLOCK);
+  cellest_begin(env, lds_cellest, env.cellest_n_r, BLOCK, env.E.J, env.E.nuJ, env.E.ffheatingestimator);
   if (CONT_LDS) {
     const D2 *src = (const D2 *)env.M.cont_pack;
     D2 *dst = (D2 *)lds_cont;
@@ -817,7 +823,9 @@ __global__ void __launch_bounds__(BLOCK) k_bfest_dense(Env env) {
 __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, const int32_t *list, int32_t n, Lists next,
                                                                      unsigned long long *gstats, int budget, int32_t *cursors, int nchunks) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
+  __shared__ double lds_cellest[GAMMA_CELLEST_CAP];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  cellest_begin(env, lds_cellest, env.cellest_n_g, BLOCK, env.E.dep_estimator_gamma);
   __syncthreads();
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
@@ -857,6 +865,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
     append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
   }
   __syncthreads();
+  cellest_flush(env, CELLEST_DEPGAMMA, env.E.dep_estimator_gamma, BLOCK);
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
@@ -948,7 +957,7 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
   __shared__ double __attribute__((aligned(16))) hot_lds[USE_LDS ? NSLOT * HOT_DOUBLES : 2];
   __shared__ double lds_cellest[USE_LDS ? 1 : THERMAL_CELLEST_CAP];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
-  cellest_begin(env, lds_cellest, USE_LDS ? 0 : env.cellest_n_t, 1, TB);
+  cellest_begin(env, lds_cellest, USE_LDS ? 0 : env.cellest_n_t, TB, env.E.colheatingestimator);
   if (USE_LDS) {
     if (threadIdx.x < NSLOT) {
       hs.cell[threadIdx.x] = -1;
@@ -1264,6 +1273,7 @@ Env make_env(const artis_amd_engine *e) {
     const int nc = e->Mh.npts_nonempty;
     env.cellest_n_t = (e->cellest_in_lds && nc <= THERMAL_CELLEST_CAP) ? nc : 0;
     env.cellest_n_r = (e->cellest_in_lds && nc <= RPKT_CELLEST_CAP) ? nc : 0;
+    env.cellest_n_g = (e->cellest_in_lds && nc <= GAMMA_CELLEST_CAP) ? nc : 0;
   }
   env.S = e->S;
   env.E = e->E;

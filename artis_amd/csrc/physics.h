@@ -97,11 +97,11 @@ typedef unsigned long long stat_t;
 #endif
 
 // add to a per-cell estimator: the workgroup's LDS accumulator when the kernel keeps one for this cell (Env::cellest_lds)
-enum { CELLEST_COLHEAT = 0, CELLEST_J = 0, CELLEST_NUJ = 1, CELLEST_FFHEAT = 2 };
+enum { CELLEST_COLHEAT = 0, CELLEST_DEPGAMMA = 0, CELLEST_J = 0, CELLEST_NUJ = 1, CELLEST_FFHEAT = 2 };  // per kernel
 template <typename EnvT>
 AHD void cellest_add(const EnvT &env, double *global_array, int kind, int c, double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (c < env.cellest_n) {
+  if (c < env.cellest_n && env.cellest_owner[kind] == global_array) {
     __hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(env.cellest_lds + (kind * env.cellest_n) + c), v, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
@@ -141,9 +141,10 @@ struct Env {
   // a few addresses, and device-wide atomics on one address are serialised in memory (measured, 30 shells, 1e7 packets:
   // k_thermal 2330 ms with its one atomic per walk on colheatingestimator[cell], 590 ms without it). A workgroup then
   // accumulates in LDS, cellest_lds[kind * cellest_n + cell] for cell < cellest_n, and adds its sums to the global
-  // arrays once, when the kernel ends. cellest_n_t / cellest_n_r: set by the host for k_thermal / k_rpkt (0 = off).
+  // arrays once, when the kernel ends. cellest_n_t / _r / _g: set by the host for k_thermal / k_rpkt / k_gamma (0 = off).
   double *cellest_lds;
-  int32_t cellest_n, cellest_n_t, cellest_n_r;
+  const double *cellest_owner[3];  // the global array each kind of the running kernel stands for (anything else: global add)
+  int32_t cellest_n, cellest_n_t, cellest_n_r, cellest_n_g;
   // deferred detailed bound-free estimator updates (DETAILED_BF builds on the GPU; null: added in place)
   BfEvent *bfev;
   int32_t *bfev_count;
@@ -3163,7 +3164,7 @@ AHD void update_gamma_dep(const Env &env, const Pkt &p, int c, double dist) {  /
   if (c < 0) return;
   const double doppler_sq = pow2(doppler(p));
   const double heating_cont = chi_cmf_loss_weighted(env, c, p.nu_cmf) * p.e_rf * dist * doppler_sq;
-  ARTIS_EST_ADD(&env.E.dep_estimator_gamma[c], heating_cont);
+  cellest_add(env, env.E.dep_estimator_gamma, CELLEST_DEPGAMMA, c, heating_cont);
 }
 AHD double thomson_angle(Pkt &p) {  // gammapkt.cc:284
   const double B_coeff = (8. * rng_uniform(p)) - 4.;
