@@ -646,6 +646,14 @@ __device__ inline void cellest_begin(Env &env, double *lds, int n, int nthreads,
   env.cellest_owner[1] = a1;
   env.cellest_owner[2] = a2;
 }
+__device__ inline void scalars_begin(Env &env, double *lds) {
+  if (threadIdx.x < ARTIS_NSCALARS) lds[threadIdx.x] = 0.;
+  env.scalars_lds = (env.scalars_in_lds && env.E.scalars != nullptr) ? lds : nullptr;
+}
+__device__ inline void scalars_flush(const Env &env) {  // after a __syncthreads()
+  if (env.scalars_lds != nullptr && threadIdx.x < ARTIS_NSCALARS && env.scalars_lds[threadIdx.x] != 0.)
+    unsafeAtomicAdd(&env.E.scalars[threadIdx.x], env.scalars_lds[threadIdx.x]);
+}
 // call after a __syncthreads(): the workgroup's sums of one estimator go to the global array
 __device__ inline void cellest_flush(const Env &env, int kind, double *global_array, int nthreads) {
   for (int c = threadIdx.x; c < env.cellest_n; c += nthreads) {
@@ -824,7 +832,9 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
                                                                      unsigned long long *gstats, int budget, int32_t *cursors, int nchunks) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ double lds_cellest[GAMMA_CELLEST_CAP];
+  __shared__ double lds_scalars[ARTIS_NSCALARS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  scalars_begin(env, lds_scalars);
   cellest_begin(env, lds_cellest, env.cellest_n_g, BLOCK, env.E.dep_estimator_gamma);
   __syncthreads();
   env.stats = lstats;
@@ -866,6 +876,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
   }
   __syncthreads();
   cellest_flush(env, CELLEST_DEPGAMMA, env.E.dep_estimator_gamma, BLOCK);
+  scalars_flush(env);
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
@@ -1092,7 +1103,9 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
 // slow path: the rare bound-free actions (rate coefficients with exp(), adaptive Gauss-Kronrod frequency sampling)
 __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
+  __shared__ double lds_scalars[ARTIS_NSCALARS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  scalars_begin(env, lds_scalars);
   __syncthreads();
   env.stats = lstats;
   const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1110,6 +1123,7 @@ __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, in
   }
   append_by_kind(kind, pi, cellindex, nu_cmf, next);
   __syncthreads();
+  scalars_flush(env);
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
@@ -1274,6 +1288,7 @@ Env make_env(const artis_amd_engine *e) {
     env.cellest_n_t = (e->cellest_in_lds && nc <= THERMAL_CELLEST_CAP) ? nc : 0;
     env.cellest_n_r = (e->cellest_in_lds && nc <= RPKT_CELLEST_CAP) ? nc : 0;
     env.cellest_n_g = (e->cellest_in_lds && nc <= GAMMA_CELLEST_CAP) ? nc : 0;
+    env.scalars_in_lds = e->cellest_in_lds ? 1 : 0;
   }
   env.S = e->S;
   env.E = e->E;

@@ -110,6 +110,17 @@ AHD void cellest_add(const EnvT &env, double *global_array, int kind, int c, dou
   ARTIS_EST_ADD(&global_array[c], v);
 }
 
+template <typename EnvT>
+AHD void scalar_add(const EnvT &env, int idx, double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (env.scalars_lds != nullptr) {
+    __hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(env.scalars_lds + idx), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+#endif
+  ARTIS_EST_ADD(&env.E.scalars[idx], v);
+}
+
 AHD double pow2(double x) { return x * x; }
 AHD double pow3(double x) { return x * x * x; }
 AHD double dmin(double a, double b) { return (b < a) ? b : a; }
@@ -145,6 +156,10 @@ struct Env {
   double *cellest_lds;
   const double *cellest_owner[3];  // the global array each kind of the running kernel stands for (anything else: global add)
   int32_t cellest_n, cellest_n_t, cellest_n_r, cellest_n_g;
+  // the per-timestep scalar sums (ARTIS_SCALAR_*: ONE address each for every packet of the launch) of the running
+  // kernel's workgroup in LDS, added to E.scalars when the kernel ends; null: global atomics. scalars_in_lds: host switch
+  double *scalars_lds;
+  int32_t scalars_in_lds;
   // deferred detailed bound-free estimator updates (DETAILED_BF builds on the GPU; null: added in place)
   BfEvent *bfev;
   int32_t *bfev_count;
@@ -3351,7 +3366,7 @@ AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
     change_cell_or_escape(env, p, pi, -99);  // escape_type stays TYPE_GAMMA
   }
   if (p.type != ARTIS_TYPE_GAMMA && p.type != ARTIS_TYPE_ESCAPE) {
-    if (!ARTIS_GAMMAPRODUCTS) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE], p.e_cmf);
+    if (!ARTIS_GAMMAPRODUCTS) scalar_add(env, ARTIS_SCALAR_GAMMA_DEP_DISCRETE, p.e_cmf);
     const int c = env.M.propcell_nonemptymgi[p.cellindex];  // no transport: the path estimator is fed here (gammapkt.cc:930)
     if (c >= 0) ARTIS_EST_ADD(&env.E.dep_estimator_gamma[c], p.e_cmf);
   }
@@ -3402,7 +3417,7 @@ AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
     fail(env, 82);
   }
   if (p.type != ARTIS_TYPE_GAMMA && p.type != ARTIS_TYPE_ESCAPE && !ARTIS_GAMMAPRODUCTS)
-    ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE], p.e_cmf);  // gammapkt.cc:926
+    scalar_add(env, ARTIS_SCALAR_GAMMA_DEP_DISCRETE, p.e_cmf);  // gammapkt.cc:926
 }
 #endif
 // nonthermal::do_ntlepton_deposit nonthermal.cc:2529. NT_ON == false (artisoptions_classic.h:95): every deposit is heat.
@@ -3410,7 +3425,7 @@ AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
 // with the solution's fractions; the activation is recorded in the packet (ma_activate) and the walk runs in the thermal
 // kernel, the packet keeping its deposit type until the macro-atom deactivates (as in the reference's do_macroatom()).
 AHD void do_ntlepton_deposit(const Env &env, Pkt &p) {
-  ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_NT_ENERGY_DEPOSITED], p.e_cmf);
+  scalar_add(env, ARTIS_SCALAR_NT_ENERGY_DEPOSITED, p.e_cmf);
 #if ARTIS_OPT_NT_ON
   const DevModel &M = env.M;
   const int c = M.propcell_nonemptymgi[p.cellindex];
@@ -3483,7 +3498,7 @@ AHD void do_ntlepton_deposit(const Env &env, Pkt &p) {
 
 // nonthermal::do_ntalpha_fisprod_deposit nonthermal.cc:2520
 AHD void do_ntalpha_fisprod_deposit(const Env &env, Pkt &p) {
-  ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_NT_ENERGY_DEPOSITED], p.e_cmf);
+  scalar_add(env, ARTIS_SCALAR_NT_ENERGY_DEPOSITED, p.e_cmf);
   p.type = ARTIS_TYPE_KPKT;
   ARTIS_STAT(env, ARTIS_STAT_NT_TO_KPKT);
 }
@@ -3550,17 +3565,17 @@ AHD void do_nonthermal_predeposit(const Env &env, Pkt &p, int64_t pi) {
   if (env.P.cold[pi].originated_particle != 0) {
     if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS) {
       ARTIS_EST_ADD(&env.E.dep_estimator_electron[c], e_cmf_deposited);
-      if (p.type == deposit_type) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ELECTRON_DEP_DISCRETE], p.e_cmf);
+      if (p.type == deposit_type) scalar_add(env, ARTIS_SCALAR_ELECTRON_DEP_DISCRETE, p.e_cmf);
     } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS) {
       ARTIS_EST_ADD(&env.E.dep_estimator_positron[c], e_cmf_deposited);
-      if (p.type == deposit_type) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_POSITRON_DEP_DISCRETE], p.e_cmf);
+      if (p.type == deposit_type) scalar_add(env, ARTIS_SCALAR_POSITRON_DEP_DISCRETE, p.e_cmf);
     } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) {
       ARTIS_EST_ADD(&env.E.dep_estimator_alpha[c], e_cmf_deposited);
-      if (p.type == deposit_type) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ALPHA_DEP_DISCRETE], p.e_cmf);
+      if (p.type == deposit_type) scalar_add(env, ARTIS_SCALAR_ALPHA_DEP_DISCRETE, p.e_cmf);
     }
   } else if (ARTIS_GAMMAPRODUCTS) {  // update_packets.cc:174: products of gamma rays count as gamma deposition
     ARTIS_EST_ADD(&env.E.dep_estimator_gamma[c], e_cmf_deposited);
-    if (p.type == ARTIS_TYPE_NTLEPTON_DEPOSITED) ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_DEP_DISCRETE], p.e_cmf);
+    if (p.type == ARTIS_TYPE_NTLEPTON_DEPOSITED) scalar_add(env, ARTIS_SCALAR_GAMMA_DEP_DISCRETE, p.e_cmf);
   }
 }
 // update_pellet update_packets.cc:185 with pellet_gamma_decay gammapkt.cc:894
@@ -3575,7 +3590,7 @@ AHD void update_pellet(const Env &env, Pkt &p, int64_t pi) {
     p.pz = p.pz * scale;
     p.prop_time = t2;
   } else if (tdecay > ts) {
-    ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_PELLET_DECAYS], 1.);
+    scalar_add(env, ARTIS_SCALAR_PELLET_DECAYS, 1.);
     p.prop_time = tdecay;
     const double scale = tdecay / ts;
     p.px = p.px * scale;
@@ -3585,15 +3600,15 @@ AHD void update_pellet(const Env &env, Pkt &p, int64_t pi) {
       const int decaytype = env.P.cold[pi].pellet_decaytype;
       if (decaytype == ARTIS_DECAYTYPE_BETAPLUS) {
         p.type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS;
-        ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_POSITRON_EMISSION], p.e_cmf);
+        scalar_add(env, ARTIS_SCALAR_POSITRON_EMISSION, p.e_cmf);
       } else if (decaytype == ARTIS_DECAYTYPE_BETAMINUS) {
         p.type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS;
-        ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ELECTRON_EMISSION], p.e_cmf);
+        scalar_add(env, ARTIS_SCALAR_ELECTRON_EMISSION, p.e_cmf);
       } else if (decaytype == ARTIS_DECAYTYPE_ALPHA) {
-        ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_ALPHA_EMISSION], p.e_cmf);
+        scalar_add(env, ARTIS_SCALAR_ALPHA_EMISSION, p.e_cmf);
         p.type = ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA;
       } else if (decaytype == ARTIS_DECAYTYPE_SPONTFISSION) {
-        ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_SPFISSION_DEP_DISCRETE], p.e_cmf);
+        scalar_add(env, ARTIS_SCALAR_SPFISSION_DEP_DISCRETE, p.e_cmf);
         p.type = ARTIS_TYPE_NTALPHA_FISPROD_DEPOSITED;
       } else {
         fail(env, 90);
@@ -3603,7 +3618,7 @@ AHD void update_pellet(const Env &env, Pkt &p, int64_t pi) {
       env.P.flight[pi].em_time = (float)p.prop_time;
       p.absorptiontype = ARTIS_ABSTYPE_PELLET_PARTICLEDECAY;
     } else {
-      ARTIS_EST_ADD(&env.E.scalars[ARTIS_SCALAR_GAMMA_EMISSION], p.e_cmf);
+      scalar_add(env, ARTIS_SCALAR_GAMMA_EMISSION, p.e_cmf);
       if (p.nu_cmf < 0) {  // no gamma spectrum known for the nuclide: straight to a k-packet
         p.type = ARTIS_TYPE_KPKT;
         p.absorptiontype = ARTIS_ABSTYPE_PELLET_NOGAMMASPEC;
