@@ -18,7 +18,7 @@ from oracle import oracle_py  # noqa: E402
 npk = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 ncoord = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 for preset in ("classic", "kilonova_lte"):
-    for gridtype in (abi.GRID_CARTESIAN3D, abi.GRID_CYLINDRICAL2D):
+    for gridtype in (abi.GRID_CARTESIAN3D, abi.GRID_CYLINDRICAL2D, abi.GRID_SPHERICAL1D):
         model, cs, ts, aux = synth.build("w7", ncoord=ncoord, gridtype=gridtype, options=preset)
         pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=0.1, gamma_fraction=0.1, pellet_fraction=0.2)
         n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
