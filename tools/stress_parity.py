@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off stress of the GPU parity claim at a larger packet count than the test suite uses: HIP engine vs the CPU oracle
 (tests/parity.py bars: integer fields, RNG state and event counters identical; floats to 1e-9) for every options preset,
-all packet types, on the w7 atomic data. Usage (GPU box): python tools/stress_parity.py [npackets] [ncoord]"""
+all packet types, on the w7 atomic data. Usage (GPU box): python tools/stress_parity.py [npackets] [ncoord] [preset,preset,...]"""
 import os
 import sys
 import time
@@ -17,13 +17,14 @@ from oracle import oracle_py  # noqa: E402
 
 npk = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 ncoord = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-for preset in ("classic", "kilonova_lte"):
+presets = sys.argv[3].split(",") if len(sys.argv) > 3 else ["classic", "kilonova_lte"]
+for preset in presets:
     for gridtype in (abi.GRID_CARTESIAN3D, abi.GRID_CYLINDRICAL2D, abi.GRID_SPHERICAL1D):
         model, cs, ts, aux = synth.build("w7", ncoord=ncoord, gridtype=gridtype, options=preset)
         pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=0.1, gamma_fraction=0.1, pellet_fraction=0.2)
         n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
         pa, pb = pk0.copy(), pk0.copy()
-        ea, eb = abi.Estimators(n, g), abi.Estimators(n, g)
+        ea, eb = abi.estimators_for(model, preset), abi.estimators_for(model, preset)
         t0 = time.time()
         oracle_py.update_packets(model, cs, ts, pa, ea, preset=preset)
         t1 = time.time()
