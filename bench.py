@@ -173,15 +173,19 @@ def main():
     # binding on the same device block, and the JSON line says so.
     reduce_via = None
     if world > 1:
-        ids = [None]
-        if rank == 0:
-            try:
-                ids = [eng.comm_unique_id()]
-            except Exception as exc:  # noqa: BLE001
-                print(f"[bench] librccl not reachable from the engine library ({exc})", file=sys.stderr)
+        # every rank first proves that its engine library reaches librccl (a local call), so that no rank can be left
+        # waiting inside ncclCommInitRank for one that never got there
+        my_id = None
+        try:
+            my_id = eng.comm_unique_id()
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] rank {rank}: librccl not reachable from the engine library ({exc})", file=sys.stderr)
+        reachable = [None] * world
+        dist.all_gather_object(reachable, my_id is not None)
+        ids = [my_id if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         reduce_via = "torch.distributed.all_reduce (RCCL)"
-        if ids[0] is not None:
+        if all(reachable) and ids[0] is not None:
             try:
                 eng.comm_init(world, rank, ids[0])
                 reduce_via = "artis_amd_allreduce_estimators (RCCL, C-ABI)"
