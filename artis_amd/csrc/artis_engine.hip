@@ -1100,6 +1100,66 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
 }
 
 
+// Tail kernel: the LAST few thousand r-packets and thermal packets of a timestep, one per lane, each carried through
+// r-packet steps, macro-atom walks and k-packet steps until it leaves these kinds (end of the timestep, escape, a
+// slow-path action, a gamma-ray type, a blackbody step, another cache tile). The event-split kernels need one launch
+// pair per r-packet <-> thermal alternation of the longest-lived packets, and a launch lasts as long as its slowest
+// packet: with the nltenebular options 530 of 720 launches of a step hold fewer than 10^4 packets and cost 490 ms
+// (the last 150 hold 1-5 packets). Here the packets do not wait for each other. Same functions in the same order per
+// packet as the split kernels (state goes through the packet record at every change of kind, as it does between
+// launches), so the same results; a fat kernel (both bodies: scratch, low occupancy), which is why it is the tail only.
+struct TailLists {
+  const int32_t *list[4];  // the current r-packet, thermal, slow-path and blackbody lists
+  int32_t n[4];
+};
+__global__ void __launch_bounds__(BLOCK) k_tail(Env env, TailLists in, Lists next, unsigned long long *gstats) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  env.stats = lstats;
+  const double ts_end = env.S.ts_end;
+  // ONE PACKET PER WAVE (lane 0): packets in different kinds of step would otherwise serialise inside a wave (measured
+  // with a packet per lane: slower than the split kernels); the tail has fewer packets than the GPU has waves
+  const int64_t tid = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  int kind = NEXT_DONE;
+  int32_t pi = 0, cellindex = 0;
+  double nu_cmf = 0.;
+  if ((threadIdx.x & 63) == 0 && tid < (int64_t)in.n[0] + in.n[1] + in.n[2] + in.n[3]) {
+    int32_t j = (int32_t)tid;
+    int which = 0;
+    while (j >= in.n[which]) j -= in.n[which++];
+    pi = in.list[which][j];
+    Pkt p;
+    pkt_load(env.P, pi, p);
+    while (true) {
+      kind = classify(env, p, ts_end);
+      if (kind == NEXT_RPKT) {
+        Chi x;
+        chi_load(env.P, pi, p, x);
+        bool go = rpkt_can_continue(p, ts_end);
+        while (go) go = rpkt_iter(env, p, pi, x);
+        chi_store(env.P, pi, p, x);
+      } else if (kind == NEXT_MA || kind == NEXT_KPKT) {
+        MACtx k = ma_ctx(env, p);
+        bool go = thermal_can_continue(p, ts_end);
+        while (go) (void)thermal_iter(env, p, pi, k, &go);
+      } else if (kind == NEXT_SLOW) {
+        (void)advance_slow(env, p, pi);
+      } else if (kind == NEXT_BB) {
+        (void)advance_blackbody(env, p, pi);
+      } else {
+        break;
+      }
+    }
+    pkt_store(env.P, pi, p);
+    cellindex = p.cellindex;
+    nu_cmf = p.nu_cmf;
+  }
+  append_by_kind(kind, pi, cellindex, nu_cmf, next);
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
+}
+
 // slow path: the rare bound-free actions (rate coefficients with exp(), adaptive Gauss-Kronrod frequency sampling)
 __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
@@ -1216,6 +1276,9 @@ struct artis_amd_engine {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   double last_propagate_ms = 0.;
   double kms[NEXT_NKINDS] = {};       // summed launch durations per kind of the last update_packets_device call
+  double kms_tail = 0.;               // ... and of the tail kernel
+  int tail_max = 4096;                // r-packets + thermal packets left at which k_tail takes over (ARTIS_AMD_TAIL; 0 = never)
+  bool tail_always = false;           // ... also for a population that starts below it (ARTIS_AMD_TAIL_ALWAYS=1)
   int64_t klaunches[NEXT_NKINDS] = {};
   int64_t kthreads[NEXT_NKINDS] = {};
   int64_t last_nlaunches = 0;
@@ -1672,6 +1735,8 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NU")) e->sort_nu = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_TAIL")) e->tail_max = std::max(0, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_TAIL_ALWAYS")) e->tail_always = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_CELLEST_LDS")) e->cellest_in_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_R")) e->sort_maxpc_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_T")) e->sort_maxpc_t = std::max(1, std::atoi(b));
@@ -2026,6 +2091,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   e->last_nlaunches = 0;
   for (int k = 0; k < NEXT_NKINDS; k++) {
     e->kms[k] = 0.;
+    e->kms_tail = 0.;
     e->klaunches[k] = 0;
     e->kthreads[k] = 0;
   }
@@ -2100,7 +2166,49 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
 
   // one launch = the whole current list of one kind. Order: slow path, k-packets, macro-atoms, r-packets, so that a
   // k-packet -> macro-atom -> k-packet cycle costs two launches.
+  // the tail kernel takes the end of a population that began larger (a population that begins below the threshold runs on
+  // the split kernels throughout, unless ARTIS_AMD_TAIL_ALWAYS=1)
+  int64_t listed = 0;
+  for (int k = 1; k < NEXT_NKINDS; k++) listed += cnt[k];
+  const bool tail_ok = e->tail_max > 0 && (e->tail_always || listed > e->tail_max);
   while (cnt[NEXT_RPKT] > 0 || cnt[NEXT_MA] > 0 || cnt[NEXT_SLOW] > 0 || cnt[NEXT_KPKT] > 0 || cnt[NEXT_GAMMA] > 0 || cnt[NEXT_BB] > 0) {
+    const int tail_kinds[4] = {NEXT_RPKT, NEXT_MA, NEXT_SLOW, NEXT_BB};
+    int64_t tail_n = 0;
+    for (int k : tail_kinds) tail_n += cnt[k];
+    if (tail_ok && tail_n > 0 && tail_n <= e->tail_max && cnt[NEXT_KPKT] == 0) {
+      // the last packets of these kinds: one launch carries each through all its remaining alternations (k_tail)
+      const int32_t nr = (int32_t)tail_n, nt = 0;
+      const Lists next = lists_for(0);  // the four current lists are consumed whole; nothing is appended to them
+      TailLists in;
+      for (int i = 0; i < 4; i++) {
+        in.list[i] = e->d_lists[tail_kinds[i]][cur[tail_kinds[i]]];
+        in.n[i] = cnt[tail_kinds[i]];
+        HIP_TRY(hipMemsetAsync(e->d_count + tail_kinds[i], 0, sizeof(int32_t), s));
+      }
+      HIP_TRY(hipEventRecord(e->ev0, s));
+      hipLaunchKernelGGL(k_tail, dim3(nblocks(tail_n * 64)), dim3(BLOCK), 0, s, env, in, next, e->d_stats);
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+      if (env.bfev != nullptr) {
+        hipLaunchKernelGGL(k_bfest_dense, dim3(e->ncu * 8), dim3(BLOCK), 0, s, env);
+        HIP_TRY(hipMemsetAsync(e->d_bfev_count, 0, sizeof(int32_t), s));
+      }
+#endif
+      HIP_TRY(hipEventRecord(e->ev1, s));
+      rc = read_counts();
+      if (rc != ARTIS_OK) return rc;
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+      e->kms_tail += ms;
+      e->last_nlaunches++;
+      if (e->trace)
+        fprintf(stderr, "[artis_amd] launch %lld tail n=%d+%d %.3f ms -> r %d ma %d slow %d gamma %d bb %d\n", (long long)e->last_nlaunches, nr, nt,
+                ms, cnt[NEXT_RPKT], cnt[NEXT_MA], cnt[NEXT_SLOW], cnt[NEXT_GAMMA], cnt[NEXT_BB]);
+      if (++guard > 2000000LL) {
+        g_last_error = "packet loop did not terminate";
+        return ARTIS_ERR_NOTCONVERGED;
+      }
+      continue;
+    }
     for (int kind : order) {
       const int32_t nk = cnt[kind];
       if (nk <= 0) continue;
@@ -2181,6 +2289,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   if (e->ntiles == 1 || !any_active) break;
   }  // sweeps
   for (int k = 1; k < NEXT_NKINDS; k++) e->last_propagate_ms += e->kms[k];
+  e->last_propagate_ms += e->kms_tail;
   int32_t err = 0;
   HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
   if (err != 0) {

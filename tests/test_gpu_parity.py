@@ -416,6 +416,36 @@ def test_work_list_order_does_not_change_packets(engine_mod, oracle, monkeypatch
     parity.compare_packets(outs[0][0][:6000], pa, FLOAT_RTOL, "default list policy vs oracle")
 
 
+@pytest.mark.parametrize("options,gridtype,ncoord", [("classic", abi.GRID_CARTESIAN3D, 8), ("classic", abi.GRID_SPHERICAL1D, 16),
+                                                     ("nltenebular", abi.GRID_CARTESIAN3D, 8), ("kilonova_expopac", abi.GRID_CARTESIAN3D, 8)])
+def test_tail_kernel_gives_the_split_kernels_packets(engine_mod, oracle, monkeypatch, options, gridtype, ncoord):
+    """k_tail carries the last r-packets and thermal packets of a population through all their remaining steps in one
+    launch. Whole population through it (ARTIS_AMD_TAIL_ALWAYS), never (ARTIS_AMD_TAIL=0) and the default (the end of a
+    population that began above the threshold): identical packets and counters, estimators to summation order; and the
+    oracle's packets. All packet types, so that packets leave the tail kernel for the other kernels and come back."""
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options)
+    pk0 = synth.make_packets(model, aux, 30000, kpkt_fraction=0.2, gamma_fraction=0.1, pellet_fraction=0.1)
+    outs = []
+    for env in ({"ARTIS_AMD_TAIL": "0"}, {"ARTIS_AMD_TAIL": "100000000", "ARTIS_AMD_TAIL_ALWAYS": "1"}, {"ARTIS_AMD_TAIL": "2000"}, {}):
+        for v in ("ARTIS_AMD_TAIL", "ARTIS_AMD_TAIL_ALWAYS"):
+            monkeypatch.delenv(v, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = engine_mod.Engine(model, preset=options)
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, options)
+        eng.update_packets(p, e)
+        eng.close()
+        outs.append((p, e))
+    for p, e in outs[1:]:
+        parity.compare_packets(p, outs[0][0], 0.0, "tail kernel vs split kernels")
+        parity.compare_stats(e, outs[0][1], "tail kernel vs split kernels")
+        parity.compare_estimators(e, outs[0][1], 1e-11, "tail kernel vs split kernels")
+    pa, ea = pk0[:6000].copy(), abi.estimators_for(model, options)
+    oracle.update_packets(model, cs, ts, pa, ea, preset=options)
+    parity.compare_packets(outs[1][0][:6000], pa, FLOAT_RTOL, "tail kernel vs oracle")
+
+
 def test_budget_independence_on_device(engine_mod, monkeypatch):
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
     pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.3)
