@@ -1112,7 +1112,7 @@ struct TailLists {
   const int32_t *list[4];  // the current r-packet, thermal, slow-path and blackbody lists
   int32_t n[4];
 };
-__global__ void __launch_bounds__(BLOCK) k_tail(Env env, TailLists in, Lists next, unsigned long long *gstats) {
+__global__ void __launch_bounds__(BLOCK, 2) k_tail(Env env, TailLists in, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   __syncthreads();
