@@ -634,6 +634,7 @@ inline int chunks_for(int64_t n, int nwaves) {
 constexpr int CONT_LDS_MAX = 2048;  // continua (64 KB per workgroup, two workgroups per CU)
 // LDS accumulators of per-cell estimators for models with few cells (physics.h Env::cellest_lds)
 constexpr int RPKT_CELLEST_CAP = 512;      // cells: 3 estimators x 8 B x 512 = 12 KB per workgroup (next to the 64 KB above)
+constexpr int RPKT_CELLEST_CAP_NOCONT = 3072;  // ... 72 KB in the kernel form without the continuum table in LDS
 constexpr int GAMMA_CELLEST_CAP = 2048;    // cells: 16 KB per workgroup
 constexpr int THERMAL_CELLEST_CAP = 4096;  // cells: 32 KB per workgroup, four workgroups per CU
 __device__ inline void cellest_begin(Env &env, double *lds, int n, int nthreads, const double *a0, const double *a1 = nullptr,
@@ -666,7 +667,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
                                                                    unsigned long long *gstats, int budget, int32_t *cursors, int nchunks) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
-  __shared__ double lds_cellest[3 * RPKT_CELLEST_CAP];
+  __shared__ double lds_cellest[3 * (CONT_LDS ? RPKT_CELLEST_CAP : RPKT_CELLEST_CAP_NOCONT)];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   cellest_begin(env, lds_cellest, env.cellest_n_r, BLOCK, env.E.J, env.E.nuJ, env.E.ffheatingestimator);
   if (CONT_LDS) {
@@ -1290,6 +1291,9 @@ struct artis_amd_engine {
   // lists with more entries per cell of the tile than this are not sorted (sort_by_key) unless the kernel accumulates its
   // per-cell estimators in LDS; measured crossover of the thermal lists with 1e7 packets: between 20^3 and 30^3 cells
   // (1 250 / 370 per cell). ARTIS_AMD_SORT_MAXPC_R / _T.
+  // 512 < cells <= 3072: k_rpkt keeps J / nuJ / ffheating in LDS instead of the continuum table (12^3 grid, 912 cells:
+  // k_rpkt 292 -> 215 ms; 14^3, 1472 cells: 249 -> 225 ms). ARTIS_AMD_RPKT_EST_OVER_CONT=0: the table wins the LDS.
+  bool rpkt_est_over_cont = true;
   bool cellest_in_lds = true;  // ARTIS_AMD_CELLEST_LDS=0: every estimator add is a global atomic
   int sort_maxpc_r = 20000;
   int sort_maxpc_t = 600;
@@ -1349,7 +1353,8 @@ Env make_env(const artis_amd_engine *e) {
   {  // few cells: per-cell estimators accumulate in LDS (physics.h Env::cellest_lds)
     const int nc = e->Mh.npts_nonempty;
     env.cellest_n_t = (e->cellest_in_lds && nc <= THERMAL_CELLEST_CAP) ? nc : 0;
-    env.cellest_n_r = (e->cellest_in_lds && nc <= RPKT_CELLEST_CAP) ? nc : 0;
+    // between the two caps k_rpkt runs without the continuum table in LDS and keeps the estimators there instead
+    env.cellest_n_r = (e->cellest_in_lds && nc <= (e->rpkt_est_over_cont ? RPKT_CELLEST_CAP_NOCONT : RPKT_CELLEST_CAP)) ? nc : 0;
     env.cellest_n_g = (e->cellest_in_lds && nc <= GAMMA_CELLEST_CAP) ? nc : 0;
     env.scalars_in_lds = e->cellest_in_lds ? 1 : 0;
   }
@@ -1737,6 +1742,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TAIL")) e->tail_max = std::max(0, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_TAIL_ALWAYS")) e->tail_always = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_RPKT_EST_OVER_CONT")) e->rpkt_est_over_cont = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_CELLEST_LDS")) e->cellest_in_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_R")) e->sort_maxpc_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_T")) e->sort_maxpc_t = std::max(1, std::atoi(b));
@@ -2228,7 +2234,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       if (kind == NEXT_RPKT) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
         const int nch = e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8;
-        if (e->cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0)
+        if (e->cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0 &&
+            !(env.cellest_n_r > RPKT_CELLEST_CAP))
           hipLaunchKernelGGL((k_rpkt<true>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch);
         else
           hipLaunchKernelGGL((k_rpkt<false>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch);

@@ -386,7 +386,8 @@ def test_device_runs_are_deterministic_and_idempotent(engine_mod):
     eng.close()
 
 
-@pytest.mark.parametrize("gridtype,ncoord", [(abi.GRID_SPHERICAL1D, 12), (abi.GRID_CARTESIAN3D, 6)])
+@pytest.mark.parametrize("gridtype,ncoord", [(abi.GRID_SPHERICAL1D, 12), (abi.GRID_CARTESIAN3D, 6),
+                                             (abi.GRID_CARTESIAN3D, 12)])  # 912 cells: k_rpkt's estimators take the LDS of its continuum table
 def test_work_list_order_does_not_change_packets(engine_mod, oracle, monkeypatch, gridtype, ncoord):
     """Models with few cells: the kernels accumulate the per-cell estimators (J, nuJ, ffheating, colheating) in LDS and add
     a workgroup's sums to the global arrays once, and the work lists are counting-sorted by cell with the LDS form of the
