@@ -222,11 +222,10 @@ AHD uint32_t rng_next(Pkt &p) {
 // float, and the product with 2^-24 is exact, so the largest value is 1 - 2^-24. Without the (dead) loop a draw is
 // straight-line code that the compiler can schedule under the latency of loads in flight.
 AHD float rng_uniform(Pkt &p) { return (float)(rng_next(p) >> 8U) * 0x1.0p-24F; }
-AHD float rng_uniform_pos(Pkt &p) {
-  while (true) {
-    const float z = rng_uniform(p);
-    if (z > 0) return z;
-  }
+AHD float rng_uniform_pos(Pkt &p) {  // random.h:59: redraw while the value is 0 (one draw in 2^24)
+  float z = rng_uniform(p);
+  while (!(z > 0)) z = rng_uniform(p);
+  return z;
 }
 
 // ---------------------------------------------------------------- vectors.h
