@@ -770,12 +770,25 @@ __device__ inline int select_kth_bit(unsigned long long x, int k) {  // position
 // (Keeping a cell's sums in LDS across a run of records of the same cell -- per wave, or per workgroup with ds_add_f64 --
 // was measured and lost, 651 / 427 ms against 364 ms: the kernel is bound by the latency of a record's chain of reads,
 // not by the HBM atomics, and LDS costs resident waves.)
-__global__ void __launch_bounds__(BLOCK) k_bfest_dense(Env env) {
+// CONT_LDS: the static continuum table (ContPack, two of a contribution's ~six 16-byte reads) is staged in LDS by a
+// workgroup of DENSE_TB threads, one per CU.
+constexpr int DENSE_TB = 1024;
+template <bool CONT_LDS, int TB>
+__global__ void __launch_bounds__(TB) k_bfest_dense(Env env) {
+  __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
+  if (CONT_LDS) {
+    const D2 *src = (const D2 *)env.M.cont_pack;
+    D2 *dst = (D2 *)lds_cont;
+    for (int i = threadIdx.x; i < env.M.nbfcontinua * 2; i += TB) dst[i] = src[i];
+    env.M.cont_pack = lds_cont;
+    env.cont_in_lds = 1;
+    __syncthreads();
+  }
   const DevModel &M = env.M;
   const int n = min(*env.bfev_count, env.bfev_cap);
   const int lane = threadIdx.x & 63;
-  const int nwaves = gridDim.x * (BLOCK / 64);
-  for (int ei = (blockIdx.x * BLOCK + threadIdx.x) >> 6; ei < n; ei += nwaves) {
+  const int nwaves = gridDim.x * (TB / 64);
+  for (int ei = (blockIdx.x * TB + threadIdx.x) >> 6; ei < n; ei += nwaves) {
     const BfEvent ev = env.bfev[ei];
     const int c = ev.c;
     const double nu = ev.nu;
@@ -1294,6 +1307,7 @@ struct artis_amd_engine {
   // 512 < cells <= 3072: k_rpkt keeps J / nuJ / ffheating in LDS instead of the continuum table (12^3 grid, 912 cells:
   // k_rpkt 292 -> 215 ms; 14^3, 1472 cells: 249 -> 225 ms). ARTIS_AMD_RPKT_EST_OVER_CONT=0: the table wins the LDS.
   bool rpkt_est_over_cont = true;
+  bool dense_cont_lds = true;   // k_bfest_dense reads the continuum table from LDS (nltenebular step 1917 -> 1882 ms); ARTIS_AMD_DENSE_CONTLDS=0
   bool cellest_in_lds = true;  // ARTIS_AMD_CELLEST_LDS=0: every estimator add is a global atomic
   int sort_maxpc_r = 20000;
   int sort_maxpc_t = 600;
@@ -1743,6 +1757,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_TAIL")) e->tail_max = std::max(0, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_TAIL_ALWAYS")) e->tail_always = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_RPKT_EST_OVER_CONT")) e->rpkt_est_over_cont = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_DENSE_CONTLDS")) e->dense_cont_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_CELLEST_LDS")) e->cellest_in_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_R")) e->sort_maxpc_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_T")) e->sort_maxpc_t = std::max(1, std::atoi(b));
@@ -2195,7 +2210,10 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       hipLaunchKernelGGL(k_tail, dim3(nblocks(tail_n * 64)), dim3(BLOCK), 0, s, env, in, next, e->d_stats);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
       if (env.bfev != nullptr) {
-        hipLaunchKernelGGL(k_bfest_dense, dim3(e->ncu * 8), dim3(BLOCK), 0, s, env);
+        if (e->dense_cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX)
+          hipLaunchKernelGGL((k_bfest_dense<true, DENSE_TB>), dim3(e->ncu), dim3(DENSE_TB), 0, s, env);
+        else
+          hipLaunchKernelGGL((k_bfest_dense<false, BLOCK>), dim3(e->ncu * 8), dim3(BLOCK), 0, s, env);
         HIP_TRY(hipMemsetAsync(e->d_bfev_count, 0, sizeof(int32_t), s));
       }
 #endif
@@ -2241,7 +2259,10 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
           hipLaunchKernelGGL((k_rpkt<false>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
         if (env.bfev != nullptr) {  // the estimator updates the launch recorded (the cells' cache rows are still resident)
-          hipLaunchKernelGGL(k_bfest_dense, dim3(e->ncu * 8), dim3(BLOCK), 0, s, env);
+          if (e->dense_cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX)
+            hipLaunchKernelGGL((k_bfest_dense<true, DENSE_TB>), dim3(e->ncu), dim3(DENSE_TB), 0, s, env);
+          else
+            hipLaunchKernelGGL((k_bfest_dense<false, BLOCK>), dim3(e->ncu * 8), dim3(BLOCK), 0, s, env);
           HIP_TRY(hipMemsetAsync(e->d_bfev_count, 0, sizeof(int32_t), s));
         }
 #endif
