@@ -1113,6 +1113,272 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
+// ---- k_thermal_q: the thermal kernel with IN-KERNEL COMPACTION of the macro-atom walkers (ARTIS_AMD_REFILL=0: k_thermal).
+// k_thermal gives a lane one packet and lets it walk for up to ARTIS_MA_PHASE rounds; walks are short on average but
+// heavy-tailed, so most lanes sit out most rounds of a phase (measured: 34.8 of 64 lanes per round, VALU lane utilisation
+// 0.38) while the CU's vector L1 -- the unit that limits the kernel -- is charged per wave INSTRUCTION, not per lane.
+// Here the walk is decoupled from the packet. A wave owns TQ_V (> 64) packets at a time; what a walk needs of a packet is
+// its WALK CONTEXT (generator state, cell, record offset and shape, level, counters: 56 B), kept in the wave's LDS
+// slots, while the packet's hot line rests in HBM. Two phases alternate per wave:
+//   walk:    every lane holds one context in registers and makes one transition per round; a lane whose walk ends writes
+//            (generator, level, action, rate) back to its slot, pushes the slot on the wave's service stack and pops the
+//            next READY slot in the same round (ballot + popcount, like pull()) -- the gather instructions of the
+//            transition loop carry 64 lanes as long as the ready stack has entries;
+//   service: once 64 slots wait (or the walkers run dry), ONE full-wave pass reloads those packets' hot lines, carries
+//            out the process that ended each walk (ma_jump_exit), makes the k-packet step that follows, and either
+//            prepares the next walk (slot READY, hot line stored) or retires the packet (stored, appended to the list of
+//            its next kind) and pulls a new one from the work list into the slot.
+// Per packet the same functions run in the same order on the same per-packet generator as in k_thermal, so packets,
+// generator states and event counters are identical (GPU test); estimator sums differ by summation order only.
+#ifndef ARTIS_TQ_SLOTS
+#define ARTIS_TQ_SLOTS 128
+#endif
+#ifndef ARTIS_TQ_LOW
+#define ARTIS_TQ_LOW 52
+#endif
+#ifndef ARTIS_TQ_BURST
+#define ARTIS_TQ_BURST 1
+#endif
+constexpr int TQ_BURST = ARTIS_TQ_BURST;  // transitions between two hand-outs of slots
+constexpr int TQ_V = ARTIS_TQ_SLOTS;  // slots per wave: 64 walking + a buffer that lets a full service pass fall due before the walkers starve
+static_assert(TQ_V >= 64 && TQ_V <= 256, "slot indices are kept in bytes");
+enum { TQ_EMPTY = -2, TQ_BUDGET = -3 };  // action of a slot on the service stack: no packet | walk interrupted by the launch budget
+struct TQWave {  // SoA: a lane reads field[its slot]
+  uint32_t s0[TQ_V], s1[TQ_V], s2[TQ_V], s3[TQ_V];
+  int32_t pi[TQ_V], c[TQ_V], rec[TQ_V], ndnu[TQ_V], level[TQ_V], units[TQ_V], njumps[TQ_V], action[TQ_V];
+  double rate[TQ_V];
+  uint8_t ready[TQ_V];    // stack of the slots whose walk can go on
+  uint8_t service[TQ_V];  // stack of the slots that wait for the service pass
+};
+__global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal_q(Env env, const int32_t *list, int32_t n, Lists next,
+                                                                           unsigned long long *gstats, int budget, int32_t *cursors,
+                                                                           int nchunks, int chunk_mode, int low_water) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  __shared__ TQWave tq[BLOCK / 64];
+  extern __shared__ double lds_cellest_dyn[];  // [env.cellest_n_t] (models with few cells; 0 bytes otherwise)
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  cellest_begin(env, lds_cellest_dyn, env.cellest_n_t, BLOCK, env.E.colheatingestimator);
+  __syncthreads();
+  env.stats = lstats;
+  const double ts_end = env.S.ts_end;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lanebit = 1ull << lane;
+  TQWave &Q = tq[threadIdx.x >> 6];
+  Puller q;
+  puller_init(q, n, nchunks, chunk_mode);
+  // wave-uniform stack heights; every slot starts empty and waits for a packet
+  int nready = 0, nservice = TQ_V, ndead = 0;
+  for (int i = lane; i < TQ_V; i += 64) {
+    Q.service[i] = (uint8_t)i;
+    Q.action[i] = TQ_EMPTY;
+  }
+  __builtin_amdgcn_wave_barrier();
+#ifdef ARTIS_PROFILE
+  long long tq_t = clock64();  // wave clocks / 16 of the two phases in the spare stats slots 42 (service) and 43 (walk)
+#define TQ_PROF(slot)                                                                   \
+  do {                                                                                  \
+    const long long now = clock64();                                                    \
+    if (lane == 0) atomicAdd(&lstats[slot], (stat_t)((now - tq_t) >> 4));               \
+    tq_t = now;                                                                         \
+  } while (0)
+#else
+#define TQ_PROF(slot) ((void)0)
+#endif
+  while (true) {
+    // ---------------- service passes: while a full wave of slots waits, or the walkers would run short
+    while (nservice >= 64 || (nservice > 0 && nready < low_water)) {
+      const int take = min(64, nservice);
+      const bool has = lane < take;
+      const int s = has ? (int)Q.service[nservice - 1 - lane] : 0;
+      nservice -= take;
+      const int act = has ? Q.action[s] : TQ_EMPTY;
+      const bool isdone = has && act != TQ_EMPTY;
+      const int32_t idx = pull(q, has && !isdone, n, cursors);
+      const bool have = isdone || idx >= 0;
+      int32_t pi = 0;
+      int units = 0;
+      Pkt p;
+      MACtx k;
+      if (have) {
+        pi = isdone ? Q.pi[s] : list[idx];
+        pkt_load_thermal(env.P, pi, p);  // the hot line only
+        k = ma_ctx(env, p);
+        if (isdone) {  // the walk's own state is the slot's
+          p.s0 = Q.s0[s]; p.s1 = Q.s1[s]; p.s2 = Q.s2[s]; p.s3 = Q.s3[s];
+          p.ma_level = Q.level[s];
+          k.rec = Q.rec[s];
+          const int ndnu = Q.ndnu[s];
+          k.nd = ndnu & 0xFFFF;
+          k.nu = ndnu >> 16;
+          k.njumps = Q.njumps[s];
+          units = Q.units[s];
+        }
+      }
+      if (lane == 0) {
+        ARTIS_STAT(env, 47);            // service passes
+        ARTIS_STAT_ADD(env, 44, take);  // ... and the slots they served
+      }
+      int kind = NEXT_DONE;
+      int32_t out_pi = 0;
+      bool walking = false;
+      if (have) {
+        bool go = thermal_can_continue(p, ts_end);
+        if (isdone) {
+          ma_flush_stats(env, k);
+          if (act >= 0) ma_jump_exit(env, p, pi, k, k.cellma + k.rec, act, Q.rate[s]);
+          chi_after_ma(p);
+        }
+        if (go) {
+          // a pre-k-packet, or a k-packet in a grey cell, leaves for the blackbody kernel (classify() below)
+          const bool blackbody = (p.type == ARTIS_TYPE_PRE_KPKT) || k.thick;
+          if (kpkt_eligible(p, ts_end) && !blackbody) {
+            do_kpkt(env, p, pi);
+            p.chi_mgi = -1;
+            units++;
+          }
+          go = thermal_can_continue(p, ts_end) && !(blackbody && kpkt_eligible(p, ts_end));
+        }
+        walking = go && units < budget && ma_pending(p) && p.pend == PEND_NONE;
+        if (walking) ma_prepare<false>(env, p, k);  // the record of the level the walk starts from
+        pkt_store_thermal(env.P, pi, p);  // the hot line; the flight line only if an r-packet was emitted
+        if (walking) {
+          Q.s0[s] = p.s0; Q.s1[s] = p.s1; Q.s2[s] = p.s2; Q.s3[s] = p.s3;
+          Q.pi[s] = pi;
+          Q.c[s] = k.c;
+          Q.rec[s] = k.rec;
+          Q.ndnu[s] = k.nd | (k.nu << 16);
+          Q.level[s] = p.ma_level;
+          Q.units[s] = units;
+          Q.njumps[s] = 0;
+        } else {
+          kind = classify(env, p, ts_end);
+          out_pi = pi;
+        }
+      }
+      append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
+      // where the slots go: READY, or back on the service stack as empty (a packet is pulled into it by the next pass), or --
+      // once the work list is used up -- out of use
+      {
+        const unsigned long long rm = __ballot(walking);
+        if (walking) Q.ready[nready + __popcll(rm & (lanebit - 1ull))] = (uint8_t)s;
+        nready += __popcll(rm);
+        const bool again = has && !walking && !q.exhausted;
+        const unsigned long long em = __ballot(again);
+        if (again) {
+          Q.action[s] = TQ_EMPTY;
+          Q.service[nservice + __popcll(em & (lanebit - 1ull))] = (uint8_t)s;
+        }
+        nservice += __popcll(em);
+        ndead += take - __popcll(rm) - __popcll(em);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    TQ_PROF(42);
+    if (nready == 0) break;  // (then nothing waits for service either: every slot is out of use)
+    // ---------------- walk phase
+    {
+      // in the drain (work list used up) a service pass is worth its cost only for a reasonable share of the live slots
+      const int drain_min = max(1, min(16, (TQ_V - ndead) / 4));
+      int myslot = -1;
+      int units = 0;
+      Pkt w;  // only the generator state and ma_level are live
+      MACtx k;
+      w.ma_level = -1;
+      k.c = 0; k.cellma = nullptr; k.rec = 0; k.nd = k.nu = 0; k.njumps = 0;
+      k.hot = -1; k.start = 0;
+      int prof_rounds = 0, prof_lanes = 0;  // wave-uniform: micro-steps of this phase and the lanes that made one
+      while (true) {
+        {  // lanes without a context pop READY slots
+          const bool need = myslot < 0;
+          const unsigned long long m = __ballot(need);
+          if (m != 0 && nready > 0) {
+            const int takeN = min(__popcll(m), nready);
+            const int prefix = __popcll(m & (lanebit - 1ull));
+            if (need && prefix < takeN) {
+              const int s = (int)Q.ready[nready - 1 - prefix];
+              myslot = s;
+              w.s0 = Q.s0[s]; w.s1 = Q.s1[s]; w.s2 = Q.s2[s]; w.s3 = Q.s3[s];
+              w.ma_level = Q.level[s];
+              k.c = Q.c[s];
+              k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
+              k.rec = Q.rec[s];
+              const int ndnu = Q.ndnu[s];
+              k.nd = ndnu & 0xFFFF;
+              k.nu = ndnu >> 16;
+              k.njumps = Q.njumps[s];
+              units = Q.units[s];
+            }
+            nready -= takeN;
+          }
+        }
+        const int nactive = __popcll(__ballot(myslot >= 0));
+        if (nactive == 0 || nservice >= 64 || (nactive < low_water && nservice >= drain_min)) break;
+        // TQ_BURST transitions without any bookkeeping: the hand-out of slots is paid once per burst, not per transition. A
+        // lane whose walk ends inside a burst idles to its end.
+        bool ended = false;
+        int end_action = 0;
+        double end_rate = 0.;
+#pragma unroll 1
+        for (int b = 0; b < TQ_BURST; b++) {
+          const bool go = myslot >= 0 && !ended;
+          prof_lanes += __popcll(__ballot(go));
+          if (go) {
+            double rate = 0.;
+            const int action = ma_jump_internal<false>(env, w, k, k.cellma + k.rec, &rate);
+            units++;
+            if (action >= 0 || units >= budget) {
+              ended = true;
+              end_action = action >= 0 ? action : TQ_BUDGET;
+              end_rate = rate;
+            }
+          }
+        }
+        prof_rounds += TQ_BURST;
+        const unsigned long long em = __ballot(ended);
+        if (em != 0) {
+          if (ended) {
+            const int s = myslot;
+            Q.s0[s] = w.s0; Q.s1[s] = w.s1; Q.s2[s] = w.s2; Q.s3[s] = w.s3;
+            Q.level[s] = w.ma_level;
+            Q.rec[s] = k.rec;
+            Q.ndnu[s] = k.nd | (k.nu << 16);
+            Q.units[s] = units;
+            Q.njumps[s] = k.njumps;
+            Q.action[s] = end_action;
+            Q.rate[s] = end_rate;
+            Q.service[nservice + __popcll(em & (lanebit - 1ull))] = (uint8_t)s;
+            myslot = -1;
+          }
+          nservice += __popcll(em);
+        }
+      }
+      // park the walks in progress: their slots are READY again
+      const bool parked = myslot >= 0;
+      const unsigned long long pm = __ballot(parked);
+      if (parked) {
+        const int s = myslot;
+        Q.s0[s] = w.s0; Q.s1[s] = w.s1; Q.s2[s] = w.s2; Q.s3[s] = w.s3;
+        Q.level[s] = w.ma_level;
+        Q.rec[s] = k.rec;
+        Q.ndnu[s] = k.nd | (k.nu << 16);
+        Q.units[s] = units;
+        Q.njumps[s] = k.njumps;
+        Q.ready[nready + __popcll(pm & (lanebit - 1ull))] = (uint8_t)s;
+      }
+      nready += __popcll(pm);
+      if (lane == 0) {
+        ARTIS_STAT_ADD(env, 46, prof_rounds);  // wave-rounds of the transition loop
+        ARTIS_STAT_ADD(env, 45, prof_lanes);   // ... and the lanes that made a micro-step in them
+      }
+      __builtin_amdgcn_wave_barrier();
+      TQ_PROF(43);
+    }
+  }
+  __syncthreads();
+  cellest_flush(env, CELLEST_COLHEAT, env.E.colheatingestimator, BLOCK);
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
+}
+
 
 // Tail kernel: the LAST few thousand r-packets and thermal packets of a timestep, one per lane, each carried through
 // r-packet steps, macro-atom walks and k-packet steps until it leaves these kinds (end of the timestep, escape, a
@@ -1325,6 +1591,12 @@ struct artis_amd_engine {
   // HBM without it (measured: k_thermal -3.5 %, populate +25 ms: no net gain)
   bool hot_blocks = false;
   int thermal_blocks_per_cu = ARTIS_THERMAL_WAVES;  // tuning: resident k_thermal blocks per CU
+  // k_thermal_q: walk contexts in per-wave LDS slots, lanes refilled inside the transition loop (ARTIS_AMD_REFILL=0: k_thermal,
+  // one packet per lane and phases of ARTIS_MA_PHASE rounds). refill_low: a wave leaves the transition loop for a service
+  // pass when fewer lanes than this still walk and nothing is READY (ARTIS_AMD_REFILL_LOW).
+  bool thermal_refill = false;
+  int refill_low = ARTIS_TQ_LOW;
+  int refill_minpk = 128;  // packets per wave below which a launch uses fewer waves (ARTIS_AMD_REFILL_MINPK)
   bool trace = false;
   ncclComm_t comm = nullptr;  // created by artis_amd_comm_init(), owned by the engine
 };
@@ -1767,6 +2039,9 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_CONTLDS")) e->cont_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_HOTLDS")) e->hot_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_HOTBLOCKS")) e->hot_blocks = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_REFILL")) e->thermal_refill = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_REFILL_LOW")) e->refill_low = std::max(1, std::min(64, std::atoi(b)));
+  if (const char *b = std::getenv("ARTIS_AMD_REFILL_MINPK")) e->refill_minpk = std::max(64, std::atoi(b));
   e->hot_blocks = e->hot_blocks || e->hot_lds;
   {
     // the static part of every macro-atom record (header, transition targets) is written once; without hot blocks no
@@ -2280,7 +2555,13 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
                              e->d_cursors, chunks_for(nk, grid), 1);
         } else
 #endif
-        {
+        if (e->thermal_refill) {  // in-kernel compaction of the macro-atom walkers (k_thermal_q)
+          // a wave keeps its lanes full only while its slots can be refilled: give every wave several fills' worth of packets
+          const int64_t per_block = (int64_t)e->refill_minpk * (BLOCK / 64);
+          const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nk + per_block - 1) / per_block, (int64_t)e->ncu * e->thermal_blocks_per_cu));
+          hipLaunchKernelGGL(k_thermal_q, dim3(grid), dim3(BLOCK), sizeof(double) * (size_t)env.cellest_n_t, s, env, lst, nk, next, e->d_stats,
+                             e->budget_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8, 0, e->refill_low);
+        } else {
           const int grid = std::min(nblocks(nk), e->ncu * e->thermal_blocks_per_cu);
           const bool per_cu = e->cu_chunks_t && nk >= 256 * 1024;
           hipLaunchKernelGGL((k_thermal<false, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,

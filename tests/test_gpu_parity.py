@@ -447,6 +447,39 @@ def test_tail_kernel_gives_the_split_kernels_packets(engine_mod, oracle, monkeyp
     parity.compare_packets(outs[1][0][:6000], pa, FLOAT_RTOL, "tail kernel vs oracle")
 
 
+@pytest.mark.parametrize("options,gridtype,ncoord", [("classic", abi.GRID_CARTESIAN3D, 8), ("classic", abi.GRID_SPHERICAL1D, 16),
+                                                     ("nltenebular", abi.GRID_CARTESIAN3D, 8)])
+def test_walker_compaction_kernel_gives_the_phase_kernels_packets(engine_mod, oracle, monkeypatch, options, gridtype, ncoord):
+    """k_thermal_q (ARTIS_AMD_REFILL=1): walk contexts in per-wave LDS slots, lanes refilled inside the transition loop,
+    exits / k-packet steps / retires in full-wave service passes. Against k_thermal (the default: one packet per lane,
+    phases of ARTIS_MA_PHASE rounds): identical packets, generator states and counters, estimators to summation order --
+    with a small launch budget too (walks interrupted and resumed) and without the tail kernel (whole population
+    through it); and the oracle's packets."""
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options)
+    pk0 = synth.make_packets(model, aux, 30000, kpkt_fraction=0.3, gamma_fraction=0.05, pellet_fraction=0.05)
+    outs = []
+    for env in ({"ARTIS_AMD_REFILL": "0"}, {"ARTIS_AMD_REFILL": "1"}, {"ARTIS_AMD_REFILL": "1", "ARTIS_AMD_BUDGET_T": "7", "ARTIS_AMD_TAIL": "0"},
+                {"ARTIS_AMD_REFILL": "1", "ARTIS_AMD_REFILL_LOW": "64", "ARTIS_AMD_REFILL_MINPK": "4096"}):
+        for v in ("ARTIS_AMD_REFILL", "ARTIS_AMD_BUDGET_T", "ARTIS_AMD_TAIL", "ARTIS_AMD_REFILL_LOW", "ARTIS_AMD_REFILL_MINPK"):
+            monkeypatch.delenv(v, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = engine_mod.Engine(model, preset=options)
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, options)
+        eng.update_packets(p, e)
+        eng.close()
+        outs.append((p, e))
+    assert outs[1][1].stats[46] > 0, "k_thermal_q did not run"
+    for p, e in outs[1:]:
+        parity.compare_packets(p, outs[0][0], 0.0, "walker compaction vs phase kernel")
+        parity.compare_stats(e, outs[0][1], "walker compaction vs phase kernel")
+        parity.compare_estimators(e, outs[0][1], 1e-11, "walker compaction vs phase kernel")
+    pa, ea = pk0[:6000].copy(), abi.estimators_for(model, options)
+    oracle.update_packets(model, cs, ts, pa, ea, preset=options)
+    parity.compare_packets(outs[1][0][:6000], pa, FLOAT_RTOL, "walker compaction vs oracle")
+
+
 def test_budget_independence_on_device(engine_mod, monkeypatch):
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
     pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.3)
