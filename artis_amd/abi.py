@@ -10,6 +10,7 @@ import ctypes as C
 
 import numpy as np
 
+ABI_VERSION = 3  # artis_amd_abi_version() of the library these ctypes structs describe (include/artis_amd.h)
 NSTATS = 64
 NSCALARS = 11  # ARTIS_SCALAR_* of include/artis_amd.h
 SCALAR_NAMES = ["gamma_dep_discrete", "nt_energy_deposited", "pellet_decays", "gamma_emission", "positron_emission",

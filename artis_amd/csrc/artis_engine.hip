@@ -1733,6 +1733,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;  // optional: artis_amd_comm_count()
   bool ok = false;
 };
 const RcclApi &rccl_api() {
@@ -1754,6 +1755,7 @@ const RcclApi &rccl_api() {
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
     a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
     return a;
   }();
@@ -2699,6 +2701,17 @@ int artis_amd_comm_init(artis_amd_engine *e, int nranks, int rank, const void *i
   ncclUniqueId id;
   std::memcpy(id.internal, id_bytes, ARTIS_AMD_COMM_ID_BYTES);
   RCCL_TRY(rccl_api().CommInitRank(&e->comm, nranks, id, rank));
+  return ARTIS_OK;
+}
+
+int artis_amd_comm_count(artis_amd_engine *e, void *nccl_comm, int *nranks) {
+  if (!e || !nranks) return ARTIS_ERR_ARG;
+  ncclComm_t comm = nccl_comm ? (ncclComm_t)nccl_comm : e->comm;
+  if (!comm || !rccl_api().ok || !rccl_api().CommCount) {
+    g_last_error = "no communicator (artis_amd_comm_init), or librccl without ncclCommCount";
+    return ARTIS_ERR_RCCL;
+  }
+  RCCL_TRY(rccl_api().CommCount(comm, nranks));
   return ARTIS_OK;
 }
 

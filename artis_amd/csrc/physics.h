@@ -2070,6 +2070,9 @@ AHD double possible_event_expopac(const Env &env, int c, Pkt &p, const Chi &x, M
     pz += (p.dz * binedgedist);
     prop_time += binedgedist / CLIGHT_PROP;
     nu_cmf = p.nu_cmf + (dnu_on_dl * dist);
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+    e_cmf = nu_cmf * p.e_rf / p.nu_rf;  // rpkt.cc:306: it seeds the packet copy of the line-by-line retrace
+#endif
 #endif
     if (nu_cmf <= nu_cmf_abort) {
       *is_bb = false;

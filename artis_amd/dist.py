@@ -38,10 +38,13 @@ def allreduce_estimators(block, dist=None):
 def flatten_estimators(est) -> np.ndarray:
     """Host estimators in the engine's block order
     [J | nuJ | ffheating | colheating | gamma | bfheating | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars],
-    followed in nltenebular builds by [radfieldbin_J | radfieldbin_nuJ | bfrate_raw]."""
+    followed in nltenebular builds by [radfieldbin_J | radfieldbin_nuJ | bfrate_raw] and, with detailed line estimators,
+    by [Jb_lu_raw | Jb_lu_contribcount] (the counts as f64, like the engine's device block: one all-reduce covers it)."""
     parts = [est.J, est.nuJ, est.ffheatingestimator, est.colheatingestimator, est.gammaestimator,
              est.bfheatingestimator, est.dep_estimator_gamma, est.dep_estimator_electron,
              est.dep_estimator_positron, est.dep_estimator_alpha, est.scalars]
     if getattr(est, "extended", False):
         parts += [est.radfieldbin_J, est.radfieldbin_nuJ, est.bfrate_raw]
+    if getattr(est, "lineest", False):
+        parts += [est.Jb_lu_raw, est.Jb_lu_contribcount.astype(np.float64)]
     return np.concatenate(parts)

@@ -54,6 +54,8 @@ def load_library(build_if_missing: bool = False, preset: str = "classic"):
     L.artis_amd_estimators_download.argtypes = [C.c_void_p, C.c_void_p]
     L.artis_amd_estimators_devptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     L.artis_amd_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    if L.artis_amd_abi_version() != abi.ABI_VERSION:  # a stale or foreign build would read these ctypes structs with another layout
+        raise EngineError(f"{so}: ABI version {L.artis_amd_abi_version()}, this package describes version {abi.ABI_VERSION}")
     assert L.artis_amd_sizeof_packet() == abi.PACKET_DTYPE.itemsize
     L.artis_amd_options_preset.restype = C.c_char_p
     assert L.artis_amd_options_preset().decode() == preset, (L.artis_amd_options_preset(), preset)
@@ -72,7 +74,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_last_kernel_launches",
     "artis_amd_last_kernel_table",
     "artis_amd_options_preset",
-    "artis_amd_allreduce_estimators", "artis_amd_comm_unique_id", "artis_amd_comm_init",
+    "artis_amd_allreduce_estimators", "artis_amd_comm_unique_id", "artis_amd_comm_init", "artis_amd_comm_count",
     "artis_amd_cache_tiles",
 ]
 
@@ -168,6 +170,13 @@ class Engine:
         self.L.artis_amd_comm_unique_id.argtypes = [C.c_void_p]
         self._check(self.L.artis_amd_comm_unique_id(buf))
         return buf.raw
+
+    def comm_count(self) -> int:
+        """ranks of the engine's communicator as RCCL reports them (ncclCommCount)"""
+        n = C.c_int(0)
+        self.L.artis_amd_comm_count.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        self._check(self.L.artis_amd_comm_count(self.h, None, C.byref(n)))
+        return int(n.value)
 
     def comm_init(self, nranks: int, rank: int, id_bytes: bytes):
         assert len(id_bytes) == self.COMM_ID_BYTES

@@ -56,7 +56,10 @@ W_PER_RPKT_VISIT = 224.0      # hot line + 96 B of the flight line
 W_PER_EMISSION = 120.0
 W_PER_ATOMIC = 8.0            # one f64 estimator add
 W_PER_LIST_ENTRY = 8.0        # (slot, key) appended to a work list
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
+NCU, NSIMD, CLOCK_GHZ = 256, 1024, 2.4   # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+GATHER_INSTR_CLOCKS = 40.0             # CU clocks per 64-lane 16-byte gather instruction out of L2 (profiles/r02/gather_microbench.txt)
+LINE_FILL_CLOCKS = 150.0 / 64          # CU clocks per 128-byte line filled from L2 (profiles/r03/sector_bench.txt)
 
 
 class _CudaArrayView:
@@ -108,7 +111,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--packets", type=int, default=10_000_000, help="packets per GPU")
+    ap.add_argument("--packets", type=int, default=10_000_000, help="packets per GPU (weak scaling: per-GPU work fixed as N grows)")
+    ap.add_argument("--packets-total", type=int, default=0,
+                    help="total packets sharded over the N GPUs with the reference's range rule (BASELINE.json configs[2]: 1e8 over 8); "
+                         "overrides --packets, and the line then says scaling: strong")
     ap.add_argument("--ncoord", type=int, default=50)
     ap.add_argument("--preset", default="w7")
     ap.add_argument("--grid", default="3d", choices=("1d", "2d", "3d"),
@@ -141,7 +147,13 @@ def main():
     gridtype = {"1d": abi.GRID_SPHERICAL1D, "2d": abi.GRID_CYLINDRICAL2D, "3d": abi.GRID_CARTESIAN3D}[args.grid]
     model, cs, ts, aux = synth.build(args.preset, ncoord=args.ncoord, gridtype=gridtype, options=args.options)
     # packet seeds: the reference's per-rank spacing (input.cc:1912: rank_seed_base = seed + rank * npackets)
-    seed_base = (1281360349 + rank * args.packets) & 0xFFFFFFFF
+    if args.packets_total > 0:  # get_range_chunk (mpi_logging.h:158): nearly equal contiguous shares of one global population
+        from artis_amd import dist as adist
+
+        shard_start, args.packets = adist.packet_shard(args.packets_total, world, rank)
+        seed_base = (1281360349 + shard_start) & 0xFFFFFFFF
+    else:
+        seed_base = (1281360349 + rank * args.packets) & 0xFFFFFFFF
     pk = synth.make_packets(model, aux, args.packets, seed_base=seed_base, kpkt_fraction=0.02, seed=99 + rank)
 
     baseline = None
@@ -198,6 +210,7 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     kern_ms, kern_launches = 0.0, 0
+    reduce_events = []  # (start, end) torch events around the estimator all-reduce of every timed step
 
     def one_step(timed: bool):
         nonlocal kern_ms, kern_launches
@@ -206,10 +219,15 @@ def main():
         eng.populate_cellcache(stream)
         eng.step(stream)
         if world > 1:  # [J | nuJ | ffheat | colheat | gamma | bfheat | dep_* | scalars], one in-place sum over the ranks
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()  # on torch's current stream = the stream the library's all-reduce is issued on
             if reduce_via.startswith("artis_amd"):
                 eng.allreduce_estimators(stream)
             else:
                 dist.all_reduce(est_view)
+            ev1.record()
+            if timed:
+                reduce_events.append((ev0, ev1))
         if timed:
             ms, nl = eng.last_kernel_ms()
             kern_ms += ms
@@ -229,10 +247,23 @@ def main():
         one_step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_rank = elapsed
+    rank_ms = [1e3 * elapsed_rank / args.steps]
+    reduce_ms = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        gathered = [None] * world
+        # per rank: wall ms per step, propagation-kernel ms per step, all-reduce ms per step (waiting for the slowest rank included)
+        mine = (1e3 * elapsed_rank / args.steps, kern_ms / max(args.steps, 1),
+                sum(a.elapsed_time(b) for a, b in reduce_events) / max(len(reduce_events), 1))
+        dist.all_gather_object(gathered, mine)
+        rank_ms = [g[0] for g in gathered]
+        reduce_ms = {"per_rank_ms": [round(g[2], 3) for g in gathered], "min_ms": min(g[2] for g in gathered),
+                     "bytes": int(ndoubles) * 8,
+                     "note": "events around the call on each rank; the minimum over ranks is the collective itself, the rest is waiting for the slowest rank"}
+        rank_kernel_ms = [g[1] for g in gathered]
 
     est = abi.estimators_for(model, args.options)
     # counters of the last step (identical every step: packet histories are deterministic)
@@ -294,7 +325,7 @@ def main():
                  "algorithmic_bytes_per_launch": alg[k] / nl,
                  "algorithmic_gbs": alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                  "hbm_bytes_per_launch_measured": None, "hbm_gbs_measured": None, "hbm_frac_measured": None,
-                 "write_amplification": None}
+                 "hbm_gbs_measured_fetch_undoubled": None, "write_amplification": None, "limiter": None}
             if k in tj and ms > 0:
                 t = tj[k]
                 r["hbm_bytes_per_launch_measured"] = t["hbm_bytes_per_launch"]
@@ -302,37 +333,78 @@ def main():
                 gbs = t["hbm_bytes_per_launch"] * nl / (ms * 1e-3) / 1e9
                 r["hbm_gbs_measured"] = gbs
                 r["hbm_frac_measured"] = gbs / HBM_PEAK_GBS
+                if "hbm_bytes_per_launch_fetch_undoubled" in t:  # FETCH_SIZE as counted (the guide's x2 is for wide coalesced reads)
+                    r["hbm_gbs_measured_fetch_undoubled"] = t["hbm_bytes_per_launch_fetch_undoubled"] * nl / (ms * 1e-3) / 1e9
                 r["write_amplification"] = t["write_size_kb"] * 1024.0 / t["dispatches"] * nl / wr[k] if wr[k] > 0 else None
+                c = t.get("counters") or {}
+                if c and t.get("seconds_in_fetch_pass"):
+                    # what the kernel is held by, from the same committed counters (sums over one step's dispatches);
+                    # SQ_* busy counters are in units of 4 clocks
+                    clk = t["seconds_in_fetch_pass"] * CLOCK_GHZ * 1e9  # kernel clocks of the profiled step
+                    lim = {}
+                    if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU"):
+                        lim["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+                        lim["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (NSIMD * clk)
+                    if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+                        lim["wave_wait_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+                    if "SQ_INSTS_VMEM_RD" in c:
+                        ach = c["SQ_INSTS_VMEM_RD"] / (NCU * clk)
+                        lim["issue"] = {"load_instr_per_clk_cu": ach, "ceiling": 1.0 / GATHER_INSTR_CLOCKS,
+                                        "frac": ach * GATHER_INSTR_CLOCKS, "ceiling_source": "tools/gather_bench.hip, 64-lane 16-B gathers out of L2"}
+                    if "TCP_TCC_READ_REQ_sum" in c:
+                        ach = c["TCP_TCC_READ_REQ_sum"] / (NCU * clk)
+                        lim["l1_fill"] = {"read_requests_per_clk_cu": ach, "ceiling": 1.0 / LINE_FILL_CLOCKS,
+                                          "frac": ach * LINE_FILL_CLOCKS, "ceiling_source": "tools/sector_bench.hip, 128-B lines out of L2"}
+                    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+                        lim["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0)
+                    r["limiter"] = lim
             return r
 
         per_kernel = {k: kernel_roofline(k) for k in ("k_thermal", "k_rpkt")}
         d = per_kernel[dominant]
         out = {
             "metric": "packet-steps/sec", "value": value, "unit": "packet-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if args.packets_total > 0 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{geometry} W7-like ejecta, artisoptions_{args.options} physics "
-                                   f"(line-by-line Sobolev + macro-atom + k-packets), {args.packets} packets per GPU, "
-                                   f"synthetic atomic data '{args.preset}' ({model['nlines']} lines, {model['nlevels']} levels, "
+                                   f"(line-by-line Sobolev + macro-atom + k-packets), "
+                                   + (f"{args.packets_total} packets over {world} GPU(s)" if args.packets_total > 0 else f"{args.packets} packets per GPU")
+                                   + f", synthetic atomic data '{args.preset}' ({model['nlines']} lines, {model['nlevels']} levels, "
                                    f"{model['nions']} ions), one timestep at t=20 d (dt/t=0.05)",
                        "options": args.options,
                        "packets_per_gpu": args.packets, "nonempty_cells": int(model["npts_nonempty"]),
                        "packet_steps_per_step": steps_all, "setup_s": round(setup_s, 1),
                        "parallelism": f"packets sharded over {world} GPU(s); estimator all-reduce: {reduce_via}" if world > 1
                        else "1 GPU"},
-            # achieved/frac: ALGORITHMIC bytes (requested by design, cache-served re-reads included) over the kernel's launch
-            # time; hbm_frac_measured: bytes that reached HBM by the rocprofv3 counters over the same time -- the number
-            # north_star's ">= 30 % of HBM roofline" is about
-            "roofline": {"bound": "hbm", "achieved": d["algorithmic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": d["algorithmic_gbs"] / HBM_PEAK_GBS, "traffic": d["hbm_bytes_per_launch_measured"],
+            # achieved / frac / traffic: bytes that REACHED HBM by the committed rocprofv3 counters (2 x FETCH_SIZE + WRITE_SIZE
+            # per launch) over the kernel's launch time measured live with HIP events -- the number north_star's ">= 30 % of
+            # HBM roofline" is about. null when the workload is not the profiled one. The bytes the kernel REQUESTS by design
+            # (most of them served by L1/L2) are algorithmic_gbs: never to be read as an HBM fraction. The kernel is not
+            # HBM-bound: `limiter` holds the measured ratios of what does hold it.
+            "roofline": {"bound": "hbm", "achieved": d["hbm_gbs_measured"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": d["hbm_frac_measured"], "traffic": d["hbm_bytes_per_launch_measured"],
                          "traffic_source": traffic_src, "kernel": dominant,
-                         "hbm_gbs_measured": d["hbm_gbs_measured"], "hbm_frac_measured": d["hbm_frac_measured"],
+                         "hbm_gbs_measured_fetch_undoubled": d["hbm_gbs_measured_fetch_undoubled"],
                          "write_amplification": d["write_amplification"],
                          "launches_per_step": d["launches_per_step"], "kernel_ms_per_step": d["kernel_ms_per_step"],
                          "avg_launch_ms": d["avg_launch_ms"],
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                         "algorithmic_gbs": d["algorithmic_gbs"], "algorithmic_over_hbm_peak": d["algorithmic_gbs"] / HBM_PEAK_GBS,
+                         "measured_limiter": "not HBM: SIMD instruction issue at ~35 of 64 active lanes, the wave's chain of dependent "
+                                             "reads and the CU's memory pipeline meet (profiles/r03/k_thermal_lane_compaction.md)",
+                         "limiter": d["limiter"],
                          "kernels": per_kernel},
         }
+        if world > 1:
+            out["per_rank_ms_per_step"] = {"min": min(rank_ms), "max": max(rank_ms), "all": [round(x, 2) for x in rank_ms]}
+            out["per_rank_kernel_ms_per_step"] = [round(x, 2) for x in rank_kernel_ms]
+            out["allreduce"] = reduce_ms
+            try:
+                out["rccl_nranks"] = eng.comm_count() if reduce_via.startswith("artis_amd") else dist.get_world_size()
+            except Exception as exc:  # noqa: BLE001
+                out["rccl_nranks"] = None
+                print(f"[bench] ncclCommCount not available ({exc})", file=sys.stderr)
         bd.update(ma_transitions=int(S("X_MA_JUMPS")), kpkt_steps=int(S("X_KPKT_STEPS")), rpkt_steps=int(S("X_RPKT_STEPS")))
         out["kernel_breakdown_last_step"] = bd
         if os.environ.get("ARTIS_BENCH_VERBOSE"):

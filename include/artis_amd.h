@@ -501,6 +501,8 @@ int artis_amd_allreduce_estimators(artis_amd_engine *eng, void *nccl_comm, void 
  * engine owns the communicator and destroys it with itself. */
 int artis_amd_comm_unique_id(void *id_out /* ARTIS_AMD_COMM_ID_BYTES */);
 int artis_amd_comm_init(artis_amd_engine *eng, int nranks, int rank, const void *id_bytes);
+/* Number of ranks RCCL itself reports for the communicator (ncclCommCount): what the reduce really spans. */
+int artis_amd_comm_count(artis_amd_engine *eng, void *nccl_comm, int *nranks);
 
 /* Timing of the dominant kernel inside the last artis_amd_update_packets_device
  * call, measured with HIP events on the launch stream. */

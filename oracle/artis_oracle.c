@@ -1755,6 +1755,9 @@ static double get_possible_event_expansion_opacity(Oracle *o, const CellCache *c
     pos[2] += (pkt->dir[2] * binedgedist);
     prop_time += binedgedist / CLIGHT_PROP;
     nu_cmf = pkt->nu_cmf + (dnu_on_dl * dist);
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+    e_cmf = nu_cmf * e_rf / nu_rf; /* rpkt.cc:303-307 */
+#endif
 #endif
     if (nu_cmf <= nu_cmf_abort) {
       *is_bb = 0;

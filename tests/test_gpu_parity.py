@@ -313,6 +313,7 @@ def test_estimator_allreduce_through_the_c_abi(engine_mod):
     ident = eng.comm_unique_id()
     assert len(ident) == 128 and any(ident)
     eng.comm_init(1, 0, ident)
+    assert eng.comm_count() == 1  # ncclCommCount: what bench.py reports as rccl_nranks
     eng.allreduce_estimators()
     import torch
 

@@ -46,7 +46,7 @@ def _worker(rank, world, port, outdir, options):
 import pytest
 
 
-@pytest.mark.parametrize("options", ["classic", "nltenebular"])   # nltenebular: the block carries the bin and bound-free estimators too
+@pytest.mark.parametrize("options", ["classic", "nltenebular", "nltenebular_lineest"])   # nltenebular: the block carries the bin and bound-free estimators too; _lineest: the detailed line estimators
 def test_two_ranks_equal_one(tmp_path, options):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -37,7 +37,15 @@ out = {}
 for k, v in agg.items():
     if k in ("k_thermal", "k_rpkt") and "FETCH_SIZE" in v and "WRITE_SIZE" in v and ndisp[k]:
         out[k] = {"fetch_size_kb": v["FETCH_SIZE"], "write_size_kb": v["WRITE_SIZE"], "dispatches": ndisp[k],
-                  "hbm_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / ndisp[k]}
+                  "hbm_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / ndisp[k],
+                  "hbm_bytes_per_launch_fetch_undoubled": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / ndisp[k],
+                  "seconds_in_fetch_pass": dur[k],
+                  # the raw counters bench.py derives its limiter figures from (sums over the dispatches of one step)
+                  "counters": {c: v[c] for c in ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
+                                                 "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                                                 "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum",
+                                                 "TCP_TOTAL_ACCESSES_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum",
+                                                 "TCC_EA0_RDREQ_32B_sum") if c in v}}
 if out and os.environ.get("PMC_TRAFFIC_JSON"):
     with open(os.environ["PMC_TRAFFIC_JSON"], "w") as f:
         json.dump(out, f, indent=1)
