@@ -10,7 +10,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3  # artis_amd_abi_version() of the library these ctypes structs describe (include/artis_amd.h)
+ABI_VERSION = 4  # artis_amd_abi_version() of the library these ctypes structs describe (include/artis_amd.h)
 NSTATS = 64
 NSCALARS = 11  # ARTIS_SCALAR_* of include/artis_amd.h
 SCALAR_NAMES = ["gamma_dep_discrete", "nt_energy_deposited", "pellet_decays", "gamma_emission", "positron_emission",
@@ -170,18 +170,36 @@ _CELL_FIELDS = [
     ("nt_excitations_stored", C.c_int32, None),
     ("expansionopacities", _F32P, np.float32), ("expansionopacity_planck_cumulative", _F64P, np.float64),
     ("Jb_lu_normed", _F64P, np.float64),
+    ("elem_meanweight", _F32P, np.float32),
 ]
 EXPOPAC_NBINS = 1997
 _CELL_OPTIONAL = ("levelpops", "corrphotoioncoeff", "radfieldbin_W", "radfieldbin_T_R", "nt_frac_ionisation",
                   "nt_frac_excitation", "nt_deposition_rate_density", "nt_eff_ionpot", "nt_prob_num_auger",
                   "nt_ionenfrac_num_auger", "nt_exc_count", "nt_exc_frac_deposition", "nt_exc_ratecoeffperdeposition",
-                  "nt_exc_alltransindex", "nt_excitations_stored", "expansionopacities", "expansionopacity_planck_cumulative", "Jb_lu_normed")
+                  "nt_exc_alltransindex", "nt_excitations_stored", "expansionopacities", "expansionopacity_planck_cumulative", "Jb_lu_normed",
+                  "elem_meanweight")
 NT_NAUGER = 3  # NT_MAX_AUGER_ELECTRONS + 1
 RADFIELDBINCOUNT = 256
 # options presets with the multibin radiation field and the detailed bound-free estimators (artisoptions_nltenebular.h and
 # the three files that differ from it in constants): RADFIELDBINCOUNT of each
 NEBULAR_FAMILY = {"nltenebular": 256, "christinenonthermal": 64, "nltephotospheric": 256, "nltewithoutnonthermal": 512,
-                  "nltenebular_lineest": 256}
+                  "nltenebular_lineest": 256, "ci_nebular": 256, "ci_nebular_limitbfest": 256, "ci_nltephotospheric": 24}
+# The option sets of the reference's CI (tests/setup_*.sh; include/artis_options.h ARTIS_PRESET_CI_*): the setup script, the
+# preset whose host inputs the build needs (what synth.build hands over), and TABLESIZE / MINTEMP / MAXTEMP
+CI_PRESETS = {
+    "ci_kilonova": ("setup_kilonova_2d.sh", "kilonova_lte", (20, 1000.0, 20000.0)),
+    "ci_kilonova_barnes": ("setup_kilonova_2d_barnesthermalisation.sh", "kilonova_lte", (20, 1000.0, 20000.0)),
+    "ci_kilonova_expopac": ("setup_kilonova_2d_expansionopac.sh", "kilonova_expopac", (20, 1000.0, 20000.0)),
+    "ci_kilonova_xcom": ("setup_kilonova_2d_xcomgammaphotoion.sh", "classic_gamma_xcom", (20, 1000.0, 20000.0)),
+    "ci_nebular": ("setup_nebular_1d_3dgrid.sh", "nltenebular", (20, 2000.0, 10000.0)),
+    "ci_nebular_limitbfest": ("setup_nebular_1d_3dgrid_limitbfest.sh", "nltephotospheric", (20, 2000.0, 10000.0)),
+    "ci_nltephotospheric": ("setup_nltephotospheric_dynamic_ion_range_1d_1dgrid.sh", "nltephotospheric", (40, 3500.0, 140000.0)),
+}
+
+
+def inputs_like(options: str) -> str:
+    """the preset whose kind of host inputs (synth.build) an options preset needs"""
+    return CI_PRESETS[options][1] if options in CI_PRESETS else options
 
 
 class CModel(C.Structure):
@@ -342,7 +360,7 @@ def estimators_for(model, options: str = "classic") -> Estimators:
     if options not in NEBULAR_FAMILY:
         return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
     nest = model.d.get("nbfestim") or model["nbfcontinua"]
-    nlines = (model.d.get("detailed_linecount") or 0) if options.endswith("_lineest") else 0
+    nlines = (model.d.get("detailed_linecount") or 0) if options.endswith("_lineest") else 0  # (no CI option set has them)
     return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"], nest, NEBULAR_FAMILY[options], nlines)
 
 

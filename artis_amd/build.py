@@ -22,7 +22,10 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp
 
 PRESETS = ("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal", "nltenebular_lineest", "kilonova_barnes", "kilonova_wollaeger", "kilonova_gammaproducts",
            "kilonova_gamma_barnes", "kilonova_gamma_wollaeger", "kilonova_gamma_guttman", "kilonova_gamma_grey", "classic_gamma_xcom",
-           "kilonova_expopac", "classic_expopac_therm")  # options presets of include/artis_options.h (the reference's artisoptions_*.h)
+           "kilonova_expopac", "classic_expopac_therm",
+           # the option sets of the reference's CI (tests/setup_*.sh)
+           "ci_kilonova", "ci_kilonova_barnes", "ci_kilonova_expopac", "ci_kilonova_xcom", "ci_nebular", "ci_nebular_limitbfest",
+           "ci_nltephotospheric")  # options presets of include/artis_options.h (the reference's artisoptions_*.h)
 
 
 def so_path(preset: str = "classic") -> str:
@@ -45,7 +48,7 @@ def build(force: bool = False, extra_flags=(), preset: str = "classic") -> str:
     if not force and not needs_build(preset):
         return so
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    pflags = [] if preset == "classic" else [f"-DARTIS_PRESET_{preset.upper()}"]
+    pflags = [] if preset == "classic" else [f"-DARTIS_PRESET_{preset.upper()}", f'-DARTIS_PRESET_NAME="{preset}"']
     cmd = [hipcc, *FLAGS, *pflags, *extra_flags, "-o", so, os.path.join(CSRC, "artis_engine.hip")]
     subprocess.check_call(cmd)
     return so

@@ -1774,9 +1774,11 @@ const RcclApi &rccl_api() {
 extern "C" {
 
 const char *artis_amd_last_error(void) { return g_last_error.c_str(); }
-int artis_amd_abi_version(void) { return 3; }
+int artis_amd_abi_version(void) { return 4; }
 const char *artis_amd_options_preset(void) {
-#if defined(ARTIS_PRESET_NLTENEBULAR_LINEEST)
+#if defined(ARTIS_PRESET_NAME)  // given by the build (artis_amd/build.py): the presets of the reference's CI option sets
+  return ARTIS_PRESET_NAME;
+#elif defined(ARTIS_PRESET_NLTENEBULAR_LINEEST)
   return "nltenebular_lineest";
 #elif defined(ARTIS_PRESET_CHRISTINENONTHERMAL)
   return "christinenonthermal";
@@ -2128,6 +2130,10 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
     return ARTIS_ERR_ARG;
   }
   e->expopac_own = false;
+  if (ARTIS_OPT_USE_CALCULATED_MEANATOMICWEIGHT && (ARTIS_OPT_USE_XCOM_GAMMAPHOTOION || ARTIS_OPT_NT_ON) && !e->C.elem_meanweight) {
+    g_last_error = "this build has USE_CALCULATED_MEANATOMICWEIGHT and reads element number densities: artis_cellstate.elem_meanweight is required";
+    return ARTIS_ERR_ARG;
+  }
   if (ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON && !e->C.Jb_lu_normed) {
     g_last_error = "this build has DETAILED_LINE_ESTIMATORS_ON: artis_cellstate.Jb_lu_normed is required";
     return ARTIS_ERR_ARG;

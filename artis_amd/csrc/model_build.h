@@ -139,7 +139,8 @@ struct ModelOwned {
   X(nt_exc_alltransindex, int32_t, ((int64_t)(m).npts_nonempty * (nt_stored)))                      \
   X(expansionopacities, float, ((int64_t)(m).npts_nonempty * ARTIS_EXPOPAC_NBINS))                  \
   X(expansionopacity_planck_cumulative, double, ((int64_t)(m).npts_nonempty * ARTIS_EXPOPAC_NBINS)) \
-  X(Jb_lu_normed, double, ((int64_t)(m).npts_nonempty * (m).detailed_linecount))
+  X(Jb_lu_normed, double, ((int64_t)(m).npts_nonempty * (m).detailed_linecount))            \
+  X(elem_meanweight, float, ((int64_t)(m).npts_nonempty * (m).nelements))
 
 // X(field, element type, elements per cell) for every array of DevCache
 #define ARTIS_CACHE_ARRAYS(X, m)                                \
@@ -365,6 +366,7 @@ inline DevCells make_host_cells_view(const artis_cellstate &c) {
   v.expansionopacities = c.expansionopacities;
   v.expansionopacity_planck_cumulative = c.expansionopacity_planck_cumulative;
   v.Jb_lu_normed = c.Jb_lu_normed;
+  v.elem_meanweight = c.elem_meanweight;
   return v;
 }
 

@@ -1028,7 +1028,12 @@ AHD void populate_corrphotoion(const Env &env, int c, int ul, int t) {
 }
 #if ARTIS_OPT_NT_ON || ARTIS_OPT_USE_XCOM_GAMMAPHOTOION
 AHD double elem_numberdens(const DevModel &M, const DevCells &C, int c, int element) {  // grid.cc:1693
-  return C.elem_massfracs[((int64_t)c * M.nelements) + element] / (double)M.elem_meannucmass[element] * C.rho[c];
+#if ARTIS_OPT_USE_CALCULATED_MEANATOMICWEIGHT  // grid::get_element_meanweight grid.cc:1509: the cell's own mean weight of the element
+  const float mu = C.elem_meanweight[((int64_t)c * M.nelements) + element];
+#else
+  const float mu = M.elem_meannucmass[element];
+#endif
+  return C.elem_massfracs[((int64_t)c * M.nelements) + element] / (double)mu * C.rho[c];
 }
 #endif
 #if ARTIS_OPT_NT_ON

@@ -209,6 +209,7 @@ struct DevCells {
   const float *expansionopacities;
   const double *expansionopacity_planck_cumulative;
   const double *Jb_lu_normed;  // [cell][detailed_linecount] normalised line intensities of the previous timestep
+  const float *elem_meanweight;  // [cell][nelements] mean atomic weights (USE_CALCULATED_MEANATOMICWEIGHT builds), else null
 };
 
 struct DevCache {

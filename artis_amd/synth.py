@@ -291,7 +291,7 @@ def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fr
             ion_ncoolingterms[ui] = len(cl_type) - ion_coolingoffset[ui]
 
     # ---- temperature LUTs (ratecoeff.cc:143 precalculate_rate_coefficient_integrals), simple quadrature
-    TABLESIZE, MINTEMP, MAXTEMP = OPTION_TABLES[options]
+    TABLESIZE, MINTEMP, MAXTEMP = abi.CI_PRESETS[options][2] if options in abi.CI_PRESETS else OPTION_TABLES[options]
     T_step_log = (np.log(MAXTEMP) - np.log(MINTEMP)) / (TABLESIZE - 1.0)
     Tgrid = (MINTEMP * np.exp(np.arange(TABLESIZE) * T_step_log)).astype(np.float32).astype(np.float64)
     spont = np.zeros((nbfcontinua, TABLESIZE))
@@ -654,9 +654,16 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     md["rho_tmin"] = (np.asarray(cells["rho"], dtype=np.float64) * (aux["t"] / grid["tmin"]) ** 3).astype(np.float32)  # grid::get_rho_tmin
     md["mtot_input"] = float(m_cell.sum())
     md["ejecta_kinetic_energy"] = float((0.5 * m_cell * aux["v"] ** 2).sum())
-    if options == "classic_gamma_xcom":
+    like = abi.inputs_like(options)
+    if like == "classic_gamma_xcom":
         md.update(nonthermal_model_inputs(atomic))     # element masses for the number densities
         md.update(xcom_tables(atomic))
+    if options == "ci_kilonova_xcom":
+        # USE_CALCULATED_MEANATOMICWEIGHT (artisoptions_kilonova_lte.h:120): grid::elem_meanweight_allcells, the mean weight
+        # of each element's isotope mix in each cell (here: the stable mean scattered by a few per cent from cell to cell)
+        rng = np.random.default_rng(seed + 600)
+        amass = np.asarray(md["elem_meannucmass"], dtype=np.float64)
+        cells["elem_meanweight"] = (amass[None, :] * rng.uniform(0.97, 1.05, (grid["npts_nonempty"], len(amass)))).astype(np.float32).ravel()
     model = abi.Model(md)
     if "expopac" in options and host_expopac:
         cells.update(expansion_opacity_cellstate(cells, grid["npts_nonempty"], seed=seed + 400))
@@ -676,7 +683,7 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
             jb *= rng.uniform(0.3, 3.0, jb.shape)
             md.update(detailed_lineindices=idx, detailed_linecount=len(idx))
             cells["Jb_lu_normed"] = jb.ravel()
-        if options == "nltephotospheric":
+        if like == "nltephotospheric":
             # LEVEL_HAS_BFEST (artisoptions_nltephotospheric_dynamic_ion_range.h:80): estimators for the lowest levels only;
             # globals::allcont.bfestimindex is the running count over the continua that have one (input.cc:932-947)
             has = np.asarray(atomic["allcont_level"]) <= 3

@@ -361,6 +361,10 @@ typedef struct artis_cellstate {
   /* [npts_nonempty*detailed_linecount] radfield.cc prev_Jb_lu_normed[].value: the normalised line intensities of the previous
    * timestep, what get_Jb_lu() returns (builds with DETAILED_LINE_ESTIMATORS_ON) */
   const double *Jb_lu_normed;
+  /* [npts_nonempty*nelements] grid::elem_meanweight_allcells (grid.cc:1509): the mean atomic weight [g] of each element in
+   * each cell; read for the element number densities (XCOM photoelectric opacities, non-thermal channels) by builds with
+   * USE_CALCULATED_MEANATOMICWEIGHT (kilonova_lte and its variants); NULL elsewhere (ABI 4) */
+  const float *elem_meanweight;
 } artis_cellstate;
 
 typedef struct artis_timestep {
@@ -432,7 +436,7 @@ typedef struct artis_amd_engine artis_amd_engine;
 #define ARTIS_ERR_RCCL (-6)
 
 const char *artis_amd_last_error(void);
-int artis_amd_abi_version(void); /* 3: cell state and estimators of the nltenebular options appended */
+int artis_amd_abi_version(void); /* 4: artis_cellstate.elem_meanweight appended (3: cell state and estimators of the nltenebular options) */
 /* Name of the options preset the library was compiled with (include/artis_options.h): "classic" or "kilonova_lte".
  * Like the reference, one binary per artisoptions.h. */
 const char *artis_amd_options_preset(void);

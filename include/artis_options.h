@@ -19,6 +19,56 @@
 #define ARTIS_PARTICLE_BARNES 4
 #define ARTIS_PARTICLE_WOLLAEGER 5
 
+/* ---- The option sets the reference's own CI runs (tests/setup_*.sh: an options file + sed edits). Each is pinned option by
+ * option against the file the script makes (oracle/Makefile target `ref`: the script's own sed lines applied to a scratch
+ * copy under oracle/_ref/, compiled with oracle/ref_harness/ref_options_main.cc; tests/golden/options_reference.json).
+ *   -DARTIS_PRESET_CI_KILONOVA             setup_kilonova_1d.sh, setup_kilonova_2d.sh: kilonova_lte, TABLESIZE 20, 1000-20000 K
+ *   -DARTIS_PRESET_CI_KILONOVA_BARNES      setup_kilonova_2d_barnesthermalisation.sh: + PARTICLE and GAMMA thermalisation BARNES
+ *   -DARTIS_PRESET_CI_KILONOVA_EXPOPAC     setup_kilonova_2d_expansionopac.sh: + RPKT_USE_EXPANSION_OPACITIES,
+ *                                          RPKT_BOUNDBOUND_THERMALISATION_PROBABILITY = 1. (rpkt.cc:626 draws no random number then)
+ *   -DARTIS_PRESET_CI_KILONOVA_XCOM        setup_kilonova_2d_xcomgammaphotoion.sh: + USE_XCOM_GAMMAPHOTOION (element number
+ *                                          densities from the per-cell mean atomic weights: artis_cellstate.elem_meanweight)
+ *   -DARTIS_PRESET_CI_NEBULAR              setup_nebular_1d_3dgrid.sh: nltenebular, TABLESIZE 20, 2000-10000 K,
+ *                                          FIRST_NLTE_RADFIELD_TIMESTEP 7
+ *   -DARTIS_PRESET_CI_NEBULAR_LIMITBFEST   setup_nebular_1d_3dgrid_limitbfest.sh: + LEVEL_HAS_BFEST for the NLTE levels only
+ *   -DARTIS_PRESET_CI_NLTEPHOTOSPHERIC     setup_nltephotospheric_dynamic_ion_range_1d_1dgrid.sh: TABLESIZE 40,
+ *                                          FIRST_NLTE_RADFIELD_TIMESTEP 4, RADFIELDBINCOUNT 24 */
+#if defined(ARTIS_PRESET_CI_KILONOVA) || defined(ARTIS_PRESET_CI_KILONOVA_BARNES) || defined(ARTIS_PRESET_CI_KILONOVA_EXPOPAC) || \
+    defined(ARTIS_PRESET_CI_KILONOVA_XCOM)
+#define ARTIS_PRESET_KILONOVA_LTE
+#define ARTIS_OPT_TABLESIZE 20
+#define ARTIS_OPT_MINTEMP 1000.
+#define ARTIS_OPT_MAXTEMP 20000.
+#endif
+#ifdef ARTIS_PRESET_CI_KILONOVA_BARNES
+#define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_BARNES
+#define ARTIS_OPT_GAMMA_THERMALISATION_SCHEME 1
+#endif
+#ifdef ARTIS_PRESET_CI_KILONOVA_EXPOPAC
+#define ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES 1
+#define ARTIS_OPT_RPKT_BB_THERMALISATION 1
+#define ARTIS_OPT_RPKT_BB_THERMALISATION_PROBABILITY 1.f
+#endif
+#ifdef ARTIS_PRESET_CI_KILONOVA_XCOM
+#define ARTIS_OPT_USE_XCOM_GAMMAPHOTOION 1
+#endif
+#if defined(ARTIS_PRESET_CI_NEBULAR) || defined(ARTIS_PRESET_CI_NEBULAR_LIMITBFEST)
+#define ARTIS_PRESET_NLTENEBULAR
+#define ARTIS_OPT_TABLESIZE 20
+#define ARTIS_OPT_MINTEMP 2000.
+#define ARTIS_OPT_MAXTEMP 10000.
+#define ARTIS_OPT_FIRST_NLTE_RADFIELD_TIMESTEP 7
+#endif
+#ifdef ARTIS_PRESET_CI_NEBULAR_LIMITBFEST
+#define ARTIS_OPT_BFEST_SUBSET 1
+#endif
+#ifdef ARTIS_PRESET_CI_NLTEPHOTOSPHERIC
+#define ARTIS_PRESET_NLTEPHOTOSPHERIC
+#define ARTIS_OPT_TABLESIZE 40
+#define ARTIS_OPT_FIRST_NLTE_RADFIELD_TIMESTEP 4
+#define ARTIS_OPT_RADFIELDBINCOUNT 24
+#endif
+
 /* -DARTIS_PRESET_KILONOVA_BARNES / _WOLLAEGER: artisoptions_kilonova_lte.h with the analytic thermalisation efficiency of
  * Barnes et al. (2016) or Wollaeger et al. (2018) instead of the local time-dependent scheme (update_packets.cc:69-88).
  * No options file of the reference selects them; built so that every branch of do_nonthermal_predeposit() is covered. */
@@ -92,12 +142,14 @@
 #define ARTIS_OPT_NU_MAX_R 5e16                       /* :57 */
 #define ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION 0    /* :59 */
 #define ARTIS_OPT_DIRECT_COL_HEAT 1                   /* :37 */
+#ifndef ARTIS_OPT_TABLESIZE
 #define ARTIS_OPT_TABLESIZE 200                       /* :42 */
 #define ARTIS_OPT_MINTEMP 500.                        /* :43 */
 #define ARTIS_OPT_MAXTEMP 150000.                     /* :44 */
+#endif
 #define ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT 1    /* :118 */
-#define ARTIS_OPT_USE_CALCULATED_MEANATOMICWEIGHT 1   /* :120 (on the packet path only the XCOM opacities and the NT_ON
-                                                       * channels read element number densities; this preset has neither) */
+#define ARTIS_OPT_USE_CALCULATED_MEANATOMICWEIGHT 1   /* :120 (on the packet path only the XCOM opacities and the NT_ON channels
+                                                       * read element number densities: artis_cellstate.elem_meanweight) */
 #ifndef ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME
 #define ARTIS_OPT_PARTICLE_THERMALISATION_SCHEME ARTIS_PARTICLE_TIMEDEPENDENT /* :146 */
 #endif
@@ -134,7 +186,10 @@
 #endif
 #ifdef ARTIS_PRESET_NLTEPHOTOSPHERIC
 #define ARTIS_PRESET_NLTENEBULAR
-#define ARTIS_OPT_MINTEMP 3500.                       /* artisoptions_nltephotospheric_dynamic_ion_range.h:46 */
+#ifndef ARTIS_OPT_TABLESIZE
+#define ARTIS_OPT_TABLESIZE 100                       /* artisoptions_nltephotospheric_dynamic_ion_range.h:45 */
+#endif
+#define ARTIS_OPT_MINTEMP 3500.                       /* :46 */
 #define ARTIS_OPT_MAXTEMP 140000.                     /* :47 */
 #define ARTIS_OPT_BFEST_SUBSET 1                      /* :80 LEVEL_HAS_BFEST: only some continua have an estimator */
 #endif
@@ -185,7 +240,9 @@
 #ifndef ARTIS_OPT_RADFIELDBINCOUNT
 #define ARTIS_OPT_RADFIELDBINCOUNT 256
 #endif
+#ifndef ARTIS_OPT_FIRST_NLTE_RADFIELD_TIMESTEP
 #define ARTIS_OPT_FIRST_NLTE_RADFIELD_TIMESTEP 12
+#endif
 #define ARTIS_OPT_RADFIELDBINS_NU_MIN (2.99792458e+10 / 40000e-8)
 #ifndef ARTIS_OPT_RADFIELDBINS_NU_MAX
 #define ARTIS_OPT_RADFIELDBINS_NU_MAX (2.99792458e+10 / 1085e-8)
@@ -277,7 +334,12 @@
 #ifndef ARTIS_OPT_NT_ON
 #define ARTIS_OPT_NT_ON 0                           /* artisoptions_classic.h:100 */
 #endif
-#define ARTIS_OPT_VPKT_ON 0                         /* artisoptions_classic.h:50 */
+#ifndef ARTIS_OPT_VPKT_ON
+#define ARTIS_OPT_VPKT_ON 0                         /* artisoptions_classic.h:49 */
+#endif
+#ifndef ARTIS_OPT_VPKT_USE_EXPANSION_OPACITIES
+#define ARTIS_OPT_VPKT_USE_EXPANSION_OPACITIES 0    /* artisoptions_classic.h:138 */
+#endif
 /* gamma packets: the classic choices (artisoptions_classic.h:144-150) are the ones built */
 #ifndef ARTIS_OPT_USE_XCOM_GAMMAPHOTOION
 #define ARTIS_OPT_USE_XCOM_GAMMAPHOTOION 0            /* artisoptions_classic.h:144: Veigele fit for the photoelectric opacity */
@@ -299,8 +361,5 @@
 /* kpkt.cc:51 kpktdiffusion_timestep_fraction (a float in the reference) */
 #define ARTIS_KPKTDIFFUSION_TIMESTEP_FRACTION 0.001f
 
-#if ARTIS_OPT_NT_ON && ARTIS_OPT_USE_CALCULATED_MEANATOMICWEIGHT
-#error "NT_ON reads element number densities from the static mean nuclear masses (artis_model.elem_meannucmass); per-cell mean atomic weights are not in the ABI"
-#endif
 
 #endif

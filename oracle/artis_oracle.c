@@ -726,7 +726,12 @@ static double get_nnion(const Oracle *o, int c, int element, int ion) {
 #if ARTIS_OPT_NT_ON || ARTIS_OPT_USE_XCOM_GAMMAPHOTOION
 /* grid::get_elem_numberdens grid.cc:1693 (float mass fraction / double(float mean weight) * float rho) */
 static double get_elem_numberdens(const Oracle *o, int c, int element) {
-  return o->cs->elem_massfracs[((ptrdiff_t)c * o->m->nelements) + element] / (double)o->m->elem_meannucmass[element] * o->cs->rho[c];
+#if ARTIS_OPT_USE_CALCULATED_MEANATOMICWEIGHT /* grid::get_element_meanweight grid.cc:1509-1515 */
+  const float mu = o->cs->elem_meanweight[((ptrdiff_t)c * o->m->nelements) + element];
+#else
+  const float mu = o->m->elem_meannucmass[element];
+#endif
+  return o->cs->elem_massfracs[((ptrdiff_t)c * o->m->nelements) + element] / (double)mu * o->cs->rho[c];
 }
 #endif
 #if ARTIS_OPT_NT_ON

@@ -686,6 +686,32 @@ def test_deferred_bound_free_estimators_equal_in_place(engine_mod, oracle, monke
     parity.compare_estimators(e1, ea, EST_RTOL, "nltenebular, w7 atomic data: HIP engine vs oracle")
 
 
+@pytest.mark.parametrize("options", sorted(abi.CI_PRESETS))
+def test_engine_matches_oracle_reference_ci_option_sets(engine_mod, oracle, options):
+    """the engine built for each option COMBINATION the reference's CI runs (tests/setup_*.sh -> presets ci_*; see
+    tests/test_kernel_bodies_vs_oracle.py::test_reference_ci_option_sets_bit_exact), on the grid type that set-up uses,
+    all packet types, against the oracle built with the same options"""
+    from test_kernel_bodies_vs_oracle import ci_case
+
+    model, cs, ts, aux = ci_case(options)
+    pk0 = synth.make_packets(model, aux, 16000, kpkt_fraction=0.15, gamma_fraction=0.2, pellet_fraction=0.3)
+    pa, pb = pk0.copy(), pk0.copy()
+    ea, eb = abi.estimators_for(model, options), abi.estimators_for(model, options)
+    oracle.update_packets(model, cs, ts, pa, ea, preset=options)
+    eng = engine_mod.Engine(model, preset=options)
+    eng.set_cellstate(cs, ts)
+    eng.update_packets(pb, eb)
+    rep = parity.compare_packets(pb, pa, FLOAT_RTOL, options + ": HIP engine vs oracle")
+    parity.compare_stats(eb, ea, options + ": HIP engine vs oracle", same_libm=False)
+    parity.compare_estimators(eb, ea, EST_RTOL, options + ": HIP engine vs oracle")
+    assert eb.stats[abi.STAT_X_RPKT_STEPS] > 10000
+    if options == "ci_kilonova_xcom":  # a cell state without the per-cell mean atomic weights is refused
+        with pytest.raises(engine_mod.EngineError):
+            eng.set_cellstate(abi.CellState({k: v for k, v in cs.d.items() if k != "elem_meanweight"}), ts)
+    print(f"worst float rel diff {rep['worst_rel']:.3e}")
+    eng.close()
+
+
 @pytest.mark.parametrize("options", ["classic", "kilonova_lte", "nltenebular"])
 def test_full_size_properties_50cubed_1e7_packets(engine_mod, options):
     """BASELINE.json's bench configuration itself (50^3 cells, w7 atomic data, 1e7 packets; configs[1] with the classic

@@ -471,3 +471,53 @@ def test_detailed_line_estimators_bit_exact(oracle, gridtype, ncoord):
     pc, ec = pk0.copy(), abi.estimators_for(model, "nltenebular")
     oracle.update_packets(model, cs, ts, pc, ec, preset="nltenebular")
     assert not np.array_equal(pc["nu_cmf"], pa["nu_cmf"])
+
+
+# grid type each of the reference's CI set-ups runs on (tests/setup_<script>.sh: the model it links and GRID_TYPE_OVERRIDE)
+CI_GRIDS = {"ci_kilonova": (abi.GRID_CYLINDRICAL2D, 6), "ci_kilonova_barnes": (abi.GRID_CYLINDRICAL2D, 6),
+            "ci_kilonova_expopac": (abi.GRID_CYLINDRICAL2D, 6), "ci_kilonova_xcom": (abi.GRID_CYLINDRICAL2D, 6),
+            "ci_nebular": (abi.GRID_CARTESIAN3D, 8), "ci_nebular_limitbfest": (abi.GRID_CARTESIAN3D, 8),
+            "ci_nltephotospheric": (abi.GRID_SPHERICAL1D, 16)}
+
+
+def ci_case(options):
+    """model, cell state, timestep and a population of every packet type for one of the reference's CI option sets, with
+    what the set's physics needs to be exercised (a light, fast ejecta for the Barnes efficiencies)"""
+    gridtype, ncoord = CI_GRIDS[options]
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options, nts=13)
+    if options == "ci_kilonova_barnes":
+        mtot = 5.0e-3 * 1.98855e33
+        model = abi.Model({**model.d, "mtot_input": mtot, "ejecta_kinetic_energy": 0.5 * mtot * (0.2 * 2.99792458e10) ** 2})
+        cs = abi.CellState({**cs.d, "rho": cs.d["rho"] * 1e-4})
+    return model, cs, ts, aux
+
+
+@pytest.mark.parametrize("options", sorted(abi.CI_PRESETS))
+def test_reference_ci_option_sets_bit_exact(oracle, options):
+    """The option COMBINATIONS the reference's own CI runs (tests/setup_*.sh; presets ci_* of include/artis_options.h, each
+    pinned against the options file its script makes): kilonova_lte on the 20-point 1000-20000 K tables, with particle AND
+    gamma thermalisation after Barnes, with expansion opacities and thermalisation probability 1 (no random number drawn
+    at rpkt.cc:626), with XCOM photoelectric opacities over per-cell mean atomic weights; nltenebular on its CI tables with
+    FIRST_NLTE_RADFIELD_TIMESTEP 7, and with bound-free estimators for a subset of the levels; nltephotospheric with 24
+    radiation-field bins. On the grid type the CI set-up uses; all packet types."""
+    model, cs, ts, aux = ci_case(options)
+    pk0 = synth.make_packets(model, aux, 4000, kpkt_fraction=0.15, gamma_fraction=0.2, pellet_fraction=0.3)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, options + ": kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, options + ": kernel bodies vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, options + ": kernel bodies vs oracle")
+    st = ea.stats_dict()
+    assert st["X_RPKT_STEPS"] > 3000
+    if options == "ci_kilonova_barnes":
+        esc = pa[pa["type"] == abi.TYPE_ESCAPE]
+        assert np.count_nonzero(np.isin(esc["escape_type"], [21, 22, 23])) > 30      # particles that left without thermalising
+        gam = pk0["type"] == abi.TYPE_GAMMA
+        assert st["X_GAMMA_STEPS"] <= np.count_nonzero(gam) + np.count_nonzero(pk0["type"] == abi.TYPE_RADIOACTIVE_PELLET)  # one call each: deposited or gone, no transport
+    if options == "ci_kilonova_expopac":
+        assert st["MA_STAT_ACTIVATION_BB"] == 0 and st["X_LINES_VISITED"] == 0        # thermalisation, never a macro-atom; no line walk
+    if options == "ci_kilonova_xcom":
+        assert st["X_GAMMA_STEPS"] > 1000
+    if options in abi.NEBULAR_FAMILY:
+        assert ea.radfieldbin_J.size == model["npts_nonempty"] * abi.NEBULAR_FAMILY[options] and ea.radfieldbin_J.sum() > 0
+    if options in ("ci_nebular_limitbfest", "ci_nltephotospheric"):
+        assert 0 < model["nbfestim"] < model["nbfcontinua"] and np.count_nonzero(ea.bfrate_raw) > 50

@@ -403,7 +403,7 @@ def test_planck_function_integrals_unittests_cc_254(oracle):
 
 
 @pytest.mark.parametrize("preset", ["classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric",
-                                    "nltewithoutnonthermal"])
+                                    "nltewithoutnonthermal", *abi.CI_PRESETS])  # ci_*: the option sets of the reference's CI scripts
 def test_options_presets_match_reference_option_files(preset, tmp_path):
     """include/artis_options.h against the reference's own artisoptions_<preset>.h, all six files: every compile-time
     option the packet path reads (39 of them: grids of the rate-coefficient tables, frequency limits, scattering and polarisation switches,
@@ -419,7 +419,7 @@ def test_options_presets_match_reference_option_files(preset, tmp_path):
     flags = [] if preset == "classic" else [f"-DARTIS_PRESET_{preset.upper()}"]
     subprocess.check_call(["gcc", *flags, "-o", exe, os.path.join(HERE, "options_printer.c")], cwd=root)
     got = dict(line.split() for line in subprocess.check_output([exe], text=True).strip().splitlines())
-    assert len(want) >= 39 and set(got) == set(want)
+    assert len(want) >= 41 and set(got) == set(want)
     for name, val in want.items():
         assert got[name] == val, f"{preset}: {name} = {got[name]}, reference {val}"
 
