@@ -120,8 +120,10 @@ def test_one_library_per_options_preset():
     library; each reports the preset it was compiled with and exports the same C-ABI."""
     from artis_amd.build import PRESETS, build as build_preset, so_path
     from artis_amd.engine import EXPORTED_SYMBOLS
-    assert set(PRESETS) == {"classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal", "nltenebular_lineest", "kilonova_barnes", "kilonova_wollaeger", "kilonova_gammaproducts", "kilonova_gamma_barnes", "kilonova_gamma_wollaeger", "kilonova_gamma_guttman", "kilonova_gamma_grey", "classic_gamma_xcom", "kilonova_expopac",
-                            "classic_expopac_therm"}
+    assert set(PRESETS) == {"classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal",
+                            "nltenebular_lineest", "kilonova_barnes", "kilonova_wollaeger", "kilonova_gammaproducts", "kilonova_gamma_barnes",
+                            "kilonova_gamma_wollaeger", "kilonova_gamma_guttman", "kilonova_gamma_grey", "classic_gamma_xcom", "kilonova_expopac",
+                            "classic_expopac_therm", *abi.CI_PRESETS}
     for preset in PRESETS:
         L = C.CDLL(build_preset(preset=preset))
         assert os.path.samefile(build_preset(preset=preset), so_path(preset))
