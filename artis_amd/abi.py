@@ -10,7 +10,8 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4  # artis_amd_abi_version() of the library these ctypes structs describe (include/artis_amd.h)
+STAT_X_VPKT_CREATED = 48  # then _ESC_RPKT, _ESC_KPKT, _ESC_MA (include/artis_amd.h ARTIS_STAT_X_VPKT_*)
+ABI_VERSION = 5  # artis_amd_abi_version() of the library these ctypes structs describe (include/artis_amd.h)
 NSTATS = 64
 NSCALARS = 11  # ARTIS_SCALAR_* of include/artis_amd.h
 SCALAR_NAMES = ["gamma_dep_discrete", "nt_energy_deposited", "pellet_decays", "gamma_emission", "positron_emission",
@@ -146,10 +147,24 @@ _MODEL_FIELDS = [
     ("rho_tmin", _F32P, np.float32),
     ("xcom_elem_start", _I32P, np.int32), ("xcom_energy", _F64P, np.float64), ("xcom_sigma", _F64P, np.float64),
     ("detailed_lineindices", _I32P, np.int32), ("detailed_linecount", C.c_int32, None),
+    # optional: the virtual-packet configuration (vpkt.txt as read_vpktparameterfile() leaves it; builds with VPKT_ON)
+    ("vpkt_nobsdirections", C.c_int32, None), ("vpkt_obsdirs_costheta", _F64P, np.float64), ("vpkt_obsdirs_phi", _F64P, np.float64),
+    ("vpkt_nspectraperobsdir", C.c_int32, None), ("vpkt_opacityexclusions", _I32P, np.int32),
+    ("vpkt_timemin_input", C.c_double, None), ("vpkt_timemax_input", C.c_double, None),
+    ("vpkt_nwavelengthranges", C.c_int32, None), ("vpkt_numin_input", _F64P, np.float64), ("vpkt_numax_input", _F64P, np.float64),
+    ("vpkt_tau_max", C.c_double, None), ("vpkt_vgrid_on", C.c_int32, None),
+    ("vpkt_tmin_grid", C.c_double, None), ("vpkt_tmax_grid", C.c_double, None),
+    ("vpkt_grid_nwavelengthranges", C.c_int32, None), ("vpkt_nu_grid_min", _F64P, np.float64), ("vpkt_nu_grid_max", _F64P, np.float64),
+    ("vpkt_nprocs", C.c_int32, None),
 ]
+VSPEC_NUBINS, VSPEC_TIMEBINS, VGRID_NY, VGRID_NZ = 2500, 5, 50, 50  # vpkt.h:21-32
 _MODEL_OPTIONAL = ("elem_meannucmass", "ion_nt_sum_q_over_binding", "ejecta_kinetic_energy", "mtot_input",
                    "allcont_bfestimindex", "nbfestim", "rho_tmin", "xcom_elem_start", "xcom_energy", "xcom_sigma",
-                   "detailed_lineindices", "detailed_linecount")
+                   "detailed_lineindices", "detailed_linecount",
+                   "vpkt_nobsdirections", "vpkt_obsdirs_costheta", "vpkt_obsdirs_phi", "vpkt_nspectraperobsdir",
+                   "vpkt_opacityexclusions", "vpkt_timemin_input", "vpkt_timemax_input", "vpkt_nwavelengthranges",
+                   "vpkt_numin_input", "vpkt_numax_input", "vpkt_tau_max", "vpkt_vgrid_on", "vpkt_tmin_grid", "vpkt_tmax_grid",
+                   "vpkt_grid_nwavelengthranges", "vpkt_nu_grid_min", "vpkt_nu_grid_max", "vpkt_nprocs")
 
 _CELL_FIELDS = [
     ("rho", _F32P, np.float32), ("Te", _F32P, np.float32), ("TJ", _F32P, np.float32), ("TR", _F32P, np.float32),
@@ -194,6 +209,9 @@ CI_PRESETS = {
     "ci_nebular": ("setup_nebular_1d_3dgrid.sh", "nltenebular", (20, 2000.0, 10000.0)),
     "ci_nebular_limitbfest": ("setup_nebular_1d_3dgrid_limitbfest.sh", "nltephotospheric", (20, 2000.0, 10000.0)),
     "ci_nltephotospheric": ("setup_nltephotospheric_dynamic_ion_range_1d_1dgrid.sh", "nltephotospheric", (40, 3500.0, 140000.0)),
+    # classic + virtual packets (VPKT_ON): line by line, and with the binned expansion opacities beyond the first bin
+    "ci_classic_vpkt": ("setup_classicmode_1d_3dgrid.sh", "classic", (100, 3500.0, 140000.0)),
+    "ci_classic_vpkt_expopac": ("setup_classicmode_3d.sh", "classic", (100, 3500.0, 140000.0)),
 }
 
 
@@ -221,7 +239,7 @@ class CEstimators(C.Structure):
                 ("dep_estimator_gamma", _F64P), ("scalars", _F64P), ("dep_estimator_electron", _F64P),
                 ("dep_estimator_positron", _F64P), ("dep_estimator_alpha", _F64P),
                 ("radfieldbin_J", _F64P), ("radfieldbin_nuJ", _F64P), ("bfrate_raw", _F64P),
-                ("Jb_lu_raw", _F64P), ("Jb_lu_contribcount", _I64P)]
+                ("Jb_lu_raw", _F64P), ("Jb_lu_contribcount", _I64P), ("vspecpol", _F64P), ("vgrid_flux", _F64P)]
 
 
 def _as_ptr(arr: np.ndarray, ptype):
@@ -301,8 +319,9 @@ class Estimators:
     """Host estimator arrays (accumulated into by update_packets)."""
 
     def __init__(self, npts_nonempty: int, nbfcontinua_ground: int, nbfcontinua: int = 0, nbins: int = RADFIELDBINCOUNT,
-                 ndetailedlines: int = 0):
-        """nbfcontinua > 0: also the estimators of the nltenebular options (radiation-field bins, detailed bound-free;
+                 ndetailedlines: int = 0, vpkt_shape=None):
+        """vpkt_shape = (nobsdirections * nspectraperobsdir, nobsdirections * grid_nwavelengthranges or 0): also the
+        virtual-packet spectra and velocity-grid map (builds with VPKT_ON). nbfcontinua > 0: also the estimators of the nltenebular options (radiation-field bins, detailed bound-free;
         nbfcontinua = the number of bound-free estimators, nbins = RADFIELDBINCOUNT of the options preset)"""
         n, g = npts_nonempty, max(nbfcontinua_ground, 1)
         self.radfieldbin_J = np.zeros(n * nbins if nbfcontinua > 0 else 1)
@@ -312,6 +331,10 @@ class Estimators:
         self.Jb_lu_contribcount = np.zeros(max(n * ndetailedlines, 1), dtype=np.int64)
         self.lineest = ndetailedlines > 0
         self.extended = nbfcontinua > 0
+        self.vpkt = vpkt_shape is not None
+        ncomb, ngridcomb = vpkt_shape if self.vpkt else (0, 0)
+        self.vspecpol = np.zeros(max(VSPEC_TIMEBINS * ncomb * VSPEC_NUBINS * 3, 1))
+        self.vgrid_flux = np.zeros(max(VGRID_NY * VGRID_NZ * ngridcomb * 3, 1))
         self.J = np.zeros(n)
         self.nuJ = np.zeros(n)
         self.ffheatingestimator = np.zeros(n)
@@ -335,7 +358,9 @@ class Estimators:
             _as_ptr(self.radfieldbin_nuJ, _F64P) if self.extended else None,
             _as_ptr(self.bfrate_raw, _F64P) if self.extended else None,
             _as_ptr(self.Jb_lu_raw, _F64P) if self.lineest else None,
-            _as_ptr(self.Jb_lu_contribcount, _I64P) if self.lineest else None)
+            _as_ptr(self.Jb_lu_contribcount, _I64P) if self.lineest else None,
+            _as_ptr(self.vspecpol, _F64P) if self.vpkt else None,
+            _as_ptr(self.vgrid_flux, _F64P) if (self.vpkt and ngridcomb > 0) else None)
 
     def ref(self):
         return C.byref(self.c)
@@ -345,6 +370,8 @@ class Estimators:
                "bfrate_raw": self.bfrate_raw} if self.extended else {}
         if self.lineest:
             ext = {**ext, "Jb_lu_raw": self.Jb_lu_raw, "Jb_lu_contribcount": self.Jb_lu_contribcount}
+        if self.vpkt:
+            ext = {**ext, "vspecpol": self.vspecpol, "vgrid_flux": self.vgrid_flux}
         return {**ext, "J": self.J, "nuJ": self.nuJ, "ffheatingestimator": self.ffheatingestimator,
                 "colheatingestimator": self.colheatingestimator, "gammaestimator": self.gammaestimator,
                 "bfheatingestimator": self.bfheatingestimator, "dep_estimator_gamma": self.dep_estimator_gamma,
@@ -357,6 +384,11 @@ class Estimators:
 
 def estimators_for(model, options: str = "classic") -> Estimators:
     """Estimator arrays sized for a model under an options preset (nltenebular adds the bin and bound-free arrays)"""
+    if "vpkt" in options:
+        nobs = model.d.get("vpkt_nobsdirections") or 0
+        ngrid = (model.d.get("vpkt_grid_nwavelengthranges") or 0) if model.d.get("vpkt_vgrid_on") else 0
+        return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"],
+                          vpkt_shape=(nobs * (model.d.get("vpkt_nspectraperobsdir") or 0), nobs * ngrid))
     if options not in NEBULAR_FAMILY:
         return Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
     nest = model.d.get("nbfestim") or model["nbfcontinua"]

@@ -25,7 +25,7 @@ PRESETS = ("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nlt
            "kilonova_expopac", "classic_expopac_therm",
            # the option sets of the reference's CI (tests/setup_*.sh)
            "ci_kilonova", "ci_kilonova_barnes", "ci_kilonova_expopac", "ci_kilonova_xcom", "ci_nebular", "ci_nebular_limitbfest",
-           "ci_nltephotospheric")  # options presets of include/artis_options.h (the reference's artisoptions_*.h)
+           "ci_nltephotospheric", "ci_classic_vpkt", "ci_classic_vpkt_expopac")  # options presets of include/artis_options.h (the reference's artisoptions_*.h)
 
 
 def so_path(preset: str = "classic") -> str:

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(BLOCK) k_line_dpop(Env env) {
   if (i >= total) return;
   populate_line_dpop(env, env.tile_lo + (int)(i / env.M.nlines), (int)(i % env.M.nlines));
 }
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
 // calculate_expansion_opacities() for the cells of the resident tile, when the host did not hand the tables over
 __global__ void __launch_bounds__(BLOCK) k_expopac(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1491,6 +1491,27 @@ __global__ void __launch_bounds__(BLOCK) k_blackbody(Env env, const int32_t *lis
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
+#if ARTIS_OPT_VPKT_ON
+// Virtual packets (vpkt.cc): the emissions and electron scatterings the launch before recorded (physics.h trace_vpkts), one
+// lane per (event, observer direction): the optical depths of every opacity choice along the ray to the grid's edge, then
+// the attenuated energy into that observer's spectrum (f64 atomics). Nothing of the real packets is read or written.
+__global__ void __launch_bounds__(BLOCK) k_vpkt(Env env, unsigned long long *gstats) {
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  __syncthreads();
+  env.stats = lstats;
+  const int nobs = env.M.vpkt->nobsdirections;
+  const int64_t n = (int64_t)min(*env.vpkt_count, env.vpkt_cap) * nobs;
+  const VpktSeed *queue = env.vpkt_queue;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+    const VpktSeed seed = queue[i / nobs];
+    vpkt_trace_seed_direction(env, seed, (int)(i % nobs));
+  }
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
+}
+#endif
+
 inline int nblocks(int64_t n) { return (int)((n + BLOCK - 1) / BLOCK); }
 
 }  // namespace
@@ -1516,6 +1537,12 @@ struct artis_amd_engine {
   int32_t *d_bfev_count = nullptr;
   int32_t bfev_cap = 0;
   bool bf_defer = true;          // ARTIS_AMD_BFDEFER=0: add in place inside k_rpkt
+  // virtual packets (VPKT_ON builds): the configuration block, and the events one launch records for k_vpkt (at most
+  // budget_r per packet on the launch's list: an electron scattering per do_rpkt_step(), one emission per thermal visit)
+  VpktConfig *d_vpkt_config = nullptr;
+  VpktSeed *d_vpkt_queue = nullptr;
+  int32_t *d_vpkt_count = nullptr;
+  int32_t vpkt_cap = 0;
   // Cell-cache tiling: the cache rows of `tile_cells` non-empty cells are resident at a time (all of them when they fit
   // the budget: ntiles == 1). With more tiles, update_packets sweeps over them -- populate a tile, advance every packet
   // that sits in one of its cells until it leaves the tile or is done -- until no packet is left (what the reference's
@@ -1528,6 +1555,7 @@ struct artis_amd_engine {
   int32_t *d_target_level = nullptr;
   double *d_est = nullptr;
   int64_t est_ndoubles = 0;
+  int64_t nvspec = 0, nvgrid = 0;  // doubles of the virtual-packet spectra / velocity-grid map at the end of the block
   unsigned long long *d_stats = nullptr;
   int32_t *d_err = nullptr;
   // packets
@@ -1655,13 +1683,18 @@ Env make_env(const artis_amd_engine *e) {
   env.gamma_gi = e->d_gamma_gi;
   env.gamma_n = e->d_gamma_n;
   env.errflag = e->d_err;
+  env.vpkt_queue = e->d_vpkt_queue;
+  env.vpkt_count = e->d_vpkt_count;
+  env.vpkt_cap = e->vpkt_cap;
   return env;
 }
 
 void free_packet_buffers(artis_amd_engine *e) {
   void **singles[] = {&e->d_pkt, &e->d_pkt_snapshot, (void **)&e->d_sorted, (void **)&e->d_perm, (void **)&e->d_gamma_ws,
-                      (void **)&e->d_gamma_gi, (void **)&e->d_gamma_n, (void **)&e->d_bfev, (void **)&e->d_bfev_count};
+                      (void **)&e->d_gamma_gi, (void **)&e->d_gamma_n, (void **)&e->d_bfev, (void **)&e->d_bfev_count,
+                      (void **)&e->d_vpkt_queue, (void **)&e->d_vpkt_count};
   e->bfev_cap = 0;
+  e->vpkt_cap = 0;
   for (void **q : singles) {
     if (*q) (void)hipFree(*q);
     *q = nullptr;
@@ -1704,6 +1737,15 @@ int ensure_packet_buffers(artis_amd_engine *e, int64_t n) {
     HIP_TRY(hipMalloc((void **)&e->d_bfev_count, sizeof(int32_t)));
     HIP_TRY(hipMemset(e->d_bfev_count, 0, sizeof(int32_t)));
     e->bfev_cap = (int32_t)cap;
+  }
+#endif
+#if ARTIS_OPT_VPKT_ON
+  {
+    const int64_t cap = std::min<int64_t>((int64_t)(n > 0 ? n : 1) * std::max(e->budget_r, 1), 0x7FFFFFF0LL);
+    HIP_TRY(hipMalloc((void **)&e->d_vpkt_queue, sizeof(VpktSeed) * (size_t)cap));
+    HIP_TRY(hipMalloc((void **)&e->d_vpkt_count, sizeof(int32_t)));
+    HIP_TRY(hipMemset(e->d_vpkt_count, 0, sizeof(int32_t)));
+    e->vpkt_cap = (int32_t)cap;
   }
 #endif
   e->npackets = n;  // committed only now: a failed allocation above leaves "nothing resident" (npackets == -1)
@@ -1774,7 +1816,7 @@ const RcclApi &rccl_api() {
 extern "C" {
 
 const char *artis_amd_last_error(void) { return g_last_error.c_str(); }
-int artis_amd_abi_version(void) { return 4; }
+int artis_amd_abi_version(void) { return 5; }
 const char *artis_amd_options_preset(void) {
 #if defined(ARTIS_PRESET_NAME)  // given by the build (artis_amd/build.py): the presets of the reference's CI option sets
   return ARTIS_PRESET_NAME;
@@ -1983,7 +2025,27 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   const int64_t nbinest = ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON ? ncell * ARTIS_OPT_RADFIELDBINCOUNT : 0;
   const int64_t nbfest = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? ncell * (int64_t)h.nbfestim : 0;
   const int64_t nlineest = ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON ? ncell * (int64_t)h.detailed_linecount : 0;
-  e->est_ndoubles = ncell * 8 + 2 * ncell * g + ARTIS_NSCALARS + 2 * nbinest + nbfest + 2 * nlineest;
+  // ... | (vspecpol | vgrid_flux)]: the observers' spectra of a VPKT_ON build, inside the block the all-reduce covers
+  int64_t nvspec = 0, nvgrid = 0;
+#if ARTIS_OPT_VPKT_ON
+  {
+    VpktConfig V;
+    if (!make_vpkt_config(*model, V)) {
+      g_last_error = "this build has VPKT_ON: artis_model.vpkt_* (the configuration read from vpkt.txt) is required";
+      return ARTIS_ERR_ARG;
+    }
+    HIP_TRY(hipMalloc((void **)&e->d_vpkt_config, sizeof(VpktConfig)));
+    e->model_allocs.push_back(e->d_vpkt_config);
+    HIP_TRY(hipMemcpy(e->d_vpkt_config, &V, sizeof(V), hipMemcpyHostToDevice));
+    e->M.vpkt = e->d_vpkt_config;
+    nvspec = (int64_t)ARTIS_VSPEC_TIMEBINS * V.nobsdirections * V.nspectraperobsdir * ARTIS_VSPEC_NUBINS * 3;
+    nvgrid = V.vgrid_on ? (int64_t)ARTIS_VGRID_NY * ARTIS_VGRID_NZ * V.grid_nwavelengthranges * V.nobsdirections * 3 : 0;
+    e->tail_max = 0;  // k_tail takes a packet through any number of steps in one launch: more events than the queue is sized for
+  }
+#endif
+  e->nvspec = nvspec;
+  e->nvgrid = nvgrid;
+  e->est_ndoubles = ncell * 8 + 2 * ncell * g + ARTIS_NSCALARS + 2 * nbinest + nbfest + 2 * nlineest + nvspec + nvgrid;
   HIP_TRY(hipMalloc((void **)&e->d_est, sizeof(double) * (size_t)e->est_ndoubles));
   HIP_TRY(hipMemset(e->d_est, 0, sizeof(double) * (size_t)e->est_ndoubles));
   e->E.J = e->d_est;
@@ -2002,6 +2064,8 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   e->E.bfrate_raw = nbfest ? e->E.scalars + ARTIS_NSCALARS + 2 * nbinest : nullptr;
   e->E.Jb_lu_raw = nlineest ? e->E.scalars + ARTIS_NSCALARS + 2 * nbinest + nbfest : nullptr;
   e->E.Jb_lu_contribcount = nlineest ? e->E.Jb_lu_raw + nlineest : nullptr;
+  e->E.vspecpol = nvspec ? e->E.scalars + ARTIS_NSCALARS + 2 * nbinest + nbfest + 2 * nlineest : nullptr;
+  e->E.vgrid_flux = nvgrid ? e->E.vspecpol + nvspec : nullptr;
   HIP_TRY(hipMalloc((void **)&e->d_stats, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
@@ -2032,6 +2096,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MA")) e->sort_ma = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TAIL")) e->tail_max = std::max(0, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_TAIL_ALWAYS")) e->tail_always = std::atoi(b) != 0;
+  if (ARTIS_OPT_VPKT_ON) e->tail_max = 0;  // (see the estimator block: the event queue is sized per split launch)
   if (const char *b = std::getenv("ARTIS_AMD_RPKT_EST_OVER_CONT")) e->rpkt_est_over_cont = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_DENSE_CONTLDS")) e->dense_cont_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_CELLEST_LDS")) e->cellest_in_lds = std::atoi(b) != 0;
@@ -2138,7 +2203,7 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
     g_last_error = "this build has DETAILED_LINE_ESTIMATORS_ON: artis_cellstate.Jb_lu_normed is required";
     return ARTIS_ERR_ARG;
   }
-  if (ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION) {
+  if (ARTIS_EXPOPAC_TABLES) {
     // the tables of calculate_expansion_opacities(): the host's, or (both NULL) made by the engine at cell-cache population
     const bool need_planck = ARTIS_OPT_RPKT_BB_THERMALISATION;
     if (!e->C.expansionopacities && !e->C.expansionopacity_planck_cumulative) {
@@ -2217,7 +2282,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s) {
     hipLaunchKernelGGL(k_hotselect, dim3(nblocks(ncell * 64)), dim3(BLOCK), 0, s, env);
     hipLaunchKernelGGL(k_hotfill, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   }
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
   if (e->expopac_own) {  // needs line_dpop and chi_ff_nnionpart of the tile's cells (k_line_dpop, k_cell_scalars above)
     hipLaunchKernelGGL(k_expopac, dim3(nblocks((int64_t)ncell * ARTIS_EXPOPAC_NBINS)), dim3(BLOCK), 0, s, env);
     if (ARTIS_OPT_RPKT_BB_THERMALISATION) hipLaunchKernelGGL(k_expopac_planck, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
@@ -2580,6 +2645,12 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       } else {
         hipLaunchKernelGGL(k_slow, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);
       }
+#if ARTIS_OPT_VPKT_ON
+      if (kind != NEXT_GAMMA && kind != NEXT_BB) {  // the virtual packets of the events the launch recorded
+        hipLaunchKernelGGL(k_vpkt, dim3(e->ncu * 8), dim3(BLOCK), 0, s, env, e->d_stats);
+        HIP_TRY(hipMemsetAsync(e->d_vpkt_count, 0, sizeof(int32_t), s));
+      }
+#endif
       HIP_TRY(hipEventRecord(e->ev1, s));
       rc = read_counts();
       if (rc != ARTIS_OK) return rc;
@@ -2662,6 +2733,8 @@ int artis_amd_estimators_download(artis_amd_engine *e, artis_estimators *est) {
       if (est->Jb_lu_contribcount)
         for (int64_t i = 0; i < nlineest; i++) est->Jb_lu_contribcount[i] += (int64_t)ext[2 * nbinest + nbfest + nlineest + i];
     }
+    if (e->nvspec) add(est->vspecpol, ext + 2 * nbinest + nbfest + 2 * nlineest, e->nvspec);
+    if (e->nvgrid) add(est->vgrid_flux, ext + 2 * nbinest + nbfest + 2 * nlineest + e->nvspec, e->nvgrid);
   }
   if (est->stats) {
     unsigned long long st[ARTIS_NSTATS];

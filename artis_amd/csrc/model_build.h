@@ -321,7 +321,61 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.detailed_lineindices = m.detailed_lineindices;
   v.detailed_linecount = m.detailed_lineindices ? m.detailed_linecount : 0;
   v.nbfestim = (m.allcont_bfestimindex && m.nbfestim > 0) ? m.nbfestim : m.nbfcontinua;
+  v.vpkt = nullptr;  // the owner of the view places the block (make_vpkt_config)
   return v;
+}
+
+// The virtual-packet configuration of a VPKT_ON build as one block (tables.h VpktConfig): the observer unit vectors as
+// trace_vpkts() forms them (vpkt.cc:967-971), the bin widths of init_vspecpol() (vpkt.cc:491-512; floats there). False when
+// the model carries no usable configuration.
+inline bool make_vpkt_config(const artis_model &m, VpktConfig &V) {
+  std::memset(&V, 0, sizeof(V));
+  if (m.vpkt_nobsdirections < 1 || m.vpkt_nobsdirections > VPKT_MAXOBS || !m.vpkt_obsdirs_costheta || !m.vpkt_obsdirs_phi ||
+      m.vpkt_nspectraperobsdir < 1 || m.vpkt_nspectraperobsdir > VPKT_MAXSPEC || !m.vpkt_opacityexclusions ||
+      m.vpkt_nwavelengthranges < 1 || m.vpkt_nwavelengthranges > VPKT_MAXRANGES || !m.vpkt_numin_input || !m.vpkt_numax_input ||
+      m.vpkt_nprocs < 1)
+    return false;
+  if (m.vpkt_vgrid_on && (m.vpkt_grid_nwavelengthranges < 1 || m.vpkt_grid_nwavelengthranges > VPKT_MAXRANGES || !m.vpkt_nu_grid_min ||
+                          !m.vpkt_nu_grid_max))
+    return false;
+  V.nobsdirections = m.vpkt_nobsdirections;
+  V.nspectraperobsdir = m.vpkt_nspectraperobsdir;
+  V.nwavelengthranges = m.vpkt_nwavelengthranges;
+  V.vgrid_on = m.vpkt_vgrid_on ? 1 : 0;
+  V.grid_nwavelengthranges = m.vpkt_vgrid_on ? m.vpkt_grid_nwavelengthranges : 0;
+  V.nprocs = m.vpkt_nprocs;
+  for (int i = 0; i < V.nobsdirections; i++) {
+    const double ct = m.vpkt_obsdirs_costheta[i], ph = m.vpkt_obsdirs_phi[i];
+    V.obsdir[i][0] = std::sqrt(1 - (ct * ct)) * std::cos(ph);
+    V.obsdir[i][1] = std::sqrt(1 - (ct * ct)) * std::sin(ph);
+    V.obsdir[i][2] = ct;
+  }
+  for (int i = 0; i < V.nspectraperobsdir; i++) V.opacityexclusions[i] = m.vpkt_opacityexclusions[i];
+  V.timemin_input = m.vpkt_timemin_input;
+  V.timemax_input = m.vpkt_timemax_input;
+  V.tau_max = m.vpkt_tau_max;
+  V.tmin_grid = m.vpkt_tmin_grid;
+  V.tmax_grid = m.vpkt_tmax_grid;
+  for (int i = 0; i < V.nwavelengthranges; i++) {
+    V.numin_input[i] = m.vpkt_numin_input[i];
+    V.numax_input[i] = m.vpkt_numax_input[i];
+  }
+  for (int i = 0; i < V.grid_nwavelengthranges; i++) {
+    V.nu_grid_min[i] = m.vpkt_nu_grid_min[i];
+    V.nu_grid_max[i] = m.vpkt_nu_grid_max[i];
+  }
+  const double dlogt = (std::log(ARTIS_VSPEC_TIMEMAX) - std::log(ARTIS_VSPEC_TIMEMIN)) / ARTIS_VSPEC_TIMEBINS;
+  const double dlognu = (std::log(ARTIS_VSPEC_NUMAX) - std::log(ARTIS_VSPEC_NUMIN)) / ARTIS_VSPEC_NUBINS;
+  auto edge = [](double minvalue, double dlog, double index) { return std::exp(std::log(minvalue) + (index * dlog)); };  // sn3d.h:142
+  for (int n = 0; n < ARTIS_VSPEC_TIMEBINS; n++) {
+    const float lower = (float)edge(ARTIS_VSPEC_TIMEMIN, dlogt, n);
+    V.delta_t[n] = (float)(edge(ARTIS_VSPEC_TIMEMIN, dlogt, n + 1) - lower);
+  }
+  for (int n = 0; n < ARTIS_VSPEC_NUBINS; n++) {
+    const float lower = (float)edge(ARTIS_VSPEC_NUMIN, dlognu, n);
+    V.delta_freq[n] = (float)(edge(ARTIS_VSPEC_NUMIN, dlognu, n + 1) - lower);
+  }
+  return true;
 }
 
 // Unpack one cell's row of macro-atom records into the reference's two arrays (globals.h:286-287):

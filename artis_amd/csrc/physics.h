@@ -164,6 +164,10 @@ struct Env {
   BfEvent *bfev;
   int32_t *bfev_count;
   int32_t bfev_cap;
+  // recorded virtual-packet events (VPKT_ON builds on the GPU; null: traced in place)
+  VpktSeed *vpkt_queue;
+  int32_t *vpkt_count;
+  int32_t vpkt_cap;
 };
 // the packet's cell is empty (no cache needed) or its cache row is resident
 AHD bool in_tile(const Env &env, int cellindex) {
@@ -1960,7 +1964,7 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
   return result;
 }
 
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
 // wavelength bins in ascending wavelength (descending frequency), rpkt.h:30-40
 AHD double expopac_bin_nu_upper(int64_t b) { return 1e8 * CLIGHT / (ARTIS_EXPOPAC_LAMBDAMIN + ((double)b * ARTIS_EXPOPAC_DELTALAMBDA)); }
 AHD double expopac_bin_nu_lower(int64_t b) { return 1e8 * CLIGHT / (ARTIS_EXPOPAC_LAMBDAMIN + ((double)(b + 1) * ARTIS_EXPOPAC_DELTALAMBDA)); }
@@ -1970,7 +1974,7 @@ AHD int64_t linearbinindex(double value, double minvalue, double binwidth) {  //
   return (fracindex < (double)truncated) ? truncated - 1 : truncated;
 }
 #endif
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
 // calculate_expansion_opacities rpkt.cc:1071, run by the engine when the host does not hand the tables over (they are a
 // product of update_grid() in the reference, update_grid.cc:655). One (cell, bin): the lines of the bin in list order.
 AHD void populate_expopac_bin(const Env &env, int c, int b) {
@@ -2363,6 +2367,277 @@ AHD double select_continuum_nu(const Env &env, int element, int lowerion, int lo
   return nu;
 }
 
+
+#if ARTIS_OPT_VPKT_ON
+// ---------------------------------------------------------------- vpkt.cc: virtual packets
+constexpr double PARSEC = 3.0857e+18;  // constants.h:39
+AHD int64_t logbinindex(double value, double minvalue, double dlog, int64_t nbins) {  // get_logbinindex sn3d.h:134
+  const int64_t i = (int64_t)floor((log(value) - log(minvalue)) / dlog);
+  return i < 0 ? 0 : (i > nbins - 1 ? nbins - 1 : i);
+}
+// add_to_vspecpol vpkt.cc:116
+AHD void add_to_vspecpol(const Env &env, const VpktConfig &V, double nu_rf, double e_rf, double prob, double q_rf, double u_rf,
+                         int obsdirindex, int opachoiceindex, double t_arrive) {
+  if (t_arrive <= ARTIS_VSPEC_TIMEMIN || t_arrive >= ARTIS_VSPEC_TIMEMAX || nu_rf <= ARTIS_VSPEC_NUMIN || nu_rf >= ARTIS_VSPEC_NUMAX) return;
+  const double dlogt = (log(ARTIS_VSPEC_TIMEMAX) - log(ARTIS_VSPEC_TIMEMIN)) / ARTIS_VSPEC_TIMEBINS;  // vpkt.cc:106-107
+  const double dlognu = (log(ARTIS_VSPEC_NUMAX) - log(ARTIS_VSPEC_NUMIN)) / ARTIS_VSPEC_NUBINS;
+  const int nt = (int)logbinindex(t_arrive, ARTIS_VSPEC_TIMEMIN, dlogt, ARTIS_VSPEC_TIMEBINS);
+  const int nnu = (int)logbinindex(nu_rf, ARTIS_VSPEC_NUMIN, dlognu, ARTIS_VSPEC_NUBINS);
+  const int ind_comb = (V.nspectraperobsdir * obsdirindex) + opachoiceindex;
+  const double pktcontrib = e_rf / V.delta_t[nt] / V.delta_freq[nnu] / 4.e12 / PI / PARSEC / PARSEC / V.nprocs * 4 * PI;
+  double *flux = env.E.vspecpol + ((((int64_t)nt * (V.nobsdirections * V.nspectraperobsdir) + ind_comb) * ARTIS_VSPEC_NUBINS + nnu) * 3);
+  ARTIS_EST_ADD(&flux[0], prob * pktcontrib);
+  ARTIS_EST_ADD(&flux[1], prob * q_rf * pktcontrib);
+  ARTIS_EST_ADD(&flux[2], prob * u_rf * pktcontrib);
+}
+// add_to_vpkt_grid vpkt.cc:138
+AHD void add_to_vpkt_grid(const Env &env, const VpktConfig &V, double nu_rf, double e_rf, double prob, double stokes_q, double stokes_u,
+                          const double vel[3], int wlbin, int obsdirindex, const double obsdir[3]) {
+  const double vmax = env.M.vmax;
+  double vref1, vref2;
+  if (obsdir[0] == 1) {
+    vref1 = vel[1];
+    vref2 = vel[2];
+  } else if (obsdir[0] == -1) {
+    vref1 = -vel[1];
+    vref2 = -vel[2];
+  } else {
+    const double crossterm = obsdir[1] * obsdir[2] / (1 + obsdir[0]);
+    vref1 = (-obsdir[1] * vel[0]) + ((obsdir[0] + (pow2(obsdir[2]) / (1 + obsdir[0]))) * vel[1]) - (crossterm * vel[2]);
+    vref2 = (-obsdir[2] * vel[0]) - (crossterm * vel[1]) + ((obsdir[0] + (pow2(obsdir[1]) / (1 + obsdir[0]))) * vel[2]);
+  }
+  if (fabs(vref1) >= vmax || fabs(vref2) >= vmax) return;
+  const int ny = (int)((vmax - vref1) / (2 * vmax / ARTIS_VGRID_NY));
+  const int nz = (int)((vmax - vref2) / (2 * vmax / ARTIS_VGRID_NZ));
+  if (nu_rf > V.nu_grid_min[wlbin] && nu_rf < V.nu_grid_max[wlbin]) {
+    double *flux = env.E.vgrid_flux + (((((int64_t)ny * ARTIS_VGRID_NZ + nz) * V.grid_nwavelengthranges + wlbin) * V.nobsdirections + obsdirindex) * 3);
+    ARTIS_EST_ADD(&flux[0], prob * e_rf);
+    ARTIS_EST_ADD(&flux[1], prob * stokes_q * e_rf);
+    ARTIS_EST_ADD(&flux[2], prob * stokes_u * e_rf);
+  }
+}
+AHD bool all_taus_past_taumax(const double *tau, int n, double tau_max) {  // vpkt.cc:111
+  for (int i = 0; i < n; i++)
+    if (!(tau[i] > tau_max)) return false;
+  return true;
+}
+// the loop of trace_lines_to_dist (vpkt.cc:298-358): false when every opacity choice is past tau_max. The populations
+// are the cell cache's (B_lu n_l - B_ul n_u) of the grid state, scaled to the time the line is reached.
+AHD bool vpkt_trace_lines_to_dist(const Env &env, const VpktConfig &V, int c, double dist_limit, double t_future, double nu_cmf,
+                                  double dnu_on_dl, int &next_trans, double *tau_vpkt) {
+  const DevModel &M = env.M;
+  const double *dpop = env.K.line_dpop + ((int64_t)c * M.nlines);
+  const double t_gridstate = env.S.mid;
+  while (true) {
+    const int li = closest_transition(M.line_nu, M.nlines, nu_cmf, next_trans);
+    if (li < 0) {
+      next_trans = M.nlines + 1;
+      break;
+    }
+    const double nutrans = M.line_nu[li];
+    next_trans = li + 1;
+    const double ldist = linedistance(t_future, nu_cmf, nutrans, dnu_on_dl);
+    if (ldist > dist_limit) {
+      next_trans--;
+      break;
+    }
+    const double t_line = t_future + (ldist / CLIGHT_PROP);
+    const double popscalefactor = pow3(t_gridstate / t_line);
+    const double tau_line = dmax(0., dpop[li] * popscalefactor * HCLIGHTOVERFOURPI * t_line);
+    const int Z = M.elem_anumber[M.line_elementindex[li]];
+    for (int i = 0; i < V.nspectraperobsdir; i++)
+      if (V.opacityexclusions[i] != -1 && V.opacityexclusions[i] != Z) tau_vpkt[i] += tau_line;
+    if (all_taus_past_taumax(tau_vpkt, V.nspectraperobsdir, V.tau_max)) return false;
+  }
+  return true;
+}
+// trace_vpkt_direction vpkt.cc:183
+AHD bool trace_vpkt_direction(const Env &env, const VpktSeed &r, double t_arrive, double nu_rf, double e_rf, double rpkt_doppler,
+                              int obsdirindex, const double obsdir[3]) {
+  const DevModel &M = env.M;
+  const VpktConfig &V = *M.vpkt;
+  const int nspec = V.nspectraperobsdir;
+  Pkt v;  // position, direction, time and cell of the virtual packet (what boundary_distance() reads)
+  v.px = r.pos[0]; v.py = r.pos[1]; v.pz = r.pos[2];
+  v.dx = obsdir[0]; v.dy = obsdir[1]; v.dz = obsdir[2];
+  v.cellindex = r.cellindex;
+  v.prop_time = r.prop_time;
+  int next_trans = r.next_trans;
+  double e_cmf = r.e_cmf;
+  double nu_cmf = r.nu_cmf;
+  const double t_start = r.prop_time;
+  const double t_gridstate = env.S.mid;
+  double tau_vpkt[VPKT_MAXSPEC];
+  for (int i = 0; i < VPKT_MAXSPEC; i++) tau_vpkt[i] = 0.;
+  ARTIS_STAT(env, ARTIS_STAT_X_VPKT_CREATED);
+  const double vel_vec[3] = {r.pos[0] / t_start, r.pos[1] / t_start, r.pos[2] / t_start};  // get_velocity vectors.h:50
+  double pn = 1 / (4 * PI);
+  double q_rf = 0., u_rf = 0.;
+  if (r.type_before == ARTIS_TYPE_RPKT) {
+    double old_dir_cmf[3], q_i_cmf = 0., u_i_cmf = 0.;
+    frame_transform(r.dir, r.stokes_q, r.stokes_u, vel_vec, old_dir_cmf, &q_i_cmf, &u_i_cmf);
+    double obs_cmf[3], new_dir_rf[3];
+    angle_ab(obsdir, vel_vec, obs_cmf);
+    scatter_polarisation_to_rf(old_dir_cmf, obs_cmf, q_i_cmf, u_i_cmf, vel_vec, new_dir_rf, &q_rf, &u_rf);
+    // pn of scatter_polarisation_to_rf (vectors.h:353): the phase function of the scattering
+    double ref1[3], ref2[3];
+    meridian(old_dir_cmf, ref1, ref2);
+    const double i1 = rot_angle(old_dir_cmf, obs_cmf, ref1, ref2);
+    const double q_old = (q_i_cmf * cos(2 * i1)) - (u_i_cmf * sin(2 * i1));
+    const double musquared = pow2(vdot(old_dir_cmf, obs_cmf));
+    pn = 3. / (16. * PI) * (1. + musquared + ((musquared - 1.) * q_old));
+  }
+  pn /= pow2(rpkt_doppler);
+
+  int mgi = M.propcell_nonemptymgi[v.cellindex];
+  Chi x;  // the virtual packet's own ContinuumOpacity: fresh per traced direction
+  x.nonemptymgi = -1;
+  x.nu = NAN;
+  x.chi_escatter = x.chi_freefree_heat = x.chi_boundfree = 0.;
+  bool end_packet = false;
+  while (!end_packet) {
+    int next_cellindex = -1;
+    const double boundarydist = boundary_distance(env, v, &next_cellindex);
+    if (mgi < 0) {
+      next_trans = -1;
+    } else if (boundarydist > 0) {
+      const int c = mgi;
+      const double dop = doppler(v);
+      // calculate_chi_rpkt_cont<false> rpkt.cc:1021: the same sums without the packet's phixslist
+      if (!((c == x.nonemptymgi) && (fabs((x.nu / nu_cmf) - 1.0) < 1e-4))) {
+        const float cnne = env.C.nne[c] * env.C.clumpfactor[c];
+        const float T_e = env.C.Te[c];
+        x.chi_freefree_heat = env.K.chi_ff_nnionpart[c] / pow3(nu_cmf) * cnne * (1 - exp(-HOVERKB * nu_cmf / T_e));
+        x.chi_escatter = SIGMA_T * env.C.nne[c];
+        int dummy = -1;
+        x.chi_boundfree = chi_bf_gammacontr<true>(env, c, nu_cmf, 0, DBLMAX, &dummy);
+        x.nonemptymgi = c;
+        x.nu = nu_cmf;
+      }
+      const double densityscalefactor = pow3(t_gridstate / v.prop_time);
+      const double chi_escatter = x.chi_escatter * densityscalefactor;
+      const double chi_bf = x.chi_boundfree * densityscalefactor;
+      const double chi_ff = x.chi_freefree_heat * pow2(densityscalefactor);
+      const double chi_cont = chi_escatter + chi_bf + chi_ff;
+      for (int i = 0; i < nspec; i++) {
+        double chi_cont_thischoice = chi_cont;
+        if (V.opacityexclusions[i] == -2) {
+          chi_cont_thischoice -= chi_bf;
+        } else if (V.opacityexclusions[i] == -3) {
+          chi_cont_thischoice -= chi_ff;
+        } else if (V.opacityexclusions[i] == -4) {
+          chi_cont_thischoice -= chi_escatter;
+        }
+        tau_vpkt[i] += chi_cont_thischoice * boundarydist * dop;
+      }
+      if (all_taus_past_taumax(tau_vpkt, nspec, V.tau_max)) return false;
+      const double nu_cmf_boundary =
+          dmin(nu_rf * doppler_at(v.px + (obsdir[0] * boundarydist), v.py + (obsdir[1] * boundarydist), v.pz + (obsdir[2] * boundarydist),
+                                  obsdir[0], obsdir[1], obsdir[2], v.prop_time + (boundarydist / CLIGHT_PROP)),
+               nu_cmf);
+      const double dnu_on_dl = (nu_cmf_boundary - nu_cmf) / boundarydist;
+#if ARTIS_OPT_VPKT_USE_EXPANSION_OPACITIES
+      int64_t binindex_start = linearbinindex(1e8 * CLIGHT / nu_cmf, ARTIS_EXPOPAC_LAMBDAMIN, ARTIS_EXPOPAC_DELTALAMBDA);
+      if (binindex_start < -1) binindex_start = -1;
+      if (binindex_start < ARTIS_EXPOPAC_NBINS) {
+        const double first_bin_edge_nu = (binindex_start < 0) ? expopac_bin_nu_upper(0) : expopac_bin_nu_lower(binindex_start);
+        const double first_bin_edge_dist = linedistance(v.prop_time, nu_cmf, first_bin_edge_nu, dnu_on_dl);
+        const double line_by_line_limit = dmin(first_bin_edge_dist, boundarydist);
+        next_trans = -1;
+        if (!vpkt_trace_lines_to_dist(env, V, c, line_by_line_limit, v.prop_time, nu_cmf, dnu_on_dl, next_trans, tau_vpkt)) return false;
+        double dist = line_by_line_limit;
+        if (dist < boundarydist) {
+          const float *kappa_bins = env.C.expansionopacities + ((int64_t)c * ARTIS_EXPOPAC_NBINS);
+          const float rho = env.C.rho[c];
+          for (int64_t binindex = binindex_start + 1; binindex < ARTIS_EXPOPAC_NBINS; binindex++) {
+            const double next_bin_edge_nu = expopac_bin_nu_lower(binindex);
+            const double binedgedist = linedistance(v.prop_time, nu_cmf, next_bin_edge_nu, dnu_on_dl);
+            const double chi_bb_expansionopac = kappa_bins[binindex] * rho * densityscalefactor;  // float product first
+            const double tau_bin = chi_bb_expansionopac * (dmin(binedgedist, boundarydist) - dist);
+            dist = dmin(binedgedist, boundarydist);
+            for (int i = 0; i < nspec; i++)
+              if (V.opacityexclusions[i] != -1) tau_vpkt[i] += tau_bin;
+            if (all_taus_past_taumax(tau_vpkt, nspec, V.tau_max)) return false;
+            if (dist >= boundarydist) break;
+          }
+        }
+      }
+#else
+      if (!vpkt_trace_lines_to_dist(env, V, c, boundarydist, v.prop_time, nu_cmf, dnu_on_dl, next_trans, tau_vpkt)) return false;
+#endif
+    }
+    move_raw(v.px, v.py, v.pz, obsdir[0], obsdir[1], obsdir[2], v.prop_time, nu_rf, nu_cmf, e_rf, e_cmf, boundarydist);
+    if (next_cellindex >= 0) {
+      if (next_cellindex != v.cellindex && M.gridtype == ARTIS_GRID_CARTESIAN3D) {  // snap_pos_to_cell grid.cc:2460
+        double *pos[3] = {&v.px, &v.py, &v.pz};
+        for (int d = 0; d < 3; d++) {
+          const int idx = coordidx(M, next_cellindex, d);
+          const double lo = M.coord_pos_min_tmin[d][idx] / M.tmin * v.prop_time;
+          const double hi = (idx < (M.ncoordgrid[d] - 1)) ? M.coord_pos_min_tmin[d][idx + 1] / M.tmin * v.prop_time
+                                                           : M.rmax / M.tmin * v.prop_time;
+          *pos[d] = dclamp(*pos[d], lo, hi);
+        }
+      }
+      v.cellindex = next_cellindex;
+      mgi = M.propcell_nonemptymgi[v.cellindex];
+      if (mgi >= 0 && env.C.thick[mgi] != ARTIS_CELL_THIN) return false;
+    } else {
+      end_packet = true;
+    }
+  }
+  ARTIS_STAT(env, r.type_before == ARTIS_TYPE_RPKT ? ARTIS_STAT_X_VPKT_ESC_RPKT
+                                                   : (r.type_before == ARTIS_TYPE_KPKT ? ARTIS_STAT_X_VPKT_ESC_KPKT : ARTIS_STAT_X_VPKT_ESC_MA));
+  for (int i = 0; i < nspec; i++) {
+    const double prob = pn * exp(-tau_vpkt[i]);
+    if (!isfinite(prob)) fail(env, 91);
+    add_to_vspecpol(env, V, nu_rf, e_rf, prob, q_rf, u_rf, obsdirindex, i, t_arrive);
+  }
+  if (V.vgrid_on) {
+    const double prob = pn * exp(-tau_vpkt[0]);
+    for (int wlbin = 0; wlbin < V.grid_nwavelengthranges; wlbin++)
+      if ((nu_rf > V.nu_grid_min[wlbin] && nu_rf < V.nu_grid_max[wlbin]) && (t_arrive > V.tmin_grid && t_arrive < V.tmax_grid))
+        add_to_vpkt_grid(env, V, nu_rf, e_rf, prob, q_rf, u_rf, vel_vec, wlbin, obsdirindex, obsdir);
+  }
+  return true;
+}
+// the body of trace_vpkts()'s loop (vpkt.cc:962-991) for one observer direction
+AHD void vpkt_trace_seed_direction(const Env &env, const VpktSeed &r, int obsdirindex) {
+  const VpktConfig &V = *env.M.vpkt;
+  const double obsdir[3] = {V.obsdir[obsdirindex][0], V.obsdir[obsdirindex][1], V.obsdir[obsdirindex][2]};
+  const double t_arrive = r.prop_time - (((r.pos[0] * obsdir[0]) + (r.pos[1] * obsdir[1]) + (r.pos[2] * obsdir[2])) / CLIGHT_PROP);
+  if (t_arrive >= V.timemin_input && t_arrive <= V.timemax_input) {
+    const double dop = doppler_at(r.pos[0], r.pos[1], r.pos[2], obsdir[0], obsdir[1], obsdir[2], r.prop_time);
+    const double nu_rf = r.nu_cmf / dop;
+    const double e_rf = r.e_cmf / dop;
+    for (int i = 0; i < V.nwavelengthranges; i++) {
+      if ((nu_rf > V.numin_input[i] && nu_rf < V.numax_input[i]) || (r.absorptionfreq > V.numin_input[i] && r.absorptionfreq < V.numax_input[i])) {
+        (void)trace_vpkt_direction(env, r, t_arrive, nu_rf, e_rf, dop, obsdirindex, obsdir);
+        break;
+      }
+    }
+  }
+}
+// trace_vpkts vpkt.cc:948: called where a real packet is emitted or scattered by an electron. On the GPU the event is
+// recorded for k_vpkt; in the test emulation it is traced in place.
+AHD void trace_vpkts(const Env &env, const Pkt &p, int64_t pi, int type_before) {
+  const int c = env.M.propcell_nonemptymgi[p.cellindex];
+  if (env.C.thick[c] != ARTIS_CELL_THIN) return;
+  VpktSeed r;
+  r.pos[0] = p.px; r.pos[1] = p.py; r.pos[2] = p.pz;
+  r.dir[0] = p.dx; r.dir[1] = p.dy; r.dir[2] = p.dz;
+  r.nu_cmf = p.nu_cmf; r.e_cmf = p.e_cmf; r.prop_time = p.prop_time;
+  r.stokes_q = p.stokes_q; r.stokes_u = p.stokes_u;
+  r.absorptionfreq = env.P.flight[pi].absorptionfreq;
+  r.cellindex = p.cellindex; r.next_trans = p.next_trans; r.type_before = type_before; r.pad = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int idx = atomicAdd(env.vpkt_count, 1);  // (the propagation kernels never carry the trace itself)
+  if (idx < env.vpkt_cap) env.vpkt_queue[idx] = r; else fail(env, 92);
+#else
+  for (int o = 0; o < env.M.vpkt->nobsdirections; o++) vpkt_trace_seed_direction(env, r, o);
+#endif
+}
+#endif
+
 // ---------------------------------------------------------------- do_macroatom macroatom.cc:360
 // The reference runs a macro-atom to deactivation inside do_macroatom(). Here the activation only records
 // the state in the packet (ma_activate) and the walk is advanced one transition at a time by ma_jump(), so
@@ -2385,6 +2660,9 @@ AHD void ma_finish(const Env &env, Pkt &p, int64_t pi) {
       p.trueemissiontype = p.emissiontype;
       set_trueem_from_em(env, p, pi);
     }
+#if ARTIS_OPT_VPKT_ON
+    trace_vpkts(env, p, pi, ARTIS_TYPE_MA);  // macroatom.cc:588
+#endif
   } else {
     p.trueemissiontype = ARTIS_EMTYPE_NOTSET;
   }
@@ -2719,6 +2997,9 @@ AHD void rpkt_event_continuum(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_
   if (chi_rnd < chi_es) {
     p.nscatterings++;
     ARTIS_STAT(env, ARTIS_STAT_ELECTRON_SCATTERINGS);
+#if ARTIS_OPT_VPKT_ON
+    trace_vpkts(env, p, pi, ARTIS_TYPE_RPKT);  // rpkt.cc:441
+#endif
     electron_scatter(p);
     set_em_here(env, p, pi);
   } else if (chi_rnd < chi_es + chi_ff) {
@@ -2988,6 +3269,9 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     emit_rpkt(env, p, pi);
     ARTIS_STAT(env, ARTIS_STAT_K_TO_R_FF);
     thermal_emission_flags(env, p, pi, ARTIS_EMTYPE_FREEFREE);
+#if ARTIS_OPT_VPKT_ON
+    trace_vpkts(env, p, pi, ARTIS_TYPE_KPKT);  // kpkt.cc:515
+#endif
   } else if (ctype == ARTIS_COOLING_FREEBOUND) {
     // the frequency sampling (an adaptive quadrature) runs in the slow-path kernel: kpkt_fb_emission()
     p.pend = PEND_KPKT_FB;
@@ -3046,6 +3330,9 @@ AHD void kpkt_fb_emission(const Env &env, Pkt &p, int64_t pi) {
   emit_rpkt(env, p, pi);
   ARTIS_STAT(env, ARTIS_STAT_K_TO_R_FB);
   thermal_emission_flags(env, p, pi, emtype_continuum(M, lstart(M, element, ion) + lowerlevel, t));
+#if ARTIS_OPT_VPKT_ON
+  trace_vpkts(env, p, pi, ARTIS_TYPE_KPKT);  // kpkt.cc:541
+#endif
 }
 
 // ---------------------------------------------------------------- gammapkt.cc / gammapkt.h, classic preset:

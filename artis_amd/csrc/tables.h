@@ -104,6 +104,7 @@ struct alignas(16) D2 {
   double x, y;
 };
 
+struct VpktConfig;  // virtual packets, below
 struct DevModel {
   int32_t nelements, nions, nlevels, nlines, nalltrans, nphixstargets_total, nphixslevels, nbfcontinua, nbfcontinua_ground,
       ncoolingterms, nmatransblock, NPHIXSPOINTS;
@@ -143,6 +144,7 @@ struct DevModel {
   // optional (DETAILED_LINE_ESTIMATORS_ON builds): the lines with their own intensity estimator, rising line index
   const int32_t *detailed_lineindices;
   int32_t detailed_linecount;
+  const VpktConfig *vpkt;  // builds with VPKT_ON (else null)
   const int32_t *ion_element, *ion_nlevels, *ion_nlevels_ionising, *ion_maxrecombininglevel, *ion_uniquelevelindexstart,
       *ion_coolingoffset, *ion_ncoolingterms;
   const double *level_epsilon;
@@ -248,6 +250,28 @@ struct DevStep {
   double start, width, mid, max_path_step, ts_end;
 };
 
+// Virtual packets (builds with VPKT_ON). What read_vpktparameterfile() (vpkt.cc:673) leaves, as one small block in HBM;
+// the observer directions as the unit vectors trace_vpkts() forms from (costheta, phi) (vpkt.cc:967), made once on the host.
+constexpr int VPKT_MAXOBS = 16, VPKT_MAXSPEC = 16, VPKT_MAXRANGES = 16;
+struct VpktConfig {
+  int32_t nobsdirections, nspectraperobsdir, nwavelengthranges, vgrid_on, grid_nwavelengthranges, nprocs;
+  double obsdir[VPKT_MAXOBS][3];
+  int32_t opacityexclusions[VPKT_MAXSPEC];
+  double timemin_input, timemax_input, tau_max, tmin_grid, tmax_grid;
+  double numin_input[VPKT_MAXRANGES], numax_input[VPKT_MAXRANGES], nu_grid_min[VPKT_MAXRANGES], nu_grid_max[VPKT_MAXRANGES];
+  // init_vspecpol() vpkt.cc:491: widths of the time and frequency bins of the spectra (floats there), made on the host
+  float delta_t[ARTIS_VSPEC_TIMEBINS];
+  float delta_freq[ARTIS_VSPEC_NUBINS];
+};
+// The real packet as trace_vpkts() (vpkt.cc:948) sees it at an emission or an electron scattering. A virtual packet never
+// changes the real one and draws no random number, so the kernels only RECORD the event; k_vpkt traces every recorded
+// event towards every observer afterwards (one lane per event and direction) and adds to the spectra.
+struct alignas(16) VpktSeed {
+  double pos[3], dir[3];
+  double nu_cmf, e_cmf, prop_time, stokes_q, stokes_u, absorptionfreq;
+  int32_t cellindex, next_trans, type_before, pad;
+};
+
 struct DevEst {
   double *J, *nuJ, *ffheatingestimator, *colheatingestimator, *gammaestimator, *bfheatingestimator;
   double *dep_estimator_gamma;  // [cell] gammapkt.cc:568
@@ -257,6 +281,8 @@ struct DevEst {
   double *radfieldbin_J, *radfieldbin_nuJ;  // [cell][RADFIELDBINCOUNT] radfield.cc:745-790
   double *bfrate_raw;                       // [cell][nbfestim] radfield.cc:215
   double *Jb_lu_raw, *Jb_lu_contribcount;   // [cell][detailed_linecount] radfield.cc:773 (the count kept as f64: one block, one all-reduce)
+  // builds with VPKT_ON (else null): the observers' spectra and the velocity-grid map (include/artis_amd.h artis_estimators)
+  double *vspecpol, *vgrid_flux;
 };
 
 // Packet population in HBM: three arrays of cache-line records, slot-major ("structure of lines").

@@ -39,7 +39,8 @@ def flatten_estimators(est) -> np.ndarray:
     """Host estimators in the engine's block order
     [J | nuJ | ffheating | colheating | gamma | bfheating | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars],
     followed in nltenebular builds by [radfieldbin_J | radfieldbin_nuJ | bfrate_raw] and, with detailed line estimators,
-    by [Jb_lu_raw | Jb_lu_contribcount] (the counts as f64, like the engine's device block: one all-reduce covers it)."""
+    by [Jb_lu_raw | Jb_lu_contribcount] (the counts as f64, like the engine's device block: one all-reduce covers it); in
+    VPKT_ON builds by [vspecpol | vgrid_flux] (vpkt.cc sums them over the ranks when it writes the spectra)."""
     parts = [est.J, est.nuJ, est.ffheatingestimator, est.colheatingestimator, est.gammaestimator,
              est.bfheatingestimator, est.dep_estimator_gamma, est.dep_estimator_electron,
              est.dep_estimator_positron, est.dep_estimator_alpha, est.scalars]
@@ -47,4 +48,6 @@ def flatten_estimators(est) -> np.ndarray:
         parts += [est.radfieldbin_J, est.radfieldbin_nuJ, est.bfrate_raw]
     if getattr(est, "lineest", False):
         parts += [est.Jb_lu_raw, est.Jb_lu_contribcount.astype(np.float64)]
+    if getattr(est, "vpkt", False):  # the observers' spectra (and the velocity-grid map when it is on) of a VPKT_ON build
+        parts += [est.vspecpol] + ([est.vgrid_flux] if est.c.vgrid_flux else [])
     return np.concatenate(parts)

@@ -655,6 +655,8 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     md["mtot_input"] = float(m_cell.sum())
     md["ejecta_kinetic_energy"] = float((0.5 * m_cell * aux["v"] ** 2).sum())
     like = abi.inputs_like(options)
+    if "vpkt" in options:
+        md.update(vpkt_config(expopac="expopac" in options))
     if like == "classic_gamma_xcom":
         md.update(nonthermal_model_inputs(atomic))     # element masses for the number densities
         md.update(xcom_tables(atomic))
@@ -693,6 +695,24 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     cs = abi.CellState(cells)
     ts = make_timestep(aux["t"], width_frac=width_frac, vmax=grid["vmax"], nts=nts)
     return model, cs, ts, aux
+
+
+def vpkt_config(expopac: bool = False) -> dict:
+    """What read_vpktparameterfile() (vpkt.cc:673) leaves of a vpkt.txt like tests/classicmode_3d_inputfiles/vpkt.txt: three
+    observers near +z, on the equator and towards -z (not ON the axis as in that file: there the meridian frame of the
+    Stokes rotation, vectors.h meridian(), is singular and the sign of Q / U hangs on the last bit of sin / cos / acos --
+    measured: glibc and the GPU's libm give opposite signs for single packets, equal I); four spectra per observer with different opacity choices (with the binned
+    expansion opacities no element can be excluded, vpkt.cc:395); packets arriving inside the spectra's own window; one
+    frequency range; a low optical-depth cut so that it is exercised; the velocity-grid map on for the line-by-line form."""
+    day = 86400.0
+    numin, numax = CLIGHT / 10000 * 1e8, CLIGHT / 3500 * 1e8
+    return dict(vpkt_nobsdirections=3, vpkt_obsdirs_costheta=np.array([0.9, 0.0, -0.6]), vpkt_obsdirs_phi=np.array([0.0, 0.7, 0.0]),
+                vpkt_nspectraperobsdir=4, vpkt_opacityexclusions=np.array([0, -1, -3, -4] if expopac else [0, -1, -2, 26], dtype=np.int32),
+                vpkt_timemin_input=3 * day, vpkt_timemax_input=8 * day, vpkt_nwavelengthranges=1,
+                vpkt_numin_input=np.array([numin]), vpkt_numax_input=np.array([numax]), vpkt_tau_max=8.0,
+                vpkt_vgrid_on=0 if expopac else 1, vpkt_tmin_grid=3 * day, vpkt_tmax_grid=8 * day,
+                vpkt_grid_nwavelengthranges=2, vpkt_nu_grid_min=np.array([numin, CLIGHT / 6000 * 1e8]),
+                vpkt_nu_grid_max=np.array([CLIGHT / 6000 * 1e8, numax]), vpkt_nprocs=1)
 
 
 def expansion_opacity_cellstate(cells: dict, ncell: int, seed: int = 401) -> dict:

@@ -116,6 +116,8 @@ enum {
   ARTIS_STAT_X_CHI_EVALS = 38, /* continuum opacity evaluations that missed the packet's cache, rpkt.cc:1029 */
   ARTIS_STAT_X_CONT_VISITED = 39, /* bound-free continua summed in calculate_chi_bf_gammacontr() rpkt.cc:808 */
   ARTIS_STAT_X_GAMMA_STEPS = 40, /* calls of gammapkt::do_gamma() gammapkt.cc:911 */
+  /* virtual packets (vpkt.h:34-37): nvpkt_created, nvpkt_esc_from_rpkt / _kpkt / _macroatom */
+  ARTIS_STAT_X_VPKT_CREATED = 48, ARTIS_STAT_X_VPKT_ESC_RPKT = 49, ARTIS_STAT_X_VPKT_ESC_KPKT = 50, ARTIS_STAT_X_VPKT_ESC_MA = 51,
   /* 42..63: free for profiling builds (-DARTIS_PROFILE: wave-cycle accounting, units of 16 clocks) */
   ARTIS_NSTATS = 64
 };
@@ -297,7 +299,38 @@ typedef struct artis_model {
    * (builds with DETAILED_LINE_ESTIMATORS_ON; NULL / 0 elsewhere) */
   const int32_t *detailed_lineindices;
   int32_t detailed_linecount;
+
+  /* ---- virtual packets (builds with VPKT_ON): what read_vpktparameterfile() (vpkt.cc:673) leaves of vpkt.txt; 0 / NULL
+   * elsewhere (ABI 5). Observer directions (costheta, phi); the opacity choices of every spectrum (vpkt.cc:79: 0 full, -1 no
+   * lines, -2 no bound-free, -3 no free-free, -4 no electron scattering, Z > 0 without that element's lines); the arrival
+   * time window and the frequency ranges in which a virtual packet is traced at all; the optical depth at which it is
+   * dropped; the optional velocity-grid map (time window, frequency ranges); globals::nprocs (vpkt.cc:130). */
+  int32_t vpkt_nobsdirections;
+  const double *vpkt_obsdirs_costheta; /* [vpkt_nobsdirections] */
+  const double *vpkt_obsdirs_phi;
+  int32_t vpkt_nspectraperobsdir;
+  const int32_t *vpkt_opacityexclusions; /* [vpkt_nspectraperobsdir] */
+  double vpkt_timemin_input, vpkt_timemax_input;
+  int32_t vpkt_nwavelengthranges;
+  const double *vpkt_numin_input; /* [vpkt_nwavelengthranges] */
+  const double *vpkt_numax_input;
+  double vpkt_tau_max;
+  int32_t vpkt_vgrid_on;
+  double vpkt_tmin_grid, vpkt_tmax_grid;
+  int32_t vpkt_grid_nwavelengthranges;
+  const double *vpkt_nu_grid_min; /* [vpkt_grid_nwavelengthranges] */
+  const double *vpkt_nu_grid_max;
+  int32_t vpkt_nprocs;
 } artis_model;
+/* the fixed grids of the virtual-packet spectra, vpkt.h:21-32 */
+#define ARTIS_VGRID_NY 50
+#define ARTIS_VGRID_NZ 50
+#define ARTIS_VSPEC_NUBINS 2500
+#define ARTIS_VSPEC_TIMEBINS 5
+#define ARTIS_VSPEC_NUMIN (2.99792458e+10 / 10000 * 1e8)
+#define ARTIS_VSPEC_NUMAX (2.99792458e+10 / 3500 * 1e8)
+#define ARTIS_VSPEC_TIMEMIN (3 * 86400.)
+#define ARTIS_VSPEC_TIMEMAX (8 * 86400.)
 
 /* ---- per-timestep cell state written by the reference's update_grid() ----- */
 typedef struct artis_cellstate {
@@ -400,6 +433,13 @@ typedef struct artis_estimators {
    * update_lineestimator). Builds with DETAILED_LINE_ESTIMATORS_ON; may be NULL. */
   double *Jb_lu_raw;
   int64_t *Jb_lu_contribcount;
+  /* virtual-packet spectra vspecpol[timebin][obsdir * nspectraperobsdir + opacity choice].flux[nubin].{I, Q, U}
+   * (vpkt.cc:56, add_to_vspecpol :116): [ARTIS_VSPEC_TIMEBINS][nobsdirections*nspectraperobsdir][ARTIS_VSPEC_NUBINS][3], and the
+   * velocity-grid map vgrid[ny][nz].flux[wlbin][obsdir].{I, Q, U} (:138): [ARTIS_VGRID_NY][ARTIS_VGRID_NZ][grid_nwavelengthranges]
+   * [nobsdirections][3]. Builds with VPKT_ON; may be NULL (ABI 5). The counters nvpkt_created / nvpkt_esc_from_* are
+   * stats[ARTIS_STAT_X_VPKT_*]. */
+  double *vspecpol;
+  double *vgrid_flux;
 } artis_estimators;
 enum {
   ARTIS_SCALAR_GAMMA_DEP_DISCRETE = 0,   /* globals::timesteps[nts].gamma_dep_discrete gammapkt.cc:926 */
@@ -436,7 +476,7 @@ typedef struct artis_amd_engine artis_amd_engine;
 #define ARTIS_ERR_RCCL (-6)
 
 const char *artis_amd_last_error(void);
-int artis_amd_abi_version(void); /* 4: artis_cellstate.elem_meanweight appended (3: cell state and estimators of the nltenebular options) */
+int artis_amd_abi_version(void); /* 5: virtual-packet configuration and spectra appended; 4: artis_cellstate.elem_meanweight appended (3: cell state and estimators of the nltenebular options) */
 /* Name of the options preset the library was compiled with (include/artis_options.h): "classic" or "kilonova_lte".
  * Like the reference, one binary per artisoptions.h. */
 const char *artis_amd_options_preset(void);

@@ -32,7 +32,19 @@
  *                                          FIRST_NLTE_RADFIELD_TIMESTEP 7
  *   -DARTIS_PRESET_CI_NEBULAR_LIMITBFEST   setup_nebular_1d_3dgrid_limitbfest.sh: + LEVEL_HAS_BFEST for the NLTE levels only
  *   -DARTIS_PRESET_CI_NLTEPHOTOSPHERIC     setup_nltephotospheric_dynamic_ion_range_1d_1dgrid.sh: TABLESIZE 40,
- *                                          FIRST_NLTE_RADFIELD_TIMESTEP 4, RADFIELDBINCOUNT 24 */
+ *                                          FIRST_NLTE_RADFIELD_TIMESTEP 4, RADFIELDBINCOUNT 24
+ *   -DARTIS_PRESET_CI_CLASSIC_VPKT         setup_classicmode_1d_3dgrid.sh: classic + VPKT_ON (virtual packets, vpkt.cc: at every
+ *                                          emission and electron scattering a packet is traced towards each observer and
+ *                                          its attenuated energy added to that observer's spectrum)
+ *   -DARTIS_PRESET_CI_CLASSIC_VPKT_EXPOPAC setup_classicmode_3d.sh: + VPKT_USE_EXPANSION_OPACITIES (the virtual packets
+ *                                          walk the binned expansion opacities beyond their first wavelength bin) */
+#ifdef ARTIS_PRESET_CI_CLASSIC_VPKT
+#define ARTIS_OPT_VPKT_ON 1
+#endif
+#ifdef ARTIS_PRESET_CI_CLASSIC_VPKT_EXPOPAC
+#define ARTIS_OPT_VPKT_ON 1
+#define ARTIS_OPT_VPKT_USE_EXPANSION_OPACITIES 1
+#endif
 #if defined(ARTIS_PRESET_CI_KILONOVA) || defined(ARTIS_PRESET_CI_KILONOVA_BARNES) || defined(ARTIS_PRESET_CI_KILONOVA_EXPOPAC) || \
     defined(ARTIS_PRESET_CI_KILONOVA_XCOM)
 #define ARTIS_PRESET_KILONOVA_LTE
@@ -340,6 +352,14 @@
 #ifndef ARTIS_OPT_VPKT_USE_EXPANSION_OPACITIES
 #define ARTIS_OPT_VPKT_USE_EXPANSION_OPACITIES 0    /* artisoptions_classic.h:138 */
 #endif
+#if ARTIS_OPT_VPKT_ON && !ARTIS_OPT_POL_ON
+#error "VPKT_ON needs POL_ON (vpkt.cc:44)"
+#endif
+#if ARTIS_OPT_VPKT_ON && ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES
+#error "VPKT cannot be used with r-packet expansion opacities (rpkt.cc:44)"
+#endif
+/* the per-cell tables of calculate_expansion_opacities() exist (rpkt.cc:953, :1055, :1102) */
+#define ARTIS_EXPOPAC_TABLES (ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION || ARTIS_OPT_VPKT_USE_EXPANSION_OPACITIES)
 /* gamma packets: the classic choices (artisoptions_classic.h:144-150) are the ones built */
 #ifndef ARTIS_OPT_USE_XCOM_GAMMAPHOTOION
 #define ARTIS_OPT_USE_XCOM_GAMMAPHOTOION 0            /* artisoptions_classic.h:144: Veigele fit for the photoelectric opacity */

@@ -1287,7 +1287,7 @@ static void cellcache_free_one(CellCache *cc) {
   memset(cc, 0, sizeof(*cc));
 }
 
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
 static void calculate_expansion_opacities(Oracle *o, CellCache *cc, int c);
 #endif
 /* cellcacheslot_populate update_packets.cc:397. As in the reference's CPU build (cellcache_singleslot,
@@ -1362,7 +1362,7 @@ static void cellcache_populate(Oracle *o, int c) {
     for (int t = 0; t < nt; t++) cc->corrphotoioncoeff[m->level_phixstargetstart[ul] + t] = calc_corrphotoioncoeff(o, c, ul, t);
     cc->maprocessrates[(ptrdiff_t)ul * ARTIS_MA_ACTION_COUNT] = -99.; /* update_packets.cc:461 */
   }
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
   if (!o->cs->expansionopacities && o->cs->thick[c] != ARTIS_CELL_THICK) calculate_expansion_opacities(o, cc, c); /* update_grid.cc:655 */
 #endif
   cc->have_ion_cooling = 0;
@@ -1616,7 +1616,7 @@ static double get_possible_event(Oracle *o, const CellCache *cc, const artis_pac
 }
 
 /* emit_rpkt rpkt.cc:991 */
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
 /* wavelength bins in ascending wavelength (descending frequency), rpkt.h:30-40 */
 static inline double get_expopac_bin_nu_upper(ptrdiff_t binindex) {
   return 1e8 * CLIGHT / (ARTIS_EXPOPAC_LAMBDAMIN + ((double)binindex * ARTIS_EXPOPAC_DELTALAMBDA));
@@ -1677,7 +1677,7 @@ static void calculate_expansion_opacities(Oracle *o, CellCache *cc, int c) {
   }
 }
 #endif
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
 /* the cell's tables: the host's (artis_cellstate) or the ones calculate_expansion_opacities() below made at population */
 static const float *cell_expansionopacities(const Oracle *o, int c) {
   return o->cs->expansionopacities ? o->cs->expansionopacities + ((ptrdiff_t)c * ARTIS_EXPOPAC_NBINS) : o->cache[c].expansionopacities;
@@ -1997,6 +1997,276 @@ static double select_continuum_nu(Oracle *o, int element, int lowerion, int lowe
 }
 
 /* ------------------------------------------------------------------ macroatom.cc */
+
+#if ARTIS_OPT_VPKT_ON
+/* ------------------------------------------------------------------ vpkt.cc: virtual packets
+ * Restated from vpkt.cc:116-490 and :948-1010. The per-call continuum opacity of a virtual packet is a fresh
+ * ContinuumOpacity per traced direction (THREADLOCALONHOST is empty in the reference's GPU build, constants.h:110). */
+#define PARSEC 3.0857e+18 /* constants.h:39 */
+static inline double get_loggrid_edge(double minvalue, double dlog, double index) { return exp(log(minvalue) + (index * dlog)); } /* sn3d.h:142 */
+static inline ptrdiff_t get_logbinindex(double value, double minvalue, double dlog, ptrdiff_t nbins) { /* sn3d.h:134 */
+  ptrdiff_t i = (ptrdiff_t)floor((log(value) - log(minvalue)) / dlog);
+  return i < 0 ? 0 : (i > nbins - 1 ? nbins - 1 : i);
+}
+static inline double vspec_dlogt(void) { return (log(ARTIS_VSPEC_TIMEMAX) - log(ARTIS_VSPEC_TIMEMIN)) / ARTIS_VSPEC_TIMEBINS; } /* vpkt.cc:106 */
+static inline double vspec_dlognu(void) { return (log(ARTIS_VSPEC_NUMAX) - log(ARTIS_VSPEC_NUMIN)) / ARTIS_VSPEC_NUBINS; }   /* vpkt.cc:107 */
+/* add_to_vspecpol vpkt.cc:116 (delta_t and delta_freq_vspec are floats there: init_vspecpol vpkt.cc:491-512) */
+static void add_to_vspecpol(Oracle *o, double nu_rf, double e_rf, double prob, double q_rf, double u_rf, int obsdirindex,
+                            int opachoiceindex, double t_arrive) {
+  const artis_model *m = o->m;
+  if (t_arrive <= ARTIS_VSPEC_TIMEMIN || t_arrive >= ARTIS_VSPEC_TIMEMAX || nu_rf <= ARTIS_VSPEC_NUMIN || nu_rf >= ARTIS_VSPEC_NUMAX) return;
+  const int nt = (int)get_logbinindex(t_arrive, ARTIS_VSPEC_TIMEMIN, vspec_dlogt(), ARTIS_VSPEC_TIMEBINS);
+  const int nnu = (int)get_logbinindex(nu_rf, ARTIS_VSPEC_NUMIN, vspec_dlognu(), ARTIS_VSPEC_NUBINS);
+  const float lower_time = (float)get_loggrid_edge(ARTIS_VSPEC_TIMEMIN, vspec_dlogt(), nt);
+  const float delta_t = (float)(get_loggrid_edge(ARTIS_VSPEC_TIMEMIN, vspec_dlogt(), nt + 1) - lower_time);
+  const float lower_freq = (float)get_loggrid_edge(ARTIS_VSPEC_NUMIN, vspec_dlognu(), nnu);
+  const float delta_freq = (float)(get_loggrid_edge(ARTIS_VSPEC_NUMIN, vspec_dlognu(), nnu + 1) - lower_freq);
+  const int ind_comb = (m->vpkt_nspectraperobsdir * obsdirindex) + opachoiceindex;
+  const double pktcontrib = e_rf / delta_t / delta_freq / 4.e12 / PI / PARSEC / PARSEC / m->vpkt_nprocs * 4 * PI;
+  double *flux = o->est.vspecpol + ((((ptrdiff_t)nt * (m->vpkt_nobsdirections * m->vpkt_nspectraperobsdir) + ind_comb) * ARTIS_VSPEC_NUBINS + nnu) * 3);
+  flux[0] += prob * pktcontrib;
+  flux[1] += prob * q_rf * pktcontrib;
+  flux[2] += prob * u_rf * pktcontrib;
+}
+/* add_to_vpkt_grid vpkt.cc:138 */
+static void add_to_vpkt_grid(Oracle *o, double nu_rf, double e_rf, double prob, double stokes_q, double stokes_u, const double vel[3],
+                             int wlbin, int obsdirindex, const double obsdir[3]) {
+  const artis_model *m = o->m;
+  double vref1, vref2;
+  if (obsdir[0] == 1) {
+    vref1 = vel[1];
+    vref2 = vel[2];
+  } else if (obsdir[0] == -1) {
+    vref1 = -vel[1];
+    vref2 = -vel[2];
+  } else {
+    const double crossterm = obsdir[1] * obsdir[2] / (1 + obsdir[0]);
+    vref1 = (-obsdir[1] * vel[0]) + ((obsdir[0] + (pow2(obsdir[2]) / (1 + obsdir[0]))) * vel[1]) - (crossterm * vel[2]);
+    vref2 = (-obsdir[2] * vel[0]) - (crossterm * vel[1]) + ((obsdir[0] + (pow2(obsdir[1]) / (1 + obsdir[0]))) * vel[2]);
+  }
+  if (fabs(vref1) >= m->vmax || fabs(vref2) >= m->vmax) return;
+  const int ny = (int)((m->vmax - vref1) / (2 * m->vmax / ARTIS_VGRID_NY));
+  const int nz = (int)((m->vmax - vref2) / (2 * m->vmax / ARTIS_VGRID_NZ));
+  if (nu_rf > m->vpkt_nu_grid_min[wlbin] && nu_rf < m->vpkt_nu_grid_max[wlbin]) {
+    double *flux = o->est.vgrid_flux + (((((ptrdiff_t)ny * ARTIS_VGRID_NZ + nz) * m->vpkt_grid_nwavelengthranges + wlbin) * m->vpkt_nobsdirections + obsdirindex) * 3);
+    flux[0] += prob * e_rf;
+    flux[1] += prob * stokes_q * e_rf;
+    flux[2] += prob * stokes_u * e_rf;
+  }
+}
+static int all_taus_past_taumax(const double *tau, int n, double tau_max) { /* vpkt.cc:111 */
+  for (int i = 0; i < n; i++)
+    if (!(tau[i] > tau_max)) return 0;
+  return 1;
+}
+#define VPKT_MAXSPEC 16
+/* the loop of trace_lines_to_dist (vpkt.cc:298-358): 0 when every opacity choice is past tau_max */
+static int vpkt_trace_lines_to_dist(Oracle *o, const CellCache *cc, double dist_limit, double t_future, double nu_cmf, double dnu_on_dl,
+                                    int *next_trans, double *tau_vpkt) {
+  const artis_model *m = o->m;
+  const double t_gridstate = o->ts.mid;
+  while (1) {
+    const int lineindex = closest_transition(m->line_nu, m->nlines, nu_cmf, *next_trans);
+    if (lineindex < 0) {
+      *next_trans = m->nlines + 1;
+      break;
+    }
+    const double nutrans = m->line_nu[lineindex];
+    *next_trans = lineindex + 1;
+    const double ldist = get_linedistance(t_future, nu_cmf, nutrans, dnu_on_dl);
+    if (ldist > dist_limit) {
+      (*next_trans)--;
+      break;
+    }
+    const double t_line = t_future + (ldist / CLIGHT_PROP);
+    const double B_ul = m->line_B_ul[lineindex];
+    const double B_lu = m->line_B_lu[lineindex];
+    const double n_u = cc->levelpops[m->line_uniquelevelindex_upper[lineindex]]; /* calculate_levelpop(): what the cache holds */
+    const double n_l = cc->levelpops[m->line_uniquelevelindex_lower[lineindex]];
+    const double popscalefactor = pow3(t_gridstate / t_line);
+    const double tau_line = dmax(0., ((B_lu * n_l) - (B_ul * n_u)) * popscalefactor * HCLIGHTOVERFOURPI * t_line);
+    const int Z = m->elem_anumber[m->line_elementindex[lineindex]];
+    for (int i = 0; i < m->vpkt_nspectraperobsdir; i++)
+      if (m->vpkt_opacityexclusions[i] != -1 && m->vpkt_opacityexclusions[i] != Z) tau_vpkt[i] += tau_line;
+    if (all_taus_past_taumax(tau_vpkt, m->vpkt_nspectraperobsdir, m->vpkt_tau_max)) return 0;
+  }
+  return 1;
+}
+/* trace_vpkt_direction vpkt.cc:183 */
+static int trace_vpkt_direction(Oracle *o, const artis_packet *rpkt, double t_arrive, double nu_rf, double e_rf, double rpkt_doppler,
+                                int obsdirindex, const double obsdir[3], int type_before_rpkt) {
+  const artis_model *m = o->m;
+  const int nspec = m->vpkt_nspectraperobsdir;
+  int cellindex = rpkt->cellindex;
+  int next_trans = rpkt->next_trans;
+  double e_cmf = rpkt->e_cmf;
+  double nu_cmf = rpkt->nu_cmf;
+  double vpktpos[3] = {rpkt->pos[0], rpkt->pos[1], rpkt->pos[2]};
+  int end_packet = 0;
+  const double t_start = rpkt->prop_time;
+  double t_future = t_start;
+  const double t_gridstate = o->ts.mid;
+  double tau_vpkt[VPKT_MAXSPEC];
+  for (int i = 0; i < nspec; i++) tau_vpkt[i] = 0.;
+  stat_inc(o, ARTIS_STAT_X_VPKT_CREATED);
+  double vel_vec[3];
+  get_velocity(rpkt->pos, t_start, vel_vec);
+  double pn = 1 / (4 * PI);
+  double q_rf = 0., u_rf = 0.;
+  if (type_before_rpkt == ARTIS_TYPE_RPKT) {
+    double old_dir_cmf[3], q_i_cmf = 0., u_i_cmf = 0.;
+#if ARTIS_OPT_POL_ON
+    frame_transform(rpkt->dir, rpkt->stokes_q, rpkt->stokes_u, vel_vec, old_dir_cmf, &q_i_cmf, &u_i_cmf);
+#else
+    angle_ab(rpkt->dir, vel_vec, old_dir_cmf);
+#endif
+    double obs_cmf[3];
+    angle_ab(obsdir, vel_vec, obs_cmf);
+    double new_dir_rf[3];
+    scatter_polarisation_to_rf(old_dir_cmf, obs_cmf, q_i_cmf, u_i_cmf, vel_vec, new_dir_rf, &q_rf, &u_rf);
+    /* pn of scatter_polarisation_to_rf (vectors.h:353): the phase function of the scattering */
+    {
+      double ref1[3], ref2[3];
+      meridian(old_dir_cmf, ref1, ref2);
+      const double i1 = get_rot_angle(old_dir_cmf, obs_cmf, ref1, ref2);
+      const double q_old = (q_i_cmf * cos(2 * i1)) - (u_i_cmf * sin(2 * i1));
+      const double musquared = pow2(dot3(old_dir_cmf, obs_cmf));
+      pn = 3. / (16. * PI) * (1. + musquared + ((musquared - 1.) * q_old));
+    }
+  }
+  pn /= pow2(rpkt_doppler);
+
+  int mgi = propcell_nonemptymgi(o, cellindex); /* model cells are the non-empty cells here */
+  ContOpacity chi_vpkt_cont;
+  memset(&chi_vpkt_cont, 0, sizeof(chi_vpkt_cont));
+  chi_vpkt_cont.nonemptymgi = -1;
+  chi_vpkt_cont.nu = NAN;
+  while (!end_packet) {
+    int next_cellindex = -1;
+    const double boundarydist = boundary_distance(o, obsdir, vpktpos, t_future, cellindex, &next_cellindex);
+    if (mgi < 0) {
+      next_trans = -1;
+    } else if (boundarydist > 0) {
+      const int c = mgi;
+      cellcache_populate(o, c);
+      const CellCache *cc = &o->cache[c];
+      const double doppler = doppler_nucmf_on_nurf(vpktpos, obsdir, t_future);
+      /* calculate_chi_rpkt_cont<false> rpkt.cc:1021: the same sums without the packet's phixslist */
+      if (!((c == chi_vpkt_cont.nonemptymgi) && (fabs((chi_vpkt_cont.nu / nu_cmf) - 1.0) < 1e-4))) {
+        chi_vpkt_cont.chi_freefree_heat = calculate_chi_ffheating(o, cc, c, nu_cmf);
+        chi_vpkt_cont.chi_escatter = SIGMA_T * cell_nne(o, c);
+        int dummy = -1;
+        chi_vpkt_cont.chi_boundfree = calculate_chi_bf_gammacontr(o, cc, c, nu_cmf, NULL, 1, DBL_MAXV, &dummy, NULL);
+        chi_vpkt_cont.nonemptymgi = c;
+        chi_vpkt_cont.nu = nu_cmf;
+      }
+      const double densityscalefactor = pow3(t_gridstate / t_future);
+      const double chi_escatter = chi_vpkt_cont.chi_escatter * densityscalefactor;
+      const double chi_bf = chi_vpkt_cont.chi_boundfree * densityscalefactor;
+      const double chi_ff = chi_vpkt_cont.chi_freefree_heat * pow2(densityscalefactor);
+      const double chi_cont = chi_escatter + chi_bf + chi_ff;
+      for (int i = 0; i < nspec; i++) {
+        double chi_cont_thischoice = chi_cont;
+        if (m->vpkt_opacityexclusions[i] == -2) {
+          chi_cont_thischoice -= chi_bf;
+        } else if (m->vpkt_opacityexclusions[i] == -3) {
+          chi_cont_thischoice -= chi_ff;
+        } else if (m->vpkt_opacityexclusions[i] == -4) {
+          chi_cont_thischoice -= chi_escatter;
+        }
+        tau_vpkt[i] += chi_cont_thischoice * boundarydist * doppler;
+      }
+      if (all_taus_past_taumax(tau_vpkt, nspec, m->vpkt_tau_max)) return 0;
+      const double pos_boundary[3] = {vpktpos[0] + (obsdir[0] * boundarydist), vpktpos[1] + (obsdir[1] * boundarydist),
+                                      vpktpos[2] + (obsdir[2] * boundarydist)};
+      const double nu_cmf_boundary =
+          dmin(nu_rf * doppler_nucmf_on_nurf(pos_boundary, obsdir, t_future + (boundarydist / CLIGHT_PROP)), nu_cmf);
+      const double dnu_on_dl = (nu_cmf_boundary - nu_cmf) / boundarydist;
+#if ARTIS_OPT_VPKT_USE_EXPANSION_OPACITIES
+      ptrdiff_t binindex_start = get_linearbinindex(1e8 * CLIGHT / nu_cmf, ARTIS_EXPOPAC_LAMBDAMIN, ARTIS_EXPOPAC_DELTALAMBDA);
+      if (binindex_start < -1) binindex_start = -1;
+      if (binindex_start < ARTIS_EXPOPAC_NBINS) {
+        const double first_bin_edge_nu = (binindex_start < 0) ? get_expopac_bin_nu_upper(0) : get_expopac_bin_nu_lower(binindex_start);
+        const double first_bin_edge_dist = get_linedistance(t_future, nu_cmf, first_bin_edge_nu, dnu_on_dl);
+        const double line_by_line_limit = dmin(first_bin_edge_dist, boundarydist);
+        next_trans = -1;
+        if (!vpkt_trace_lines_to_dist(o, cc, line_by_line_limit, t_future, nu_cmf, dnu_on_dl, &next_trans, tau_vpkt)) return 0;
+        double dist = line_by_line_limit;
+        if (dist < boundarydist) {
+          const float *kappa_bins = cell_expansionopacities(o, c);
+          for (ptrdiff_t binindex = binindex_start + 1; binindex < ARTIS_EXPOPAC_NBINS; binindex++) {
+            const double next_bin_edge_nu = get_expopac_bin_nu_lower(binindex);
+            const double binedgedist = get_linedistance(t_future, nu_cmf, next_bin_edge_nu, dnu_on_dl);
+            const float kappa = kappa_bins[binindex];
+            const double chi_bb_expansionopac = kappa * o->cs->rho[c] * densityscalefactor; /* float product first */
+            const double tau_bin = chi_bb_expansionopac * (dmin(binedgedist, boundarydist) - dist);
+            dist = dmin(binedgedist, boundarydist);
+            for (int i = 0; i < nspec; i++)
+              if (m->vpkt_opacityexclusions[i] != -1) tau_vpkt[i] += tau_bin;
+            if (all_taus_past_taumax(tau_vpkt, nspec, m->vpkt_tau_max)) return 0;
+            if (dist >= boundarydist) break;
+          }
+        }
+      }
+#else
+      if (!vpkt_trace_lines_to_dist(o, cc, boundarydist, t_future, nu_cmf, dnu_on_dl, &next_trans, tau_vpkt)) return 0;
+#endif
+    }
+    move_pkt_withtime_raw(vpktpos, obsdir, &t_future, nu_rf, &nu_cmf, e_rf, &e_cmf, boundarydist);
+    if (next_cellindex >= 0) {
+      if (next_cellindex != cellindex) snap_pos_to_cell(o, vpktpos, t_future, next_cellindex);
+      cellindex = next_cellindex;
+      mgi = propcell_nonemptymgi(o, cellindex);
+      if (mgi >= 0 && o->cs->thick[mgi] != ARTIS_CELL_THIN) return 0;
+    } else {
+      end_packet = 1;
+    }
+  }
+  if (type_before_rpkt == ARTIS_TYPE_RPKT) {
+    stat_inc(o, ARTIS_STAT_X_VPKT_ESC_RPKT);
+  } else if (type_before_rpkt == ARTIS_TYPE_KPKT) {
+    stat_inc(o, ARTIS_STAT_X_VPKT_ESC_KPKT);
+  } else if (type_before_rpkt == ARTIS_TYPE_MA) {
+    stat_inc(o, ARTIS_STAT_X_VPKT_ESC_MA);
+  }
+  for (int i = 0; i < nspec; i++) {
+    const double prob = pn * exp(-tau_vpkt[i]);
+    if (!isfinite(prob)) ORACLE_FAIL(o, "vpkt: prob not finite");
+    add_to_vspecpol(o, nu_rf, e_rf, prob, q_rf, u_rf, obsdirindex, i, t_arrive);
+  }
+  if (m->vpkt_vgrid_on) {
+    const double prob = pn * exp(-tau_vpkt[0]);
+    for (int wlbin = 0; wlbin < m->vpkt_grid_nwavelengthranges; wlbin++)
+      if ((nu_rf > m->vpkt_nu_grid_min[wlbin] && nu_rf < m->vpkt_nu_grid_max[wlbin]) && (t_arrive > m->vpkt_tmin_grid && t_arrive < m->vpkt_tmax_grid))
+        add_to_vpkt_grid(o, nu_rf, e_rf, prob, q_rf, u_rf, vel_vec, wlbin, obsdirindex, obsdir);
+  }
+  return 1;
+}
+/* trace_vpkts vpkt.cc:948 */
+static void trace_vpkts(Oracle *o, const artis_packet *pkt, int type_before_rpkt) {
+  const artis_model *m = o->m;
+  const int c = propcell_nonemptymgi(o, pkt->cellindex);
+  if (o->cs->thick[c] != ARTIS_CELL_THIN) return;
+  for (int obsdirindex = 0; obsdirindex < m->vpkt_nobsdirections; obsdirindex++) {
+    const double ct = m->vpkt_obsdirs_costheta[obsdirindex], ph = m->vpkt_obsdirs_phi[obsdirindex];
+    const double obsdir[3] = {sqrt(1 - (ct * ct)) * cos(ph), sqrt(1 - (ct * ct)) * sin(ph), ct};
+    const double t_arrive = pkt->prop_time - (dot3(pkt->pos, obsdir) / CLIGHT_PROP);
+    if (t_arrive >= m->vpkt_timemin_input && t_arrive <= m->vpkt_timemax_input) {
+      const double doppler = doppler_nucmf_on_nurf(pkt->pos, obsdir, pkt->prop_time);
+      const double nu_rf = pkt->nu_cmf / doppler;
+      const double e_rf = pkt->e_cmf / doppler;
+      for (int i = 0; i < m->vpkt_nwavelengthranges; i++) {
+        if ((nu_rf > m->vpkt_numin_input[i] && nu_rf < m->vpkt_numax_input[i]) ||
+            (pkt->absorptionfreq > m->vpkt_numin_input[i] && pkt->absorptionfreq < m->vpkt_numax_input[i])) {
+          (void)trace_vpkt_direction(o, pkt, t_arrive, nu_rf, e_rf, doppler, obsdirindex, obsdir, type_before_rpkt);
+          break;
+        }
+      }
+    }
+  }
+}
+#endif
+
 static int index_upperbound(const double *a, int n, double target) { return upper_bound_d(a, n, target); } /* sn3d.h:85 */
 
 /* do_macroatom_raddeexcitation macroatom.cc:204 */
@@ -2208,6 +2478,9 @@ static void do_macroatom(Oracle *o, artis_packet *p, const MacroAtomState *ma) {
       p->trueem_pos[2] = p->em_pos[2];
       p->trueem_time = p->em_time;
     }
+#if ARTIS_OPT_VPKT_ON
+    trace_vpkts(o, p, ARTIS_TYPE_MA); /* macroatom.cc:588 */
+#endif
   } else {
     p->trueemissiontype = ARTIS_EMTYPE_NOTSET;
   }
@@ -2227,6 +2500,9 @@ static void rpkt_event_continuum(Oracle *o, const CellCache *cc, artis_packet *p
   if (chi_rnd < chi_escatter) {
     p->nscatterings++;
     stat_inc(o, ARTIS_STAT_ELECTRON_SCATTERINGS);
+#if ARTIS_OPT_VPKT_ON
+    trace_vpkts(o, p, ARTIS_TYPE_RPKT); /* rpkt.cc:441 */
+#endif
     electron_scatter_rpkt(p);
     p->em_pos[0] = p->pos[0];
     p->em_pos[1] = p->pos[1];
@@ -2501,6 +2777,9 @@ static void do_kpkt(Oracle *o, artis_packet *p, double t2) {
     p->trueem_pos[0] = p->em_pos[0]; p->trueem_pos[1] = p->em_pos[1]; p->trueem_pos[2] = p->em_pos[2];
     p->trueem_time = p->em_time;
     p->nscatterings = 0;
+#if ARTIS_OPT_VPKT_ON
+    trace_vpkts(o, p, ARTIS_TYPE_KPKT); /* kpkt.cc:515 */
+#endif
   } else if (rndcoolingtype == ARTIS_COOLING_FREEBOUND) {
     const int lowerion = ion;
     const int lowerlevel = m->coolinglist_level[i];
@@ -2514,6 +2793,9 @@ static void do_kpkt(Oracle *o, artis_packet *p, double t2) {
     p->trueem_pos[0] = p->em_pos[0]; p->trueem_pos[1] = p->em_pos[1]; p->trueem_pos[2] = p->em_pos[2];
     p->trueem_time = p->em_time;
     p->nscatterings = 0;
+#if ARTIS_OPT_VPKT_ON
+    trace_vpkts(o, p, ARTIS_TYPE_KPKT); /* kpkt.cc:541 */
+#endif
   } else if (rndcoolingtype == ARTIS_COOLING_COLLEXC) {
     const float clumpednne = cell_clumpednne(o, c);
     const double contrib_low = (i > ionstart) ? cc->cooling_contrib[i - 1] : 0.;
@@ -3145,6 +3427,10 @@ static void oracle_init(Oracle *o, const artis_model *m, const artis_cellstate *
   o->last_phixs_nuovernuedge = (1.0 + (m->NPHIXSNUINCREMENT * (m->NPHIXSPOINTS - 1))); /* input.cc:310 */
   const char *cap = getenv("ARTIS_ORACLE_CACHE_CAP");
   o->cache_cap = cap ? atoi(cap) : 0;
+#if ARTIS_OPT_VPKT_ON
+  o->cache_cap = 0; /* a virtual packet fills the caches of the cells it crosses while its caller still reads one: no eviction */
+  if (!m->vpkt_obsdirs_costheta || m->vpkt_nspectraperobsdir > VPKT_MAXSPEC || !est->vspecpol) ORACLE_FAIL(o, "VPKT_ON: vpkt configuration / vspecpol missing");
+#endif
   /* input.cc:932-955: estimator index of every continuum and the estimators' edge frequencies */
   o->allcont_bfestimindex = (int32_t *)calloc((size_t)m->nbfcontinua + 1, sizeof(int32_t));
   o->bfestim_nu_edge = (double *)calloc((size_t)m->nbfcontinua + 1, sizeof(double));
@@ -3321,7 +3607,7 @@ float artis_oracle_phixs_fromtable(const float *xs, int npoints, double nuincrem
   return photoionisation_crosssection_fromtable(&o, xs, nu_edge, nu);
 }
 double artis_oracle_planck(double nu, double T) { return planck(nu, T); }
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
 long long artis_oracle_linearbinindex(double value, double minvalue, double binwidth) { return get_linearbinindex(value, minvalue, binwidth); }
 double artis_oracle_expopac_bin_nu(long long b, int upper) { return upper ? get_expopac_bin_nu_upper(b) : get_expopac_bin_nu_lower(b); }
 #endif

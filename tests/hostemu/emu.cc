@@ -29,6 +29,7 @@ struct Emu {
   std::vector<float> expopac_kappa;
   std::vector<double> expopac_planck;
   bool expopac_own = false;
+  VpktConfig vpkt_config;
   int32_t err = 0;
 };
 
@@ -49,12 +50,19 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
     e.env.E.radfieldbin_J = est->radfieldbin_J;
     e.env.E.radfieldbin_nuJ = est->radfieldbin_nuJ;
     e.env.E.bfrate_raw = est->bfrate_raw;
+    e.env.E.vspecpol = est->vspecpol;
+    e.env.E.vgrid_flux = est->vgrid_flux;
     e.env.E.Jb_lu_raw = est->Jb_lu_raw;
     if (est->Jb_lu_raw) {  // counted as f64 here (like the engine's block) and handed back as integers at the end
       e.lineest_count.assign((size_t)((int64_t)m->npts_nonempty * m->detailed_linecount) + 1, 0.);
       e.env.E.Jb_lu_contribcount = e.lineest_count.data();
     }
   }
+#if ARTIS_OPT_VPKT_ON
+  if (!make_vpkt_config(*m, e.vpkt_config) || !est || !est->vspecpol) e.err = 93;
+  e.env.M.vpkt = &e.vpkt_config;
+  e.env.vpkt_queue = nullptr;  // traced in place
+#endif
   const DevModel &M = e.env.M;
   const int64_t ncell = M.npts_nonempty;
 #define ALLOC(f, T, per) { e.cachebuf.emplace_back((size_t)(ncell * (int64_t)(per) + MAREC_SLACK) * sizeof(T)); e.env.K.f = (T *)e.cachebuf.back().data(); }
@@ -72,7 +80,7 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   e.env.tile_lo = 0;
   e.env.tile_hi = M.npts_nonempty;
   e.env.tile_all = 1;
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
   if (!e.env.C.expansionopacities) {  // the engine's own tables (artis_amd_set_cellstate), filled in populate_all()
     e.expopac_kappa.assign((size_t)(ncell * ARTIS_EXPOPAC_NBINS) + 1, 0.f);
     e.expopac_planck.assign((size_t)(ncell * ARTIS_EXPOPAC_NBINS) + 1, 0.);
@@ -111,7 +119,7 @@ void populate_all(Emu &e) {
     for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom(e.env, c, ul);
     populate_hotselect(e.env, c);
     for (int ul = 0; ul < M.nlevels; ul++) populate_hotfill(e.env, c, ul);
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
     if (e.expopac_own && e.env.C.thick[c] != ARTIS_CELL_THICK) {  // k_expopac, k_expopac_planck
       for (int b = 0; b < ARTIS_EXPOPAC_NBINS; b++) populate_expopac_bin(e.env, c, b);
       if (ARTIS_OPT_RPKT_BB_THERMALISATION) populate_expopac_planck(e.env, c);
@@ -150,7 +158,7 @@ double artis_emu_sigma_compton_partial(double x, double f_max) { return artis::s
 double artis_emu_choose_f(double xx, double zrand) { return artis::choose_f(xx, zrand); }
 double artis_emu_meanf_sigma(double x) { return artis::meanf_sigma(x); }
 double artis_emu_planck(double nu, double T) { return artis::planck(nu, T); }
-#if ARTIS_OPT_RPKT_USE_EXPANSION_OPACITIES || ARTIS_OPT_RPKT_BB_THERMALISATION
+#if ARTIS_EXPOPAC_TABLES
 // the wavelength-bin helpers of the expansion opacities (sn3d.h:115, rpkt.h:30-40), for tests/test_oracle_reference_props.py
 long long artis_emu_linearbinindex(double value, double minvalue, double binwidth) { return artis::linearbinindex(value, minvalue, binwidth); }
 double artis_emu_expopac_bin_nu(long long b, int upper) { return upper ? artis::expopac_bin_nu_upper(b) : artis::expopac_bin_nu_lower(b); }

@@ -7,7 +7,9 @@ from artis_amd import abi
 
 # Reference-defined counters must match exactly; so must the step counters this project adds.
 EXACT_STATS = list(range(abi.STAT_COUNT)) + [abi.STAT_X_RPKT_STEPS, abi.STAT_X_KPKT_STEPS, abi.STAT_X_LINES_VISITED,
-                                            abi.STAT_X_MA_JUMPS]
+                                            abi.STAT_X_MA_JUMPS,
+                                            # virtual packets created / escaped after an r-packet, k-packet, macro-atom (VPKT_ON builds)
+                                            *range(abi.STAT_X_VPKT_CREATED, abi.STAT_X_VPKT_CREATED + 4)]
 
 
 def compare_packets(got: np.ndarray, want: np.ndarray, rtol: float, what: str = "") -> dict:

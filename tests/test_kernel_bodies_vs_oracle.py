@@ -477,14 +477,17 @@ def test_detailed_line_estimators_bit_exact(oracle, gridtype, ncoord):
 CI_GRIDS = {"ci_kilonova": (abi.GRID_CYLINDRICAL2D, 6), "ci_kilonova_barnes": (abi.GRID_CYLINDRICAL2D, 6),
             "ci_kilonova_expopac": (abi.GRID_CYLINDRICAL2D, 6), "ci_kilonova_xcom": (abi.GRID_CYLINDRICAL2D, 6),
             "ci_nebular": (abi.GRID_CARTESIAN3D, 8), "ci_nebular_limitbfest": (abi.GRID_CARTESIAN3D, 8),
-            "ci_nltephotospheric": (abi.GRID_SPHERICAL1D, 16)}
+            "ci_nltephotospheric": (abi.GRID_SPHERICAL1D, 16),
+            "ci_classic_vpkt": (abi.GRID_CARTESIAN3D, 8), "ci_classic_vpkt_expopac": (abi.GRID_CARTESIAN3D, 8)}
 
 
 def ci_case(options):
     """model, cell state, timestep and a population of every packet type for one of the reference's CI option sets, with
     what the set's physics needs to be exercised (a light, fast ejecta for the Barnes efficiencies)"""
     gridtype, ncoord = CI_GRIDS[options]
-    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options, nts=13)
+    # (virtual packets: a timestep inside the spectra's own window of 3-8 days, vpkt.h:30)
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options, nts=13,
+                                     **({"t_days": 5.0, "thick_below_v": 3e8} if "vpkt" in options else {}))
     if options == "ci_kilonova_barnes":
         mtot = 5.0e-3 * 1.98855e33
         model = abi.Model({**model.d, "mtot_input": mtot, "ejecta_kinetic_energy": 0.5 * mtot * (0.2 * 2.99792458e10) ** 2})
@@ -521,3 +524,17 @@ def test_reference_ci_option_sets_bit_exact(oracle, options):
         assert ea.radfieldbin_J.size == model["npts_nonempty"] * abi.NEBULAR_FAMILY[options] and ea.radfieldbin_J.sum() > 0
     if options in ("ci_nebular_limitbfest", "ci_nltephotospheric"):
         assert 0 < model["nbfestim"] < model["nbfcontinua"] and np.count_nonzero(ea.bfrate_raw) > 50
+    if "vpkt" in options:
+        # virtual packets (vpkt.cc): created at every emission / electron scattering in a thin cell, escapes of all three
+        # origins, spectra of all observers and opacity choices filled, Q/U only from scattered packets
+        created, esc_r, esc_k, esc_ma = (int(ea.stats[i]) for i in (abi.STAT_X_VPKT_CREATED, abi.STAT_X_VPKT_CREATED + 1,
+                                                                     abi.STAT_X_VPKT_CREATED + 2, abi.STAT_X_VPKT_CREATED + 3))
+        assert created > 20000 and esc_r > 1000 and esc_k > 20 and esc_ma > 200 and created > esc_r + esc_k + esc_ma
+        v = ea.vspecpol.reshape(abi.VSPEC_TIMEBINS, 3 * 4, abi.VSPEC_NUBINS, 3)
+        per_comb = v[..., 0].sum(axis=(0, 2))
+        assert np.all(per_comb > 0) and np.all(v[..., 0] >= 0) and np.abs(v[..., 1]).sum() > 0
+        full, nolines = per_comb[0::4], per_comb[1::4]
+        assert np.all(nolines > full)                       # switching the line opacity off lets more through
+        if options == "ci_classic_vpkt":
+            assert ea.vgrid_flux.sum() > 0                  # the velocity-grid map
+            assert np.all(per_comb[3::4] >= full)           # without the lines of one element

@@ -18,6 +18,10 @@ NPK = 1200
 SEED = 4242
 
 
+def _build_kw(options):
+    return {"t_days": 5.0} if "vpkt" in options else {}  # virtual packets: inside the spectra's window of 3-8 days
+
+
 def _population(model, aux, start, count):
     pk = synth.make_packets(model, aux, NPK, seed_base=adist.rank_seed_base(SEED, 0, NPK), kpkt_fraction=0.2)
     return pk[start:start + count].copy()
@@ -26,7 +30,7 @@ def _population(model, aux, start, count):
 def _worker(rank, world, port, outdir, options):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    model, cs, ts, aux = synth.build("tiny", ncoord=6, options=options)
+    model, cs, ts, aux = synth.build("tiny", ncoord=6, options=options, **_build_kw(options))
     start, count = adist.packet_shard(NPK, world, rank)
     pk = _population(model, aux, start, count)
     est = abi.estimators_for(model, options)
@@ -46,18 +50,20 @@ def _worker(rank, world, port, outdir, options):
 import pytest
 
 
-@pytest.mark.parametrize("options", ["classic", "nltenebular", "nltenebular_lineest"])   # nltenebular: the block carries the bin and bound-free estimators too; _lineest: the detailed line estimators
+@pytest.mark.parametrize("options", ["classic", "nltenebular", "nltenebular_lineest", "ci_classic_vpkt"])   # nltenebular: the block carries the bin and bound-free estimators too; _lineest: the detailed line estimators
 def test_two_ranks_equal_one(tmp_path, options):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(2, port, str(tmp_path), options), nprocs=2, join=True)
-    model, cs, ts, aux = synth.build("tiny", ncoord=6, options=options)
+    model, cs, ts, aux = synth.build("tiny", ncoord=6, options=options, **_build_kw(options))
     pk = _population(model, aux, 0, NPK)
     est = abi.estimators_for(model, options)
     emu.update_packets(model, cs, ts, pk, est, preset=options)
     block = np.load(tmp_path / "block.npy")
     want = adist.flatten_estimators(est)
+    if "vpkt" in options:
+        assert est.vspecpol.sum() > 0 and want.size > est.vspecpol.size
     assert np.allclose(block, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
     counters = np.load(tmp_path / "counters.npy")
     skip = abi.STAT_NAMES.index("UPDATECELL")  # each rank fills the cell cache once
