@@ -1566,6 +1566,7 @@ struct artis_amd_engine {
   PktStore P{};
   artis_packet *d_aos = nullptr;
   int64_t aos_capacity = 0;
+  bool aos_valid = false;  // d_aos still holds the caller's structs of the resident population (set by the upload)
   int32_t *d_lists[NEXT_NKINDS][2] = {};      // per kind: current and alternate work list
   int32_t *d_keys[NEXT_NKINDS][2] = {};       // ... and the sort keys of their entries
   int32_t *d_sorted = nullptr;                // counting-sort output
@@ -1756,6 +1757,7 @@ int ensure_aos(artis_amd_engine *e, int64_t n) {
   if (n <= e->aos_capacity && e->d_aos) return ARTIS_OK;
   if (e->d_aos) (void)hipFree(e->d_aos);
   e->d_aos = nullptr;
+  e->aos_valid = false;
   HIP_TRY(hipMalloc((void **)&e->d_aos, sizeof(artis_packet) * (size_t)(n > 0 ? n : 1)));
   e->aos_capacity = n;
   return ARTIS_OK;
@@ -2349,6 +2351,7 @@ int artis_amd_packets_upload(artis_amd_engine *e, const artis_packet *packets, i
   e->d_pkt_snapshot = nullptr;
   if (npackets > 0) {
     HIP_TRY(hipMemcpy(e->d_aos, packets, sizeof(artis_packet) * (size_t)npackets, hipMemcpyHostToDevice));
+    e->aos_valid = true;
     e->use_perm = false;
     if (e->slot_order_by_cell && e->sort_lists && npackets >= 2 * BLOCK) {
       // counting sort of the packet indices by propagation cell (the work-list sort kernels; the lists are free now)
@@ -2388,8 +2391,9 @@ int artis_amd_packets_download(artis_amd_engine *e, artis_packet *packets, int64
   if (npackets == 0) return ARTIS_OK;
   int rc = ensure_aos(e, npackets);
   if (rc != ARTIS_OK) return rc;
-  // start from the caller's structs so that the fields this path never touches keep their values
-  HIP_TRY(hipMemcpy(e->d_aos, packets, sizeof(artis_packet) * (size_t)npackets, hipMemcpyHostToDevice));
+  // the fields this path never touches keep the values the caller uploaded: the structs are still on the device from
+  // artis_amd_packets_upload() (no second trip over PCIe: 256 B per packet); copied again only if that buffer was replaced
+  if (!e->aos_valid) HIP_TRY(hipMemcpy(e->d_aos, packets, sizeof(artis_packet) * (size_t)npackets, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_rec_to_aos, dim3(nblocks(npackets)), dim3(BLOCK), 0, nullptr, e->P, e->d_aos, e->use_perm ? e->d_perm : nullptr);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(packets, e->d_aos, sizeof(artis_packet) * (size_t)npackets, hipMemcpyDeviceToHost));

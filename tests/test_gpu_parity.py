@@ -326,6 +326,43 @@ def test_estimator_allreduce_through_the_c_abi(engine_mod):
     eng.close()
 
 
+def test_compiled_reference_side_binding(engine_mod, tmp_path):
+    """tests/binding/update_packets_amd.cc: a C++20 translation unit that includes the REFERENCE's packet.h / constants.h /
+    stats.h (static_asserts: struct Packet == artis_packet member by member, packet types, counters), owns the packets as
+    std::span<Packet> and calls the engine through the C-ABI alone -- what a maintainer adds beside update_packets.cc.
+    Prebuilt by `make -C oracle ref` (the reference's headers do not travel to the GPU box; the binary does). Every
+    member of every packet is bit for bit that of the ctypes path; estimators to summation order."""
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "binding"))
+    import dump as bdump
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "update_packets_amd")
+    assert os.path.exists(exe), "oracle/_ref/update_packets_amd is missing: run `make -C oracle ref` where /root/reference exists"
+    model, cs, ts, aux = synth.build("small", ncoord=8)
+    pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.2, gamma_fraction=0.1, pellet_fraction=0.1)
+    dfile, ofile = str(tmp_path / "case.dump"), str(tmp_path / "case.out")
+    bdump.write_dump(dfile, model, cs, ts, pk0)
+    from artis_amd.build import so_path
+
+    out = subprocess.run([exe, so_path("classic"), dfile, ofile], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    pk_bin, est_bin, stats_bin = bdump.read_output(ofile, model, len(pk0))
+    eng = engine_mod.Engine(model)
+    eng.set_cellstate(cs, ts)
+    pk_py, est_py = pk0.copy(), abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
+    eng.update_packets(pk_py, est_py)
+    eng.close()
+    for f in abi.PACKET_DTYPE.names:  # every member bit for bit (the padding between members is nobody's: numpy's copy does not keep it)
+        assert pk_bin[f].tobytes() == pk_py[f].tobytes(), f
+    assert np.array_equal(stats_bin[parity.EXACT_STATS], np.asarray(est_py.stats)[parity.EXACT_STATS])
+    for k, a in est_bin.items():
+        b = est_py.arrays()[k]
+        assert np.abs(a - b).max() <= 1e-11 * max(np.abs(b).max(), 1e-300), k
+    assert "packet-steps" in out.stdout
+
+
 def test_cellcache_matches_oracle(engine_mod, oracle):
     model, cs, ts, aux = synth.build("small", ncoord=8, thick_below_v=4e8)
     eng = engine_mod.Engine(model)

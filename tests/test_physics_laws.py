@@ -7,6 +7,19 @@ evaluated on the packets the engine returns (GPU, `-m gpu`) and on the kernel bo
    time dt is Poisson distributed with mean kappa * rho * c * dt.
 3. Adiabatic losses (vectors.h:119 move_pkt_withtime + rpkt.cc:331 scattering in the comoving frame): radiation trapped
    in homologously expanding matter loses energy as 1/t: <e_cmf(t1)/e_cmf(t0)> = t0/t1.
+4. Thomson scattering (rpkt.cc:331 electron_scatter_rpkt with DIPOLE, vectors.h:325): unpolarised radiation scatters with
+   the phase function 3/(16 pi) (1 + mu^2): <mu> = 0, <mu^2> = 2/5 (isotropic would give 1/3).
+5. Free-free emission (kpkt.cc:495-515): a k-packet that cools by free-free emission emits at h nu / k T_e drawn from
+   exp(-x): mean 1, P(x > 1) = 1/e, P(x > 2) = 1/e^2.
+6. Cooling channels (kpkt.cc:57-260, :430-470): the channels k-packets of one cell leave through (free-free, free-bound,
+   collisional excitation, collisional ionisation) occur in the ratio of the cell's summed cooling rates of each kind.
+7. Free-bound emission (ratecoeff.cc:563 select_continuum_nu): the photons of one recombination continuum are distributed
+   as sigma_bf(nu) nu^3 exp(-h (nu - nu_edge) / k T_e) (the emissivity of Milne's relation): mean frequency and the
+   fraction above the median of that law.
+8. Compton scattering (gammapkt.cc:266-420): the energy ratio f = E'/E of the gamma packets that survive a scattering
+   follows f * dsigma/df of Klein and Nishina, dsigma/df ~ f + 1/f - 1 + cos^2(theta(f)): mean and quartile fractions.
+Each would catch a misreading of the transport loop that oracle and kernels share (same hand, same reading): a wrong
+phase function or frame, a wrong sampling law, a channel that is drawn with the wrong weight.
 """
 import numpy as np
 import pytest
@@ -131,6 +144,197 @@ def _check_grey(backend, n):
     assert abs(ns.var() / ns.mean() - 1.) < 6 * np.sqrt(2. / n) + 0.02, ns.var() / ns.mean()  # ... and Poisson variance
     ratio = (pk["e_cmf"] / e0).mean()                                                          # law 3: 1/t
     assert abs(ratio - ts.c.start / (ts.c.start + ts.c.width)) < 1.5e-3, ratio
+
+
+def _centre_cell(nc):
+    return (nc // 2) * (1 + nc + nc * nc)
+
+
+def _check_thomson(backend, n):
+    """r-packets of one frequency in the central cell (v << c: comoving and rest frame directions agree to 1e-3); those
+    that scattered off an electron exactly once and met nothing else"""
+    model, cs, ts, aux = synth.build("tiny", ncoord=7, width_frac=2e-4)  # ~0.2 scatterings per packet in this cell
+    cell = _centre_cell(7)
+    rng = np.random.default_rng(21)
+    pk = _rpackets(model, aux, cell, n, 6e14, rng, margin=0.3)
+    d0 = pk["dir"].copy()
+    backend(model, cs, ts, pk)
+    once = (pk["nscatterings"] == 1) & (pk["absorptiontype"] == -77) & (pk["type"] == abi.TYPE_RPKT) & (pk["emissiontype"] == abi.EMTYPE_NOTSET)
+    m = int(once.sum())
+    assert m > n // 50, m
+    mu = (d0[once] * pk["dir"][once]).sum(axis=1)
+    # var(mu) = 2/5, var(mu^2) = <mu^4> - (2/5)^2 = (2/5 + 2/7) / (8/3) - 4/25
+    assert abs(mu.mean()) < 4 * np.sqrt(0.4 / m) + 2e-3, mu.mean()
+    var_mu2 = (2 / 5 + 2 / 7) / (8 / 3) - 0.16
+    assert abs((mu**2).mean() - 0.4) < 4 * np.sqrt(var_mu2 / m) + 2e-3, ((mu**2).mean(), m)
+    assert abs((mu**2).mean() - 1 / 3) > 0.03  # ... and is told from isotropic scattering
+
+
+def _kpkt_case(n, width_frac=2e-5, preset="small", ncoord=6):
+    """k-packets, one very short timestep: each samples its cooling channel where it sits; what is emitted barely moves"""
+    model, cs, ts, aux = synth.build(preset, ncoord=ncoord, width_frac=width_frac)
+    pk = synth.make_packets(model, aux, n, kpkt_fraction=1.0, seed=7)
+    return model, cs, ts, aux, pk
+
+
+def _check_freefree_spectrum(backend, n):
+    model, cs, ts, aux, pk = _kpkt_case(n)
+    est = backend(model, cs, ts, pk)
+    ff = (pk["type"] == abi.TYPE_RPKT) & (pk["emissiontype"] == abi.EMTYPE_FREEFREE) & (pk["nscatterings"] == 0)
+    m = int(ff.sum())
+    assert m > n // 200 and est.stats_dict()["K_STAT_TO_R_FF"] >= m, m
+    c = model.d["propcell_nonemptymgi"][pk["cellindex"][ff]]
+    x = 6.6260755e-27 * pk["nu_cmf"][ff] / (1.38064852e-16 * cs.d["Te"][c].astype(np.float64))
+    assert abs(x.mean() - 1.) < 4 / np.sqrt(m) + 3e-3, (x.mean(), m)
+    for cut in (1., 2.):
+        pexp = np.exp(-cut)
+        assert abs(np.mean(x > cut) - pexp) < 4 * np.sqrt(pexp * (1 - pexp) / m) + 3e-3, (cut, np.mean(x > cut))
+
+
+def _check_cooling_channels(oracle, backend, n):
+    """all k-packets in ONE cell; expected channel fractions from the cell's cooling list (cumulative per ion, kpkt.cc:57)"""
+    model, cs, ts, aux = synth.build("small", ncoord=6, width_frac=2e-5)
+    c = model["npts_nonempty"] // 2
+    pk = synth.make_packets(model, aux, n, kpkt_fraction=1.0, seed=8, cells_only=[c])
+    est = backend(model, cs, ts, pk)
+    d = model.d
+    contrib = oracle.cellcache(model, cs, ts, c)["cooling_contrib"]
+    want = np.zeros(4)
+    for ui in range(d["nions"]):
+        o, nt = int(d["ion_coolingoffset"][ui]), int(d["ion_ncoolingterms"][ui])
+        terms = np.diff(np.concatenate([[0.], contrib[o:o + nt]]))
+        for k in range(4):
+            want[k] += terms[np.asarray(d["coolinglist_type"][o:o + nt]) == k].sum()
+    want /= want.sum()
+    st = est.stats_dict()
+    got = np.array([st["K_STAT_TO_R_FF"], st["K_STAT_TO_R_FB"], st["K_STAT_TO_MA_COLLEXC"], st["K_STAT_TO_MA_COLLION"]], dtype=np.float64)
+    tot = got.sum()
+    assert tot >= n
+    for k in range(4):
+        sig = np.sqrt(max(want[k] * (1 - want[k]), 1e-12) / tot)
+        assert abs(got[k] / tot - want[k]) < 5 * sig + 2e-3, (k, got / tot, want)
+
+
+def _check_freebound_spectrum(backend, n):
+    """every free-bound photon of the run (k-packet cooling and macro-atom recombination, any continuum, any cell) through
+    the probability integral transform of ITS continuum's law at ITS cell's temperature: the values are uniform on [0, 1].
+    (The masses of the law over the reference's pieces are what is tested; inside a piece the reference draws uniformly.)"""
+    model, cs, ts, aux, pk = _kpkt_case(n)
+    backend(model, cs, ts, pk)
+    d = model.d
+    fb = (pk["type"] == abi.TYPE_RPKT) & (pk["emissiontype"] < 0) & (pk["emissiontype"] > abi.EMTYPE_NOTSET) & (pk["nscatterings"] == 0) & \
+         (pk["emissiontype"] == pk["trueemissiontype"])
+    m = int(fb.sum())
+    assert m > n // 400, m
+    bfl = np.asarray(d["level_bflist_start"])
+    npts, inc = int(d["NPHIXSPOINTS"]), float(d["NPHIXSNUINCREMENT"])
+    allxs = np.asarray(d["allphixs"], dtype=np.float64)
+    cont_ul, cont_t = np.asarray(d["allcont_uniquelevelindex"]), np.asarray(d["allcont_phixstargetindex"])
+    cells = d["propcell_nonemptymgi"][pk["cellindex"]]
+    grid = np.linspace(0, inc * (npts - 1), 20001)
+    u = []
+    for code, c in set(zip(pk["emissiontype"][fb].tolist(), cells[fb].tolist())):
+        sel = fb & (pk["emissiontype"] == code) & (cells == c)
+        key = -1 - code   # emtype = -1 - level_bflist_start[ul] - t (atomic.h:508)
+        ul = int(np.searchsorted(bfl, key, side="right") - 1)
+        t = key - int(bfl[ul])
+        i = int(np.nonzero((cont_ul == ul) & (cont_t == t))[0][0])
+        nu_edge = float(d["allcont_nu_edge"][i])
+        xs = allxs[int(d["level_phixsstart"][ul]) * npts:][:npts]
+        nu = nu_edge * (1 + grid)
+        idx = np.minimum((grid / inc).astype(int), npts - 1)   # photoionisation_crosssection_fromtable, classic: no interpolation
+        w = xs[idx] * nu**3 * np.exp(-6.6260755e-27 * (nu - nu_edge) / (1.38064852e-16 * float(cs.d["Te"][c])))
+        cdf = np.concatenate([[0.], np.cumsum(0.5 * (w[1:] + w[:-1]))])
+        cdf /= cdf[-1]
+        got = pk["nu_cmf"][sel]
+        assert got.min() >= nu_edge * (1 - 1e-4) and got.max() <= nu[-1] * (1 + 1e-4), (code, got.min(), got.max(), nu_edge)
+        # select_continuum_nu() inverts the law piece by piece: NPHIXSPOINTS pieces of equal width, each drawn with its exact
+        # mass, the place inside a piece by linear interpolation (ratecoeff.cc:590-620): the law's CDF at the piece boundaries
+        bounds = nu_edge * (1 + np.linspace(0, inc * (npts - 1), npts + 1))
+        u.append(np.interp(got, bounds, np.interp(bounds, nu, cdf)))
+    u = np.concatenate(u)
+    assert abs(u.mean() - 0.5) < 4 * np.sqrt(1 / 12 / m) + 4e-3, (u.mean(), m)
+    assert abs(u.var() - 1 / 12) < 4 * np.sqrt(1 / 180 / m) + 4e-3, u.var()
+    for q in (0.25, 0.75):
+        assert abs(np.mean(u < q) - q) < 4 * 0.5 / np.sqrt(m) + 6e-3, (q, np.mean(u < q))
+
+
+def _check_compton(backend, n):
+    """gamma packets of 0.8 MeV (below the pair-production threshold, far above the photoelectric range), a timestep short
+    enough that few scatter twice; f = nu_cmf' / nu_cmf of the packets that are still gamma packets at another frequency"""
+    model, cs, ts, aux = synth.build("tiny", ncoord=6, width_frac=4e-4)
+    pk = synth.make_packets(model, aux, n, kpkt_fraction=0.0, gamma_fraction=1.0, seed=10)
+    isg = pk["type"] == abi.TYPE_GAMMA
+    nu0 = 0.8e6 * 1.6021772e-12 / 6.6260755e-27
+    dop = pk["nu_cmf"] / pk["nu_rf"]
+    pk["nu_cmf"] = np.where(isg, nu0, pk["nu_cmf"])
+    pk["nu_rf"] = np.where(isg, nu0 / dop, pk["nu_rf"])
+    backend(model, cs, ts, pk)
+    x = 0.8 / 0.51099891
+    fmin = 1 / (1 + 2 * x)
+    fcut = 0.99  # (the comoving frequency of a packet in flight drifts by ~1e-3 in this timestep: scattered = below the cut)
+    f_all = pk["nu_cmf"] / nu0
+    sc = isg & (pk["type"] == abi.TYPE_GAMMA) & (f_all < fcut) & (f_all > fmin * (1 - 3e-3))   # (below fmin: scattered twice)
+    m = int(sc.sum())
+    assert m > n // 200, m
+    assert np.count_nonzero(isg & (pk["type"] == abi.TYPE_GAMMA) & (f_all <= fmin * (1 - 3e-3))) < 0.05 * m
+    f = f_all[sc]
+    ff = np.linspace(fmin, fcut, 400001)
+    cos_t = 1 - (1 / ff - 1) / x
+    w = ff * (ff + 1 / ff - 1 + cos_t**2)          # survivors: f * dsigma/df (Klein-Nishina)
+    cdf = np.cumsum(w) / w.sum()
+    mean_want = (ff * w).sum() / w.sum()
+    sd = np.sqrt(((ff - mean_want) ** 2 * w).sum() / w.sum())
+    # (a few per cent of the packets scattered twice: their f is a product of two draws, lower than one)
+    assert abs(f.mean() - mean_want) < 4 * sd / np.sqrt(m) + 0.012, (f.mean(), mean_want, m)
+    for q in (0.25, 0.5, 0.75):
+        cut = ff[np.searchsorted(cdf, q)]
+        assert abs(np.mean(f < cut) - q) < 4 * 0.5 / np.sqrt(m) + 0.02, (q, np.mean(f < cut))
+
+
+def test_thomson_phase_function_kernel_bodies():
+    _check_thomson(_backend_emu, 120000)
+
+
+def test_freefree_emission_spectrum_kernel_bodies():
+    _check_freefree_spectrum(_backend_emu, 20000)
+
+
+def test_cooling_channel_fractions_kernel_bodies(oracle):
+    _check_cooling_channels(oracle, _backend_emu, 10000)
+
+
+def test_freebound_emission_spectrum_kernel_bodies():
+    _check_freebound_spectrum(_backend_emu, 20000)
+
+
+def test_compton_klein_nishina_kernel_bodies():
+    _check_compton(_backend_emu, 60000)
+
+
+@pytest.mark.gpu
+def test_thomson_phase_function_engine():
+    _check_thomson(_backend_gpu, 2000000)
+
+
+@pytest.mark.gpu
+def test_freefree_emission_spectrum_engine():
+    _check_freefree_spectrum(_backend_gpu, 600000)
+
+
+@pytest.mark.gpu
+def test_cooling_channel_fractions_engine(oracle):
+    _check_cooling_channels(oracle, _backend_gpu, 400000)
+
+
+@pytest.mark.gpu
+def test_freebound_emission_spectrum_engine():
+    _check_freebound_spectrum(_backend_gpu, 600000)
+
+
+@pytest.mark.gpu
+def test_compton_klein_nishina_engine():
+    _check_compton(_backend_gpu, 2000000)
 
 
 def test_sobolev_escape_probability_kernel_bodies(oracle):
