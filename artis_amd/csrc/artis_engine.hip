@@ -1591,6 +1591,10 @@ struct artis_amd_engine {
   int64_t klaunches[NEXT_NKINDS] = {};
   int64_t kthreads[NEXT_NKINDS] = {};
   int64_t last_nlaunches = 0;
+  // tiled runs: sweeps over the tiles, tile fills and their summed time, packets listed per (sweep, tile) of the last call
+  bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
+  int64_t last_sweeps = 0, last_tile_fills = 0, last_listed = 0;
+  double last_fill_ms = 0.;
   int budget_r = 8;      // do_rpkt_step() calls per packet per launch
   int budget_t = 2048;   // macro-atom transitions / k-packet steps per packet per launch
   bool sort_lists = true;
@@ -2110,6 +2114,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_CONTLDS")) e->cont_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_HOTLDS")) e->hot_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_HOTBLOCKS")) e->hot_blocks = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_TILE_ZIGZAG")) e->tile_zigzag = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_REFILL")) e->thermal_refill = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_REFILL_LOW")) e->refill_low = std::max(1, std::min(64, std::atoi(b)));
   if (const char *b = std::getenv("ARTIS_AMD_REFILL_MINPK")) e->refill_minpk = std::max(64, std::atoi(b));
@@ -2462,6 +2467,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   hipStream_t s = (hipStream_t)hip_stream;
   e->last_propagate_ms = 0.;
   e->last_nlaunches = 0;
+  e->last_sweeps = e->last_tile_fills = e->last_listed = 0;
+  e->last_fill_ms = 0.;
   for (int k = 0; k < NEXT_NKINDS; k++) {
     e->kms[k] = 0.;
     e->kms_tail = 0.;
@@ -2512,7 +2519,10 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   // sweep finds no packet left to advance.
   for (int sweep = 0;; sweep++) {
   bool any_active = false;
-  for (int tile = 0; tile < e->ntiles; tile++) {
+  for (int tstep = 0; tstep < e->ntiles; tstep++) {
+  // sweeps alternate their direction: a packet that left its tile against the direction of one sweep is met by the next
+  // one on its way back (with one direction it waits a whole sweep per backward crossing)
+  const int tile = (e->tile_zigzag && (sweep & 1)) ? e->ntiles - 1 - tstep : tstep;
   const int lo = (int)(tile * e->tile_cells);
   const int hi = (int)std::min<int64_t>(ncell_all, lo + e->tile_cells);
   if (e->tile_lo != lo || e->tile_hi != hi) {
@@ -2531,11 +2541,20 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   for (int k = 1; k < NEXT_NKINDS; k++) tile_active = tile_active || cnt[k] > 0;
   if (!tile_active) continue;
   any_active = true;
+  for (int k = 1; k < NEXT_NKINDS; k++) e->last_listed += cnt[k];
   if (e->tile_valid_lo != lo) {
+    HIP_TRY(hipEventRecord(e->ev2, s));
     rc = populate_tile(e, lo, hi, s);
     if (rc != ARTIS_OK) return rc;
+    HIP_TRY(hipEventRecord(e->ev3, s));
+    HIP_TRY(hipEventSynchronize(e->ev3));
+    float fms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&fms, e->ev2, e->ev3));
+    e->last_fill_ms += fms;
+    e->last_tile_fills++;
     env = make_env(e);
   }
+  if (e->trace) fprintf(stderr, "[artis_amd] sweep %d tile %d of %d: cells [%d, %d)\n", sweep, tile, e->ntiles, lo, hi);
 
   // one launch = the whole current list of one kind. Order: slow path, k-packets, macro-atoms, r-packets, so that a
   // k-packet -> macro-atom -> k-packet cycle costs two launches.
@@ -2678,6 +2697,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     }
   }
   }  // tiles
+  if (any_active) e->last_sweeps++;
   if (e->ntiles == 1 || !any_active) break;
   }  // sweeps
   for (int k = 1; k < NEXT_NKINDS; k++) e->last_propagate_ms += e->kms[k];
@@ -2855,6 +2875,15 @@ int artis_amd_last_kernel_breakdown(artis_amd_engine *e, double *rpkt_ms, int64_
   if (rpkt_threads) *rpkt_threads = e->kthreads[NEXT_RPKT];
   if (thermal_ms) *thermal_ms = e->kms[NEXT_MA] + e->kms[NEXT_KPKT];
   if (thermal_threads) *thermal_threads = e->kthreads[NEXT_MA] + e->kthreads[NEXT_KPKT];
+  return ARTIS_OK;
+}
+
+int artis_amd_last_tiling(artis_amd_engine *e, int64_t *sweeps, int64_t *tile_fills, double *fill_ms, int64_t *listed) {
+  if (!e) return ARTIS_ERR_ARG;
+  if (sweeps) *sweeps = e->last_sweeps;
+  if (tile_fills) *tile_fills = e->last_tile_fills;
+  if (fill_ms) *fill_ms = e->last_fill_ms;
+  if (listed) *listed = e->last_listed;
   return ARTIS_OK;
 }
 

@@ -75,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_last_kernel_table",
     "artis_amd_options_preset",
     "artis_amd_allreduce_estimators", "artis_amd_comm_unique_id", "artis_amd_comm_init", "artis_amd_comm_count",
-    "artis_amd_cache_tiles",
+    "artis_amd_cache_tiles", "artis_amd_last_tiling",
 ]
 
 
@@ -161,6 +161,13 @@ class Engine:
         self.L.artis_amd_cache_tiles.argtypes = [C.c_void_p] * 4
         self._check(self.L.artis_amd_cache_tiles(self.h, C.byref(nt), C.byref(cells), C.byref(bpc)))
         return nt.value, cells.value, bpc.value
+
+    def last_tiling(self):
+        """sweeps over the cache tiles, tile fills, their summed ms and the packets listed in the last step()"""
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_double(), C.c_int64()
+        self.L.artis_amd_last_tiling.argtypes = [C.c_void_p] * 5
+        self._check(self.L.artis_amd_last_tiling(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"sweeps": a.value, "tile_fills": b.value, "fill_ms": c.value, "listed": d.value}
 
     # estimator reduction in the C++ host layer (RCCL)
     COMM_ID_BYTES = 128

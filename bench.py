@@ -405,6 +405,8 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 out["rccl_nranks"] = None
                 print(f"[bench] ncclCommCount not available ({exc})", file=sys.stderr)
+        nt, tcells, bpc = eng.cache_tiles()
+        out["config"]["cell_cache"] = {"tiles": nt, "cells_per_tile": tcells, "bytes_per_cell": bpc, **(eng.last_tiling() if nt > 1 else {})}
         bd.update(ma_transitions=int(S("X_MA_JUMPS")), kpkt_steps=int(S("X_KPKT_STEPS")), rpkt_steps=int(S("X_RPKT_STEPS")))
         out["kernel_breakdown_last_step"] = bd
         if os.environ.get("ARTIS_BENCH_VERBOSE"):

@@ -551,6 +551,9 @@ int artis_amd_comm_count(artis_amd_engine *eng, void *nccl_comm, int *nranks);
 /* Timing of the dominant kernel inside the last artis_amd_update_packets_device
  * call, measured with HIP events on the launch stream. */
 int artis_amd_last_kernel_ms(artis_amd_engine *eng, double *propagate_ms, int64_t *nlaunches);
+/* Tiled cell cache (artis_amd_cache_tiles): sweeps over the tiles made by the last artis_amd_update_packets_device call, tile
+ * fills inside it with their summed duration [ms], and the packets listed over all (sweep, tile) visits. */
+int artis_amd_last_tiling(artis_amd_engine *eng, int64_t *sweeps, int64_t *tile_fills, double *fill_ms, int64_t *listed);
 
 /* Per-kernel split of the last artis_amd_update_packets_device call: summed launch durations [ms] and summed
  * packet counts of the r-packet kernel (k_rpkt) and of the thermal kernels (k_ma + k_kpkt). */
