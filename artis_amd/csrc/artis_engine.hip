@@ -664,7 +664,8 @@ __device__ inline void cellest_flush(const Env &env, int kind, double *global_ar
 }
 template <bool CONT_LDS>
 __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                   unsigned long long *gstats, int budget, int32_t *cursors, int nchunks) {
+                                                                   unsigned long long *gstats, int budget, int32_t *cursors, int nchunks,
+                                                                   int drain_budget) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
   __shared__ double lds_cellest[3 * (CONT_LDS ? RPKT_CELLEST_CAP : RPKT_CELLEST_CAP_NOCONT)];
@@ -683,6 +684,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
   Puller q;
   puller_init(q, n, nchunks);
   bool have = false;
+  bool drained = false;  // the launch's work list is used up (k_thermal: same hand-over to the next launch)
   int32_t pi = 0;
   int steps = 0;
   Pkt p;
@@ -699,6 +701,12 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
       steps = 0;
       have = true;
     }
+    if (!drained && q.exhausted) {
+      drained = true;
+      if ((threadIdx.x & 63) == 0) __hip_atomic_store(&cursors[MAX_CHUNKS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!drained && drain_budget < budget && (steps & 1) == 0)
+      drained = __hip_atomic_load(&cursors[MAX_CHUNKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     if (!__any(have)) {
       if (q.exhausted) break;
       continue;
@@ -721,7 +729,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
         go = rpkt_iter(env, p, pi, x);
         steps++;
       }
-      if (!go || steps >= budget) {
+      if (!go || steps >= budget || (drained && steps >= drain_budget)) {
         chi_store(env.P, pi, p, x);
         pkt_store(env.P, pi, p);
         kind = classify(env, p, ts_end);
@@ -976,7 +984,7 @@ __device__ inline int hot_acquire(HotSlots &hs, double *hot_lds, const Env &env,
 template <bool USE_LDS, int TB>
 __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                      unsigned long long *gstats, int budget, int32_t *cursors,
-                                                                     int nchunks, int chunk_mode) {
+                                                                     int nchunks, int chunk_mode, int drain_budget) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ HotSlots hs;
   __shared__ double __attribute__((aligned(16))) hot_lds[USE_LDS ? NSLOT * HOT_DOUBLES : 2];
@@ -1001,6 +1009,7 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
   int units = 0;
   int myslot = -1;       // LDS slot of this lane's cell
   bool slot_ok = false;  // ... and its copy is complete
+  bool drained = false;  // the launch's work list is used up (any wave found out)
   Pkt p;
   MACtx k;
 #ifdef ARTIS_PROFILE
@@ -1090,7 +1099,17 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
     const long long t2 = clock64();
     PROF_ADD(44, t2 - t1);
 #endif
-    if (have && (!go || units >= budget)) {
+    // Once the work list is used up, the launch lasts as long as its slowest packets keep their lanes (up to `budget`
+    // units each) while the rest of the GPU idles. In a launch whose successor is large anyway (drain_budget set by the
+    // host), a packet then leaves after drain_budget units for that next launch, where its work runs beside a full list.
+    // (Where a packet is handed from launch to launch never changes it: budgets are placement, tested.)
+    if (!drained && q.exhausted) {
+      drained = true;
+      if ((threadIdx.x & 63) == 0) __hip_atomic_store(&cursors[MAX_CHUNKS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!drained && drain_budget < budget)
+      drained = __hip_atomic_load(&cursors[MAX_CHUNKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    if (have && (!go || units >= budget || (drained && units >= drain_budget))) {
       pkt_store_thermal(env.P, pi, p);  // the hot line; the flight line only if an r-packet was emitted
       kind = classify(env, p, ts_end);
       out_pi = pi;
@@ -1597,6 +1616,10 @@ struct artis_amd_engine {
   double last_fill_ms = 0.;
   int budget_r = 8;      // do_rpkt_step() calls per packet per launch
   int budget_t = 2048;   // macro-atom transitions / k-packet steps per packet per launch
+  // ... and after the launch's list is used up (ARTIS_AMD_DRAIN_T; 0 = off), in launches of at least drain_min_list packets
+  int drain_t = 48;
+  int drain_r = 1;       // ... do_rpkt_step() calls after the r-packet list is used up (ARTIS_AMD_DRAIN_R; 0 = off)
+  int64_t drain_min_list = 1000000;
   bool sort_lists = true;
   bool sort_nu = true;
   bool sort_ma = true;
@@ -2077,7 +2100,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
   HIP_TRY(hipMemset(e->d_err, 0, sizeof(int32_t)));
   HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 2 * NEXT_NKINDS));
-  HIP_TRY(hipMalloc((void **)&e->d_cursors, sizeof(int32_t) * MAX_CHUNKS));
+  HIP_TRY(hipMalloc((void **)&e->d_cursors, sizeof(int32_t) * (MAX_CHUNKS + 1)));  // + the launch's "list used up" flag
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -2095,6 +2118,9 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   }
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_R")) e->budget_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_T")) e->budget_t = std::max(1, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_DRAIN_T")) e->drain_t = std::max(0, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_DRAIN_R")) e->drain_r = std::max(0, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_DRAIN_MIN")) e->drain_min_list = std::max(0, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_SLOTSORT")) e->slot_order_by_cell = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_BFDEFER")) e->bf_defer = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT")) e->sort_lists = std::atoi(b) != 0;
@@ -2618,16 +2644,18 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       // the kernel starts with an empty current list of its own kind: everything it keeps goes to the alternate list
       HIP_TRY(hipMemsetAsync(e->d_count + kind, 0, sizeof(int32_t), s));
       HIP_TRY(hipMemsetAsync(e->d_count + NEXT_NKINDS, 0, sizeof(int32_t), s));
-      HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * MAX_CHUNKS, s));
+      HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * (MAX_CHUNKS + 1), s));
       HIP_TRY(hipEventRecord(e->ev0, s));
       if (kind == NEXT_RPKT) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
         const int nch = e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8;
         if (e->cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0 &&
             !(env.cellest_n_r > RPKT_CELLEST_CAP))
-          hipLaunchKernelGGL((k_rpkt<true>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch);
+          hipLaunchKernelGGL((k_rpkt<true>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch,
+                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : e->budget_r);
         else
-          hipLaunchKernelGGL((k_rpkt<false>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch);
+          hipLaunchKernelGGL((k_rpkt<false>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch,
+                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : e->budget_r);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
         if (env.bfev != nullptr) {  // the estimator updates the launch recorded (the cells' cache rows are still resident)
           if (e->dense_cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX)
@@ -2648,7 +2676,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
           const int per_cu = std::max(1, e->thermal_blocks_per_cu * BLOCK / TBLOCK);
           const int grid = std::min((int)((nk + TBLOCK - 1) / TBLOCK), e->ncu * per_cu);
           hipLaunchKernelGGL((k_thermal<true, TBLOCK>), dim3(grid), dim3(TBLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
-                             e->d_cursors, chunks_for(nk, grid), 1);
+                             e->d_cursors, chunks_for(nk, grid), 1, e->budget_t);
         } else
 #endif
         if (e->thermal_refill) {  // in-kernel compaction of the macro-atom walkers (k_thermal_q)
@@ -2660,8 +2688,10 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
         } else {
           const int grid = std::min(nblocks(nk), e->ncu * e->thermal_blocks_per_cu);
           const bool per_cu = e->cu_chunks_t && nk >= 256 * 1024;
+          // (drain: only where the next thermal launch will be large too, so that what is handed on runs beside a full list)
+          const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : e->budget_t;
           hipLaunchKernelGGL((k_thermal<false, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
-                             e->d_cursors, per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8), per_cu ? 2 : 0);
+                             e->d_cursors, per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8), per_cu ? 2 : 0, drain);
         }
       } else if (kind == NEXT_BB) {
         hipLaunchKernelGGL(k_blackbody, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);

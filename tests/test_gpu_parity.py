@@ -530,6 +530,18 @@ def test_budget_independence_on_device(engine_mod, monkeypatch):
         eng.update_packets(p, abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"]))
         outs.append(p)
         eng.close()
+    # ... and the hand-over to the next launch once a launch's list is used up (ARTIS_AMD_DRAIN_T / _R), forced on for every
+    # launch however short its list, and switched off
+    monkeypatch.delenv("ARTIS_AMD_BUDGET", raising=False)
+    for env in ({"ARTIS_AMD_DRAIN_T": "1", "ARTIS_AMD_DRAIN_R": "1", "ARTIS_AMD_DRAIN_MIN": "0"}, {"ARTIS_AMD_DRAIN_T": "0", "ARTIS_AMD_DRAIN_R": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = engine_mod.Engine(model)
+        eng.set_cellstate(cs, ts)
+        p = pk0.copy()
+        eng.update_packets(p, abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"]))
+        outs.append(p)
+        eng.close()
     for p in outs[1:]:
         parity.compare_packets(p, outs[0], 0.0, "launch budget independence")
 
