@@ -93,6 +93,9 @@ def cpu_baseline(model, cs, ts, pk, sample: int, cores: int, options: str = "cla
     bounds = [(sample * i // cores, sample * (i + 1) // cores) for i in range(cores)]
     _cpu_worker.shared = (model, cs, ts, pk)
     _cpu_worker.options = options
+    from oracle import oracle_py
+
+    oracle_py.lib(options)  # loaded (and, if it has to be, built) ONCE here: the forked workers inherit it instead of racing to build it
     ctx = mp.get_context("fork")
     t0 = time.perf_counter()
     with ctx.Pool(cores) as pool:

@@ -95,6 +95,9 @@ def oracle_parallel(model, cs, ts, pk, est: abi.Estimators, preset: str = "class
     import multiprocessing as mp
     import os
 
+    from oracle import oracle_py
+
+    oracle_py.lib(preset)  # built (if its sources are newer) and loaded once here, not by every forked worker at once
     nproc = nproc or min(os.cpu_count() or 1, 16)
     n = len(pk)
     bounds = [(n * i // nproc, n * (i + 1) // nproc) for i in range(nproc)]

@@ -31,6 +31,10 @@ BIG_CASES = {
     # bench exercises -- many packets of one cell in a wave, sorted lists, chunked work pulling -- meet the oracle
     "w7_50cubed_dense_2e5": dict(build=dict(preset="w7", ncoord=50), npk=200_000, pkw=dict(kpkt_fraction=0.02),
                                  dense_cells=1500),
+    # the same cut for the nltenebular build (BASELINE.json configs[4] on the bench grid): the deferred bound-free estimator
+    # records and k_bfest_dense at the bench's packet density, against the oracle (smaller: its per-step work is ~15x)
+    "nltenebular_50cubed_dense_6e4": dict(build=dict(preset="w7", ncoord=50, options="nltenebular", nts=13), npk=60_000,
+                                          pkw=dict(kpkt_fraction=0.02), dense_cells=500),
 }
 
 
@@ -47,8 +51,9 @@ def oracle_big(oracle):
             pkw["cells_only"] = np.argsort(w)[-c["dense_cells"]:]
         pk0 = synth.make_packets(model, aux, c["npk"], **pkw)
         pa = pk0.copy()
-        ea = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
-        parity.oracle_parallel(model, cs, ts, pa, ea)
+        options = c["build"].get("options", "classic")
+        ea = abi.estimators_for(model, options)
+        parity.oracle_parallel(model, cs, ts, pa, ea, preset=options)
         out[name] = (model, cs, ts, pk0, pa, ea)
     return out
 
@@ -216,9 +221,10 @@ def test_engine_matches_oracle_w7_atomic_data(engine_mod, oracle):
 def test_engine_matches_oracle_large_cases(engine_mod, oracle_big, name):
     """configs[0] at its stated size and a dense cut of the bench grid (see BIG_CASES), same bars as the small cases"""
     model, cs, ts, pk0, pa, ea = oracle_big[name]
+    options = BIG_CASES[name]["build"].get("options", "classic")
     pb = pk0.copy()
-    eb = abi.Estimators(model["npts_nonempty"], model["nbfcontinua_ground"])
-    eng = engine_mod.Engine(model)
+    eb = abi.estimators_for(model, options)
+    eng = engine_mod.Engine(model, preset=options)
     eng.set_cellstate(cs, ts)
     eng.update_packets(pb, eb)
     rep = parity.compare_packets(pb, pa, FLOAT_RTOL, f"{name}: HIP engine vs oracle")
