@@ -1605,7 +1605,10 @@ struct artis_amd_engine {
   double last_propagate_ms = 0.;
   double kms[NEXT_NKINDS] = {};       // summed launch durations per kind of the last update_packets_device call
   double kms_tail = 0.;               // ... and of the tail kernel
-  int tail_max = 4096;                // r-packets + thermal packets left at which k_tail takes over (ARTIS_AMD_TAIL; 0 = never)
+  // (builds with the detailed bound-free estimators -- the nltenebular family -- alternate twice as often between the
+  // kernels and their r-packet steps are ~3x as heavy: measured optimum 16384 / 4 / 1024 instead of 4096 / 8 / 2048,
+  // nltenebular step 1801 -> 1690 ms, profiles/r03/neb_sweep*.txt)
+  int tail_max = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 16384 : 4096;  // r-packets + thermal packets left at which k_tail takes over (ARTIS_AMD_TAIL; 0 = never)
   bool tail_always = false;           // ... also for a population that starts below it (ARTIS_AMD_TAIL_ALWAYS=1)
   int64_t klaunches[NEXT_NKINDS] = {};
   int64_t kthreads[NEXT_NKINDS] = {};
@@ -1614,8 +1617,8 @@ struct artis_amd_engine {
   bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
   int64_t last_sweeps = 0, last_tile_fills = 0, last_listed = 0;
   double last_fill_ms = 0.;
-  int budget_r = 8;      // do_rpkt_step() calls per packet per launch
-  int budget_t = 2048;   // macro-atom transitions / k-packet steps per packet per launch
+  int budget_r = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 4 : 8;        // do_rpkt_step() calls per packet per launch
+  int budget_t = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 1024 : 2048;  // macro-atom transitions / k-packet steps per packet per launch
   // ... and after the launch's list is used up (ARTIS_AMD_DRAIN_T; 0 = off), in launches of at least drain_min_list packets
   int drain_t = 48;
   int drain_r = 1;       // ... do_rpkt_step() calls after the r-packet list is used up (ARTIS_AMD_DRAIN_R; 0 = off)
