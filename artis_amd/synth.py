@@ -635,6 +635,9 @@ PRESETS = {
     "tiny": ([(14, 1, 3), (26, 1, 4)], 6, 0.5, 12),
     "small": ([(14, 1, 4), (26, 1, 5), (27, 1, 5)], 12, 0.4, 40),
     "w7": ([(8, 1, 4), (14, 1, 5), (16, 1, 5), (20, 1, 4), (26, 1, 5), (27, 1, 5), (28, 1, 5)], 60, 0.3, 100),
+    # the same ions with 170 levels each: 5.6e3 levels, ~1.4e5 lines -- the size at which the cell cache of a 50^3 grid no
+    # longer fits one tile (profiles/r03/tiling.md)
+    "w7big": ([(8, 1, 4), (14, 1, 5), (16, 1, 5), (20, 1, 4), (26, 1, 5), (27, 1, 5), (28, 1, 5)], 170, 0.3, 100),
 }
 
 
