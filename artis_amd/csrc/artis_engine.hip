@@ -41,31 +41,37 @@ thread_local std::string g_last_error;
 constexpr int BLOCK = 256;
 
 // ------------------------------------------------------------------ populate kernels
+// The cells a fill works on: every cell of the resident tile, or -- a SPARSE fill (Env::fill_cells) -- the listed ones only
+// (the cells of the tile in which packets wait: the later sweeps of a tiled run bring a tile a few stragglers at a time).
+__device__ inline int64_t fill_count(const Env &env) { return env.fill_cells ? env.nfill : (env.tile_hi - env.tile_lo); }
+__device__ inline int fill_cell(const Env &env, int64_t k) { return env.fill_cells ? env.fill_cells[k] : env.tile_lo + (int)k; }
 __global__ void __launch_bounds__(BLOCK) k_levelpops(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nlevels;
+  const int64_t total = fill_count(env) * env.M.nlevels;
   if (i >= total) return;
-  populate_levelpop(env, env.tile_lo + (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
+  populate_levelpop(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
 __global__ void __launch_bounds__(BLOCK) k_line_dpop(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nlines;
+  const int64_t total = fill_count(env) * env.M.nlines;
   if (i >= total) return;
-  populate_line_dpop(env, env.tile_lo + (int)(i / env.M.nlines), (int)(i % env.M.nlines));
+  populate_line_dpop(env, fill_cell(env, i / env.M.nlines), (int)(i % env.M.nlines));
 }
 #if ARTIS_EXPOPAC_TABLES
 // calculate_expansion_opacities() for the cells of the resident tile, when the host did not hand the tables over
 __global__ void __launch_bounds__(BLOCK) k_expopac(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * ARTIS_EXPOPAC_NBINS;
+  const int64_t total = fill_count(env) * ARTIS_EXPOPAC_NBINS;
   if (i >= total) return;
-  const int c = env.tile_lo + (int)(i / ARTIS_EXPOPAC_NBINS);
+  const int c = fill_cell(env, i / ARTIS_EXPOPAC_NBINS);
   if (env.C.thick[c] == ARTIS_CELL_THICK) return;  // update_grid.cc:657
   populate_expopac_bin(env, c, (int)(i % ARTIS_EXPOPAC_NBINS));
 }
 __global__ void __launch_bounds__(BLOCK) k_expopac_planck(Env env) {
-  const int c = env.tile_lo + blockIdx.x * BLOCK + threadIdx.x;
-  if (c >= env.tile_hi || env.C.thick[c] == ARTIS_CELL_THICK) return;
+  const int64_t kf = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (kf >= fill_count(env)) return;
+  const int c = fill_cell(env, kf);
+  if (env.C.thick[c] == ARTIS_CELL_THICK) return;
   populate_expopac_planck(env, c);
 }
 #endif
@@ -78,17 +84,18 @@ __global__ void __launch_bounds__(BLOCK) k_nt_cells(Env env, int ncell) {
 }
 #endif
 __global__ void __launch_bounds__(BLOCK) k_cell_scalars(Env env) {
-  const int c = env.tile_lo + blockIdx.x * BLOCK + threadIdx.x;
-  if (c >= env.tile_hi) return;
+  const int64_t kf = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (kf >= fill_count(env)) return;
+  const int c = fill_cell(env, kf);
   populate_chi_ff(env, c);
 }
 // one wave = one 64-bit word of a cell's keep bitmap: the ballot IS the word (globals.h:296-305)
 __global__ void __launch_bounds__(BLOCK) k_allcont(Env env) {
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  const int64_t nwaves = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nkeepwords;
+  const int64_t nwaves = fill_count(env) * env.M.nkeepwords;
   if (wave >= nwaves) return;
-  const int c = env.tile_lo + (int)(wave / env.M.nkeepwords);
+  const int c = fill_cell(env, wave / env.M.nkeepwords);
   const int word = (int)(wave % env.M.nkeepwords);
   const int i = word * 64 + lane;
   bool keep = false;
@@ -98,9 +105,9 @@ __global__ void __launch_bounds__(BLOCK) k_allcont(Env env) {
 }
 __global__ void __launch_bounds__(BLOCK) k_corrphotoion(Env env, const int32_t *target_level) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nphixstargets_total;
+  const int64_t total = fill_count(env) * env.M.nphixstargets_total;
   if (i >= total) return;
-  const int c = env.tile_lo + (int)(i / env.M.nphixstargets_total);
+  const int c = fill_cell(env, i / env.M.nphixstargets_total);
   const int k = (int)(i % env.M.nphixstargets_total);
   const int ul = target_level[k];
   populate_corrphotoion(env, c, ul, k - env.M.level_phixstargetstart[ul]);
@@ -124,8 +131,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {  // 128 VGPR wi
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int nblk = env.M.nscanblk;
-  if (wave >= (int64_t)(env.tile_hi - env.tile_lo) * nblk) return;
-  const int c = env.tile_lo + (int)(wave / nblk);
+  if (wave >= fill_count(env) * nblk) return;
+  const int c = fill_cell(env, wave / nblk);
   const int blk = (int)(wave % nblk);
   const int a0 = env.M.scanblk_start[blk], a1 = env.M.scanblk_start[blk + 1];
   double *row = env.K.macache + ((int64_t)c * env.M.nmacache);
@@ -182,16 +189,16 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {  // 128 VGPR wi
 }
 __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nlevels;
+  const int64_t total = fill_count(env) * env.M.nlevels;
   if (i >= total) return;
-  populate_macroatom(env, env.tile_lo + (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
+  populate_macroatom(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
 // hot levels of every cell (physics.h populate_hotselect: the same rule, the levels spread over the lanes of one wave)
 __global__ void __launch_bounds__(BLOCK) k_hotselect(Env env) {
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (wave >= env.tile_hi - env.tile_lo) return;
-  const int c = env.tile_lo + (int)wave;
+  if (wave >= fill_count(env)) return;
+  const int c = fill_cell(env, wave);
   const int nl = env.M.nlevels;
   const int per = (nl + 63) / 64;
   const int l0 = lane * per < nl ? lane * per : nl;
@@ -231,9 +238,9 @@ __global__ void __launch_bounds__(BLOCK) k_hotselect(Env env) {
 }
 __global__ void __launch_bounds__(BLOCK) k_hotfill(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nlevels;
+  const int64_t total = fill_count(env) * env.M.nlevels;
   if (i >= total) return;
-  populate_hotfill(env, env.tile_lo + (int)(i / env.M.nlevels), (int)(i % env.M.nlevels));
+  populate_hotfill(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
 // The cooling list of a (cell, ion) is one running sum over hundreds of terms (kpkt.cc:57-190): a free-free term, the
 // collisional-excitation terms k_matrans left in collexc_cum (most of them), and the bound-free tail. Three kernels:
@@ -245,9 +252,9 @@ __global__ void __launch_bounds__(BLOCK) k_hotfill(Env env) {
 // travels between the kernels in ion_cooling_C.
 __global__ void __launch_bounds__(BLOCK) k_cooling_head(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * env.M.nions;
+  const int64_t total = fill_count(env) * env.M.nions;
   if (i >= total) return;
-  const int c = env.tile_lo + (int)(i / env.M.nions);
+  const int c = fill_cell(env, i / env.M.nions);
   const int ui = (int)(i % env.M.nions);
   int k = 0;
   env.K.ion_cooling_C[((int64_t)c * env.M.nions) + ui] = cooling_ion_head(env, c, ui, &k);
@@ -265,9 +272,9 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_chain(Env env) {
   const int64_t row_id = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4;
   const int r = threadIdx.x & 15;
   const DevModel &M = env.M;
-  const int64_t nchains = (int64_t)(env.tile_hi - env.tile_lo) * M.nions;
+  const int64_t nchains = fill_count(env) * M.nions;
   const bool valid = row_id < nchains;
-  const int c = env.tile_lo + (int)((valid ? row_id : 0) / M.nions);
+  const int c = fill_cell(env, (valid ? row_id : 0) / M.nions);
   const int ui = (int)((valid ? row_id : 0) % M.nions);
   const int start = M.ion_uniquelevelindexstart[ui];
   const int nlevels = M.ion_nlevels[ui];
@@ -299,9 +306,9 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_chain(Env env) {
 __global__ void __launch_bounds__(BLOCK) k_cooling_tail(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const DevModel &M = env.M;
-  const int64_t total = (int64_t)(env.tile_hi - env.tile_lo) * M.nions;
+  const int64_t total = fill_count(env) * M.nions;
   if (i >= total) return;
-  const int c = env.tile_lo + (int)(i / M.nions);
+  const int c = fill_cell(env, i / M.nions);
   const int ui = (int)(i % M.nions);
   // the entries written so far: the free-free one and one per level with upward transitions
   const int element = M.ion_element[ui];
@@ -311,8 +318,9 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_tail(Env env) {
   cooling_ion_tail(env, c, ui, env.K.ion_cooling_C[((int64_t)c * M.nions) + ui], k);
 }
 __global__ void __launch_bounds__(BLOCK) k_cooling_prefix(Env env) {
-  const int c = env.tile_lo + blockIdx.x * BLOCK + threadIdx.x;
-  if (c >= env.tile_hi) return;
+  const int64_t kf = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (kf >= fill_count(env)) return;
+  const int c = fill_cell(env, kf);
   populate_cooling_prefix(env, c);
 }
 
@@ -420,6 +428,43 @@ __global__ void __launch_bounds__(BLOCK) k_classify(Env env, Lists L, int reset_
     }
   }
   append_by_kind(kind, (int32_t)i, cellindex, nu_cmf, L);
+}
+
+// Sparse fill of a tile: mark the cells of the tile [lo, hi) in which a packet waits (the predicate of k_classify) ...
+__global__ void __launch_bounds__(BLOCK) k_mark_cells(Env env, uint32_t *resident) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= env.P.n) return;
+  const PktHot &h = env.P.hot[i];
+  const int type = h.type;
+  const bool active = type_handled(type) && h.prop_time < env.S.ts_end;
+  const bool waiting = h.pend != PEND_NONE || h.ma_level >= 0;
+  if (!(waiting || active) || (active && type_gamma(type) && !waiting)) return;
+  // ... and the cells around it (one step in every grid direction): an r-packet crosses a few cells per visit
+  const DevModel &M = env.M;
+  int idx[3], lo3[3], hi3[3];
+  for (int d = 0; d < 3; d++) {
+    idx[d] = (h.cellindex / M.coordstride[d]) % M.ncoordgrid[d];
+    lo3[d] = idx[d] > 0 ? -1 : 0;
+    hi3[d] = idx[d] < M.ncoordgrid[d] - 1 ? 1 : 0;
+  }
+  for (int dz = lo3[2]; dz <= hi3[2]; dz++)
+    for (int dy = lo3[1]; dy <= hi3[1]; dy++)
+      for (int dx = lo3[0]; dx <= hi3[0]; dx++) {
+        const int c = M.propcell_nonemptymgi[h.cellindex + (dx * M.coordstride[0]) + (dy * M.coordstride[1]) + (dz * M.coordstride[2])];
+        if (c >= env.tile_lo && c < env.tile_hi) atomicOr(&resident[c >> 5], 1u << (c & 31));
+      }
+}
+// ... and list them
+__global__ void __launch_bounds__(BLOCK) k_compact_cells(int lo, int hi, const uint32_t *resident, int32_t *cells, int32_t *count) {
+  const int c = lo + blockIdx.x * BLOCK + threadIdx.x;
+  const bool set = c < hi && ((resident[c >> 5] >> (c & 31)) & 1u) != 0;
+  const unsigned long long m = __ballot(set);
+  if (m == 0) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, __popcll(m));
+  base = __shfl(base, __ffsll((long long)m) - 1);
+  if (set) cells[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
 }
 
 // ---- counting sort of a work list by its entries' keys (propagation cell, frequency bin): three tiny kernels.
@@ -1614,6 +1659,13 @@ struct artis_amd_engine {
   int64_t kthreads[NEXT_NKINDS] = {};
   int64_t last_nlaunches = 0;
   // tiled runs: sweeps over the tiles, tile fills and their summed time, packets listed per (sweep, tile) of the last call
+  // sparse fills (later sweeps of a tiled run): the cells of the tile in which packets wait, as a bitmap over the model's
+  // non-empty cells and as a list; resident_on: the current visit runs on such a fill. ARTIS_AMD_SPARSE_FILL=0: whole tiles.
+  uint32_t *d_resident = nullptr;
+  int32_t *d_fill_cells = nullptr, *d_nfill = nullptr;
+  bool resident_on = false, sparse_fill = true;
+  int64_t sparse_max_listed = 512;  // ... for visits that list at most this many packets (ARTIS_AMD_SPARSE_MAX)
+  int64_t last_sparse_fills = 0, last_cells_filled = 0;
   bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
   int64_t last_sweeps = 0, last_tile_fills = 0, last_listed = 0;
   double last_fill_ms = 0.;
@@ -1695,6 +1747,9 @@ Env make_env(const artis_amd_engine *e) {
   env.tile_lo = e->tile_lo;
   env.tile_hi = e->tile_hi;
   env.tile_all = (e->tile_lo == 0 && e->tile_hi >= e->Mh.npts_nonempty) ? 1 : 0;
+  env.resident = e->resident_on ? e->d_resident : nullptr;
+  env.fill_cells = nullptr;  // (set by a sparse populate_tile() for its own launches)
+  env.nfill = 0;
   {  // few cells: per-cell estimators accumulate in LDS (physics.h Env::cellest_lds)
     const int nc = e->Mh.npts_nonempty;
     env.cellest_n_t = (e->cellest_in_lds && nc <= THERMAL_CELLEST_CAP) ? nc : 0;
@@ -2104,6 +2159,9 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   HIP_TRY(hipMemset(e->d_err, 0, sizeof(int32_t)));
   HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 2 * NEXT_NKINDS));
   HIP_TRY(hipMalloc((void **)&e->d_cursors, sizeof(int32_t) * (MAX_CHUNKS + 1)));  // + the launch's "list used up" flag
+  HIP_TRY(hipMalloc((void **)&e->d_resident, sizeof(uint32_t) * (size_t)((ncell_all + 31) / 32 + 1)));
+  HIP_TRY(hipMalloc((void **)&e->d_fill_cells, sizeof(int32_t) * (size_t)(ncell_all > 0 ? ncell_all : 1)));
+  HIP_TRY(hipMalloc((void **)&e->d_nfill, sizeof(int32_t)));
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -2144,6 +2202,8 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_HOTLDS")) e->hot_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_HOTBLOCKS")) e->hot_blocks = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TILE_ZIGZAG")) e->tile_zigzag = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_SPARSE_FILL")) e->sparse_fill = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_SPARSE_MAX")) e->sparse_max_listed = std::max(0, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_REFILL")) e->thermal_refill = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_REFILL_LOW")) e->refill_low = std::max(1, std::min(64, std::atoi(b)));
   if (const char *b = std::getenv("ARTIS_AMD_REFILL_MINPK")) e->refill_minpk = std::max(64, std::atoi(b));
@@ -2177,7 +2237,8 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
   free_packet_buffers(e);
-  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors};
+  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_resident, e->d_fill_cells,
+                  e->d_nfill};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3})
@@ -2298,13 +2359,17 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
 
 namespace {
 // populate the cell cache of the non-empty cells [lo, hi) (at most tile_cells of them) into the resident rows
-int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s) {
+int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nfill = -1) {
   const DevModel &h = e->Mh;
   e->tile_lo = lo;
   e->tile_hi = hi;
   e->tile_valid_lo = -1;
   Env env = make_env(e);
-  const int64_t ncell = hi - lo;
+  if (nfill >= 0) {  // sparse: the cells e->d_fill_cells[0..nfill) only
+    env.fill_cells = e->d_fill_cells;
+    env.nfill = (int32_t)nfill;
+  }
+  const int64_t ncell = nfill >= 0 ? nfill : hi - lo;
   if (ncell <= 0) return ARTIS_OK;
   hipLaunchKernelGGL(k_levelpops, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   if (h.nlines > 0) hipLaunchKernelGGL(k_line_dpop, dim3(nblocks(ncell * h.nlines)), dim3(BLOCK), 0, s, env);
@@ -2342,7 +2407,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s) {
     g_last_error = "cell cache population raised error flag " + std::to_string(err);
     return ARTIS_ERR_NOTCONVERGED;
   }
-  e->tile_valid_lo = lo;
+  e->tile_valid_lo = nfill >= 0 ? -1 : lo;  // (a sparse fill leaves the tile partly valid: never reused)
   return ARTIS_OK;
 }
 }  // namespace
@@ -2497,6 +2562,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   e->last_propagate_ms = 0.;
   e->last_nlaunches = 0;
   e->last_sweeps = e->last_tile_fills = e->last_listed = 0;
+  e->last_sparse_fills = e->last_cells_filled = 0;
+  e->resident_on = false;
   e->last_fill_ms = 0.;
   for (int k = 0; k < NEXT_NKINDS; k++) {
     e->kms[k] = 0.;
@@ -2571,9 +2638,37 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   if (!tile_active) continue;
   any_active = true;
   for (int k = 1; k < NEXT_NKINDS; k++) e->last_listed += cnt[k];
+  e->resident_on = false;
+  int64_t nfill = -1;
+  if (e->sparse_fill && e->ntiles > 1 && sweep > 0) {
+    // which cells of the tile hold the waiting packets? Few of them (stragglers): fill those only; a packet that moves into
+    // another cell of the tile waits for the tile's next visit like one that leaves the tile
+    int64_t listed_now = 0;
+    for (int k = 1; k < NEXT_NKINDS; k++) listed_now += cnt[k];
+    if (listed_now <= e->sparse_max_listed) {
+      HIP_TRY(hipMemsetAsync(e->d_resident, 0, sizeof(uint32_t) * (size_t)((ncell_all + 31) / 32 + 1), s));
+      HIP_TRY(hipMemsetAsync(e->d_nfill, 0, sizeof(int32_t), s));
+      hipLaunchKernelGGL(k_mark_cells, dim3(nblocks(n)), dim3(BLOCK), 0, s, env, e->d_resident);
+      hipLaunchKernelGGL(k_compact_cells, dim3(nblocks(hi - lo)), dim3(BLOCK), 0, s, lo, hi, e->d_resident, e->d_fill_cells, e->d_nfill);
+      int32_t nf = 0;
+      HIP_TRY(hipMemcpyAsync(&nf, e->d_nfill, sizeof(nf), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (nf > 0 && nf * 2 < hi - lo) {
+        nfill = nf;
+        e->tile_valid_lo = -1;
+      }
+    }
+  }
   if (e->tile_valid_lo != lo) {
     HIP_TRY(hipEventRecord(e->ev2, s));
-    rc = populate_tile(e, lo, hi, s);
+    rc = populate_tile(e, lo, hi, s, nfill);
+    e->resident_on = (nfill >= 0);
+    if (nfill >= 0) {
+      e->last_sparse_fills++;
+      e->last_cells_filled += nfill;
+    } else {
+      e->last_cells_filled += hi - lo;
+    }
     if (rc != ARTIS_OK) return rc;
     HIP_TRY(hipEventRecord(e->ev3, s));
     HIP_TRY(hipEventSynchronize(e->ev3));
@@ -2591,7 +2686,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   // the split kernels throughout, unless ARTIS_AMD_TAIL_ALWAYS=1)
   int64_t listed = 0;
   for (int k = 1; k < NEXT_NKINDS; k++) listed += cnt[k];
-  const bool tail_ok = e->tail_max > 0 && (e->tail_always || listed > e->tail_max);
+  // (tiled runs: the later sweeps bring a tile a few stragglers at a time; each such visit is a tail from its first launch)
+  const bool tail_ok = e->tail_max > 0 && (e->tail_always || listed > e->tail_max || sweep > 0);
   while (cnt[NEXT_RPKT] > 0 || cnt[NEXT_MA] > 0 || cnt[NEXT_SLOW] > 0 || cnt[NEXT_KPKT] > 0 || cnt[NEXT_GAMMA] > 0 || cnt[NEXT_BB] > 0) {
     const int tail_kinds[4] = {NEXT_RPKT, NEXT_MA, NEXT_SLOW, NEXT_BB};
     int64_t tail_n = 0;
@@ -2730,6 +2826,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     }
   }
   }  // tiles
+  e->resident_on = false;
   if (any_active) e->last_sweeps++;
   if (e->ntiles == 1 || !any_active) break;
   }  // sweeps
@@ -2908,6 +3005,13 @@ int artis_amd_last_kernel_breakdown(artis_amd_engine *e, double *rpkt_ms, int64_
   if (rpkt_threads) *rpkt_threads = e->kthreads[NEXT_RPKT];
   if (thermal_ms) *thermal_ms = e->kms[NEXT_MA] + e->kms[NEXT_KPKT];
   if (thermal_threads) *thermal_threads = e->kthreads[NEXT_MA] + e->kthreads[NEXT_KPKT];
+  return ARTIS_OK;
+}
+
+int artis_amd_last_tiling_fills(artis_amd_engine *e, int64_t *sparse_fills, int64_t *cells_filled) {
+  if (!e) return ARTIS_ERR_ARG;
+  if (sparse_fills) *sparse_fills = e->last_sparse_fills;
+  if (cells_filled) *cells_filled = e->last_cells_filled;
   return ARTIS_OK;
 }
 

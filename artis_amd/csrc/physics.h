@@ -147,6 +147,12 @@ struct Env {
   // cell waits for that cell's tile (classify()). One tile = all cells unless the cache would not fit in HBM.
   int32_t tile_lo, tile_hi;
   int32_t tile_all;  // the tile covers every cell (the usual case): in_tile() needs no look-up
+  // SPARSE fill of a tile (the later sweeps of a tiled run): only the cells fill_cells[0..nfill) were populated; resident has
+  // a bit per non-empty cell of the model for them, and a packet that enters another cell of the tile waits like one that
+  // leaves the tile. Both null: every cell of the tile is populated.
+  const int32_t *fill_cells;
+  const uint32_t *resident;
+  int32_t nfill;
   int32_t cont_in_lds;  // M.cont_pack points into LDS (k_rpkt<true>)
   // Per-cell estimators of a model with FEW cells (1D / 2D models, small grids): every packet of the launch adds to one of
   // a few addresses, and device-wide atomics on one address are serialised in memory (measured, 30 shells, 1e7 packets:
@@ -173,7 +179,9 @@ struct Env {
 AHD bool in_tile(const Env &env, int cellindex) {
   if (env.tile_all) return true;
   const int c = env.M.propcell_nonemptymgi[cellindex];
-  return c < 0 || (c >= env.tile_lo && c < env.tile_hi);
+  if (c < 0) return true;
+  if (c < env.tile_lo || c >= env.tile_hi) return false;
+  return env.resident == nullptr || ((env.resident[c >> 5] >> (c & 31)) & 1u) != 0;
 }
 
 // Hot packet state, kept in registers.

@@ -75,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_last_kernel_table",
     "artis_amd_options_preset",
     "artis_amd_allreduce_estimators", "artis_amd_comm_unique_id", "artis_amd_comm_init", "artis_amd_comm_count",
-    "artis_amd_cache_tiles", "artis_amd_last_tiling",
+    "artis_amd_cache_tiles", "artis_amd_last_tiling", "artis_amd_last_tiling_fills",
 ]
 
 
@@ -167,7 +167,11 @@ class Engine:
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_double(), C.c_int64()
         self.L.artis_amd_last_tiling.argtypes = [C.c_void_p] * 5
         self._check(self.L.artis_amd_last_tiling(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
-        return {"sweeps": a.value, "tile_fills": b.value, "fill_ms": c.value, "listed": d.value}
+        e, f = C.c_int64(), C.c_int64()
+        self.L.artis_amd_last_tiling_fills.argtypes = [C.c_void_p] * 3
+        self._check(self.L.artis_amd_last_tiling_fills(self.h, C.byref(e), C.byref(f)))
+        return {"sweeps": a.value, "tile_fills": b.value, "fill_ms": c.value, "listed": d.value, "sparse_fills": e.value,
+                "cells_filled": f.value}
 
     # estimator reduction in the C++ host layer (RCCL)
     COMM_ID_BYTES = 128

@@ -554,6 +554,8 @@ int artis_amd_last_kernel_ms(artis_amd_engine *eng, double *propagate_ms, int64_
 /* Tiled cell cache (artis_amd_cache_tiles): sweeps over the tiles made by the last artis_amd_update_packets_device call, tile
  * fills inside it with their summed duration [ms], and the packets listed over all (sweep, tile) visits. */
 int artis_amd_last_tiling(artis_amd_engine *eng, int64_t *sweeps, int64_t *tile_fills, double *fill_ms, int64_t *listed);
+/* ... of which sparse fills (only the cells of the tile in which packets waited), and the cells populated over all fills */
+int artis_amd_last_tiling_fills(artis_amd_engine *eng, int64_t *sparse_fills, int64_t *cells_filled);
 
 /* Per-kernel split of the last artis_amd_update_packets_device call: summed launch durations [ms] and summed
  * packet counts of the r-packet kernel (k_rpkt) and of the thermal kernels (k_ma + k_kpkt). */

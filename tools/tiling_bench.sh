@@ -5,5 +5,5 @@ for mb in 200000 50000 25000 12500; do
   ARTIS_AMD_CACHE_BUDGET_MB=$mb python bench.py --steps 1 --warmup 1 --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']['cell_cache']; b=d['kernel_breakdown_last_step']
-print('budget %6d MB: tiles %d cells/tile %d | %.1f ms/step %.1f M packet-steps/s | thermal %.1f rpkt %.1f ms | %s' % ($mb, c['tiles'], c['cells_per_tile'], d['ms_per_step'], d['value']/1e6, b['thermal_ms'], b['rpkt_ms'], {k:c[k] for k in c if k in ('sweeps','tile_fills','fill_ms','listed')}))"
+print('budget %6d MB: tiles %d cells/tile %d | %.1f ms/step %.1f M packet-steps/s | thermal %.1f rpkt %.1f ms | %s' % ($mb, c['tiles'], c['cells_per_tile'], d['ms_per_step'], d['value']/1e6, b['thermal_ms'], b['rpkt_ms'], {k:c[k] for k in c if k in ('sweeps','tile_fills','fill_ms','listed','sparse_fills','cells_filled')}))"
 done
