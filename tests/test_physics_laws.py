@@ -18,6 +18,9 @@ evaluated on the packets the engine returns (GPU, `-m gpu`) and on the kernel bo
    fraction above the median of that law.
 8. Compton scattering (gammapkt.cc:266-420): the energy ratio f = E'/E of the gamma packets that survive a scattering
    follows f * dsigma/df of Klein and Nishina, dsigma/df ~ f + 1/f - 1 + cos^2(theta(f)): mean and quartile fractions.
+9. Lorentz transformation of an emission (vectors.h:70 angle_ab, :91 calculate_doppler_nucmf_on_nurf; kpkt.cc:495-560 and
+   macroatom.cc:283-330 emit isotropically in the comoving frame): matter moving with beta = v/c radiates, seen from the
+   rest frame, the momentum beta * E / c along v and the energy E (1 + O(beta^2)): sum(e_rf dir.beta) = sum(e_cmf beta^2).
 Each would catch a misreading of the transport loop that oracle and kernels share (same hand, same reading): a wrong
 phase function or frame, a wrong sampling law, a channel that is drawn with the wrong weight.
 """
@@ -292,6 +295,32 @@ def _check_compton(backend, n):
         assert abs(np.mean(f < cut) - q) < 4 * 0.5 / np.sqrt(m) + 0.02, (q, np.mean(f < cut))
 
 
+def _check_emission_aberration(backend, n):
+    """k-packets in the outer cells (beta = 0.06 ... 0.1), one very short timestep; every r-packet they turned into (free-free,
+    free-bound or a macro-atom line) that has not scattered since: its rest-frame direction and energy against v = r / t"""
+    nc = 6
+    model, cs, ts, aux = synth.build("small", ncoord=nc, width_frac=2e-5)
+    d = model.d
+    idx = np.arange(nc**3)
+    ijk = np.stack([idx % nc, (idx // nc) % nc, idx // (nc * nc)], axis=1)
+    radius = np.linalg.norm((ijk + 0.5) * (2 * d["rmax"] / nc) - d["rmax"], axis=1)
+    mgi = np.asarray(d["propcell_nonemptymgi"])
+    outer = np.unique(mgi[(mgi >= 0) & (radius > 0.7 * d["rmax"])])
+    pk = synth.make_packets(model, aux, n, kpkt_fraction=1.0, seed=12, cells_only=outer)
+    backend(model, cs, ts, pk)
+    em = (pk["type"] == abi.TYPE_RPKT) & (pk["nscatterings"] == 0) & (pk["emissiontype"] != abi.EMTYPE_NOTSET)
+    m = int(em.sum())
+    assert m > n // 2, m
+    beta = pk["pos"][em] / pk["prop_time"][em][:, None] / CLIGHT
+    beta2 = (beta * beta).sum(axis=1)
+    assert 3e-3 < beta2.mean() < 1e-2
+    momentum = ((pk["dir"][em] * beta).sum(axis=1) * pk["e_rf"][em]).sum() / (beta2 * pk["e_cmf"][em]).sum()
+    sigma = 1 / np.sqrt(3 * beta2.sum())  # e * beta * mu' of an isotropic mu' has the variance e^2 beta^2 / 3
+    assert abs(momentum - 1.) < 4 * sigma + 3 * beta2.mean(), (momentum, sigma, m)  # (no aberration: 0; the wrong sign: -1)
+    energy = pk["e_rf"][em].sum() / pk["e_cmf"][em].sum() - 1.
+    assert abs(energy) < 4 * np.sqrt(beta2.mean() / 3 / m) + 2 * beta2.mean(), (energy, beta2.mean())
+
+
 def test_thomson_phase_function_kernel_bodies():
     _check_thomson(_backend_emu, 120000)
 
@@ -310,6 +339,15 @@ def test_freebound_emission_spectrum_kernel_bodies():
 
 def test_compton_klein_nishina_kernel_bodies():
     _check_compton(_backend_emu, 60000)
+
+
+def test_emission_momentum_and_energy_in_the_rest_frame_kernel_bodies():
+    _check_emission_aberration(_backend_emu, 200000)
+
+
+@pytest.mark.gpu
+def test_emission_momentum_and_energy_in_the_rest_frame_engine():
+    _check_emission_aberration(_backend_gpu, 3000000)
 
 
 @pytest.mark.gpu
