@@ -103,6 +103,42 @@ __global__ void __launch_bounds__(BLOCK) k_allcont(Env env) {
   const unsigned long long bits = __ballot(keep);
   if (lane == 0) env.K.allcont_keepbits[(int64_t)c * env.M.nkeepwords + word] = bits;
 }
+// one wave = one cell: the kept continua as a list, the count of kept continua below each bitmap word and the pairs in list
+// order (physics.h populate_keptlist; after k_allcont)
+__global__ void __launch_bounds__(BLOCK) k_keptlist(Env env) {
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= fill_count(env)) return;
+  const int c = fill_cell(env, wave);
+  const int nw = env.M.nkeepwords;
+  const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * nw);
+  int32_t *list = env.K.allcont_keptlist + ((int64_t)c * env.M.nbfcontinua);
+  int32_t *prefix = env.K.allcont_keepprefix + ((int64_t)c * nw);
+  const D2 *pair = env.K.allcont_pair + ((int64_t)c * env.M.nbfcontinua);
+  D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * env.M.nbfcontinua);
+  int base = 0;
+  for (int w0 = 0; w0 < nw; w0 += 64) {
+    const int j = w0 + lane;
+    unsigned long long word = (j < nw) ? keep[j] : 0ull;
+    const int pc = __popcll(word);
+    int incl = pc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
+    }
+    int at = base + incl - pc;
+    if (j < nw) prefix[j] = at;
+    while (word != 0ull) {
+      const int i = (j * 64) + __builtin_ctzll(word);
+      list[at] = i;
+      keptpair[at] = pair[i];
+      at++;
+      word &= word - 1ull;
+    }
+    base += __shfl(incl, 63);
+  }
+}
 __global__ void __launch_bounds__(BLOCK) k_corrphotoion(Env env, const int32_t *target_level) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const int64_t total = fill_count(env) * env.M.nphixstargets_total;
@@ -799,34 +835,23 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
 }
 
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
-// The deferred updates of the detailed bound-free estimators (radfield.cc:215), one WAVE per record: the lanes share the
-// record's cell, frequency and window and take one kept continuum each (rank -> continuum through the cell's keep
-// bitmap: prefix sums of the words' bit counts, then the k-th set bit of a word), so every lane of the wave is busy
-// however long the window is. The contributions are the ones update_bfestimators() would have added in place (same
-// arithmetic); only the order of the f64 atomic additions differs.
-__device__ inline int select_kth_bit(unsigned long long x, int k) {  // position of the k-th (0-based) set bit of x
-  int pos = 0;
-#pragma unroll
-  for (int sh = 32; sh >= 1; sh >>= 1) {
-    const unsigned long long lowmask = (1ull << sh) - 1ull;
-    const int cnt = __popcll(x & lowmask);
-    if (k >= cnt) {
-      k -= cnt;
-      x >>= sh;
-      pos += sh;
-    } else {
-      x &= lowmask;
-    }
-  }
-  return pos;
-}
+// The deferred updates of the detailed bound-free estimators (radfield.cc:215). A record's continua are the kept ones of
+// its window [begin, end); LPR lanes share the record (cell, frequency, weight) and take one kept continuum each, so the
+// lanes are busy however long the window is (a lane-per-packet loop ran at 17 % of the lanes). Which continuum is the
+// k-th kept one of the window comes from two small per-cell tables made with the keep bitmap (k_keptlist): the kept
+// continua as a list, and the number of kept continua below each bitmap word -- two reads and two bit counts give the
+// window's places [r0, r1) in the list. (Before: prefix sums of the words' bit counts over the lanes, a bisection with six
+// ds_bpermute and a select-k-th-bit per lane and round: 2.5x the VALU instructions.) The contributions are the ones
+// update_bfestimators() would have added in place (same arithmetic); only the order of the f64 atomic additions differs.
 // (Keeping a cell's sums in LDS across a run of records of the same cell -- per wave, or per workgroup with ds_add_f64 --
-// was measured and lost, 651 / 427 ms against 364 ms: the kernel is bound by the latency of a record's chain of reads,
-// not by the HBM atomics, and LDS costs resident waves.)
+// was measured and lost, 651 / 427 ms against 364 ms; so did sorting the records by cell first and summing a cell's whole
+// run in an LDS row, 1101 vs 989 ms for k_rpkt + this kernel, profiles/r03/bfest_sorted_lds_rows.patch. Compiled out, the
+// additions are worth 98 of the 989 ms.)
 // CONT_LDS: the static continuum table (ContPack, two of a contribution's ~six 16-byte reads) is staged in LDS by a
 // workgroup of DENSE_TB threads, one per CU.
 constexpr int DENSE_TB = 1024;
-template <bool CONT_LDS, int TB>
+// LPR lanes per record: a window holds ~30 kept continua (ARTIS_AMD_DENSE_LPR = 64, 32 or 16)
+template <bool CONT_LDS, int TB, int LPR>
 __global__ void __launch_bounds__(TB) k_bfest_dense(Env env) {
   __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
   if (CONT_LDS) {
@@ -837,54 +862,53 @@ __global__ void __launch_bounds__(TB) k_bfest_dense(Env env) {
     env.cont_in_lds = 1;
     __syncthreads();
   }
+  static_assert(LPR == 64 || LPR == 32 || LPR == 16, "lanes per record");
   const DevModel &M = env.M;
   const int n = min(*env.bfev_count, env.bfev_cap);
-  const int lane = threadIdx.x & 63;
-  const int nwaves = gridDim.x * (TB / 64);
-  for (int ei = (blockIdx.x * TB + threadIdx.x) >> 6; ei < n; ei += nwaves) {
+  const int lane = threadIdx.x & (LPR - 1);
+  const int unit = (blockIdx.x * TB + threadIdx.x) / LPR;
+  const int nunits = gridDim.x * (TB / LPR);
+  for (int ei = unit; ei < n; ei += nunits) {
     const BfEvent ev = env.bfev[ei];
     const int c = ev.c;
     const double nu = ev.nu;
     const float T_e = env.C.Te[c];
+    // the record's continua are the kept ones of [begin, end): places [r0, r1) of the cell's list of kept continua
+    int r0, r1;
+    kept_range(env, c, ev.begin, ev.end, r0, r1);
     const double ex = exp(-HOVERKB * nu / T_e);
     const bool split_usable = (ex >= DBLMIN);
-    const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
-    double *dst = env.E.bfrate_raw + ((int64_t)c * M.nbfestim);
-    const int wfirst = ev.begin / 64, wlast = (ev.end - 1) / 64;
-    for (int wb = wfirst; wb <= wlast; wb += 64) {  // 64 bitmap words (4096 continua) at a time
-      const int j = wb + lane;
-      unsigned long long word = (j <= wlast) ? keep[j] : 0ull;
-      if (j == wfirst) word &= ~0ull << (ev.begin % 64);
-      if (j == wlast && (ev.end % 64) != 0) word &= (1ull << (ev.end % 64)) - 1ull;
-      const int pc = __popcll(word);
-      int incl = pc;  // inclusive prefix sum over the lanes
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-      }
-      const int total = __shfl(incl, 63);
-      const int wlo = (int)(word & 0xFFFFFFFFull), whi = (int)(word >> 32);
-      for (int s0 = 0; s0 < total; s0 += 64) {  // every lane runs the shuffles; the last round may have idle lanes
-        const int s = s0 + lane;
-        const bool valid = s < total;
-        const int sq = valid ? s : total - 1;
-        int lo = 0, hi = 63;  // first lane whose inclusive count exceeds sq
-#pragma unroll
-        for (int it = 0; it < 6; it++) {
-          const int mid = (lo + hi) >> 1;
-          const int v = __shfl(incl, mid);
-          if (v > sq) hi = mid; else lo = mid + 1;
-        }
-        const int src = lo;
-        const int before = __shfl(incl, src) - __shfl(pc, src);
-        const unsigned long long w64 = ((unsigned long long)(unsigned int)__shfl(whi, src) << 32) | (unsigned int)__shfl(wlo, src);
-        if (valid) {
-          const int i = ((wb + src) * 64) + select_kth_bit(w64, sq - before);
-          const int bi = bfestimindex(M, i);
-          if (bi >= 0) ARTIS_EST_ADD(&dst[bi], bf_sigma_contr(env, c, i, nu, T_e, ex, split_usable) * ev.w);
-        }
-      }
+    const int32_t *list = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
+    const D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * M.nbfcontinua);
+    // the sums go to the continuum's place in the list when the call keeps them there (all cells resident), else to its
+    // estimator: ~30 additions of a record then fall into 4-5 neighbouring 64-byte sectors instead of ~16 scattered ones
+    // (k_rpkt + this kernel 978 -> 858 ms per step; with the additions compiled out: 891)
+    double *dst = env.bfrate_kept ? env.bfrate_kept + ((int64_t)c * M.nbfcontinua) : env.E.bfrate_raw + ((int64_t)c * M.nbfestim);
+    for (int r = r0 + lane; r < r1; r += LPR) {
+      const int i = list[r];
+      const double ep = keptpair[r].y;
+      const int bi = bfestimindex(M, i);
+      if (bi >= 0) ARTIS_EST_ADD(&dst[env.bfrate_kept ? r : bi], bf_sigma_contr_ep(env, c, i, nu, T_e, ex, split_usable, ep) * ev.w);
+    }
+  }
+}
+// the sums kept by place in the list go to their estimators (one wave per cell; the places are left zero for the next call)
+__global__ void __launch_bounds__(BLOCK) k_bfrate_expand(Env env) {
+  const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const DevModel &M = env.M;
+  if (wave >= M.npts_nonempty) return;
+  const int c = (int)wave;
+  const int nw = M.nkeepwords;
+  const int nkept = env.K.allcont_keepprefix[((int64_t)c * nw) + nw - 1] + __popcll(env.K.allcont_keepbits[((int64_t)c * nw) + nw - 1]);
+  const int32_t *list = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
+  double *kept = env.bfrate_kept + ((int64_t)c * M.nbfcontinua);
+  double *dst = env.E.bfrate_raw + ((int64_t)c * M.nbfestim);
+  for (int r = lane; r < nkept; r += 64) {
+    const double v = kept[r];
+    if (v != 0.) {
+      dst[bfestimindex(M, list[r])] += v;  // (a continuum without an estimator was never added to: v == 0)
+      kept[r] = 0.;
     }
   }
 }
@@ -1599,6 +1623,10 @@ struct artis_amd_engine {
   bool expopac_own = false;  // the expansion-opacity tables are the engine's (calculated at cell-cache population)
   BfEvent *d_bfev = nullptr;     // deferred bound-free estimator updates of one k_rpkt launch (DETAILED_BF builds)
   int32_t *d_bfev_count = nullptr;
+  // the sums of the deferred updates, [cell][place in the cell's list of kept continua]: the additions of a record go to
+  // neighbouring doubles instead of ~30 separate 64-byte sectors of bfrate_raw; k_bfrate_expand moves them when a call ends
+  double *d_bfrate_kept = nullptr;
+  bool bfrate_kept_dirty = false;  // a call ended in an error before its sums were moved
   int32_t bfev_cap = 0;
   bool bf_defer = true;          // ARTIS_AMD_BFDEFER=0: add in place inside k_rpkt
   // virtual packets (VPKT_ON builds): the configuration block, and the events one launch records for k_vpkt (at most
@@ -1684,6 +1712,7 @@ struct artis_amd_engine {
   // 512 < cells <= 3072: k_rpkt keeps J / nuJ / ffheating in LDS instead of the continuum table (12^3 grid, 912 cells:
   // k_rpkt 292 -> 215 ms; 14^3, 1472 cells: 249 -> 225 ms). ARTIS_AMD_RPKT_EST_OVER_CONT=0: the table wins the LDS.
   bool rpkt_est_over_cont = true;
+  int dense_lpr = 32;           // k_bfest_dense: lanes per record (64 = a wave per record; ARTIS_AMD_DENSE_LPR)
   bool dense_cont_lds = true;   // k_bfest_dense reads the continuum table from LDS (nltenebular step 1917 -> 1882 ms); ARTIS_AMD_DENSE_CONTLDS=0
   bool cellest_in_lds = true;  // ARTIS_AMD_CELLEST_LDS=0: every estimator add is a global atomic
   int sort_maxpc_r = 20000;
@@ -1766,6 +1795,7 @@ Env make_env(const artis_amd_engine *e) {
   env.bfev = e->bf_defer ? e->d_bfev : nullptr;
   env.bfev_count = e->d_bfev_count;
   env.bfev_cap = e->bfev_cap;
+  env.bfrate_kept = (e->bf_defer && e->ntiles == 1) ? e->d_bfrate_kept : nullptr;
   env.gamma_gi = e->d_gamma_gi;
   env.gamma_n = e->d_gamma_n;
   env.errflag = e->d_err;
@@ -2153,6 +2183,13 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   e->E.Jb_lu_contribcount = nlineest ? e->E.Jb_lu_raw + nlineest : nullptr;
   e->E.vspecpol = nvspec ? e->E.scalars + ARTIS_NSCALARS + 2 * nbinest + nbfest + 2 * nlineest : nullptr;
   e->E.vgrid_flux = nvgrid ? e->E.vspecpol + nvspec : nullptr;
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+  if (nbfest > 0 && h.nbfcontinua > 0 && e->ntiles == 1) {
+    const size_t bytes = sizeof(double) * (size_t)ncell * (size_t)h.nbfcontinua;
+    HIP_TRY(hipMalloc((void **)&e->d_bfrate_kept, bytes));
+    HIP_TRY(hipMemset(e->d_bfrate_kept, 0, bytes));
+  }
+#endif
   HIP_TRY(hipMalloc((void **)&e->d_stats, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
@@ -2192,6 +2229,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (ARTIS_OPT_VPKT_ON) e->tail_max = 0;  // (see the estimator block: the event queue is sized per split launch)
   if (const char *b = std::getenv("ARTIS_AMD_RPKT_EST_OVER_CONT")) e->rpkt_est_over_cont = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_DENSE_CONTLDS")) e->dense_cont_lds = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_DENSE_LPR")) e->dense_lpr = (std::atoi(b) == 64) ? 64 : (std::atoi(b) == 16 ? 16 : 32);
   if (const char *b = std::getenv("ARTIS_AMD_CELLEST_LDS")) e->cellest_in_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_R")) e->sort_maxpc_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_T")) e->sort_maxpc_t = std::max(1, std::atoi(b));
@@ -2238,7 +2276,7 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cache_allocs);
   free_packet_buffers(e);
   void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_resident, e->d_fill_cells,
-                  e->d_nfill};
+                  e->d_nfill, e->d_bfrate_kept};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3})
@@ -2375,6 +2413,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
   if (h.nlines > 0) hipLaunchKernelGGL(k_line_dpop, dim3(nblocks(ncell * h.nlines)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cell_scalars, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
   if (h.nbfcontinua > 0) hipLaunchKernelGGL(k_allcont, dim3(nblocks(ncell * h.nkeepwords * 64)), dim3(BLOCK), 0, s, env);
+  if (h.nbfcontinua > 0) hipLaunchKernelGGL(k_keptlist, dim3(nblocks(ncell * 64)), dim3(BLOCK), 0, s, env);
   if (h.nphixstargets_total > 0)
     hipLaunchKernelGGL(k_corrphotoion, dim3(nblocks(ncell * h.nphixstargets_total)), dim3(BLOCK), 0, s, env, e->d_target_level);
   if (h.nalltrans > 0) hipLaunchKernelGGL(k_matrans, dim3(nblocks(ncell * h.nscanblk * 64)), dim3(BLOCK), 0, s, env);
@@ -2552,6 +2591,27 @@ int sort_by_key(artis_amd_engine *e, hipStream_t s, const int32_t *list, const i
 }
 }  // namespace
 
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+// the estimator updates the propagation launch before it recorded (the cells' cache rows are still resident)
+static int launch_bfest_dense(artis_amd_engine *e, const Env &env, hipStream_t s) {
+  const bool lds = e->dense_cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX;
+#define DENSE_LAUNCH(LPR)                                                                                        \
+  if (lds)                                                                                                       \
+    hipLaunchKernelGGL((k_bfest_dense<true, DENSE_TB, LPR>), dim3(e->ncu), dim3(DENSE_TB), 0, s, env);           \
+  else                                                                                                           \
+    hipLaunchKernelGGL((k_bfest_dense<false, BLOCK, LPR>), dim3(e->ncu * 8), dim3(BLOCK), 0, s, env);
+  if (e->dense_lpr == 64) {
+    DENSE_LAUNCH(64)
+  } else if (e->dense_lpr == 16) {
+    DENSE_LAUNCH(16)
+  } else {
+    DENSE_LAUNCH(32)
+  }
+#undef DENSE_LAUNCH
+  return ARTIS_OK;
+}
+#endif
+
 int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   if (!e || !e->have_cells || !e->d_pkt) {
     g_last_error = "engine needs artis_amd_set_cellstate() and resident packets first";
@@ -2574,6 +2634,11 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   const int64_t n = e->npackets;
   if (n == 0) return ARTIS_OK;
   Env env = make_env(e);
+  if (e->d_bfrate_kept != nullptr) {
+    if (e->bfrate_kept_dirty)
+      HIP_TRY(hipMemsetAsync(e->d_bfrate_kept, 0, sizeof(double) * (size_t)e->Mh.npts_nonempty * (size_t)e->Mh.nbfcontinua, s));
+    e->bfrate_kept_dirty = true;
+  }
   int cur[NEXT_NKINDS] = {};             // which of the two buffers is the current list of each kind
   const int r_nubins = e->sort_nu ? SORT_NUBINS : 1;  // frequency bins in the keys of the r-packet list
   int32_t cnt[2 * NEXT_NKINDS];                        // host copy of the device counters
@@ -2706,10 +2771,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       hipLaunchKernelGGL(k_tail, dim3(nblocks(tail_n * 64)), dim3(BLOCK), 0, s, env, in, next, e->d_stats);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
       if (env.bfev != nullptr) {
-        if (e->dense_cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX)
-          hipLaunchKernelGGL((k_bfest_dense<true, DENSE_TB>), dim3(e->ncu), dim3(DENSE_TB), 0, s, env);
-        else
-          hipLaunchKernelGGL((k_bfest_dense<false, BLOCK>), dim3(e->ncu * 8), dim3(BLOCK), 0, s, env);
+        rc = launch_bfest_dense(e, env, s);
+        if (rc != ARTIS_OK) return rc;
         HIP_TRY(hipMemsetAsync(e->d_bfev_count, 0, sizeof(int32_t), s));
       }
 #endif
@@ -2757,10 +2820,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
                              (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : e->budget_r);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
         if (env.bfev != nullptr) {  // the estimator updates the launch recorded (the cells' cache rows are still resident)
-          if (e->dense_cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX)
-            hipLaunchKernelGGL((k_bfest_dense<true, DENSE_TB>), dim3(e->ncu), dim3(DENSE_TB), 0, s, env);
-          else
-            hipLaunchKernelGGL((k_bfest_dense<false, BLOCK>), dim3(e->ncu * 8), dim3(BLOCK), 0, s, env);
+          rc = launch_bfest_dense(e, env, s);
+          if (rc != ARTIS_OK) return rc;
           HIP_TRY(hipMemsetAsync(e->d_bfev_count, 0, sizeof(int32_t), s));
         }
 #endif
@@ -2832,6 +2893,11 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   }  // sweeps
   for (int k = 1; k < NEXT_NKINDS; k++) e->last_propagate_ms += e->kms[k];
   e->last_propagate_ms += e->kms_tail;
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+  if (env.bfrate_kept != nullptr && env.bfev != nullptr)
+    hipLaunchKernelGGL(k_bfrate_expand, dim3(nblocks((int64_t)e->Mh.npts_nonempty * 64)), dim3(BLOCK), 0, s, env);
+  e->bfrate_kept_dirty = false;
+#endif
   int32_t err = 0;
   HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
   if (err != 0) {
@@ -2846,6 +2912,7 @@ int artis_amd_estimators_zero(artis_amd_engine *e, void *hip_stream) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipMemsetAsync(e->d_est, 0, sizeof(double) * (size_t)e->est_ndoubles, (hipStream_t)hip_stream));
   HIP_TRY(hipMemsetAsync(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS, (hipStream_t)hip_stream));
+  // (d_bfrate_kept is zero between calls: k_bfrate_expand leaves it so)
   return ARTIS_OK;
 }
 

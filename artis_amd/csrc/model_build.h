@@ -154,6 +154,9 @@ struct ModelOwned {
   X(allcont_edgepart, double, (m).nbfcontinua)                  \
   X(allcont_pair, D2, (m).nbfcontinua)                          \
   X(allcont_keepbits, uint64_t, (m).nkeepwords)                 \
+  X(allcont_keptlist, int32_t, (m).nbfcontinua)                 \
+  X(allcont_keepprefix, int32_t, (m).nkeepwords)                \
+  X(allcont_keptpair, D2, (m).nbfcontinua)                      \
   X(corrphotoioncoeff, double, (m).nphixstargets_total)         \
   X(bf_radrecomb, double, (m).nphixstargets_total)              \
   X(bf_colrecomb, double, (m).nphixstargets_total)              \

@@ -170,6 +170,8 @@ struct Env {
   BfEvent *bfev;
   int32_t *bfev_count;
   int32_t bfev_cap;
+  // ... and where the deferred updates are summed: [cell][place in the cell's list of kept continua] (null: in bfrate_raw)
+  double *bfrate_kept;
   // recorded virtual-packet events (VPKT_ON builds on the GPU; null: traced in place)
   VpktSeed *vpkt_queue;
   int32_t *vpkt_count;
@@ -1004,6 +1006,38 @@ AHD bool populate_allcont(const Env &env, int c, int i) {
   env.K.allcont_pair[o] = D2{nnlevel, edge};
   return keep;
 }
+// after every populate_allcont() of the cell and its keep bitmap: the kept continua as a list, the count of kept continua
+// below each bitmap word, and their {nnlevel, edge part} pairs in list order (on the GPU: k_keptlist, a wave per cell)
+AHD void populate_keptlist(const Env &env, int c) {
+  const DevModel &M = env.M;
+  const int nw = M.nkeepwords;
+  const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * nw);
+  int32_t *list = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
+  int32_t *prefix = env.K.allcont_keepprefix + ((int64_t)c * nw);
+  const D2 *pair = env.K.allcont_pair + ((int64_t)c * M.nbfcontinua);
+  D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * M.nbfcontinua);
+  int at = 0;
+  for (int j = 0; j < nw; j++) {
+    prefix[j] = at;
+    uint64_t word = keep[j];
+    while (word != 0) {
+      const int i = (j * 64) + __builtin_ctzll(word);
+      list[at] = i;
+      keptpair[at] = pair[i];
+      at++;
+      word &= word - 1;
+    }
+  }
+}
+// the places [r0, r1) of the continua [begin, end) in the cell's list of kept continua (begin < end)
+AHD void kept_range(const Env &env, int c, int begin, int end, int &r0, int &r1) {
+  const int nw = env.M.nkeepwords;
+  const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * nw);
+  const int32_t *prefix = env.K.allcont_keepprefix + ((int64_t)c * nw);
+  const int wfirst = begin / 64, wlast = (end - 1) / 64;
+  r0 = prefix[wfirst] + __builtin_popcountll(keep[wfirst] & ~(~UINT64_C(0) << (unsigned)(begin % 64)));
+  r1 = prefix[wlast] + __builtin_popcountll(keep[wlast] & (~UINT64_C(0) >> (unsigned)(63 - ((end - 1) % 64))));
+}
 // one (cell, phixs target): get_corrphotoioncoeff ratecoeff.cc:840 (USE_LUT_PHOTOION)
 // ... and the other rate coefficients of the same bound-free pair (level ul of an ion -> target t in the next ion), which
 // the per-level and per-ion stages below only have to combine: rad_recomb / col_recomb (macroatom.cc:646, :660),
@@ -1648,33 +1682,27 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   }
 #endif
   int nvisited = 0;
-  const D2 *pairs = env.K.allcont_pair + ((int64_t)c * M.nbfcontinua);  // {nnlevel, edgepart}
   const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
-  KeepIter it;
-  it.keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
-  it.cbegin = cbegin;
-  it.cend = cend;
-  it.word = cbegin / 64;
-  it.bits = (it.word * 64 < cend) ? keep_masked(it) : 0;
-  bool more = (it.word * 64 < cend);
-  while (more) {
+  // the kept continua of the window: places [r0, r1) of the cell's list; their indices and {nnlevel, edgepart} pairs lie
+  // next to each other there (rising index, so the sum runs in the reference's order)
+  int r0 = 0, r1 = 0;
+  if (cbegin < cend) kept_range(env, c, cbegin, cend, r0, r1);
+  const int32_t *keptlist = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
+  const D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * M.nbfcontinua);
+  for (int r = r0; r < r1; r += ARTIS_CHI_BATCH) {
     int idx[ARTIS_CHI_BATCH];
-#pragma unroll
-    for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
-      idx[k] = more ? keep_next(it) : -1;
-      if (idx[k] < 0) more = false;
-    }
-    if (idx[0] < 0) break;
     ContPack cp[ARTIS_CHI_BATCH];
     double nn[ARTIS_CHI_BATCH], ep[ARTIS_CHI_BATCH];
 #pragma unroll
     for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
-      const int i = (idx[k] >= 0) ? idx[k] : idx[0];
-      cp[k] = M.cont_pack[i];
-      const D2 pr = pairs[i];
+      const int rk = (r + k < r1) ? r + k : r;
+      idx[k] = (r + k < r1) ? keptlist[rk] : -1;
+      const D2 pr = keptpair[rk];
       nn[k] = pr.x;
       ep[k] = pr.y;
     }
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) cp[k] = M.cont_pack[(idx[k] >= 0) ? idx[k] : idx[0]];
     PhixsRead xr[ARTIS_CHI_BATCH];
 #pragma unroll
     for (int k = 0; k < ARTIS_CHI_BATCH; k++) xr[k] = phixs_lookup(M, M.allphixs + cp[k].xs_off, cp[k].nu_edge, nu);
@@ -1733,11 +1761,10 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
 AHD int bfestimindex(const DevModel &M, int i) { return M.allcont_bfestimindex ? M.allcont_bfestimindex[i] : i; }
 // the contribution of continuum i at frequency nu in cell c: sigma_bf * probability * stimulated-emission correction, the
 // arithmetic of calculate_chi_bf_gammacontr() (rpkt.cc:770-798) for one continuum
-AHD double bf_sigma_contr(const Env &env, int c, int i, double nu, float T_e, double ex, bool split_usable) {
+AHD double bf_sigma_contr_ep(const Env &env, int c, int i, double nu, float T_e, double ex, bool split_usable, double ep) {
   const DevModel &M = env.M;
   const ContPack cp = M.cont_pack[i];
   const double sigma_bf = phixs_fromtable(M, M.allphixs + cp.xs_off, cp.nu_edge, nu);
-  const double ep = env.K.allcont_pair[((int64_t)c * M.nbfcontinua) + i].y;
   double stim;
   if (ep >= 0. && split_usable) {
     stim = ep * ex;
@@ -1746,6 +1773,9 @@ AHD double bf_sigma_contr(const Env &env, int c, int i, double nu, float T_e, do
   }
   const double corr = dmax(0., 1 - stim);
   return sigma_bf * cp.probability * corr;
+}
+AHD double bf_sigma_contr(const Env &env, int c, int i, double nu, float T_e, double ex, bool split_usable) {
+  return bf_sigma_contr_ep(env, c, i, nu, T_e, ex, split_usable, env.K.allcont_pair[((int64_t)c * env.M.nbfcontinua) + i].y);
 }
 // radfield::update_bfestimators radfield.cc:215. The reference keeps, per packet, the contribution sigma_contr of every
 // continuum of the window that calculate_chi_bf_gammacontr() walked at the frequency x.nu (Phixslist::gamma_contr), and
@@ -1895,6 +1925,11 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
   double dist = 0.;
   int nvisited = 0;
   double result;
+  // The walk's chain of dependent reads is one (line frequency, population factor) pair per line visited. The pair of
+  // line li + 1 is requested while line li is worked on (the next line of the list is the next line of the walk,
+  // closest_transition() with next_trans > 0): ahead_li says which line nu_ahead / dpop_ahead belong to.
+  int ahead_li = -1;
+  double nu_ahead = 0., dpop_ahead = 0.;
   while (true) {
     const int li = closest_transition(M.line_nu, M.nlines, nu_cmf, next_trans);
     if (li < 0) {
@@ -1911,7 +1946,14 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
       break;
     }
     nvisited++;
-    const double nu_trans = M.line_nu[li];
+    const bool was_ahead = (li == ahead_li);
+    const double nu_trans = was_ahead ? nu_ahead : M.line_nu[li];
+    const double dpop_li = was_ahead ? dpop_ahead : dpop[li];
+    if (li + 1 < M.nlines) {
+      ahead_li = li + 1;
+      nu_ahead = M.line_nu[li + 1];
+      dpop_ahead = dpop[li + 1];
+    }
     next_trans = li + 1;
     const double ldist = linedistance(prop_time, nu_cmf, nu_trans, dnu_on_dl);
     const double tau_cont = chi_cont * ldist;
@@ -1923,7 +1965,7 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
         break;
       }
       // get_tau_sobolev<true> rpkt.cc:75 with the cell cache's (B_lu n_l - B_ul n_u)
-      const double tau_line = dmax(dpop[li] * HCLIGHTOVERFOURPI * prop_time, 0.);
+      const double tau_line = dmax(dpop_li * HCLIGHTOVERFOURPI * prop_time, 0.);
       if ((tau_rnd - tau) <= (tau_cont + tau_line)) {
         const LinePack lp = M.line_pack[li];
         const int element = M.line_elementindex[li];

@@ -225,6 +225,12 @@ struct DevCache {
   double *allcont_edgepart;      // [cell][nbfcontinua]
   D2 *allcont_pair;              // [cell][nbfcontinua] {nnlevel, edgepart} as one 16-byte read for calculate_chi_bf_gammacontr
   uint64_t *allcont_keepbits;    // [cell][nkeepwords]
+  // the kept continua of the cell as a list (rising index), per bitmap word the number of kept continua below it, and
+  // allcont_pair in the order of the list: the kept continua of a window [begin, end) are the places [r0, r1) of the list
+  // (two words, two counts), and what the opacity sum and k_bfest_dense read of them is contiguous
+  int32_t *allcont_keptlist;     // [cell][nbfcontinua]
+  int32_t *allcont_keepprefix;   // [cell][nkeepwords]
+  D2 *allcont_keptpair;          // [cell][nbfcontinua]
   double *line_dpop;             // [cell][nlines]: B_lu n_l - B_ul n_u of every line, the population factor of get_tau_sobolev() (rpkt.cc:75)
   double *collexc_cum;           // [cell][nupcum]: running cooling sum after each upward transition of each level (kpkt.cc:461-476)
   double *corrphotoioncoeff;     // [cell][nphixstargets_total]

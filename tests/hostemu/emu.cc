@@ -112,6 +112,7 @@ void populate_all(Emu &e) {
     for (int w = 0; w < M.nkeepwords; w++) kb[w] = 0;
     for (int i = 0; i < M.nbfcontinua; i++)
       if (populate_allcont(e.env, c, i)) kb[i / 64] |= UINT64_C(1) << (unsigned)(i % 64);
+    if (M.nbfcontinua > 0) populate_keptlist(e.env, c);
     for (int ul = 0; ul < M.nlevels; ul++)
       for (int t = 0; t < M.level_nphixstargets[ul]; t++) populate_corrphotoion(e.env, c, ul, t);
     for (int ati = 0; ati < M.nalltrans; ati++) populate_matrans(e.env, c, ati);

@@ -18,7 +18,7 @@ for d in dirs:
                     dur[k] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
                     ndisp[k] += 1
 for k, v in sorted(agg.items()):
-    if not any(x in k for x in ("k_thermal", "k_rpkt", "k_slow", "k_macroatom")):
+    if not any(x in k for x in ("k_thermal", "k_rpkt", "k_slow", "k_macroatom", "k_bfest_dense", "k_tail")):
         continue
     print(f"{k}: {ndisp[k]} dispatches, {dur[k]:.4f} s (in the FETCH_SIZE pass)")
     for c, val in sorted(v.items()):
@@ -35,7 +35,7 @@ for k, v in sorted(agg.items()):
 import json, os
 out = {}
 for k, v in agg.items():
-    if k in ("k_thermal", "k_rpkt") and "FETCH_SIZE" in v and "WRITE_SIZE" in v and ndisp[k]:
+    if k in ("k_thermal", "k_rpkt", "k_bfest_dense") and "FETCH_SIZE" in v and "WRITE_SIZE" in v and ndisp[k]:
         out[k] = {"fetch_size_kb": v["FETCH_SIZE"], "write_size_kb": v["WRITE_SIZE"], "dispatches": ndisp[k],
                   "hbm_bytes_per_launch": (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / ndisp[k],
                   "hbm_bytes_per_launch_fetch_undoubled": (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 / ndisp[k],
@@ -45,7 +45,7 @@ for k, v in agg.items():
                                                  "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
                                                  "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum",
                                                  "TCP_TOTAL_ACCESSES_sum", "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum",
-                                                 "TCC_EA0_RDREQ_32B_sum") if c in v}}
+                                                 "TCC_EA0_RDREQ_32B_sum", "TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum", "TCC_REQ_sum") if c in v}}
 if out and os.environ.get("PMC_TRAFFIC_JSON"):
     with open(os.environ["PMC_TRAFFIC_JSON"], "w") as f:
         json.dump(out, f, indent=1)
