@@ -54,7 +54,15 @@ constexpr int MA_N = ARTIS_MA_ACTION_COUNT;
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef unsigned long long stat_t;  // per-block LDS counters (ds_add_u64): X_MA_JUMPS alone passes 2^32 at realistic sizes
 #define ARTIS_STAT_ADD(env, i, v) atomicAdd(&(env).stats[(i)], (stat_t)(v))
+#ifdef ARTIS_EST_NOADD  // (measurement only: the kernels without their estimator additions)
+#define ARTIS_EST_ADD(ptr, v)                                 \
+  do {                                                        \
+    const double est_v = (v);                                 \
+    if (est_v == 1.2345e-300) unsafeAtomicAdd((ptr), est_v);  \
+  } while (0)
+#else
 #define ARTIS_EST_ADD(ptr, v) unsafeAtomicAdd((ptr), (v))
+#endif
 #else
 typedef unsigned long long stat_t;
 #define ARTIS_STAT_ADD(env, i, v) ((env).stats[(i)] += (stat_t)(v))

@@ -314,12 +314,24 @@ def main():
         # (profiles/<round>/pmc_traffic.json, written by tools/pmc_summary.py; FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950). None when the workload is not the profiled one.
         tj, traffic_src = {}, None
-        tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic.json")
+        tname = "pmc_traffic.json" if args.options == "classic" else f"pmc_traffic_{args.options}.json"
+        tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, tname)
         if (os.path.exists(tfile) and args.packets == 10_000_000 and args.ncoord == 50 and args.preset == "w7" and world == 1
-                and args.options == "classic"):
+                and args.grid == "3d"):
             with open(tfile) as f:
                 tj = json.load(f)
-            traffic_src = f"profiles/{PROFILE_ROUND}/pmc_traffic.json"
+            traffic_src = f"profiles/{PROFILE_ROUND}/{tname}"
+            if "k_bfest_dense" in tj and "k_rpkt" in tj:
+                # DETAILED_BF builds: the engine times k_rpkt together with the k_bfest_dense launch that follows it
+                # (kernel_breakdown.rpkt_ms), so their counters are added; "per launch" = per k_rpkt launch
+                a, b = tj["k_rpkt"], tj.pop("k_bfest_dense")
+                nl_pmc = a["dispatches"]
+                m = {"fetch_size_kb": a["fetch_size_kb"] + b["fetch_size_kb"], "write_size_kb": a["write_size_kb"] + b["write_size_kb"],
+                     "dispatches": nl_pmc, "seconds_in_fetch_pass": a["seconds_in_fetch_pass"] + b["seconds_in_fetch_pass"],
+                     "counters": {k: a["counters"].get(k, 0.) + b["counters"].get(k, 0.) for k in set(a["counters"]) | set(b["counters"])}}
+                m["hbm_bytes_per_launch"] = (2.0 * m["fetch_size_kb"] + m["write_size_kb"]) * 1024.0 / nl_pmc
+                m["hbm_bytes_per_launch_fetch_undoubled"] = (m["fetch_size_kb"] + m["write_size_kb"]) * 1024.0 / nl_pmc
+                tj["k_rpkt"] = m
 
         def kernel_roofline(k):
             ms = kms[k]
@@ -338,7 +350,9 @@ def main():
                 r["hbm_frac_measured"] = gbs / HBM_PEAK_GBS
                 if "hbm_bytes_per_launch_fetch_undoubled" in t:  # FETCH_SIZE as counted (the guide's x2 is for wide coalesced reads)
                     r["hbm_gbs_measured_fetch_undoubled"] = t["hbm_bytes_per_launch_fetch_undoubled"] * nl / (ms * 1e-3) / 1e9
-                r["write_amplification"] = t["write_size_kb"] * 1024.0 / t["dispatches"] * nl / wr[k] if wr[k] > 0 else None
+                # (the designed writes are counted for the classic build only: no counter holds the nebular builds' estimator additions)
+                r["write_amplification"] = (t["write_size_kb"] * 1024.0 / t["dispatches"] * nl / wr[k]
+                                            if wr[k] > 0 and args.options == "classic" else None)
                 c = t.get("counters") or {}
                 if c and t.get("seconds_in_fetch_pass"):
                     # what the kernel is held by, from the same committed counters (sums over one step's dispatches);
@@ -394,8 +408,11 @@ def main():
                          "avg_launch_ms": d["avg_launch_ms"],
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                          "algorithmic_gbs": d["algorithmic_gbs"], "algorithmic_over_hbm_peak": d["algorithmic_gbs"] / HBM_PEAK_GBS,
-                         "measured_limiter": "not HBM: SIMD instruction issue at ~35 of 64 active lanes, the wave's chain of dependent "
-                                             "reads and the CU's memory pipeline meet (profiles/r03/k_thermal_lane_compaction.md)",
+                         "measured_limiter": ("not HBM: SIMD instruction issue at ~35 of 64 active lanes, the wave's chain of dependent "
+                                              "reads and the CU's memory pipeline meet (profiles/r03/k_thermal_lane_compaction.md)")
+                         if dominant == "k_thermal" else
+                         ("k_rpkt (+ k_bfest_dense in DETAILED_BF builds, timed together): divergent per-lane loops over continua and "
+                          "lines at 2 waves/SIMD; see `limiter` and DESIGN.md section 7"),
                          "limiter": d["limiter"],
                          "kernels": per_kernel},
         }

@@ -20,5 +20,5 @@ cp $O/pmc_traffic.json $R/profiles/$T/pmc_traffic.json
 rm -rf $R/gpurun_out/pmc_$T
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --options kilonova_lte --no-cpu-baseline > $O/bench_kilonova_lte.json 2> /dev/null
-python3 bench.py --options nltenebular --no-cpu-baseline > $O/bench_nltenebular.json 2> /dev/null
+bash tools/profile_nltenebular.sh $T
 tail -c 400 $O/bench_default.json
