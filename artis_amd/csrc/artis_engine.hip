@@ -1480,7 +1480,10 @@ struct TailLists {
   const int32_t *list[4];  // the current r-packet, thermal, slow-path and blackbody lists
   int32_t n[4];
 };
-__global__ void __launch_bounds__(BLOCK, 2) k_tail(Env env, TailLists in, Lists next, unsigned long long *gstats) {
+#ifndef ARTIS_TAIL_WAVES
+#define ARTIS_TAIL_WAVES 2
+#endif
+__global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailLists in, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   __syncthreads();
@@ -1699,6 +1702,13 @@ struct artis_amd_engine {
   double last_fill_ms = 0.;
   int budget_r = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 4 : 8;        // do_rpkt_step() calls per packet per launch
   int budget_t = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 1024 : 2048;  // macro-atom transitions / k-packet steps per packet per launch
+  // A launch lasts as long as its slowest packet, and a list that does not fill the GPU any more (the last tenth of a
+  // timestep's rounds) is bound by that alone. Smaller budgets for such lists (ARTIS_AMD_SMALL_LIST, ARTIS_AMD_BUDGET_T_SMALL /
+  // _R_SMALL; 0 = off, the default) were measured: classic 1160 -> 1182..1258 ms per step (the extra rounds cost more than
+  // the shorter launches save), nltenebular 1500 -> 1481 (profiles/r03/small_list_budgets.txt).
+  int small_list = 300000;
+  int budget_t_small = 0;
+  int budget_r_small = 0;
   // ... and after the launch's list is used up (ARTIS_AMD_DRAIN_T; 0 = off), in launches of at least drain_min_list packets
   int drain_t = 48;
   int drain_r = 1;       // ... do_rpkt_step() calls after the r-packet list is used up (ARTIS_AMD_DRAIN_R; 0 = off)
@@ -2216,6 +2226,9 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   }
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_R")) e->budget_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_T")) e->budget_t = std::max(1, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_SMALL_LIST")) e->small_list = std::max(0, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_BUDGET_T_SMALL")) e->budget_t_small = std::max(0, std::atoi(b));
+  if (const char *b = std::getenv("ARTIS_AMD_BUDGET_R_SMALL")) e->budget_r_small = std::max(0, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_DRAIN_T")) e->drain_t = std::max(0, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_DRAIN_R")) e->drain_r = std::max(0, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_DRAIN_MIN")) e->drain_min_list = std::max(0, std::atoi(b));
@@ -2810,14 +2823,15 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       HIP_TRY(hipEventRecord(e->ev0, s));
       if (kind == NEXT_RPKT) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
+        const int bud_r = (e->budget_r_small > 0 && nk < e->small_list) ? std::min(e->budget_r_small, e->budget_r) : e->budget_r;
         const int nch = e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8;
         if (e->cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0 &&
             !(env.cellest_n_r > RPKT_CELLEST_CAP))
-          hipLaunchKernelGGL((k_rpkt<true>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch,
-                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : e->budget_r);
+          hipLaunchKernelGGL((k_rpkt<true>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
+                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
         else
-          hipLaunchKernelGGL((k_rpkt<false>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r, e->d_cursors, nch,
-                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : e->budget_r);
+          hipLaunchKernelGGL((k_rpkt<false>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
+                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
         if (env.bfev != nullptr) {  // the estimator updates the launch recorded (the cells' cache rows are still resident)
           rc = launch_bfest_dense(e, env, s);
@@ -2849,8 +2863,9 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
           const int grid = std::min(nblocks(nk), e->ncu * e->thermal_blocks_per_cu);
           const bool per_cu = e->cu_chunks_t && nk >= 256 * 1024;
           // (drain: only where the next thermal launch will be large too, so that what is handed on runs beside a full list)
-          const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : e->budget_t;
-          hipLaunchKernelGGL((k_thermal<false, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
+          const int bud_t = (e->budget_t_small > 0 && nk < e->small_list) ? std::min(e->budget_t_small, e->budget_t) : e->budget_t;
+          const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : bud_t;
+          hipLaunchKernelGGL((k_thermal<false, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, bud_t,
                              e->d_cursors, per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8), per_cu ? 2 : 0, drain);
         }
       } else if (kind == NEXT_BB) {
