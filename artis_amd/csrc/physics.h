@@ -2835,6 +2835,15 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
     r[0] = q0.x; r[1] = q0.y; r[2] = q1.x; r[3] = q1.y; r[4] = q2.x; r[5] = q2.y; r[6] = q3.x; r[7] = q3.y;
     // MA_ACTION_INTERNALUPHIGHERNT: only NT_ON puts anything there (macroatom.cc:171); adding the 0 leaves cum[8] = cum[7]
     r[8] = ARTIS_OPT_NT_ON ? rec[10] : 0.;
+#if defined(ARTIS_MA_EXTRA_LOADS) && defined(__HIP_DEVICE_COMPILE__)
+    // (measurement only: ARTIS_MA_EXTRA_LOADS more 8-byte reads of the same line, results kept alive and unused -- what
+    // does one more load INSTRUCTION per transition cost when it brings no new line?)
+#pragma unroll
+    for (int xl = 0; xl < ARTIS_MA_EXTRA_LOADS; xl++) {
+      const double qx = *(const volatile double *)(rec + 10 + xl);
+      asm volatile("" ::"v"(qx));
+    }
+#endif
   }
   double cum[MA_N];
   cum[0] = r[0];
