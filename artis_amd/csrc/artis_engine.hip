@@ -229,6 +229,19 @@ __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   if (i >= total) return;
   populate_macroatom(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
+// the uint16 filters of every record (tables.h "FILTERS"), once its rates and sums are final: a thread per (cell, level)
+// for the action filters, then a thread per (cell, line of sums)
+__global__ void __launch_bounds__(BLOCK) k_mafilter(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t per = (int64_t)env.M.nlevels + env.M.nmalines;
+  if (i >= fill_count(env) * per) return;
+  const int c = fill_cell(env, i / per);
+  const int j = (int)(i % per);
+  if (j < env.M.nlevels)
+    populate_mafilter_level(env, c, j);
+  else
+    populate_mafilter_line(env, c, j - env.M.nlevels);
+}
 // hot levels of every cell (physics.h populate_hotselect: the same rule, the levels spread over the lanes of one wave)
 __global__ void __launch_bounds__(BLOCK) k_hotselect(Env env) {
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
@@ -2431,6 +2444,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
     hipLaunchKernelGGL(k_corrphotoion, dim3(nblocks(ncell * h.nphixstargets_total)), dim3(BLOCK), 0, s, env, e->d_target_level);
   if (h.nalltrans > 0) hipLaunchKernelGGL(k_matrans, dim3(nblocks(ncell * h.nscanblk * 64)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_macroatom, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
+  hipLaunchKernelGGL(k_mafilter, dim3(nblocks(ncell * ((int64_t)h.nlevels + h.nmalines))), dim3(BLOCK), 0, s, env);
   if (e->hot_blocks) {  // per-cell hot blocks: which levels are hot depends on the cell state
     hipLaunchKernelGGL(k_hotselect, dim3(nblocks(ncell * 64)), dim3(BLOCK), 0, s, env);
     hipLaunchKernelGGL(k_hotfill, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);

@@ -19,6 +19,7 @@ struct ModelOwned {
   std::vector<int32_t> level_upcum_start;
   std::vector<int32_t> alltrans_owner;
   std::vector<int32_t> scanblk_start;
+  std::vector<MaLineRef> malines;
   std::vector<ContPack> cont_pack;
   std::vector<int32_t> expopac_linestart;
   std::vector<int32_t> upcum_coolslot;
@@ -57,6 +58,7 @@ struct ModelOwned {
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
   X(alltrans_owner, int32_t, (m).nalltrans)                                        \
   X(scanblk_start, int32_t, ((m).nscanblk + 1))                                    \
+  X(malines, MaLineRef, (m).nmalines)                                              \
   X(alltrans_einstein_A, float, (m).nalltrans)                                     \
   X(alltrans_coll_str, float, (m).nalltrans)                                       \
   X(alltrans_osc_strength, float, (m).nalltrans)                                   \
@@ -201,6 +203,20 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   }
   v.nmacache = rec;
   v.level_pack = own.level_pack.data();
+  own.malines.clear();
+  for (int i = 0; i < m.nlevels; i++) {
+    const LevelPack &lp = own.level_pack[i];
+    for (int dir = 0; dir < 2; dir++) {
+      const int n = dir == 0 ? lp.ndown : lp.nup;
+      const int base = dir == 0 ? marec_down : marec_up(lp.ndown);
+      const int rate = marec_rates + (dir == 0 ? ARTIS_MA_ACTION_INTERNALDOWNSAME : ARTIS_MA_ACTION_INTERNALUPSAME);
+      for (int l = 0; l < marec_lines(n); l++)
+        own.malines.push_back(MaLineRef{lp.rec_off + base + (l * MAREC_LINE), lp.rec_off + rate, l * MAREC_PER, n});
+    }
+  }
+  if (own.malines.empty()) own.malines.push_back(MaLineRef{0, 0, 0, 0});
+  v.nmalines = (int32_t)own.malines.size();
+  v.malines = own.malines.data();
   own.level_upcum_start.resize(m.nlevels);
   int32_t nupcum = 0;
   for (int i = 0; i < m.nlevels; i++) {

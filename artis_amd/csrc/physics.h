@@ -244,6 +244,9 @@ AHD uint32_t rng_next(Pkt &p) {
 // float, and the product with 2^-24 is exact, so the largest value is 1 - 2^-24. Without the (dead) loop a draw is
 // straight-line code that the compiler can schedule under the latency of loads in flight.
 AHD float rng_uniform(Pkt &p) { return (float)(rng_next(p) >> 8U) * 0x1.0p-24F; }
+// the same draw as its 24-bit integer u (rng_uniform() = u * 2^-24 exactly) and back
+AHD uint32_t rng_u24(Pkt &p) { return rng_next(p) >> 8U; }
+AHD float rng_u24_value(uint32_t u) { return (float)u * 0x1.0p-24F; }
 AHD float rng_uniform_pos(Pkt &p) {  // random.h:59: redraw while the value is 0 (one draw in 2^24)
   float z = rng_uniform(p);
   while (!(z > 0)) z = rng_uniform(p);
@@ -1430,8 +1433,8 @@ AHD void populate_hotfill(const Env &env, int c, int ul) {
     if (j == 0) tgt[marec_tgt0 + (down ? 0 : 1)] = tg;
   }
   // the sum slots after each direction's last entry: +inf, so that ma_search_lines() needs no bounds checks
-  for (int j = lpk.ndown; j < marec_lines(lpk.ndown) * 8; j++) rec[marec_sum(marec_down, j)] = __builtin_inf();
-  for (int j = lpk.nup; j < marec_lines(lpk.nup) * 8; j++) rec[marec_sum(marec_up(lpk.ndown), j)] = __builtin_inf();
+  for (int j = lpk.ndown; j < marec_lines(lpk.ndown) * MAREC_PER; j++) rec[marec_sum(marec_down, j)] = __builtin_inf();
+  for (int j = lpk.nup; j < marec_lines(lpk.nup) * MAREC_PER; j++) rec[marec_sum(marec_up(lpk.ndown), j)] = __builtin_inf();
   if (off[ul] >= 0) {
     double *dst = env.K.hotblk + ((int64_t)c * HOT_DOUBLES) + ((int)off[ul] * MAREC_ALIGN);
     const int n = marec_units(lpk) * MAREC_ALIGN;
@@ -2777,16 +2780,87 @@ AHD int ma_search(const double *a, int n, double v) {
 // reference: it is the whole rate, >= v) can only be counted when v rounds up to it, hence the final clamp.
 AHD int ma_search_lines(const double *a, int n, double v) {
   int idx = 0;
-  for (int base = 0; base < n; base += 8, a += MAREC_LINE) {
-    const D2 q0 = *(const D2 *)(a), q1 = *(const D2 *)(a + 2), q2 = *(const D2 *)(a + 4), q3 = *(const D2 *)(a + 6);
-    const double x[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
+  for (int base = 0; base < n; base += MAREC_PER, a += MAREC_LINE) {
+    // the line's 7 sums are its doubles [2..9); the fourth 16-byte read also brings the first target, which is not counted
+    const D2 q0 = *(const D2 *)(a + 2), q1 = *(const D2 *)(a + 4), q2 = *(const D2 *)(a + 6), q3 = *(const D2 *)(a + 8);
+    const double x[MAREC_PER] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
     int cnt = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) cnt += (x[k] <= v) ? 1 : 0;
+    for (int k = 0; k < MAREC_PER; k++) cnt += (x[k] <= v) ? 1 : 0;
     idx += cnt;
-    if (cnt < 8) break;
+    if (cnt < MAREC_PER) break;
   }
   return idx < n ? idx : n;
+}
+// The uint16 filters of a record (tables.h "FILTERS"). q = floor(value / whole * 32768), clamped to 32767.
+AHD uint32_t mafilt_quant(double value, double whole, bool *ok) {
+  const double f = (value / whole) * MAFILT_SCALE;
+  if (!(f >= 0. && f <= MAFILT_SCALE)) {
+    *ok = false;
+    return 0;
+  }
+  return (f >= MAFILT_SCALE - 1.) ? MAFILT_NONE : (uint32_t)f;
+}
+// how many of the filter's 8 entries are certainly <= z (zi = (int)(z * 32768)): zi >= q + 3 proves value <= z * whole,
+// zi <= q - 2 proves value > z * whole; *amb: some entry is in between (q - 1 <= zi <= q + 2). Two counts instead of two tests
+// per entry: the entries with q <= zi - 3 are counted, and the filter is ambiguous iff more entries have q <= zi + 1. An entry
+// that is not to be counted at all holds 0x7FFF (it can only turn a draw with zi >= 32766 ambiguous). Two entries per 32-bit
+// word and subtraction: with h = bound + 32768 in both halves, (h - q) has bit 15 set in a half iff q <= bound there, and
+// no half borrows from the other (q <= 32767 <= h).
+AHD int mafilt_count(const U4 &f, int zi, bool *amb) {
+  const int lo = (zi - 3 > -1) ? zi - 3 : -1, hi = (zi + 1 < 32767) ? zi + 1 : 32767;
+  const uint32_t hl = (uint32_t)(lo + 32768) * 0x10001u, hh = (uint32_t)(hi + 32768) * 0x10001u;
+  int c1 = 0, c2 = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    c1 += __builtin_popcount((hl - f.w[j]) & 0x80008000u);
+    c2 += __builtin_popcount((hh - f.w[j]) & 0x80008000u);
+  }
+  *amb = (c1 != c2);
+  return c1;
+}
+// After every rate and sum of a cell's records is final (populate_macroatom): the action filter of one level's line 0 ...
+AHD void populate_mafilter_level(const Env &env, int c, int ul) {
+  const DevModel &M = env.M;
+  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + M.level_pack[ul].rec_off;
+  const double *rates = rec + marec_rates;
+  // cumulative rates of the actions 0..7 over the total of all 9, summed as ma_load_rates() sums them
+  double cum[MA_N];
+  cum[0] = rates[0];
+  for (int a = 1; a < MA_N; a++) cum[a] = cum[a - 1] + rates[a];
+  const double total = cum[MA_N - 1];
+  bool ok = (total > 0.) && (total <= DBLMAX);
+  uint32_t q[8];
+  for (int a = 0; a < 8; a++) q[a] = ok ? mafilt_quant(cum[a], total, &ok) : 0u;
+  for (int a = 1; a < 8; a++)
+    if (q[a] < q[a - 1]) ok = false;  // (a negative rate: never seen; the marker below needs q[0] <= q[7] otherwise)
+  if (!ok) {  // marker: first entry above the last one (never so in a usable filter): decided on the f64 rates
+    for (int a = 0; a < 8; a++) q[a] = 0u;
+    q[0] = MAFILT_NONE;
+  }
+  U4 f;
+  for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
+  *(U4 *)(rec + marec_filt0) = f;
+}
+// ... and the filter of one line of sums (M.malines[li])
+AHD void populate_mafilter_line(const Env &env, int c, int li) {
+  const DevModel &M = env.M;
+  const MaLineRef lr = M.malines[li];
+  if (lr.n <= 0) return;
+  double *row = env.K.macache + ((int64_t)c * M.nmacache);
+  double *line = row + lr.line_off;
+  const double whole = row[lr.rate_off];
+  bool ok = (whole > 0.) && (whole <= DBLMAX);
+  uint32_t q[8];
+  for (int j = 0; j < 8; j++) q[j] = MAFILT_NONE;  // not searched (the direction's last sum, slots past it, the 8th entry)
+  for (int j = 0; j < MAREC_PER; j++)
+    if (lr.first + j < lr.n - 1 && ok) q[j] = mafilt_quant(line[2 + j], whole, &ok);
+  if (!ok) {  // marker: the 8th entry is not 0x7FFF: this line is searched on its f64 sums
+    for (int j = 0; j < 8; j++) q[j] = 0u;
+  }
+  U4 f;
+  for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
+  *(U4 *)line = f;
 }
 
 // one iteration of the loop of do_macroatom(), macroatom.cc:385-577. ma_prepare() finds the record of the packet's
@@ -2821,59 +2895,96 @@ AHD const double *ma_record(const MACtx &k) {
 // for the slow path): its index is returned with its rate, and ma_jump_exit() carries it out. The split lets a kernel
 // keep the rare, long deactivation code out of its transition loop.
 constexpr int MA_EXIT_FAILED = 99;
+// the 9 process rates of a record and their running sums (std::partial_sum macroatom.cc:425), kept in registers
+AHD void ma_load_rates(const double *rec, double *r, double *cum) {
+  const D2 q0 = *(const D2 *)(rec + 2), q1 = *(const D2 *)(rec + 4), q2 = *(const D2 *)(rec + 6), q3 = *(const D2 *)(rec + 8);
+  r[0] = q0.x; r[1] = q0.y; r[2] = q1.x; r[3] = q1.y; r[4] = q2.x; r[5] = q2.y; r[6] = q3.x; r[7] = q3.y;
+  // MA_ACTION_INTERNALUPHIGHERNT: only NT_ON puts anything there (macroatom.cc:171); adding the 0 leaves cum[8] = cum[7]
+  r[8] = ARTIS_OPT_NT_ON ? rec[10] : 0.;
+  cum[0] = r[0];
+#pragma unroll
+  for (int i = 1; i < MA_N; i++) cum[i] = cum[i - 1] + r[i];
+}
 template <bool HOT = true>
 AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, double *rate_out) {
-  // std::partial_sum macroatom.cc:425 and index_upperbound sn3d.h:85 over the 9 cumulative rates, kept in
-  // registers (statically indexed): action = number of cumulative values <= randomrate, clamped to the last one
-  double r[MA_N];
+  // index_upperbound (sn3d.h:85) over the 9 cumulative rates: action = number of cumulative values <= zrand * total,
+  // clamped to the last one. Decided on the record's 16-byte filter (tables.h "FILTERS") unless the random number lies
+  // within the filter's resolution of one of its entries; then on the f64 rates, with the same random number.
   MA_PROF_BEGIN();
   MA_PROF_MARK(env, 63);  // (clocks between the marks themselves: the cost of one mark)
+  int action;
   {
-    const D2 q0 = *(const D2 *)(rec + 2), q1 = *(const D2 *)(rec + 4), q2 = *(const D2 *)(rec + 6), q3 = *(const D2 *)(rec + 8);
+    const U4 f = *(const U4 *)(rec + marec_filt0);
     MA_PROF_WAIT();
     MA_PROF_MARK(env, 59);
-    r[0] = q0.x; r[1] = q0.y; r[2] = q1.x; r[3] = q1.y; r[4] = q2.x; r[5] = q2.y; r[6] = q3.x; r[7] = q3.y;
-    // MA_ACTION_INTERNALUPHIGHERNT: only NT_ON puts anything there (macroatom.cc:171); adding the 0 leaves cum[8] = cum[7]
-    r[8] = ARTIS_OPT_NT_ON ? rec[10] : 0.;
 #if defined(ARTIS_MA_EXTRA_LOADS) && defined(__HIP_DEVICE_COMPILE__)
     // (measurement only: ARTIS_MA_EXTRA_LOADS more 8-byte reads of the same line, results kept alive and unused -- what
     // does one more load INSTRUCTION per transition cost when it brings no new line?)
 #pragma unroll
     for (int xl = 0; xl < ARTIS_MA_EXTRA_LOADS; xl++) {
-      const double qx = *(const volatile double *)(rec + 10 + xl);
+      const double qx = *(const volatile double *)(rec + 2 + xl);
       asm volatile("" ::"v"(qx));
     }
 #endif
-  }
-  double cum[MA_N];
-  cum[0] = r[0];
+    double r[MA_N], cum[MA_N];
+    // first entry above the last: the record has no usable filter (populate_mafilters: its total is not a positive finite
+    // number); the reference's assertion on the total comes before the random number is drawn
+    const bool usable = !((f.w[0] & 0xFFFFu) > (f.w[3] >> 16));
+    if (!usable) {
+      ma_load_rates(rec, r, cum);
+      if (!(cum[MA_N - 1] > 0.)) {
+        fail(env, 40);
+        p.ma_level = -1;
+        ARTIS_STAT(env, ARTIS_STAT_X_MA_JUMPS);
+        return MA_EXIT_FAILED;
+      }
+    }
+    const uint32_t u1 = rng_u24(p);
+    const int zi = (int)(u1 >> 9);  // = (int)(zrand * 32768): zrand = u1 * 2^-24
+    bool amb;
+    action = mafilt_count(f, zi, &amb);
+    // (zi at the top of the range: "cum[8] = total <= zrand * total" cannot be excluded by the filter)
+    amb = amb || !usable || zi >= 32765;
+    if (amb) {
+      if (usable) ma_load_rates(rec, r, cum);
+      const double randomrate = rng_u24_value(u1) * cum[MA_N - 1];
+      action = 0;
 #pragma unroll
-  for (int i = 1; i < MA_N; i++) cum[i] = cum[i - 1] + r[i];
-  const double total = cum[MA_N - 1];
-  if (!(total > 0.)) {
-    fail(env, 40);
-    p.ma_level = -1;
-    ARTIS_STAT(env, ARTIS_STAT_X_MA_JUMPS);
-    return MA_EXIT_FAILED;
+      for (int i = 0; i < MA_N; i++) action += (cum[i] <= randomrate) ? 1 : 0;  // cum is non-decreasing
+      if (action > MA_N - 1) action = MA_N - 1;
+    }
   }
-  const double randomrate = rng_uniform(p) * total;
-  int action = 0;
-#pragma unroll
-  for (int i = 0; i < MA_N; i++) action += (cum[i] <= randomrate) ? 1 : 0;  // cum is non-decreasing
-  if (action > MA_N - 1) action = MA_N - 1;
   k.njumps++;  // stats::increment(INTERACTIONS) macroatom.cc:430 and the engine's transition counter: ma_flush_stats()
   const bool down = (action == ARTIS_MA_ACTION_INTERNALDOWNSAME);
   if (down || action == ARTIS_MA_ACTION_INTERNALUPSAME) {
-    // macroatom.cc:433-447 and 536-550: one search for both directions, so that a wave runs it once
+    // macroatom.cc:433-447 and 536-550: one search for both directions, so that a wave runs it once. The target is the
+    // number of the direction's cumulative sums <= zrand * (the direction's rate), the last sum (= the rate) left out.
     const int ndown = k.nd;
     const int nsel = down ? ndown : k.nu;
-    const int base = down ? marec_down : marec_up(ndown);      // the direction's lines (sums + targets)
-    const double targetval = rng_uniform(p) * (down ? r[ARTIS_MA_ACTION_INTERNALDOWNSAME] : r[ARTIS_MA_ACTION_INTERNALUPSAME]);
+    const int nsearch = nsel - 1;
+    const int base = down ? marec_down : marec_up(ndown);      // the direction's lines (filter, sums, targets)
+    const uint32_t u2 = rng_u24(p);
     MA_PROF_MARK(env, 60);
-    const int ti = ma_search_lines(rec + base, nsel - 1, targetval);
+    int ti = 0;
+    if (nsearch > 0) {
+      const int zi = (int)(u2 >> 9);
+      bool amb = false;
+      for (int b0 = 0; b0 < nsearch; b0 += MAREC_PER) {
+        const U4 f = *(const U4 *)(rec + base + ((b0 / MAREC_PER) * MAREC_LINE));
+        const int cnt = mafilt_count(f, zi, &amb);
+        amb = amb || (f.w[3] >> 16) != MAFILT_NONE;
+        if (amb) break;
+        ti += cnt;
+        if (cnt < MAREC_PER) break;
+      }
+      if (amb) {
+        const double targetval = rng_u24_value(u2) * rec[marec_rates + (down ? ARTIS_MA_ACTION_INTERNALDOWNSAME : ARTIS_MA_ACTION_INTERNALUPSAME)];
+        ti = ma_search_lines(rec + base, nsearch, targetval);
+      }
+    }
     MA_PROF_MARK(env, 61);
     // the first transition's target is also in line 0: a direction with one transition reads nothing else
-    const uint64_t tg = ((const MaTarget *)rec)[ti == 0 ? marec_tgt0 + (down ? 0 : 1) : marec_tgt(base, ti)].bits;
+    const uint64_t tg = ((const MaTarget *)rec)[nsearch == 0 ? marec_tgt0 + (down ? 0 : 1) : marec_tgt(base, ti)].bits;
     MA_PROF_WAIT();
     MA_PROF_MARK(env, 62);
     p.ma_level = (int)((tg >> 20) & 0xFFFF);

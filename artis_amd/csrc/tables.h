@@ -53,20 +53,28 @@ struct alignas(32) ContPack {
 //            [2..10]       the 9 process rates              (alllevels_maprocessrates, globals.h:286)
 //            [12], [13]    copies of the MaTarget of the first downward and of the first upward transition (a direction
 //                          with one transition, a third of all searches, reads no other line)
-//   then one line per 8 transitions of a direction, downward lines first (marec_down), then upward (marec_up(ndown)):
-//            [0..8)        cumulative internal-down-same / internal-up-same (allmacroatomictransitions blocks 2 and 3,
-//                          macroatom.cc:44, :51) of transitions 8b .. 8b+7
-//            [8..16)       their MaTarget (8 B each): the target level and the offset of ITS record in the cell's row
+//            [14..15]      FILTER: 8 x uint16, the cumulative rates of actions 0..7 as fractions of the total (below)
+//   then one line per 7 transitions of a direction, downward lines first (marec_down), then upward (marec_up(ndown)):
+//            [0..1]        FILTER: 7 x uint16, the line's cumulative sums as fractions of the direction's whole rate
+//                          (0x7FFF for a sum that is not searched); the 8th uint16: 0x7FFF, anything else = "do not use
+//                          this line's filter" (a sum that is not a finite fraction)
+//            [2..9)        cumulative internal-down-same / internal-up-same (allmacroatomictransitions blocks 2 and 3,
+//                          macroatom.cc:44, :51) of transitions 7b .. 7b+6
+//            [9..16)       their MaTarget (8 B each): the target level and the offset of ITS record in the cell's row
 //                          (static data, repeated per cell so that it sits in the line of the sums that select it)
 //   [marec_rad(..) ..)     cumulative radiative deexc.      (block 1, macroatom.cc:58), contiguous (read once per walk)
 // A search reads whole lines of sums (entries beyond the count are never used); the rad block may be read up to 7 doubles
 // past its end, which stays inside the row (+ MAREC_SLACK at the end of the allocation).
 //
-// HOT BLOCK. A walk spends ~90 % of its transitions in a few dozen levels of its cell. At population time the records of
-// the cell's hottest levels (by level population x total rate, i.e. the flow through the level) are copied, bit for bit,
-// into a compact per-cell block of HOT_DOUBLES doubles, which the thermal kernel stages in LDS for the cells its
-// workgroup is working on. `hot` (header: of this level; target: of the target level) is the place of a level's copy in
-// that block in units of MAREC_ALIGN doubles, or -1. Which levels are hot only decides where a record is read from.
+// FILTERS. k_thermal is bound by the NUMBER of vector-memory instructions it issues (two more 8-byte reads of a line it
+// has already read, per transition: 617 -> 786 ms), and a transition decided on the f64 values reads
+// 64 B of rates + 56 B of sums + a target = 9 instructions. Both decisions are "how many cumulative values are <= z * whole"
+// with z uniform in [0, 1): the same as "how many fractions value / whole are <= z" unless z lies within rounding of a
+// fraction. The fractions are kept as 15-bit integers q = floor(fraction * 32768) (clamped to 32767) in uint16, so
+// q <= fraction * 32768 <= q + 1: with zi = (int)(z * 32768), zi >= q + 3 proves value <= z * whole and zi <= q - 2 proves
+// the opposite, with a margin of 3e-5 against f64 rounding errors of 1e-16. Anything in between (1e-3 of the draws per
+// decision) is decided on the f64 values as before -- same random numbers, same result. 15 bits, so that two entries are
+// compared by ONE 32-bit subtraction (physics.h mafilt_count). A transition then reads 16 B + 16 B + a target.
 struct alignas(16) MaHeader {
   int16_t ndown, nup;
   int32_t ul, alltrans_startdown;
@@ -89,19 +97,31 @@ constexpr int MAREC_ALIGN = 16;  // doubles
 constexpr int marec_even(int n) { return (n + 1) & ~1; }
 constexpr int marec_rates = 2;
 constexpr int marec_tgt0 = 12;   // [12] first downward target, [13] first upward target
-constexpr int MAREC_LINE = 16;   // doubles per line of a direction: 8 sums, 8 targets
-constexpr int marec_lines(int n) { return (n + 7) >> 3; }
+constexpr int marec_filt0 = 14;  // [14..15] the action filter of line 0
+constexpr int MAREC_LINE = 16;   // doubles per line of a direction: filter (2), 7 sums, 7 targets
+constexpr int MAREC_PER = 7;     // transitions per line
+constexpr int marec_lines(int n) { return (n + MAREC_PER - 1) / MAREC_PER; }
 constexpr int marec_down = 16;
 constexpr int marec_up(int ndown) { return marec_down + (marec_lines(ndown) * MAREC_LINE); }
 constexpr int marec_rad(int ndown, int nup) { return marec_up(ndown) + (marec_lines(nup) * MAREC_LINE); }
 constexpr int marec_size(int ndown, int nup) { return marec_rad(ndown, nup) + marec_even(ndown); }
 // entry i of a direction whose lines begin at `base`: its cumulative sum, its target
-constexpr int marec_sum(int base, int i) { return base + ((i >> 3) * MAREC_LINE) + (i & 7); }
-constexpr int marec_tgt(int base, int i) { return marec_sum(base, i) + 8; }
+constexpr int marec_sum(int base, int i) { return base + ((i / MAREC_PER) * MAREC_LINE) + 2 + (i % MAREC_PER); }
+constexpr int marec_tgt(int base, int i) { return marec_sum(base, i) + MAREC_PER; }
+constexpr double MAFILT_SCALE = 32768.;
+constexpr uint32_t MAFILT_NONE = 0x7FFFu;  // an entry that is never counted
 constexpr int MAREC_SLACK = 16;  // doubles past the last row that a padded search may touch
 
 struct alignas(16) D2 {
   double x, y;
+};
+struct alignas(16) U4 {  // 8 x uint16 of a macro-atom filter
+  uint32_t w[4];
+};
+// one line of sums of one direction of one level's record (static): where it is in a cell's row, where the direction's
+// whole rate is, which transitions of the direction it holds (k_mafilter: a thread per cell and line)
+struct alignas(16) MaLineRef {
+  int32_t line_off, rate_off, first, n;
 };
 
 struct VpktConfig;  // virtual packets, below
@@ -160,6 +180,8 @@ struct DevModel {
   // of k_matrans forms the running sums of one run
   const int32_t *scanblk_start;
   int32_t nscanblk;
+  const MaLineRef *malines;  // derived: every line of sums of every record, [nmalines]
+  int32_t nmalines;
   const float *alltrans_einstein_A, *alltrans_coll_str, *alltrans_osc_strength;
   const uint8_t *alltrans_forbidden;
   const double *line_nu;
