@@ -44,7 +44,8 @@ from artis_amd import abi, synth  # noqa: E402
 B_PER_THERMAL_VISIT = 256.0   # hot line (128 B) loaded + stored once per packet per k_thermal launch
 B_PER_RPKT_VISIT = 448.0      # hot + flight line (96 of 128 B used) loaded + stored once per packet per k_rpkt launch
 B_PER_EMISSION = 120.0        # flight line direction/rest-frame part 56 + em_pos/em_time 28 + trueem 36
-B_PER_MA_JUMP = 116.0         # 8 process rates 64 + the direction's line of 8 sums 64 x 0.675 (a third of the searches read none) + target 8
+B_PER_MA_JUMP = 35.0          # action filter 16 + the direction's line filter 16 x 0.675 (a third of the searches read none) + target 8
+                              # (round 2: 116 = 64 B of rates + 64 x 0.675 of sums + 8; the f64 values are read for one draw in ~500)
 B_PER_KPKT_STEP = 200.0       # ~6 ion sums 48 + ~7 cooling-list sums 56 + ~6 collisional-excitation sums 48 + indices/flags 48
 B_PER_RPKT_STEP = 120.0       # cell scalars ~40 + boundary tables ~56 + J, nuJ, ffheating atomics 24
 B_PER_LINE = 16.0             # line frequency 8 + the cell's population factor of the line 8
@@ -408,8 +409,9 @@ def main():
                          "avg_launch_ms": d["avg_launch_ms"],
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                          "algorithmic_gbs": d["algorithmic_gbs"], "algorithmic_over_hbm_peak": d["algorithmic_gbs"] / HBM_PEAK_GBS,
-                         "measured_limiter": ("not HBM: SIMD instruction issue at ~35 of 64 active lanes, the wave's chain of dependent "
-                                              "reads and the CU's memory pipeline meet (profiles/r03/k_thermal_lane_compaction.md)")
+                         "measured_limiter": ("not HBM: the wave's chain of three dependent reads per macro-atom transition at 4 waves/SIMD, "
+                                              "after the 16-byte filters halved the load instructions the kernel was bound by "
+                                              "(two more loads per transition: +27 %; DESIGN.md section 7)")
                          if dominant == "k_thermal" else
                          ("k_rpkt (+ k_bfest_dense in DETAILED_BF builds, timed together): divergent per-lane loops over continua and "
                           "lines at 2 waves/SIMD; see `limiter` and DESIGN.md section 7"),
