@@ -1712,6 +1712,12 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
       nn[k] = pr.x;
       ep[k] = pr.y;
     }
+#if defined(ARTIS_RPKT_EXTRA_LOADS) && defined(__HIP_DEVICE_COMPILE__)
+    {  // (measurement only: one more 8-byte read per batch of continua, of a pair just read)
+      const double qx = *(const volatile double *)(&keptpair[r].x);
+      asm volatile("" ::"v"(qx));
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < ARTIS_CHI_BATCH; k++) cp[k] = M.cont_pack[(idx[k] >= 0) ? idx[k] : idx[0]];
     PhixsRead xr[ARTIS_CHI_BATCH];
@@ -1957,6 +1963,12 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
       break;
     }
     nvisited++;
+#if defined(ARTIS_RPKT_EXTRA_LOADS) && defined(__HIP_DEVICE_COMPILE__)
+    if (ARTIS_RPKT_EXTRA_LOADS > 1) {  // (measurement only: one more 8-byte read per line visited, of the frequency just read)
+      const double qx = *(const volatile double *)(M.line_nu + li);
+      asm volatile("" ::"v"(qx));
+    }
+#endif
     const bool was_ahead = (li == ahead_li);
     const double nu_trans = was_ahead ? nu_ahead : M.line_nu[li];
     const double dpop_li = was_ahead ? dpop_ahead : dpop[li];
