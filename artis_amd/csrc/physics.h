@@ -2813,14 +2813,16 @@ AHD uint32_t mafilt_quant(double value, double whole, bool *ok) {
   }
   return (f >= MAFILT_SCALE - 1.) ? MAFILT_NONE : (uint32_t)f;
 }
-// how many of the filter's 8 entries are certainly <= z (zi = (int)(z * 32768)): zi >= q + 3 proves value <= z * whole,
-// zi <= q - 2 proves value > z * whole; *amb: some entry is in between (q - 1 <= zi <= q + 2). Two counts instead of two tests
-// per entry: the entries with q <= zi - 3 are counted, and the filter is ambiguous iff more entries have q <= zi + 1. An entry
-// that is not to be counted at all holds 0x7FFF (it can only turn a draw with zi >= 32766 ambiguous). Two entries per 32-bit
-// word and subtraction: with h = bound + 32768 in both halves, (h - q) has bit 15 set in a half iff q <= bound there, and
-// no half borrows from the other (q <= 32767 <= h).
+// how many of the filter's 8 entries are certainly <= z. z = u * 2^-24 (a 24-bit draw), zi = u >> 9 = floor(z * 32768), so
+// zi <= z * 32768 <= zi + 1 - 2^-9. With q <= fraction * 32768 <= q + 1: zi >= q + 2 proves fraction < z by at least 3e-5,
+// and zi <= q - 1 proves fraction > z by at least 2^-9 / 32768 = 6e-8 -- both far beyond the 1e-16 by which the f64
+// comparison "value <= z * whole" can differ from the exact one. *amb: some entry has q == zi or q == zi - 1. Two counts
+// instead of two tests per entry: the entries with q <= zi - 2 are counted, and the filter is ambiguous iff more entries
+// have q <= zi. An entry that is not to be counted at all holds 0x7FFF (it can only turn a draw with zi = 32767 ambiguous).
+// Two entries per 32-bit word and subtraction: with h = bound + 32768 in both halves, (h - q) has bit 15 set in a half iff
+// q <= bound there, and no half borrows from the other (q <= 32767 <= h).
 AHD int mafilt_count(const U4 &f, int zi, bool *amb) {
-  const int lo = (zi - 3 > -1) ? zi - 3 : -1, hi = (zi + 1 < 32767) ? zi + 1 : 32767;
+  const int lo = (zi - 2 > -1) ? zi - 2 : -1, hi = zi;
   const uint32_t hl = (uint32_t)(lo + 32768) * 0x10001u, hh = (uint32_t)(hi + 32768) * 0x10001u;
   int c1 = 0, c2 = 0;
 #pragma unroll
@@ -2955,8 +2957,8 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
     const int zi = (int)(u1 >> 9);  // = (int)(zrand * 32768): zrand = u1 * 2^-24
     bool amb;
     action = mafilt_count(f, zi, &amb);
-    // (zi at the top of the range: "cum[8] = total <= zrand * total" cannot be excluded by the filter)
-    amb = amb || !usable || zi >= 32765;
+    // ("cum[8] = total <= zrand * total" never holds: zrand <= 1 - 2^-24, and the product of that with total is below total)
+    amb = amb || !usable;
     if (amb) {
       if (usable) ma_load_rates(rec, r, cum);
       const double randomrate = rng_u24_value(u1) * cum[MA_N - 1];

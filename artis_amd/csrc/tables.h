@@ -71,8 +71,9 @@ struct alignas(32) ContPack {
 // 64 B of rates + 56 B of sums + a target = 9 instructions. Both decisions are "how many cumulative values are <= z * whole"
 // with z uniform in [0, 1): the same as "how many fractions value / whole are <= z" unless z lies within rounding of a
 // fraction. The fractions are kept as 15-bit integers q = floor(fraction * 32768) (clamped to 32767) in uint16, so
-// q <= fraction * 32768 <= q + 1: with zi = (int)(z * 32768), zi >= q + 3 proves value <= z * whole and zi <= q - 2 proves
-// the opposite, with a margin of 3e-5 against f64 rounding errors of 1e-16. Anything in between (1e-3 of the draws per
+// q <= fraction * 32768 <= q + 1: with zi = floor(z * 32768) (the top 15 bits of the 24-bit draw), zi >= q + 2 proves
+// value <= z * whole and zi <= q - 1 proves the opposite, by margins of 3e-5 and 6e-8 of the whole against f64 rounding errors
+// of 1e-16 (physics.h mafilt_count). Anything in between (q == zi or zi - 1: 5e-4 of the draws per
 // decision) is decided on the f64 values as before -- same random numbers, same result. 15 bits, so that two entries are
 // compared by ONE 32-bit subtraction (physics.h mafilt_count). A transition then reads 16 B + 16 B + a target.
 struct alignas(16) MaHeader {
