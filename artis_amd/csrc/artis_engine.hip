@@ -1152,11 +1152,14 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, co
         if (myslot >= 0) ARTIS_STAT(env, 58);            // transitions of a packet whose cell has a slot
 #endif
         rec = ma_record<USE_LDS>(k);
-        exit_action = ma_jump_internal<USE_LDS>(env, p, k, rec, &exit_rate);
+        exit_action = ma_jump_internal<USE_LDS, false>(env, p, k, rec, &exit_rate);
         j++;
       }
       ma_flush_stats(env, k);
-      if (exit_action >= 0) ma_jump_exit(env, p, pi, k, rec, exit_action, exit_rate);
+      if (exit_action >= 0) {
+        exit_rate = rec[marec_rates + exit_action];  // (here, once per phase, not in the loop: ma_jump_internal<.., false>)
+        ma_jump_exit(env, p, pi, k, rec, exit_action, exit_rate);
+      }
       if (j > 0) chi_after_ma(p);
       units += j;
     }

@@ -2919,7 +2919,10 @@ AHD void ma_load_rates(const double *rec, double *r, double *cum) {
 #pragma unroll
   for (int i = 1; i < MA_N; i++) cum[i] = cum[i - 1] + r[i];
 }
-template <bool HOT = true>
+// RATE = false: the caller reads the rate of the process that ended the walk itself (rec[marec_rates + action]), once its
+// loop is over -- in k_thermal's transition loop the read would otherwise be issued in every round in which any lane of
+// the wave ends its walk (~0.7 load instructions per round of a kernel that is bound by their number)
+template <bool HOT = true, bool RATE = true>
 AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, double *rate_out) {
   // index_upperbound (sn3d.h:85) over the 9 cumulative rates: action = number of cumulative values <= zrand * total,
   // clamped to the last one. Decided on the record's 16-byte filter (tables.h "FILTERS") unless the random number lies
@@ -3009,7 +3012,7 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
     k.hot = HOT ? (int)env.K.hotoff[((int64_t)k.c * env.M.nlevels) + (k.start + p.ma_level)] : -1;
     return -1;
   }
-  *rate_out = rec[marec_rates + action];  // once per walk: not worth a select chain in the loop
+  if (RATE) *rate_out = rec[marec_rates + action];  // once per walk
   return action;
 }
 AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double *rec, int action, double rate_sel) {
