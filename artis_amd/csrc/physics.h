@@ -3483,6 +3483,9 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     const double *upcum = env.K.collexc_cum + ((int64_t)c * M.nupcum) + M.level_upcum_start[ul];
     int first = nup;  // first transition whose running sum is greater than rnd_process
     for (int base = 0; base < nup && first == nup; base += 8) {
+#if defined(ARTIS_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+      if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 58);  // wave-level rounds of this scan
+#endif
 #pragma unroll
       for (int k = 7; k >= 0; k--) {
         const int j = base + k;
