@@ -756,19 +756,27 @@ __device__ inline void cellest_flush(const Env &env, int kind, double *global_ar
     if (v != 0.) unsafeAtomicAdd(&global_array[c], v);
   }
 }
-template <bool CONT_LDS>
-__global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const int32_t *list, int32_t n, Lists next,
+// One workgroup of 768 threads per CU: 3 waves/SIMD at 168 VGPRs (the LDS tables allow two workgroups per CU, so 256-thread
+// workgroups stop at 2 waves/SIMD whatever their registers). Measured against 256 x 2 (2 waves/SIMD, 256 VGPRs): k_rpkt
+// 352 -> 339 ms (classic), 398 -> 379 (kilonova_lte), k_rpkt + k_bfest_dense 825 -> 781 (nltenebular); 1024 x 1 (4
+// waves/SIMD, 128 VGPRs, 768 B of scratch): 457 ms.
+#ifndef ARTIS_RPKT_TB
+#define ARTIS_RPKT_TB 768  // threads per workgroup of k_rpkt ...
+#define ARTIS_RPKT_WGS 1   // ... and workgroups per CU
+#endif
+template <bool CONT_LDS, int TB>
+__global__ void __launch_bounds__(TB, ARTIS_RPKT_WGS) k_rpkt(Env env, const int32_t *list, int32_t n, Lists next,
                                                                    unsigned long long *gstats, int budget, int32_t *cursors, int nchunks,
                                                                    int drain_budget) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
   __shared__ double lds_cellest[3 * (CONT_LDS ? RPKT_CELLEST_CAP : RPKT_CELLEST_CAP_NOCONT)];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
-  cellest_begin(env, lds_cellest, env.cellest_n_r, BLOCK, env.E.J, env.E.nuJ, env.E.ffheatingestimator);
+  cellest_begin(env, lds_cellest, env.cellest_n_r, TB, env.E.J, env.E.nuJ, env.E.ffheatingestimator);
   if (CONT_LDS) {
     const D2 *src = (const D2 *)env.M.cont_pack;
     D2 *dst = (D2 *)lds_cont;
-    for (int i = threadIdx.x; i < env.M.nbfcontinua * 2; i += BLOCK) dst[i] = src[i];
+    for (int i = threadIdx.x; i < env.M.nbfcontinua * 2; i += TB) dst[i] = src[i];
     env.M.cont_pack = lds_cont;
     env.cont_in_lds = 1;
   }
@@ -841,9 +849,9 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_RPKT_WAVES) k_rpkt(Env env, const
     append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
   }
   __syncthreads();
-  cellest_flush(env, CELLEST_J, env.E.J, BLOCK);
-  cellest_flush(env, CELLEST_NUJ, env.E.nuJ, BLOCK);
-  cellest_flush(env, CELLEST_FFHEAT, env.E.ffheatingestimator, BLOCK);
+  cellest_flush(env, CELLEST_J, env.E.J, TB);
+  cellest_flush(env, CELLEST_NUJ, env.E.nuJ, TB);
+  cellest_flush(env, CELLEST_FFHEAT, env.E.ffheatingestimator, TB);
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
@@ -2839,15 +2847,15 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * (MAX_CHUNKS + 1), s));
       HIP_TRY(hipEventRecord(e->ev0, s));
       if (kind == NEXT_RPKT) {
-        const int grid = std::min(nblocks(nk), e->ncu * ARTIS_RPKT_WAVES);  // persistent: every block resident
+        const int grid = (int)std::min<int64_t>(((int64_t)nk + ARTIS_RPKT_TB - 1) / ARTIS_RPKT_TB, (int64_t)e->ncu * ARTIS_RPKT_WGS);  // persistent: every block resident
         const int bud_r = (e->budget_r_small > 0 && nk < e->small_list) ? std::min(e->budget_r_small, e->budget_r) : e->budget_r;
-        const int nch = e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8;
+        const int nch = e->wave_chunks_r ? chunks_for(nk, grid * (ARTIS_RPKT_TB / 64)) : 8;
         if (e->cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0 &&
             !(env.cellest_n_r > RPKT_CELLEST_CAP))
-          hipLaunchKernelGGL((k_rpkt<true>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
+          hipLaunchKernelGGL((k_rpkt<true, ARTIS_RPKT_TB>), dim3(grid), dim3(ARTIS_RPKT_TB), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
                              (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
         else
-          hipLaunchKernelGGL((k_rpkt<false>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
+          hipLaunchKernelGGL((k_rpkt<false, ARTIS_RPKT_TB>), dim3(grid), dim3(ARTIS_RPKT_TB), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
                              (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
         if (env.bfev != nullptr) {  // the estimator updates the launch recorded (the cells' cache rows are still resident)
