@@ -872,8 +872,11 @@ __global__ void __launch_bounds__(TB, ARTIS_RPKT_WGS) k_rpkt(Env env, const int3
 // workgroup of DENSE_TB threads, one per CU.
 constexpr int DENSE_TB = 1024;
 // LPR lanes per record: a window holds ~30 kept continua (ARTIS_AMD_DENSE_LPR = 64, 32 or 16)
+#ifndef ARTIS_DENSE_WGS
+#define ARTIS_DENSE_WGS 2  // workgroups of DENSE_TB threads per CU: 8 waves/SIMD at 60 VGPRs (1: 4 waves/SIMD; k_rpkt + this kernel 781 -> 774 ms)
+#endif
 template <bool CONT_LDS, int TB, int LPR>
-__global__ void __launch_bounds__(TB) k_bfest_dense(Env env) {
+__global__ void __launch_bounds__(TB, (TB == DENSE_TB ? ARTIS_DENSE_WGS : 1)) k_bfest_dense(Env env) {
   __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
   if (CONT_LDS) {
     const D2 *src = (const D2 *)env.M.cont_pack;
@@ -2635,7 +2638,7 @@ static int launch_bfest_dense(artis_amd_engine *e, const Env &env, hipStream_t s
   const bool lds = e->dense_cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX;
 #define DENSE_LAUNCH(LPR)                                                                                        \
   if (lds)                                                                                                       \
-    hipLaunchKernelGGL((k_bfest_dense<true, DENSE_TB, LPR>), dim3(e->ncu), dim3(DENSE_TB), 0, s, env);           \
+    hipLaunchKernelGGL((k_bfest_dense<true, DENSE_TB, LPR>), dim3(e->ncu * ARTIS_DENSE_WGS), dim3(DENSE_TB), 0, s, env); \
   else                                                                                                           \
     hipLaunchKernelGGL((k_bfest_dense<false, BLOCK, LPR>), dim3(e->ncu * 8), dim3(BLOCK), 0, s, env);
   if (e->dense_lpr == 64) {
