@@ -1074,8 +1074,13 @@ __device__ inline int hot_acquire(HotSlots &hs, double *hot_lds, const Env &env,
 // k-packet step, per iteration; lanes take a new packet between iterations. USE_LDS: with the hot-block slots above
 // (workgroups of TBLOCK threads, one list chunk per workgroup); otherwise workgroups of BLOCK threads on the XCD chunks,
 // every record read from HBM (a hot level from the cell's compact hot block there).
+#ifndef ARTIS_THERMAL_TB
+#define ARTIS_THERMAL_TB BLOCK                 // threads per workgroup of k_thermal<false>,
+#define ARTIS_THERMAL_EU ARTIS_THERMAL_WAVES   // the waves per SIMD its registers are to allow (512 / EU VGPRs) ...
+#define ARTIS_THERMAL_WGS ARTIS_THERMAL_WAVES  // ... and its workgroups per CU
+#endif
 template <bool USE_LDS, int TB>
-__global__ void __launch_bounds__(TB, ARTIS_THERMAL_WAVES) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
+__global__ void __launch_bounds__(TB, (USE_LDS ? ARTIS_THERMAL_WAVES : ARTIS_THERMAL_EU)) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                      unsigned long long *gstats, int budget, int32_t *cursors,
                                                                      int nchunks, int chunk_mode, int drain_budget) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
@@ -2888,13 +2893,14 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
           hipLaunchKernelGGL(k_thermal_q, dim3(grid), dim3(BLOCK), sizeof(double) * (size_t)env.cellest_n_t, s, env, lst, nk, next, e->d_stats,
                              e->budget_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8, 0, e->refill_low);
         } else {
-          const int grid = std::min(nblocks(nk), e->ncu * e->thermal_blocks_per_cu);
+          const int grid = (int)std::min<int64_t>(((int64_t)nk + ARTIS_THERMAL_TB - 1) / ARTIS_THERMAL_TB,
+                                                  (int64_t)e->ncu * std::min(e->thermal_blocks_per_cu, ARTIS_THERMAL_WGS));
           const bool per_cu = e->cu_chunks_t && nk >= 256 * 1024;
           // (drain: only where the next thermal launch will be large too, so that what is handed on runs beside a full list)
           const int bud_t = (e->budget_t_small > 0 && nk < e->small_list) ? std::min(e->budget_t_small, e->budget_t) : e->budget_t;
           const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : bud_t;
-          hipLaunchKernelGGL((k_thermal<false, BLOCK>), dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, bud_t,
-                             e->d_cursors, per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8), per_cu ? 2 : 0, drain);
+          hipLaunchKernelGGL((k_thermal<false, ARTIS_THERMAL_TB>), dim3(grid), dim3(ARTIS_THERMAL_TB), 0, s, env, lst, nk, next, e->d_stats, bud_t,
+                             e->d_cursors, per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (ARTIS_THERMAL_TB / 64)) : 8), per_cu ? 2 : 0, drain);
         }
       } else if (kind == NEXT_BB) {
         hipLaunchKernelGGL(k_blackbody, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);
