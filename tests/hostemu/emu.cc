@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 
 #include "../../artis_amd/csrc/model_build.h"
@@ -137,6 +138,59 @@ void populate_all(Emu &e) {
 extern "C" {
 
 // the constants of constants.h as restated in physics.h, for tests/test_oracle_reference_props.py
+// Property check of the macro-atom filters (tables.h "FILTERS") on the functions the kernels use: for cumulative lists of 8
+// values and 24-bit draws u, whenever mafilt_count() does not call the draw ambiguous its count equals the number of values
+// <= (double)(u * 2^-24f) * whole, the comparison the f64 path makes. Every fourth trial puts a value within a few ulp of
+// z * whole (the cases the margins exist for). Returns the number of mismatches; *n_ambiguous: draws left to the f64 path.
+int64_t artis_emu_mafilter_selftest(int64_t ntrials, uint64_t seed, int64_t *n_ambiguous) {
+  using namespace artis;
+  uint64_t s = seed ? seed : 1;
+  auto next = [&s]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  auto unif = [&next]() { return (double)(next() >> 11) * 0x1.0p-53; };
+  int64_t mism = 0, namb = 0;
+  for (int64_t t = 0; t < ntrials; t++) {
+    double v[8];
+    const double scale = std::exp((unif() - 0.5) * 200.);  // wholes from 1e-43 to 1e43
+    double run = 0.;
+    for (int j = 0; j < 8; j++) {
+      if (unif() < 0.7) run += unif() * unif();  // (equal neighbours now and then, like actions without a rate)
+      v[j] = run;
+    }
+    const double whole_raw = (v[7] > 0.) ? v[7] : 1.;
+    const uint32_t u = (uint32_t)(next() >> 40);  // 24 bits
+    const double z = (double)rng_u24_value(u);
+    double whole = whole_raw * scale;
+    for (int j = 0; j < 8; j++) v[j] *= scale;
+    if ((t & 3) == 0) {  // a value right at the decision: z * whole and its neighbours in f64
+      const int j = (int)(next() % 7);
+      double x = z * whole;
+      const int k = (int)(next() % 5) - 2;
+      for (int i = 0; i < (k < 0 ? -k : k); i++) x = std::nextafter(x, k < 0 ? 0. : 2. * whole);
+      v[j] = x;  // ... kept non-decreasing by moving the neighbours it passes
+      for (int i = 0; i < j; i++) v[i] = (v[i] < x) ? v[i] : x;
+      for (int i = j + 1; i < 7; i++) v[i] = (v[i] > x) ? v[i] : x;
+    }
+    bool ok = true;
+    uint32_t q[8];
+    for (int j = 0; j < 8; j++) q[j] = mafilt_quant(v[j], whole, &ok);
+    if (!ok) continue;
+    U4 f;
+    for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
+    bool amb = false;
+    const int cnt = mafilt_count(f, (int)(u >> 9), &amb);
+    if (amb) {
+      namb++;
+      continue;
+    }
+    const double target = z * whole;
+    int exact = 0;
+    for (int j = 0; j < 8; j++) exact += (v[j] <= target) ? 1 : 0;
+    if (cnt != exact) mism++;
+  }
+  if (n_ambiguous) *n_ambiguous = namb;
+  return mism;
+}
+
 int artis_emu_constants(const char **names, double *values, int maxn) {
   using namespace artis;
   static const char *N[] = {"CLIGHT", "CLIGHT_PROP", "H", "MH", "ME", "PI", "EV", "MEV", "SIGMA_T", "THOMSON_LIMIT", "KB", "SAHACONST",

@@ -538,3 +538,18 @@ def test_reference_ci_option_sets_bit_exact(oracle, options):
         if options == "ci_classic_vpkt":
             assert ea.vgrid_flux.sum() > 0                  # the velocity-grid map
             assert np.all(per_comb[3::4] >= full)           # without the lines of one element
+
+
+def test_macroatom_filters_decide_what_the_f64_comparison_decides():
+    """tables.h "FILTERS": 4e6 random cumulative lists and 24-bit draws, a quarter of them with a value within two ulp of
+    z * whole; whenever the 15-bit filter does not hand the draw to the f64 path, its count is the f64 comparison's"""
+    import ctypes as C
+
+    L = emu.lib()
+    L.artis_emu_mafilter_selftest.restype = C.c_int64
+    L.artis_emu_mafilter_selftest.argtypes = [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]
+    namb = C.c_int64(0)
+    n = 4_000_000
+    assert L.artis_emu_mafilter_selftest(n, 12345, C.byref(namb)) == 0
+    # ambiguous: the planted quarter, plus ~8 entries x 2 of 32768 values of zi for the rest
+    assert 0.25 * n <= namb.value < 0.3 * n, namb.value
