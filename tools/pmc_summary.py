@@ -18,7 +18,7 @@ for d in dirs:
                     dur[k] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
                     ndisp[k] += 1
 for k, v in sorted(agg.items()):
-    if not any(x in k for x in ("k_thermal", "k_rpkt", "k_slow", "k_macroatom", "k_bfest_dense", "k_tail")):
+    if not any(x in k for x in ("k_thermal", "k_rpkt", "k_slow", "k_macroatom", "k_bfest_dense", "k_tail", "k_matrans", "k_mafilter")):
         continue
     print(f"{k}: {ndisp[k]} dispatches, {dur[k]:.4f} s (in the FETCH_SIZE pass)")
     for c, val in sorted(v.items()):
