@@ -217,6 +217,23 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {  // 128 VGPR wi
         if (t.i == seglen - 1) rec[marec_rates + ARTIS_MA_ACTION_INTERNALUPSAME] = s0;
       }
     }
+    {
+      // The filter entry of this transition (tables.h "FILTERS"): its running sum as a fraction of the direction's whole
+      // rate, which is the sum of the direction's last transition -- at hand when that one is in this chunk. (A direction
+      // that the scan meets in more than one chunk: DevModel::malines_fix, k_mafilter.)
+      const int seglen = valid ? (t.isdown ? t.lpk.ndown : t.lpk.nup) : 1;
+      const int ti = valid ? t.i : 0;
+      const int endlane = lane + (seglen - 1 - ti);
+      const double mysum = t.isdown ? s2 : s0;
+      const double whole = __shfl(mysum, endlane & 63);
+      if (valid && endlane < 64) {
+        bool ok = (whole > 0.) && (whole <= DBLMAX);
+        const uint32_t q = (ok && ti < seglen - 1) ? mafilt_quant(mysum, whole, &ok) : MAFILT_NONE;
+        uint16_t *f = (uint16_t *)(row + t.lpk.rec_off + (t.isdown ? marec_down : marec_up(t.lpk.ndown)) + ((ti / MAREC_PER) * MAREC_LINE));
+        f[ti % MAREC_PER] = (uint16_t)(ok ? q : 0u);
+        if (ti % MAREC_PER == 0) f[7] = (uint16_t)(ok ? MAFILT_NONE : 0u);  // the line's "usable" mark
+      }
+    }
     // the last lane's sums go on if its segment does (the run ends at a level boundary, so only inside the run)
     c0 = __shfl(s0, 63);
     c1 = __shfl(s1, 63);
@@ -229,18 +246,29 @@ __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   if (i >= total) return;
   populate_macroatom(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
-// the uint16 filters of every record (tables.h "FILTERS"), once its rates and sums are final: a thread per (cell, level)
-// for the action filters, then a thread per (cell, line of sums)
+// the filters of the lines of sums that k_matrans could not write (DevModel::malines_fix): a thread per (cell, line)
 __global__ void __launch_bounds__(BLOCK) k_mafilter(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t per = (int64_t)env.M.nlevels + env.M.nmalines;
+  const int64_t per = env.M.nmalines_fix;
   if (i >= fill_count(env) * per) return;
+  const MaLineRef lr = env.M.malines_fix[i % per];
   const int c = fill_cell(env, i / per);
-  const int j = (int)(i % per);
-  if (j < env.M.nlevels)
-    populate_mafilter_level(env, c, j);
-  else
-    populate_mafilter_line(env, c, j - env.M.nlevels);
+  const DevModel &M = env.M;
+  // (populate_mafilter_line() for an entry of the other list)
+  if (lr.n <= 0) return;
+  double *row = env.K.macache + ((int64_t)c * M.nmacache);
+  double *line = row + lr.line_off;
+  const double whole = row[lr.rate_off];
+  bool ok = (whole > 0.) && (whole <= DBLMAX);
+  uint32_t q[8];
+  for (int j = 0; j < 8; j++) q[j] = MAFILT_NONE;
+  for (int j = 0; j < MAREC_PER; j++)
+    if (lr.first + j < lr.n - 1 && ok) q[j] = mafilt_quant(line[2 + j], whole, &ok);
+  if (!ok)
+    for (int j = 0; j < 8; j++) q[j] = 0u;
+  U4 f;
+  for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
+  *(U4 *)line = f;
 }
 // hot levels of every cell (physics.h populate_hotselect: the same rule, the levels spread over the lanes of one wave)
 __global__ void __launch_bounds__(BLOCK) k_hotselect(Env env) {
@@ -2463,7 +2491,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
     hipLaunchKernelGGL(k_corrphotoion, dim3(nblocks(ncell * h.nphixstargets_total)), dim3(BLOCK), 0, s, env, e->d_target_level);
   if (h.nalltrans > 0) hipLaunchKernelGGL(k_matrans, dim3(nblocks(ncell * h.nscanblk * 64)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_macroatom, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
-  hipLaunchKernelGGL(k_mafilter, dim3(nblocks(ncell * ((int64_t)h.nlevels + h.nmalines))), dim3(BLOCK), 0, s, env);
+  if (h.nmalines_fix > 0) hipLaunchKernelGGL(k_mafilter, dim3(nblocks(ncell * (int64_t)h.nmalines_fix)), dim3(BLOCK), 0, s, env);
   if (e->hot_blocks) {  // per-cell hot blocks: which levels are hot depends on the cell state
     hipLaunchKernelGGL(k_hotselect, dim3(nblocks(ncell * 64)), dim3(BLOCK), 0, s, env);
     hipLaunchKernelGGL(k_hotfill, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);

@@ -19,7 +19,7 @@ struct ModelOwned {
   std::vector<int32_t> level_upcum_start;
   std::vector<int32_t> alltrans_owner;
   std::vector<int32_t> scanblk_start;
-  std::vector<MaLineRef> malines;
+  std::vector<MaLineRef> malines, malines_fix;
   std::vector<ContPack> cont_pack;
   std::vector<int32_t> expopac_linestart;
   std::vector<int32_t> upcum_coolslot;
@@ -59,6 +59,7 @@ struct ModelOwned {
   X(alltrans_owner, int32_t, (m).nalltrans)                                        \
   X(scanblk_start, int32_t, ((m).nscanblk + 1))                                    \
   X(malines, MaLineRef, (m).nmalines)                                              \
+  X(malines_fix, MaLineRef, ((m).nmalines_fix > 0 ? (m).nmalines_fix : 1))         \
   X(alltrans_einstein_A, float, (m).nalltrans)                                     \
   X(alltrans_coll_str, float, (m).nalltrans)                                       \
   X(alltrans_osc_strength, float, (m).nalltrans)                                   \
@@ -240,6 +241,30 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   own.scanblk_start.push_back(m.nalltrans);
   v.nscanblk = (int32_t)own.scanblk_start.size() - 1;
   v.scanblk_start = own.scanblk_start.data();
+  {  // the directions that k_matrans' scan meets in more than one chunk of 64 transitions of their scan block
+    own.malines_fix.clear();
+    for (int b = 0; b < v.nscanblk; b++) {
+      const int a0 = own.scanblk_start[b], a1 = own.scanblk_start[b + 1];
+      for (int i = a0; i < a1;) {
+        const int ul = own.alltrans_owner[i];
+        const LevelPack &lp = own.level_pack[ul];
+        for (int dir = 0; dir < 2; dir++) {
+          const int n = dir == 0 ? lp.ndown : lp.nup;
+          if (n <= 0) continue;
+          const int sa = lp.alltrans_startdown + (dir == 0 ? 0 : lp.ndown), sb = sa + n;
+          if ((sa - a0) / 64 == (sb - 1 - a0) / 64) continue;
+          const int base = dir == 0 ? marec_down : marec_up(lp.ndown);
+          const int rate = marec_rates + (dir == 0 ? ARTIS_MA_ACTION_INTERNALDOWNSAME : ARTIS_MA_ACTION_INTERNALUPSAME);
+          for (int l = 0; l < marec_lines(n); l++)
+            own.malines_fix.push_back(MaLineRef{lp.rec_off + base + (l * MAREC_LINE), lp.rec_off + rate, l * MAREC_PER, n});
+        }
+        i = lp.alltrans_startdown + lp.ndown + lp.nup;
+      }
+    }
+    v.nmalines_fix = (int32_t)own.malines_fix.size();
+    if (own.malines_fix.empty()) own.malines_fix.push_back(MaLineRef{0, 0, 0, 0});
+    v.malines_fix = own.malines_fix.data();
+  }
   v.level_upcum_start = own.level_upcum_start.data();
   own.cont_pack.resize(m.nbfcontinua);
   for (int i = 0; i < m.nbfcontinua; i++)

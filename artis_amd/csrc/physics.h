@@ -1296,6 +1296,7 @@ AHD void populate_macroatom_sums(const Env &env, int c, int ul) {
   }
   rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s_up_same;
 }
+AHD void populate_mafilter_level(const Env &env, int c, int ul);  // (below, with the filters)
 // one (cell, level): the bound-free channels of calculate_macroatom_transitionrates macroatom.cc:141-190 (the four
 // bound-bound rates are already in the record: populate_macroatom_sums() / k_matrans), and the level's hotness
 AHD void populate_macroatom(const Env &env, int c, int ul) {
@@ -1365,6 +1366,7 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   for (int a = 0; a < MA_N; a++) total += rates[a];
   const float h = (float)(nnlevel * total);
   env.K.hotness[((int64_t)c * M.nlevels) + ul] = (h > 0.f && h <= 3.0e38f) ? h : 0.f;
+  populate_mafilter_level(env, c, ul);  // every rate of the record is final now: the action filter of its line 0
 }
 // ---- hot block of a cell (tables.h): which levels, where, and the copies
 AHD MaTarget matgt_pack(const LevelPack &target, int level) {
@@ -1435,6 +1437,13 @@ AHD void populate_hotfill(const Env &env, int c, int ul) {
   // the sum slots after each direction's last entry: +inf, so that ma_search_lines() needs no bounds checks
   for (int j = lpk.ndown; j < marec_lines(lpk.ndown) * MAREC_PER; j++) rec[marec_sum(marec_down, j)] = __builtin_inf();
   for (int j = lpk.nup; j < marec_lines(lpk.nup) * MAREC_PER; j++) rec[marec_sum(marec_up(lpk.ndown), j)] = __builtin_inf();
+  // ... and the filter entries of those slots: never counted (k_matrans writes the entries of the transitions only)
+  for (int dir = 0; dir < 2; dir++) {
+    const int n = dir == 0 ? lpk.ndown : lpk.nup;
+    const int base = dir == 0 ? marec_down : marec_up(lpk.ndown);
+    for (int j = n; j < marec_lines(n) * MAREC_PER; j++)
+      ((uint16_t *)(rec + base + ((j / MAREC_PER) * MAREC_LINE)))[j % MAREC_PER] = (uint16_t)MAFILT_NONE;
+  }
   if (off[ul] >= 0) {
     double *dst = env.K.hotblk + ((int64_t)c * HOT_DOUBLES) + ((int)off[ul] * MAREC_ALIGN);
     const int n = marec_units(lpk) * MAREC_ALIGN;

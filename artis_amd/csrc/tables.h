@@ -183,6 +183,10 @@ struct DevModel {
   int32_t nscanblk;
   const MaLineRef *malines;  // derived: every line of sums of every record, [nmalines]
   int32_t nmalines;
+  // ... and those whose direction's transitions are not all inside one 64-transition chunk of k_matrans' scan: k_matrans
+  // writes the filter of a line when it has the direction's whole rate at hand, k_mafilter the filters of these lines
+  const MaLineRef *malines_fix;
+  int32_t nmalines_fix;
   const float *alltrans_einstein_A, *alltrans_coll_str, *alltrans_osc_strength;
   const uint8_t *alltrans_forbidden;
   const double *line_nu;

@@ -119,7 +119,6 @@ void populate_all(Emu &e) {
     for (int ati = 0; ati < M.nalltrans; ati++) populate_matrans(e.env, c, ati);
     for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom_sums(e.env, c, ul);
     for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom(e.env, c, ul);
-    for (int ul = 0; ul < M.nlevels; ul++) populate_mafilter_level(e.env, c, ul);
     for (int li = 0; li < M.nmalines; li++) populate_mafilter_line(e.env, c, li);
     populate_hotselect(e.env, c);
     for (int ul = 0; ul < M.nlevels; ul++) populate_hotfill(e.env, c, ul);
