@@ -1782,6 +1782,7 @@ struct artis_amd_engine {
   // 512 < cells <= 3072: k_rpkt keeps J / nuJ / ffheating in LDS instead of the continuum table (12^3 grid, 912 cells:
   // k_rpkt 292 -> 215 ms; 14^3, 1472 cells: 249 -> 225 ms). ARTIS_AMD_RPKT_EST_OVER_CONT=0: the table wins the LDS.
   bool rpkt_est_over_cont = true;
+  bool ma_filters = true;       // macro-atom transitions decided on the records' 15-bit filters (ARTIS_AMD_MAFILTERS=0: on the f64 values)
   int dense_lpr = 32;           // k_bfest_dense: lanes per record (64 = a wave per record; ARTIS_AMD_DENSE_LPR)
   bool dense_cont_lds = true;   // k_bfest_dense reads the continuum table from LDS (nltenebular step 1917 -> 1882 ms); ARTIS_AMD_DENSE_CONTLDS=0
   bool cellest_in_lds = true;  // ARTIS_AMD_CELLEST_LDS=0: every estimator add is a global atomic
@@ -1856,6 +1857,7 @@ Env make_env(const artis_amd_engine *e) {
     env.cellest_n_r = (e->cellest_in_lds && nc <= (e->rpkt_est_over_cont ? RPKT_CELLEST_CAP_NOCONT : RPKT_CELLEST_CAP)) ? nc : 0;
     env.cellest_n_g = (e->cellest_in_lds && nc <= GAMMA_CELLEST_CAP) ? nc : 0;
     env.scalars_in_lds = e->cellest_in_lds ? 1 : 0;
+    env.ma_filters_off = e->ma_filters ? 0 : 1;
   }
   env.S = e->S;
   env.E = e->E;
@@ -2302,6 +2304,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (ARTIS_OPT_VPKT_ON) e->tail_max = 0;  // (see the estimator block: the event queue is sized per split launch)
   if (const char *b = std::getenv("ARTIS_AMD_RPKT_EST_OVER_CONT")) e->rpkt_est_over_cont = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_DENSE_CONTLDS")) e->dense_cont_lds = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_MAFILTERS")) e->ma_filters = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_DENSE_LPR")) e->dense_lpr = (std::atoi(b) == 64) ? 64 : (std::atoi(b) == 16 ? 16 : 32);
   if (const char *b = std::getenv("ARTIS_AMD_CELLEST_LDS")) e->cellest_in_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_R")) e->sort_maxpc_r = std::max(1, std::atoi(b));

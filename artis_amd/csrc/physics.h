@@ -174,6 +174,9 @@ struct Env {
   // kernel's workgroup in LDS, added to E.scalars when the kernel ends; null: global atomics. scalars_in_lds: host switch
   double *scalars_lds;
   int32_t scalars_in_lds;
+  // 1: macro-atom transitions are decided on the f64 rates and sums only (ARTIS_AMD_MAFILTERS=0: the filters of tables.h
+  // switched off, for the test that finds the same packets either way)
+  int32_t ma_filters_off;
   // deferred detailed bound-free estimator updates (DETAILED_BF builds on the GPU; null: added in place)
   BfEvent *bfev;
   int32_t *bfev_count;
@@ -2970,7 +2973,7 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
     bool amb;
     action = mafilt_count(f, zi, &amb);
     // ("cum[8] = total <= zrand * total" never holds: zrand <= 1 - 2^-24, and the product of that with total is below total)
-    amb = amb || !usable;
+    amb = amb || !usable || env.ma_filters_off != 0;
     if (amb) {
       if (usable) ma_load_rates(rec, r, cum);
       const double randomrate = rng_u24_value(u1) * cum[MA_N - 1];
@@ -2994,8 +2997,8 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
     int ti = 0;
     if (nsearch > 0) {
       const int zi = (int)(u2 >> 9);
-      bool amb = false;
-      for (int b0 = 0; b0 < nsearch; b0 += MAREC_PER) {
+      bool amb = env.ma_filters_off != 0;
+      for (int b0 = 0; b0 < nsearch && !amb; b0 += MAREC_PER) {
         const U4 f = *(const U4 *)(rec + base + ((b0 / MAREC_PER) * MAREC_LINE));
         const int cnt = mafilt_count(f, zi, &amb);
         amb = amb || (f.w[3] >> 16) != MAFILT_NONE;

@@ -491,6 +491,31 @@ def test_tail_kernel_gives_the_split_kernels_packets(engine_mod, oracle, monkeyp
     parity.compare_packets(outs[1][0][:6000], pa, FLOAT_RTOL, "tail kernel vs oracle")
 
 
+@pytest.mark.parametrize("options", ["classic", "nltenebular"])
+def test_macroatom_filters_decide_nothing_the_f64_values_would_not(engine_mod, monkeypatch, options):
+    """The 15-bit filters of the macro-atom records (tables.h "FILTERS") against the f64 comparisons they stand for, on the
+    bench grid with the bench's atomic data: 2e6 packets (5e9 transitions) with the filters and with ARTIS_AMD_MAFILTERS=0
+    (every transition decided on the f64 rates and sums): every field of every packet, the generator states and the event
+    counters are identical; the estimators to summation order."""
+    model, cs, ts, aux = synth.build("w7", ncoord=50, options=options)
+    pk0 = synth.make_packets(model, aux, 2_000_000 if options == "classic" else 1_000_000, seed_base=1281360349, kpkt_fraction=0.02)
+    outs = []
+    for off in (False, True):
+        monkeypatch.delenv("ARTIS_AMD_MAFILTERS", raising=False)
+        if off:
+            monkeypatch.setenv("ARTIS_AMD_MAFILTERS", "0")
+        eng = engine_mod.Engine(model, preset=options)
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, options)
+        eng.update_packets(p, e)
+        eng.close()
+        outs.append((p, e))
+    assert outs[0][1].stats[abi.STAT_X_MA_JUMPS] > (4e9 if options == "classic" else 5e8)
+    parity.compare_packets(outs[1][0], outs[0][0], 0.0, "f64 decisions vs filters")
+    parity.compare_stats(outs[1][1], outs[0][1], "f64 decisions vs filters")
+    parity.compare_estimators(outs[1][1], outs[0][1], 1e-10, "f64 decisions vs filters")
+
+
 @pytest.mark.parametrize("options,gridtype,ncoord", [("classic", abi.GRID_CARTESIAN3D, 8), ("classic", abi.GRID_SPHERICAL1D, 16),
                                                      ("nltenebular", abi.GRID_CARTESIAN3D, 8)])
 def test_walker_compaction_kernel_gives_the_phase_kernels_packets(engine_mod, oracle, monkeypatch, options, gridtype, ncoord):
