@@ -462,10 +462,14 @@ struct Lists {
   int32_t kpkt_slot;          // list that takes k-packets: NEXT_KPKT, or NEXT_MA when k-packets and macro-atoms share the
                               // fused thermal kernel
   int32_t nubins;             // frequency bins of the r-packet list's keys (1 = sort by cell only)
+  int32_t mabins;             // sub-keys of the thermal list's keys (1 = sort by cell only)
 };
-__device__ inline void append_by_kind(int kind, int32_t pi, int32_t cellindex, double nu_cmf, const Lists &L) {
+// ma_sub: (tuning, ARTIS_AMD_MABINS=16) a sub-key 0..15 of a thermal-list entry below its cell, -1: none
+__device__ inline void append_by_kind(int kind, int32_t pi, int32_t cellindex, double nu_cmf, const Lists &L, int ma_sub = -1) {
   const int slot = (kind == NEXT_KPKT) ? L.kpkt_slot : kind;
-  const int32_t key = list_sort_key(cellindex, nu_cmf, (slot == NEXT_RPKT) ? L.nubins : 1);
+  int32_t key = list_sort_key(cellindex, nu_cmf, (slot == NEXT_RPKT) ? L.nubins : 1);
+  if (slot == NEXT_MA && L.mabins > 1)
+    key = (cellindex * SORT_NUBINS) + ((kind == NEXT_KPKT || ma_sub < 0) ? SORT_NUBINS - 1 : (ma_sub & (SORT_NUBINS - 1)));
 #pragma unroll
   for (int k = 1; k < NEXT_NKINDS; k++) {
     int32_t *dst = (k == L.self_kind) ? L.self_list : L.lst[k];
@@ -874,7 +878,7 @@ __global__ void __launch_bounds__(TB, ARTIS_RPKT_WGS) k_rpkt(Env env, const int3
       tprev = now;
     }
 #endif
-    append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
+    append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next, (p.ma_element * 5 + p.ma_ion));
   }
   __syncthreads();
   cellest_flush(env, CELLEST_J, env.E.J, TB);
@@ -1015,7 +1019,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
         have = false;
       }
     }
-    append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
+    append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next, (p.ma_element * 5 + p.ma_ion));
   }
   __syncthreads();
   cellest_flush(env, CELLEST_DEPGAMMA, env.E.dep_estimator_gamma, BLOCK);
@@ -1249,7 +1253,7 @@ __global__ void __launch_bounds__(TB, (USE_LDS ? ARTIS_THERMAL_WAVES : ARTIS_THE
         slot_ok = false;
       }
     }
-    append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
+    append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next, (p.ma_element * 5 + p.ma_ion));
     pkt_clear_flight(p);  // a thermal packet never reads them: no live range across iterations
 #ifdef ARTIS_PROFILE
     tprev = clock64();
@@ -1403,7 +1407,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal_q(Env en
           out_pi = pi;
         }
       }
-      append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next);
+      append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next, (p.ma_element * 5 + p.ma_ion));
       // where the slots go: READY, or back on the service stack as empty (a packet is pulled into it by the next pass), or --
       // once the work list is used up -- out of use
       {
@@ -1782,6 +1786,8 @@ struct artis_amd_engine {
   // 512 < cells <= 3072: k_rpkt keeps J / nuJ / ffheating in LDS instead of the continuum table (12^3 grid, 912 cells:
   // k_rpkt 292 -> 215 ms; 14^3, 1472 cells: 249 -> 225 ms). ARTIS_AMD_RPKT_EST_OVER_CONT=0: the table wins the LDS.
   bool rpkt_est_over_cont = true;
+  int ma_bins = SORT_NUBINS;    // the thermal list sorted by (cell, a hash of the macro-atom's ion) instead of by cell alone: the lanes of a wave
+                                // start in the records of one or two ions (ARTIS_AMD_MABINS=1: by cell; step 1060 -> ~1050 ms)
   bool ma_filters = true;       // macro-atom transitions decided on the records' 15-bit filters (ARTIS_AMD_MAFILTERS=0: on the f64 values)
   int dense_lpr = 32;           // k_bfest_dense: lanes per record (64 = a wave per record; ARTIS_AMD_DENSE_LPR)
   bool dense_cont_lds = true;   // k_bfest_dense reads the continuum table from LDS (nltenebular step 1917 -> 1882 ms); ARTIS_AMD_DENSE_CONTLDS=0
@@ -2304,6 +2310,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (ARTIS_OPT_VPKT_ON) e->tail_max = 0;  // (see the estimator block: the event queue is sized per split launch)
   if (const char *b = std::getenv("ARTIS_AMD_RPKT_EST_OVER_CONT")) e->rpkt_est_over_cont = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_DENSE_CONTLDS")) e->dense_cont_lds = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_MABINS")) e->ma_bins = (std::atoi(b) > 1) ? SORT_NUBINS : 1;
   if (const char *b = std::getenv("ARTIS_AMD_MAFILTERS")) e->ma_filters = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_DENSE_LPR")) e->dense_lpr = (std::atoi(b) == 64) ? 64 : (std::atoi(b) == 16 ? 16 : 32);
   if (const char *b = std::getenv("ARTIS_AMD_CELLEST_LDS")) e->cellest_in_lds = std::atoi(b) != 0;
@@ -2732,6 +2739,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     L.self_count = e->d_count + NEXT_NKINDS;  // one alternate counter: only one kernel runs at a time
     L.kpkt_slot = NEXT_MA;  // k-packets travel in the thermal list
     L.nubins = r_nubins;
+    L.mabins = e->ma_bins;
     return L;
   };
   int32_t errflag = 0;
@@ -2875,7 +2883,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       const Lists next = lists_for(kind);
       const int32_t *lst = e->d_lists[kind][cur[kind]];
       if (kind == NEXT_RPKT || kind == NEXT_GAMMA || (kind == NEXT_MA && e->sort_ma)) {
-        rc = sort_by_key(e, s, e->d_lists[kind][cur[kind]], e->d_keys[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? r_nubins : 1,
+        rc = sort_by_key(e, s, e->d_lists[kind][cur[kind]], e->d_keys[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? r_nubins : (kind == NEXT_MA ? e->ma_bins : 1),
                          hi - lo, kind == NEXT_MA ? (env.cellest_n_t > 0 ? INT32_MAX : e->sort_maxpc_t)
                                                   : (env.cellest_n_r > 0 ? INT32_MAX : e->sort_maxpc_r));
         if (rc != ARTIS_OK) return rc;
