@@ -1642,8 +1642,10 @@ AHD float phixs_finish(const DevModel &M, const PhixsRead r, double nu_edge, dou
 // calculate_chi_bf_gammacontr<true, SELECT> rpkt.cc:721. The continua that contribute (keep bitmap of the cell) are
 // taken CHI_BATCH at a time: all reads of a batch are issued before any of its arithmetic, the sum is accumulated in
 // the reference's order.
+// Batch of 2 (4 in the builds with detailed bound-free estimators): measured with k_rpkt at 3 waves/SIMD and 168 VGPRs, where
+// a batch of 4 costs 96 B more scratch: k_rpkt 340 -> 330 ms (classic), 383 -> 357 ms (kilonova_lte), 773 -> 779 (nltenebular).
 #ifndef ARTIS_CHI_BATCH
-#define ARTIS_CHI_BATCH 4
+#define ARTIS_CHI_BATCH (ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 4 : 2)
 #endif
 // iterator over the set bits of a cell's keep bitmap inside [cbegin, cend), one 64-bit word per read
 struct KeepIter {
