@@ -2202,6 +2202,12 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
     if (e->ntiles < 1) e->ntiles = 1;
     e->tile_lo = 0;
     e->tile_hi = (int)std::min<int64_t>(ncell_all, e->tile_cells);
+    if (ARTIS_OPT_VPKT_ON && e->ntiles > 1) {
+      // a virtual packet's ray reads the cache rows of every cell up to the grid's edge (vpkt.cc:183): all of them have to be resident
+      g_last_error = "this build has VPKT_ON and the cell cache does not fit one tile (" + std::to_string(per_cell) + " B per cell x " +
+                     std::to_string((long long)ncell_all) + " cells): virtual packets need every cell's row resident";
+      return ARTIS_ERR_UNSUPPORTED;
+    }
   }
   const int64_t nrows = e->tile_cells;  // rows allocated
 #define CA(f, T, per)                                                                       \
@@ -2776,6 +2782,9 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     e->tile_hi = hi;
     e->tile_valid_lo = -1;
   }
+  // (a sparse fill of the tile before left its residency bitmap on: it describes that tile's cells only, and classified with
+  // it every packet of this tile would be parked and the tile skipped)
+  e->resident_on = false;
   env = make_env(e);
   for (int k = 0; k < NEXT_NKINDS; k++) cur[k] = 0;
   HIP_TRY(hipMemsetAsync(e->d_count, 0, sizeof(int32_t) * 2 * NEXT_NKINDS, s));

@@ -71,6 +71,9 @@ typedef unsigned long long stat_t;
 #define ARTIS_STAT(env, i) ARTIS_STAT_ADD(env, i, 1)
 // -DARTIS_PROFILE (device only): wave-cycle accounting into the spare stats slots, units of 16 clocks, charged by
 // the first active lane of the wave for the code between two marks
+#if defined(ARTIS_PROFILE) && ARTIS_OPT_VPKT_ON
+#error "-DARTIS_PROFILE keeps its phase clocks in the stats slots 48..52, which a VPKT_ON build uses for nvpkt_created / nvpkt_esc_*"
+#endif
 #if defined(ARTIS_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define PROF_BEGIN() long long prof_t = clock64()
 #define PROF_MARK(env, slot)                                                                   \

@@ -397,10 +397,11 @@ def main():
                        else "1 GPU"},
             # achieved / frac / traffic: bytes that REACHED HBM by the committed rocprofv3 counters (2 x FETCH_SIZE + WRITE_SIZE
             # per launch) over the kernel's launch time measured live with HIP events -- the number north_star's ">= 30 % of
-            # HBM roofline" is about. null when the workload is not the profiled one. The bytes the kernel REQUESTS by design
+            # HBM roofline" is about. null when the workload is not the profiled one. `bound` is what the counters say holds the
+            # kernel (dependent L2-served gathers: waves wait most of their cycles with idle issue slots), not the priced roof. The bytes the kernel REQUESTS by design
             # (most of them served by L1/L2) are algorithmic_gbs: never to be read as an HBM fraction. The kernel is not
             # HBM-bound: `limiter` holds the measured ratios of what does hold it.
-            "roofline": {"bound": "hbm", "achieved": d["hbm_gbs_measured"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "latency", "priced_against": "hbm", "achieved": d["hbm_gbs_measured"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": d["hbm_frac_measured"], "traffic": d["hbm_bytes_per_launch_measured"],
                          "traffic_source": traffic_src, "kernel": dominant,
                          "hbm_gbs_measured_fetch_undoubled": d["hbm_gbs_measured_fetch_undoubled"],

@@ -118,7 +118,8 @@ enum {
   ARTIS_STAT_X_GAMMA_STEPS = 40, /* calls of gammapkt::do_gamma() gammapkt.cc:911 */
   /* virtual packets (vpkt.h:34-37): nvpkt_created, nvpkt_esc_from_rpkt / _kpkt / _macroatom */
   ARTIS_STAT_X_VPKT_CREATED = 48, ARTIS_STAT_X_VPKT_ESC_RPKT = 49, ARTIS_STAT_X_VPKT_ESC_KPKT = 50, ARTIS_STAT_X_VPKT_ESC_MA = 51,
-  /* 42..63: free for profiling builds (-DARTIS_PROFILE: wave-cycle accounting, units of 16 clocks) */
+  /* 42..47 and 52..63: free for profiling builds (-DARTIS_PROFILE / -DARTIS_PROFILE_MA: wave-cycle accounting; the
+   * do_rpkt_step() phase clocks also take 48..52, so a profiling build of a VPKT_ON preset is refused at compile time) */
   ARTIS_NSTATS = 64
 };
 
