@@ -163,19 +163,28 @@ __device__ inline double wave_shr1(double x) {
   hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
+// the lanes of the wave that hold the entries of this lane's filter line (7 transitions of one direction: consecutive lanes)
+__device__ inline unsigned long long line_lanes(int lane, int ti, int seglen) {
+  const int first = lane - (ti % MAREC_PER);
+  const int left = seglen - (ti - (ti % MAREC_PER));
+  const int cnt = left < MAREC_PER ? left : MAREC_PER;
+  return ((1ull << cnt) - 1ull) << first;
+}
 __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {  // 128 VGPR without spills: 4 waves/SIMD (-6 ms per step)
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int nblk = env.M.nscanblk;
   if (wave >= fill_count(env) * nblk) return;
-  const int c = fill_cell(env, wave / nblk);
+  const int64_t kf = wave / nblk;
+  const int c = fill_cell(env, kf);
   const int blk = (int)(wave % nblk);
-  const int a0 = env.M.scanblk_start[blk], a1 = env.M.scanblk_start[blk + 1];
-  double *row = env.K.macache + ((int64_t)c * env.M.nmacache);
-  double c0 = 0., c1 = 0., c2 = 0.;  // sums carried into the chunk by a segment that began before it
-  for (int base = a0; base < a1; base += 64) {
-    const int ati = base + lane;
-    const bool valid = ati < a1;
+  U4 *row = env.K.macache + ((int64_t)c * env.M.nmacache);
+  double *upterms = env.collexc_terms + (kf * env.M.nupcum);
+  double c0 = 0., c1 = 0., c2 = 0.;  // sums carried into the chunk by a segment that began before it (segments of > 64 transitions)
+  for (int ch = env.M.scanblk_chunk0[blk]; ch < env.M.scanblk_chunk0[blk + 1]; ch++) {
+    const int a0 = env.M.scanchunk_start[ch], nvalid = env.M.scanchunk_start[ch + 1] - a0;
+    const int ati = a0 + lane;
+    const bool valid = lane < nvalid;
     MaTransTerms t;
     t.v0 = t.v1 = t.v2 = t.kterm = 0.;
     t.i = 0;
@@ -200,44 +209,56 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {  // 128 VGPR wi
         s2 = p2 + t.v2;
       }
     }
+    U4 *rec = row + t.lpk.rec_off;
+    const int seglen = valid ? (t.isdown ? t.lpk.ndown : t.lpk.nup) : 1;
     if (valid) {
-      double *rec = row + t.lpk.rec_off;
-      const int seglen = t.isdown ? t.lpk.ndown : t.lpk.nup;
+      double *rates = ma_rates_of(rec, t.lpk.ndown, t.lpk.nup);
       if (t.isdown) {
-        rec[marec_rad(t.lpk.ndown, t.lpk.nup) + t.i] = s0;
-        rec[marec_sum(marec_down, t.i)] = s2;
         if (t.i == seglen - 1) {
-          rec[marec_rates + ARTIS_MA_ACTION_RADDEEXC] = s0;
-          rec[marec_rates + ARTIS_MA_ACTION_COLDEEXC] = s1;
-          rec[marec_rates + ARTIS_MA_ACTION_INTERNALDOWNSAME] = s2;
+          rates[ARTIS_MA_ACTION_RADDEEXC] = s0;
+          rates[ARTIS_MA_ACTION_COLDEEXC] = s1;
+          rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = s2;
         }
       } else {
-        rec[marec_sum(marec_up(t.lpk.ndown), t.i)] = s0;
-        env.K.collexc_cum[((int64_t)c * env.M.nupcum) + env.M.level_upcum_start[t.ul] + t.i] = t.kterm;
-        if (t.i == seglen - 1) rec[marec_rates + ARTIS_MA_ACTION_INTERNALUPSAME] = s0;
+        upterms[env.M.level_upcum_start[t.ul] + t.i] = t.kterm;
+        if (t.i == seglen - 1) rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s0;
       }
     }
     {
-      // The filter entry of this transition (tables.h "FILTERS"): its running sum as a fraction of the direction's whole
-      // rate, which is the sum of the direction's last transition -- at hand when that one is in this chunk. (A direction
-      // that the scan meets in more than one chunk: DevModel::malines_fix, k_mafilter.)
-      const int seglen = valid ? (t.isdown ? t.lpk.ndown : t.lpk.nup) : 1;
+      // The filter entries of this transition (tables.h "FILTERS"): its running sums as fractions of the direction's whole
+      // rates, which are the sums of the direction's last transition -- at hand when the segment lies inside this chunk (all
+      // but the segments of more than 64 transitions: DevModel::malongsegs, k_mafilter_long). A line is usable when every one
+      // of its entries is a finite fraction: a vote of the lanes that hold the line's entries.
       const int ti = valid ? t.i : 0;
       const int endlane = lane + (seglen - 1 - ti);
-      const double mysum = t.isdown ? s2 : s0;
-      const double whole = __shfl(mysum, endlane & 63);
-      if (valid && endlane < 64) {
-        bool ok = (whole > 0.) && (whole <= DBLMAX);
-        const uint32_t q = (ok && ti < seglen - 1) ? mafilt_quant(mysum, whole, &ok) : MAFILT_NONE;
-        uint16_t *f = (uint16_t *)(row + t.lpk.rec_off + (t.isdown ? marec_down : marec_up(t.lpk.ndown)) + ((ti / MAREC_PER) * MAREC_LINE));
-        f[ti % MAREC_PER] = (uint16_t)(ok ? q : 0u);
-        if (ti % MAREC_PER == 0) f[7] = (uint16_t)(ok ? MAFILT_NONE : 0u);  // the line's "usable" mark
+      const bool inchunk = valid && ti <= lane && endlane < nvalid;
+      const double whole_int = __shfl(t.isdown ? s2 : s0, endlane & 63);
+      const double whole_rad = __shfl(s0, endlane & 63);
+      bool ok_int = (whole_int > 0.) && (whole_int <= DBLMAX), ok_rad = (whole_rad > 0.) && (whole_rad <= DBLMAX);
+      uint32_t q_int = MAFILT_NONE, q_rad = MAFILT_NONE;
+      if (inchunk && ti < seglen - 1) {
+        if (ok_int) q_int = mafilt_quant(t.isdown ? s2 : s0, whole_int, &ok_int);
+        if (ok_rad && t.isdown) q_rad = mafilt_quant(s0, whole_rad, &ok_rad);
+      }
+      const unsigned long long bad_int = __ballot(inchunk && !ok_int), bad_rad = __ballot(inchunk && t.isdown && !ok_rad);
+      if (inchunk) {
+        const unsigned long long mine = line_lanes(lane, ti, seglen);
+        const bool lok_int = (bad_int & mine) == 0ull, lok_rad = (bad_rad & mine) == 0ull;
+        U4 *line = rec + marec_slot(t.isdown ? MADIR_DOWN : MADIR_UP, ti / MAREC_PER, t.lpk.ndown, t.lpk.nup);
+        mafilt_put(line, ti % MAREC_PER, lok_int ? q_int : 0u);
+        if (ti % MAREC_PER == 0) mafilt_put(line, 7, lok_int ? MAFILT_NONE : 0u);  // the line's "usable" mark
+        if (t.isdown) {
+          U4 *rline = rec + marec_slot(MADIR_RAD, ti / MAREC_PER, t.lpk.ndown, t.lpk.nup);
+          mafilt_put(rline, ti % MAREC_PER, lok_rad ? q_rad : 0u);
+          if (ti % MAREC_PER == 0) mafilt_put(rline, 7, lok_rad ? MAFILT_NONE : 0u);
+        }
       }
     }
-    // the last lane's sums go on if its segment does (the run ends at a level boundary, so only inside the run)
-    c0 = __shfl(s0, 63);
-    c1 = __shfl(s1, 63);
-    c2 = __shfl(s2, 63);
+    // the last lane's sums go on if its segment does (a long segment's chunks follow each other inside one block)
+    const int last = (nvalid > 0 ? nvalid : 1) - 1;
+    c0 = __shfl(s0, last);
+    c1 = __shfl(s1, last);
+    c2 = __shfl(s2, last);
   }
 }
 __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
@@ -246,81 +267,80 @@ __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   if (i >= total) return;
   populate_macroatom(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
-// the filters of the lines of sums that k_matrans could not write (DevModel::malines_fix): a thread per (cell, line)
-__global__ void __launch_bounds__(BLOCK) k_mafilter(Env env) {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t per = env.M.nmalines_fix;
-  if (i >= fill_count(env) * per) return;
-  const MaLineRef lr = env.M.malines_fix[i % per];
-  const int c = fill_cell(env, i / per);
-  const DevModel &M = env.M;
-  // (populate_mafilter_line() for an entry of the other list)
-  if (lr.n <= 0) return;
-  double *row = env.K.macache + ((int64_t)c * M.nmacache);
-  double *line = row + lr.line_off;
-  const double whole = row[lr.rate_off];
-  bool ok = (whole > 0.) && (whole <= DBLMAX);
-  uint32_t q[8];
-  for (int j = 0; j < 8; j++) q[j] = MAFILT_NONE;
-  for (int j = 0; j < MAREC_PER; j++)
-    if (lr.first + j < lr.n - 1 && ok) q[j] = mafilt_quant(line[2 + j], whole, &ok);
-  if (!ok)
-    for (int j = 0; j < 8; j++) q[j] = 0u;
-  U4 f;
-  for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
-  *(U4 *)line = f;
-}
-// hot levels of every cell (physics.h populate_hotselect: the same rule, the levels spread over the lanes of one wave)
-__global__ void __launch_bounds__(BLOCK) k_hotselect(Env env) {
+// The filters of the directions with more than 64 transitions (DevModel::malongsegs), which k_matrans' chunks cannot hold
+// whole: a wave per (cell, segment) re-forms the running sums 63 transitions (nine filter lines) at a time -- the same terms
+// added in the same order, lane k to the finished sum of lane k-1 -- and quantises them with the direction's whole rates,
+// which k_matrans has left in the record. (physics.h populate_dirfilter_seq is the sequential form.)
+__global__ void __launch_bounds__(BLOCK) k_mafilter_long(Env env) {
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (wave >= fill_count(env)) return;
-  const int c = fill_cell(env, wave);
-  const int nl = env.M.nlevels;
-  const int per = (nl + 63) / 64;
-  const int l0 = lane * per < nl ? lane * per : nl;
-  const int l1 = l0 + per < nl ? l0 + per : nl;
-  auto fits = [&](uint32_t t) {
-    int u = hot_units_at(env, c, l0, l1, t);
-    for (int o = 32; o > 0; o >>= 1) u += __shfl_xor(u, o);
-    return u <= HOT_UNITS;
-  };
-  uint32_t lo = 1u, hi = 0xFFFFFFFFu;
-  if (fits(lo)) {
-    hi = lo;
-  } else {
-    while (hi - lo > 1u) {
-      const uint32_t mid = lo + ((hi - lo) >> 1);
-      if (fits(mid)) hi = mid; else lo = mid;
+  const int nseg = env.M.nmalongsegs;
+  if (wave >= fill_count(env) * nseg) return;
+  const int c = fill_cell(env, wave / nseg);
+  const MaLongSeg seg = env.M.malongsegs[wave % nseg];
+  const LevelPack lpk = env.M.level_pack[seg.ul];
+  U4 *rec = env.K.macache + ((int64_t)c * env.M.nmacache) + lpk.rec_off;
+  const double *rates = ma_rates_of(rec, lpk.ndown, lpk.nup);
+  const bool down = seg.dir == 0;
+  const double whole_int = rates[down ? ARTIS_MA_ACTION_INTERNALDOWNSAME : ARTIS_MA_ACTION_INTERNALUPSAME];
+  const double whole_rad = rates[ARTIS_MA_ACTION_RADDEEXC];
+  double ca = 0., cb = 0.;
+  for (int base = 0; base < seg.n; base += 63) {
+    const int ti = base + lane;
+    const bool valid = lane < 63 && ti < seg.n;
+    double a = 0., b = 0.;
+    if (valid) {
+      const MaTransTerms t = matrans_terms(env, c, seg.ats0 + ti);
+      a = down ? t.v2 : t.v0;
+      b = down ? t.v0 : 0.;
     }
-  }
-  // places: exclusive prefix sum of the selected levels' sizes in level order
-  const int mine = hot_units_at(env, c, l0, l1, hi);
-  int incl = mine;
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o);
-    if (lane >= o) incl += v;
-  }
-  int u = incl - mine;
-  const float *hn = env.K.hotness + ((int64_t)c * nl);
-  int16_t *off = env.K.hotoff + ((int64_t)c * nl);
-  for (int l = l0; l < l1; l++) {
-    if (hot_key(hn[l]) >= hi) {
-      off[l] = (int16_t)u;
-      u += marec_units(env.M.level_pack[l]);
-    } else {
-      off[l] = -1;
+    double sa = (lane == 0 ? ca : 0.) + a, sb = (lane == 0 ? cb : 0.) + b;
+    for (int k = 1; k < 63; k++) {
+      const double pa = wave_shr1(sa), pb = wave_shr1(sb);
+      if (lane == k) {
+        sa = pa + a;
+        sb = pb + b;
+      }
     }
+    bool ok_int = (whole_int > 0.) && (whole_int <= DBLMAX), ok_rad = (whole_rad > 0.) && (whole_rad <= DBLMAX);
+    uint32_t q_int = MAFILT_NONE, q_rad = MAFILT_NONE;
+    if (valid && ti < seg.n - 1) {
+      if (ok_int) q_int = mafilt_quant(sa, whole_int, &ok_int);
+      if (ok_rad && down) q_rad = mafilt_quant(sb, whole_rad, &ok_rad);
+    }
+    const unsigned long long bad_int = __ballot(valid && !ok_int), bad_rad = __ballot(valid && down && !ok_rad);
+    if (valid) {
+      const unsigned long long mine = line_lanes(lane, ti, seg.n);  // (63 lanes = nine whole lines: lane % 7 == ti % 7)
+      const bool lok_int = (bad_int & mine) == 0ull, lok_rad = (bad_rad & mine) == 0ull;
+      U4 *line = rec + marec_slot(down ? MADIR_DOWN : MADIR_UP, ti / MAREC_PER, lpk.ndown, lpk.nup);
+      mafilt_put(line, ti % MAREC_PER, lok_int ? q_int : 0u);
+      if (ti % MAREC_PER == 0) mafilt_put(line, 7, lok_int ? MAFILT_NONE : 0u);
+      if (down) {
+        U4 *rline = rec + marec_slot(MADIR_RAD, ti / MAREC_PER, lpk.ndown, lpk.nup);
+        mafilt_put(rline, ti % MAREC_PER, lok_rad ? q_rad : 0u);
+        if (ti % MAREC_PER == 0) mafilt_put(rline, 7, lok_rad ? MAFILT_NONE : 0u);
+      }
+    }
+    const int last = (seg.n - base < 63 ? seg.n - base : 63) - 1;
+    ca = __shfl(sa, last);
+    cb = __shfl(sb, last);
   }
 }
-__global__ void __launch_bounds__(BLOCK) k_hotfill(Env env) {
+// test / debug view of one cell's records (artis_amd_debug_cellcache): a thread per level
+__global__ void __launch_bounds__(BLOCK) k_debug_macache(Env env, int c, double *maprocessrates, double *matrans, int32_t *bad) {
+  const int ul = blockIdx.x * BLOCK + threadIdx.x;
+  if (ul >= env.M.nlevels) return;
+  const int b = debug_level_record(env, c, ul, maprocessrates, matrans);
+  if (b != 0) atomicAdd(bad, b);
+}
+// the static part of every record of every resident row, once per engine: filter entries "never counted", lines usable
+__global__ void __launch_bounds__(BLOCK) k_mainit(Env env, int64_t nrows) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  const int64_t total = fill_count(env) * env.M.nlevels;
-  if (i >= total) return;
-  populate_hotfill(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
+  if (i >= nrows * env.M.nlevels) return;
+  populate_mainit(env, i / env.M.nlevels, (int)(i % env.M.nlevels));
 }
 // The cooling list of a (cell, ion) is one running sum over hundreds of terms (kpkt.cc:57-190): a free-free term, the
-// collisional-excitation terms k_matrans left in collexc_cum (most of them), and the bound-free tail. Three kernels:
+// collisional-excitation terms k_matrans left in the population's scratch rows (most of them), and the bound-free tail. Three kernels:
 // head and tail with a lane per (cell, ion) -- 64 chains side by side, each short -- and the long middle with a ROW OF
 // 16 LANES per (cell, ion): it reads 16 terms (one cache line) at a time, forms the running sum with the sequential
 // additions of the reference's loop (lane k adds its term to lane k-1's finished sum: DPP row shifts, same order, same
@@ -358,7 +378,7 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_chain(Env env) {
   const int j0 = (valid && nlevels > 0) ? M.level_upcum_start[start] : 0;
   const int j1 = (valid && nlevels > 0) ? M.level_upcum_start[start + nlevels - 1] + M.level_nuptrans[start + nlevels - 1] : 0;
   double carry = valid ? env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] : 0.;
-  double *upcum = env.K.collexc_cum + ((int64_t)c * M.nupcum);
+  double *upcum = env.collexc_terms + (((valid ? row_id : 0) / M.nions) * M.nupcum);  // the cell's row of the population's scratch
   double *cool = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
   for (int j = j0; __any(j < j1); j += 16) {  // rows with shorter chains idle through the longer ones' chunks
     const bool in = (j + r) < j1;
@@ -379,6 +399,14 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_chain(Env env) {
     carry = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(acc)), __builtin_amdgcn_ds_bpermute(src, __double2loint(acc)));
   }
   if (valid && r == 0 && j1 > j0) env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] = carry;
+}
+// the cooling filters of the levels' records from the running sums the chain left in the scratch rows: a thread per (cell, line)
+__global__ void __launch_bounds__(BLOCK) k_collexc_filter(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t per = env.M.ncoollines;
+  if (i >= fill_count(env) * per) return;
+  const int64_t kf = i / per;
+  populate_coolfilter_line(env, fill_cell(env, kf), (int)(i % per), env.collexc_terms + (kf * env.M.nupcum));
 }
 __global__ void __launch_bounds__(BLOCK) k_cooling_tail(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1030,115 +1058,37 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
 // Thermal packets (k-packets and walking macro-atoms) are advanced by ONE persistent kernel, so that the k-packet ->
 // macro-atom -> k-packet cycle (tens of times per packet and timestep, kpkt.cc:51) needs no kernel boundary.
 //
-// LDS staging of the macro-atom tables. The kernel is bound by the rate at which a CU's vector L1 takes the scattered
-// record reads of the walk (rocprof: ~0.6 tag look-ups per cycle and CU; 3 and 4 waves/SIMD run at the same speed). The
-// work list is sorted by cell and a workgroup pulls one contiguous run of it, so its lanes sit in a handful of cells at
-// any time. For each of those cells the workgroup keeps the cell's HOT BLOCK (tables.h: bit-identical copies of the
-// records of its hottest levels, ~90 % of all transitions) in one of ARTIS_HOT_SLOTS slots of LDS: the first wave that
-// pulls a packet of a new cell claims a free slot and copies the block in (12 KB, coalesced); a slot is free again when
-// the last packet of its cell has retired. A transition reads its record through a generic pointer -- the LDS copy when
-// the level is hot and the slot is ready, the block in HBM or the cell's full row otherwise -- so hot and cold lanes of
-// a wave share one instruction stream and only the cold ones go through L1/L2.
+// Staging macro-atom records in LDS was built and measured in rounds 2 and 3 (per-workgroup slots holding the hot levels'
+// records of the cells in flight, k_thermal<true>; and k_thermal_q, walk contexts in per-wave LDS slots with lanes refilled
+// inside the transition loop): both bit-identical, both slower (profiles/r02/lds_staging.md,
+// profiles/r03/k_thermal_lane_compaction.md). Round 4 took the cumulative sums and targets those variants staged out of
+// the records altogether (tables.h), and the variants with them.
 #ifndef ARTIS_THERMAL_WAVES
 #define ARTIS_THERMAL_WAVES 4
 #endif
-#ifndef ARTIS_THERMAL_BLOCK
-#define ARTIS_THERMAL_BLOCK 512
-#endif
-#ifndef ARTIS_HOT_SLOTS
-#define ARTIS_HOT_SLOTS 18
-#endif
-constexpr int TBLOCK = ARTIS_THERMAL_BLOCK;
-constexpr int NSLOT = ARTIS_HOT_SLOTS;
-static_assert((size_t)NSLOT * HOT_DOUBLES * 8 * (1024 * ARTIS_THERMAL_WAVES / 4 / TBLOCK) <= 156 * 1024, "hot slots exceed the CU's LDS");
-struct HotSlots {
-  int cell[NSLOT];   // non-empty cell whose hot block the slot holds (-1: never used)
-  int ref[NSLOT];    // packets of that cell held by lanes of this workgroup that were given the slot
-  int ready[NSLOT];  // the copy is complete
-  int lock;
-};
-// The lanes with isnew==true have just pulled a packet of non-empty cell c (thermal packets never change cell): give
-// each of them the slot of its cell, claiming and filling a free one for a cell that has none. Returns the slot or -1
-// (every slot is held by a cell with packets in flight: those lanes read the block in HBM). Wave-uniform control flow.
-__device__ inline int hot_acquire(HotSlots &hs, double *hot_lds, const Env &env, bool isnew, int c) {
-  volatile int *vcell = hs.cell, *vref = hs.ref, *vready = hs.ready;
-  const int lane = threadIdx.x & 63;
-  int myslot = -1;
-  unsigned long long todo = __ballot(isnew && c >= 0);
-  while (todo != 0) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int cc = __shfl(c, leader);
-    const unsigned long long same = __ballot(isnew && c == cc) & todo;
-    const int nn = __popcll(same);
-    int s = -1, stage = 0;
-    if (lane == leader) {
-      while (atomicCAS(&hs.lock, 0, 1) != 0) {}
-      for (int i = 0; i < NSLOT; i++)
-        if (vcell[i] == cc) s = i;
-      if (s < 0) {
-        for (int i = 0; i < NSLOT && s < 0; i++)
-          if (vref[i] == 0) s = i;
-        if (s >= 0) {
-          vcell[s] = cc;
-          vready[s] = 0;
-          stage = 1;
-        }
-      }
-      if (s >= 0) vref[s] = vref[s] + nn;
-      __threadfence_block();
-      atomicExch(&hs.lock, 0);
-    }
-    s = __shfl(s, leader);
-    stage = __shfl(stage, leader);
-    if (stage) {  // this wave copies the cell's hot block into the slot: 16 bytes per lane and round
-      const D2 *src = (const D2 *)(env.K.hotblk + ((int64_t)cc * HOT_DOUBLES));
-      D2 *dst = (D2 *)(hot_lds + (s * HOT_DOUBLES));
-      for (int i = lane; i < HOT_DOUBLES / 2; i += 64) dst[i] = src[i];
-      __threadfence_block();
-      if (lane == leader) vready[s] = 1;
-    }
-    if ((same >> lane) & 1ull) myslot = s;
-    todo &= ~same;
-  }
-  return myslot;
-}
 // Fused thermal kernel, phase form (physics.h thermal_iter): up to ARTIS_MA_PHASE macro-atom transitions, then one
-// k-packet step, per iteration; lanes take a new packet between iterations. USE_LDS: with the hot-block slots above
-// (workgroups of TBLOCK threads, one list chunk per workgroup); otherwise workgroups of BLOCK threads on the XCD chunks,
-// every record read from HBM (a hot level from the cell's compact hot block there).
+// k-packet step, per iteration; lanes take a new packet between iterations. Workgroups of TB threads on the XCD chunks.
 #ifndef ARTIS_THERMAL_TB
-#define ARTIS_THERMAL_TB BLOCK                 // threads per workgroup of k_thermal<false>,
+#define ARTIS_THERMAL_TB BLOCK                 // threads per workgroup of k_thermal,
 #define ARTIS_THERMAL_EU ARTIS_THERMAL_WAVES   // the waves per SIMD its registers are to allow (512 / EU VGPRs) ...
 #define ARTIS_THERMAL_WGS ARTIS_THERMAL_WAVES  // ... and its workgroups per CU
 #endif
-template <bool USE_LDS, int TB>
-__global__ void __launch_bounds__(TB, (USE_LDS ? ARTIS_THERMAL_WAVES : ARTIS_THERMAL_EU)) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
+template <int TB>
+__global__ void __launch_bounds__(TB, ARTIS_THERMAL_EU) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                      unsigned long long *gstats, int budget, int32_t *cursors,
                                                                      int nchunks, int chunk_mode, int drain_budget) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
-  __shared__ HotSlots hs;
-  __shared__ double __attribute__((aligned(16))) hot_lds[USE_LDS ? NSLOT * HOT_DOUBLES : 2];
-  __shared__ double lds_cellest[USE_LDS ? 1 : THERMAL_CELLEST_CAP];
+  __shared__ double lds_cellest[THERMAL_CELLEST_CAP];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
-  cellest_begin(env, lds_cellest, USE_LDS ? 0 : env.cellest_n_t, TB, env.E.colheatingestimator);
-  if (USE_LDS) {
-    if (threadIdx.x < NSLOT) {
-      hs.cell[threadIdx.x] = -1;
-      hs.ref[threadIdx.x] = 0;
-      hs.ready[threadIdx.x] = 0;
-    }
-    if (threadIdx.x == 0) hs.lock = 0;
-  }
+  cellest_begin(env, lds_cellest, env.cellest_n_t, TB, env.E.colheatingestimator);
   __syncthreads();
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
   Puller q;
-  puller_init(q, n, nchunks, USE_LDS ? 1 : chunk_mode);
+  puller_init(q, n, nchunks, chunk_mode);
   bool have = false;
   int32_t pi = 0;
   int units = 0;
-  int myslot = -1;       // LDS slot of this lane's cell
-  bool slot_ok = false;  // ... and its copy is complete
   bool drained = false;  // the launch's work list is used up (any wave found out)
   Pkt p;
   MACtx k;
@@ -1158,13 +1108,6 @@ __global__ void __launch_bounds__(TB, (USE_LDS ? ARTIS_THERMAL_WAVES : ARTIS_THE
       units = 0;
       have = true;
     }
-    if (USE_LDS) {
-      const int s = hot_acquire(hs, hot_lds, env, idx >= 0, k.c);
-      if (idx >= 0) {
-        myslot = s;
-        slot_ok = false;
-      }
-    }
     if (!__any(have)) {
       if (q.exhausted) break;
       continue;
@@ -1183,31 +1126,18 @@ __global__ void __launch_bounds__(TB, (USE_LDS ? ARTIS_THERMAL_WAVES : ARTIS_THE
       // the loop makes the internal transitions; the process that ends a walk is carried out after it, once per phase
       int j = 0;
       int exit_action = -1;
-      double exit_rate = 0.;
-      const double *rec = nullptr;
-      if (ma_pending(p) && p.pend == PEND_NONE) {
-        ma_prepare<USE_LDS>(env, p, k);  // the record of the current level; the walk carries it on
-        if (USE_LDS) {
-          if (myslot >= 0 && !slot_ok) slot_ok = ((volatile int *)hs.ready)[myslot] != 0;
-          if (slot_ok) k.hotbase = hot_lds + (myslot * HOT_DOUBLES);  // generic pointer into LDS
-        }
-      }
+      const U4 *rec = nullptr;
+      if (ma_pending(p) && p.pend == PEND_NONE) ma_prepare(env, p, k);  // the record of the current level; the walk carries it on
       while (j < ARTIS_MA_PHASE && exit_action < 0 && ma_pending(p) && p.pend == PEND_NONE) {
 #ifdef ARTIS_PROFILE
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 46);
-        if (k.hot >= 0 && slot_ok) ARTIS_STAT(env, 56);  // transitions read from LDS
-        if (k.hot >= 0) ARTIS_STAT(env, 57);             // transitions from a hot level
-        if (myslot >= 0) ARTIS_STAT(env, 58);            // transitions of a packet whose cell has a slot
 #endif
-        rec = ma_record<USE_LDS>(k);
-        exit_action = ma_jump_internal<USE_LDS, false>(env, p, k, rec, &exit_rate);
+        rec = ma_record(k);
+        exit_action = ma_jump_internal(env, p, k, rec);
         j++;
       }
       ma_flush_stats(env, k);
-      if (exit_action >= 0) {
-        exit_rate = rec[marec_rates + exit_action];  // (here, once per phase, not in the loop: ma_jump_internal<.., false>)
-        ma_jump_exit(env, p, pi, k, rec, exit_action, exit_rate);
-      }
+      if (exit_action >= 0) ma_jump_exit(env, p, pi, k, rec, exit_action);
       if (j > 0) chi_after_ma(p);
       units += j;
     }
@@ -1247,11 +1177,6 @@ __global__ void __launch_bounds__(TB, (USE_LDS ? ARTIS_THERMAL_WAVES : ARTIS_THE
       kind = classify(env, p, ts_end);
       out_pi = pi;
       have = false;
-      if (USE_LDS) {
-        if (myslot >= 0) atomicSub(&hs.ref[myslot], 1);  // the slot is free again when its cell's last packet has retired
-        myslot = -1;
-        slot_ok = false;
-      }
     }
     append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next, (p.ma_element * 5 + p.ma_ion));
     pkt_clear_flight(p);  // a thermal packet never reads them: no live range across iterations
@@ -1264,273 +1189,6 @@ __global__ void __launch_bounds__(TB, (USE_LDS ? ARTIS_THERMAL_WAVES : ARTIS_THE
   cellest_flush(env, CELLEST_COLHEAT, env.E.colheatingestimator, TB);
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
-
-// ---- k_thermal_q: the thermal kernel with IN-KERNEL COMPACTION of the macro-atom walkers (ARTIS_AMD_REFILL=0: k_thermal).
-// k_thermal gives a lane one packet and lets it walk for up to ARTIS_MA_PHASE rounds; walks are short on average but
-// heavy-tailed, so most lanes sit out most rounds of a phase (measured: 34.8 of 64 lanes per round, VALU lane utilisation
-// 0.38) while the CU's vector L1 -- the unit that limits the kernel -- is charged per wave INSTRUCTION, not per lane.
-// Here the walk is decoupled from the packet. A wave owns TQ_V (> 64) packets at a time; what a walk needs of a packet is
-// its WALK CONTEXT (generator state, cell, record offset and shape, level, counters: 56 B), kept in the wave's LDS
-// slots, while the packet's hot line rests in HBM. Two phases alternate per wave:
-//   walk:    every lane holds one context in registers and makes one transition per round; a lane whose walk ends writes
-//            (generator, level, action, rate) back to its slot, pushes the slot on the wave's service stack and pops the
-//            next READY slot in the same round (ballot + popcount, like pull()) -- the gather instructions of the
-//            transition loop carry 64 lanes as long as the ready stack has entries;
-//   service: once 64 slots wait (or the walkers run dry), ONE full-wave pass reloads those packets' hot lines, carries
-//            out the process that ended each walk (ma_jump_exit), makes the k-packet step that follows, and either
-//            prepares the next walk (slot READY, hot line stored) or retires the packet (stored, appended to the list of
-//            its next kind) and pulls a new one from the work list into the slot.
-// Per packet the same functions run in the same order on the same per-packet generator as in k_thermal, so packets,
-// generator states and event counters are identical (GPU test); estimator sums differ by summation order only.
-#ifndef ARTIS_TQ_SLOTS
-#define ARTIS_TQ_SLOTS 128
-#endif
-#ifndef ARTIS_TQ_LOW
-#define ARTIS_TQ_LOW 52
-#endif
-#ifndef ARTIS_TQ_BURST
-#define ARTIS_TQ_BURST 1
-#endif
-constexpr int TQ_BURST = ARTIS_TQ_BURST;  // transitions between two hand-outs of slots
-constexpr int TQ_V = ARTIS_TQ_SLOTS;  // slots per wave: 64 walking + a buffer that lets a full service pass fall due before the walkers starve
-static_assert(TQ_V >= 64 && TQ_V <= 256, "slot indices are kept in bytes");
-enum { TQ_EMPTY = -2, TQ_BUDGET = -3 };  // action of a slot on the service stack: no packet | walk interrupted by the launch budget
-struct TQWave {  // SoA: a lane reads field[its slot]
-  uint32_t s0[TQ_V], s1[TQ_V], s2[TQ_V], s3[TQ_V];
-  int32_t pi[TQ_V], c[TQ_V], rec[TQ_V], ndnu[TQ_V], level[TQ_V], units[TQ_V], njumps[TQ_V], action[TQ_V];
-  double rate[TQ_V];
-  uint8_t ready[TQ_V];    // stack of the slots whose walk can go on
-  uint8_t service[TQ_V];  // stack of the slots that wait for the service pass
-};
-__global__ void __launch_bounds__(BLOCK, ARTIS_THERMAL_WAVES) k_thermal_q(Env env, const int32_t *list, int32_t n, Lists next,
-                                                                           unsigned long long *gstats, int budget, int32_t *cursors,
-                                                                           int nchunks, int chunk_mode, int low_water) {
-  __shared__ stat_t lstats[ARTIS_NSTATS];
-  __shared__ TQWave tq[BLOCK / 64];
-  extern __shared__ double lds_cellest_dyn[];  // [env.cellest_n_t] (models with few cells; 0 bytes otherwise)
-  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
-  cellest_begin(env, lds_cellest_dyn, env.cellest_n_t, BLOCK, env.E.colheatingestimator);
-  __syncthreads();
-  env.stats = lstats;
-  const double ts_end = env.S.ts_end;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long lanebit = 1ull << lane;
-  TQWave &Q = tq[threadIdx.x >> 6];
-  Puller q;
-  puller_init(q, n, nchunks, chunk_mode);
-  // wave-uniform stack heights; every slot starts empty and waits for a packet
-  int nready = 0, nservice = TQ_V, ndead = 0;
-  for (int i = lane; i < TQ_V; i += 64) {
-    Q.service[i] = (uint8_t)i;
-    Q.action[i] = TQ_EMPTY;
-  }
-  __builtin_amdgcn_wave_barrier();
-#ifdef ARTIS_PROFILE
-  long long tq_t = clock64();  // wave clocks / 16 of the two phases in the spare stats slots 42 (service) and 43 (walk)
-#define TQ_PROF(slot)                                                                   \
-  do {                                                                                  \
-    const long long now = clock64();                                                    \
-    if (lane == 0) atomicAdd(&lstats[slot], (stat_t)((now - tq_t) >> 4));               \
-    tq_t = now;                                                                         \
-  } while (0)
-#else
-#define TQ_PROF(slot) ((void)0)
-#endif
-  while (true) {
-    // ---------------- service passes: while a full wave of slots waits, or the walkers would run short
-    while (nservice >= 64 || (nservice > 0 && nready < low_water)) {
-      const int take = min(64, nservice);
-      const bool has = lane < take;
-      const int s = has ? (int)Q.service[nservice - 1 - lane] : 0;
-      nservice -= take;
-      const int act = has ? Q.action[s] : TQ_EMPTY;
-      const bool isdone = has && act != TQ_EMPTY;
-      const int32_t idx = pull(q, has && !isdone, n, cursors);
-      const bool have = isdone || idx >= 0;
-      int32_t pi = 0;
-      int units = 0;
-      Pkt p;
-      MACtx k;
-      if (have) {
-        pi = isdone ? Q.pi[s] : list[idx];
-        pkt_load_thermal(env.P, pi, p);  // the hot line only
-        k = ma_ctx(env, p);
-        if (isdone) {  // the walk's own state is the slot's
-          p.s0 = Q.s0[s]; p.s1 = Q.s1[s]; p.s2 = Q.s2[s]; p.s3 = Q.s3[s];
-          p.ma_level = Q.level[s];
-          k.rec = Q.rec[s];
-          const int ndnu = Q.ndnu[s];
-          k.nd = ndnu & 0xFFFF;
-          k.nu = ndnu >> 16;
-          k.njumps = Q.njumps[s];
-          units = Q.units[s];
-        }
-      }
-      if (lane == 0) {
-        ARTIS_STAT(env, 47);            // service passes
-        ARTIS_STAT_ADD(env, 44, take);  // ... and the slots they served
-      }
-      int kind = NEXT_DONE;
-      int32_t out_pi = 0;
-      bool walking = false;
-      if (have) {
-        bool go = thermal_can_continue(p, ts_end);
-        if (isdone) {
-          ma_flush_stats(env, k);
-          if (act >= 0) ma_jump_exit(env, p, pi, k, k.cellma + k.rec, act, Q.rate[s]);
-          chi_after_ma(p);
-        }
-        if (go) {
-          // a pre-k-packet, or a k-packet in a grey cell, leaves for the blackbody kernel (classify() below)
-          const bool blackbody = (p.type == ARTIS_TYPE_PRE_KPKT) || k.thick;
-          if (kpkt_eligible(p, ts_end) && !blackbody) {
-            do_kpkt(env, p, pi);
-            p.chi_mgi = -1;
-            units++;
-          }
-          go = thermal_can_continue(p, ts_end) && !(blackbody && kpkt_eligible(p, ts_end));
-        }
-        walking = go && units < budget && ma_pending(p) && p.pend == PEND_NONE;
-        if (walking) ma_prepare<false>(env, p, k);  // the record of the level the walk starts from
-        pkt_store_thermal(env.P, pi, p);  // the hot line; the flight line only if an r-packet was emitted
-        if (walking) {
-          Q.s0[s] = p.s0; Q.s1[s] = p.s1; Q.s2[s] = p.s2; Q.s3[s] = p.s3;
-          Q.pi[s] = pi;
-          Q.c[s] = k.c;
-          Q.rec[s] = k.rec;
-          Q.ndnu[s] = k.nd | (k.nu << 16);
-          Q.level[s] = p.ma_level;
-          Q.units[s] = units;
-          Q.njumps[s] = 0;
-        } else {
-          kind = classify(env, p, ts_end);
-          out_pi = pi;
-        }
-      }
-      append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next, (p.ma_element * 5 + p.ma_ion));
-      // where the slots go: READY, or back on the service stack as empty (a packet is pulled into it by the next pass), or --
-      // once the work list is used up -- out of use
-      {
-        const unsigned long long rm = __ballot(walking);
-        if (walking) Q.ready[nready + __popcll(rm & (lanebit - 1ull))] = (uint8_t)s;
-        nready += __popcll(rm);
-        const bool again = has && !walking && !q.exhausted;
-        const unsigned long long em = __ballot(again);
-        if (again) {
-          Q.action[s] = TQ_EMPTY;
-          Q.service[nservice + __popcll(em & (lanebit - 1ull))] = (uint8_t)s;
-        }
-        nservice += __popcll(em);
-        ndead += take - __popcll(rm) - __popcll(em);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    TQ_PROF(42);
-    if (nready == 0) break;  // (then nothing waits for service either: every slot is out of use)
-    // ---------------- walk phase
-    {
-      // in the drain (work list used up) a service pass is worth its cost only for a reasonable share of the live slots
-      const int drain_min = max(1, min(16, (TQ_V - ndead) / 4));
-      int myslot = -1;
-      int units = 0;
-      Pkt w;  // only the generator state and ma_level are live
-      MACtx k;
-      w.ma_level = -1;
-      k.c = 0; k.cellma = nullptr; k.rec = 0; k.nd = k.nu = 0; k.njumps = 0;
-      k.hot = -1; k.start = 0;
-      int prof_rounds = 0, prof_lanes = 0;  // wave-uniform: micro-steps of this phase and the lanes that made one
-      while (true) {
-        {  // lanes without a context pop READY slots
-          const bool need = myslot < 0;
-          const unsigned long long m = __ballot(need);
-          if (m != 0 && nready > 0) {
-            const int takeN = min(__popcll(m), nready);
-            const int prefix = __popcll(m & (lanebit - 1ull));
-            if (need && prefix < takeN) {
-              const int s = (int)Q.ready[nready - 1 - prefix];
-              myslot = s;
-              w.s0 = Q.s0[s]; w.s1 = Q.s1[s]; w.s2 = Q.s2[s]; w.s3 = Q.s3[s];
-              w.ma_level = Q.level[s];
-              k.c = Q.c[s];
-              k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
-              k.rec = Q.rec[s];
-              const int ndnu = Q.ndnu[s];
-              k.nd = ndnu & 0xFFFF;
-              k.nu = ndnu >> 16;
-              k.njumps = Q.njumps[s];
-              units = Q.units[s];
-            }
-            nready -= takeN;
-          }
-        }
-        const int nactive = __popcll(__ballot(myslot >= 0));
-        if (nactive == 0 || nservice >= 64 || (nactive < low_water && nservice >= drain_min)) break;
-        // TQ_BURST transitions without any bookkeeping: the hand-out of slots is paid once per burst, not per transition. A
-        // lane whose walk ends inside a burst idles to its end.
-        bool ended = false;
-        int end_action = 0;
-        double end_rate = 0.;
-#pragma unroll 1
-        for (int b = 0; b < TQ_BURST; b++) {
-          const bool go = myslot >= 0 && !ended;
-          prof_lanes += __popcll(__ballot(go));
-          if (go) {
-            double rate = 0.;
-            const int action = ma_jump_internal<false>(env, w, k, k.cellma + k.rec, &rate);
-            units++;
-            if (action >= 0 || units >= budget) {
-              ended = true;
-              end_action = action >= 0 ? action : TQ_BUDGET;
-              end_rate = rate;
-            }
-          }
-        }
-        prof_rounds += TQ_BURST;
-        const unsigned long long em = __ballot(ended);
-        if (em != 0) {
-          if (ended) {
-            const int s = myslot;
-            Q.s0[s] = w.s0; Q.s1[s] = w.s1; Q.s2[s] = w.s2; Q.s3[s] = w.s3;
-            Q.level[s] = w.ma_level;
-            Q.rec[s] = k.rec;
-            Q.ndnu[s] = k.nd | (k.nu << 16);
-            Q.units[s] = units;
-            Q.njumps[s] = k.njumps;
-            Q.action[s] = end_action;
-            Q.rate[s] = end_rate;
-            Q.service[nservice + __popcll(em & (lanebit - 1ull))] = (uint8_t)s;
-            myslot = -1;
-          }
-          nservice += __popcll(em);
-        }
-      }
-      // park the walks in progress: their slots are READY again
-      const bool parked = myslot >= 0;
-      const unsigned long long pm = __ballot(parked);
-      if (parked) {
-        const int s = myslot;
-        Q.s0[s] = w.s0; Q.s1[s] = w.s1; Q.s2[s] = w.s2; Q.s3[s] = w.s3;
-        Q.level[s] = w.ma_level;
-        Q.rec[s] = k.rec;
-        Q.ndnu[s] = k.nd | (k.nu << 16);
-        Q.units[s] = units;
-        Q.njumps[s] = k.njumps;
-        Q.ready[nready + __popcll(pm & (lanebit - 1ull))] = (uint8_t)s;
-      }
-      nready += __popcll(pm);
-      if (lane == 0) {
-        ARTIS_STAT_ADD(env, 46, prof_rounds);  // wave-rounds of the transition loop
-        ARTIS_STAT_ADD(env, 45, prof_lanes);   // ... and the lanes that made a micro-step in them
-      }
-      __builtin_amdgcn_wave_barrier();
-      TQ_PROF(43);
-    }
-  }
-  __syncthreads();
-  cellest_flush(env, CELLEST_COLHEAT, env.E.colheatingestimator, BLOCK);
-  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
-}
-
 
 // Tail kernel: the LAST few thousand r-packets and thermal packets of a timestep, one per lane, each carried through
 // r-packet steps, macro-atom walks and k-packet steps until it leaves these kinds (end of the timestep, escape, a
@@ -1801,19 +1459,11 @@ struct artis_amd_engine {
   bool cu_chunks_t = false;  // ARTIS_AMD_CUCHUNKS_T=1: k_thermal takes one list chunk per compute unit (HW_REG_HW_ID);
                              // measured +7 %: like every finer chunking it puts more cells in flight per XCD
   bool cont_lds = true;      // k_rpkt keeps the static continuum table (ContPack) in LDS when it fits (ARTIS_AMD_CONTLDS=0: HBM)
-  // ARTIS_AMD_HOTLDS=1: the cells' hot blocks of macro-atom records are staged in LDS (k_thermal<true>). Parity-tested;
-  // measured slower than reading them from HBM on MI355X (profiles/r02/lds_staging.md), so it is off by default.
-  bool hot_lds = false;
-  // per-cell hot blocks (tables.h) are built when the LDS staging is on; ARTIS_AMD_HOTBLOCKS=1 builds and reads them in
-  // HBM without it (measured: k_thermal -3.5 %, populate +25 ms: no net gain)
-  bool hot_blocks = false;
   int thermal_blocks_per_cu = ARTIS_THERMAL_WAVES;  // tuning: resident k_thermal blocks per CU
-  // k_thermal_q: walk contexts in per-wave LDS slots, lanes refilled inside the transition loop (ARTIS_AMD_REFILL=0: k_thermal,
-  // one packet per lane and phases of ARTIS_MA_PHASE rounds). refill_low: a wave leaves the transition loop for a service
-  // pass when fewer lanes than this still walk and nothing is READY (ARTIS_AMD_REFILL_LOW).
-  bool thermal_refill = false;
-  int refill_low = ARTIS_TQ_LOW;
-  int refill_minpk = 128;  // packets per wave below which a launch uses fewer waves (ARTIS_AMD_REFILL_MINPK)
+  // the population's scratch: the collisional-excitation cooling terms of `pop_batch` cells at a time (k_matrans writes them,
+  // k_cooling_chain turns them into running sums, k_collexc_filter into the records' cooling filters; nothing of it is kept)
+  double *d_collexc_terms = nullptr;
+  int64_t pop_batch = 0;
   bool trace = false;
   ncclComm_t comm = nullptr;  // created by artis_amd_comm_init(), owned by the engine
 };
@@ -1856,6 +1506,7 @@ Env make_env(const artis_amd_engine *e) {
   env.resident = e->resident_on ? e->d_resident : nullptr;
   env.fill_cells = nullptr;  // (set by a sparse populate_tile() for its own launches)
   env.nfill = 0;
+  env.collexc_terms = e->d_collexc_terms;
   {  // few cells: per-cell estimators accumulate in LDS (physics.h Env::cellest_lds)
     const int nc = e->Mh.npts_nonempty;
     env.cellest_n_t = (e->cellest_in_lds && nc <= THERMAL_CELLEST_CAP) ? nc : 0;
@@ -2087,12 +1738,6 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
       return ARTIS_ERR_UNSUPPORTED;
     }
   }
-  for (int i = 0; i < model->nions; i++) {
-    if (model->ion_nlevels[i] >= MATGT_MAX_LEVEL) {
-      g_last_error = "an ion has more levels than a packed transition target can describe";
-      return ARTIS_ERR_UNSUPPORTED;
-    }
-  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_last_error = "no HIP device: the artis_amd engine has no CPU path";
@@ -2116,10 +1761,6 @@ namespace {
 int engine_fill(artis_amd_engine *e, const artis_model *model) {
   const int device = e->device;
   e->Mh = make_host_model_view(*model, e->own);
-  if ((int64_t)e->Mh.nmacache / MAREC_ALIGN >= MATGT_MAX_RECUNITS) {
-    g_last_error = "a cell's macro-atom row is larger than a packed transition target can address";
-    return ARTIS_ERR_UNSUPPORTED;
-  }
   e->model_copy = *model;
   e->own_matransblock_start.assign(model->level_matransblock_start, model->level_matransblock_start + model->nlevels);
   e->model_copy.level_matransblock_start = e->own_matransblock_start.data();
@@ -2326,27 +1967,25 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_T")) e->wave_chunks_t = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_CUCHUNKS_T")) e->cu_chunks_t = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_CONTLDS")) e->cont_lds = std::atoi(b) != 0;
-  if (const char *b = std::getenv("ARTIS_AMD_HOTLDS")) e->hot_lds = std::atoi(b) != 0;
-  if (const char *b = std::getenv("ARTIS_AMD_HOTBLOCKS")) e->hot_blocks = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TILE_ZIGZAG")) e->tile_zigzag = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_FILL")) e->sparse_fill = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_MAX")) e->sparse_max_listed = std::max(0, std::atoi(b));
-  if (const char *b = std::getenv("ARTIS_AMD_REFILL")) e->thermal_refill = std::atoi(b) != 0;
-  if (const char *b = std::getenv("ARTIS_AMD_REFILL_LOW")) e->refill_low = std::max(1, std::min(64, std::atoi(b)));
-  if (const char *b = std::getenv("ARTIS_AMD_REFILL_MINPK")) e->refill_minpk = std::max(64, std::atoi(b));
-  e->hot_blocks = e->hot_blocks || e->hot_lds;
   {
-    // the static part of every macro-atom record (header, transition targets) is written once; without hot blocks no
-    // level has a place in one
+    // the static part of every macro-atom record (tables.h: filter entries that are never counted) is written once
     const int64_t nrows_ = e->tile_cells;  // every resident row; the static parts do not depend on the cell
-    HIP_TRY(hipMemset(e->K.hotoff, 0xFF, sizeof(int16_t) * (size_t)(nrows_ * e->Mh.nlevels)));
     Env env0 = make_env(e);
-    env0.tile_lo = 0;
-    env0.tile_hi = (int)nrows_;
     env0.K = e->K;
-    hipLaunchKernelGGL(k_hotfill, dim3(nblocks(nrows_ * e->Mh.nlevels)), dim3(BLOCK), 0, nullptr, env0);
+    hipLaunchKernelGGL(k_mainit, dim3(nblocks(nrows_ * e->Mh.nlevels)), dim3(BLOCK), 0, nullptr, env0, nrows_);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
+  }
+  {
+    // the population works through the cells in batches whose cooling terms fit a scratch of ~2 GB (ARTIS_AMD_POP_SCRATCH_MB)
+    double mb = 2048.;
+    if (const char *b = std::getenv("ARTIS_AMD_POP_SCRATCH_MB")) mb = std::max(1., std::atof(b));
+    const int64_t per = std::max<int64_t>(1, (int64_t)e->Mh.nupcum) * (int64_t)sizeof(double);
+    e->pop_batch = std::max<int64_t>(1, std::min<int64_t>(e->tile_cells, (int64_t)(mb * 1048576.) / per));
+    HIP_TRY(hipMalloc((void **)&e->d_collexc_terms, (size_t)(e->pop_batch * per) + 64));
   }
   if (const char *b = std::getenv("ARTIS_AMD_THERMAL_BLOCKS")) e->thermal_blocks_per_cu = std::max(1, std::min(ARTIS_THERMAL_WAVES, std::atoi(b)));
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
@@ -2365,7 +2004,7 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cache_allocs);
   free_packet_buffers(e);
   void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_resident, e->d_fill_cells,
-                  e->d_nfill, e->d_bfrate_kept};
+                  e->d_nfill, e->d_bfrate_kept, e->d_collexc_terms};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3})
@@ -2496,8 +2135,21 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
     env.fill_cells = e->d_fill_cells;
     env.nfill = (int32_t)nfill;
   }
-  const int64_t ncell = nfill >= 0 ? nfill : hi - lo;
-  if (ncell <= 0) return ARTIS_OK;
+  const int64_t ncell_fill = nfill >= 0 ? nfill : hi - lo;
+  if (ncell_fill <= 0) return ARTIS_OK;
+  // in batches of pop_batch cells (the scratch of cooling terms holds that many rows); the kernels of a batch see it as
+  // their whole fill: a sub-range of the tile, or a stretch of the list of a sparse fill
+  const Env env_tile = env;
+  for (int64_t b0 = 0; b0 < ncell_fill; b0 += e->pop_batch) {
+  const int64_t ncell = std::min<int64_t>(e->pop_batch, ncell_fill - b0);
+  env = env_tile;
+  if (nfill >= 0) {
+    env.fill_cells = e->d_fill_cells + b0;
+    env.nfill = (int32_t)ncell;
+  } else {
+    env.tile_lo = lo + (int)b0;
+    env.tile_hi = lo + (int)(b0 + ncell);
+  }
   hipLaunchKernelGGL(k_levelpops, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   if (h.nlines > 0) hipLaunchKernelGGL(k_line_dpop, dim3(nblocks(ncell * h.nlines)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cell_scalars, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
@@ -2507,11 +2159,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
     hipLaunchKernelGGL(k_corrphotoion, dim3(nblocks(ncell * h.nphixstargets_total)), dim3(BLOCK), 0, s, env, e->d_target_level);
   if (h.nalltrans > 0) hipLaunchKernelGGL(k_matrans, dim3(nblocks(ncell * h.nscanblk * 64)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_macroatom, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
-  if (h.nmalines_fix > 0) hipLaunchKernelGGL(k_mafilter, dim3(nblocks(ncell * (int64_t)h.nmalines_fix)), dim3(BLOCK), 0, s, env);
-  if (e->hot_blocks) {  // per-cell hot blocks: which levels are hot depends on the cell state
-    hipLaunchKernelGGL(k_hotselect, dim3(nblocks(ncell * 64)), dim3(BLOCK), 0, s, env);
-    hipLaunchKernelGGL(k_hotfill, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
-  }
+  if (h.nmalongsegs > 0) hipLaunchKernelGGL(k_mafilter_long, dim3(nblocks(ncell * (int64_t)h.nmalongsegs * 64)), dim3(BLOCK), 0, s, env);
 #if ARTIS_EXPOPAC_TABLES
   if (e->expopac_own) {  // needs line_dpop and chi_ff_nnionpart of the tile's cells (k_line_dpop, k_cell_scalars above)
     hipLaunchKernelGGL(k_expopac, dim3(nblocks((int64_t)ncell * ARTIS_EXPOPAC_NBINS)), dim3(BLOCK), 0, s, env);
@@ -2520,8 +2168,11 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
 #endif
   hipLaunchKernelGGL(k_cooling_head, dim3(nblocks((int64_t)ncell * h.nions)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_chain, dim3(nblocks((int64_t)ncell * h.nions * 16)), dim3(BLOCK), 0, s, env);
+  if (h.ncoollines > 0) hipLaunchKernelGGL(k_collexc_filter, dim3(nblocks(ncell * (int64_t)h.ncoollines)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_tail, dim3(nblocks((int64_t)ncell * h.nions)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_prefix, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
+  }  // batches
+  const int64_t ncell = ncell_fill;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
   // UPDATECELL (stats.h:47): one populate per cell
@@ -2926,28 +2577,14 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
                            e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
       } else if (kind == NEXT_MA) {
         // persistent: every workgroup resident (ARTIS_THERMAL_WAVES waves per SIMD)
-#ifndef ARTIS_NO_LDS_VARIANT
-        if (e->hot_lds) {  // hot blocks staged in LDS: one list chunk per workgroup
-          const int per_cu = std::max(1, e->thermal_blocks_per_cu * BLOCK / TBLOCK);
-          const int grid = std::min((int)((nk + TBLOCK - 1) / TBLOCK), e->ncu * per_cu);
-          hipLaunchKernelGGL((k_thermal<true, TBLOCK>), dim3(grid), dim3(TBLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_t,
-                             e->d_cursors, chunks_for(nk, grid), 1, e->budget_t);
-        } else
-#endif
-        if (e->thermal_refill) {  // in-kernel compaction of the macro-atom walkers (k_thermal_q)
-          // a wave keeps its lanes full only while its slots can be refilled: give every wave several fills' worth of packets
-          const int64_t per_block = (int64_t)e->refill_minpk * (BLOCK / 64);
-          const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nk + per_block - 1) / per_block, (int64_t)e->ncu * e->thermal_blocks_per_cu));
-          hipLaunchKernelGGL(k_thermal_q, dim3(grid), dim3(BLOCK), sizeof(double) * (size_t)env.cellest_n_t, s, env, lst, nk, next, e->d_stats,
-                             e->budget_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid * (BLOCK / 64)) : 8, 0, e->refill_low);
-        } else {
+        {
           const int grid = (int)std::min<int64_t>(((int64_t)nk + ARTIS_THERMAL_TB - 1) / ARTIS_THERMAL_TB,
                                                   (int64_t)e->ncu * std::min(e->thermal_blocks_per_cu, ARTIS_THERMAL_WGS));
           const bool per_cu = e->cu_chunks_t && nk >= 256 * 1024;
           // (drain: only where the next thermal launch will be large too, so that what is handed on runs beside a full list)
           const int bud_t = (e->budget_t_small > 0 && nk < e->small_list) ? std::min(e->budget_t_small, e->budget_t) : e->budget_t;
           const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : bud_t;
-          hipLaunchKernelGGL((k_thermal<false, ARTIS_THERMAL_TB>), dim3(grid), dim3(ARTIS_THERMAL_TB), 0, s, env, lst, nk, next, e->d_stats, bud_t,
+          hipLaunchKernelGGL((k_thermal<ARTIS_THERMAL_TB>), dim3(grid), dim3(ARTIS_THERMAL_TB), 0, s, env, lst, nk, next, e->d_stats, bud_t,
                              e->d_cursors, per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (ARTIS_THERMAL_TB / 64)) : 8), per_cu ? 2 : 0, drain);
         }
       } else if (kind == NEXT_BB) {
@@ -3222,9 +2859,30 @@ int artis_amd_debug_cellcache(artis_amd_engine *e, int c, double *levelpops, dou
   if (dst && (per) > 0) HIP_TRY(hipMemcpy(dst, e->K.f + (int64_t)c * (per), sizeof(T) * (size_t)(per), hipMemcpyDeviceToHost));
   DL(levelpops, levelpops, double, h.nlevels)
   if (maprocessrates || matrans) {
-    std::vector<double> row((size_t)h.nmacache + 1);
-    HIP_TRY(hipMemcpy(row.data(), e->K.macache + (int64_t)c * h.nmacache, sizeof(double) * (size_t)h.nmacache, hipMemcpyDeviceToHost));
-    unpack_macache_row(h, e->model_copy, row.data(), maprocessrates, matrans);
+    // the rates from the records; the cumulative sums -- which the records hold as filters only -- re-added on the device from
+    // the transitions' terms, the way an undecided draw gets them. A record whose filters are not those of the sequential
+    // form fails the call.
+    double *d_rates = nullptr, *d_trans = nullptr;
+    int32_t *d_bad = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rates, sizeof(double) * (size_t)(h.nlevels * 9 + 1)));
+    HIP_TRY(hipMalloc((void **)&d_trans, sizeof(double) * (size_t)(h.nmatransblock + 1)));
+    HIP_TRY(hipMalloc((void **)&d_bad, sizeof(int32_t)));
+    HIP_TRY(hipMemset(d_bad, 0, sizeof(int32_t)));
+    const Env env = make_env(e);
+    hipLaunchKernelGGL(k_debug_macache, dim3(nblocks(h.nlevels)), dim3(BLOCK), 0, nullptr, env, c + e->tile_lo, d_rates, d_trans, d_bad);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    int32_t bad = 0;
+    HIP_TRY(hipMemcpy(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost));
+    if (maprocessrates) HIP_TRY(hipMemcpy(maprocessrates, d_rates, sizeof(double) * (size_t)h.nlevels * 9, hipMemcpyDeviceToHost));
+    if (matrans) HIP_TRY(hipMemcpy(matrans, d_trans, sizeof(double) * (size_t)h.nmatransblock, hipMemcpyDeviceToHost));
+    (void)hipFree(d_rates);
+    (void)hipFree(d_trans);
+    (void)hipFree(d_bad);
+    if (bad != 0) {
+      g_last_error = std::to_string(bad) + " filter entries of the cell's macro-atom records differ from the sequential form";
+      return ARTIS_ERR_NOTCONVERGED;
+    }
   }
   DL(allcont_nnlevel, allcont_nnlevel, double, h.nbfcontinua)
   DL(allcont_departure, allcont_departure, double, h.nbfcontinua)

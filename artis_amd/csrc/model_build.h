@@ -18,8 +18,10 @@ struct ModelOwned {
   std::vector<LevelPack> level_pack;
   std::vector<int32_t> level_upcum_start;
   std::vector<int32_t> alltrans_owner;
-  std::vector<int32_t> scanblk_start;
-  std::vector<MaLineRef> malines, malines_fix;
+  std::vector<int32_t> scanchunk_start, scanblk_chunk0;
+  std::vector<MaLongSeg> malongsegs;
+  std::vector<MaTarget> alltrans_target;
+  std::vector<CoolLineRef> coollines;
   std::vector<ContPack> cont_pack;
   std::vector<int32_t> expopac_linestart;
   std::vector<int32_t> upcum_coolslot;
@@ -57,9 +59,11 @@ struct ModelOwned {
   X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
   X(alltrans_owner, int32_t, (m).nalltrans)                                        \
-  X(scanblk_start, int32_t, ((m).nscanblk + 1))                                    \
-  X(malines, MaLineRef, (m).nmalines)                                              \
-  X(malines_fix, MaLineRef, ((m).nmalines_fix > 0 ? (m).nmalines_fix : 1))         \
+  X(scanchunk_start, int32_t, ((m).nscanchunk + 1))                                \
+  X(scanblk_chunk0, int32_t, ((m).nscanblk + 1))                                   \
+  X(malongsegs, MaLongSeg, ((m).nmalongsegs > 0 ? (m).nmalongsegs : 1))            \
+  X(alltrans_target, MaTarget, (m).nalltrans)                                      \
+  X(coollines, CoolLineRef, ((m).ncoollines > 0 ? (m).ncoollines : 1))             \
   X(alltrans_einstein_A, float, (m).nalltrans)                                     \
   X(alltrans_coll_str, float, (m).nalltrans)                                       \
   X(alltrans_osc_strength, float, (m).nalltrans)                                   \
@@ -148,10 +152,7 @@ struct ModelOwned {
 // X(field, element type, elements per cell) for every array of DevCache
 #define ARTIS_CACHE_ARRAYS(X, m)                                \
   X(levelpops, double, (m).nlevels)                             \
-  X(macache, double, (m).nmacache)                              \
-  X(hotblk, double, HOT_DOUBLES)                                \
-  X(hotness, float, (m).nlevels)                                \
-  X(hotoff, int16_t, (m).nlevels)                               \
+  X(macache, U4, (m).nmacache)                                  \
   X(allcont_nnlevel, double, (m).nbfcontinua)                   \
   X(allcont_departure, double, (m).nbfcontinua)                 \
   X(allcont_edgepart, double, (m).nbfcontinua)                  \
@@ -166,7 +167,6 @@ struct ModelOwned {
   X(bf_colion, double, (m).nphixstargets_total)                 \
   X(bf_cooling, double, (m).nphixstargets_total)                \
   X(cooling_contrib, double, (m).ncoolingterms)                 \
-  X(collexc_cum, double, (m).nupcum)                            \
   X(line_dpop, double, (m).nlines)                              \
   X(ion_cooling_contribs, double, (m).nions)                    \
   X(ion_cooling_C, double, (m).nions)                           \
@@ -196,28 +196,28 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.level_ion = own.level_ion.data();
   v.line_pack = own.line_pack.data();
   own.level_pack.resize(m.nlevels);
-  int32_t rec = 0;
+  int32_t rec = 0;  // in 16-byte slots
   for (int i = 0; i < m.nlevels; i++) {
     own.level_pack[i] = LevelPack{rec, m.level_alltrans_startdown[i], m.level_ndowntrans[i], m.level_nuptrans[i]};
-    const int sz = marec_size(m.level_ndowntrans[i], m.level_nuptrans[i]);
+    const int sz = marec_slots(m.level_ndowntrans[i], m.level_nuptrans[i]);
     rec += ((sz + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
   }
   v.nmacache = rec;
   v.level_pack = own.level_pack.data();
-  own.malines.clear();
-  for (int i = 0; i < m.nlevels; i++) {
-    const LevelPack &lp = own.level_pack[i];
-    for (int dir = 0; dir < 2; dir++) {
-      const int n = dir == 0 ? lp.ndown : lp.nup;
-      const int base = dir == 0 ? marec_down : marec_up(lp.ndown);
-      const int rate = marec_rates + (dir == 0 ? ARTIS_MA_ACTION_INTERNALDOWNSAME : ARTIS_MA_ACTION_INTERNALUPSAME);
-      for (int l = 0; l < marec_lines(n); l++)
-        own.malines.push_back(MaLineRef{lp.rec_off + base + (l * MAREC_LINE), lp.rec_off + rate, l * MAREC_PER, n});
+  // what a transition needs to know of the level it leads to (tables.h MaTarget): static, one table for all cells
+  own.alltrans_target.assign((size_t)(m.nalltrans > 0 ? m.nalltrans : 1), MaTarget{0, 0, 0, 0});
+  for (int ui = 0; ui < m.nions; ui++) {
+    const int start = m.ion_uniquelevelindexstart[ui];
+    for (int l = 0; l < m.ion_nlevels[ui]; l++) {
+      const LevelPack &lp = own.level_pack[start + l];
+      for (int t = 0; t < lp.ndown + lp.nup; t++) {
+        const int tl = m.alltrans_targetlevelindex[lp.alltrans_startdown + t];
+        const LevelPack &tp = own.level_pack[start + tl];
+        own.alltrans_target[lp.alltrans_startdown + t] = MaTarget{tp.rec_off, tp.alltrans_startdown, tl, (uint32_t)tp.ndown | ((uint32_t)tp.nup << 16)};
+      }
     }
   }
-  if (own.malines.empty()) own.malines.push_back(MaLineRef{0, 0, 0, 0});
-  v.nmalines = (int32_t)own.malines.size();
-  v.malines = own.malines.data();
+  v.alltrans_target = own.alltrans_target.data();
   own.level_upcum_start.resize(m.nlevels);
   int32_t nupcum = 0;
   for (int i = 0; i < m.nlevels; i++) {
@@ -229,41 +229,55 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   for (int i = 0; i < m.nlevels; i++)
     for (int t = 0; t < m.level_ndowntrans[i] + m.level_nuptrans[i]; t++) own.alltrans_owner[m.level_alltrans_startdown[i] + t] = i;
   v.alltrans_owner = own.alltrans_owner.data();
-  own.scanblk_start.assign(1, 0);
-  for (int i = 0, run = 0; i < m.nlevels; i++) {
-    const int nt = m.level_ndowntrans[i] + m.level_nuptrans[i];
-    if (run > 0 && run + nt > 256) {
-      own.scanblk_start.push_back(m.level_alltrans_startdown[i]);
-      run = 0;
-    }
-    run += nt;
-  }
-  own.scanblk_start.push_back(m.nalltrans);
-  v.nscanblk = (int32_t)own.scanblk_start.size() - 1;
-  v.scanblk_start = own.scanblk_start.data();
-  {  // the directions that k_matrans' scan meets in more than one chunk of 64 transitions of their scan block
-    own.malines_fix.clear();
-    for (int b = 0; b < v.nscanblk; b++) {
-      const int a0 = own.scanblk_start[b], a1 = own.scanblk_start[b + 1];
-      for (int i = a0; i < a1;) {
-        const int ul = own.alltrans_owner[i];
-        const LevelPack &lp = own.level_pack[ul];
-        for (int dir = 0; dir < 2; dir++) {
-          const int n = dir == 0 ? lp.ndown : lp.nup;
-          if (n <= 0) continue;
-          const int sa = lp.alltrans_startdown + (dir == 0 ? 0 : lp.ndown), sb = sa + n;
-          if ((sa - a0) / 64 == (sb - 1 - a0) / 64) continue;
-          const int base = dir == 0 ? marec_down : marec_up(lp.ndown);
-          const int rate = marec_rates + (dir == 0 ? ARTIS_MA_ACTION_INTERNALDOWNSAME : ARTIS_MA_ACTION_INTERNALUPSAME);
-          for (int l = 0; l < marec_lines(n); l++)
-            own.malines_fix.push_back(MaLineRef{lp.rec_off + base + (l * MAREC_LINE), lp.rec_off + rate, l * MAREC_PER, n});
+  {
+    // the scan of k_matrans (tables.h DevModel::scanchunk_start): chunks of whole (level, direction) segments, at most 64 entries;
+    // a segment with more than 64 transitions is cut into chunks of its own; blocks of ~256 entries never split such a segment
+    own.scanchunk_start.assign(1, 0);
+    own.scanblk_chunk0.assign(1, 0);
+    own.malongsegs.clear();
+    int chunk_fill = 0, blk_fill = 0;
+    auto close_chunk = [&](int at) {
+      if (chunk_fill > 0) {
+        own.scanchunk_start.push_back(at);
+        chunk_fill = 0;
+      }
+    };
+    auto close_block = [&]() {
+      if (blk_fill > 0) {
+        own.scanblk_chunk0.push_back((int32_t)own.scanchunk_start.size() - 1);
+        blk_fill = 0;
+      }
+    };
+    for (int i = 0; i < m.nlevels; i++) {
+      const LevelPack &lp = own.level_pack[i];
+      for (int dir = 0; dir < 2; dir++) {
+        const int n = dir == 0 ? lp.ndown : lp.nup;
+        if (n <= 0) continue;
+        const int sa = lp.alltrans_startdown + (dir == 0 ? 0 : lp.ndown);
+        if (n > 64) {
+          close_chunk(sa);
+          close_block();
+          for (int o = 64; o < n; o += 64) own.scanchunk_start.push_back(sa + o);
+          own.scanchunk_start.push_back(sa + n);
+          own.scanblk_chunk0.push_back((int32_t)own.scanchunk_start.size() - 1);
+          own.malongsegs.push_back(MaLongSeg{sa, n, i, dir});
+          continue;
         }
-        i = lp.alltrans_startdown + lp.ndown + lp.nup;
+        if (chunk_fill + n > 64) close_chunk(sa);
+        if (chunk_fill == 0 && blk_fill + n > 256) close_block();
+        chunk_fill += n;
+        blk_fill += n;
       }
     }
-    v.nmalines_fix = (int32_t)own.malines_fix.size();
-    if (own.malines_fix.empty()) own.malines_fix.push_back(MaLineRef{0, 0, 0, 0});
-    v.malines_fix = own.malines_fix.data();
+    close_chunk(m.nalltrans);
+    close_block();
+    v.nscanchunk = (int32_t)own.scanchunk_start.size() - 1;
+    v.nscanblk = (int32_t)own.scanblk_chunk0.size() - 1;
+    v.scanchunk_start = own.scanchunk_start.data();
+    v.scanblk_chunk0 = own.scanblk_chunk0.data();
+    v.nmalongsegs = (int32_t)own.malongsegs.size();
+    if (own.malongsegs.empty()) own.malongsegs.push_back(MaLongSeg{0, 0, 0, 0});
+    v.malongsegs = own.malongsegs.data();
   }
   v.level_upcum_start = own.level_upcum_start.data();
   own.cont_pack.resize(m.nbfcontinua);
@@ -298,6 +312,29 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
       }
     }
   v.upcum_coolslot = own.upcum_coolslot.data();
+  // the lines of every level's collisional-excitation cooling filter (tables.h CoolLineRef): the level's entry of the cooling
+  // list holds the running sum after its last upward transition, the entry before it (the free-free term or the previous level
+  // with upward transitions; none for the first entry of an ion: the sum starts at 0) the sum before its first
+  own.coollines.clear();
+  for (int e = 0; e < m.nelements; e++)
+    for (int ion = 0; ion < m.elem_nions[e]; ion++) {
+      const int ui = m.elem_uniqueionindexstart[e] + ion;
+      int k = ((m.elem_lowest_ionstage[e] + ion - 1) > 0) ? 1 : 0;
+      for (int l = 0; l < m.ion_nlevels[ui]; l++) {
+        const int ul = m.ion_uniquelevelindexstart[ui] + l;
+        const int nup = m.level_nuptrans[ul];
+        if (nup <= 0) continue;
+        const LevelPack &lp = own.level_pack[ul];
+        const int hi = m.ion_coolingoffset[ui] + k, lo = (k > 0) ? hi - 1 : -1;
+        for (int line = 0; line < marec_lines(nup); line++)
+          own.coollines.push_back(CoolLineRef{lp.rec_off + marec_slot(MADIR_COOL, line, lp.ndown, lp.nup), own.level_upcum_start[ul],
+                                              line * MAREC_PER, nup, hi, lo});
+        k++;
+      }
+    }
+  v.ncoollines = (int32_t)own.coollines.size();
+  if (own.coollines.empty()) own.coollines.push_back(CoolLineRef{0, 0, 0, 0, 0, -1});
+  v.coollines = own.coollines.data();
   // recombination lists: for every level of ion i > 0, the levels of ion i-1 with a photoionisation target equal to it
   // (the first such target, like find_phixstargetindex atomic.h:493), lower level rising
   own.level_recomb_start.assign((size_t)m.nlevels + 1, 0);
@@ -420,27 +457,6 @@ inline bool make_vpkt_config(const artis_model &m, VpktConfig &V) {
     V.delta_freq[n] = (float)(edge(ARTIS_VSPEC_NUMIN, dlognu, n + 1) - lower);
   }
   return true;
-}
-
-// Unpack one cell's row of macro-atom records into the reference's two arrays (globals.h:286-287):
-// alllevels_maprocessrates [nlevels*9] and allmacroatomictransitions [nmatransblock] (block order of input.cc:1542:
-// per level: radiative de-excitation sums, internal-down-same sums, internal-up-same sums).
-inline void unpack_macache_row(const DevModel &hostview, const artis_model &m, const double *row, double *maprocessrates,
-                               double *matrans) {
-  for (int ul = 0; ul < m.nlevels; ul++) {
-    const LevelPack lp = hostview.level_pack[ul];
-    const double *rec = row + lp.rec_off;
-    if (maprocessrates)
-      for (int a = 0; a < 9; a++) maprocessrates[(int64_t)ul * 9 + a] = rec[marec_rates + a];
-    if (matrans) {
-      double *blk = matrans + m.level_matransblock_start[ul];
-      for (int i = 0; i < lp.ndown; i++) {
-        blk[i] = rec[marec_rad(lp.ndown, lp.nup) + i];
-        blk[lp.ndown + i] = rec[marec_sum(marec_down, i)];
-      }
-      for (int i = 0; i < lp.nup; i++) blk[2 * lp.ndown + i] = rec[marec_sum(marec_up(lp.ndown), i)];
-    }
-  }
 }
 
 inline DevCells make_host_cells_view(const artis_cellstate &c) {

@@ -164,6 +164,10 @@ struct Env {
   const int32_t *fill_cells;
   const uint32_t *resident;
   int32_t nfill;
+  // scratch of the cell-cache population: [cell of the fill][M.nupcum] the collisional-excitation cooling terms of the levels'
+  // upward transitions (k_matrans), turned into the ions' running sums in place (k_cooling_chain) and into the records' cooling
+  // filters (k_collexc_filter); not kept
+  double *collexc_terms;
   int32_t cont_in_lds;  // M.cont_pack points into LDS (k_rpkt<true>)
   // Per-cell estimators of a model with FEW cells (1D / 2D models, small grids): every packet of the launch adds to one of
   // a few addresses, and device-wide atomics on one address are serialised in memory (measured, 30 shells, 1e7 packets:
@@ -1260,51 +1264,124 @@ AHD MaTransTerms matrans_terms(const Env &env, int c, int ati) {
   }
   return r;
 }
-// sequential form (test emulation): the terms are stored in the blocks the sums go to (the collisional de-excitation
-// term, which has no block, in the target area until populate_hotfill() writes the targets)
-AHD void populate_matrans(const Env &env, int c, int ati) {
-  const DevModel &M = env.M;
-  const MaTransTerms t = matrans_terms(env, c, ati);
-  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + t.lpk.rec_off;
-  if (t.isdown) {
-    rec[marec_rad(t.lpk.ndown, t.lpk.nup) + t.i] = t.v0;
-    rec[marec_tgt(marec_down, t.i)] = t.v1;
-    rec[marec_sum(marec_down, t.i)] = t.v2;
-  } else {
-    rec[marec_sum(marec_up(t.lpk.ndown), t.i)] = t.v0;
-    env.K.collexc_cum[((int64_t)c * M.nupcum) + M.level_upcum_start[t.ul] + t.i] = t.kterm;
+// where things are in a level's record (tables.h): the record of level ul in cell c, its nine process rates
+AHD U4 *ma_rec_of(const Env &env, int c, const LevelPack &lpk) { return env.K.macache + ((int64_t)c * env.M.nmacache) + lpk.rec_off; }
+AHD double *ma_rates_of(U4 *rec, int nd, int nu) { return (double *)(rec + marec_rates_slot(nd, nu)); }
+AHD const double *ma_rates_of(const U4 *rec, int nd, int nu) { return (const double *)(rec + marec_rates_slot(nd, nu)); }
+AHD uint32_t mafilt_quant(double value, double whole, bool *ok);
+// entry i of a filter line (0..6; 7 = the line's "usable" mark)
+AHD void mafilt_put(U4 *line, int i, uint32_t q) { ((uint16_t *)line)[i] = (uint16_t)q; }
+// The term of one transition that a direction's cumulative sums add up (macroatom.cc:64-140):
+// MADIR_DOWN (R + C) e_target, MADIR_RAD R e_trans (both of a downward transition), MADIR_UP (R + C + NT) e_cur
+AHD double matrans_term_of(const MaTransTerms &t, int dir) { return dir == MADIR_DOWN ? t.v2 : t.v0; }
+// The filter entries of one direction of one level from its terms, sequential form: the running sums of the reference's loop as
+// 15-bit fractions of their last value. `whole` = that last value (the direction's rate in the record). The GPU forms the same
+// sums in k_matrans (a wave scan in this order: same bits) and quantises them with the same mafilt_quant().
+// check != nullptr: nothing is written; *check counts the entries and marks of the record that differ from these.
+AHD void populate_dirfilter_seq(const Env &env, int c, const LevelPack &lpk, int dir, double whole, int *check = nullptr) {
+  const bool down = dir != MADIR_UP;
+  const int n = down ? lpk.ndown : lpk.nup;
+  if (n <= 0) return;
+  U4 *rec = ma_rec_of(env, c, lpk);
+  const int ats0 = lpk.alltrans_startdown + (down ? 0 : lpk.ndown);
+  bool whole_ok = (whole > 0.) && (whole <= DBLMAX);
+  double s = 0.;
+  for (int l = 0; l < marec_lines(n); l++) {
+    U4 *line = rec + marec_slot(dir, l, lpk.ndown, lpk.nup);
+    bool ok = whole_ok;
+    uint32_t q[MAREC_PER];
+    const int cnt = (n - (l * MAREC_PER) < MAREC_PER) ? n - (l * MAREC_PER) : MAREC_PER;
+    for (int j = 0; j < cnt; j++) {
+      const int i = (l * MAREC_PER) + j;
+      s += matrans_term_of(matrans_terms(env, c, ats0 + i), dir);
+      q[j] = (ok && i < n - 1) ? mafilt_quant(s, whole, &ok) : MAFILT_NONE;  // (the last sum is the whole: never searched)
+    }
+    // the line's mark: anything but 0x7FFF = decide this line on the f64 sums
+    if (check) {
+      const uint16_t *have = (const uint16_t *)line;
+      for (int j = 0; j < cnt; j++) *check += (have[j] != (uint16_t)(ok ? q[j] : 0u)) ? 1 : 0;
+      for (int j = cnt; j < MAREC_PER; j++) *check += (have[j] != (uint16_t)MAFILT_NONE) ? 1 : 0;
+      *check += (have[7] != (uint16_t)(ok ? MAFILT_NONE : 0u)) ? 1 : 0;
+    } else {
+      for (int j = 0; j < cnt; j++) mafilt_put(line, j, ok ? q[j] : 0u);
+      mafilt_put(line, 7, ok ? MAFILT_NONE : 0u);
+    }
   }
 }
-// sequential form: the running sums of one level over the terms left by populate_matrans(), in the reference's order
-// (macroatom.cc:64-140). The GPU does the same additions in the same order inside k_matrans (a wave scan).
-AHD void populate_macroatom_sums(const Env &env, int c, int ul) {
+// one (cell, level), sequential form (test emulation; k_mafilter_long's reference): the four bound-bound rates of the record
+// (macroatom.cc:64-140), the filters of its three directions, and the level's collisional-excitation cooling terms
+// n C e_trans (kpkt.cc:108-121) into the cell's row of upward-transition terms. The GPU: k_matrans.
+AHD void populate_level_bb(const Env &env, int c, int ul, double *upterms) {
   const DevModel &M = env.M;
   const LevelPack lpk = M.level_pack[ul];
-  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
-  double *rates = rec + marec_rates;
-  double *blk_rad = rec + marec_rad(lpk.ndown, lpk.nup);
-  double s_down_same = 0., s_raddeexc = 0., s_coldeexc = 0.;
+  U4 *rec = ma_rec_of(env, c, lpk);
+  double *rates = ma_rates_of(rec, lpk.ndown, lpk.nup);
+  double s_raddeexc = 0., s_coldeexc = 0., s_down_same = 0., s_up_same = 0.;
   for (int i = 0; i < lpk.ndown; i++) {
-    s_raddeexc += blk_rad[i];
-    s_coldeexc += rec[marec_tgt(marec_down, i)];  // parked there by populate_matrans()
-    s_down_same += rec[marec_sum(marec_down, i)];
-    blk_rad[i] = s_raddeexc;
-    rec[marec_sum(marec_down, i)] = s_down_same;
+    const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + i);
+    s_raddeexc += t.v0;
+    s_coldeexc += t.v1;
+    s_down_same += t.v2;
+  }
+  for (int i = 0; i < lpk.nup; i++) {
+    const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + lpk.ndown + i);
+    s_up_same += t.v0;
+    upterms[M.level_upcum_start[ul] + i] = t.kterm;
   }
   rates[ARTIS_MA_ACTION_RADDEEXC] = s_raddeexc;
   rates[ARTIS_MA_ACTION_COLDEEXC] = s_coldeexc;
   rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = s_down_same;
-  double s_up_same = 0.;
-  const int up = marec_up(lpk.ndown);
-  for (int ii = 0; ii < lpk.nup; ii++) {
-    s_up_same += rec[marec_sum(up, ii)];
-    rec[marec_sum(up, ii)] = s_up_same;
-  }
   rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s_up_same;
+  populate_dirfilter_seq(env, c, lpk, MADIR_DOWN, s_down_same);
+  populate_dirfilter_seq(env, c, lpk, MADIR_RAD, s_raddeexc);
+  populate_dirfilter_seq(env, c, lpk, MADIR_UP, s_up_same);
+}
+// the static part of a level's record, written once per resident row (k_mainit): every filter entry "never counted", every
+// line usable; the population then writes the entries of the transitions and the marks
+AHD void populate_mainit(const Env &env, int64_t row, int ul) {
+  const LevelPack lpk = env.M.level_pack[ul];
+  U4 *rec = env.K.macache + (row * env.M.nmacache) + lpk.rec_off;
+  const int nfilt = marec_rates_slot(lpk.ndown, lpk.nup);
+  const uint32_t none2 = MAFILT_NONE | (MAFILT_NONE << 16);
+  for (int i = 0; i < nfilt; i++) rec[i] = U4{{none2, none2, none2, none2}};
+  const int ntot = ((marec_slots(lpk.ndown, lpk.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
+  for (int i = nfilt; i < ntot; i++) rec[i] = U4{{0u, 0u, 0u, 0u}};
+}
+// Test / debug view of one level's record (artis_amd_debug_cellcache): the nine process rates as the record holds them, and
+// the level's block of allmacroatomictransitions (globals.h:287; block order of input.cc:1542: radiative de-excitation sums,
+// internal-down-same sums, internal-up-same sums) RE-ADDED from the transitions' terms -- the values a draw gets that the
+// filters cannot decide (ma_exact_search). Returns the number of filter entries and marks of the record that differ from the
+// sequential form's (populate_dirfilter_seq): 0 unless the population's scans and the sequential loop disagree.
+AHD int debug_level_record(const Env &env, int c, int ul, double *maprocessrates, double *matrans) {
+  const DevModel &M = env.M;
+  const LevelPack lpk = M.level_pack[ul];
+  const double *rates = ma_rates_of(ma_rec_of(env, c, lpk), lpk.ndown, lpk.nup);
+  if (maprocessrates)
+    for (int a = 0; a < MA_N; a++) maprocessrates[((int64_t)ul * MA_N) + a] = rates[a];
+  if (matrans) {
+    double *blk = matrans + M.level_matransblock_start[ul];
+    double s_rad = 0., s_down = 0., s_up = 0.;
+    for (int i = 0; i < lpk.ndown; i++) {
+      const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + i);
+      s_rad += t.v0;
+      s_down += t.v2;
+      blk[i] = s_rad;
+      blk[lpk.ndown + i] = s_down;
+    }
+    for (int i = 0; i < lpk.nup; i++) {
+      s_up += matrans_terms(env, c, lpk.alltrans_startdown + lpk.ndown + i).v0;
+      blk[(2 * lpk.ndown) + i] = s_up;
+    }
+  }
+  int bad = 0;
+  populate_dirfilter_seq(env, c, lpk, MADIR_DOWN, rates[ARTIS_MA_ACTION_INTERNALDOWNSAME], &bad);
+  populate_dirfilter_seq(env, c, lpk, MADIR_RAD, rates[ARTIS_MA_ACTION_RADDEEXC], &bad);
+  populate_dirfilter_seq(env, c, lpk, MADIR_UP, rates[ARTIS_MA_ACTION_INTERNALUPSAME], &bad);
+  return bad;
 }
 AHD void populate_mafilter_level(const Env &env, int c, int ul);  // (below, with the filters)
 // one (cell, level): the bound-free channels of calculate_macroatom_transitionrates macroatom.cc:141-190 (the four
-// bound-bound rates are already in the record: populate_macroatom_sums() / k_matrans), and the level's hotness
+// bound-bound rates are already in the record: populate_level_bb() / k_matrans), then the record's action filter
 AHD void populate_macroatom(const Env &env, int c, int ul) {
   const DevModel &M = env.M;
   const int ui = M.level_ion[ul];
@@ -1314,9 +1391,7 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   const int level = ul - start;
   const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
   const LevelPack lpk = M.level_pack[ul];
-  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
-  double *rates = rec + marec_rates;
-  // (the record's header and transition targets are written by populate_hotfill(), once the cell's hot levels are known)
+  double *rates = ma_rates_of(ma_rec_of(env, c, lpk), lpk.ndown, lpk.nup);
   const double t_mid = env.S.mid;
   const float T_e = env.C.Te[c];
   const float cnne = clumpednne(env.C, c);
@@ -1366,95 +1441,7 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
 #endif
   rates[ARTIS_MA_ACTION_INTERNALUPHIGHERNT] = s_up_highernt;
   rates[ARTIS_MA_ACTION_INTERNALUPHIGHER] = s_up_higher;
-  // flow through the level ~ population x total rate: the hotness that ranks the levels of a cell for its hot block
-  // (tables.h). A heuristic: it decides only where the thermal kernel reads a record from.
-  double total = 0.;
-  for (int a = 0; a < MA_N; a++) total += rates[a];
-  const float h = (float)(nnlevel * total);
-  env.K.hotness[((int64_t)c * M.nlevels) + ul] = (h > 0.f && h <= 3.0e38f) ? h : 0.f;
   populate_mafilter_level(env, c, ul);  // every rate of the record is final now: the action filter of its line 0
-}
-// ---- hot block of a cell (tables.h): which levels, where, and the copies
-AHD MaTarget matgt_pack(const LevelPack &target, int level) {
-  return MaTarget{(uint64_t)(target.rec_off / MAREC_ALIGN) | ((uint64_t)level << 20) | ((uint64_t)target.ndown << 36) |
-                  ((uint64_t)target.nup << 50)};
-}
-AHD int marec_units(const LevelPack &lp) { return (marec_size(lp.ndown, lp.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN; }
-constexpr int HOT_UNITS = HOT_DOUBLES / MAREC_ALIGN;
-AHD uint32_t hot_key(float h) {  // positive floats order like their bit patterns
-  union { float f; uint32_t u; } v;
-  v.f = h;
-  return (h > 0.f) ? v.u : 0u;
-}
-// units taken by the levels [l0, l1) of cell c whose key is >= t
-AHD int hot_units_at(const Env &env, int c, int l0, int l1, uint32_t t) {
-  const float *hn = env.K.hotness + ((int64_t)c * env.M.nlevels);
-  int u = 0;
-  for (int l = l0; l < l1; l++)
-    if (hot_key(hn[l]) >= t) u += marec_units(env.M.level_pack[l]);
-  return u;
-}
-// Selection rule: the hot levels of a cell are those with key >= T, T the smallest threshold whose levels fit in
-// HOT_UNITS (bisection on the 32-bit key). The sequential form; the GPU kernel (artis_engine.hip k_hotselect) runs the
-// same rule with the levels spread over the lanes of a wave.
-AHD void populate_hotselect(const Env &env, int c) {
-  const DevModel &M = env.M;
-  uint32_t lo = 1u, hi = 0xFFFFFFFFu;  // invariant: units(hi) fit; units(lo - 1) do not, or lo == 1
-  if (hot_units_at(env, c, 0, M.nlevels, lo) <= HOT_UNITS) {
-    hi = lo;
-  } else {
-    while (hi - lo > 1u) {
-      const uint32_t mid = lo + ((hi - lo) >> 1);
-      if (hot_units_at(env, c, 0, M.nlevels, mid) <= HOT_UNITS) hi = mid; else lo = mid;
-    }
-  }
-  const float *hn = env.K.hotness + ((int64_t)c * M.nlevels);
-  int16_t *off = env.K.hotoff + ((int64_t)c * M.nlevels);
-  int u = 0;
-  for (int l = 0; l < M.nlevels; l++) {
-    if (hot_key(hn[l]) >= hi) {
-      off[l] = (int16_t)u;
-      u += marec_units(M.level_pack[l]);
-    } else {
-      off[l] = -1;
-    }
-  }
-}
-// one (cell, level): the static part of the level's record -- header and transition targets, each with the place of
-// the level it leads to in the cell's hot block -- and, for a hot level, the copy of the whole record
-AHD void populate_hotfill(const Env &env, int c, int ul) {
-  const DevModel &M = env.M;
-  const LevelPack lpk = M.level_pack[ul];
-  const int start = M.ion_uniquelevelindexstart[M.level_ion[ul]];
-  const int16_t *off = env.K.hotoff + ((int64_t)c * M.nlevels);
-  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + lpk.rec_off;
-  *(MaHeader *)rec = MaHeader{(int16_t)lpk.ndown, (int16_t)lpk.nup, ul, lpk.alltrans_startdown, off[ul], 0};
-  MaTarget *tgt = (MaTarget *)rec;
-  const int ntrans = lpk.ndown + lpk.nup;
-  tgt[marec_tgt0] = tgt[marec_tgt0 + 1] = MaTarget{0};
-  for (int i = 0; i < ntrans; i++) {
-    const int tl = M.alltrans_targetlevelindex[lpk.alltrans_startdown + i];
-    const MaTarget tg = matgt_pack(M.level_pack[start + tl], tl);
-    const bool down = i < lpk.ndown;
-    const int j = down ? i : i - lpk.ndown;
-    tgt[marec_tgt(down ? marec_down : marec_up(lpk.ndown), j)] = tg;
-    if (j == 0) tgt[marec_tgt0 + (down ? 0 : 1)] = tg;
-  }
-  // the sum slots after each direction's last entry: +inf, so that ma_search_lines() needs no bounds checks
-  for (int j = lpk.ndown; j < marec_lines(lpk.ndown) * MAREC_PER; j++) rec[marec_sum(marec_down, j)] = __builtin_inf();
-  for (int j = lpk.nup; j < marec_lines(lpk.nup) * MAREC_PER; j++) rec[marec_sum(marec_up(lpk.ndown), j)] = __builtin_inf();
-  // ... and the filter entries of those slots: never counted (k_matrans writes the entries of the transitions only)
-  for (int dir = 0; dir < 2; dir++) {
-    const int n = dir == 0 ? lpk.ndown : lpk.nup;
-    const int base = dir == 0 ? marec_down : marec_up(lpk.ndown);
-    for (int j = n; j < marec_lines(n) * MAREC_PER; j++)
-      ((uint16_t *)(rec + base + ((j / MAREC_PER) * MAREC_LINE)))[j % MAREC_PER] = (uint16_t)MAFILT_NONE;
-  }
-  if (off[ul] >= 0) {
-    double *dst = env.K.hotblk + ((int64_t)c * HOT_DOUBLES) + ((int)off[ul] * MAREC_ALIGN);
-    const int n = marec_units(lpk) * MAREC_ALIGN;
-    for (int i = 0; i < n; i++) dst[i] = rec[i];
-  }
 }
 // one (cell, ion): calculate_cooling_rates_ion<true> kpkt.cc:57 in three parts, so that the GPU can form the long middle
 // part -- the running sum over the ion's collisional-excitation terms -- with rows of 16 lanes (k_cooling_chain) while the
@@ -1479,11 +1466,13 @@ AHD double cooling_ion_head(const Env &env, int c, int ui, int *k_out) {
   *k_out = k;
   return C_ion;
 }
-// middle, sequential form: the running sum after every upward transition is kept: do_kpkt() (kpkt.cc:461-476) re-adds
-// exactly these terms, in this order and from the same starting value, to pick the transition, and reads the sums here
-// instead (the terms nnlevel * C * e_trans were left there by populate_matrans()); one list entry per level that has
-// upward transitions (kpkt.cc:108-121)
-AHD double cooling_ion_collexc_chain(const Env &env, int c, int ui, double C_ion, int *k_inout) {
+// middle, sequential form: the running sum over the collisional-excitation terms of the ion's levels (the terms
+// nnlevel * C * e_trans were left in `upterms`, the cell's row of upward-transition terms, by populate_level_bb() / k_matrans),
+// turned into running sums in place; one list entry per level that has upward transitions (kpkt.cc:108-121). do_kpkt()
+// (kpkt.cc:461-476) re-adds exactly these terms, in this order and from the same starting value, to pick the transition: the
+// running sums themselves are not kept (round 4) -- populate_coolfilter_line() turns them into the level's 15-bit filter and a
+// draw the filter cannot decide re-adds the terms (kpkt_collexc_exact)
+AHD double cooling_ion_collexc_chain(const Env &env, int c, int ui, double C_ion, int *k_inout, double *upterms) {
   const DevModel &M = env.M;
   double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + M.ion_coolingoffset[ui];
   int k = *k_inout;
@@ -1492,7 +1481,7 @@ AHD double cooling_ion_collexc_chain(const Env &env, int c, int ui, double C_ion
   for (int level = 0; level < nlevels; level++) {
     const int ul = start + level;
     const int nup = M.level_nuptrans[ul];
-    double *upcum = env.K.collexc_cum + ((int64_t)c * M.nupcum) + M.level_upcum_start[ul];
+    double *upcum = upterms + M.level_upcum_start[ul];
     for (int i = 0; i < nup; i++) {
       C_ion += upcum[i];
       upcum[i] = C_ion;
@@ -1501,6 +1490,29 @@ AHD double cooling_ion_collexc_chain(const Env &env, int c, int ui, double C_ion
   }
   *k_inout = k;
   return C_ion;
+}
+// One line of a level's cooling filter (M.coollines[li]) from the running sums in `upcum` (the cell's row, after the chain):
+// entry j = the running sum after the level's transition j as a 15-bit fraction of the level's span [lo, hi] of the ion's
+// cooling list, F = (sum - lo) / (hi - lo). do_kpkt() compares the sums with rnd_process, lo <= rnd_process < hi: "sum <= rnd"
+// is "F <= y", y = (rnd - lo) / (hi - lo) formed the same way, each quotient within 3e-16 of its exact value (the
+// differences of doubles are exact to one rounding of the RESULT). The last sum is hi itself: never counted.
+AHD void populate_coolfilter_line(const Env &env, int c, int li, const double *upcum) {
+  const DevModel &M = env.M;
+  const CoolLineRef lr = M.coollines[li];
+  if (lr.n <= 0) return;
+  const double *cool = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
+  const double hi = cool[lr.cool_hi], lo = (lr.cool_lo >= 0) ? cool[lr.cool_lo] : 0.;
+  const double span = hi - lo;
+  bool ok = (span > 0.) && (span <= DBLMAX);
+  uint32_t q[8];
+  for (int j = 0; j < 8; j++) q[j] = MAFILT_NONE;
+  for (int j = 0; j < MAREC_PER; j++)
+    if (lr.first + j < lr.n - 1 && ok) q[j] = mafilt_quant(upcum[lr.up0 + lr.first + j] - lo, span, &ok);
+  if (!ok)
+    for (int j = 0; j < 8; j++) q[j] = 0u;
+  U4 f;
+  for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
+  env.K.macache[((int64_t)c * M.nmacache) + lr.slot] = f;
 }
 // tail: collisional ionisation and bound-free cooling (kpkt.cc:123-190), then the ion total for the prefix sum of kpkt.cc:281
 AHD void cooling_ion_tail(const Env &env, int c, int ui, double C_ion, int k) {
@@ -1566,10 +1578,10 @@ AHD void cooling_ion_tail(const Env &env, int c, int ui, double C_ion, int k) {
   if (k != M.ion_ncoolingterms[ui]) fail(env, 20);
   env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] = C_ion;
 }
-AHD void populate_cooling_ion(const Env &env, int c, int ui) {
+AHD void populate_cooling_ion(const Env &env, int c, int ui, double *upterms) {
   int k = 0;
   double C_ion = cooling_ion_head(env, c, ui, &k);
-  C_ion = cooling_ion_collexc_chain(env, c, ui, C_ion, &k);
+  C_ion = cooling_ion_collexc_chain(env, c, ui, C_ion, &k, upterms);
   cooling_ion_tail(env, c, ui, C_ion, k);
 }
 // one cell: cumulative cooling over ions, kpkt.cc:288-294
@@ -2763,12 +2775,11 @@ AHD void ma_finish(const Env &env, Pkt &p, int64_t pi) {
 struct MACtx {
   int c;                    // non-empty model cell
   bool thick;               // the cell is optically thick (grey): its k-packets go to do_kpkt_blackbody()
-  const double *cellma;     // the cell's row of macro-atom records
+  const U4 *cellma;         // the cell's row of macro-atom records
   int start_key, start;     // cached get_ionuniquelevelindexstart(element, ion)
-  int rec;                  // offset of the current level's record in the cell's row (ma_prepare, then carried by the walk)
-  int nd, nu;               // ... and its numbers of downward / upward transitions (where the record's blocks begin)
-  int hot;                  // ... and its place in the cell's hot block (units of MAREC_ALIGN doubles), or -1
-  const double *hotbase;    // where the cell's hot block is read from: its LDS copy (k_thermal) or the block in HBM
+  int rec;                  // slot of the current level's record in the cell's row (ma_prepare, then carried by the walk)
+  int nd, nu;               // ... its numbers of downward / upward transitions (where the record's lines are)
+  int ats;                  // ... and its first entry in alltrans (where its transitions' targets are)
   int njumps;               // transitions made since the last ma_flush_stats()
 };
 AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
@@ -2776,51 +2787,15 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   k.c = env.M.propcell_nonemptymgi[p.cellindex];
   k.thick = (k.c >= 0) && (env.C.thick[k.c] == ARTIS_CELL_THICK);
   k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
-  k.hotbase = env.K.hotblk + ((int64_t)k.c * HOT_DOUBLES);  // in HBM; k_thermal points it at its LDS copy
   k.start_key = -1;
   k.start = 0;
   k.rec = 0;
   k.nd = k.nu = 0;
-  k.hot = -1;
+  k.ats = 0;
   k.njumps = 0;
   return k;
 }
 
-// upper_bound over the cumulative sums of one block of a macro-atom record (non-decreasing): index of the first
-// element > v, at most n. Eight independent reads per round, issued without bounds checks as four 16-byte loads (a
-// block is 16-byte aligned and reading past its end stays inside the row, tables.h); entries at or beyond n are never
-// counted. Measured alternatives, all slower on MI355X: bisection (dependent reads), reads clamped to the last element.
-AHD int ma_search(const double *a, int n, double v) {
-  int idx = 0;
-  for (int base = 0; base < n; base += 8, a += 8) {
-    const D2 q0 = *(const D2 *)(a), q1 = *(const D2 *)(a + 2), q2 = *(const D2 *)(a + 4), q3 = *(const D2 *)(a + 6);
-    const double x[8] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x, q3.y};
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) cnt += ((base + k < n) && (x[k] <= v)) ? 1 : 0;
-    idx += cnt;
-    if (cnt < 8) break;
-  }
-  return idx;
-}
-
-// The same over the first n sums of a direction's lines (tables.h). The slots after a direction's last sum hold +inf
-// (populate_hotfill), so no entry needs a bounds check; the direction's last sum itself (entry n, never searched by the
-// reference: it is the whole rate, >= v) can only be counted when v rounds up to it, hence the final clamp.
-AHD int ma_search_lines(const double *a, int n, double v) {
-  int idx = 0;
-  for (int base = 0; base < n; base += MAREC_PER, a += MAREC_LINE) {
-    // the line's 7 sums are its doubles [2..9); the fourth 16-byte read also brings the first target, which is not counted
-    const D2 q0 = *(const D2 *)(a + 2), q1 = *(const D2 *)(a + 4), q2 = *(const D2 *)(a + 6), q3 = *(const D2 *)(a + 8);
-    const double x[MAREC_PER] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, q3.x};
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < MAREC_PER; k++) cnt += (x[k] <= v) ? 1 : 0;
-    idx += cnt;
-    if (cnt < MAREC_PER) break;
-  }
-  return idx < n ? idx : n;
-}
 // The uint16 filters of a record (tables.h "FILTERS"). q = floor(value / whole * 32768), clamped to 32767.
 AHD uint32_t mafilt_quant(double value, double whole, bool *ok) {
   const double f = (value / whole) * MAFILT_SCALE;
@@ -2830,16 +2805,10 @@ AHD uint32_t mafilt_quant(double value, double whole, bool *ok) {
   }
   return (f >= MAFILT_SCALE - 1.) ? MAFILT_NONE : (uint32_t)f;
 }
-// how many of the filter's 8 entries are certainly <= z. z = u * 2^-24 (a 24-bit draw), zi = u >> 9 = floor(z * 32768), so
-// zi <= z * 32768 <= zi + 1 - 2^-9. With q <= fraction * 32768 <= q + 1: zi >= q + 2 proves fraction < z by at least 3e-5,
-// and zi <= q - 1 proves fraction > z by at least 2^-9 / 32768 = 6e-8 -- both far beyond the 1e-16 by which the f64
-// comparison "value <= z * whole" can differ from the exact one. *amb: some entry has q == zi or q == zi - 1. Two counts
-// instead of two tests per entry: the entries with q <= zi - 2 are counted, and the filter is ambiguous iff more entries
-// have q <= zi. An entry that is not to be counted at all holds 0x7FFF (it can only turn a draw with zi = 32767 ambiguous).
-// Two entries per 32-bit word and subtraction: with h = bound + 32768 in both halves, (h - q) has bit 15 set in a half iff
-// q <= bound there, and no half borrows from the other (q <= 32767 <= h).
-AHD int mafilt_count(const U4 &f, int zi, bool *amb) {
-  const int lo = (zi - 2 > -1) ? zi - 2 : -1, hi = zi;
+// how many of the filter's 8 entries have q <= lo, and whether more have q <= hi (*amb): lo >= -1, hi <= 32767. Two entries
+// per 32-bit word and subtraction: with h = bound + 32768 in both halves, (h - q) has bit 15 set in a half iff q <= bound
+// there, and no half borrows from the other (q <= 32767 <= h).
+AHD int mafilt_count_between(const U4 &f, int lo, int hi, bool *amb) {
   const uint32_t hl = (uint32_t)(lo + 32768) * 0x10001u, hh = (uint32_t)(hi + 32768) * 0x10001u;
   int c1 = 0, c2 = 0;
 #pragma unroll
@@ -2850,11 +2819,19 @@ AHD int mafilt_count(const U4 &f, int zi, bool *amb) {
   *amb = (c1 != c2);
   return c1;
 }
-// After every rate and sum of a cell's records is final (populate_macroatom): the action filter of one level's line 0 ...
+// how many of the filter's 8 entries are certainly <= z. z = u * 2^-24 (a 24-bit draw), zi = u >> 9 = floor(z * 32768), so
+// zi <= z * 32768 <= zi + 1 - 2^-9. With q <= fraction * 32768 <= q + 1: zi >= q + 2 proves fraction < z by at least 3e-5,
+// and zi <= q - 1 proves fraction > z by at least 2^-9 / 32768 = 6e-8 -- both far beyond the 1e-16 by which the f64
+// comparison "value <= z * whole" can differ from the exact one. *amb: some entry has q == zi or q == zi - 1. Two counts
+// instead of two tests per entry: the entries with q <= zi - 2 are counted, and the filter is ambiguous iff more entries
+// have q <= zi. An entry that is not to be counted at all holds 0x7FFF (it can only turn a draw with zi = 32767 ambiguous).
+AHD int mafilt_count(const U4 &f, int zi, bool *amb) { return mafilt_count_between(f, (zi - 2 > -1) ? zi - 2 : -1, zi, amb); }
+// After every rate of a cell's records is final (populate_macroatom): the action filter of one level's record
 AHD void populate_mafilter_level(const Env &env, int c, int ul) {
   const DevModel &M = env.M;
-  double *rec = env.K.macache + ((int64_t)c * M.nmacache) + M.level_pack[ul].rec_off;
-  const double *rates = rec + marec_rates;
+  const LevelPack lpk = M.level_pack[ul];
+  U4 *rec = ma_rec_of(env, c, lpk);
+  const double *rates = ma_rates_of(rec, lpk.ndown, lpk.nup);
   // cumulative rates of the actions 0..7 over the total of all 9, summed as ma_load_rates() sums them
   double cum[MA_N];
   cum[0] = rates[0];
@@ -2871,27 +2848,7 @@ AHD void populate_mafilter_level(const Env &env, int c, int ul) {
   }
   U4 f;
   for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
-  *(U4 *)(rec + marec_filt0) = f;
-}
-// ... and the filter of one line of sums (M.malines[li])
-AHD void populate_mafilter_line(const Env &env, int c, int li) {
-  const DevModel &M = env.M;
-  const MaLineRef lr = M.malines[li];
-  if (lr.n <= 0) return;
-  double *row = env.K.macache + ((int64_t)c * M.nmacache);
-  double *line = row + lr.line_off;
-  const double whole = row[lr.rate_off];
-  bool ok = (whole > 0.) && (whole <= DBLMAX);
-  uint32_t q[8];
-  for (int j = 0; j < 8; j++) q[j] = MAFILT_NONE;  // not searched (the direction's last sum, slots past it, the 8th entry)
-  for (int j = 0; j < MAREC_PER; j++)
-    if (lr.first + j < lr.n - 1 && ok) q[j] = mafilt_quant(line[2 + j], whole, &ok);
-  if (!ok) {  // marker: the 8th entry is not 0x7FFF: this line is searched on its f64 sums
-    for (int j = 0; j < 8; j++) q[j] = 0u;
-  }
-  U4 f;
-  for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
-  *(U4 *)line = f;
+  rec[0] = f;
 }
 
 // one iteration of the loop of do_macroatom(), macroatom.cc:385-577. ma_prepare() finds the record of the packet's
@@ -2905,42 +2862,68 @@ AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
   }
   return k.start + p.ma_level;
 }
-// HOT = false: the caller never uses hot blocks (the thermal kernel without LDS staging): nothing about them is read
-template <bool HOT = true>
 AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) {
   const int ul = ma_locate(env, p, k);
   const LevelPack lp = env.M.level_pack[ul];
   k.rec = lp.rec_off;
   k.nd = lp.ndown;
   k.nu = lp.nup;
-  k.hot = HOT ? (int)env.K.hotoff[((int64_t)k.c * env.M.nlevels) + ul] : -1;
+  k.ats = lp.alltrans_startdown;
 }
-// the current level's record: its copy in the hot block when there is one and the block is readable, else the cell's row
-template <bool HOT = true>
-AHD const double *ma_record(const MACtx &k) {
-  if (!HOT) return k.cellma + k.rec;
-  return (k.hot >= 0 && k.hotbase != nullptr) ? k.hotbase + (k.hot * MAREC_ALIGN) : k.cellma + k.rec;
-}
+AHD const U4 *ma_record(const MACtx &k) { return k.cellma + k.rec; }
 // First half of a transition: draw the process (macroatom.cc:425-431); an internal transition inside the ion is made
 // at once and -1 is returned. Every other process ends the walk in this kernel (deactivation, or a bound-free process
-// for the slow path): its index is returned with its rate, and ma_jump_exit() carries it out. The split lets a kernel
-// keep the rare, long deactivation code out of its transition loop.
+// for the slow path): its index is returned, and ma_jump_exit() carries it out. The split lets a kernel keep the rare,
+// long deactivation code out of its transition loop.
 constexpr int MA_EXIT_FAILED = 99;
 // the 9 process rates of a record and their running sums (std::partial_sum macroatom.cc:425), kept in registers
-AHD void ma_load_rates(const double *rec, double *r, double *cum) {
-  const D2 q0 = *(const D2 *)(rec + 2), q1 = *(const D2 *)(rec + 4), q2 = *(const D2 *)(rec + 6), q3 = *(const D2 *)(rec + 8);
+AHD void ma_load_rates(const double *rates, double *r, double *cum) {
+  const D2 q0 = *(const D2 *)(rates), q1 = *(const D2 *)(rates + 2), q2 = *(const D2 *)(rates + 4), q3 = *(const D2 *)(rates + 6);
   r[0] = q0.x; r[1] = q0.y; r[2] = q1.x; r[3] = q1.y; r[4] = q2.x; r[5] = q2.y; r[6] = q3.x; r[7] = q3.y;
   // MA_ACTION_INTERNALUPHIGHERNT: only NT_ON puts anything there (macroatom.cc:171); adding the 0 leaves cum[8] = cum[7]
-  r[8] = ARTIS_OPT_NT_ON ? rec[10] : 0.;
+  r[8] = ARTIS_OPT_NT_ON ? rates[8] : 0.;
   cum[0] = r[0];
 #pragma unroll
   for (int i = 1; i < MA_N; i++) cum[i] = cum[i - 1] + r[i];
 }
-// RATE = false: the caller reads the rate of the process that ended the walk itself (rec[marec_rates + action]), once its
-// loop is over -- in k_thermal's transition loop the read would otherwise be issued in every round in which any lane of
-// the wave ends its walk (~0.7 load instructions per round of a kernel that is bound by their number)
-template <bool HOT = true, bool RATE = true>
-AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, double *rate_out) {
+// A search the filter could not decide: how many of the direction's first nsearch cumulative sums are <= targetval, the sums
+// RE-ADDED from the transitions' terms in the reference's order (macroatom.cc:64-140; the same matrans_terms() the
+// population ran, added in the same order: the values the round-3 records held, bit for bit). Sums are non-decreasing, so
+// the count is the index of the first sum above targetval. Out of line: rare (5e-4 per decision) and register-hungry.
+AHD int ma_exact_search(const Env &env, int c, int ats0, int dir, int nsearch, double targetval) {
+  double s = 0.;
+  int j = 0;
+  for (; j < nsearch; j++) {
+    s += matrans_term_of(matrans_terms(env, c, ats0 + j), dir);
+    if (!(s <= targetval)) break;
+  }
+  return j;
+}
+// the search of one direction of the record `rec` (level with nd / nu transitions, first entry of alltrans `ats`) with the
+// 24-bit draw u: number of the direction's cumulative sums (the last one left out) <= (u * 2^-24) * (the direction's rate)
+AHD int ma_search_dir(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u) {
+  const bool down = dir != MADIR_UP;
+  const int nsearch = (down ? k.nd : k.nu) - 1;
+  if (nsearch <= 0) return 0;
+  const int zi = (int)(u >> 9);
+  bool amb = env.ma_filters_off != 0;
+  int ti = 0;
+  for (int b0 = 0; b0 < nsearch && !amb; b0 += MAREC_PER) {
+    const U4 f = rec[marec_slot(dir, b0 / MAREC_PER, k.nd, k.nu)];
+    const int cnt = mafilt_count(f, zi, &amb);
+    amb = amb || (f.w[3] >> 16) != MAFILT_NONE;
+    if (amb) break;
+    ti += cnt;
+    if (cnt < MAREC_PER) break;
+  }
+  if (amb) {
+    const int action = dir == MADIR_DOWN ? ARTIS_MA_ACTION_INTERNALDOWNSAME : (dir == MADIR_UP ? ARTIS_MA_ACTION_INTERNALUPSAME : ARTIS_MA_ACTION_RADDEEXC);
+    const double targetval = rng_u24_value(u) * ma_rates_of(rec, k.nd, k.nu)[action];
+    ti = ma_exact_search(env, k.c, k.ats + (down ? 0 : k.nd), dir, nsearch, targetval);
+  }
+  return ti;
+}
+AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
   // index_upperbound (sn3d.h:85) over the 9 cumulative rates: action = number of cumulative values <= zrand * total,
   // clamped to the last one. Decided on the record's 16-byte filter (tables.h "FILTERS") unless the random number lies
   // within the filter's resolution of one of its entries; then on the f64 rates, with the same random number.
@@ -2948,24 +2931,15 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
   MA_PROF_MARK(env, 63);  // (clocks between the marks themselves: the cost of one mark)
   int action;
   {
-    const U4 f = *(const U4 *)(rec + marec_filt0);
+    const U4 f = rec[0];
     MA_PROF_WAIT();
     MA_PROF_MARK(env, 59);
-#if defined(ARTIS_MA_EXTRA_LOADS) && defined(__HIP_DEVICE_COMPILE__)
-    // (measurement only: ARTIS_MA_EXTRA_LOADS more 8-byte reads of the same line, results kept alive and unused -- what
-    // does one more load INSTRUCTION per transition cost when it brings no new line?)
-#pragma unroll
-    for (int xl = 0; xl < ARTIS_MA_EXTRA_LOADS; xl++) {
-      const double qx = *(const volatile double *)(rec + 2 + xl);
-      asm volatile("" ::"v"(qx));
-    }
-#endif
     double r[MA_N], cum[MA_N];
-    // first entry above the last: the record has no usable filter (populate_mafilters: its total is not a positive finite
+    // first entry above the last: the record has no usable filter (populate_mafilter_level: its total is not a positive finite
     // number); the reference's assertion on the total comes before the random number is drawn
     const bool usable = !((f.w[0] & 0xFFFFu) > (f.w[3] >> 16));
     if (!usable) {
-      ma_load_rates(rec, r, cum);
+      ma_load_rates(ma_rates_of(rec, k.nd, k.nu), r, cum);
       if (!(cum[MA_N - 1] > 0.)) {
         fail(env, 40);
         p.ma_level = -1;
@@ -2980,7 +2954,7 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
     // ("cum[8] = total <= zrand * total" never holds: zrand <= 1 - 2^-24, and the product of that with total is below total)
     amb = amb || !usable || env.ma_filters_off != 0;
     if (amb) {
-      if (usable) ma_load_rates(rec, r, cum);
+      if (usable) ma_load_rates(ma_rates_of(rec, k.nd, k.nu), r, cum);
       const double randomrate = rng_u24_value(u1) * cum[MA_N - 1];
       action = 0;
 #pragma unroll
@@ -2993,61 +2967,36 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const double *rec, do
   if (down || action == ARTIS_MA_ACTION_INTERNALUPSAME) {
     // macroatom.cc:433-447 and 536-550: one search for both directions, so that a wave runs it once. The target is the
     // number of the direction's cumulative sums <= zrand * (the direction's rate), the last sum (= the rate) left out.
-    const int ndown = k.nd;
-    const int nsel = down ? ndown : k.nu;
-    const int nsearch = nsel - 1;
-    const int base = down ? marec_down : marec_up(ndown);      // the direction's lines (filter, sums, targets)
     const uint32_t u2 = rng_u24(p);
     MA_PROF_MARK(env, 60);
-    int ti = 0;
-    if (nsearch > 0) {
-      const int zi = (int)(u2 >> 9);
-      bool amb = env.ma_filters_off != 0;
-      for (int b0 = 0; b0 < nsearch && !amb; b0 += MAREC_PER) {
-        const U4 f = *(const U4 *)(rec + base + ((b0 / MAREC_PER) * MAREC_LINE));
-        const int cnt = mafilt_count(f, zi, &amb);
-        amb = amb || (f.w[3] >> 16) != MAFILT_NONE;
-        if (amb) break;
-        ti += cnt;
-        if (cnt < MAREC_PER) break;
-      }
-      if (amb) {
-        const double targetval = rng_u24_value(u2) * rec[marec_rates + (down ? ARTIS_MA_ACTION_INTERNALDOWNSAME : ARTIS_MA_ACTION_INTERNALUPSAME)];
-        ti = ma_search_lines(rec + base, nsearch, targetval);
-      }
-    }
+    const int ti = ma_search_dir(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2);
     MA_PROF_MARK(env, 61);
-    // the first transition's target is also in line 0: a direction with one transition reads nothing else
-    const uint64_t tg = ((const MaTarget *)rec)[nsearch == 0 ? marec_tgt0 + (down ? 0 : 1) : marec_tgt(base, ti)].bits;
+    const MaTarget tg = env.M.alltrans_target[k.ats + (down ? 0 : k.nd) + ti];
     MA_PROF_WAIT();
     MA_PROF_MARK(env, 62);
-    p.ma_level = (int)((tg >> 20) & 0xFFFF);
-    k.rec = (int)(tg & 0xFFFFF) * MAREC_ALIGN;
-    k.nd = (int)((tg >> 36) & 0x3FFF);
-    k.nu = (int)(tg >> 50);
-    // (only the LDS option asks where the target's copy sits in the cell's hot block)
-    k.hot = HOT ? (int)env.K.hotoff[((int64_t)k.c * env.M.nlevels) + (k.start + p.ma_level)] : -1;
+    p.ma_level = tg.level;
+    k.rec = tg.rec;
+    k.ats = tg.ats;
+    k.nd = (int)(tg.ndnu & 0xFFFFu);
+    k.nu = (int)(tg.ndnu >> 16);
     return -1;
   }
-  if (RATE) *rate_out = rec[marec_rates + action];  // once per walk
   return action;
 }
-AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const double *rec, int action, double rate_sel) {
+// `rec`: the record the action was drawn from (the packet's current level: k still describes it)
+AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const U4 *rec, int action) {
   const DevModel &M = env.M;
   const int c = k.c;
-  const MaHeader hd = *(const MaHeader *)rec;  // of the record the action was drawn from: the packet's current level
   const int activatingline = p.ma_line;
   if (action == ARTIS_MA_ACTION_RADDEEXC) {
-    // do_macroatom_raddeexcitation macroatom.cc:204
-    const double targetval = rng_uniform(p) * rate_sel;
-    const int ndown = hd.ndown;
-    const double *sums = rec + marec_rad(ndown, hd.nup);
-    const int dti = ma_search(sums, ndown - 1, targetval);
-    const int lineindex = M.alltrans_lineindex[hd.alltrans_startdown + dti];
+    // do_macroatom_raddeexcitation macroatom.cc:204: targetval = zrand * (the rate); the transition is the number of
+    // cumulative radiative de-excitation sums <= targetval among the first ndown - 1
+    const uint32_t u = rng_u24(p);
+    const int dti = ma_search_dir(env, k, rec, MADIR_RAD, u);
+    const int lineindex = M.alltrans_lineindex[k.ats + dti];
     if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
-    const int ul = hd.ul;
-    const uint64_t tg = ((const MaTarget *)rec)[marec_tgt(marec_down, dti)].bits;
-    const int lul = (ul - p.ma_level) + (int)((tg >> 20) & 0xFFFF);
+    const int ul = k.start + p.ma_level;
+    const int lul = k.start + M.alltrans_targetlevelindex[k.ats + dti];
     const double e_trans = eps(M, ul) - eps(M, lul);
     const double oldnucmf = p.nu_cmf;
     p.nu_cmf = e_trans / HPLANCK;
@@ -3081,10 +3030,9 @@ AHD void ma_flush_stats(const Env &env, MACtx &k) {
 }
 AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
   ma_prepare(env, p, k);
-  const double *rec = ma_record(k);
-  double rate_sel = 0.;
-  const int action = ma_jump_internal(env, p, k, rec, &rate_sel);
-  if (action >= 0) ma_jump_exit(env, p, pi, k, rec, action, rate_sel);
+  const U4 *rec = ma_record(k);
+  const int action = ma_jump_internal(env, p, k, rec);
+  if (action >= 0) ma_jump_exit(env, p, pi, k, rec, action);
   ma_flush_stats(env, k);
 }
 
@@ -3100,7 +3048,8 @@ AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi) {
   const int ui = uion(M, element, ion);
   const int ul = M.ion_uniquelevelindexstart[ui] + level;
   const double e_cur = eps(M, ul);
-  const double rate_sel = env.K.macache[((int64_t)c * M.nmacache) + M.level_pack[ul].rec_off + marec_rates + action];
+  const LevelPack lpk = M.level_pack[ul];
+  const double rate_sel = ma_rates_of(ma_rec_of(env, c, lpk), lpk.ndown, lpk.nup)[action];
   const float T_e = env.C.Te[c];
   const float cnne = clumpednne(env.C, c);
   if (action == ARTIS_MA_ACTION_RADRECOMB) {
@@ -3436,6 +3385,17 @@ AHD void do_kpkt_blackbody(const Env &env, Pkt &p, int64_t pi) {  // kpkt.cc:399
   ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
   thermal_emission_flags(env, p, pi, ARTIS_EMTYPE_FREEFREE);
 }
+// kpkt.cc:461-476 on the terms themselves: the number of the level's first nsearch running cooling sums <= rnd_process, the
+// sums re-added from `lo` (the ion's running sum before the level) term by term, as calculate_cooling_rates_ion() adds them
+AHD int kpkt_collexc_exact(const Env &env, int c, int ats_up0, int nsearch, double lo, double rnd_process) {
+  double s = lo;
+  int j = 0;
+  for (; j < nsearch; j++) {
+    s += matrans_terms(env, c, ats_up0 + j).kterm;
+    if (s > rnd_process) break;
+  }
+  return j;
+}
 // do_kpkt kpkt.cc:425
 AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   const DevModel &M = env.M;
@@ -3493,28 +3453,36 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     p.pend_arg = M.coolinglist_level[i];
   } else if (ctype == ARTIS_COOLING_COLLEXC) {
     // kpkt.cc:455-476: the reference adds the level's collisional-excitation terms to contrib_low one by one until the
-    // sum exceeds rnd_process; those running sums are the cell cache's collexc_cum (populate_cooling_ion)
+    // sum exceeds rnd_process. The running sums are not kept: the level's record holds them as 15-bit fractions of the
+    // level's span [lo, hi) of the ion's list (populate_coolfilter_line); a draw within the filter's resolution of an entry
+    // re-adds the terms (kpkt_collexc_exact).
     const int start = M.ion_uniquelevelindexstart[ui];
     const int ul = start + M.coolinglist_level[i];
-    const int nup = M.level_nuptrans[ul];
-    const double *upcum = env.K.collexc_cum + ((int64_t)c * M.nupcum) + M.level_upcum_start[ul];
-    int first = nup;  // first transition whose running sum is greater than rnd_process
-    for (int base = 0; base < nup && first == nup; base += 8) {
+    const LevelPack lpk = M.level_pack[ul];
+    const int nup = lpk.nup;
+    const double lo = (ionoffset > 0) ? contribs[ionoffset - 1] : 0., hi = contribs[ionoffset];
+    const int nsearch = nup - 1;  // the last sum is hi itself: > rnd_process
+    int first = 0;                // first transition whose running sum is greater than rnd_process = the number of sums <= it
+    if (nsearch > 0) {
+      const U4 *rec = ma_rec_of(env, c, lpk);
+      const double y = ((rnd_process - lo) / (hi - lo)) * MAFILT_SCALE;
+      bool amb = env.ma_filters_off != 0 || !(y >= 0. && y < MAFILT_SCALE);
+      const int yi = amb ? 0 : (int)y;
+      for (int b0 = 0; b0 < nsearch && !amb; b0 += MAREC_PER) {
 #if defined(ARTIS_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-      if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 58);  // wave-level rounds of this scan
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 58);  // wave-level rounds of this scan
 #endif
-#pragma unroll
-      for (int k = 7; k >= 0; k--) {
-        const int j = base + k;
-        if (j < nup && upcum[j] > rnd_process) first = j;
+        const U4 f = rec[marec_slot(MADIR_COOL, b0 / MAREC_PER, lpk.ndown, lpk.nup)];
+        // (y is not a 24-bit draw: an entry within one unit of it either way is left to the f64 path)
+        const int cnt = mafilt_count_between(f, (yi - 2 > -1) ? yi - 2 : -1, (yi + 1 < 32767) ? yi + 1 : 32767, &amb);
+        amb = amb || (f.w[3] >> 16) != MAFILT_NONE;
+        if (amb) break;
+        first += cnt;
+        if (cnt < MAREC_PER) break;
       }
+      if (amb) first = kpkt_collexc_exact(env, c, lpk.alltrans_startdown + lpk.ndown, nsearch, lo, rnd_process);
     }
-    if (first == nup) {
-      fail(env, 72);
-      return;
-    }
-    const int startup = M.level_alltrans_startdown[ul] + M.level_ndowntrans[ul];
-    const int upper = M.alltrans_targetlevelindex[startup + first];
+    const int upper = M.alltrans_targetlevelindex[lpk.alltrans_startdown + lpk.ndown + first];
     ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_COLLEXC);
     ARTIS_STAT(env, ARTIS_STAT_K_TO_MA_COLLEXC);
     p.trueemissiontype = ARTIS_EMTYPE_NOTSET;

@@ -27,7 +27,7 @@ struct alignas(16) LinePack {
 };
 
 // 16-byte record of the static per-level indices a macro-atom transition needs (AllLevels, globals.h:181):
-// alltrans_startdown, ndowntrans, nuptrans, and the offset (in doubles) of the level's macro-atom record inside a
+// alltrans_startdown, ndowntrans, nuptrans, and the offset (in 16-byte slots) of the level's macro-atom record inside a
 // cell's macache row (see DevCache::macache)
 struct alignas(16) LevelPack {
   int32_t rec_off;
@@ -45,92 +45,89 @@ struct alignas(32) ContPack {
   int32_t gi;
   int32_t pad[2];
 };
-// Macro-atom record of one (cell, level), 128-byte aligned and SELF-CONTAINED: one transition of the walk
-// (macroatom.cc:385-577) reads this record and nothing else -- no level table, no transition table -- so the chain of
-// dependent reads per transition is record -> cumulative sums -> target, all inside a few adjacent cache lines.
-// The unit of the layout is the 128-byte line: a transition touches line 0 and one line of its direction. In doubles:
-//   line 0   [0..1]        MaHeader (16 B): ndown, nup, unique level index, alltrans_startdown, place in the hot block
-//            [2..10]       the 9 process rates              (alllevels_maprocessrates, globals.h:286)
-//            [12], [13]    copies of the MaTarget of the first downward and of the first upward transition (a direction
-//                          with one transition, a third of all searches, reads no other line)
-//            [14..15]      FILTER: 8 x uint16, the cumulative rates of actions 0..7 as fractions of the total (below)
-//   then one line per 7 transitions of a direction, downward lines first (marec_down), then upward (marec_up(ndown)):
-//            [0..1]        FILTER: 7 x uint16, the line's cumulative sums as fractions of the direction's whole rate
-//                          (0x7FFF for a sum that is not searched); the 8th uint16: 0x7FFF, anything else = "do not use
-//                          this line's filter" (a sum that is not a finite fraction)
-//            [2..9)        cumulative internal-down-same / internal-up-same (allmacroatomictransitions blocks 2 and 3,
-//                          macroatom.cc:44, :51) of transitions 7b .. 7b+6
-//            [9..16)       their MaTarget (8 B each): the target level and the offset of ITS record in the cell's row
-//                          (static data, repeated per cell so that it sits in the line of the sums that select it)
-//   [marec_rad(..) ..)     cumulative radiative deexc.      (block 1, macroatom.cc:58), contiguous (read once per walk)
-// A search reads whole lines of sums (entries beyond the count are never used); the rad block may be read up to 7 doubles
-// past its end, which stays inside the row (+ MAREC_SLACK at the end of the allocation).
+// Macro-atom record of one (cell, level): FILTERS ONLY (round 4). The decisions of a macro-atom transition (macroatom.cc:385-577)
+// are "how many cumulative values are <= z * whole" with z a 24-bit draw; a record holds the cumulative values as 15-bit
+// fractions of their whole (below, "FILTERS") and the nine process rates as doubles, nothing else: no cumulative sums, no
+// transition targets. Rounds 2-3 kept both per cell (7 sums + 7 targets per 128-byte line: 1.08 of the 1.55 MB of a row with
+// the 13 619-line atomic data, 6.3 of 8.75 MB with 110 860 lines); now a draw that the filter cannot decide (5e-4 per decision)
+// RECOMPUTES the sums it needs from the rate coefficients, term by term in the reference's order (physics.h ma_exact_search:
+// the same matrans_terms() that fills the records, so the same bits), and the targets -- static data -- sit in one table for all
+// cells (DevModel::alltrans_target). A level's record is 12 slots of 16 bytes with ~9 transitions per direction (192 B instead
+// of 690), 18 with 25 (288 B instead of 1415). The unit is the 16-byte SLOT (one load instruction):
+//   slot 0            action filter: 8 x uint16, the cumulative rates of actions 0..7 as fractions of the total of all nine
+//   slot 1, 2, 3      the FIRST line of the internal-down-same, internal-up-same and radiative-deexcitation filters: 7 x uint16
+//                     fractions of the direction's whole rate + the line's "usable" mark (87.7 % of the searches end in the first
+//                     two entries: profiles/r03/ti_hist.txt) -- with slot 0 one aligned 64-byte block: a transition reads ONE
+//                     cell-specific sector
+//   then              the further lines of the three directions (7 transitions per slot), the lines of the level's
+//                     collisional-excitation cooling filter (kpkt.cc:461-476: fractions of the level's span of the ion's cooling
+//                     list), and 5 slots with the 9 process rates (alllevels_maprocessrates, globals.h:286) as doubles, read only
+//                     when a filter cannot decide and by the slow-path actions
+// Records are aligned to 4 slots (64 B). Entries of a line beyond its direction's searched sums hold 0x7FFF (never counted);
+// those slots are initialised once (k_mainit), the population writes the entries of real transitions and each line's mark.
 //
 // FILTERS. k_thermal is bound by the NUMBER of vector-memory instructions it issues (two more 8-byte reads of a line it
-// has already read, per transition: 617 -> 786 ms), and a transition decided on the f64 values reads
-// 64 B of rates + 56 B of sums + a target = 9 instructions. Both decisions are "how many cumulative values are <= z * whole"
-// with z uniform in [0, 1): the same as "how many fractions value / whole are <= z" unless z lies within rounding of a
-// fraction. The fractions are kept as 15-bit integers q = floor(fraction * 32768) (clamped to 32767) in uint16, so
+// has already read, per transition: 617 -> 786 ms). Both decisions are "how many cumulative values are
+// <= z * whole" with z uniform in [0, 1): the same as "how many fractions value / whole are <= z" unless z lies within rounding
+// of a fraction. The fractions are kept as 15-bit integers q = floor(fraction * 32768) (clamped to 32767) in uint16, so
 // q <= fraction * 32768 <= q + 1: with zi = floor(z * 32768) (the top 15 bits of the 24-bit draw), zi >= q + 2 proves
 // value <= z * whole and zi <= q - 1 proves the opposite, by margins of 3e-5 and 6e-8 of the whole against f64 rounding errors
-// of 1e-16 (physics.h mafilt_count). Anything in between (q == zi or zi - 1: 5e-4 of the draws per
-// decision) is decided on the f64 values as before -- same random numbers, same result. 15 bits, so that two entries are
-// compared by ONE 32-bit subtraction (physics.h mafilt_count). A transition then reads 16 B + 16 B + a target.
-struct alignas(16) MaHeader {
-  int16_t ndown, nup;
-  int32_t ul, alltrans_startdown;
-  int16_t hot, pad;
+// of 1e-16 (physics.h mafilt_count). Anything in between (q == zi or zi - 1: 5e-4 of the draws per decision) is decided on
+// f64 values -- same random numbers, same result. 15 bits, so that two entries are compared by ONE 32-bit subtraction.
+// What a transition needs to know about the level it leads to (static, one 16-byte load from DevModel::alltrans_target): where
+// the target's record is in a cell's row (slots), its first entry in alltrans, its index within the ion, its transition counts.
+struct alignas(16) MaTarget {
+  int32_t rec, ats, level;
+  uint32_t ndnu;  // ndown | nup << 16
 };
-// What a transition needs to know about the level it leads to, in 8 bytes, so that the NEXT transition reads neither a
-// level table nor the target record's header: where the target's record is, which level it is, and how many downward
-// and upward transitions it has (= where the blocks of its record begin).
-struct MaTarget {
-  uint64_t bits;  // [0..20) record offset / MAREC_ALIGN   [20..36) level within its ion   [36..50) ndown   [50..64) nup
+constexpr int MATGT_MAX_NTRANS = 1 << 16;
+static_assert(sizeof(MaTarget) == 16, "transition target size");
+struct alignas(16) U4 {  // one slot: 8 x uint16 of a macro-atom filter
+  uint32_t w[4];
 };
-constexpr int64_t MATGT_MAX_RECUNITS = 1 << 20;  // rows up to 128 MB
-constexpr int MATGT_MAX_LEVEL = 1 << 16, MATGT_MAX_NTRANS = 1 << 14;
-static_assert(sizeof(MaHeader) == 16 && sizeof(MaTarget) == 8, "record header and target sizes");
-#ifndef ARTIS_HOT_DOUBLES
-#define ARTIS_HOT_DOUBLES 512  // 4 KB per cell
-#endif
-constexpr int HOT_DOUBLES = ARTIS_HOT_DOUBLES;
-constexpr int MAREC_ALIGN = 16;  // doubles
-constexpr int marec_even(int n) { return (n + 1) & ~1; }
-constexpr int marec_rates = 2;
-constexpr int marec_tgt0 = 12;   // [12] first downward target, [13] first upward target
-constexpr int marec_filt0 = 14;  // [14..15] the action filter of line 0
-constexpr int MAREC_LINE = 16;   // doubles per line of a direction: filter (2), 7 sums, 7 targets
-constexpr int MAREC_PER = 7;     // transitions per line
+constexpr int MAREC_ALIGN = 4;   // slots: records start on 64-byte boundaries
+constexpr int MAREC_PER = 7;     // transitions per filter line
+constexpr int MAREC_QUAD = 4;    // slots 0..3: action filter, first lines of the down / up / rad filters
+constexpr int MAREC_RATE_SLOTS = 5;  // 9 doubles (+ one spare)
+enum { MADIR_DOWN = 0, MADIR_UP = 1, MADIR_RAD = 2, MADIR_COOL = 3 };
 constexpr int marec_lines(int n) { return (n + MAREC_PER - 1) / MAREC_PER; }
-constexpr int marec_down = 16;
-constexpr int marec_up(int ndown) { return marec_down + (marec_lines(ndown) * MAREC_LINE); }
-constexpr int marec_rad(int ndown, int nup) { return marec_up(ndown) + (marec_lines(nup) * MAREC_LINE); }
-constexpr int marec_size(int ndown, int nup) { return marec_rad(ndown, nup) + marec_even(ndown); }
-// entry i of a direction whose lines begin at `base`: its cumulative sum, its target
-constexpr int marec_sum(int base, int i) { return base + ((i / MAREC_PER) * MAREC_LINE) + 2 + (i % MAREC_PER); }
-constexpr int marec_tgt(int base, int i) { return marec_sum(base, i) + MAREC_PER; }
+constexpr int marec_rest(int n) { return n > MAREC_PER ? marec_lines(n) - 1 : 0; }  // a direction's lines after its first
+// slot of line l of direction d in the record of a level with nd downward and nu upward transitions
+constexpr int marec_slot(int d, int l, int nd, int nu) {
+  return (d < MADIR_COOL && l == 0)
+             ? 1 + d
+             : (d == MADIR_DOWN ? MAREC_QUAD + (l - 1)
+                                : (d == MADIR_UP ? MAREC_QUAD + marec_rest(nd) + (l - 1)
+                                                 : (d == MADIR_RAD ? MAREC_QUAD + marec_rest(nd) + marec_rest(nu) + (l - 1)
+                                                                   : MAREC_QUAD + (2 * marec_rest(nd)) + marec_rest(nu) + l)));
+}
+constexpr int marec_rates_slot(int nd, int nu) { return MAREC_QUAD + (2 * marec_rest(nd)) + marec_rest(nu) + marec_lines(nu); }
+constexpr int marec_slots(int nd, int nu) { return marec_rates_slot(nd, nu) + MAREC_RATE_SLOTS; }
 constexpr double MAFILT_SCALE = 32768.;
 constexpr uint32_t MAFILT_NONE = 0x7FFFu;  // an entry that is never counted
-constexpr int MAREC_SLACK = 16;  // doubles past the last row that a padded search may touch
+constexpr int MAREC_SLACK = 16;  // elements past the last row of every cache array (padded reads stay inside the allocation)
 
 struct alignas(16) D2 {
   double x, y;
 };
-struct alignas(16) U4 {  // 8 x uint16 of a macro-atom filter
-  uint32_t w[4];
+// a (level, direction) whose transitions do not fit one 64-lane chunk of k_matrans' scan (static; real atomic data: levels
+// with hundreds of transitions): k_mafilter_long writes its filters, a wave per (cell, entry)
+struct alignas(16) MaLongSeg {
+  int32_t ats0, n, ul, dir;  // first entry in alltrans, transitions, level, 0 = downward / 1 = upward
 };
-// one line of sums of one direction of one level's record (static): where it is in a cell's row, where the direction's
-// whole rate is, which transitions of the direction it holds (k_mafilter: a thread per cell and line)
-struct alignas(16) MaLineRef {
-  int32_t line_off, rate_off, first, n;
+// one line of a level's collisional-excitation cooling filter (static): its slot in a cell's row, the level's first entry of
+// the cell's upward-transition terms, the line's first transition, the level's nup, and the entries of the cooling list
+// that hold the running sum after (hi) and before (lo; -1: the sum starts at 0) the level (k_collexc_filter)
+struct alignas(8) CoolLineRef {
+  int32_t slot, up0, first, n, cool_hi, cool_lo;
 };
 
 struct VpktConfig;  // virtual packets, below
 struct DevModel {
   int32_t nelements, nions, nlevels, nlines, nalltrans, nphixstargets_total, nphixslevels, nbfcontinua, nbfcontinua_ground,
       ncoolingterms, nmatransblock, NPHIXSPOINTS;
-  int32_t nmacache;    // doubles per cell in DevCache::macache
-  int32_t nupcum;      // doubles per cell in DevCache::collexc_cum (= number of upward transitions = nlines)
+  int32_t nmacache;    // 16-byte slots per cell in DevCache::macache
+  int32_t nupcum;      // upward transitions (= nlines): doubles per cell of the population's scratch of cooling terms (Env::collexc_terms)
   int32_t nkeepwords;  // ceil(nbfcontinua/64) (get_allcont_keepwordcount globals.h:401) rounded up to a multiple of 4
   double NPHIXSNUINCREMENT;
   double last_phixs_nuovernuedge;  // input.cc:310
@@ -174,19 +171,20 @@ struct DevModel {
       *level_nphixstargets, *level_phixstargetstart, *level_bflist_start, *level_matransblock_start;
   const int32_t *level_ion;  // derived: uniqueionindex of each level
   const LevelPack *level_pack;  // derived
-  const int32_t *level_upcum_start;  // derived: offset of the level's upward transitions in DevCache::collexc_cum
+  const int32_t *level_upcum_start;  // derived: offset of the level's upward transitions in a cell's row of Env::collexc_terms
   const int32_t *alltrans_lineindex, *alltrans_targetlevelindex;
   const int32_t *alltrans_owner;  // derived: the level whose block of alltrans an entry belongs to
-  // derived: alltrans cut at level boundaries into runs of at most ~256 entries, [nscanblk + 1] start indices: one wave
-  // of k_matrans forms the running sums of one run
-  const int32_t *scanblk_start;
-  int32_t nscanblk;
-  const MaLineRef *malines;  // derived: every line of sums of every record, [nmalines]
-  int32_t nmalines;
-  // ... and those whose direction's transitions are not all inside one 64-transition chunk of k_matrans' scan: k_matrans
-  // writes the filter of a line when it has the direction's whole rate at hand, k_mafilter the filters of these lines
-  const MaLineRef *malines_fix;
-  int32_t nmalines_fix;
+  // derived: the scan of k_matrans. alltrans is cut into CHUNKS of at most 64 entries, [nscanchunk + 1] start indices, each
+  // a whole number of (level, direction) segments -- a segment with more than 64 transitions takes chunks of its own --
+  // and runs of chunks (~256 entries, a long segment whole) into BLOCKS, [nscanblk + 1] first chunks: one wave per (cell, block)
+  const int32_t *scanchunk_start;
+  const int32_t *scanblk_chunk0;
+  int32_t nscanchunk, nscanblk;
+  const MaLongSeg *malongsegs;  // derived: the segments longer than a chunk, [nmalongsegs]
+  int32_t nmalongsegs;
+  const MaTarget *alltrans_target;  // derived: [nalltrans] what a transition needs to know of the level it leads to
+  const CoolLineRef *coollines;     // derived: every line of every level's cooling filter, [ncoollines]
+  int32_t ncoollines;
   const float *alltrans_einstein_A, *alltrans_coll_str, *alltrans_osc_strength;
   const uint8_t *alltrans_forbidden;
   const double *line_nu;
@@ -243,10 +241,7 @@ struct DevCells {
 
 struct DevCache {
   double *levelpops;             // [cell][nlevels]
-  double *macache;               // [cell][nmacache]: one record per level, see LevelPack
-  double *hotblk;                // [cell][HOT_DOUBLES]: copies of the records of the cell's hottest levels (MaHeader::hot)
-  float *hotness;                // [cell][nlevels]: level population x total macro-atom rate (populate_macroatom)
-  int16_t *hotoff;               // [cell][nlevels]: place of each level's copy in the hot block, or -1
+  U4 *macache;                   // [cell][nmacache]: one record of filters + process rates per level (above; LevelPack::rec_off)
   double *allcont_nnlevel;       // [cell][nbfcontinua]
   double *allcont_departure;     // [cell][nbfcontinua]
   double *allcont_edgepart;      // [cell][nbfcontinua]
@@ -259,7 +254,6 @@ struct DevCache {
   int32_t *allcont_keepprefix;   // [cell][nkeepwords]
   D2 *allcont_keptpair;          // [cell][nbfcontinua]
   double *line_dpop;             // [cell][nlines]: B_lu n_l - B_ul n_u of every line, the population factor of get_tau_sobolev() (rpkt.cc:75)
-  double *collexc_cum;           // [cell][nupcum]: running cooling sum after each upward transition of each level (kpkt.cc:461-476)
   double *corrphotoioncoeff;     // [cell][nphixstargets_total]
   // [cell][nphixstargets_total] the other coefficients of each bound-free pair (populate_corrphotoion): radiative and
   // collisional recombination, collisional ionisation, bound-free cooling

@@ -44,8 +44,9 @@ from artis_amd import abi, synth  # noqa: E402
 B_PER_THERMAL_VISIT = 256.0   # hot line (128 B) loaded + stored once per packet per k_thermal launch
 B_PER_RPKT_VISIT = 448.0      # hot + flight line (96 of 128 B used) loaded + stored once per packet per k_rpkt launch
 B_PER_EMISSION = 120.0        # flight line direction/rest-frame part 56 + em_pos/em_time 28 + trueem 36
-B_PER_MA_JUMP = 35.0          # action filter 16 + the direction's line filter 16 x 0.675 (a third of the searches read none) + target 8
-                              # (round 2: 116 = 64 B of rates + 64 x 0.675 of sums + 8; the f64 values are read for one draw in ~500)
+B_PER_MA_JUMP = 43.0          # action filter 16 + the direction's filter line 16 x 0.675 (a third of the searches read none) + the
+                              # static 16-byte target (round 3: 35 with an 8-byte target in the line of the sums; round 2: 116 =
+                              # 64 B of rates + 64 x 0.675 of sums + 8)
 B_PER_KPKT_STEP = 200.0       # ~6 ion sums 48 + ~7 cooling-list sums 56 + ~6 collisional-excitation sums 48 + indices/flags 48
 B_PER_RPKT_STEP = 120.0       # cell scalars ~40 + boundary tables ~56 + J, nuJ, ffheating atomics 24
 B_PER_LINE = 16.0             # line frequency 8 + the cell's population factor of the line 8

@@ -78,6 +78,8 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   e.env.gamma_gi = e.ws_gi.data();
   e.env.gamma_n = e.ws_n.data();
   e.env.errflag = &e.err;
+  // ARTIS_EMU_MAFILTERS=0: every macro-atom and cooling decision on the re-added f64 sums (the path of an undecided draw)
+  if (const char *b = std::getenv("ARTIS_EMU_MAFILTERS")) e.env.ma_filters_off = (std::atoi(b) == 0) ? 1 : 0;
   e.env.tile_lo = 0;
   e.env.tile_hi = M.npts_nonempty;
   e.env.tile_all = 1;
@@ -102,9 +104,10 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
 }
 
 // the populate kernels, in launch order (artis_engine.hip: k_levelpops, k_line_dpop, k_cell_scalars, k_allcont, k_corrphotoion,
-// k_macroatom, k_cooling_head / _chain / _tail, k_cooling_prefix)
+// k_matrans, k_macroatom, k_cooling_head / _chain, k_collexc_filter, k_cooling_tail, k_cooling_prefix)
 void populate_all(Emu &e) {
   const DevModel &M = e.env.M;
+  std::vector<double> upterms((size_t)M.nupcum + 1, 0.);  // the population's scratch row of cooling terms (Env::collexc_terms)
   for (int c = 0; c < M.npts_nonempty; c++) {
     for (int ul = 0; ul < M.nlevels; ul++) populate_levelpop(e.env, c, ul);
     for (int li = 0; li < M.nlines; li++) populate_line_dpop(e.env, c, li);
@@ -116,19 +119,17 @@ void populate_all(Emu &e) {
     if (M.nbfcontinua > 0) populate_keptlist(e.env, c);
     for (int ul = 0; ul < M.nlevels; ul++)
       for (int t = 0; t < M.level_nphixstargets[ul]; t++) populate_corrphotoion(e.env, c, ul, t);
-    for (int ati = 0; ati < M.nalltrans; ati++) populate_matrans(e.env, c, ati);
-    for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom_sums(e.env, c, ul);
+    for (int ul = 0; ul < M.nlevels; ul++) populate_mainit(e.env, c, ul);  // k_mainit (once per engine there)
+    for (int ul = 0; ul < M.nlevels; ul++) populate_level_bb(e.env, c, ul, upterms.data());  // k_matrans (+ k_mafilter_long)
     for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom(e.env, c, ul);
-    for (int li = 0; li < M.nmalines; li++) populate_mafilter_line(e.env, c, li);
-    populate_hotselect(e.env, c);
-    for (int ul = 0; ul < M.nlevels; ul++) populate_hotfill(e.env, c, ul);
 #if ARTIS_EXPOPAC_TABLES
     if (e.expopac_own && e.env.C.thick[c] != ARTIS_CELL_THICK) {  // k_expopac, k_expopac_planck
       for (int b = 0; b < ARTIS_EXPOPAC_NBINS; b++) populate_expopac_bin(e.env, c, b);
       if (ARTIS_OPT_RPKT_BB_THERMALISATION) populate_expopac_planck(e.env, c);
     }
 #endif
-    for (int ui = 0; ui < M.nions; ui++) populate_cooling_ion(e.env, c, ui);
+    for (int ui = 0; ui < M.nions; ui++) populate_cooling_ion(e.env, c, ui, upterms.data());
+    for (int li = 0; li < M.ncoollines; li++) populate_coolfilter_line(e.env, c, li, upterms.data());  // k_collexc_filter
     populate_cooling_prefix(e.env, c);
   }
 }
@@ -300,7 +301,8 @@ int artis_emu_cellcache(const artis_model *m, const artis_cellstate *cs, const a
   const DevModel &M = e.env.M;
   const DevCache &K = e.env.K;
   std::memcpy(levelpops, K.levelpops + (int64_t)c * M.nlevels, sizeof(double) * M.nlevels);
-  unpack_macache_row(M, *m, K.macache + (int64_t)c * M.nmacache, maprocessrates, matrans);
+  for (int ul = 0; ul < M.nlevels; ul++)
+    if (debug_level_record(e.env, c, ul, maprocessrates, matrans) != 0) e.err = 94;
   std::memcpy(allcont_nnlevel, K.allcont_nnlevel + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
   std::memcpy(allcont_departure, K.allcont_departure + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);
   std::memcpy(allcont_edgepart, K.allcont_edgepart + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);

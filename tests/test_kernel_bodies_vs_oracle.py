@@ -540,6 +540,26 @@ def test_reference_ci_option_sets_bit_exact(oracle, options):
             assert np.all(per_comb[3::4] >= full)           # without the lines of one element
 
 
+@pytest.mark.parametrize("options,preset,ncoord,gridtype,npk", [
+    ("classic", "small", 8, abi.GRID_CARTESIAN3D, 3000),
+    ("classic", "w7", 5, abi.GRID_CARTESIAN3D, 600),
+    ("kilonova_lte", "small", 16, abi.GRID_SPHERICAL1D, 1500),
+    ("nltenebular", "small", 6, abi.GRID_CARTESIAN3D, 1500),
+])
+def test_undecided_draws_readd_the_sums_bit_exact(oracle, monkeypatch, options, preset, ncoord, gridtype, npk):
+    """Round 4: the records hold filters only; a draw a filter cannot decide re-adds the cumulative sums from the transitions'
+    terms (physics.h ma_exact_search, kpkt_collexc_exact). With ARTIS_EMU_MAFILTERS=0 EVERY macro-atom transition,
+    radiative de-excitation and collisional-excitation cooling draw takes that path: bit-exact against the oracle, whose
+    sums are the reference's stored arrays."""
+    monkeypatch.setenv("ARTIS_EMU_MAFILTERS", "0")
+    model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, options=options)
+    pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=0.3)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, "re-added sums vs oracle")
+    parity.compare_stats(eb, ea, "re-added sums vs oracle")
+    assert ea.stats[abi.STAT_X_MA_JUMPS] > 10 * npk and ea.stats_dict()["K_STAT_TO_MA_COLLEXC"] > 0
+
+
 def test_macroatom_filters_decide_what_the_f64_comparison_decides():
     """tables.h "FILTERS": 4e6 random cumulative lists and 24-bit draws, a quarter of them with a value within two ulp of
     z * whole; whenever the 15-bit filter does not hand the draw to the f64 path, its count is the f64 comparison's"""
