@@ -813,7 +813,7 @@ __device__ inline void scalars_flush(const Env &env) {  // after a __syncthreads
 __device__ inline void cellest_flush(const Env &env, int kind, double *global_array, int nthreads) {
   for (int c = threadIdx.x; c < env.cellest_n; c += nthreads) {
     const double v = env.cellest_lds[(kind * env.cellest_n) + c];
-    if (v != 0.) unsafeAtomicAdd(&global_array[c], v);
+    if (v != 0.) unsafeAtomicAdd(&global_array[(int64_t)c * env.est_stride], v);
   }
 }
 // One workgroup of 768 threads per CU: 3 waves/SIMD at 168 VGPRs (the LDS tables allow two workgroups per CU, so 256-thread
@@ -1073,6 +1073,9 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
 #define ARTIS_THERMAL_EU ARTIS_THERMAL_WAVES   // the waves per SIMD its registers are to allow (512 / EU VGPRs) ...
 #define ARTIS_THERMAL_WGS ARTIS_THERMAL_WAVES  // ... and its workgroups per CU
 #endif
+#ifndef ARTIS_MA_DEFER_EXACT
+#define ARTIS_MA_DEFER_EXACT 1  // the re-adding of a search's sums outside the transition loop (physics.h ma_jump_internal<true>)
+#endif
 template <int TB>
 __global__ void __launch_bounds__(TB, ARTIS_THERMAL_EU) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                      unsigned long long *gstats, int budget, int32_t *cursors,
@@ -1133,11 +1136,14 @@ __global__ void __launch_bounds__(TB, ARTIS_THERMAL_EU) k_thermal(Env env, const
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 46);
 #endif
         rec = ma_record(k);
-        exit_action = ma_jump_internal(env, p, k, rec);
+        exit_action = ma_jump_internal<ARTIS_MA_DEFER_EXACT != 0>(env, p, k, rec);
         j++;
       }
       ma_flush_stats(env, k);
-      if (exit_action >= 0) ma_jump_exit(env, p, pi, k, rec, exit_action);
+      // (a transition whose search the filters could not decide is finished here, outside the loop: the walk goes on in the
+      // next phase)
+      if (exit_action == MA_EXIT_DEFER) ma_jump_deferred(env, p, k, rec);
+      else if (exit_action >= 0) ma_jump_exit(env, p, pi, k, rec, exit_action);
       if (j > 0) chi_after_ma(p);
       units += j;
     }
@@ -1518,6 +1524,8 @@ Env make_env(const artis_amd_engine *e) {
   }
   env.S = e->S;
   env.E = e->E;
+  env.est_stride = 8;
+  env.pair_stride = 2;
   env.P = e->P;
   env.stats = nullptr;
   env.gamma_ws = e->d_gamma_ws;
@@ -1835,7 +1843,9 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
     e->cache_bytes_per_cell = per_cell;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    double budget = 0.6 * (double)free_b;  // the packets, their lists and the caller's buffers need room too
+    // the packets (320 B each), their work lists (~100 B), the caller's structs (256 B) and a snapshot need room too: ~1 KB per
+    // packet, 10 GB at 1e7 packets; the population's scratch 2 GB
+    double budget = 0.8 * (double)free_b;
     if (const char *b = std::getenv("ARTIS_AMD_CACHE_BUDGET_MB")) budget = std::atof(b) * 1048576.0;
     int64_t fit = (int64_t)(budget / (double)(per_cell > 0 ? per_cell : 1));
     e->tile_cells = std::max<int64_t>(1, std::min<int64_t>(ncell_all > 0 ? ncell_all : 1, fit));
@@ -1860,10 +1870,10 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   }
   ARTIS_CACHE_ARRAYS(CA, h)
 #undef CA
-  // estimators: one contiguous block [J | nuJ | ff | col | gamma | bfheat | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars]
+  // estimators: one contiguous block [cell][8]{J, nuJ, ff, col, dep_gamma, dep_electron, dep_positron, dep_alpha} | [cell][ground continuum][2]{gamma, bfheat} | scalars
   const int64_t ncell = ncell_all;  // estimators cover every cell
   const int64_t g = h.nbfcontinua_ground > 0 ? h.nbfcontinua_ground : 1;
-  // ... | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars | (radfieldbin_J | radfieldbin_nuJ) | (bfrate_raw)]
+  // ... | scalars | ([cell][bin][2]{radfieldbin_J, radfieldbin_nuJ}) | (bfrate_raw)]
   const int64_t nbinest = ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON ? ncell * ARTIS_OPT_RADFIELDBINCOUNT : 0;
   const int64_t nbfest = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? ncell * (int64_t)h.nbfestim : 0;
   const int64_t nlineest = ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON ? ncell * (int64_t)h.detailed_linecount : 0;
@@ -1890,19 +1900,21 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   e->est_ndoubles = ncell * 8 + 2 * ncell * g + ARTIS_NSCALARS + 2 * nbinest + nbfest + 2 * nlineest + nvspec + nvgrid;
   HIP_TRY(hipMalloc((void **)&e->d_est, sizeof(double) * (size_t)e->est_ndoubles));
   HIP_TRY(hipMemset(e->d_est, 0, sizeof(double) * (size_t)e->est_ndoubles));
+  // [cell][8] {J, nuJ, ffheating, colheating, dep_gamma, dep_electron, dep_positron, dep_alpha}: one 64-byte record per cell
+  // (physics.h Env::est_stride), then [cell][ground continuum][2] {gamma, bfheating}
   e->E.J = e->d_est;
-  e->E.nuJ = e->d_est + ncell;
-  e->E.ffheatingestimator = e->d_est + 2 * ncell;
-  e->E.colheatingestimator = e->d_est + 3 * ncell;
-  e->E.gammaestimator = e->d_est + 4 * ncell;
-  e->E.bfheatingestimator = e->d_est + 4 * ncell + ncell * g;
-  e->E.dep_estimator_gamma = e->d_est + 4 * ncell + 2 * ncell * g;
-  e->E.dep_estimator_electron = e->d_est + 5 * ncell + 2 * ncell * g;
-  e->E.dep_estimator_positron = e->d_est + 6 * ncell + 2 * ncell * g;
-  e->E.dep_estimator_alpha = e->d_est + 7 * ncell + 2 * ncell * g;
+  e->E.nuJ = e->d_est + 1;
+  e->E.ffheatingestimator = e->d_est + 2;
+  e->E.colheatingestimator = e->d_est + 3;
+  e->E.dep_estimator_gamma = e->d_est + 4;
+  e->E.dep_estimator_electron = e->d_est + 5;
+  e->E.dep_estimator_positron = e->d_est + 6;
+  e->E.dep_estimator_alpha = e->d_est + 7;
+  e->E.gammaestimator = e->d_est + 8 * ncell;
+  e->E.bfheatingestimator = e->d_est + 8 * ncell + 1;
   e->E.scalars = e->d_est + 8 * ncell + 2 * ncell * g;
   e->E.radfieldbin_J = nbinest ? e->E.scalars + ARTIS_NSCALARS : nullptr;
-  e->E.radfieldbin_nuJ = nbinest ? e->E.radfieldbin_J + nbinest : nullptr;
+  e->E.radfieldbin_nuJ = nbinest ? e->E.radfieldbin_J + 1 : nullptr;  // [cell][bin][2] {J, nuJ}
   e->E.bfrate_raw = nbfest ? e->E.scalars + ARTIS_NSCALARS + 2 * nbinest : nullptr;
   e->E.Jb_lu_raw = nlineest ? e->E.scalars + ARTIS_NSCALARS + 2 * nbinest + nbfest : nullptr;
   e->E.Jb_lu_contribcount = nlineest ? e->E.Jb_lu_raw + nlineest : nullptr;
@@ -2662,24 +2674,28 @@ int artis_amd_estimators_download(artis_amd_engine *e, artis_estimators *est) {
     if (!dst) return;
     for (int64_t i = 0; i < cnt; i++) dst[i] += s[i];
   };
-  add(est->J, src, ncell);
-  add(est->nuJ, src + ncell, ncell);
-  add(est->ffheatingestimator, src + 2 * ncell, ncell);
-  add(est->colheatingestimator, src + 3 * ncell, ncell);
-  add(est->gammaestimator, src + 4 * ncell, ncell * g);
-  add(est->bfheatingestimator, src + 4 * ncell + ncell * g, ncell * g);
-  add(est->dep_estimator_gamma, src + 4 * ncell + 2 * ncell * g, ncell);
-  add(est->dep_estimator_electron, src + 5 * ncell + 2 * ncell * g, ncell);
-  add(est->dep_estimator_positron, src + 6 * ncell + 2 * ncell * g, ncell);
-  add(est->dep_estimator_alpha, src + 7 * ncell + 2 * ncell * g, ncell);
+  auto add_strided = [](double *dst, const double *s, int64_t cnt, int64_t stride) {
+    if (!dst) return;
+    for (int64_t i = 0; i < cnt; i++) dst[i] += s[i * stride];
+  };
+  add_strided(est->J, src, ncell, 8);
+  add_strided(est->nuJ, src + 1, ncell, 8);
+  add_strided(est->ffheatingestimator, src + 2, ncell, 8);
+  add_strided(est->colheatingestimator, src + 3, ncell, 8);
+  add_strided(est->dep_estimator_gamma, src + 4, ncell, 8);
+  add_strided(est->dep_estimator_electron, src + 5, ncell, 8);
+  add_strided(est->dep_estimator_positron, src + 6, ncell, 8);
+  add_strided(est->dep_estimator_alpha, src + 7, ncell, 8);
+  add_strided(est->gammaestimator, src + 8 * ncell, ncell * g, 2);
+  add_strided(est->bfheatingestimator, src + 8 * ncell + 1, ncell * g, 2);
   add(est->scalars, src + 8 * ncell + 2 * ncell * g, ARTIS_NSCALARS);
   {
     const int64_t nbinest = ARTIS_OPT_MULTIBIN_RADFIELD_MODEL_ON ? ncell * ARTIS_OPT_RADFIELDBINCOUNT : 0;
     const int64_t nbfest = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? ncell * (int64_t)e->Mh.nbfestim : 0;
     const double *ext = src + 8 * ncell + 2 * ncell * g + ARTIS_NSCALARS;
     if (nbinest) {
-      add(est->radfieldbin_J, ext, nbinest);
-      add(est->radfieldbin_nuJ, ext + nbinest, nbinest);
+      add_strided(est->radfieldbin_J, ext, nbinest, 2);
+      add_strided(est->radfieldbin_nuJ, ext + 1, nbinest, 2);
     }
     if (nbfest) add(est->bfrate_raw, ext + 2 * nbinest, nbfest);
     const int64_t nlineest = ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON ? ncell * (int64_t)e->Mh.detailed_linecount : 0;

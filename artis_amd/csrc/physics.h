@@ -118,7 +118,7 @@ AHD void cellest_add(const EnvT &env, double *global_array, int kind, int c, dou
     return;
   }
 #endif
-  ARTIS_EST_ADD(&global_array[c], v);
+  ARTIS_EST_ADD(&global_array[(int64_t)c * env.est_stride], v);
 }
 
 template <typename EnvT>
@@ -181,6 +181,12 @@ struct Env {
   // kernel's workgroup in LDS, added to E.scalars when the kernel ends; null: global atomics. scalars_in_lds: host switch
   double *scalars_lds;
   int32_t scalars_in_lds;
+  // Layout of the per-cell estimators in HBM. On the device the eight per-cell sums {J, nuJ, ffheating, colheating,
+  // dep_gamma, dep_electron, dep_positron, dep_alpha} of a cell are ONE 64-byte record (est_stride = 8: E.J[c * 8] etc.), so that
+  // the three additions of an r-packet step (rpkt.cc:502-541) land in one sector instead of three arrays' sectors; and
+  // gammaestimator / bfheatingestimator of a (cell, ground continuum) are neighbours (pair_stride = 2). The host emulation adds
+  // into the caller's separate arrays (strides 1).
+  int32_t est_stride, pair_stride;
   // 1: macro-atom transitions are decided on the f64 rates and sums only (ARTIS_AMD_MAFILTERS=0: the filters of tables.h
   // switched off, for the test that finds the same packets either way)
   int32_t ma_filters_off;
@@ -2781,6 +2787,7 @@ struct MACtx {
   int nd, nu;               // ... its numbers of downward / upward transitions (where the record's lines are)
   int ats;                  // ... and its first entry in alltrans (where its transitions' targets are)
   int njumps;               // transitions made since the last ma_flush_stats()
+  int defer;                // ma_jump_internal<true>: the draw of a transition left to ma_jump_deferred() (bit 24: downward)
 };
 AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   MACtx k;
@@ -2793,6 +2800,7 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   k.nd = k.nu = 0;
   k.ats = 0;
   k.njumps = 0;
+  k.defer = 0;
   return k;
 }
 
@@ -2900,29 +2908,54 @@ AHD int ma_exact_search(const Env &env, int c, int ats0, int dir, int nsearch, d
   return j;
 }
 // the search of one direction of the record `rec` (level with nd / nu transitions, first entry of alltrans `ats`) with the
-// 24-bit draw u: number of the direction's cumulative sums (the last one left out) <= (u * 2^-24) * (the direction's rate)
-AHD int ma_search_dir(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u) {
-  const bool down = dir != MADIR_UP;
-  const int nsearch = (down ? k.nd : k.nu) - 1;
+// 24-bit draw u: number of the direction's cumulative sums (the last one left out) <= (u * 2^-24) * (the direction's rate).
+// On the filters; *amb: they cannot decide (the result is then meaningless).
+AHD int ma_search_filters(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u, bool *amb) {
+  const int nsearch = ((dir != MADIR_UP) ? k.nd : k.nu) - 1;
+  *amb = false;
   if (nsearch <= 0) return 0;
   const int zi = (int)(u >> 9);
-  bool amb = env.ma_filters_off != 0;
+  bool a = env.ma_filters_off != 0;
   int ti = 0;
-  for (int b0 = 0; b0 < nsearch && !amb; b0 += MAREC_PER) {
+  for (int b0 = 0; b0 < nsearch && !a; b0 += MAREC_PER) {
     const U4 f = rec[marec_slot(dir, b0 / MAREC_PER, k.nd, k.nu)];
-    const int cnt = mafilt_count(f, zi, &amb);
-    amb = amb || (f.w[3] >> 16) != MAFILT_NONE;
-    if (amb) break;
+    const int cnt = mafilt_count(f, zi, &a);
+    a = a || (f.w[3] >> 16) != MAFILT_NONE;
+    if (a) break;
     ti += cnt;
     if (cnt < MAREC_PER) break;
   }
-  if (amb) {
-    const int action = dir == MADIR_DOWN ? ARTIS_MA_ACTION_INTERNALDOWNSAME : (dir == MADIR_UP ? ARTIS_MA_ACTION_INTERNALUPSAME : ARTIS_MA_ACTION_RADDEEXC);
-    const double targetval = rng_u24_value(u) * ma_rates_of(rec, k.nd, k.nu)[action];
-    ti = ma_exact_search(env, k.c, k.ats + (down ? 0 : k.nd), dir, nsearch, targetval);
-  }
+  *amb = a;
   return ti;
 }
+// ... on the re-added sums (a draw the filters could not decide)
+AHD int ma_search_exact(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u) {
+  const bool down = dir != MADIR_UP;
+  const int action = dir == MADIR_DOWN ? ARTIS_MA_ACTION_INTERNALDOWNSAME : (dir == MADIR_UP ? ARTIS_MA_ACTION_INTERNALUPSAME : ARTIS_MA_ACTION_RADDEEXC);
+  const double targetval = rng_u24_value(u) * ma_rates_of(rec, k.nd, k.nu)[action];
+  return ma_exact_search(env, k.c, k.ats + (down ? 0 : k.nd), dir, (down ? k.nd : k.nu) - 1, targetval);
+}
+AHD int ma_search_dir(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u) {
+  bool amb;
+  const int ti = ma_search_filters(env, k, rec, dir, u, &amb);
+  return amb ? ma_search_exact(env, k, rec, dir, u) : ti;
+}
+// the internal transition to the ti-th downward / upward transition's level: the walk goes on in that level's record
+AHD void ma_take_transition(const Env &env, Pkt &p, MACtx &k, bool down, int ti) {
+  const MaTarget tg = env.M.alltrans_target[k.ats + (down ? 0 : k.nd) + ti];
+  MA_PROF_WAIT();
+  p.ma_level = tg.level;
+  k.rec = tg.rec;
+  k.ats = tg.ats;
+  k.nd = (int)(tg.ndnu & 0xFFFFu);
+  k.nu = (int)(tg.ndnu >> 16);
+}
+// DEFER: an internal transition whose search the filters cannot decide (5e-4 of them) is not made here: MA_EXIT_DEFER is
+// returned with the draw in k.defer, and the caller finishes it with ma_jump_deferred() once its transition loop is over --
+// the re-adding of the sums (exp() and divisions of the rate coefficients) stays out of the loop of a kernel that runs
+// at the edge of its registers, like the processes that end a walk.
+constexpr int MA_EXIT_DEFER = 98;
+template <bool DEFER = false>
 AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
   // index_upperbound (sn3d.h:85) over the 9 cumulative rates: action = number of cumulative values <= zrand * total,
   // clamped to the last one. Decided on the record's 16-byte filter (tables.h "FILTERS") unless the random number lies
@@ -2969,19 +3002,28 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
     // number of the direction's cumulative sums <= zrand * (the direction's rate), the last sum (= the rate) left out.
     const uint32_t u2 = rng_u24(p);
     MA_PROF_MARK(env, 60);
-    const int ti = ma_search_dir(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2);
+    bool amb;
+    int ti = ma_search_filters(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2, &amb);
+    if (amb) {
+      if (DEFER) {
+        k.defer = (int)(u2 | (down ? 0x1000000u : 0u));
+        return MA_EXIT_DEFER;
+      }
+      ti = ma_search_exact(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2);
+    }
     MA_PROF_MARK(env, 61);
-    const MaTarget tg = env.M.alltrans_target[k.ats + (down ? 0 : k.nd) + ti];
-    MA_PROF_WAIT();
+    ma_take_transition(env, p, k, down, ti);
     MA_PROF_MARK(env, 62);
-    p.ma_level = tg.level;
-    k.rec = tg.rec;
-    k.ats = tg.ats;
-    k.nd = (int)(tg.ndnu & 0xFFFFu);
-    k.nu = (int)(tg.ndnu >> 16);
     return -1;
   }
   return action;
+}
+// the second half of a transition that ma_jump_internal<true>() left undecided (MA_EXIT_DEFER): `rec` and k still describe
+// the level the draw was made in
+AHD void ma_jump_deferred(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
+  const bool down = (k.defer & 0x1000000) != 0;
+  const int ti = ma_search_exact(env, k, rec, down ? MADIR_DOWN : MADIR_UP, (uint32_t)k.defer & 0xFFFFFFu);
+  ma_take_transition(env, p, k, down, ti);
 }
 // `rec`: the record the action was drawn from (the packet's current level: k still describes it)
 AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const U4 *rec, int action) {
@@ -3206,8 +3248,8 @@ AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double d
     const int b = radbin_select(nu_cmf);
     if (b >= 0) {
       const int64_t k = ((int64_t)c * ARTIS_OPT_RADFIELDBINCOUNT) + b;
-      ARTIS_EST_ADD(&env.E.radfieldbin_J[k], de);
-      ARTIS_EST_ADD(&env.E.radfieldbin_nuJ[k], de * nu_cmf);
+      ARTIS_EST_ADD(&env.E.radfieldbin_J[k * env.pair_stride], de);  // ({J, nuJ} of a bin: neighbours on the device)
+      ARTIS_EST_ADD(&env.E.radfieldbin_nuJ[k * env.pair_stride], de * nu_cmf);
     }
   }
 #endif
@@ -3226,10 +3268,10 @@ AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double d
     const int64_t k = ((int64_t)c * nbfg) + i;
     const double contr = wsv[j];
 #if ARTIS_OPT_USE_LUT_PHOTOION
-    ARTIS_EST_ADD(&env.E.gammaestimator[k], contr * (de / nu_cmf));
+    ARTIS_EST_ADD(&env.E.gammaestimator[k * env.pair_stride], contr * (de / nu_cmf));
 #endif
 #if ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
-    ARTIS_EST_ADD(&env.E.bfheatingestimator[k], contr * de * (1. - (nu_edge / nu_cmf)));
+    ARTIS_EST_ADD(&env.E.bfheatingestimator[k * env.pair_stride], contr * de * (1. - (nu_edge / nu_cmf)));
 #endif
   }
 #endif
@@ -3845,7 +3887,7 @@ AHD void do_gamma(const Env &env, Pkt &p, int64_t pi) {
   if (p.type != ARTIS_TYPE_GAMMA && p.type != ARTIS_TYPE_ESCAPE) {
     if (!ARTIS_GAMMAPRODUCTS) scalar_add(env, ARTIS_SCALAR_GAMMA_DEP_DISCRETE, p.e_cmf);
     const int c = env.M.propcell_nonemptymgi[p.cellindex];  // no transport: the path estimator is fed here (gammapkt.cc:930)
-    if (c >= 0) ARTIS_EST_ADD(&env.E.dep_estimator_gamma[c], p.e_cmf);
+    if (c >= 0) ARTIS_EST_ADD(&env.E.dep_estimator_gamma[(int64_t)c * env.est_stride], p.e_cmf);
   }
 }
 #else
@@ -4041,17 +4083,17 @@ AHD void do_nonthermal_predeposit(const Env &env, Pkt &p, int64_t pi) {
 #endif
   if (env.P.cold[pi].originated_particle != 0) {
     if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAMINUS) {
-      ARTIS_EST_ADD(&env.E.dep_estimator_electron[c], e_cmf_deposited);
+      ARTIS_EST_ADD(&env.E.dep_estimator_electron[(int64_t)c * env.est_stride], e_cmf_deposited);
       if (p.type == deposit_type) scalar_add(env, ARTIS_SCALAR_ELECTRON_DEP_DISCRETE, p.e_cmf);
     } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_BETAPLUS) {
-      ARTIS_EST_ADD(&env.E.dep_estimator_positron[c], e_cmf_deposited);
+      ARTIS_EST_ADD(&env.E.dep_estimator_positron[(int64_t)c * env.est_stride], e_cmf_deposited);
       if (p.type == deposit_type) scalar_add(env, ARTIS_SCALAR_POSITRON_DEP_DISCRETE, p.e_cmf);
     } else if (priortype == ARTIS_TYPE_NONTHERMAL_PREDEPOSIT_ALPHA) {
-      ARTIS_EST_ADD(&env.E.dep_estimator_alpha[c], e_cmf_deposited);
+      ARTIS_EST_ADD(&env.E.dep_estimator_alpha[(int64_t)c * env.est_stride], e_cmf_deposited);
       if (p.type == deposit_type) scalar_add(env, ARTIS_SCALAR_ALPHA_DEP_DISCRETE, p.e_cmf);
     }
   } else if (ARTIS_GAMMAPRODUCTS) {  // update_packets.cc:174: products of gamma rays count as gamma deposition
-    ARTIS_EST_ADD(&env.E.dep_estimator_gamma[c], e_cmf_deposited);
+    ARTIS_EST_ADD(&env.E.dep_estimator_gamma[(int64_t)c * env.est_stride], e_cmf_deposited);
     if (p.type == ARTIS_TYPE_NTLEPTON_DEPOSITED) scalar_add(env, ARTIS_SCALAR_GAMMA_DEP_DISCRETE, p.e_cmf);
   }
 }

@@ -36,16 +36,18 @@ def allreduce_estimators(block, dist=None):
 
 
 def flatten_estimators(est) -> np.ndarray:
-    """Host estimators in the engine's block order
-    [J | nuJ | ffheating | colheating | gamma | bfheating | dep_gamma | dep_electron | dep_positron | dep_alpha | scalars],
-    followed in nltenebular builds by [radfieldbin_J | radfieldbin_nuJ | bfrate_raw] and, with detailed line estimators,
-    by [Jb_lu_raw | Jb_lu_contribcount] (the counts as f64, like the engine's device block: one all-reduce covers it); in
-    VPKT_ON builds by [vspecpol | vgrid_flux] (vpkt.cc sums them over the ranks when it writes the spectra)."""
-    parts = [est.J, est.nuJ, est.ffheatingestimator, est.colheatingestimator, est.gammaestimator,
-             est.bfheatingestimator, est.dep_estimator_gamma, est.dep_estimator_electron,
-             est.dep_estimator_positron, est.dep_estimator_alpha, est.scalars]
+    """Host estimators in the engine's block order (artis_engine.hip engine_fill; physics.h Env::est_stride):
+    [cell][8]{J, nuJ, ffheating, colheating, dep_gamma, dep_electron, dep_positron, dep_alpha} -- the per-cell sums of a cell in
+    one 64-byte record -- | [cell][ground continuum][2]{gamma, bfheating} | scalars,
+    followed in nltenebular builds by [cell][bin][2]{radfieldbin_J, radfieldbin_nuJ} | bfrate_raw and, with detailed line
+    estimators, by [Jb_lu_raw | Jb_lu_contribcount] (the counts as f64, like the engine's device block: one all-reduce covers it);
+    in VPKT_ON builds by [vspecpol | vgrid_flux] (vpkt.cc sums them over the ranks when it writes the spectra)."""
+    percell = np.stack([est.J, est.nuJ, est.ffheatingestimator, est.colheatingestimator, est.dep_estimator_gamma,
+                        est.dep_estimator_electron, est.dep_estimator_positron, est.dep_estimator_alpha], axis=1).ravel()
+    pairs = np.stack([est.gammaestimator, est.bfheatingestimator], axis=1).ravel()
+    parts = [percell, pairs, est.scalars]
     if getattr(est, "extended", False):
-        parts += [est.radfieldbin_J, est.radfieldbin_nuJ, est.bfrate_raw]
+        parts += [np.stack([est.radfieldbin_J, est.radfieldbin_nuJ], axis=1).ravel(), est.bfrate_raw]
     if getattr(est, "lineest", False):
         parts += [est.Jb_lu_raw, est.Jb_lu_contribcount.astype(np.float64)]
     if getattr(est, "vpkt", False):  # the observers' spectra (and the velocity-grid map when it is on) of a VPKT_ON build

@@ -386,9 +386,11 @@ def _zone_massfracs(elements, v, vmax):
 
 def make_grid_and_cells(atomic: dict, ncoord: int = 8, gridtype: int = abi.GRID_CARTESIAN3D, t_days: float = 20.0,
                         tmin_days: float = 2.0, vmax: float = 2.4e9, mass_msun: float = 1.38, ve: float = 2.7e8,
-                        thick_below_v: float = 0.0, seed: int = 7):
+                        thick_below_v: float = 0.0, seed: int = 7, uniform_te: dict | None = None):
     """W7-like ejecta on an ncoord^3 Cartesian grid (or ncoord radial shells): exponential density profile,
-    stratified composition, Saha ion balance at (T_e, nne). Returns (grid dict, cellstate dict, aux)."""
+    stratified composition, Saha ion balance at (T_e, nne). Returns (grid dict, cellstate dict, aux).
+    uniform_te = dict(T=..., rho=...): every cell in strict thermodynamic equilibrium instead -- one density, T_e = T_R = T_J = T,
+    W = 1, Saha-Boltzmann populations at T, unit photoionisation renormalisation (tests/test_physics_laws.py)."""
     rng = np.random.default_rng(seed)
     elements = atomic["_elements"]
     nelements = len(elements)
@@ -455,6 +457,10 @@ def make_grid_and_cells(atomic: dict, ncoord: int = 8, gridtype: int = abi.GRID_
     W = np.clip(W, 1e-3, 1.0)
     thick = (v < thick_below_v).astype(np.int32)
     W = np.where(thick == 1, 1.0, W)
+    if uniform_te is not None:
+        rho = np.full(nne_cells, float(uniform_te["rho"]))
+        Te = np.full(nne_cells, float(uniform_te["T"]))
+        TR, TJ, W = Te.copy(), Te.copy(), np.ones(nne_cells)
 
     X = _zone_massfracs(elements, v, vmax)  # [cells, elements]
     amass = np.array([_AMASS.get(Z, 2.0 * Z) for Z, _, _ in elements])
@@ -500,6 +506,8 @@ def make_grid_and_cells(atomic: dict, ncoord: int = 8, gridtype: int = abi.GRID_
 
     nbfg = atomic["nbfcontinua_ground"]
     renorm = 0.8 + 0.4 * rng.random((nne_cells, max(nbfg, 1)))
+    if uniform_te is not None:
+        renorm = np.ones((nne_cells, max(nbfg, 1)))
 
     grid = dict(gridtype=gridtype, ncoordgrid=ncoordgrid, ngrid=int(ngrid), npts_nonempty=nne_cells, tmin=float(tmin),
                 vmax=float(vmax), rmax=float(rmax), coord_pos_min_tmin=coord, propcell_nonemptymgi=propcell_nonemptymgi)

@@ -127,8 +127,12 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=160_000)
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--options", default="classic", choices=("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal"),
-                    help="options preset of include/artis_options.h (the reference's artisoptions_*.h)")
+    ap.add_argument("--options", default="classic", choices=("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal",
+                                                             "kilonova_expopac", "classic_expopac_therm", "ci_classic_vpkt", "ci_classic_vpkt_expopac"),
+                    help="options preset of include/artis_options.h (the reference's artisoptions_*.h; the expansion-opacity builds of "
+                         "BASELINE.json configs[3]'s text; the reference's classic CI set-up with virtual packets)")
+    ap.add_argument("--t-days", type=float, default=20.0,
+                    help="time of the timestep (a VPKT_ON build traces virtual packets inside its spectra window only: synth.vpkt_config 3-8 d)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -150,7 +154,7 @@ def main():
 
     t_setup = time.perf_counter()
     gridtype = {"1d": abi.GRID_SPHERICAL1D, "2d": abi.GRID_CYLINDRICAL2D, "3d": abi.GRID_CARTESIAN3D}[args.grid]
-    model, cs, ts, aux = synth.build(args.preset, ncoord=args.ncoord, gridtype=gridtype, options=args.options)
+    model, cs, ts, aux = synth.build(args.preset, ncoord=args.ncoord, gridtype=gridtype, options=args.options, t_days=args.t_days)
     # packet seeds: the reference's per-rank spacing (input.cc:1912: rank_seed_base = seed + rank * npackets)
     if args.packets_total > 0:  # get_range_chunk (mpi_logging.h:158): nearly equal contiguous shares of one global population
         from artis_amd import dist as adist
@@ -390,7 +394,7 @@ def main():
                                    f"(line-by-line Sobolev + macro-atom + k-packets), "
                                    + (f"{args.packets_total} packets over {world} GPU(s)" if args.packets_total > 0 else f"{args.packets} packets per GPU")
                                    + f", synthetic atomic data '{args.preset}' ({model['nlines']} lines, {model['nlevels']} levels, "
-                                   f"{model['nions']} ions), one timestep at t=20 d (dt/t=0.05)",
+                                   f"{model['nions']} ions), one timestep at t={args.t_days:g} d (dt/t=0.05)",
                        "options": args.options,
                        "packets_per_gpu": args.packets, "nonempty_cells": int(model["npts_nonempty"]),
                        "packet_steps_per_step": steps_all, "setup_s": round(setup_s, 1),

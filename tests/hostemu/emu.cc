@@ -78,6 +78,8 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   e.env.gamma_gi = e.ws_gi.data();
   e.env.gamma_n = e.ws_n.data();
   e.env.errflag = &e.err;
+  e.env.est_stride = 1;  // the caller's separate arrays
+  e.env.pair_stride = 1;
   // ARTIS_EMU_MAFILTERS=0: every macro-atom and cooling decision on the re-added f64 sums (the path of an undecided draw)
   if (const char *b = std::getenv("ARTIS_EMU_MAFILTERS")) e.env.ma_filters_off = (std::atoi(b) == 0) ? 1 : 0;
   e.env.tile_lo = 0;

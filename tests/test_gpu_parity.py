@@ -35,6 +35,9 @@ BIG_CASES = {
     # records and k_bfest_dense at the bench's packet density, against the oracle (smaller: its per-step work is ~15x)
     "nltenebular_50cubed_dense_6e4": dict(build=dict(preset="w7", ncoord=50, options="nltenebular", nts=13), npk=60_000,
                                           pkw=dict(kpkt_fraction=0.02), dense_cells=500),
+    # ... and for the kilonova_lte build (configs[3]'s packet-path options on the bench grid; round 4)
+    "kilonova_lte_50cubed_dense_1e5": dict(build=dict(preset="w7", ncoord=50, options="kilonova_lte"), npk=100_000,
+                                           pkw=dict(kpkt_fraction=0.02), dense_cells=800),
 }
 
 

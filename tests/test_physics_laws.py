@@ -21,6 +21,18 @@ evaluated on the packets the engine returns (GPU, `-m gpu`) and on the kernel bo
 9. Lorentz transformation of an emission (vectors.h:70 angle_ab, :91 calculate_doppler_nucmf_on_nurf; kpkt.cc:495-560 and
    macroatom.cc:283-330 emit isotropically in the comoving frame): matter moving with beta = v/c radiates, seen from the
    rest frame, the momentum beta * E / c along v and the energy E (1 + O(beta^2)): sum(e_rf dir.beta) = sum(e_cmf beta^2).
+10. Reciprocity of the macro-atom in thermodynamic equilibrium (macroatom.cc:64-190 rate coefficients, :385-577 the walk;
+   kpkt.cc:57-260 the thermal pool). With LTE populations, T_R = T_e = T_J and W = 1 every process balances its inverse, the
+   macro-atom's internal "conductances" n_i R_ij eps are symmetric, and energy absorbed in line a and re-emitted in line e
+   flows at the same rate as from e to a (Lucy 2002): N(a -> e) = N(e -> a) for Planck-distributed packets -- for every pair
+   of lines, whatever lies between (internal jumps up and down, collisional de-excitation into the thermal pool and back,
+   ionisation and recombination). Would catch a wrong Boltzmann or statistical-weight factor in any rate coefficient, a
+   missing stimulated term, a channel drawn with the wrong weight: none of the macro-atom's rates is pinned otherwise.
+11. The photon number of a packet and the energy in the Hubble flow: e_cmf / nu_cmf = e_rf / nu_rf for every r-packet (both
+   transform with one Doppler factor, vectors.h:91), and e_cmf * t is conserved by every step of the path -- free flight in
+   homologous expansion, scattering, the macro-atom and the thermal pool (kpkt.cc:441 e_cmf *= t / t_new) -- to the first
+   order in v/c: sum(e_cmf t) after a timestep equals the sum before within (v/c)(dt/t). Would catch an energy leak, a missing
+   adiabatic loss, an emission in the wrong frame.
 Each would catch a misreading of the transport loop that oracle and kernels share (same hand, same reading): a wrong
 phase function or frame, a wrong sampling law, a channel that is drawn with the wrong weight.
 """
@@ -319,6 +331,109 @@ def _check_emission_aberration(backend, n):
     assert abs(momentum - 1.) < 4 * sigma + 3 * beta2.mean(), (momentum, sigma, m)  # (no aberration: 0; the wrong sign: -1)
     energy = pk["e_rf"][em].sum() / pk["e_cmf"][em].sum() - 1.
     assert abs(energy) < 4 * np.sqrt(beta2.mean() / 3 / m) + 2 * beta2.mean(), (energy, beta2.mean())
+
+
+def _te_medium(T=11000., rho=3e-14, ncoord=4, width_frac=5e-4):
+    """every cell in strict thermodynamic equilibrium (synth.make_grid_and_cells uniform_te). A SHORT timestep: only a packet's
+    last absorption and emission are recorded, and with dt/t = 2e-3 a tenth of the re-emitted packets meet another line before
+    the step ends -- which ones depends on the emitting line, a bias of several per cent per pair (measured: chi2 246 over 118
+    pairs); with 5e-4 the pairs are clean (53 over 70 at 8e6 packets)"""
+    p = synth.PRESETS["small"]
+    atomic = synth.make_atomic(seed=3, elements=p[0], nlevels_per_ion=p[1], line_fraction=0.6, nphixspoints=p[3])
+    grid, cells, aux = synth.make_grid_and_cells(atomic, ncoord=ncoord, uniform_te=dict(T=T, rho=rho))
+    md = {k: v for k, v in atomic.items() if not k.startswith("_")}
+    md.update(grid)
+    model, cs = abi.Model(md), abi.CellState(cells)
+    ts = synth.make_timestep(aux["t"], width_frac=width_frac, vmax=grid["vmax"])
+    return model, cs, ts, aux, T
+
+
+def _planck_packets(model, aux, n, T, rng):
+    """equal-energy r-packets of a Planck field: nu drawn from B_nu(T) (x^3 / (e^x - 1): the sum of four exponential
+    variates over a geometric index), in the inner cells, isotropic"""
+    nc = int(model.d["ncoordgrid"][0])
+    inner = [ix + nc * (iy + nc * iz) for ix in (nc // 2 - 1, nc // 2) for iy in (nc // 2 - 1, nc // 2) for iz in (nc // 2 - 1, nc // 2)]
+    # x^3/(e^x-1) = sum_k x^3 e^{-kx}: pick k with weight 1/k^4, then x = Gamma(4)/k
+    k = np.arange(1, 60)
+    w = 1.0 / k**4
+    kk = rng.choice(k, size=n, p=w / w.sum())
+    x = rng.gamma(4.0, 1.0, size=n) / kk
+    nu = x * 1.380658e-16 * T / 6.6260755e-27
+    parts = [_rpackets(model, aux, c, n // len(inner), 1.0, rng, margin=0.02) for c in inner]
+    pk = np.concatenate(parts)
+    nu = nu[:len(pk)]
+    f = nu / pk["nu_cmf"]
+    pk["nu_cmf"] *= f
+    pk["nu_rf"] *= f
+    pk["number"] = np.arange(len(pk))
+    abi.seed_packet_rng(pk, 777)
+    return pk
+
+
+def _check_te_reciprocity(backend, n):
+    model, cs, ts, aux, T = _te_medium()
+    rng = np.random.default_rng(21)
+    pk = _planck_packets(model, aux, n, T, rng)
+    backend(model, cs, ts, pk)
+    nlines = model["nlines"]
+    nu_line = np.asarray(model.d["line_nu"])
+    sel = (pk["type"] == abi.TYPE_RPKT) & (pk["absorptiontype"] >= 0) & (pk["absorptiontype"] < nlines) & (pk["emissiontype"] >= 0)
+    a, e = pk["absorptiontype"][sel].astype(np.int64), pk["emissiontype"][sel].astype(np.int64)
+    assert len(a) > n // 1000, len(a)
+    N = np.zeros((nlines, nlines))
+    np.add.at(N, (a, e), 1.0)
+    off = N.copy()
+    np.fill_diagonal(off, 0.)
+    assert off.sum() > 0.2 * len(a)  # not resonance scattering alone: the walks do redistribute
+    up = off[nu_line[None, :] > nu_line[:, None]].sum()    # re-emitted bluewards of the absorbing line ...
+    down = off[nu_line[None, :] < nu_line[:, None]].sum()  # ... and redwards: equal in equilibrium
+    assert abs(up - down) < 4.5 * np.sqrt(up + down) + 0.01 * (up + down), (up, down)
+    S, D = off + off.T, off - off.T
+    iu = np.triu_indices(nlines, 1)
+    big = S[iu] >= 60
+    z = D[iu][big] / np.sqrt(S[iu][big])
+    K = int(big.sum())
+    assert K >= 8, K
+    chi2 = float((z * z).sum())
+    assert chi2 < K + 5 * np.sqrt(2. * K) + 0.15 * K, (chi2, K)  # pair by pair: N(a -> e) = N(e -> a)
+    assert np.abs(z).max() < 5.5, np.abs(z).max()
+    # (the test has teeth: with T_R = 0.8 T_e the same packets give up : down = 8774 : 10093)
+    return up, down, chi2, K
+
+
+def _check_hubble_flow_energy(backend, n):
+    model, cs, ts, aux = synth.build("small", ncoord=6, width_frac=0.05)
+    pk = synth.make_packets(model, aux, n, kpkt_fraction=0.3, seed=31)
+    before = (pk["e_cmf"] * pk["prop_time"]).sum()
+    backend(model, cs, ts, pk)
+    r = (pk["type"] == abi.TYPE_RPKT) | (pk["type"] == abi.TYPE_ESCAPE)
+    assert r.sum() > n // 2
+    photons_cmf, photons_rf = pk["e_cmf"][r] / pk["nu_cmf"][r], pk["e_rf"][r] / pk["nu_rf"][r]
+    assert np.abs(photons_cmf / photons_rf - 1.).max() < 1e-12, np.abs(photons_cmf / photons_rf - 1.).max()
+    # an escaped packet keeps the time and energy of its escape; everything else has been advanced to the end of the step
+    after = (pk["e_cmf"] * np.where(pk["type"] == abi.TYPE_ESCAPE, pk["escape_time"], pk["prop_time"])).sum()
+    beta_max = model.d["vmax"] / CLIGHT
+    assert abs(after / before - 1.) < beta_max * 0.05 + 2e-3, after / before
+    assert abs(after / before - 1.) > 0. or n < 10
+
+
+def test_macroatom_reciprocity_in_equilibrium_kernel_bodies():
+    _check_te_reciprocity(_backend_emu, 2_400_000)
+
+
+def test_photon_number_and_hubble_flow_energy_kernel_bodies():
+    _check_hubble_flow_energy(_backend_emu, 20000)
+
+
+@pytest.mark.gpu
+def test_macroatom_reciprocity_in_equilibrium_engine():
+    up, down, chi2, K = _check_te_reciprocity(_backend_gpu, 16_000_000)
+    print(f"TE reciprocity: {up:.0f} up, {down:.0f} down, chi2 {chi2:.1f} over {K} pairs")
+
+
+@pytest.mark.gpu
+def test_photon_number_and_hubble_flow_energy_engine():
+    _check_hubble_flow_energy(_backend_gpu, 400000)
 
 
 def test_thomson_phase_function_kernel_bodies():

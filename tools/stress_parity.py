@@ -20,7 +20,8 @@ ncoord = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 presets = sys.argv[3].split(",") if len(sys.argv) > 3 else ["classic", "kilonova_lte"]
 for preset in presets:
     for gridtype in (abi.GRID_CARTESIAN3D, abi.GRID_CYLINDRICAL2D, abi.GRID_SPHERICAL1D):
-        model, cs, ts, aux = synth.build("w7", ncoord=ncoord, gridtype=gridtype, options=preset)
+        # (a VPKT_ON preset traces virtual packets inside its spectra window only, synth.vpkt_config: 3-8 d)
+        model, cs, ts, aux = synth.build("w7", ncoord=ncoord, gridtype=gridtype, options=preset, t_days=5.0 if "vpkt" in preset else 20.0)
         pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=0.1, gamma_fraction=0.1, pellet_fraction=0.2)
         n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
         pa, pb = pk0.copy(), pk0.copy()
@@ -36,6 +37,9 @@ for preset in presets:
         parity.compare_stats(eb, ea, preset, same_libm=False)
         parity.compare_estimators(eb, ea, 1e-9, preset)
         steps = int(ea.stats[abi.STAT_X_RPKT_STEPS] + ea.stats[abi.STAT_X_KPKT_STEPS])
+        if "vpkt" in preset:
+            assert ea.stats[48] > 0, "no virtual packet was traced"  # ARTIS_STAT_X_VPKT_CREATED
+            print(f"  virtual packets: {int(ea.stats[48])} created, {int(ea.stats[49] + ea.stats[50] + ea.stats[51])} escaped", flush=True)
         print(f"{preset} grid {gridtype}: {npk} packets, {steps} packet-steps, {int(ea.stats[abi.STAT_X_MA_JUMPS])} transitions: "
               f"identical integer fields and counters, worst float rel diff {rep['worst_rel']:.2e} "
               f"(oracle {t1 - t0:.0f} s, engine {t2 - t1:.1f} s)", flush=True)
