@@ -1076,14 +1076,34 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
 #ifndef ARTIS_MA_DEFER_EXACT
 #define ARTIS_MA_DEFER_EXACT 1  // the re-adding of a search's sums outside the transition loop (physics.h ma_jump_internal<true>)
 #endif
-template <int TB>
-__global__ void __launch_bounds__(TB, ARTIS_THERMAL_EU) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
+// TABLES_LDS: the two static tables a transition's target is read from -- the target level of every entry of alltrans
+// (2 bytes) and the LevelPack of every level (16 bytes) -- are copied into LDS once per workgroup (one workgroup of 1024
+// threads per CU: the same 4 waves/SIMD at 128 VGPRs), and a transition reads its target with two ds_reads instead of a
+// 16-byte gather from the static target table in L2: of a transition's three dependent reads (action filter; the
+// direction's filter, in the sector the first one brought; the target) one long wait is left. For atomic data whose
+// tables fit (MA_LDS_LEVELS / MA_LDS_TRANS: the bench's 1567 levels and 27 238 entries take 80 KB); larger data keep the
+// target table in HBM. Static tables, the same for every cell: nothing to stage per cell (what lost in rounds 2-3).
+constexpr int MA_LDS_LEVELS = 2048;   // 32 KB
+constexpr int MA_LDS_TRANS = 32768;   // 64 KB
+template <int TB, bool TABLES_LDS>
+__global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                      unsigned long long *gstats, int budget, int32_t *cursors,
                                                                      int nchunks, int chunk_mode, int drain_budget) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ double lds_cellest[THERMAL_CELLEST_CAP];
+  __shared__ LevelPack lds_levelpack[TABLES_LDS ? MA_LDS_LEVELS : 1];
+  __shared__ uint16_t lds_tlevel[TABLES_LDS ? MA_LDS_TRANS : 8];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   cellest_begin(env, lds_cellest, env.cellest_n_t, TB, env.E.colheatingestimator);
+  if (TABLES_LDS) {
+    for (int i = threadIdx.x; i < env.M.nlevels; i += TB) lds_levelpack[i] = env.M.level_pack[i];
+    const uint32_t *src = (const uint32_t *)env.M.alltrans_tlevel16;  // (the allocation is padded to whole words)
+    uint32_t *dst = (uint32_t *)lds_tlevel;
+    for (int i = threadIdx.x; i < (env.M.nalltrans + 1) / 2; i += TB) dst[i] = src[i];
+    env.M.level_pack = lds_levelpack;
+    env.M.alltrans_tlevel16 = lds_tlevel;
+    env.ma_tables_in_lds = 1;
+  }
   __syncthreads();
   env.stats = lstats;
   const double ts_end = env.S.ts_end;
@@ -1466,6 +1486,7 @@ struct artis_amd_engine {
                              // measured +7 %: like every finer chunking it puts more cells in flight per XCD
   bool cont_lds = true;      // k_rpkt keeps the static continuum table (ContPack) in LDS when it fits (ARTIS_AMD_CONTLDS=0: HBM)
   int thermal_blocks_per_cu = ARTIS_THERMAL_WAVES;  // tuning: resident k_thermal blocks per CU
+  bool ma_tables_lds = true;  // k_thermal<1024, true>: the static target tables in LDS when they fit (ARTIS_AMD_MATABLES_LDS=0: in HBM)
   // the population's scratch: the collisional-excitation cooling terms of `pop_batch` cells at a time (k_matrans writes them,
   // k_cooling_chain turns them into running sums, k_collexc_filter into the records' cooling filters; nothing of it is kept)
   double *d_collexc_terms = nullptr;
@@ -1980,6 +2001,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_CUCHUNKS_T")) e->cu_chunks_t = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_CONTLDS")) e->cont_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TILE_ZIGZAG")) e->tile_zigzag = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_MATABLES_LDS")) e->ma_tables_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_FILL")) e->sparse_fill = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_MAX")) e->sparse_max_listed = std::max(0, std::atoi(b));
   {
@@ -2596,7 +2618,12 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
           // (drain: only where the next thermal launch will be large too, so that what is handed on runs beside a full list)
           const int bud_t = (e->budget_t_small > 0 && nk < e->small_list) ? std::min(e->budget_t_small, e->budget_t) : e->budget_t;
           const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : bud_t;
-          hipLaunchKernelGGL((k_thermal<ARTIS_THERMAL_TB>), dim3(grid), dim3(ARTIS_THERMAL_TB), 0, s, env, lst, nk, next, e->d_stats, bud_t,
+          if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS && e->Mh.nalltrans <= MA_LDS_TRANS && nk >= 4096) {
+            const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
+            hipLaunchKernelGGL((k_thermal<1024, true>), dim3(grid1), dim3(1024), 0, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
+                               e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
+          } else
+          hipLaunchKernelGGL((k_thermal<ARTIS_THERMAL_TB, false>), dim3(grid), dim3(ARTIS_THERMAL_TB), 0, s, env, lst, nk, next, e->d_stats, bud_t,
                              e->d_cursors, per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (ARTIS_THERMAL_TB / 64)) : 8), per_cu ? 2 : 0, drain);
         }
       } else if (kind == NEXT_BB) {

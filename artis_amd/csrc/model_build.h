@@ -21,6 +21,7 @@ struct ModelOwned {
   std::vector<int32_t> scanchunk_start, scanblk_chunk0;
   std::vector<MaLongSeg> malongsegs;
   std::vector<MaTarget> alltrans_target;
+  std::vector<uint16_t> alltrans_tlevel16;
   std::vector<CoolLineRef> coollines;
   std::vector<ContPack> cont_pack;
   std::vector<int32_t> expopac_linestart;
@@ -63,6 +64,7 @@ struct ModelOwned {
   X(scanblk_chunk0, int32_t, ((m).nscanblk + 1))                                   \
   X(malongsegs, MaLongSeg, ((m).nmalongsegs > 0 ? (m).nmalongsegs : 1))            \
   X(alltrans_target, MaTarget, (m).nalltrans)                                      \
+  X(alltrans_tlevel16, uint16_t, (m).nalltrans)                                    \
   X(coollines, CoolLineRef, ((m).ncoollines > 0 ? (m).ncoollines : 1))             \
   X(alltrans_einstein_A, float, (m).nalltrans)                                     \
   X(alltrans_coll_str, float, (m).nalltrans)                                       \
@@ -218,6 +220,9 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
     }
   }
   v.alltrans_target = own.alltrans_target.data();
+  own.alltrans_tlevel16.assign((size_t)(m.nalltrans > 0 ? m.nalltrans : 1), 0);
+  for (int i = 0; i < m.nalltrans; i++) own.alltrans_tlevel16[i] = (uint16_t)m.alltrans_targetlevelindex[i];
+  v.alltrans_tlevel16 = own.alltrans_tlevel16.data();
   own.level_upcum_start.resize(m.nlevels);
   int32_t nupcum = 0;
   for (int i = 0; i < m.nlevels; i++) {

@@ -169,6 +169,7 @@ struct Env {
   // filters (k_collexc_filter); not kept
   double *collexc_terms;
   int32_t cont_in_lds;  // M.cont_pack points into LDS (k_rpkt<true>)
+  int32_t ma_tables_in_lds;  // M.level_pack and M.alltrans_tlevel16 point into LDS (k_thermal<.., true>)
   // Per-cell estimators of a model with FEW cells (1D / 2D models, small grids): every packet of the launch adds to one of
   // a few addresses, and device-wide atomics on one address are serialised in memory (measured, 30 shells, 1e7 packets:
   // k_thermal 2330 ms with its one atomic per walk on colheatingestimator[cell], 590 ms without it). A workgroup then
@@ -2942,6 +2943,18 @@ AHD int ma_search_dir(const Env &env, const MACtx &k, const U4 *rec, int dir, ui
 }
 // the internal transition to the ti-th downward / upward transition's level: the walk goes on in that level's record
 AHD void ma_take_transition(const Env &env, Pkt &p, MACtx &k, bool down, int ti) {
+  if (env.ma_tables_in_lds) {
+    // the same information from two small static tables that the kernel has copied into LDS (k_thermal<.., true>): the
+    // transition's target level (2 bytes), then that level's LevelPack -- two LDS reads instead of one trip to L2
+    const int tl = env.M.alltrans_tlevel16[k.ats + (down ? 0 : k.nd) + ti];
+    const LevelPack lp = env.M.level_pack[k.start + tl];
+    p.ma_level = tl;
+    k.rec = lp.rec_off;
+    k.ats = lp.alltrans_startdown;
+    k.nd = lp.ndown;
+    k.nu = lp.nup;
+    return;
+  }
   const MaTarget tg = env.M.alltrans_target[k.ats + (down ? 0 : k.nd) + ti];
   MA_PROF_WAIT();
   p.ma_level = tg.level;

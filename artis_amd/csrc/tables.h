@@ -183,6 +183,9 @@ struct DevModel {
   const MaLongSeg *malongsegs;  // derived: the segments longer than a chunk, [nmalongsegs]
   int32_t nmalongsegs;
   const MaTarget *alltrans_target;  // derived: [nalltrans] what a transition needs to know of the level it leads to
+  // derived: [nalltrans] the target level alone (index within the ion), 2 bytes: with level_pack the same information in two
+  // small static tables that fit the LDS of a compute unit for atomic data of the bench's size (k_thermal<.., true>)
+  const uint16_t *alltrans_tlevel16;
   const CoolLineRef *coollines;     // derived: every line of every level's cooling filter, [ncoollines]
   int32_t ncoollines;
   const float *alltrans_einstein_A, *alltrans_coll_str, *alltrans_osc_strength;
