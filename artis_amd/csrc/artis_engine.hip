@@ -1083,25 +1083,31 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
 // direction's filter, in the sector the first one brought; the target) one long wait is left. For atomic data whose
 // tables fit (MA_LDS_LEVELS / MA_LDS_TRANS: the bench's 1567 levels and 27 238 entries take 80 KB); larger data keep the
 // target table in HBM. Static tables, the same for every cell: nothing to stage per cell (what lost in rounds 2-3).
+// TABLES_LDS = 2: atomic data whose alltrans table does not fit (the 110 860-line set: 221 720 entries) keep the 2-byte target
+// levels in HBM (443 KB instead of the 3.5 MB of 16-byte targets: L2-resident beside the cells' records) and the LevelPack
+// table alone in LDS (up to MA_LDS_LEVELS2 levels).
 constexpr int MA_LDS_LEVELS = 2048;   // 32 KB
 constexpr int MA_LDS_TRANS = 32768;   // 64 KB
-template <int TB, bool TABLES_LDS>
+constexpr int MA_LDS_LEVELS2 = 6144;  // 96 KB
+template <int TB, int TABLES_LDS>
 __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                      unsigned long long *gstats, int budget, int32_t *cursors,
                                                                      int nchunks, int chunk_mode, int drain_budget) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ double lds_cellest[THERMAL_CELLEST_CAP];
-  __shared__ LevelPack lds_levelpack[TABLES_LDS ? MA_LDS_LEVELS : 1];
-  __shared__ uint16_t lds_tlevel[TABLES_LDS ? MA_LDS_TRANS : 8];
+  __shared__ LevelPack lds_levelpack[TABLES_LDS == 1 ? MA_LDS_LEVELS : (TABLES_LDS == 2 ? MA_LDS_LEVELS2 : 1)];
+  __shared__ uint16_t lds_tlevel[TABLES_LDS == 1 ? MA_LDS_TRANS : 8];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   cellest_begin(env, lds_cellest, env.cellest_n_t, TB, env.E.colheatingestimator);
   if (TABLES_LDS) {
     for (int i = threadIdx.x; i < env.M.nlevels; i += TB) lds_levelpack[i] = env.M.level_pack[i];
-    const uint32_t *src = (const uint32_t *)env.M.alltrans_tlevel16;  // (the allocation is padded to whole words)
-    uint32_t *dst = (uint32_t *)lds_tlevel;
-    for (int i = threadIdx.x; i < (env.M.nalltrans + 1) / 2; i += TB) dst[i] = src[i];
     env.M.level_pack = lds_levelpack;
-    env.M.alltrans_tlevel16 = lds_tlevel;
+    if (TABLES_LDS == 1) {
+      const uint32_t *src = (const uint32_t *)env.M.alltrans_tlevel16;  // (the allocation is padded to whole words)
+      uint32_t *dst = (uint32_t *)lds_tlevel;
+      for (int i = threadIdx.x; i < (env.M.nalltrans + 1) / 2; i += TB) dst[i] = src[i];
+      env.M.alltrans_tlevel16 = lds_tlevel;
+    }
     env.ma_tables_in_lds = 1;
   }
   __syncthreads();
@@ -2620,10 +2626,14 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
           const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : bud_t;
           if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS && e->Mh.nalltrans <= MA_LDS_TRANS && nk >= 4096) {
             const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
-            hipLaunchKernelGGL((k_thermal<1024, true>), dim3(grid1), dim3(1024), 0, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
+            hipLaunchKernelGGL((k_thermal<1024, 1>), dim3(grid1), dim3(1024), 0, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
+                               e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
+          } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS2 && nk >= 4096) {
+            const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
+            hipLaunchKernelGGL((k_thermal<1024, 2>), dim3(grid1), dim3(1024), 0, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
                                e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
           } else
-          hipLaunchKernelGGL((k_thermal<ARTIS_THERMAL_TB, false>), dim3(grid), dim3(ARTIS_THERMAL_TB), 0, s, env, lst, nk, next, e->d_stats, bud_t,
+          hipLaunchKernelGGL((k_thermal<ARTIS_THERMAL_TB, 0>), dim3(grid), dim3(ARTIS_THERMAL_TB), 0, s, env, lst, nk, next, e->d_stats, bud_t,
                              e->d_cursors, per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (ARTIS_THERMAL_TB / 64)) : 8), per_cu ? 2 : 0, drain);
         }
       } else if (kind == NEXT_BB) {

@@ -2911,7 +2911,8 @@ AHD int ma_exact_search(const Env &env, int c, int ats0, int dir, int nsearch, d
 // the search of one direction of the record `rec` (level with nd / nu transitions, first entry of alltrans `ats`) with the
 // 24-bit draw u: number of the direction's cumulative sums (the last one left out) <= (u * 2^-24) * (the direction's rate).
 // On the filters; *amb: they cannot decide (the result is then meaningless).
-AHD int ma_search_filters(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u, bool *amb) {
+// first0: the direction's first filter line when the caller has read it already (with the action filter: -DARTIS_MA_SPEC_DIR)
+AHD int ma_search_filters(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u, bool *amb, const U4 *first0 = nullptr) {
   const int nsearch = ((dir != MADIR_UP) ? k.nd : k.nu) - 1;
   *amb = false;
   if (nsearch <= 0) return 0;
@@ -2919,7 +2920,7 @@ AHD int ma_search_filters(const Env &env, const MACtx &k, const U4 *rec, int dir
   bool a = env.ma_filters_off != 0;
   int ti = 0;
   for (int b0 = 0; b0 < nsearch && !a; b0 += MAREC_PER) {
-    const U4 f = rec[marec_slot(dir, b0 / MAREC_PER, k.nd, k.nu)];
+    const U4 f = (b0 == 0 && first0 != nullptr) ? *first0 : rec[marec_slot(dir, b0 / MAREC_PER, k.nd, k.nu)];
     const int cnt = mafilt_count(f, zi, &a);
     a = a || (f.w[3] >> 16) != MAFILT_NONE;
     if (a) break;
@@ -2968,6 +2969,9 @@ AHD void ma_take_transition(const Env &env, Pkt &p, MACtx &k, bool down, int ti)
 // the re-adding of the sums (exp() and divisions of the rate coefficients) stays out of the loop of a kernel that runs
 // at the edge of its registers, like the processes that end a walk.
 constexpr int MA_EXIT_DEFER = 98;
+#ifndef ARTIS_MA_SPEC_DIR
+#define ARTIS_MA_SPEC_DIR 1  // measured: k_thermal 466 -> 446 ms (the three slots are one 64-byte sector; the same idea lost in round 3, when they were three lines)
+#endif
 template <bool DEFER = false>
 AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
   // index_upperbound (sn3d.h:85) over the 9 cumulative rates: action = number of cumulative values <= zrand * total,
@@ -2976,8 +2980,17 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
   MA_PROF_BEGIN();
   MA_PROF_MARK(env, 63);  // (clocks between the marks themselves: the cost of one mark)
   int action;
+#if ARTIS_MA_SPEC_DIR
+  U4 fdir[2];
+#endif
   {
     const U4 f = rec[0];
+#if ARTIS_MA_SPEC_DIR
+    // (measurement) the first filter lines of both directions with it: the three slots are one 64-byte sector, and the search
+    // then waits for no second read
+    fdir[0] = rec[1];
+    fdir[1] = rec[2];
+#endif
     MA_PROF_WAIT();
     MA_PROF_MARK(env, 59);
     double r[MA_N], cum[MA_N];
@@ -3016,7 +3029,12 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
     const uint32_t u2 = rng_u24(p);
     MA_PROF_MARK(env, 60);
     bool amb;
+#if ARTIS_MA_SPEC_DIR
+    const U4 fsel = down ? fdir[0] : fdir[1];
+    int ti = ma_search_filters(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2, &amb, &fsel);
+#else
     int ti = ma_search_filters(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2, &amb);
+#endif
     if (amb) {
       if (DEFER) {
         k.defer = (int)(u2 | (down ? 0x1000000u : 0u));
@@ -4182,9 +4200,36 @@ AHD bool type_handled(int type) {
 }
 AHD bool pkt_active(const Pkt &p, double ts_end) { return type_handled(p.type) && p.prop_time < ts_end; }  // update_packets.cc:321
 
+// -DARTIS_PKT_NT=1 (measurement): the packet lines are read and written with non-temporal accesses -- each is touched once
+// per visit, and every line of them that stays in the CU's 32 KB L1 displaces a macro-atom record's
+#ifndef ARTIS_PKT_NT
+#define ARTIS_PKT_NT 0
+#endif
+template <typename T>
+AHD T pkt_line_load(const T *src) {
+#if ARTIS_PKT_NT && defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  T out;
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 16; k++) ((u4v *)&out)[k] = __builtin_nontemporal_load(((const u4v *)src) + k);
+  return out;
+#else
+  return *src;
+#endif
+}
+template <typename T>
+AHD void pkt_line_store(T *dst, const T &v) {
+#if ARTIS_PKT_NT && defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (unsigned k = 0; k < sizeof(T) / 16; k++) __builtin_nontemporal_store(((const u4v *)&v)[k], ((u4v *)dst) + k);
+#else
+  *dst = v;
+#endif
+}
 // Hot line <-> registers: everything a thermal packet needs; 128 B, one cache line, eight 16-byte accesses.
 AHD void pkt_load_hot(const PktStore &P, int64_t i, Pkt &p) {
-  const PktHot h = P.hot[i];
+  const PktHot h = pkt_line_load(&P.hot[i]);
   p.s0 = h.rng[0]; p.s1 = h.rng[1]; p.s2 = h.rng[2]; p.s3 = h.rng[3];
   p.prop_time = h.prop_time;
   p.px = h.pos_x; p.py = h.pos_y; p.pz = h.pos_z;
@@ -4206,7 +4251,7 @@ AHD void pkt_store_hot(const PktStore &P, int64_t i, const Pkt &p) {
   h.ma_origin = p.ma_origin; h.pend = p.pend; h.pend_arg = p.pend_arg; h.chi_mgi = p.chi_mgi;
   h.emissiontype = p.emissiontype; h.trueemissiontype = p.trueemissiontype; h.absorptiontype = p.absorptiontype;
   h.flags = p.flags & ~PKT_FLAG_EMITTED;
-  P.hot[i] = h;
+  pkt_line_store(&P.hot[i], h);
 }
 // Flight line: direction, rest-frame quantities, polarisation ...
 AHD void pkt_load_flight(const PktStore &P, int64_t i, Pkt &p) {
