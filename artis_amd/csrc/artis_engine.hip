@@ -824,15 +824,27 @@ __device__ inline void cellest_flush(const Env &env, int kind, double *global_ar
 #define ARTIS_RPKT_TB 768  // threads per workgroup of k_rpkt ...
 #define ARTIS_RPKT_WGS 1   // ... and workgroups per CU
 #endif
-template <bool CONT_LDS, int TB>
+// LINE_LDS (ARTIS_AMD_LINELDS=1; instead of the continuum table, which it leaves no room for): the line list's frequencies
+// (globals::linelist nu, rpkt.cc:106-207 get_possible_event: one of the two reads per line visited, the other being the cell's
+// population factor) in LDS, the whole list when it has at most LINE_LDS_MAX lines. What a per-cell, per-wave WINDOW of
+// {frequency, population factor} pairs would need -- many lanes of a wave in one cell and one stretch of the list -- the
+// cell-sorted work list does not give: a wave's 64 packets sit in ~21 cells (2.6 lanes per cell) and
+// anywhere in the spectrum. Measured slower than the continuum table in LDS: profiles/r04/line_window.md.
+constexpr int LINE_LDS_MAX = 14336;  // lines (112 KB)
+template <bool CONT_LDS, int TB, bool LINE_LDS = false>
 __global__ void __launch_bounds__(TB, ARTIS_RPKT_WGS) k_rpkt(Env env, const int32_t *list, int32_t n, Lists next,
                                                                    unsigned long long *gstats, int budget, int32_t *cursors, int nchunks,
                                                                    int drain_budget) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
-  __shared__ double lds_cellest[3 * (CONT_LDS ? RPKT_CELLEST_CAP : RPKT_CELLEST_CAP_NOCONT)];
+  __shared__ double lds_line_nu[LINE_LDS ? LINE_LDS_MAX : 1];
+  __shared__ double lds_cellest[3 * ((CONT_LDS || LINE_LDS) ? RPKT_CELLEST_CAP : RPKT_CELLEST_CAP_NOCONT)];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   cellest_begin(env, lds_cellest, env.cellest_n_r, TB, env.E.J, env.E.nuJ, env.E.ffheatingestimator);
+  if (LINE_LDS) {
+    for (int i = threadIdx.x; i < env.M.nlines; i += TB) lds_line_nu[i] = env.M.line_nu[i];
+    env.M.line_nu = lds_line_nu;
+  }
   if (CONT_LDS) {
     const D2 *src = (const D2 *)env.M.cont_pack;
     D2 *dst = (D2 *)lds_cont;
@@ -1491,6 +1503,7 @@ struct artis_amd_engine {
   bool cu_chunks_t = false;  // ARTIS_AMD_CUCHUNKS_T=1: k_thermal takes one list chunk per compute unit (HW_REG_HW_ID);
                              // measured +7 %: like every finer chunking it puts more cells in flight per XCD
   bool cont_lds = true;      // k_rpkt keeps the static continuum table (ContPack) in LDS when it fits (ARTIS_AMD_CONTLDS=0: HBM)
+  bool line_lds = false;     // ARTIS_AMD_LINELDS=1: the line list's frequencies in LDS instead (k_rpkt<false, .., true>; measured slower)
   int thermal_blocks_per_cu = ARTIS_THERMAL_WAVES;  // tuning: resident k_thermal blocks per CU
   bool ma_tables_lds = true;  // k_thermal<1024, true>: the static target tables in LDS when they fit (ARTIS_AMD_MATABLES_LDS=0: in HBM)
   // the population's scratch: the collisional-excitation cooling terms of `pop_batch` cells at a time (k_matrans writes them,
@@ -2006,6 +2019,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_T")) e->wave_chunks_t = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_CUCHUNKS_T")) e->cu_chunks_t = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_CONTLDS")) e->cont_lds = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_LINELDS")) e->line_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TILE_ZIGZAG")) e->tile_zigzag = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_MATABLES_LDS")) e->ma_tables_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_FILL")) e->sparse_fill = std::atoi(b) != 0;
@@ -2597,7 +2611,10 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
         const int grid = (int)std::min<int64_t>(((int64_t)nk + ARTIS_RPKT_TB - 1) / ARTIS_RPKT_TB, (int64_t)e->ncu * ARTIS_RPKT_WGS);  // persistent: every block resident
         const int bud_r = (e->budget_r_small > 0 && nk < e->small_list) ? std::min(e->budget_r_small, e->budget_r) : e->budget_r;
         const int nch = e->wave_chunks_r ? chunks_for(nk, grid * (ARTIS_RPKT_TB / 64)) : 8;
-        if (e->cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0 &&
+        if (e->line_lds && e->Mh.nlines <= LINE_LDS_MAX && e->Mh.nlines > 0 && !(env.cellest_n_r > RPKT_CELLEST_CAP))
+          hipLaunchKernelGGL((k_rpkt<false, ARTIS_RPKT_TB, true>), dim3(grid), dim3(ARTIS_RPKT_TB), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
+                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
+        else if (e->cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0 &&
             !(env.cellest_n_r > RPKT_CELLEST_CAP))
           hipLaunchKernelGGL((k_rpkt<true, ARTIS_RPKT_TB>), dim3(grid), dim3(ARTIS_RPKT_TB), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
                              (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
