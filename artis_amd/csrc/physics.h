@@ -2560,26 +2560,42 @@ AHD bool vpkt_trace_lines_to_dist(const Env &env, const VpktConfig &V, int c, do
   }
   return true;
 }
-// trace_vpkt_direction vpkt.cc:183
-AHD bool trace_vpkt_direction(const Env &env, const VpktSeed &r, double t_arrive, double nu_rf, double e_rf, double rpkt_doppler,
-                              int obsdirindex, const double obsdir[3]) {
-  const DevModel &M = env.M;
-  const VpktConfig &V = *M.vpkt;
-  const int nspec = V.nspectraperobsdir;
+// trace_vpkt_direction vpkt.cc:183, in three parts so that a kernel can give a lane its next ray as soon as its ray has ended (k_vpkt: a
+// ray crosses 1 ... 50 cells, and with one ray per lane from start to end a wave lasts as long as its longest): vray_begin() =
+// everything before the loop, vray_step() = one turn of the loop (one cell), vray_finish() = the contributions to the spectra.
+struct VRay {
   Pkt v;  // position, direction, time and cell of the virtual packet (what boundary_distance() reads)
+  double vel_vec[3];  // velocity of the matter at the event (get_velocity vectors.h:50)
+  int type_before;    // ... and what the real packet was there
+  double obsdir[3];
+  double t_arrive, nu_rf, e_rf, e_cmf, nu_cmf, pn, q_rf, u_rf;
+  double tau_vpkt[VPKT_MAXSPEC];
+  Chi x;  // the virtual packet's own ContinuumOpacity: fresh per traced direction
+  int next_trans, mgi, obsdirindex;
+};
+AHD void vray_begin(const Env &env, const VpktSeed &r, double t_arrive, double nu_rf, double e_rf, double rpkt_doppler, int obsdirindex,
+                    const double obsdir_in[3], VRay &y) {
+  const DevModel &M = env.M;
+  y.type_before = r.type_before;
+  y.obsdirindex = obsdirindex;
+  y.t_arrive = t_arrive;
+  y.nu_rf = nu_rf;
+  y.e_rf = e_rf;
+  for (int d = 0; d < 3; d++) y.obsdir[d] = obsdir_in[d];
+  const double *obsdir = y.obsdir;
+  Pkt &v = y.v;
   v.px = r.pos[0]; v.py = r.pos[1]; v.pz = r.pos[2];
   v.dx = obsdir[0]; v.dy = obsdir[1]; v.dz = obsdir[2];
   v.cellindex = r.cellindex;
   v.prop_time = r.prop_time;
-  int next_trans = r.next_trans;
-  double e_cmf = r.e_cmf;
-  double nu_cmf = r.nu_cmf;
+  y.next_trans = r.next_trans;
+  y.e_cmf = r.e_cmf;
+  y.nu_cmf = r.nu_cmf;
   const double t_start = r.prop_time;
-  const double t_gridstate = env.S.mid;
-  double tau_vpkt[VPKT_MAXSPEC];
-  for (int i = 0; i < VPKT_MAXSPEC; i++) tau_vpkt[i] = 0.;
+  for (int i = 0; i < VPKT_MAXSPEC; i++) y.tau_vpkt[i] = 0.;
   ARTIS_STAT(env, ARTIS_STAT_X_VPKT_CREATED);
   const double vel_vec[3] = {r.pos[0] / t_start, r.pos[1] / t_start, r.pos[2] / t_start};  // get_velocity vectors.h:50
+  for (int d = 0; d < 3; d++) y.vel_vec[d] = vel_vec[d];
   double pn = 1 / (4 * PI);
   double q_rf = 0., u_rf = 0.;
   if (r.type_before == ARTIS_TYPE_RPKT) {
@@ -2597,14 +2613,53 @@ AHD bool trace_vpkt_direction(const Env &env, const VpktSeed &r, double t_arrive
     pn = 3. / (16. * PI) * (1. + musquared + ((musquared - 1.) * q_old));
   }
   pn /= pow2(rpkt_doppler);
-
-  int mgi = M.propcell_nonemptymgi[v.cellindex];
-  Chi x;  // the virtual packet's own ContinuumOpacity: fresh per traced direction
-  x.nonemptymgi = -1;
-  x.nu = NAN;
-  x.chi_escatter = x.chi_freefree_heat = x.chi_boundfree = 0.;
+  y.pn = pn;
+  y.q_rf = q_rf;
+  y.u_rf = u_rf;
+  y.mgi = M.propcell_nonemptymgi[v.cellindex];
+  y.x.nonemptymgi = -1;
+  y.x.nu = NAN;
+  y.x.chi_escatter = y.x.chi_freefree_heat = y.x.chi_boundfree = 0.;
+}
+// the contributions of a ray that has left the grid (vpkt.cc:395-420)
+AHD void vray_finish(const Env &env, VRay &y) {
+  const VpktConfig &V = *env.M.vpkt;
+  const int nspec = V.nspectraperobsdir;
+  const double *obsdir = y.obsdir;
+  const double *tau_vpkt = y.tau_vpkt;
+  const double pn = y.pn, q_rf = y.q_rf, u_rf = y.u_rf, nu_rf = y.nu_rf, e_rf = y.e_rf, t_arrive = y.t_arrive;
+  const int obsdirindex = y.obsdirindex;
+  const double *vel_vec = y.vel_vec;
+  ARTIS_STAT(env, y.type_before == ARTIS_TYPE_RPKT ? ARTIS_STAT_X_VPKT_ESC_RPKT
+                                                   : (y.type_before == ARTIS_TYPE_KPKT ? ARTIS_STAT_X_VPKT_ESC_KPKT : ARTIS_STAT_X_VPKT_ESC_MA));
+  for (int i = 0; i < nspec; i++) {
+    const double prob = pn * exp(-tau_vpkt[i]);
+    if (!isfinite(prob)) fail(env, 91);
+    add_to_vspecpol(env, V, nu_rf, e_rf, prob, q_rf, u_rf, obsdirindex, i, t_arrive);
+  }
+  if (V.vgrid_on) {
+    const double prob = pn * exp(-tau_vpkt[0]);
+    for (int wlbin = 0; wlbin < V.grid_nwavelengthranges; wlbin++)
+      if ((nu_rf > V.nu_grid_min[wlbin] && nu_rf < V.nu_grid_max[wlbin]) && (t_arrive > V.tmin_grid && t_arrive < V.tmax_grid))
+        add_to_vpkt_grid(env, V, nu_rf, e_rf, prob, q_rf, u_rf, vel_vec, wlbin, obsdirindex, obsdir);
+  }
+}
+// one turn of the loop of trace_vpkt_direction() (vpkt.cc:240-393): the cell the ray is in. Returns true while the ray goes on; a ray that
+// leaves the grid adds its contributions (vray_finish) before it returns false, one that is absorbed or enters a thick cell just ends.
+AHD bool vray_step(const Env &env, VRay &y) {
+  const DevModel &M = env.M;
+  const VpktConfig &V = *M.vpkt;
+  const int nspec = V.nspectraperobsdir;
+  Pkt &v = y.v;
+  Chi &x = y.x;
+  const double *obsdir = y.obsdir;
+  double *tau_vpkt = y.tau_vpkt;
+  int &next_trans = y.next_trans;
+  int &mgi = y.mgi;
+  double &e_cmf = y.e_cmf, &nu_cmf = y.nu_cmf;
+  const double nu_rf = y.nu_rf, e_rf = y.e_rf;
+  const double t_gridstate = env.S.mid;
   bool end_packet = false;
-  while (!end_packet) {
     int next_cellindex = -1;
     const double boundarydist = boundary_distance(env, v, &next_cellindex);
     if (mgi < 0) {
@@ -2693,19 +2748,17 @@ AHD bool trace_vpkt_direction(const Env &env, const VpktSeed &r, double t_arrive
     } else {
       end_packet = true;
     }
+  if (end_packet) {
+    vray_finish(env, y);
+    return false;
   }
-  ARTIS_STAT(env, r.type_before == ARTIS_TYPE_RPKT ? ARTIS_STAT_X_VPKT_ESC_RPKT
-                                                   : (r.type_before == ARTIS_TYPE_KPKT ? ARTIS_STAT_X_VPKT_ESC_KPKT : ARTIS_STAT_X_VPKT_ESC_MA));
-  for (int i = 0; i < nspec; i++) {
-    const double prob = pn * exp(-tau_vpkt[i]);
-    if (!isfinite(prob)) fail(env, 91);
-    add_to_vspecpol(env, V, nu_rf, e_rf, prob, q_rf, u_rf, obsdirindex, i, t_arrive);
-  }
-  if (V.vgrid_on) {
-    const double prob = pn * exp(-tau_vpkt[0]);
-    for (int wlbin = 0; wlbin < V.grid_nwavelengthranges; wlbin++)
-      if ((nu_rf > V.nu_grid_min[wlbin] && nu_rf < V.nu_grid_max[wlbin]) && (t_arrive > V.tmin_grid && t_arrive < V.tmax_grid))
-        add_to_vpkt_grid(env, V, nu_rf, e_rf, prob, q_rf, u_rf, vel_vec, wlbin, obsdirindex, obsdir);
+  return true;
+}
+AHD bool trace_vpkt_direction(const Env &env, const VpktSeed &r, double t_arrive, double nu_rf, double e_rf, double rpkt_doppler,
+                              int obsdirindex, const double obsdir[3]) {
+  VRay y;
+  vray_begin(env, r, t_arrive, nu_rf, e_rf, rpkt_doppler, obsdirindex, obsdir, y);
+  while (vray_step(env, y)) {
   }
   return true;
 }
@@ -2725,6 +2778,23 @@ AHD void vpkt_trace_seed_direction(const Env &env, const VpktSeed &r, int obsdir
       }
     }
   }
+}
+// ... as the start of a ray for k_vpkt: false when the direction is not traced (outside the time or frequency windows)
+AHD bool vray_begin_seed(const Env &env, const VpktSeed &r, int obsdirindex, VRay &y) {
+  const VpktConfig &V = *env.M.vpkt;
+  const double obsdir[3] = {V.obsdir[obsdirindex][0], V.obsdir[obsdirindex][1], V.obsdir[obsdirindex][2]};
+  const double t_arrive = r.prop_time - (((r.pos[0] * obsdir[0]) + (r.pos[1] * obsdir[1]) + (r.pos[2] * obsdir[2])) / CLIGHT_PROP);
+  if (!(t_arrive >= V.timemin_input && t_arrive <= V.timemax_input)) return false;
+  const double dop = doppler_at(r.pos[0], r.pos[1], r.pos[2], obsdir[0], obsdir[1], obsdir[2], r.prop_time);
+  const double nu_rf = r.nu_cmf / dop;
+  const double e_rf = r.e_cmf / dop;
+  for (int i = 0; i < V.nwavelengthranges; i++) {
+    if ((nu_rf > V.numin_input[i] && nu_rf < V.numax_input[i]) || (r.absorptionfreq > V.numin_input[i] && r.absorptionfreq < V.numax_input[i])) {
+      vray_begin(env, r, t_arrive, nu_rf, e_rf, dop, obsdirindex, obsdir, y);
+      return true;
+    }
+  }
+  return false;
 }
 // trace_vpkts vpkt.cc:948: called where a real packet is emitted or scattered by an electron. On the GPU the event is
 // recorded for k_vpkt; in the test emulation it is traced in place.

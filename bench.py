@@ -44,9 +44,10 @@ from artis_amd import abi, synth  # noqa: E402
 B_PER_THERMAL_VISIT = 256.0   # hot line (128 B) loaded + stored once per packet per k_thermal launch
 B_PER_RPKT_VISIT = 448.0      # hot + flight line (96 of 128 B used) loaded + stored once per packet per k_rpkt launch
 B_PER_EMISSION = 120.0        # flight line direction/rest-frame part 56 + em_pos/em_time 28 + trueem 36
-B_PER_MA_JUMP = 43.0          # action filter 16 + the direction's filter line 16 x 0.675 (a third of the searches read none) + the
-                              # static 16-byte target (round 3: 35 with an 8-byte target in the line of the sums; round 2: 116 =
-                              # 64 B of rates + 64 x 0.675 of sums + 8)
+B_PER_MA_JUMP = 50.0          # action filter 16 + the first filter lines of both directions 32 (one 64-byte sector, read together) + ~2 for
+                              # the searches that go on to a second line; the target comes from LDS (2 + 16 B, not counted) where the
+                              # static tables fit, else from HBM (2 + 16). Round 3: 35 (16 + 16 x 0.675 + an 8-byte target in the
+                              # line of the sums); round 2: 116
 B_PER_KPKT_STEP = 200.0       # ~6 ion sums 48 + ~7 cooling-list sums 56 + ~6 collisional-excitation sums 48 + indices/flags 48
 B_PER_RPKT_STEP = 120.0       # cell scalars ~40 + boundary tables ~56 + J, nuJ, ffheating atomics 24
 B_PER_LINE = 16.0             # line frequency 8 + the cell's population factor of the line 8
@@ -58,7 +59,7 @@ W_PER_RPKT_VISIT = 224.0      # hot line + 96 B of the flight line
 W_PER_EMISSION = 120.0
 W_PER_ATOMIC = 8.0            # one f64 estimator add
 W_PER_LIST_ENTRY = 8.0        # (slot, key) appended to a work list
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 NCU, NSIMD, CLOCK_GHZ = 256, 1024, 2.4   # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
 GATHER_INSTR_CLOCKS = 40.0             # CU clocks per 64-lane 16-byte gather instruction out of L2 (profiles/r02/gather_microbench.txt)
 LINE_FILL_CLOCKS = 150.0 / 64          # CU clocks per 128-byte line filled from L2 (profiles/r03/sector_bench.txt)
@@ -415,9 +416,10 @@ def main():
                          "avg_launch_ms": d["avg_launch_ms"],
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                          "algorithmic_gbs": d["algorithmic_gbs"], "algorithmic_over_hbm_peak": d["algorithmic_gbs"] / HBM_PEAK_GBS,
-                         "measured_limiter": ("not HBM: the wave's chain of three dependent reads per macro-atom transition at 4 waves/SIMD, "
-                                              "after the 16-byte filters halved the load instructions the kernel was bound by "
-                                              "(two more loads per transition: +27 %; DESIGN.md section 7)")
+                         "measured_limiter": ("not HBM: instruction issue and the waves' dependent reads together -- VALU busy 0.55 of the SIMDs' "
+                                              "cycles at 0.41 lane utilisation, scalar instructions another 0.29, waves waiting 0.67 of theirs; "
+                                              "a transition is one sector of the cell's record from L2 (94 % hits) and two LDS reads "
+                                              "(DESIGN.md section 7, profiles/r04/k_thermal_experiments.md)")
                          if dominant == "k_thermal" else
                          ("k_rpkt (+ k_bfest_dense in DETAILED_BF builds, timed together): divergent per-lane loops over continua and "
                           "lines at 2 waves/SIMD; see `limiter` and DESIGN.md section 7"),

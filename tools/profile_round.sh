@@ -5,7 +5,7 @@
 #   3. bench.py with the fresh pmc_traffic.json in place (its roofline.traffic)  -> bench_default.json
 #   4. the same workload on the other two options builds                         -> bench_kilonova_lte.json, bench_nltenebular.json
 # usage: bash tools/profile_round.sh r02
-T=${1:-r02}
+T=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profile_$T
 mkdir -p $O
@@ -21,4 +21,9 @@ rm -rf $R/gpurun_out/pmc_$T
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --options kilonova_lte --no-cpu-baseline > $O/bench_kilonova_lte.json 2> /dev/null
 bash tools/profile_nltenebular.sh $T
+# round 4: the built paths without a headline of their own, and atomic data of realistic size in one tile
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --options kilonova_expopac > $O/bench_kilonova_expopac.json 2> /dev/null
+python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --options classic_expopac_therm > $O/bench_classic_expopac_therm.json 2> /dev/null
+python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --options ci_classic_vpkt --t-days 5 --packets 1000000 > $O/bench_ci_classic_vpkt_1e6_t5d.json 2> /dev/null
+python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --preset w7big > $O/bench_w7big.json 2> /dev/null
 tail -c 400 $O/bench_default.json
