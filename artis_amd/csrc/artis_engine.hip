@@ -1810,6 +1810,12 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
       return ARTIS_ERR_UNSUPPORTED;
     }
   }
+  for (int i = 0; i < model->nions; i++) {  // DevModel::alltrans_tlevel16: a target level within its ion in 16 bits
+    if (model->ion_nlevels[i] > 65535) {
+      g_last_error = "an ion has more levels than a 16-bit target level can describe";
+      return ARTIS_ERR_UNSUPPORTED;
+    }
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_last_error = "no HIP device: the artis_amd engine has no CPU path";

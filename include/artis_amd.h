@@ -567,8 +567,11 @@ int artis_amd_last_kernel_launches(artis_amd_engine *eng, int64_t *rpkt_launches
 /* The same for each kernel: index 0 k_rpkt, 1 k_ma, 2 k_kpkt, 3 k_slow. */
 int artis_amd_last_kernel_table(artis_amd_engine *eng, double ms[4], int64_t launches[4], int64_t packets[4]);
 
-/* Diagnostics: copy the cell cache of one non-empty cell back to the host (the reference's
- * globals::cellcache[nonemptymgi] spans, globals.h:283-311). Any pointer may be NULL. */
+/* Diagnostics: the cell cache of one non-empty cell in the reference's layout (globals::cellcache[nonemptymgi] spans,
+ * globals.h:283-311). Any pointer may be NULL. The engine's rows hold the macro-atom's cumulative sums as 15-bit filters only
+ * (DESIGN.md section 2): `matrans` (allmacroatomictransitions, globals.h:287) is re-added on the device from the transitions'
+ * rate coefficients -- the values a draw gets that the filters cannot decide -- and the call fails with
+ * ARTIS_ERR_NOTCONVERGED if a filter entry of the cell's records differs from the sequential form's. */
 int artis_amd_debug_cellcache(artis_amd_engine *eng, int nonemptymgi, double *levelpops, double *maprocessrates,
                               double *matrans, double *allcont_nnlevel, double *allcont_departure,
                               double *allcont_edgepart, uint64_t *allcont_keepbits, double *corrphotoioncoeff,
