@@ -4462,7 +4462,7 @@ AHD int advance_ma(const Env &env, Pkt &p, int64_t pi, int budget) {
 // k-packet step for every lane whose macro-atom has deactivated. The phases make the lanes of a wave run the same code
 // at the same time; they only order the work of different packets.
 #ifndef ARTIS_MA_PHASE
-#define ARTIS_MA_PHASE 24  // measured optimum on MI355X (12..64 tried): short enough to keep the lanes busy, long enough to amortise the k-packet phase
+#define ARTIS_MA_PHASE 32  // measured optimum on MI355X (round 4, filter-only records + LDS tables: 16 / 24 / 32 / 40 rounds: 488 / 446 / 435 / 438 ms; round 3: 24): short enough to keep the lanes busy, long enough to amortise the per-phase work
 #endif
 AHD bool kpkt_eligible(const Pkt &p, double ts_end);
 AHD bool thermal_can_continue(const Pkt &p, double ts_end) {

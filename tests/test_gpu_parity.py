@@ -296,6 +296,42 @@ def test_cell_cache_tiling_gives_identical_packets(engine_mod, oracle, monkeypat
     parity.compare_packets(p3, pa, FLOAT_RTOL, "3 cache tiles vs oracle")
 
 
+def test_sparse_fills_do_not_cost_sweeps_and_vpkt_refuses_tiles(engine_mod, monkeypatch):
+    """Two findings of the round-3 review of the tiled cache. (1) A sparse fill (a late visit that populates only the cells in which
+    packets wait) left its residency bitmap switched on while the next tile's packets were classified, which hid that tile until the
+    next sweep: with the fills on, a tiled run must not need more sweeps than with whole-tile fills, and gives the same packets.
+    (2) A VPKT_ON build reads every cell's row along a virtual packet's ray: an engine whose cache does not fit one tile is refused."""
+    model, cs, ts, aux = synth.build("small", ncoord=12)
+    pk0 = synth.make_packets(model, aux, 60000, kpkt_fraction=0.2)
+    n = model["npts_nonempty"]
+    outs = []
+    for sparse in ("0", "1"):
+        monkeypatch.delenv("ARTIS_AMD_CACHE_BUDGET_MB", raising=False)
+        eng = engine_mod.Engine(model)
+        bpc = eng.cache_tiles()[2]
+        eng.close()
+        monkeypatch.setenv("ARTIS_AMD_CACHE_BUDGET_MB", str(bpc * (n // 4 + 1) / 1048576.0 + 0.01))
+        monkeypatch.setenv("ARTIS_AMD_SPARSE_FILL", sparse)
+        monkeypatch.setenv("ARTIS_AMD_SPARSE_MAX", "100000")  # every late visit of this small population qualifies
+        eng = engine_mod.Engine(model)
+        assert eng.cache_tiles()[0] == 4
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, "classic")
+        eng.update_packets(p, e)
+        outs.append((p, e, eng.last_tiling()))
+        eng.close()
+    (p0, e0, t0), (p1, e1, t1) = outs
+    assert t1["sparse_fills"] > 0 and t0["sparse_fills"] == 0, (t0, t1)
+    assert t1["sweeps"] <= t0["sweeps"], (t0, t1)
+    parity.compare_packets(p1, p0, 0.0, "sparse fills vs whole-tile fills")
+    # (2)
+    vmodel, vcs, vts, vaux = synth.build("small", ncoord=8, options="ci_classic_vpkt", t_days=5.0)
+    monkeypatch.setenv("ARTIS_AMD_CACHE_BUDGET_MB", "1")
+    with pytest.raises(Exception, match="VPKT_ON"):
+        engine_mod.Engine(vmodel, preset="ci_classic_vpkt")
+    monkeypatch.delenv("ARTIS_AMD_CACHE_BUDGET_MB", raising=False)
+
+
 def test_estimator_allreduce_through_the_c_abi(engine_mod):
     """artis_amd_comm_unique_id / artis_amd_comm_init / artis_amd_allreduce_estimators on a one-rank communicator (the GPU
     box has one device): RCCL is found at run time, the communicator comes up, the in-place sum leaves the block as is"""
