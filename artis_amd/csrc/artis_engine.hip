@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(BLOCK) k_corrphotoion(Env env, const int32_t *
 // the running sums of macroatom.cc:64-140 with an ORDER-PRESERVING scan: in step k the lanes that are k entries into
 // their (level, direction) segment add their term to the sum of the lane before them -- the additions of the
 // reference's loop, in its order, so the sums carry the same bits as the sequential form (physics.h
-// populate_macroatom_sums) -- while loads and stores stay coalesced (round 2's per-level loop ran at ~1 TB/s on strided
+// populate_level_bb / populate_dirfilter_seq) -- while loads and stores stay coalesced (round 2's per-level loop ran at ~1 TB/s on strided
 // 8-byte accesses). A segment that crosses a 64-entry chunk hands its partial sums to the next chunk.
 // the value of the lane below (lane 0: 0), as two DPP wave-shift moves: the scan's steps are a serial chain, and a DPP
 // move costs a few cycles where ds_bpermute (what __shfl_up compiles to) costs an LDS round trip

@@ -3554,6 +3554,7 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   p.prop_time = t_current;
   if (t_current >= t2) return;
   ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
+  PROF_BEGIN();
   const int c = M.propcell_nonemptymgi[p.cellindex];
   const double *ioncontribs = env.K.ion_cooling_contribs + ((int64_t)c * M.nions);
   const double rndcool_ion = rng_uniform(p) * ioncontribs[M.nions - 1];
@@ -3563,6 +3564,7 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     fail(env, 70);
     return;
   }
+  PROF_MARK(env, 56);  // (-DARTIS_PROFILE) the ion drawn
   const int element = M.ion_element[ui];
   const int ion = ui - M.elem_uniqueionindexstart[element];
   const int ionstart = M.ion_coolingoffset[ui];
@@ -3579,6 +3581,7 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   const int i = ionstart + ionoffset;
   const int ctype = M.coolinglist_type[i];
   const float T_e = env.C.Te[c];
+  PROF_MARK(env, 57);  // ... the cooling term drawn
   if (ctype == ARTIS_COOLING_FREEFREE) {
     p.nu_cmf = -KB * T_e / HPLANCK * log((double)rng_uniform_pos(p));
     emit_rpkt(env, p, pi);
@@ -3643,6 +3646,7 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   } else {
     fail(env, 73);
   }
+  PROF_MARK(env, 59);  // ... the term's process carried out
 }
 
 // free-bound emission of a k-packet, kpkt.cc:518-542

@@ -418,7 +418,7 @@ def _check_hubble_flow_energy(backend, n):
 
 
 def test_macroatom_reciprocity_in_equilibrium_kernel_bodies():
-    _check_te_reciprocity(_backend_emu, 2_400_000)
+    _check_te_reciprocity(_backend_emu, 1_000_000)
 
 
 def test_photon_number_and_hubble_flow_energy_kernel_bodies():
