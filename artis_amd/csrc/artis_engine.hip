@@ -1085,6 +1085,13 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
 #define ARTIS_THERMAL_EU ARTIS_THERMAL_WAVES   // the waves per SIMD its registers are to allow (512 / EU VGPRs) ...
 #define ARTIS_THERMAL_WGS ARTIS_THERMAL_WAVES  // ... and its workgroups per CU
 #endif
+// 1: k_thermal holds no rate-coefficient code: a search its filters cannot decide (3e-4 per transition) is handed to the slow-path
+// kernel with the draw in the packet's pend fields (physics.h PEND_MA_SEARCH / _RADSEARCH / PEND_KPKT_COLLEXC), which re-adds the sums
+// and carries on; the packet is back on the thermal list for the next launch. With the code inlined here the kernel spilled 122
+// instead of 21 registers, reloaded around every phase: 200 GB of scratch traffic per step.
+#ifndef ARTIS_THERMAL_SPLIT_EXACT
+#define ARTIS_THERMAL_SPLIT_EXACT 1
+#endif
 #ifndef ARTIS_MA_DEFER_EXACT
 #define ARTIS_MA_DEFER_EXACT 1  // the re-adding of a search's sums outside the transition loop (physics.h ma_jump_internal<true>)
 #endif
@@ -1180,8 +1187,16 @@ __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_the
       ma_flush_stats(env, k);
       // (a transition whose search the filters could not decide is finished here, outside the loop: the walk goes on in the
       // next phase)
-      if (exit_action == MA_EXIT_DEFER) ma_jump_deferred(env, p, k, rec);
-      else if (exit_action >= 0) ma_jump_exit(env, p, pi, k, rec, exit_action);
+      if (exit_action == MA_EXIT_DEFER) {
+#if ARTIS_THERMAL_SPLIT_EXACT
+        p.pend = PEND_MA_SEARCH;  // the slow-path kernel re-adds the sums and makes the transition (physics.h ma_slow_search)
+        p.pend_arg = k.defer;
+#else
+        ma_jump_deferred(env, p, k, rec);
+#endif
+      } else if (exit_action >= 0) {
+        ma_jump_exit<ARTIS_THERMAL_SPLIT_EXACT != 0>(env, p, pi, k, rec, exit_action);
+      }
       if (j > 0) chi_after_ma(p);
       units += j;
     }
@@ -1196,7 +1211,7 @@ __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_the
 #ifdef ARTIS_PROFILE
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 47);
 #endif
-        do_kpkt(env, p, pi);
+        do_kpkt<ARTIS_THERMAL_SPLIT_EXACT != 0>(env, p, pi);
         p.chi_mgi = -1;
         units++;
       }
@@ -1569,6 +1584,7 @@ Env make_env(const artis_amd_engine *e) {
 #define BIAS(f, T, per) env.K.f = e->K.f - (lo * (int64_t)(per));
     ARTIS_CACHE_ARRAYS(BIAS, h)
 #undef BIAS
+    if (h.ndpop == 0) env.K.line_dpop = nullptr;  // formed on the fly (physics.h line_dpop_at)
   }
   env.tile_lo = e->tile_lo;
   env.tile_hi = e->tile_hi;
@@ -1910,9 +1926,29 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
 #define SZ(f, T, per) per_cell += sizeof(T) * (size_t)(per);
     ARTIS_CACHE_ARRAYS(SZ, h)
 #undef SZ
-    e->cache_bytes_per_cell = per_cell;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    {
+      // The rows of line_dpop (8 bytes per line and cell: 0.9 of the 3.2 MB of a row with 110 860 lines) are dropped when the cell
+      // cache does not fit one tile with them and needs fewer tiles without: the line walk then forms a line's population factor from
+      // its record and the two level populations (physics.h line_dpop_at: the same expression, the same bits; two more reads per
+      // line visited). ARTIS_AMD_DPOP=0 / 1 forces either.
+      double budget0 = 0.8 * (double)free_b;
+      if (const char *b = std::getenv("ARTIS_AMD_CACHE_BUDGET_MB")) budget0 = std::atof(b) * 1048576.0;
+      const size_t per_without = per_cell - (sizeof(double) * (size_t)h.ndpop);
+      auto tiles_of = [&](size_t per) {
+        const int64_t fit = std::max<int64_t>(1, (int64_t)(budget0 / (double)(per > 0 ? per : 1)));
+        return (ncell_all + fit - 1) / fit;
+      };
+      bool drop = tiles_of(per_cell) > 1 && tiles_of(per_without) < tiles_of(per_cell);
+      if (const char *b = std::getenv("ARTIS_AMD_DPOP")) drop = std::atoi(b) == 0;
+      if (drop && h.ndpop > 0) {
+        e->Mh.ndpop = 0;
+        e->M.ndpop = 0;
+        per_cell = per_without;
+      }
+    }
+    e->cache_bytes_per_cell = per_cell;
     // the packets (320 B each), their work lists (~100 B), the caller's structs (256 B) and a snapshot need room too: ~1 KB per
     // packet, 10 GB at 1e7 packets; the population's scratch 2 GB
     double budget = 0.8 * (double)free_b;
@@ -2235,7 +2271,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
     env.tile_hi = lo + (int)(b0 + ncell);
   }
   hipLaunchKernelGGL(k_levelpops, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
-  if (h.nlines > 0) hipLaunchKernelGGL(k_line_dpop, dim3(nblocks(ncell * h.nlines)), dim3(BLOCK), 0, s, env);
+  if (h.ndpop > 0) hipLaunchKernelGGL(k_line_dpop, dim3(nblocks(ncell * h.nlines)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cell_scalars, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
   if (h.nbfcontinua > 0) hipLaunchKernelGGL(k_allcont, dim3(nblocks(ncell * h.nkeepwords * 64)), dim3(BLOCK), 0, s, env);
   if (h.nbfcontinua > 0) hipLaunchKernelGGL(k_keptlist, dim3(nblocks(ncell * 64)), dim3(BLOCK), 0, s, env);

@@ -169,7 +169,7 @@ struct ModelOwned {
   X(bf_colion, double, (m).nphixstargets_total)                 \
   X(bf_cooling, double, (m).nphixstargets_total)                \
   X(cooling_contrib, double, (m).ncoolingterms)                 \
-  X(line_dpop, double, (m).nlines)                              \
+  X(line_dpop, double, (m).ndpop)                               \
   X(ion_cooling_contribs, double, (m).nions)                    \
   X(ion_cooling_C, double, (m).nions)                           \
   X(chi_ff_nnionpart, double, 1)
@@ -182,6 +182,7 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.nphixstargets_total = m.nphixstargets_total; v.nphixslevels = m.nphixslevels; v.nbfcontinua = m.nbfcontinua;
   v.nbfcontinua_ground = m.nbfcontinua_ground; v.ncoolingterms = m.ncoolingterms; v.nmatransblock = m.nmatransblock;
   v.NPHIXSPOINTS = m.NPHIXSPOINTS;
+  v.ndpop = m.nlines;  // (the engine drops the rows when the cell cache would not fit one tile with them)
   v.nkeepwords = (((m.nbfcontinua + 63) / 64) + 3) & ~3;  // rows padded to whole 4-word chunks (physics.h KeepIter)
   v.NPHIXSNUINCREMENT = m.NPHIXSNUINCREMENT;
   v.last_phixs_nuovernuedge = (1.0 + (m.NPHIXSNUINCREMENT * (m.NPHIXSPOINTS - 1)));                    // input.cc:310

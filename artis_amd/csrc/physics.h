@@ -223,7 +223,11 @@ struct Pkt {
   int32_t emissiontype, trueemissiontype, absorptiontype;
   int32_t flags;           // PKT_FLAG_*
 };
-enum { PEND_NONE = 0, PEND_MA_ACTION = 2, PEND_KPKT_FB = 3 };
+// PEND_MA_SEARCH / _RADSEARCH / PEND_KPKT_COLLEXC (round 4): a search of the active macro-atom's internal transition / of its radiative
+// de-excitation / of a k-packet's collisional-excitation cooling term that the records' filters could not decide; the draw is in
+// pend_arg (24 bits; bit 24 of PEND_MA_SEARCH: downward), and the slow-path kernel re-adds the sums (physics.h ma_search_exact,
+// kpkt_collexc_exact) and carries on. k_thermal hands these over so that the rate-coefficient code is not in it at all.
+enum { PEND_NONE = 0, PEND_MA_ACTION = 2, PEND_KPKT_FB = 3, PEND_MA_SEARCH = 4, PEND_MA_RADSEARCH = 5, PEND_KPKT_COLLEXC = 6 };
 
 // ContinuumOpacity (rpkt.h:70); groundcont_gamma_contr lives in env.gamma_ws
 struct Chi {
@@ -986,6 +990,25 @@ AHD void populate_line_dpop(const Env &env, int c, int li) {
   const double B_ul = lp.B_ul;
   const double B_lu = lp.B_lu;
   env.K.line_dpop[((int64_t)c * M.nlines) + li] = (B_lu * n_l) - (B_ul * n_u);
+}
+// ... and the reader: the stored value, or -- when the engine keeps no line_dpop rows (atomic data too large for them: 8 bytes per line
+// and cell are then a quarter of the cell cache; artis_engine.hip engine_fill) -- the same expression from the line record and the two
+// level populations, the same bits
+struct LineDpop {
+  const double *dpop;  // the cell's row of line_dpop, or null
+  const double *pops;  // the cell's level populations
+};
+AHD LineDpop line_dpop_of(const Env &env, int c) {
+  LineDpop r;
+  r.dpop = env.K.line_dpop ? env.K.line_dpop + ((int64_t)c * env.M.nlines) : nullptr;
+  r.pops = env.K.levelpops + ((int64_t)c * env.M.nlevels);
+  return r;
+}
+AHD double line_dpop_at(const DevModel &M, const LineDpop &d, int li) {
+  if (d.dpop) return d.dpop[li];
+  const LinePack lp = M.line_pack[li];
+  const double B_ul = lp.B_ul, B_lu = lp.B_lu;
+  return (B_lu * d.pops[lp.lower]) - (B_ul * d.pops[lp.upper]);
 }
 // one cell: calculate_chi_ffheat_nnionpart rpkt.cc:932
 AHD void populate_chi_ff(const Env &env, int c) {
@@ -1967,7 +1990,7 @@ AHD double linedistance(double prop_time, double nu_cmf, double nu_trans, double
 AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAState &ma, double tau_rnd, double abort_dist,
                           double nu_cmf_abort, double dnu_on_dl, double dop, int *next_trans_out, bool *is_bb) {
   const DevModel &M = env.M;
-  const double *dpop = env.K.line_dpop + ((int64_t)c * M.nlines);
+  const LineDpop dpop = line_dpop_of(env, c);
   double px = p.px, py = p.py, pz = p.pz;
   double nu_cmf = p.nu_cmf;
   double e_cmf = p.e_cmf;
@@ -2007,11 +2030,11 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
 #endif
     const bool was_ahead = (li == ahead_li);
     const double nu_trans = was_ahead ? nu_ahead : M.line_nu[li];
-    const double dpop_li = was_ahead ? dpop_ahead : dpop[li];
+    const double dpop_li = was_ahead ? dpop_ahead : line_dpop_at(M, dpop, li);
     if (li + 1 < M.nlines) {
       ahead_li = li + 1;
       nu_ahead = M.line_nu[li + 1];
-      dpop_ahead = dpop[li + 1];
+      dpop_ahead = line_dpop_at(M, dpop, li + 1);
     }
     next_trans = li + 1;
     const double ldist = linedistance(prop_time, nu_cmf, nu_trans, dnu_on_dl);
@@ -2088,12 +2111,12 @@ AHD int64_t linearbinindex(double value, double minvalue, double binwidth) {  //
 // product of update_grid() in the reference, update_grid.cc:655). One (cell, bin): the lines of the bin in list order.
 AHD void populate_expopac_bin(const Env &env, int c, int b) {
   const DevModel &M = env.M;
-  const double *dpop = env.K.line_dpop + ((int64_t)c * M.nlines);
+  const LineDpop dpop = line_dpop_of(env, c);
   const double t_mid = env.S.mid;
   double bin_linesum = 0.;
   const int l1 = M.expopac_linestart[b + 1];
   for (int li = M.expopac_linestart[b]; li < l1; li++) {
-    const double tau_line = dmax(dpop[li] * HCLIGHTOVERFOURPI * t_mid, 0.);  // get_tau_sobolev rpkt.cc:75
+    const double tau_line = dmax(line_dpop_at(M, dpop, li) * HCLIGHTOVERFOURPI * t_mid, 0.);  // get_tau_sobolev rpkt.cc:75
     const double linelambda = 1e8 * CLIGHT / M.line_nu[li];
     bin_linesum += (linelambda / ARTIS_EXPOPAC_DELTALAMBDA) * -expm1(-tau_line);
   }
@@ -2535,7 +2558,7 @@ AHD bool all_taus_past_taumax(const double *tau, int n, double tau_max) {  // vp
 AHD bool vpkt_trace_lines_to_dist(const Env &env, const VpktConfig &V, int c, double dist_limit, double t_future, double nu_cmf,
                                   double dnu_on_dl, int &next_trans, double *tau_vpkt) {
   const DevModel &M = env.M;
-  const double *dpop = env.K.line_dpop + ((int64_t)c * M.nlines);
+  const LineDpop dpop = line_dpop_of(env, c);
   const double t_gridstate = env.S.mid;
   while (true) {
     const int li = closest_transition(M.line_nu, M.nlines, nu_cmf, next_trans);
@@ -2552,7 +2575,7 @@ AHD bool vpkt_trace_lines_to_dist(const Env &env, const VpktConfig &V, int c, do
     }
     const double t_line = t_future + (ldist / CLIGHT_PROP);
     const double popscalefactor = pow3(t_gridstate / t_line);
-    const double tau_line = dmax(0., dpop[li] * popscalefactor * HCLIGHTOVERFOURPI * t_line);
+    const double tau_line = dmax(0., line_dpop_at(M, dpop, li) * popscalefactor * HCLIGHTOVERFOURPI * t_line);
     const int Z = M.elem_anumber[M.line_elementindex[li]];
     for (int i = 0; i < V.nspectraperobsdir; i++)
       if (V.opacityexclusions[i] != -1 && V.opacityexclusions[i] != Z) tau_vpkt[i] += tau_line;
@@ -2970,6 +2993,9 @@ AHD void ma_load_rates(const double *rates, double *r, double *cum) {
 // population ran, added in the same order: the values the round-3 records held, bit for bit). Sums are non-decreasing, so
 // the count is the index of the first sum above targetval. Out of line: rare (5e-4 per decision) and register-hungry.
 AHD int ma_exact_search(const Env &env, int c, int ats0, int dir, int nsearch, double targetval) {
+#if defined(ARTIS_MA_FAKE_EXACT) && defined(__HIP_DEVICE_COMPILE__)
+  return (int)(targetval * 0.) + (nsearch > 1 ? 1 : 0);  // (timing experiment only: WRONG results -- what would k_thermal cost without the re-adding code in it?)
+#endif
   double s = 0.;
   int j = 0;
   for (; j < nsearch; j++) {
@@ -3010,7 +3036,8 @@ AHD int ma_search_exact(const Env &env, const MACtx &k, const U4 *rec, int dir, 
 AHD int ma_search_dir(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u) {
   bool amb;
   const int ti = ma_search_filters(env, k, rec, dir, u, &amb);
-  return amb ? ma_search_exact(env, k, rec, dir, u) : ti;
+  if (__builtin_expect(amb, 0)) return ma_search_exact(env, k, rec, dir, u);
+  return ti;
 }
 // the internal transition to the ti-th downward / upward transition's level: the walk goes on in that level's record
 AHD void ma_take_transition(const Env &env, Pkt &p, MACtx &k, bool down, int ti) {
@@ -3126,30 +3153,45 @@ AHD void ma_jump_deferred(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
   const int ti = ma_search_exact(env, k, rec, down ? MADIR_DOWN : MADIR_UP, (uint32_t)k.defer & 0xFFFFFFu);
   ma_take_transition(env, p, k, down, ti);
 }
-// `rec`: the record the action was drawn from (the packet's current level: k still describes it)
-AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const U4 *rec, int action) {
+// do_macroatom_raddeexcitation macroatom.cc:204 once the transition dti is known
+AHD void ma_exit_raddeexc(const Env &env, Pkt &p, int64_t pi, const MACtx &k, int dti) {
   const DevModel &M = env.M;
-  const int c = k.c;
   const int activatingline = p.ma_line;
+  const int lineindex = M.alltrans_lineindex[k.ats + dti];
+  if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
+  const int ul = k.start + p.ma_level;
+  const int lul = k.start + M.alltrans_targetlevelindex[k.ats + dti];
+  const double e_trans = eps(M, ul) - eps(M, lul);
+  const double oldnucmf = p.nu_cmf;
+  p.nu_cmf = e_trans / HPLANCK;
+  if (activatingline >= 0) ARTIS_STAT(env, (oldnucmf < p.nu_cmf) ? ARTIS_STAT_UPSCATTER : ARTIS_STAT_DOWNSCATTER);
+  ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_BB);
+  emit_rpkt(env, p, pi);
+  p.next_trans = lineindex + 1;
+  p.emissiontype = lineindex;
+  p.nscatterings = 0;
+  ma_finish(env, p, pi);
+}
+// `rec`: the record the action was drawn from (the packet's current level: k still describes it).
+// SPLIT: a search the filters cannot decide is left to the slow-path kernel (PEND_MA_RADSEARCH) instead of re-adding the sums here.
+template <bool SPLIT = false>
+AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const U4 *rec, int action) {
+  const int c = k.c;
   if (action == ARTIS_MA_ACTION_RADDEEXC) {
-    // do_macroatom_raddeexcitation macroatom.cc:204: targetval = zrand * (the rate); the transition is the number of
-    // cumulative radiative de-excitation sums <= targetval among the first ndown - 1
+    // targetval = zrand * (the rate); the transition is the number of cumulative radiative de-excitation sums <= targetval
+    // among the first ndown - 1
     const uint32_t u = rng_u24(p);
-    const int dti = ma_search_dir(env, k, rec, MADIR_RAD, u);
-    const int lineindex = M.alltrans_lineindex[k.ats + dti];
-    if (lineindex == activatingline) ARTIS_STAT(env, ARTIS_STAT_RESONANCESCATTERINGS);
-    const int ul = k.start + p.ma_level;
-    const int lul = k.start + M.alltrans_targetlevelindex[k.ats + dti];
-    const double e_trans = eps(M, ul) - eps(M, lul);
-    const double oldnucmf = p.nu_cmf;
-    p.nu_cmf = e_trans / HPLANCK;
-    if (activatingline >= 0) ARTIS_STAT(env, (oldnucmf < p.nu_cmf) ? ARTIS_STAT_UPSCATTER : ARTIS_STAT_DOWNSCATTER);
-    ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_BB);
-    emit_rpkt(env, p, pi);
-    p.next_trans = lineindex + 1;
-    p.emissiontype = lineindex;
-    p.nscatterings = 0;
-    ma_finish(env, p, pi);
+    bool amb;
+    int dti = ma_search_filters(env, k, rec, MADIR_RAD, u, &amb);
+    if (amb) {
+      if (SPLIT) {
+        p.pend = PEND_MA_RADSEARCH;
+        p.pend_arg = (int)u;
+        return;
+      }
+      dti = ma_search_exact(env, k, rec, MADIR_RAD, u);
+    }
+    ma_exit_raddeexc(env, p, pi, k, dti);
   } else if (action == ARTIS_MA_ACTION_COLDEEXC || action == ARTIS_MA_ACTION_COLRECOMB) {
     ARTIS_STAT(env, action == ARTIS_MA_ACTION_COLDEEXC ? ARTIS_STAT_MA_DEACTIVATION_COLLDEEXC : ARTIS_STAT_MA_DEACTIVATION_COLLRECOMB);
     p.type = ARTIS_TYPE_KPKT;
@@ -3171,12 +3213,37 @@ AHD void ma_flush_stats(const Env &env, MACtx &k) {
     k.njumps = 0;
   }
 }
+// SPLIT: the form k_thermal runs -- a search the filters cannot decide becomes a pending slow-path action (PEND_MA_SEARCH / _RADSEARCH)
+template <bool SPLIT = false>
 AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
   ma_prepare(env, p, k);
   const U4 *rec = ma_record(k);
-  const int action = ma_jump_internal(env, p, k, rec);
-  if (action >= 0) ma_jump_exit(env, p, pi, k, rec, action);
+  const int action = ma_jump_internal<SPLIT>(env, p, k, rec);
+  if (SPLIT && action == MA_EXIT_DEFER) {
+    p.pend = PEND_MA_SEARCH;
+    p.pend_arg = k.defer;
+  } else if (action >= 0) {
+    ma_jump_exit<SPLIT>(env, p, pi, k, rec, action);
+  }
   ma_flush_stats(env, k);
+}
+
+// the searches k_thermal left undecided (PEND_MA_SEARCH, PEND_MA_RADSEARCH), in the slow-path kernel
+AHD void ma_slow_search(const Env &env, Pkt &p, int64_t pi) {
+  MACtx k = ma_ctx(env, p);
+  ma_prepare(env, p, k);
+  const U4 *rec = ma_record(k);
+  const uint32_t u = (uint32_t)p.pend_arg & 0xFFFFFFu;
+  if (p.pend == PEND_MA_SEARCH) {
+    const bool down = ((uint32_t)p.pend_arg & 0x1000000u) != 0;
+    p.pend = PEND_NONE;
+    const int ti = ma_search_exact(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u);
+    ma_take_transition(env, p, k, down, ti);  // (the transition was counted when its process was drawn)
+  } else {
+    p.pend = PEND_NONE;
+    const int dti = ma_search_exact(env, k, rec, MADIR_RAD, u);
+    ma_exit_raddeexc(env, p, pi, k, dti);
+  }
 }
 
 // the bound-free transitions of do_macroatom(): macroatom.cc:481-488, 501-533, 552-560
@@ -3531,6 +3598,9 @@ AHD void do_kpkt_blackbody(const Env &env, Pkt &p, int64_t pi) {  // kpkt.cc:399
 // kpkt.cc:461-476 on the terms themselves: the number of the level's first nsearch running cooling sums <= rnd_process, the
 // sums re-added from `lo` (the ion's running sum before the level) term by term, as calculate_cooling_rates_ion() adds them
 AHD int kpkt_collexc_exact(const Env &env, int c, int ats_up0, int nsearch, double lo, double rnd_process) {
+#if defined(ARTIS_MA_FAKE_EXACT) && defined(__HIP_DEVICE_COMPILE__)
+  return 0;
+#endif
   double s = lo;
   int j = 0;
   for (; j < nsearch; j++) {
@@ -3539,7 +3609,40 @@ AHD int kpkt_collexc_exact(const Env &env, int c, int ats_up0, int nsearch, doub
   }
   return j;
 }
-// do_kpkt kpkt.cc:425
+// kpkt.cc:477-490: the k-packet activates the macro-atom in the upper level of the chosen collisional excitation
+AHD void kpkt_collexc_activate(const Env &env, Pkt &p, int element, int ion, const LevelPack &lpk, int first) {
+  const int upper = env.M.alltrans_targetlevelindex[lpk.alltrans_startdown + lpk.ndown + first];
+  ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_COLLEXC);
+  ARTIS_STAT(env, ARTIS_STAT_K_TO_MA_COLLEXC);
+  p.trueemissiontype = ARTIS_EMTYPE_NOTSET;
+  p.flags |= PKT_FLAG_TRUEEM_NAN;  // trueem_pos = NaN (kpkt.cc:483)
+  const MAState ma = {element, ion, upper, -99};
+  ma_activate(p, ma, 0);
+}
+// ... in the slow-path kernel, for a k-packet whose cooling-term search k_thermal left undecided (PEND_KPKT_COLLEXC: the ion in
+// ma_element / ma_ion, the draw of rnd_process in pend_arg): the term is found again from the draw, the sums re-added
+AHD void kpkt_slow_collexc(const Env &env, Pkt &p) {
+  const DevModel &M = env.M;
+  const int c = M.propcell_nonemptymgi[p.cellindex];
+  const int element = p.ma_element, ion = p.ma_ion;
+  const uint32_t u = (uint32_t)p.pend_arg & 0xFFFFFFu;
+  p.pend = PEND_NONE;
+  p.ma_element = -1;
+  p.ma_ion = -1;
+  const int ui = uion(M, element, ion);
+  const int ionstart = M.ion_coolingoffset[ui];
+  const int nterms = M.ion_ncoolingterms[ui];
+  const double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + ionstart;
+  const double rnd_process = rng_u24_value(u) * contribs[nterms - 1];
+  const int ionoffset = upper_bound_d(contribs, nterms, rnd_process);
+  const int ul = M.ion_uniquelevelindexstart[ui] + M.coolinglist_level[ionstart + ionoffset];
+  const LevelPack lpk = M.level_pack[ul];
+  const double lo = (ionoffset > 0) ? contribs[ionoffset - 1] : 0.;
+  const int first = kpkt_collexc_exact(env, c, lpk.alltrans_startdown + lpk.ndown, lpk.nup - 1, lo, rnd_process);
+  kpkt_collexc_activate(env, p, element, ion, lpk, first);
+}
+// do_kpkt kpkt.cc:425. SPLIT: a collisional-excitation search the level's filter cannot decide is left to the slow-path kernel.
+template <bool SPLIT = false>
 AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   const DevModel &M = env.M;
   const double t2 = env.S.ts_end;
@@ -3571,7 +3674,8 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   const int nterms = M.ion_ncoolingterms[ui];
   const double *cellcontrib = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
   const double *contribs = cellcontrib + ionstart;
-  const double rnd_process = rng_uniform(p) * contribs[nterms - 1];
+  const uint32_t u_process = rng_u24(p);
+  const double rnd_process = rng_u24_value(u_process) * contribs[nterms - 1];
   const int ionoffset = ARTIS_KPKT_BLOCKED_SEARCH ? upper_bound_blocked<16>(contribs, nterms, rnd_process)
                                                   : upper_bound_d(contribs, nterms, rnd_process);
   if (!(ionoffset < nterms)) {
@@ -3626,15 +3730,18 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
         first += cnt;
         if (cnt < MAREC_PER) break;
       }
-      if (amb) first = kpkt_collexc_exact(env, c, lpk.alltrans_startdown + lpk.ndown, nsearch, lo, rnd_process);
+      if (__builtin_expect(amb, 0)) {
+        if (SPLIT) {
+          p.pend = PEND_KPKT_COLLEXC;
+          p.ma_element = element;
+          p.ma_ion = ion;
+          p.pend_arg = (int)u_process;
+          return;
+        }
+        first = kpkt_collexc_exact(env, c, lpk.alltrans_startdown + lpk.ndown, nsearch, lo, rnd_process);
+      }
     }
-    const int upper = M.alltrans_targetlevelindex[lpk.alltrans_startdown + lpk.ndown + first];
-    ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_COLLEXC);
-    ARTIS_STAT(env, ARTIS_STAT_K_TO_MA_COLLEXC);
-    p.trueemissiontype = ARTIS_EMTYPE_NOTSET;
-    p.flags |= PKT_FLAG_TRUEEM_NAN;  // trueem_pos = NaN (kpkt.cc:483)
-    const MAState ma = {element, ion, upper, -99};
-    ma_activate(p, ma, 0);
+    kpkt_collexc_activate(env, p, element, ion, lpk, first);
   } else if (ctype == ARTIS_COOLING_COLLION) {
     const int upper = phixs_upperlevel(M, lstart(M, element, ion) + M.coolinglist_level[i], M.coolinglist_phixstargetindex[i]);
     ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_COLLION);
@@ -4445,18 +4552,20 @@ AHD void chi_after_ma(Pkt &p) {
 
 // ---- macro-atom kernel body: one iteration = one transition of the walk (ma_jump). Returns true while the walk goes on
 // in this kernel (not deactivated, not handed to the slow path).
+template <bool SPLIT = false>
 AHD bool ma_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
-  ma_jump(env, p, pi, k);
+  ma_jump<SPLIT>(env, p, pi, k);
   const bool go = ma_pending(p) && p.pend == PEND_NONE;
   if (!ma_pending(p)) chi_after_ma(p);
   return go;
 }
+template <bool SPLIT = false>
 AHD int advance_ma(const Env &env, Pkt &p, int64_t pi, int budget) {
   MACtx k = ma_ctx(env, p);
   int units = 0;
   bool go = ma_pending(p) && p.pend == PEND_NONE;
   while (go && units < budget) {
-    go = ma_iter(env, p, pi, k);
+    go = ma_iter<SPLIT>(env, p, pi, k);
     units++;
   }
   return classify(env, p, env.S.ts_end);
@@ -4498,9 +4607,10 @@ AHD int thermal_iter(const Env &env, Pkt &p, int64_t pi, MACtx &k, bool *go) {
 AHD bool kpkt_eligible(const Pkt &p, double ts_end) {
   return p.pend == PEND_NONE && !ma_pending(p) && pkt_active(p, ts_end) && p.type != ARTIS_TYPE_RPKT && !type_gamma(p.type);
 }
+template <bool SPLIT = false>
 AHD int advance_kpkt(const Env &env, Pkt &p, int64_t pi) {
   if (kpkt_eligible(p, env.S.ts_end) && !kpkt_blackbody_case(env, p.type, p.cellindex)) {
-    do_kpkt(env, p, pi);
+    do_kpkt<SPLIT>(env, p, pi);
     p.chi_mgi = -1;
   }
   return classify(env, p, env.S.ts_end);
@@ -4551,6 +4661,12 @@ AHD int advance_slow(const Env &env, Pkt &p, int64_t pi) {
     chi_after_ma(p);
   } else if (p.pend == PEND_KPKT_FB) {
     kpkt_fb_emission(env, p, pi);
+    p.chi_mgi = -1;
+  } else if (p.pend == PEND_MA_SEARCH || p.pend == PEND_MA_RADSEARCH) {
+    ma_slow_search(env, p, pi);
+    chi_after_ma(p);
+  } else if (p.pend == PEND_KPKT_COLLEXC) {
+    kpkt_slow_collexc(env, p);
     p.chi_mgi = -1;
   }
   return classify(env, p, env.S.ts_end);

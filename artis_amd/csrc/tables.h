@@ -128,6 +128,7 @@ struct DevModel {
       ncoolingterms, nmatransblock, NPHIXSPOINTS;
   int32_t nmacache;    // 16-byte slots per cell in DevCache::macache
   int32_t nupcum;      // upward transitions (= nlines): doubles per cell of the population's scratch of cooling terms (Env::collexc_terms)
+  int32_t ndpop;       // doubles per cell in DevCache::line_dpop: nlines, or 0 when the population factors are formed on the fly
   int32_t nkeepwords;  // ceil(nbfcontinua/64) (get_allcont_keepwordcount globals.h:401) rounded up to a multiple of 4
   double NPHIXSNUINCREMENT;
   double last_phixs_nuovernuedge;  // input.cc:310
@@ -256,7 +257,7 @@ struct DevCache {
   int32_t *allcont_keptlist;     // [cell][nbfcontinua]
   int32_t *allcont_keepprefix;   // [cell][nkeepwords]
   D2 *allcont_keptpair;          // [cell][nbfcontinua]
-  double *line_dpop;             // [cell][nlines]: B_lu n_l - B_ul n_u of every line, the population factor of get_tau_sobolev() (rpkt.cc:75)
+  double *line_dpop;             // [cell][ndpop]: B_lu n_l - B_ul n_u of every line, the population factor of get_tau_sobolev() (rpkt.cc:75); null when ndpop == 0
   double *corrphotoioncoeff;     // [cell][nphixstargets_total]
   // [cell][nphixstargets_total] the other coefficients of each bound-free pair (populate_corrphotoion): radiative and
   // collisional recombination, collisional ionisation, bound-free cooling

@@ -64,11 +64,15 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   e.env.M.vpkt = &e.vpkt_config;
   e.env.vpkt_queue = nullptr;  // traced in place
 #endif
+  // ARTIS_EMU_DPOP=0: no line_dpop rows, the population factor of a line formed where it is read (physics.h line_dpop_at)
+  if (const char *b = std::getenv("ARTIS_EMU_DPOP"))
+    if (std::atoi(b) == 0) e.env.M.ndpop = 0;
   const DevModel &M = e.env.M;
   const int64_t ncell = M.npts_nonempty;
 #define ALLOC(f, T, per) { e.cachebuf.emplace_back((size_t)(ncell * (int64_t)(per) + MAREC_SLACK) * sizeof(T)); e.env.K.f = (T *)e.cachebuf.back().data(); }
   ARTIS_CACHE_ARRAYS(ALLOC, M)
 #undef ALLOC
+  if (M.ndpop == 0) e.env.K.line_dpop = nullptr;
   e.stats.assign(ARTIS_NSTATS, 0);
   e.env.stats = e.stats.data();
   e.ws.assign((size_t)((M.nbfcontinua_ground + 1) * nslots), 0.);
@@ -112,7 +116,8 @@ void populate_all(Emu &e) {
   std::vector<double> upterms((size_t)M.nupcum + 1, 0.);  // the population's scratch row of cooling terms (Env::collexc_terms)
   for (int c = 0; c < M.npts_nonempty; c++) {
     for (int ul = 0; ul < M.nlevels; ul++) populate_levelpop(e.env, c, ul);
-    for (int li = 0; li < M.nlines; li++) populate_line_dpop(e.env, c, li);
+    if (M.ndpop > 0)
+      for (int li = 0; li < M.nlines; li++) populate_line_dpop(e.env, c, li);
     populate_chi_ff(e.env, c);
     uint64_t *kb = e.env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
     for (int w = 0; w < M.nkeepwords; w++) kb[w] = 0;
@@ -251,6 +256,7 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
     return false;
   };
   const int order[6] = {NEXT_SLOW, NEXT_GAMMA, NEXT_BB, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
+  const bool split = std::getenv("ARTIS_EMU_SPLIT") != nullptr && std::atoi(std::getenv("ARTIS_EMU_SPLIT")) != 0;
   while (any() && !e.err) {
     for (int kind : order) {
       if (lists[kind].empty()) continue;
@@ -263,6 +269,11 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
           // as k_thermal / k_blackbody do: only the hot line is loaded, the flight line is written when (and only when) an
           // r-packet was emitted
           pkt_load_thermal(e.env.P, pi, p);
+          // ARTIS_EMU_SPLIT=1: the form k_thermal runs -- undecided searches become pending slow-path actions
+          if (split)
+            next = (kind == NEXT_MA) ? advance_ma<true>(e.env, p, pi, budget * 8)
+                                     : ((kind == NEXT_KPKT) ? advance_kpkt<true>(e.env, p, pi) : advance_blackbody(e.env, p, pi));
+          else
           next = (kind == NEXT_MA) ? advance_ma(e.env, p, pi, budget * 8)
                                    : ((kind == NEXT_KPKT) ? advance_kpkt(e.env, p, pi) : advance_blackbody(e.env, p, pi));
           pkt_store_thermal(e.env.P, pi, p);

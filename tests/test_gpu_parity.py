@@ -296,6 +296,30 @@ def test_cell_cache_tiling_gives_identical_packets(engine_mod, oracle, monkeypat
     parity.compare_packets(p3, pa, FLOAT_RTOL, "3 cache tiles vs oracle")
 
 
+@pytest.mark.parametrize("options", ["classic", "kilonova_expopac"])
+def test_line_population_factors_on_the_fly_give_identical_packets(engine_mod, oracle, monkeypatch, options):
+    """ARTIS_AMD_DPOP=0: no line_dpop rows in the cell cache (what the engine chooses by itself when the cache does not fit one tile with
+    them); the row shrinks by 8 bytes per line, the packets are those of the default run and of the oracle."""
+    model, cs, ts, aux = synth.build("small", ncoord=8, options=options)
+    pk0 = synth.make_packets(model, aux, 30000, kpkt_fraction=0.2)
+    outs = []
+    for dpop in ("1", "0"):
+        monkeypatch.setenv("ARTIS_AMD_DPOP", dpop)
+        eng = engine_mod.Engine(model, preset=options)
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, options)
+        eng.update_packets(p, e)
+        outs.append((p, e, eng.cache_tiles()[2]))
+        eng.close()
+    monkeypatch.delenv("ARTIS_AMD_DPOP", raising=False)
+    assert outs[0][2] - outs[1][2] == 8 * model["nlines"], (outs[0][2], outs[1][2])
+    parity.compare_packets(outs[1][0], outs[0][0], 0.0, "population factors on the fly vs stored")
+    parity.compare_stats(outs[1][1], outs[0][1], "population factors on the fly vs stored")
+    pa, ea = pk0[:6000].copy(), abi.estimators_for(model, options)
+    oracle.update_packets(model, cs, ts, pa, ea, preset=options)
+    parity.compare_packets(outs[1][0][:6000], pa, FLOAT_RTOL, "population factors on the fly vs oracle")
+
+
 def test_sparse_fills_do_not_cost_sweeps_and_vpkt_refuses_tiles(engine_mod, monkeypatch):
     """Two findings of the round-3 review of the tiled cache. (1) A sparse fill (a late visit that populates only the cells in which
     packets wait) left its residency bitmap switched on while the next tile's packets were classified, which hid that tile until the

@@ -540,6 +540,24 @@ def test_reference_ci_option_sets_bit_exact(oracle, options):
             assert np.all(per_comb[3::4] >= full)           # without the lines of one element
 
 
+@pytest.mark.parametrize("filters", ["1", "0"])
+@pytest.mark.parametrize("options,gridtype,ncoord", [("classic", abi.GRID_CARTESIAN3D, 8), ("nltenebular", abi.GRID_SPHERICAL1D, 16),
+                                                     ("ci_classic_vpkt", abi.GRID_CARTESIAN3D, 6)])
+def test_undecided_searches_through_the_slow_path_bit_exact(oracle, monkeypatch, options, gridtype, ncoord, filters):
+    """What k_thermal does with a search its filters cannot decide (ARTIS_EMU_SPLIT=1: ma_jump<true>, do_kpkt<true>): the packet
+    leaves with the draw in its pend fields (PEND_MA_SEARCH / _RADSEARCH / PEND_KPKT_COLLEXC) and the slow path re-adds the sums and
+    carries on. With the filters as they are (3e-4 of the transitions take that way) and with ARTIS_EMU_MAFILTERS=0 (EVERY transition,
+    radiative de-excitation and cooling draw does): bit-exact against the oracle."""
+    monkeypatch.setenv("ARTIS_EMU_SPLIT", "1")
+    monkeypatch.setenv("ARTIS_EMU_MAFILTERS", filters)
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options, t_days=5.0 if "vpkt" in options else 20.0)
+    pk0 = synth.make_packets(model, aux, 2500 if filters == "1" else 600, kpkt_fraction=0.3)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, "searches through the slow path vs oracle")
+    parity.compare_stats(eb, ea, "searches through the slow path vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, "searches through the slow path vs oracle")
+
+
 @pytest.mark.parametrize("options,preset,ncoord,gridtype,npk", [
     ("classic", "small", 8, abi.GRID_CARTESIAN3D, 3000),
     ("classic", "w7", 5, abi.GRID_CARTESIAN3D, 600),
@@ -558,6 +576,25 @@ def test_undecided_draws_readd_the_sums_bit_exact(oracle, monkeypatch, options, 
     parity.compare_packets(pb, pa, 0.0, "re-added sums vs oracle")
     parity.compare_stats(eb, ea, "re-added sums vs oracle")
     assert ea.stats[abi.STAT_X_MA_JUMPS] > 10 * npk and ea.stats_dict()["K_STAT_TO_MA_COLLEXC"] > 0
+
+
+@pytest.mark.parametrize("options,gridtype,ncoord,t_days", [
+    ("classic", abi.GRID_CARTESIAN3D, 8, 20.0),
+    ("kilonova_expopac", abi.GRID_CYLINDRICAL2D, 6, 20.0),     # k_expopac reads the population factors too
+    ("ci_classic_vpkt", abi.GRID_CARTESIAN3D, 6, 5.0),         # ... and the virtual packets' line walk
+])
+def test_line_population_factors_formed_on_the_fly_bit_exact(oracle, monkeypatch, options, gridtype, ncoord, t_days):
+    """The engine drops the cell cache's line_dpop rows (8 bytes per line and cell) when the cache would not fit one tile with them:
+    the line walk then forms B_lu n_l - B_ul n_u from the line record and the two level populations where it reads it (physics.h
+    line_dpop_at). ARTIS_EMU_DPOP=0 runs the kernel bodies that way: bit-exact against the oracle."""
+    monkeypatch.setenv("ARTIS_EMU_DPOP", "0")
+    model, cs, ts, aux = synth.build("small", ncoord=ncoord, gridtype=gridtype, options=options, t_days=t_days)
+    pk0 = synth.make_packets(model, aux, 2000, kpkt_fraction=0.2)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, "population factors on the fly vs oracle")
+    parity.compare_stats(eb, ea, "population factors on the fly vs oracle")
+    parity.compare_estimators(eb, ea, 1e-11, "population factors on the fly vs oracle")
+    assert ea.stats[abi.STAT_X_LINES_VISITED] > (10 * len(pk0) if "expopac" not in options else 1000)
 
 
 def test_macroatom_filters_decide_what_the_f64_comparison_decides():
