@@ -1089,8 +1089,10 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
 // kernel with the draw in the packet's pend fields (physics.h PEND_MA_SEARCH / _RADSEARCH / PEND_KPKT_COLLEXC), which re-adds the sums
 // and carries on; the packet is back on the thermal list for the next launch. With the code inlined here the kernel spilled 122
 // instead of 21 registers, reloaded around every phase: 200 GB of scratch traffic per step.
+// (Not in the builds with detailed bound-free estimators -- the nltenebular family: their steps are made of twice as many launch rounds,
+// and every hand-over costs a packet the rest of its launch: measured 1417 ms with, 1403 without.)
 #ifndef ARTIS_THERMAL_SPLIT_EXACT
-#define ARTIS_THERMAL_SPLIT_EXACT 1
+#define ARTIS_THERMAL_SPLIT_EXACT (ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 0 : 1)
 #endif
 #ifndef ARTIS_MA_DEFER_EXACT
 #define ARTIS_MA_DEFER_EXACT 1  // the re-adding of a search's sums outside the transition loop (physics.h ma_jump_internal<true>)
