@@ -148,15 +148,20 @@ __global__ void __launch_bounds__(BLOCK) k_corrphotoion(Env env, const int32_t *
   const int ul = target_level[k];
   populate_corrphotoion(env, c, ul, k - env.M.level_phixstargetstart[ul]);
 }
-// Bound-bound part of a cell's macro-atom records: one WAVE per (cell, run of alltrans entries). Each lane evaluates
-// the rate coefficients of one transition (every lane busy, whatever the levels' transition counts), then the wave forms
-// the running sums of macroatom.cc:64-140 with an ORDER-PRESERVING scan: in step k the lanes that are k entries into
-// their (level, direction) segment add their term to the sum of the lane before them -- the additions of the
-// reference's loop, in its order, so the sums carry the same bits as the sequential form (physics.h
-// populate_level_bb / populate_dirfilter_seq) -- while loads and stores stay coalesced (round 2's per-level loop ran at ~1 TB/s on strided
-// 8-byte accesses). A segment that crosses a 64-entry chunk hands its partial sums to the next chunk.
-// the value of the lane below (lane 0: 0), as two DPP wave-shift moves: the scan's steps are a serial chain, and a DPP
-// move costs a few cycles where ds_bpermute (what __shfl_up compiles to) costs an LDS round trip
+// Bound-bound part of a cell's macro-atom records: one WAVE per (cell, block of alltrans entries), three passes over the
+// block's entries in LDS (round 4; rounds 2-3: a wave scan in registers whose serial steps -- one per position in the longest
+// segment of a 64-entry chunk, 18 instructions each for all 64 lanes -- were 11 % of the population with ~9 transitions per
+// direction and 26 % with ~25):
+//   1. every lane evaluates the rate coefficients of its transitions (every lane busy, whatever the levels' transition counts)
+//      and leaves the three terms each adds to its level's running sums (macroatom.cc:64-140) in LDS;
+//   2. ONE LANE PER SEGMENT (a level's downward or upward transitions) adds its segment's terms up in the reference's order --
+//      the additions of the sequential form (physics.h populate_level_bb / populate_dirfilter_seq), so the same bits -- 10-30
+//      segments side by side, and writes the level's rates;
+//   3. every lane turns its transitions' sums into filter entries (tables.h "FILTERS": fractions of the segment's last sum); a
+//      line is usable when every one of its entries is a finite fraction (a flag per line in LDS).
+// A segment longer than a block (DevModel::malongsegs) is a block of its own: its rates are summed here 64 terms at a time, its
+// filters written by k_mafilter_long.
+// the value of the lane below (lane 0: 0), as two DPP wave-shift moves
 __device__ inline double wave_shr1(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
@@ -170,95 +175,145 @@ __device__ inline unsigned long long line_lanes(int lane, int ti, int seglen) {
   const int cnt = left < MAREC_PER ? left : MAREC_PER;
   return ((1ull << cnt) - 1ull) << first;
 }
-__global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {  // 128 VGPR without spills: 4 waves/SIMD (-6 ms per step)
+// where entry e of a block (alltrans index a0 + e) sits in its segment
+struct MaEntryPos {
+  LevelPack lpk;
+  int ti, seglen, e_seg0;  // index within the direction, the direction's transitions, the block entry of the direction's first
+  bool isdown;
+};
+__device__ inline MaEntryPos ma_entry_pos(const DevModel &M, int a0, int e) {
+  MaEntryPos r;
+  r.lpk = M.level_pack[M.alltrans_owner[a0 + e]];
+  const int i = (a0 + e) - r.lpk.alltrans_startdown;
+  r.isdown = i < r.lpk.ndown;
+  r.ti = r.isdown ? i : i - r.lpk.ndown;
+  r.seglen = r.isdown ? r.lpk.ndown : r.lpk.nup;
+  r.e_seg0 = e - r.ti;
+  return r;
+}
+__global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
+  __shared__ double lds_v[BLOCK / 64][3][MATRANS_BLOCK];          // the terms, then the running sums
+  __shared__ uint16_t lds_q[BLOCK / 64][2][MATRANS_BLOCK];        // filter entries: internal, radiative
+  __shared__ uint8_t lds_ok[BLOCK / 64][2][MATRANS_BLOCK];        // per filter line (at its first entry): every entry a finite fraction
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  const int nblk = env.M.nscanblk;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const DevModel &M = env.M;
+  const int nblk = M.nscanblk;
   if (wave >= fill_count(env) * nblk) return;
   const int64_t kf = wave / nblk;
   const int c = fill_cell(env, kf);
   const int blk = (int)(wave % nblk);
-  U4 *row = env.K.macache + ((int64_t)c * env.M.nmacache);
-  double *upterms = env.collexc_terms + (kf * env.M.nupcum);
-  double c0 = 0., c1 = 0., c2 = 0.;  // sums carried into the chunk by a segment that began before it (segments of > 64 transitions)
-  for (int ch = env.M.scanblk_chunk0[blk]; ch < env.M.scanblk_chunk0[blk + 1]; ch++) {
-    const int a0 = env.M.scanchunk_start[ch], nvalid = env.M.scanchunk_start[ch + 1] - a0;
-    const int ati = a0 + lane;
-    const bool valid = lane < nvalid;
-    MaTransTerms t;
-    t.v0 = t.v1 = t.v2 = t.kterm = 0.;
-    t.i = 0;
-    t.isdown = false;
-    t.ul = 0;
-    t.lpk = LevelPack{0, 0, 0, 0};
-    if (valid) t = matrans_terms(env, c, ati);
-    // distance to the first entry of the lane's segment inside this chunk (a segment = one level, one direction)
-    const int off = valid ? (t.i < lane ? t.i : lane) : 0;
-    const bool continues = valid && t.i > lane;  // the segment began in the previous chunk: lane 0 takes the carry
-    double s0 = (continues ? c0 : 0.) + t.v0, s1 = (continues ? c1 : 0.) + t.v1, s2 = (continues ? c2 : 0.) + t.v2;
-    int maxoff = off;
-    for (int o = 32; o > 0; o >>= 1) {
-      const int v = __shfl_xor(maxoff, o);
-      maxoff = v > maxoff ? v : maxoff;
-    }
-    for (int k = 1; k <= maxoff; k++) {
-      const double p0 = wave_shr1(s0), p1 = wave_shr1(s1), p2 = wave_shr1(s2);
-      if (off == k) {
-        s0 = p0 + t.v0;
-        s1 = p1 + t.v1;
-        s2 = p2 + t.v2;
+  const int seg0 = M.scanblk_seg0[blk], seg1 = M.scanblk_seg0[blk + 1];
+  const MaLongSeg sfirst = M.scansegs[seg0], slast = M.scansegs[seg1 - 1];
+  const int a0 = sfirst.ats0, nent = (slast.ats0 + slast.n) - a0;
+  U4 *row = env.K.macache + ((int64_t)c * M.nmacache);
+  double *upterms = env.collexc_terms + (kf * M.nupcum);
+  double(*v)[MATRANS_BLOCK] = lds_v[w];
+  if (nent > MATRANS_BLOCK) {
+    // one long segment: its rates, 64 terms at a time (lane k adds its term to the finished sum of lane k - 1; lane 0 takes the carry)
+    const LevelPack lpk = M.level_pack[sfirst.ul];
+    double c0 = 0., c1 = 0., c2 = 0.;
+    for (int base = 0; base < nent; base += 64) {
+      const bool valid = base + lane < nent;
+      MaTransTerms t;
+      t.v0 = t.v1 = t.v2 = t.kterm = 0.;
+      if (valid) {
+        t = matrans_terms(env, c, a0 + base + lane);
+        if (!t.isdown) upterms[M.level_upcum_start[t.ul] + t.i] = t.kterm;
       }
-    }
-    U4 *rec = row + t.lpk.rec_off;
-    const int seglen = valid ? (t.isdown ? t.lpk.ndown : t.lpk.nup) : 1;
-    if (valid) {
-      double *rates = ma_rates_of(rec, t.lpk.ndown, t.lpk.nup);
-      if (t.isdown) {
-        if (t.i == seglen - 1) {
-          rates[ARTIS_MA_ACTION_RADDEEXC] = s0;
-          rates[ARTIS_MA_ACTION_COLDEEXC] = s1;
-          rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = s2;
+      double s0 = (lane == 0 ? c0 : 0.) + t.v0, s1 = (lane == 0 ? c1 : 0.) + t.v1, s2 = (lane == 0 ? c2 : 0.) + t.v2;
+      for (int k = 1; k < 64; k++) {
+        const double p0 = wave_shr1(s0), p1 = wave_shr1(s1), p2 = wave_shr1(s2);
+        if (lane == k) {
+          s0 = p0 + t.v0;
+          s1 = p1 + t.v1;
+          s2 = p2 + t.v2;
         }
+      }
+      const int last = (nent - base < 64 ? nent - base : 64) - 1;
+      c0 = __shfl(s0, last);
+      c1 = __shfl(s1, last);
+      c2 = __shfl(s2, last);
+    }
+    if (lane == 0) {
+      double *rates = ma_rates_of(row + lpk.rec_off, lpk.ndown, lpk.nup);
+      if (sfirst.dir == 0) {
+        rates[ARTIS_MA_ACTION_RADDEEXC] = c0;
+        rates[ARTIS_MA_ACTION_COLDEEXC] = c1;
+        rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = c2;
       } else {
-        upterms[env.M.level_upcum_start[t.ul] + t.i] = t.kterm;
-        if (t.i == seglen - 1) rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s0;
+        rates[ARTIS_MA_ACTION_INTERNALUPSAME] = c0;
       }
     }
-    {
-      // The filter entries of this transition (tables.h "FILTERS"): its running sums as fractions of the direction's whole
-      // rates, which are the sums of the direction's last transition -- at hand when the segment lies inside this chunk (all
-      // but the segments of more than 64 transitions: DevModel::malongsegs, k_mafilter_long). A line is usable when every one
-      // of its entries is a finite fraction: a vote of the lanes that hold the line's entries.
-      const int ti = valid ? t.i : 0;
-      const int endlane = lane + (seglen - 1 - ti);
-      const bool inchunk = valid && ti <= lane && endlane < nvalid;
-      const double whole_int = __shfl(t.isdown ? s2 : s0, endlane & 63);
-      const double whole_rad = __shfl(s0, endlane & 63);
-      bool ok_int = (whole_int > 0.) && (whole_int <= DBLMAX), ok_rad = (whole_rad > 0.) && (whole_rad <= DBLMAX);
-      uint32_t q_int = MAFILT_NONE, q_rad = MAFILT_NONE;
-      if (inchunk && ti < seglen - 1) {
-        if (ok_int) q_int = mafilt_quant(t.isdown ? s2 : s0, whole_int, &ok_int);
-        if (ok_rad && t.isdown) q_rad = mafilt_quant(s0, whole_rad, &ok_rad);
-      }
-      const unsigned long long bad_int = __ballot(inchunk && !ok_int), bad_rad = __ballot(inchunk && t.isdown && !ok_rad);
-      if (inchunk) {
-        const unsigned long long mine = line_lanes(lane, ti, seglen);
-        const bool lok_int = (bad_int & mine) == 0ull, lok_rad = (bad_rad & mine) == 0ull;
-        U4 *line = rec + marec_slot(t.isdown ? MADIR_DOWN : MADIR_UP, ti / MAREC_PER, t.lpk.ndown, t.lpk.nup);
-        mafilt_put(line, ti % MAREC_PER, lok_int ? q_int : 0u);
-        if (ti % MAREC_PER == 0) mafilt_put(line, 7, lok_int ? MAFILT_NONE : 0u);  // the line's "usable" mark
-        if (t.isdown) {
-          U4 *rline = rec + marec_slot(MADIR_RAD, ti / MAREC_PER, t.lpk.ndown, t.lpk.nup);
-          mafilt_put(rline, ti % MAREC_PER, lok_rad ? q_rad : 0u);
-          if (ti % MAREC_PER == 0) mafilt_put(rline, 7, lok_rad ? MAFILT_NONE : 0u);
-        }
-      }
+    return;
+  }
+  // 1. the terms
+  for (int e = lane; e < nent; e += 64) {
+    const MaTransTerms t = matrans_terms(env, c, a0 + e);
+    v[0][e] = t.v0;
+    v[1][e] = t.v1;
+    v[2][e] = t.v2;
+    lds_ok[w][0][e] = 1;
+    lds_ok[w][1][e] = 1;
+    if (!t.isdown) upterms[M.level_upcum_start[t.ul] + t.i] = t.kterm;
+  }
+  __threadfence_block();  // (the passes exchange data between the lanes of this wave through LDS: in order, but the compiler must not move them)
+  // 2. the running sums, a lane per segment
+  for (int si = seg0 + lane; si < seg1; si += 64) {
+    const MaLongSeg sg = M.scansegs[si];
+    const int o = sg.ats0 - a0;
+    double s0 = 0., s1 = 0., s2 = 0.;
+    for (int i = 0; i < sg.n; i++) {
+      s0 += v[0][o + i];
+      s1 += v[1][o + i];
+      s2 += v[2][o + i];
+      v[0][o + i] = s0;
+      v[2][o + i] = s2;
     }
-    // the last lane's sums go on if its segment does (a long segment's chunks follow each other inside one block)
-    const int last = (nvalid > 0 ? nvalid : 1) - 1;
-    c0 = __shfl(s0, last);
-    c1 = __shfl(s1, last);
-    c2 = __shfl(s2, last);
+    const LevelPack lpk = M.level_pack[sg.ul];
+    double *rates = ma_rates_of(row + lpk.rec_off, lpk.ndown, lpk.nup);
+    if (sg.dir == 0) {
+      rates[ARTIS_MA_ACTION_RADDEEXC] = s0;
+      rates[ARTIS_MA_ACTION_COLDEEXC] = s1;
+      rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = s2;
+    } else {
+      rates[ARTIS_MA_ACTION_INTERNALUPSAME] = s0;
+    }
+  }
+  __threadfence_block();
+  // 3a. the filter entries of every transition: its running sums as fractions of the direction's last ones
+  for (int e = lane; e < nent; e += 64) {
+    const MaEntryPos ps = ma_entry_pos(M, a0, e);
+    const int e_last = ps.e_seg0 + ps.seglen - 1;
+    const double whole_int = v[ps.isdown ? 2 : 0][e_last], whole_rad = v[0][e_last];
+    bool ok_int = (whole_int > 0.) && (whole_int <= DBLMAX), ok_rad = (whole_rad > 0.) && (whole_rad <= DBLMAX);
+    uint32_t q_int = MAFILT_NONE, q_rad = MAFILT_NONE;
+    if (ps.ti < ps.seglen - 1) {
+      if (ok_int) q_int = mafilt_quant(v[ps.isdown ? 2 : 0][e], whole_int, &ok_int);
+      if (ok_rad && ps.isdown) q_rad = mafilt_quant(v[0][e], whole_rad, &ok_rad);
+    }
+    lds_q[w][0][e] = (uint16_t)q_int;
+    lds_q[w][1][e] = (uint16_t)q_rad;
+    const int e_line = e - (ps.ti % MAREC_PER);
+    if (!ok_int) lds_ok[w][0][e_line] = 0;
+    if (ps.isdown && !ok_rad) lds_ok[w][1][e_line] = 0;
+  }
+  __threadfence_block();
+  // 3b. ... into the records: the entries of a line that is not usable are 0, its mark too
+  for (int e = lane; e < nent; e += 64) {
+    const MaEntryPos ps = ma_entry_pos(M, a0, e);
+    const int e_line = e - (ps.ti % MAREC_PER);
+    U4 *rec = row + ps.lpk.rec_off;
+    const bool lok_int = lds_ok[w][0][e_line] != 0;
+    U4 *line = rec + marec_slot(ps.isdown ? MADIR_DOWN : MADIR_UP, ps.ti / MAREC_PER, ps.lpk.ndown, ps.lpk.nup);
+    mafilt_put(line, ps.ti % MAREC_PER, lok_int ? lds_q[w][0][e] : 0u);
+    if (ps.ti % MAREC_PER == 0) mafilt_put(line, 7, lok_int ? MAFILT_NONE : 0u);  // the line's "usable" mark
+    if (ps.isdown) {
+      const bool lok_rad = lds_ok[w][1][e_line] != 0;
+      U4 *rline = rec + marec_slot(MADIR_RAD, ps.ti / MAREC_PER, ps.lpk.ndown, ps.lpk.nup);
+      mafilt_put(rline, ps.ti % MAREC_PER, lok_rad ? lds_q[w][1][e] : 0u);
+      if (ps.ti % MAREC_PER == 0) mafilt_put(rline, 7, lok_rad ? MAFILT_NONE : 0u);
+    }
   }
 }
 __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
@@ -267,8 +322,8 @@ __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   if (i >= total) return;
   populate_macroatom(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
-// The filters of the directions with more than 64 transitions (DevModel::malongsegs), which k_matrans' chunks cannot hold
-// whole: a wave per (cell, segment) re-forms the running sums 63 transitions (nine filter lines) at a time -- the same terms
+// The filters of the directions with more transitions than a block of k_matrans holds (DevModel::malongsegs: > MATRANS_BLOCK):
+// a wave per (cell, segment) re-forms the running sums 63 transitions (nine filter lines) at a time -- the same terms
 // added in the same order, lane k to the finished sum of lane k-1 -- and quantises them with the direction's whole rates,
 // which k_matrans has left in the record. (physics.h populate_dirfilter_seq is the sequential form.)
 __global__ void __launch_bounds__(BLOCK) k_mafilter_long(Env env) {

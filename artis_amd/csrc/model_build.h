@@ -18,8 +18,8 @@ struct ModelOwned {
   std::vector<LevelPack> level_pack;
   std::vector<int32_t> level_upcum_start;
   std::vector<int32_t> alltrans_owner;
-  std::vector<int32_t> scanchunk_start, scanblk_chunk0;
-  std::vector<MaLongSeg> malongsegs;
+  std::vector<int32_t> scanblk_seg0;
+  std::vector<MaLongSeg> scansegs, malongsegs;
   std::vector<MaTarget> alltrans_target;
   std::vector<uint16_t> alltrans_tlevel16;
   std::vector<CoolLineRef> coollines;
@@ -60,8 +60,8 @@ struct ModelOwned {
   X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
   X(alltrans_owner, int32_t, (m).nalltrans)                                        \
-  X(scanchunk_start, int32_t, ((m).nscanchunk + 1))                                \
-  X(scanblk_chunk0, int32_t, ((m).nscanblk + 1))                                   \
+  X(scansegs, MaLongSeg, ((m).nscansegs > 0 ? (m).nscansegs : 1))                  \
+  X(scanblk_seg0, int32_t, ((m).nscanblk + 1))                                     \
   X(malongsegs, MaLongSeg, ((m).nmalongsegs > 0 ? (m).nmalongsegs : 1))            \
   X(alltrans_target, MaTarget, (m).nalltrans)                                      \
   X(alltrans_tlevel16, uint16_t, (m).nalltrans)                                    \
@@ -236,51 +236,37 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
     for (int t = 0; t < m.level_ndowntrans[i] + m.level_nuptrans[i]; t++) own.alltrans_owner[m.level_alltrans_startdown[i] + t] = i;
   v.alltrans_owner = own.alltrans_owner.data();
   {
-    // the scan of k_matrans (tables.h DevModel::scanchunk_start): chunks of whole (level, direction) segments, at most 64 entries;
-    // a segment with more than 64 transitions is cut into chunks of its own; blocks of ~256 entries never split such a segment
-    own.scanchunk_start.assign(1, 0);
-    own.scanblk_chunk0.assign(1, 0);
+    // the work of k_matrans (tables.h DevModel::scansegs): the (level, direction) segments in alltrans order, and blocks of whole
+    // segments with at most MATRANS_BLOCK entries together; a longer segment is a block of its own
+    own.scansegs.clear();
+    own.scanblk_seg0.assign(1, 0);
     own.malongsegs.clear();
-    int chunk_fill = 0, blk_fill = 0;
-    auto close_chunk = [&](int at) {
-      if (chunk_fill > 0) {
-        own.scanchunk_start.push_back(at);
-        chunk_fill = 0;
-      }
-    };
-    auto close_block = [&]() {
-      if (blk_fill > 0) {
-        own.scanblk_chunk0.push_back((int32_t)own.scanchunk_start.size() - 1);
-        blk_fill = 0;
-      }
-    };
+    int blk_fill = 0;
     for (int i = 0; i < m.nlevels; i++) {
       const LevelPack &lp = own.level_pack[i];
       for (int dir = 0; dir < 2; dir++) {
         const int n = dir == 0 ? lp.ndown : lp.nup;
         if (n <= 0) continue;
         const int sa = lp.alltrans_startdown + (dir == 0 ? 0 : lp.ndown);
-        if (n > 64) {
-          close_chunk(sa);
-          close_block();
-          for (int o = 64; o < n; o += 64) own.scanchunk_start.push_back(sa + o);
-          own.scanchunk_start.push_back(sa + n);
-          own.scanblk_chunk0.push_back((int32_t)own.scanchunk_start.size() - 1);
-          own.malongsegs.push_back(MaLongSeg{sa, n, i, dir});
-          continue;
+        if (blk_fill > 0 && (blk_fill + n > MATRANS_BLOCK)) {
+          own.scanblk_seg0.push_back((int32_t)own.scansegs.size());
+          blk_fill = 0;
         }
-        if (chunk_fill + n > 64) close_chunk(sa);
-        if (chunk_fill == 0 && blk_fill + n > 256) close_block();
-        chunk_fill += n;
+        own.scansegs.push_back(MaLongSeg{sa, n, i, dir});
         blk_fill += n;
+        if (n > MATRANS_BLOCK) {
+          own.malongsegs.push_back(MaLongSeg{sa, n, i, dir});
+          own.scanblk_seg0.push_back((int32_t)own.scansegs.size());
+          blk_fill = 0;
+        }
       }
     }
-    close_chunk(m.nalltrans);
-    close_block();
-    v.nscanchunk = (int32_t)own.scanchunk_start.size() - 1;
-    v.nscanblk = (int32_t)own.scanblk_chunk0.size() - 1;
-    v.scanchunk_start = own.scanchunk_start.data();
-    v.scanblk_chunk0 = own.scanblk_chunk0.data();
+    if (blk_fill > 0) own.scanblk_seg0.push_back((int32_t)own.scansegs.size());
+    v.nscansegs = (int32_t)own.scansegs.size();
+    v.nscanblk = (int32_t)own.scanblk_seg0.size() - 1;
+    if (own.scansegs.empty()) own.scansegs.push_back(MaLongSeg{0, 0, 0, 0});
+    v.scansegs = own.scansegs.data();
+    v.scanblk_seg0 = own.scanblk_seg0.data();
     v.nmalongsegs = (int32_t)own.malongsegs.size();
     if (own.malongsegs.empty()) own.malongsegs.push_back(MaLongSeg{0, 0, 0, 0});
     v.malongsegs = own.malongsegs.data();

@@ -105,13 +105,14 @@ constexpr int marec_rates_slot(int nd, int nu) { return MAREC_QUAD + (2 * marec_
 constexpr int marec_slots(int nd, int nu) { return marec_rates_slot(nd, nu) + MAREC_RATE_SLOTS; }
 constexpr double MAFILT_SCALE = 32768.;
 constexpr uint32_t MAFILT_NONE = 0x7FFFu;  // an entry that is never counted
+constexpr int MATRANS_BLOCK = 256;  // entries of alltrans a wave of k_matrans holds in LDS at a time
 constexpr int MAREC_SLACK = 16;  // elements past the last row of every cache array (padded reads stay inside the allocation)
 
 struct alignas(16) D2 {
   double x, y;
 };
-// a (level, direction) whose transitions do not fit one 64-lane chunk of k_matrans' scan (static; real atomic data: levels
-// with hundreds of transitions): k_mafilter_long writes its filters, a wave per (cell, entry)
+// a (level, direction) with transitions (static): the segments k_matrans sums (DevModel::scansegs); those longer than one of its
+// blocks (real atomic data: levels with hundreds of transitions) are listed again in DevModel::malongsegs, for k_mafilter_long
 struct alignas(16) MaLongSeg {
   int32_t ats0, n, ul, dir;  // first entry in alltrans, transitions, level, 0 = downward / 1 = upward
 };
@@ -175,13 +176,13 @@ struct DevModel {
   const int32_t *level_upcum_start;  // derived: offset of the level's upward transitions in a cell's row of Env::collexc_terms
   const int32_t *alltrans_lineindex, *alltrans_targetlevelindex;
   const int32_t *alltrans_owner;  // derived: the level whose block of alltrans an entry belongs to
-  // derived: the scan of k_matrans. alltrans is cut into CHUNKS of at most 64 entries, [nscanchunk + 1] start indices, each
-  // a whole number of (level, direction) segments -- a segment with more than 64 transitions takes chunks of its own --
-  // and runs of chunks (~256 entries, a long segment whole) into BLOCKS, [nscanblk + 1] first chunks: one wave per (cell, block)
-  const int32_t *scanchunk_start;
-  const int32_t *scanblk_chunk0;
-  int32_t nscanchunk, nscanblk;
-  const MaLongSeg *malongsegs;  // derived: the segments longer than a chunk, [nmalongsegs]
+  // derived: the work of k_matrans. scansegs: every (level, direction) with transitions, in alltrans order; scanblk_seg0: [nscanblk + 1]
+  // first segment of each BLOCK, a run of whole segments of at most MATRANS_BLOCK entries together (a longer segment is a block of its
+  // own): one wave per (cell, block). malongsegs: the segments longer than a block, whose filters k_mafilter_long writes.
+  const MaLongSeg *scansegs;
+  const int32_t *scanblk_seg0;
+  int32_t nscansegs, nscanblk;
+  const MaLongSeg *malongsegs;
   int32_t nmalongsegs;
   const MaTarget *alltrans_target;  // derived: [nalltrans] what a transition needs to know of the level it leads to
   // derived: [nalltrans] the target level alone (index within the ion), 2 bytes: with level_pack the same information in two

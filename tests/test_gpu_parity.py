@@ -441,12 +441,27 @@ def test_cellcache_matches_oracle(engine_mod, oracle):
 
 
 def test_filter_records_of_long_directions_match_the_sequential_form(engine_mod, oracle):
-    """Atomic data with levels of more than 64 transitions per direction (w7big: up to 73): their filters are written by
-    k_mafilter_long (a wave per cell and direction, 63 transitions at a time) instead of k_matrans' chunks. debug_cellcache()
-    re-adds every cumulative sum of the cell on the device, compares every filter entry and mark of every record with the
-    sequential form's (it fails otherwise), and its sums and rates meet the oracle's stored arrays."""
-    model, cs, ts, aux = synth.build("w7big", ncoord=4)
-    assert max(model.d["level_ndowntrans"]) > 64
+    """Atomic data with more transitions per direction than a block of k_matrans holds in LDS (256; here one ion with 420 levels: up to
+    ~250 upward and ~290 downward transitions of a level): the rates of such a direction are summed 64 terms at a time and its filters
+    written by k_mafilter_long (a wave per cell and direction, 63 transitions at a time). debug_cellcache() re-adds every cumulative
+    sum of the cell on the device, compares every filter entry and mark of every record with the sequential form's (it fails
+    otherwise), and its sums and rates meet the oracle's stored arrays. (The w7big data -- directions of up to 73 transitions,
+    blocks of ~10 segments -- are checked the same way.)"""
+    synth.PRESETS["longdir"] = ([(26, 1, 2)], 420, 0.7, 20)
+    for preset in ("longdir", "w7big"):
+        model, cs, ts, aux = synth.build(preset, ncoord=4)
+        assert max(model.d["level_ndowntrans"]) > (256 if preset == "longdir" else 64)
+        eng = engine_mod.Engine(model)
+        eng.set_cellstate(cs, ts)
+        c = model["npts_nonempty"] // 2
+        a = oracle.cellcache(model, cs, ts, c)
+        b = eng.debug_cellcache(c)
+        for k in ("maprocessrates", "matrans", "cooling_contrib"):
+            x, y = np.asarray(a[k], dtype=np.float64), np.asarray(b[k], dtype=np.float64)
+            denom = np.maximum(np.maximum(np.abs(x), np.abs(y)), 1e-300)
+            assert (np.abs(x - y) / denom).max() < 1e-12, f"{preset} cell {c}: {k}"
+        eng.close()
+    model, cs, ts, aux = synth.build("longdir", ncoord=4)
     eng = engine_mod.Engine(model)
     eng.set_cellstate(cs, ts)
     for c in (0, model["npts_nonempty"] - 1):
