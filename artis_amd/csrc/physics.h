@@ -1664,6 +1664,37 @@ AHD PhixsRead phixs_lookup(const DevModel &M, const float *xs, double nu_edge, d
 #endif
   return r;
 }
+// ... with the table read at a clamped place whatever the branch (one or two unconditional loads; an entry that phixs_finish()
+// does not use is read for nothing): phixs_finish(phixs_lookup_u()) == phixs_finish(phixs_lookup())
+AHD PhixsRead phixs_lookup_u(const DevModel &M, const float *xs, double nu_edge, double nu) {
+  const int NP = M.NPHIXSPOINTS;
+  const double INC = M.NPHIXSNUINCREMENT;
+  PhixsRead r = {0.f, 0.f, -1};
+#if ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION
+  int i = -1;
+  if (!(nu < nu_edge)) {
+    if (nu == nu_edge) {
+      i = 0;
+    } else if (nu < nu_edge * (1 + (INC * NP))) {
+      i = (int)((nu - nu_edge) / (INC * nu_edge));
+      if (NP - 1 < i) i = NP - 1;
+    } else {
+      i = NP;
+    }
+  }
+  r.i = i;
+  r.a = xs[(i < 0) ? 0 : ((i < NP) ? i : NP - 1)];
+#else
+  const double ireal = ((nu / nu_edge) - 1.0) / INC;
+  const int i = (int)floor(ireal);
+  r.i = (i < 0) ? -1 : i;
+  const int ia = (i < 0) ? 0 : ((i < NP - 1) ? i : NP - 1);
+  const int ib = (ia + 1 < NP) ? ia + 1 : NP - 1;
+  r.a = xs[ia];
+  r.b = xs[ib];
+#endif
+  return r;
+}
 AHD float phixs_finish(const DevModel &M, const PhixsRead r, double nu_edge, double nu) {
   const int NP = M.NPHIXSPOINTS;
   const double INC = M.NPHIXSNUINCREMENT;
@@ -1687,10 +1718,24 @@ AHD float phixs_finish(const DevModel &M, const PhixsRead r, double nu_edge, dou
 // calculate_chi_bf_gammacontr<true, SELECT> rpkt.cc:721. The continua that contribute (keep bitmap of the cell) are
 // taken CHI_BATCH at a time: all reads of a batch are issued before any of its arithmetic, the sum is accumulated in
 // the reference's order.
-// Batch of 2 (4 in the builds with detailed bound-free estimators): measured with k_rpkt at 3 waves/SIMD and 168 VGPRs, where
-// a batch of 4 costs 96 B more scratch: k_rpkt 340 -> 330 ms (classic), 383 -> 357 ms (kilonova_lte), 773 -> 779 (nltenebular).
+// Round 4: index -> table row -> cross section is a chain of two memory latencies per continuum, and the loop waited for both.
+// ARTIS_CHI_PREFETCH 2 = three continua in flight per lane (indices two ahead, pairs and cross sections one ahead; below), with
+// batches of ONE: k_rpkt 345 -> 287 ms (classic), 745 -> 612 ms (nltenebular, with k_bfest_dense). Measured beside it: 1 = only the
+// next batch's index and pair requested ahead (323 ms at batches of 2, 397 at 1, 375 / 395 at 3 / 4); 2 with batches of 2: 413 ms
+// (its operands do not fit 168 VGPRs: values still on their way are spilled, i.e. waited for); cross sections two / three ahead
+// (ARTIS_CHI_DEPTH 2 / 3): 299 / 406 ms. 0 = rounds 2-3 (batches of 2, 4 with detailed bound-free estimators: 345 ms).
+#ifndef ARTIS_LINE_AHEAD
+#define ARTIS_LINE_AHEAD 3  // lines whose (frequency, population factor) pairs are in flight in the line walk (possible_event()):
+                           // k_rpkt 287 (1: the next line's pair only, rounds 2-3) / 283 / 278 / 288 ms at 1 / 2 / 3 / 4 (MI355X, round 4)
+#endif
 #ifndef ARTIS_CHI_BATCH
-#define ARTIS_CHI_BATCH (ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 4 : 2)
+#define ARTIS_CHI_BATCH 1
+#endif
+#ifndef ARTIS_CHI_PREFETCH
+#define ARTIS_CHI_PREFETCH 2
+#endif
+#ifndef ARTIS_CHI_DEPTH
+#define ARTIS_CHI_DEPTH 1
 #endif
 // iterator over the set bits of a cell's keep bitmap inside [cbegin, cend), one 64-bit word per read
 struct KeepIter {
@@ -1759,10 +1804,123 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   if (cbegin < cend) kept_range(env, c, cbegin, cend, r0, r1);
   const int32_t *keptlist = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
   const D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * M.nbfcontinua);
+  // one continuum's term (rpkt.cc:770-798); true: SELECT has found its continuum
+  auto add_term = [&](int i, const ContPack &cpk, const PhixsRead &xrk, double nnk, double epk) -> bool {
+    nvisited++;
+    const double nu_edge = cpk.nu_edge;
+    const double sigma_bf = phixs_finish(M, xrk, nu_edge, nu);
+    double stim;
+    if (epk >= 0. && split_usable) {
+      stim = epk * ex;
+    } else {
+      stim = departure[i] * exp(-HOVERKB * (nu - nu_edge) / T_e);
+    }
+    const double corr = dmax(0., 1 - stim);
+    const double sigma_contr = sigma_bf * cpk.probability * corr;
+#if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
+    if (!SELECT) {
+      const int gi = cpk.gi;
+      if (gi >= 0) {
+        if (gi == lastgi) {
+          wsv[ng - 1] = sigma_contr;
+        } else {
+          wsv[ng] = sigma_contr;
+          wsi[ng] = gi;
+          ng++;
+          lastgi = gi;
+        }
+      }
+    }
+#endif
+    sum += nnk * sigma_contr;
+    if (SELECT && sum > threshold) {
+      *selected = i;
+      return true;
+    }
+    return false;
+  };
+#if ARTIS_CHI_PREFETCH == 2
+  // Three batches in flight (round 4): index -> table row -> cross section is a chain of two memory latencies and one LDS read per
+  // continuum. The indices are requested two batches ahead, the pairs and the cross sections one batch ahead (every read
+  // unconditional and from a clamped place, so that the wait for this batch's operands leaves exactly the younger requests in
+  // flight), and the arithmetic of a batch runs on operands requested a whole iteration earlier. Same terms, same order.
+  // The sets of operands rotate by NAME (the loop is unrolled ARTIS_CHI_DEPTH + 2 batches deep): a register move of a value still
+  // on its way would wait for it. ARTIS_CHI_DEPTH = how many batches ahead the cross sections are requested (the indices one more,
+  // the pairs -- contiguous, four to a 64-byte line -- one).
+  {
+    constexpr int B = ARTIS_CHI_BATCH, DX = ARTIS_CHI_DEPTH, NS = DX + 2;
+    int idx[NS][B];
+    D2 pr[NS][B];
+    PhixsRead xr[NS][B];
+    if (r0 < r1) {
+#pragma unroll
+      for (int d = 0; d <= DX; d++) {
+#pragma unroll
+        for (int k = 0; k < B; k++) idx[d][k] = keptlist[(r0 + (d * B) + k < r1) ? r0 + (d * B) + k : r1 - 1];
+      }
+#pragma unroll
+      for (int k = 0; k < B; k++) pr[0][k] = keptpair[(r0 + k < r1) ? r0 + k : r1 - 1];
+#pragma unroll
+      for (int d = 0; d < DX; d++) {
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+          const ContPack cpk = M.cont_pack[idx[d][k]];
+          xr[d][k] = phixs_lookup_u(M, M.allphixs + cpk.xs_off, cpk.nu_edge, nu);
+        }
+      }
+    }
+    for (int rs = r0; rs < r1; rs += NS * B) {
+#pragma unroll
+      for (int u = 0; u < NS; u++) {
+        const int r = rs + (u * B);
+        if (r >= r1) break;
+        const int sc = u, sp = (u + 1) % NS, sx = (u + DX) % NS, si = (u + DX + 1) % NS;
+#pragma unroll
+        for (int k = 0; k < B; k++) pr[sp][k] = keptpair[(r + B + k < r1) ? r + B + k : r1 - 1];
+#pragma unroll
+        for (int k = 0; k < B; k++) idx[si][k] = keptlist[(r + ((DX + 1) * B) + k < r1) ? r + ((DX + 1) * B) + k : r1 - 1];
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+          const ContPack cpk = M.cont_pack[idx[sx][k]];
+          xr[sx][k] = phixs_lookup_u(M, M.allphixs + cpk.xs_off, cpk.nu_edge, nu);
+        }
+#pragma unroll
+        for (int k = 0; k < B; k++) {
+          if (r + k < r1) {
+            const ContPack cpk = M.cont_pack[idx[sc][k]];
+            if (add_term(idx[sc][k], cpk, xr[sc][k], pr[sc][k].x, pr[sc][k].y)) return sum;
+          }
+        }
+      }
+    }
+  }
+#else
+#if ARTIS_CHI_PREFETCH
+  // (the next batch's indices and pairs are requested while this batch's cross sections are on their way: one memory latency
+  // per batch instead of two -- index -> table row -> cross section is a chain)
+  int idx_n[ARTIS_CHI_BATCH];
+  D2 pr_n[ARTIS_CHI_BATCH];
+  if (r0 < r1) {
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
+      const int rk = (r0 + k < r1) ? r0 + k : r1 - 1;  // (a place past the end reads the last one: unconditional loads)
+      idx_n[k] = keptlist[rk];
+      pr_n[k] = keptpair[rk];
+    }
+  }
+#endif
   for (int r = r0; r < r1; r += ARTIS_CHI_BATCH) {
     int idx[ARTIS_CHI_BATCH];
     ContPack cp[ARTIS_CHI_BATCH];
     double nn[ARTIS_CHI_BATCH], ep[ARTIS_CHI_BATCH];
+#if ARTIS_CHI_PREFETCH
+#pragma unroll
+    for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
+      idx[k] = (r + k < r1) ? idx_n[k] : -1;
+      nn[k] = pr_n[k].x;
+      ep[k] = pr_n[k].y;
+    }
+#else
 #pragma unroll
     for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
       const int rk = (r + k < r1) ? r + k : r;
@@ -1771,6 +1929,7 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
       nn[k] = pr.x;
       ep[k] = pr.y;
     }
+#endif
 #if defined(ARTIS_RPKT_EXTRA_LOADS) && defined(__HIP_DEVICE_COMPILE__)
     {  // (measurement only: one more 8-byte read per batch of continua, of a pair just read)
       const double qx = *(const volatile double *)(&keptpair[r].x);
@@ -1782,44 +1941,25 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
     PhixsRead xr[ARTIS_CHI_BATCH];
 #pragma unroll
     for (int k = 0; k < ARTIS_CHI_BATCH; k++) xr[k] = phixs_lookup(M, M.allphixs + cp[k].xs_off, cp[k].nu_edge, nu);
+#if ARTIS_CHI_PREFETCH
+    {  // (unconditional, from clamped places: the wait for this batch's cross sections can then leave exactly these in flight)
+      const int rn = r + ARTIS_CHI_BATCH;
+#pragma unroll
+      for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
+        const int rk = (rn + k < r1) ? rn + k : r1 - 1;
+        idx_n[k] = keptlist[rk];
+        pr_n[k] = keptpair[rk];
+      }
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < ARTIS_CHI_BATCH; k++) {
       if (idx[k] >= 0) {
-        const int i = idx[k];
-        nvisited++;
-        const double nu_edge = cp[k].nu_edge;
-        const double sigma_bf = phixs_finish(M, xr[k], nu_edge, nu);
-        double stim;
-        if (ep[k] >= 0. && split_usable) {
-          stim = ep[k] * ex;
-        } else {
-          stim = departure[i] * exp(-HOVERKB * (nu - nu_edge) / T_e);
-        }
-        const double corr = dmax(0., 1 - stim);
-        const double sigma_contr = sigma_bf * cp[k].probability * corr;
-#if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
-        if (!SELECT) {
-          const int gi = cp[k].gi;
-          if (gi >= 0) {
-            if (gi == lastgi) {
-              wsv[ng - 1] = sigma_contr;
-            } else {
-              wsv[ng] = sigma_contr;
-              wsi[ng] = gi;
-              ng++;
-              lastgi = gi;
-            }
-          }
-        }
-#endif
-        sum += nn[k] * sigma_contr;
-        if (SELECT && sum > threshold) {
-          *selected = i;
-          return sum;
-        }
+        if (add_term(idx[k], cp[k], xr[k], nn[k], ep[k])) return sum;
       }
     }
   }
+#endif
   if (!SELECT) {
     env.gamma_n[slot] = ng;
     ARTIS_STAT(env, ARTIS_STAT_X_CHI_EVALS);
@@ -2001,6 +2141,113 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
   double dist = 0.;
   int nvisited = 0;
   double result;
+#if ARTIS_LINE_AHEAD > 1
+  // The walk's chain of dependent reads is one (line frequency, population factor) pair per line visited, and after its first
+  // line the walk takes the lines of the list one after the other (closest_transition() with next_trans > 0). The pairs of the
+  // next ARTIS_LINE_AHEAD lines are in flight while a line is worked on: a ring of slots that rotates by NAME (the loop is
+  // unrolled once round the ring; a register move of a value still on its way would wait for it); a slot is refilled as soon as
+  // its line has been taken. Reads past the walk's last line are wasted, reads past the list's end go to its last line.
+  {
+    constexpr int NL = ARTIS_LINE_AHEAD;
+    double nu_s[NL], dp_s[NL];
+    int li = closest_transition(M.line_nu, M.nlines, nu_cmf, next_trans);
+    if (li >= 0) {
+#pragma unroll
+      for (int d = 0; d < NL; d++) {
+        const int l = (li + d < M.nlines) ? li + d : M.nlines - 1;
+        nu_s[d] = M.line_nu[l];
+        dp_s[d] = line_dpop_at(M, dpop, l);
+      }
+    }
+    bool stop = false;
+    while (!stop) {
+#pragma unroll
+      for (int u = 0; u < NL; u++) {
+    if (li < 0) {
+      const double tau_cont = chi_cont * (abort_dist - dist);
+      if (tau_rnd - tau > tau_cont) {
+        *next_trans_out = next_trans;
+        *is_bb = false;
+        result = DBLMAX;
+      } else {
+        *next_trans_out = M.nlines + 1;
+        *is_bb = false;
+        result = dist + ((tau_rnd - tau) / chi_cont);
+      }
+      stop = true;
+      break;
+    }
+    nvisited++;
+    const double nu_trans = nu_s[u];
+    const double dpop_li = dp_s[u];
+    {
+      const int l = (li + NL < M.nlines) ? li + NL : M.nlines - 1;
+      nu_s[u] = M.line_nu[l];
+      dp_s[u] = line_dpop_at(M, dpop, l);
+    }
+    next_trans = li + 1;
+    const double ldist = linedistance(prop_time, nu_cmf, nu_trans, dnu_on_dl);
+    const double tau_cont = chi_cont * ldist;
+    if (tau_rnd - tau > tau_cont) {
+      if (nu_trans < nu_cmf_abort) {
+        *next_trans_out = next_trans - 1;
+        *is_bb = false;
+        result = DBLMAX;
+        stop = true;
+        break;
+      }
+      // get_tau_sobolev<true> rpkt.cc:75 with the cell cache's (B_lu n_l - B_ul n_u)
+      const double tau_line = dmax(dpop_li * HCLIGHTOVERFOURPI * prop_time, 0.);
+      if ((tau_rnd - tau) <= (tau_cont + tau_line)) {
+        const LinePack lp = M.line_pack[li];
+        const int element = M.line_elementindex[li];
+        const int ion = M.line_ionindex[li];
+        ma.element = element;
+        ma.ion = ion;
+        ma.level = lp.upper - lstart(M, element, ion);
+        ma.activatingline = li;
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+        move_raw(px, py, pz, p.dx, p.dy, p.dz, prop_time, p.nu_rf, nu_cmf, p.e_rf, e_cmf, ldist);  // rpkt.cc:173-176
+        update_lineestimator(env, c, li, prop_time * CLIGHT * e_cmf / nu_cmf);
+#endif
+        *next_trans_out = next_trans;
+        *is_bb = true;
+        result = dist + ldist;
+        stop = true;
+        break;
+      }
+      dist += ldist;
+      tau += tau_cont + tau_line;
+#if !ARTIS_OPT_USE_RELATIVISTIC_DOPPLER_SHIFT
+      move_raw(px, py, pz, p.dx, p.dy, p.dz, prop_time, p.nu_rf, nu_cmf, p.e_rf, e_cmf, ldist);
+#else
+      // rpkt.cc:190-196: the linear approximation instead of the Doppler formula
+      px += (p.dx * ldist);
+      py += (p.dy * ldist);
+      pz += (p.dz * ldist);
+      prop_time += ldist / CLIGHT_PROP;
+      nu_cmf = p.nu_cmf + (dnu_on_dl * dist);
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+      e_cmf = nu_cmf * p.e_rf / p.nu_rf;  // consistent with the linearly approximated nu_cmf, rpkt.cc:199-203
+#else
+      (void)e_cmf;
+#endif
+#endif
+#if ARTIS_OPT_DETAILED_LINE_ESTIMATORS_ON
+      update_lineestimator(env, c, li, prop_time * CLIGHT * e_cmf / nu_cmf);  // rpkt.cc:206
+#endif
+    } else {
+      *next_trans_out = next_trans - 1;
+      *is_bb = false;
+      result = dist + ((tau_rnd - tau) / chi_cont);
+      stop = true;
+      break;
+    }
+    li = closest_transition(M.line_nu, M.nlines, nu_cmf, next_trans);
+      }
+    }
+  }
+#else
   // The walk's chain of dependent reads is one (line frequency, population factor) pair per line visited. The pair of
   // line li + 1 is requested while line li is worked on (the next line of the list is the next line of the walk,
   // closest_transition() with next_trans > 0): ahead_li says which line nu_ahead / dpop_ahead belong to.
@@ -2092,6 +2339,7 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
       break;
     }
   }
+#endif
   ARTIS_STAT_ADD(env, ARTIS_STAT_X_LINES_VISITED, nvisited);
   return result;
 }
