@@ -1426,14 +1426,29 @@ __global__ void __launch_bounds__(BLOCK) k_blackbody(Env env, const int32_t *lis
 // the attenuated energy into that observer's spectrum (f64 atomics). Nothing of the real packets is read or written.
 // Persistent and work-pulling like the propagation kernels: a lane whose ray has ended (left the grid, absorbed beyond tau_max, met a
 // thick cell) takes the next (event, observer) pair at once -- rays cross 1 ... 50 cells, and with one ray per lane from start to end a
-// wave lasted as long as its longest. 128 VGPRs (4 waves/SIMD; at 256 VGPRs and 1 wave/SIMD the kernel took 23 % longer).
+// wave lasted as long as its longest.
 #ifndef ARTIS_VPKT_WGS
 #define ARTIS_VPKT_WGS 4
 #endif
+#ifndef ARTIS_VPKT_TB
+#define ARTIS_VPKT_TB 768  // threads of the one workgroup per CU of the form with the continuum table in LDS: 3 waves/SIMD at 168 VGPRs.
+                          // Virtual-packet bench (1e6 packets, t = 5 d): 1470 / 1284 / 1290 ms per step at 1024 / 768 / 512 (MI355X, round 4)
+#endif
 constexpr int VPKT_CHUNKS = 2048;
-__global__ void __launch_bounds__(BLOCK, ARTIS_VPKT_WGS) k_vpkt(Env env, unsigned long long *gstats, int32_t *cursors) {
+// CONT_LDS (round 4): the static continuum table in LDS as in k_rpkt -- every cell a ray crosses sums the bound-free opacity
+// (chi_bf_gammacontr) -- with ONE workgroup of 1024 threads per CU instead of four of 256 (the same 4 waves/SIMD).
+template <bool CONT_LDS, int TB>
+__global__ void __launch_bounds__(TB, (CONT_LDS ? 1 : ARTIS_VPKT_WGS)) k_vpkt(Env env, unsigned long long *gstats, int32_t *cursors) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
+  __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  if (CONT_LDS) {
+    const D2 *src = (const D2 *)env.M.cont_pack;
+    D2 *dst = (D2 *)lds_cont;
+    for (int i = threadIdx.x; i < env.M.nbfcontinua * 2; i += TB) dst[i] = src[i];
+    env.M.cont_pack = lds_cont;
+    env.cont_in_lds = 1;
+  }
   __syncthreads();
   env.stats = lstats;
   const int nobs = env.M.vpkt->nobsdirections;
@@ -1455,7 +1470,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_VPKT_WGS) k_vpkt(Env env, unsigne
       if (have) have = vray_step(env, ray);
     }
   } else {  // (more pairs than a list index holds: one ray per lane from start to end)
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n64; i += (int64_t)gridDim.x * BLOCK) {
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n64; i += (int64_t)gridDim.x * TB) {
       const VpktSeed seed = queue[i / nobs];
       vpkt_trace_seed_direction(env, seed, (int)(i % nobs));
     }
@@ -1559,6 +1574,7 @@ struct artis_amd_engine {
   bool resident_on = false, sparse_fill = true;
   int64_t sparse_max_listed = 512;  // ... for visits that list at most this many packets (ARTIS_AMD_SPARSE_MAX)
   int64_t last_sparse_fills = 0, last_cells_filled = 0;
+  bool vpkt_cont_lds = true;  // ARTIS_AMD_VPKT_CONTLDS=0: k_vpkt reads the continuum table from memory (four workgroups of 256 per CU)
   bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
   int64_t last_sweeps = 0, last_tile_fills = 0, last_listed = 0;
   double last_fill_ms = 0.;
@@ -2166,6 +2182,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   }
   if (const char *b = std::getenv("ARTIS_AMD_THERMAL_BLOCKS")) e->thermal_blocks_per_cu = std::max(1, std::min(ARTIS_THERMAL_WAVES, std::atoi(b)));
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
+  if (const char *b = std::getenv("ARTIS_AMD_VPKT_CONTLDS")) e->vpkt_cont_lds = std::atoi(b) != 0;
   return ARTIS_OK;
 }
 }  // namespace
@@ -2784,7 +2801,10 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
 #if ARTIS_OPT_VPKT_ON
       if (kind != NEXT_GAMMA && kind != NEXT_BB) {  // the virtual packets of the events the launch recorded
         HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * (MAX_CHUNKS + 1), s));
-        hipLaunchKernelGGL(k_vpkt, dim3(e->ncu * ARTIS_VPKT_WGS), dim3(BLOCK), 0, s, env, e->d_stats, e->d_cursors);
+        if (e->vpkt_cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0)
+          hipLaunchKernelGGL((k_vpkt<true, ARTIS_VPKT_TB>), dim3(e->ncu), dim3(ARTIS_VPKT_TB), 0, s, env, e->d_stats, e->d_cursors);
+        else
+          hipLaunchKernelGGL((k_vpkt<false, BLOCK>), dim3(e->ncu * ARTIS_VPKT_WGS), dim3(BLOCK), 0, s, env, e->d_stats, e->d_cursors);
         HIP_TRY(hipMemsetAsync(e->d_vpkt_count, 0, sizeof(int32_t), s));
       }
 #endif

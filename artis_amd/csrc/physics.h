@@ -2803,11 +2803,77 @@ AHD bool all_taus_past_taumax(const double *tau, int n, double tau_max) {  // vp
 }
 // the loop of trace_lines_to_dist (vpkt.cc:298-358): false when every opacity choice is past tau_max. The populations
 // are the cell cache's (B_lu n_l - B_ul n_u) of the grid state, scaled to the time the line is reached.
-AHD bool vpkt_trace_lines_to_dist(const Env &env, const VpktConfig &V, int c, double dist_limit, double t_future, double nu_cmf,
-                                  double dnu_on_dl, int &next_trans, double *tau_vpkt) {
+// NREG > 0: the optical depths and exclusions of at most NREG opacity choices, held in registers by the caller below (every loop over
+// them unrolled and predicated); NREG == 0: any number, in memory.
+template <int NREG>
+AHD bool vpkt_trace_lines_core(const Env &env, int nspec, double tau_max, const int *excl, int c, double dist_limit, double t_future,
+                               double nu_cmf, double dnu_on_dl, int &next_trans, double *tau_vpkt) {
   const DevModel &M = env.M;
   const LineDpop dpop = line_dpop_of(env, c);
   const double t_gridstate = env.S.mid;
+  auto add_line = [&](int Z, double tau_line) -> bool {  // vpkt.cc:340-356; true: every choice is past tau_max
+    if (NREG > 0) {
+      bool all = true;
+#pragma unroll
+      for (int i = 0; i < NREG; i++) {
+        if (excl[i] != -1 && excl[i] != Z) tau_vpkt[i] += tau_line;
+        if (i < nspec && !(tau_vpkt[i] > tau_max)) all = false;
+      }
+      return all;
+    }
+    for (int i = 0; i < nspec; i++)
+      if (excl[i] != -1 && excl[i] != Z) tau_vpkt[i] += tau_line;
+    return all_taus_past_taumax(tau_vpkt, nspec, tau_max);
+  };
+#if ARTIS_LINE_AHEAD > 1
+  // (the lines' frequencies, population factors and elements ARTIS_LINE_AHEAD lines ahead, as in possible_event(): a ring of slots
+  // that rotates by name)
+  constexpr int NL = ARTIS_LINE_AHEAD;
+  double nu_s[NL], dp_s[NL];
+  int el_s[NL];
+  int li = closest_transition(M.line_nu, M.nlines, nu_cmf, next_trans);
+  if (li >= 0) {
+#pragma unroll
+    for (int d = 0; d < NL; d++) {
+      const int l = (li + d < M.nlines) ? li + d : M.nlines - 1;
+      nu_s[d] = M.line_nu[l];
+      dp_s[d] = line_dpop_at(M, dpop, l);
+      el_s[d] = M.line_elementindex[l];
+    }
+  }
+  bool stop = false;
+  while (!stop) {
+#pragma unroll
+    for (int u = 0; u < NL; u++) {
+      if (li < 0) {
+        next_trans = M.nlines + 1;
+        stop = true;
+        break;
+      }
+      const double nutrans = nu_s[u];
+      const double dpop_li = dp_s[u];
+      const int el = el_s[u];
+      {
+        const int l = (li + NL < M.nlines) ? li + NL : M.nlines - 1;
+        nu_s[u] = M.line_nu[l];
+        dp_s[u] = line_dpop_at(M, dpop, l);
+        el_s[u] = M.line_elementindex[l];
+      }
+      next_trans = li + 1;
+      const double ldist = linedistance(t_future, nu_cmf, nutrans, dnu_on_dl);
+      if (ldist > dist_limit) {
+        next_trans--;
+        stop = true;
+        break;
+      }
+      const double t_line = t_future + (ldist / CLIGHT_PROP);
+      const double popscalefactor = pow3(t_gridstate / t_line);
+      const double tau_line = dmax(0., dpop_li * popscalefactor * HCLIGHTOVERFOURPI * t_line);
+      if (add_line(M.elem_anumber[el], tau_line)) return false;
+      li = closest_transition(M.line_nu, M.nlines, nu_cmf, next_trans);
+    }
+  }
+#else
   while (true) {
     const int li = closest_transition(M.line_nu, M.nlines, nu_cmf, next_trans);
     if (li < 0) {
@@ -2824,12 +2890,30 @@ AHD bool vpkt_trace_lines_to_dist(const Env &env, const VpktConfig &V, int c, do
     const double t_line = t_future + (ldist / CLIGHT_PROP);
     const double popscalefactor = pow3(t_gridstate / t_line);
     const double tau_line = dmax(0., line_dpop_at(M, dpop, li) * popscalefactor * HCLIGHTOVERFOURPI * t_line);
-    const int Z = M.elem_anumber[M.line_elementindex[li]];
-    for (int i = 0; i < V.nspectraperobsdir; i++)
-      if (V.opacityexclusions[i] != -1 && V.opacityexclusions[i] != Z) tau_vpkt[i] += tau_line;
-    if (all_taus_past_taumax(tau_vpkt, V.nspectraperobsdir, V.tau_max)) return false;
+    if (add_line(M.elem_anumber[M.line_elementindex[li]], tau_line)) return false;
   }
+#endif
   return true;
+}
+// ... with up to four opacity choices (the reference's example configurations have one to four) the optical depths stay in registers for
+// the walk: per line visited the memory form reads and writes every choice's sum and reads its exclusion (round 4)
+AHD bool vpkt_trace_lines_to_dist(const Env &env, const VpktConfig &V, int c, double dist_limit, double t_future, double nu_cmf,
+                                  double dnu_on_dl, int &next_trans, double *tau_vpkt) {
+  constexpr int NREG = 4;
+  const int nspec = V.nspectraperobsdir;
+  if (nspec > NREG) return vpkt_trace_lines_core<0>(env, nspec, V.tau_max, V.opacityexclusions, c, dist_limit, t_future, nu_cmf, dnu_on_dl, next_trans, tau_vpkt);
+  double t[NREG];
+  int ex[NREG];
+#pragma unroll
+  for (int i = 0; i < NREG; i++) {
+    t[i] = (i < nspec) ? tau_vpkt[i] : 0.;
+    ex[i] = (i < nspec) ? V.opacityexclusions[i] : -1;  // (-1: no line is ever added)
+  }
+  const bool go = vpkt_trace_lines_core<NREG>(env, nspec, V.tau_max, ex, c, dist_limit, t_future, nu_cmf, dnu_on_dl, next_trans, t);
+#pragma unroll
+  for (int i = 0; i < NREG; i++)
+    if (i < nspec) tau_vpkt[i] = t[i];
+  return go;
 }
 // trace_vpkt_direction vpkt.cc:183, in three parts so that a kernel can give a lane its next ray as soon as its ray has ended (k_vpkt: a
 // ray crosses 1 ... 50 cells, and with one ray per lane from start to end a wave lasts as long as its longest): vray_begin() =
