@@ -1572,8 +1572,11 @@ struct artis_amd_engine {
   uint32_t *d_resident = nullptr;
   int32_t *d_fill_cells = nullptr, *d_nfill = nullptr;
   bool resident_on = false, sparse_fill = true;
-  int64_t sparse_max_listed = 512;  // ... for visits that list at most this many packets (ARTIS_AMD_SPARSE_MAX)
+  int64_t sparse_max_listed = 16384;  // ... for visits that list at most this many packets (ARTIS_AMD_SPARSE_MAX; 512 in round 3:
+                                      // 4 tiles 3327 / 3205 / 3188 ms at 512 / 4096 / 16384, with parked tails 3222 / 3123 / 2982)
   int64_t last_sparse_fills = 0, last_cells_filled = 0;
+  bool park_tails = true;     // ARTIS_AMD_TILE_PARK=0: every visit of a tile runs its packets to their end (rounds 2-3)
+  int64_t last_parked = 0;
   bool vpkt_cont_lds = true;  // ARTIS_AMD_VPKT_CONTLDS=0: k_vpkt reads the continuum table from memory (four workgroups of 256 per CU)
   bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
   int64_t last_sweeps = 0, last_tile_fills = 0, last_listed = 0;
@@ -2183,6 +2186,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_THERMAL_BLOCKS")) e->thermal_blocks_per_cu = std::max(1, std::min(ARTIS_THERMAL_WAVES, std::atoi(b)));
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
   if (const char *b = std::getenv("ARTIS_AMD_VPKT_CONTLDS")) e->vpkt_cont_lds = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_TILE_PARK")) e->park_tails = std::atoi(b) != 0;
   return ARTIS_OK;
 }
 }  // namespace
@@ -2558,6 +2562,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   e->last_nlaunches = 0;
   e->last_sweeps = e->last_tile_fills = e->last_listed = 0;
   e->last_sparse_fills = e->last_cells_filled = 0;
+  e->last_parked = 0;
   e->resident_on = false;
   e->last_fill_ms = 0.;
   for (int k = 0; k < NEXT_NKINDS; k++) {
@@ -2692,11 +2697,21 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   for (int k = 1; k < NEXT_NKINDS; k++) listed += cnt[k];
   // (tiled runs: the later sweeps bring a tile a few stragglers at a time; each such visit is a tail from its first launch)
   const bool tail_ok = e->tail_max > 0 && (e->tail_always || listed > e->tail_max || sweep > 0);
+  int64_t visit_launches = 0;  // split-kernel launches of this visit (a visit parks its tail only after it has advanced its packets)
   while (cnt[NEXT_RPKT] > 0 || cnt[NEXT_MA] > 0 || cnt[NEXT_SLOW] > 0 || cnt[NEXT_KPKT] > 0 || cnt[NEXT_GAMMA] > 0 || cnt[NEXT_BB] > 0) {
     const int tail_kinds[4] = {NEXT_RPKT, NEXT_MA, NEXT_SLOW, NEXT_BB};
     int64_t tail_n = 0;
     for (int k : tail_kinds) tail_n += cnt[k];
     if (tail_ok && tail_n > 0 && tail_n <= e->tail_max && cnt[NEXT_KPKT] == 0) {
+      if (e->park_tails && e->ntiles > 1 && listed > e->tail_max && visit_launches > 0) {
+        // tiled run, a visit that began larger: its last packets wait in the tile (their state is in the packet store; the next
+        // classify pass lists them again) and run with the packets that return to it in the next sweep, instead of one long
+        // k_tail launch per visit. A visit that BEGINS with a tail's worth of packets runs them to their end (below): no
+        // packet waits more than once without the tile's population having shrunk to that.
+        e->last_parked += tail_n + cnt[NEXT_GAMMA];
+        if (e->trace) fprintf(stderr, "[artis_amd] sweep %d tile %d: %lld packets parked\n", sweep, tile, (long long)tail_n);
+        break;
+      }
       // the last packets of these kinds: one launch carries each through all its remaining alternations (k_tail)
       const int32_t nr = (int32_t)tail_n, nt = 0;
       const Lists next = lists_for(0);  // the four current lists are consumed whole; nothing is appended to them
@@ -2815,6 +2830,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
       e->kms[kind] += ms;
       e->klaunches[kind]++;
+      visit_launches++;
       e->kthreads[kind] += nk;
       e->last_nlaunches++;
       if (e->trace)
@@ -3027,6 +3043,12 @@ int artis_amd_last_tiling_fills(artis_amd_engine *e, int64_t *sparse_fills, int6
   if (!e) return ARTIS_ERR_ARG;
   if (sparse_fills) *sparse_fills = e->last_sparse_fills;
   if (cells_filled) *cells_filled = e->last_cells_filled;
+  return ARTIS_OK;
+}
+
+int artis_amd_last_tiling_parked(artis_amd_engine *e, int64_t *parked) {
+  if (!e) return ARTIS_ERR_ARG;
+  if (parked) *parked = e->last_parked;
   return ARTIS_OK;
 }
 

@@ -557,6 +557,9 @@ int artis_amd_last_kernel_ms(artis_amd_engine *eng, double *propagate_ms, int64_
 int artis_amd_last_tiling(artis_amd_engine *eng, int64_t *sweeps, int64_t *tile_fills, double *fill_ms, int64_t *listed);
 /* ... of which sparse fills (only the cells of the tile in which packets waited), and the cells populated over all fills */
 int artis_amd_last_tiling_fills(artis_amd_engine *eng, int64_t *sparse_fills, int64_t *cells_filled);
+/* ... and the packets that a visit of a tile left waiting in it for the tile's next visit instead of running them to their end in a
+ * launch of their own (round 4: the last <= ARTIS_AMD_TAIL packets of a visit that began larger; ARTIS_AMD_TILE_PARK=0 switches it off) */
+int artis_amd_last_tiling_parked(artis_amd_engine *eng, int64_t *parked);
 
 /* Per-kernel split of the last artis_amd_update_packets_device call: summed launch durations [ms] and summed
  * packet counts of the r-packet kernel (k_rpkt) and of the thermal kernels (k_ma + k_kpkt). */

@@ -1,5 +1,6 @@
 """ctypes binding of the test-only host emulation of the kernel bodies (tests/hostemu)."""
 import ctypes as C
+import fcntl
 import os
 import subprocess
 
@@ -13,7 +14,9 @@ _LIBS = {}
 
 def lib(preset: str = "classic"):
     if preset not in _LIBS:
-        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lock:  # (pytest-xdist workers: one make at a time)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
         L = C.CDLL(os.path.join(_HERE, "libartis_hostemu.so" if preset == "classic" else f"libartis_hostemu_{preset}.so"))
         L.artis_emu_update_packets.restype = C.c_int
         L.artis_emu_update_packets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]

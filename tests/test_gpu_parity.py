@@ -356,6 +356,36 @@ def test_sparse_fills_do_not_cost_sweeps_and_vpkt_refuses_tiles(engine_mod, monk
     monkeypatch.delenv("ARTIS_AMD_CACHE_BUDGET_MB", raising=False)
 
 
+def test_parked_visit_tails_give_identical_packets(engine_mod, monkeypatch):
+    """Round 4: in a tiled run the last packets of a visit that began larger wait in the tile for its next visit (they run with the
+    packets that return to it) instead of getting a long launch of their own. Packet histories do not depend on it."""
+    model, cs, ts, aux = synth.build("small", ncoord=12)
+    pk0 = synth.make_packets(model, aux, 60000, kpkt_fraction=0.2)
+    n = model["npts_nonempty"]
+    monkeypatch.delenv("ARTIS_AMD_CACHE_BUDGET_MB", raising=False)
+    eng = engine_mod.Engine(model)
+    bpc = eng.cache_tiles()[2]
+    eng.close()
+    monkeypatch.setenv("ARTIS_AMD_CACHE_BUDGET_MB", str(bpc * (n // 4 + 1) / 1048576.0 + 0.01))
+    monkeypatch.setenv("ARTIS_AMD_TAIL", "1024")
+    outs = []
+    for park in ("0", "1"):
+        monkeypatch.setenv("ARTIS_AMD_TILE_PARK", park)
+        eng = engine_mod.Engine(model)
+        assert eng.cache_tiles()[0] == 4
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, "classic")
+        eng.update_packets(p, e)
+        outs.append((p, e, eng.last_tiling()))
+        eng.close()
+    for k in ("ARTIS_AMD_CACHE_BUDGET_MB", "ARTIS_AMD_TAIL", "ARTIS_AMD_TILE_PARK"):
+        monkeypatch.delenv(k, raising=False)
+    (p0, e0, t0), (p1, e1, t1) = outs
+    assert t0["parked"] == 0 and t1["parked"] > 0, (t0, t1)
+    parity.compare_packets(p1, p0, 0.0, "parked visit tails vs visits run to their end")
+    parity.compare_estimators(e1, e0, EST_RTOL, "parked visit tails vs visits run to their end")
+
+
 def test_estimator_allreduce_through_the_c_abi(engine_mod):
     """artis_amd_comm_unique_id / artis_amd_comm_init / artis_amd_allreduce_estimators on a one-rank communicator (the GPU
     box has one device): RCCL is found at run time, the communicator comes up, the in-place sum leaves the block as is"""
