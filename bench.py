@@ -422,7 +422,8 @@ def main():
                                               "(DESIGN.md section 7, profiles/r04/k_thermal_experiments.md)")
                          if dominant == "k_thermal" else
                          ("k_rpkt (+ k_bfest_dense in DETAILED_BF builds, timed together): divergent per-lane loops over continua and "
-                          "lines at 2 waves/SIMD; see `limiter` and DESIGN.md section 7"),
+                          "lines at 3 waves/SIMD and 0.26 lane utilisation, their reads requested an iteration ahead; see `limiter` and "
+                          "DESIGN.md section 7"),
                          "limiter": d["limiter"],
                          "kernels": per_kernel},
         }
