@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of one environment switch of the engine on the headline bench, interleaved: tools/ab_env4.sh VAR "v1 v2 ..." [rounds] [bench args]
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 V=$1; VALS=$2; R=${3:-2}; shift 3
 for r in $(seq 1 $R); do
   for v in $VALS; do

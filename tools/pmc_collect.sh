@@ -4,7 +4,7 @@
 # usage (on the GPU box): bash tools/pmc_collect.sh [packets] [tag] [options preset] [passes, e.g. "1 2 4"]
 #   -> gpurun_out/pmc_<tag>/<pass>/..., gpurun_out/pmc_<tag>_<pass>.log
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 P=${1:-10000000}
 T=${2:-r02}
 O=${3:-classic}

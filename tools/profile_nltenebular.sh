@@ -3,7 +3,7 @@
 #   kernel_stats_bench_nltenebular.csv, pmc_summary_nltenebular.txt, pmc_traffic_nltenebular.json, bench_nltenebular.json
 # usage: bash tools/profile_nltenebular.sh r03
 T=${1:-r03}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 O=$R/gpurun_out/profile_$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

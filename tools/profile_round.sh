@@ -6,7 +6,7 @@
 #   4. the same workload on the other two options builds                         -> bench_kilonova_lte.json, bench_nltenebular.json
 # usage: bash tools/profile_round.sh r02
 T=${1:-r04}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 O=$R/gpurun_out/profile_$T
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

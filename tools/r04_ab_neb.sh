@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of nltenebular engine builds, interleaved: tools/r04_ab_neb.sh <rounds> <name> ... ("base" = the preset's own library)
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 R=$1; shift
 for r in $(seq 1 $R); do
   for name in "$@"; do

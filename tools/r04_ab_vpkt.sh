@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of ci_classic_vpkt engine builds on the virtual-packet bench: tools/r04_ab_vpkt.sh <name> ... ("base" = the preset's own library)
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-$(dirname $0)/..}
 for name in "$@"; do
   so=$PWD/artis_amd/libartis_amd_$name.so
   [ "$name" = base ] && so=$PWD/artis_amd/libartis_amd_ci_classic_vpkt.so

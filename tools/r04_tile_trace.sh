@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: launch-by-launch trace of a run forced into 4 tiles (where does the 3.5x go?), then the full GPU suite
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 O=$R/gpurun_out/r04t
 mkdir -p $O
 cd $R

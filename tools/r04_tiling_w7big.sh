@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, first measurements of the filter-only records: kernel trace of the headline bench, w7big in one tile, 4 tiles
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 O=$R/gpurun_out/r04a
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
