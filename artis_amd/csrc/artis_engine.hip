@@ -316,11 +316,70 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
     }
   }
 }
+__device__ inline double row_shr1(double x);
+// The recombination sums of a level (macroatom.cc:147-168: over the levels of the ion below that ionise into it) -- three running sums
+// over up to ~60 channels for the 45 levels of the bench's data that have any, none for the other 1522. As a loop of populate_macroatom()
+// the lane of such a level walked its list with three dependent gathers per channel while the other 63 lanes of its wave waited
+// (k_macroatom at 0.21 lane utilisation). Here a ROW OF 16 LANES per (cell, listed level) reads 16 channels at a time and forms the
+// sums with the loop's additions in the loop's order (lane k adds its term to lane k-1's finished sum, as k_cooling_chain does).
+__global__ void __launch_bounds__(BLOCK) k_macroatom_recomb(Env env) {
+  const int64_t row_id = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4;
+  const int r = threadIdx.x & 15;
+  const DevModel &M = env.M;
+  const int64_t nrows = fill_count(env) * M.nrecomblevels;
+  const bool valid = row_id < nrows;
+  const int c = fill_cell(env, (valid ? row_id : 0) / M.nrecomblevels);
+  const int ul = M.recomb_levels[(valid ? row_id : 0) % M.nrecomblevels];
+  const int ui = M.level_ion[ul];
+  const int ls = M.ion_uniquelevelindexstart[ui > 0 ? ui - 1 : 0];
+  const int64_t cb = (int64_t)c * M.nphixstargets_total;
+  const double e_cur = eps(M, ul);
+  const int j0 = valid ? M.level_recomb_start[ul] : 0, j1 = valid ? M.level_recomb_start[ul + 1] : 0;
+  double carry0 = 0., carry1 = 0., carry2 = 0.;
+  for (int j = j0; __any(j < j1); j += 16) {
+    const bool in = (j + r) < j1;
+    double x0 = 0., x1 = 0., x2 = 0.;
+    if (in) {
+      const int lower = M.recomb_lower[j + r];
+      const int t = M.recomb_target[j + r];
+      const double e_target = eps(M, ls + lower);
+      const double e_trans = e_cur - e_target;
+      const int64_t o = cb + M.level_phixstargetstart[ls + lower] + t;
+      const double R = env.K.bf_radrecomb[o];
+      const double Cc = env.K.bf_colrecomb[o];
+      x0 = (R + Cc) * e_target;
+      x1 = R * e_trans;
+      x2 = Cc * e_trans;
+    }
+    double a0 = (r == 0) ? carry0 + x0 : x0, a1 = (r == 0) ? carry1 + x1 : x1, a2 = (r == 0) ? carry2 + x2 : x2;
+#pragma unroll
+    for (int s = 1; s < 16; s++) {
+      const double p0 = row_shr1(a0), p1 = row_shr1(a1), p2 = row_shr1(a2);
+      if (r == s) {
+        a0 = p0 + x0;
+        a1 = p1 + x1;
+        a2 = p2 + x2;
+      }
+    }
+    // the sums after the row's last channel, broadcast to the row (lanes past the list's end added 0. to them)
+    const int src = ((threadIdx.x & 63) | 15) << 2;
+    carry0 = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(a0)), __builtin_amdgcn_ds_bpermute(src, __double2loint(a0)));
+    carry1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(a1)), __builtin_amdgcn_ds_bpermute(src, __double2loint(a1)));
+    carry2 = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(a2)), __builtin_amdgcn_ds_bpermute(src, __double2loint(a2)));
+  }
+  if (valid && r == 0) {
+    const LevelPack lpk = M.level_pack[ul];
+    double *rates = ma_rates_of(ma_rec_of(env, c, lpk), lpk.ndown, lpk.nup);
+    rates[ARTIS_MA_ACTION_INTERNALDOWNLOWER] = carry0;
+    rates[ARTIS_MA_ACTION_RADRECOMB] = carry1;
+    rates[ARTIS_MA_ACTION_COLRECOMB] = carry2;
+  }
+}
 __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const int64_t total = fill_count(env) * env.M.nlevels;
   if (i >= total) return;
-  populate_macroatom(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
+  populate_macroatom<true>(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
 // The filters of the directions with more transitions than a block of k_matrans holds (DevModel::malongsegs: > MATRANS_BLOCK):
 // a wave per (cell, segment) re-forms the running sums 63 transitions (nine filter lines) at a time -- the same terms
@@ -463,19 +522,80 @@ __global__ void __launch_bounds__(BLOCK) k_collexc_filter(Env env) {
   const int64_t kf = i / per;
   populate_coolfilter_line(env, fill_cell(env, kf), (int)(i % per), env.collexc_terms + (kf * env.M.nupcum));
 }
+// The bound-free tail of an ion's cooling list (kpkt.cc:122-190: a collisional-ionisation term and then a bound-free term per (ionising
+// level, target), ~120 entries, each behind three or four dependent gathers): a lane per (cell, ion) walked it serially (11 ms per step).
+// Round 4: a ROW OF 16 LANES per (cell, ion), like k_cooling_chain -- every lane forms the term of one entry (what the entry is it reads
+// from the cooling list's own static tables, checked against the loop order when the engine is created), the running sum is formed with the
+// loop's additions in the loop's order (DPP row shifts) and written back 16 entries = one 128-byte line at a time.
+// physics.h cooling_ion_tail() is the sequential form (test emulation).
 __global__ void __launch_bounds__(BLOCK) k_cooling_tail(Env env) {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t row_id = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 4;
+  const int r = threadIdx.x & 15;
   const DevModel &M = env.M;
-  const int64_t total = fill_count(env) * M.nions;
-  if (i >= total) return;
-  const int c = fill_cell(env, i / M.nions);
-  const int ui = (int)(i % M.nions);
-  // the entries written so far: the free-free one and one per level with upward transitions
+  const int64_t nrows = fill_count(env) * M.nions;
+  const bool valid = row_id < nrows;
+  const int c = fill_cell(env, (valid ? row_id : 0) / M.nions);
+  const int ui = (int)((valid ? row_id : 0) % M.nions);
   const int element = M.ion_element[ui];
-  int k = ((ionstage(M, element, ui - M.elem_uniqueionindexstart[element]) - 1) > 0) ? 1 : 0;
+  const int ion = ui - M.elem_uniqueionindexstart[element];
+  const bool has = valid && ion < (M.elem_nions[element] - 1) && M.nbfcontinua > 0;
+  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  const int ionstart = M.ion_coolingoffset[ui];
+  double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + ionstart;
+  const float cnne = clumpednne(env.C, c);
+  const float T_e = env.C.Te[c];
   const int start = M.ion_uniquelevelindexstart[ui];
-  for (int l = 0; l < M.ion_nlevels[ui]; l++) k += (M.level_nuptrans[start + l] > 0) ? 1 : 0;
-  cooling_ion_tail(env, c, ui, env.K.ion_cooling_C[((int64_t)c * M.nions) + ui], k);
+  const int ustart = has ? M.ion_uniquelevelindexstart[ui + 1] : 0;
+  const double nnupperion = has ? nnion(env, c, element, ion + 1) : 0.;
+  const int k0 = has ? M.ion_cooltail_start[ui] : 0, k1 = has ? M.ion_ncoolingterms[ui] : 0;
+  double carry = valid ? env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] : 0.;
+  for (int j = k0; __any(j < k1); j += 16) {
+    const bool in = (j + r) < k1;
+    double x = 0.;
+    if (in) {
+      const int i = ionstart + j + r;
+      const int level = M.coolinglist_level[i];
+      const int t = M.coolinglist_phixstargetindex[i];
+      const int ul = start + level;
+      const int64_t o = ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
+      if (M.coolinglist_type[i] == ARTIS_COOLING_COLLION) {
+        const double e_trans = eps(M, ustart + phixs_upperlevel(M, ul, t)) - eps(M, ul);
+        x = pops[ul] * env.K.bf_colion[o + t] * e_trans;
+      } else {
+        double pop;
+#if ARTIS_OPT_BFCOOLING_USELEVELPOPNOTIONPOP
+        pop = pops[ustart + phixs_upperlevel(M, ul, t)];
+#else
+        const int nt = M.level_nphixstargets[ul];
+        if (nt == 1) {
+          pop = nnupperion;
+        } else {
+          double E_min = DBLMAX;
+          for (int tt = 0; tt < nt; tt++) E_min = dmin(E_min, eps(M, ustart + phixs_upperlevel(M, ul, tt)));
+          double wsum = 0.;
+          for (int tt = 0; tt < nt; tt++) {
+            const int up = phixs_upperlevel(M, ul, tt);
+            wsum += statw(M, ustart + up) * exp(-(eps(M, ustart + up) - E_min) / KB / T_e);
+          }
+          const int up = phixs_upperlevel(M, ul, t);
+          const double w = statw(M, ustart + up) * exp(-(eps(M, ustart + up) - E_min) / KB / T_e);
+          pop = nnupperion * w / wsum;
+        }
+#endif
+        x = env.K.bf_cooling[o + t] * pop * cnne;
+      }
+    }
+    double acc = (r == 0) ? carry + x : x;
+#pragma unroll
+    for (int s = 1; s < 16; s++) {
+      const double prev = row_shr1(acc);
+      if (r == s) acc = prev + x;
+    }
+    if (in) contribs[j + r] = acc;
+    const int src = ((threadIdx.x & 63) | 15) << 2;
+    carry = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(acc)), __builtin_amdgcn_ds_bpermute(src, __double2loint(acc)));
+  }
+  if (has && r == 0) env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] = carry;
 }
 __global__ void __launch_bounds__(BLOCK) k_cooling_prefix(Env env) {
   const int64_t kf = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1902,6 +2022,29 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
       return ARTIS_ERR_UNSUPPORTED;
     }
   }
+  // k_cooling_tail reads what the entries of an ion's cooling list after the collisional excitations are from the list itself
+  // (coolinglist_type / _level / _phixstargetindex): they must be in the order calculate_cooling_rates_ion() writes them
+  // (kpkt.cc:122-190: the collisional ionisations level by level and target by target, then the bound-free terms likewise)
+  for (int el = 0; el < model->nelements && model->ncoolingterms > 0; el++)
+    for (int ion = 0; ion < model->elem_nions[el]; ion++) {
+      const int ui = model->elem_uniqueionindexstart[el] + ion;
+      int k = ((model->elem_lowest_ionstage[el] + ion - 1) > 0) ? 1 : 0;
+      const int start = model->ion_uniquelevelindexstart[ui];
+      for (int l = 0; l < model->ion_nlevels[ui]; l++) k += (model->level_nuptrans[start + l] > 0) ? 1 : 0;
+      bool ok = true;
+      if (ion < model->elem_nions[el] - 1 && model->nbfcontinua > 0) {
+        const int off = model->ion_coolingoffset[ui];
+        for (int pass = 0; pass < 2 && ok; pass++)
+          for (int l = 0; l < model->ion_nlevels_ionising[ui] && ok; l++)
+            for (int t = 0; t < model->level_nphixstargets[start + l] && ok; t++, k++)
+              ok = k < model->ion_ncoolingterms[ui] && model->coolinglist_type[off + k] == (pass == 0 ? ARTIS_COOLING_COLLION : ARTIS_COOLING_FREEBOUND) &&
+                   model->coolinglist_level[off + k] == l && model->coolinglist_phixstargetindex[off + k] == t;
+      }
+      if (!ok || k != model->ion_ncoolingterms[ui]) {
+        g_last_error = "the cooling list of an ion is not in the order of calculate_cooling_rates_ion()";
+        return ARTIS_ERR_ARG;
+      }
+    }
   for (int i = 0; i < model->nions; i++) {  // DevModel::alltrans_tlevel16: a target level within its ion in 16 bits
     if (model->ion_nlevels[i] > 65535) {
       g_last_error = "an ion has more levels than a 16-bit target level can describe";
@@ -2356,6 +2499,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
   if (h.nphixstargets_total > 0)
     hipLaunchKernelGGL(k_corrphotoion, dim3(nblocks(ncell * h.nphixstargets_total)), dim3(BLOCK), 0, s, env, e->d_target_level);
   if (h.nalltrans > 0) hipLaunchKernelGGL(k_matrans, dim3(nblocks(ncell * h.nscanblk * 64)), dim3(BLOCK), 0, s, env);
+  if (h.nrecomblevels > 0) hipLaunchKernelGGL(k_macroatom_recomb, dim3(nblocks(ncell * (int64_t)h.nrecomblevels * 16)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_macroatom, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   if (h.nmalongsegs > 0) hipLaunchKernelGGL(k_mafilter_long, dim3(nblocks(ncell * (int64_t)h.nmalongsegs * 64)), dim3(BLOCK), 0, s, env);
 #if ARTIS_EXPOPAC_TABLES
@@ -2367,7 +2511,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
   hipLaunchKernelGGL(k_cooling_head, dim3(nblocks((int64_t)ncell * h.nions)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_chain, dim3(nblocks((int64_t)ncell * h.nions * 16)), dim3(BLOCK), 0, s, env);
   if (h.ncoollines > 0) hipLaunchKernelGGL(k_collexc_filter, dim3(nblocks(ncell * (int64_t)h.ncoollines)), dim3(BLOCK), 0, s, env);
-  hipLaunchKernelGGL(k_cooling_tail, dim3(nblocks((int64_t)ncell * h.nions)), dim3(BLOCK), 0, s, env);
+  hipLaunchKernelGGL(k_cooling_tail, dim3(nblocks((int64_t)ncell * h.nions * 16)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_prefix, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
   }  // batches
   const int64_t ncell = ncell_fill;

@@ -26,7 +26,7 @@ struct ModelOwned {
   std::vector<ContPack> cont_pack;
   std::vector<int32_t> expopac_linestart;
   std::vector<int32_t> upcum_coolslot;
-  std::vector<int32_t> level_recomb_start, recomb_lower, recomb_target;
+  std::vector<int32_t> level_recomb_start, recomb_lower, recomb_target, recomb_levels, ion_cooltail_start;
 };
 
 // X(field, element type, element count) for every array pointer of DevModel
@@ -99,6 +99,8 @@ struct ModelOwned {
   X(level_recomb_start, int32_t, ((m).nlevels + 1))                                \
   X(recomb_lower, int32_t, (m).nrecomb)                                            \
   X(recomb_target, int32_t, (m).nrecomb)                                           \
+  X(recomb_levels, int32_t, (m).nrecomblevels)                                     \
+  X(ion_cooltail_start, int32_t, (m).nions)                                        \
   X(propcell_nonemptymgi, int32_t, (m).ngrid)
 
 // arrays of DevModel that may be absent (null) on the host
@@ -355,6 +357,24 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.level_recomb_start = own.level_recomb_start.data();
   v.recomb_lower = own.recomb_lower.data();
   v.recomb_target = own.recomb_target.data();
+  own.recomb_levels.clear();
+  for (int ui = 0; ui < m.nions; ui++)
+    for (int l = 0; l < m.ion_nlevels[ui]; l++) {
+      const int ul = m.ion_uniquelevelindexstart[ui] + l;
+      if (own.level_recomb_start[ul + 1] > own.level_recomb_start[ul] && l <= m.ion_maxrecombininglevel[ui]) own.recomb_levels.push_back(ul);
+    }
+  v.nrecomblevels = (int32_t)own.recomb_levels.size();
+  if (own.recomb_levels.empty()) own.recomb_levels.push_back(0);
+  v.recomb_levels = own.recomb_levels.data();
+  own.ion_cooltail_start.assign((size_t)(m.nions > 0 ? m.nions : 1), 0);
+  for (int e = 0; e < m.nelements; e++)
+    for (int ion = 0; ion < m.elem_nions[e]; ion++) {
+      const int ui = m.elem_uniqueionindexstart[e] + ion;
+      int k = ((m.elem_lowest_ionstage[e] + ion - 1) > 0) ? 1 : 0;  // the free-free entry (kpkt.cc:75)
+      for (int l = 0; l < m.ion_nlevels[ui]; l++) k += (m.level_nuptrans[m.ion_uniquelevelindexstart[ui] + l] > 0) ? 1 : 0;
+      own.ion_cooltail_start[ui] = k;
+    }
+  v.ion_cooltail_start = own.ion_cooltail_start.data();
 #define ARTIS_COPY_PTR(f) v.f = m.f;
   ARTIS_COPY_PTR(elem_nions) ARTIS_COPY_PTR(elem_uniqueionindexstart) ARTIS_COPY_PTR(elem_lowest_ionstage)
   ARTIS_COPY_PTR(elem_anumber) ARTIS_COPY_PTR(elem_meannucmass) ARTIS_COPY_PTR(ion_nt_sum_q_over_binding)

@@ -1412,6 +1412,9 @@ AHD int debug_level_record(const Env &env, int c, int ul, double *maprocessrates
 AHD void populate_mafilter_level(const Env &env, int c, int ul);  // (below, with the filters)
 // one (cell, level): the bound-free channels of calculate_macroatom_transitionrates macroatom.cc:141-190 (the four
 // bound-bound rates are already in the record: populate_level_bb() / k_matrans), then the record's action filter
+// RECOMB_DONE: the three sums over the level's recombination list are in the record already (k_macroatom_recomb formed them with a
+// row of lanes, the additions in this loop's order)
+template <bool RECOMB_DONE = false>
 AHD void populate_macroatom(const Env &env, int c, int ul) {
   const DevModel &M = env.M;
   const int ui = M.level_ion[ul];
@@ -1433,7 +1436,13 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   if (lpk.ndown == 0) rates[ARTIS_MA_ACTION_RADDEEXC] = rates[ARTIS_MA_ACTION_COLDEEXC] = rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = 0.;
   if (lpk.nup == 0) rates[ARTIS_MA_ACTION_INTERNALUPSAME] = 0.;
   double s_down_lower = 0., s_radrecomb = 0., s_colrecomb = 0.;
-  if (ion > 0 && level <= M.ion_maxrecombininglevel[ui]) {
+  if (RECOMB_DONE) {
+    if (ion > 0 && level <= M.ion_maxrecombininglevel[ui] && M.level_recomb_start[ul + 1] > M.level_recomb_start[ul]) {
+      s_down_lower = rates[ARTIS_MA_ACTION_INTERNALDOWNLOWER];
+      s_radrecomb = rates[ARTIS_MA_ACTION_RADRECOMB];
+      s_colrecomb = rates[ARTIS_MA_ACTION_COLRECOMB];
+    }
+  } else if (ion > 0 && level <= M.ion_maxrecombininglevel[ui]) {
     const int ls = M.ion_uniquelevelindexstart[ui - 1];
     const int64_t cb = (int64_t)c * M.nphixstargets_total;
     // the levels of the ion below that ionise into this one (find_phixstargetindex() >= 0), from the static list

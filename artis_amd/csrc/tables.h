@@ -153,6 +153,12 @@ struct DevModel {
   const int32_t *recomb_lower;         // [nrecomb] level index within the lower ion
   const int32_t *recomb_target;        // [nrecomb] its phixstargetindex
   int32_t nrecomb;
+  // the levels whose recombination list is summed at all (non-empty list, level <= ion_maxrecombininglevel): k_macroatom_recomb
+  const int32_t *recomb_levels;        // [nrecomblevels] unique level index
+  int32_t nrecomblevels;
+  // first entry of an ion's part of the cooling list that calculate_cooling_rates_ion() writes after the collisional excitations
+  // (the free-free entry and one entry per level with upward transitions come before it; kpkt.cc:122-190). Static.
+  const int32_t *ion_cooltail_start;   // [nions]
   // detailed bound-free estimators: estimator index of every continuum (-1: none) or null = identity; their number
   const int32_t *allcont_bfestimindex;
   int32_t nbfestim;
