@@ -247,8 +247,9 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
     }
     return;
   }
-  // 1. the terms
-  for (int e = lane; e < nent; e += 64) {
+  // 1. the terms (the block's entries in the order of DevModel::scanperm: a wave's 64 entries are of one kind wherever the block has 64 of it)
+  for (int k = lane; k < nent; k += 64) {
+    const int e = M.scanperm[a0 + k];
     const MaTransTerms t = matrans_terms(env, c, a0 + e);
     v[0][e] = t.v0;
     v[1][e] = t.v1;

@@ -3,6 +3,7 @@
 // test build. No physics here: only pointer plumbing and the three derived tables
 // (temperature grid ratecoeff.cc:39-46, level -> ion map, packed line records).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -19,6 +20,7 @@ struct ModelOwned {
   std::vector<int32_t> level_upcum_start;
   std::vector<int32_t> alltrans_owner;
   std::vector<int32_t> scanblk_seg0;
+  std::vector<uint8_t> scanperm;
   std::vector<MaLongSeg> scansegs, malongsegs;
   std::vector<MaTarget> alltrans_target;
   std::vector<uint16_t> alltrans_tlevel16;
@@ -62,6 +64,7 @@ struct ModelOwned {
   X(alltrans_owner, int32_t, (m).nalltrans)                                        \
   X(scansegs, MaLongSeg, ((m).nscansegs > 0 ? (m).nscansegs : 1))                  \
   X(scanblk_seg0, int32_t, ((m).nscanblk + 1))                                     \
+  X(scanperm, uint8_t, ((m).nalltrans > 0 ? (m).nalltrans : 1))                    \
   X(malongsegs, MaLongSeg, ((m).nmalongsegs > 0 ? (m).nmalongsegs : 1))            \
   X(alltrans_target, MaTarget, (m).nalltrans)                                      \
   X(alltrans_tlevel16, uint16_t, (m).nalltrans)                                    \
@@ -269,6 +272,24 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
     if (own.scansegs.empty()) own.scansegs.push_back(MaLongSeg{0, 0, 0, 0});
     v.scansegs = own.scansegs.data();
     v.scanblk_seg0 = own.scanblk_seg0.data();
+    // the order in which a wave of k_matrans evaluates the entries of its block
+    own.scanperm.assign((size_t)(m.nalltrans > 0 ? m.nalltrans : 1), 0);
+    for (int b = 0; b < v.nscanblk; b++) {
+      const MaLongSeg &s0 = own.scansegs[own.scanblk_seg0[b]], &s1 = own.scansegs[own.scanblk_seg0[b + 1] - 1];
+      const int a0 = s0.ats0, nent = (s1.ats0 + s1.n) - a0;
+      if (nent > MATRANS_BLOCK) continue;  // (a long segment: evaluated 64 consecutive entries at a time)
+      std::vector<int> idx((size_t)nent);
+      for (int e = 0; e < nent; e++) idx[e] = e;
+      auto kind = [&](int e) {
+        const int ati = a0 + e, ul = own.alltrans_owner[ati];
+        const bool down = (ati - m.level_alltrans_startdown[ul]) < m.level_ndowntrans[ul];
+        const int branch = (m.alltrans_coll_str[ati] < 0) ? (m.alltrans_forbidden[ati] ? 2 : 1) : 0;
+        return (down ? 0 : 3) + branch;
+      };
+      std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return kind(x) < kind(y); });
+      for (int e = 0; e < nent; e++) own.scanperm[a0 + e] = (uint8_t)idx[e];
+    }
+    v.scanperm = own.scanperm.data();
     v.nmalongsegs = (int32_t)own.malongsegs.size();
     if (own.malongsegs.empty()) own.malongsegs.push_back(MaLongSeg{0, 0, 0, 0});
     v.malongsegs = own.malongsegs.data();

@@ -188,6 +188,10 @@ struct DevModel {
   const MaLongSeg *scansegs;
   const int32_t *scanblk_seg0;
   int32_t nscansegs, nscanblk;
+  // [nalltrans] per block of k_matrans: the block's entries (offsets from its first) ordered by kind -- downward / upward, and the
+  // branch of the collisional rate coefficient they take (macroatom.cc:708-792) -- so that the 64 entries a wave evaluates together run
+  // the same code (round 4: with the entries in alltrans order every wave held both directions and ran both)
+  const uint8_t *scanperm;
   const MaLongSeg *malongsegs;
   int32_t nmalongsegs;
   const MaTarget *alltrans_target;  // derived: [nalltrans] what a transition needs to know of the level it leads to
