@@ -252,6 +252,8 @@ typedef struct artis_model {
   const double *bfcooling_coeffs;
 
   /* cooling list (kpkt.cc:44-46) */
+  /* (the entries of an ion after its collisional excitations must be in the order calculate_cooling_rates_ion() writes them -- kpkt.cc:122-190,
+   * i.e. as setup_coolinglist() lays them out: artis_amd_engine_create() checks it and refuses a list that is not, ARTIS_ERR_ARG) */
   const uint8_t *coolinglist_type;
   const int32_t *coolinglist_level;
   const int32_t *coolinglist_phixstargetindex;
