@@ -1,6 +1,7 @@
 """Build the HIP engine in-tree: artis_amd/libartis_amd.so (gfx950)."""
 from __future__ import annotations
 
+import fcntl
 import os
 import shutil
 import subprocess
@@ -52,8 +53,15 @@ def build(force: bool = False, extra_flags=(), preset: str = "classic") -> str:
         return so
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     pflags = [] if preset == "classic" else [f"-DARTIS_PRESET_{preset.upper()}", f'-DARTIS_PRESET_NAME="{preset}"']
-    cmd = [hipcc, *FLAGS, *pflags, *extra_flags, "-o", so, os.path.join(CSRC, "artis_engine.hip")]
-    subprocess.check_call(cmd)
+    # one compiler run per library at a time (pytest-xdist workers, ranks of one node): the others wait, find it fresh and return;
+    # the library appears under its name only when it is complete
+    with open(so + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or needs_build(preset):
+            tmp = f"{so}.{os.getpid()}.tmp"
+            cmd = [hipcc, *FLAGS, *pflags, *extra_flags, "-o", tmp, os.path.join(CSRC, "artis_engine.hip")]
+            subprocess.check_call(cmd)
+            os.replace(tmp, so)
     return so
 
 
