@@ -33,6 +33,12 @@ def compare_packets(got: np.ndarray, want: np.ndarray, rtol: float, what: str = 
             if a.ndim == 2:  # 3-vectors (pos, dir, em_pos, trueem_pos): error relative to the length of the vector,
                 # not to each component (a component that happens to be ~0 carries the absolute rounding of the others)
                 denom = np.broadcast_to(np.sqrt(np.nansum(b * b, axis=1))[:, None], a.shape).copy()
+            elif f in ("stokes_q", "stokes_u"):
+                # components of the normalised Stokes vector (I = 1, q, u) (vectors.h:266-370): a difference of O(1) terms, so the
+                # error is measured against that vector's length like the 3-vectors', not against |q| itself. (Round 4, 2e6
+                # packets: one packet with q = -3.2e-7 differed by 3.7e-16 = 1.2e-9 of |q|; the largest absolute difference of
+                # all was 1.6e-13: tools/r04_stokes_check.py, profiles/r04/stress_parity_2e6.txt.)
+                denom = np.sqrt(1.0 + np.asarray(want["stokes_q"], dtype=np.float64) ** 2 + np.asarray(want["stokes_u"], dtype=np.float64) ** 2)
             else:
                 denom = np.maximum(np.abs(a), np.abs(b))
             denom[~(denom > 0)] = 1.0
