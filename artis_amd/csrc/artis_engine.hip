@@ -1702,7 +1702,11 @@ struct artis_amd_engine {
   bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
   int64_t last_sweeps = 0, last_tile_fills = 0, last_listed = 0;
   double last_fill_ms = 0.;
-  int budget_r = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 4 : 8;        // do_rpkt_step() calls per packet per launch
+  // do_rpkt_step() calls per packet per launch. 8 in rounds 2-3; with the r-packet kernel's reads requested ahead (round 4) the list's order
+  // -- sorted by cell and frequency before every launch -- is worth more than the launches saved: 857 / 855 / 851 / 846 / 860 / 881 ms per step
+  // at 8 / 6 / 5 / 4 / 3 / 2 (classic; kilonova_lte 859 / 844 / 858 at 8 / 4 / 3; nltenebular, 4 since round 3: 1199 / 1204 / 1235 at 4 / 3 / 2)
+  int budget_r = 4;
+  int budget_g = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 32 : 64;      // ... of a gamma packet (k_gamma)
   int budget_t = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 1024 : 2048;  // macro-atom transitions / k-packet steps per packet per launch
   // A launch lasts as long as its slowest packet, and a list that does not fill the GPU any more (the last tenth of a
   // timestep's rounds) is bound by that alone. Smaller budgets for such lists (ARTIS_AMD_SMALL_LIST, ARTIS_AMD_BUDGET_T_SMALL /
@@ -2276,6 +2280,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET")) {  // tuning / tests: launch budgets never change results
     e->budget_r = std::max(1, std::atoi(b));
     e->budget_t = std::max(1, std::atoi(b));
+    e->budget_g = e->budget_r * 8;
   }
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_R")) e->budget_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_BUDGET_T")) e->budget_t = std::max(1, std::atoi(b));
@@ -2930,7 +2935,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
 #endif
       } else if (kind == NEXT_GAMMA) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_GAMMA_WAVES);
-        hipLaunchKernelGGL(k_gamma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_r * 8, e->d_cursors,
+        hipLaunchKernelGGL(k_gamma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_g, e->d_cursors,
                            e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
       } else if (kind == NEXT_MA) {
         // persistent: every workgroup resident (ARTIS_THERMAL_WAVES waves per SIMD)
