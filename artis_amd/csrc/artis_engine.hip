@@ -1705,7 +1705,9 @@ struct artis_amd_engine {
   // do_rpkt_step() calls per packet per launch. 8 in rounds 2-3; with the r-packet kernel's reads requested ahead (round 4) the list's order
   // -- sorted by cell and frequency before every launch -- is worth more than the launches saved: 857 / 855 / 851 / 846 / 860 / 881 ms per step
   // at 8 / 6 / 5 / 4 / 3 / 2 (classic; kilonova_lte 859 / 844 / 858 at 8 / 4 / 3; nltenebular, 4 since round 3: 1199 / 1204 / 1235 at 4 / 3 / 2)
-  int budget_r = 4;
+  // (8 stays where a step is cheap and launches are not: the expansion-opacity build with thermalising bound-bound events, 520 vs 567 ms,
+  // and the virtual-packet builds, whose every launch is followed by k_vpkt: 1250 vs 1268 ms)
+  int budget_r = (ARTIS_OPT_RPKT_BB_THERMALISATION || ARTIS_OPT_VPKT_ON) ? 8 : 4;
   int budget_g = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 32 : 64;      // ... of a gamma packet (k_gamma)
   int budget_t = ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 1024 : 2048;  // macro-atom transitions / k-packet steps per packet per launch
   // A launch lasts as long as its slowest packet, and a list that does not fill the GPU any more (the last tenth of a
