@@ -1753,6 +1753,7 @@ struct artis_amd_engine {
   double *d_collexc_terms = nullptr;
   int64_t pop_batch = 0;
   bool trace = false;
+  uint32_t *d_visit_counts = nullptr;  // -DARTIS_VISIT_COUNTS builds: [cell][level] transitions drawn per record in the last call
   ncclComm_t comm = nullptr;  // created by artis_amd_comm_init(), owned by the engine
 };
 
@@ -1822,6 +1823,9 @@ Env make_env(const artis_amd_engine *e) {
   env.vpkt_queue = e->d_vpkt_queue;
   env.vpkt_count = e->d_vpkt_count;
   env.vpkt_cap = e->vpkt_cap;
+#ifdef ARTIS_VISIT_COUNTS
+  env.visit_counts = e->d_visit_counts;
+#endif
   return env;
 }
 
@@ -1902,6 +1906,23 @@ int ensure_aos(artis_amd_engine *e, int64_t n) {
 
 namespace {
 int engine_fill(artis_amd_engine *e, const artis_model *model);
+// scratch of the cell-cache population (allocated after the cache rows): ~2 GB, ARTIS_AMD_POP_SCRATCH_MB
+double pop_scratch_mb() {
+  double mb = 2048.;
+  if (const char *b = std::getenv("ARTIS_AMD_POP_SCRATCH_MB")) mb = std::max(1., std::atof(b));
+  return mb;
+}
+// Bytes the cell-cache rows may take: 80 % of what is free once the population's scratch and a head-room for everything that is
+// allocated later (ARTIS_AMD_CACHE_HEADROOM_MB, default 0: the packets at ~1 KB each with their work lists, the caller's structs
+// and a snapshot -- 10 GB at 1e7 packets -- fit the remaining fifth of a 288 GB card; a smaller GPU, or two engines on one
+// device, set it) are taken off; ARTIS_AMD_CACHE_BUDGET_MB overrides the lot. One rule for the tile count and for the decision
+// to drop line_dpop.
+double cache_budget_bytes(size_t free_b) {
+  if (const char *b = std::getenv("ARTIS_AMD_CACHE_BUDGET_MB")) return std::atof(b) * 1048576.0;
+  double headroom_mb = 0.;
+  if (const char *b = std::getenv("ARTIS_AMD_CACHE_HEADROOM_MB")) headroom_mb = std::max(0., std::atof(b));
+  return std::max(0., 0.8 * ((double)free_b - (pop_scratch_mb() + headroom_mb) * 1048576.0));
+}
 
 // RCCL entry points, resolved at run time from the librccl the process already has (a host that links RCCL itself, or
 // torch's own copy in bench.py) or else from the ROCm installation: the engine library itself carries no link-time
@@ -2052,6 +2073,23 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
         return ARTIS_ERR_ARG;
       }
     }
+  {
+    // alltrans is laid out level by level, downward then upward transitions, without gaps (input.cc:565): k_matrans takes a block's
+    // extent from its first and last segment, ma_entry_pos() an entry's place from its offset, and the records' filter lines are
+    // counted from a level's first entry
+    int64_t next = 0;
+    for (int ul = 0; ul < model->nlevels; ul++) {
+      if (model->level_alltrans_startdown[ul] != next || model->level_ndowntrans[ul] < 0 || model->level_nuptrans[ul] < 0) {
+        g_last_error = "alltrans is not contiguous in level order (level_alltrans_startdown[i+1] == startdown[i] + ndown[i] + nup[i])";
+        return ARTIS_ERR_ARG;
+      }
+      next += (int64_t)model->level_ndowntrans[ul] + model->level_nuptrans[ul];
+    }
+    if (next != model->nalltrans) {
+      g_last_error = "the last level's transitions do not end at nalltrans";
+      return ARTIS_ERR_ARG;
+    }
+  }
   for (int i = 0; i < model->nions; i++) {  // DevModel::alltrans_tlevel16: a target level within its ion in 16 bits
     if (model->ion_nlevels[i] > 65535) {
       g_last_error = "an ion has more levels than a 16-bit target level can describe";
@@ -2159,8 +2197,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
       // cache does not fit one tile with them and needs fewer tiles without: the line walk then forms a line's population factor from
       // its record and the two level populations (physics.h line_dpop_at: the same expression, the same bits; two more reads per
       // line visited). ARTIS_AMD_DPOP=0 / 1 forces either.
-      double budget0 = 0.8 * (double)free_b;
-      if (const char *b = std::getenv("ARTIS_AMD_CACHE_BUDGET_MB")) budget0 = std::atof(b) * 1048576.0;
+      double budget0 = cache_budget_bytes(free_b);
       const size_t per_without = per_cell - (sizeof(double) * (size_t)h.ndpop);
       auto tiles_of = [&](size_t per) {
         const int64_t fit = std::max<int64_t>(1, (int64_t)(budget0 / (double)(per > 0 ? per : 1)));
@@ -2175,10 +2212,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
       }
     }
     e->cache_bytes_per_cell = per_cell;
-    // the packets (320 B each), their work lists (~100 B), the caller's structs (256 B) and a snapshot need room too: ~1 KB per
-    // packet, 10 GB at 1e7 packets; the population's scratch 2 GB
-    double budget = 0.8 * (double)free_b;
-    if (const char *b = std::getenv("ARTIS_AMD_CACHE_BUDGET_MB")) budget = std::atof(b) * 1048576.0;
+    double budget = cache_budget_bytes(free_b);
     int64_t fit = (int64_t)(budget / (double)(per_cell > 0 ? per_cell : 1));
     e->tile_cells = std::max<int64_t>(1, std::min<int64_t>(ncell_all > 0 ? ncell_all : 1, fit));
     e->ntiles = (int)((ncell_all + e->tile_cells - 1) / e->tile_cells);
@@ -2328,8 +2362,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   }
   {
     // the population works through the cells in batches whose cooling terms fit a scratch of ~2 GB (ARTIS_AMD_POP_SCRATCH_MB)
-    double mb = 2048.;
-    if (const char *b = std::getenv("ARTIS_AMD_POP_SCRATCH_MB")) mb = std::max(1., std::atof(b));
+    const double mb = pop_scratch_mb();
     const int64_t per = std::max<int64_t>(1, (int64_t)e->Mh.nupcum) * (int64_t)sizeof(double);
     e->pop_batch = std::max<int64_t>(1, std::min<int64_t>(e->tile_cells, (int64_t)(mb * 1048576.) / per));
     HIP_TRY(hipMalloc((void **)&e->d_collexc_terms, (size_t)(e->pop_batch * per) + 64));
@@ -2353,7 +2386,7 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cache_allocs);
   free_packet_buffers(e);
   void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_resident, e->d_fill_cells,
-                  e->d_nfill, e->d_bfrate_kept, e->d_collexc_terms};
+                  e->d_nfill, e->d_bfrate_kept, e->d_collexc_terms, e->d_visit_counts};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3})
@@ -2725,6 +2758,13 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   }
   const int64_t n = e->npackets;
   if (n == 0) return ARTIS_OK;
+#ifdef ARTIS_VISIT_COUNTS
+  {
+    const size_t vb = sizeof(uint32_t) * (size_t)e->Mh.npts_nonempty * (size_t)e->Mh.nlevels;
+    if (e->d_visit_counts == nullptr) HIP_TRY(hipMalloc((void **)&e->d_visit_counts, vb));
+    HIP_TRY(hipMemsetAsync(e->d_visit_counts, 0, vb, s));
+  }
+#endif
   Env env = make_env(e);
   if (e->d_bfrate_kept != nullptr) {
     if (e->bfrate_kept_dirty)
@@ -3221,6 +3261,20 @@ int artis_amd_last_kernel_table(artis_amd_engine *e, double ms[4], int64_t launc
     if (launches) launches[i] = e->klaunches[kinds[i]];
     if (packets) packets[i] = e->kthreads[kinds[i]];
   }
+  return ARTIS_OK;
+}
+
+int artis_amd_debug_visit_counts(artis_amd_engine *e, uint32_t *counts, int64_t n) {
+  if (!e || !counts || n != (int64_t)e->Mh.npts_nonempty * e->Mh.nlevels) {
+    g_last_error = "visit counts: [npts_nonempty][nlevels] uint32 expected";
+    return ARTIS_ERR_ARG;
+  }
+  if (e->d_visit_counts == nullptr) {
+    g_last_error = "this library was not built with -DARTIS_VISIT_COUNTS (or no propagation call has run yet)";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpy(counts, e->d_visit_counts, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost));
   return ARTIS_OK;
 }
 

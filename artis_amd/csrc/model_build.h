@@ -67,7 +67,7 @@ struct ModelOwned {
   X(scanperm, uint8_t, ((m).nalltrans > 0 ? (m).nalltrans : 1))                    \
   X(malongsegs, MaLongSeg, ((m).nmalongsegs > 0 ? (m).nmalongsegs : 1))            \
   X(alltrans_target, MaTarget, (m).nalltrans)                                      \
-  X(alltrans_tlevel16, uint16_t, (m).nalltrans)                                    \
+  X(alltrans_tlevel16, uint16_t, (((m).nalltrans + 1) & ~1)) /* whole 32-bit words: k_thermal copies it as words */ \
   X(coollines, CoolLineRef, ((m).ncoollines > 0 ? (m).ncoollines : 1))             \
   X(alltrans_einstein_A, float, (m).nalltrans)                                     \
   X(alltrans_coll_str, float, (m).nalltrans)                                       \
@@ -226,7 +226,7 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
     }
   }
   v.alltrans_target = own.alltrans_target.data();
-  own.alltrans_tlevel16.assign((size_t)(m.nalltrans > 0 ? m.nalltrans : 1), 0);
+  own.alltrans_tlevel16.assign((size_t)(m.nalltrans > 0 ? ((m.nalltrans + 1) & ~1) : 2), 0);  // padded to whole 32-bit words
   for (int i = 0; i < m.nalltrans; i++) own.alltrans_tlevel16[i] = (uint16_t)m.alltrans_targetlevelindex[i];
   v.alltrans_tlevel16 = own.alltrans_tlevel16.data();
   own.level_upcum_start.resize(m.nlevels);
@@ -442,6 +442,8 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
 // The virtual-packet configuration of a VPKT_ON build as one block (tables.h VpktConfig): the observer unit vectors as
 // trace_vpkts() forms them (vpkt.cc:967-971), the bin widths of init_vspecpol() (vpkt.cc:491-512; floats there). False when
 // the model carries no usable configuration.
+// get_loggrid_edge sn3d.h:142: lower edge of bin `index` of a grid spaced uniformly in the log of the value
+inline double loggrid_edge(double minvalue, double dlog, double index) { return std::exp(std::log(minvalue) + (index * dlog)); }
 inline bool make_vpkt_config(const artis_model &m, VpktConfig &V) {
   std::memset(&V, 0, sizeof(V));
   if (m.vpkt_nobsdirections < 1 || m.vpkt_nobsdirections > VPKT_MAXOBS || !m.vpkt_obsdirs_costheta || !m.vpkt_obsdirs_phi ||
@@ -480,7 +482,7 @@ inline bool make_vpkt_config(const artis_model &m, VpktConfig &V) {
   }
   const double dlogt = (std::log(ARTIS_VSPEC_TIMEMAX) - std::log(ARTIS_VSPEC_TIMEMIN)) / ARTIS_VSPEC_TIMEBINS;
   const double dlognu = (std::log(ARTIS_VSPEC_NUMAX) - std::log(ARTIS_VSPEC_NUMIN)) / ARTIS_VSPEC_NUBINS;
-  auto edge = [](double minvalue, double dlog, double index) { return std::exp(std::log(minvalue) + (index * dlog)); };  // sn3d.h:142
+  const auto edge = loggrid_edge;
   for (int n = 0; n < ARTIS_VSPEC_TIMEBINS; n++) {
     const float lower = (float)edge(ARTIS_VSPEC_TIMEMIN, dlogt, n);
     V.delta_t[n] = (float)(edge(ARTIS_VSPEC_TIMEMIN, dlogt, n + 1) - lower);

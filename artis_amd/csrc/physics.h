@@ -201,6 +201,10 @@ struct Env {
   VpktSeed *vpkt_queue;
   int32_t *vpkt_count;
   int32_t vpkt_cap;
+#ifdef ARTIS_VISIT_COUNTS
+  // (measurement build, tools/visit_sparsity.py) [cell][level] macro-atom transitions drawn in that level's record this call
+  uint32_t *visit_counts;
+#endif
 };
 // the packet's cell is empty (no cache needed) or its cache row is resident
 AHD bool in_tile(const Env &env, int cellindex) {
@@ -3417,6 +3421,9 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
   // within the filter's resolution of one of its entries; then on the f64 rates, with the same random number.
   MA_PROF_BEGIN();
   MA_PROF_MARK(env, 63);  // (clocks between the marks themselves: the cost of one mark)
+#if defined(ARTIS_VISIT_COUNTS) && defined(__HIP_DEVICE_COMPILE__)
+  if (env.visit_counts != nullptr) atomicAdd(&env.visit_counts[((int64_t)k.c * env.M.nlevels) + k.start + p.ma_level], 1u);
+#endif
   int action;
 #if ARTIS_MA_SPEC_DIR
   U4 fdir[2];
@@ -4094,7 +4101,7 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   } else {
     fail(env, 73);
   }
-  PROF_MARK(env, 59);  // ... the term's process carried out
+  PROF_MARK(env, 41);  // ... the term's process carried out (slot 59 is the macro-atom stage clock of -DARTIS_PROFILE_MA, 58 counts scan rounds)
 }
 
 // free-bound emission of a k-packet, kpkt.cc:518-542

@@ -68,7 +68,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_engine_destroy", "artis_amd_set_cellstate", "artis_amd_update_packets", "artis_amd_packets_upload",
     "artis_amd_packets_download", "artis_amd_packets_snapshot", "artis_amd_packets_restore",
     "artis_amd_update_packets_device", "artis_amd_estimators_zero", "artis_amd_estimators_download",
-    "artis_amd_estimators_devptr", "artis_amd_last_kernel_ms", "artis_amd_debug_cellcache",
+    "artis_amd_estimators_devptr", "artis_amd_last_kernel_ms", "artis_amd_debug_cellcache", "artis_amd_debug_visit_counts",
     "artis_amd_populate_cellcache",
     "artis_amd_last_kernel_breakdown",
     "artis_amd_last_kernel_launches",

@@ -59,7 +59,7 @@ W_PER_RPKT_VISIT = 224.0      # hot line + 96 B of the flight line
 W_PER_EMISSION = 120.0
 W_PER_ATOMIC = 8.0            # one f64 estimator add
 W_PER_LIST_ENTRY = 8.0        # (slot, key) appended to a work list
-PROFILE_ROUND = "r04"
+PROFILE_ROUNDS = ("r05", "r04")  # the newest round that holds the counters of this command
 NCU, NSIMD, CLOCK_GHZ = 256, 1024, 2.4   # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
 GATHER_INSTR_CLOCKS = 40.0             # CU clocks per 64-lane 16-byte gather instruction out of L2 (profiles/r02/gather_microbench.txt)
 LINE_FILL_CLOCKS = 150.0 / 64          # CU clocks per 128-byte line filled from L2 (profiles/r03/sector_bench.txt)
@@ -80,17 +80,37 @@ def _cpu_worker(args):
     sub = pk[lo:hi].copy()
     est = abi.estimators_for(model, _cpu_worker.options)
     t0 = time.perf_counter()
-    oracle_py.update_packets(model, cs, ts, sub, est, preset=_cpu_worker.options)
+    try:
+        oracle_py.update_packets(model, cs, ts, sub, est, preset=_cpu_worker.options, fast=_cpu_worker.fast)
+    except RuntimeError:
+        return None  # (the fast-math build tripped one of the restatement's assertions: reported, not hidden)
     wall = time.perf_counter() - t0
-    oracle_py.lib(_cpu_worker.options).artis_oracle_last_populate_seconds.restype = __import__("ctypes").c_double
-    tpop = oracle_py.lib(_cpu_worker.options).artis_oracle_last_populate_seconds()
+    L = oracle_py.lib(_cpu_worker.options, _cpu_worker.fast)
+    L.artis_oracle_last_populate_seconds.restype = __import__("ctypes").c_double
+    tpop = L.artis_oracle_last_populate_seconds()
     return int(est.stats[abi.STAT_X_RPKT_STEPS] + est.stats[abi.STAT_X_KPKT_STEPS]), wall, tpop
+
+
+def _cpu_leg(bounds, cores, fast):
+    _cpu_worker.fast = fast
+    ctx = mp.get_context("fork")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, bounds)
+    wall = time.perf_counter() - t0
+    if any(r is None for r in res):
+        return None
+    steps = sum(r[0] for r in res)
+    busy = max(r[1] - r[2] for r in res)
+    return steps, busy, max(r[2] for r in res), wall
 
 
 def cpu_baseline(model, cs, ts, pk, sample: int, cores: int, options: str = "classic"):
     """The CPU oracle (a scalar port of the reference's path) on the first `sample` packets of the same population,
     one process per core. Cell-cache filling is lazy as in the reference's CPU build and its time is excluded
-    (at full scale it is amortised over ~150 packets per cell; in a small sample it would dominate)."""
+    (at full scale it is amortised over ~150 packets per cell; in a small sample it would dominate).
+    Timed twice: compiled with the reference's own default flags (-O3 -march=native -flto, fast-math: `value`) and as the parity
+    checker is compiled (-O2 -ffp-contract=off: `value_checker_flags`)."""
     os.environ.setdefault("ARTIS_ORACLE_CACHE_CAP", "3000")
     sample = min(sample, len(pk))
     bounds = [(sample * i // cores, sample * (i + 1) // cores) for i in range(cores)]
@@ -99,17 +119,28 @@ def cpu_baseline(model, cs, ts, pk, sample: int, cores: int, options: str = "cla
     from oracle import oracle_py
 
     oracle_py.lib(options)  # loaded (and, if it has to be, built) ONCE here: the forked workers inherit it instead of racing to build it
-    ctx = mp.get_context("fork")
-    t0 = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, bounds)
-    wall = time.perf_counter() - t0
-    steps = sum(r[0] for r in res)
-    busy = max(r[1] - r[2] for r in res)
-    return {"value": steps / busy, "unit": "packet-steps/s", "cores": cores, "kind": "port",
-            "sample": f"first {sample} packets of the same population on {cores} processes of the C oracle "
-                      f"(oracle/artis_oracle.c); {steps} packet-steps in {busy:.1f} s of propagation "
-                      f"(+{max(r[2] for r in res):.1f} s lazy cell-cache fill excluded; leg wall {wall:.1f} s)"}
+    fast = None
+    try:
+        oracle_py.lib(options, fast=True)
+        fast = _cpu_leg(bounds, cores, True)
+    except Exception as exc:  # noqa: BLE001  (no compiler on the box, or the fast-math build failed an assertion)
+        print(f"[bench] cpu_baseline: the -O3 -march=native build of the oracle is not available ({exc})", file=sys.stderr)
+    steps, busy, tpop, wall = _cpu_leg(bounds, cores, False)
+    out = {"value": steps / busy, "unit": "packet-steps/s", "cores": cores, "kind": "port",
+           "flags": "-O2 -ffp-contract=off (the parity checker's build, oracle/Makefile)",
+           "value_checker_flags": steps / busy,
+           "sample": f"first {sample} packets of the same population on {cores} processes of the C oracle "
+                     f"(oracle/artis_oracle.c); {steps} packet-steps in {busy:.1f} s of propagation "
+                     f"(+{tpop:.1f} s lazy cell-cache fill excluded; leg wall {wall:.1f} s)"}
+    if fast is not None:
+        fsteps, fbusy, ftpop, fwall = fast
+        out["value"] = fsteps / fbusy
+        out["flags"] = " ".join(oracle_py.FAST_CFLAGS[:6]) + " (the reference Makefile's defaults: Makefile:38, :236-251; built on this host)"
+        out["sample"] = (f"first {sample} packets of the same population on {cores} processes of the C oracle (oracle/artis_oracle.c) "
+                         f"compiled with the reference's default flags: {fsteps} packet-steps in {fbusy:.1f} s of propagation "
+                         f"(+{ftpop:.1f} s lazy cell-cache fill excluded; leg wall {fwall:.1f} s); compiled as the parity checker is "
+                         f"(-O2 -ffp-contract=off): {steps} packet-steps in {busy:.1f} s = value_checker_flags")
+    return out
 
 
 def main():
@@ -322,6 +353,7 @@ def main():
         # MI355X_MICROARCH.md prescribes for gfx950). None when the workload is not the profiled one.
         tj, traffic_src = {}, None
         tname = "pmc_traffic.json" if args.options == "classic" else f"pmc_traffic_{args.options}.json"
+        PROFILE_ROUND = next((r for r in PROFILE_ROUNDS if os.path.exists(os.path.join(ROOT, "profiles", r, tname))), PROFILE_ROUNDS[-1])
         tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, tname)
         if (os.path.exists(tfile) and args.packets == 10_000_000 and args.ncoord == 50 and args.preset == "w7" and world == 1
                 and args.grid == "3d"):
@@ -369,6 +401,9 @@ def main():
                     if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU"):
                         lim["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
                         lim["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (NSIMD * clk)
+                        # the ceiling this branchy f64 path is actually under: the fraction of the SIMDs' lane-cycles that do
+                        # vector arithmetic (1.0 = every SIMD issues a full 64-lane VALU instruction every cycle)
+                        lim["valu_lane_frac"] = lim["valu_busy_frac"] * lim["valu_lane_utilisation"]
                     if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES"):
                         lim["wave_wait_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
                     if "SQ_INSTS_VMEM_RD" in c:
@@ -409,6 +444,9 @@ def main():
             # HBM-bound: `limiter` holds the measured ratios of what does hold it.
             "roofline": {"bound": "latency", "priced_against": "hbm", "achieved": d["hbm_gbs_measured"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": d["hbm_frac_measured"], "traffic": d["hbm_bytes_per_launch_measured"],
+                         # VALU lane-throughput (busy fraction x lane utilisation, from the same committed counters): the yardstick
+                         # that applies to this kernel, beside the HBM fraction north_star names; per kernel in `kernels`
+                         "valu_lane_frac": (d["limiter"] or {}).get("valu_lane_frac"),
                          "traffic_source": traffic_src, "kernel": dominant,
                          "hbm_gbs_measured_fetch_undoubled": d["hbm_gbs_measured_fetch_undoubled"],
                          "write_amplification": d["write_amplification"],

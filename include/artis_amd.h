@@ -118,7 +118,7 @@ enum {
   ARTIS_STAT_X_GAMMA_STEPS = 40, /* calls of gammapkt::do_gamma() gammapkt.cc:911 */
   /* virtual packets (vpkt.h:34-37): nvpkt_created, nvpkt_esc_from_rpkt / _kpkt / _macroatom */
   ARTIS_STAT_X_VPKT_CREATED = 48, ARTIS_STAT_X_VPKT_ESC_RPKT = 49, ARTIS_STAT_X_VPKT_ESC_KPKT = 50, ARTIS_STAT_X_VPKT_ESC_MA = 51,
-  /* 42..47 and 52..63: free for profiling builds (-DARTIS_PROFILE / -DARTIS_PROFILE_MA: wave-cycle accounting; the
+  /* 41 (do_kpkt's third phase clock), 42..47 and 52..63: free for profiling builds (-DARTIS_PROFILE / -DARTIS_PROFILE_MA: wave-cycle accounting; the
    * do_rpkt_step() phase clocks also take 48..52, so a profiling build of a VPKT_ON preset is refused at compile time) */
   ARTIS_NSTATS = 64
 };
@@ -581,6 +581,11 @@ int artis_amd_debug_cellcache(artis_amd_engine *eng, int nonemptymgi, double *le
                               double *matrans, double *allcont_nnlevel, double *allcont_departure,
                               double *allcont_edgepart, uint64_t *allcont_keepbits, double *corrphotoioncoeff,
                               double *cooling_contrib, double *ion_cooling_contribs, double *chi_ff_nnionpart);
+
+/* Measurement builds only (-DARTIS_VISIT_COUNTS, tools/visit_sparsity.py): how many macro-atom transitions the last
+ * propagation call drew in the record of every (non-empty cell, level), counts[nonemptymgi * nlevels + level]; the reference fills a
+ * level's rates when a packet first reaches it (macroatom.cc:398-417 calc_rates_if_needed). Any other build returns ARTIS_ERR_ARG. */
+int artis_amd_debug_visit_counts(artis_amd_engine *eng, uint32_t *counts, int64_t n);
 
 #ifdef __cplusplus
 }

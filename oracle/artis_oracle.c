@@ -3607,6 +3607,38 @@ float artis_oracle_phixs_fromtable(const float *xs, int npoints, double nuincrem
   return photoionisation_crosssection_fromtable(&o, xs, nu_edge, nu);
 }
 double artis_oracle_planck(double nu, double T) { return planck(nu, T); }
+#if ARTIS_OPT_VPKT_ON
+/* sn3d.h:134, :142 -- for the restatement of unittests.cc:68 test_binindex_helpers (the virtual-packet spectra bin with them, vpkt.cc:124-125) */
+long long artis_oracle_logbinindex(double value, double minvalue, double dlog, long long nbins) { return (long long)get_logbinindex(value, minvalue, dlog, (ptrdiff_t)nbins); }
+double artis_oracle_loggrid_edge(double minvalue, double dlog, double index) { return get_loggrid_edge(minvalue, dlog, index); }
+#endif
+/* get_escapedirectionbin vectors.h:147 (syn_dir = z constants.h:94; NPHIBINS = NCOSTHETABINS = 10 exspec.h:10-12): the direction bin of
+ * an escaping packet, by which the reference's exspec resolves spectra and light curves (spectrum_lightcurve.cc:545, :689). Not on
+ * the packet path; restated for tools/exspec.py's direction-resolved spectra and for unittests.cc:175. */
+int artis_oracle_escapedirectionbin(const double dir_in[3]) {
+  enum { NPHIBINS = 10, NCOSTHETABINS = 10 };
+  const double syn_dir[3] = {0., 0., 1.};
+  const double xhat[3] = {1.0, 0.0, 0.0};
+  const double dirmag = vec_len3(dir_in);
+  const double dir[3] = {dir_in[0] / dirmag, dir_in[1] / dirmag, dir_in[2] / dirmag};
+  const double costheta = dot3(dir, syn_dir);
+  int costhetabin = (int)((costheta + 1.0) * NCOSTHETABINS / 2.0);
+  costhetabin = costhetabin < 0 ? 0 : (costhetabin > NCOSTHETABINS - 1 ? NCOSTHETABINS - 1 : costhetabin);
+  double vec1[3], vec2[3], vec3[3];
+  cross_prod(dir, syn_dir, vec1);
+  cross_prod(xhat, syn_dir, vec2);
+  const double vec1_len = vec_len3(vec1);
+  double cosphi = 1.0;
+  if (vec1_len > 1e-12) {
+    cosphi = dot3(vec1, vec2) / vec1_len;
+    cosphi = cosphi < -1.0 ? -1.0 : (cosphi > 1.0 ? 1.0 : cosphi);
+  }
+  cross_prod(vec2, syn_dir, vec3);
+  const double testphi = dot3(vec1, vec3);
+  int phibin = (int)((testphi > 0 ? acos(cosphi) : acos(cosphi) + PI) / 2. / PI * NPHIBINS);
+  phibin = phibin < 0 ? 0 : (phibin > NPHIBINS - 1 ? NPHIBINS - 1 : phibin);
+  return (costhetabin * NPHIBINS) + phibin;
+}
 #if ARTIS_EXPOPAC_TABLES
 long long artis_oracle_linearbinindex(double value, double minvalue, double binwidth) { return get_linearbinindex(value, minvalue, binwidth); }
 double artis_oracle_expopac_bin_nu(long long b, int upper) { return upper ? get_expopac_bin_nu_upper(b) : get_expopac_bin_nu_lower(b); }

@@ -222,6 +222,11 @@ double artis_emu_sigma_compton_partial(double x, double f_max) { return artis::s
 double artis_emu_choose_f(double xx, double zrand) { return artis::choose_f(xx, zrand); }
 double artis_emu_meanf_sigma(double x) { return artis::meanf_sigma(x); }
 double artis_emu_planck(double nu, double T) { return artis::planck(nu, T); }
+#if ARTIS_OPT_VPKT_ON
+// the bin helpers of the virtual-packet spectra (sn3d.h:134, :142): the kernels' index, the host's edges; for unittests.cc:68
+long long artis_emu_logbinindex(double value, double minvalue, double dlog, long long nbins) { return (long long)artis::logbinindex(value, minvalue, dlog, nbins); }
+double artis_emu_loggrid_edge(double minvalue, double dlog, double index) { return artis::loggrid_edge(minvalue, dlog, index); }
+#endif
 #if ARTIS_EXPOPAC_TABLES
 // the wavelength-bin helpers of the expansion opacities (sn3d.h:115, rpkt.h:30-40), for tests/test_oracle_reference_props.py
 long long artis_emu_linearbinindex(double value, double minvalue, double binwidth) { return artis::linearbinindex(value, minvalue, binwidth); }

@@ -447,3 +447,83 @@ def test_expansion_opacity_bin_helpers_static_asserts(oracle):
         b = idx(5000., 60., 20.)
         assert nu(b, 0) < 1e8 * 2.99792458e10 / 5000. <= nu(b, 1)
     assert abi.EXPOPAC_NBINS == int((40000. - 60.) / 20.)
+
+
+def test_binindex_helpers_unittests_cc_68(oracle):
+    """unittests.cc:68 test_binindex_helpers on the oracle's get_logbinindex / get_loggrid_edge (sn3d.h:134, :142) and on the
+    kernel bodies' logbinindex (physics.h add_to_vspecpol, vpkt.cc:124-125) with the host's loggrid_edge (model_build.h
+    make_vpkt_config, vpkt.cc:500-501): increasing edges, the geometric midpoint of every bin maps back to it, both clamps."""
+    import hostemu_binding
+
+    P = "ci_classic_vpkt"
+    minvalue, dlog, nbins = 1e14, 0.05, 100
+    for L, pre in ((oracle.lib(P), "artis_oracle_"), (hostemu_binding.lib(P), "artis_emu_")):
+        idx = getattr(L, pre + "logbinindex")
+        idx.restype, idx.argtypes = C.c_longlong, [C.c_double, C.c_double, C.c_double, C.c_longlong]
+        edge = getattr(L, pre + "loggrid_edge")
+        edge.restype, edge.argtypes = C.c_double, [C.c_double] * 3
+        for i in range(nbins):
+            lo, hi = edge(minvalue, dlog, float(i)), edge(minvalue, dlog, float(i + 1))
+            assert hi > lo, "get_loggrid_edge produces increasing bin edges"
+            assert idx(math.sqrt(lo * hi), minvalue, dlog, nbins) == i, "get_logbinindex returns the bin containing its geometric midpoint"
+        assert idx(minvalue / 10., minvalue, dlog, nbins) == 0, "clamps below-range to bin 0"
+        assert idx(minvalue * 1e10, minvalue, dlog, nbins) == nbins - 1, "clamps above-range to the last bin"
+    # the two restatements give the same edges bit for bit (both are exp(log(min) + i * dlog) through glibc)
+    ea = [oracle.lib(P).artis_oracle_loggrid_edge(minvalue, dlog, float(i)) for i in range(nbins + 1)]
+    eb = [hostemu_binding.lib(P).artis_emu_loggrid_edge(minvalue, dlog, float(i)) for i in range(nbins + 1)]
+    assert ea == eb
+
+
+def test_range_chunks_unittests_cc_91(oracle):
+    """unittests.cc:91 test_range_chunks on artis_amd.dist.packet_shard (get_range_chunk mpi_logging.h:158: how the packets of one
+    population are shared out over the ranks, bench.py --packets-total): 200 random (size, nchunks) drawn with the reference's
+    generator and seed -- contiguous, complete, chunk sizes within one of each other; and the static_asserts of mpi_logging.h:175-177."""
+    from artis_amd import dist as adist
+
+    rng = Rng(oracle.lib(), 20260729)
+    for _ in range(200):
+        size = int(rng.uniform() * 10000)
+        nchunks = 1 + int(rng.uniform() * 32)
+        expected_next_start, sizes = 0, []
+        for nchunk in range(nchunks):
+            nstart, nsize = adist.packet_shard(size, nchunks, nchunk)
+            assert nstart == expected_next_start and nsize >= 0
+            expected_next_start = nstart + nsize
+            sizes.append(nsize)
+        assert expected_next_start == size and max(sizes) - min(sizes) <= 1
+    assert [adist.packet_shard(10, 3, r) for r in range(3)] == [(0, 4), (4, 3), (7, 3)]
+    # get_chunk_count (mpi_logging.h:179; globals.h:401 counts the keep-bitmap words with it): abi.keepwordcount's rule
+    chunk_count = lambda size, mx: size // mx + (1 if size % mx else 0)  # noqa: E731
+    assert chunk_count(0, 5) == 0 and chunk_count(10, 5) == 2 and chunk_count(11, 5) == 3
+
+
+def test_escapedirectionbin_unittests_cc_175(oracle):
+    """unittests.cc:175 test_escapedirectionbin on the oracle's restatement of get_escapedirectionbin (vectors.h:147) and on
+    tools/exspec.py's numpy form: 200 000 isotropic directions from the reference's generator (seed 5501) fall in [0, MABINS) and
+    fill the equal-solid-angle bins to within six sigma; the two forms agree on every direction."""
+    import sys
+
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import exspec
+
+    L = oracle.lib()
+    ndirs = 200000
+    s = (C.c_uint32 * 4)()
+    L.artis_oracle_rng_seed(s, C.c_uint32(5501))
+    dirs = np.zeros((ndirs, 3))
+    L.artis_oracle_fill_isotropic(s, C.c_int64(ndirs), dirs.ctypes.data_as(C.c_void_p))
+    L.artis_oracle_escapedirectionbin.restype = C.c_int
+    L.artis_oracle_escapedirectionbin.argtypes = [C.c_void_p]
+    bins_np = exspec.escapedirectionbin(dirs)
+    sample = np.array([L.artis_oracle_escapedirectionbin(dirs[i].ctypes.data_as(C.c_void_p)) for i in range(0, ndirs, 7)])
+    assert np.array_equal(sample, bins_np[::7])
+    assert bins_np.min() >= 0 and bins_np.max() < exspec.MABINS
+    counts = np.bincount(bins_np, minlength=exspec.MABINS)
+    expected = ndirs / exspec.MABINS
+    sixsigma = 6. * math.sqrt(expected * (1. - 1. / exspec.MABINS))
+    assert abs(counts.min() - expected) < sixsigma and abs(counts.max() - expected) < sixsigma
+    # the axis itself and unnormalised directions (vectors.h:151: "sometimes dir vectors aren't accurately normalised")
+    for d, want in (((0., 0., 1.), 90), ((0., 0., -1.), 0), ((0., 0., 3.), 90)):
+        v = np.array(d)
+        assert L.artis_oracle_escapedirectionbin(v.ctypes.data_as(C.c_void_p)) // 10 * 10 == want
+        assert exspec.escapedirectionbin(v[None, :])[0] // 10 * 10 == want

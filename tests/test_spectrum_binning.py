@@ -81,3 +81,25 @@ def test_engine_spectrum_matches_oracle_spectrum(oracle):
     ca = sa["flux"].reshape(50, 20, -1).sum(axis=1)
     cb = sb["flux"].reshape(50, 20, -1).sum(axis=1)
     assert np.abs(ca - cb).max() <= 1e-6 * ca.max()
+
+
+def test_direction_resolved_spectra_add_up_to_the_angle_average(oracle):
+    """Direction-resolved spectra and light curves (add_to_spec_res / add_to_lc_res with dirbin >= 0, spectrum_lightcurve.cc:545,
+    :562, :689-691): every escaped packet falls in exactly one of the MABINS direction bins and counts MABINS-fold there, so the
+    mean over the bins is the angle-averaged result."""
+    model, cs, ts, pk0 = _case()
+    n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+    pa = pk0.copy()
+    oracle.update_packets(model, cs, ts, pa, abi.Estimators(n, g))
+    starts, widths, tmin, tmax = _timegrid(model, ts)
+    avg = exspec.spectrum_and_lightcurve(pa, starts, widths, tmin, tmax, model["vmax"])
+    acc = {k: np.zeros_like(avg[k]) for k in ("flux", "lum", "lumcmf")}
+    nesc = 0
+    for b in range(exspec.MABINS):
+        r = exspec.spectrum_and_lightcurve(pa, starts, widths, tmin, tmax, model["vmax"], dirbin=b)
+        nesc += r["nescaped"]
+        for k in acc:
+            acc[k] += r[k] / exspec.MABINS
+    assert nesc == avg["nescaped"]
+    for k in acc:
+        assert np.allclose(acc[k], avg[k], rtol=1e-12, atol=0), k

@@ -24,5 +24,5 @@ for name, slot in (("mark cost", 63), ("rates read (stage 1 wait)", 59), ("proce
     print(f"{name:32s} {s[slot]:.4g} clocks  = {s[slot] / wr:8.1f} per wave-round")
 print("MA phase per wave-round", 16 * s[43] / wr)
 print(eng.last_kernel_breakdown() if hasattr(eng, "last_kernel_breakdown") else "")
-print("do_kpkt wave clocks /16 (slots 56, 57, 59): ion drawn", s[56], "term drawn", s[57], "process", s[59], " per kpkt wave-iteration:",
-      [round(16 * s[k] / max(s[47], 1)) for k in (56, 57, 59)])
+print("do_kpkt wave clocks /16 (slots 56, 57, 41): ion drawn", s[56], "term drawn", s[57], "process", s[41], " per kpkt wave-iteration:",
+      [round(16 * s[k] / max(s[47], 1)) for k in (56, 57, 41)])
