@@ -1354,7 +1354,7 @@ __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_the
       int exit_action = -1;
       const U4 *rec = nullptr;
       if (ma_pending(p) && p.pend == PEND_NONE) ma_prepare(env, p, k);  // the record of the current level; the walk carries it on
-      while (j < ARTIS_MA_PHASE && exit_action < 0 && ma_pending(p) && p.pend == PEND_NONE) {
+      while (j < ARTIS_MA_PHASE && exit_action < 0 && ma_pending(p) && p.pend == PEND_NONE) {  // [census: transition loop]
 #ifdef ARTIS_PROFILE
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 46);
 #endif

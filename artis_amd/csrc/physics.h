@@ -1882,7 +1882,7 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
         }
       }
     }
-    for (int rs = r0; rs < r1; rs += NS * B) {
+    for (int rs = r0; rs < r1; rs += NS * B) {  // [census: opacity sum] (tools/isa_census.py finds the loop by this tag)
 #pragma unroll
       for (int u = 0; u < NS; u++) {
         const int r = rs + (u * B);
@@ -2173,7 +2173,7 @@ AHD double possible_event(const Env &env, int c, const Pkt &p, const Chi &x, MAS
       }
     }
     bool stop = false;
-    while (!stop) {
+    while (!stop) {  // [census: line walk]
 #pragma unroll
       for (int u = 0; u < NL; u++) {
     if (li < 0) {

@@ -72,6 +72,27 @@ def main():
           f"{(touched.sum(axis=0) >= 0.5 * (per_cell > 0).sum()).mean():.3f}")
     print(f"* a cell's visited levels by the cell's packet count: correlation of per-cell fraction with transitions per cell "
           f"{np.corrcoef(per_cell, counts.sum(axis=1))[0, 1]:.2f}")
+    # What would a STATIC set of levels (the same in every cell) capture? Levels ranked by their transitions over all cells, and --
+    # what the engine could know before the step -- by excitation energy within their ion.
+    lev_tot = counts.sum(axis=0, dtype=np.float64)
+    order = np.argsort(-lev_tot)
+    ion_start = np.asarray(model["ion_uniquelevelindexstart"])
+    ion_nlev = np.asarray(model["ion_nlevels"])
+    rank_in_ion = np.concatenate([np.arange(n) for n in ion_nlev])  # levels of an ion are in rising energy
+    print("\n| static set of levels | share of levels | transitions drawn inside the set | visited (cell, level) records inside | worst cell: transitions inside |")
+    print("|---|---|---|---|---|")
+    cell_tot = np.maximum(counts.sum(axis=1, dtype=np.float64), 1.0)
+    for frac in (0.02, 0.05, 0.1, 0.2, 0.3, 0.5):
+        k = max(1, int(frac * nlev))
+        sel = np.zeros(nlev, dtype=bool)
+        sel[order[:k]] = True
+        inside = counts[:, sel].sum(axis=1, dtype=np.float64)
+        print(f"| the {k} levels with most transitions | {frac:.2f} | {lev_tot[sel].sum() / total:.5f} | {touched[:, sel].sum() / touched.sum():.3f} | {(inside / cell_tot).min():.4f} |")
+    for frac in (0.05, 0.1, 0.2, 0.3, 0.5):
+        sel = rank_in_ion < np.repeat(np.maximum(1, (frac * ion_nlev).astype(int)), ion_nlev)
+        inside = counts[:, sel].sum(axis=1, dtype=np.float64)
+        print(f"| the lowest {frac:.2f} of every ion's levels | {sel.mean():.2f} | {lev_tot[sel].sum() / total:.5f} | {touched[:, sel].sum() / touched.sum():.3f} | {(inside / cell_tot).min():.4f} |")
+    np.save(os.path.join(os.environ.get("VISIT_OUT", tempfile.gettempdir()), f"visit_level_totals_{args.preset}.npy"), lev_tot)
     eng.close()
 
 
