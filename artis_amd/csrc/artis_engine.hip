@@ -1427,6 +1427,294 @@ __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_the
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }
 
+// ---- k_thermal_q (round 5; ARTIS_AMD_REFILL=1): the thermal kernel with the macro-atom walk DECOUPLED from the packet, so that the
+// transition loop's lanes are refilled inside the loop. Round 3 built this once (profiles/r03/k_thermal_lane_compaction.md: lanes 35 -> 50,
+// and slower, because a transition was then three dependent L2 gathers whose wait grew with the lanes in flight). A transition is now one
+// 64-byte sector of the cell's record and two reads of static tables in LDS, and k_thermal runs at 37 of 64 lanes in a loop that is bound
+// by instruction issue: re-measured here under today's read pattern.
+// A wave owns TQ_V (> 64) packets. What a walk needs of a packet -- generator state, cell, ion's first level, level, counters: 36 B -- is its
+// WALK CONTEXT, kept in the wave's LDS slots; the packet's hot line rests in memory meanwhile. Two phases alternate per wave:
+//   walk:    every lane holds one context in registers and makes one transition per round; a lane whose walk ends (any process but an
+//            internal transition, an undecided search, the launch budget) writes the context back, pushes the slot on the wave's SERVICE
+//            stack and pops the next READY slot in the same round (ballot + popcount);
+//   service: once 64 slots wait (or the walkers run short), ONE full-wave pass reloads those packets' hot lines, carries out the process
+//            that ended each walk (ma_jump_exit), makes the k-packet step that follows, and either prepares the next walk (slot READY, hot
+//            line stored) or retires the packet (stored, appended to the list of its next kind) and pulls a new one into the slot.
+// Per packet the same functions run in the same order on the packet's own generator as in k_thermal: identical packets, generator states
+// and counters (GPU test); estimator sums differ by the order of their additions only.
+#ifndef ARTIS_TQ_SLOTS
+#define ARTIS_TQ_SLOTS 128
+#endif
+constexpr int TQ_V = ARTIS_TQ_SLOTS;  // slots per wave: 64 walking + a buffer that lets a full service pass fall due before the walkers starve
+static_assert(TQ_V >= 64 && TQ_V <= 256, "slot indices are kept in bytes");
+enum { TQ_EMPTY = -2, TQ_BUDGET = -3 };  // action of a slot on the service stack: no packet | walk interrupted by the launch budget
+struct TQWave {  // SoA: a lane reads field[its slot]
+  uint32_t s0[TQ_V], s1[TQ_V], s2[TQ_V], s3[TQ_V];
+  // lv = level within the ion | the ion's first level << 16; cnt = units | njumps << 16; act = (action + 3) | the draw of an undecided search << 7
+  int32_t pi[TQ_V], c[TQ_V], lv[TQ_V], cnt[TQ_V];
+  uint32_t act[TQ_V];
+  uint8_t ready[TQ_V];    // stack of the slots whose walk can go on
+  uint8_t service[TQ_V];  // stack of the slots that wait for the service pass
+};
+template <int TB>
+__global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats, int budget,
+                                                     int32_t *cursors, int nchunks, int drain_budget, int low_water) {
+  // dynamic LDS: [TQWave x waves | LevelPack x nlevels | uint16 x nalltrans (padded to words)]
+  extern __shared__ __attribute__((aligned(16))) unsigned char tq_lds[];
+  __shared__ stat_t lstats[ARTIS_NSTATS];
+  TQWave *tq = (TQWave *)tq_lds;
+  LevelPack *lds_levelpack = (LevelPack *)(tq_lds + (((sizeof(TQWave) * (TB / 64)) + 15) & ~(size_t)15));
+  uint16_t *lds_tlevel = (uint16_t *)(lds_levelpack + env.M.nlevels);
+  if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < env.M.nlevels; i += TB) lds_levelpack[i] = env.M.level_pack[i];
+  {
+    const uint32_t *src = (const uint32_t *)env.M.alltrans_tlevel16;  // (the allocation is padded to whole words)
+    uint32_t *dst = (uint32_t *)lds_tlevel;
+    for (int i = threadIdx.x; i < (env.M.nalltrans + 1) / 2; i += TB) dst[i] = src[i];
+  }
+  env.M.level_pack = lds_levelpack;
+  env.M.alltrans_tlevel16 = lds_tlevel;
+  env.ma_tables_in_lds = 1;
+  env.cellest_lds = nullptr;
+  env.cellest_n = 0;
+  __syncthreads();
+  env.stats = lstats;
+  const double ts_end = env.S.ts_end;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lanebit = 1ull << lane;
+  TQWave &Q = tq[threadIdx.x >> 6];
+  Puller q;
+  puller_init(q, n, nchunks, 0);
+  // wave-uniform stack heights; every slot starts empty and waits for a packet
+  int nready = 0, nservice = TQ_V, ndead = 0;
+  for (int i = lane; i < TQ_V; i += 64) {
+    Q.service[i] = (uint8_t)i;
+    Q.act[i] = (uint32_t)(TQ_EMPTY + 3);
+  }
+  __builtin_amdgcn_wave_barrier();
+  bool drained = false;
+#ifdef ARTIS_PROFILE
+  long long tq_t = clock64();  // wave clocks / 16 of the two phases in the spare stats slots 42 (service) and 43 (walk)
+#define TQ_PROF(slot)                                                                   \
+  do {                                                                                  \
+    const long long now = clock64();                                                    \
+    if (lane == 0) atomicAdd(&lstats[slot], (stat_t)((now - tq_t) >> 4));               \
+    tq_t = now;                                                                         \
+  } while (0)
+#else
+#define TQ_PROF(slot) ((void)0)
+#endif
+  while (true) {
+    // ---------------- service passes: while a full wave of slots waits, or the walkers would run short
+    while (nservice >= 64 || (nservice > 0 && nready < low_water)) {
+      const int take = min(64, nservice);
+      const bool has = lane < take;
+      const int s = has ? (int)Q.service[nservice - 1 - lane] : 0;
+      nservice -= take;
+      const uint32_t actw = has ? Q.act[s] : (uint32_t)(TQ_EMPTY + 3);
+      const int act = (int)(actw & 127u) - 3;
+      const bool isdone = has && act != TQ_EMPTY;
+      const int32_t idx = pull(q, has && !isdone, n, cursors);
+      if (!drained && q.exhausted) {
+        drained = true;
+        if (lane == 0) __hip_atomic_store(&cursors[MAX_CHUNKS], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (!drained && drain_budget < budget) drained = __hip_atomic_load(&cursors[MAX_CHUNKS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      const int budget_now = drained ? drain_budget : budget;
+      const bool have = isdone || idx >= 0;
+      int32_t pi = 0;
+      int units = 0;
+      Pkt p;
+      MACtx k;
+      if (have) {
+        pi = isdone ? Q.pi[s] : list[idx];
+        pkt_load_thermal(env.P, pi, p);  // the hot line only
+        k = ma_ctx(env, p);
+        if (isdone) {  // the walk's own state is the slot's; the level's record comes from the static table again
+          p.s0 = Q.s0[s]; p.s1 = Q.s1[s]; p.s2 = Q.s2[s]; p.s3 = Q.s3[s];
+          const int lv = Q.lv[s];
+          p.ma_level = lv & 0xFFFF;
+          k.start = lv >> 16;
+          k.start_key = (p.ma_element << 8) | p.ma_ion;
+          const LevelPack lp = env.M.level_pack[k.start + p.ma_level];
+          k.rec = lp.rec_off; k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
+          const int cnt = Q.cnt[s];
+          units = cnt & 0xFFFF;
+          k.njumps = cnt >> 16;
+          k.defer = (int)(actw >> 7);
+        }
+      }
+#ifdef ARTIS_PROFILE
+      if (lane == 0) {
+        ARTIS_STAT(env, 47);            // service passes
+        ARTIS_STAT_ADD(env, 44, take);  // ... and the slots they served
+      }
+#endif
+      int kind = NEXT_DONE;
+      int32_t out_pi = 0;
+      bool walking = false;
+      if (have) {
+        bool go = thermal_can_continue(p, ts_end);
+        if (isdone) {
+          ma_flush_stats(env, k);
+          const U4 *rec = ma_record(k);
+          if (act == MA_EXIT_DEFER) {
+            p.pend = PEND_MA_SEARCH;  // the slow-path kernel re-adds the sums and makes the transition (physics.h ma_slow_search)
+            p.pend_arg = k.defer;
+          } else if (act >= 0) {
+            ma_jump_exit<true>(env, p, pi, k, rec, act);
+          }
+          chi_after_ma(p);
+          go = thermal_can_continue(p, ts_end);
+        }
+        if (go) {
+          // a pre-k-packet, or a k-packet in a grey cell, leaves for the blackbody kernel (classify() below)
+          const bool blackbody = (p.type == ARTIS_TYPE_PRE_KPKT) || k.thick;
+          if (kpkt_eligible(p, ts_end) && !blackbody) {
+            do_kpkt<true>(env, p, pi);
+            p.chi_mgi = -1;
+            units++;
+          }
+          go = thermal_can_continue(p, ts_end) && !(blackbody && kpkt_eligible(p, ts_end));
+        }
+        walking = go && units < budget_now && ma_pending(p) && p.pend == PEND_NONE;
+        if (walking) ma_prepare(env, p, k);  // (only k.start is kept: the walk phase reads the level's record shape from LDS)
+        pkt_store_thermal(env.P, pi, p);  // the hot line; the flight line only if an r-packet was emitted
+        if (walking) {
+          Q.s0[s] = p.s0; Q.s1[s] = p.s1; Q.s2[s] = p.s2; Q.s3[s] = p.s3;
+          Q.pi[s] = pi;
+          Q.c[s] = k.c;
+          Q.lv[s] = p.ma_level | (k.start << 16);
+          Q.cnt[s] = units;
+        } else {
+          kind = classify(env, p, ts_end);
+          out_pi = pi;
+        }
+      }
+      append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next, (p.ma_element * 5 + p.ma_ion));
+      // where the slots go: READY, or back on the service stack as empty (a packet is pulled into it by the next pass), or --
+      // once the work list is used up -- out of use
+      {
+        const unsigned long long rm = __ballot(walking);
+        if (walking) Q.ready[nready + __popcll(rm & (lanebit - 1ull))] = (uint8_t)s;
+        nready += __popcll(rm);
+        const bool again = has && !walking && !q.exhausted;
+        const unsigned long long em = __ballot(again);
+        if (again) {
+          Q.act[s] = (uint32_t)(TQ_EMPTY + 3);
+          Q.service[nservice + __popcll(em & (lanebit - 1ull))] = (uint8_t)s;
+        }
+        nservice += __popcll(em);
+        ndead += take - __popcll(rm) - __popcll(em);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    TQ_PROF(42);
+    if (nready == 0) break;  // (then nothing waits for service either: every slot is out of use)
+    // ---------------- walk phase
+    {
+      // in the drain (work list used up) a service pass is worth its cost only for a reasonable share of the live slots
+      const int drain_min = max(1, min(16, (TQ_V - ndead) / 4));
+      const int budget_now = drained ? drain_budget : budget;
+      int myslot = -1;
+      int units = 0;
+      Pkt w;  // only the generator state and ma_level are live
+      MACtx k;
+      w.ma_level = -1;
+      k.c = 0; k.cellma = nullptr; k.rec = 0; k.nd = k.nu = 0; k.ats = 0; k.njumps = 0; k.start = 0; k.start_key = -1; k.defer = 0; k.thick = false;
+#ifdef ARTIS_PROFILE
+      int prof_rounds = 0, prof_lanes = 0;  // wave-uniform: rounds of this phase and the lanes that made a transition in them
+#endif
+      while (true) {
+        {  // lanes without a context pop READY slots
+          const bool need = myslot < 0;
+          const unsigned long long m = __ballot(need);
+          if (m != 0 && nready > 0) {
+            const int takeN = min(__popcll(m), nready);
+            const int prefix = __popcll(m & (lanebit - 1ull));
+            if (need && prefix < takeN) {
+              const int s = (int)Q.ready[nready - 1 - prefix];
+              myslot = s;
+              w.s0 = Q.s0[s]; w.s1 = Q.s1[s]; w.s2 = Q.s2[s]; w.s3 = Q.s3[s];
+              const int lv = Q.lv[s];
+              w.ma_level = lv & 0xFFFF;
+              k.c = Q.c[s];
+              k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
+              k.start = lv >> 16;
+              const LevelPack lp = env.M.level_pack[k.start + w.ma_level];
+              k.rec = lp.rec_off; k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
+              const int cnt = Q.cnt[s];
+              units = cnt & 0xFFFF;
+              k.njumps = cnt >> 16;
+            }
+            nready -= takeN;
+          }
+        }
+        const int nactive = __popcll(__ballot(myslot >= 0));
+        if (nactive == 0 || nservice >= 64 || (nactive < low_water && nservice >= drain_min)) break;
+        bool ended = false;
+        int end_action = 0;
+        {
+          const bool go = myslot >= 0;
+#ifdef ARTIS_PROFILE
+          prof_lanes += __popcll(__ballot(go));
+          prof_rounds++;
+#endif
+          if (go) {
+            const int action = ma_jump_internal<true>(env, w, k, k.cellma + k.rec);
+            units++;
+            if (action >= 0 || units >= budget_now) {
+              ended = true;
+              end_action = action >= 0 ? action : TQ_BUDGET;
+            }
+          }
+        }
+        const unsigned long long em = __ballot(ended);
+        if (em != 0) {
+          if (ended) {
+            const int s = myslot;
+            Q.s0[s] = w.s0; Q.s1[s] = w.s1; Q.s2[s] = w.s2; Q.s3[s] = w.s3;
+            Q.lv[s] = w.ma_level | (k.start << 16);
+            Q.cnt[s] = units | (k.njumps << 16);
+            Q.act[s] = (uint32_t)(end_action + 3) | ((uint32_t)k.defer << 7);
+            Q.service[nservice + __popcll(em & (lanebit - 1ull))] = (uint8_t)s;
+            myslot = -1;
+          }
+          nservice += __popcll(em);
+        }
+      }
+      // park the walks in progress: their slots are READY again
+      const bool parked = myslot >= 0;
+      const unsigned long long pm = __ballot(parked);
+      if (parked) {
+        const int s = myslot;
+        Q.s0[s] = w.s0; Q.s1[s] = w.s1; Q.s2[s] = w.s2; Q.s3[s] = w.s3;
+        Q.lv[s] = w.ma_level | (k.start << 16);
+        Q.cnt[s] = units | (k.njumps << 16);
+        Q.ready[nready + __popcll(pm & (lanebit - 1ull))] = (uint8_t)s;
+      }
+      nready += __popcll(pm);
+#ifdef ARTIS_PROFILE
+      if (lane == 0) {
+        ARTIS_STAT_ADD(env, 46, prof_rounds);  // wave-rounds of the transition loop
+        ARTIS_STAT_ADD(env, 45, prof_lanes);   // ... and the lanes that made a transition in them
+      }
+#endif
+      __builtin_amdgcn_wave_barrier();
+      TQ_PROF(43);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
+}
+#ifndef ARTIS_TQ_TB
+#define ARTIS_TQ_TB 768
+#endif
+constexpr int TQ_TB = ARTIS_TQ_TB;  // 12 waves per CU = 3 waves/SIMD at 168 VGPRs (round 3's optimum for this form; the slots of 16 waves and the tables do not fit the LDS)
+inline size_t tq_lds_bytes(int tb, int nlevels, int nalltrans) {
+  return (((sizeof(TQWave) * (size_t)(tb / 64)) + 15) & ~(size_t)15) + (sizeof(LevelPack) * (size_t)nlevels) + (sizeof(uint32_t) * (size_t)((nalltrans + 1) / 2));
+}
+
 // Tail kernel: the LAST few thousand r-packets and thermal packets of a timestep, one per lane, each carried through
 // r-packet steps, macro-atom walks and k-packet steps until it leaves these kinds (end of the timestep, escape, a
 // slow-path action, a gamma-ray type, a blackbody step, another cache tile). The event-split kernels need one launch
@@ -1442,6 +1730,9 @@ struct TailLists {
 #ifndef ARTIS_TAIL_WAVES
 #define ARTIS_TAIL_WAVES 2
 #endif
+#ifndef ARTIS_SLOW_WAVE_FB
+#define ARTIS_SLOW_WAVE_FB 1  // free-bound emission frequencies selected by the wave (physics.h FbSel) in k_slow and k_tail
+#endif
 __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailLists in, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
@@ -1454,33 +1745,58 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
   int kind = NEXT_DONE;
   int32_t pi = 0, cellindex = 0;
   double nu_cmf = 0.;
-  if ((threadIdx.x & 63) == 0 && tid < (int64_t)in.n[0] + in.n[1] + in.n[2] + in.n[3]) {
+  // (every lane runs the loop over the packet's kinds of step with lane 0's kind; only lane 0 holds the packet and carries the steps out,
+  // the other 63 join it where the wave works together: the frequency of a free-bound emission, physics.h FbSel)
+  const bool owner = (threadIdx.x & 63) == 0 && tid < (int64_t)in.n[0] + in.n[1] + in.n[2] + in.n[3];
+  Pkt p;
+  if (owner) {
     int32_t j = (int32_t)tid;
     int which = 0;
     while (j >= in.n[which]) j -= in.n[which++];
     pi = in.list[which][j];
-    Pkt p;
     pkt_load(env.P, pi, p);
-    while (true) {
-      kind = classify(env, p, ts_end);
-      if (kind == NEXT_RPKT) {
+  }
+  while (true) {
+    if (owner) kind = classify(env, p, ts_end);
+    const int kind_w = __builtin_amdgcn_readfirstlane(__shfl(kind, 0));
+    if (kind_w == NEXT_SLOW) {
+#if ARTIS_SLOW_WAVE_FB
+      FbSel sel;
+      sel.mode = 1;
+      sel.valid = false;
+      sel.element = sel.lowerion = sel.lower = sel.t = 0;
+      sel.T_e = 0.f;
+      sel.zrand = sel.nu = 0.;
+      if (owner && slow_selects_continuum_nu(p)) {
+        Pkt t = p;
+        (void)advance_slow(env, t, pi, &sel);
+      }
+      fbsel_wave(env, sel);
+      if (owner) (void)advance_slow(env, p, pi, sel.valid ? &sel : nullptr);
+#else
+      if (owner) (void)advance_slow(env, p, pi);
+#endif
+    } else if (kind_w == NEXT_RPKT) {
+      if (owner) {
         Chi x;
         chi_load(env.P, pi, p, x);
         bool go = rpkt_can_continue(p, ts_end);
         while (go) go = rpkt_iter(env, p, pi, x);
         chi_store(env.P, pi, p, x);
-      } else if (kind == NEXT_MA || kind == NEXT_KPKT) {
+      }
+    } else if (kind_w == NEXT_MA || kind_w == NEXT_KPKT) {
+      if (owner) {
         MACtx k = ma_ctx(env, p);
         bool go = thermal_can_continue(p, ts_end);
         while (go) (void)thermal_iter(env, p, pi, k, &go);
-      } else if (kind == NEXT_SLOW) {
-        (void)advance_slow(env, p, pi);
-      } else if (kind == NEXT_BB) {
-        (void)advance_blackbody(env, p, pi);
-      } else {
-        break;
       }
+    } else if (kind_w == NEXT_BB) {
+      if (owner) (void)advance_blackbody(env, p, pi);
+    } else {
+      break;
     }
+  }
+  if (owner) {
     pkt_store(env.P, pi, p);
     cellindex = p.cellindex;
     nu_cmf = p.nu_cmf;
@@ -1502,11 +1818,33 @@ __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, in
   int kind = NEXT_DONE;
   int32_t pi = 0, cellindex = 0;
   double nu_cmf = 0.;
-  if (tid < n) {
+  // A free-bound emission's frequency (select_continuum_nu ratecoeff.cc:563: up to a hundred adaptive 31-point quadratures) is selected by
+  // the WAVE (physics.h FbSel): the action is first run on a copy of the packet up to the selection, whose arguments are recorded; the
+  // wave's lanes evaluate the abscissae of each rule side by side for one recorded selection after the other; then the action runs for real.
+  // (Round 4: one lane per emission while the other lanes of its wave waited -- lane utilisation 0.11; ARTIS_SLOW_WAVE_FB=0 builds that form.)
+  const bool mine = tid < n;
+  Pkt p;
+  FbSel sel;
+  sel.mode = 1;
+  sel.valid = false;
+  sel.element = sel.lowerion = sel.lower = sel.t = 0;
+  sel.T_e = 0.f;
+  sel.zrand = sel.nu = 0.;
+  if (mine) {
     pi = list[tid];
-    Pkt p;
     pkt_load(env.P, pi, p);
-    kind = advance_slow(env, p, pi);
+#if ARTIS_SLOW_WAVE_FB
+    if (slow_selects_continuum_nu(p)) {
+      Pkt t = p;
+      (void)advance_slow(env, t, pi, &sel);
+    }
+#endif
+  }
+#if ARTIS_SLOW_WAVE_FB
+  fbsel_wave(env, sel);
+#endif
+  if (mine) {
+    kind = advance_slow(env, p, pi, sel.valid ? &sel : nullptr);
     pkt_store(env.P, pi, p);
     cellindex = p.cellindex;
     nu_cmf = p.nu_cmf;
@@ -1747,6 +2085,8 @@ struct artis_amd_engine {
   bool cont_lds = true;      // k_rpkt keeps the static continuum table (ContPack) in LDS when it fits (ARTIS_AMD_CONTLDS=0: HBM)
   bool line_lds = false;     // ARTIS_AMD_LINELDS=1: the line list's frequencies in LDS instead (k_rpkt<false, .., true>; measured slower)
   int thermal_blocks_per_cu = ARTIS_THERMAL_WAVES;  // tuning: resident k_thermal blocks per CU
+  bool thermal_refill = false;  // ARTIS_AMD_REFILL=1: k_thermal_q (walk contexts in per-wave LDS slots, lanes refilled inside the transition loop)
+  int tq_low = 48;              // ... its low-water mark of walking lanes (ARTIS_AMD_TQ_LOW)
   bool ma_tables_lds = true;  // k_thermal<1024, true>: the static target tables in LDS when they fit (ARTIS_AMD_MATABLES_LDS=0: in HBM)
   // the population's scratch: the collisional-excitation cooling terms of `pop_batch` cells at a time (k_matrans writes them,
   // k_cooling_chain turns them into running sums, k_collexc_filter into the records' cooling filters; nothing of it is kept)
@@ -2349,6 +2689,8 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_LINELDS")) e->line_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TILE_ZIGZAG")) e->tile_zigzag = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_MATABLES_LDS")) e->ma_tables_lds = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_REFILL")) e->thermal_refill = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_TQ_LOW")) e->tq_low = std::max(1, std::min(64, std::atoi(b)));
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_FILL")) e->sparse_fill = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_MAX")) e->sparse_max_listed = std::max(0, std::atoi(b));
   {
@@ -2988,7 +3330,17 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
           // (drain: only where the next thermal launch will be large too, so that what is handed on runs beside a full list)
           const int bud_t = (e->budget_t_small > 0 && nk < e->small_list) ? std::min(e->budget_t_small, e->budget_t) : e->budget_t;
           const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : bud_t;
-          if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS && e->Mh.nalltrans <= MA_LDS_TRANS && nk >= 4096) {
+          const size_t tq_bytes = tq_lds_bytes(TQ_TB, e->Mh.nlevels, e->Mh.nalltrans);
+          if (e->thermal_refill && ARTIS_THERMAL_SPLIT_EXACT && env.cellest_n_t == 0 && tq_bytes <= 160 * 1024 - 1024 && nk >= 4096 && e->Mh.nlevels < 32768) {
+            static bool attr_set = false;
+            if (!attr_set) {
+              HIP_TRY(hipFuncSetAttribute((const void *)k_thermal_q<TQ_TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+              attr_set = true;
+            }
+            const int grid1 = (int)std::min<int64_t>(((int64_t)nk + TQ_TB - 1) / TQ_TB, (int64_t)e->ncu);
+            hipLaunchKernelGGL((k_thermal_q<TQ_TB>), dim3(grid1), dim3(TQ_TB), tq_bytes, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
+                               e->wave_chunks_t ? chunks_for(nk, grid1 * (TQ_TB / 64)) : 8, drain, e->tq_low);
+          } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS && e->Mh.nalltrans <= MA_LDS_TRANS && nk >= 4096) {
             const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
             hipLaunchKernelGGL((k_thermal<1024, 1>), dim3(grid1), dim3(1024), 0, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
                                e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
@@ -3261,6 +3613,22 @@ int artis_amd_last_kernel_table(artis_amd_engine *e, double ms[4], int64_t launc
     if (launches) launches[i] = e->klaunches[kinds[i]];
     if (packets) packets[i] = e->kthreads[kinds[i]];
   }
+  return ARTIS_OK;
+}
+
+int artis_amd_last_kernel_ms_by_kind(artis_amd_engine *e, double ms[8], int64_t launches[8]) {
+  if (!e || !ms) return ARTIS_ERR_ARG;
+  const int kinds[5] = {NEXT_RPKT, NEXT_MA, NEXT_SLOW, NEXT_GAMMA, NEXT_BB};
+  for (int i = 0; i < 8; i++) {
+    ms[i] = 0.;
+    if (launches) launches[i] = 0;
+  }
+  for (int i = 0; i < 5; i++) {
+    ms[i] = e->kms[kinds[i]];
+    if (launches) launches[i] = e->klaunches[kinds[i]];
+  }
+  ms[5] = e->kms_tail;
+  ms[6] = e->last_fill_ms;
   return ARTIS_OK;
 }
 

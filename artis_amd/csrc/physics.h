@@ -2759,6 +2759,173 @@ AHD double select_continuum_nu(const Env &env, int element, int lowerion, int lo
   p.s0 = rs.s0; p.s1 = rs.s1; p.s2 = rs.s2; p.s3 = rs.s3;
   return nu;
 }
+// A free-bound emission whose frequency a WAVE selects (round 5; k_slow, k_tail): the slow-path action is run twice on the lane that owns
+// the packet -- first on a copy, up to the point where it would call select_continuum_nu(), whose arguments and random number are
+// RECORDED there (mode 1: the action returns at once, nothing but the copy has changed); then the wave evaluates the up to 100 adaptive
+// 31-point quadratures together (select_continuum_nu_wave: one abscissa per lane, the weighted sums added in gausskronrod.h's order: the
+// same bits), and the action runs for real with the frequency handed in (mode 2: the generator makes the one draw the selection makes).
+struct FbSel {
+  int mode;  // 1: record and return, 2: replay with `nu`
+  bool valid;
+  int element, lowerion, lower, t;
+  float T_e;
+  double zrand, nu;
+};
+AHD double select_continuum_nu_sel(const Env &env, int element, int lowerion, int lower, int t, float T_e, Pkt &p, FbSel *sel) {
+  if (sel == nullptr) return select_continuum_nu(env, element, lowerion, lower, t, T_e, p);
+  if (sel->mode == 1) {
+    sel->valid = true;
+    sel->element = element; sel->lowerion = lowerion; sel->lower = lower; sel->t = t;
+    sel->T_e = T_e;
+    sel->zrand = 1. - rng_uniform(p);  // ratecoeff.cc:575, the selection's only draw
+    return 0.;
+  }
+  (void)rng_uniform(p);
+  return sel->nu;
+}
+#if defined(__HIPCC__) && !defined(ARTIS_HOST_EMU)
+// gk31_unit() by a wave: lane 0 evaluates the integrand at the centre, lanes 1..15 at +x[lane], lanes 16..30 at -x[lane - 15]; every
+// lane then adds the weighted sums in gk31_unit()'s order from the values of the other lanes (wave-uniform results)
+__device__ inline double wave_bcast(double v, int srclane) {
+  union { double d; int32_t i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], srclane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], srclane);
+  return u.d;
+}
+__device__ inline double gk31_unit_wave(const FbIntegrand &f, const GK31 &g, double scale, double mean, double *error) {
+  const int lane = (int)(threadIdx.x & 63);
+  double xj = 0.;
+#pragma unroll
+  for (int i = 1; i < 16; i++) xj = (lane == i || lane == 15 + i) ? g.x[i] : xj;  // (selects: no indexed table in memory)
+  const double arg = (lane == 0) ? ((scale * 0.) + mean) : ((lane <= 15) ? ((scale * xj) + mean) : ((scale * -xj) + mean));
+  const double fv = fb_integrand(f, arg);
+  const double fc = wave_bcast(fv, 0);
+  double kr = fc * g.w[0];
+  double gr = 0.;
+  gr += fc * g.wg[0];
+#pragma unroll
+  for (unsigned i = 2; i < 16; i += 2) {
+    const double fp = wave_bcast(fv, (int)i);
+    const double fm = wave_bcast(fv, (int)(15 + i));
+    kr += (fp + fm) * g.w[i];
+    gr += (fp + fm) * g.wg[i / 2];
+  }
+#pragma unroll
+  for (unsigned i = 1; i < 16; i += 2) {
+    const double fp = wave_bcast(fv, (int)i);
+    const double fm = wave_bcast(fv, (int)(15 + i));
+    kr += (fp + fm) * g.w[i];
+  }
+  *error = dmax(fabs(kr - gr), fabs(kr * 2.220446049250313e-16 * 2));
+  return kr;
+}
+// gk31_adaptive() with the wave's unit: the same depth-first walk; every value is wave-uniform
+__device__ inline double gk31_adaptive_wave(const FbIntegrand &f, const GK31 &g, double tol, double a0, double b0, double *error_out) {
+  constexpr int MAXD = 16;
+  double ra[MAXD], rb[MAXD], rtol[MAXD], est_left[MAXD], err_left[MAXD];
+  int state[MAXD];
+  int depth = 0;
+  double a = a0, b = b0, abs_tol = 0.;
+  unsigned levels = 15;
+  double ret_est = 0., ret_err = 0.;
+  while (true) {
+    double err_local = 0.;
+    const double mean = (b + a) / 2;
+    const double scale = (b - a) / 2;
+    const double r1 = gk31_unit_wave(f, g, scale, mean, &err_local);
+    const double estimate = scale * r1;
+    const double abs_tol1 = fabs(estimate * tol);
+    if (abs_tol == 0) abs_tol = abs_tol1;
+    if ((levels != 0) && (abs_tol1 < err_local) && (abs_tol < err_local)) {
+      const double mid = (a + b) / 2;
+      ra[depth] = mid;
+      rb[depth] = b;
+      rtol[depth] = abs_tol / 2;
+      state[depth] = 0;
+      depth++;
+      b = mid;
+      abs_tol = abs_tol / 2;
+      levels--;
+      continue;
+    }
+    ret_est = estimate;
+    ret_err = err_local;
+    while (true) {
+      if (depth == 0) {
+        *error_out = ret_err;
+        return ret_est;
+      }
+      const int d = depth - 1;
+      if (state[d] == 0) {
+        est_left[d] = ret_est;
+        err_left[d] = ret_err;
+        state[d] = 1;
+        a = ra[d];
+        b = rb[d];
+        abs_tol = rtol[d];
+        levels = 15 - depth;
+        break;
+      }
+      ret_est = est_left[d] + ret_est;
+      ret_err = err_left[d] + ret_err;
+      depth--;
+    }
+  }
+}
+__device__ inline double integrator31_wave(const FbIntegrand &f, const GK31 &g, double a, double b, double epsrel, double *abserr) {
+  if (a == b) return 0.;
+  if (b < a) return -gk31_adaptive_wave(f, g, epsrel, b, a, abserr);
+  return gk31_adaptive_wave(f, g, epsrel, a, b, abserr);
+}
+// select_continuum_nu_impl() (ratecoeff.cc:563) by a wave, for the recorded arguments and random number of one packet (all wave-uniform)
+__device__ inline double select_continuum_nu_wave(const DevModel &M, int element, int lowerion, int lower, int t, float T_e, double zrand) {
+  const GK31 g = gk31_tables();
+  const int ul = lstart(M, element, lowerion) + lower;
+  const double E_threshold = phixs_threshold(M, element, lowerion, lower, t);
+  const double nu_threshold = (1. / HPLANCK) * E_threshold;
+  const double nu_max_phixs = nu_threshold * M.last_phixs_nuovernuedge;
+  const int npieces = M.NPHIXSPOINTS;
+  const FbIntegrand f = {&M, phixs_table(M, ul), nu_threshold, T_e};
+  const double nu_range = nu_max_phixs - nu_threshold;
+  const double deltanu = nu_range / npieces;
+  double error = 0.;
+  const double total = integrator31_wave(f, g, 0., nu_range, 1e-3, &error);
+  if (!(total > 0.) || !isfinite(total)) return nu_threshold;
+  double tail_prev = total;
+  double tail = total;
+  int i = 1;
+  for (; i < npieces; i++) {
+    tail_prev = tail;
+    const double low = i * deltanu;
+    tail = integrator31_wave(f, g, low, nu_range, 1e-3, &error);
+    if (zrand >= tail / total) break;
+  }
+  double nuoffset = 0.;
+  if (i < npieces) {
+    nuoffset = (tail != tail_prev) ? ((total * zrand) - tail_prev) / (tail - tail_prev) * deltanu : 0.;
+  } else if (tail > 0.) {
+    nuoffset = (tail - (total * zrand)) / tail * deltanu;
+  }
+  return nu_threshold + ((i - 1) * deltanu) + nuoffset;
+}
+// the wave's part of a slow-path step: every lane whose recorded selection is valid gets its frequency (lane by lane, all lanes working)
+__device__ inline void fbsel_wave(const Env &env, FbSel &sel) {
+  unsigned long long m = __ballot(sel.valid);
+  const int lane = (int)(threadIdx.x & 63);
+  while (m != 0) {
+    const int src = __ffsll((long long)m) - 1;
+    const int element = __builtin_amdgcn_readlane(sel.element, src), lowerion = __builtin_amdgcn_readlane(sel.lowerion, src);
+    const int lower = __builtin_amdgcn_readlane(sel.lower, src), t = __builtin_amdgcn_readlane(sel.t, src);
+    const float T_e = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sel.T_e), src));
+    const double zrand = wave_bcast(sel.zrand, src);
+    const double nu = select_continuum_nu_wave(env.M, element, lowerion, lower, t, T_e, zrand);
+    if (lane == src) sel.nu = nu;
+    m &= m - 1;
+  }
+  sel.mode = 2;
+}
+#endif
 
 
 #if ARTIS_OPT_VPKT_ON
@@ -3595,7 +3762,7 @@ AHD void ma_slow_search(const Env &env, Pkt &p, int64_t pi) {
 }
 
 // the bound-free transitions of do_macroatom(): macroatom.cc:481-488, 501-533, 552-560
-AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi) {
+AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi, FbSel *sel = nullptr) {
   const DevModel &M = env.M;
   const int c = M.propcell_nonemptymgi[p.cellindex];
   const int element = p.ma_element;
@@ -3633,7 +3800,8 @@ AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi) {
       p.ma_level = -1;
       return;
     }
-    p.nu_cmf = select_continuum_nu(env, element, ion - 1, lowerlevel, sel_t, T_e, p);
+    p.nu_cmf = select_continuum_nu_sel(env, element, ion - 1, lowerlevel, sel_t, T_e, p, sel);
+    if (sel != nullptr && sel->mode == 1) return;  // (recorded: the wave selects the frequency, then the action runs again)
     ARTIS_STAT(env, ARTIS_STAT_MA_DEACTIVATION_FB);
     emit_rpkt(env, p, pi);
     p.next_trans = -1;
@@ -4105,13 +4273,14 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
 }
 
 // free-bound emission of a k-packet, kpkt.cc:518-542
-AHD void kpkt_fb_emission(const Env &env, Pkt &p, int64_t pi) {
+AHD void kpkt_fb_emission(const Env &env, Pkt &p, int64_t pi, FbSel *sel = nullptr) {
   const DevModel &M = env.M;
   const int c = M.propcell_nonemptymgi[p.cellindex];
   const int element = p.ma_element, ion = p.ma_ion, lowerlevel = p.pend_arg, t = p.ma_line;
   p.pend = PEND_NONE;
   p.ma_line = -99;
-  p.nu_cmf = select_continuum_nu(env, element, ion, lowerlevel, t, env.C.Te[c], p);
+  p.nu_cmf = select_continuum_nu_sel(env, element, ion, lowerlevel, t, env.C.Te[c], p, sel);
+  if (sel != nullptr && sel->mode == 1) return;
   emit_rpkt(env, p, pi);
   ARTIS_STAT(env, ARTIS_STAT_K_TO_R_FB);
   thermal_emission_flags(env, p, pi, emtype_continuum(M, lstart(M, element, ion) + lowerlevel, t));
@@ -5003,12 +5172,16 @@ AHD int advance_gamma(const Env &env, Pkt &p, int64_t pi, int budget) {
 }
 
 // slow-path kernel body: the one deferred action of the packet
-AHD int advance_slow(const Env &env, Pkt &p, int64_t pi) {
+// the slow-path actions that end in select_continuum_nu(): a free-bound emission of a k-packet, a radiative recombination of a macro-atom
+AHD bool slow_selects_continuum_nu(const Pkt &p) {
+  return p.pend == PEND_KPKT_FB || (p.pend == PEND_MA_ACTION && p.pend_arg == ARTIS_MA_ACTION_RADRECOMB);
+}
+AHD int advance_slow(const Env &env, Pkt &p, int64_t pi, FbSel *sel = nullptr) {
   if (p.pend == PEND_MA_ACTION) {
-    ma_slow_action(env, p, pi);
+    ma_slow_action(env, p, pi, sel);
     chi_after_ma(p);
   } else if (p.pend == PEND_KPKT_FB) {
-    kpkt_fb_emission(env, p, pi);
+    kpkt_fb_emission(env, p, pi, sel);
     p.chi_mgi = -1;
   } else if (p.pend == PEND_MA_SEARCH || p.pend == PEND_MA_RADSEARCH) {
     ma_slow_search(env, p, pi);

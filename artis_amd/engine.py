@@ -68,7 +68,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_engine_destroy", "artis_amd_set_cellstate", "artis_amd_update_packets", "artis_amd_packets_upload",
     "artis_amd_packets_download", "artis_amd_packets_snapshot", "artis_amd_packets_restore",
     "artis_amd_update_packets_device", "artis_amd_estimators_zero", "artis_amd_estimators_download",
-    "artis_amd_estimators_devptr", "artis_amd_last_kernel_ms", "artis_amd_debug_cellcache", "artis_amd_debug_visit_counts",
+    "artis_amd_estimators_devptr", "artis_amd_last_kernel_ms", "artis_amd_debug_cellcache", "artis_amd_debug_visit_counts", "artis_amd_last_kernel_ms_by_kind",
     "artis_amd_populate_cellcache",
     "artis_amd_last_kernel_breakdown",
     "artis_amd_last_kernel_launches",
@@ -217,6 +217,13 @@ class Engine:
         self._check(self.L.artis_amd_last_kernel_table(self.h, ms, nl, npk))
         names = ["k_rpkt", "k_ma", "k_kpkt", "k_slow"]
         return {n: {"ms": ms[i], "launches": nl[i], "packets": npk[i]} for i, n in enumerate(names)}
+
+    def last_kernel_ms_by_kind(self):
+        ms, nl = (C.c_double * 8)(), (C.c_int64 * 8)()
+        self.L.artis_amd_last_kernel_ms_by_kind.argtypes = [C.c_void_p] * 3
+        self._check(self.L.artis_amd_last_kernel_ms_by_kind(self.h, ms, nl))
+        names = ["k_rpkt", "k_thermal", "k_slow", "k_gamma", "k_blackbody", "k_tail", "tile_fills"]
+        return {n: {"ms": round(ms[i], 3), "launches": nl[i]} for i, n in enumerate(names)}
 
     def last_kernel_ms(self):
         ms, n = C.c_double(), C.c_int64()

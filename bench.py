@@ -478,6 +478,7 @@ def main():
         out["config"]["cell_cache"] = {"tiles": nt, "cells_per_tile": tcells, "bytes_per_cell": bpc, **(eng.last_tiling() if nt > 1 else {})}
         bd.update(ma_transitions=int(S("X_MA_JUMPS")), kpkt_steps=int(S("X_KPKT_STEPS")), rpkt_steps=int(S("X_RPKT_STEPS")))
         out["kernel_breakdown_last_step"] = bd
+        out["kernel_ms_by_kind_last_step"] = eng.last_kernel_ms_by_kind()
         if os.environ.get("ARTIS_BENCH_VERBOSE"):
             print({abi.STAT_NAMES[i]: int(stats[i]) for i in range(abi.NSTATS) if stats[i]}, file=sys.stderr)
         if baseline is not None:

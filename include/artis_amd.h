@@ -582,6 +582,11 @@ int artis_amd_debug_cellcache(artis_amd_engine *eng, int nonemptymgi, double *le
                               double *allcont_edgepart, uint64_t *allcont_keepbits, double *corrphotoioncoeff,
                               double *cooling_contrib, double *ion_cooling_contribs, double *chi_ff_nnionpart);
 
+/* Summed launch durations (HIP events on the launch stream) of the last artis_amd_update_packets_device() call by kind of kernel:
+ * 0 k_rpkt (+ k_bfest_dense), 1 k_thermal, 2 k_slow, 3 k_gamma, 4 k_blackbody, 5 k_tail, 6 tile fills inside the call; 7 unused.
+ * launches may be NULL. */
+int artis_amd_last_kernel_ms_by_kind(artis_amd_engine *eng, double ms[8], int64_t launches[8]);
+
 /* Measurement builds only (-DARTIS_VISIT_COUNTS, tools/visit_sparsity.py): how many macro-atom transitions the last
  * propagation call drew in the record of every (non-empty cell, level), counts[nonemptymgi * nlevels + level]; the reference fills a
  * level's rates when a packet first reaches it (macroatom.cc:398-417 calc_rates_if_needed). Any other build returns ARTIS_ERR_ARG. */

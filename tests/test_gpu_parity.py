@@ -644,6 +644,32 @@ def test_macroatom_filters_decide_nothing_the_f64_values_would_not(engine_mod, m
     parity.compare_estimators(outs[1][1], outs[0][1], 1e-10, "f64 decisions vs filters")
 
 
+def test_walker_refill_kernel_gives_the_phase_kernels_packets(engine_mod, monkeypatch):
+    """k_thermal_q (ARTIS_AMD_REFILL=1: walk contexts in per-wave LDS slots, the transition loop's lanes refilled inside the loop,
+    exits and k-packet steps in full-wave service passes; round 5) against k_thermal on the bench grid with the bench's atomic data:
+    every field of every packet, the generator states and the event counters identical (the same functions in the same order per
+    packet, on the packet's own generator); estimators to summation order. With a low and a high low-water mark."""
+    model, cs, ts, aux = synth.build("w7", ncoord=50)
+    pk0 = synth.make_packets(model, aux, 400_000, seed_base=1281360349, kpkt_fraction=0.02)
+    outs = []
+    for cfg in ({}, {"ARTIS_AMD_REFILL": "1"}, {"ARTIS_AMD_REFILL": "1", "ARTIS_AMD_TQ_LOW": "16"}):
+        for k in ("ARTIS_AMD_REFILL", "ARTIS_AMD_TQ_LOW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in cfg.items():
+            monkeypatch.setenv(k, v)
+        eng = engine_mod.Engine(model)
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, "classic")
+        eng.update_packets(p, e)
+        eng.close()
+        outs.append((p, e))
+    assert outs[0][1].stats[abi.STAT_X_MA_JUMPS] > 5e8
+    for o in outs[1:]:
+        parity.compare_packets(o[0], outs[0][0], 0.0, "k_thermal_q vs k_thermal")
+        parity.compare_stats(o[1], outs[0][1], "k_thermal_q vs k_thermal")
+        parity.compare_estimators(o[1], outs[0][1], 1e-10, "k_thermal_q vs k_thermal")
+
+
 def test_budget_independence_on_device(engine_mod, monkeypatch):
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
     pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.3)

@@ -7,5 +7,6 @@ d=json.loads(sys.stdin.read()); b=d['kernel_breakdown_last_step']
 err=open('/tmp/_err').read()
 m=re.search(r\"'X_MA_JUMPS': (\d+)\", err); j=int(m.group(1)) if m else 0
 m=re.search(r\"'X_56': (\d+)\", err); h=int(m.group(1)) if m else 0
-print('%-70s %.1f ms/step thermal %.1f ms rpkt %.1f ms launches %d lds-frac %.2f' % ('$cfg', d['ms_per_step'], b['thermal_ms'], b['rpkt_ms'], b['thermal_launches'], (h/j if j else 0)))"
+k=d.get('kernel_ms_by_kind_last_step',{})
+print('%-70s %.1f ms/step thermal %.1f ms rpkt %.1f ms launches %d slow %.1f tail %.1f bb %.1f' % ('$cfg', d['ms_per_step'], b['thermal_ms'], b['rpkt_ms'], b['thermal_launches'], k.get('k_slow',{}).get('ms',0), k.get('k_tail',{}).get('ms',0), k.get('k_blackbody',{}).get('ms',0)))"
 done
