@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
       c1 = __shfl(s1, last);
       c2 = __shfl(s2, last);
     }
-    if (lane == 0) {
+    if (lane == 0 && lpk.rec_off >= 0) {  // (a cold level has no static record: only its cooling terms above are kept)
       double *rates = ma_rates_of(row + lpk.rec_off, lpk.ndown, lpk.nup);
       if (sfirst.dir == 0) {
         rates[ARTIS_MA_ACTION_RADDEEXC] = c0;
@@ -272,6 +272,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
       v[2][o + i] = s2;
     }
     const LevelPack lpk = M.level_pack[sg.ul];
+    if (lpk.rec_off < 0) continue;
     double *rates = ma_rates_of(row + lpk.rec_off, lpk.ndown, lpk.nup);
     if (sg.dir == 0) {
       rates[ARTIS_MA_ACTION_RADDEEXC] = s0;
@@ -303,6 +304,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
   // 3b. ... into the records: the entries of a line that is not usable are 0, its mark too
   for (int e = lane; e < nent; e += 64) {
     const MaEntryPos ps = ma_entry_pos(M, a0, e);
+    if (ps.lpk.rec_off < 0) continue;
     const int e_line = e - (ps.ti % MAREC_PER);
     U4 *rec = row + ps.lpk.rec_off;
     const bool lok_int = lds_ok[w][0][e_line] != 0;
@@ -380,6 +382,7 @@ __global__ void __launch_bounds__(BLOCK) k_macroatom(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const int64_t total = fill_count(env) * env.M.nlevels;
   if (i >= total) return;
+  if (env.M.level_pack[i % env.M.nlevels].rec_off < 0) return;  // (a cold level: filled when a packet reaches it, physics.h ma_slow_fill)
   populate_macroatom<true>(env, fill_cell(env, i / env.M.nlevels), (int)(i % env.M.nlevels));
 }
 // The filters of the directions with more transitions than a block of k_matrans holds (DevModel::malongsegs: > MATRANS_BLOCK):
@@ -445,8 +448,18 @@ __global__ void __launch_bounds__(BLOCK) k_mafilter_long(Env env) {
 __global__ void __launch_bounds__(BLOCK) k_debug_macache(Env env, int c, double *maprocessrates, double *matrans, int32_t *bad) {
   const int ul = blockIdx.x * BLOCK + threadIdx.x;
   if (ul >= env.M.nlevels) return;
+  if (ma_resolve(env, c, env.M.level_pack[ul].rec_off) < 0) return;  // (a cold level no packet has reached in this cell: no record)
   const int b = debug_level_record(env, c, ul, maprocessrates, matrans);
   if (b != 0) atomicAdd(bad, b);
+}
+// before a fill: no cold level of the cells to be filled has a record, their pools are empty (tables.h "ON-DEMAND RECORDS")
+__global__ void __launch_bounds__(BLOCK) k_ma_reset(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int ncold = env.M.ncold;
+  if (i >= fill_count(env) * ncold) return;
+  const int c = fill_cell(env, i / ncold);
+  env.K.ma_rowtab[((int64_t)c * ncold) + (i % ncold)] = -1;
+  if (i % ncold == 0) env.K.ma_pool_used[c] = 0;
 }
 // the static part of every record of every resident row, once per engine: filter entries "never counted", lines usable
 __global__ void __launch_bounds__(BLOCK) k_mainit(Env env, int64_t nrows) {
@@ -1365,7 +1378,9 @@ __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_the
       ma_flush_stats(env, k);
       // (a transition whose search the filters could not decide is finished here, outside the loop: the walk goes on in the
       // next phase)
-      if (exit_action == MA_EXIT_DEFER) {
+      if (exit_action == MA_EXIT_FILL) {
+        p.pend = PEND_MA_FILL;  // a cold level without a record in this cell: the slow-path kernel fills it (physics.h ma_slow_fill)
+      } else if (exit_action == MA_EXIT_DEFER) {
 #if ARTIS_THERMAL_SPLIT_EXACT
         p.pend = PEND_MA_SEARCH;  // the slow-path kernel re-adds the sums and makes the transition (physics.h ma_slow_search)
         p.pend_arg = k.defer;
@@ -1504,9 +1519,23 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
 #else
 #define TQ_PROF(slot) ((void)0)
 #endif
+#if defined(ARTIS_PROFILE) && !defined(ARTIS_PROFILE_MA)
+  long long tq_s = clock64();
+#define TQ_SUB(slot)                                                                    \
+  do {                                                                                  \
+    const long long now = clock64();                                                    \
+    if (lane == 0) atomicAdd(&lstats[slot], (stat_t)((now - tq_s) >> 4));               \
+    tq_s = now;                                                                         \
+  } while (0)
+#else
+#define TQ_SUB(slot) ((void)0)
+#endif
   while (true) {
     // ---------------- service passes: while a full wave of slots waits, or the walkers would run short
     while (nservice >= 64 || (nservice > 0 && nready < low_water)) {
+#if defined(ARTIS_PROFILE) && !defined(ARTIS_PROFILE_MA)
+      tq_s = clock64();
+#endif
       const int take = min(64, nservice);
       const bool has = lane < take;
       const int s = has ? (int)Q.service[nservice - 1 - lane] : 0;
@@ -1537,7 +1566,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
           k.start = lv >> 16;
           k.start_key = (p.ma_element << 8) | p.ma_ion;
           const LevelPack lp = env.M.level_pack[k.start + p.ma_level];
-          k.rec = lp.rec_off; k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
+          k.rec = ma_resolve(env, k.c, lp.rec_off); k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
           const int cnt = Q.cnt[s];
           units = cnt & 0xFFFF;
           k.njumps = cnt >> 16;
@@ -1550,15 +1579,19 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
         ARTIS_STAT_ADD(env, 44, take);  // ... and the slots they served
       }
 #endif
+      TQ_SUB(59);  // (-DARTIS_PROFILE: wave clocks / 16 of the parts of a service pass: 59 pull + hot line + context | 60 the process that ended
+                   //  the walk | 61 the k-packet step | 62 prepare + store + context | 63 classify + append + stacks)
       int kind = NEXT_DONE;
       int32_t out_pi = 0;
       bool walking = false;
-      if (have) {
+      if (have) {  // (one block: split into parts -- as the profile marks would like it -- the compiler spills 93 instead of 13 registers)
         bool go = thermal_can_continue(p, ts_end);
         if (isdone) {
           ma_flush_stats(env, k);
           const U4 *rec = ma_record(k);
-          if (act == MA_EXIT_DEFER) {
+          if (act == MA_EXIT_FILL) {
+            p.pend = PEND_MA_FILL;
+          } else if (act == MA_EXIT_DEFER) {
             p.pend = PEND_MA_SEARCH;  // the slow-path kernel re-adds the sums and makes the transition (physics.h ma_slow_search)
             p.pend_arg = k.defer;
           } else if (act >= 0) {
@@ -1567,6 +1600,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
           chi_after_ma(p);
           go = thermal_can_continue(p, ts_end);
         }
+        TQ_SUB(60);
         if (go) {
           // a pre-k-packet, or a k-packet in a grey cell, leaves for the blackbody kernel (classify() below)
           const bool blackbody = (p.type == ARTIS_TYPE_PRE_KPKT) || k.thick;
@@ -1577,6 +1611,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
           }
           go = thermal_can_continue(p, ts_end) && !(blackbody && kpkt_eligible(p, ts_end));
         }
+        TQ_SUB(61);
         walking = go && units < budget_now && ma_pending(p) && p.pend == PEND_NONE;
         if (walking) ma_prepare(env, p, k);  // (only k.start is kept: the walk phase reads the level's record shape from LDS)
         pkt_store_thermal(env.P, pi, p);  // the hot line; the flight line only if an r-packet was emitted
@@ -1591,6 +1626,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
           out_pi = pi;
         }
       }
+      TQ_SUB(62);
       append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next, (p.ma_element * 5 + p.ma_ion));
       // where the slots go: READY, or back on the service stack as empty (a packet is pulled into it by the next pass), or --
       // once the work list is used up -- out of use
@@ -1608,6 +1644,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
         ndead += take - __popcll(rm) - __popcll(em);
       }
       __builtin_amdgcn_wave_barrier();
+      TQ_SUB(63);
     }
     TQ_PROF(42);
     if (nready == 0) break;  // (then nothing waits for service either: every slot is out of use)
@@ -1642,7 +1679,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
               k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
               k.start = lv >> 16;
               const LevelPack lp = env.M.level_pack[k.start + w.ma_level];
-              k.rec = lp.rec_off; k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
+              k.rec = ma_resolve(env, k.c, lp.rec_off); k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
               const int cnt = Q.cnt[s];
               units = cnt & 0xFFFF;
               k.njumps = cnt >> 16;
@@ -2458,7 +2495,32 @@ int artis_amd_engine_create(const artis_model *model, int device, artis_amd_engi
 namespace {
 int engine_fill(artis_amd_engine *e, const artis_model *model) {
   const int device = e->device;
-  e->Mh = make_host_model_view(*model, e->own);
+  {
+    // Macro-atom record tiers (tables.h "ON-DEMAND RECORDS"): every level a static record while the whole cell cache fits one tile; when it
+    // does not (even without line_dpop), static records for the lowest ARTIS_AMD_MA_HOTFRAC (0.3) of every ion's levels and a pool of
+    // ARTIS_AMD_MA_POOLFRAC (0.25) of the rest for the cold levels packets reach. Either variable set: taken as given.
+    double hot = 1., pool = 0.25;
+    const bool given = std::getenv("ARTIS_AMD_MA_HOTFRAC") != nullptr;
+    ma_tiers_from_env(&hot, &pool);
+    e->Mh = make_host_model_view(*model, e->own, hot, pool);
+    if (!given) {
+      size_t free_b = 0, total_b = 0;
+      HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+      auto fits = [&]() {
+        size_t per_cell = 0;
+#define SZ(f, T, per) per_cell += sizeof(T) * (size_t)(per);
+        ARTIS_CACHE_ARRAYS(SZ, e->Mh)
+#undef SZ
+        per_cell -= sizeof(double) * (size_t)e->Mh.ndpop;  // (dropped first when the cache does not fit: below)
+        return (double)per_cell * (double)model->npts_nonempty <= cache_budget_bytes(free_b);
+      };
+      // the largest hot share that lets the whole cache be resident (the fewer cold levels, the fewer first visits pay a fill)
+      for (const double h : {0.5, 0.3, 0.2, 0.1}) {
+        if (fits()) break;
+        e->Mh = make_host_model_view(*model, e->own, h, pool);
+      }
+    }
+  }
   e->model_copy = *model;
   e->own_matransblock_start.assign(model->level_matransblock_start, model->level_matransblock_start + model->nlevels);
   e->model_copy.level_matransblock_start = e->own_matransblock_start.data();
@@ -2874,6 +2936,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
     env.tile_lo = lo + (int)b0;
     env.tile_hi = lo + (int)(b0 + ncell);
   }
+  if (h.ncold > 0) hipLaunchKernelGGL(k_ma_reset, dim3(nblocks(ncell * h.ncold)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_levelpops, dim3(nblocks(ncell * h.nlevels)), dim3(BLOCK), 0, s, env);
   if (h.ndpop > 0) hipLaunchKernelGGL(k_line_dpop, dim3(nblocks(ncell * h.nlines)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cell_scalars, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
@@ -3140,6 +3203,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     HIP_TRY(hipGetLastError());
     if (errflag != 0) {
       g_last_error = "a kernel raised error flag " + std::to_string(errflag) + " (an assert_always of the reference would have fired)";
+      if (errflag == 46) g_last_error = "a cell's pool of on-demand macro-atom records is used up (error flag 46): raise ARTIS_AMD_MA_POOLFRAC (or ARTIS_AMD_MA_HOTFRAC)";
       (void)hipMemsetAsync(e->d_err, 0, sizeof(int32_t), s);
       return ARTIS_ERR_NOTCONVERGED;
     }
@@ -3406,6 +3470,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
   if (err != 0) {
     g_last_error = "a kernel raised error flag " + std::to_string(err) + " (an assert_always of the reference would have fired)";
+    if (err == 46) g_last_error = "a cell's pool of on-demand macro-atom records is used up (error flag 46): raise ARTIS_AMD_MA_POOLFRAC (or ARTIS_AMD_MA_HOTFRAC)";
     return ARTIS_ERR_NOTCONVERGED;
   }
   return ARTIS_OK;

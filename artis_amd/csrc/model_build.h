@@ -5,6 +5,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -28,7 +29,7 @@ struct ModelOwned {
   std::vector<ContPack> cont_pack;
   std::vector<int32_t> expopac_linestart;
   std::vector<int32_t> upcum_coolslot;
-  std::vector<int32_t> level_recomb_start, recomb_lower, recomb_target, recomb_levels, ion_cooltail_start;
+  std::vector<int32_t> level_recomb_start, recomb_lower, recomb_target, recomb_levels, ion_cooltail_start, level_coolhi;
 };
 
 // X(field, element type, element count) for every array pointer of DevModel
@@ -58,6 +59,7 @@ struct ModelOwned {
   X(level_matransblock_start, int32_t, (m).nlevels)                                \
   X(level_ion, int32_t, (m).nlevels)                                               \
   X(level_pack, LevelPack, (m).nlevels)                                            \
+  X(level_coolhi, int32_t, (m).nlevels)                                            \
   X(level_upcum_start, int32_t, (m).nlevels)                                       \
   X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
@@ -160,6 +162,8 @@ struct ModelOwned {
 #define ARTIS_CACHE_ARRAYS(X, m)                                \
   X(levelpops, double, (m).nlevels)                             \
   X(macache, U4, (m).nmacache)                                  \
+  X(ma_rowtab, int32_t, (m).ncold)                              \
+  X(ma_pool_used, int32_t, ((m).ncold > 0 ? 1 : 0))             \
   X(allcont_nnlevel, double, (m).nbfcontinua)                   \
   X(allcont_departure, double, (m).nbfcontinua)                 \
   X(allcont_edgepart, double, (m).nbfcontinua)                  \
@@ -180,7 +184,14 @@ struct ModelOwned {
   X(chi_ff_nnionpart, double, 1)
 
 // Host view of the model: pointers into the caller's arrays plus the derived tables in `own`.
-inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
+// The macro-atom record tiers (tables.h "ON-DEMAND RECORDS"): ARTIS_AMD_MA_HOTFRAC = share of every ion's levels (the lowest ones) with a
+// static record in every cell's row, ARTIS_AMD_MA_POOLFRAC = the pool's slots as a share of what all cold levels' records would take.
+// Unset: hot 1 (everything static); the engine sets them itself when the whole cache does not fit one tile.
+inline void ma_tiers_from_env(double *hotfrac, double *poolfrac) {
+  if (const char *b = std::getenv("ARTIS_AMD_MA_HOTFRAC")) *hotfrac = std::min(1., std::max(0., std::atof(b)));
+  if (const char *b = std::getenv("ARTIS_AMD_MA_POOLFRAC")) *poolfrac = std::min(1., std::max(0., std::atof(b)));
+}
+inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own, double hotfrac = 1., double poolfrac = 0.25) {
   DevModel v;
   std::memset(&v, 0, sizeof(v));
   v.nelements = m.nelements; v.nions = m.nions; v.nlevels = m.nlevels; v.nlines = m.nlines; v.nalltrans = m.nalltrans;
@@ -205,12 +216,27 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   v.line_pack = own.line_pack.data();
   own.level_pack.resize(m.nlevels);
   int32_t rec = 0;  // in 16-byte slots
-  for (int i = 0; i < m.nlevels; i++) {
-    own.level_pack[i] = LevelPack{rec, m.level_alltrans_startdown[i], m.level_ndowntrans[i], m.level_nuptrans[i]};
-    const int sz = marec_slots(m.level_ndowntrans[i], m.level_nuptrans[i]);
-    rec += ((sz + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
+  int32_t ncold = 0;
+  int64_t cold_slots = 0;
+  for (int ui = 0; ui < m.nions; ui++) {
+    const int nl = m.ion_nlevels[ui];
+    const int nhot = (hotfrac >= 1.) ? nl : std::min(nl, std::max(1, (int)std::ceil(hotfrac * nl)));  // (an ion's ground level is always hot)
+    for (int l = 0; l < nl; l++) {
+      const int i = m.ion_uniquelevelindexstart[ui] + l;
+      const int sz = ((marec_slots(m.level_ndowntrans[i], m.level_nuptrans[i]) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
+      if (l < nhot) {
+        own.level_pack[i] = LevelPack{rec, m.level_alltrans_startdown[i], m.level_ndowntrans[i], m.level_nuptrans[i]};
+        rec += sz;
+      } else {
+        own.level_pack[i] = LevelPack{-(ncold++) - 1, m.level_alltrans_startdown[i], m.level_ndowntrans[i], m.level_nuptrans[i]};
+        cold_slots += sz;
+      }
+    }
   }
-  v.nmacache = rec;
+  v.ncold = ncold;
+  v.ma_pool_off = rec;
+  v.ma_pool_slots = (ncold > 0) ? (int32_t)(((int64_t)std::ceil(poolfrac * (double)cold_slots) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN : 0;
+  v.nmacache = rec + v.ma_pool_slots;
   v.level_pack = own.level_pack.data();
   // what a transition needs to know of the level it leads to (tables.h MaTarget): static, one table for all cells
   own.alltrans_target.assign((size_t)(m.nalltrans > 0 ? m.nalltrans : 1), MaTarget{0, 0, 0, 0});
@@ -260,7 +286,7 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
         own.scansegs.push_back(MaLongSeg{sa, n, i, dir});
         blk_fill += n;
         if (n > MATRANS_BLOCK) {
-          own.malongsegs.push_back(MaLongSeg{sa, n, i, dir});
+          if (lp.rec_off >= 0) own.malongsegs.push_back(MaLongSeg{sa, n, i, dir});  // (k_mafilter_long writes filters of static records only)
           own.scanblk_seg0.push_back((int32_t)own.scansegs.size());
           blk_fill = 0;
         }
@@ -331,6 +357,7 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   // list holds the running sum after its last upward transition, the entry before it (the free-free term or the previous level
   // with upward transitions; none for the first entry of an ion: the sum starts at 0) the sum before its first
   own.coollines.clear();
+  own.level_coolhi.assign((size_t)(m.nlevels > 0 ? m.nlevels : 1), -1);
   for (int e = 0; e < m.nelements; e++)
     for (int ion = 0; ion < m.elem_nions[e]; ion++) {
       const int ui = m.elem_uniqueionindexstart[e] + ion;
@@ -340,13 +367,16 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
         const int nup = m.level_nuptrans[ul];
         if (nup <= 0) continue;
         const LevelPack &lp = own.level_pack[ul];
-        const int hi = m.ion_coolingoffset[ui] + k, lo = (k > 0) ? hi - 1 : -1;
-        for (int line = 0; line < marec_lines(nup); line++)
-          own.coollines.push_back(CoolLineRef{lp.rec_off + marec_slot(MADIR_COOL, line, lp.ndown, lp.nup), own.level_upcum_start[ul],
-                                              line * MAREC_PER, nup, hi, lo});
+        const int hi = m.ion_coolingoffset[ui] + k, lo = (k > 0) ? hi - 1 : -1;  // (lo = hi - 1 unless hi is the ion's first entry)
+        own.level_coolhi[ul] = hi;
+        if (lp.rec_off >= 0)  // (a cold level's filter is written with its record, on demand: physics.h ma_fill_record)
+          for (int line = 0; line < marec_lines(nup); line++)
+            own.coollines.push_back(CoolLineRef{lp.rec_off + marec_slot(MADIR_COOL, line, lp.ndown, lp.nup), own.level_upcum_start[ul],
+                                                line * MAREC_PER, nup, hi, lo});
         k++;
       }
     }
+  v.level_coolhi = own.level_coolhi.data();
   v.ncoollines = (int32_t)own.coollines.size();
   if (own.coollines.empty()) own.coollines.push_back(CoolLineRef{0, 0, 0, 0, 0, -1});
   v.coollines = own.coollines.data();
@@ -382,7 +412,8 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own) {
   for (int ui = 0; ui < m.nions; ui++)
     for (int l = 0; l < m.ion_nlevels[ui]; l++) {
       const int ul = m.ion_uniquelevelindexstart[ui] + l;
-      if (own.level_recomb_start[ul + 1] > own.level_recomb_start[ul] && l <= m.ion_maxrecombininglevel[ui]) own.recomb_levels.push_back(ul);
+      if (own.level_recomb_start[ul + 1] > own.level_recomb_start[ul] && l <= m.ion_maxrecombininglevel[ui] && own.level_pack[ul].rec_off >= 0)
+        own.recomb_levels.push_back(ul);  // (k_macroatom_recomb: the levels with a static record; a cold level's sums are formed when it is filled)
     }
   v.nrecomblevels = (int32_t)own.recomb_levels.size();
   if (own.recomb_levels.empty()) own.recomb_levels.push_back(0);

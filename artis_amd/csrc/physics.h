@@ -231,7 +231,9 @@ struct Pkt {
 // de-excitation / of a k-packet's collisional-excitation cooling term that the records' filters could not decide; the draw is in
 // pend_arg (24 bits; bit 24 of PEND_MA_SEARCH: downward), and the slow-path kernel re-adds the sums (physics.h ma_search_exact,
 // kpkt_collexc_exact) and carries on. k_thermal hands these over so that the rate-coefficient code is not in it at all.
-enum { PEND_NONE = 0, PEND_MA_ACTION = 2, PEND_KPKT_FB = 3, PEND_MA_SEARCH = 4, PEND_MA_RADSEARCH = 5, PEND_KPKT_COLLEXC = 6 };
+// PEND_MA_FILL (round 5, tables.h "ON-DEMAND RECORDS"): the macro-atom stands in a cold level whose record does not exist in this cell yet; the
+// slow-path kernel fills it (ma_slow_fill) and the walk goes on.
+enum { PEND_NONE = 0, PEND_MA_ACTION = 2, PEND_KPKT_FB = 3, PEND_MA_SEARCH = 4, PEND_MA_RADSEARCH = 5, PEND_KPKT_COLLEXC = 6, PEND_MA_FILL = 7 };
 
 // ContinuumOpacity (rpkt.h:70); groundcont_gamma_contr lives in env.gamma_ws
 struct Chi {
@@ -1299,7 +1301,32 @@ AHD MaTransTerms matrans_terms(const Env &env, int c, int ati) {
   return r;
 }
 // where things are in a level's record (tables.h): the record of level ul in cell c, its nine process rates
-AHD U4 *ma_rec_of(const Env &env, int c, const LevelPack &lpk) { return env.K.macache + ((int64_t)c * env.M.nmacache) + lpk.rec_off; }
+// (tables.h "ON-DEMAND RECORDS") rec_off >= 0: the level's static slot in every row. rec_off < 0: a cold level, whose record -- if a packet
+// has reached the level in this cell -- lies in the cell's pool where ma_rowtab says. ma_resolve(): the slot for a WALKER (-1 unless the
+// record is complete); ma_rec_of(): the record for the code that fills or reads it knowingly (also while it is being filled).
+AHD int32_t ma_rowtab_load(const int32_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (k_tail: another wave may be filling the record right now)
+#else
+  return *p;
+#endif
+}
+AHD int ma_resolve(const Env &env, int c, int rec_off) {
+#ifdef ARTIS_BISECT_NO_ONDEMAND
+  return rec_off;
+#endif
+  if (__builtin_expect(rec_off >= 0, 1)) return rec_off;
+  const int32_t v = ma_rowtab_load(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-rec_off - 1));
+  return v >= 0 ? v : -1;
+}
+AHD U4 *ma_rec_of(const Env &env, int c, const LevelPack &lpk) {
+  int off = lpk.rec_off;
+  if (off < 0) {
+    const int32_t v = ma_rowtab_load(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-off - 1));
+    off = (v >= 0) ? v : -(v + 3);  // (ready, or being filled by the caller; never asked for a level without a record)
+  }
+  return env.K.macache + ((int64_t)c * env.M.nmacache) + off;
+}
 AHD double *ma_rates_of(U4 *rec, int nd, int nu) { return (double *)(rec + marec_rates_slot(nd, nu)); }
 AHD const double *ma_rates_of(const U4 *rec, int nd, int nu) { return (const double *)(rec + marec_rates_slot(nd, nu)); }
 AHD uint32_t mafilt_quant(double value, double whole, bool *ok);
@@ -1345,9 +1372,16 @@ AHD void populate_dirfilter_seq(const Env &env, int c, const LevelPack &lpk, int
 // one (cell, level), sequential form (test emulation; k_mafilter_long's reference): the four bound-bound rates of the record
 // (macroatom.cc:64-140), the filters of its three directions, and the level's collisional-excitation cooling terms
 // n C e_trans (kpkt.cc:108-121) into the cell's row of upward-transition terms. The GPU: k_matrans.
+// upterms == nullptr: the record alone (a cold level filled on demand; its cooling terms went into the cell's list at population).
+// ONDEMAND false: the population's pass over every level -- a cold level (no static record) contributes its cooling terms only.
+template <bool ONDEMAND = false>
 AHD void populate_level_bb(const Env &env, int c, int ul, double *upterms) {
   const DevModel &M = env.M;
   const LevelPack lpk = M.level_pack[ul];
+  if (!ONDEMAND && lpk.rec_off < 0) {
+    for (int i = 0; i < lpk.nup; i++) upterms[M.level_upcum_start[ul] + i] = matrans_terms(env, c, lpk.alltrans_startdown + lpk.ndown + i).kterm;
+    return;
+  }
   U4 *rec = ma_rec_of(env, c, lpk);
   double *rates = ma_rates_of(rec, lpk.ndown, lpk.nup);
   double s_raddeexc = 0., s_coldeexc = 0., s_down_same = 0., s_up_same = 0.;
@@ -1360,7 +1394,7 @@ AHD void populate_level_bb(const Env &env, int c, int ul, double *upterms) {
   for (int i = 0; i < lpk.nup; i++) {
     const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + lpk.ndown + i);
     s_up_same += t.v0;
-    upterms[M.level_upcum_start[ul] + i] = t.kterm;
+    if (upterms != nullptr) upterms[M.level_upcum_start[ul] + i] = t.kterm;
   }
   rates[ARTIS_MA_ACTION_RADDEEXC] = s_raddeexc;
   rates[ARTIS_MA_ACTION_COLDEEXC] = s_coldeexc;
@@ -1372,9 +1406,13 @@ AHD void populate_level_bb(const Env &env, int c, int ul, double *upterms) {
 }
 // the static part of a level's record, written once per resident row (k_mainit): every filter entry "never counted", every
 // line usable; the population then writes the entries of the transitions and the marks
+AHD void populate_mainit_at(U4 *rec, const LevelPack &lpk);
 AHD void populate_mainit(const Env &env, int64_t row, int ul) {
   const LevelPack lpk = env.M.level_pack[ul];
-  U4 *rec = env.K.macache + (row * env.M.nmacache) + lpk.rec_off;
+  if (lpk.rec_off < 0) return;  // (a cold level: initialised with the rest of its record, on demand)
+  populate_mainit_at(env.K.macache + (row * env.M.nmacache) + lpk.rec_off, lpk);
+}
+AHD void populate_mainit_at(U4 *rec, const LevelPack &lpk) {
   const int nfilt = marec_rates_slot(lpk.ndown, lpk.nup);
   const uint32_t none2 = MAFILT_NONE | (MAFILT_NONE << 16);
   for (int i = 0; i < nfilt; i++) rec[i] = U4{{none2, none2, none2, none2}};
@@ -1556,6 +1594,37 @@ AHD void populate_coolfilter_line(const Env &env, int c, int li, const double *u
   U4 f;
   for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
   env.K.macache[((int64_t)c * M.nmacache) + lr.slot] = f;
+}
+// ... all lines of ONE level's cooling filter, the running sums re-added from the level's own terms starting at the list's value before
+// the level (cooling_ion_collexc_chain()'s additions in its order: the bits the chain left in the population's scratch). For a cold level's
+// record filled on demand (the scratch is gone by then).
+AHD void populate_coolfilter_level_seq(const Env &env, int c, int ul) {
+  const DevModel &M = env.M;
+  const LevelPack lpk = M.level_pack[ul];
+  const int hi_i = M.level_coolhi[ul];
+  if (lpk.nup <= 0 || hi_i < 0) return;
+  const int ui = M.level_ion[ul];
+  const double *cool = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
+  const double hi = cool[hi_i], lo = (hi_i > M.ion_coolingoffset[ui]) ? cool[hi_i - 1] : 0.;
+  const double span = hi - lo;
+  U4 *rec = ma_rec_of(env, c, lpk);
+  double s = lo;
+  for (int l = 0; l < marec_lines(lpk.nup); l++) {
+    bool ok = (span > 0.) && (span <= DBLMAX);
+    uint32_t q[8];
+    for (int j = 0; j < 8; j++) q[j] = MAFILT_NONE;
+    for (int j = 0; j < MAREC_PER; j++) {
+      const int i = (l * MAREC_PER) + j;
+      if (i >= lpk.nup) break;
+      s += matrans_terms(env, c, lpk.alltrans_startdown + lpk.ndown + i).kterm;
+      if (i < lpk.nup - 1 && ok) q[j] = mafilt_quant(s - lo, span, &ok);
+    }
+    if (!ok)
+      for (int j = 0; j < 8; j++) q[j] = 0u;
+    U4 f;
+    for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
+    rec[marec_slot(MADIR_COOL, l, lpk.ndown, lpk.nup)] = f;
+  }
 }
 // tail: collisional ionisation and bound-free cooling (kpkt.cc:123-190), then the ion total for the prefix sum of kpkt.cc:281
 AHD void cooling_ion_tail(const Env &env, int c, int ui, double C_ion, int k) {
@@ -3479,7 +3548,7 @@ AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
 AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) {
   const int ul = ma_locate(env, p, k);
   const LevelPack lp = env.M.level_pack[ul];
-  k.rec = lp.rec_off;
+  k.rec = ma_resolve(env, k.c, lp.rec_off);  // (-1: a cold level without a record in this cell yet: ma_jump_internal() returns MA_EXIT_FILL)
   k.nd = lp.ndown;
   k.nu = lp.nup;
   k.ats = lp.alltrans_startdown;
@@ -3559,7 +3628,7 @@ AHD void ma_take_transition(const Env &env, Pkt &p, MACtx &k, bool down, int ti)
     const int tl = env.M.alltrans_tlevel16[k.ats + (down ? 0 : k.nd) + ti];
     const LevelPack lp = env.M.level_pack[k.start + tl];
     p.ma_level = tl;
-    k.rec = lp.rec_off;
+    k.rec = ma_resolve(env, k.c, lp.rec_off);
     k.ats = lp.alltrans_startdown;
     k.nd = lp.ndown;
     k.nu = lp.nup;
@@ -3568,7 +3637,7 @@ AHD void ma_take_transition(const Env &env, Pkt &p, MACtx &k, bool down, int ti)
   const MaTarget tg = env.M.alltrans_target[k.ats + (down ? 0 : k.nd) + ti];
   MA_PROF_WAIT();
   p.ma_level = tg.level;
-  k.rec = tg.rec;
+  k.rec = ma_resolve(env, k.c, tg.rec);
   k.ats = tg.ats;
   k.nd = (int)(tg.ndnu & 0xFFFFu);
   k.nu = (int)(tg.ndnu >> 16);
@@ -3578,6 +3647,9 @@ AHD void ma_take_transition(const Env &env, Pkt &p, MACtx &k, bool down, int ti)
 // the re-adding of the sums (exp() and divisions of the rate coefficients) stays out of the loop of a kernel that runs
 // at the edge of its registers, like the processes that end a walk.
 constexpr int MA_EXIT_DEFER = 98;
+// the walk stands in a cold level that has no record in this cell yet (tables.h "ON-DEMAND RECORDS"): nothing was drawn; the caller hands
+// the packet to the slow path (PEND_MA_FILL)
+constexpr int MA_EXIT_FILL = 97;
 #ifndef ARTIS_MA_SPEC_DIR
 #define ARTIS_MA_SPEC_DIR 1  // measured: k_thermal 466 -> 446 ms (the three slots are one 64-byte sector; the same idea lost in round 3, when they were three lines)
 #endif
@@ -3586,6 +3658,7 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
   // index_upperbound (sn3d.h:85) over the 9 cumulative rates: action = number of cumulative values <= zrand * total,
   // clamped to the last one. Decided on the record's 16-byte filter (tables.h "FILTERS") unless the random number lies
   // within the filter's resolution of one of its entries; then on the f64 rates, with the same random number.
+  if (__builtin_expect(k.rec < 0, 0)) return MA_EXIT_FILL;
   MA_PROF_BEGIN();
   MA_PROF_MARK(env, 63);  // (clocks between the marks themselves: the cost of one mark)
 #if defined(ARTIS_VISIT_COUNTS) && defined(__HIP_DEVICE_COMPILE__)
@@ -3734,13 +3807,65 @@ AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
   ma_prepare(env, p, k);
   const U4 *rec = ma_record(k);
   const int action = ma_jump_internal<SPLIT>(env, p, k, rec);
-  if (SPLIT && action == MA_EXIT_DEFER) {
+  if (action == MA_EXIT_FILL) {
+    p.pend = PEND_MA_FILL;
+  } else if (SPLIT && action == MA_EXIT_DEFER) {
     p.pend = PEND_MA_SEARCH;
     p.pend_arg = k.defer;
   } else if (action >= 0) {
     ma_jump_exit<SPLIT>(env, p, pi, k, rec, action);
   }
   ma_flush_stats(env, k);
+}
+
+// A cold level's record in cell c, filled at the first visit (tables.h "ON-DEMAND RECORDS"; the reference: calc_rates_if_needed
+// macroatom.cc:398-417): the sequential forms of the population, which add the same terms in the same order as its kernels (the host
+// emulation fills every record with them; artis_amd_debug_cellcache() checks the kernels' records against them).
+AHD void ma_fill_record(const Env &env, int c, int ul) {
+  const LevelPack lpk = env.M.level_pack[ul];
+  populate_mainit_at(ma_rec_of(env, c, lpk), lpk);
+  populate_level_bb<true>(env, c, ul, nullptr);
+  populate_macroatom<false>(env, c, ul);
+  populate_coolfilter_level_seq(env, c, ul);
+}
+// PEND_MA_FILL in the slow-path kernel: one lane claims the level's place in the cell's table, takes slots from the cell's pool, fills
+// the record and publishes it; any other packet that asks meanwhile just goes back to its list (the record is complete before the next
+// launch of the thermal kernel; the tail kernel's waves come here again until it is).
+AHD void ma_slow_fill(const Env &env, Pkt &p) {
+  const DevModel &M = env.M;
+  p.pend = PEND_NONE;
+  const int c = M.propcell_nonemptymgi[p.cellindex];
+  const int ul = M.ion_uniquelevelindexstart[uion(M, p.ma_element, p.ma_ion)] + p.ma_level;
+  const LevelPack lpk = M.level_pack[ul];
+  if (lpk.rec_off >= 0) return;
+  int32_t *tab = env.K.ma_rowtab + ((int64_t)c * M.ncold) + (-lpk.rec_off - 1);
+  const int nslots = ((marec_slots(lpk.ndown, lpk.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (ma_rowtab_load(tab) != -1) return;  // ready, or another lane is at it
+  const int32_t off = atomicAdd(env.K.ma_pool_used + c, nslots);
+  if (off + nslots > M.ma_pool_slots) {
+    fail(env, 46);  // the cell's pool is used up: ARTIS_AMD_MA_POOLFRAC (artis_engine.hip names the remedy)
+    p.ma_level = -1;
+    return;
+  }
+  const int32_t slot = M.ma_pool_off + off;
+  if (atomicCAS(tab, -1, -(slot + 3)) != -1) return;  // (lost the race after all: its slots stay unused)
+  ma_fill_record(env, c, ul);
+  __threadfence();
+  __hip_atomic_store(tab, slot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  if (*tab != -1) return;
+  const int32_t off = env.K.ma_pool_used[c];
+  if (off + nslots > M.ma_pool_slots) {
+    fail(env, 46);
+    p.ma_level = -1;
+    return;
+  }
+  env.K.ma_pool_used[c] = off + nslots;
+  *tab = -(M.ma_pool_off + off + 3);
+  ma_fill_record(env, c, ul);
+  *tab = M.ma_pool_off + off;
+#endif
 }
 
 // the searches k_thermal left undecided (PEND_MA_SEARCH, PEND_MA_RADSEARCH), in the slow-path kernel
@@ -4230,9 +4355,11 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     const int nsearch = nup - 1;  // the last sum is hi itself: > rnd_process
     int first = 0;                // first transition whose running sum is greater than rnd_process = the number of sums <= it
     if (nsearch > 0) {
-      const U4 *rec = ma_rec_of(env, c, lpk);
+      // (a cold level without a record in this cell: decided on the re-added sums like a draw the filter cannot decide)
+      const int rslot = ma_resolve(env, c, lpk.rec_off);
+      const U4 *rec = env.K.macache + ((int64_t)c * M.nmacache) + (rslot >= 0 ? rslot : 0);
       const double y = ((rnd_process - lo) / (hi - lo)) * MAFILT_SCALE;
-      bool amb = env.ma_filters_off != 0 || !(y >= 0. && y < MAFILT_SCALE);
+      bool amb = env.ma_filters_off != 0 || rslot < 0 || !(y >= 0. && y < MAFILT_SCALE);
       const int yi = amb ? 0 : (int)y;
       for (int b0 = 0; b0 < nsearch && !amb; b0 += MAREC_PER) {
 #if defined(ARTIS_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -5189,6 +5316,8 @@ AHD int advance_slow(const Env &env, Pkt &p, int64_t pi, FbSel *sel = nullptr) {
   } else if (p.pend == PEND_KPKT_COLLEXC) {
     kpkt_slow_collexc(env, p);
     p.chi_mgi = -1;
+  } else if (p.pend == PEND_MA_FILL) {
+    ma_slow_fill(env, p);
   }
   return classify(env, p, env.S.ts_end);
 }

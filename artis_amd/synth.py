@@ -646,6 +646,9 @@ PRESETS = {
     # the same ions with 170 levels each: 5.6e3 levels, ~1.4e5 lines -- the size at which the cell cache of a 50^3 grid no
     # longer fits one tile (profiles/r03/tiling.md)
     "w7big": ([(8, 1, 4), (14, 1, 5), (16, 1, 5), (20, 1, 4), (26, 1, 5), (27, 1, 5), (28, 1, 5)], 170, 0.3, 100),
+    # the size of the small real classic data set (CD23-like: >= 4e5 lines): 325 levels per ion, 1.07e4 levels. With a static macro-atom
+    # record for every level its cell-cache row is ~11 MB (710 GB for the 50^3 grid: four tiles); with on-demand records (tables.h) ~3.5 MB
+    "cd23like": ([(8, 1, 4), (14, 1, 5), (16, 1, 5), (20, 1, 4), (26, 1, 5), (27, 1, 5), (28, 1, 5)], 325, 0.3, 100),
 }
 
 

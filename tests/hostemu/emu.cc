@@ -36,7 +36,11 @@ struct Emu {
 
 void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_timestep *ts, artis_estimators *est, int64_t nslots) {
   std::memset(&e.env, 0, sizeof(e.env));
-  e.env.M = make_host_model_view(*m, e.own);
+  {  // macro-atom record tiers (tables.h "ON-DEMAND RECORDS"): ARTIS_AMD_MA_HOTFRAC / _POOLFRAC as in the engine (default: every level static)
+    double hot = 1., pool = 0.25;
+    ma_tiers_from_env(&hot, &pool);
+    e.env.M = make_host_model_view(*m, e.own, hot, pool);
+  }
   e.env.C = make_host_cells_view(*cs);
   e.env.S = make_step(*ts);
   if (est) {
@@ -73,6 +77,7 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   ARTIS_CACHE_ARRAYS(ALLOC, M)
 #undef ALLOC
   if (M.ndpop == 0) e.env.K.line_dpop = nullptr;
+  for (int64_t i = 0; i < ncell * (int64_t)M.ncold; i++) e.env.K.ma_rowtab[i] = -1;  // k_ma_reset: no cold level has a record yet
   e.stats.assign(ARTIS_NSTATS, 0);
   e.env.stats = e.stats.data();
   e.ws.assign((size_t)((M.nbfcontinua_ground + 1) * nslots), 0.);
@@ -128,7 +133,8 @@ void populate_all(Emu &e) {
       for (int t = 0; t < M.level_nphixstargets[ul]; t++) populate_corrphotoion(e.env, c, ul, t);
     for (int ul = 0; ul < M.nlevels; ul++) populate_mainit(e.env, c, ul);  // k_mainit (once per engine there)
     for (int ul = 0; ul < M.nlevels; ul++) populate_level_bb(e.env, c, ul, upterms.data());  // k_matrans (+ k_mafilter_long)
-    for (int ul = 0; ul < M.nlevels; ul++) populate_macroatom(e.env, c, ul);
+    for (int ul = 0; ul < M.nlevels; ul++)
+      if (M.level_pack[ul].rec_off >= 0) populate_macroatom(e.env, c, ul);  // (a cold level: when a packet reaches it, ma_slow_fill)
 #if ARTIS_EXPOPAC_TABLES
     if (e.expopac_own && e.env.C.thick[c] != ARTIS_CELL_THICK) {  // k_expopac, k_expopac_planck
       for (int b = 0; b < ARTIS_EXPOPAC_NBINS; b++) populate_expopac_bin(e.env, c, b);
@@ -319,6 +325,24 @@ int artis_emu_cellcache(const artis_model *m, const artis_cellstate *cs, const a
   const DevModel &M = e.env.M;
   const DevCache &K = e.env.K;
   std::memcpy(levelpops, K.levelpops + (int64_t)c * M.nlevels, sizeof(double) * M.nlevels);
+  if (M.ncold > 0) {
+    // on-demand records (ARTIS_AMD_MA_HOTFRAC < 1): the view shows every level, so the cold ones of this cell are filled the way a packet's
+    // first visit fills them (physics.h ma_slow_fill) -- the test then holds the on-demand form against the oracle like the population's
+    Pkt p;
+    std::memset(&p, 0, sizeof(p));
+    int cellindex = 0;
+    while (M.propcell_nonemptymgi[cellindex] != c) cellindex++;
+    p.cellindex = cellindex;
+    for (int ui = 0; ui < M.nions; ui++)
+      for (int l = 0; l < M.ion_nlevels[ui]; l++) {
+        if (M.level_pack[M.ion_uniquelevelindexstart[ui] + l].rec_off >= 0) continue;
+        p.ma_element = M.ion_element[ui];
+        p.ma_ion = ui - M.elem_uniqueionindexstart[p.ma_element];
+        p.ma_level = l;
+        p.pend = PEND_MA_FILL;
+        ma_slow_fill(e.env, p);
+      }
+  }
   for (int ul = 0; ul < M.nlevels; ul++)
     if (debug_level_record(e.env, c, ul, maprocessrates, matrans) != 0) e.err = 94;
   std::memcpy(allcont_nnlevel, K.allcont_nnlevel + (int64_t)c * M.nbfcontinua, sizeof(double) * M.nbfcontinua);

@@ -670,6 +670,41 @@ def test_walker_refill_kernel_gives_the_phase_kernels_packets(engine_mod, monkey
         parity.compare_estimators(o[1], outs[0][1], 1e-10, "k_thermal_q vs k_thermal")
 
 
+def test_on_demand_records_give_the_static_records_packets(engine_mod, monkeypatch):
+    """On-demand macro-atom records (tables.h "ON-DEMAND RECORDS"; round 5): static records for the lowest 30 % of every ion's levels,
+    the others filled in their cell's pool by the slow-path kernel when a packet first reaches them -- against the run with a static record
+    for every level, on the bench grid with the bench's atomic data: every field of every packet, the generator states and the event
+    counters identical; estimators to summation order. Also through k_thermal_q, and with a pool too small (an error, not a wrong answer)."""
+    model, cs, ts, aux = synth.build("w7", ncoord=50)
+    pk0 = synth.make_packets(model, aux, 400_000, seed_base=1281360349, kpkt_fraction=0.02)
+    outs = []
+    for cfg in ({}, {"ARTIS_AMD_MA_HOTFRAC": "0.3", "ARTIS_AMD_MA_POOLFRAC": "0.5"},
+                {"ARTIS_AMD_MA_HOTFRAC": "0.1", "ARTIS_AMD_MA_POOLFRAC": "0.5", "ARTIS_AMD_REFILL": "1"}):
+        for k in ("ARTIS_AMD_MA_HOTFRAC", "ARTIS_AMD_MA_POOLFRAC", "ARTIS_AMD_REFILL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in cfg.items():
+            monkeypatch.setenv(k, v)
+        eng = engine_mod.Engine(model)
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, "classic")
+        eng.update_packets(p, e)
+        outs.append((p, e, eng.cache_tiles()[2]))
+        eng.close()
+    assert outs[1][2] < 0.8 * outs[0][2] and outs[2][2] < outs[1][2]  # bytes per cell of the cache row
+    for o in outs[1:]:
+        parity.compare_packets(o[0], outs[0][0], 0.0, "on-demand records vs static records")
+        parity.compare_stats(o[1], outs[0][1], "on-demand records vs static records")
+        parity.compare_estimators(o[1], outs[0][1], 1e-10, "on-demand records vs static records")
+    monkeypatch.setenv("ARTIS_AMD_MA_HOTFRAC", "0.1")
+    monkeypatch.setenv("ARTIS_AMD_MA_POOLFRAC", "0.001")
+    monkeypatch.delenv("ARTIS_AMD_REFILL", raising=False)
+    eng = engine_mod.Engine(model)
+    eng.set_cellstate(cs, ts)
+    with pytest.raises(Exception, match="pool"):
+        eng.update_packets(pk0.copy(), abi.estimators_for(model, "classic"))
+    eng.close()
+
+
 def test_budget_independence_on_device(engine_mod, monkeypatch):
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
     pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.3)

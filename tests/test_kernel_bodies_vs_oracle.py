@@ -610,3 +610,39 @@ def test_macroatom_filters_decide_what_the_f64_comparison_decides():
     assert L.artis_emu_mafilter_selftest(n, 12345, C.byref(namb)) == 0
     # ambiguous: the planted quarter, plus ~8 entries x 2 of 32768 values of zi for the rest
     assert 0.25 * n <= namb.value < 0.3 * n, namb.value
+
+
+@pytest.mark.parametrize("options,preset,ncoord,gridtype,npk", [
+    ("classic", "w7", 5, abi.GRID_CARTESIAN3D, 600),
+    ("classic", "small", 8, abi.GRID_CYLINDRICAL2D, 2500),
+    ("kilonova_lte", "small", 16, abi.GRID_SPHERICAL1D, 1500),
+    ("nltenebular", "small", 6, abi.GRID_CARTESIAN3D, 1500),
+    ("ci_classic_vpkt", "small", 6, abi.GRID_CARTESIAN3D, 1500),
+])
+def test_on_demand_macroatom_records_bit_exact(oracle, monkeypatch, options, preset, ncoord, gridtype, npk):
+    """Round 5 (tables.h "ON-DEMAND RECORDS"; the reference: calc_rates_if_needed macroatom.cc:398-417): static macro-atom records for the
+    lowest third of every ion's levels only, a cold level's record filled in its cell's pool when a packet first reaches it there (the
+    slow path's ma_slow_fill with the sequential forms of the population), the k-packet step deciding on the re-added sums where a cold
+    level has no record yet. Bit-exact against the oracle, also with every decision on the f64 sums; and test_cellcache_bit_exact's view of a
+    cell -- every cold record filled the on-demand way -- holds against the oracle's stored arrays."""
+    monkeypatch.setenv("ARTIS_AMD_MA_HOTFRAC", "0.3")
+    monkeypatch.setenv("ARTIS_AMD_MA_POOLFRAC", "1")
+    model, cs, ts, aux = synth.build(preset, ncoord=ncoord, gridtype=gridtype, options=options, **({"t_days": 5.0} if "vpkt" in options else {}))
+    pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=0.3)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, "on-demand records vs oracle")
+    parity.compare_stats(eb, ea, "on-demand records vs oracle")
+    assert ea.stats[abi.STAT_X_MA_JUMPS] > 10 * npk
+    monkeypatch.setenv("ARTIS_EMU_MAFILTERS", "0")
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, "on-demand records, f64 decisions vs oracle")
+    if options == "classic" and preset == "small":
+        monkeypatch.delenv("ARTIS_EMU_MAFILTERS")
+        c = int(model["npts_nonempty"]) // 2
+        got, want = emu.cellcache(model, cs, ts, c), oracle.cellcache(model, cs, ts, c)
+        for k in ("maprocessrates", "matrans"):
+            assert np.array_equal(got[k], want[k]), k
+        # a pool that cannot hold the cold records the packets reach is an error, never a wrong answer
+        monkeypatch.setenv("ARTIS_AMD_MA_POOLFRAC", "0.02")
+        with pytest.raises(RuntimeError, match="46"):
+            _run_both(oracle, model, cs, ts, pk0, 3, options=options)

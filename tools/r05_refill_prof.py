@@ -21,6 +21,8 @@ for refill in ("0", "1"):
         print(f"k_thermal_q: {bd['thermal_ms']:.1f} ms in {bd['thermal_launches']} launches; transitions {tr:.4g}; wave-rounds {s[46]:.4g}; lanes per round {s[45] / max(s[46], 1):.1f}; "
               f"service passes {s[47]:.4g}, slots per pass {s[44] / max(s[47], 1):.1f}; wave clocks: service {16 * s[42]:.4g} ({s[42] / (s[42] + s[43]):.2f}), walk {16 * s[43]:.4g}; "
               f"clocks per wave-round {16 * s[43] / max(s[46], 1):.0f}, per service pass {16 * s[42] / max(s[47], 1):.0f}")
+        names = {59: "pull + hot line + context", 60: "the process that ended the walk", 61: "k-packet step", 62: "prepare + store + context", 63: "classify + append + stacks"}
+        print("             service pass by part (clocks per pass): " + ", ".join(f"{n} {16 * s[k] / max(s[47], 1):.0f}" for k, n in names.items()))
     else:
         tot = s[42] + s[43] + s[44] + s[45]
         print(f"k_thermal:   {bd['thermal_ms']:.1f} ms in {bd['thermal_launches']} launches; transitions {tr:.4g}; wave-rounds {s[46]:.4g}; lanes per round {tr / max(s[46], 1):.1f}; "
