@@ -448,18 +448,17 @@ __global__ void __launch_bounds__(BLOCK) k_mafilter_long(Env env) {
 __global__ void __launch_bounds__(BLOCK) k_debug_macache(Env env, int c, double *maprocessrates, double *matrans, int32_t *bad) {
   const int ul = blockIdx.x * BLOCK + threadIdx.x;
   if (ul >= env.M.nlevels) return;
-  if (ma_resolve(env, c, env.M.level_pack[ul].rec_off) < 0) return;  // (a cold level no packet has reached in this cell: no record)
+  if (ma_resolve(env, c, env.M.level_pack[ul].rec_off) == MA_REC_NONE) return;  // (a cold level no packet has reached in this cell: no record)
   const int b = debug_level_record(env, c, ul, maprocessrates, matrans);
   if (b != 0) atomicAdd(bad, b);
 }
-// before a fill: no cold level of the cells to be filled has a record, their pools are empty (tables.h "ON-DEMAND RECORDS")
+// before a fill: no cold level of the cells to be filled has a record (tables.h "ON-DEMAND RECORDS"; the pool itself is emptied by populate_tile())
 __global__ void __launch_bounds__(BLOCK) k_ma_reset(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const int ncold = env.M.ncold;
   if (i >= fill_count(env) * ncold) return;
   const int c = fill_cell(env, i / ncold);
   env.K.ma_rowtab[((int64_t)c * ncold) + (i % ncold)] = -1;
-  if (i % ncold == 0) env.K.ma_pool_used[c] = 0;
 }
 // the static part of every record of every resident row, once per engine: filter entries "never counted", lines usable
 __global__ void __launch_bounds__(BLOCK) k_mainit(Env env, int64_t nrows) {
@@ -680,13 +679,15 @@ struct Lists {
                               // fused thermal kernel
   int32_t nubins;             // frequency bins of the r-packet list's keys (1 = sort by cell only)
   int32_t mabins;             // sub-keys of the thermal list's keys (1 = sort by cell only)
+  int32_t numajor;            // (tuning, ARTIS_AMD_SORT_NUMAJOR=1) > 0 = the grid's cell count: r-packet keys with the frequency bin as the MAJOR part
 };
 // ma_sub: (tuning, ARTIS_AMD_MABINS=16) a sub-key 0..15 of a thermal-list entry below its cell, -1: none
 __device__ inline void append_by_kind(int kind, int32_t pi, int32_t cellindex, double nu_cmf, const Lists &L, int ma_sub = -1) {
   const int slot = (kind == NEXT_KPKT) ? L.kpkt_slot : kind;
   int32_t key = list_sort_key(cellindex, nu_cmf, (slot == NEXT_RPKT) ? L.nubins : 1);
+  if (slot == NEXT_RPKT && L.numajor > 0 && L.nubins > 1) key = ((key % SORT_NUBINS) * L.numajor) + (key / SORT_NUBINS);
   if (slot == NEXT_MA && L.mabins > 1)
-    key = (cellindex * SORT_NUBINS) + ((kind == NEXT_KPKT || ma_sub < 0) ? SORT_NUBINS - 1 : (ma_sub & (SORT_NUBINS - 1)));
+    key = (cellindex * SORT_MABINS) + ((kind == NEXT_KPKT || ma_sub < 0) ? SORT_MABINS - 1 : (ma_sub & (SORT_MABINS - 1)));
 #pragma unroll
   for (int k = 1; k < NEXT_NKINDS; k++) {
     int32_t *dst = (k == L.self_kind) ? L.self_list : L.lst[k];
@@ -1020,6 +1021,9 @@ __device__ inline void cellest_flush(const Env &env, int kind, double *global_ar
 // cell-sorted work list does not give: a wave's 64 packets sit in ~21 cells (2.6 lanes per cell) and
 // anywhere in the spectrum. Measured slower than the continuum table in LDS: profiles/r04/line_window.md.
 constexpr int LINE_LDS_MAX = 14336;  // lines (112 KB)
+#ifndef ARTIS_RPKT_SPLIT_ABSORB
+#define ARTIS_RPKT_SPLIT_ABSORB 0  // (1: measured round 5: k_rpkt 265 -> 258 ms, k_slow 16 -> 32 ms, step unchanged, scratch unchanged: off) free-free / bound-free absorptions of r-packets carried out by the slow-path kernel (physics.h PEND_RPKT_ABSORB)
+#endif
 template <bool CONT_LDS, int TB, bool LINE_LDS = false>
 __global__ void __launch_bounds__(TB, ARTIS_RPKT_WGS) k_rpkt(Env env, const int32_t *list, int32_t n, Lists next,
                                                                    unsigned long long *gstats, int budget, int32_t *cursors, int nchunks,
@@ -1089,7 +1093,7 @@ __global__ void __launch_bounds__(TB, ARTIS_RPKT_WGS) k_rpkt(Env env, const int3
     if (have) {
       bool go = rpkt_can_continue(p, ts_end);
       if (go) {
-        go = rpkt_iter(env, p, pi, x);
+        go = rpkt_iter<ARTIS_RPKT_SPLIT_ABSORB != 0>(env, p, pi, x);
         steps++;
       }
       if (!go || steps >= budget || (drained && steps >= drain_budget)) {
@@ -1299,7 +1303,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
 constexpr int MA_LDS_LEVELS = 2048;   // 32 KB
 constexpr int MA_LDS_TRANS = 32768;   // 64 KB
 constexpr int MA_LDS_LEVELS2 = 6144;  // 96 KB
-template <int TB, int TABLES_LDS>
+template <int TB, int TABLES_LDS, bool COLD = false>
 __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                      unsigned long long *gstats, int budget, int32_t *cursors,
                                                                      int nchunks, int chunk_mode, int drain_budget) {
@@ -1366,13 +1370,13 @@ __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_the
       int j = 0;
       int exit_action = -1;
       const U4 *rec = nullptr;
-      if (ma_pending(p) && p.pend == PEND_NONE) ma_prepare(env, p, k);  // the record of the current level; the walk carries it on
+      if (ma_pending(p) && p.pend == PEND_NONE) ma_prepare<COLD>(env, p, k);  // the record of the current level; the walk carries it on
       while (j < ARTIS_MA_PHASE && exit_action < 0 && ma_pending(p) && p.pend == PEND_NONE) {  // [census: transition loop]
 #ifdef ARTIS_PROFILE
         if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) ARTIS_STAT(env, 46);
 #endif
-        rec = ma_record(k);
-        exit_action = ma_jump_internal<ARTIS_MA_DEFER_EXACT != 0>(env, p, k, rec);
+        rec = ma_record<COLD>(env, k);
+        exit_action = ma_jump_internal<ARTIS_MA_DEFER_EXACT != 0, COLD>(env, p, k, rec);
         j++;
       }
       ma_flush_stats(env, k);
@@ -1471,7 +1475,7 @@ struct TQWave {  // SoA: a lane reads field[its slot]
   uint8_t ready[TQ_V];    // stack of the slots whose walk can go on
   uint8_t service[TQ_V];  // stack of the slots that wait for the service pass
 };
-template <int TB>
+template <int TB, bool COLD = false>
 __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats, int budget,
                                                      int32_t *cursors, int nchunks, int drain_budget, int low_water) {
   // dynamic LDS: [TQWave x waves | LevelPack x nlevels | uint16 x nalltrans (padded to words)]
@@ -1566,7 +1570,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
           k.start = lv >> 16;
           k.start_key = (p.ma_element << 8) | p.ma_ion;
           const LevelPack lp = env.M.level_pack[k.start + p.ma_level];
-          k.rec = ma_resolve(env, k.c, lp.rec_off); k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
+          k.rec = ma_resolve<COLD>(env, k.c, lp.rec_off); k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
           const int cnt = Q.cnt[s];
           units = cnt & 0xFFFF;
           k.njumps = cnt >> 16;
@@ -1588,7 +1592,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
         bool go = thermal_can_continue(p, ts_end);
         if (isdone) {
           ma_flush_stats(env, k);
-          const U4 *rec = ma_record(k);
+          const U4 *rec = ma_record<COLD>(env, k);
           if (act == MA_EXIT_FILL) {
             p.pend = PEND_MA_FILL;
           } else if (act == MA_EXIT_DEFER) {
@@ -1613,7 +1617,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
         }
         TQ_SUB(61);
         walking = go && units < budget_now && ma_pending(p) && p.pend == PEND_NONE;
-        if (walking) ma_prepare(env, p, k);  // (only k.start is kept: the walk phase reads the level's record shape from LDS)
+        if (walking) ma_prepare<COLD>(env, p, k);  // (only k.start is kept: the walk phase reads the level's record shape from LDS)
         pkt_store_thermal(env.P, pi, p);  // the hot line; the flight line only if an r-packet was emitted
         if (walking) {
           Q.s0[s] = p.s0; Q.s1[s] = p.s1; Q.s2[s] = p.s2; Q.s3[s] = p.s3;
@@ -1679,7 +1683,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
               k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
               k.start = lv >> 16;
               const LevelPack lp = env.M.level_pack[k.start + w.ma_level];
-              k.rec = ma_resolve(env, k.c, lp.rec_off); k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
+              k.rec = ma_resolve<COLD>(env, k.c, lp.rec_off); k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
               const int cnt = Q.cnt[s];
               units = cnt & 0xFFFF;
               k.njumps = cnt >> 16;
@@ -1698,7 +1702,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
           prof_rounds++;
 #endif
           if (go) {
-            const int action = ma_jump_internal<true>(env, w, k, k.cellma + k.rec);
+            const int action = ma_jump_internal<true, COLD>(env, w, k, ma_record<COLD>(env, k));
             units++;
             if (action >= 0 || units >= budget_now) {
               ended = true;
@@ -2098,6 +2102,11 @@ struct artis_amd_engine {
   int64_t drain_min_list = 1000000;
   bool sort_lists = true;
   bool sort_nu = true;
+  // The r-packet list sorted by (frequency bin, cell) instead of (cell, frequency bin) (round 5; ARTIS_AMD_SORT_NUMAJOR=0: rounds 2-4): the
+  // 64 packets a wave holds then lie in one of 32 frequency bins (four per octave) -- their opacity sums run over windows of similar length
+  // and their line walks through the same stretch of the line list -- and in ~7 neighbouring cells of it. k_rpkt 263 -> 251 ms with 16 bins,
+  // 244 with 32, 245 with 64, 250 with 128 (MI355X, headline workload; profiles/r05/sort_numajor.txt).
+  bool sort_numajor = true;
   bool sort_ma = true;
   // lists with more entries per cell of the tile than this are not sorted (sort_by_key) unless the kernel accumulates its
   // per-cell estimators in LDS; measured crossover of the thermal lists with 1e7 packets: between 20^3 and 30^3 cells
@@ -2105,7 +2114,7 @@ struct artis_amd_engine {
   // 512 < cells <= 3072: k_rpkt keeps J / nuJ / ffheating in LDS instead of the continuum table (12^3 grid, 912 cells:
   // k_rpkt 292 -> 215 ms; 14^3, 1472 cells: 249 -> 225 ms). ARTIS_AMD_RPKT_EST_OVER_CONT=0: the table wins the LDS.
   bool rpkt_est_over_cont = true;
-  int ma_bins = SORT_NUBINS;    // the thermal list sorted by (cell, a hash of the macro-atom's ion) instead of by cell alone: the lanes of a wave
+  int ma_bins = SORT_MABINS;    // the thermal list sorted by (cell, a hash of the macro-atom's ion) instead of by cell alone: the lanes of a wave
                                 // start in the records of one or two ions (ARTIS_AMD_MABINS=1: by cell; step 1060 -> ~1050 ms)
   bool ma_filters = true;       // macro-atom transitions decided on the records' 15-bit filters (ARTIS_AMD_MAFILTERS=0: on the f64 values)
   int dense_lpr = 32;           // k_bfest_dense: lanes per record (64 = a wave per record; ARTIS_AMD_DENSE_LPR)
@@ -2166,6 +2175,10 @@ Env make_env(const artis_amd_engine *e) {
     ARTIS_CACHE_ARRAYS(BIAS, h)
 #undef BIAS
     if (h.ndpop == 0) env.K.line_dpop = nullptr;  // formed on the fly (physics.h line_dpop_at)
+    // the pool of on-demand records is one for all resident cells (tables.h "ON-DEMAND RECORDS"): not indexed by cell
+    env.K.ma_pool = e->K.ma_pool;
+    env.K.ma_pool_used = e->K.ma_pool_used;
+    env.ma_pool_cap = (uint32_t)std::min<int64_t>(((int64_t)e->tile_cells * h.ma_pool_slots) / MAREC_ALIGN, 0x7FFFFFF0LL);
   }
   env.tile_lo = e->tile_lo;
   env.tile_hi = e->tile_hi;
@@ -2738,7 +2751,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (ARTIS_OPT_VPKT_ON) e->tail_max = 0;  // (see the estimator block: the event queue is sized per split launch)
   if (const char *b = std::getenv("ARTIS_AMD_RPKT_EST_OVER_CONT")) e->rpkt_est_over_cont = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_DENSE_CONTLDS")) e->dense_cont_lds = std::atoi(b) != 0;
-  if (const char *b = std::getenv("ARTIS_AMD_MABINS")) e->ma_bins = (std::atoi(b) > 1) ? SORT_NUBINS : 1;
+  if (const char *b = std::getenv("ARTIS_AMD_MABINS")) e->ma_bins = (std::atoi(b) > 1) ? SORT_MABINS : 1;
   if (const char *b = std::getenv("ARTIS_AMD_MAFILTERS")) e->ma_filters = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_DENSE_LPR")) e->dense_lpr = (std::atoi(b) == 64) ? 64 : (std::atoi(b) == 16 ? 16 : 32);
   if (const char *b = std::getenv("ARTIS_AMD_CELLEST_LDS")) e->cellest_in_lds = std::atoi(b) != 0;
@@ -2752,6 +2765,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_TILE_ZIGZAG")) e->tile_zigzag = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_MATABLES_LDS")) e->ma_tables_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_REFILL")) e->thermal_refill = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_SORT_NUMAJOR")) e->sort_numajor = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TQ_LOW")) e->tq_low = std::max(1, std::min(64, std::atoi(b)));
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_FILL")) e->sparse_fill = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_MAX")) e->sparse_max_listed = std::max(0, std::atoi(b));
@@ -2923,6 +2937,8 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
   }
   const int64_t ncell_fill = nfill >= 0 ? nfill : hi - lo;
   if (ncell_fill <= 0) return ARTIS_OK;
+  // (whatever the pool of on-demand records held belonged to cells whose rows are not valid after this fill)
+  if (h.ncold > 0) HIP_TRY(hipMemsetAsync(e->K.ma_pool_used, 0, sizeof(uint32_t), s));
   // in batches of pop_batch cells (the scratch of cooling terms holds that many rows); the kernels of a batch see it as
   // their whole fill: a sub-range of the tile, or a stretch of the list of a sparse fill
   const Env env_tile = env;
@@ -3192,6 +3208,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     L.self_count = e->d_count + NEXT_NKINDS;  // one alternate counter: only one kernel runs at a time
     L.kpkt_slot = NEXT_MA;  // k-packets travel in the thermal list
     L.nubins = r_nubins;
+    L.numajor = e->sort_numajor ? e->Mh.ngrid : 0;
     L.mabins = e->ma_bins;
     return L;
   };
@@ -3395,26 +3412,40 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
           const int bud_t = (e->budget_t_small > 0 && nk < e->small_list) ? std::min(e->budget_t_small, e->budget_t) : e->budget_t;
           const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : bud_t;
           const size_t tq_bytes = tq_lds_bytes(TQ_TB, e->Mh.nlevels, e->Mh.nalltrans);
+          const bool cold = e->Mh.ncold > 0;  // (kernels built with the on-demand records' look-ups only where the model has cold levels)
+          // the COLD = false / true instantiation of a thermal kernel (K<A, B, COLD>)
+#define LAUNCH_T2(K, A, B, GRID, TBS, LDSB, ...)                                                                   \
+  do {                                                                                                             \
+    if (cold)                                                                                                      \
+      hipLaunchKernelGGL((K<A, B, true>), dim3(GRID), dim3(TBS), LDSB, s, __VA_ARGS__);                            \
+    else                                                                                                           \
+      hipLaunchKernelGGL((K<A, B, false>), dim3(GRID), dim3(TBS), LDSB, s, __VA_ARGS__);                           \
+  } while (0)
           if (e->thermal_refill && ARTIS_THERMAL_SPLIT_EXACT && env.cellest_n_t == 0 && tq_bytes <= 160 * 1024 - 1024 && nk >= 4096 && e->Mh.nlevels < 32768) {
             static bool attr_set = false;
             if (!attr_set) {
-              HIP_TRY(hipFuncSetAttribute((const void *)k_thermal_q<TQ_TB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+              HIP_TRY(hipFuncSetAttribute((const void *)k_thermal_q<TQ_TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+              HIP_TRY(hipFuncSetAttribute((const void *)k_thermal_q<TQ_TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
               attr_set = true;
             }
             const int grid1 = (int)std::min<int64_t>(((int64_t)nk + TQ_TB - 1) / TQ_TB, (int64_t)e->ncu);
-            hipLaunchKernelGGL((k_thermal_q<TQ_TB>), dim3(grid1), dim3(TQ_TB), tq_bytes, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
-                               e->wave_chunks_t ? chunks_for(nk, grid1 * (TQ_TB / 64)) : 8, drain, e->tq_low);
+            if (cold)
+              hipLaunchKernelGGL((k_thermal_q<TQ_TB, true>), dim3(grid1), dim3(TQ_TB), tq_bytes, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
+                                 e->wave_chunks_t ? chunks_for(nk, grid1 * (TQ_TB / 64)) : 8, drain, e->tq_low);
+            else
+              hipLaunchKernelGGL((k_thermal_q<TQ_TB, false>), dim3(grid1), dim3(TQ_TB), tq_bytes, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
+                                 e->wave_chunks_t ? chunks_for(nk, grid1 * (TQ_TB / 64)) : 8, drain, e->tq_low);
           } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS && e->Mh.nalltrans <= MA_LDS_TRANS && nk >= 4096) {
             const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
-            hipLaunchKernelGGL((k_thermal<1024, 1>), dim3(grid1), dim3(1024), 0, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
-                               e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
+            LAUNCH_T2(k_thermal, 1024, 1, grid1, 1024, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
           } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS2 && nk >= 4096) {
             const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
-            hipLaunchKernelGGL((k_thermal<1024, 2>), dim3(grid1), dim3(1024), 0, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
-                               e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
-          } else
-          hipLaunchKernelGGL((k_thermal<ARTIS_THERMAL_TB, 0>), dim3(grid), dim3(ARTIS_THERMAL_TB), 0, s, env, lst, nk, next, e->d_stats, bud_t,
-                             e->d_cursors, per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (ARTIS_THERMAL_TB / 64)) : 8), per_cu ? 2 : 0, drain);
+            LAUNCH_T2(k_thermal, 1024, 2, grid1, 1024, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
+          } else {
+            LAUNCH_T2(k_thermal, ARTIS_THERMAL_TB, 0, grid, ARTIS_THERMAL_TB, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
+                      per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (ARTIS_THERMAL_TB / 64)) : 8), per_cu ? 2 : 0, drain);
+          }
+#undef LAUNCH_T2
         }
       } else if (kind == NEXT_BB) {
         hipLaunchKernelGGL(k_blackbody, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);

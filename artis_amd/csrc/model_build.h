@@ -163,7 +163,8 @@ struct ModelOwned {
   X(levelpops, double, (m).nlevels)                             \
   X(macache, U4, (m).nmacache)                                  \
   X(ma_rowtab, int32_t, (m).ncold)                              \
-  X(ma_pool_used, int32_t, ((m).ncold > 0 ? 1 : 0))             \
+  X(ma_pool, U4, (m).ma_pool_slots)                             \
+  X(ma_pool_used, uint32_t, ((m).ncold > 0 ? 1 : 0))            \
   X(allcont_nnlevel, double, (m).nbfcontinua)                   \
   X(allcont_departure, double, (m).nbfcontinua)                 \
   X(allcont_edgepart, double, (m).nbfcontinua)                  \
@@ -185,7 +186,8 @@ struct ModelOwned {
 
 // Host view of the model: pointers into the caller's arrays plus the derived tables in `own`.
 // The macro-atom record tiers (tables.h "ON-DEMAND RECORDS"): ARTIS_AMD_MA_HOTFRAC = share of every ion's levels (the lowest ones) with a
-// static record in every cell's row, ARTIS_AMD_MA_POOLFRAC = the pool's slots as a share of what all cold levels' records would take.
+// static record in every cell's row, ARTIS_AMD_MA_POOLFRAC = the pool (shared by the resident cells) as a share of what the cold levels'
+// records of all of them would take.
 // Unset: hot 1 (everything static); the engine sets them itself when the whole cache does not fit one tile.
 inline void ma_tiers_from_env(double *hotfrac, double *poolfrac) {
   if (const char *b = std::getenv("ARTIS_AMD_MA_HOTFRAC")) *hotfrac = std::min(1., std::max(0., std::atof(b)));
@@ -234,9 +236,8 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own, doub
     }
   }
   v.ncold = ncold;
-  v.ma_pool_off = rec;
   v.ma_pool_slots = (ncold > 0) ? (int32_t)(((int64_t)std::ceil(poolfrac * (double)cold_slots) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN : 0;
-  v.nmacache = rec + v.ma_pool_slots;
+  v.nmacache = rec;
   v.level_pack = own.level_pack.data();
   // what a transition needs to know of the level it leads to (tables.h MaTarget): static, one table for all cells
   own.alltrans_target.assign((size_t)(m.nalltrans > 0 ? m.nalltrans : 1), MaTarget{0, 0, 0, 0});

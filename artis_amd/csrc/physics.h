@@ -201,6 +201,7 @@ struct Env {
   VpktSeed *vpkt_queue;
   int32_t *vpkt_count;
   int32_t vpkt_cap;
+  uint32_t ma_pool_cap;  // units of 64 bytes in DevCache::ma_pool (tables.h "ON-DEMAND RECORDS")
 #ifdef ARTIS_VISIT_COUNTS
   // (measurement build, tools/visit_sparsity.py) [cell][level] macro-atom transitions drawn in that level's record this call
   uint32_t *visit_counts;
@@ -231,9 +232,12 @@ struct Pkt {
 // de-excitation / of a k-packet's collisional-excitation cooling term that the records' filters could not decide; the draw is in
 // pend_arg (24 bits; bit 24 of PEND_MA_SEARCH: downward), and the slow-path kernel re-adds the sums (physics.h ma_search_exact,
 // kpkt_collexc_exact) and carries on. k_thermal hands these over so that the rate-coefficient code is not in it at all.
+// PEND_RPKT_ABSORB (round 5): a continuum event of an r-packet that is not an electron scattering -- a free-free or bound-free absorption,
+// 5e-4 of the r-packet steps -- with the event's draw in pend_arg; the slow-path kernel carries it out (rpkt_slow_absorption), so that the
+// r-packet kernel holds no second copy of the opacity sum (the selection of the absorbing continuum, rpkt.cc:455-470).
 // PEND_MA_FILL (round 5, tables.h "ON-DEMAND RECORDS"): the macro-atom stands in a cold level whose record does not exist in this cell yet; the
 // slow-path kernel fills it (ma_slow_fill) and the walk goes on.
-enum { PEND_NONE = 0, PEND_MA_ACTION = 2, PEND_KPKT_FB = 3, PEND_MA_SEARCH = 4, PEND_MA_RADSEARCH = 5, PEND_KPKT_COLLEXC = 6, PEND_MA_FILL = 7 };
+enum { PEND_NONE = 0, PEND_MA_ACTION = 2, PEND_KPKT_FB = 3, PEND_MA_SEARCH = 4, PEND_MA_RADSEARCH = 5, PEND_KPKT_COLLEXC = 6, PEND_MA_FILL = 7, PEND_RPKT_ABSORB = 8 };
 
 // ContinuumOpacity (rpkt.h:70); groundcont_gamma_contr lives in env.gamma_ws
 struct Chi {
@@ -1311,21 +1315,20 @@ AHD int32_t ma_rowtab_load(const int32_t *p) {
   return *p;
 #endif
 }
+// MACtx::rec: >= 0 the record's slot in the cell's row; MA_REC_NONE a cold level that has no record in its cell yet; <= -2 a cold level's
+// record in the pool, at unit -(rec + 2). COLD = false (a kernel built for models without cold levels, the default): rec_off as it is.
+constexpr int MA_REC_NONE = -1;
+template <bool COLD = true>
 AHD int ma_resolve(const Env &env, int c, int rec_off) {
-#ifdef ARTIS_BISECT_NO_ONDEMAND
-  return rec_off;
-#endif
+  if (!COLD) return rec_off;
   if (__builtin_expect(rec_off >= 0, 1)) return rec_off;
   const int32_t v = ma_rowtab_load(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-rec_off - 1));
-  return v >= 0 ? v : -1;
+  return v >= 0 ? -(v + 2) : MA_REC_NONE;
 }
 AHD U4 *ma_rec_of(const Env &env, int c, const LevelPack &lpk) {
-  int off = lpk.rec_off;
-  if (off < 0) {
-    const int32_t v = ma_rowtab_load(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-off - 1));
-    off = (v >= 0) ? v : -(v + 3);  // (ready, or being filled by the caller; never asked for a level without a record)
-  }
-  return env.K.macache + ((int64_t)c * env.M.nmacache) + off;
+  if (lpk.rec_off >= 0) return env.K.macache + ((int64_t)c * env.M.nmacache) + lpk.rec_off;
+  const int32_t v = ma_rowtab_load(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-lpk.rec_off - 1));
+  return env.K.ma_pool + ((int64_t)((v >= 0) ? v : -(v + 3)) * MAREC_ALIGN);  // (ready, or being filled by the caller; never asked for a level without a record)
 }
 AHD double *ma_rates_of(U4 *rec, int nd, int nu) { return (double *)(rec + marec_rates_slot(nd, nu)); }
 AHD const double *ma_rates_of(const U4 *rec, int nd, int nu) { return (const double *)(rec + marec_rates_slot(nd, nu)); }
@@ -3458,7 +3461,7 @@ struct MACtx {
   bool thick;               // the cell is optically thick (grey): its k-packets go to do_kpkt_blackbody()
   const U4 *cellma;         // the cell's row of macro-atom records
   int start_key, start;     // cached get_ionuniquelevelindexstart(element, ion)
-  int rec;                  // slot of the current level's record in the cell's row (ma_prepare, then carried by the walk)
+  int rec;                  // the current level's record (ma_prepare, then carried by the walk): its slot in the cell's row, or -- a cold level -- its place in the pool / MA_REC_NONE (ma_resolve)
   int nd, nu;               // ... its numbers of downward / upward transitions (where the record's lines are)
   int ats;                  // ... and its first entry in alltrans (where its transitions' targets are)
   int njumps;               // transitions made since the last ma_flush_stats()
@@ -3545,15 +3548,20 @@ AHD int ma_locate(const Env &env, const Pkt &p, MACtx &k) {
   }
   return k.start + p.ma_level;
 }
+template <bool COLD = true>
 AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) {
   const int ul = ma_locate(env, p, k);
   const LevelPack lp = env.M.level_pack[ul];
-  k.rec = ma_resolve(env, k.c, lp.rec_off);  // (-1: a cold level without a record in this cell yet: ma_jump_internal() returns MA_EXIT_FILL)
+  k.rec = ma_resolve<COLD>(env, k.c, lp.rec_off);  // (MA_REC_NONE: a cold level without a record in this cell yet: ma_jump_internal() returns MA_EXIT_FILL)
   k.nd = lp.ndown;
   k.nu = lp.nup;
   k.ats = lp.alltrans_startdown;
 }
-AHD const U4 *ma_record(const MACtx &k) { return k.cellma + k.rec; }
+template <bool COLD = true>
+AHD const U4 *ma_record(const Env &env, const MACtx &k) {
+  if (COLD && k.rec < 0) return env.K.ma_pool + ((int64_t)(-(k.rec + 2)) * MAREC_ALIGN);  // (MA_REC_NONE: never read, ma_jump_internal() returns first)
+  return k.cellma + k.rec;
+}
 // First half of a transition: draw the process (macroatom.cc:425-431); an internal transition inside the ion is made
 // at once and -1 is returned. Every other process ends the walk in this kernel (deactivation, or a bound-free process
 // for the slow path): its index is returned, and ma_jump_exit() carries it out. The split lets a kernel keep the rare,
@@ -3621,6 +3629,7 @@ AHD int ma_search_dir(const Env &env, const MACtx &k, const U4 *rec, int dir, ui
   return ti;
 }
 // the internal transition to the ti-th downward / upward transition's level: the walk goes on in that level's record
+template <bool COLD = true>
 AHD void ma_take_transition(const Env &env, Pkt &p, MACtx &k, bool down, int ti) {
   if (env.ma_tables_in_lds) {
     // the same information from two small static tables that the kernel has copied into LDS (k_thermal<.., true>): the
@@ -3628,7 +3637,7 @@ AHD void ma_take_transition(const Env &env, Pkt &p, MACtx &k, bool down, int ti)
     const int tl = env.M.alltrans_tlevel16[k.ats + (down ? 0 : k.nd) + ti];
     const LevelPack lp = env.M.level_pack[k.start + tl];
     p.ma_level = tl;
-    k.rec = ma_resolve(env, k.c, lp.rec_off);
+    k.rec = ma_resolve<COLD>(env, k.c, lp.rec_off);
     k.ats = lp.alltrans_startdown;
     k.nd = lp.ndown;
     k.nu = lp.nup;
@@ -3637,7 +3646,7 @@ AHD void ma_take_transition(const Env &env, Pkt &p, MACtx &k, bool down, int ti)
   const MaTarget tg = env.M.alltrans_target[k.ats + (down ? 0 : k.nd) + ti];
   MA_PROF_WAIT();
   p.ma_level = tg.level;
-  k.rec = ma_resolve(env, k.c, tg.rec);
+  k.rec = ma_resolve<COLD>(env, k.c, tg.rec);
   k.ats = tg.ats;
   k.nd = (int)(tg.ndnu & 0xFFFFu);
   k.nu = (int)(tg.ndnu >> 16);
@@ -3653,12 +3662,12 @@ constexpr int MA_EXIT_FILL = 97;
 #ifndef ARTIS_MA_SPEC_DIR
 #define ARTIS_MA_SPEC_DIR 1  // measured: k_thermal 466 -> 446 ms (the three slots are one 64-byte sector; the same idea lost in round 3, when they were three lines)
 #endif
-template <bool DEFER = false>
+template <bool DEFER = false, bool COLD = true>
 AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
   // index_upperbound (sn3d.h:85) over the 9 cumulative rates: action = number of cumulative values <= zrand * total,
   // clamped to the last one. Decided on the record's 16-byte filter (tables.h "FILTERS") unless the random number lies
   // within the filter's resolution of one of its entries; then on the f64 rates, with the same random number.
-  if (__builtin_expect(k.rec < 0, 0)) return MA_EXIT_FILL;
+  if (COLD && __builtin_expect(k.rec == MA_REC_NONE, 0)) return MA_EXIT_FILL;
   MA_PROF_BEGIN();
   MA_PROF_MARK(env, 63);  // (clocks between the marks themselves: the cost of one mark)
 #if defined(ARTIS_VISIT_COUNTS) && defined(__HIP_DEVICE_COMPILE__)
@@ -3728,7 +3737,7 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
       ti = ma_search_exact(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2);
     }
     MA_PROF_MARK(env, 61);
-    ma_take_transition(env, p, k, down, ti);
+    ma_take_transition<COLD>(env, p, k, down, ti);
     MA_PROF_MARK(env, 62);
     return -1;
   }
@@ -3805,7 +3814,7 @@ AHD void ma_flush_stats(const Env &env, MACtx &k) {
 template <bool SPLIT = false>
 AHD void ma_jump(const Env &env, Pkt &p, int64_t pi, MACtx &k) {
   ma_prepare(env, p, k);
-  const U4 *rec = ma_record(k);
+  const U4 *rec = ma_record(env, k);
   const int action = ma_jump_internal<SPLIT>(env, p, k, rec);
   if (action == MA_EXIT_FILL) {
     p.pend = PEND_MA_FILL;
@@ -3840,31 +3849,33 @@ AHD void ma_slow_fill(const Env &env, Pkt &p) {
   if (lpk.rec_off >= 0) return;
   int32_t *tab = env.K.ma_rowtab + ((int64_t)c * M.ncold) + (-lpk.rec_off - 1);
   const int nslots = ((marec_slots(lpk.ndown, lpk.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
+  const uint32_t nunits = (uint32_t)(nslots / MAREC_ALIGN);
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ma_rowtab_load(tab) != -1) return;  // ready, or another lane is at it
-  const int32_t off = atomicAdd(env.K.ma_pool_used + c, nslots);
-  if (off + nslots > M.ma_pool_slots) {
-    fail(env, 46);  // the cell's pool is used up: ARTIS_AMD_MA_POOLFRAC (artis_engine.hip names the remedy)
+  if (atomicCAS(tab, -1, -2) != -1) return;  // claimed: exactly one lane goes on
+  const uint32_t unit = atomicAdd(env.K.ma_pool_used, nunits);
+  if (unit + nunits > env.ma_pool_cap) {
+    __hip_atomic_store(tab, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fail(env, 46);  // the pool is used up: ARTIS_AMD_MA_POOLFRAC (artis_engine.hip names the remedy)
     p.ma_level = -1;
     return;
   }
-  const int32_t slot = M.ma_pool_off + off;
-  if (atomicCAS(tab, -1, -(slot + 3)) != -1) return;  // (lost the race after all: its slots stay unused)
+  __hip_atomic_store(tab, -((int32_t)unit + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (where ma_rec_of() finds it while it is filled)
   ma_fill_record(env, c, ul);
   __threadfence();
-  __hip_atomic_store(tab, slot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(tab, (int32_t)unit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #else
   if (*tab != -1) return;
-  const int32_t off = env.K.ma_pool_used[c];
-  if (off + nslots > M.ma_pool_slots) {
+  const uint32_t unit = *env.K.ma_pool_used;
+  if (unit + nunits > env.ma_pool_cap) {
     fail(env, 46);
     p.ma_level = -1;
     return;
   }
-  env.K.ma_pool_used[c] = off + nslots;
-  *tab = -(M.ma_pool_off + off + 3);
+  *env.K.ma_pool_used = unit + nunits;
+  *tab = -((int32_t)unit + 3);
   ma_fill_record(env, c, ul);
-  *tab = M.ma_pool_off + off;
+  *tab = (int32_t)unit;
 #endif
 }
 
@@ -3872,7 +3883,7 @@ AHD void ma_slow_fill(const Env &env, Pkt &p) {
 AHD void ma_slow_search(const Env &env, Pkt &p, int64_t pi) {
   MACtx k = ma_ctx(env, p);
   ma_prepare(env, p, k);
-  const U4 *rec = ma_record(k);
+  const U4 *rec = ma_record(env, k);
   const uint32_t u = (uint32_t)p.pend_arg & 0xFFFFFFu;
   if (p.pend == PEND_MA_SEARCH) {
     const bool down = ((uint32_t)p.pend_arg & 0x1000000u) != 0;
@@ -3997,7 +4008,9 @@ AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi, FbSel *sel = nullptr
 }
 
 // rpkt_event_continuum rpkt.cc:422
-AHD void rpkt_event_continuum(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) {
+// SPLIT: an absorption is left to the slow-path kernel (PEND_RPKT_ABSORB; U24 >= 0: that kernel, with the event's draw handed in)
+template <bool SPLIT = false>
+AHD void rpkt_event_continuum(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot, int32_t U24 = -1) {
   const DevModel &M = env.M;
   const double nu = p.nu_cmf;
   const double dop = doppler(p);
@@ -4005,7 +4018,13 @@ AHD void rpkt_event_continuum(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_
   const double chi_es = x.chi_escatter * dop;
   const double chi_ff = x.chi_freefree_heat * dop;
   const double chi_bf = x.chi_boundfree * dop;
-  const double chi_rnd = rng_uniform(p) * chi_cont;
+  const uint32_t u_event = (U24 >= 0) ? (uint32_t)U24 : rng_u24(p);
+  const double chi_rnd = rng_u24_value(u_event) * chi_cont;  // (= rng_uniform(p) * chi_cont)
+  if (SPLIT && !(chi_rnd < chi_es)) {
+    p.pend = PEND_RPKT_ABSORB;
+    p.pend_arg = (int32_t)u_event;
+    return;
+  }
   if (chi_rnd < chi_es) {
     p.nscatterings++;
     ARTIS_STAT(env, ARTIS_STAT_ELECTRON_SCATTERINGS);
@@ -4087,6 +4106,7 @@ AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double d
 }
 
 // do_rpkt_step rpkt.cc:542
+template <bool SPLIT = false>
 AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) {
   const DevModel &M = env.M;
   const double t2 = env.S.ts_end;
@@ -4149,7 +4169,7 @@ AHD bool do_rpkt_step(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_t slot) 
       ARTIS_STAT(env, ARTIS_STAT_ELECTRON_SCATTERINGS);
       emit_rpkt(env, p, pi);
     } else if (!is_bb) {
-      rpkt_event_continuum(env, p, pi, x, slot);
+      rpkt_event_continuum<SPLIT>(env, p, pi, x, slot);
     } else {
 #if !ARTIS_OPT_RPKT_BB_THERMALISATION
       ARTIS_STAT(env, ARTIS_STAT_MA_ACTIVATION_BB);
@@ -4357,9 +4377,9 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     if (nsearch > 0) {
       // (a cold level without a record in this cell: decided on the re-added sums like a draw the filter cannot decide)
       const int rslot = ma_resolve(env, c, lpk.rec_off);
-      const U4 *rec = env.K.macache + ((int64_t)c * M.nmacache) + (rslot >= 0 ? rslot : 0);
+      const U4 *rec = (rslot >= 0) ? env.K.macache + ((int64_t)c * M.nmacache) + rslot : env.K.ma_pool + ((int64_t)(rslot < -1 ? -(rslot + 2) : 0) * MAREC_ALIGN);
       const double y = ((rnd_process - lo) / (hi - lo)) * MAFILT_SCALE;
-      bool amb = env.ma_filters_off != 0 || rslot < 0 || !(y >= 0. && y < MAFILT_SCALE);
+      bool amb = env.ma_filters_off != 0 || rslot == MA_REC_NONE || !(y >= 0. && y < MAFILT_SCALE);
       const int yi = amb ? 0 : (int)y;
       for (int b0 = 0; b0 < nsearch && !amb; b0 += MAREC_PER) {
 #if defined(ARTIS_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -5136,14 +5156,21 @@ AHD void pkt_store_thermal(const PktStore &P, int64_t i, Pkt &p) {
 // r-packet, so it gets a small kernel of its own instead of widening the thermal kernel's register footprint.
 enum { NEXT_DONE = 0, NEXT_RPKT = 1, NEXT_MA = 2, NEXT_SLOW = 3, NEXT_KPKT = 4, NEXT_GAMMA = 5, NEXT_BB = 6, NEXT_NKINDS = 7 };
 // Sort key of a work-list entry: the packet's propagation cell and, for r-packets, a coarse comoving-frequency bin
-// (two per octave over 2^46 .. 2^54 Hz = 7e13 .. 1.8e16 Hz, bluest first, like the reference's own packet order
+// (four per octave over 2^46 .. 2^54 Hz = 7e13 .. 1.8e16 Hz, bluest first, like the reference's own packet order
 // compare_packet_order update_packets.cc:363). Read off the exponent and top mantissa bit: placement only, never results.
-constexpr int SORT_NUBINS = 16;
+#ifndef ARTIS_SORT_NUBINS
+#define ARTIS_SORT_NUBINS 32  // frequency bins of an r-packet's sort key: 8 octaves x 2, 4, 8, 16 per octave = 16, 32, 64, 128 (round 5: 32, with the bin as the key's major part)
+#endif
+constexpr int SORT_NUBINS = ARTIS_SORT_NUBINS;
+constexpr int SORT_NU_LOG2PEROCTAVE = (SORT_NUBINS == 16) ? 1 : ((SORT_NUBINS == 32) ? 2 : ((SORT_NUBINS == 64) ? 3 : ((SORT_NUBINS == 128) ? 4 : -1)));
+static_assert(SORT_NU_LOG2PEROCTAVE > 0, "ARTIS_SORT_NUBINS: 16, 32, 64 or 128");
+constexpr int SORT_MABINS = 16;  // sub-keys of a thermal-list entry below its cell
 AHD int32_t list_sort_key(int32_t cellindex, double nu_cmf, int nbins) {
   if (nbins <= 1) return cellindex;
   union { double d; uint64_t u; } v;
   v.d = nu_cmf;
-  const int e2 = (int)((v.u >> 51) & 0xFFF) - (2 * (1023 + 46));  // 2 * (exponent - 46) + top mantissa bit
+  constexpr int m = SORT_NU_LOG2PEROCTAVE;
+  const int e2 = (int)((v.u >> (52 - m)) & ((1u << (11 + m)) - 1u)) - ((1023 + 46) << m);  // 2^m * (exponent - 46) + the top m mantissa bits
   const int b = (nu_cmf > 0.) ? (e2 < 0 ? 0 : (e2 > SORT_NUBINS - 1 ? SORT_NUBINS - 1 : e2)) : 0;
   return (cellindex * SORT_NUBINS) + (SORT_NUBINS - 1 - b);
 }
@@ -5173,8 +5200,9 @@ AHD int classify(const Env &env, const Pkt &p, double ts_end) {
 AHD bool rpkt_can_continue(const Pkt &p, double ts_end) {
   return !ma_pending(p) && p.pend == PEND_NONE && p.type == ARTIS_TYPE_RPKT && p.prop_time < ts_end;
 }
+template <bool SPLIT = false>
 AHD bool rpkt_iter(const Env &env, Pkt &p, int64_t pi, Chi &x) {
-  const bool cont = do_rpkt_step(env, p, pi, x, pi);
+  const bool cont = do_rpkt_step<SPLIT>(env, p, pi, x, pi);
   if (!ma_pending(p) && !cont) x.nonemptymgi = -1;
   return rpkt_can_continue(p, env.S.ts_end) && in_tile(env, p.cellindex);  // a new cell may belong to another tile
 }
@@ -5299,6 +5327,18 @@ AHD int advance_gamma(const Env &env, Pkt &p, int64_t pi, int budget) {
 }
 
 // slow-path kernel body: the one deferred action of the packet
+// PEND_RPKT_ABSORB in the slow-path kernel: the free-free / bound-free branch of rpkt_event_continuum() with the draw the r-packet kernel
+// made, then what do_rpkt_step() and rpkt_iter() do after the event
+AHD void rpkt_slow_absorption(const Env &env, Pkt &p, int64_t pi) {
+  Chi x;
+  chi_load(env.P, pi, p, x);
+  const int32_t u = p.pend_arg;
+  p.pend = PEND_NONE;
+  p.pend_arg = 0;
+  rpkt_event_continuum<false>(env, p, pi, x, pi, u);
+  if (!ma_pending(p) && p.type != ARTIS_TYPE_RPKT) x.nonemptymgi = -1;
+  chi_store(env.P, pi, p, x);
+}
 // the slow-path actions that end in select_continuum_nu(): a free-bound emission of a k-packet, a radiative recombination of a macro-atom
 AHD bool slow_selects_continuum_nu(const Pkt &p) {
   return p.pend == PEND_KPKT_FB || (p.pend == PEND_MA_ACTION && p.pend_arg == ARTIS_MA_ACTION_RADRECOMB);
@@ -5318,6 +5358,8 @@ AHD int advance_slow(const Env &env, Pkt &p, int64_t pi, FbSel *sel = nullptr) {
     p.chi_mgi = -1;
   } else if (p.pend == PEND_MA_FILL) {
     ma_slow_fill(env, p);
+  } else if (p.pend == PEND_RPKT_ABSORB) {
+    rpkt_slow_absorption(env, p, pi);
   }
   return classify(env, p, env.S.ts_end);
 }

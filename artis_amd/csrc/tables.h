@@ -130,12 +130,12 @@ struct DevModel {
   int32_t nmacache;    // 16-byte slots per cell in DevCache::macache
   // ON-DEMAND RECORDS (round 5; the reference fills a level's rates when a packet first reaches it, macroatom.cc:398-417). A step visits
   // 13-15 % of the (cell, level) records (profiles/r05/visit_sparsity_*.md), and 98-99 % of its transitions are drawn in the lowest third of
-  // every ion's levels. With ncold > 0 a cell's row holds static records for those HOT levels only (LevelPack::rec_off >= 0) and a POOL of
-  // ma_pool_slots slots from slot ma_pool_off on; a COLD level (rec_off = -(cold index) - 1) gets a record in its cell's pool when a packet
-  // first reaches it there -- the slow-path kernel fills it with the sequential forms of the population (the same terms added in the same
-  // order: the same bits) -- and DevCache::ma_rowtab[cell][cold index] says where it is. ncold == 0: every level has a static record (the
-  // default whenever the whole cache fits one tile).
-  int32_t ncold, ma_pool_off, ma_pool_slots;
+  // every ion's levels. With ncold > 0 a cell's row holds static records for those HOT levels only (LevelPack::rec_off >= 0); a COLD level
+  // (rec_off = -(cold index) - 1) gets a record in the POOL -- one for all resident cells: DevCache::ma_pool, ma_pool_slots slots per resident
+  // cell on average, handed out in units of 64 bytes -- when a packet first reaches it in a cell: the slow-path kernel fills it with the
+  // sequential forms of the population (the same terms added in the same order: the same bits), and DevCache::ma_rowtab[cell][cold index]
+  // says where it is. ncold == 0: every level has a static record (the default whenever the whole cache fits one tile).
+  int32_t ncold, ma_pool_slots;
   // [nlevels] the entry of the cooling list that holds the running sum after the level's collisional excitations (-1: no upward transitions)
   const int32_t *level_coolhi;
   int32_t nupcum;      // upward transitions (= nlines): doubles per cell of the population's scratch of cooling terms (Env::collexc_terms)
@@ -267,9 +267,11 @@ struct DevCells {
 struct DevCache {
   double *levelpops;             // [cell][nlevels]
   U4 *macache;                   // [cell][nmacache]: one record of filters + process rates per level (above; LevelPack::rec_off)
-  // [cell][ncold] where a cold level's record is in the cell's row (slots): -1 none yet, <= -3 being filled at slot -(v + 3), >= 0 ready;
-  // [cell] slots of the cell's pool handed out
-  int32_t *ma_rowtab, *ma_pool_used;
+  // [cell][ncold] where a cold level's record is in the pool (64-byte units): -1 none yet, <= -3 being filled at unit -(v + 3), >= 0 ready;
+  // the pool ([resident cells x ma_pool_slots] slots, shared by all of them: NOT biased by the tile's first cell) and the units handed out
+  int32_t *ma_rowtab;
+  U4 *ma_pool;
+  uint32_t *ma_pool_used;
   double *allcont_nnlevel;       // [cell][nbfcontinua]
   double *allcont_departure;     // [cell][nbfcontinua]
   double *allcont_edgepart;      // [cell][nbfcontinua]
