@@ -444,6 +444,165 @@ __global__ void __launch_bounds__(BLOCK) k_mafilter_long(Env env) {
     cb = __shfl(sb, last);
   }
 }
+// ---- A cold level's record filled by a WAVE (tables.h "ON-DEMAND RECORDS"; physics.h ma_fill_record is the sequential form, which one lane of
+// the slow-path kernel ran in the first version: 585 ms of a 6.5 s step with the w7big data, most of the 3.3 s of k_slow with cd23like). The
+// transitions' terms -- the expensive part: rate coefficients with exp() and divisions -- are evaluated by 63 lanes side by side; the running
+// sums are formed in the sequential loop's order (lane j ends with carry + t_0 + ... + t_j, added left to right); each lane quantises its own
+// entry, a filter line's "usable" mark is a vote of its lanes (as in k_mafilter_long); lane 0 writes the rates and runs the bound-free part
+// and the action filter (populate_macroatom). Same terms, same additions in the same order: the same bits (GPU test: the records a run
+// left in the pool against populate_dirfilter_seq, artis_amd_debug_cellcache()).
+__device__ inline double wave_prefix_inorder(double t, double carry, int n, int lane) {
+  double acc = carry;
+  for (int k = 0; k < n; k++) {
+    const double x = wave_bcast(t, k);
+    if (lane >= k) acc += x;
+  }
+  return acc;
+}
+// the entries of one block (lanes 0..62 = transitions base .. base + 62 of a direction of n) into the record: internal filter from s_int,
+// radiative filter (downward only) from s_rad
+__device__ inline void wave_put_dirfilters(U4 *rec, const LevelPack &lpk, bool down, int n, int ti, bool valid, double s_int, double s_rad,
+                                           double whole_int, double whole_rad, int lane) {
+  bool ok_int = (whole_int > 0.) && (whole_int <= DBLMAX), ok_rad = (whole_rad > 0.) && (whole_rad <= DBLMAX);
+  uint32_t q_int = MAFILT_NONE, q_rad = MAFILT_NONE;
+  if (valid && ti < n - 1) {
+    if (ok_int) q_int = mafilt_quant(s_int, whole_int, &ok_int);
+    if (ok_rad && down) q_rad = mafilt_quant(s_rad, whole_rad, &ok_rad);
+  }
+  const unsigned long long bad_int = __ballot(valid && !ok_int), bad_rad = __ballot(valid && down && !ok_rad);
+  if (valid) {
+    const unsigned long long mine = line_lanes(lane, ti, n);
+    const bool lok_int = (bad_int & mine) == 0ull, lok_rad = (bad_rad & mine) == 0ull;
+    U4 *line = rec + marec_slot(down ? MADIR_DOWN : MADIR_UP, ti / MAREC_PER, lpk.ndown, lpk.nup);
+    mafilt_put(line, ti % MAREC_PER, lok_int ? q_int : 0u);
+    if (ti % MAREC_PER == 0) mafilt_put(line, 7, lok_int ? MAFILT_NONE : 0u);
+    if (down) {
+      U4 *rline = rec + marec_slot(MADIR_RAD, ti / MAREC_PER, lpk.ndown, lpk.nup);
+      mafilt_put(rline, ti % MAREC_PER, lok_rad ? q_rad : 0u);
+      if (ti % MAREC_PER == 0) mafilt_put(rline, 7, lok_rad ? MAFILT_NONE : 0u);
+    }
+  }
+}
+__device__ inline void ma_fill_record_wave(const Env &env, int c, int ul) {
+  const DevModel &M = env.M;
+  const int lane = (int)(threadIdx.x & 63);
+  const LevelPack lpk = M.level_pack[ul];
+  U4 *rec = ma_rec_of(env, c, lpk);
+  const int nd = lpk.ndown, nu = lpk.nup;
+  {  // populate_mainit_at(): every filter entry "never counted", the rates zero
+    const int nfilt = marec_rates_slot(nd, nu);
+    const int ntot = ((marec_slots(nd, nu) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
+    const uint32_t none2 = MAFILT_NONE | (MAFILT_NONE << 16);
+    for (int i = lane; i < ntot; i += 64) rec[i] = (i < nfilt) ? U4{{none2, none2, none2, none2}} : U4{{0u, 0u, 0u, 0u}};
+  }
+  __threadfence_block();  // (other lanes write into these slots below)
+  // ---- downward: rates (radiative, collisional de-excitation, internal down), then the internal-down and radiative filters
+  double w_rad = 0., w_col = 0., w_down = 0.;
+  double b0_rad = 0., b0_down = 0.;  // block 0's running sums, kept for a direction of one block (no second evaluation of its terms)
+  for (int base = 0; base < nd; base += 63) {
+    const int nb = (nd - base < 63) ? nd - base : 63;
+    const bool valid = lane < nb;
+    double v0 = 0., v1 = 0., v2 = 0.;
+    if (valid) {
+      const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + base + lane);
+      v0 = t.v0; v1 = t.v1; v2 = t.v2;
+    }
+    const double s0 = wave_prefix_inorder(v0, w_rad, nb, lane), s1 = wave_prefix_inorder(v1, w_col, nb, lane), s2 = wave_prefix_inorder(v2, w_down, nb, lane);
+    if (base == 0) { b0_rad = s0; b0_down = s2; }
+    w_rad = wave_bcast(s0, nb - 1);
+    w_col = wave_bcast(s1, nb - 1);
+    w_down = wave_bcast(s2, nb - 1);
+  }
+  if (nd > 0 && nd <= 63) {
+    wave_put_dirfilters(rec, lpk, true, nd, lane, lane < nd, b0_down, b0_rad, w_down, w_rad, lane);
+  } else {
+    double c_rad = 0., c_down = 0.;
+    for (int base = 0; base < nd; base += 63) {
+      const int nb = (nd - base < 63) ? nd - base : 63;
+      const bool valid = lane < nb;
+      double v0 = 0., v2 = 0.;
+      if (valid) {
+        const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + base + lane);
+        v0 = t.v0; v2 = t.v2;
+      }
+      const double s0 = wave_prefix_inorder(v0, c_rad, nb, lane), s2 = wave_prefix_inorder(v2, c_down, nb, lane);
+      wave_put_dirfilters(rec, lpk, true, nd, base + lane, valid, s2, s0, w_down, w_rad, lane);
+      c_rad = wave_bcast(s0, nb - 1);
+      c_down = wave_bcast(s2, nb - 1);
+    }
+  }
+  // ---- upward: the internal-up rate and filter, and the level's collisional-excitation cooling filter (running sums from the
+  // cooling list's value before the level; populate_coolfilter_level_seq)
+  const int hi_i = M.level_coolhi[ul];
+  const double *cool = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
+  const double c_hi = (nu > 0 && hi_i >= 0) ? cool[hi_i] : 0.;
+  const double c_lo = (nu > 0 && hi_i > M.ion_coolingoffset[M.level_ion[ul]]) ? cool[hi_i - 1] : 0.;
+  const double span = c_hi - c_lo;
+  double w_up = 0.;
+  double b0_up = 0., b0_kt = 0.;
+  for (int base = 0; base < nu; base += 63) {
+    const int nb = (nu - base < 63) ? nu - base : 63;
+    double v0 = 0., kt = 0.;
+    if (lane < nb) {
+      const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + nd + base + lane);
+      v0 = t.v0; kt = t.kterm;
+    }
+    const double s0 = wave_prefix_inorder(v0, w_up, nb, lane);
+    if (base == 0) { b0_up = s0; b0_kt = kt; }
+    w_up = wave_bcast(s0, nb - 1);
+  }
+  {
+    double c_up = 0., c_cool = c_lo;
+    for (int base = 0; base < nu; base += 63) {
+      const int nb = (nu - base < 63) ? nu - base : 63;
+      const bool valid = lane < nb;
+      const int ti = base + lane;
+      double v0 = 0., kt = b0_kt;
+      if (valid && nu > 63) {  // (a direction of one block keeps its terms from the pass above)
+        const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + nd + base + lane);
+        v0 = t.v0; kt = t.kterm;
+      }
+      const double s0 = (nu <= 63) ? b0_up : wave_prefix_inorder(v0, c_up, nb, lane);
+      wave_put_dirfilters(rec, lpk, false, nu, ti, valid, s0, 0., w_up, 0., lane);
+      c_up = wave_bcast(s0, nb - 1);
+      if (hi_i >= 0) {
+        const double sk = wave_prefix_inorder(kt, c_cool, nb, lane);
+        bool ok = (span > 0.) && (span <= DBLMAX);
+        uint32_t q = MAFILT_NONE;
+        if (valid && ti < nu - 1 && ok) q = mafilt_quant(sk - c_lo, span, &ok);
+        const unsigned long long bad = __ballot(valid && !ok);
+        if (valid) {
+          const bool lok = (bad & line_lanes(lane, ti, nu)) == 0ull;
+          U4 *line = rec + marec_slot(MADIR_COOL, ti / MAREC_PER, nd, nu);
+          if (lok) {
+            mafilt_put(line, ti % MAREC_PER, q);
+          } else if (ti % MAREC_PER == 0) {
+            *line = U4{{0u, 0u, 0u, 0u}};  // (populate_coolfilter_line: a line that is not usable is all zero, its mark too)
+          }
+        }
+        c_cool = wave_bcast(sk, nb - 1);
+      }
+    }
+  }
+  __threadfence_block();
+  if (lane == 0) {
+    double *rates = ma_rates_of(rec, nd, nu);
+    rates[ARTIS_MA_ACTION_RADDEEXC] = w_rad;
+    rates[ARTIS_MA_ACTION_COLDEEXC] = w_col;
+    rates[ARTIS_MA_ACTION_INTERNALDOWNSAME] = w_down;
+    rates[ARTIS_MA_ACTION_INTERNALUPSAME] = w_up;
+    populate_macroatom<false>(env, c, ul);  // the bound-free channels and the action filter
+  }
+}
+// every lane of the wave whose packet waits for a record it has claimed (physics.h ma_slow_fill_claim) gets it filled, lane by lane
+__device__ inline void ma_fill_wave(const Env &env, bool mine, int c, int ul) {
+  unsigned long long m = __ballot(mine);
+  while (m != 0) {
+    const int src = __ffsll((long long)m) - 1;
+    ma_fill_record_wave(env, __builtin_amdgcn_readlane(c, src), __builtin_amdgcn_readlane(ul, src));
+    m &= m - 1;
+  }
+}
 // test / debug view of one cell's records (artis_amd_debug_cellcache): a thread per level
 __global__ void __launch_bounds__(BLOCK) k_debug_macache(Env env, int c, double *maprocessrates, double *matrans, int32_t *bad) {
   const int ul = blockIdx.x * BLOCK + threadIdx.x;
@@ -1813,6 +1972,15 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
         (void)advance_slow(env, t, pi, &sel);
       }
       fbsel_wave(env, sel);
+#endif
+      {
+        int fc = 0, ful = 0;
+        int32_t funit = 0;
+        const bool fill = owner && p.pend == PEND_MA_FILL && ma_slow_fill_claim(env, p, &fc, &ful, &funit);
+        ma_fill_wave(env, fill, fc, ful);
+        if (fill) ma_slow_fill_publish(env, fc, ful, funit);
+      }
+#if ARTIS_SLOW_WAVE_FB
       if (owner) (void)advance_slow(env, p, pi, sel.valid ? &sel : nullptr);
 #else
       if (owner) (void)advance_slow(env, p, pi);
@@ -1884,6 +2052,13 @@ __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, in
 #if ARTIS_SLOW_WAVE_FB
   fbsel_wave(env, sel);
 #endif
+  {  // a cold level's record (PEND_MA_FILL): claimed by the lane, filled by the wave, published by the lane
+    int fc = 0, ful = 0;
+    int32_t funit = 0;
+    const bool fill = mine && p.pend == PEND_MA_FILL && ma_slow_fill_claim(env, p, &fc, &ful, &funit);
+    ma_fill_wave(env, fill, fc, ful);
+    if (fill) ma_slow_fill_publish(env, fc, ful, funit);
+  }
   if (mine) {
     kind = advance_slow(env, p, pi, sel.valid ? &sel : nullptr);
     pkt_store(env.P, pi, p);

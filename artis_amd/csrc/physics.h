@@ -3879,6 +3879,40 @@ AHD void ma_slow_fill(const Env &env, Pkt &p) {
 #endif
 }
 
+#if defined(__HIPCC__) && !defined(ARTIS_HOST_EMU)
+// ma_slow_fill() in three parts for the kernels that let the WAVE fill the record (artis_engine.hip ma_fill_record_wave): the lane claims the
+// level's place and takes units of the pool (true: this lane's record is to be filled at *unit; the packet's pend is cleared either way),
+// the wave fills, the lane publishes.
+__device__ inline bool ma_slow_fill_claim(const Env &env, Pkt &p, int *c_out, int *ul_out, int32_t *unit_out) {
+  const DevModel &M = env.M;
+  p.pend = PEND_NONE;
+  const int c = M.propcell_nonemptymgi[p.cellindex];
+  const int ul = M.ion_uniquelevelindexstart[uion(M, p.ma_element, p.ma_ion)] + p.ma_level;
+  const LevelPack lpk = M.level_pack[ul];
+  if (lpk.rec_off >= 0) return false;
+  int32_t *tab = env.K.ma_rowtab + ((int64_t)c * M.ncold) + (-lpk.rec_off - 1);
+  if (ma_rowtab_load(tab) != -1) return false;
+  if (atomicCAS(tab, -1, -2) != -1) return false;
+  const uint32_t nunits = (uint32_t)((marec_slots(lpk.ndown, lpk.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN);
+  const uint32_t unit = atomicAdd(env.K.ma_pool_used, nunits);
+  if (unit + nunits > env.ma_pool_cap) {
+    __hip_atomic_store(tab, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fail(env, 46);
+    p.ma_level = -1;
+    return false;
+  }
+  __hip_atomic_store(tab, -((int32_t)unit + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *c_out = c;
+  *ul_out = ul;
+  *unit_out = (int32_t)unit;
+  return true;
+}
+__device__ inline void ma_slow_fill_publish(const Env &env, int c, int ul, int32_t unit) {
+  __threadfence();
+  __hip_atomic_store(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-env.M.level_pack[ul].rec_off - 1), unit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 // the searches k_thermal left undecided (PEND_MA_SEARCH, PEND_MA_RADSEARCH), in the slow-path kernel
 AHD void ma_slow_search(const Env &env, Pkt &p, int64_t pi) {
   MACtx k = ma_ctx(env, p);

@@ -689,6 +689,14 @@ def test_on_demand_records_give_the_static_records_packets(engine_mod, monkeypat
         p, e = pk0.copy(), abi.estimators_for(model, "classic")
         eng.update_packets(p, e)
         outs.append((p, e, eng.cache_tiles()[2]))
+        if cfg:
+            # the records the run left in the pool (filled by waves of the slow-path kernel, ma_fill_record_wave) against the sequential
+            # form: artis_amd_debug_cellcache() fails if any filter entry or mark of any record of the cell differs from populate_dirfilter_seq()
+            nfilled = 0
+            for c in (0, 777, 20000, 33000, 65000):
+                d = eng.debug_cellcache(c)
+                nfilled += int(np.count_nonzero(d["maprocessrates"].reshape(-1, 9).sum(axis=1) > 0))
+            assert nfilled > 100  # (records with rates: the static ones and the cold ones packets reached in these cells)
         eng.close()
     assert outs[1][2] < 0.85 * outs[0][2] and outs[2][2] < outs[1][2]  # bytes per cell of the cache row
     for o in outs[1:]:
