@@ -3837,46 +3837,69 @@ AHD void ma_fill_record(const Env &env, int c, int ul) {
   populate_macroatom<false>(env, c, ul);
   populate_coolfilter_level_seq(env, c, ul);
 }
-// PEND_MA_FILL in the slow-path kernel: one lane claims the level's place in the cell's table, takes slots from the cell's pool, fills
-// the record and publishes it; any other packet that asks meanwhile just goes back to its list (the record is complete before the next
-// launch of the thermal kernel; the tail kernel's waves come here again until it is).
-AHD void ma_slow_fill(const Env &env, Pkt &p) {
+// The record of cold level ul in cell c exists (true), or another lane is filling it right now (false: ask again). A level without one gets it
+// here: the lane claims the level's place in the cell's table, takes units of the pool, fills the record with the sequential forms and
+// publishes it. (The pool used up: error flag 46, *failed.)
+AHD bool ma_ensure_record(const Env &env, int c, int ul, bool *failed) {
   const DevModel &M = env.M;
-  p.pend = PEND_NONE;
-  const int c = M.propcell_nonemptymgi[p.cellindex];
-  const int ul = M.ion_uniquelevelindexstart[uion(M, p.ma_element, p.ma_ion)] + p.ma_level;
   const LevelPack lpk = M.level_pack[ul];
-  if (lpk.rec_off >= 0) return;
+  if (lpk.rec_off >= 0) return true;
   int32_t *tab = env.K.ma_rowtab + ((int64_t)c * M.ncold) + (-lpk.rec_off - 1);
-  const int nslots = ((marec_slots(lpk.ndown, lpk.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
-  const uint32_t nunits = (uint32_t)(nslots / MAREC_ALIGN);
+  const uint32_t nunits = (uint32_t)((marec_slots(lpk.ndown, lpk.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN);
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (ma_rowtab_load(tab) != -1) return;  // ready, or another lane is at it
-  if (atomicCAS(tab, -1, -2) != -1) return;  // claimed: exactly one lane goes on
+  const int32_t v = ma_rowtab_load(tab);
+  if (v >= 0) return true;
+  if (v != -1) return false;                       // another lane is at it
+  if (atomicCAS(tab, -1, -2) != -1) return false;  // claimed: exactly one lane goes on
   const uint32_t unit = atomicAdd(env.K.ma_pool_used, nunits);
   if (unit + nunits > env.ma_pool_cap) {
     __hip_atomic_store(tab, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     fail(env, 46);  // the pool is used up: ARTIS_AMD_MA_POOLFRAC (artis_engine.hip names the remedy)
-    p.ma_level = -1;
-    return;
+    *failed = true;
+    return false;
   }
   __hip_atomic_store(tab, -((int32_t)unit + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (where ma_rec_of() finds it while it is filled)
   ma_fill_record(env, c, ul);
   __threadfence();
   __hip_atomic_store(tab, (int32_t)unit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
 #else
-  if (*tab != -1) return;
+  if (*tab >= 0) return true;
   const uint32_t unit = *env.K.ma_pool_used;
   if (unit + nunits > env.ma_pool_cap) {
     fail(env, 46);
-    p.ma_level = -1;
-    return;
+    *failed = true;
+    return false;
   }
   *env.K.ma_pool_used = unit + nunits;
   *tab = -((int32_t)unit + 3);
   ma_fill_record(env, c, ul);
   *tab = (int32_t)unit;
+  return true;
 #endif
+}
+// PEND_MA_FILL in the slow-path kernel (the sequential form: the tail kernel's and the host emulation's; k_slow lets the wave fill,
+// ma_slow_fill_claim() below): whether this lane filled the record or another is at it, the packet goes back to its list -- the record is
+// complete before the next launch of the thermal kernel (the tail kernel's waves come here again until it is).
+AHD void ma_slow_fill(const Env &env, Pkt &p) {
+  const DevModel &M = env.M;
+  p.pend = PEND_NONE;
+  bool failed = false;
+  (void)ma_ensure_record(env, M.propcell_nonemptymgi[p.cellindex], M.ion_uniquelevelindexstart[uion(M, p.ma_element, p.ma_ion)] + p.ma_level, &failed);
+  if (failed) p.ma_level = -1;
+}
+// A slow-path action of the active macro-atom reads its level's record. The record of a cold level may be gone by now: a tiled run refills
+// a tile (and empties the pool) while packets wait for it. true: it is there (again).
+AHD bool ma_slow_record_ready(const Env &env, Pkt &p) {
+  const DevModel &M = env.M;
+  if (M.ncold == 0) return true;
+  bool failed = false;
+  const bool ready = ma_ensure_record(env, M.propcell_nonemptymgi[p.cellindex], M.ion_uniquelevelindexstart[uion(M, p.ma_element, p.ma_ion)] + p.ma_level, &failed);
+  if (failed) {
+    p.pend = PEND_NONE;
+    p.ma_level = -1;
+  }
+  return ready;
 }
 
 #if defined(__HIPCC__) && !defined(ARTIS_HOST_EMU)
@@ -5378,6 +5401,9 @@ AHD bool slow_selects_continuum_nu(const Pkt &p) {
   return p.pend == PEND_KPKT_FB || (p.pend == PEND_MA_ACTION && p.pend_arg == ARTIS_MA_ACTION_RADRECOMB);
 }
 AHD int advance_slow(const Env &env, Pkt &p, int64_t pi, FbSel *sel = nullptr) {
+  // (the actions of the active macro-atom need its level's record: a cold level's may have to be filled again first -- or be waited for)
+  if ((p.pend == PEND_MA_ACTION || p.pend == PEND_MA_SEARCH || p.pend == PEND_MA_RADSEARCH) && !ma_slow_record_ready(env, p))
+    return classify(env, p, env.S.ts_end);
   if (p.pend == PEND_MA_ACTION) {
     ma_slow_action(env, p, pi, sel);
     chi_after_ma(p);

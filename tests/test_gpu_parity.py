@@ -243,8 +243,11 @@ def test_engine_matches_oracle_large_cases(engine_mod, oracle_big, name):
     eng.close()
 
 
-@pytest.mark.parametrize("options", ["classic", "nltenebular", "classic_expopac_therm"])
-def test_cell_cache_tiling_gives_identical_packets(engine_mod, oracle, monkeypatch, options):
+@pytest.mark.parametrize("options,hotfrac", [("classic", "1"), ("nltenebular", "1"), ("classic_expopac_therm", "1"),
+                                             # round 5: tiles AND on-demand macro-atom records (a refill empties the pool: a packet that
+                                             # waited for its tile finds its cold level's record gone and has it filled again)
+                                             ("classic", "0.3"), ("nltenebular", "0.3")])
+def test_cell_cache_tiling_gives_identical_packets(engine_mod, oracle, monkeypatch, options, hotfrac):
     """the cell cache cut into tiles that do not fit together (ARTIS_AMD_CACHE_BUDGET_MB): the engine sweeps over the
     tiles, parking packets that enter a cell of another tile; packet histories must not depend on it. Compared with the
     untiled engine bit for bit, and with the oracle to the usual bars; all packet types, two consecutive timesteps. Also
@@ -253,6 +256,9 @@ def test_cell_cache_tiling_gives_identical_packets(engine_mod, oracle, monkeypat
     model, cs, ts, aux = synth.build("small", ncoord=8, options=options, nts=13)
     pk0 = synth.make_packets(model, aux, 30000, kpkt_fraction=0.2, gamma_fraction=0.1, pellet_fraction=0.2)
     n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
+    # (given, so that the forced budget does not make the engine choose record tiers of its own; the pool of this small model whole)
+    monkeypatch.setenv("ARTIS_AMD_MA_HOTFRAC", hotfrac)
+    monkeypatch.setenv("ARTIS_AMD_MA_POOLFRAC", "1")
 
     def run(budget_mb):
         if budget_mb is None:
@@ -328,6 +334,7 @@ def test_sparse_fills_do_not_cost_sweeps_and_vpkt_refuses_tiles(engine_mod, monk
     model, cs, ts, aux = synth.build("small", ncoord=12)
     pk0 = synth.make_packets(model, aux, 60000, kpkt_fraction=0.2)
     n = model["npts_nonempty"]
+    monkeypatch.setenv("ARTIS_AMD_MA_HOTFRAC", "1")  # (the forced budget is not to make the engine choose on-demand record tiers)
     outs = []
     for sparse in ("0", "1"):
         monkeypatch.delenv("ARTIS_AMD_CACHE_BUDGET_MB", raising=False)
@@ -362,6 +369,7 @@ def test_parked_visit_tails_give_identical_packets(engine_mod, monkeypatch):
     model, cs, ts, aux = synth.build("small", ncoord=12)
     pk0 = synth.make_packets(model, aux, 60000, kpkt_fraction=0.2)
     n = model["npts_nonempty"]
+    monkeypatch.setenv("ARTIS_AMD_MA_HOTFRAC", "1")
     monkeypatch.delenv("ARTIS_AMD_CACHE_BUDGET_MB", raising=False)
     eng = engine_mod.Engine(model)
     bpc = eng.cache_tiles()[2]
@@ -956,8 +964,11 @@ def test_engine_matches_oracle_reference_ci_option_sets(engine_mod, oracle, opti
     eng.close()
 
 
-@pytest.mark.parametrize("options", ["classic", "kilonova_lte", "nltenebular"])
-def test_full_size_properties_50cubed_1e7_packets(engine_mod, options):
+@pytest.mark.parametrize("options,npk,t_days", [("classic", 10_000_000, 20.0), ("kilonova_lte", 10_000_000, 20.0), ("nltenebular", 10_000_000, 20.0),
+                                                # round 5: the expansion-opacity build at full size; the virtual-packet build inside its spectra
+                                                # window (1e6 packets send 3.9e6 virtual packets to the observers: what its bench line runs)
+                                                ("kilonova_expopac", 10_000_000, 20.0), ("ci_classic_vpkt", 1_000_000, 5.0)])
+def test_full_size_properties_50cubed_1e7_packets(engine_mod, options, npk, t_days):
     """BASELINE.json's bench configuration itself (50^3 cells, w7 atomic data, 1e7 packets; configs[1] with the classic
     options, configs[3]'s packet-path options with libartis_amd_kilonova_lte.so, configs[4]'s with
     libartis_amd_nltenebular.so) through properties that do not
@@ -965,8 +976,7 @@ def test_full_size_properties_50cubed_1e7_packets(engine_mod, options):
     (2) every packet ends escaped or exactly at the end of the timestep, with finite positive state; (3) packets are
     independent, so the event counters of the whole population equal the sum over its two halves run separately --
     exactly -- and the estimators agree to the accuracy of float summation (a checksum of checksums)."""
-    npk = 10_000_000
-    model, cs, ts, aux = synth.build("w7", ncoord=50, options=options)
+    model, cs, ts, aux = synth.build("w7", ncoord=50, options=options, t_days=t_days)
     pk0 = synth.make_packets(model, aux, npk, seed_base=1281360349, kpkt_fraction=0.02)
     n, g = model["npts_nonempty"], model["nbfcontinua_ground"]
     t_end = ts.c.start + ts.c.width
@@ -1004,6 +1014,8 @@ def test_full_size_properties_50cubed_1e7_packets(engine_mod, options):
     assert np.all(r_esc > 0.7 * model["rmax"])
     steps = int(e1.stats[abi.STAT_X_RPKT_STEPS] + e1.stats[abi.STAT_X_KPKT_STEPS])
     assert steps > 3e8 and e1.stats_dict()["PKTESCAPES"] == int(esc.sum())
+    if "vpkt" in options:  # virtual packets were traced and reached the observers' spectra
+        assert e1.stats[abi.STAT_X_VPKT_CREATED] > npk and e1.vspecpol.sum() > 0
     assert np.all(e1.J >= 0) and e1.J.sum() > 0 and np.all(np.isfinite(e1.gammaestimator))
     del p1
 

@@ -25,15 +25,15 @@ KERNELS = {  # substring of the mangled name -> label
     "9k_thermalILi1024ELi1E": "k_thermal<1024, 1>",
     "6k_rpktILb1ELi768ELb0E": "k_rpkt<true, 768>",
 }
-# the hot loops, found in the source by their tags: (kernel substring, name, reference lines, file, tag)
+# the hot loops, found in the source by their tags: (kernel substring, name, reference lines, file, tag, largest body in assembly lines)
 HOT = [
-    ("9k_thermalILi1024ELi1E", "transition loop", "macroatom.cc:385-577", "artis_engine.hip", "[census: transition loop]"),
-    ("6k_rpktILb1ELi768ELb0E", "opacity sum", "rpkt.cc:721-830", "physics.h", "[census: opacity sum]"),
-    ("6k_rpktILb1ELi768ELb0E", "line walk", "rpkt.cc:106-207", "physics.h", "[census: line walk]"),
+    ("9k_thermalILi1024ELi1E", "transition loop", "macroatom.cc:385-577", "artis_engine.hip", "[census: transition loop]", 1100),
+    ("6k_rpktILb1ELi768ELb0E", "opacity sum", "rpkt.cc:721-830", "physics.h", "[census: opacity sum]", 1100),
+    ("6k_rpktILb1ELi768ELb0E", "line walk", "rpkt.cc:106-207", "physics.h", "[census: line walk]", 1500),
 ]
 
 
-MIN_BODY, MAX_BODY = 300, 1100  # assembly lines
+MIN_BODY = 300  # assembly lines
 
 
 def tagged_range(path, tag):
@@ -120,7 +120,7 @@ def main():
         print("| loop | ISA loop body: instr | VALU | SALU | VMEM | LDS | SMEM | branch | wait | v_readlane / v_writelane | scratch_ |")
         print("|---|---|---|---|---|---|---|---|---|---|---|")
         uniq = sorted(set(loops), key=lambda t: t[1] - t[0])
-        for kkey, name, ref, fname, tag in HOT:
+        for kkey, name, ref, fname, tag, max_body in HOT:
             if kkey != key:
                 continue
             lo_l, hi_l = tagged_range(os.path.join(B.CSRC, fname), tag)
@@ -129,9 +129,9 @@ def main():
             head = [i for i, op, f, l, _ in insts if f == fname and l == lo_l]
             taken = []
             # a loop has several backward branches (to its header and to the flow blocks before it): of the natural loops of
-            # MIN_BODY..MAX_BODY assembly lines that hold instructions of the loop statement's line, the largest, none inside another
+            # MIN_BODY..max_body assembly lines that hold instructions of the loop statement's line, the largest, none inside another
             for lo, hi in sorted(uniq, key=lambda t: t[0] - t[1]):
-                if MIN_BODY <= hi - lo <= MAX_BODY and any(lo <= i <= hi for i in head) and not any(tlo <= lo and hi <= thi for tlo, thi in taken):
+                if MIN_BODY <= hi - lo <= max_body and any(lo <= i <= hi for i in head) and not any(tlo <= lo and hi <= thi for tlo, thi in taken):
                     taken.append((lo, hi))
             if not taken:
                 print(f"| {name} ({ref}) | not found | | | | | | | | | |")
