@@ -454,14 +454,16 @@ def main():
                          "avg_launch_ms": d["avg_launch_ms"],
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                          "algorithmic_gbs": d["algorithmic_gbs"], "algorithmic_over_hbm_peak": d["algorithmic_gbs"] / HBM_PEAK_GBS,
-                         "measured_limiter": ("not HBM: instruction issue and the waves' dependent reads together -- VALU busy 0.55 of the SIMDs' "
-                                              "cycles at 0.41 lane utilisation, scalar instructions another 0.29, waves waiting 0.67 of theirs; "
-                                              "a transition is one sector of the cell's record from L2 (94 % hits) and two LDS reads "
-                                              "(DESIGN.md section 7, profiles/r04/k_thermal_experiments.md)")
+                         "measured_limiter": ("not HBM: instruction issue and the waves' dependent reads together -- VALU busy 0.53 of the SIMDs' "
+                                              "cycles at 0.42 lane utilisation (valu_lane_frac 0.22), scalar instructions another 0.29, waves waiting "
+                                              "0.61 of theirs; a transition is one sector of the cell's record from L2 (91 % hits) and two LDS reads; "
+                                              "filling the transition loop's lanes (k_thermal_q: 57 of 64 at the same clocks per round) does not pay "
+                                              "while a walk's end stays a chain of ~25 dependent reads (DESIGN.md section 7, "
+                                              "profiles/r05/k_thermal_refill.md)")
                          if dominant == "k_thermal" else
                          ("k_rpkt (+ k_bfest_dense in DETAILED_BF builds, timed together): divergent per-lane loops over continua and "
-                          "lines at 3 waves/SIMD and 0.26 lane utilisation, their reads requested an iteration ahead; see `limiter` and "
-                          "DESIGN.md section 7"),
+                          "lines at 3 waves/SIMD and 0.27 lane utilisation, their reads requested an iteration ahead, the work list "
+                          "sorted by (frequency bin, cell) so that a wave's loops are of similar length; see `limiter` and DESIGN.md section 7"),
                          "limiter": d["limiter"],
                          "kernels": per_kernel},
         }
