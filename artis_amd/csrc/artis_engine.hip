@@ -1933,6 +1933,9 @@ struct TailLists {
 #ifndef ARTIS_SLOW_WAVE_FB
 #define ARTIS_SLOW_WAVE_FB 1  // free-bound emission frequencies selected by the wave (physics.h FbSel) in k_slow and k_tail
 #endif
+#ifndef ARTIS_SLOW_WAVE_FB_MAX
+#define ARTIS_SLOW_WAVE_FB_MAX 6  // ... in k_slow for waves with at most this many emissions
+#endif
 __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailLists in, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
@@ -2042,15 +2045,22 @@ __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, in
   if (mine) {
     pi = list[tid];
     pkt_load(env.P, pi, p);
-#if ARTIS_SLOW_WAVE_FB
-    if (slow_selects_continuum_nu(p)) {
-      Pkt t = p;
-      (void)advance_slow(env, t, pi, &sel);
-    }
-#endif
   }
 #if ARTIS_SLOW_WAVE_FB
-  fbsel_wave(env, sel);
+  {
+    // (only where a few lanes of the wave have an emission: the wave takes them one after the other, each ~9x faster than a lane; with many --
+    // the nltenebular family, where a bound-free action is pending in nearly every round -- the lanes' own selections side by side are faster:
+    // k_slow 83 ms with the wave's form throughout against 68 ms)
+    const bool isfb = mine && slow_selects_continuum_nu(p);
+    const int nfb = __popcll(__ballot(isfb));
+    if (nfb > 0 && nfb <= ARTIS_SLOW_WAVE_FB_MAX) {
+      if (isfb) {
+        Pkt t = p;
+        (void)advance_slow(env, t, pi, &sel);
+      }
+      fbsel_wave(env, sel);
+    }
+  }
 #endif
   {  // a cold level's record (PEND_MA_FILL): claimed by the lane, filled by the wave, published by the lane
     int fc = 0, ful = 0;
@@ -2702,11 +2712,17 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
         per_cell -= sizeof(double) * (size_t)e->Mh.ndpop;  // (dropped first when the cache does not fit: below)
         return (double)per_cell * (double)model->npts_nonempty <= cache_budget_bytes(free_b);
       };
-      // the largest hot share that lets the whole cache be resident (the fewer cold levels, the fewer first visits pay a fill)
+      // the largest hot share that lets the whole cache be resident (the fewer cold levels, the fewer first visits pay a fill). If none
+      // does, the rows stay static and the cache is tiled: every refill of a tile empties the pool, and a tiled run on on-demand records pays
+      // its fills again and again (the headline forced to a quarter of its cache: 3.7 s with them, 3.0 s with four tiles of static rows;
+      // profiles/r05/quarter_cache.txt)
+      bool ok = fits();
       for (const double h : {0.5, 0.3, 0.2, 0.1}) {
-        if (fits()) break;
+        if (ok) break;
         e->Mh = make_host_model_view(*model, e->own, h, pool);
+        ok = fits();
       }
+      if (!ok) e->Mh = make_host_model_view(*model, e->own, 1., pool);
     }
   }
   e->model_copy = *model;
