@@ -45,6 +45,12 @@ constexpr int BLOCK = 256;
 // (the cells of the tile in which packets wait: the later sweeps of a tiled run bring a tile a few stragglers at a time).
 __device__ inline int64_t fill_count(const Env &env) { return env.fill_cells ? env.nfill : (env.tile_hi - env.tile_lo); }
 __device__ inline int fill_cell(const Env &env, int64_t k) { return env.fill_cells ? env.fill_cells[k] : env.tile_lo + (int)k; }
+#ifndef ARTIS_MA_WAVE_FILL
+#define ARTIS_MA_WAVE_FILL 1  // a cold level's record filled by the wave (ma_fill_record_wave); 0: by the lane (physics.h ma_fill_record)
+#endif
+#ifndef ARTIS_COLD_COOLING_ONLY
+#define ARTIS_COLD_COOLING_ONLY 1  // the population evaluates of a cold level's transitions only the cooling terms (physics.h matrans_terms<true>)
+#endif
 __global__ void __launch_bounds__(BLOCK) k_levelpops(Env env) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   const int64_t total = fill_count(env) * env.M.nlevels;
@@ -218,7 +224,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
       MaTransTerms t;
       t.v0 = t.v1 = t.v2 = t.kterm = 0.;
       if (valid) {
-        t = matrans_terms(env, c, a0 + base + lane);
+        t = matrans_terms<ARTIS_COLD_COOLING_ONLY != 0>(env, c, a0 + base + lane);
         if (!t.isdown) upterms[M.level_upcum_start[t.ul] + t.i] = t.kterm;
       }
       double s0 = (lane == 0 ? c0 : 0.) + t.v0, s1 = (lane == 0 ? c1 : 0.) + t.v1, s2 = (lane == 0 ? c2 : 0.) + t.v2;
@@ -250,7 +256,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
   // 1. the terms (the block's entries in the order of DevModel::scanperm: a wave's 64 entries are of one kind wherever the block has 64 of it)
   for (int k = lane; k < nent; k += 64) {
     const int e = M.scanperm[a0 + k];
-    const MaTransTerms t = matrans_terms(env, c, a0 + e);
+    const MaTransTerms t = matrans_terms<ARTIS_COLD_COOLING_ONLY != 0>(env, c, a0 + e);
     v[0][e] = t.v0;
     v[1][e] = t.v1;
     v[2][e] = t.v2;
@@ -838,13 +844,14 @@ struct Lists {
                               // fused thermal kernel
   int32_t nubins;             // frequency bins of the r-packet list's keys (1 = sort by cell only)
   int32_t mabins;             // sub-keys of the thermal list's keys (1 = sort by cell only)
-  int32_t numajor;            // (tuning, ARTIS_AMD_SORT_NUMAJOR=1) > 0 = the grid's cell count: r-packet keys with the frequency bin as the MAJOR part
+  int32_t numajor;            // > 0 = the cell groups of the grid: r-packet keys with the frequency bin as the MAJOR part (ARTIS_AMD_SORT_NUMAJOR=0: cell-major)
+  int32_t cellshift;          // ... groups of 2^cellshift cells with neighbouring indices share a key (ARTIS_AMD_SORT_CELLSHIFT)
 };
 // ma_sub: (tuning, ARTIS_AMD_MABINS=16) a sub-key 0..15 of a thermal-list entry below its cell, -1: none
 __device__ inline void append_by_kind(int kind, int32_t pi, int32_t cellindex, double nu_cmf, const Lists &L, int ma_sub = -1) {
   const int slot = (kind == NEXT_KPKT) ? L.kpkt_slot : kind;
   int32_t key = list_sort_key(cellindex, nu_cmf, (slot == NEXT_RPKT) ? L.nubins : 1);
-  if (slot == NEXT_RPKT && L.numajor > 0 && L.nubins > 1) key = ((key % SORT_NUBINS) * L.numajor) + (key / SORT_NUBINS);
+  if (slot == NEXT_RPKT && L.numajor > 0 && L.nubins > 1) key = ((key % SORT_NUBINS) * L.numajor) + ((key / SORT_NUBINS) >> L.cellshift);
   if (slot == NEXT_MA && L.mabins > 1)
     key = (cellindex * SORT_MABINS) + ((kind == NEXT_KPKT || ma_sub < 0) ? SORT_MABINS - 1 : (ma_sub & (SORT_MABINS - 1)));
 #pragma unroll
@@ -1979,7 +1986,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
       {
         int fc = 0, ful = 0;
         int32_t funit = 0;
-        const bool fill = owner && p.pend == PEND_MA_FILL && ma_slow_fill_claim(env, p, &fc, &ful, &funit);
+        const bool fill = ARTIS_MA_WAVE_FILL && owner && p.pend == PEND_MA_FILL && ma_slow_fill_claim(env, p, &fc, &ful, &funit);
         ma_fill_wave(env, fill, fc, ful);
         if (fill) ma_slow_fill_publish(env, fc, ful, funit);
       }
@@ -2065,7 +2072,7 @@ __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, in
   {  // a cold level's record (PEND_MA_FILL): claimed by the lane, filled by the wave, published by the lane
     int fc = 0, ful = 0;
     int32_t funit = 0;
-    const bool fill = mine && p.pend == PEND_MA_FILL && ma_slow_fill_claim(env, p, &fc, &ful, &funit);
+    const bool fill = ARTIS_MA_WAVE_FILL && mine && p.pend == PEND_MA_FILL && ma_slow_fill_claim(env, p, &fc, &ful, &funit);
     ma_fill_wave(env, fill, fc, ful);
     if (fill) ma_slow_fill_publish(env, fc, ful, funit);
   }
@@ -2292,6 +2299,7 @@ struct artis_amd_engine {
   // and their line walks through the same stretch of the line list -- and in ~7 neighbouring cells of it. k_rpkt 263 -> 251 ms with 16 bins,
   // 244 with 32, 245 with 64, 250 with 128 (MI355X, headline workload; profiles/r05/sort_numajor.txt).
   bool sort_numajor = true;
+  int sort_cellshift = 0;  // ARTIS_AMD_SORT_CELLSHIFT (with the frequency bin as the major part only)
   bool sort_ma = true;
   // lists with more entries per cell of the tile than this are not sorted (sort_by_key) unless the kernel accumulates its
   // per-cell estimators in LDS; measured crossover of the thermal lists with 1e7 packets: between 20^3 and 30^3 cells
@@ -2363,7 +2371,7 @@ Env make_env(const artis_amd_engine *e) {
     // the pool of on-demand records is one for all resident cells (tables.h "ON-DEMAND RECORDS"): not indexed by cell
     env.K.ma_pool = e->K.ma_pool;
     env.K.ma_pool_used = e->K.ma_pool_used;
-    env.ma_pool_cap = (uint32_t)std::min<int64_t>(((int64_t)e->tile_cells * h.ma_pool_slots) / MAREC_ALIGN, 0x7FFFFFF0LL);
+    env.ma_pool_cap = (uint32_t)std::min<int64_t>(((int64_t)e->tile_cells * h.ma_pool_slots) / MAPOOL_UNIT, 0x7FFFFFF0LL);
   }
   env.tile_lo = e->tile_lo;
   env.tile_hi = e->tile_hi;
@@ -2957,6 +2965,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_MATABLES_LDS")) e->ma_tables_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_REFILL")) e->thermal_refill = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NUMAJOR")) e->sort_numajor = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_SORT_CELLSHIFT")) e->sort_cellshift = e->sort_numajor ? std::max(0, std::min(20, std::atoi(b))) : 0;
   if (const char *b = std::getenv("ARTIS_AMD_TQ_LOW")) e->tq_low = std::max(1, std::min(64, std::atoi(b)));
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_FILL")) e->sparse_fill = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SPARSE_MAX")) e->sparse_max_listed = std::max(0, std::atoi(b));
@@ -3304,11 +3313,11 @@ namespace {
 // because fewer cells' tables compete for the caches. Models with so few cells that the kernels accumulate their per-cell
 // estimators in LDS (Env::cellest_lds) have no such atomics and are always sorted (6^3 cells: 494 ms sorted, 593 unsorted).
 int sort_by_key(artis_amd_engine *e, hipStream_t s, const int32_t *list, const int32_t *keys, int32_t n, const int32_t **out, int nbins,
-                int64_t ncells, int max_per_cell) {
+                int64_t ncells, int max_per_cell, int32_t nkeys_given = 0) {
   *out = list;
   if (!e->sort_lists || n < 2 * BLOCK) return ARTIS_OK;
   if ((int64_t)n > (int64_t)max_per_cell * (ncells > 0 ? ncells : 1)) return ARTIS_OK;
-  const int32_t nkeys = e->Mh.ngrid * nbins;
+  const int32_t nkeys = nkeys_given > 0 ? nkeys_given : e->Mh.ngrid * nbins;
   HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(nkeys + 1), s));
   if (nkeys <= SORT_LDS_KEYS)
     hipLaunchKernelGGL(k_sort_hist_lds, dim3(sort_lds_grid(n)), dim3(BLOCK), 0, s, keys, n, e->d_hist, nkeys);
@@ -3385,6 +3394,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   }
   int cur[NEXT_NKINDS] = {};             // which of the two buffers is the current list of each kind
   const int r_nubins = e->sort_nu ? SORT_NUBINS : 1;  // frequency bins in the keys of the r-packet list
+  // cell groups of the frequency-major keys: the ONE number both the keys (Lists::numajor) and the sort's key count are made of
+  const int32_t r_ngroups = (e->sort_cellshift > 0) ? ((e->Mh.ngrid >> e->sort_cellshift) + 1) : e->Mh.ngrid;
   int32_t cnt[2 * NEXT_NKINDS];                        // host copy of the device counters
   auto lists_for = [&](int self_kind) {
     Lists L;
@@ -3399,7 +3410,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     L.self_count = e->d_count + NEXT_NKINDS;  // one alternate counter: only one kernel runs at a time
     L.kpkt_slot = NEXT_MA;  // k-packets travel in the thermal list
     L.nubins = r_nubins;
-    L.numajor = e->sort_numajor ? e->Mh.ngrid : 0;
+    L.numajor = e->sort_numajor ? r_ngroups : 0;
+    L.cellshift = e->sort_cellshift;
     L.mabins = e->ma_bins;
     return L;
   };
@@ -3560,7 +3572,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       if (kind == NEXT_RPKT || kind == NEXT_GAMMA || (kind == NEXT_MA && e->sort_ma)) {
         rc = sort_by_key(e, s, e->d_lists[kind][cur[kind]], e->d_keys[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? r_nubins : (kind == NEXT_MA ? e->ma_bins : 1),
                          hi - lo, kind == NEXT_MA ? (env.cellest_n_t > 0 ? INT32_MAX : e->sort_maxpc_t)
-                                                  : (env.cellest_n_r > 0 ? INT32_MAX : e->sort_maxpc_r));
+                                                  : (env.cellest_n_r > 0 ? INT32_MAX : e->sort_maxpc_r),
+                         (kind == NEXT_RPKT && r_nubins > 1 && e->sort_numajor) ? r_ngroups * r_nubins : 0);
         if (rc != ARTIS_OK) return rc;
       }
       // the kernel starts with an empty current list of its own kind: everything it keeps goes to the alternate list

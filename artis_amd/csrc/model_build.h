@@ -231,12 +231,12 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own, doub
         rec += sz;
       } else {
         own.level_pack[i] = LevelPack{-(ncold++) - 1, m.level_alltrans_startdown[i], m.level_ndowntrans[i], m.level_nuptrans[i]};
-        cold_slots += sz;
+        cold_slots += ((sz + MAPOOL_UNIT - 1) / MAPOOL_UNIT) * MAPOOL_UNIT;  // (the pool's records are whole units)
       }
     }
   }
   v.ncold = ncold;
-  v.ma_pool_slots = (ncold > 0) ? (int32_t)(((int64_t)std::ceil(poolfrac * (double)cold_slots) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN : 0;
+  v.ma_pool_slots = (ncold > 0) ? (int32_t)(((int64_t)std::ceil(poolfrac * (double)cold_slots) + MAPOOL_UNIT - 1) / MAPOOL_UNIT) * MAPOOL_UNIT : 0;
   v.nmacache = rec;
   v.level_pack = own.level_pack.data();
   // what a transition needs to know of the level it leads to (tables.h MaTarget): static, one table for all cells

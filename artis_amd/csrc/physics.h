@@ -201,7 +201,7 @@ struct Env {
   VpktSeed *vpkt_queue;
   int32_t *vpkt_count;
   int32_t vpkt_cap;
-  uint32_t ma_pool_cap;  // units of 64 bytes in DevCache::ma_pool (tables.h "ON-DEMAND RECORDS")
+  uint32_t ma_pool_cap;  // units (MAPOOL_UNIT slots) in DevCache::ma_pool (tables.h "ON-DEMAND RECORDS")
 #ifdef ARTIS_VISIT_COUNTS
   // (measurement build, tools/visit_sparsity.py) [cell][level] macro-atom transitions drawn in that level's record this call
   uint32_t *visit_counts;
@@ -1258,12 +1258,28 @@ struct MaTransTerms {
   double v0, v1, v2;
   double kterm;
 };
+// COOLING_ONLY_IF_COLD: the population's pass over a transition of a COLD level (tables.h "ON-DEMAND RECORDS": no static record to fill) needs
+// nothing of a downward transition and of an upward one only its collisional-excitation cooling term (the same expression: the same bits).
+template <bool COOLING_ONLY_IF_COLD = false>
 AHD MaTransTerms matrans_terms(const Env &env, int c, int ati) {
   const DevModel &M = env.M;
   MaTransTerms r;
   r.ul = M.alltrans_owner[ati];
   r.lpk = M.level_pack[r.ul];
   const int ul = r.ul;
+  if (COOLING_ONLY_IF_COLD && r.lpk.rec_off < 0) {
+    const int i = ati - r.lpk.alltrans_startdown;
+    r.isdown = i < r.lpk.ndown;
+    r.i = r.isdown ? i : i - r.lpk.ndown;
+    r.v0 = r.v1 = r.v2 = r.kterm = 0.;
+    if (!r.isdown) {
+      const int tul = M.ion_uniquelevelindexstart[M.level_ion[ul]] + M.alltrans_targetlevelindex[ati];
+      const double e_trans = eps(M, tul) - eps(M, ul);
+      const double Cc = col_exc(M, env.C.Te[c], clumpednne(env.C, c), e_trans, statw(M, tul), statw(M, ul), ati);
+      r.kterm = env.K.levelpops[((int64_t)c * M.nlevels) + ul] * Cc * e_trans;
+    }
+    return r;
+  }
   const int start = M.ion_uniquelevelindexstart[M.level_ion[ul]];
   const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
   const float T_e = env.C.Te[c];
@@ -1328,7 +1344,7 @@ AHD int ma_resolve(const Env &env, int c, int rec_off) {
 AHD U4 *ma_rec_of(const Env &env, int c, const LevelPack &lpk) {
   if (lpk.rec_off >= 0) return env.K.macache + ((int64_t)c * env.M.nmacache) + lpk.rec_off;
   const int32_t v = ma_rowtab_load(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-lpk.rec_off - 1));
-  return env.K.ma_pool + ((int64_t)((v >= 0) ? v : -(v + 3)) * MAREC_ALIGN);  // (ready, or being filled by the caller; never asked for a level without a record)
+  return env.K.ma_pool + ((int64_t)((v >= 0) ? v : -(v + 3)) * MAPOOL_UNIT);  // (ready, or being filled by the caller; never asked for a level without a record)
 }
 AHD double *ma_rates_of(U4 *rec, int nd, int nu) { return (double *)(rec + marec_rates_slot(nd, nu)); }
 AHD const double *ma_rates_of(const U4 *rec, int nd, int nu) { return (const double *)(rec + marec_rates_slot(nd, nu)); }
@@ -3559,7 +3575,7 @@ AHD void ma_prepare(const Env &env, const Pkt &p, MACtx &k) {
 }
 template <bool COLD = true>
 AHD const U4 *ma_record(const Env &env, const MACtx &k) {
-  if (COLD && k.rec < 0) return env.K.ma_pool + ((int64_t)(-(k.rec + 2)) * MAREC_ALIGN);  // (MA_REC_NONE: never read, ma_jump_internal() returns first)
+  if (COLD && k.rec < 0) return env.K.ma_pool + ((int64_t)(-(k.rec + 2)) * MAPOOL_UNIT);  // (MA_REC_NONE: never read, ma_jump_internal() returns first)
   return k.cellma + k.rec;
 }
 // First half of a transition: draw the process (macroatom.cc:425-431); an internal transition inside the ion is made
@@ -3845,7 +3861,7 @@ AHD bool ma_ensure_record(const Env &env, int c, int ul, bool *failed) {
   const LevelPack lpk = M.level_pack[ul];
   if (lpk.rec_off >= 0) return true;
   int32_t *tab = env.K.ma_rowtab + ((int64_t)c * M.ncold) + (-lpk.rec_off - 1);
-  const uint32_t nunits = (uint32_t)((marec_slots(lpk.ndown, lpk.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN);
+  const uint32_t nunits = (uint32_t)((marec_slots(lpk.ndown, lpk.nup) + MAPOOL_UNIT - 1) / MAPOOL_UNIT);
 #if defined(__HIP_DEVICE_COMPILE__)
   const int32_t v = ma_rowtab_load(tab);
   if (v >= 0) return true;
@@ -3916,7 +3932,7 @@ __device__ inline bool ma_slow_fill_claim(const Env &env, Pkt &p, int *c_out, in
   int32_t *tab = env.K.ma_rowtab + ((int64_t)c * M.ncold) + (-lpk.rec_off - 1);
   if (ma_rowtab_load(tab) != -1) return false;
   if (atomicCAS(tab, -1, -2) != -1) return false;
-  const uint32_t nunits = (uint32_t)((marec_slots(lpk.ndown, lpk.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN);
+  const uint32_t nunits = (uint32_t)((marec_slots(lpk.ndown, lpk.nup) + MAPOOL_UNIT - 1) / MAPOOL_UNIT);
   const uint32_t unit = atomicAdd(env.K.ma_pool_used, nunits);
   if (unit + nunits > env.ma_pool_cap) {
     __hip_atomic_store(tab, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -4434,7 +4450,7 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     if (nsearch > 0) {
       // (a cold level without a record in this cell: decided on the re-added sums like a draw the filter cannot decide)
       const int rslot = ma_resolve(env, c, lpk.rec_off);
-      const U4 *rec = (rslot >= 0) ? env.K.macache + ((int64_t)c * M.nmacache) + rslot : env.K.ma_pool + ((int64_t)(rslot < -1 ? -(rslot + 2) : 0) * MAREC_ALIGN);
+      const U4 *rec = (rslot >= 0) ? env.K.macache + ((int64_t)c * M.nmacache) + rslot : env.K.ma_pool + ((int64_t)(rslot < -1 ? -(rslot + 2) : 0) * MAPOOL_UNIT);
       const double y = ((rnd_process - lo) / (hi - lo)) * MAFILT_SCALE;
       bool amb = env.ma_filters_off != 0 || rslot == MA_REC_NONE || !(y >= 0. && y < MAFILT_SCALE);
       const int yi = amb ? 0 : (int)y;

@@ -86,6 +86,11 @@ struct alignas(16) U4 {  // one slot: 8 x uint16 of a macro-atom filter
   uint32_t w[4];
 };
 constexpr int MAREC_ALIGN = 4;   // slots: records start on 64-byte boundaries
+// The pool of on-demand records is handed out in units of 128 bytes = one line of a compute unit's vector L1: a record filled by one wave
+// while the same kernel's waves on other compute units read their own records (the tail kernel) must not share a line with them -- the L1s
+// are not coherent within a kernel, and a line fetched for a neighbouring record before this one was written would be read stale (found
+// as one packet in 30 000 of a tiled run taking another history, round 5).
+constexpr int MAPOOL_UNIT = 8;   // slots
 constexpr int MAREC_PER = 7;     // transitions per filter line
 constexpr int MAREC_QUAD = 4;    // slots 0..3: action filter, first lines of the down / up / rad filters
 constexpr int MAREC_RATE_SLOTS = 5;  // 9 doubles (+ one spare)
@@ -132,7 +137,7 @@ struct DevModel {
   // 13-15 % of the (cell, level) records (profiles/r05/visit_sparsity_*.md), and 98-99 % of its transitions are drawn in the lowest third of
   // every ion's levels. With ncold > 0 a cell's row holds static records for those HOT levels only (LevelPack::rec_off >= 0); a COLD level
   // (rec_off = -(cold index) - 1) gets a record in the POOL -- one for all resident cells: DevCache::ma_pool, ma_pool_slots slots per resident
-  // cell on average, handed out in units of 64 bytes -- when a packet first reaches it in a cell: the slow-path kernel fills it with the
+  // cell on average, handed out in units of 128 bytes (MAPOOL_UNIT) -- when a packet first reaches it in a cell: the slow-path kernel fills it with the
   // sequential forms of the population (the same terms added in the same order: the same bits), and DevCache::ma_rowtab[cell][cold index]
   // says where it is. ncold == 0: every level has a static record (the default whenever the whole cache fits one tile).
   int32_t ncold, ma_pool_slots;
@@ -267,7 +272,7 @@ struct DevCells {
 struct DevCache {
   double *levelpops;             // [cell][nlevels]
   U4 *macache;                   // [cell][nmacache]: one record of filters + process rates per level (above; LevelPack::rec_off)
-  // [cell][ncold] where a cold level's record is in the pool (64-byte units): -1 none yet, <= -3 being filled at unit -(v + 3), >= 0 ready;
+  // [cell][ncold] where a cold level's record is in the pool (units of MAPOOL_UNIT slots): -1 none yet, <= -3 being filled at unit -(v + 3), >= 0 ready;
   // the pool ([resident cells x ma_pool_slots] slots, shared by all of them: NOT biased by the tile's first cell) and the units handed out
   int32_t *ma_rowtab;
   U4 *ma_pool;

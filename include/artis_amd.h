@@ -576,7 +576,9 @@ int artis_amd_last_kernel_table(artis_amd_engine *eng, double ms[4], int64_t lau
  * globals.h:283-311). Any pointer may be NULL. The engine's rows hold the macro-atom's cumulative sums as 15-bit filters only
  * (DESIGN.md section 2): `matrans` (allmacroatomictransitions, globals.h:287) is re-added on the device from the transitions'
  * rate coefficients -- the values a draw gets that the filters cannot decide -- and the call fails with
- * ARTIS_ERR_NOTCONVERGED if a filter entry of the cell's records differs from the sequential form's. */
+ * ARTIS_ERR_NOTCONVERGED if a filter entry of the cell's records differs from the sequential form's. An engine that keeps
+ * on-demand records (atomic data whose static records do not fit; ARTIS_AMD_MA_HOTFRAC) shows the records
+ * that exist: a cold level that no packet has reached in this cell since the cache was filled reads as zeros. */
 int artis_amd_debug_cellcache(artis_amd_engine *eng, int nonemptymgi, double *levelpops, double *maprocessrates,
                               double *matrans, double *allcont_nnlevel, double *allcont_departure,
                               double *allcont_edgepart, uint64_t *allcont_keepbits, double *corrphotoioncoeff,

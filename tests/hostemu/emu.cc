@@ -79,7 +79,7 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   if (M.ndpop == 0) e.env.K.line_dpop = nullptr;
   for (int64_t i = 0; i < ncell * (int64_t)M.ncold; i++) e.env.K.ma_rowtab[i] = -1;  // k_ma_reset: no cold level has a record yet
   if (M.ncold > 0) *e.env.K.ma_pool_used = 0;
-  e.env.ma_pool_cap = (uint32_t)((ncell * (int64_t)M.ma_pool_slots) / MAREC_ALIGN);
+  e.env.ma_pool_cap = (uint32_t)((ncell * (int64_t)M.ma_pool_slots) / MAPOOL_UNIT);
   e.stats.assign(ARTIS_NSTATS, 0);
   e.env.stats = e.stats.data();
   e.ws.assign((size_t)((M.nbfcontinua_ground + 1) * nslots), 0.);

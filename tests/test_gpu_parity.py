@@ -706,7 +706,7 @@ def test_on_demand_records_give_the_static_records_packets(engine_mod, monkeypat
                 nfilled += int(np.count_nonzero(d["maprocessrates"].reshape(-1, 9).sum(axis=1) > 0))
             assert nfilled > 100  # (records with rates: the static ones and the cold ones packets reached in these cells)
         eng.close()
-    assert outs[1][2] < 0.85 * outs[0][2] and outs[2][2] < outs[1][2]  # bytes per cell of the cache row
+    assert outs[1][2] < 0.9 * outs[0][2] and outs[2][2] < outs[1][2]  # bytes per cell of the cache row
     for o in outs[1:]:
         parity.compare_packets(o[0], outs[0][0], 0.0, "on-demand records vs static records")
         parity.compare_stats(o[1], outs[0][1], "on-demand records vs static records")
