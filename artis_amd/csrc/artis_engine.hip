@@ -781,6 +781,13 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_prefix(Env env) {
   const int c = fill_cell(env, kf);
   populate_cooling_prefix(env, c);
 }
+// the guides of the two cumulative lists a k-packet step draws from (tables.h "COOLING GUIDES"): a thread per entry
+__global__ void __launch_bounds__(BLOCK) k_cool_guide(Env env) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const int64_t total = fill_count(env) * env.M.nguide;
+  if (i >= total) return;
+  populate_cool_guide(env, fill_cell(env, i / env.M.nguide), (int)(i % env.M.nguide));
+}
 
 // ------------------------------------------------------------------ packet layout kernels
 // The slot of a packet is not its index in the caller's array: slots are handed out in the order of the packets'
@@ -1943,6 +1950,8 @@ struct TailLists {
 #ifndef ARTIS_SLOW_WAVE_FB_MAX
 #define ARTIS_SLOW_WAVE_FB_MAX 6  // ... in k_slow for waves with at most this many emissions
 #endif
+// (Round 5: with the static tables of a transition's target in LDS as in k_thermal -- workgroups of 8 packets, one per compute unit -- the
+// classic tail took 27.6 / 26.7 ms against 29.0 / 25.3, the nltenebular tail 123 against 108: profiles/r05/tail_profile.txt. Not kept.)
 __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailLists in, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
@@ -1966,10 +1975,27 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
     pi = in.list[which][j];
     pkt_load(env.P, pi, p);
   }
+#ifdef ARTIS_PROFILE_TAIL
+  // (-DARTIS_PROFILE_TAIL, tools/tail_profile.py) clocks / 16 of the owner lane by kind of step: slots 42 slow, 43 r-packet, 44 thermal, 45 blackbody,
+  // 46 / 47 the r-packet and thermal iterations; 50..53 the same clocks of the waves that ran longer than 2^25 clocks (~15 ms) only
+  long long tp[4] = {0, 0, 0, 0};
+  long long tp_n[2] = {0, 0};
+#define TAILP(i, code)                   \
+  {                                      \
+    const long long tp0_ = clock64();    \
+    code;                                \
+    tp[i] += clock64() - tp0_;           \
+  }
+#else
+#define TAILP(i, code) code
+#endif
   while (true) {
     if (owner) kind = classify(env, p, ts_end);
     const int kind_w = __builtin_amdgcn_readfirstlane(__shfl(kind, 0));
     if (kind_w == NEXT_SLOW) {
+#ifdef ARTIS_PROFILE_TAIL
+      const long long tps0 = clock64();
+#endif
 #if ARTIS_SLOW_WAVE_FB
       FbSel sel;
       sel.mode = 1;
@@ -1995,26 +2021,63 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
 #else
       if (owner) (void)advance_slow(env, p, pi);
 #endif
+#ifdef ARTIS_PROFILE_TAIL
+      tp[0] += clock64() - tps0;
+#endif
     } else if (kind_w == NEXT_RPKT) {
       if (owner) {
         Chi x;
         chi_load(env.P, pi, p, x);
         bool go = rpkt_can_continue(p, ts_end);
+#ifdef ARTIS_PROFILE_TAIL
+        const long long tpr0 = clock64();
+        while (go) {
+          go = rpkt_iter(env, p, pi, x);
+          tp_n[0]++;
+        }
+        tp[1] += clock64() - tpr0;
+#else
         while (go) go = rpkt_iter(env, p, pi, x);
+#endif
         chi_store(env.P, pi, p, x);
       }
     } else if (kind_w == NEXT_MA || kind_w == NEXT_KPKT) {
       if (owner) {
         MACtx k = ma_ctx(env, p);
         bool go = thermal_can_continue(p, ts_end);
+#ifdef ARTIS_PROFILE_TAIL
+        const long long tpt0 = clock64();
+        while (go) {
+          (void)thermal_iter(env, p, pi, k, &go);
+          tp_n[1]++;
+        }
+        tp[2] += clock64() - tpt0;
+#else
         while (go) (void)thermal_iter(env, p, pi, k, &go);
+#endif
       }
     } else if (kind_w == NEXT_BB) {
-      if (owner) (void)advance_blackbody(env, p, pi);
+      TAILP(3, if (owner) (void)advance_blackbody(env, p, pi));
     } else {
       break;
     }
   }
+#ifdef ARTIS_PROFILE_TAIL
+  if (owner) {
+    const bool longwave = (tp[0] + tp[1] + tp[2] + tp[3]) > (1LL << 25);
+    for (int i = 0; i < 4; i++) {
+      atomicAdd(&lstats[42 + i], (stat_t)(tp[i] >> 4));
+      if (longwave) atomicAdd(&lstats[50 + i], (stat_t)(tp[i] >> 4));
+    }
+    atomicAdd(&lstats[46], (stat_t)tp_n[0]);
+    atomicAdd(&lstats[47], (stat_t)tp_n[1]);
+    if (longwave) {
+      atomicAdd(&lstats[54], (stat_t)1);
+      atomicAdd(&lstats[55], (stat_t)tp_n[0]);
+      atomicAdd(&lstats[56], (stat_t)tp_n[1]);
+    }
+  }
+#endif
   if (owner) {
     pkt_store(env.P, pi, p);
     cellindex = p.cellindex;
@@ -3175,6 +3238,7 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
   if (h.ncoollines > 0) hipLaunchKernelGGL(k_collexc_filter, dim3(nblocks(ncell * (int64_t)h.ncoollines)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_tail, dim3(nblocks((int64_t)ncell * h.nions * 16)), dim3(BLOCK), 0, s, env);
   hipLaunchKernelGGL(k_cooling_prefix, dim3(nblocks(ncell)), dim3(BLOCK), 0, s, env);
+  if (h.nguide > 0) hipLaunchKernelGGL(k_cool_guide, dim3(nblocks(ncell * h.nguide)), dim3(BLOCK), 0, s, env);
   }  // batches
   const int64_t ncell = ncell_fill;
   HIP_TRY(hipGetLastError());

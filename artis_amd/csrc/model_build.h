@@ -29,7 +29,7 @@ struct ModelOwned {
   std::vector<ContPack> cont_pack;
   std::vector<int32_t> expopac_linestart;
   std::vector<int32_t> upcum_coolslot;
-  std::vector<int32_t> level_recomb_start, recomb_lower, recomb_target, recomb_levels, ion_cooltail_start, level_coolhi;
+  std::vector<int32_t> level_recomb_start, recomb_lower, recomb_target, recomb_levels, ion_cooltail_start, level_coolhi, ion_guideoff, ion_guideshift;
 };
 
 // X(field, element type, element count) for every array pointer of DevModel
@@ -60,6 +60,8 @@ struct ModelOwned {
   X(level_ion, int32_t, (m).nlevels)                                               \
   X(level_pack, LevelPack, (m).nlevels)                                            \
   X(level_coolhi, int32_t, (m).nlevels)                                            \
+  X(ion_guideoff, int32_t, (m).nions)                                              \
+  X(ion_guideshift, int32_t, (m).nions)                                            \
   X(level_upcum_start, int32_t, (m).nlevels)                                       \
   X(alltrans_lineindex, int32_t, (m).nalltrans)                                    \
   X(alltrans_targetlevelindex, int32_t, (m).nalltrans)                             \
@@ -182,6 +184,7 @@ struct ModelOwned {
   X(line_dpop, double, (m).ndpop)                               \
   X(ion_cooling_contribs, double, (m).nions)                    \
   X(ion_cooling_C, double, (m).nions)                           \
+  X(cool_guide, uint16_t, (m).nguide)                           \
   X(chi_ff_nnionpart, double, 1)
 
 // Host view of the model: pointers into the caller's arrays plus the derived tables in `own`.
@@ -378,6 +381,29 @@ inline DevModel make_host_model_view(const artis_model &m, ModelOwned &own, doub
       }
     }
   v.level_coolhi = own.level_coolhi.data();
+  {
+    // the cooling guides (tables.h "COOLING GUIDES"): as many ranges of the draw as the list has entries / 2, rounded up to a power of two
+    auto shift_for = [](int n) {
+      int lg = 0;
+      while ((1 << lg) < n && lg < 16) lg++;
+      return 24 - lg;
+    };
+    own.ion_guideoff.assign((size_t)(m.nions > 0 ? m.nions : 1), 0);
+    own.ion_guideshift.assign((size_t)(m.nions > 0 ? m.nions : 1), 24);
+    bool ok = m.nions > 0 && m.nions <= 65535;
+    if (const char *b = std::getenv("ARTIS_AMD_COOLGUIDE")) ok = ok && std::atoi(b) != 0;
+    v.guide_ion_shift = shift_for(2 * m.nions);
+    int64_t n = ((int64_t)1 << (24 - v.guide_ion_shift)) + 1;
+    for (int ui = 0; ui < m.nions && ok; ui++) {
+      if (m.ion_ncoolingterms[ui] > 65535) ok = false;
+      own.ion_guideoff[ui] = (int32_t)n;
+      own.ion_guideshift[ui] = shift_for((m.ion_ncoolingterms[ui] + 1) / 2);
+      n += ((int64_t)1 << (24 - own.ion_guideshift[ui])) + 1;
+    }
+    v.nguide = ok ? (int32_t)((n + 3) & ~(int64_t)3) : 0;  // (rows of whole 8 bytes)
+    v.ion_guideoff = own.ion_guideoff.data();
+    v.ion_guideshift = own.ion_guideshift.data();
+  }
   v.ncoollines = (int32_t)own.coollines.size();
   if (own.coollines.empty()) own.coollines.push_back(CoolLineRef{0, 0, 0, 0, 0, -1});
   v.coollines = own.coollines.data();

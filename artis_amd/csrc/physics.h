@@ -1724,6 +1724,41 @@ AHD void populate_cooling_prefix(const Env &env, int c) {
   }
 }
 
+// The cooling guides (tables.h "COOLING GUIDES"). Entry e of a cell's row: the ions' guide first, then every ion's.
+AHD void populate_cool_guide(const Env &env, int c, int e) {
+  const DevModel &M = env.M;
+  uint16_t *g = env.K.cool_guide + ((int64_t)c * M.nguide);
+  const double *list = env.K.ion_cooling_contribs + ((int64_t)c * M.nions);
+  int n = M.nions, shift = M.guide_ion_shift, k = e;
+  if (e >= M.ion_guideoff[0]) {
+    int ui = 0;
+    while (ui + 1 < M.nions && M.ion_guideoff[ui + 1] <= e) ui++;
+    list = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + M.ion_coolingoffset[ui];
+    n = M.ion_ncoolingterms[ui];
+    shift = M.ion_guideshift[ui];
+    k = e - M.ion_guideoff[ui];
+  }
+  const int nranges = 1 << (24 - shift);
+  if (k > nranges) {
+    g[e] = 0;  // (the row's padding)
+  } else if (k == nranges) {
+    g[e] = (uint16_t)n;
+  } else {
+    // the value the draw u = k << shift is compared with in do_kpkt(): the same expression
+    const double b = rng_u24_value((uint32_t)k << shift) * list[n - 1];
+    g[e] = (uint16_t)upper_bound_d(list, n, b);
+  }
+}
+// upper_bound_d(list, n, v) for v = the value of the 24-bit draw u, by the guide g of the list: the same index
+AHD int guided_upper_bound(const double *list, int n, double v, const uint16_t *g, int shift, uint32_t u) {
+  const int k = (int)(u >> shift);
+  const int lo = g[k], hi = g[k + 1];
+  // (the sums of the range, few and rarely any: most ranges lie inside one term; non-decreasing, so the first greater one ends the count)
+  int r = lo;
+  while (r < hi && !(v < list[r])) r++;
+  return r;
+}
+
 // ================================================================ r-packet path
 AHD double chi_total(const Chi &x) { return x.chi_escatter + x.chi_boundfree + x.chi_freefree_heat; }  // rpkt.h:100
 
@@ -4394,9 +4429,12 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   PROF_BEGIN();
   const int c = M.propcell_nonemptymgi[p.cellindex];
   const double *ioncontribs = env.K.ion_cooling_contribs + ((int64_t)c * M.nions);
-  const double rndcool_ion = rng_uniform(p) * ioncontribs[M.nions - 1];
-  const int ui = ARTIS_KPKT_BLOCKED_SEARCH ? upper_bound_blocked<6>(ioncontribs, M.nions, rndcool_ion)
-                                           : upper_bound_d(ioncontribs, M.nions, rndcool_ion);
+  const uint16_t *guide = env.K.cool_guide + ((int64_t)c * M.nguide);  // (tables.h "COOLING GUIDES"; nguide == 0: none)
+  const uint32_t u_ion = rng_u24(p);
+  const double rndcool_ion = rng_u24_value(u_ion) * ioncontribs[M.nions - 1];  // (= rng_uniform(p) * ...)
+  const int ui = (M.nguide > 0) ? guided_upper_bound(ioncontribs, M.nions, rndcool_ion, guide, M.guide_ion_shift, u_ion)
+                 : ARTIS_KPKT_BLOCKED_SEARCH ? upper_bound_blocked<6>(ioncontribs, M.nions, rndcool_ion)
+                                             : upper_bound_d(ioncontribs, M.nions, rndcool_ion);
   if (!(ui < M.nions)) {
     fail(env, 70);
     return;
@@ -4410,8 +4448,9 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   const double *contribs = cellcontrib + ionstart;
   const uint32_t u_process = rng_u24(p);
   const double rnd_process = rng_u24_value(u_process) * contribs[nterms - 1];
-  const int ionoffset = ARTIS_KPKT_BLOCKED_SEARCH ? upper_bound_blocked<16>(contribs, nterms, rnd_process)
-                                                  : upper_bound_d(contribs, nterms, rnd_process);
+  const int ionoffset = (M.nguide > 0) ? guided_upper_bound(contribs, nterms, rnd_process, guide + M.ion_guideoff[ui], M.ion_guideshift[ui], u_process)
+                        : ARTIS_KPKT_BLOCKED_SEARCH ? upper_bound_blocked<16>(contribs, nterms, rnd_process)
+                                                    : upper_bound_d(contribs, nterms, rnd_process);
   if (!(ionoffset < nterms)) {
     fail(env, 71);
     return;

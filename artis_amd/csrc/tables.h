@@ -143,6 +143,17 @@ struct DevModel {
   int32_t ncold, ma_pool_slots;
   // [nlevels] the entry of the cooling list that holds the running sum after the level's collisional excitations (-1: no upward transitions)
   const int32_t *level_coolhi;
+  // COOLING GUIDES (round 5). A k-packet step draws an ion from the cell's cumulative list of the ions' cooling and then a term from that ion's
+  // cumulative list (kpkt.cc:430-447): two bisections, 6 + 8 DEPENDENT reads with the bench's data, each waiting for the one before. Both
+  // draws are 24-bit integers u; DevCache::cool_guide holds, for the 2^(24 - shift) equal ranges of u, the answer for the range's first draw:
+  // g[k] = upper_bound(list, value of the draw k << shift). Rounding is monotonic, so the answer for any u of range k lies in [g[k], g[k + 1]]:
+  // one read of two neighbouring guide entries -- issued beside the read of the list's total, not after it -- and, only where the two differ
+  // (5 % of the draws: most ranges lie inside one dominant term), the comparison with those few sums. The same index as the bisection gives.
+  // Row of a cell: [the ions' guide: 2^(24 - guide_ion_shift) + 1 entries | ion 0's guide | ...]; ion ui's guide starts at ion_guideoff[ui]
+  // and has 2^(24 - ion_guideshift[ui]) + 1 entries (as many ranges as half the ion's terms, rounded up to a power of two); the last entry
+  // of a guide is the list's length. nguide == 0: no guides (a list longer than 65535 entries, or ARTIS_AMD_COOLGUIDE=0): bisection.
+  int32_t nguide, guide_ion_shift;
+  const int32_t *ion_guideoff, *ion_guideshift;
   int32_t nupcum;      // upward transitions (= nlines): doubles per cell of the population's scratch of cooling terms (Env::collexc_terms)
   int32_t ndpop;       // doubles per cell in DevCache::line_dpop: nlines, or 0 when the population factors are formed on the fly
   int32_t nkeepwords;  // ceil(nbfcontinua/64) (get_allcont_keepwordcount globals.h:401) rounded up to a multiple of 4
@@ -295,6 +306,7 @@ struct DevCache {
   double *bf_radrecomb, *bf_colrecomb, *bf_colion, *bf_cooling;
   double *cooling_contrib;       // [cell][ncoolingterms]
   double *ion_cooling_contribs;  // [cell][nions]
+  uint16_t *cool_guide;          // [cell][nguide] (DevModel "COOLING GUIDES")
   double *ion_cooling_C;         // [cell][nions] per-ion totals before the prefix sum
   double *chi_ff_nnionpart;      // [cell]
 };

@@ -146,6 +146,7 @@ void populate_all(Emu &e) {
     for (int ui = 0; ui < M.nions; ui++) populate_cooling_ion(e.env, c, ui, upterms.data());
     for (int li = 0; li < M.ncoollines; li++) populate_coolfilter_line(e.env, c, li, upterms.data());  // k_collexc_filter
     populate_cooling_prefix(e.env, c);
+    for (int g = 0; g < M.nguide; g++) populate_cool_guide(e.env, c, g);  // k_cool_guide
   }
 }
 }  // namespace

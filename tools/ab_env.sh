@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/ab_env.sh "<ENV=.. ENV=..>" ... : one bench run per argument (environment assignments), prints ms/step and the split
 for cfg in "$@"; do
-  env $cfg ARTIS_BENCH_VERBOSE=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2>/tmp/_err | python -c "
+  env $cfg ARTIS_BENCH_VERBOSE=1 python bench.py --steps 1 --warmup 1 --no-cpu-baseline $AB_ARGS 2>/tmp/_err | python -c "
 import json,sys,re
 d=json.loads(sys.stdin.read()); b=d['kernel_breakdown_last_step']
 err=open('/tmp/_err').read()

@@ -140,6 +140,10 @@ def main():
                 c = collections.Counter(classify(op) for op, _, _ in inside)
                 print(f"| {name}, copy {n + 1} of {len(taken)} ({ref}; {fname}:{lo_l}-{hi_l}) | {len(inside)} | {c['valu']} | {c['salu']} | {c['vmem']} | "
                       f"{c['lds']} | {c['smem']} | {c['branch']} | {c['wait']} | {c['sgpr_spill_lane_ops']} | {c['scratch']} |")
+                if os.environ.get("CENSUS_LINES"):  # the body's instructions by source line (to stderr: not part of the table)
+                    by = collections.Counter((f, l) for _, f, l in inside)
+                    for (f, l), cnt in sorted(by.items(), key=lambda t: (t[0][0], t[0][1])):
+                        print(f"    {name} copy {n + 1}: {f}:{l} {cnt}", file=sys.stderr)
         print()
 
 

@@ -14,5 +14,5 @@ print("transitions %.4g  k-packet steps %.4g  thermal visits %.4g" % (s[abi.STAT
 print("wave-level: transition rounds %.4g (%.1f lanes)  k-packet phases %.4g (%.1f lanes)" % (s[46], s[abi.STAT_X_MA_JUMPS] / s[46], s[47], s[abi.STAT_X_KPKT_STEPS] / max(s[47], 1)))
 print("wave-level rounds of the collisional-excitation scan of the k-packet step (8 reads each): %.4g" % s[58])
 print("wave clocks x1e9: pull+load %.1f | MA phase %.1f | kpkt phase %.1f | store+append %.1f" % (16*s[42]/1e9, 16*s[43]/1e9, 16*s[44]/1e9, 16*s[45]/1e9))
-print("k-packet step, wave clocks x1e9: up to the ion drawn %.1f | up to the cooling term drawn %.1f | the term's process %.1f" % (16*s[56]/1e9, 16*s[57]/1e9, 16*s[59]/1e9))
+print("k-packet step, wave clocks x1e9: up to the ion drawn %.1f | up to the cooling term drawn %.1f | the term's process %.1f" % (16*s[56]/1e9, 16*s[57]/1e9, 16*s[41]/1e9))
 print(eng.last_kernel_breakdown())
