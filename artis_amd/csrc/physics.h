@@ -1724,7 +1724,17 @@ AHD void populate_cooling_prefix(const Env &env, int c) {
   }
 }
 
-// The cooling guides (tables.h "COOLING GUIDES"). Entry e of a cell's row: the ions' guide first, then every ion's.
+// The cooling guides (tables.h "COOLING GUIDES"). Entry k of the guide of a cumulative list of n sums whose draws fall into 2^(24 - shift)
+// ranges: the bisection's answer for the range's first draw; the list's length after the last range; 0 in a row's padding
+AHD uint16_t cool_guide_entry(const double *list, int n, int shift, int k) {
+  const int nranges = 1 << (24 - shift);
+  if (k > nranges) return 0;
+  if (k == nranges) return (uint16_t)n;
+  // the value the draw u = k << shift is compared with in do_kpkt(): the same expression
+  const double b = rng_u24_value((uint32_t)k << shift) * list[n - 1];
+  return (uint16_t)upper_bound_d(list, n, b);
+}
+// Entry e of a cell's row: the ions' guide first, then every ion's.
 AHD void populate_cool_guide(const Env &env, int c, int e) {
   const DevModel &M = env.M;
   uint16_t *g = env.K.cool_guide + ((int64_t)c * M.nguide);
@@ -1738,16 +1748,7 @@ AHD void populate_cool_guide(const Env &env, int c, int e) {
     shift = M.ion_guideshift[ui];
     k = e - M.ion_guideoff[ui];
   }
-  const int nranges = 1 << (24 - shift);
-  if (k > nranges) {
-    g[e] = 0;  // (the row's padding)
-  } else if (k == nranges) {
-    g[e] = (uint16_t)n;
-  } else {
-    // the value the draw u = k << shift is compared with in do_kpkt(): the same expression
-    const double b = rng_u24_value((uint32_t)k << shift) * list[n - 1];
-    g[e] = (uint16_t)upper_bound_d(list, n, b);
-  }
+  g[e] = cool_guide_entry(list, n, shift, k);
 }
 // upper_bound_d(list, n, v) for v = the value of the 24-bit draw u, by the guide g of the list: the same index
 AHD int guided_upper_bound(const double *list, int n, double v, const uint16_t *g, int shift, uint32_t u) {

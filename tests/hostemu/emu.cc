@@ -207,6 +207,54 @@ int64_t artis_emu_mafilter_selftest(int64_t ntrials, uint64_t seed, int64_t *n_a
   return mism;
 }
 
+// Property check of the cooling guides (tables.h "COOLING GUIDES") on the functions the kernels use: random cumulative lists (1..400 sums,
+// equal neighbours and leading zeros now and then, one dominant term in most), guides of 2^lg ranges; for random 24-bit draws and for the
+// first and last draw of every range, guided_upper_bound() must return what upper_bound_d() returns. Returns the number of mismatches;
+// *n_noread: draws decided by the two guide entries alone.
+int64_t artis_emu_coolguide_selftest(int64_t ntrials, uint64_t seed, int64_t *n_noread) {
+  using namespace artis;
+  uint64_t s = seed ? seed : 1;
+  auto next = [&s]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  auto unif = [&next]() { return (double)(next() >> 11) * 0x1.0p-53; };
+  int64_t mism = 0, noread = 0;
+  std::vector<double> list;
+  std::vector<uint16_t> g;
+  for (int64_t t = 0; t < ntrials; t++) {
+    const int n = 1 + (int)(next() % 400);
+    list.assign((size_t)n, 0.);
+    const double scale = std::exp((unif() - 0.5) * 150.);
+    double run = 0.;
+    const int dominant = (int)(next() % (uint64_t)n);
+    for (int j = 0; j < n; j++) {
+      const double r = unif();
+      if (r > 0.15) run += unif() * unif() * ((j == dominant && unif() < 0.8) ? 1000. * n : 1.);  // (else: an entry that adds nothing)
+      list[(size_t)j] = run * scale;
+    }
+    if (!(list[(size_t)n - 1] > 0.)) list[(size_t)n - 1] = scale;
+    const int lg = (int)(next() % 10);  // 1 .. 512 ranges
+    const int shift = 24 - lg, nranges = 1 << lg;
+    g.assign((size_t)nranges + 2, 0);
+    for (int k = 0; k <= nranges; k++) g[(size_t)k] = cool_guide_entry(list.data(), n, shift, k);
+    auto check = [&](uint32_t u) {
+      const double v = rng_u24_value(u) * list[(size_t)n - 1];
+      const int want = upper_bound_d(list.data(), n, v);
+      const int got = guided_upper_bound(list.data(), n, v, g.data(), shift, u);
+      if (want != got) mism++;
+      const int k = (int)(u >> shift);
+      if (g[(size_t)k] == g[(size_t)k + 1]) noread++;
+    };
+    for (int i = 0; i < 64; i++) check((uint32_t)(next() >> 40));
+    for (int k = 0; k < nranges; k += (nranges > 16 ? nranges / 16 : 1)) {
+      check((uint32_t)k << shift);
+      check((((uint32_t)k + 1u) << shift) - 1u);
+    }
+    check(0u);
+    check(0xFFFFFFu);
+  }
+  if (n_noread) *n_noread = noread;
+  return mism;
+}
+
 int artis_emu_constants(const char **names, double *values, int maxn) {
   using namespace artis;
   static const char *N[] = {"CLIGHT", "CLIGHT_PROP", "H", "MH", "ME", "PI", "EV", "MEV", "SIGMA_T", "THOMSON_LIMIT", "KB", "SAHACONST",

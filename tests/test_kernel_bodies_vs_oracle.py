@@ -612,6 +612,20 @@ def test_macroatom_filters_decide_what_the_f64_comparison_decides():
     assert 0.25 * n <= namb.value < 0.3 * n, namb.value
 
 
+def test_cooling_guides_give_the_bisections_index():
+    """tables.h "COOLING GUIDES": 2e5 random cumulative lists (equal neighbours, entries that add nothing, a dominant term in most) with guides
+    of 1 ... 512 ranges; for random 24-bit draws and for the first and last draw of the ranges the guided look-up of do_kpkt() returns the
+    index upper_bound_d() returns (kpkt.cc:430-447's std::upper_bound); most draws are decided by the two guide entries alone"""
+    import ctypes as C
+
+    L = emu.lib()
+    L.artis_emu_coolguide_selftest.restype = C.c_int64
+    L.artis_emu_coolguide_selftest.argtypes = [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]
+    noread = C.c_int64(0)
+    assert L.artis_emu_coolguide_selftest(200_000, 20261004, C.byref(noread)) == 0
+    assert noread.value > 0.5 * 200_000 * 64
+
+
 @pytest.mark.parametrize("options,preset,ncoord,gridtype,npk", [
     ("classic", "w7", 5, abi.GRID_CARTESIAN3D, 600),
     ("classic", "small", 8, abi.GRID_CYLINDRICAL2D, 2500),

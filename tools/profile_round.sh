@@ -26,5 +26,6 @@ python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --options kilonova_expop
 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --options classic_expopac_therm > $O/bench_classic_expopac_therm.json 2> /dev/null
 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --options ci_classic_vpkt --t-days 5 --packets 1000000 > $O/bench_ci_classic_vpkt_1e6_t5d.json 2> /dev/null
 python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --preset w7big > $O/bench_w7big.json 2> /dev/null
+python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --preset cd23like > $O/bench_cd23like.json 2> /dev/null
 bash tools/r04_populate_trace.sh w7 > $O/populate_trace.txt 2>&1; cp $R/gpurun_out/populate_trace/kernel_stats_populate_w7.csv $O/ 2>/dev/null
 tail -c 400 $O/bench_default.json
