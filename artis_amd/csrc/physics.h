@@ -1728,7 +1728,7 @@ AHD void populate_cooling_prefix(const Env &env, int c) {
 // ranges: the bisection's answer for the range's first draw; the list's length after the last range; 0 in a row's padding
 AHD uint16_t cool_guide_entry(const double *list, int n, int shift, int k) {
   const int nranges = 1 << (24 - shift);
-  if (k > nranges) return 0;
+  if (k > nranges || n <= 0) return 0;
   if (k == nranges) return (uint16_t)n;
   // the value the draw u = k << shift is compared with in do_kpkt(): the same expression
   const double b = rng_u24_value((uint32_t)k << shift) * list[n - 1];

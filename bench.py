@@ -457,9 +457,11 @@ def main():
                          "measured_limiter": ("not HBM: instruction issue and the waves' dependent reads together -- VALU busy 0.53 of the SIMDs' "
                                               "cycles at 0.42 lane utilisation (valu_lane_frac 0.22), scalar instructions another 0.29, waves waiting "
                                               "0.61 of theirs; a transition is one sector of the cell's record from L2 (91 % hits) and two LDS reads; "
-                                              "filling the transition loop's lanes (k_thermal_q: 57 of 64 at the same clocks per round) does not pay "
-                                              "while a walk's end stays a chain of ~25 dependent reads (DESIGN.md section 7, "
-                                              "profiles/r05/k_thermal_refill.md)")
+                                              "one wave alone needs ~2900 clocks per transition, ~1000 of them instruction issue, and four waves per "
+                                              "SIMD share one issue port: 4 x ~850 = the 3400 clocks of a wave-round. Filling the loop's lanes "
+                                              "(k_thermal_q: 57 of 64) costs in its service passes what the fuller rounds save; shortening the chain of "
+                                              "dependent reads of a walk's end (cooling guides) took 1 % (DESIGN.md section 7, "
+                                              "profiles/r05/k_thermal_refill.md, cooling_guides.txt, tail_profile.txt)")
                          if dominant == "k_thermal" else
                          ("k_rpkt (+ k_bfest_dense in DETAILED_BF builds, timed together): divergent per-lane loops over continua and "
                           "lines at 3 waves/SIMD and 0.27 lane utilisation, their reads requested an iteration ahead, the work list "

@@ -326,6 +326,28 @@ def test_line_population_factors_on_the_fly_give_identical_packets(engine_mod, o
     parity.compare_packets(outs[1][0][:6000], pa, FLOAT_RTOL, "population factors on the fly vs oracle")
 
 
+@pytest.mark.parametrize("options", ["classic", "nltenebular"])
+def test_cooling_guides_give_the_bisections_packets(engine_mod, monkeypatch, options):
+    """ARTIS_AMD_COOLGUIDE=0: the two draws of a k-packet step (kpkt.cc:430-447) by bisection, as in rounds 1-4, instead of by the per-cell
+    guide tables (tables.h "COOLING GUIDES"): the row shrinks by the guides, packets, generator states and counters are identical."""
+    model, cs, ts, aux = synth.build("small", ncoord=8, options=options)
+    pk0 = synth.make_packets(model, aux, 30000, kpkt_fraction=0.5)
+    outs = []
+    for guide in ("1", "0"):
+        monkeypatch.setenv("ARTIS_AMD_COOLGUIDE", guide)
+        eng = engine_mod.Engine(model, preset=options)
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, options)
+        eng.update_packets(p, e)
+        outs.append((p, e, eng.cache_tiles()[2]))
+        eng.close()
+    monkeypatch.delenv("ARTIS_AMD_COOLGUIDE", raising=False)
+    assert 0 < outs[0][2] - outs[1][2] < 2 * 2 * (model["ncoolingterms"] + 4 * model["nions"] + 70), (outs[0][2], outs[1][2])
+    assert outs[0][1].stats[abi.STAT_X_KPKT_STEPS] > 10000
+    parity.compare_packets(outs[1][0], outs[0][0], 0.0, "cooling guides vs bisection")
+    parity.compare_stats(outs[1][1], outs[0][1], "cooling guides vs bisection")
+
+
 def test_sparse_fills_do_not_cost_sweeps_and_vpkt_refuses_tiles(engine_mod, monkeypatch):
     """Two findings of the round-3 review of the tiled cache. (1) A sparse fill (a late visit that populates only the cells in which
     packets wait) left its residency bitmap switched on while the next tile's packets were classified, which hid that tile until the
