@@ -2021,6 +2021,16 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
 #else
       if (owner) (void)advance_slow(env, p, pi);
 #endif
+      {
+        // the pool of on-demand records is used up and the packet still waits for a record: it leaves for the slow-path list (the host empties
+        // the pool before that list's next launch); nothing in this kernel could end the wait
+        const bool waits = owner && env.M.ncold > 0 && p.pend != PEND_NONE &&
+                           __hip_atomic_load(env.ma_pool_full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (__builtin_amdgcn_readfirstlane(__shfl((int)waits, 0)) != 0) {
+          if (owner) kind = NEXT_SLOW;
+          break;
+        }
+      }
 #ifdef ARTIS_PROFILE_TAIL
       tp[0] += clock64() - tps0;
 #endif
@@ -2332,6 +2342,7 @@ struct artis_amd_engine {
   int64_t last_sparse_fills = 0, last_cells_filled = 0;
   bool park_tails = true;     // ARTIS_AMD_TILE_PARK=0: every visit of a tile runs its packets to their end (rounds 2-3)
   int64_t last_parked = 0;
+  int64_t last_pool_resets = 0;  // times the pool of on-demand records was emptied because it was used up (this call)
   bool vpkt_cont_lds = true;  // ARTIS_AMD_VPKT_CONTLDS=0: k_vpkt reads the continuum table from memory (four workgroups of 256 per CU)
   bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
   int64_t last_sweeps = 0, last_tile_fills = 0, last_listed = 0;
@@ -2435,6 +2446,7 @@ Env make_env(const artis_amd_engine *e) {
     env.K.ma_pool = e->K.ma_pool;
     env.K.ma_pool_used = e->K.ma_pool_used;
     env.ma_pool_cap = (uint32_t)std::min<int64_t>(((int64_t)e->tile_cells * h.ma_pool_slots) / MAPOOL_UNIT, 0x7FFFFFF0LL);
+    env.ma_pool_full = e->d_count + (2 * NEXT_NKINDS - 1);  // (a spare slot of the counts the host reads after every launch)
   }
   env.tile_lo = e->tile_lo;
   env.tile_hi = e->tile_hi;
@@ -3433,6 +3445,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   e->last_sweeps = e->last_tile_fills = e->last_listed = 0;
   e->last_sparse_fills = e->last_cells_filled = 0;
   e->last_parked = 0;
+  e->last_pool_resets = 0;
   e->resident_on = false;
   e->last_fill_ms = 0.;
   for (int k = 0; k < NEXT_NKINDS; k++) {
@@ -3461,6 +3474,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   // cell groups of the frequency-major keys: the ONE number both the keys (Lists::numajor) and the sort's key count are made of
   const int32_t r_ngroups = (e->sort_cellshift > 0) ? ((e->Mh.ngrid >> e->sort_cellshift) + 1) : e->Mh.ngrid;
   int32_t cnt[2 * NEXT_NKINDS];                        // host copy of the device counters
+  bool pool_reset_due = false;
   auto lists_for = [&](int self_kind) {
     Lists L;
     for (int k = 0; k < NEXT_NKINDS; k++) {
@@ -3487,10 +3501,29 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     HIP_TRY(hipGetLastError());
     if (errflag != 0) {
       g_last_error = "a kernel raised error flag " + std::to_string(errflag) + " (an assert_always of the reference would have fired)";
-      if (errflag == 46) g_last_error = "a cell's pool of on-demand macro-atom records is used up (error flag 46): raise ARTIS_AMD_MA_POOLFRAC (or ARTIS_AMD_MA_HOTFRAC)";
+      if (errflag == 46) g_last_error = "the pool of on-demand macro-atom records cannot hold a single record of this atomic data (error flag 46): raise ARTIS_AMD_MA_POOLFRAC (or ARTIS_AMD_MA_HOTFRAC)";
       (void)hipMemsetAsync(e->d_err, 0, sizeof(int32_t), s);
       return ARTIS_ERR_NOTCONVERGED;
     }
+    if (cnt[2 * NEXT_NKINDS - 1] != 0) {  // a lane found the pool of on-demand records used up (Env::ma_pool_full)
+      pool_reset_due = true;
+      HIP_TRY(hipMemsetAsync(e->d_count + (2 * NEXT_NKINDS - 1), 0, sizeof(int32_t), s));
+    }
+    return ARTIS_OK;
+  };
+  // The pool of on-demand records used up: the packets that wait for a record sit on the slow-path list (PEND_MA_FILL). Before that list's next
+  // launch -- after the thermal kernel has walked on with the records the last one filled -- the pool is emptied: every cold level of the resident
+  // cells is without a record again and is filled when next needed, exactly as after a tile's refill. Costs fills, never an answer.
+  auto reset_pool_if_due = [&](const Env &env_now) -> int {
+    if (!pool_reset_due || e->Mh.ncold <= 0) return ARTIS_OK;
+    pool_reset_due = false;
+    Env er = env_now;
+    er.fill_cells = nullptr;
+    const int64_t ncell = (int64_t)er.tile_hi - er.tile_lo;
+    hipLaunchKernelGGL(k_ma_reset, dim3(nblocks(ncell * e->Mh.ncold)), dim3(BLOCK), 0, s, er);
+    HIP_TRY(hipMemsetAsync(e->K.ma_pool_used, 0, sizeof(uint32_t), s));
+    e->last_pool_resets++;
+    if (e->trace) fprintf(stderr, "[artis_amd] the pool of on-demand records was used up: emptied (%lld)\n", (long long)e->last_pool_resets);
     return ARTIS_OK;
   };
   int rc = ARTIS_OK;
@@ -3603,6 +3636,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
         in.n[i] = cnt[tail_kinds[i]];
         HIP_TRY(hipMemsetAsync(e->d_count + tail_kinds[i], 0, sizeof(int32_t), s));
       }
+      rc = reset_pool_if_due(env);
+      if (rc != ARTIS_OK) return rc;
       HIP_TRY(hipEventRecord(e->ev0, s));
       hipLaunchKernelGGL(k_tail, dim3(nblocks(tail_n * 64)), dim3(BLOCK), 0, s, env, in, next, e->d_stats);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
@@ -3638,6 +3673,10 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
                          hi - lo, kind == NEXT_MA ? (env.cellest_n_t > 0 ? INT32_MAX : e->sort_maxpc_t)
                                                   : (env.cellest_n_r > 0 ? INT32_MAX : e->sort_maxpc_r),
                          (kind == NEXT_RPKT && r_nubins > 1 && e->sort_numajor) ? r_ngroups * r_nubins : 0);
+        if (rc != ARTIS_OK) return rc;
+      }
+      if (kind == NEXT_SLOW) {
+        rc = reset_pool_if_due(env);
         if (rc != ARTIS_OK) return rc;
       }
       // the kernel starts with an empty current list of its own kind: everything it keeps goes to the alternate list
@@ -3951,6 +3990,12 @@ int artis_amd_last_tiling_fills(artis_amd_engine *e, int64_t *sparse_fills, int6
   if (!e) return ARTIS_ERR_ARG;
   if (sparse_fills) *sparse_fills = e->last_sparse_fills;
   if (cells_filled) *cells_filled = e->last_cells_filled;
+  return ARTIS_OK;
+}
+
+int artis_amd_last_pool_resets(artis_amd_engine *e, int64_t *resets) {
+  if (!e) return ARTIS_ERR_ARG;
+  if (resets) *resets = e->last_pool_resets;
   return ARTIS_OK;
 }
 

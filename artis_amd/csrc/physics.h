@@ -202,6 +202,7 @@ struct Env {
   int32_t *vpkt_count;
   int32_t vpkt_cap;
   uint32_t ma_pool_cap;  // units (MAPOOL_UNIT slots) in DevCache::ma_pool (tables.h "ON-DEMAND RECORDS")
+  int32_t *ma_pool_full;  // set by a lane that found the pool used up: the host empties the pool before the next slow-path launch (the records are filled again on demand)
 #ifdef ARTIS_VISIT_COUNTS
   // (measurement build, tools/visit_sparsity.py) [cell][level] macro-atom transitions drawn in that level's record this call
   uint32_t *visit_counts;
@@ -3892,12 +3893,17 @@ AHD void ma_fill_record(const Env &env, int c, int ul) {
 // The record of cold level ul in cell c exists (true), or another lane is filling it right now (false: ask again). A level without one gets it
 // here: the lane claims the level's place in the cell's table, takes units of the pool, fills the record with the sequential forms and
 // publishes it. (The pool used up: error flag 46, *failed.)
-AHD bool ma_ensure_record(const Env &env, int c, int ul, bool *failed) {
+AHD bool ma_ensure_record(const Env &env, int c, int ul, bool *failed, bool *full = nullptr) {
   const DevModel &M = env.M;
   const LevelPack lpk = M.level_pack[ul];
   if (lpk.rec_off >= 0) return true;
   int32_t *tab = env.K.ma_rowtab + ((int64_t)c * M.ncold) + (-lpk.rec_off - 1);
   const uint32_t nunits = (uint32_t)((marec_slots(lpk.ndown, lpk.nup) + MAPOOL_UNIT - 1) / MAPOOL_UNIT);
+  if (nunits > env.ma_pool_cap) {  // a pool that cannot hold this one record: ARTIS_AMD_MA_POOLFRAC (artis_engine.hip names the remedy)
+    fail(env, 46);
+    *failed = true;
+    return false;
+  }
 #if defined(__HIP_DEVICE_COMPILE__)
   const int32_t v = ma_rowtab_load(tab);
   if (v >= 0) return true;
@@ -3905,9 +3911,11 @@ AHD bool ma_ensure_record(const Env &env, int c, int ul, bool *failed) {
   if (atomicCAS(tab, -1, -2) != -1) return false;  // claimed: exactly one lane goes on
   const uint32_t unit = atomicAdd(env.K.ma_pool_used, nunits);
   if (unit + nunits > env.ma_pool_cap) {
+    // the pool is used up: the level stays without a record, the packet waits on the slow-path list; the host empties the pool before that
+    // list's next launch (what the pool held is filled again when next needed, as after a tile's refill)
     __hip_atomic_store(tab, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    fail(env, 46);  // the pool is used up: ARTIS_AMD_MA_POOLFRAC (artis_engine.hip names the remedy)
-    *failed = true;
+    __hip_atomic_store(env.ma_pool_full, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (full) *full = true;
     return false;
   }
   __hip_atomic_store(tab, -((int32_t)unit + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (where ma_rec_of() finds it while it is filled)
@@ -3917,11 +3925,12 @@ AHD bool ma_ensure_record(const Env &env, int c, int ul, bool *failed) {
   return true;
 #else
   if (*tab >= 0) return true;
-  const uint32_t unit = *env.K.ma_pool_used;
+  uint32_t unit = *env.K.ma_pool_used;
   if (unit + nunits > env.ma_pool_cap) {
-    fail(env, 46);
-    *failed = true;
-    return false;
+    // (the host emulation is one thread: it empties the pool on the spot -- every cold level of every cell is without a record again)
+    for (int64_t i = 0; i < (int64_t)M.npts_nonempty * M.ncold; i++) env.K.ma_rowtab[i] = -1;
+    unit = 0;
+    if (env.ma_pool_full) *env.ma_pool_full += 1;
   }
   *env.K.ma_pool_used = unit + nunits;
   *tab = -((int32_t)unit + 3);
@@ -3936,9 +3945,10 @@ AHD bool ma_ensure_record(const Env &env, int c, int ul, bool *failed) {
 AHD void ma_slow_fill(const Env &env, Pkt &p) {
   const DevModel &M = env.M;
   p.pend = PEND_NONE;
-  bool failed = false;
-  (void)ma_ensure_record(env, M.propcell_nonemptymgi[p.cellindex], M.ion_uniquelevelindexstart[uion(M, p.ma_element, p.ma_ion)] + p.ma_level, &failed);
+  bool failed = false, full = false;
+  (void)ma_ensure_record(env, M.propcell_nonemptymgi[p.cellindex], M.ion_uniquelevelindexstart[uion(M, p.ma_element, p.ma_ion)] + p.ma_level, &failed, &full);
   if (failed) p.ma_level = -1;
+  if (full) p.pend = PEND_MA_FILL;  // (the pool is used up: the packet waits on the slow-path list for the emptied pool)
 }
 // A slow-path action of the active macro-atom reads its level's record. The record of a cold level may be gone by now: a tiled run refills
 // a tile (and empties the pool) while packets wait for it. true: it is there (again).
@@ -3969,11 +3979,17 @@ __device__ inline bool ma_slow_fill_claim(const Env &env, Pkt &p, int *c_out, in
   if (ma_rowtab_load(tab) != -1) return false;
   if (atomicCAS(tab, -1, -2) != -1) return false;
   const uint32_t nunits = (uint32_t)((marec_slots(lpk.ndown, lpk.nup) + MAPOOL_UNIT - 1) / MAPOOL_UNIT);
-  const uint32_t unit = atomicAdd(env.K.ma_pool_used, nunits);
-  if (unit + nunits > env.ma_pool_cap) {
+  if (nunits > env.ma_pool_cap) {
     __hip_atomic_store(tab, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     fail(env, 46);
     p.ma_level = -1;
+    return false;
+  }
+  const uint32_t unit = atomicAdd(env.K.ma_pool_used, nunits);
+  if (unit + nunits > env.ma_pool_cap) {  // (used up: ma_ensure_record())
+    __hip_atomic_store(tab, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(env.ma_pool_full, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.pend = PEND_MA_FILL;
     return false;
   }
   __hip_atomic_store(tab, -((int32_t)unit + 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -75,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_last_kernel_table",
     "artis_amd_options_preset",
     "artis_amd_allreduce_estimators", "artis_amd_comm_unique_id", "artis_amd_comm_init", "artis_amd_comm_count",
-    "artis_amd_cache_tiles", "artis_amd_last_tiling", "artis_amd_last_tiling_fills", "artis_amd_last_tiling_parked",
+    "artis_amd_cache_tiles", "artis_amd_last_tiling", "artis_amd_last_tiling_fills", "artis_amd_last_tiling_parked", "artis_amd_last_pool_resets",
 ]
 
 
@@ -173,8 +173,11 @@ class Engine:
         g = C.c_int64()
         self.L.artis_amd_last_tiling_parked.argtypes = [C.c_void_p] * 2
         self._check(self.L.artis_amd_last_tiling_parked(self.h, C.byref(g)))
+        r = C.c_int64()
+        self.L.artis_amd_last_pool_resets.argtypes = [C.c_void_p] * 2
+        self._check(self.L.artis_amd_last_pool_resets(self.h, C.byref(r)))
         return {"sweeps": a.value, "tile_fills": b.value, "fill_ms": c.value, "listed": d.value, "sparse_fills": e.value,
-                "cells_filled": f.value, "parked": g.value}
+                "cells_filled": f.value, "parked": g.value, "pool_resets": r.value}
 
     # estimator reduction in the C++ host layer (RCCL)
     COMM_ID_BYTES = 128

@@ -562,6 +562,10 @@ int artis_amd_last_tiling_fills(artis_amd_engine *eng, int64_t *sparse_fills, in
 /* ... and the packets that a visit of a tile left waiting in it for the tile's next visit instead of running them to their end in a
  * launch of their own (round 4: the last <= ARTIS_AMD_TAIL packets of a visit that began larger; ARTIS_AMD_TILE_PARK=0 switches it off) */
 int artis_amd_last_tiling_parked(artis_amd_engine *eng, int64_t *parked);
+/* On-demand macro-atom records (rows that hold static records for the lowest levels of every ion only: DESIGN.md section 2): how often the last
+ * artis_amd_update_packets_device call found the shared pool of the other levels' records used up and emptied it (the records are filled again
+ * when next needed: it costs fills, never an answer; the reference, which fills a level's rates on first use too, keeps them all: macroatom.cc:398-417) */
+int artis_amd_last_pool_resets(artis_amd_engine *eng, int64_t *resets);
 
 /* Per-kernel split of the last artis_amd_update_packets_device call: summed launch durations [ms] and summed
  * packet counts of the r-packet kernel (k_rpkt) and of the thermal kernels (k_ma + k_kpkt). */

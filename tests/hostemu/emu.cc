@@ -30,6 +30,7 @@ struct Emu {
   std::vector<float> expopac_kappa;
   std::vector<double> expopac_planck;
   bool expopac_own = false;
+  int32_t pool_resets = 0;  // times the pool of on-demand records was used up and emptied (Env::ma_pool_full)
   VpktConfig vpkt_config;
   int32_t err = 0;
 };
@@ -80,6 +81,8 @@ void setup(Emu &e, const artis_model *m, const artis_cellstate *cs, const artis_
   for (int64_t i = 0; i < ncell * (int64_t)M.ncold; i++) e.env.K.ma_rowtab[i] = -1;  // k_ma_reset: no cold level has a record yet
   if (M.ncold > 0) *e.env.K.ma_pool_used = 0;
   e.env.ma_pool_cap = (uint32_t)((ncell * (int64_t)M.ma_pool_slots) / MAPOOL_UNIT);
+  e.pool_resets = 0;
+  e.env.ma_pool_full = &e.pool_resets;  // (the emulation empties a used-up pool on the spot and counts it here: physics.h ma_ensure_record)
   e.stats.assign(ARTIS_NSTATS, 0);
   e.env.stats = e.stats.data();
   e.ws.assign((size_t)((M.nbfcontinua_ground + 1) * nslots), 0.);
@@ -293,6 +296,7 @@ int artis_emu_closest_transition(const double *nu, int nlines, double nu_cmf, in
   return artis::closest_transition(nu, nlines, nu_cmf, next_trans);
 }
 
+static int g_last_pool_resets = 0;
 int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, const artis_timestep *ts, artis_packet *packets,
                              int64_t npackets, artis_estimators *est, int budget) {
   Emu e;
@@ -363,8 +367,11 @@ int artis_emu_update_packets(const artis_model *m, const artis_cellstate *cs, co
   if (est && est->stats) est->stats[ARTIS_STAT_UPDATECELL] += e.env.M.npts_nonempty;
   if (est && est->Jb_lu_contribcount)
     for (size_t i = 0; i + 1 < e.lineest_count.size(); i++) est->Jb_lu_contribcount[i] += (int64_t)e.lineest_count[i];
+  g_last_pool_resets = e.pool_resets;
   return e.err;
 }
+// times the last artis_emu_update_packets() call found the pool of on-demand records used up and emptied it
+int artis_emu_last_pool_resets() { return g_last_pool_resets; }
 
 int artis_emu_cellcache(const artis_model *m, const artis_cellstate *cs, const artis_timestep *ts, int c, double *levelpops,
                         double *maprocessrates, double *matrans, double *allcont_nnlevel, double *allcont_departure,

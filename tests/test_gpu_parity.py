@@ -704,7 +704,7 @@ def test_on_demand_records_give_the_static_records_packets(engine_mod, monkeypat
     """On-demand macro-atom records (tables.h "ON-DEMAND RECORDS"; round 5): static records for the lowest 30 % of every ion's levels,
     the others filled in their cell's pool by the slow-path kernel when a packet first reaches them -- against the run with a static record
     for every level, on the bench grid with the bench's atomic data: every field of every packet, the generator states and the event
-    counters identical; estimators to summation order. Also through k_thermal_q, and with a pool too small (an error, not a wrong answer)."""
+    counters identical; estimators to summation order. Also through k_thermal_q, and with a pool too small (emptied whenever it is used up: the same packets)."""
     model, cs, ts, aux = synth.build("w7", ncoord=50)
     pk0 = synth.make_packets(model, aux, 400_000, seed_base=1281360349, kpkt_fraction=0.02)
     outs = []
@@ -733,9 +733,22 @@ def test_on_demand_records_give_the_static_records_packets(engine_mod, monkeypat
         parity.compare_packets(o[0], outs[0][0], 0.0, "on-demand records vs static records")
         parity.compare_stats(o[1], outs[0][1], "on-demand records vs static records")
         parity.compare_estimators(o[1], outs[0][1], 1e-10, "on-demand records vs static records")
+    # a pool too small for the cold records the packets reach is emptied whenever it is used up (the records are filled again when next
+    # needed, as after a tile's refill): the same packets, at the price of fills
     monkeypatch.setenv("ARTIS_AMD_MA_HOTFRAC", "0.1")
     monkeypatch.setenv("ARTIS_AMD_MA_POOLFRAC", "0.001")
     monkeypatch.delenv("ARTIS_AMD_REFILL", raising=False)
+    eng = engine_mod.Engine(model)
+    eng.set_cellstate(cs, ts)
+    p, e = pk0.copy(), abi.estimators_for(model, "classic")
+    eng.update_packets(p, e)
+    resets = eng.last_tiling()["pool_resets"]
+    eng.close()
+    assert resets >= 2, resets
+    parity.compare_packets(p, outs[0][0], 0.0, "on-demand records in a pool used up again and again vs static records")
+    parity.compare_stats(e, outs[0][1], "on-demand records in a pool used up again and again vs static records")
+    # ... and a pool that cannot hold one record is an error
+    monkeypatch.setenv("ARTIS_AMD_MA_POOLFRAC", "0")
     eng = engine_mod.Engine(model)
     eng.set_cellstate(cs, ts)
     with pytest.raises(Exception, match="pool"):

@@ -612,6 +612,19 @@ def test_macroatom_filters_decide_what_the_f64_comparison_decides():
     assert 0.25 * n <= namb.value < 0.3 * n, namb.value
 
 
+@pytest.mark.parametrize("options,preset,ncoord,npk", [("classic", "small", 8, 3000), ("nltenebular", "small", 6, 1500)])
+def test_kpkt_draws_by_bisection_bit_exact(oracle, monkeypatch, options, preset, ncoord, npk):
+    """ARTIS_AMD_COOLGUIDE=0: the two draws of a k-packet step by std::upper_bound's bisection (kpkt.cc:430-447, rounds 1-4) instead of by the
+    guide tables every other test of this file runs with: bit-exact against the oracle as well."""
+    monkeypatch.setenv("ARTIS_AMD_COOLGUIDE", "0")
+    model, cs, ts, aux = synth.build(preset, ncoord=ncoord, options=options)
+    pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=0.5)
+    pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+    parity.compare_packets(pb, pa, 0.0, "k-packet draws by bisection vs oracle")
+    parity.compare_stats(eb, ea, "k-packet draws by bisection vs oracle")
+    assert ea.stats[abi.STAT_X_KPKT_STEPS] > npk
+
+
 def test_cooling_guides_give_the_bisections_index():
     """tables.h "COOLING GUIDES": 2e5 random cumulative lists (equal neighbours, entries that add nothing, a dominant term in most) with guides
     of 1 ... 512 ranges; for random 24-bit draws and for the first and last draw of the ranges the guided look-up of do_kpkt() returns the
@@ -656,7 +669,16 @@ def test_on_demand_macroatom_records_bit_exact(oracle, monkeypatch, options, pre
         got, want = emu.cellcache(model, cs, ts, c), oracle.cellcache(model, cs, ts, c)
         for k in ("maprocessrates", "matrans"):
             assert np.array_equal(got[k], want[k]), k
-        # a pool that cannot hold the cold records the packets reach is an error, never a wrong answer
+        # a pool that cannot hold the cold records the packets reach is emptied when it is used up and filled again on demand: it costs fills,
+        # never an answer
         monkeypatch.setenv("ARTIS_AMD_MA_POOLFRAC", "0.02")
+        pa, pb, ea, eb = _run_both(oracle, model, cs, ts, pk0, 3, options=options)
+        parity.compare_packets(pb, pa, 0.0, "on-demand records in a pool that is used up again and again vs oracle")
+        parity.compare_stats(eb, ea, "on-demand records in a pool that is used up again and again vs oracle")
+        L = emu.lib()
+        L.artis_emu_last_pool_resets.restype = __import__("ctypes").c_int
+        assert L.artis_emu_last_pool_resets() > 3
+        # ... and one that cannot hold a single record of the level a packet reaches is an error
+        monkeypatch.setenv("ARTIS_AMD_MA_POOLFRAC", "0")
         with pytest.raises(RuntimeError, match="46"):
             _run_both(oracle, model, cs, ts, pk0, 3, options=options)
