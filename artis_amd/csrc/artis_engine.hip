@@ -1947,6 +1947,9 @@ struct TailLists {
 #ifndef ARTIS_SLOW_WAVE_FB
 #define ARTIS_SLOW_WAVE_FB 1  // free-bound emission frequencies selected by the wave (physics.h FbSel) in k_slow and k_tail
 #endif
+#ifndef ARTIS_TAIL_WAVE_CHI
+#define ARTIS_TAIL_WAVE_CHI 1  // k_tail: the continuum opacity of a step evaluated by the wave (physics.h chi_rpkt_cont_wave); 0: by the packet's lane
+#endif
 #ifndef ARTIS_SLOW_WAVE_FB_MAX
 #define ARTIS_SLOW_WAVE_FB_MAX 6  // ... in k_slow for waves with at most this many emissions
 #endif
@@ -2035,22 +2038,37 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
       tp[0] += clock64() - tps0;
 #endif
     } else if (kind_w == NEXT_RPKT) {
-      if (owner) {
-        Chi x;
-        chi_load(env.P, pi, p, x);
-        bool go = rpkt_can_continue(p, ts_end);
+      // every lane runs the loop over the packet's steps; before a step that evaluates the continuum opacity (do_rpkt_step()'s own conditions:
+      // rpkt_step_evaluates_chi) the WAVE evaluates it -- the window's kept continua side by side, their terms added by the packet's lane in
+      // the sequential loop's order (physics.h chi_bf_gammacontr_wave) -- and the step finds it in the packet's cache
+      Chi x;
+      if (owner) chi_load(env.P, pi, p, x);
+      bool go = owner && rpkt_can_continue(p, ts_end);
 #ifdef ARTIS_PROFILE_TAIL
-        const long long tpr0 = clock64();
-        while (go) {
-          go = rpkt_iter(env, p, pi, x);
-          tp_n[0]++;
-        }
-        tp[1] += clock64() - tpr0;
-#else
-        while (go) go = rpkt_iter(env, p, pi, x);
+      const long long tpr0 = clock64();
 #endif
-        chi_store(env.P, pi, p, x);
+      while (__builtin_amdgcn_readfirstlane(__shfl((int)go, 0)) != 0) {
+#if ARTIS_TAIL_WAVE_CHI
+        int cc = 0;
+        const bool need = go && rpkt_step_evaluates_chi(env, p, x, &cc);
+        if (__builtin_amdgcn_readfirstlane(__shfl((int)need, 0)) != 0) {
+          const int cw = __builtin_amdgcn_readfirstlane(__shfl(cc, 0));
+          const double nuw = wave_bcast(p.nu_cmf, 0);
+          const int piw = __builtin_amdgcn_readfirstlane(__shfl(pi, 0));
+          chi_rpkt_cont_wave(env, nuw, x, cw, (int64_t)piw, owner);
+        }
+#endif
+        if (go) {
+          go = rpkt_iter(env, p, pi, x);
+#ifdef ARTIS_PROFILE_TAIL
+          tp_n[0]++;
+#endif
+        }
       }
+#ifdef ARTIS_PROFILE_TAIL
+      tp[1] += clock64() - tpr0;
+#endif
+      if (owner) chi_store(env.P, pi, p, x);
     } else if (kind_w == NEXT_MA || kind_w == NEXT_KPKT) {
       if (owner) {
         MACtx k = ma_ctx(env, p);

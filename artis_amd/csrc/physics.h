@@ -3050,6 +3050,113 @@ __device__ inline void fbsel_wave(const Env &env, FbSel &sel) {
   }
   sel.mode = 2;
 }
+
+// The continuum opacity of ONE packet evaluated by its WAVE (the tail kernel: a packet per wave, 63 idle lanes; round 5: an r-packet step of the
+// nltenebular tail is 269 000 clocks, most of them this sum by one lane). chi_bf_gammacontr<false>() with the kept continua of the window side by
+// side -- lane j the (base + j)-th: the same reads and the same arithmetic as add_term() -- and then what the sequential loop does with a
+// continuum's contribution IN ITS ORDER: the packet's lane adds the terms one after the other (rpkt.cc:808: the same additions in the same order,
+// the same bits) and keeps the ground continua's list. All lanes call with lane 0's arguments (owner: lane 0 holds the packet).
+__device__ inline double chi_bf_gammacontr_wave(const Env &env, int c, double nu, int64_t slot, Chi *keep, bool owner) {
+  const DevModel &M = env.M;
+  const int lane = (int)(threadIdx.x & 63);
+  double sum = 0.;
+  int ng = 0;
+#if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
+  int lastgi = -1;
+  double *wsv = env.gamma_ws + (slot * M.nbfcontinua_ground);
+  int32_t *wsi = env.gamma_gi + (slot * M.nbfcontinua_ground);
+#endif
+  const float T_e = env.C.Te[c];
+  const double ex = exp(-HOVERKB * nu / T_e);
+  const bool split_usable = (ex >= DBLMIN);
+  const int cend = upper_bound_d(M.allcont_nu_edge, M.nbfcontinua, nu);
+  const int cbegin = lower_bound_d(M.allcont_nu_edge, cend, nu / M.last_phixs_nuovernuedge);
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+  if (owner && keep != nullptr) {
+    keep->bf_begin = cbegin;
+    keep->bf_end = cend;
+  }
+#else
+  (void)keep;
+#endif
+  const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
+  int r0 = 0, r1 = 0;
+  if (cbegin < cend) kept_range(env, c, cbegin, cend, r0, r1);
+  const int32_t *keptlist = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
+  const D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * M.nbfcontinua);
+  for (int base = r0; base < r1; base += 64) {
+    const int n = (r1 - base < 64) ? r1 - base : 64;
+    double sigma_contr = 0., term = 0.;
+    int gi = -1;
+    if (lane < n) {
+      const int i = keptlist[base + lane];
+      const D2 pr = keptpair[base + lane];
+      const ContPack cpk = M.cont_pack[i];
+      const PhixsRead xrk = phixs_lookup_u(M, M.allphixs + cpk.xs_off, cpk.nu_edge, nu);
+      const double nu_edge = cpk.nu_edge;
+      const double sigma_bf = phixs_finish(M, xrk, nu_edge, nu);
+      double stim;
+      if (pr.y >= 0. && split_usable) {
+        stim = pr.y * ex;
+      } else {
+        stim = departure[i] * exp(-HOVERKB * (nu - nu_edge) / T_e);
+      }
+      const double corr = dmax(0., 1 - stim);
+      sigma_contr = sigma_bf * cpk.probability * corr;
+      term = pr.x * sigma_contr;
+      gi = cpk.gi;
+    }
+    for (int k = 0; k < n; k++) {  // (k is wave-uniform: the lane index of a v_readlane)
+      const double tk = wave_bcast(term, k);
+#if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
+      const double sk = wave_bcast(sigma_contr, k);
+      const int gk = __builtin_amdgcn_readlane(gi, k);
+      if (owner && gk >= 0) {
+        if (gk == lastgi) {
+          wsv[ng - 1] = sk;
+        } else {
+          wsv[ng] = sk;
+          wsi[ng] = gk;
+          ng++;
+          lastgi = gk;
+        }
+      }
+#endif
+      sum += tk;
+    }
+  }
+  if (owner) {
+    env.gamma_n[slot] = ng;
+    ARTIS_STAT(env, ARTIS_STAT_X_CHI_EVALS);
+    ARTIS_STAT_ADD(env, ARTIS_STAT_X_CONT_VISITED, r1 - r0);
+    if (!isfinite(sum)) fail(env, 30);
+  }
+  return sum;
+}
+// whether the coming do_rpkt_step() of this r-packet evaluates the continuum opacity (its own conditions, in its order: a step that begins on a
+// cell boundary changes cell and returns; an empty or grey cell has no continuum opacity; chi_rpkt_cont()'s cache test) -- and in which cell
+AHD bool rpkt_step_evaluates_chi(const Env &env, const Pkt &p, const Chi &x, int *c_out) {
+  const int c = env.M.propcell_nonemptymgi[p.cellindex];
+  *c_out = c;
+  if (c < 0 || env.C.thick[c] == ARTIS_CELL_THICK) return false;
+  int next_cell = -1;
+  if (boundary_distance(env, p, &next_cell) == 0) return false;
+  return !((c == x.nonemptymgi) && (fabs((x.nu / p.nu_cmf) - 1.0) < 1e-4));
+}
+// chi_rpkt_cont() by the wave, for lane 0's packet; leaves x as chi_rpkt_cont() would (the step's own call then finds it evaluated)
+__device__ inline void chi_rpkt_cont_wave(const Env &env, double nu_cmf, Chi &x, int c, int64_t slot, bool owner) {
+  const double chi_bf = chi_bf_gammacontr_wave(env, c, nu_cmf, slot, &x, owner);
+  if (owner) {
+    const float nne = env.C.nne[c];
+    const float cnne = env.C.nne[c] * env.C.clumpfactor[c];
+    const float T_e = env.C.Te[c];
+    x.chi_freefree_heat = env.K.chi_ff_nnionpart[c] / pow3(nu_cmf) * cnne * (1 - exp(-HOVERKB * nu_cmf / T_e));
+    x.chi_escatter = SIGMA_T * nne;
+    x.chi_boundfree = chi_bf;
+    x.nonemptymgi = c;
+    x.nu = nu_cmf;
+  }
+}
 #endif
 
 
