@@ -139,7 +139,9 @@ struct DevModel {
   // (rec_off = -(cold index) - 1) gets a record in the POOL -- one for all resident cells: DevCache::ma_pool, ma_pool_slots slots per resident
   // cell on average, handed out in units of 128 bytes (MAPOOL_UNIT) -- when a packet first reaches it in a cell: the slow-path kernel fills it with the
   // sequential forms of the population (the same terms added in the same order: the same bits), and DevCache::ma_rowtab[cell][cold index]
-  // says where it is. ncold == 0: every level has a static record (the default whenever the whole cache fits one tile).
+  // says where it is. A pool that is used up is emptied by the host before the slow-path list's next launch (Env::ma_pool_full; every cold level
+  // is then without a record again and is filled when next needed, as after a tile's refill): it costs fills, never an answer.
+  // ncold == 0: every level has a static record (the default whenever the whole cache fits one tile).
   int32_t ncold, ma_pool_slots;
   // [nlevels] the entry of the cooling list that holds the running sum after the level's collisional excitations (-1: no upward transitions)
   const int32_t *level_coolhi;
