@@ -2143,6 +2143,9 @@ __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, in
   if (mine) {
     pi = list[tid];
     pkt_load(env.P, pi, p);
+#ifdef ARTIS_PROFILE_SLOW
+    atomicAdd(&lstats[48 + (p.pend < 9 ? p.pend : 9)], (stat_t)1);  // (-DARTIS_PROFILE_SLOW: the slow-path visits by kind of pending action, stats slots 48..57)
+#endif
   }
 #if ARTIS_SLOW_WAVE_FB
   {
