@@ -3671,7 +3671,15 @@ AHD int mafilt_count_between(const U4 &f, int lo, int hi, bool *amb) {
 // comparison "value <= z * whole" can differ from the exact one. *amb: some entry has q == zi or q == zi - 1. Two counts
 // instead of two tests per entry: the entries with q <= zi - 2 are counted, and the filter is ambiguous iff more entries
 // have q <= zi. An entry that is not to be counted at all holds 0x7FFF (it can only turn a draw with zi = 32767 ambiguous).
-AHD int mafilt_count(const U4 &f, int zi, bool *amb) { return mafilt_count_between(f, (zi - 2 > -1) ? zi - 2 : -1, zi, amb); }
+// Round 5: the draw's nine bits below zi decide half of those. z * 32768 = zi + sub / 512 (sub = u & 511), so an entry with q == zi - 1
+// has fraction * 32768 < zi <= z * 32768 - sub / 512: with sub >= 2 the fraction lies below z by at least 2^-23 = 1.2e-7 of the whole -- a
+// margin of the size the other side's proof (6e-8) already relies on -- and the entry is counted. The lower bound of the count is therefore
+// ((u - 2) >> 9) - 1: zi - 1 where sub >= 2, zi - 2 otherwise. Undecided draws fall from ~2n to ~n of 32768 for a direction of n transitions
+// (with 4e5 lines 83 % of the slow path's visits were such searches: profiles/r05/slow_path_cd23like.txt).
+AHD int mafilt_count(const U4 &f, uint32_t u, bool *amb) {
+  const int zi = (int)(u >> 9), lo = (((int)u - 2) >> 9) - 1;
+  return mafilt_count_between(f, (lo > -1) ? lo : -1, zi, amb);
+}
 // After every rate of a cell's records is final (populate_macroatom): the action filter of one level's record
 AHD void populate_mafilter_level(const Env &env, int c, int ul) {
   const DevModel &M = env.M;
@@ -3761,12 +3769,11 @@ AHD int ma_search_filters(const Env &env, const MACtx &k, const U4 *rec, int dir
   const int nsearch = ((dir != MADIR_UP) ? k.nd : k.nu) - 1;
   *amb = false;
   if (nsearch <= 0) return 0;
-  const int zi = (int)(u >> 9);
   bool a = env.ma_filters_off != 0;
   int ti = 0;
   for (int b0 = 0; b0 < nsearch && !a; b0 += MAREC_PER) {
     const U4 f = (b0 == 0 && first0 != nullptr) ? *first0 : rec[marec_slot(dir, b0 / MAREC_PER, k.nd, k.nu)];
-    const int cnt = mafilt_count(f, zi, &a);
+    const int cnt = mafilt_count(f, u, &a);
     a = a || (f.w[3] >> 16) != MAFILT_NONE;
     if (a) break;
     ti += cnt;
@@ -3863,7 +3870,7 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
     const uint32_t u1 = rng_u24(p);
     const int zi = (int)(u1 >> 9);  // = (int)(zrand * 32768): zrand = u1 * 2^-24
     bool amb;
-    action = mafilt_count(f, zi, &amb);
+    action = mafilt_count(f, u1, &amb);
     // ("cum[8] = total <= zrand * total" never holds: zrand <= 1 - 2^-24, and the product of that with total is below total)
     amb = amb || !usable || env.ma_filters_off != 0;
     if (amb) {

@@ -73,7 +73,8 @@ struct alignas(32) ContPack {
 // q <= fraction * 32768 <= q + 1: with zi = floor(z * 32768) (the top 15 bits of the 24-bit draw), zi >= q + 2 proves
 // value <= z * whole and zi <= q - 1 proves the opposite, by margins of 3e-5 and 6e-8 of the whole against f64 rounding errors
 // of 1e-16 (physics.h mafilt_count). Anything in between (q == zi or zi - 1: 5e-4 of the draws per decision) is decided on
-// f64 values -- same random numbers, same result. 15 bits, so that two entries are compared by ONE 32-bit subtraction.
+// f64 values -- same random numbers, same result. (Round 5: the draw's nine bits below zi also settle q == zi - 1 unless they are 0 or 1:
+// half as many undecided draws, physics.h mafilt_count.) 15 bits, so that two entries are compared by ONE 32-bit subtraction.
 // What a transition needs to know about the level it leads to (static, one 16-byte load from DevModel::alltrans_target): where
 // the target's record is in a cell's row (slots), its first entry in alltrans, its index within the ion, its transition counts.
 struct alignas(16) MaTarget {

@@ -196,7 +196,7 @@ int64_t artis_emu_mafilter_selftest(int64_t ntrials, uint64_t seed, int64_t *n_a
     U4 f;
     for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
     bool amb = false;
-    const int cnt = mafilt_count(f, (int)(u >> 9), &amb);
+    const int cnt = mafilt_count(f, u, &amb);
     if (amb) {
       namb++;
       continue;
