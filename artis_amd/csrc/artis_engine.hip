@@ -3650,13 +3650,17 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       }
       // the last packets of these kinds: one launch carries each through all its remaining alternations (k_tail)
       const int32_t nr = (int32_t)tail_n, nt = 0;
-      const Lists next = lists_for(0);  // the four current lists are consumed whole; nothing is appended to them
+      // the four current lists are consumed whole, and no packet comes back to them -- but for one case: a packet that waits for a record of a
+      // pool that is used up leaves for the slow-path list (k_tail "waits"). That entry must not land in a buffer other waves still read their
+      // packets from: the slow-path kind is the launch's own kind, its entries go to the ALTERNATE slow-path list, which becomes the current one.
+      const Lists next = lists_for(NEXT_SLOW);
       TailLists in;
       for (int i = 0; i < 4; i++) {
         in.list[i] = e->d_lists[tail_kinds[i]][cur[tail_kinds[i]]];
         in.n[i] = cnt[tail_kinds[i]];
         HIP_TRY(hipMemsetAsync(e->d_count + tail_kinds[i], 0, sizeof(int32_t), s));
       }
+      HIP_TRY(hipMemsetAsync(e->d_count + NEXT_NKINDS, 0, sizeof(int32_t), s));
       rc = reset_pool_if_due(env);
       if (rc != ARTIS_OK) return rc;
       HIP_TRY(hipEventRecord(e->ev0, s));
@@ -3671,6 +3675,10 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       HIP_TRY(hipEventRecord(e->ev1, s));
       rc = read_counts();
       if (rc != ARTIS_OK) return rc;
+      // (the alternate slow-path list becomes the current one, as after a launch of the slow-path kernel)
+      cur[NEXT_SLOW] = 1 - cur[NEXT_SLOW];
+      cnt[NEXT_SLOW] = cnt[NEXT_NKINDS];
+      HIP_TRY(hipMemcpyAsync(e->d_count + NEXT_SLOW, e->d_count + NEXT_NKINDS, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
       float ms = 0.f;
       HIP_TRY(hipEventElapsedTime(&ms, e->ev0, e->ev1));
       e->kms_tail += ms;

@@ -756,6 +756,41 @@ def test_on_demand_records_give_the_static_records_packets(engine_mod, monkeypat
     eng.close()
 
 
+@pytest.mark.parametrize("options", ["classic", "nltenebular"])
+def test_pool_used_up_under_the_tail_kernel_gives_the_static_records_packets(engine_mod, monkeypatch, options):
+    """The pool of on-demand records used up while the TAIL kernel holds the packets (ARTIS_AMD_TAIL above the population: every packet is a
+    tail packet from the start): a packet that waits for a record leaves the kernel for the slow-path list -- into the list's ALTERNATE buffer,
+    not into the one other waves still read their packets from (round 5: found by tools/r05_determinism.py as packets that never finished their
+    timestep) -- the host empties the pool, the tail takes the packets up again. Two timesteps, against static records: identical."""
+    model, cs, ts, aux = synth.build("small", ncoord=8, options=options, nts=13)
+    pk0 = synth.make_packets(model, aux, 30000, kpkt_fraction=0.2, gamma_fraction=0.1, pellet_fraction=0.2)
+    outs = []
+    for cfg in ({"ARTIS_AMD_MA_HOTFRAC": "1"}, {"ARTIS_AMD_MA_HOTFRAC": "0.3", "ARTIS_AMD_MA_POOLFRAC": "0.02", "ARTIS_AMD_TAIL": "40000"},
+                {"ARTIS_AMD_MA_HOTFRAC": "0.3", "ARTIS_AMD_MA_POOLFRAC": "0.02"}):
+        for k in ("ARTIS_AMD_MA_HOTFRAC", "ARTIS_AMD_MA_POOLFRAC", "ARTIS_AMD_TAIL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in cfg.items():
+            monkeypatch.setenv(k, v)
+        eng = engine_mod.Engine(model, preset=options)
+        p, est = pk0.copy(), abi.estimators_for(model, options)
+        eng.upload_packets(p)
+        t, resets = aux["t"], 0
+        for step in range(2):
+            tsn = synth.make_timestep(t, width_frac=0.05, vmax=model["vmax"], nts=12 + step)
+            eng.set_cellstate(cs, tsn)
+            eng.step()
+            resets += eng.last_tiling()["pool_resets"]
+            t = tsn.c.start + tsn.c.width
+        eng.download_packets(p)
+        eng.download_estimators(est)
+        eng.close()
+        outs.append((p, est, resets))
+    assert outs[0][2] == 0 and outs[1][2] >= 2 and outs[2][2] >= 2, [o[2] for o in outs]
+    for o in outs[1:]:
+        parity.compare_packets(o[0], outs[0][0], 0.0, "pool used up (tail kernel / split kernels) vs static records")
+        parity.compare_stats(o[1], outs[0][1], "pool used up (tail kernel / split kernels) vs static records")
+
+
 def test_budget_independence_on_device(engine_mod, monkeypatch):
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
     pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.3)
