@@ -791,6 +791,33 @@ def test_pool_used_up_under_the_tail_kernel_gives_the_static_records_packets(eng
         parity.compare_stats(o[1], outs[0][1], "pool used up (tail kernel / split kernels) vs static records")
 
 
+def test_repeated_runs_give_identical_packets(engine_mod):
+    """The same two timesteps three times over on fresh engines: every named field of every packet identical between the runs. Work-pulling,
+    atomics and list order make the ORDER of the work different from run to run; a packet's history must not notice (its own generator, its own
+    record). Both defects of round 5 that lost a packet now and then -- a sort key beyond the histogram, an entry appended to a list other waves
+    still read -- showed up here (tools/r05_determinism.py) before anywhere else."""
+    model, cs, ts, aux = synth.build("small", ncoord=8, nts=13)
+    pk0 = synth.make_packets(model, aux, 30000, kpkt_fraction=0.2, gamma_fraction=0.1, pellet_fraction=0.2)
+    runs = []
+    for _ in range(3):
+        eng = engine_mod.Engine(model)
+        p = pk0.copy()
+        eng.upload_packets(p)
+        t = aux["t"]
+        for step in range(2):
+            tsn = synth.make_timestep(t, width_frac=0.05, vmax=model["vmax"], nts=12 + step)
+            eng.set_cellstate(cs, tsn)
+            eng.step()
+            t = tsn.c.start + tsn.c.width
+        eng.download_packets(p)
+        eng.close()
+        runs.append(p)
+    for r in runs[1:]:
+        parity.compare_packets(r, runs[0], 0.0, "a repeated run vs the first")
+    assert np.count_nonzero(runs[0]["prop_time"] < tsn.c.start + tsn.c.width * (1 - 1e-12)) == np.count_nonzero(
+        (runs[0]["prop_time"] < tsn.c.start + tsn.c.width * (1 - 1e-12)) & (runs[0]["type"] != abi.TYPE_RPKT)), "an r-packet stopped before the end of the timestep"
+
+
 def test_budget_independence_on_device(engine_mod, monkeypatch):
     model, cs, ts, aux = synth.build("tiny", ncoord=6)
     pk0 = synth.make_packets(model, aux, 20000, kpkt_fraction=0.3)
