@@ -160,7 +160,8 @@ extern "C" {
 // Property check of the macro-atom filters (tables.h "FILTERS") on the functions the kernels use: for cumulative lists of 8
 // values and 24-bit draws u, whenever mafilt_count() does not call the draw ambiguous its count equals the number of values
 // <= (double)(u * 2^-24f) * whole, the comparison the f64 path makes. Every fourth trial puts a value within a few ulp of
-// z * whole (the cases the margins exist for). Returns the number of mismatches; *n_ambiguous: draws left to the f64 path.
+// z * whole (the cases the margins exist for); another fourth a value within a few ulp of the lower edge of the draw's filter cell, with
+// a draw 0 ... 4 units of 2^-24 above that edge (the bound of the rule that counts an entry one unit below the draw's). Returns the number of mismatches; *n_ambiguous: draws left to the f64 path.
 int64_t artis_emu_mafilter_selftest(int64_t ntrials, uint64_t seed, int64_t *n_ambiguous) {
   using namespace artis;
   uint64_t s = seed ? seed : 1;
@@ -176,7 +177,10 @@ int64_t artis_emu_mafilter_selftest(int64_t ntrials, uint64_t seed, int64_t *n_a
       v[j] = run;
     }
     const double whole_raw = (v[7] > 0.) ? v[7] : 1.;
-    const uint32_t u = (uint32_t)(next() >> 40);  // 24 bits
+    uint32_t u = (uint32_t)(next() >> 40);  // 24 bits
+    // every fourth trial (t & 3 == 1): a draw whose nine bits below the filter's resolution are 0 ... 4 -- the cases around the bound of
+    // mafilt_count()'s round-5 rule (an entry one unit below zi is counted where those bits are >= 2) ...
+    if ((t & 3) == 1) u = (u & ~0x1FFu) | (uint32_t)(next() % 5);
     const double z = (double)rng_u24_value(u);
     double whole = whole_raw * scale;
     for (int j = 0; j < 8; j++) v[j] *= scale;
@@ -186,6 +190,15 @@ int64_t artis_emu_mafilter_selftest(int64_t ntrials, uint64_t seed, int64_t *n_a
       const int k = (int)(next() % 5) - 2;
       for (int i = 0; i < (k < 0 ? -k : k); i++) x = std::nextafter(x, k < 0 ? 0. : 2. * whole);
       v[j] = x;  // ... kept non-decreasing by moving the neighbours it passes
+      for (int i = 0; i < j; i++) v[i] = (v[i] < x) ? v[i] : x;
+      for (int i = j + 1; i < 7; i++) v[i] = (v[i] > x) ? v[i] : x;
+    }
+    if ((t & 3) == 1 && (u >> 9) > 0) {  // ... with a value within a few ulp of the edge of the filter cell just below the draw's: zi / 32768 * whole
+      const int j = (int)(next() % 7);
+      double x = ((double)(u >> 9) / MAFILT_SCALE) * whole;
+      const int k = (int)(next() % 7) - 3;
+      for (int i = 0; i < (k < 0 ? -k : k); i++) x = std::nextafter(x, k < 0 ? 0. : 2. * whole);
+      v[j] = x;
       for (int i = 0; i < j; i++) v[i] = (v[i] < x) ? v[i] : x;
       for (int i = j + 1; i < 7; i++) v[i] = (v[i] > x) ? v[i] : x;
     }
