@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 STAT_X_VPKT_CREATED = 48  # then _ESC_RPKT, _ESC_KPKT, _ESC_MA (include/artis_amd.h ARTIS_STAT_X_VPKT_*)
-ABI_VERSION = 5  # artis_amd_abi_version() of the library these ctypes structs describe (include/artis_amd.h)
+ABI_VERSION = 6  # artis_amd_abi_version() of the library these ctypes structs describe (include/artis_amd.h)
 NSTATS = 64
 NSCALARS = 11  # ARTIS_SCALAR_* of include/artis_amd.h
 SCALAR_NAMES = ["gamma_dep_discrete", "nt_energy_deposited", "pellet_decays", "gamma_emission", "positron_emission",

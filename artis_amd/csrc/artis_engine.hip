@@ -200,6 +200,7 @@ __device__ inline MaEntryPos ma_entry_pos(const DevModel &M, int a0, int e) {
 __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
   __shared__ double lds_v[BLOCK / 64][3][MATRANS_BLOCK];          // the terms, then the running sums
   __shared__ uint16_t lds_q[BLOCK / 64][2][MATRANS_BLOCK];        // filter entries: internal, radiative
+  __shared__ uint8_t lds_qf[BLOCK / 64][MATRANS_BLOCK];           // ... the internal entries' fine bytes (tables.h "FINE BYTES")
   __shared__ uint8_t lds_ok[BLOCK / 64][2][MATRANS_BLOCK];        // per filter line (at its first entry): every entry a finite fraction
   const int64_t wave = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -295,12 +296,13 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
     const int e_last = ps.e_seg0 + ps.seglen - 1;
     const double whole_int = v[ps.isdown ? 2 : 0][e_last], whole_rad = v[0][e_last];
     bool ok_int = (whole_int > 0.) && (whole_int <= DBLMAX), ok_rad = (whole_rad > 0.) && (whole_rad <= DBLMAX);
-    uint32_t q_int = MAFILT_NONE, q_rad = MAFILT_NONE;
+    uint32_t q_int = MAFILT_NONE23, q_rad = MAFILT_NONE;
     if (ps.ti < ps.seglen - 1) {
-      if (ok_int) q_int = mafilt_quant(v[ps.isdown ? 2 : 0][e], whole_int, &ok_int);
+      if (ok_int) q_int = mafilt_quant23(v[ps.isdown ? 2 : 0][e], whole_int, &ok_int);
       if (ok_rad && ps.isdown) q_rad = mafilt_quant(v[0][e], whole_rad, &ok_rad);
     }
-    lds_q[w][0][e] = (uint16_t)q_int;
+    lds_q[w][0][e] = (uint16_t)(q_int >> 8);
+    lds_qf[w][e] = (uint8_t)(q_int & 0xFFu);
     lds_q[w][1][e] = (uint16_t)q_rad;
     const int e_line = e - (ps.ti % MAREC_PER);
     if (!ok_int) lds_ok[w][0][e_line] = 0;
@@ -316,6 +318,8 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
     const bool lok_int = lds_ok[w][0][e_line] != 0;
     U4 *line = rec + marec_slot(ps.isdown ? MADIR_DOWN : MADIR_UP, ps.ti / MAREC_PER, ps.lpk.ndown, ps.lpk.nup);
     mafilt_put(line, ps.ti % MAREC_PER, lok_int ? lds_q[w][0][e] : 0u);
+    ((uint8_t *)rec)[marec_fine_byte0(ps.isdown ? MADIR_DOWN : MADIR_UP, ps.ti / MAREC_PER, ps.lpk.ndown, ps.lpk.nup) + (ps.ti % MAREC_PER)] =
+        lok_int ? lds_qf[w][e] : (uint8_t)0u;
     if (ps.ti % MAREC_PER == 0) mafilt_put(line, 7, lok_int ? MAFILT_NONE : 0u);  // the line's "usable" mark
     if (ps.isdown) {
       const bool lok_rad = lds_ok[w][1][e_line] != 0;
@@ -427,9 +431,9 @@ __global__ void __launch_bounds__(BLOCK) k_mafilter_long(Env env) {
       }
     }
     bool ok_int = (whole_int > 0.) && (whole_int <= DBLMAX), ok_rad = (whole_rad > 0.) && (whole_rad <= DBLMAX);
-    uint32_t q_int = MAFILT_NONE, q_rad = MAFILT_NONE;
+    uint32_t q_int = MAFILT_NONE23, q_rad = MAFILT_NONE;
     if (valid && ti < seg.n - 1) {
-      if (ok_int) q_int = mafilt_quant(sa, whole_int, &ok_int);
+      if (ok_int) q_int = mafilt_quant23(sa, whole_int, &ok_int);
       if (ok_rad && down) q_rad = mafilt_quant(sb, whole_rad, &ok_rad);
     }
     const unsigned long long bad_int = __ballot(valid && !ok_int), bad_rad = __ballot(valid && down && !ok_rad);
@@ -437,7 +441,7 @@ __global__ void __launch_bounds__(BLOCK) k_mafilter_long(Env env) {
       const unsigned long long mine = line_lanes(lane, ti, seg.n);  // (63 lanes = nine whole lines: lane % 7 == ti % 7)
       const bool lok_int = (bad_int & mine) == 0ull, lok_rad = (bad_rad & mine) == 0ull;
       U4 *line = rec + marec_slot(down ? MADIR_DOWN : MADIR_UP, ti / MAREC_PER, lpk.ndown, lpk.nup);
-      mafilt_put(line, ti % MAREC_PER, lok_int ? q_int : 0u);
+      mafilt_put23(rec, down ? MADIR_DOWN : MADIR_UP, ti, lpk.ndown, lpk.nup, lok_int ? q_int : 0u);
       if (ti % MAREC_PER == 0) mafilt_put(line, 7, lok_int ? MAFILT_NONE : 0u);
       if (down) {
         U4 *rline = rec + marec_slot(MADIR_RAD, ti / MAREC_PER, lpk.ndown, lpk.nup);
@@ -470,9 +474,9 @@ __device__ inline double wave_prefix_inorder(double t, double carry, int n, int 
 __device__ inline void wave_put_dirfilters(U4 *rec, const LevelPack &lpk, bool down, int n, int ti, bool valid, double s_int, double s_rad,
                                            double whole_int, double whole_rad, int lane) {
   bool ok_int = (whole_int > 0.) && (whole_int <= DBLMAX), ok_rad = (whole_rad > 0.) && (whole_rad <= DBLMAX);
-  uint32_t q_int = MAFILT_NONE, q_rad = MAFILT_NONE;
+  uint32_t q_int = MAFILT_NONE23, q_rad = MAFILT_NONE;
   if (valid && ti < n - 1) {
-    if (ok_int) q_int = mafilt_quant(s_int, whole_int, &ok_int);
+    if (ok_int) q_int = mafilt_quant23(s_int, whole_int, &ok_int);
     if (ok_rad && down) q_rad = mafilt_quant(s_rad, whole_rad, &ok_rad);
   }
   const unsigned long long bad_int = __ballot(valid && !ok_int), bad_rad = __ballot(valid && down && !ok_rad);
@@ -480,7 +484,7 @@ __device__ inline void wave_put_dirfilters(U4 *rec, const LevelPack &lpk, bool d
     const unsigned long long mine = line_lanes(lane, ti, n);
     const bool lok_int = (bad_int & mine) == 0ull, lok_rad = (bad_rad & mine) == 0ull;
     U4 *line = rec + marec_slot(down ? MADIR_DOWN : MADIR_UP, ti / MAREC_PER, lpk.ndown, lpk.nup);
-    mafilt_put(line, ti % MAREC_PER, lok_int ? q_int : 0u);
+    mafilt_put23(rec, down ? MADIR_DOWN : MADIR_UP, ti, lpk.ndown, lpk.nup, lok_int ? q_int : 0u);
     if (ti % MAREC_PER == 0) mafilt_put(line, 7, lok_int ? MAFILT_NONE : 0u);
     if (down) {
       U4 *rline = rec + marec_slot(MADIR_RAD, ti / MAREC_PER, lpk.ndown, lpk.nup);
@@ -496,10 +500,11 @@ __device__ inline void ma_fill_record_wave(const Env &env, int c, int ul) {
   U4 *rec = ma_rec_of(env, c, lpk);
   const int nd = lpk.ndown, nu = lpk.nup;
   {  // populate_mainit_at(): every filter entry "never counted", the rates zero
-    const int nfilt = marec_rates_slot(nd, nu);
-    const int ntot = ((marec_slots(nd, nu) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
+    const int nfilt = marec_rates_slot(nd, nu), nfine0 = marec_fine_slot0(nd, nu), nrec = marec_slots(nd, nu);
+    const int ntot = ((nrec + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
     const uint32_t none2 = MAFILT_NONE | (MAFILT_NONE << 16);
-    for (int i = lane; i < ntot; i += 64) rec[i] = (i < nfilt) ? U4{{none2, none2, none2, none2}} : U4{{0u, 0u, 0u, 0u}};
+    for (int i = lane; i < ntot; i += 64)
+      rec[i] = (i < nfilt) ? U4{{none2, none2, none2, none2}} : ((i >= nfine0 && i < nrec) ? U4{{~0u, ~0u, ~0u, ~0u}} : U4{{0u, 0u, 0u, 0u}});
   }
   __threadfence_block();  // (other lanes write into these slots below)
   // ---- downward: rates (radiative, collisional de-excitation, internal down), then the internal-down and radiative filters
@@ -1559,8 +1564,11 @@ __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_the
         p.pend = PEND_MA_FILL;  // a cold level without a record in this cell: the slow-path kernel fills it (physics.h ma_slow_fill)
       } else if (exit_action == MA_EXIT_DEFER) {
 #if ARTIS_THERMAL_SPLIT_EXACT
-        p.pend = PEND_MA_SEARCH;  // the slow-path kernel re-adds the sums and makes the transition (physics.h ma_slow_search)
-        p.pend_arg = k.defer;
+        // the lines' fine bytes decide all but 1e-6 of these (round 6; tables.h "FINE BYTES"): the walk goes on in the next phase. What they leave:
+        if (!ma_jump_deferred_fine<COLD>(env, p, k, rec)) {
+          p.pend = PEND_MA_SEARCH;  // the slow-path kernel re-adds the sums and makes the transition (physics.h ma_slow_search)
+          p.pend_arg = k.defer;
+        }
 #else
         ma_jump_deferred(env, p, k, rec);
 #endif
@@ -1769,8 +1777,10 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
           if (act == MA_EXIT_FILL) {
             p.pend = PEND_MA_FILL;
           } else if (act == MA_EXIT_DEFER) {
-            p.pend = PEND_MA_SEARCH;  // the slow-path kernel re-adds the sums and makes the transition (physics.h ma_slow_search)
-            p.pend_arg = k.defer;
+            if (!ma_jump_deferred_fine<COLD>(env, p, k, rec)) {
+              p.pend = PEND_MA_SEARCH;  // the slow-path kernel re-adds the sums and makes the transition (physics.h ma_slow_search)
+              p.pend_arg = k.defer;
+            }
           } else if (act >= 0) {
             ma_jump_exit<true>(env, p, pi, k, rec, act);
           }
@@ -1960,6 +1970,7 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   __syncthreads();
   env.stats = lstats;
+  env.ma_concurrent_fill = 1;  // this kernel's waves fill pool records while others read them: published places are read with acquire (physics.h ma_rowtab_acquire)
   const double ts_end = env.S.ts_end;
   // ONE PACKET PER WAVE (lane 0): packets in different kinds of step would otherwise serialise inside a wave (measured
   // with a packet per lane: slower than the split kernels); the tail has fewer packets than the GPU has waves
@@ -2027,8 +2038,9 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
       {
         // the pool of on-demand records is used up and the packet still waits for a record: it leaves for the slow-path list (the host empties
         // the pool before that list's next launch); nothing in this kernel could end the wait
+        // (only a packet whose level has no record and none being filled: one whose record another wave is filling goes on -- ADVICE r05)
         const bool waits = owner && env.M.ncold > 0 && p.pend != PEND_NONE &&
-                           __hip_atomic_load(env.ma_pool_full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                           __hip_atomic_load(env.ma_pool_full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 && ma_record_absent(env, p);
         if (__builtin_amdgcn_readfirstlane(__shfl((int)waits, 0)) != 0) {
           if (owner) kind = NEXT_SLOW;
           break;
@@ -2124,6 +2136,7 @@ __global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, in
   scalars_begin(env, lds_scalars);
   __syncthreads();
   env.stats = lstats;
+  env.ma_concurrent_fill = 1;  // this kernel's waves fill pool records while others read them: published places are read with acquire (physics.h ma_rowtab_acquire)
   const int64_t tid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   int kind = NEXT_DONE;
   int32_t pi = 0, cellindex = 0;
@@ -2364,6 +2377,7 @@ struct artis_amd_engine {
   bool park_tails = true;     // ARTIS_AMD_TILE_PARK=0: every visit of a tile runs its packets to their end (rounds 2-3)
   int64_t last_parked = 0;
   int64_t last_pool_resets = 0;  // times the pool of on-demand records was emptied because it was used up (this call)
+  double ma_hotfrac = 1.;        // the share of every ion's levels that has a static record (given, or chosen by engine_fill from the cache budget)
   bool vpkt_cont_lds = true;  // ARTIS_AMD_VPKT_CONTLDS=0: k_vpkt reads the continuum table from memory (four workgroups of 256 per CU)
   bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
   int64_t last_sweeps = 0, last_tile_fills = 0, last_listed = 0;
@@ -2421,6 +2435,8 @@ struct artis_amd_engine {
   int thermal_blocks_per_cu = ARTIS_THERMAL_WAVES;  // tuning: resident k_thermal blocks per CU
   bool thermal_refill = false;  // ARTIS_AMD_REFILL=1: k_thermal_q (walk contexts in per-wave LDS slots, lanes refilled inside the transition loop)
   int tq_low = 48;              // ... its low-water mark of walking lanes (ARTIS_AMD_TQ_LOW)
+  bool tq_attr_set = false;     // ... its dynamic-LDS attribute has been set on this engine's device
+  int32_t thermal_variants = 0; // which instantiations of the thermal kernel the last call launched (artis_amd_last_thermal_variants)
   bool ma_tables_lds = true;  // k_thermal<1024, true>: the static target tables in LDS when they fit (ARTIS_AMD_MATABLES_LDS=0: in HBM)
   // the population's scratch: the collisional-excitation cooling terms of `pop_batch` cells at a time (k_matrans writes them,
   // k_cooling_chain turns them into running sums, k_collexc_filter into the records' cooling filters; nothing of it is kept)
@@ -2653,7 +2669,7 @@ const RcclApi &rccl_api() {
 extern "C" {
 
 const char *artis_amd_last_error(void) { return g_last_error.c_str(); }
-int artis_amd_abi_version(void) { return 5; }
+int artis_amd_abi_version(void) { return 6; }
 const char *artis_amd_options_preset(void) {
 #if defined(ARTIS_PRESET_NAME)  // given by the build (artis_amd/build.py): the presets of the reference's CI option sets
   return ARTIS_PRESET_NAME;
@@ -2805,6 +2821,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
     const bool given = std::getenv("ARTIS_AMD_MA_HOTFRAC") != nullptr;
     ma_tiers_from_env(&hot, &pool);
     e->Mh = make_host_model_view(*model, e->own, hot, pool);
+    e->ma_hotfrac = hot;
     if (!given) {
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -2824,9 +2841,13 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
       for (const double h : {0.5, 0.3, 0.2, 0.1}) {
         if (ok) break;
         e->Mh = make_host_model_view(*model, e->own, h, pool);
+        e->ma_hotfrac = h;
         ok = fits();
       }
-      if (!ok) e->Mh = make_host_model_view(*model, e->own, 1., pool);
+      if (!ok) {
+        e->Mh = make_host_model_view(*model, e->own, 1., pool);
+        e->ma_hotfrac = 1.;
+      }
     }
   }
   e->model_copy = *model;
@@ -3083,6 +3104,9 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   }
   if (const char *b = std::getenv("ARTIS_AMD_THERMAL_BLOCKS")) e->thermal_blocks_per_cu = std::max(1, std::min(ARTIS_THERMAL_WAVES, std::atoi(b)));
   e->trace = std::getenv("ARTIS_AMD_TRACE") != nullptr;
+  if (e->trace)
+    fprintf(stderr, "[artis_amd] record tiers: static records for %.2f of every ion's levels, %d cold levels, pool of %d slots per resident cell; %d tile(s) of %lld cells, %zu B per cell\n",
+            e->ma_hotfrac, e->Mh.ncold, e->Mh.ma_pool_slots, e->ntiles, (long long)e->tile_cells, e->cache_bytes_per_cell);
   if (const char *b = std::getenv("ARTIS_AMD_VPKT_CONTLDS")) e->vpkt_cont_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TILE_PARK")) e->park_tails = std::atoi(b) != 0;
   return ARTIS_OK;
@@ -3467,6 +3491,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   e->last_sparse_fills = e->last_cells_filled = 0;
   e->last_parked = 0;
   e->last_pool_resets = 0;
+  e->thermal_variants = 0;
   e->resident_on = false;
   e->last_fill_ms = 0.;
   for (int k = 0; k < NEXT_NKINDS; k++) {
@@ -3664,6 +3689,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       rc = reset_pool_if_due(env);
       if (rc != ARTIS_OK) return rc;
       HIP_TRY(hipEventRecord(e->ev0, s));
+      e->thermal_variants |= ARTIS_AMD_THERMAL_TAIL;
       hipLaunchKernelGGL(k_tail, dim3(nblocks(tail_n * 64)), dim3(BLOCK), 0, s, env, in, next, e->d_stats);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
       if (env.bfev != nullptr) {
@@ -3757,12 +3783,13 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     else                                                                                                           \
       hipLaunchKernelGGL((K<A, B, false>), dim3(GRID), dim3(TBS), LDSB, s, __VA_ARGS__);                           \
   } while (0)
+          if (cold) e->thermal_variants |= ARTIS_AMD_THERMAL_COLD;
           if (e->thermal_refill && ARTIS_THERMAL_SPLIT_EXACT && env.cellest_n_t == 0 && tq_bytes <= 160 * 1024 - 1024 && nk >= 4096 && e->Mh.nlevels < 32768) {
-            static bool attr_set = false;
-            if (!attr_set) {
+            e->thermal_variants |= ARTIS_AMD_THERMAL_REFILL;
+            if (!e->tq_attr_set) {  // (per engine, i.e. per device: the attribute is the device's, not the process's -- ADVICE r05)
               HIP_TRY(hipFuncSetAttribute((const void *)k_thermal_q<TQ_TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
               HIP_TRY(hipFuncSetAttribute((const void *)k_thermal_q<TQ_TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-              attr_set = true;
+              e->tq_attr_set = true;
             }
             const int grid1 = (int)std::min<int64_t>(((int64_t)nk + TQ_TB - 1) / TQ_TB, (int64_t)e->ncu);
             if (cold)
@@ -3773,11 +3800,14 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
                                  e->wave_chunks_t ? chunks_for(nk, grid1 * (TQ_TB / 64)) : 8, drain, e->tq_low);
           } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS && e->Mh.nalltrans <= MA_LDS_TRANS && nk >= 4096) {
             const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
+            e->thermal_variants |= ARTIS_AMD_THERMAL_LDS_TABLES;
             LAUNCH_T2(k_thermal, 1024, 1, grid1, 1024, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
           } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS2 && nk >= 4096) {
             const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
+            e->thermal_variants |= ARTIS_AMD_THERMAL_LDS_LEVELPACK;
             LAUNCH_T2(k_thermal, 1024, 2, grid1, 1024, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
           } else {
+            e->thermal_variants |= ARTIS_AMD_THERMAL_PLAIN;
             LAUNCH_T2(k_thermal, ARTIS_THERMAL_TB, 0, grid, ARTIS_THERMAL_TB, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
                       per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (ARTIS_THERMAL_TB / 64)) : 8), per_cu ? 2 : 0, drain);
           }
@@ -4028,6 +4058,18 @@ int artis_amd_last_pool_resets(artis_amd_engine *e, int64_t *resets) {
   return ARTIS_OK;
 }
 
+int artis_amd_record_tiers(artis_amd_engine *e, double *hot_fraction, int32_t *ncold_levels, int64_t *pool_slots) {
+  if (!e) return ARTIS_ERR_ARG;
+  if (hot_fraction) *hot_fraction = e->ma_hotfrac;
+  if (ncold_levels) *ncold_levels = e->Mh.ncold;
+  if (pool_slots) *pool_slots = e->Mh.ma_pool_slots;
+  return ARTIS_OK;
+}
+int artis_amd_last_thermal_variants(artis_amd_engine *e, int32_t *mask) {
+  if (!e || !mask) return ARTIS_ERR_ARG;
+  *mask = e->thermal_variants;
+  return ARTIS_OK;
+}
 int artis_amd_last_tiling_parked(artis_amd_engine *e, int64_t *parked) {
   if (!e) return ARTIS_ERR_ARG;
   if (parked) *parked = e->last_parked;

@@ -203,6 +203,9 @@ struct Env {
   int32_t vpkt_cap;
   uint32_t ma_pool_cap;  // units (MAPOOL_UNIT slots) in DevCache::ma_pool (tables.h "ON-DEMAND RECORDS")
   int32_t *ma_pool_full;  // set by a lane that found the pool used up: the host empties the pool before the next slow-path launch (the records are filled again on demand)
+  // set by a kernel whose waves FILL pool records while others read them (k_tail, k_slow): a cold level's published place is then read with
+  // acquire semantics (ma_rowtab_acquire), pairing with the filler's release store. The thermal kernels read records of earlier launches only.
+  int32_t ma_concurrent_fill;
 #ifdef ARTIS_VISIT_COUNTS
   // (measurement build, tools/visit_sparsity.py) [cell][level] macro-atom transitions drawn in that level's record this call
   uint32_t *visit_counts;
@@ -1332,6 +1335,20 @@ AHD int32_t ma_rowtab_load(const int32_t *p) {
   return *p;
 #endif
 }
+// A READY place (v >= 0) seen in a kernel whose waves fill records (Env::ma_concurrent_fill): the record's plain loads that follow must not be
+// served from lines this compute unit or this XCD's L2 fetched before the filler's release (ma_slow_fill_publish / ma_ensure_record) -- an
+// acquire fence at agent scope after the relaxed load, i.e. the acquire half of the pair. The pool's 128-byte units (tables.h
+// MAPOOL_UNIT: no record shares a vector-L1 line with another) stay as what keeps such stale lines from existing in the first place; this
+// makes the ordering hold whatever the line sizes are. The fence invalidates the CU's L1, so only the kernels that need it pay it (cold levels
+// only: the headline's records are all static).
+AHD void ma_rowtab_acquire(const Env &env, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (env.ma_concurrent_fill != 0 && v >= 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+  (void)env;
+  (void)v;
+#endif
+}
 // MACtx::rec: >= 0 the record's slot in the cell's row; MA_REC_NONE a cold level that has no record in its cell yet; <= -2 a cold level's
 // record in the pool, at unit -(rec + 2). COLD = false (a kernel built for models without cold levels, the default): rec_off as it is.
 constexpr int MA_REC_NONE = -1;
@@ -1340,18 +1357,27 @@ AHD int ma_resolve(const Env &env, int c, int rec_off) {
   if (!COLD) return rec_off;
   if (__builtin_expect(rec_off >= 0, 1)) return rec_off;
   const int32_t v = ma_rowtab_load(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-rec_off - 1));
+  ma_rowtab_acquire(env, v);
   return v >= 0 ? -(v + 2) : MA_REC_NONE;
 }
 AHD U4 *ma_rec_of(const Env &env, int c, const LevelPack &lpk) {
   if (lpk.rec_off >= 0) return env.K.macache + ((int64_t)c * env.M.nmacache) + lpk.rec_off;
   const int32_t v = ma_rowtab_load(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-lpk.rec_off - 1));
+  ma_rowtab_acquire(env, v);
   return env.K.ma_pool + ((int64_t)((v >= 0) ? v : -(v + 3)) * MAPOOL_UNIT);  // (ready, or being filled by the caller; never asked for a level without a record)
 }
 AHD double *ma_rates_of(U4 *rec, int nd, int nu) { return (double *)(rec + marec_rates_slot(nd, nu)); }
 AHD const double *ma_rates_of(const U4 *rec, int nd, int nu) { return (const double *)(rec + marec_rates_slot(nd, nu)); }
 AHD uint32_t mafilt_quant(double value, double whole, bool *ok);
+AHD uint32_t mafilt_quant23(double value, double whole, bool *ok);
 // entry i of a filter line (0..6; 7 = the line's "usable" mark)
 AHD void mafilt_put(U4 *line, int i, uint32_t q) { ((uint16_t *)line)[i] = (uint16_t)q; }
+// ... with its fine byte (tables.h "FINE BYTES"; internal-down / internal-up filters only): q23 = the entry's 23-bit fraction
+AHD void mafilt_put23(U4 *rec, int dir, int ti, int nd, int nu, uint32_t q23) {
+  mafilt_put(rec + marec_slot(dir, ti / MAREC_PER, nd, nu), ti % MAREC_PER, q23 >> 8);
+  ((uint8_t *)rec)[marec_fine_byte0(dir, ti / MAREC_PER, nd, nu) + (ti % MAREC_PER)] = (uint8_t)(q23 & 0xFFu);
+}
+constexpr uint32_t MAFILT_NONE23 = 0x7FFFFFu;  // never counted: 0x7FFF in the line, 0xFF in its fine byte
 // The term of one transition that a direction's cumulative sums add up (macroatom.cc:64-140):
 // MADIR_DOWN (R + C) e_target, MADIR_RAD R e_trans (both of a downward transition), MADIR_UP (R + C + NT) e_cur
 AHD double matrans_term_of(const MaTransTerms &t, int dir) { return dir == MADIR_DOWN ? t.v2 : t.v0; }
@@ -1370,22 +1396,30 @@ AHD void populate_dirfilter_seq(const Env &env, int c, const LevelPack &lpk, int
   for (int l = 0; l < marec_lines(n); l++) {
     U4 *line = rec + marec_slot(dir, l, lpk.ndown, lpk.nup);
     bool ok = whole_ok;
-    uint32_t q[MAREC_PER];
+    uint32_t q[MAREC_PER];  // 23-bit fractions: the line's entry is q >> 8, its fine byte q & 0xFF (tables.h "FINE BYTES")
     const int cnt = (n - (l * MAREC_PER) < MAREC_PER) ? n - (l * MAREC_PER) : MAREC_PER;
     for (int j = 0; j < cnt; j++) {
       const int i = (l * MAREC_PER) + j;
       s += matrans_term_of(matrans_terms(env, c, ats0 + i), dir);
-      q[j] = (ok && i < n - 1) ? mafilt_quant(s, whole, &ok) : MAFILT_NONE;  // (the last sum is the whole: never searched)
+      q[j] = (ok && i < n - 1) ? mafilt_quant23(s, whole, &ok) : MAFILT_NONE23;  // (the last sum is the whole: never searched)
     }
     // the line's mark: anything but 0x7FFF = decide this line on the f64 sums
+    const bool fine = dir != MADIR_RAD;
+    uint8_t *fb = (uint8_t *)rec + marec_fine_byte0(fine ? dir : MADIR_DOWN, l, lpk.ndown, lpk.nup);
     if (check) {
       const uint16_t *have = (const uint16_t *)line;
-      for (int j = 0; j < cnt; j++) *check += (have[j] != (uint16_t)(ok ? q[j] : 0u)) ? 1 : 0;
+      for (int j = 0; j < cnt; j++) *check += (have[j] != (uint16_t)(ok ? q[j] >> 8 : 0u)) ? 1 : 0;
       for (int j = cnt; j < MAREC_PER; j++) *check += (have[j] != (uint16_t)MAFILT_NONE) ? 1 : 0;
       *check += (have[7] != (uint16_t)(ok ? MAFILT_NONE : 0u)) ? 1 : 0;
+      if (fine) {
+        for (int j = 0; j < cnt; j++) *check += (fb[j] != (uint8_t)(ok ? q[j] & 0xFFu : 0u)) ? 1 : 0;
+        for (int j = cnt; j < MAREC_PER; j++) *check += (fb[j] != (uint8_t)0xFFu) ? 1 : 0;
+      }
     } else {
-      for (int j = 0; j < cnt; j++) mafilt_put(line, j, ok ? q[j] : 0u);
+      for (int j = 0; j < cnt; j++) mafilt_put(line, j, ok ? q[j] >> 8 : 0u);
       mafilt_put(line, 7, ok ? MAFILT_NONE : 0u);
+      if (fine)
+        for (int j = 0; j < cnt; j++) fb[j] = (uint8_t)(ok ? q[j] & 0xFFu : 0u);
     }
   }
 }
@@ -1436,8 +1470,9 @@ AHD void populate_mainit_at(U4 *rec, const LevelPack &lpk) {
   const int nfilt = marec_rates_slot(lpk.ndown, lpk.nup);
   const uint32_t none2 = MAFILT_NONE | (MAFILT_NONE << 16);
   for (int i = 0; i < nfilt; i++) rec[i] = U4{{none2, none2, none2, none2}};
-  const int ntot = ((marec_slots(lpk.ndown, lpk.nup) + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
-  for (int i = nfilt; i < ntot; i++) rec[i] = U4{{0u, 0u, 0u, 0u}};
+  const int nfine0 = marec_fine_slot0(lpk.ndown, lpk.nup), nrec = marec_slots(lpk.ndown, lpk.nup);
+  const int ntot = ((nrec + MAREC_ALIGN - 1) / MAREC_ALIGN) * MAREC_ALIGN;
+  for (int i = nfilt; i < ntot; i++) rec[i] = (i >= nfine0 && i < nrec) ? U4{{~0u, ~0u, ~0u, ~0u}} : U4{{0u, 0u, 0u, 0u}};  // (fine bytes: "never counted")
 }
 // Test / debug view of one level's record (artis_amd_debug_cellcache): the nine process rates as the record holds them, and
 // the level's block of allmacroatomictransitions (globals.h:287; block order of input.cc:1542: radiative de-excitation sums,
@@ -3651,6 +3686,34 @@ AHD uint32_t mafilt_quant(double value, double whole, bool *ok) {
   }
   return (f >= MAFILT_SCALE - 1.) ? MAFILT_NONE : (uint32_t)f;
 }
+// ... with 8 more bits (tables.h "FINE BYTES"): q23 = floor(value / whole * 2^23), clamped to 2^23 - 1 (value == whole: "value <= z * whole" never
+// holds, z < 1: never counted). q23 >> 8 is mafilt_quant()'s value always (f * 256 is exact; f >= 32767 gives 0x7FFF there and here).
+AHD uint32_t mafilt_quant23(double value, double whole, bool *ok) {
+  const double f = (value / whole) * MAFILT_SCALE;
+  if (!(f >= 0. && f <= MAFILT_SCALE)) {
+    *ok = false;
+    return 0;
+  }
+  const double f23 = f * 256.;
+  return (f23 >= 8388607.) ? MAFILT_NONE23 : (uint32_t)f23;
+}
+// The decision of one line on its 23-bit fractions (the line's entries and its fine bytes) for the 24-bit draw u (z = u * 2^-24):
+// q23 <= F * 2^23 < q23 + 1 for the computed fraction F = fl(value / whole) (within 2^-53 of the exact one); z * 2^23 = u / 2. u >= 2 q23 + 3:
+// z * 2^23 >= q23 + 1.5 > F * 2^23 + 0.5, so F < z - 2^-24: "value <= fl(z * whole)" holds with a margin of 6e-8 of the whole against roundings of
+// 2e-16. u <= 2 q23 - 1: z * 2^23 <= q23 - 0.5 <= F * 2^23 - 0.5: it fails by the same margin. u in {2 q23, 2 q23 + 1, 2 q23 + 2}: undecided (*amb).
+// Returns the number of entries certainly <= z (entries are non-decreasing; a padding entry, 0x7FFFFF, is never counted).
+AHD int mafilt_count_fine(const U4 &f, uint64_t fine, uint32_t u, bool *amb) {
+  int lo = 0, hi = 0;
+#pragma unroll
+  for (int j = 0; j < MAREC_PER; j++) {
+    const uint32_t q15 = (f.w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+    const uint32_t q2 = (((q15 << 8) | (uint32_t)((fine >> (8 * j)) & 0xFFu)) << 1);
+    lo += (u >= q2 + 3u) ? 1 : 0;
+    hi += (u >= q2) ? 1 : 0;
+  }
+  *amb = (lo != hi);
+  return lo;
+}
 // how many of the filter's 8 entries have q <= lo, and whether more have q <= hi (*amb): lo >= -1, hi <= 32767. Two entries
 // per 32-bit word and subtraction: with h = bound + 32768 in both halves, (h - q) has bit 15 set in a half iff q <= bound
 // there, and no half borrows from the other (q <= 32767 <= h).
@@ -3782,8 +3845,46 @@ AHD int ma_search_filters(const Env &env, const MACtx &k, const U4 *rec, int dir
   *amb = a;
   return ti;
 }
-// ... on the re-added sums (a draw the filters could not decide)
+// ... again with the fine bytes of the lines whose 15-bit entries cannot decide (internal-down / internal-up; tables.h "FINE BYTES"): for the
+// draws ma_search_filters() left. *amb: still undecided (3 draws of 2^24 per entry, or a line that is not usable).
+AHD int ma_search_filters_fine(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u, bool *amb) {
+  const int nsearch = ((dir != MADIR_UP) ? k.nd : k.nu) - 1;
+  *amb = false;
+  if (nsearch <= 0) return 0;
+  if (env.ma_filters_off != 0 || dir == MADIR_RAD) {
+    *amb = true;
+    return 0;
+  }
+  int ti = 0;
+  for (int b0 = 0; b0 < nsearch; b0 += MAREC_PER) {
+    const int l = b0 / MAREC_PER;
+    const U4 f = rec[marec_slot(dir, l, k.nd, k.nu)];
+    bool a;
+    int cnt = mafilt_count(f, u, &a);
+    if ((f.w[3] >> 16) != MAFILT_NONE) {  // (the line is not usable: its sums were not finite fractions)
+      *amb = true;
+      return 0;
+    }
+    if (a) {
+      const uint64_t fine = *(const uint64_t *)((const uint8_t *)rec + marec_fine_byte0(dir, l, k.nd, k.nu));
+      cnt = mafilt_count_fine(f, fine, u, &a);
+      if (a) {
+        *amb = true;
+        return 0;
+      }
+    }
+    ti += cnt;
+    if (cnt < MAREC_PER) break;
+  }
+  return ti;
+}
+// ... on the re-added sums (a draw the filters could not decide, fine bytes included)
 AHD int ma_search_exact(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u) {
+  if (dir != MADIR_RAD) {
+    bool amb;
+    const int ti = ma_search_filters_fine(env, k, rec, dir, u, &amb);
+    if (!amb) return ti;
+  }
   const bool down = dir != MADIR_UP;
   const int action = dir == MADIR_DOWN ? ARTIS_MA_ACTION_INTERNALDOWNSAME : (dir == MADIR_UP ? ARTIS_MA_ACTION_INTERNALUPSAME : ARTIS_MA_ACTION_RADDEEXC);
   const double targetval = rng_u24_value(u) * ma_rates_of(rec, k.nd, k.nu)[action];
@@ -3917,6 +4018,17 @@ AHD void ma_jump_deferred(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
   const int ti = ma_search_exact(env, k, rec, down ? MADIR_DOWN : MADIR_UP, (uint32_t)k.defer & 0xFFFFFFu);
   ma_take_transition(env, p, k, down, ti);
 }
+// ... tried on the record's fine bytes first, where the caller would otherwise hand the packet to the slow-path kernel (k_thermal): true = the
+// transition is made and the walk goes on in the caller's next phase; false = still undecided (k.defer keeps the draw)
+template <bool COLD = true>
+AHD bool ma_jump_deferred_fine(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
+  const bool down = (k.defer & 0x1000000) != 0;
+  bool amb;
+  const int ti = ma_search_filters_fine(env, k, rec, down ? MADIR_DOWN : MADIR_UP, (uint32_t)k.defer & 0xFFFFFFu, &amb);
+  if (amb) return false;
+  ma_take_transition<COLD>(env, p, k, down, ti);
+  return true;
+}
 // do_macroatom_raddeexcitation macroatom.cc:204 once the transition dti is known
 AHD void ma_exit_raddeexc(const Env &env, Pkt &p, int64_t pi, const MACtx &k, int dti) {
   const DevModel &M = env.M;
@@ -4007,6 +4119,25 @@ AHD void ma_fill_record(const Env &env, int c, int ul) {
 // The record of cold level ul in cell c exists (true), or another lane is filling it right now (false: ask again). A level without one gets it
 // here: the lane claims the level's place in the cell's table, takes units of the pool, fills the record with the sequential forms and
 // publishes it. (The pool used up: error flag 46, *failed.)
+AHD bool ma_pool_known_full(const Env &env, uint32_t nunits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint64_t)__hip_atomic_load(env.K.ma_pool_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + nunits > (uint64_t)env.ma_pool_cap;
+#else
+  (void)env;
+  (void)nunits;
+  return false;
+#endif
+}
+// A packet's macro-atom stands in a cold level that has NO record in its cell and none on its way (the row table says -1): with the pool used
+// up nothing in the running kernel can give it one (k_tail hands such a packet to the slow-path list, before whose next launch the host
+// empties the pool). A record another wave is filling right now (<= -2) will be published: not absent.
+AHD bool ma_record_absent(const Env &env, const Pkt &p) {
+  const DevModel &M = env.M;
+  if (M.ncold == 0 || p.ma_level < 0) return false;
+  const LevelPack lpk = M.level_pack[M.ion_uniquelevelindexstart[uion(M, p.ma_element, p.ma_ion)] + p.ma_level];
+  if (lpk.rec_off >= 0) return false;
+  return ma_rowtab_load(env.K.ma_rowtab + ((int64_t)M.propcell_nonemptymgi[p.cellindex] * M.ncold) + (-lpk.rec_off - 1)) == -1;
+}
 AHD bool ma_ensure_record(const Env &env, int c, int ul, bool *failed, bool *full = nullptr) {
   const DevModel &M = env.M;
   const LevelPack lpk = M.level_pack[ul];
@@ -4020,11 +4151,15 @@ AHD bool ma_ensure_record(const Env &env, int c, int ul, bool *failed, bool *ful
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   const int32_t v = ma_rowtab_load(tab);
+  ma_rowtab_acquire(env, v);
   if (v >= 0) return true;
   if (v != -1) return false;                       // another lane is at it
   if (atomicCAS(tab, -1, -2) != -1) return false;  // claimed: exactly one lane goes on
-  const uint32_t unit = atomicAdd(env.K.ma_pool_used, nunits);
-  if (unit + nunits > env.ma_pool_cap) {
+  // (a pool already known to be used up is not asked again: the counter only ever grows by requests that can still be served plus the few in
+  // flight when it fills, so it cannot wrap however long packets wait -- ADVICE r05; the sums are compared in 64 bits)
+  const bool known_full = ma_pool_known_full(env, nunits);
+  const uint32_t unit = known_full ? env.ma_pool_cap : atomicAdd(env.K.ma_pool_used, nunits);
+  if ((uint64_t)unit + nunits > (uint64_t)env.ma_pool_cap) {
     // the pool is used up: the level stays without a record, the packet waits on the slow-path list; the host empties the pool before that
     // list's next launch (what the pool held is filled again when next needed, as after a tile's refill)
     __hip_atomic_store(tab, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -4099,8 +4234,9 @@ __device__ inline bool ma_slow_fill_claim(const Env &env, Pkt &p, int *c_out, in
     p.ma_level = -1;
     return false;
   }
-  const uint32_t unit = atomicAdd(env.K.ma_pool_used, nunits);
-  if (unit + nunits > env.ma_pool_cap) {  // (used up: ma_ensure_record())
+  const bool known_full = ma_pool_known_full(env, nunits);
+  const uint32_t unit = known_full ? env.ma_pool_cap : atomicAdd(env.K.ma_pool_used, nunits);
+  if ((uint64_t)unit + nunits > (uint64_t)env.ma_pool_cap) {  // (used up: ma_ensure_record())
     __hip_atomic_store(tab, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(env.ma_pool_full, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     p.pend = PEND_MA_FILL;

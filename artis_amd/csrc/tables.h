@@ -108,7 +108,21 @@ constexpr int marec_slot(int d, int l, int nd, int nu) {
                                                                    : MAREC_QUAD + (2 * marec_rest(nd)) + marec_rest(nu) + l)));
 }
 constexpr int marec_rates_slot(int nd, int nu) { return MAREC_QUAD + (2 * marec_rest(nd)) + marec_rest(nu) + marec_lines(nu); }
-constexpr int marec_slots(int nd, int nu) { return marec_rates_slot(nd, nu) + MAREC_RATE_SLOTS; }
+// FINE BYTES (round 6). The 15-bit entries leave ~n / 32768 of the draws of a direction of n transitions undecided, and each such draw re-adds
+// the direction's sums from its first transition (n rate coefficients: the cost grows with n^2) in the slow-path kernel, a launch later: with
+// 4e5 lines 83 % of the slow path's 3.7e8 visits per step (profiles/r05/slow_path_cd23like.txt). Behind the rates every line of the internal-down
+// and internal-up filters therefore has 8 more bytes: entry j's byte holds the next 8 bits of its fraction, q23 = floor(fraction * 2^23) =
+// (q15 << 8) | byte (clamped to 2^23 - 1; an entry that is never counted: 0x7FFF | 0xFF). They are read only when the 15-bit entries cannot
+// decide (physics.h mafilt_count_fine): with the 24-bit draw u = z * 2^24, u >= 2 q23 + 3 proves fraction < z by 2^-24 of the whole and
+// u <= 2 q23 - 1 proves the opposite by the same -- the margins (6e-8) the 15-bit rule already relies on, against f64 rounding of 1e-16 -- so three
+// draws of 2^24 per entry are left to the re-added sums instead of ~1.5 of 32768: 170x fewer. Two lines' bytes per slot, downward lines first.
+constexpr int marec_fine_dirslots(int n) { return (marec_lines(n) + 1) / 2; }
+constexpr int marec_fine_slot0(int nd, int nu) { return marec_rates_slot(nd, nu) + MAREC_RATE_SLOTS; }
+// byte offset (from the record's start) of the 8 fine bytes of line l of direction d (MADIR_DOWN / MADIR_UP only)
+constexpr int marec_fine_byte0(int d, int l, int nd, int nu) {
+  return ((marec_fine_slot0(nd, nu) + (d == MADIR_UP ? marec_fine_dirslots(nd) : 0)) * 16) + (l * 8);
+}
+constexpr int marec_slots(int nd, int nu) { return marec_fine_slot0(nd, nu) + marec_fine_dirslots(nd) + marec_fine_dirslots(nu); }
 constexpr double MAFILT_SCALE = 32768.;
 constexpr uint32_t MAFILT_NONE = 0x7FFFu;  // an entry that is never counted
 constexpr int MATRANS_BLOCK = 256;  // entries of alltrans a wave of k_matrans holds in LDS at a time

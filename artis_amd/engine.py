@@ -75,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_last_kernel_table",
     "artis_amd_options_preset",
     "artis_amd_allreduce_estimators", "artis_amd_comm_unique_id", "artis_amd_comm_init", "artis_amd_comm_count",
-    "artis_amd_cache_tiles", "artis_amd_last_tiling", "artis_amd_last_tiling_fills", "artis_amd_last_tiling_parked", "artis_amd_last_pool_resets",
+    "artis_amd_cache_tiles", "artis_amd_last_tiling", "artis_amd_last_tiling_fills", "artis_amd_last_tiling_parked", "artis_amd_last_pool_resets", "artis_amd_record_tiers", "artis_amd_last_thermal_variants",
 ]
 
 
@@ -161,6 +161,23 @@ class Engine:
         self.L.artis_amd_cache_tiles.argtypes = [C.c_void_p] * 4
         self._check(self.L.artis_amd_cache_tiles(self.h, C.byref(nt), C.byref(cells), C.byref(bpc)))
         return nt.value, cells.value, bpc.value
+
+    def record_tiers(self):
+        """(share of every ion's levels with a static macro-atom record, cold levels, pool slots per resident cell): what the engine chose
+        from its cache budget at creation, or was given (ARTIS_AMD_MA_HOTFRAC / _POOLFRAC)"""
+        h, n, p = C.c_double(), C.c_int32(), C.c_int64()
+        self.L.artis_amd_record_tiers.argtypes = [C.c_void_p] * 4
+        self._check(self.L.artis_amd_record_tiers(self.h, C.byref(h), C.byref(n), C.byref(p)))
+        return {"hot_fraction": h.value, "ncold": n.value, "pool_slots": p.value}
+
+    THERMAL_PLAIN, THERMAL_LDS_TABLES, THERMAL_LDS_LEVELPACK, THERMAL_REFILL, THERMAL_COLD, THERMAL_TAIL = 1, 2, 4, 8, 16, 32
+
+    def last_thermal_variants(self) -> int:
+        """mask of the thermal-kernel forms the last step() launched (include/artis_amd.h ARTIS_AMD_THERMAL_*)"""
+        m = C.c_int32()
+        self.L.artis_amd_last_thermal_variants.argtypes = [C.c_void_p] * 2
+        self._check(self.L.artis_amd_last_thermal_variants(self.h, C.byref(m)))
+        return int(m.value)
 
     def last_tiling(self):
         """sweeps over the cache tiles, tile fills, their summed ms and the packets listed in the last step()"""

@@ -479,7 +479,7 @@ typedef struct artis_amd_engine artis_amd_engine;
 #define ARTIS_ERR_RCCL (-6)
 
 const char *artis_amd_last_error(void);
-int artis_amd_abi_version(void); /* 5: virtual-packet configuration and spectra appended; 4: artis_cellstate.elem_meanweight appended (3: cell state and estimators of the nltenebular options) */
+int artis_amd_abi_version(void); /* 6: artis_amd_record_tiers() added (no struct changed); 5: virtual-packet configuration and spectra appended; 4: artis_cellstate.elem_meanweight appended (3: cell state and estimators of the nltenebular options) */
 /* Name of the options preset the library was compiled with (include/artis_options.h): "classic" or "kilonova_lte".
  * Like the reference, one binary per artisoptions.h. */
 const char *artis_amd_options_preset(void);
@@ -566,6 +566,21 @@ int artis_amd_last_tiling_parked(artis_amd_engine *eng, int64_t *parked);
  * artis_amd_update_packets_device call found the shared pool of the other levels' records used up and emptied it (the records are filled again
  * when next needed: it costs fills, never an answer; the reference, which fills a level's rates on first use too, keeps them all: macroatom.cc:398-417) */
 int artis_amd_last_pool_resets(artis_amd_engine *eng, int64_t *resets);
+/* Which record tiers the engine keeps for this model (chosen at artis_amd_engine_create from the cache budget -- free device memory at that
+ * moment or ARTIS_AMD_CACHE_BUDGET_MB -- unless ARTIS_AMD_MA_HOTFRAC gives them): the share of every ion's levels with a static record in every
+ * cell's row (1 = all of them: no on-demand records), the number of cold levels, and the 16-byte slots of the shared pool per resident cell.
+ * Two runs are comparable in time and in artis_amd_last_pool_resets() only if these agree. Any pointer may be NULL. (ABI 6) */
+int artis_amd_record_tiers(artis_amd_engine *eng, double *hot_fraction, int32_t *ncold_levels, int64_t *pool_slots);
+/* Which forms of the thermal kernel (macro-atom walks + k-packet steps) the last artis_amd_update_packets_device call
+ * launched, as a mask: the form is chosen per launch from the atomic data's size and the list's length, and a parity test has to know that the
+ * form it means to check is the one that ran. (ABI 6) */
+#define ARTIS_AMD_THERMAL_PLAIN 1         /* k_thermal<256, 0>: target tables in HBM (any size; lists below 4096 entries) */
+#define ARTIS_AMD_THERMAL_LDS_TABLES 2    /* k_thermal<1024, 1>: target levels + LevelPack in LDS (<= 2048 levels, <= 32768 transitions) */
+#define ARTIS_AMD_THERMAL_LDS_LEVELPACK 4 /* k_thermal<1024, 2>: LevelPack alone in LDS (<= 6144 levels) */
+#define ARTIS_AMD_THERMAL_REFILL 8        /* k_thermal_q (ARTIS_AMD_REFILL=1) */
+#define ARTIS_AMD_THERMAL_COLD 16         /* ... instantiated with the on-demand records' look-ups (the model has cold levels) */
+#define ARTIS_AMD_THERMAL_TAIL 32         /* k_tail took the population's last packets */
+int artis_amd_last_thermal_variants(artis_amd_engine *eng, int32_t *mask);
 
 /* Per-kernel split of the last artis_amd_update_packets_device call: summed launch durations [ms] and summed
  * packet counts of the r-packet kernel (k_rpkt) and of the thermal kernels (k_ma + k_kpkt). */

@@ -223,6 +223,75 @@ int64_t artis_emu_mafilter_selftest(int64_t ntrials, uint64_t seed, int64_t *n_a
   return mism;
 }
 
+// The same property for the lines' FINE BYTES (tables.h "FINE BYTES"; round 6) on mafilt_quant23() / mafilt_count_fine(): cumulative lists of 7 values,
+// 24-bit draws; a third of the trials put a value within a few ulp of z * whole, another third within a few ulp of an edge of the draw's 23-bit
+// cell or the cells beside it ((u / 2 + k) * 2^-23 * whole, k = -2 ... 2: the bounds of the rule "u >= 2 q + 3 counts, u <= 2 q - 1 does not"), and some
+// lists end in values equal to the whole (never counted). Whenever the fine count does not call the draw undecided it must equal the number of
+// values <= (double)(u * 2^-24f) * whole; q23 >> 8 must be mafilt_quant()'s entry; and whenever the 15-bit count decides, the fine count agrees.
+// Returns the number of mismatches; *n_ambiguous: draws left to the re-added sums.
+int64_t artis_emu_mafilter_fine_selftest(int64_t ntrials, uint64_t seed, int64_t *n_ambiguous) {
+  using namespace artis;
+  uint64_t s = seed ? seed : 1;
+  auto next = [&s]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  auto unif = [&next]() { return (double)(next() >> 11) * 0x1.0p-53; };
+  int64_t mism = 0, namb = 0;
+  for (int64_t t = 0; t < ntrials; t++) {
+    double v[MAREC_PER];
+    const double scale = std::exp((unif() - 0.5) * 200.);
+    double run = 0.;
+    for (int j = 0; j < MAREC_PER; j++) {
+      if (unif() < 0.7) run += unif() * unif();
+      v[j] = run;
+    }
+    double whole = ((run > 0.) ? run : 1.) * (1. + ((next() & 1) ? unif() : 0.)) * scale;  // (half of the lists reach the whole at their end)
+    for (int j = 0; j < MAREC_PER; j++) v[j] *= scale;
+    for (int j = 0; j < MAREC_PER; j++) v[j] = (v[j] < whole) ? v[j] : whole;
+    const uint32_t u = (uint32_t)(next() >> 40);
+    const double z = (double)rng_u24_value(u);
+    const int mode = (int)(t % 3);
+    if (mode != 2) {
+      const int j = (int)(next() % MAREC_PER);
+      double x = z * whole;
+      if (mode == 1) x = (((double)(u >> 1) + (double)((int)(next() % 5) - 2)) / 8388608.) * whole;
+      if (x < 0.) x = 0.;
+      const int k = (int)(next() % 7) - 3;
+      for (int i = 0; i < (k < 0 ? -k : k); i++) x = std::nextafter(x, k < 0 ? 0. : 2. * whole);
+      if (x > whole) x = whole;
+      v[j] = x;
+      for (int i = 0; i < j; i++) v[i] = (v[i] < x) ? v[i] : x;
+      for (int i = j + 1; i < MAREC_PER; i++) v[i] = (v[i] > x) ? v[i] : x;
+    }
+    bool ok = true;
+    uint32_t q23[MAREC_PER], q15[8];
+    for (int j = 0; j < MAREC_PER; j++) {
+      q23[j] = mafilt_quant23(v[j], whole, &ok);
+      bool ok15 = true;
+      q15[j] = mafilt_quant(v[j], whole, &ok15);
+      if (ok && ok15 && (q23[j] >> 8) != q15[j]) mism++;
+    }
+    if (!ok) continue;
+    q15[7] = MAFILT_NONE;
+    U4 f;
+    for (int j = 0; j < 4; j++) f.w[j] = q15[2 * j] | (q15[2 * j + 1] << 16);
+    uint64_t fine = 0;
+    for (int j = 0; j < MAREC_PER; j++) fine |= (uint64_t)(q23[j] & 0xFFu) << (8 * j);
+    const double target = z * whole;
+    int exact = 0;
+    for (int j = 0; j < MAREC_PER; j++) exact += (v[j] <= target) ? 1 : 0;
+    bool amb15 = false, amb = false;
+    const int cnt15 = mafilt_count(f, u, &amb15);
+    const int cnt = mafilt_count_fine(f, fine, u, &amb);
+    if (!amb15 && cnt15 != exact) mism++;
+    if (amb) {
+      namb++;
+      continue;
+    }
+    if (cnt != exact) mism++;
+  }
+  if (n_ambiguous) *n_ambiguous = namb;
+  return mism;
+}
+
 // Property check of the cooling guides (tables.h "COOLING GUIDES") on the functions the kernels use: random cumulative lists (1..400 sums,
 // equal neighbours and leading zeros now and then, one dominant term in most), guides of 2^lg ranges; for random 24-bit draws and for the
 // first and last draw of every range, guided_upper_bound() must return what upper_bound_d() returns. Returns the number of mismatches;

@@ -32,7 +32,7 @@ def test_exports_every_declared_symbol(lib):
 def test_packet_layout_matches_header(lib):
     lib.artis_amd_sizeof_packet.restype = C.c_size_t
     assert lib.artis_amd_sizeof_packet() == abi.PACKET_DTYPE.itemsize == 256
-    assert lib.artis_amd_abi_version() == abi.ABI_VERSION == 5
+    assert lib.artis_amd_abi_version() == abi.ABI_VERSION == 6
 
 
 def test_no_cpu_fallback(lib):

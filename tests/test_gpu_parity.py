@@ -38,6 +38,16 @@ BIG_CASES = {
     # ... and for the kilonova_lte build (configs[3]'s packet-path options on the bench grid; round 4)
     "kilonova_lte_50cubed_dense_1e5": dict(build=dict(preset="w7", ncoord=50, options="kilonova_lte"), npk=100_000,
                                            pkw=dict(kpkt_fraction=0.02), dense_cells=800),
+    # Round 6 -- the realistic-size atomic data under the oracle. `w7big` (110 860 lines, 4 427 levels): 6000 packets of
+    # which 4800 start as k-packets, so that the first thermal lists hold >= 4096 entries and the launch takes k_thermal<1024, 2> (LevelPack
+    # alone in LDS, the 2-byte target levels in HBM: what the 50^3 / 1e7 run of this data set executes); 3.9e8 transitions
+    "w7big_5cubed_6e3": dict(build=dict(preset="w7big", ncoord=5), npk=6000, pkw=dict(kpkt_fraction=0.8), dense_cells=0,
+                             expect_variants="LDS_LEVELPACK"),
+    # `cd23like` (406 132 lines, 8 457 levels, directions of hundreds of transitions: k_mafilter_long) with the record tiers the ENGINE chooses
+    # when its static rows do not fit the cache budget (forced here to 0.7 of them on a 5^3 grid): static records for the lowest levels of every
+    # ion, the rest filled on demand in the shared pool by the slow-path kernel's waves, k_thermal<256, 0, COLD>; 3.2e8 transitions
+    "cd23like_5cubed_ondemand_5e3": dict(build=dict(preset="cd23like", ncoord=5), npk=5000, pkw=dict(kpkt_fraction=0.5), dense_cells=0,
+                                         budget_frac=0.7, expect_variants="PLAIN|COLD"),
 }
 
 
@@ -221,15 +231,37 @@ def test_engine_matches_oracle_w7_atomic_data(engine_mod, oracle):
 
 
 @pytest.mark.parametrize("name", list(BIG_CASES))
-def test_engine_matches_oracle_large_cases(engine_mod, oracle_big, name):
-    """configs[0] at its stated size and a dense cut of the bench grid (see BIG_CASES), same bars as the small cases"""
+def test_engine_matches_oracle_large_cases(engine_mod, oracle_big, name, monkeypatch):
+    """configs[0] at its stated size, dense cuts of the bench grid, and the atomic data sets of realistic size on the kernels the 50^3 / 1e7 runs
+    of those data take (see BIG_CASES), same bars as the small cases"""
     model, cs, ts, pk0, pa, ea = oracle_big[name]
-    options = BIG_CASES[name]["build"].get("options", "classic")
+    case = BIG_CASES[name]
+    options = case["build"].get("options", "classic")
     pb = pk0.copy()
     eb = abi.estimators_for(model, options)
+    if "budget_frac" in case:
+        # a cache budget below what the static rows take (without line_dpop, which the engine drops first): the engine chooses the tiers itself
+        eng = engine_mod.Engine(model, preset=options)
+        ntiles, _, bpc = eng.cache_tiles()
+        assert ntiles == 1 and eng.record_tiers()["ncold"] == 0      # (with the whole device free the static rows fit)
+        eng.close()
+        static_mb = (bpc - 8 * model["nlines"]) * model["npts_nonempty"] / 2**20
+        monkeypatch.setenv("ARTIS_AMD_CACHE_BUDGET_MB", f"{case['budget_frac'] * static_mb:.1f}")
+        monkeypatch.delenv("ARTIS_AMD_MA_HOTFRAC", raising=False)
     eng = engine_mod.Engine(model, preset=options)
+    if "budget_frac" in case:
+        tiers = eng.record_tiers()
+        assert eng.cache_tiles()[0] == 1 and tiers["ncold"] > 0 and 0 < tiers["hot_fraction"] < 1 and tiers["pool_slots"] > 0, tiers
+        print(f"{name}: record tiers chosen by the engine: {tiers}")
     eng.set_cellstate(cs, ts)
     eng.update_packets(pb, eb)
+    if "expect_variants" in case:
+        want = 0
+        for v in case["expect_variants"].split("|"):
+            want |= getattr(eng, "THERMAL_" + v)
+        got = eng.last_thermal_variants()
+        assert got & want == want, f"{name}: thermal kernel forms launched {got:#x}, expected {want:#x} among them"
+        print(f"{name}: thermal kernel forms {got:#x}, pool resets {eng.last_tiling()['pool_resets']}")
     rep = parity.compare_packets(pb, pa, FLOAT_RTOL, f"{name}: HIP engine vs oracle")
     parity.compare_stats(eb, ea, f"{name}: HIP engine vs oracle", same_libm=False)
     parity.compare_estimators(eb, ea, EST_RTOL, f"{name}: HIP engine vs oracle")
@@ -537,8 +569,8 @@ def test_filter_records_of_long_directions_match_the_sequential_form(engine_mod,
     ea, eb = abi.estimators_for(model, "classic"), abi.estimators_for(model, "classic")
     oracle.update_packets(model, cs, ts, pa, ea)
     eng.update_packets(pb, eb)
-    parity.compare_packets(pb, pa, FLOAT_RTOL, "w7big atomic data: HIP engine vs oracle")
-    parity.compare_stats(eb, ea, "w7big atomic data: HIP engine vs oracle", same_libm=False)
+    parity.compare_packets(pb, pa, FLOAT_RTOL, "longdir atomic data: HIP engine vs oracle")
+    parity.compare_stats(eb, ea, "longdir atomic data: HIP engine vs oracle", same_libm=False)
     eng.close()
 
 

@@ -615,6 +615,25 @@ def test_macroatom_filters_decide_what_the_f64_comparison_decides():
     assert 0.42 * n <= namb.value < 0.46 * n, namb.value
 
 
+def test_macroatom_fine_bytes_decide_what_the_f64_comparison_decides():
+    """tables.h "FINE BYTES" (round 6): 6e6 random lines of 7 cumulative values and 24-bit draws on the kernels' own mafilt_quant23() /
+    mafilt_count_fine(); a third with a value within three ulp of z * whole, a third with a value within three ulp of an edge of the draw's
+    23-bit cell or its neighbours (the bounds of "u >= 2 q + 3 counts, u <= 2 q - 1 does not"); half of the lists reach the whole at their end.
+    Whenever the 23-bit count does not leave the draw to the re-added sums it equals the f64 comparison's; the line's 15-bit entry is q23 >> 8;
+    the 15-bit count, where it decides, agrees."""
+    import ctypes as C
+
+    L = emu.lib()
+    L.artis_emu_mafilter_fine_selftest.restype = C.c_int64
+    L.artis_emu_mafilter_fine_selftest.argtypes = [C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]
+    namb = C.c_int64(0)
+    n = 6_000_000
+    assert L.artis_emu_mafilter_fine_selftest(n, 4242, C.byref(namb)) == 0
+    # undecided: the first planted third (the value IS the draw's product), ~3/5 of the second (k = -1 ... 1 lands in {2q, 2q+1, 2q+2}: roughly), and
+    # ~7 entries x 3 of 2^24 draws of the rest: nothing
+    assert 0.33 * n <= namb.value < 0.60 * n, namb.value
+
+
 @pytest.mark.parametrize("options,preset,ncoord,npk", [("classic", "small", 8, 3000), ("nltenebular", "small", 6, 1500)])
 def test_kpkt_draws_by_bisection_bit_exact(oracle, monkeypatch, options, preset, ncoord, npk):
     """ARTIS_AMD_COOLGUIDE=0: the two draws of a k-packet step by std::upper_bound's bisection (kpkt.cc:430-447, rounds 1-4) instead of by the
