@@ -2377,6 +2377,7 @@ struct artis_amd_engine {
   bool park_tails = true;     // ARTIS_AMD_TILE_PARK=0: every visit of a tile runs its packets to their end (rounds 2-3)
   int64_t last_parked = 0;
   int64_t last_pool_resets = 0;  // times the pool of on-demand records was emptied because it was used up (this call)
+  int64_t last_pool_used = 0, last_pool_cap = 0;  // units (128 B) of the pool in use at the end of the last call / the pool's size
   double ma_hotfrac = 1.;        // the share of every ion's levels that has a static record (given, or chosen by engine_fill from the cache budget)
   bool vpkt_cont_lds = true;  // ARTIS_AMD_VPKT_CONTLDS=0: k_vpkt reads the continuum table from memory (four workgroups of 256 per CU)
   bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
@@ -2838,7 +2839,9 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
       // its fills again and again (the headline forced to a quarter of its cache: 3.7 s with them, 3.0 s with four tiles of static rows;
       // profiles/r05/quarter_cache.txt)
       bool ok = fits();
-      for (const double h : {0.5, 0.3, 0.2, 0.1}) {
+      // (round 6: in steps of 0.05 below one half -- with the round-5 steps 0.5 / 0.3 / 0.2 / 0.1 a record that grew by a quarter, the fine bytes, sent
+      // the 4e5-line set from 0.2 to 0.1 and doubled its fills)
+      for (const double h : {0.9, 0.8, 0.7, 0.6, 0.5, 0.45, 0.4, 0.35, 0.3, 0.25, 0.2, 0.15, 0.1, 0.05}) {
         if (ok) break;
         e->Mh = make_host_model_view(*model, e->own, h, pool);
         e->ma_hotfrac = h;
@@ -3863,6 +3866,12 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     hipLaunchKernelGGL(k_bfrate_expand, dim3(nblocks((int64_t)e->Mh.npts_nonempty * 64)), dim3(BLOCK), 0, s, env);
   e->bfrate_kept_dirty = false;
 #endif
+  if (e->Mh.ncold > 0) {  // what the pool of on-demand records holds at the call's end (since its last emptying): artis_amd_last_pool_usage()
+    uint32_t used = 0;
+    HIP_TRY(hipMemcpy(&used, e->K.ma_pool_used, sizeof(used), hipMemcpyDeviceToHost));
+    e->last_pool_used = std::min<int64_t>(used, env.ma_pool_cap);
+    e->last_pool_cap = env.ma_pool_cap;
+  }
   int32_t err = 0;
   HIP_TRY(hipMemcpy(&err, e->d_err, sizeof(err), hipMemcpyDeviceToHost));
   if (err != 0) {
@@ -4063,6 +4072,12 @@ int artis_amd_record_tiers(artis_amd_engine *e, double *hot_fraction, int32_t *n
   if (hot_fraction) *hot_fraction = e->ma_hotfrac;
   if (ncold_levels) *ncold_levels = e->Mh.ncold;
   if (pool_slots) *pool_slots = e->Mh.ma_pool_slots;
+  return ARTIS_OK;
+}
+int artis_amd_last_pool_usage(artis_amd_engine *e, int64_t *units_used, int64_t *units_cap) {
+  if (!e) return ARTIS_ERR_ARG;
+  if (units_used) *units_used = e->last_pool_used;
+  if (units_cap) *units_cap = e->last_pool_cap;
   return ARTIS_OK;
 }
 int artis_amd_last_thermal_variants(artis_amd_engine *e, int32_t *mask) {

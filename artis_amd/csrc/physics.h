@@ -3739,9 +3739,32 @@ AHD int mafilt_count_between(const U4 &f, int lo, int hi, bool *amb) {
 // margin of the size the other side's proof (6e-8) already relies on -- and the entry is counted. The lower bound of the count is therefore
 // ((u - 2) >> 9) - 1: zi - 1 where sub >= 2, zi - 2 otherwise. Undecided draws fall from ~2n to ~n of 32768 for a direction of n transitions
 // (with 4e5 lines 83 % of the slow path's visits were such searches: profiles/r05/slow_path_cd23like.txt).
+// Round 6: the entries of a filter are SORTED (cumulative sums of non-negative terms, quantised by a monotonic rule; padding is the largest
+// value; populate_mafilter_level() refuses an action filter that is not), so the count of entries <= zi is a three-step binary search over
+// e0 .. e6 (+ one look at e7 where all seven are counted: the action filter's eighth entry; a direction line's mark, 0x7FFF, is counted only by
+// zi = 32767) -- and the draw is undecided iff the LARGEST counted entry lies above the lower bound: one count and one comparison instead of two
+// counts (27 -> ~17 instructions of the ~200 a wave-round issues). Same result as mafilt_count_between(f, lo, zi) on sorted entries (property
+// tests, tests/hostemu artis_emu_mafilter_selftest).
 AHD int mafilt_count(const U4 &f, uint32_t u, bool *amb) {
-  const int zi = (int)(u >> 9), lo = (((int)u - 2) >> 9) - 1;
-  return mafilt_count_between(f, (lo > -1) ? lo : -1, zi, amb);
+  const uint32_t zi = u >> 9;
+  int lo = (((int)u - 2) >> 9) - 1;
+  lo = (lo > -1) ? lo : -1;
+  const uint32_t e3 = f.w[1] >> 16;
+  const bool b2 = e3 <= zi;
+  const uint32_t x = b2 ? f.w[2] : f.w[0];
+  const uint32_t k2 = x >> 16;  // e5 or e1
+  const bool b1 = k2 <= zi;
+  const uint32_t ya = b1 ? f.w[1] : f.w[0], yb = b1 ? f.w[3] : f.w[2];
+  const uint32_t k3 = (b2 ? yb : ya) & 0xFFFFu;  // e6 / e4 / e2 / e0
+  const bool b0 = k3 <= zi;
+  int c = (b2 ? 4 : 0) + (b1 ? 2 : 0) + (b0 ? 1 : 0);
+  int m = b0 ? (int)k3 : (b1 ? (int)k2 : (b2 ? (int)e3 : -1));  // the largest counted entry
+  const uint32_t e7 = f.w[3] >> 16;
+  const bool b3 = (c == 7) && (e7 <= zi);
+  c += b3 ? 1 : 0;
+  m = b3 ? (int)e7 : m;
+  *amb = m > lo;
+  return c;
 }
 // After every rate of a cell's records is final (populate_macroatom): the action filter of one level's record
 AHD void populate_mafilter_level(const Env &env, int c, int ul) {
@@ -3844,6 +3867,32 @@ AHD int ma_search_filters(const Env &env, const MACtx &k, const U4 *rec, int dir
   }
   *amb = a;
   return ti;
+}
+// The same search for the transition loop (round 6: one result instead of a count and a flag, the first line given): the number of the
+// direction's cumulative sums <= z * (its rate), or -1 where the 15-bit entries cannot decide (a draw within their resolution of an entry,
+// a line that is not usable, filters switched off). f0: the direction's first line, read with the action filter.
+AHD int ma_search_filters_first(const Env &env, const MACtx &k, const U4 *rec, int dir, uint32_t u, const U4 &f0) {
+  const int nsearch = ((dir != MADIR_UP) ? k.nd : k.nu) - 1;
+  bool a;
+  int ti = mafilt_count(f0, u, &a);
+  // (a line's mark is 0x7FFF when it is usable; a direction of one transition has nothing to search: its line holds padding only, count 0)
+  const bool bad = (int)a | (int)((f0.w[3] >> 16) != MAFILT_NONE) | (int)(env.ma_filters_off != 0);
+  ti = bad ? -1 : ti;
+  if (__builtin_expect(ti == MAREC_PER && nsearch > MAREC_PER, 0)) {
+    // the first line's seven sums all lie below the draw and the direction has more: its further lines, one at a time
+    const U4 *line = rec + marec_slot(dir, 1, k.nd, k.nu);
+    int b0 = MAREC_PER;
+    int cnt;
+    do {
+      const U4 f = *line++;
+      cnt = mafilt_count(f, u, &a);
+      const bool badl = (int)a | (int)((f.w[3] >> 16) != MAFILT_NONE);
+      ti = badl ? -1 : ti + cnt;
+      cnt = badl ? 0 : cnt;
+      b0 += MAREC_PER;
+    } while (cnt == MAREC_PER && b0 < nsearch);
+  }
+  return (nsearch <= 0) ? 0 : ti;
 }
 // ... again with the fine bytes of the lines whose 15-bit entries cannot decide (internal-down / internal-up; tables.h "FINE BYTES"): for the
 // draws ma_search_filters() left. *amb: still undecided (3 draws of 2^24 per entry, or a line that is not usable).
@@ -3955,27 +4004,24 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
 #endif
     MA_PROF_WAIT();
     MA_PROF_MARK(env, 59);
-    double r[MA_N], cum[MA_N];
     // first entry above the last: the record has no usable filter (populate_mafilter_level: its total is not a positive finite
-    // number); the reference's assertion on the total comes before the random number is drawn
-    const bool usable = !((f.w[0] & 0xFFFFu) > (f.w[3] >> 16));
-    if (!usable) {
+    // number). Round 6: ONE test leaves the common path -- "the filter cannot decide, or is not usable, or filters are off" -- and the
+    // random number is drawn before it (the reference asserts on the total first, macroatom.cc:425: a record that fails ends the
+    // call with an error, and what its generator holds then is never looked at).
+    const uint32_t u1 = rng_u24(p);
+    bool amb;
+    action = mafilt_count(f, u1, &amb);
+    // ("cum[8] = total <= zrand * total" never holds: zrand <= 1 - 2^-24, and the product of that with total is below total)
+    const bool unusable = (f.w[0] & 0xFFFFu) > (f.w[3] >> 16);
+    if (__builtin_expect((int)amb | (int)unusable | (int)(env.ma_filters_off != 0), 0)) {
+      double r[MA_N], cum[MA_N];
       ma_load_rates(ma_rates_of(rec, k.nd, k.nu), r, cum);
-      if (!(cum[MA_N - 1] > 0.)) {
+      if (unusable && !(cum[MA_N - 1] > 0.)) {
         fail(env, 40);
         p.ma_level = -1;
         ARTIS_STAT(env, ARTIS_STAT_X_MA_JUMPS);
         return MA_EXIT_FAILED;
       }
-    }
-    const uint32_t u1 = rng_u24(p);
-    const int zi = (int)(u1 >> 9);  // = (int)(zrand * 32768): zrand = u1 * 2^-24
-    bool amb;
-    action = mafilt_count(f, u1, &amb);
-    // ("cum[8] = total <= zrand * total" never holds: zrand <= 1 - 2^-24, and the product of that with total is below total)
-    amb = amb || !usable || env.ma_filters_off != 0;
-    if (amb) {
-      if (usable) ma_load_rates(ma_rates_of(rec, k.nd, k.nu), r, cum);
       const double randomrate = rng_u24_value(u1) * cum[MA_N - 1];
       action = 0;
 #pragma unroll
@@ -3985,19 +4031,21 @@ AHD int ma_jump_internal(const Env &env, Pkt &p, MACtx &k, const U4 *rec) {
   }
   k.njumps++;  // stats::increment(INTERACTIONS) macroatom.cc:430 and the engine's transition counter: ma_flush_stats()
   const bool down = (action == ARTIS_MA_ACTION_INTERNALDOWNSAME);
-  if (down || action == ARTIS_MA_ACTION_INTERNALUPSAME) {
+  static_assert(ARTIS_MA_ACTION_INTERNALDOWNSAME == 4 && ARTIS_MA_ACTION_INTERNALUPSAME == 6, "the test below");
+  if ((action | 2) == 6) {  // down or up, as ONE comparison (the compiler turns "== 4 || == 6" into a tree of branches)
     // macroatom.cc:433-447 and 536-550: one search for both directions, so that a wave runs it once. The target is the
     // number of the direction's cumulative sums <= zrand * (the direction's rate), the last sum (= the rate) left out.
     const uint32_t u2 = rng_u24(p);
     MA_PROF_MARK(env, 60);
-    bool amb;
 #if ARTIS_MA_SPEC_DIR
     const U4 fsel = down ? fdir[0] : fdir[1];
-    int ti = ma_search_filters(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2, &amb, &fsel);
+    int ti = ma_search_filters_first(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2, fsel);
 #else
-    int ti = ma_search_filters(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2, &amb);
+    bool amb2;
+    int ti = ma_search_filters(env, k, rec, down ? MADIR_DOWN : MADIR_UP, u2, &amb2);
+    if (amb2) ti = -1;
 #endif
-    if (amb) {
+    if (__builtin_expect(ti < 0, 0)) {
       if (DEFER) {
         k.defer = (int)(u2 | (down ? 0x1000000u : 0u));
         return MA_EXIT_DEFER;

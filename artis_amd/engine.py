@@ -75,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "artis_amd_last_kernel_table",
     "artis_amd_options_preset",
     "artis_amd_allreduce_estimators", "artis_amd_comm_unique_id", "artis_amd_comm_init", "artis_amd_comm_count",
-    "artis_amd_cache_tiles", "artis_amd_last_tiling", "artis_amd_last_tiling_fills", "artis_amd_last_tiling_parked", "artis_amd_last_pool_resets", "artis_amd_record_tiers", "artis_amd_last_thermal_variants",
+    "artis_amd_cache_tiles", "artis_amd_last_tiling", "artis_amd_last_tiling_fills", "artis_amd_last_tiling_parked", "artis_amd_last_pool_resets", "artis_amd_record_tiers", "artis_amd_last_thermal_variants", "artis_amd_last_pool_usage",
 ]
 
 
@@ -193,8 +193,11 @@ class Engine:
         r = C.c_int64()
         self.L.artis_amd_last_pool_resets.argtypes = [C.c_void_p] * 2
         self._check(self.L.artis_amd_last_pool_resets(self.h, C.byref(r)))
+        pu, pc = C.c_int64(), C.c_int64()
+        self.L.artis_amd_last_pool_usage.argtypes = [C.c_void_p] * 3
+        self._check(self.L.artis_amd_last_pool_usage(self.h, C.byref(pu), C.byref(pc)))
         return {"sweeps": a.value, "tile_fills": b.value, "fill_ms": c.value, "listed": d.value, "sparse_fills": e.value,
-                "cells_filled": f.value, "parked": g.value, "pool_resets": r.value}
+                "cells_filled": f.value, "parked": g.value, "pool_resets": r.value, "pool_units_used": pu.value, "pool_units": pc.value}
 
     # estimator reduction in the C++ host layer (RCCL)
     COMM_ID_BYTES = 128

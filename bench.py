@@ -479,7 +479,12 @@ def main():
                 out["rccl_nranks"] = None
                 print(f"[bench] ncclCommCount not available ({exc})", file=sys.stderr)
         nt, tcells, bpc = eng.cache_tiles()
-        out["config"]["cell_cache"] = {"tiles": nt, "cells_per_tile": tcells, "bytes_per_cell": bpc, **(eng.last_tiling() if nt > 1 else {})}
+        tiers = eng.record_tiers()
+        lt = eng.last_tiling()
+        out["config"]["cell_cache"] = {"tiles": nt, "cells_per_tile": tcells, "bytes_per_cell": bpc, **(lt if nt > 1 else {})}
+        if tiers["ncold"] > 0:  # on-demand macro-atom records: the tiers the engine chose and what the step made of the pool
+            out["config"]["cell_cache"].update(record_tiers=tiers, pool_resets=lt["pool_resets"], pool_units_used=lt["pool_units_used"],
+                                               pool_units=lt["pool_units"])
         bd.update(ma_transitions=int(S("X_MA_JUMPS")), kpkt_steps=int(S("X_KPKT_STEPS")), rpkt_steps=int(S("X_RPKT_STEPS")))
         out["kernel_breakdown_last_step"] = bd
         out["kernel_ms_by_kind_last_step"] = eng.last_kernel_ms_by_kind()

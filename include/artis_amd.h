@@ -571,6 +571,10 @@ int artis_amd_last_pool_resets(artis_amd_engine *eng, int64_t *resets);
  * cell's row (1 = all of them: no on-demand records), the number of cold levels, and the 16-byte slots of the shared pool per resident cell.
  * Two runs are comparable in time and in artis_amd_last_pool_resets() only if these agree. Any pointer may be NULL. (ABI 6) */
 int artis_amd_record_tiers(artis_amd_engine *eng, double *hot_fraction, int32_t *ncold_levels, int64_t *pool_slots);
+/* ... and how much of that pool the last artis_amd_update_packets_device call left in use (since the pool was last emptied), in units of 128
+ * bytes, beside the pool's size: a pool that runs near its size thrashes (artis_amd_last_pool_resets), one far below it could give its memory
+ * to static records (a larger hot fraction). (ABI 6) */
+int artis_amd_last_pool_usage(artis_amd_engine *eng, int64_t *units_used, int64_t *units_cap);
 /* Which forms of the thermal kernel (macro-atom walks + k-packet steps) the last artis_amd_update_packets_device call
  * launched, as a mask: the form is chosen per launch from the atomic data's size and the list's length, and a parity test has to know that the
  * form it means to check is the one that ran. (ABI 6) */

@@ -191,7 +191,7 @@ int64_t artis_emu_mafilter_selftest(int64_t ntrials, uint64_t seed, int64_t *n_a
       for (int i = 0; i < (k < 0 ? -k : k); i++) x = std::nextafter(x, k < 0 ? 0. : 2. * whole);
       v[j] = x;  // ... kept non-decreasing by moving the neighbours it passes
       for (int i = 0; i < j; i++) v[i] = (v[i] < x) ? v[i] : x;
-      for (int i = j + 1; i < 7; i++) v[i] = (v[i] > x) ? v[i] : x;
+      for (int i = j + 1; i < 8; i++) v[i] = (v[i] > x) ? v[i] : x;  // (all eight: the entries of a filter are sorted, mafilt_count() relies on it)
     }
     if ((t & 3) == 1 && (u >> 9) > 0) {  // ... with a value within a few ulp of the edge of the filter cell just below the draw's: zi / 32768 * whole
       const int j = (int)(next() % 7);
@@ -200,7 +200,7 @@ int64_t artis_emu_mafilter_selftest(int64_t ntrials, uint64_t seed, int64_t *n_a
       for (int i = 0; i < (k < 0 ? -k : k); i++) x = std::nextafter(x, k < 0 ? 0. : 2. * whole);
       v[j] = x;
       for (int i = 0; i < j; i++) v[i] = (v[i] < x) ? v[i] : x;
-      for (int i = j + 1; i < 7; i++) v[i] = (v[i] > x) ? v[i] : x;
+      for (int i = j + 1; i < 8; i++) v[i] = (v[i] > x) ? v[i] : x;  // (all eight: the entries of a filter are sorted, mafilt_count() relies on it)
     }
     bool ok = true;
     uint32_t q[8];
