@@ -711,6 +711,24 @@ def build(preset: str = "small", ncoord: int = 8, gridtype: int = abi.GRID_CARTE
     return model, cs, ts, aux
 
 
+def evolve_cellstate(cs: abi.CellState, t0: float, t1: float, tfloor: float = 2500.0) -> abi.CellState:
+    """The cell state of build() carried from time t0 to t1 by a DETERMINISTIC host rule that stands in for update_grid() (which is not part of
+    the packet path) in multi-timestep tests: homologous expansion thins every density as (t0/t1)^3 -- rho, nne, nnetot, the ions' ground-level
+    populations, the NLTE level populations and the non-thermal deposition rate density where the state has them -- and the temperatures
+    (T_e, T_J, T_R, the radiation-field bins' T_R) fall as t0/t1, not below `tfloor`; everything else (W, partition functions, mass
+    fractions, photoionisation renormalisation / coefficients, Spencer-Fano fractions) stays. Same arrays for oracle and engine."""
+    f3, f1 = (t0 / t1) ** 3, t0 / t1
+    d = dict(cs.d)
+    for k in ("rho", "nne", "nnetot", "ion_groundlevelpops", "levelpops", "nt_deposition_rate_density"):
+        if d.get(k) is not None:
+            d[k] = (np.asarray(d[k], dtype=np.float64) * f3).astype(np.asarray(d[k]).dtype)
+    for k in ("Te", "TJ", "TR", "radfieldbin_T_R"):
+        if d.get(k) is not None:
+            a = np.asarray(d[k], dtype=np.float64)
+            d[k] = np.maximum(a * f1, np.minimum(a, tfloor)).astype(np.asarray(d[k]).dtype)
+    return abi.CellState(d)
+
+
 def vpkt_config(expopac: bool = False) -> dict:
     """What read_vpktparameterfile() (vpkt.cc:673) leaves of a vpkt.txt like tests/classicmode_3d_inputfiles/vpkt.txt: three
     observers near +z, on the equator and towards -z (not ON the axis as in that file: there the meridian frame of the

@@ -1,0 +1,125 @@
+"""Full-phase runs: many consecutive timesteps with the packets resident, against the oracle called once per timestep.
+
+What the reference's timestep loop does around the packet path (sn3d.cc:744-797 do_timestep: update_grid -> update_packets -> estimator
+reduction -> next timestep) is restated only as far as the packet path sees it: a deterministic host rule carries the cell state from one
+timestep to the next (synth.evolve_cellstate: densities as t^-3, temperatures as t^-1, the solvers' arrays fixed), the timestep's index moves
+through FIRST_NLTE_RADFIELD_TIMESTEP for the nebular build, pellets decay all through the span. Compared: every packet field to the usual
+bars after the LAST timestep (integer fields, generator states and event counters identical), the estimators summed over the span, and the
+artefact north_star names -- the light curve per time bin (luminosity and comoving luminosity), the spectrum per time bin, and both per
+direction bin (tools/exspec.py: spectrum_lightcurve.cc:544-713 restated).
+CPU: kernel bodies (host emulation) vs oracle, bit-exact, 8 timesteps. GPU: engine vs oracle, 20 timesteps."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+import exspec  # noqa: E402
+import hostemu_binding as emu  # noqa: E402
+import parity  # noqa: E402
+from artis_amd import abi, synth  # noqa: E402
+
+WIDTH = 0.05
+
+
+def _span(options, nts_count, npk, first_nts):
+    model, cs0, _, aux = synth.build("small", ncoord=8, options=options, nts=first_nts)
+    total = (1.0 + WIDTH) ** nts_count - 1.0
+    pk0 = synth.make_packets(model, aux, npk, kpkt_fraction=0.2, gamma_fraction=0.1, pellet_fraction=0.3, ts_width_frac=total)
+    steps, t = [], aux["t"]
+    for i in range(nts_count):
+        ts = synth.make_timestep(t, width_frac=WIDTH, vmax=model["vmax"], nts=first_nts + i)
+        steps.append((synth.evolve_cellstate(cs0, aux["t"], ts.c.mid), ts))
+        t = ts.c.start + ts.c.width
+    return model, pk0, steps
+
+
+def _lightcurves(pk, steps, vmax):
+    starts = np.array([ts.c.start for _, ts in steps])
+    widths = np.array([ts.c.width for _, ts in steps])
+    tmin, tmax = starts[0], starts[-1] + widths[-1]
+    out = {-1: exspec.spectrum_and_lightcurve(pk, starts, widths, tmin, tmax, vmax)}
+    esc = (pk["type"] == abi.TYPE_ESCAPE) & (pk["escape_type"] == abi.TYPE_RPKT)
+    bins = exspec.escapedirectionbin(pk["dir"][esc]) if esc.any() else np.zeros(0, dtype=np.int64)
+    # the three most populated direction bins and one polar bin
+    top = list(np.argsort(np.bincount(bins, minlength=exspec.MABINS))[-3:]) + [0]
+    for b in top:
+        out[int(b)] = exspec.spectrum_and_lightcurve(pk, starts, widths, tmin, tmax, vmax, dirbin=int(b))
+    return out, bins
+
+
+def _compare_lightcurves(la, lb, rtol, what):
+    assert la.keys() == lb.keys(), (what, la.keys(), lb.keys())
+    for b in la:
+        sa, sb = la[b], lb[b]
+        assert sa["nescaped"] == sb["nescaped"], (what, b)
+        for k in ("lum", "lumcmf"):
+            if rtol == 0.0:
+                assert np.array_equal(sa[k], sb[k]), (what, b, k)
+            else:
+                assert np.allclose(sa[k], sb[k], rtol=rtol, atol=0), (what, b, k)
+        if rtol == 0.0:
+            assert np.array_equal(sa["flux"], sb["flux"]), (what, b)
+        else:  # frequencies agree to ~1e-12: a packet changes its bin only on an edge -- groups of 20 frequency bins
+            ca = sa["flux"].reshape(50, 20, -1).sum(axis=1)
+            cb = sb["flux"].reshape(50, 20, -1).sum(axis=1)
+            assert np.abs(ca - cb).max() <= 1e-6 * max(ca.max(), 1e-300), (what, b)
+
+
+@pytest.mark.parametrize("options,npk,first_nts", [("classic", 3000, 10), ("nltenebular", 800, 9)])
+def test_phases_kernel_bodies_match_oracle_bit_exact(oracle, options, npk, first_nts):
+    """8 consecutive timesteps (the nebular build crosses FIRST_NLTE_RADFIELD_TIMESTEP = 12 on the way): host emulation of the kernel
+    bodies vs oracle, every packet field and the light curves bit for bit"""
+    model, pk0, steps = _span(options, 8, npk, first_nts)
+    pa, pb = pk0.copy(), pk0.copy()
+    ea, eb = abi.estimators_for(model, options), abi.estimators_for(model, options)
+    for cs, ts in steps:
+        oracle.update_packets(model, cs, ts, pa, ea, preset=options)
+        emu.update_packets(model, cs, ts, pb, eb, 3, preset=options)
+    parity.compare_packets(pb, pa, 0.0, f"{options}: 8 timesteps, kernel bodies vs oracle")
+    parity.compare_stats(eb, ea, f"{options}: 8 timesteps")
+    parity.compare_estimators(eb, ea, 1e-11, f"{options}: 8 timesteps")
+    la, _ = _lightcurves(pa, steps, model["vmax"])
+    lb, _ = _lightcurves(pb, steps, model["vmax"])
+    _compare_lightcurves(la, lb, 0.0, options)
+    lum = la[-1]["lum"]
+    assert la[-1]["nescaped"] > npk // 20 and np.count_nonzero(lum) >= 6, (la[-1]["nescaped"], lum)  # a light curve, not one bin
+    assert ea.stats[abi.STAT_X_RPKT_STEPS] > 8 * npk
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("options,npk,first_nts", [("classic", 60000, 8), ("nltenebular", 20000, 4)])
+def test_phases_engine_matches_oracle_over_20_timesteps(oracle, options, npk, first_nts):
+    """configs[4]'s "full-phase spectrum" as far as it can be checked here: 20 consecutive timesteps, packets resident on the device, the cell
+    state re-set before every one (cell cache repopulated), against the oracle called once per timestep; packets, counters, estimators
+    to the usual bars; light curve and spectra per time bin, angle-averaged and for four direction bins"""
+    import torch
+
+    assert torch.cuda.is_available()
+    from artis_amd import engine
+
+    model, pk0, steps = _span(options, 20, npk, first_nts)
+    pa, pb = pk0.copy(), pk0.copy()
+    ea, eb = abi.estimators_for(model, options), abi.estimators_for(model, options)
+    for cs, ts in steps:
+        oracle.update_packets(model, cs, ts, pa, ea, preset=options)
+    eng = engine.Engine(model, preset=options)
+    eng.upload_packets(pb)
+    for cs, ts in steps:
+        eng.set_cellstate(cs, ts)
+        eng.step()
+    eng.download_packets(pb)
+    eng.download_estimators(eb)
+    eng.close()
+    rep = parity.compare_packets(pb, pa, 1e-9, f"{options}: 20 timesteps, HIP engine vs oracle")
+    parity.compare_stats(eb, ea, f"{options}: 20 timesteps", same_libm=False)
+    parity.compare_estimators(eb, ea, 1e-9, f"{options}: 20 timesteps")
+    la, bins_a = _lightcurves(pa, steps, model["vmax"])
+    lb, bins_b = _lightcurves(pb, steps, model["vmax"])
+    assert np.array_equal(bins_a, bins_b)  # every escaped packet in the same direction bin
+    _compare_lightcurves(la, lb, 1e-9, options)
+    lum = la[-1]["lum"]
+    assert la[-1]["nescaped"] > npk // 10 and np.count_nonzero(lum) >= 18, (la[-1]["nescaped"], lum)
+    print(f"{options}: 20 timesteps, {la[-1]['nescaped']} escaped, worst float rel diff {rep['worst_rel']:.2e}, "
+          f"L(t) from {lum[lum > 0][0]:.3e} to {lum[-1]:.3e} erg/s")
