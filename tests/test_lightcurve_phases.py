@@ -122,4 +122,4 @@ def test_phases_engine_matches_oracle_over_20_timesteps(oracle, options, npk, fi
     lum = la[-1]["lum"]
     assert la[-1]["nescaped"] > npk // 10 and np.count_nonzero(lum) >= 18, (la[-1]["nescaped"], lum)
     print(f"{options}: 20 timesteps, {la[-1]['nescaped']} escaped, worst float rel diff {rep['worst_rel']:.2e}, "
-          f"L(t) from {lum[lum > 0][0]:.3e} to {lum[-1]:.3e} erg/s")
+          f"L(t) from {lum[lum > 0][0]:.3e} to {lum[lum > 0][-1]:.3e} erg/s")

@@ -33,6 +33,21 @@ evaluated on the packets the engine returns (GPU, `-m gpu`) and on the kernel bo
    homologous expansion, scattering, the macro-atom and the thermal pool (kpkt.cc:441 e_cmf *= t / t_new) -- to the first
    order in v/c: sum(e_cmf t) after a timestep equals the sum before within (v/c)(dt/t). Would catch an energy leak, a missing
    adiabatic loss, an emission in the wrong frame.
+12. Detailed balance channel by channel (round 6). In the same equilibrium medium every process runs as often as its inverse -- counted
+   by the reference's own event counters (stats.h), which see EVERY event, not only a packet's last one, so the law holds at any optical
+   depth: bound-bound absorptions = emissions; photoionisations (macro-atom activations + k-packets made by bound-free absorption) =
+   radiative recombinations (macro-atom deactivations + k-packets cooling free-bound), and separately the macro-atom and the thermal halves
+   of it (bound-free heating = free-bound cooling); free-free absorptions = emissions; collisional excitations out of the thermal pool =
+   collisional de-excitations into it; ionisations inside the macro-atom (internal up to the higher ion) = recombinations (internal down to
+   the lower ion). Would catch a wrong Milne relation or Saha factor in any bound-free rate (rpkt.cc:721 opacity with its stimulated
+   correction, macroatom.cc:141-190, kpkt.cc:123-190 cooling, :519 emission), a wrong split of an absorbed photon between ionisation and
+   heating (rpkt.cc:459-480), a cooling channel with the wrong weight.
+13. Gamma-ray energy deposition counted twice (round 6). The path-length estimator of the deposited energy (gammapkt.cc:568
+   update_gamma_dep: chi_cmf * e_rf * ds * doppler^2 with the mean Compton loss, the photoelectric opacity and the kinetic share of a
+   pair production) and the energy of the packets that actually thermalise in the same span (indivisible packets: Compton scattering
+   deposits a packet with probability 1 - f, gammapkt.cc:266-420, :742-764) estimate the same number: their sums over the grid agree
+   within the Monte Carlo noise of the second. And every gamma packet is escaped, deposited or still in flight, with
+   e_rf(escaped) + e_cmf(deposited) + e_rf(in flight) = the emitted energy to first order in v/c.
 Each would catch a misreading of the transport loop that oracle and kernels share (same hand, same reading): a wrong
 phase function or frame, a wrong sampling law, a channel that is drawn with the wrong weight.
 """
@@ -415,6 +430,91 @@ def _check_hubble_flow_energy(backend, n):
     beta_max = model.d["vmax"] / CLIGHT
     assert abs(after / before - 1.) < beta_max * 0.05 + 2e-3, after / before
     assert abs(after / before - 1.) > 0. or n < 10
+
+
+def _check_te_channel_balance(backend, n):
+    """law 12: the event counters of a run in the equilibrium medium, thick enough for plenty of events of every kind (the counters see them
+    all: a photon emitted just above the dominant ion's edge is absorbed again at once, and counted again on both sides)"""
+    model, cs, ts, aux, T = _te_medium(T=25000., rho=1e-11, width_frac=1e-4)
+    rng = np.random.default_rng(33)
+    pk = _planck_packets(model, aux, n, T, rng)
+    est = backend(model, cs, ts, pk)
+    st = est.stats_dict()
+    pending = int(np.count_nonzero(pk["type"] != abi.TYPE_RPKT))  # absorbed, not emitted yet when the step ended
+    pairs = {
+        "bound-bound": (st["MA_STAT_ACTIVATION_BB"], st["MA_STAT_DEACTIVATION_BB"] + st["K_STAT_TO_R_BB"]),
+        "bound-free": (st["MA_STAT_ACTIVATION_BF"] + st["K_STAT_FROM_BF"], st["MA_STAT_DEACTIVATION_FB"] + st["K_STAT_TO_R_FB"]),
+        "bound-free, macro-atom": (st["MA_STAT_ACTIVATION_BF"], st["MA_STAT_DEACTIVATION_FB"]),
+        "bound-free, thermal pool": (st["K_STAT_FROM_BF"], st["K_STAT_TO_R_FB"]),
+        "free-free": (st["K_STAT_FROM_FF"], st["K_STAT_TO_R_FF"]),
+        "collisional (bound-bound)": (st["K_STAT_TO_MA_COLLEXC"], st["MA_STAT_DEACTIVATION_COLLDEEXC"]),
+        "collisional (bound-free)": (st["K_STAT_TO_MA_COLLION"], st["MA_STAT_DEACTIVATION_COLLRECOMB"]),
+        "ionisation inside the macro-atom": (st["MA_STAT_INTERNALUPHIGHER"], st["MA_STAT_INTERNALDOWNLOWER"]),
+    }
+    assert st["K_STAT_TO_MA_COLLEXC"] == st["MA_STAT_ACTIVATION_COLLEXC"] and st["K_STAT_TO_MA_COLLION"] == st["MA_STAT_ACTIVATION_COLLION"]
+    total_in = st["MA_STAT_ACTIVATION_BB"] + st["MA_STAT_ACTIVATION_BF"] + st["K_STAT_FROM_BF"] + st["K_STAT_FROM_FF"]
+    total_out = st["MA_STAT_DEACTIVATION_BB"] + st["MA_STAT_DEACTIVATION_FB"] + st["K_STAT_TO_R_FB"] + st["K_STAT_TO_R_FF"] + st["K_STAT_TO_R_BB"]
+    assert total_in - total_out == pending, (total_in, total_out, pending)  # bookkeeping: what went in and is not out is still inside
+    assert total_in > n // 20
+    worst = 0.
+    for name, (fwd, bwd) in pairs.items():
+        # the difference of the two counts is a sum of +1 / -1 over the events that change channel: its variance is at most their sum
+        sigma = np.sqrt(max(fwd + bwd, 1))
+        z = (fwd - bwd) / sigma
+        worst = max(worst, abs(z))
+        assert abs(fwd - bwd) <= 4.5 * sigma + pending, (name, fwd, bwd)
+    for name in ("bound-free", "free-free", "collisional (bound-bound)", "ionisation inside the macro-atom"):
+        assert min(pairs[name]) > n // 400, (name, pairs[name])  # the channels the law is about do occur
+    return pairs, worst
+
+
+def _check_gamma_deposition(backend, n):
+    """law 13: gamma packets born all over the synthetic ejecta at t = 20 d, one timestep of 5 %"""
+    model, cs, ts, aux = synth.build("small", ncoord=8, width_frac=0.05)
+    pk = synth.make_packets(model, aux, n, kpkt_fraction=0.0, gamma_fraction=1.0, seed=41)
+    assert np.all(pk["type"] == abi.TYPE_GAMMA)
+    e0_rf, e0_cmf = pk["e_rf"].copy(), pk["e_cmf"].copy()
+    est = backend(model, cs, ts, pk)
+    ty = pk["type"]
+    esc = (ty == abi.TYPE_ESCAPE) & (pk["escape_type"] == abi.TYPE_GAMMA)  # left the grid as a gamma ray
+    fly = ty == abi.TYPE_GAMMA
+    # thermalised: a non-thermal lepton's deposit, by now a k-packet, an r-packet (perhaps escaped as one) or an active macro-atom
+    dep = ~esc & ~fly
+    assert esc.sum() > n // 50 and dep.sum() > n // 10, (esc.sum(), dep.sum(), fly.sum())
+    assert est.stats_dict()["NT_STAT_FROM_GAMMA"] == dep.sum()
+    # (a) the two estimates of the deposited energy. A deposited packet carries on as a k-packet / r-packet, whose e_cmf follows e_cmf * t =
+    # const from the deposit to the end of the step (law 11): its energy AT the deposit lies between e_cmf now and e_cmf * t_end / t_start
+    analog_lo = pk["e_cmf"][dep].sum()
+    analog_hi = analog_lo * (1. + 0.05)
+    est_dep = est.dep_estimator_gamma.sum()
+    noise = 4.5 * e0_cmf.mean() * np.sqrt(dep.sum())  # the analog count's Poisson noise (the estimator's is much smaller)
+    assert analog_lo - noise <= est_dep <= analog_hi + noise, (analog_lo, est_dep, analog_hi, noise)
+    assert abs(est_dep / (0.5 * (analog_lo + analog_hi)) - 1.) < 0.06
+    # (b) energy bookkeeping to first order in v/c
+    total = pk["e_rf"][esc].sum() + pk["e_cmf"][dep].sum() + pk["e_rf"][fly].sum()
+    beta = model.d["vmax"] / CLIGHT
+    assert abs(total / e0_rf.sum() - 1.) < 2. * beta + 0.05, total / e0_rf.sum()
+    return est_dep / (0.5 * (analog_lo + analog_hi)), int(dep.sum()), int(esc.sum())
+
+
+def test_detailed_balance_channel_by_channel_kernel_bodies():
+    _check_te_channel_balance(_backend_emu, 400_000)
+
+
+def test_gamma_deposition_estimator_and_analog_kernel_bodies():
+    _check_gamma_deposition(_backend_emu, 200_000)
+
+
+@pytest.mark.gpu
+def test_detailed_balance_channel_by_channel_engine():
+    pairs, worst = _check_te_channel_balance(_backend_gpu, 8_000_000)
+    print("TE channel balance:", {k: v for k, v in pairs.items()}, f"worst {worst:.2f} sigma")
+
+
+@pytest.mark.gpu
+def test_gamma_deposition_estimator_and_analog_engine():
+    ratio, ndep, nesc = _check_gamma_deposition(_backend_gpu, 2_000_000)
+    print(f"gamma deposition: estimator / analog = {ratio:.4f} ({ndep} deposited, {nesc} escaped)")
 
 
 def test_macroatom_reciprocity_in_equilibrium_kernel_bodies():
