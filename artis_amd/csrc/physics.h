@@ -355,14 +355,27 @@ AHD void set_restframe_from_cmf(Pkt &p) {
   p.nu_rf = p.nu_cmf / d;
   p.e_rf = p.e_cmf / d;
 }
+// sin and cos of one angle. On the device ONE call with one argument reduction (round 6: every site of the packet path wants both; as two
+// calls they were 1400 of k_rpkt's 13 900 instructions, run by a wave whenever one of its lanes scatters or emits). The host emulation keeps
+// the two calls of the reference (vectors.h), whose bits the oracle has.
+AHD void sin_cos(double x, double *s, double *c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(x, s, c);
+#else
+  *s = sin(x);
+  *c = cos(x);
+#endif
+}
 // get_rand_isotropic_unitvec vectors.h:185
 AHD void rand_isotropic(Pkt &p, double out[3]) {
   const double u = rng_uniform(p);
   const double costheta = (2. * u) - 1.;
   const double sintheta = 2. * sqrt(u * (1. - u));
   const double phi = rng_uniform(p) * 2 * PI;
-  out[0] = sintheta * cos(phi);
-  out[1] = sintheta * sin(phi);
+  double sphi, cphi;
+  sin_cos(phi, &sphi, &cphi);
+  out[0] = sintheta * cphi;
+  out[1] = sintheta * sphi;
   out[2] = costheta;
 }
 // get_rot_angle vectors.h:196
@@ -420,8 +433,8 @@ ANOINLINE void frame_transform(const double n_rf[3], double q0, double u0, const
     const double pol_angle = atan2(u0, q0);
     ra = (pol_angle < 0 ? pol_angle + (2. * PI) : pol_angle) / 2.;
   }
-  const double cr = cos(ra);
-  const double sr = sin(ra);
+  double sr, cr;
+  sin_cos(ra, &sr, &cr);
   const double elec_rf[3] = {(cr * ref1_rf[0]) - (sr * ref2_rf[0]), (cr * ref1_rf[1]) - (sr * ref2_rf[1]),
                              (cr * ref1_rf[2]) - (sr * ref2_rf[2])};
   angle_ab(n_rf, v, n_cmf);
@@ -433,8 +446,10 @@ ANOINLINE void frame_transform(const double n_rf[3], double q0, double u0, const
   const double c2 = vdot(elec_cmf, ref2_cmf);
   double theta = atan2(-c2, c1);
   if (theta < 0) theta += 2 * PI;
-  *q_cmf = cos(2 * theta) * pdeg;
-  *u_cmf = sin(2 * theta) * pdeg;
+  double s2t, c2t;
+  sin_cos(2 * theta, &s2t, &c2t);
+  *q_cmf = c2t * pdeg;
+  *u_cmf = s2t * pdeg;
 }
 // scatter_polarisation_to_rf vectors.h:325
 ANOINLINE void scatter_polarisation_to_rf(const double old_dir_cmf[3], const double new_dir_cmf[3], double q_i, double u_i,
@@ -442,8 +457,8 @@ ANOINLINE void scatter_polarisation_to_rf(const double old_dir_cmf[3], const dou
   double r1o[3], r2o[3];
   meridian(old_dir_cmf, r1o, r2o);
   const double i1 = rot_angle(old_dir_cmf, new_dir_cmf, r1o, r2o);
-  const double cos2i1 = cos(2 * i1);
-  const double sin2i1 = sin(2 * i1);
+  double sin2i1, cos2i1;
+  sin_cos(2 * i1, &sin2i1, &cos2i1);
   const double q_old = (q_i * cos2i1) - (u_i * sin2i1);
   const double u_old = (q_i * sin2i1) + (u_i * cos2i1);
   const double mu = vdot(old_dir_cmf, new_dir_cmf);
@@ -454,8 +469,8 @@ ANOINLINE void scatter_polarisation_to_rf(const double old_dir_cmf[3], const dou
   double r1[3], r2[3];
   meridian(new_dir_cmf, r1, r2);
   const double i2 = PI + rot_angle(new_dir_cmf, old_dir_cmf, r1, r2);
-  const double cos2i2 = cos(2 * i2);
-  const double sin2i2 = sin(2 * i2);
+  double sin2i2, cos2i2;
+  sin_cos(2 * i2, &sin2i2, &cos2i2);
   const double q_cmf = (q_new * cos2i2) + (u_new * sin2i2);
   const double u_cmf = (-q_new * sin2i2) + (u_new * cos2i2);
   const double nv[3] = {-vel[0], -vel[1], -vel[2]};
@@ -1874,7 +1889,17 @@ AHD float phixs_finish(const DevModel &M, const PhixsRead r, double nu_edge, dou
   if (r.i < 0) return 0.f;
 #if ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION
   if (r.i < NP) return r.a;
+  // beyond the table: the last point extrapolated as nu^-3 (atomic.h:222 pow(nu_max_phixs / nu, 3)). On the device the cube is two
+  // multiplications (round 6): within 2 ulp of the correctly rounded power, i.e. 2e-16 of a value that is rounded to float next -- the device's
+  // pow() was no closer to glibc's, but cost a call with its constants in scratch inside the opacity sum (26 scratch instructions and ~150
+  // others per continuum beyond its table: the continua of excited levels seen by an ultraviolet packet, a third of all visits). The host
+  // emulation keeps pow(): it is compared with the oracle bit for bit.
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double x = nu_edge * (1 + (INC * NP)) / nu;
+  return (float)(r.a * (x * x * x));
+#else
   return (float)(r.a * pow(nu_edge * (1 + (INC * NP)) / nu, 3));
+#endif
 #else
   if (r.i < NP - 1) {
     const double a = r.a;
@@ -2705,7 +2730,9 @@ AHD void electron_scatter(Pkt &p) {
       Mc = (2. * rng_uniform_pos(p)) - 1.;
       const double mu2 = pow2(Mc);
       phisc = 2 * PI * rng_uniform(p);
-      pfn = (mu2 + 1) + ((mu2 - 1) * ((cos(2 * phisc) * q_i) + (sin(2 * phisc) * u_i)));
+      double s2p, c2p;
+      sin_cos(2 * phisc, &s2p, &c2p);
+      pfn = (mu2 + 1) + ((mu2 - 1) * ((c2p * q_i) + (s2p * u_i)));
       x = 2. * rng_uniform(p);
     }
   }
@@ -2719,14 +2746,16 @@ AHD void electron_scatter(Pkt &p) {
   if (fabs(old_cmf[2]) < 0.99999) {
     const double sin_polar = sqrt(1. - pow2(old_cmf[2]));
     const double cf = sin_tsc / sin_polar;
-    const double cph = cos(phisc);
-    const double sph = sin(phisc);
+    double sph, cph;
+    sin_cos(phisc, &sph, &cph);
     new_cmf[0] = (cf * ((old_cmf[1] * sph) - (old_cmf[0] * old_cmf[2] * cph))) + (old_cmf[0] * cos_tsc);
     new_cmf[1] = (cf * ((-old_cmf[0] * sph) - (old_cmf[1] * old_cmf[2] * cph))) + (old_cmf[1] * cos_tsc);
     new_cmf[2] = (sin_tsc * cph * sin_polar) + (old_cmf[2] * cos_tsc);
   } else {
-    new_cmf[0] = sin_tsc * cos(phisc);
-    new_cmf[1] = sin_tsc * sin(phisc);
+    double sph, cph;
+    sin_cos(phisc, &sph, &cph);
+    new_cmf[0] = sin_tsc * cph;
+    new_cmf[1] = sin_tsc * sph;
     new_cmf[2] = (old_cmf[2] > 0) ? cos_tsc : -cos_tsc;
   }
 #if ARTIS_OPT_POL_ON
@@ -3410,7 +3439,9 @@ AHD void vray_begin(const Env &env, const VpktSeed &r, double t_arrive, double n
     double ref1[3], ref2[3];
     meridian(old_dir_cmf, ref1, ref2);
     const double i1 = rot_angle(old_dir_cmf, obs_cmf, ref1, ref2);
-    const double q_old = (q_i_cmf * cos(2 * i1)) - (u_i_cmf * sin(2 * i1));
+    double s2i, c2i;
+    sin_cos(2 * i1, &s2i, &c2i);
+    const double q_old = (q_i_cmf * c2i) - (u_i_cmf * s2i);
     const double musquared = pow2(vdot(old_dir_cmf, obs_cmf));
     pn = 3. / (16. * PI) * (1. + musquared + ((musquared - 1.) * q_old));
   }
@@ -5013,8 +5044,10 @@ AHD void scatter_dir(const double dir_in[3], double cos_theta, Pkt &p, double di
   const double sin_theta_sq = 1. - pow2(cos_theta);
   const double sin_theta = sqrt(sin_theta_sq);
   const double zprime = cos_theta;
-  const double xprime = sin_theta * cos(phi);
-  const double yprime = sin_theta * sin(phi);
+  double sphi, cphi;
+  sin_cos(phi, &sphi, &cphi);
+  const double xprime = sin_theta * cphi;
+  const double yprime = sin_theta * sphi;
   if (fabs(dir_in[2]) > 0.999999999) {
     dir_out[0] = xprime;
     dir_out[1] = yprime;

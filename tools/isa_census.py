@@ -22,18 +22,18 @@ sys.path.insert(0, ROOT)
 from artis_amd import build as B  # noqa: E402
 
 KERNELS = {  # substring of the mangled name -> label
-    "9k_thermalILi1024ELi1E": "k_thermal<1024, 1>",
+    "9k_thermalILi1024ELi1ELb0E": "k_thermal<1024, 1, false>",
     "6k_rpktILb1ELi768ELb0E": "k_rpkt<true, 768>",
 }
 # the hot loops, found in the source by their tags: (kernel substring, name, reference lines, file, tag, largest body in assembly lines)
 HOT = [
-    ("9k_thermalILi1024ELi1E", "transition loop", "macroatom.cc:385-577", "artis_engine.hip", "[census: transition loop]", 1100),
+    ("9k_thermalILi1024ELi1ELb0E", "transition loop", "macroatom.cc:385-577", "artis_engine.hip", "[census: transition loop]", 520),
     ("6k_rpktILb1ELi768ELb0E", "opacity sum", "rpkt.cc:721-830", "physics.h", "[census: opacity sum]", 1100),
     ("6k_rpktILb1ELi768ELb0E", "line walk", "rpkt.cc:106-207", "physics.h", "[census: line walk]", 1500),
 ]
 
 
-MIN_BODY = 300  # assembly lines
+MIN_BODY = 120  # assembly lines (the transition loop's body is ~330 since round 6)
 
 
 def tagged_range(path, tag):
@@ -47,6 +47,29 @@ def tagged_range(path, tag):
         if depth == 0 and i > first:
             return first + 1, i + 1
     raise RuntimeError(tag)
+
+
+_FUNC_CACHE = {}
+
+
+def enclosing_function(path: str, line: int) -> str:
+    """name of the function whose definition precedes `line` in a source file (a definition = a line at column 0 that opens one:
+    AHD / __device__ / template-less `type name(`); '?' outside the tree"""
+    if not os.path.exists(path):
+        return "(library)"
+    if path not in _FUNC_CACHE:
+        defs = []
+        for i, ln in enumerate(open(path, errors="replace").read().splitlines(), 1):
+            m = re.match(r"^(?:AHD|ANOINLINE|__device__|__global__|static|inline|template\s*<[^>]*>\s*AHD)\b[^;]*?\b([A-Za-z_]\w*)\s*\(", ln)
+            if m and not ln.rstrip().endswith(";"):
+                defs.append((i, m.group(1)))
+        _FUNC_CACHE[path] = defs
+    name = "?"
+    for i, n in _FUNC_CACHE[path]:
+        if i > line:
+            break
+        name = n
+    return name
 
 
 def classify(op: str) -> str:
@@ -120,6 +143,7 @@ def main():
         print("| loop | ISA loop body: instr | VALU | SALU | VMEM | LDS | SMEM | branch | wait | v_readlane / v_writelane | scratch_ |")
         print("|---|---|---|---|---|---|---|---|---|---|---|")
         uniq = sorted(set(loops), key=lambda t: t[1] - t[0])
+        sub = []
         for kkey, name, ref, fname, tag, max_body in HOT:
             if kkey != key:
                 continue
@@ -140,11 +164,26 @@ def main():
                 c = collections.Counter(classify(op) for op, _, _ in inside)
                 print(f"| {name}, copy {n + 1} of {len(taken)} ({ref}; {fname}:{lo_l}-{hi_l}) | {len(inside)} | {c['valu']} | {c['salu']} | {c['vmem']} | "
                       f"{c['lds']} | {c['smem']} | {c['branch']} | {c['wait']} | {c['sgpr_spill_lane_ops']} | {c['scratch']} |")
+                if name == "transition loop" or os.environ.get("CENSUS_BLOCKS"):
+                    # the body by SUB-BLOCK: its instructions grouped by the source function their line belongs to (the generator, the
+                    # action-filter and direction-filter counts, the search, the target decode, the loop's own tests and counters ...)
+                    blocks = collections.defaultdict(collections.Counter)
+                    for op, f, l in inside:
+                        src = os.path.join(B.CSRC, f) if f in ("physics.h", "tables.h", "artis_engine.hip", "model_build.h") else f
+                        blocks[enclosing_function(src, l) if l else "(no line)"][classify(op)] += 1
+                    sub.append((name, n + 1, blocks))
                 if os.environ.get("CENSUS_LINES"):  # the body's instructions by source line (to stderr: not part of the table)
                     by = collections.Counter((f, l) for _, f, l in inside)
                     for (f, l), cnt in sorted(by.items(), key=lambda t: (t[0][0], t[0][1])):
                         print(f"    {name} copy {n + 1}: {f}:{l} {cnt}", file=sys.stderr)
         print()
+        for lname, copy, blocks in sub:
+            print(f"### {label}: {lname}, copy {copy}, by sub-block (source function of each instruction's line; static counts)\n")
+            print("| sub-block | instr | VALU | SALU | VMEM | LDS | branch | wait |")
+            print("|---|---|---|---|---|---|---|---|")
+            for fn, c in sorted(blocks.items(), key=lambda t: -sum(t[1].values())):
+                print(f"| `{fn}` | {sum(c.values())} | {c['valu']} | {c['salu']} | {c['vmem']} | {c['lds']} | {c['branch']} | {c['wait']} |")
+            print()
 
 
 if __name__ == "__main__":
