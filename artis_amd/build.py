@@ -20,8 +20,13 @@ SOURCES = ["artis_engine.hip", "physics.h", "tables.h", "model_build.h"]
 #   Round 3: tools/slp_repro.sh builds the nltenebular library WITH SLP vectorisation and runs that test: it passes now
 #   (profiles/r03/slp_repro.txt: the code around the store has changed since); the flag stays as a guard, and the classic
 #   bench is 1 % faster with it than without.
+# -mllvm -disable-machine-licm (round 6): the machine-level loop-invariant code motion hoists the materialisation of every literal a loop body
+#   uses (the polynomial coefficients of exp / log / sincos, masks, table strides) out of the propagation kernels' long loops, and the register
+#   allocator then spills those long-lived values: k_rpkt 48 spilled VGPRs / 416 B of scratch -> 0 / 256 B (its stack arrays), none left inside the
+#   opacity sum or the line walk; k_thermal 59 -> 16; k_tail 1109 -> 0; nltenebular k_thermal 253 -> 47 (tools/kernel_resources.py). A literal
+#   re-made inside a loop is one v_mov; a spilled one is a scratch round trip.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-munsafe-fp-atomics",
-         "-fno-slp-vectorize", "-ldl"]
+         "-fno-slp-vectorize", "-mllvm", "-disable-machine-licm", "-ldl"]
 
 
 PRESETS = ("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal", "nltenebular_lineest", "kilonova_barnes", "kilonova_wollaeger", "kilonova_gammaproducts",

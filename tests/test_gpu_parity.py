@@ -1147,6 +1147,7 @@ def test_full_size_properties_50cubed_1e7_packets(engine_mod, options, npk, t_da
     if "vpkt" in options:  # virtual packets were traced and reached the observers' spectra
         assert e1.stats[abi.STAT_X_VPKT_CREATED] > npk and e1.vspecpol.sum() > 0
     assert np.all(e1.J >= 0) and e1.J.sum() > 0 and np.all(np.isfinite(e1.gammaestimator))
+    keep = p1 if options == "classic" else None  # (for the fresh-engine comparison below)
     del p1
 
     half = npk // 2                                                    # (3) additivity over a split of the population
@@ -1162,3 +1163,19 @@ def test_full_size_properties_50cubed_1e7_packets(engine_mod, options, npk, t_da
         scale = max(np.abs(whole).max(), 1e-300)
         assert np.abs(parts - whole).max() / scale < 1e-9, k
     eng.close()
+    if keep is not None:
+        # (4) round 6: a second, FRESH engine (its own allocations, list buffers, pool and launch history) gives the same packets field by field and
+        # the same counters: the two races of round 5 (a sort key beyond the histogram; a tail packet appended to a list other waves still read)
+        # showed only across engines and only now and then, at this size
+        del pa, pb
+        eng2 = engine_mod.Engine(model, preset=options)
+        eng2.set_cellstate(cs, ts)
+        p3 = pk0.copy()
+        e3 = abi.estimators_for(model, options)
+        eng2.update_packets(p3, e3)
+        eng2.close()
+        assert np.array_equal(e3.stats[mask], e1.stats[mask])
+        for f in abi.PACKET_DTYPE.names:
+            assert np.array_equal(p3[f], keep[f], equal_nan=True), f"fresh engine: {f}"
+        esc3 = p3["type"] == abi.TYPE_ESCAPE
+        assert np.all(p3["prop_time"][~esc3] == t_end)   # no packet ends before the timestep does there either
