@@ -816,12 +816,13 @@ __global__ void __launch_bounds__(BLOCK) k_aos_cellkeys(const artis_packet *aos,
 }
 
 // append (pi, key) of every lane with flag set to list[] / keys[], one atomic per wave (wave-ballot compaction)
-// hist != nullptr (round 6): the list's key histogram is kept where its entries are appended -- one fire-and-forget atomic per entry beside the
-// producing kernel's other work -- instead of by a kernel that reads every key again before the sort (k_sort_hist: 14 of the sorts' 36 ms per step)
-__device__ inline void wave_append(bool flag, int32_t pi, int32_t key, int32_t *list, int32_t *keys, int32_t *count, int32_t *hist = nullptr) {
+// (Round 6, measured and removed: the list's key histogram kept HERE -- one fire-and-forget atomic per appended entry -- instead of by
+// k_sort_hist before the sort. Headline step 759.2 ms against 759.9: the 2.7e8 extra atomics per step cost inside the propagation kernels what
+// the 14 ms of histogram kernels cost outside them; and one run of the kilonova_expopac build at 50^3 / 1e7 gave different counters from the
+// same snapshot with it. profiles/r06/fused_histogram.md)
+__device__ inline void wave_append(bool flag, int32_t pi, int32_t key, int32_t *list, int32_t *keys, int32_t *count) {
   const unsigned long long mask = __ballot(flag);
   if (mask == 0) return;
-  if (flag && hist != nullptr) (void)__hip_atomic_fetch_add(&hist[key], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int lane = threadIdx.x & 63;
   const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
   int base = 0;
@@ -861,8 +862,6 @@ struct Lists {
   int32_t mabins;             // sub-keys of the thermal list's keys (1 = sort by cell only)
   int32_t numajor;            // > 0 = the cell groups of the grid: r-packet keys with the frequency bin as the MAJOR part (ARTIS_AMD_SORT_NUMAJOR=0: cell-major)
   int32_t cellshift;          // ... groups of 2^cellshift cells with neighbouring indices share a key (ARTIS_AMD_SORT_CELLSHIFT)
-  int32_t *hist[NEXT_NKINDS]; // key histograms of the current lists that are sorted before their launch (null: counted by the sort itself)
-  int32_t *self_hist;         // ... of the running kernel's alternate list
 };
 // ma_sub: (tuning, ARTIS_AMD_MABINS=16) a sub-key 0..15 of a thermal-list entry below its cell, -1: none
 __device__ inline void append_by_kind(int kind, int32_t pi, int32_t cellindex, double nu_cmf, const Lists &L, int ma_sub = -1) {
@@ -876,8 +875,7 @@ __device__ inline void append_by_kind(int kind, int32_t pi, int32_t cellindex, d
     int32_t *dst = (k == L.self_kind) ? L.self_list : L.lst[k];
     int32_t *dkey = (k == L.self_kind) ? L.self_key : L.key[k];
     int32_t *cnt = (k == L.self_kind) ? L.self_count : (L.counts + k);
-    int32_t *hist = (k == L.self_kind) ? L.self_hist : L.hist[k];
-    wave_append(slot == k, pi, key, dst, dkey, cnt, hist);
+    wave_append(slot == k, pi, key, dst, dkey, cnt);
   }
 }
 // start of update_packets(): every resident packet is put on the list of its kind. A ContinuumOpacity never survives
@@ -2351,10 +2349,6 @@ struct artis_amd_engine {
   bool use_perm = false;                      // d_perm describes the resident population
   bool slot_order_by_cell = true;             // ARTIS_AMD_SLOTSORT=0: slots in the caller's order
   int32_t *d_hist = nullptr;                  // [ngrid * SORT_NUBINS + 1]
-  // key histograms of the r-packet and thermal lists (both buffers of each), counted by the kernels that append the entries (wave_append);
-  // zero whenever their list is empty. Null: small grids (the sorts count in LDS) or ARTIS_AMD_FUSEHIST=0 (round 5: k_sort_hist before every sort)
-  int32_t *d_khist[NEXT_NKINDS][2] = {};
-  size_t khist_bytes[NEXT_NKINDS] = {};
   int32_t *d_tiles = nullptr;                 // scan tile totals
   int32_t *d_count = nullptr;                 // [NEXT_NKINDS] current-list counts, [NEXT_NKINDS] alternate-list count
   int32_t *d_cursors = nullptr;               // [MAX_CHUNKS] chunk cursors of the running pull kernel
@@ -3052,18 +3046,6 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
     e->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   HIP_TRY(hipMalloc((void **)&e->d_hist, sizeof(int32_t) * ((size_t)h.ngrid * SORT_NUBINS + 1)));
-  {
-    const char *fh = std::getenv("ARTIS_AMD_FUSEHIST");
-    const bool fuse = (fh == nullptr || std::atoi(fh) != 0) && (int64_t)h.ngrid * SORT_MABINS > SORT_LDS_KEYS;
-    const int kinds[2] = {NEXT_RPKT, NEXT_MA};
-    const size_t nk[2] = {(size_t)h.ngrid * SORT_NUBINS + SORT_NUBINS + 1, (size_t)h.ngrid * SORT_MABINS + 1};
-    for (int i = 0; i < 2 && fuse; i++)
-      for (int b = 0; b < 2; b++) {
-        e->khist_bytes[kinds[i]] = sizeof(int32_t) * nk[i];
-        HIP_TRY(hipMalloc((void **)&e->d_khist[kinds[i]][b], e->khist_bytes[kinds[i]]));
-        HIP_TRY(hipMemset(e->d_khist[kinds[i]][b], 0, e->khist_bytes[kinds[i]]));
-      }
-  }
   HIP_TRY(hipMalloc((void **)&e->d_tiles, sizeof(int32_t) * (((size_t)h.ngrid * SORT_NUBINS) / SCAN_TILE + 2)));
   HIP_TRY(hipEventCreate(&e->ev0));
   HIP_TRY(hipEventCreate(&e->ev1));
@@ -3148,9 +3130,6 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
   free_packet_buffers(e);
-  for (int k = 0; k < NEXT_NKINDS; k++)
-    for (int b = 0; b < 2; b++)
-      if (e->d_khist[k][b]) (void)hipFree(e->d_khist[k][b]);
   void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_resident, e->d_fill_cells,
                   e->d_nfill, e->d_bfrate_kept, e->d_collexc_terms, e->d_visit_counts};
   for (void *p : ptrs)
@@ -3461,36 +3440,25 @@ namespace {
 // 20^3 cells, 1e7 packets: k_thermal 907 ms sorted, 725 ms unsorted), while the locality the sort buys matters less
 // because fewer cells' tables compete for the caches. Models with so few cells that the kernels accumulate their per-cell
 // estimators in LDS (Env::cellest_lds) have no such atomics and are always sorted (6^3 cells: 494 ms sorted, 593 unsorted).
-// prehist: the list's key histogram as the kernels that appended its entries left it (wave_append), of prehist_bytes; it is used in place of a
-// counting pass and left ZERO (the list is consumed: its buffer starts its next generation empty) -- also when the list is not sorted at all.
 int sort_by_key(artis_amd_engine *e, hipStream_t s, const int32_t *list, const int32_t *keys, int32_t n, const int32_t **out, int nbins,
-                int64_t ncells, int max_per_cell, int32_t nkeys_given = 0, int32_t *prehist = nullptr, size_t prehist_bytes = 0) {
+                int64_t ncells, int max_per_cell, int32_t nkeys_given = 0) {
   *out = list;
-  const bool skip = !e->sort_lists || n < 2 * BLOCK || (int64_t)n > (int64_t)max_per_cell * (ncells > 0 ? ncells : 1);
-  if (skip) {
-    if (prehist != nullptr) HIP_TRY(hipMemsetAsync(prehist, 0, prehist_bytes, s));
-    return ARTIS_OK;
-  }
+  if (!e->sort_lists || n < 2 * BLOCK) return ARTIS_OK;
+  if ((int64_t)n > (int64_t)max_per_cell * (ncells > 0 ? ncells : 1)) return ARTIS_OK;
   const int32_t nkeys = nkeys_given > 0 ? nkeys_given : e->Mh.ngrid * nbins;
-  int32_t *hist = e->d_hist;
-  if (prehist != nullptr && nkeys > SORT_LDS_KEYS && sizeof(int32_t) * (size_t)(nkeys + 1) <= prehist_bytes) {
-    hist = prehist;
-  } else {
-    HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(nkeys + 1), s));
-    if (nkeys <= SORT_LDS_KEYS)
-      hipLaunchKernelGGL(k_sort_hist_lds, dim3(sort_lds_grid(n)), dim3(BLOCK), 0, s, keys, n, e->d_hist, nkeys);
-    else
-      hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n)), dim3(BLOCK), 0, s, keys, n, e->d_hist);
-  }
-  const int ntiles = (nkeys + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, s, hist, nkeys, e->d_tiles);
-  hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, e->d_tiles, ntiles);
-  hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(1024), 0, s, hist, nkeys, e->d_tiles);
+  HIP_TRY(hipMemsetAsync(e->d_hist, 0, sizeof(int32_t) * (size_t)(nkeys + 1), s));
   if (nkeys <= SORT_LDS_KEYS)
-    hipLaunchKernelGGL(k_sort_scatter_lds, dim3(sort_lds_grid(n)), dim3(BLOCK), 0, s, list, keys, n, hist, e->d_sorted, nkeys);
+    hipLaunchKernelGGL(k_sort_hist_lds, dim3(sort_lds_grid(n)), dim3(BLOCK), 0, s, keys, n, e->d_hist, nkeys);
   else
-    hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, keys, n, hist, e->d_sorted);
-  if (prehist != nullptr) HIP_TRY(hipMemsetAsync(prehist, 0, prehist_bytes, s));
+    hipLaunchKernelGGL(k_sort_hist, dim3(nblocks(n)), dim3(BLOCK), 0, s, keys, n, e->d_hist);
+  const int ntiles = (nkeys + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(k_scan_tiles, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
+  hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, s, e->d_tiles, ntiles);
+  hipLaunchKernelGGL(k_scan_add, dim3(ntiles), dim3(1024), 0, s, e->d_hist, nkeys, e->d_tiles);
+  if (nkeys <= SORT_LDS_KEYS)
+    hipLaunchKernelGGL(k_sort_scatter_lds, dim3(sort_lds_grid(n)), dim3(BLOCK), 0, s, list, keys, n, e->d_hist, e->d_sorted, nkeys);
+  else
+    hipLaunchKernelGGL(k_sort_scatter, dim3(nblocks(n)), dim3(BLOCK), 0, s, list, keys, n, e->d_hist, e->d_sorted);
   *out = e->d_sorted;
   return ARTIS_OK;
 }
@@ -3560,17 +3528,6 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   const int32_t r_ngroups = (e->sort_cellshift > 0) ? ((e->Mh.ngrid >> e->sort_cellshift) + 1) : e->Mh.ngrid;
   int32_t cnt[2 * NEXT_NKINDS];                        // host copy of the device counters
   bool pool_reset_due = false;
-  // the key histogram that travels with buffer b of a kind's list (kept by the appending kernels): only for the kinds that are sorted
-  auto khist_of = [&](int k, int b) -> int32_t * {
-    if (!e->sort_lists || !(k == NEXT_RPKT || (k == NEXT_MA && e->sort_ma))) return nullptr;
-    return e->d_khist[k][b];
-  };
-  auto zero_khists = [&]() -> int {
-    for (int k = 0; k < NEXT_NKINDS; k++)
-      for (int b = 0; b < 2; b++)
-        if (e->d_khist[k][b]) HIP_TRY(hipMemsetAsync(e->d_khist[k][b], 0, e->khist_bytes[k], s));
-    return ARTIS_OK;
-  };
   auto lists_for = [&](int self_kind) {
     Lists L;
     for (int k = 0; k < NEXT_NKINDS; k++) {
@@ -3587,8 +3544,6 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     L.numajor = e->sort_numajor ? r_ngroups : 0;
     L.cellshift = e->sort_cellshift;
     L.mabins = e->ma_bins;
-    for (int k = 0; k < NEXT_NKINDS; k++) L.hist[k] = khist_of(k, cur[k]);
-    L.self_hist = self_kind > 0 ? khist_of(self_kind, 1 - cur[self_kind]) : nullptr;
     return L;
   };
   int32_t errflag = 0;
@@ -3651,8 +3606,6 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   env = make_env(e);
   for (int k = 0; k < NEXT_NKINDS; k++) cur[k] = 0;
   HIP_TRY(hipMemsetAsync(e->d_count, 0, sizeof(int32_t) * 2 * NEXT_NKINDS, s));
-  rc = zero_khists();  // (every list starts empty)
-  if (rc != ARTIS_OK) return rc;
   hipLaunchKernelGGL(k_classify, dim3(nblocks(n)), dim3(BLOCK), 0, s, env, lists_for(0), first_pass ? 1 : 0);
   first_pass = false;
   rc = read_counts();
@@ -3738,8 +3691,6 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
         in.list[i] = e->d_lists[tail_kinds[i]][cur[tail_kinds[i]]];
         in.n[i] = cnt[tail_kinds[i]];
         HIP_TRY(hipMemsetAsync(e->d_count + tail_kinds[i], 0, sizeof(int32_t), s));
-        // (consumed whole, without a sort: the buffer's key histogram starts its next generation at zero like its count)
-        if (int32_t *hk = khist_of(tail_kinds[i], cur[tail_kinds[i]])) HIP_TRY(hipMemsetAsync(hk, 0, e->khist_bytes[tail_kinds[i]], s));
       }
       HIP_TRY(hipMemsetAsync(e->d_count + NEXT_NKINDS, 0, sizeof(int32_t), s));
       rc = reset_pool_if_due(env);
@@ -3783,8 +3734,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
         rc = sort_by_key(e, s, e->d_lists[kind][cur[kind]], e->d_keys[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? r_nubins : (kind == NEXT_MA ? e->ma_bins : 1),
                          hi - lo, kind == NEXT_MA ? (env.cellest_n_t > 0 ? INT32_MAX : e->sort_maxpc_t)
                                                   : (env.cellest_n_r > 0 ? INT32_MAX : e->sort_maxpc_r),
-                         (kind == NEXT_RPKT && r_nubins > 1 && e->sort_numajor) ? r_ngroups * r_nubins : 0, khist_of(kind, cur[kind]),
-                         e->khist_bytes[kind]);
+                         (kind == NEXT_RPKT && r_nubins > 1 && e->sort_numajor) ? r_ngroups * r_nubins : 0);
         if (rc != ARTIS_OK) return rc;
       }
       if (kind == NEXT_SLOW) {

@@ -59,7 +59,7 @@ W_PER_RPKT_VISIT = 224.0      # hot line + 96 B of the flight line
 W_PER_EMISSION = 120.0
 W_PER_ATOMIC = 8.0            # one f64 estimator add
 W_PER_LIST_ENTRY = 8.0        # (slot, key) appended to a work list
-PROFILE_ROUNDS = ("r05", "r04")  # the newest round that holds the counters of this command
+PROFILE_ROUNDS = ("r06", "r05", "r04")  # the newest round that holds the counters of this command
 NCU, NSIMD, CLOCK_GHZ = 256, 1024, 2.4   # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
 GATHER_INSTR_CLOCKS = 40.0             # CU clocks per 64-lane 16-byte gather instruction out of L2 (profiles/r02/gather_microbench.txt)
 LINE_FILL_CLOCKS = 150.0 / 64          # CU clocks per 128-byte line filled from L2 (profiles/r03/sector_bench.txt)
@@ -105,12 +105,15 @@ def _cpu_leg(bounds, cores, fast):
     return steps, busy, max(r[2] for r in res), wall
 
 
-def cpu_baseline(model, cs, ts, pk, sample: int, cores: int, options: str = "classic"):
+def cpu_baseline(model, cs, ts, pk, sample: int, cores: int, options: str = "classic", both: bool = False):
     """The CPU oracle (a scalar port of the reference's path) on the first `sample` packets of the same population,
     one process per core. Cell-cache filling is lazy as in the reference's CPU build and its time is excluded
     (at full scale it is amortised over ~150 packets per cell; in a small sample it would dominate).
-    Timed twice: compiled with the reference's own default flags (-O3 -march=native -flto, fast-math: `value`) and as the parity
-    checker is compiled (-O2 -ffp-contract=off: `value_checker_flags`)."""
+    `value` always means the build with the reference Makefile's own default flags (-O3 -march=native -flto, fast-math); `--cpu-both` also
+    times the build the parity checker uses (-O2 -ffp-contract=off: `value_checker_flags`; round 5 timed both in every run, which doubled the
+    bench's set-up). Only when the reference-flags build is not available on the host (no compiler, or it trips an assertion of the
+    restatement) is the checker's build timed in its place -- and then `kind` says so ("port-checker-flags"): `value` never silently changes
+    its meaning between runs."""
     os.environ.setdefault("ARTIS_ORACLE_CACHE_CAP", "3000")
     sample = min(sample, len(pk))
     bounds = [(sample * i // cores, sample * (i + 1) // cores) for i in range(cores)]
@@ -125,21 +128,25 @@ def cpu_baseline(model, cs, ts, pk, sample: int, cores: int, options: str = "cla
         fast = _cpu_leg(bounds, cores, True)
     except Exception as exc:  # noqa: BLE001  (no compiler on the box, or the fast-math build failed an assertion)
         print(f"[bench] cpu_baseline: the -O3 -march=native build of the oracle is not available ({exc})", file=sys.stderr)
-    steps, busy, tpop, wall = _cpu_leg(bounds, cores, False)
-    out = {"value": steps / busy, "unit": "packet-steps/s", "cores": cores, "kind": "port",
-           "flags": "-O2 -ffp-contract=off (the parity checker's build, oracle/Makefile)",
-           "value_checker_flags": steps / busy,
-           "sample": f"first {sample} packets of the same population on {cores} processes of the C oracle "
-                     f"(oracle/artis_oracle.c); {steps} packet-steps in {busy:.1f} s of propagation "
-                     f"(+{tpop:.1f} s lazy cell-cache fill excluded; leg wall {wall:.1f} s)"}
-    if fast is not None:
-        fsteps, fbusy, ftpop, fwall = fast
-        out["value"] = fsteps / fbusy
-        out["flags"] = " ".join(oracle_py.FAST_CFLAGS[:6]) + " (the reference Makefile's defaults: Makefile:38, :236-251; built on this host)"
-        out["sample"] = (f"first {sample} packets of the same population on {cores} processes of the C oracle (oracle/artis_oracle.c) "
-                         f"compiled with the reference's default flags: {fsteps} packet-steps in {fbusy:.1f} s of propagation "
-                         f"(+{ftpop:.1f} s lazy cell-cache fill excluded; leg wall {fwall:.1f} s); compiled as the parity checker is "
-                         f"(-O2 -ffp-contract=off): {steps} packet-steps in {busy:.1f} s = value_checker_flags")
+    checker = _cpu_leg(bounds, cores, False) if (both or fast is None) else None
+    if fast is None:
+        steps, busy, tpop, wall = checker
+        return {"value": steps / busy, "unit": "packet-steps/s", "cores": cores, "kind": "port-checker-flags",
+                "flags": "-O2 -ffp-contract=off (the parity checker's build, oracle/Makefile): the build with the reference Makefile's flags was not available on this host",
+                "value_checker_flags": steps / busy,
+                "sample": f"first {sample} packets of the same population on {cores} processes of the C oracle "
+                          f"(oracle/artis_oracle.c); {steps} packet-steps in {busy:.1f} s of propagation "
+                          f"(+{tpop:.1f} s lazy cell-cache fill excluded; leg wall {wall:.1f} s)"}
+    fsteps, fbusy, ftpop, fwall = fast
+    out = {"value": fsteps / fbusy, "unit": "packet-steps/s", "cores": cores, "kind": "port",
+           "flags": " ".join(oracle_py.FAST_CFLAGS[:6]) + " (the reference Makefile's defaults: Makefile:38, :236-251; built on this host)",
+           "sample": f"first {sample} packets of the same population on {cores} processes of the C oracle (oracle/artis_oracle.c) "
+                     f"compiled with the reference's default flags: {fsteps} packet-steps in {fbusy:.1f} s of propagation "
+                     f"(+{ftpop:.1f} s lazy cell-cache fill excluded; leg wall {fwall:.1f} s)"}
+    if checker is not None:
+        steps, busy, tpop, wall = checker
+        out["value_checker_flags"] = steps / busy
+        out["sample"] += (f"; compiled as the parity checker is (-O2 -ffp-contract=off): {steps} packet-steps in {busy:.1f} s = value_checker_flags")
     return out
 
 
@@ -159,6 +166,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=160_000)
     ap.add_argument("--cpu-cores", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-both", action="store_true", help="time the CPU port also as the parity checker is compiled (value_checker_flags)")
     ap.add_argument("--options", default="classic", choices=("classic", "kilonova_lte", "nltenebular", "christinenonthermal", "nltephotospheric", "nltewithoutnonthermal",
                                                              "kilonova_expopac", "classic_expopac_therm", "ci_classic_vpkt", "ci_classic_vpkt_expopac"),
                     help="options preset of include/artis_options.h (the reference's artisoptions_*.h; the expansion-opacity builds of "
@@ -200,7 +208,7 @@ def main():
     baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_sample > 0:
         cores = args.cpu_cores or min(os.cpu_count() or 1, 16)
-        baseline = cpu_baseline(model, cs, ts, pk, args.cpu_sample, cores, args.options)  # before any GPU initialisation (fork)
+        baseline = cpu_baseline(model, cs, ts, pk, args.cpu_sample, cores, args.options, both=args.cpu_both)  # before any GPU initialisation (fork)
 
     import torch
     import torch.distributed as dist
@@ -352,11 +360,11 @@ def main():
         # (profiles/<round>/pmc_traffic.json, written by tools/pmc_summary.py; FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950). None when the workload is not the profiled one.
         tj, traffic_src = {}, None
-        tname = "pmc_traffic.json" if args.options == "classic" else f"pmc_traffic_{args.options}.json"
+        # one file per (options build, atomic data set): pmc_traffic[_<options>][_<preset>].json (the headline: pmc_traffic.json)
+        tname = "pmc_traffic" + ("" if args.options == "classic" else f"_{args.options}") + ("" if args.preset == "w7" else f"_{args.preset}") + ".json"
         PROFILE_ROUND = next((r for r in PROFILE_ROUNDS if os.path.exists(os.path.join(ROOT, "profiles", r, tname))), PROFILE_ROUNDS[-1])
         tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, tname)
-        if (os.path.exists(tfile) and args.packets == 10_000_000 and args.ncoord == 50 and args.preset == "w7" and world == 1
-                and args.grid == "3d"):
+        if (os.path.exists(tfile) and args.packets == 10_000_000 and args.ncoord == 50 and world == 1 and args.grid == "3d"):
             with open(tfile) as f:
                 tj = json.load(f)
             traffic_src = f"profiles/{PROFILE_ROUND}/{tname}"

@@ -21,6 +21,6 @@ for set in \
   i=$((i+1))
   tag=pass$i
   if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $i "; then continue; fi
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_$T/$tag -- python3 $R/bench.py --packets $P --steps 1 --warmup 0 --no-cpu-baseline --options $O $PMC_EXTRA > $R/gpurun_out/pmc_${T}_$tag.log 2>&1
+  timeout ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_$T/$tag -- python3 $R/bench.py --packets $P --steps 1 --warmup 0 --no-cpu-baseline --options $O $PMC_EXTRA > $R/gpurun_out/pmc_${T}_$tag.log 2>&1
   echo "$tag rc=$? : $set"
 done
