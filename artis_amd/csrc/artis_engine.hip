@@ -2133,7 +2133,12 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
 }
 
 // slow path: the rare bound-free actions (rate coefficients with exp(), adaptive Gauss-Kronrod frequency sampling)
-__global__ void __launch_bounds__(BLOCK) k_slow(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats) {
+// (round 6, with the build's machine LICM off: the classic options' slow path fits 167 VGPRs with 2 spilled, i.e. 3 waves per SIMD instead of 2;
+// the builds with interpolated cross-sections / the nebular family need 170-256 and keep what the compiler chooses)
+#ifndef ARTIS_SLOW_EU
+#define ARTIS_SLOW_EU (ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION ? 3 : 1)
+#endif
+__global__ void __launch_bounds__(BLOCK, ARTIS_SLOW_EU) k_slow(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
   __shared__ double lds_scalars[ARTIS_NSCALARS];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;

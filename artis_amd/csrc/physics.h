@@ -5707,7 +5707,7 @@ AHD int advance_ma(const Env &env, Pkt &p, int64_t pi, int budget) {
 // k-packet step for every lane whose macro-atom has deactivated. The phases make the lanes of a wave run the same code
 // at the same time; they only order the work of different packets.
 #ifndef ARTIS_MA_PHASE
-#define ARTIS_MA_PHASE 32  // measured optimum on MI355X (round 4, filter-only records + LDS tables: 16 / 24 / 32 / 40 rounds: 488 / 446 / 435 / 438 ms; round 3: 24): short enough to keep the lanes busy, long enough to amortise the per-phase work
+#define ARTIS_MA_PHASE 40  // measured optimum on MI355X (round 6, after the loop's instruction diet -- a round costs less, so idle lanes cost less against the per-phase work: 24 / 32 / 40 / 48 / 64 rounds: k_thermal 376 / 358-362 / 356 / 363 / 386 ms, profiles/r06/sweep.txt; round 4: 32 of 16 / 24 / 32 / 40: 488 / 446 / 435 / 438 ms; round 3: 24): short enough to keep the lanes busy, long enough to amortise the per-phase work
 #endif
 AHD bool kpkt_eligible(const Pkt &p, double ts_end);
 AHD bool thermal_can_continue(const Pkt &p, double ts_end) {

@@ -5,7 +5,7 @@
 #   3. bench.py with the fresh pmc_traffic.json in place (its roofline.traffic)  -> bench_default.json
 #   4. the same workload on the other two options builds                         -> bench_kilonova_lte.json, bench_nltenebular.json
 # usage: bash tools/profile_round.sh r02
-T=${1:-r05}
+T=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 O=$R/gpurun_out/profile_$T
 mkdir -p $O
