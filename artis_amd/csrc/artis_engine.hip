@@ -469,6 +469,43 @@ __device__ inline double wave_prefix_inorder(double t, double carry, int n, int 
   }
   return acc;
 }
+// ... NS running sums at once, through LDS (round 6): the lanes leave their terms in the wave's own rows, lane j < NS adds row j up from left to
+// right -- the same additions in the same order, so the same bits -- and every lane reads its sums back. As broadcasts and masked additions the
+// three sums of a block of 63 transitions were ~950 wave instructions; this is 63 dependent additions by three lanes side by side (the fills
+// of the 4e5-line set: 2.1 s of its 17 s step).
+constexpr int PREFIX_ROWS = 3;
+// the wave's rows (one set for all instantiations: 12 KB per workgroup of BLOCK threads)
+__device__ inline double (*prefix_rows(bool out))[64] {
+  __shared__ double rows_in[BLOCK / 64][PREFIX_ROWS][64];
+  __shared__ double rows_out[BLOCK / 64][PREFIX_ROWS][64];
+  const int w = (int)(threadIdx.x >> 6) % (BLOCK / 64);
+  return out ? rows_out[w] : rows_in[w];
+}
+template <int NS>
+__device__ inline void wave_prefix_inorder_n(const double (&t)[NS], const double (&carry)[NS], int n, int lane, double (&out)[NS]) {
+  static_assert(NS <= PREFIX_ROWS, "rows");
+  double(*rin)[64] = prefix_rows(false);
+  double(*rout)[64] = prefix_rows(true);
+#pragma unroll
+  for (int j = 0; j < NS; j++) rin[j][lane] = t[j];
+  __threadfence_block();  // (lanes of one wave exchange data through LDS: in order, but the compiler must not move the accesses)
+  if (lane < NS) {
+    double acc = 0.;
+#pragma unroll
+    for (int j = 0; j < NS; j++) acc = (lane == j) ? carry[j] : acc;
+    const double *in = rin[lane];
+    double *o = rout[lane];
+    for (int k = 0; k < n; k++) {
+      acc += in[k];
+      o[k] = acc;
+    }
+  }
+  __threadfence_block();
+  const int k = (lane < n) ? lane : n - 1;  // (a lane past the block's last transition holds the block's total, as wave_prefix_inorder() gives it)
+#pragma unroll
+  for (int j = 0; j < NS; j++) out[j] = rout[j][k];
+  __threadfence_block();  // (the next call writes the rows again)
+}
 // the entries of one block (lanes 0..62 = transitions base .. base + 62 of a direction of n) into the record: internal filter from s_int,
 // radiative filter (downward only) from s_rad
 __device__ inline void wave_put_dirfilters(U4 *rec, const LevelPack &lpk, bool down, int n, int ti, bool valid, double s_int, double s_rad,
@@ -518,7 +555,9 @@ __device__ inline void ma_fill_record_wave(const Env &env, int c, int ul) {
       const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + base + lane);
       v0 = t.v0; v1 = t.v1; v2 = t.v2;
     }
-    const double s0 = wave_prefix_inorder(v0, w_rad, nb, lane), s1 = wave_prefix_inorder(v1, w_col, nb, lane), s2 = wave_prefix_inorder(v2, w_down, nb, lane);
+    double ss[3];
+    wave_prefix_inorder_n<3>({v0, v1, v2}, {w_rad, w_col, w_down}, nb, lane, ss);
+    const double s0 = ss[0], s1 = ss[1], s2 = ss[2];
     if (base == 0) { b0_rad = s0; b0_down = s2; }
     w_rad = wave_bcast(s0, nb - 1);
     w_col = wave_bcast(s1, nb - 1);
@@ -536,7 +575,9 @@ __device__ inline void ma_fill_record_wave(const Env &env, int c, int ul) {
         const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + base + lane);
         v0 = t.v0; v2 = t.v2;
       }
-      const double s0 = wave_prefix_inorder(v0, c_rad, nb, lane), s2 = wave_prefix_inorder(v2, c_down, nb, lane);
+      double ss[2];
+      wave_prefix_inorder_n<2>({v0, v2}, {c_rad, c_down}, nb, lane, ss);
+      const double s0 = ss[0], s2 = ss[1];
       wave_put_dirfilters(rec, lpk, true, nd, base + lane, valid, s2, s0, w_down, w_rad, lane);
       c_rad = wave_bcast(s0, nb - 1);
       c_down = wave_bcast(s2, nb - 1);
@@ -558,7 +599,9 @@ __device__ inline void ma_fill_record_wave(const Env &env, int c, int ul) {
       const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + nd + base + lane);
       v0 = t.v0; kt = t.kterm;
     }
-    const double s0 = wave_prefix_inorder(v0, w_up, nb, lane);
+    double ss[1];
+    wave_prefix_inorder_n<1>({v0}, {w_up}, nb, lane, ss);
+    const double s0 = ss[0];
     if (base == 0) { b0_up = s0; b0_kt = kt; }
     w_up = wave_bcast(s0, nb - 1);
   }
@@ -573,11 +616,15 @@ __device__ inline void ma_fill_record_wave(const Env &env, int c, int ul) {
         const MaTransTerms t = matrans_terms(env, c, lpk.alltrans_startdown + nd + base + lane);
         v0 = t.v0; kt = t.kterm;
       }
-      const double s0 = (nu <= 63) ? b0_up : wave_prefix_inorder(v0, c_up, nb, lane);
+      // (the internal-up sums again -- a direction of one block keeps them from the pass above -- and the cooling terms' sums from the list's
+      // value before the level, side by side)
+      double ss[2];
+      wave_prefix_inorder_n<2>({v0, kt}, {c_up, c_cool}, nb, lane, ss);
+      const double s0 = (nu <= 63) ? b0_up : ss[0];
       wave_put_dirfilters(rec, lpk, false, nu, ti, valid, s0, 0., w_up, 0., lane);
       c_up = wave_bcast(s0, nb - 1);
       if (hi_i >= 0) {
-        const double sk = wave_prefix_inorder(kt, c_cool, nb, lane);
+        const double sk = ss[1];
         bool ok = (span > 0.) && (span <= DBLMAX);
         uint32_t q = MAFILT_NONE;
         if (valid && ti < nu - 1 && ok) q = mafilt_quant(sk - c_lo, span, &ok);
@@ -911,6 +958,22 @@ __global__ void __launch_bounds__(BLOCK) k_classify(Env env, Lists L, int reset_
   append_by_kind(kind, (int32_t)i, cellindex, nu_cmf, L);
 }
 
+// Adaptive tiles (round 6): how many packets wait in every non-empty cell (the predicate of k_classify, whatever tile is resident), so
+// that the next tile can be put where most of them are; *other: packets that need no cache row (gamma-ray kinds, packets in empty cells)
+__global__ void __launch_bounds__(BLOCK) k_count_waiting(Env env, int32_t *counts, int32_t *other) {
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= env.P.n) return;
+  const PktHot &h = env.P.hot[i];
+  const int type = h.type;
+  const bool active = type_handled(type) && h.prop_time < env.S.ts_end;
+  const bool waiting = h.pend != PEND_NONE || h.ma_level >= 0;
+  if (!(waiting || active)) return;
+  const int c = env.M.propcell_nonemptymgi[h.cellindex];
+  if ((active && type_gamma(type) && !waiting) || c < 0)
+    atomicAdd(other, 1);
+  else
+    atomicAdd(&counts[c], 1);
+}
 // Sparse fill of a tile: mark the cells of the tile [lo, hi) in which a packet waits (the predicate of k_classify) ...
 __global__ void __launch_bounds__(BLOCK) k_mark_cells(Env env, uint32_t *resident) {
   const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1484,13 +1547,15 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_GAMMA_WAVES) k_gamma(Env env, con
 // table alone in LDS (up to MA_LDS_LEVELS2 levels).
 constexpr int MA_LDS_LEVELS = 2048;   // 32 KB
 constexpr int MA_LDS_TRANS = 32768;   // 64 KB
-constexpr int MA_LDS_LEVELS2 = 6144;  // 96 KB
+constexpr int MA_LDS_LEVELS2 = 9856;  // 154 KB (round 6: 6144 = 96 KB until the workgroup's per-cell estimator accumulators -- 32 KB that only models
+                                      // with few cells use -- were left out of this form: the 4e5-line set's 8 457 levels fit now; a model with few cells AND
+                                      // more than MA_LDS_LEVELS levels takes the form without LDS tables)
 template <int TB, int TABLES_LDS, bool COLD = false>
 __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_thermal(Env env, const int32_t *list, int32_t n, Lists next,
                                                                      unsigned long long *gstats, int budget, int32_t *cursors,
                                                                      int nchunks, int chunk_mode, int drain_budget) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
-  __shared__ double lds_cellest[THERMAL_CELLEST_CAP];
+  __shared__ double lds_cellest[TABLES_LDS == 2 ? 1 : THERMAL_CELLEST_CAP];
   __shared__ LevelPack lds_levelpack[TABLES_LDS == 1 ? MA_LDS_LEVELS : (TABLES_LDS == 2 ? MA_LDS_LEVELS2 : 1)];
   __shared__ uint16_t lds_tlevel[TABLES_LDS == 1 ? MA_LDS_TRANS : 8];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
@@ -2390,6 +2455,15 @@ struct artis_amd_engine {
   double ma_hotfrac = 1.;        // the share of every ion's levels that has a static record (given, or chosen by engine_fill from the cache budget)
   bool vpkt_cont_lds = true;  // ARTIS_AMD_VPKT_CONTLDS=0: k_vpkt reads the continuum table from memory (four workgroups of 256 per CU)
   bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
+  // Adaptive tiles (round 6; ARTIS_AMD_TILE_ADAPT=0: the fixed ranges of rounds 2-5). A tile is still a contiguous range of non-empty cells --
+  // the cache pointers are biased by its first cell -- but WHICH range is chosen before every visit: the window of tile_cells cells in which
+  // most packets wait (k_count_waiting + a sliding sum on the host). The first visits take the densest parts of the ejecta; afterwards the
+  // waiting packets sit on both sides of the earlier windows' edges, and a window laid across such an edge lets them cross it freely instead
+  // of waiting once per crossing and fixed tile.
+  bool tile_adapt = true;
+  int32_t *d_waiting = nullptr;  // [npts_nonempty + 1] packets waiting per cell; the last entry: packets that need no row
+  std::vector<int32_t> h_waiting;
+  int64_t last_visits = 0;
   int64_t last_sweeps = 0, last_tile_fills = 0, last_listed = 0;
   double last_fill_ms = 0.;
   // do_rpkt_step() calls per packet per launch. 8 in rounds 2-3; with the r-packet kernel's reads requested ahead (round 4) the list's order
@@ -3091,6 +3165,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_CONTLDS")) e->cont_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_LINELDS")) e->line_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TILE_ZIGZAG")) e->tile_zigzag = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_TILE_ADAPT")) e->tile_adapt = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_MATABLES_LDS")) e->ma_tables_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_REFILL")) e->thermal_refill = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NUMAJOR")) e->sort_numajor = std::atoi(b) != 0;
@@ -3135,7 +3210,7 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
   free_packet_buffers(e);
-  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_resident, e->d_fill_cells,
+  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_resident, e->d_fill_cells, e->d_waiting,
                   e->d_nfill, e->d_bfrate_kept, e->d_collexc_terms, e->d_visit_counts};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -3592,13 +3667,51 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   // Sweeps over the cell-cache tiles (one tile, one sweep when the whole cache is resident): list the packets that sit
   // in the tile, fill the tile's cache if any do, advance them until they leave the tile or are done; repeat until a
   // sweep finds no packet left to advance.
+  const bool adaptive = e->tile_adapt && e->ntiles > 1;
+  bool all_done = false;
+  if (adaptive && e->d_waiting == nullptr) {
+    HIP_TRY(hipMalloc((void **)&e->d_waiting, sizeof(int32_t) * (size_t)(ncell_all + 1)));
+    e->h_waiting.assign((size_t)ncell_all + 1, 0);
+  }
+  e->last_visits = 0;
   for (int sweep = 0;; sweep++) {
   bool any_active = false;
   for (int tstep = 0; tstep < e->ntiles; tstep++) {
   // sweeps alternate their direction: a packet that left its tile against the direction of one sweep is met by the next
   // one on its way back (with one direction it waits a whole sweep per backward crossing)
   const int tile = (e->tile_zigzag && (sweep & 1)) ? e->ntiles - 1 - tstep : tstep;
-  const int lo = (int)(tile * e->tile_cells);
+  int lo = (int)(tile * e->tile_cells);
+  if (adaptive) {
+    // where do the packets wait? The window of tile_cells consecutive non-empty cells that holds most of them is the next tile.
+    env = make_env(e);
+    HIP_TRY(hipMemsetAsync(e->d_waiting, 0, sizeof(int32_t) * (size_t)(ncell_all + 1), s));
+    hipLaunchKernelGGL(k_count_waiting, dim3(nblocks(n)), dim3(BLOCK), 0, s, env, e->d_waiting, e->d_waiting + ncell_all);
+    HIP_TRY(hipMemcpyAsync(e->h_waiting.data(), e->d_waiting, sizeof(int32_t) * (size_t)(ncell_all + 1), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const int64_t nwin = e->tile_cells;
+    int64_t sum = 0, best = -1, total = 0;
+    int best_lo = 0;
+    for (int64_t c = 0; c < ncell_all; c++) {
+      sum += e->h_waiting[(size_t)c];
+      total += e->h_waiting[(size_t)c];
+      if (c >= nwin) sum -= e->h_waiting[(size_t)(c - nwin)];
+      if (c >= nwin - 1 || c == ncell_all - 1) {
+        const int64_t wlo = std::max<int64_t>(0, c - nwin + 1);
+        if (sum > best) {
+          best = sum;
+          best_lo = (int)wlo;
+        }
+      }
+    }
+    if (total == 0 && e->h_waiting[(size_t)ncell_all] == 0) {  // nothing left anywhere
+      all_done = true;
+      break;
+    }
+    lo = (int)std::min<int64_t>(best_lo, std::max<int64_t>(0, ncell_all - nwin));
+    if (e->trace)
+      fprintf(stderr, "[artis_amd] visit %lld: %lld packets wait in cells, %d need no row; window [%d, %lld) holds %lld\n", (long long)e->last_visits,
+              (long long)total, e->h_waiting[(size_t)ncell_all], lo, (long long)std::min<int64_t>(ncell_all, lo + nwin), (long long)best);
+  }
   const int hi = (int)std::min<int64_t>(ncell_all, lo + e->tile_cells);
   if (e->tile_lo != lo || e->tile_hi != hi) {
     e->tile_lo = lo;
@@ -3619,10 +3732,11 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   for (int k = 1; k < NEXT_NKINDS; k++) tile_active = tile_active || cnt[k] > 0;
   if (!tile_active) continue;
   any_active = true;
+  e->last_visits++;
   for (int k = 1; k < NEXT_NKINDS; k++) e->last_listed += cnt[k];
   e->resident_on = false;
   int64_t nfill = -1;
-  if (e->sparse_fill && e->ntiles > 1 && sweep > 0) {
+  if (e->sparse_fill && e->ntiles > 1 && (sweep > 0 || adaptive)) {
     // which cells of the tile hold the waiting packets? Few of them (stragglers): fill those only; a packet that moves into
     // another cell of the tile waits for the tile's next visit like one that leaves the tile
     int64_t listed_now = 0;
@@ -3669,7 +3783,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   int64_t listed = 0;
   for (int k = 1; k < NEXT_NKINDS; k++) listed += cnt[k];
   // (tiled runs: the later sweeps bring a tile a few stragglers at a time; each such visit is a tail from its first launch)
-  const bool tail_ok = e->tail_max > 0 && (e->tail_always || listed > e->tail_max || sweep > 0);
+  const bool tail_ok = e->tail_max > 0 && (e->tail_always || listed > e->tail_max || sweep > 0 || (adaptive && e->last_visits > e->ntiles));
   int64_t visit_launches = 0;  // split-kernel launches of this visit (a visit parks its tail only after it has advanced its packets)
   while (cnt[NEXT_RPKT] > 0 || cnt[NEXT_MA] > 0 || cnt[NEXT_SLOW] > 0 || cnt[NEXT_KPKT] > 0 || cnt[NEXT_GAMMA] > 0 || cnt[NEXT_BB] > 0) {
     const int tail_kinds[4] = {NEXT_RPKT, NEXT_MA, NEXT_SLOW, NEXT_BB};
@@ -3814,7 +3928,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
             const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
             e->thermal_variants |= ARTIS_AMD_THERMAL_LDS_TABLES;
             LAUNCH_T2(k_thermal, 1024, 1, grid1, 1024, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
-          } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS2 && nk >= 4096) {
+          } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS2 && nk >= 4096 && env.cellest_n_t == 0) {
             const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
             e->thermal_variants |= ARTIS_AMD_THERMAL_LDS_LEVELPACK;
             LAUNCH_T2(k_thermal, 1024, 2, grid1, 1024, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
@@ -3866,7 +3980,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   }  // tiles
   e->resident_on = false;
   if (any_active) e->last_sweeps++;
-  if (e->ntiles == 1 || !any_active) break;
+  if (e->ntiles == 1 || !any_active || all_done) break;
   }  // sweeps
   for (int k = 1; k < NEXT_NKINDS; k++) e->last_propagate_ms += e->kms[k];
   e->last_propagate_ms += e->kms_tail;

@@ -41,8 +41,10 @@ BIG_CASES = {
     # Round 6 -- the realistic-size atomic data under the oracle. `w7big` (110 860 lines, 4 427 levels): 6000 packets of
     # which 4800 start as k-packets, so that the first thermal lists hold >= 4096 entries and the launch takes k_thermal<1024, 2> (LevelPack
     # alone in LDS, the 2-byte target levels in HBM: what the 50^3 / 1e7 run of this data set executes); 3.9e8 transitions
+    # (ARTIS_AMD_CELLEST_LDS=0: a model with few cells keeps its per-cell estimators in the workgroup's LDS, which that form of the kernel
+    # leaves to the level table since round 6 -- the 50^3 grid has no such accumulators either)
     "w7big_5cubed_6e3": dict(build=dict(preset="w7big", ncoord=5), npk=6000, pkw=dict(kpkt_fraction=0.8), dense_cells=0,
-                             expect_variants="LDS_LEVELPACK"),
+                             expect_variants="LDS_LEVELPACK", env={"ARTIS_AMD_CELLEST_LDS": "0"}),
     # `cd23like` (406 132 lines, 8 457 levels, directions of hundreds of transitions: k_mafilter_long) with the record tiers the ENGINE chooses
     # when its static rows do not fit the cache budget (forced here to 0.7 of them on a 5^3 grid): static records for the lowest levels of every
     # ion, the rest filled on demand in the shared pool by the slow-path kernel's waves, k_thermal<256, 0, COLD>; 3.2e8 transitions
@@ -248,6 +250,8 @@ def test_engine_matches_oracle_large_cases(engine_mod, oracle_big, name, monkeyp
         static_mb = (bpc - 8 * model["nlines"]) * model["npts_nonempty"] / 2**20
         monkeypatch.setenv("ARTIS_AMD_CACHE_BUDGET_MB", f"{case['budget_frac'] * static_mb:.1f}")
         monkeypatch.delenv("ARTIS_AMD_MA_HOTFRAC", raising=False)
+    for k, v in case.get("env", {}).items():
+        monkeypatch.setenv(k, v)
     eng = engine_mod.Engine(model, preset=options)
     if "budget_frac" in case:
         tiers = eng.record_tiers()
