@@ -2449,6 +2449,10 @@ struct artis_amd_engine {
                                       // 4 tiles 3327 / 3205 / 3188 ms at 512 / 4096 / 16384, with parked tails 3222 / 3123 / 2982)
   int64_t last_sparse_fills = 0, last_cells_filled = 0;
   bool park_tails = true;     // ARTIS_AMD_TILE_PARK=0: every visit of a tile runs its packets to their end (rounds 2-3)
+  // ARTIS_AMD_TILE_PARK_AT: packets left of a larger visit at which it parks them (0 / <= tail_max: round 4's rule, at the tail kernel's
+  // threshold). Measured on the headline at a quarter of its cache (4 tiles, adaptive windows; profiles/r06/tiling.md): 4096 / 32768 / 131072 /
+  // 524288 / 2097152 -> 2395 / 2147 / 1971 / 1899 / 1868 ms per step (untiled 760)
+  int64_t park_at = 524288;
   int64_t last_parked = 0;
   int64_t last_pool_resets = 0;  // times the pool of on-demand records was emptied because it was used up (this call)
   int64_t last_pool_used = 0, last_pool_cap = 0;  // units (128 B) of the pool in use at the end of the last call / the pool's size
@@ -3196,6 +3200,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
             e->ma_hotfrac, e->Mh.ncold, e->Mh.ma_pool_slots, e->ntiles, (long long)e->tile_cells, e->cache_bytes_per_cell);
   if (const char *b = std::getenv("ARTIS_AMD_VPKT_CONTLDS")) e->vpkt_cont_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TILE_PARK")) e->park_tails = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_TILE_PARK_AT")) e->park_at = std::max<int64_t>(0, std::atoll(b));
   return ARTIS_OK;
 }
 }  // namespace
@@ -3789,6 +3794,15 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     const int tail_kinds[4] = {NEXT_RPKT, NEXT_MA, NEXT_SLOW, NEXT_BB};
     int64_t tail_n = 0;
     for (int k : tail_kinds) tail_n += cnt[k];
+    // (round 6) tiled run: a visit that began larger parks what is left of it once that has fallen to park_at packets -- BEFORE the long run
+    // of small, latency-bound launches that its last packets would otherwise cost every visit: they wait in their cells and are listed
+    // again, merged with the other windows' stragglers, by a later visit (a visit that BEGINS with that few runs them to their end)
+    if (e->park_tails && e->ntiles > 1 && e->park_at > e->tail_max && listed > e->park_at && visit_launches > 0 && tail_n > 0 &&
+        tail_n + cnt[NEXT_KPKT] <= e->park_at) {
+      e->last_parked += tail_n + cnt[NEXT_KPKT] + cnt[NEXT_GAMMA];
+      if (e->trace) fprintf(stderr, "[artis_amd] sweep %d tile %d: %lld packets parked (park_at)\n", sweep, tile, (long long)(tail_n + cnt[NEXT_KPKT]));
+      break;
+    }
     if (tail_ok && tail_n > 0 && tail_n <= e->tail_max && cnt[NEXT_KPKT] == 0) {
       if (e->park_tails && e->ntiles > 1 && listed > e->tail_max && visit_launches > 0) {
         // tiled run, a visit that began larger: its last packets wait in the tile (their state is in the packet store; the next
