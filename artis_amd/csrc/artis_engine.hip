@@ -2904,8 +2904,11 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   {
     // Macro-atom record tiers (tables.h "ON-DEMAND RECORDS"): every level a static record while the whole cell cache fits one tile; when it
     // does not (even without line_dpop), static records for the lowest ARTIS_AMD_MA_HOTFRAC (0.3) of every ion's levels and a pool of
-    // ARTIS_AMD_MA_POOLFRAC (0.25) of the rest for the cold levels packets reach. Either variable set: taken as given.
-    double hot = 1., pool = 0.25;
+    // ARTIS_AMD_MA_POOLFRAC (0.15) of the rest for the cold levels packets reach. Either variable set: taken as given.
+    // (pool share: 0.25 in round 5. Measured on the 4e5-line set, 50^3 / 1e7, round 6 -- artis_amd_last_pool_usage(): a step leaves 48 % of a quarter-share
+    // pool in use; with 0.15 the tier search affords hot 0.25 instead of 0.15 and the step takes 15.9 s instead of 16.6 (pool 64 % used); with 0.10 hot 0.30,
+    // 15.7 s, 87 % used -- too close to a pool that is used up and emptied. profiles/r06/pool_share.txt)
+    double hot = 1., pool = 0.15;
     const bool given = std::getenv("ARTIS_AMD_MA_HOTFRAC") != nullptr;
     ma_tiers_from_env(&hot, &pool);
     e->Mh = make_host_model_view(*model, e->own, hot, pool);

@@ -429,6 +429,7 @@ def main():
 
         per_kernel = {k: kernel_roofline(k) for k in ("k_thermal", "k_rpkt")}
         d = per_kernel[dominant]
+        lim = d["limiter"] or {}
         out = {
             "metric": "packet-steps/sec", "value": value, "unit": "packet-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -462,17 +463,20 @@ def main():
                          "avg_launch_ms": d["avg_launch_ms"],
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                          "algorithmic_gbs": d["algorithmic_gbs"], "algorithmic_over_hbm_peak": d["algorithmic_gbs"] / HBM_PEAK_GBS,
-                         "measured_limiter": ("not HBM: instruction issue and the waves' dependent reads together -- VALU busy 0.53 of the SIMDs' "
-                                              "cycles at 0.42 lane utilisation (valu_lane_frac 0.22), scalar instructions another 0.29, waves waiting "
-                                              "0.61 of theirs; a transition is one sector of the cell's record from L2 (91 % hits) and two LDS reads; "
-                                              "one wave alone needs ~2900 clocks per transition, ~1000 of them instruction issue, and four waves per "
-                                              "SIMD share one issue port: 4 x ~850 = the 3400 clocks of a wave-round. Filling the loop's lanes "
-                                              "(k_thermal_q: 57 of 64) costs in its service passes what the fuller rounds save; shortening the chain of "
-                                              "dependent reads of a walk's end (cooling guides) took 1 % (DESIGN.md section 7, "
-                                              "profiles/r05/k_thermal_refill.md, cooling_guides.txt, tail_profile.txt)")
+                         "measured_limiter": (
+                             "not HBM: instruction issue and the waves' dependent reads together -- "
+                             + (f"VALU busy {lim['valu_busy_frac']:.2f} of the SIMDs' cycles at {lim['valu_lane_utilisation']:.2f} lane utilisation "
+                                f"(valu_lane_frac {lim['valu_lane_frac']:.2f}), waves waiting {lim['wave_wait_frac']:.2f} of theirs, L2 hit rate "
+                                f"{lim['l2_hit_rate']:.2f} (committed counters of this command); "
+                                if all(k in lim for k in ("valu_busy_frac", "valu_lane_utilisation", "valu_lane_frac", "wave_wait_frac", "l2_hit_rate")) else "")
+                             + "a transition is one sector of the cell's record from L2 and two LDS reads. Round 6 cut the transition loop from 484 to "
+                             "164 instructions per wave-round (sorted-entry count, one test for all rare paths: profiles/r06/isa_census.md) and the "
+                             "kernel's VALU instructions by 12 %: the loop was ~60 % of them, the rest is the ~2.7e7 wave-level walk ends per step (exit "
+                             "process, k-packet step, packet load / store) at 24 of 64 lanes. Filling the loop's lanes (k_thermal_q) still costs in its "
+                             "service passes what the fuller rounds save (790 vs 758 ms, profiles/r06/sweep.txt) (DESIGN.md section 7)")
                          if dominant == "k_thermal" else
                          ("k_rpkt (+ k_bfest_dense in DETAILED_BF builds, timed together): divergent per-lane loops over continua and "
-                          "lines at 3 waves/SIMD and 0.27 lane utilisation, their reads requested an iteration ahead, the work list "
+                          "lines at 3 waves/SIMD (no spilled register since round 6), their reads requested an iteration ahead, the work list "
                           "sorted by (frequency bin, cell) so that a wave's loops are of similar length; see `limiter` and DESIGN.md section 7"),
                          "limiter": d["limiter"],
                          "kernels": per_kernel},
