@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6, final measurements on the GPU box: what profiles/r06/ holds at the round's last source commit.
+# Final measurements of a round (written in round 6) on the GPU box: what profiles/r06/ holds at the round's last source commit.
 #   profile_round.sh r06: kernel trace + 7 PMC passes + bench line (with the CPU baseline) of the headline; kilonova_lte bench; nltenebular trace + PMC + bench;
 #                         expansion-opacity / virtual-packet benches; w7big and cd23like benches; population trace
 #   then the PMC passes of the lines that had none: kilonova_lte, w7big, cd23like -> pmc_traffic_<...>.json, and their bench lines again
