@@ -2201,7 +2201,9 @@ __global__ void __launch_bounds__(BLOCK, ARTIS_TAIL_WAVES) k_tail(Env env, TailL
 // (round 6, with the build's machine LICM off: the classic options' slow path fits 167 VGPRs with 2 spilled, i.e. 3 waves per SIMD instead of 2;
 // the builds with interpolated cross-sections / the nebular family need 170-256 and keep what the compiler chooses)
 #ifndef ARTIS_SLOW_EU
-#define ARTIS_SLOW_EU (ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION ? 3 : 1)
+// (the nebular family's -- NLTE populations, the non-thermal channels -- takes 256 VGPRs + 22 AGPRs alone at one wave per SIMD; held to 256 it
+// spills 48 and runs two: k_slow 70.6 -> 51.4 ms, nltenebular step 1018 -> 1001 ms (profiles/r06/ab_slow.txt); kilonova_lte: no difference)
+#define ARTIS_SLOW_EU (ARTIS_OPT_PHIXS_CLASSIC_NO_INTERPOLATION ? 3 : (ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON ? 2 : 1))
 #endif
 __global__ void __launch_bounds__(BLOCK, ARTIS_SLOW_EU) k_slow(Env env, const int32_t *list, int32_t n, Lists next, unsigned long long *gstats) {
   __shared__ stat_t lstats[ARTIS_NSTATS];
@@ -3667,6 +3669,84 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     if (e->trace) fprintf(stderr, "[artis_amd] the pool of on-demand records was used up: emptied (%lld)\n", (long long)e->last_pool_resets);
     return ARTIS_OK;
   };
+  // the launches of the two propagation kernels (on a given stream, with a given set of chunk cursors): one after the other on the call's stream,
+  // or side by side on two streams where both lists are short ("duet", below)
+  auto launch_rpkt = [&](hipStream_t st, const int32_t *lst, int32_t nk, const Lists &next, int32_t *cursors) -> int {
+        const int grid = (int)std::min<int64_t>(((int64_t)nk + ARTIS_RPKT_TB - 1) / ARTIS_RPKT_TB, (int64_t)e->ncu * ARTIS_RPKT_WGS);  // persistent: every block resident
+        const int bud_r = (e->budget_r_small > 0 && nk < e->small_list) ? std::min(e->budget_r_small, e->budget_r) : e->budget_r;
+        const int nch = e->wave_chunks_r ? chunks_for(nk, grid * (ARTIS_RPKT_TB / 64)) : 8;
+        if (e->line_lds && e->Mh.nlines <= LINE_LDS_MAX && e->Mh.nlines > 0 && !(env.cellest_n_r > RPKT_CELLEST_CAP))
+          hipLaunchKernelGGL((k_rpkt<false, ARTIS_RPKT_TB, true>), dim3(grid), dim3(ARTIS_RPKT_TB), 0, st, env, lst, nk, next, e->d_stats, bud_r, cursors, nch,
+                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
+        else if (e->cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0 &&
+            !(env.cellest_n_r > RPKT_CELLEST_CAP))
+          hipLaunchKernelGGL((k_rpkt<true, ARTIS_RPKT_TB>), dim3(grid), dim3(ARTIS_RPKT_TB), 0, st, env, lst, nk, next, e->d_stats, bud_r, cursors, nch,
+                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
+        else
+          hipLaunchKernelGGL((k_rpkt<false, ARTIS_RPKT_TB>), dim3(grid), dim3(ARTIS_RPKT_TB), 0, st, env, lst, nk, next, e->d_stats, bud_r, cursors, nch,
+                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
+#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
+        if (env.bfev != nullptr) {  // the estimator updates the launch recorded (the cells' cache rows are still resident)
+          {
+            const int rcd = launch_bfest_dense(e, env, st);
+            if (rcd != ARTIS_OK) return rcd;
+          }
+          HIP_TRY(hipMemsetAsync(e->d_bfev_count, 0, sizeof(int32_t), st));
+        }
+#endif
+    return ARTIS_OK;
+  };
+  auto launch_thermal = [&](hipStream_t st, const int32_t *lst, int32_t nk, const Lists &next, int32_t *cursors) -> int {
+        // persistent: every workgroup resident (ARTIS_THERMAL_WAVES waves per SIMD)
+        {
+          const int grid = (int)std::min<int64_t>(((int64_t)nk + ARTIS_THERMAL_TB - 1) / ARTIS_THERMAL_TB,
+                                                  (int64_t)e->ncu * std::min(e->thermal_blocks_per_cu, ARTIS_THERMAL_WGS));
+          const bool per_cu = e->cu_chunks_t && nk >= 256 * 1024;
+          // (drain: only where the next thermal launch will be large too, so that what is handed on runs beside a full list)
+          const int bud_t = (e->budget_t_small > 0 && nk < e->small_list) ? std::min(e->budget_t_small, e->budget_t) : e->budget_t;
+          const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : bud_t;
+          const size_t tq_bytes = tq_lds_bytes(TQ_TB, e->Mh.nlevels, e->Mh.nalltrans);
+          const bool cold = e->Mh.ncold > 0;  // (kernels built with the on-demand records' look-ups only where the model has cold levels)
+          // the COLD = false / true instantiation of a thermal kernel (K<A, B, COLD>)
+#define LAUNCH_T2(K, A, B, GRID, TBS, LDSB, ...)                                                                   \
+  do {                                                                                                             \
+    if (cold)                                                                                                      \
+      hipLaunchKernelGGL((K<A, B, true>), dim3(GRID), dim3(TBS), LDSB, st, __VA_ARGS__);                            \
+    else                                                                                                           \
+      hipLaunchKernelGGL((K<A, B, false>), dim3(GRID), dim3(TBS), LDSB, st, __VA_ARGS__);                           \
+  } while (0)
+          if (cold) e->thermal_variants |= ARTIS_AMD_THERMAL_COLD;
+          if (e->thermal_refill && ARTIS_THERMAL_SPLIT_EXACT && env.cellest_n_t == 0 && tq_bytes <= 160 * 1024 - 1024 && nk >= 4096 && e->Mh.nlevels < 32768) {
+            e->thermal_variants |= ARTIS_AMD_THERMAL_REFILL;
+            if (!e->tq_attr_set) {  // (per engine, i.e. per device: the attribute is the device'st, not the process's -- ADVICE r05)
+              HIP_TRY(hipFuncSetAttribute((const void *)k_thermal_q<TQ_TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+              HIP_TRY(hipFuncSetAttribute((const void *)k_thermal_q<TQ_TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+              e->tq_attr_set = true;
+            }
+            const int grid1 = (int)std::min<int64_t>(((int64_t)nk + TQ_TB - 1) / TQ_TB, (int64_t)e->ncu);
+            if (cold)
+              hipLaunchKernelGGL((k_thermal_q<TQ_TB, true>), dim3(grid1), dim3(TQ_TB), tq_bytes, st, env, lst, nk, next, e->d_stats, bud_t, cursors,
+                                 e->wave_chunks_t ? chunks_for(nk, grid1 * (TQ_TB / 64)) : 8, drain, e->tq_low);
+            else
+              hipLaunchKernelGGL((k_thermal_q<TQ_TB, false>), dim3(grid1), dim3(TQ_TB), tq_bytes, st, env, lst, nk, next, e->d_stats, bud_t, cursors,
+                                 e->wave_chunks_t ? chunks_for(nk, grid1 * (TQ_TB / 64)) : 8, drain, e->tq_low);
+          } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS && e->Mh.nalltrans <= MA_LDS_TRANS && nk >= 4096) {
+            const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
+            e->thermal_variants |= ARTIS_AMD_THERMAL_LDS_TABLES;
+            LAUNCH_T2(k_thermal, 1024, 1, grid1, 1024, 0, env, lst, nk, next, e->d_stats, bud_t, cursors, e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
+          } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS2 && nk >= 4096 && env.cellest_n_t == 0) {
+            const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
+            e->thermal_variants |= ARTIS_AMD_THERMAL_LDS_LEVELPACK;
+            LAUNCH_T2(k_thermal, 1024, 2, grid1, 1024, 0, env, lst, nk, next, e->d_stats, bud_t, cursors, e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
+          } else {
+            e->thermal_variants |= ARTIS_AMD_THERMAL_PLAIN;
+            LAUNCH_T2(k_thermal, ARTIS_THERMAL_TB, 0, grid, ARTIS_THERMAL_TB, 0, env, lst, nk, next, e->d_stats, bud_t, cursors,
+                      per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (ARTIS_THERMAL_TB / 64)) : 8), per_cu ? 2 : 0, drain);
+          }
+#undef LAUNCH_T2
+        }
+    return ARTIS_OK;
+  };
   int rc = ARTIS_OK;
   const int order[6] = {NEXT_SLOW, NEXT_GAMMA, NEXT_BB, NEXT_KPKT, NEXT_MA, NEXT_RPKT};
   int64_t guard = 0;
@@ -3883,79 +3963,15 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * (MAX_CHUNKS + 1), s));
       HIP_TRY(hipEventRecord(e->ev0, s));
       if (kind == NEXT_RPKT) {
-        const int grid = (int)std::min<int64_t>(((int64_t)nk + ARTIS_RPKT_TB - 1) / ARTIS_RPKT_TB, (int64_t)e->ncu * ARTIS_RPKT_WGS);  // persistent: every block resident
-        const int bud_r = (e->budget_r_small > 0 && nk < e->small_list) ? std::min(e->budget_r_small, e->budget_r) : e->budget_r;
-        const int nch = e->wave_chunks_r ? chunks_for(nk, grid * (ARTIS_RPKT_TB / 64)) : 8;
-        if (e->line_lds && e->Mh.nlines <= LINE_LDS_MAX && e->Mh.nlines > 0 && !(env.cellest_n_r > RPKT_CELLEST_CAP))
-          hipLaunchKernelGGL((k_rpkt<false, ARTIS_RPKT_TB, true>), dim3(grid), dim3(ARTIS_RPKT_TB), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
-                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
-        else if (e->cont_lds && e->Mh.nbfcontinua <= CONT_LDS_MAX && e->Mh.nbfcontinua > 0 &&
-            !(env.cellest_n_r > RPKT_CELLEST_CAP))
-          hipLaunchKernelGGL((k_rpkt<true, ARTIS_RPKT_TB>), dim3(grid), dim3(ARTIS_RPKT_TB), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
-                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
-        else
-          hipLaunchKernelGGL((k_rpkt<false, ARTIS_RPKT_TB>), dim3(grid), dim3(ARTIS_RPKT_TB), 0, s, env, lst, nk, next, e->d_stats, bud_r, e->d_cursors, nch,
-                             (e->drain_r > 0 && nk >= e->drain_min_list) ? e->drain_r : bud_r);
-#if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
-        if (env.bfev != nullptr) {  // the estimator updates the launch recorded (the cells' cache rows are still resident)
-          rc = launch_bfest_dense(e, env, s);
-          if (rc != ARTIS_OK) return rc;
-          HIP_TRY(hipMemsetAsync(e->d_bfev_count, 0, sizeof(int32_t), s));
-        }
-#endif
+        rc = launch_rpkt(s, lst, nk, next, e->d_cursors);
+        if (rc != ARTIS_OK) return rc;
       } else if (kind == NEXT_GAMMA) {
         const int grid = std::min(nblocks(nk), e->ncu * ARTIS_GAMMA_WAVES);
         hipLaunchKernelGGL(k_gamma, dim3(grid), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats, e->budget_g, e->d_cursors,
                            e->wave_chunks_r ? chunks_for(nk, grid * (BLOCK / 64)) : 8);
       } else if (kind == NEXT_MA) {
-        // persistent: every workgroup resident (ARTIS_THERMAL_WAVES waves per SIMD)
-        {
-          const int grid = (int)std::min<int64_t>(((int64_t)nk + ARTIS_THERMAL_TB - 1) / ARTIS_THERMAL_TB,
-                                                  (int64_t)e->ncu * std::min(e->thermal_blocks_per_cu, ARTIS_THERMAL_WGS));
-          const bool per_cu = e->cu_chunks_t && nk >= 256 * 1024;
-          // (drain: only where the next thermal launch will be large too, so that what is handed on runs beside a full list)
-          const int bud_t = (e->budget_t_small > 0 && nk < e->small_list) ? std::min(e->budget_t_small, e->budget_t) : e->budget_t;
-          const int drain = (e->drain_t > 0 && nk >= e->drain_min_list) ? e->drain_t : bud_t;
-          const size_t tq_bytes = tq_lds_bytes(TQ_TB, e->Mh.nlevels, e->Mh.nalltrans);
-          const bool cold = e->Mh.ncold > 0;  // (kernels built with the on-demand records' look-ups only where the model has cold levels)
-          // the COLD = false / true instantiation of a thermal kernel (K<A, B, COLD>)
-#define LAUNCH_T2(K, A, B, GRID, TBS, LDSB, ...)                                                                   \
-  do {                                                                                                             \
-    if (cold)                                                                                                      \
-      hipLaunchKernelGGL((K<A, B, true>), dim3(GRID), dim3(TBS), LDSB, s, __VA_ARGS__);                            \
-    else                                                                                                           \
-      hipLaunchKernelGGL((K<A, B, false>), dim3(GRID), dim3(TBS), LDSB, s, __VA_ARGS__);                           \
-  } while (0)
-          if (cold) e->thermal_variants |= ARTIS_AMD_THERMAL_COLD;
-          if (e->thermal_refill && ARTIS_THERMAL_SPLIT_EXACT && env.cellest_n_t == 0 && tq_bytes <= 160 * 1024 - 1024 && nk >= 4096 && e->Mh.nlevels < 32768) {
-            e->thermal_variants |= ARTIS_AMD_THERMAL_REFILL;
-            if (!e->tq_attr_set) {  // (per engine, i.e. per device: the attribute is the device's, not the process's -- ADVICE r05)
-              HIP_TRY(hipFuncSetAttribute((const void *)k_thermal_q<TQ_TB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-              HIP_TRY(hipFuncSetAttribute((const void *)k_thermal_q<TQ_TB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-              e->tq_attr_set = true;
-            }
-            const int grid1 = (int)std::min<int64_t>(((int64_t)nk + TQ_TB - 1) / TQ_TB, (int64_t)e->ncu);
-            if (cold)
-              hipLaunchKernelGGL((k_thermal_q<TQ_TB, true>), dim3(grid1), dim3(TQ_TB), tq_bytes, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
-                                 e->wave_chunks_t ? chunks_for(nk, grid1 * (TQ_TB / 64)) : 8, drain, e->tq_low);
-            else
-              hipLaunchKernelGGL((k_thermal_q<TQ_TB, false>), dim3(grid1), dim3(TQ_TB), tq_bytes, s, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
-                                 e->wave_chunks_t ? chunks_for(nk, grid1 * (TQ_TB / 64)) : 8, drain, e->tq_low);
-          } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS && e->Mh.nalltrans <= MA_LDS_TRANS && nk >= 4096) {
-            const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
-            e->thermal_variants |= ARTIS_AMD_THERMAL_LDS_TABLES;
-            LAUNCH_T2(k_thermal, 1024, 1, grid1, 1024, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
-          } else if (e->ma_tables_lds && e->Mh.nlevels <= MA_LDS_LEVELS2 && nk >= 4096 && env.cellest_n_t == 0) {
-            const int grid1 = (int)std::min<int64_t>(((int64_t)nk + 1023) / 1024, (int64_t)e->ncu);
-            e->thermal_variants |= ARTIS_AMD_THERMAL_LDS_LEVELPACK;
-            LAUNCH_T2(k_thermal, 1024, 2, grid1, 1024, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors, e->wave_chunks_t ? chunks_for(nk, grid1 * 16) : 8, 0, drain);
-          } else {
-            e->thermal_variants |= ARTIS_AMD_THERMAL_PLAIN;
-            LAUNCH_T2(k_thermal, ARTIS_THERMAL_TB, 0, grid, ARTIS_THERMAL_TB, 0, env, lst, nk, next, e->d_stats, bud_t, e->d_cursors,
-                      per_cu ? 256 : (e->wave_chunks_t ? chunks_for(nk, grid * (ARTIS_THERMAL_TB / 64)) : 8), per_cu ? 2 : 0, drain);
-          }
-#undef LAUNCH_T2
-        }
+        rc = launch_thermal(s, lst, nk, next, e->d_cursors);
+        if (rc != ARTIS_OK) return rc;
       } else if (kind == NEXT_BB) {
         hipLaunchKernelGGL(k_blackbody, dim3(nblocks(nk)), dim3(BLOCK), 0, s, env, lst, nk, next, e->d_stats);
       } else {
