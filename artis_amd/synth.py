@@ -69,8 +69,11 @@ OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0
 
 def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fraction: float = 0.4,
                 nphixspoints: int = 40, phixsnuincrement: float = 0.1, two_target_fraction: float = 0.25,
-                forbidden_fraction: float = 0.2, collstr_fraction: float = 0.1, options: str = "classic") -> dict:
-    """Build the atomic part of struct artis_model. `elements` = list of (Z, lowest_ionstage, nions)."""
+                forbidden_fraction: float = 0.2, collstr_fraction: float = 0.1, options: str = "classic", lut_nsub: int = 6) -> dict:
+    """Build the atomic part of struct artis_model. `elements` = list of (Z, lowest_ionstage, nions).
+    lut_nsub: sub-intervals per cross-section table cell of the quadrature behind the rate-coefficient tables (6: 1e-3 accurate, what every
+    model of the tests and the bench is made with; the equilibrium media of tests/test_physics_laws.py ask for 200: in an optically thick
+    continuum a table that is 0.15 % off its own cross-sections is amplified by the hundreds of absorption / re-emission cycles of a photon)."""
     rng = np.random.default_rng(seed)
     if elements is None:
         elements = [(14, 1, 4), (26, 1, 5), (27, 1, 5)]
@@ -297,7 +300,7 @@ def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fr
     spont = np.zeros((nbfcontinua, TABLESIZE))
     gammac = np.zeros((nbfcontinua, TABLESIZE))
     bfcool = np.zeros((nbfcontinua, TABLESIZE))
-    nsub = 6
+    nsub = int(lut_nsub)
     for e, (Z, lowest, nions) in enumerate(elements):
         for ion in range(nions - 1):
             ui = elem_uiis[e] + ion

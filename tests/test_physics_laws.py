@@ -348,13 +348,13 @@ def _check_emission_aberration(backend, n):
     assert abs(energy) < 4 * np.sqrt(beta2.mean() / 3 / m) + 2 * beta2.mean(), (energy, beta2.mean())
 
 
-def _te_medium(T=11000., rho=3e-14, ncoord=4, width_frac=5e-4):
+def _te_medium(T=11000., rho=3e-14, ncoord=4, width_frac=5e-4, lut_nsub=6):
     """every cell in strict thermodynamic equilibrium (synth.make_grid_and_cells uniform_te). A SHORT timestep: only a packet's
     last absorption and emission are recorded, and with dt/t = 2e-3 a tenth of the re-emitted packets meet another line before
     the step ends -- which ones depends on the emitting line, a bias of several per cent per pair (measured: chi2 246 over 118
     pairs); with 5e-4 the pairs are clean (53 over 70 at 8e6 packets)"""
     p = synth.PRESETS["small"]
-    atomic = synth.make_atomic(seed=3, elements=p[0], nlevels_per_ion=p[1], line_fraction=0.6, nphixspoints=p[3])
+    atomic = synth.make_atomic(seed=3, elements=p[0], nlevels_per_ion=p[1], line_fraction=0.6, nphixspoints=p[3], lut_nsub=lut_nsub)
     grid, cells, aux = synth.make_grid_and_cells(atomic, ncoord=ncoord, uniform_te=dict(T=T, rho=rho))
     md = {k: v for k, v in atomic.items() if not k.startswith("_")}
     md.update(grid)
@@ -463,11 +463,18 @@ def _check_te_channel_balance(backend, n):
         z = (fwd - bwd) / sigma
         if name == "bound-free, thermal pool":
             # FINDING (round 6, engine and host emulation alike, i.e. the algorithm as restated): bound-free absorption makes 5-7 % more k-packets
-            # than free-bound cooling removes (8e6 packets on the GPU: 39 445 against 36 789, 9.6 sigma; 1.6e6 on the CPU: 7 940 against 7 558),
-            # made up by ~1 % more recombination emissions than photoionisations in the macro-atom half -- the two halves together balance. Not
-            # the cross-sections' nu^-3 tail beyond their tables (the same with tables ten times as long); cause not identified. The split of an
-            # absorbed photon between ionisation and heating (rpkt.cc:459-480) against the split of the emission between macro-atom and thermal
-            # pool (macroatom.cc:141-190, kpkt.cc:152-190) is therefore held to 12 % here, not to its noise.
+            # than free-bound cooling removes (8e6 packets on the GPU: 39 445 against 36 789, 9.6 sigma; 1.6e6 on the CPU: 7 942 against 7 562),
+            # made up by ~1 % more recombination emissions than photoionisations in the macro-atom half -- the two halves together balance.
+            # What it is NOT: the RATES -- the continuous expectation of the heating, integrated over the cell's own populations and cross-
+            # sections, is 0.996 of the cooling list's free-bound total; not the tables' quadrature (the same with lut_nsub = 200) nor the nu^-3
+            # tail beyond the tables (same with tables ten times as long). What it IS, as far as it was followed: the medium does not stay
+            # stationary in its optically thick continua. The path-length estimators of the same run (bfheatingestimator x n_level against
+            # ffheatingestimator) see 15 % more radiation above the dominant ion's ground edge (optical depth ~1e3 per step: a photon there is
+            # absorbed and re-emitted hundreds of times) than the Planck field the packets were drawn from: a net flow of ~1.6 % of the free-free
+            # absorptions through the thermal pool and collisional excitation into recombination photons, which a band holding 0.3 % of the
+            # packets turns into a 15 % excess -- and more photons above the edges are more bound-free heating events. Which pair of rates is
+            # 1 % off its inverse in this medium (collisional excitation / de-excitation against the Sobolev-escape radiative rates is the
+            # candidate) was not found. The pair is therefore held to 12 % here, not to its noise.
             assert abs(fwd - bwd) <= 0.12 * max(fwd, bwd) + 4.5 * sigma, (name, fwd, bwd)
             continue
         worst = max(worst, abs(z))
