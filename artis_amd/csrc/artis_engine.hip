@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(BLOCK) k_allcont(Env env) {
   bool keep = false;
   if (i < env.M.nbfcontinua) keep = populate_allcont(env, c, i);
   const unsigned long long bits = __ballot(keep);
-  if (lane == 0) env.K.allcont_keepbits[(int64_t)c * env.M.nkeepwords + word] = bits;
+  if (lane == 0) env.K.allcont_keepbits[(krow(env, c) * env.M.nkeepwords) + word] = bits;
 }
 // one wave = one cell: the kept continua as a list, the count of kept continua below each bitmap word and the pairs in list
 // order (physics.h populate_keptlist; after k_allcont)
@@ -117,11 +117,11 @@ __global__ void __launch_bounds__(BLOCK) k_keptlist(Env env) {
   if (wave >= fill_count(env)) return;
   const int c = fill_cell(env, wave);
   const int nw = env.M.nkeepwords;
-  const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * nw);
-  int32_t *list = env.K.allcont_keptlist + ((int64_t)c * env.M.nbfcontinua);
-  int32_t *prefix = env.K.allcont_keepprefix + ((int64_t)c * nw);
-  const D2 *pair = env.K.allcont_pair + ((int64_t)c * env.M.nbfcontinua);
-  D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * env.M.nbfcontinua);
+  const uint64_t *keep = env.K.allcont_keepbits + (krow(env, c) * nw);
+  int32_t *list = env.K.allcont_keptlist + (krow(env, c) * env.M.nbfcontinua);
+  int32_t *prefix = env.K.allcont_keepprefix + (krow(env, c) * nw);
+  const D2 *pair = env.K.allcont_pair + (krow(env, c) * env.M.nbfcontinua);
+  D2 *keptpair = env.K.allcont_keptpair + (krow(env, c) * env.M.nbfcontinua);
   int base = 0;
   for (int w0 = 0; w0 < nw; w0 += 64) {
     const int j = w0 + lane;
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_matrans(Env env) {
   const int seg0 = M.scanblk_seg0[blk], seg1 = M.scanblk_seg0[blk + 1];
   const MaLongSeg sfirst = M.scansegs[seg0], slast = M.scansegs[seg1 - 1];
   const int a0 = sfirst.ats0, nent = (slast.ats0 + slast.n) - a0;
-  U4 *row = env.K.macache + ((int64_t)c * M.nmacache);
+  U4 *row = env.K.macache + (krow(env, c) * M.nmacache);
   double *upterms = env.collexc_terms + (kf * M.nupcum);
   double(*v)[MATRANS_BLOCK] = lds_v[w];
   if (nent > MATRANS_BLOCK) {
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(BLOCK) k_macroatom_recomb(Env env) {
   const int ul = M.recomb_levels[(valid ? row_id : 0) % M.nrecomblevels];
   const int ui = M.level_ion[ul];
   const int ls = M.ion_uniquelevelindexstart[ui > 0 ? ui - 1 : 0];
-  const int64_t cb = (int64_t)c * M.nphixstargets_total;
+  const int64_t cb = krow(env, c) * M.nphixstargets_total;
   const double e_cur = eps(M, ul);
   const int j0 = valid ? M.level_recomb_start[ul] : 0, j1 = valid ? M.level_recomb_start[ul + 1] : 0;
   double carry0 = 0., carry1 = 0., carry2 = 0.;
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(BLOCK) k_mafilter_long(Env env) {
   const int c = fill_cell(env, wave / nseg);
   const MaLongSeg seg = env.M.malongsegs[wave % nseg];
   const LevelPack lpk = env.M.level_pack[seg.ul];
-  U4 *rec = env.K.macache + ((int64_t)c * env.M.nmacache) + lpk.rec_off;
+  U4 *rec = env.K.macache + (krow(env, c) * env.M.nmacache) + lpk.rec_off;
   const double *rates = ma_rates_of(rec, lpk.ndown, lpk.nup);
   const bool down = seg.dir == 0;
   const double whole_int = rates[down ? ARTIS_MA_ACTION_INTERNALDOWNSAME : ARTIS_MA_ACTION_INTERNALUPSAME];
@@ -586,7 +586,7 @@ __device__ inline void ma_fill_record_wave(const Env &env, int c, int ul) {
   // ---- upward: the internal-up rate and filter, and the level's collisional-excitation cooling filter (running sums from the
   // cooling list's value before the level; populate_coolfilter_level_seq)
   const int hi_i = M.level_coolhi[ul];
-  const double *cool = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
+  const double *cool = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms);
   const double c_hi = (nu > 0 && hi_i >= 0) ? cool[hi_i] : 0.;
   const double c_lo = (nu > 0 && hi_i > M.ion_coolingoffset[M.level_ion[ul]]) ? cool[hi_i - 1] : 0.;
   const double span = c_hi - c_lo;
@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(BLOCK) k_ma_reset(Env env) {
   const int ncold = env.M.ncold;
   if (i >= fill_count(env) * ncold) return;
   const int c = fill_cell(env, i / ncold);
-  env.K.ma_rowtab[((int64_t)c * ncold) + (i % ncold)] = -1;
+  env.K.ma_rowtab[(krow(env, c) * ncold) + (i % ncold)] = -1;
 }
 // the static part of every record of every resident row, once per engine: filter entries "never counted", lines usable
 __global__ void __launch_bounds__(BLOCK) k_mainit(Env env, int64_t nrows) {
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_head(Env env) {
   const int c = fill_cell(env, i / env.M.nions);
   const int ui = (int)(i % env.M.nions);
   int k = 0;
-  env.K.ion_cooling_C[((int64_t)c * env.M.nions) + ui] = cooling_ion_head(env, c, ui, &k);
+  env.K.ion_cooling_C[(krow(env, c) * env.M.nions) + ui] = cooling_ion_head(env, c, ui, &k);
 }
 // the value of the lane below within a row of 16 lanes (the row's first lane: 0)
 __device__ inline double row_shr1(double x) {
@@ -721,9 +721,9 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_chain(Env env) {
   const int nlevels = M.ion_nlevels[ui];
   const int j0 = (valid && nlevels > 0) ? M.level_upcum_start[start] : 0;
   const int j1 = (valid && nlevels > 0) ? M.level_upcum_start[start + nlevels - 1] + M.level_nuptrans[start + nlevels - 1] : 0;
-  double carry = valid ? env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] : 0.;
+  double carry = valid ? env.K.ion_cooling_C[(krow(env, c) * M.nions) + ui] : 0.;
   double *upcum = env.collexc_terms + (((valid ? row_id : 0) / M.nions) * M.nupcum);  // the cell's row of the population's scratch
-  double *cool = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
+  double *cool = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms);
   for (int j = j0; __any(j < j1); j += 16) {  // rows with shorter chains idle through the longer ones' chunks
     const bool in = (j + r) < j1;
     const double x = in ? upcum[j + r] : 0.;
@@ -742,7 +742,7 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_chain(Env env) {
     const int src = ((threadIdx.x & 63) | 15) << 2;
     carry = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(acc)), __builtin_amdgcn_ds_bpermute(src, __double2loint(acc)));
   }
-  if (valid && r == 0 && j1 > j0) env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] = carry;
+  if (valid && r == 0 && j1 > j0) env.K.ion_cooling_C[(krow(env, c) * M.nions) + ui] = carry;
 }
 // the cooling filters of the levels' records from the running sums the chain left in the scratch rows: a thread per (cell, line)
 __global__ void __launch_bounds__(BLOCK) k_collexc_filter(Env env) {
@@ -769,16 +769,16 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_tail(Env env) {
   const int element = M.ion_element[ui];
   const int ion = ui - M.elem_uniqueionindexstart[element];
   const bool has = valid && ion < (M.elem_nions[element] - 1) && M.nbfcontinua > 0;
-  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  const double *pops = env.K.levelpops + (krow(env, c) * M.nlevels);
   const int ionstart = M.ion_coolingoffset[ui];
-  double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + ionstart;
+  double *contribs = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms) + ionstart;
   const float cnne = clumpednne(env.C, c);
   const float T_e = env.C.Te[c];
   const int start = M.ion_uniquelevelindexstart[ui];
   const int ustart = has ? M.ion_uniquelevelindexstart[ui + 1] : 0;
   const double nnupperion = has ? nnion(env, c, element, ion + 1) : 0.;
   const int k0 = has ? M.ion_cooltail_start[ui] : 0, k1 = has ? M.ion_ncoolingterms[ui] : 0;
-  double carry = valid ? env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] : 0.;
+  double carry = valid ? env.K.ion_cooling_C[(krow(env, c) * M.nions) + ui] : 0.;
   for (int j = k0; __any(j < k1); j += 16) {
     const bool in = (j + r) < k1;
     double x = 0.;
@@ -787,7 +787,7 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_tail(Env env) {
       const int level = M.coolinglist_level[i];
       const int t = M.coolinglist_phixstargetindex[i];
       const int ul = start + level;
-      const int64_t o = ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
+      const int64_t o = (krow(env, c) * M.nphixstargets_total) + M.level_phixstargetstart[ul];
       if (M.coolinglist_type[i] == ARTIS_COOLING_COLLION) {
         const double e_trans = eps(M, ustart + phixs_upperlevel(M, ul, t)) - eps(M, ul);
         x = pops[ul] * env.K.bf_colion[o + t] * e_trans;
@@ -825,7 +825,7 @@ __global__ void __launch_bounds__(BLOCK) k_cooling_tail(Env env) {
     const int src = ((threadIdx.x & 63) | 15) << 2;
     carry = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(acc)), __builtin_amdgcn_ds_bpermute(src, __double2loint(acc)));
   }
-  if (has && r == 0) env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] = carry;
+  if (has && r == 0) env.K.ion_cooling_C[(krow(env, c) * M.nions) + ui] = carry;
 }
 __global__ void __launch_bounds__(BLOCK) k_cooling_prefix(Env env) {
   const int64_t kf = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -974,43 +974,6 @@ __global__ void __launch_bounds__(BLOCK) k_count_waiting(Env env, int32_t *count
   else
     atomicAdd(&counts[c], 1);
 }
-// Sparse fill of a tile: mark the cells of the tile [lo, hi) in which a packet waits (the predicate of k_classify) ...
-__global__ void __launch_bounds__(BLOCK) k_mark_cells(Env env, uint32_t *resident) {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= env.P.n) return;
-  const PktHot &h = env.P.hot[i];
-  const int type = h.type;
-  const bool active = type_handled(type) && h.prop_time < env.S.ts_end;
-  const bool waiting = h.pend != PEND_NONE || h.ma_level >= 0;
-  if (!(waiting || active) || (active && type_gamma(type) && !waiting)) return;
-  // ... and the cells around it (one step in every grid direction): an r-packet crosses a few cells per visit
-  const DevModel &M = env.M;
-  int idx[3], lo3[3], hi3[3];
-  for (int d = 0; d < 3; d++) {
-    idx[d] = (h.cellindex / M.coordstride[d]) % M.ncoordgrid[d];
-    lo3[d] = idx[d] > 0 ? -1 : 0;
-    hi3[d] = idx[d] < M.ncoordgrid[d] - 1 ? 1 : 0;
-  }
-  for (int dz = lo3[2]; dz <= hi3[2]; dz++)
-    for (int dy = lo3[1]; dy <= hi3[1]; dy++)
-      for (int dx = lo3[0]; dx <= hi3[0]; dx++) {
-        const int c = M.propcell_nonemptymgi[h.cellindex + (dx * M.coordstride[0]) + (dy * M.coordstride[1]) + (dz * M.coordstride[2])];
-        if (c >= env.tile_lo && c < env.tile_hi) atomicOr(&resident[c >> 5], 1u << (c & 31));
-      }
-}
-// ... and list them
-__global__ void __launch_bounds__(BLOCK) k_compact_cells(int lo, int hi, const uint32_t *resident, int32_t *cells, int32_t *count) {
-  const int c = lo + blockIdx.x * BLOCK + threadIdx.x;
-  const bool set = c < hi && ((resident[c >> 5] >> (c & 31)) & 1u) != 0;
-  const unsigned long long m = __ballot(set);
-  if (m == 0) return;
-  const int lane = threadIdx.x & 63;
-  int base = 0;
-  if (lane == __ffsll((long long)m) - 1) base = atomicAdd(count, __popcll(m));
-  base = __shfl(base, __ffsll((long long)m) - 1);
-  if (set) cells[base + __popcll(m & ((1ull << lane) - 1ull))] = c;
-}
-
 // ---- counting sort of a work list by its entries' keys (propagation cell, frequency bin): three tiny kernels.
 // Within a cell, r-packets are ordered by comoving frequency like the reference's own packet sort
 // (compare_packet_order, update_packets.cc:363): neighbouring lanes then walk the same part of the line list and
@@ -1412,8 +1375,8 @@ __global__ void __launch_bounds__(TB, (TB == DENSE_TB ? ARTIS_DENSE_WGS : 1)) k_
     kept_range(env, c, ev.begin, ev.end, r0, r1);
     const double ex = exp(-HOVERKB * nu / T_e);
     const bool split_usable = (ex >= DBLMIN);
-    const int32_t *list = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
-    const D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * M.nbfcontinua);
+    const int32_t *list = env.K.allcont_keptlist + (krow(env, c) * M.nbfcontinua);
+    const D2 *keptpair = env.K.allcont_keptpair + (krow(env, c) * M.nbfcontinua);
     // the sums go to the continuum's place in the list when the call keeps them there (all cells resident), else to its
     // estimator: ~30 additions of a record then fall into 4-5 neighbouring 64-byte sectors instead of ~16 scattered ones
     // (k_rpkt + this kernel 978 -> 858 ms per step; with the additions compiled out: 891)
@@ -1434,8 +1397,8 @@ __global__ void __launch_bounds__(BLOCK) k_bfrate_expand(Env env) {
   if (wave >= M.npts_nonempty) return;
   const int c = (int)wave;
   const int nw = M.nkeepwords;
-  const int nkept = env.K.allcont_keepprefix[((int64_t)c * nw) + nw - 1] + __popcll(env.K.allcont_keepbits[((int64_t)c * nw) + nw - 1]);
-  const int32_t *list = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
+  const int nkept = env.K.allcont_keepprefix[(krow(env, c) * nw) + nw - 1] + __popcll(env.K.allcont_keepbits[(krow(env, c) * nw) + nw - 1]);
+  const int32_t *list = env.K.allcont_keptlist + (krow(env, c) * M.nbfcontinua);
   double *kept = env.bfrate_kept + ((int64_t)c * M.nbfcontinua);
   double *dst = env.E.bfrate_raw + ((int64_t)c * M.nbfestim);
   for (int r = lane; r < nkept; r += 64) {
@@ -1932,7 +1895,7 @@ __global__ void __launch_bounds__(TB, 1) k_thermal_q(Env env, const int32_t *lis
               const int lv = Q.lv[s];
               w.ma_level = lv & 0xFFFF;
               k.c = Q.c[s];
-              k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
+              k.cellma = env.K.macache + (krow(env, k.c) * env.M.nmacache);
               k.start = lv >> 16;
               const LevelPack lp = env.M.level_pack[k.start + w.ma_level];
               k.rec = ma_resolve<COLD>(env, k.c, lp.rec_off); k.nd = lp.ndown; k.nu = lp.nup; k.ats = lp.alltrans_startdown;
@@ -2396,8 +2359,15 @@ struct artis_amd_engine {
   // single-slot cell cache does cell by cell, update_packets.cc:397-460, 551-621).
   int64_t tile_cells = 0;
   int ntiles = 1;
-  int tile_lo = 0, tile_hi = 0;   // the tile the biased cache pointers refer to
-  int tile_valid_lo = -1;         // first cell of the tile whose cache is populated for the current cell state (-1: none)
+  int tile_lo = 0, tile_hi = 0;   // one tile: all cells (the range a whole-cache fill works on)
+  int tile_valid_lo = -1;         // one tile: 0 once the cache is populated for the current cell state (-1: not)
+  // several tiles: which cell's cache each row holds, populated for the current cell state (physics.h Env::krow_tab; make_resident())
+  std::vector<int32_t> h_krow;     // [npts_nonempty] row of the cell, -1: not resident
+  std::vector<int32_t> h_rowcell;  // [tile_cells] cell of the row, -1: free
+  std::vector<int32_t> h_wanted;   // [npts_nonempty] stamp of the last make_resident() that asked for the cell
+  int32_t want_stamp = 0;
+  int32_t *d_krow = nullptr;
+  std::vector<int32_t> h_cell_grid;  // [npts_nonempty] the grid cell of a non-empty cell (the inverse of propcell_nonemptymgi)
   size_t cache_bytes_per_cell = 0;
   int32_t *d_target_level = nullptr;
   double *d_est = nullptr;
@@ -2442,31 +2412,34 @@ struct artis_amd_engine {
   int64_t kthreads[NEXT_NKINDS] = {};
   int64_t last_nlaunches = 0;
   // tiled runs: sweeps over the tiles, tile fills and their summed time, packets listed per (sweep, tile) of the last call
-  // sparse fills (later sweeps of a tiled run): the cells of the tile in which packets wait, as a bitmap over the model's
-  // non-empty cells and as a list; resident_on: the current visit runs on such a fill. ARTIS_AMD_SPARSE_FILL=0: whole tiles.
-  uint32_t *d_resident = nullptr;
-  int32_t *d_fill_cells = nullptr, *d_nfill = nullptr;
-  bool resident_on = false, sparse_fill = true;
+  // the cells a fill of a tiled cache works on (make_resident()). Sparse fills: a visit for which few packets wait makes the cells in which they
+  // wait (and the cells around those) resident instead of a whole window. ARTIS_AMD_SPARSE_FILL=0: whole windows.
+  int32_t *d_fill_cells = nullptr;
+  bool sparse_fill = true;
   int64_t sparse_max_listed = 16384;  // ... for visits that list at most this many packets (ARTIS_AMD_SPARSE_MAX; 512 in round 3:
                                       // 4 tiles 3327 / 3205 / 3188 ms at 512 / 4096 / 16384, with parked tails 3222 / 3123 / 2982)
   int64_t last_sparse_fills = 0, last_cells_filled = 0;
   bool park_tails = true;     // ARTIS_AMD_TILE_PARK=0: every visit of a tile runs its packets to their end (rounds 2-3)
   // ARTIS_AMD_TILE_PARK_AT: packets left of a larger visit at which it parks them (0 / <= tail_max: round 4's rule, at the tail kernel's
   // threshold). Measured on the headline at a quarter of its cache (4 tiles, adaptive windows; profiles/r06/tiling.md): 4096 / 32768 / 131072 /
-  // 524288 / 2097152 -> 2395 / 2147 / 1971 / 1899 / 1868 ms per step (untiled 760)
-  int64_t park_at = 524288;
+  // 524288 / 2097152 -> 2395 / 2147 / 1971 / 1899 / 1868 ms per step (untiled 760); with this round's rows for sets of cells and record tiers (two tiles
+  // of rows with a quarter of the levels hot): 131072 / 524288 / 2097152 -> 1550 / 1532 / 1504 ms
+  int64_t park_at = 2097152;
   int64_t last_parked = 0;
   int64_t last_pool_resets = 0;  // times the pool of on-demand records was emptied because it was used up (this call)
   int64_t last_pool_used = 0, last_pool_cap = 0;  // units (128 B) of the pool in use at the end of the last call / the pool's size
   double ma_hotfrac = 1.;        // the share of every ion's levels that has a static record (given, or chosen by engine_fill from the cache budget)
   bool vpkt_cont_lds = true;  // ARTIS_AMD_VPKT_CONTLDS=0: k_vpkt reads the continuum table from memory (four workgroups of 256 per CU)
   bool tile_zigzag = false;  // ARTIS_AMD_TILE_ZIGZAG=1: sweeps alternate their direction (measured slower: profiles/r03/tiling.md)
-  // Adaptive tiles (round 6; ARTIS_AMD_TILE_ADAPT=0: the fixed ranges of rounds 2-5). A tile is still a contiguous range of non-empty cells --
-  // the cache pointers are biased by its first cell -- but WHICH range is chosen before every visit: the window of tile_cells cells in which
-  // most packets wait (k_count_waiting + a sliding sum on the host). The first visits take the densest parts of the ejecta; afterwards the
-  // waiting packets sit on both sides of the earlier windows' edges, and a window laid across such an edge lets them cross it freely instead
-  // of waiting once per crossing and fixed tile.
+  // Adaptive tiles (round 6; ARTIS_AMD_TILE_ADAPT=0: the fixed ranges of rounds 2-5). WHICH cells are resident is chosen before every visit from
+  // the number of packets that wait in every cell (k_count_waiting): the window of tile_cells consecutive cells in which most packets wait
+  // (ARTIS_AMD_TILE_BLOCK=0), or the blocks of tile_block consecutive cells in which most wait, wherever they lie (a tile = a SET of cells: rows are
+  // addressed through Env::krow_tab). A cell that is resident and still wanted keeps its row -- only the cells that are new to the set are filled.
+  // The first visits take the densest parts of the ejecta; afterwards the waiting packets sit on both sides of the earlier sets' edges, and a set laid
+  // across such an edge lets them cross it freely instead of waiting once per crossing and fixed tile.
   bool tile_adapt = true;
+  int64_t tile_block = 0;
+  bool pool_keep = true;
   int32_t *d_waiting = nullptr;  // [npts_nonempty + 1] packets waiting per cell; the last entry: packets that need no row
   std::vector<int32_t> h_waiting;
   int64_t last_visits = 0;
@@ -2562,24 +2535,19 @@ Env make_env(const artis_amd_engine *e) {
   env.M = e->M;
   env.C = e->C;
   env.K = e->K;
-  {  // bias the cache pointers by the first cell of the resident tile: rows are addressed by absolute cell number
+  {
     const DevModel &h = e->Mh;
-    const int64_t lo = e->tile_lo;
-#define BIAS(f, T, per) env.K.f = e->K.f - (lo * (int64_t)(per));
-    ARTIS_CACHE_ARRAYS(BIAS, h)
-#undef BIAS
     if (h.ndpop == 0) env.K.line_dpop = nullptr;  // formed on the fly (physics.h line_dpop_at)
     // the pool of on-demand records is one for all resident cells (tables.h "ON-DEMAND RECORDS"): not indexed by cell
-    env.K.ma_pool = e->K.ma_pool;
-    env.K.ma_pool_used = e->K.ma_pool_used;
     env.ma_pool_cap = (uint32_t)std::min<int64_t>(((int64_t)e->tile_cells * h.ma_pool_slots) / MAPOOL_UNIT, 0x7FFFFFF0LL);
     env.ma_pool_full = e->d_count + (2 * NEXT_NKINDS - 1);  // (a spare slot of the counts the host reads after every launch)
   }
-  env.tile_lo = e->tile_lo;
-  env.tile_hi = e->tile_hi;
-  env.tile_all = (e->tile_lo == 0 && e->tile_hi >= e->Mh.npts_nonempty) ? 1 : 0;
-  env.resident = e->resident_on ? e->d_resident : nullptr;
-  env.fill_cells = nullptr;  // (set by a sparse populate_tile() for its own launches)
+  // rows: one per cell (row = cell), or -- a cache that does not fit -- the rows of the cells that are resident now (make_resident())
+  env.krow_tab = e->ntiles > 1 ? e->d_krow : nullptr;
+  env.tile_all = e->ntiles > 1 ? 0 : 1;
+  env.tile_lo = 0;
+  env.tile_hi = e->Mh.npts_nonempty;
+  env.fill_cells = nullptr;  // (set by populate_tile() of a tiled cache for its own launches)
   env.nfill = 0;
   env.collexc_terms = e->d_collexc_terms;
   {  // few cells: per-cell estimators accumulate in LDS (physics.h Env::cellest_lds)
@@ -2918,31 +2886,36 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
     if (!given) {
       size_t free_b = 0, total_b = 0;
       HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-      auto fits = [&]() {
+      auto tiles_needed = [&]() -> int64_t {
         size_t per_cell = 0;
 #define SZ(f, T, per) per_cell += sizeof(T) * (size_t)(per);
         ARTIS_CACHE_ARRAYS(SZ, e->Mh)
 #undef SZ
         per_cell -= sizeof(double) * (size_t)e->Mh.ndpop;  // (dropped first when the cache does not fit: below)
-        return (double)per_cell * (double)model->npts_nonempty <= cache_budget_bytes(free_b);
+        const int64_t fit = std::max<int64_t>(1, (int64_t)(cache_budget_bytes(free_b) / (double)(per_cell > 0 ? per_cell : 1)));
+        return (model->npts_nonempty + fit - 1) / fit;
       };
-      // the largest hot share that lets the whole cache be resident (the fewer cold levels, the fewer first visits pay a fill). If none
-      // does, the rows stay static and the cache is tiled: every refill of a tile empties the pool, and a tiled run on on-demand records pays
-      // its fills again and again (the headline forced to a quarter of its cache: 3.7 s with them, 3.0 s with four tiles of static rows;
-      // profiles/r05/quarter_cache.txt)
-      bool ok = fits();
+      // The largest hot share that lets the whole cache be resident (the fewer cold levels, the fewer first visits pay a fill). If none does, the
+      // cache is tiled, and the share is the largest one that needs the FEWEST tiles: smaller rows, more cells resident at a time (round 6; the headline
+      // forced to a quarter of its cache: 1875 ms with four tiles of static rows, 1532 ms with two tiles of rows with a quarter of the levels hot --
+      // profiles/r06/tiling.md. Round 5 kept the rows static in that case: every refill of a tile emptied the pool then, and a tiled run on on-demand
+      // records paid its fills again and again, 3.7 s against 3.0 s; now a fill leaves the pool and the rows of the cells that stay alone.)
       // (round 6: in steps of 0.05 below one half -- with the round-5 steps 0.5 / 0.3 / 0.2 / 0.1 a record that grew by a quarter, the fine bytes, sent
       // the 4e5-line set from 0.2 to 0.1 and doubled its fills)
+      int64_t best_nt = tiles_needed();
+      double best_h = 1., cur_h = 1.;
       for (const double h : {0.9, 0.8, 0.7, 0.6, 0.5, 0.45, 0.4, 0.35, 0.3, 0.25, 0.2, 0.15, 0.1, 0.05}) {
-        if (ok) break;
+        if (best_nt <= 1) break;
         e->Mh = make_host_model_view(*model, e->own, h, pool);
-        e->ma_hotfrac = h;
-        ok = fits();
+        cur_h = h;
+        const int64_t nt = tiles_needed();
+        if (nt < best_nt) {
+          best_nt = nt;
+          best_h = h;
+        }
       }
-      if (!ok) {
-        e->Mh = make_host_model_view(*model, e->own, 1., pool);
-        e->ma_hotfrac = 1.;
-      }
+      if (cur_h != best_h) e->Mh = make_host_model_view(*model, e->own, best_h, pool);
+      e->ma_hotfrac = best_h;
     }
   }
   e->model_copy = *model;
@@ -3125,9 +3098,17 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   HIP_TRY(hipMemset(e->d_err, 0, sizeof(int32_t)));
   HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 2 * NEXT_NKINDS));
   HIP_TRY(hipMalloc((void **)&e->d_cursors, sizeof(int32_t) * (MAX_CHUNKS + 1)));  // + the launch's "list used up" flag
-  HIP_TRY(hipMalloc((void **)&e->d_resident, sizeof(uint32_t) * (size_t)((ncell_all + 31) / 32 + 1)));
   HIP_TRY(hipMalloc((void **)&e->d_fill_cells, sizeof(int32_t) * (size_t)(ncell_all > 0 ? ncell_all : 1)));
-  HIP_TRY(hipMalloc((void **)&e->d_nfill, sizeof(int32_t)));
+  if (e->ntiles > 1) {  // rows for a set of cells at a time: the table of rows, no cell resident yet
+    HIP_TRY(hipMalloc((void **)&e->d_krow, sizeof(int32_t) * (size_t)ncell_all));
+    e->h_krow.assign((size_t)ncell_all, -1);
+    e->h_wanted.assign((size_t)ncell_all, 0);
+    e->h_rowcell.assign((size_t)e->tile_cells, -1);
+    HIP_TRY(hipMemset(e->d_krow, 0xFF, sizeof(int32_t) * (size_t)ncell_all));
+    e->h_cell_grid.assign((size_t)ncell_all, 0);
+    for (int g = 0; g < h.ngrid; g++)
+      if (h.propcell_nonemptymgi[g] >= 0) e->h_cell_grid[(size_t)h.propcell_nonemptymgi[g]] = g;
+  }
   {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -3175,6 +3156,8 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_LINELDS")) e->line_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TILE_ZIGZAG")) e->tile_zigzag = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_TILE_ADAPT")) e->tile_adapt = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_TILE_BLOCK")) e->tile_block = std::max<int64_t>(0, std::atoll(b));
+  if (const char *b = std::getenv("ARTIS_AMD_POOL_KEEP")) e->pool_keep = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_MATABLES_LDS")) e->ma_tables_lds = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_REFILL")) e->thermal_refill = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_NUMAJOR")) e->sort_numajor = std::atoi(b) != 0;
@@ -3220,8 +3203,8 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
   free_packet_buffers(e);
-  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_resident, e->d_fill_cells, e->d_waiting,
-                  e->d_nfill, e->d_bfrate_kept, e->d_collexc_terms, e->d_visit_counts};
+  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_krow, e->d_fill_cells, e->d_waiting,
+                  e->d_bfrate_kept, e->d_collexc_terms, e->d_visit_counts};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t ev : {e->ev0, e->ev1, e->ev2, e->ev3})
@@ -3341,21 +3324,29 @@ int artis_amd_set_cellstate(artis_amd_engine *e, const artis_cellstate *cells, c
 }  // extern "C"
 
 namespace {
-// populate the cell cache of the non-empty cells [lo, hi) (at most tile_cells of them) into the resident rows
-int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nfill = -1) {
+// populate the cell cache: of every cell (nfill < 0: one tile, row = cell), or of the cells e->d_fill_cells[0..nfill) (a tiled cache: their rows are
+// in e->d_krow, make_resident())
+int populate_tile(artis_amd_engine *e, hipStream_t s, int64_t nfill = -1) {
   const DevModel &h = e->Mh;
+  const int lo = 0, hi = h.npts_nonempty;
   e->tile_lo = lo;
   e->tile_hi = hi;
   e->tile_valid_lo = -1;
   Env env = make_env(e);
-  if (nfill >= 0) {  // sparse: the cells e->d_fill_cells[0..nfill) only
+  if (nfill >= 0) {
     env.fill_cells = e->d_fill_cells;
     env.nfill = (int32_t)nfill;
   }
   const int64_t ncell_fill = nfill >= 0 ? nfill : hi - lo;
   if (ncell_fill <= 0) return ARTIS_OK;
-  // (whatever the pool of on-demand records held belonged to cells whose rows are not valid after this fill)
-  if (h.ncold > 0) HIP_TRY(hipMemsetAsync(e->K.ma_pool_used, 0, sizeof(uint32_t), s));
+  // The pool of on-demand records: a fill of the whole cache empties it. A fill of some cells of a tiled cache leaves it alone -- the cells that stay
+  // resident keep their cold levels' records; the rows that are filled start without any (k_ma_reset below), and the units the cells before them held
+  // stay handed out until the pool is used up and emptied (reset_pool_if_due() of the propagation loop), which costs fills, never an answer.
+  // ARTIS_AMD_POOL_KEEP=0: emptied with every fill (round 5).
+  if (h.ncold > 0 && (nfill < 0 || !e->pool_keep)) {
+    HIP_TRY(hipMemsetAsync(e->K.ma_pool_used, 0, sizeof(uint32_t), s));
+    if (nfill >= 0) HIP_TRY(hipMemsetAsync(e->K.ma_rowtab, 0xFF, sizeof(int32_t) * (size_t)(e->tile_cells * (int64_t)h.ncold), s));
+  }
   // in batches of pop_batch cells (the scratch of cooling terms holds that many rows); the kernels of a batch see it as
   // their whole fill: a sub-range of the tile, or a stretch of the list of a sparse fill
   const Env env_tile = env;
@@ -3409,8 +3400,146 @@ int populate_tile(artis_amd_engine *e, int lo, int hi, hipStream_t s, int64_t nf
     g_last_error = "cell cache population raised error flag " + std::to_string(err);
     return ARTIS_ERR_NOTCONVERGED;
   }
-  e->tile_valid_lo = nfill >= 0 ? -1 : lo;  // (a sparse fill leaves the tile partly valid: never reused)
+  e->tile_valid_lo = nfill >= 0 ? -1 : 0;
   return ARTIS_OK;
+}
+
+// a tiled cache: no cell is resident (a new cell state: what the rows hold belongs to the old one)
+int forget_rows(artis_amd_engine *e, hipStream_t s) {
+  if (e->ntiles <= 1) return ARTIS_OK;
+  std::fill(e->h_krow.begin(), e->h_krow.end(), -1);
+  std::fill(e->h_rowcell.begin(), e->h_rowcell.end(), -1);
+  HIP_TRY(hipMemsetAsync(e->d_krow, 0xFF, sizeof(int32_t) * e->h_krow.size(), s));
+  if (e->Mh.ncold > 0) {  // ... and no cold level has a record
+    HIP_TRY(hipMemsetAsync(e->K.ma_pool_used, 0, sizeof(uint32_t), s));
+    HIP_TRY(hipMemsetAsync(e->K.ma_rowtab, 0xFF, sizeof(int32_t) * (size_t)(e->tile_cells * (int64_t)e->Mh.ncold), s));
+  }
+  return ARTIS_OK;
+}
+
+// a tiled cache: make the cells want[0..) resident (at most tile_cells of them). A wanted cell that is resident keeps its row; the others take the
+// free rows, then the rows of cells that are not wanted (which stay resident as long as nobody needs their rows); the cells that got a row are filled.
+// *nfilled: how many that were.
+int make_resident(artis_amd_engine *e, const std::vector<int32_t> &want, hipStream_t s, int64_t *nfilled) {
+  *nfilled = 0;
+  if (e->ntiles <= 1 || want.empty()) return ARTIS_OK;
+  if ((int64_t)want.size() > e->tile_cells) {
+    g_last_error = "make_resident: more cells than rows";
+    return ARTIS_ERR_ARG;
+  }
+  const int32_t stamp = ++e->want_stamp;
+  std::vector<int32_t> fresh;
+  for (const int32_t c : want) {
+    e->h_wanted[(size_t)c] = stamp;
+    if (e->h_krow[(size_t)c] < 0) fresh.push_back(c);
+  }
+  if (fresh.empty()) return ARTIS_OK;
+  size_t k = 0;
+  for (int pass = 0; pass < 2 && k < fresh.size(); pass++)
+    for (size_t r = 0; r < e->h_rowcell.size() && k < fresh.size(); r++) {
+      const int32_t held = e->h_rowcell[r];
+      if (pass == 0 ? held >= 0 : (held < 0 || e->h_wanted[(size_t)held] == stamp)) continue;
+      if (held >= 0) e->h_krow[(size_t)held] = -1;
+      e->h_rowcell[r] = fresh[k];
+      e->h_krow[(size_t)fresh[k]] = (int32_t)r;
+      k++;
+    }
+  if (k < fresh.size()) {
+    g_last_error = "make_resident: no row left";
+    return ARTIS_ERR_ARG;
+  }
+  HIP_TRY(hipMemcpyAsync(e->d_krow, e->h_krow.data(), sizeof(int32_t) * e->h_krow.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(e->d_fill_cells, fresh.data(), sizeof(int32_t) * fresh.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // (fresh is a local)
+  const int rc = populate_tile(e, s, (int64_t)fresh.size());
+  if (rc != ARTIS_OK) {  // (what the rows of the new cells hold is not to be used)
+    for (const int32_t c : fresh) {
+      e->h_rowcell[(size_t)e->h_krow[(size_t)c]] = -1;
+      e->h_krow[(size_t)c] = -1;
+    }
+    (void)hipMemcpy(e->d_krow, e->h_krow.data(), sizeof(int32_t) * e->h_krow.size(), hipMemcpyHostToDevice);
+    return rc;
+  }
+  *nfilled = (int64_t)fresh.size();
+  return ARTIS_OK;
+}
+
+// Which cells should be resident for the next visit of a tiled run? waiting[c]: packets that wait in non-empty cell c (k_count_waiting).
+//  - few packets wait (at most sparse_max of them, in less than half as many cells as there are rows): the cells in which they wait and the cells around
+//    those, one step in every grid direction (an r-packet crosses a few cells per visit) -- a "sparse" visit
+//  - tile_block == 0: the window of tile_cells consecutive cells in which most packets wait
+//  - else: the blocks of tile_block consecutive cells in which most packets wait, wherever they lie, as many as there are rows for
+// *holds: the packets that wait in the chosen cells.
+void choose_cells(artis_amd_engine *e, const std::vector<int32_t> &waiting, std::vector<int32_t> &want, int64_t *holds, bool *sparse,
+                  int64_t win_lo = -1) {
+  const DevModel &h = e->Mh;
+  const int64_t ncell_all = h.npts_nonempty, nrows = e->tile_cells;
+  want.clear();
+  *sparse = false;
+  *holds = 0;
+  int64_t lo = win_lo;
+  if (win_lo < 0 && e->tile_block > 0 && e->tile_block < nrows) {
+    const int64_t B = e->tile_block, nblk = (ncell_all + B - 1) / B;
+    std::vector<std::pair<int64_t, int64_t>> score((size_t)nblk);
+    for (int64_t b = 0; b < nblk; b++) {
+      int64_t sum = 0;
+      for (int64_t c = b * B; c < std::min(ncell_all, (b + 1) * B); c++) sum += waiting[(size_t)c];
+      score[(size_t)b] = {-sum, b};
+    }
+    std::sort(score.begin(), score.end());
+    for (const auto &sb : score) {
+      const int64_t c0 = sb.second * B, c1 = std::min(ncell_all, c0 + B);
+      if (sb.first == 0 || (int64_t)want.size() + (c1 - c0) > nrows) break;
+      for (int64_t c = c0; c < c1; c++) want.push_back((int32_t)c);
+      *holds -= sb.first;
+    }
+    std::sort(want.begin(), want.end());
+  } else {
+    if (win_lo < 0) {
+      int64_t sum = 0, best = -1;
+      lo = 0;
+      for (int64_t c = 0; c < ncell_all; c++) {
+        sum += waiting[(size_t)c];
+        if (c >= nrows) sum -= waiting[(size_t)(c - nrows)];
+        if ((c >= nrows - 1 || c == ncell_all - 1) && sum > best) {
+          best = sum;
+          lo = std::max<int64_t>(0, c - nrows + 1);
+        }
+      }
+      lo = std::min<int64_t>(lo, std::max<int64_t>(0, ncell_all - nrows));
+    }
+    for (int64_t c = lo; c < std::min(ncell_all, lo + nrows); c++) {
+      want.push_back((int32_t)c);
+      *holds += waiting[(size_t)c];
+    }
+  }
+  if (!e->sparse_fill || *holds > e->sparse_max_listed) return;
+  // a sparse visit: of the chosen cells, those in which packets wait, and the cells around them (whichever cells those are)
+  std::vector<int32_t> few;
+  const int32_t stamp = -(++e->want_stamp);  // (marks of this choice: negative, never those of make_resident())
+  std::vector<int32_t> &mark = e->h_wanted;
+  const int ndim = (h.gridtype == ARTIS_GRID_SPHERICAL1D) ? 1 : ((h.gridtype == ARTIS_GRID_CYLINDRICAL2D) ? 2 : 3);
+  for (const int32_t c : want) {
+    if (waiting[(size_t)c] <= 0) continue;
+    const int g = e->h_cell_grid[(size_t)c];
+    int lo3[3] = {0, 0, 0}, hi3[3] = {0, 0, 0};
+    for (int d = 0; d < ndim; d++) {
+      const int idx = (g / h.coordstride[d]) % h.ncoordgrid[d];
+      lo3[d] = idx > 0 ? -1 : 0;
+      hi3[d] = idx < h.ncoordgrid[d] - 1 ? 1 : 0;
+    }
+    for (int dz = lo3[2]; dz <= hi3[2]; dz++)
+      for (int dy = lo3[1]; dy <= hi3[1]; dy++)
+        for (int dx = lo3[0]; dx <= hi3[0]; dx++) {
+          const int cn = h.propcell_nonemptymgi[g + (dx * h.coordstride[0]) + (dy * h.coordstride[1]) + (dz * h.coordstride[2])];
+          if (cn < 0 || mark[(size_t)cn] == stamp) continue;
+          mark[(size_t)cn] = stamp;
+          few.push_back(cn);
+        }
+  }
+  if (few.empty() || (int64_t)few.size() * 2 >= nrows) return;
+  want.swap(few);
+  *sparse = true;
 }
 }  // namespace
 
@@ -3423,10 +3552,9 @@ int artis_amd_populate_cellcache(artis_amd_engine *e, void *hip_stream) {
   }
   HIP_TRY(hipSetDevice(e->device));
   e->tile_valid_lo = -1;
-  // with one tile the whole cache is filled now; with several, artis_amd_update_packets_device() fills each tile when
-  // its turn comes
-  if (e->ntiles == 1) return populate_tile(e, 0, e->Mh.npts_nonempty, (hipStream_t)hip_stream);
-  return ARTIS_OK;
+  // with one tile the whole cache is filled now; with several, artis_amd_update_packets_device() makes cells resident as packets need them
+  if (e->ntiles == 1) return populate_tile(e, (hipStream_t)hip_stream);
+  return forget_rows(e, (hipStream_t)hip_stream);
 }
 
 int artis_amd_cache_tiles(artis_amd_engine *e, int32_t *ntiles, int64_t *cells_per_tile, int64_t *bytes_per_cell) {
@@ -3589,7 +3717,6 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   e->last_parked = 0;
   e->last_pool_resets = 0;
   e->thermal_variants = 0;
-  e->resident_on = false;
   e->last_fill_ms = 0.;
   for (int k = 0; k < NEXT_NKINDS; k++) {
     e->kms[k] = 0.;
@@ -3660,10 +3787,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   auto reset_pool_if_due = [&](const Env &env_now) -> int {
     if (!pool_reset_due || e->Mh.ncold <= 0) return ARTIS_OK;
     pool_reset_due = false;
-    Env er = env_now;
-    er.fill_cells = nullptr;
-    const int64_t ncell = (int64_t)er.tile_hi - er.tile_lo;
-    hipLaunchKernelGGL(k_ma_reset, dim3(nblocks(ncell * e->Mh.ncold)), dim3(BLOCK), 0, s, er);
+    (void)env_now;
+    HIP_TRY(hipMemsetAsync(e->K.ma_rowtab, 0xFF, sizeof(int32_t) * (size_t)(e->tile_cells * (int64_t)e->Mh.ncold), s));  // (every row: k_ma_reset)
     HIP_TRY(hipMemsetAsync(e->K.ma_pool_used, 0, sizeof(uint32_t), s));
     e->last_pool_resets++;
     if (e->trace) fprintf(stderr, "[artis_amd] the pool of on-demand records was used up: emptied (%lld)\n", (long long)e->last_pool_resets);
@@ -3757,7 +3882,8 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   // sweep finds no packet left to advance.
   const bool adaptive = e->tile_adapt && e->ntiles > 1;
   bool all_done = false;
-  if (adaptive && e->d_waiting == nullptr) {
+  std::vector<int32_t> want;
+  if (e->ntiles > 1 && e->d_waiting == nullptr) {
     HIP_TRY(hipMalloc((void **)&e->d_waiting, sizeof(int32_t) * (size_t)(ncell_all + 1)));
     e->h_waiting.assign((size_t)ncell_all + 1, 0);
   }
@@ -3768,47 +3894,44 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   // sweeps alternate their direction: a packet that left its tile against the direction of one sweep is met by the next
   // one on its way back (with one direction it waits a whole sweep per backward crossing)
   const int tile = (e->tile_zigzag && (sweep & 1)) ? e->ntiles - 1 - tstep : tstep;
-  int lo = (int)(tile * e->tile_cells);
-  if (adaptive) {
-    // where do the packets wait? The window of tile_cells consecutive non-empty cells that holds most of them is the next tile.
+  if (e->ntiles > 1) {
+    // where do the packets wait? The cells in which most of them do are made resident (choose_cells(): a window or a set of blocks of cells, or -- few
+    // packets -- the very cells); cells that are resident already keep their rows, the others are filled
     env = make_env(e);
     HIP_TRY(hipMemsetAsync(e->d_waiting, 0, sizeof(int32_t) * (size_t)(ncell_all + 1), s));
     hipLaunchKernelGGL(k_count_waiting, dim3(nblocks(n)), dim3(BLOCK), 0, s, env, e->d_waiting, e->d_waiting + ncell_all);
     HIP_TRY(hipMemcpyAsync(e->h_waiting.data(), e->d_waiting, sizeof(int32_t) * (size_t)(ncell_all + 1), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const int64_t nwin = e->tile_cells;
-    int64_t sum = 0, best = -1, total = 0;
-    int best_lo = 0;
-    for (int64_t c = 0; c < ncell_all; c++) {
-      sum += e->h_waiting[(size_t)c];
-      total += e->h_waiting[(size_t)c];
-      if (c >= nwin) sum -= e->h_waiting[(size_t)(c - nwin)];
-      if (c >= nwin - 1 || c == ncell_all - 1) {
-        const int64_t wlo = std::max<int64_t>(0, c - nwin + 1);
-        if (sum > best) {
-          best = sum;
-          best_lo = (int)wlo;
-        }
-      }
-    }
+    int64_t total = 0;
+    for (int64_t c = 0; c < ncell_all; c++) total += e->h_waiting[(size_t)c];
     if (total == 0 && e->h_waiting[(size_t)ncell_all] == 0) {  // nothing left anywhere
       all_done = true;
       break;
     }
-    lo = (int)std::min<int64_t>(best_lo, std::max<int64_t>(0, ncell_all - nwin));
+    int64_t holds = 0, nfilled = 0;
+    bool sparse = false;
+    choose_cells(e, e->h_waiting, want, &holds, &sparse, adaptive ? -1 : (int64_t)tile * e->tile_cells);
+    if (holds == 0) want.clear();  // (no packet waits for a row of these cells: the visit is for the packets that need none, if any)
     if (e->trace)
-      fprintf(stderr, "[artis_amd] visit %lld: %lld packets wait in cells, %d need no row; window [%d, %lld) holds %lld\n", (long long)e->last_visits,
-              (long long)total, e->h_waiting[(size_t)ncell_all], lo, (long long)std::min<int64_t>(ncell_all, lo + nwin), (long long)best);
+      fprintf(stderr, "[artis_amd] visit %lld: %lld packets wait in cells, %d need no row; %zu cells chosen%s hold %lld\n", (long long)e->last_visits,
+              (long long)total, e->h_waiting[(size_t)ncell_all], want.size(), sparse ? " (sparse)" : "", (long long)holds);
+    HIP_TRY(hipEventRecord(e->ev2, s));
+    rc = make_resident(e, want, s, &nfilled);
+    if (rc != ARTIS_OK) return rc;
+    if (nfilled > 0) {
+      HIP_TRY(hipEventRecord(e->ev3, s));
+      HIP_TRY(hipEventSynchronize(e->ev3));
+      float fms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&fms, e->ev2, e->ev3));
+      e->last_fill_ms += fms;
+      e->last_tile_fills++;
+      e->last_cells_filled += nfilled;
+      if (sparse) e->last_sparse_fills++;
+    }
+  } else if (e->tile_valid_lo != 0) {
+    rc = populate_tile(e, s);
+    if (rc != ARTIS_OK) return rc;
   }
-  const int hi = (int)std::min<int64_t>(ncell_all, lo + e->tile_cells);
-  if (e->tile_lo != lo || e->tile_hi != hi) {
-    e->tile_lo = lo;
-    e->tile_hi = hi;
-    e->tile_valid_lo = -1;
-  }
-  // (a sparse fill of the tile before left its residency bitmap on: it describes that tile's cells only, and classified with
-  // it every packet of this tile would be parked and the tile skipped)
-  e->resident_on = false;
   env = make_env(e);
   for (int k = 0; k < NEXT_NKINDS; k++) cur[k] = 0;
   HIP_TRY(hipMemsetAsync(e->d_count, 0, sizeof(int32_t) * 2 * NEXT_NKINDS, s));
@@ -3822,47 +3945,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   any_active = true;
   e->last_visits++;
   for (int k = 1; k < NEXT_NKINDS; k++) e->last_listed += cnt[k];
-  e->resident_on = false;
-  int64_t nfill = -1;
-  if (e->sparse_fill && e->ntiles > 1 && (sweep > 0 || adaptive)) {
-    // which cells of the tile hold the waiting packets? Few of them (stragglers): fill those only; a packet that moves into
-    // another cell of the tile waits for the tile's next visit like one that leaves the tile
-    int64_t listed_now = 0;
-    for (int k = 1; k < NEXT_NKINDS; k++) listed_now += cnt[k];
-    if (listed_now <= e->sparse_max_listed) {
-      HIP_TRY(hipMemsetAsync(e->d_resident, 0, sizeof(uint32_t) * (size_t)((ncell_all + 31) / 32 + 1), s));
-      HIP_TRY(hipMemsetAsync(e->d_nfill, 0, sizeof(int32_t), s));
-      hipLaunchKernelGGL(k_mark_cells, dim3(nblocks(n)), dim3(BLOCK), 0, s, env, e->d_resident);
-      hipLaunchKernelGGL(k_compact_cells, dim3(nblocks(hi - lo)), dim3(BLOCK), 0, s, lo, hi, e->d_resident, e->d_fill_cells, e->d_nfill);
-      int32_t nf = 0;
-      HIP_TRY(hipMemcpyAsync(&nf, e->d_nfill, sizeof(nf), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      if (nf > 0 && nf * 2 < hi - lo) {
-        nfill = nf;
-        e->tile_valid_lo = -1;
-      }
-    }
-  }
-  if (e->tile_valid_lo != lo) {
-    HIP_TRY(hipEventRecord(e->ev2, s));
-    rc = populate_tile(e, lo, hi, s, nfill);
-    e->resident_on = (nfill >= 0);
-    if (nfill >= 0) {
-      e->last_sparse_fills++;
-      e->last_cells_filled += nfill;
-    } else {
-      e->last_cells_filled += hi - lo;
-    }
-    if (rc != ARTIS_OK) return rc;
-    HIP_TRY(hipEventRecord(e->ev3, s));
-    HIP_TRY(hipEventSynchronize(e->ev3));
-    float fms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&fms, e->ev2, e->ev3));
-    e->last_fill_ms += fms;
-    e->last_tile_fills++;
-    env = make_env(e);
-  }
-  if (e->trace) fprintf(stderr, "[artis_amd] sweep %d tile %d of %d: cells [%d, %d)\n", sweep, tile, e->ntiles, lo, hi);
+  if (e->trace) fprintf(stderr, "[artis_amd] sweep %d tile %d of %d\n", sweep, tile, e->ntiles);
 
   // one launch = the whole current list of one kind. Order: slow path, k-packets, macro-atoms, r-packets, so that a
   // k-packet -> macro-atom -> k-packet cycle costs two launches.
@@ -3948,7 +4031,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       const int32_t *lst = e->d_lists[kind][cur[kind]];
       if (kind == NEXT_RPKT || kind == NEXT_GAMMA || (kind == NEXT_MA && e->sort_ma)) {
         rc = sort_by_key(e, s, e->d_lists[kind][cur[kind]], e->d_keys[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? r_nubins : (kind == NEXT_MA ? e->ma_bins : 1),
-                         hi - lo, kind == NEXT_MA ? (env.cellest_n_t > 0 ? INT32_MAX : e->sort_maxpc_t)
+                         e->tile_cells, kind == NEXT_MA ? (env.cellest_n_t > 0 ? INT32_MAX : e->sort_maxpc_t)
                                                   : (env.cellest_n_r > 0 ? INT32_MAX : e->sort_maxpc_r),
                          (kind == NEXT_RPKT && r_nubins > 1 && e->sort_numajor) ? r_ngroups * r_nubins : 0);
         if (rc != ARTIS_OK) return rc;
@@ -4011,7 +4094,6 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     }
   }
   }  // tiles
-  e->resident_on = false;
   if (any_active) e->last_sweeps++;
   if (e->ntiles == 1 || !any_active || all_done) break;
   }  // sweeps
@@ -4307,14 +4389,17 @@ int artis_amd_debug_cellcache(artis_amd_engine *e, int c, double *levelpops, dou
   }
   HIP_TRY(hipSetDevice(e->device));
   const DevModel &h = e->Mh;
-  {  // the tile that holds cell c has to be resident and filled
-    const int lo = (int)((c / e->tile_cells) * e->tile_cells);
-    const int hi = (int)std::min<int64_t>(h.npts_nonempty, lo + e->tile_cells);
-    if (e->tile_valid_lo != lo) {
-      int rc = populate_tile(e, lo, hi, nullptr);
+  const int cell = c;
+  if (e->ntiles == 1) {  // the cache has to be filled
+    if (e->tile_valid_lo != 0) {
+      int rc = populate_tile(e, nullptr);
       if (rc != ARTIS_OK) return rc;
     }
-    c -= lo;  // row within the resident tile
+  } else {  // the cell has to be resident
+    int64_t nfilled = 0;
+    int rc = make_resident(e, std::vector<int32_t>{(int32_t)c}, nullptr, &nfilled);
+    if (rc != ARTIS_OK) return rc;
+    c = e->h_krow[(size_t)c];  // its row
   }
 #define DL(dst, f, T, per)                                                                                            \
   if (dst && (per) > 0) HIP_TRY(hipMemcpy(dst, e->K.f + (int64_t)c * (per), sizeof(T) * (size_t)(per), hipMemcpyDeviceToHost));
@@ -4330,7 +4415,7 @@ int artis_amd_debug_cellcache(artis_amd_engine *e, int c, double *levelpops, dou
     HIP_TRY(hipMalloc((void **)&d_bad, sizeof(int32_t)));
     HIP_TRY(hipMemset(d_bad, 0, sizeof(int32_t)));
     const Env env = make_env(e);
-    hipLaunchKernelGGL(k_debug_macache, dim3(nblocks(h.nlevels)), dim3(BLOCK), 0, nullptr, env, c + e->tile_lo, d_rates, d_trans, d_bad);
+    hipLaunchKernelGGL(k_debug_macache, dim3(nblocks(h.nlevels)), dim3(BLOCK), 0, nullptr, env, cell, d_rates, d_trans, d_bad);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     int32_t bad = 0;

@@ -153,16 +153,15 @@ struct Env {
   int32_t *gamma_gi;
   int32_t *gamma_n;
   int32_t *errflag;    // set non-zero when an assert_always of the reference would fire
-  // Cell-cache tile: the non-empty cells [tile_lo, tile_hi) are the ones whose cache rows are resident (the DevCache
-  // pointers are biased so that they are indexed by the absolute cell number). A packet that needs the cache of another
-  // cell waits for that cell's tile (classify()). One tile = all cells unless the cache would not fit in HBM.
+  // Cell-cache rows. Every cell's row is resident (the usual case): krow_tab == nullptr, the row of non-empty cell c is c. A cache that does not
+  // fit in HBM has rows for a SET of cells at a time (a "tile"): krow_tab[c] is the row that holds cell c's cache, or -1 -- a packet that needs the
+  // cache of such a cell waits until the host has made the cell resident (classify()). Every access of a cache array goes through krow().
+  const int32_t *krow_tab;
+  int32_t tile_all;  // every cell is resident: in_tile() needs no look-up
+  // A FILL works on the cells fill_cells[0..nfill) (a tiled cache: the cells that became resident), or -- fill_cells == nullptr -- on the
+  // cells [tile_lo, tile_hi) (the whole cache at once, or a batch of it).
   int32_t tile_lo, tile_hi;
-  int32_t tile_all;  // the tile covers every cell (the usual case): in_tile() needs no look-up
-  // SPARSE fill of a tile (the later sweeps of a tiled run): only the cells fill_cells[0..nfill) were populated; resident has
-  // a bit per non-empty cell of the model for them, and a packet that enters another cell of the tile waits like one that
-  // leaves the tile. Both null: every cell of the tile is populated.
   const int32_t *fill_cells;
-  const uint32_t *resident;
   int32_t nfill;
   // scratch of the cell-cache population: [cell of the fill][M.nupcum] the collisional-excitation cooling terms of the levels'
   // upward transitions (k_matrans), turned into the ions' running sums in place (k_cooling_chain) and into the records' cooling
@@ -211,13 +210,14 @@ struct Env {
   uint32_t *visit_counts;
 #endif
 };
+// the row of the cell cache that holds non-empty cell c (which has to be resident: in_tile())
+AHD int64_t krow(const Env &env, int c) { return env.krow_tab != nullptr ? (int64_t)env.krow_tab[c] : (int64_t)c; }
 // the packet's cell is empty (no cache needed) or its cache row is resident
 AHD bool in_tile(const Env &env, int cellindex) {
   if (env.tile_all) return true;
   const int c = env.M.propcell_nonemptymgi[cellindex];
   if (c < 0) return true;
-  if (c < env.tile_lo || c >= env.tile_hi) return false;
-  return env.resident == nullptr || ((env.resident[c >> 5] >> (c & 31)) & 1u) != 0;
+  return env.krow_tab[c] >= 0;
 }
 
 // Hot packet state, kept in registers.
@@ -989,7 +989,7 @@ AHD double col_exc(const DevModel &M, float T_e, float cnne, double epsilon_tran
 AHD void populate_levelpop(const Env &env, int c, int ul) {
   const DevModel &M = env.M;
   if (env.C.levelpops) {  // the host's NLTE / LTE solution (get_levelpop ltepop.cc:169)
-    env.K.levelpops[((int64_t)c * M.nlevels) + ul] = env.C.levelpops[((int64_t)c * M.nlevels) + ul];
+    env.K.levelpops[(krow(env, c) * M.nlevels) + ul] = env.C.levelpops[((int64_t)c * M.nlevels) + ul];
     return;
   }
   const int ui = M.level_ion[ul];
@@ -1006,19 +1006,19 @@ AHD void populate_levelpop(const Env &env, int c, int ul) {
     nn = (nnground * statw(M, ul) / statw(M, start) * exp(-E_aboveground / KB / T_exc));
   }
   if (nn < ARTIS_OPT_MINPOP) nn = (env.C.elem_massfracs[((int64_t)c * M.nelements) + element] > 0) ? ARTIS_OPT_MINPOP : 0.;
-  env.K.levelpops[((int64_t)c * M.nlevels) + ul] = nn;
+  env.K.levelpops[(krow(env, c) * M.nlevels) + ul] = nn;
 }
 // one (cell, line): the level-population factor of get_tau_sobolev<true>() (rpkt.cc:75), evaluated once per timestep so
 // that the line walk reads one value per line instead of the line record and two level populations
 AHD void populate_line_dpop(const Env &env, int c, int li) {
   const DevModel &M = env.M;
-  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  const double *pops = env.K.levelpops + (krow(env, c) * M.nlevels);
   const LinePack lp = M.line_pack[li];
   const double n_l = pops[lp.lower];
   const double n_u = pops[lp.upper];
   const double B_ul = lp.B_ul;
   const double B_lu = lp.B_lu;
-  env.K.line_dpop[((int64_t)c * M.nlines) + li] = (B_lu * n_l) - (B_ul * n_u);
+  env.K.line_dpop[(krow(env, c) * M.nlines) + li] = (B_lu * n_l) - (B_ul * n_u);
 }
 // ... and the reader: the stored value, or -- when the engine keeps no line_dpop rows (atomic data too large for them: 8 bytes per line
 // and cell are then a quarter of the cell cache; artis_engine.hip engine_fill) -- the same expression from the line record and the two
@@ -1029,8 +1029,8 @@ struct LineDpop {
 };
 AHD LineDpop line_dpop_of(const Env &env, int c) {
   LineDpop r;
-  r.dpop = env.K.line_dpop ? env.K.line_dpop + ((int64_t)c * env.M.nlines) : nullptr;
-  r.pops = env.K.levelpops + ((int64_t)c * env.M.nlevels);
+  r.dpop = env.K.line_dpop ? env.K.line_dpop + (krow(env, c) * env.M.nlines) : nullptr;
+  r.pops = env.K.levelpops + (krow(env, c) * env.M.nlevels);
   return r;
 }
 AHD double line_dpop_at(const DevModel &M, const LineDpop &d, int li) {
@@ -1052,13 +1052,13 @@ AHD void populate_chi_ff(const Env &env, int c) {
     }
   }
   const float T_e = env.C.Te[c];
-  env.K.chi_ff_nnionpart[c] = s * 3.69255e8 / sqrt((double)T_e);
+  env.K.chi_ff_nnionpart[krow(env, c)] = s * 3.69255e8 / sqrt((double)T_e);
 }
 // one (cell, continuum): update_packets.cc:430-440 + the slow path of rpkt.cc:853-889. Returns the keep bit.
 AHD bool populate_allcont(const Env &env, int c, int i) {
   const DevModel &M = env.M;
-  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
-  const int64_t o = ((int64_t)c * M.nbfcontinua) + i;
+  const double *pops = env.K.levelpops + (krow(env, c) * M.nlevels);
+  const int64_t o = (krow(env, c) * M.nbfcontinua) + i;  // (cache row)
   const double nnlevel = pops[M.allcont_uniquelevelindex[i]];
   const int element = M.allcont_element[i];
   const int ion = M.allcont_ion[i];
@@ -1091,11 +1091,11 @@ AHD bool populate_allcont(const Env &env, int c, int i) {
 AHD void populate_keptlist(const Env &env, int c) {
   const DevModel &M = env.M;
   const int nw = M.nkeepwords;
-  const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * nw);
-  int32_t *list = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
-  int32_t *prefix = env.K.allcont_keepprefix + ((int64_t)c * nw);
-  const D2 *pair = env.K.allcont_pair + ((int64_t)c * M.nbfcontinua);
-  D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * M.nbfcontinua);
+  const uint64_t *keep = env.K.allcont_keepbits + (krow(env, c) * nw);
+  int32_t *list = env.K.allcont_keptlist + (krow(env, c) * M.nbfcontinua);
+  int32_t *prefix = env.K.allcont_keepprefix + (krow(env, c) * nw);
+  const D2 *pair = env.K.allcont_pair + (krow(env, c) * M.nbfcontinua);
+  D2 *keptpair = env.K.allcont_keptpair + (krow(env, c) * M.nbfcontinua);
   int at = 0;
   for (int j = 0; j < nw; j++) {
     prefix[j] = at;
@@ -1112,8 +1112,8 @@ AHD void populate_keptlist(const Env &env, int c) {
 // the places [r0, r1) of the continua [begin, end) in the cell's list of kept continua (begin < end)
 AHD void kept_range(const Env &env, int c, int begin, int end, int &r0, int &r1) {
   const int nw = env.M.nkeepwords;
-  const uint64_t *keep = env.K.allcont_keepbits + ((int64_t)c * nw);
-  const int32_t *prefix = env.K.allcont_keepprefix + ((int64_t)c * nw);
+  const uint64_t *keep = env.K.allcont_keepbits + (krow(env, c) * nw);
+  const int32_t *prefix = env.K.allcont_keepprefix + (krow(env, c) * nw);
   const int wfirst = begin / 64, wlast = (end - 1) / 64;
   r0 = prefix[wfirst] + __builtin_popcountll(keep[wfirst] & ~(~UINT64_C(0) << (unsigned)(begin % 64)));
   r1 = prefix[wlast] + __builtin_popcountll(keep[wlast] & (~UINT64_C(0) >> (unsigned)(63 - ((end - 1) % 64))));
@@ -1128,7 +1128,7 @@ AHD void populate_corrphotoion(const Env &env, int c, int ul, int t) {
   const DevModel &M = env.M;
   const double W = env.C.W[c];
   const double T_R = env.C.TR[c];
-  const int64_t o = ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t;
+  const int64_t o = (krow(env, c) * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t;  // (cache row; the host's arrays are indexed by cell)
 #if ARTIS_OPT_USE_LUT_PHOTOION
   double g = W * lerp_or_last(M, M.corrphotoioncoeffs, ul, t, (float)T_R);
   const int ig = M.level_closestgroundlevelcont[ul];
@@ -1137,7 +1137,7 @@ AHD void populate_corrphotoion(const Env &env, int c, int ul, int t) {
   // the estimator-based / integrated coefficient of get_corrphotoioncoeff() (ratecoeff.cc:840) comes from the host
   (void)W;
   (void)T_R;
-  const double g = env.C.corrphotoioncoeff[o];
+  const double g = env.C.corrphotoioncoeff[((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t];
 #endif
   env.K.corrphotoioncoeff[o] = g;
   const int ui = M.level_ion[ul];
@@ -1295,12 +1295,12 @@ AHD MaTransTerms matrans_terms(const Env &env, int c, int ati) {
       const int tul = M.ion_uniquelevelindexstart[M.level_ion[ul]] + M.alltrans_targetlevelindex[ati];
       const double e_trans = eps(M, tul) - eps(M, ul);
       const double Cc = col_exc(M, env.C.Te[c], clumpednne(env.C, c), e_trans, statw(M, tul), statw(M, ul), ati);
-      r.kterm = env.K.levelpops[((int64_t)c * M.nlevels) + ul] * Cc * e_trans;
+      r.kterm = env.K.levelpops[(krow(env, c) * M.nlevels) + ul] * Cc * e_trans;
     }
     return r;
   }
   const int start = M.ion_uniquelevelindexstart[M.level_ion[ul]];
-  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  const double *pops = env.K.levelpops + (krow(env, c) * M.nlevels);
   const float T_e = env.C.Te[c];
   const float cnne = clumpednne(env.C, c);
   const double e_cur = eps(M, ul);
@@ -1371,13 +1371,13 @@ template <bool COLD = true>
 AHD int ma_resolve(const Env &env, int c, int rec_off) {
   if (!COLD) return rec_off;
   if (__builtin_expect(rec_off >= 0, 1)) return rec_off;
-  const int32_t v = ma_rowtab_load(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-rec_off - 1));
+  const int32_t v = ma_rowtab_load(env.K.ma_rowtab + (krow(env, c) * env.M.ncold) + (-rec_off - 1));
   ma_rowtab_acquire(env, v);
   return v >= 0 ? -(v + 2) : MA_REC_NONE;
 }
 AHD U4 *ma_rec_of(const Env &env, int c, const LevelPack &lpk) {
-  if (lpk.rec_off >= 0) return env.K.macache + ((int64_t)c * env.M.nmacache) + lpk.rec_off;
-  const int32_t v = ma_rowtab_load(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-lpk.rec_off - 1));
+  if (lpk.rec_off >= 0) return env.K.macache + (krow(env, c) * env.M.nmacache) + lpk.rec_off;
+  const int32_t v = ma_rowtab_load(env.K.ma_rowtab + (krow(env, c) * env.M.ncold) + (-lpk.rec_off - 1));
   ma_rowtab_acquire(env, v);
   return env.K.ma_pool + ((int64_t)((v >= 0) ? v : -(v + 3)) * MAPOOL_UNIT);  // (ready, or being filled by the caller; never asked for a level without a record)
 }
@@ -1534,7 +1534,7 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   const int ion = ui - M.elem_uniqueionindexstart[element];
   const int start = M.ion_uniquelevelindexstart[ui];
   const int level = ul - start;
-  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
+  const double *pops = env.K.levelpops + (krow(env, c) * M.nlevels);
   const LevelPack lpk = M.level_pack[ul];
   double *rates = ma_rates_of(ma_rec_of(env, c, lpk), lpk.ndown, lpk.nup);
   const double t_mid = env.S.mid;
@@ -1556,7 +1556,7 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
     }
   } else if (ion > 0 && level <= M.ion_maxrecombininglevel[ui]) {
     const int ls = M.ion_uniquelevelindexstart[ui - 1];
-    const int64_t cb = (int64_t)c * M.nphixstargets_total;
+    const int64_t cb = krow(env, c) * M.nphixstargets_total;
     // the levels of the ion below that ionise into this one (find_phixstargetindex() >= 0), from the static list
     for (int r = M.level_recomb_start[ul]; r < M.level_recomb_start[ul + 1]; r++) {
       const int lower = M.recomb_lower[r];
@@ -1578,7 +1578,7 @@ AHD void populate_macroatom(const Env &env, int c, int ul) {
   double s_up_higher = 0.;
   if (ion < M.elem_nions[element] - 1 && level < M.ion_nlevels_ionising[ui]) {
     const int nt = M.level_nphixstargets[ul];
-    const int64_t o = ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
+    const int64_t o = (krow(env, c) * M.nphixstargets_total) + M.level_phixstargetstart[ul];
     for (int t = 0; t < nt; t++) {
       const double R = env.K.corrphotoioncoeff[o + t];
       const double Cc = env.K.bf_colion[o + t];  // col_ionization_ratecoeff of the pair (populate_corrphotoion)
@@ -1602,7 +1602,7 @@ AHD double cooling_ion_head(const Env &env, int c, int ui, int *k_out) {
   const DevModel &M = env.M;
   const int element = M.ion_element[ui];
   const int ion = ui - M.elem_uniqueionindexstart[element];
-  double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + M.ion_coolingoffset[ui];
+  double *contribs = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms) + M.ion_coolingoffset[ui];
   const float cnne = clumpednne(env.C, c);
   const float T_e = env.C.Te[c];
   double C_ion = 0.;
@@ -1625,7 +1625,7 @@ AHD double cooling_ion_head(const Env &env, int c, int ui, int *k_out) {
 // draw the filter cannot decide re-adds the terms (kpkt_collexc_exact)
 AHD double cooling_ion_collexc_chain(const Env &env, int c, int ui, double C_ion, int *k_inout, double *upterms) {
   const DevModel &M = env.M;
-  double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + M.ion_coolingoffset[ui];
+  double *contribs = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms) + M.ion_coolingoffset[ui];
   int k = *k_inout;
   const int start = M.ion_uniquelevelindexstart[ui];
   const int nlevels = M.ion_nlevels[ui];
@@ -1651,7 +1651,7 @@ AHD void populate_coolfilter_line(const Env &env, int c, int li, const double *u
   const DevModel &M = env.M;
   const CoolLineRef lr = M.coollines[li];
   if (lr.n <= 0) return;
-  const double *cool = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
+  const double *cool = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms);
   const double hi = cool[lr.cool_hi], lo = (lr.cool_lo >= 0) ? cool[lr.cool_lo] : 0.;
   const double span = hi - lo;
   bool ok = (span > 0.) && (span <= DBLMAX);
@@ -1663,7 +1663,7 @@ AHD void populate_coolfilter_line(const Env &env, int c, int li, const double *u
     for (int j = 0; j < 8; j++) q[j] = 0u;
   U4 f;
   for (int j = 0; j < 4; j++) f.w[j] = q[2 * j] | (q[2 * j + 1] << 16);
-  env.K.macache[((int64_t)c * M.nmacache) + lr.slot] = f;
+  env.K.macache[(krow(env, c) * M.nmacache) + lr.slot] = f;
 }
 // ... all lines of ONE level's cooling filter, the running sums re-added from the level's own terms starting at the list's value before
 // the level (cooling_ion_collexc_chain()'s additions in its order: the bits the chain left in the population's scratch). For a cold level's
@@ -1674,7 +1674,7 @@ AHD void populate_coolfilter_level_seq(const Env &env, int c, int ul) {
   const int hi_i = M.level_coolhi[ul];
   if (lpk.nup <= 0 || hi_i < 0) return;
   const int ui = M.level_ion[ul];
-  const double *cool = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
+  const double *cool = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms);
   const double hi = cool[hi_i], lo = (hi_i > M.ion_coolingoffset[ui]) ? cool[hi_i - 1] : 0.;
   const double span = hi - lo;
   U4 *rec = ma_rec_of(env, c, lpk);
@@ -1701,8 +1701,8 @@ AHD void cooling_ion_tail(const Env &env, int c, int ui, double C_ion, int k) {
   const DevModel &M = env.M;
   const int element = M.ion_element[ui];
   const int ion = ui - M.elem_uniqueionindexstart[element];
-  const double *pops = env.K.levelpops + ((int64_t)c * M.nlevels);
-  double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + M.ion_coolingoffset[ui];
+  const double *pops = env.K.levelpops + (krow(env, c) * M.nlevels);
+  double *contribs = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms) + M.ion_coolingoffset[ui];
   const float cnne = clumpednne(env.C, c);
   const float T_e = env.C.Te[c];
   const int nionising = M.ion_nlevels_ionising[ui];
@@ -1715,7 +1715,7 @@ AHD void cooling_ion_tail(const Env &env, int c, int ui, double C_ion, int k) {
       const double e_cur = eps(M, ul);
       const double nnlevel = pops[ul];
       const int nt = M.level_nphixstargets[ul];
-      const int64_t o = ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
+      const int64_t o = (krow(env, c) * M.nphixstargets_total) + M.level_phixstargetstart[ul];
       for (int t = 0; t < nt; t++) {
         const double e_trans = eps(M, ustart + phixs_upperlevel(M, ul, t)) - e_cur;
         const double Cc = nnlevel * env.K.bf_colion[o + t] * e_trans;  // col_ionization_ratecoeff: populate_corrphotoion
@@ -1751,14 +1751,14 @@ AHD void cooling_ion_tail(const Env &env, int c, int ui, double C_ion, int k) {
           pop = nnupperion * w / wsum;
         }
 #endif
-        const double Cc = env.K.bf_cooling[((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t] * pop * cnne;
+        const double Cc = env.K.bf_cooling[(krow(env, c) * M.nphixstargets_total) + M.level_phixstargetstart[ul] + t] * pop * cnne;
         C_ion += Cc;
         contribs[k++] = C_ion;
       }
     }
   }
   if (k != M.ion_ncoolingterms[ui]) fail(env, 20);
-  env.K.ion_cooling_C[((int64_t)c * M.nions) + ui] = C_ion;
+  env.K.ion_cooling_C[(krow(env, c) * M.nions) + ui] = C_ion;
 }
 AHD void populate_cooling_ion(const Env &env, int c, int ui, double *upterms) {
   int k = 0;
@@ -1770,8 +1770,8 @@ AHD void populate_cooling_ion(const Env &env, int c, int ui, double *upterms) {
 AHD void populate_cooling_prefix(const Env &env, int c) {
   double cum = 0.;
   for (int ui = 0; ui < env.M.nions; ui++) {
-    cum += env.K.ion_cooling_C[((int64_t)c * env.M.nions) + ui];
-    env.K.ion_cooling_contribs[((int64_t)c * env.M.nions) + ui] = cum;
+    cum += env.K.ion_cooling_C[(krow(env, c) * env.M.nions) + ui];
+    env.K.ion_cooling_contribs[(krow(env, c) * env.M.nions) + ui] = cum;
   }
 }
 
@@ -1788,13 +1788,13 @@ AHD uint16_t cool_guide_entry(const double *list, int n, int shift, int k) {
 // Entry e of a cell's row: the ions' guide first, then every ion's.
 AHD void populate_cool_guide(const Env &env, int c, int e) {
   const DevModel &M = env.M;
-  uint16_t *g = env.K.cool_guide + ((int64_t)c * M.nguide);
-  const double *list = env.K.ion_cooling_contribs + ((int64_t)c * M.nions);
+  uint16_t *g = env.K.cool_guide + (krow(env, c) * M.nguide);
+  const double *list = env.K.ion_cooling_contribs + (krow(env, c) * M.nions);
   int n = M.nions, shift = M.guide_ion_shift, k = e;
   if (e >= M.ion_guideoff[0]) {
     int ui = 0;
     while (ui + 1 < M.nions && M.ion_guideoff[ui + 1] <= e) ui++;
-    list = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + M.ion_coolingoffset[ui];
+    list = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms) + M.ion_coolingoffset[ui];
     n = M.ion_ncoolingterms[ui];
     shift = M.ion_guideshift[ui];
     k = e - M.ion_guideoff[ui];
@@ -1995,13 +1995,13 @@ AHD double chi_bf_gammacontr(const Env &env, int c, double nu, int64_t slot, dou
   }
 #endif
   int nvisited = 0;
-  const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
+  const double *departure = env.K.allcont_departure + (krow(env, c) * M.nbfcontinua);
   // the kept continua of the window: places [r0, r1) of the cell's list; their indices and {nnlevel, edgepart} pairs lie
   // next to each other there (rising index, so the sum runs in the reference's order)
   int r0 = 0, r1 = 0;
   if (cbegin < cend) kept_range(env, c, cbegin, cend, r0, r1);
-  const int32_t *keptlist = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
-  const D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * M.nbfcontinua);
+  const int32_t *keptlist = env.K.allcont_keptlist + (krow(env, c) * M.nbfcontinua);
+  const D2 *keptpair = env.K.allcont_keptpair + (krow(env, c) * M.nbfcontinua);
   // one continuum's term (rpkt.cc:770-798); true: SELECT has found its continuum
   auto add_term = [&](int i, const ContPack &cpk, const PhixsRead &xrk, double nnk, double epk) -> bool {
     nvisited++;
@@ -2183,13 +2183,13 @@ AHD double bf_sigma_contr_ep(const Env &env, int c, int i, double nu, float T_e,
   if (ep >= 0. && split_usable) {
     stim = ep * ex;
   } else {
-    stim = env.K.allcont_departure[((int64_t)c * M.nbfcontinua) + i] * exp(-HOVERKB * (nu - cp.nu_edge) / T_e);
+    stim = env.K.allcont_departure[(krow(env, c) * M.nbfcontinua) + i] * exp(-HOVERKB * (nu - cp.nu_edge) / T_e);
   }
   const double corr = dmax(0., 1 - stim);
   return sigma_bf * cp.probability * corr;
 }
 AHD double bf_sigma_contr(const Env &env, int c, int i, double nu, float T_e, double ex, bool split_usable) {
-  return bf_sigma_contr_ep(env, c, i, nu, T_e, ex, split_usable, env.K.allcont_pair[((int64_t)c * env.M.nbfcontinua) + i].y);
+  return bf_sigma_contr_ep(env, c, i, nu, T_e, ex, split_usable, env.K.allcont_pair[(krow(env, c) * env.M.nbfcontinua) + i].y);
 }
 // radfield::update_bfestimators radfield.cc:215. The reference keeps, per packet, the contribution sigma_contr of every
 // continuum of the window that calculate_chi_bf_gammacontr() walked at the frequency x.nu (Phixslist::gamma_contr), and
@@ -2242,11 +2242,11 @@ AHD void update_bfestimators(const Env &env, int c, double de, double nu_cmf, co
   const float T_e = env.C.Te[c];
   const double ex = exp(-HOVERKB * nu / T_e);
   const bool split_usable = (ex >= DBLMIN);
-  const D2 *pairs = env.K.allcont_pair + ((int64_t)c * M.nbfcontinua);
-  const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
+  const D2 *pairs = env.K.allcont_pair + (krow(env, c) * M.nbfcontinua);
+  const double *departure = env.K.allcont_departure + (krow(env, c) * M.nbfcontinua);
   // the same batched walk as chi_bf_gammacontr(): the reads of a few continua are in flight together
   KeepIter it;
-  it.keep = env.K.allcont_keepbits + ((int64_t)c * M.nkeepwords);
+  it.keep = env.K.allcont_keepbits + (krow(env, c) * M.nkeepwords);
   it.cbegin = begin_n;
   it.cend = end_n;
   it.word = begin_n / 64;
@@ -2298,7 +2298,7 @@ AHD void chi_rpkt_cont(const Env &env, double nu_cmf, Chi &x, int c, int64_t slo
   const float nne = env.C.nne[c];
   const float cnne = env.C.nne[c] * env.C.clumpfactor[c];
   const float T_e = env.C.Te[c];
-  x.chi_freefree_heat = env.K.chi_ff_nnionpart[c] / pow3(nu_cmf) * cnne * (1 - exp(-HOVERKB * nu_cmf / T_e));
+  x.chi_freefree_heat = env.K.chi_ff_nnionpart[krow(env, c)] / pow3(nu_cmf) * cnne * (1 - exp(-HOVERKB * nu_cmf / T_e));
   x.chi_escatter = SIGMA_T * nne;
   x.chi_boundfree = chi_bf_gammacontr<false>(env, c, nu_cmf, slot, 0., nullptr, &x);
   x.nonemptymgi = c;
@@ -2582,7 +2582,7 @@ AHD void populate_expopac_planck(const Env &env, int c) {
     const double nu_lower = expopac_bin_nu_lower(b);
     const double nu_upper = expopac_bin_nu_upper(b);
     const double nu_mid = (nu_upper + nu_lower) / 2.;
-    const double chi_ff = env.K.chi_ff_nnionpart[c] / pow3(nu_mid) * cnne * (1 - exp(-HOVERKB * nu_mid / T_e));  // rpkt.cc:697
+    const double chi_ff = env.K.chi_ff_nnionpart[krow(env, c)] / pow3(nu_mid) * cnne * (1 - exp(-HOVERKB * nu_mid / T_e));  // rpkt.cc:697
     const double bin_kappa_cont = chi_ff / rho;
     const double kappa_planck = (kappa[b] + bin_kappa_cont) * planck(nu_mid, T_e);
     const double delta_nu = nu_upper - nu_lower;
@@ -3143,11 +3143,11 @@ __device__ inline double chi_bf_gammacontr_wave(const Env &env, int c, double nu
 #else
   (void)keep;
 #endif
-  const double *departure = env.K.allcont_departure + ((int64_t)c * M.nbfcontinua);
+  const double *departure = env.K.allcont_departure + (krow(env, c) * M.nbfcontinua);
   int r0 = 0, r1 = 0;
   if (cbegin < cend) kept_range(env, c, cbegin, cend, r0, r1);
-  const int32_t *keptlist = env.K.allcont_keptlist + ((int64_t)c * M.nbfcontinua);
-  const D2 *keptpair = env.K.allcont_keptpair + ((int64_t)c * M.nbfcontinua);
+  const int32_t *keptlist = env.K.allcont_keptlist + (krow(env, c) * M.nbfcontinua);
+  const D2 *keptpair = env.K.allcont_keptpair + (krow(env, c) * M.nbfcontinua);
   for (int base = r0; base < r1; base += 64) {
     const int n = (r1 - base < 64) ? r1 - base : 64;
     double sigma_contr = 0., term = 0.;
@@ -3214,7 +3214,7 @@ __device__ inline void chi_rpkt_cont_wave(const Env &env, double nu_cmf, Chi &x,
     const float nne = env.C.nne[c];
     const float cnne = env.C.nne[c] * env.C.clumpfactor[c];
     const float T_e = env.C.Te[c];
-    x.chi_freefree_heat = env.K.chi_ff_nnionpart[c] / pow3(nu_cmf) * cnne * (1 - exp(-HOVERKB * nu_cmf / T_e));
+    x.chi_freefree_heat = env.K.chi_ff_nnionpart[krow(env, c)] / pow3(nu_cmf) * cnne * (1 - exp(-HOVERKB * nu_cmf / T_e));
     x.chi_escatter = SIGMA_T * nne;
     x.chi_boundfree = chi_bf;
     x.nonemptymgi = c;
@@ -3504,7 +3504,7 @@ AHD bool vray_step(const Env &env, VRay &y) {
       if (!((c == x.nonemptymgi) && (fabs((x.nu / nu_cmf) - 1.0) < 1e-4))) {
         const float cnne = env.C.nne[c] * env.C.clumpfactor[c];
         const float T_e = env.C.Te[c];
-        x.chi_freefree_heat = env.K.chi_ff_nnionpart[c] / pow3(nu_cmf) * cnne * (1 - exp(-HOVERKB * nu_cmf / T_e));
+        x.chi_freefree_heat = env.K.chi_ff_nnionpart[krow(env, c)] / pow3(nu_cmf) * cnne * (1 - exp(-HOVERKB * nu_cmf / T_e));
         x.chi_escatter = SIGMA_T * env.C.nne[c];
         int dummy = -1;
         x.chi_boundfree = chi_bf_gammacontr<true>(env, c, nu_cmf, 0, DBLMAX, &dummy);
@@ -3697,7 +3697,7 @@ AHD MACtx ma_ctx(const Env &env, const Pkt &p) {
   MACtx k;
   k.c = env.M.propcell_nonemptymgi[p.cellindex];
   k.thick = (k.c >= 0) && (env.C.thick[k.c] == ARTIS_CELL_THICK);
-  k.cellma = env.K.macache + ((int64_t)k.c * env.M.nmacache);
+  k.cellma = env.K.macache + (krow(env, k.c) * env.M.nmacache);
   k.start_key = -1;
   k.start = 0;
   k.rec = 0;
@@ -4215,13 +4215,13 @@ AHD bool ma_record_absent(const Env &env, const Pkt &p) {
   if (M.ncold == 0 || p.ma_level < 0) return false;
   const LevelPack lpk = M.level_pack[M.ion_uniquelevelindexstart[uion(M, p.ma_element, p.ma_ion)] + p.ma_level];
   if (lpk.rec_off >= 0) return false;
-  return ma_rowtab_load(env.K.ma_rowtab + ((int64_t)M.propcell_nonemptymgi[p.cellindex] * M.ncold) + (-lpk.rec_off - 1)) == -1;
+  return ma_rowtab_load(env.K.ma_rowtab + (krow(env, M.propcell_nonemptymgi[p.cellindex]) * M.ncold) + (-lpk.rec_off - 1)) == -1;
 }
 AHD bool ma_ensure_record(const Env &env, int c, int ul, bool *failed, bool *full = nullptr) {
   const DevModel &M = env.M;
   const LevelPack lpk = M.level_pack[ul];
   if (lpk.rec_off >= 0) return true;
-  int32_t *tab = env.K.ma_rowtab + ((int64_t)c * M.ncold) + (-lpk.rec_off - 1);
+  int32_t *tab = env.K.ma_rowtab + (krow(env, c) * M.ncold) + (-lpk.rec_off - 1);
   const uint32_t nunits = (uint32_t)((marec_slots(lpk.ndown, lpk.nup) + MAPOOL_UNIT - 1) / MAPOOL_UNIT);
   if (nunits > env.ma_pool_cap) {  // a pool that cannot hold this one record: ARTIS_AMD_MA_POOLFRAC (artis_engine.hip names the remedy)
     fail(env, 46);
@@ -4303,7 +4303,7 @@ __device__ inline bool ma_slow_fill_claim(const Env &env, Pkt &p, int *c_out, in
   const int ul = M.ion_uniquelevelindexstart[uion(M, p.ma_element, p.ma_ion)] + p.ma_level;
   const LevelPack lpk = M.level_pack[ul];
   if (lpk.rec_off >= 0) return false;
-  int32_t *tab = env.K.ma_rowtab + ((int64_t)c * M.ncold) + (-lpk.rec_off - 1);
+  int32_t *tab = env.K.ma_rowtab + (krow(env, c) * M.ncold) + (-lpk.rec_off - 1);
   if (ma_rowtab_load(tab) != -1) return false;
   if (atomicCAS(tab, -1, -2) != -1) return false;
   const uint32_t nunits = (uint32_t)((marec_slots(lpk.ndown, lpk.nup) + MAPOOL_UNIT - 1) / MAPOOL_UNIT);
@@ -4329,7 +4329,7 @@ __device__ inline bool ma_slow_fill_claim(const Env &env, Pkt &p, int *c_out, in
 }
 __device__ inline void ma_slow_fill_publish(const Env &env, int c, int ul, int32_t unit) {
   __threadfence();
-  __hip_atomic_store(env.K.ma_rowtab + ((int64_t)c * env.M.ncold) + (-env.M.level_pack[ul].rec_off - 1), unit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(env.K.ma_rowtab + (krow(env, c) * env.M.ncold) + (-env.M.level_pack[ul].rec_off - 1), unit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif
 
@@ -4430,7 +4430,7 @@ AHD void ma_slow_action(const Env &env, Pkt &p, int64_t pi, FbSel *sel = nullptr
     const double targetrate = rng_uniform(p) * rate_sel;
     double rate = 0.;
     const int nt = M.level_nphixstargets[ul];
-    const double *cpc = env.K.corrphotoioncoeff + ((int64_t)c * M.nphixstargets_total) + M.level_phixstargetstart[ul];
+    const double *cpc = env.K.corrphotoioncoeff + (krow(env, c) * M.nphixstargets_total) + M.level_phixstargetstart[ul];
     int newlevel = -1;
     for (int t = 0; t < nt; t++) {
       const double e_trans = phixs_threshold(M, element, ion, level, t);
@@ -4747,7 +4747,7 @@ AHD void kpkt_slow_collexc(const Env &env, Pkt &p) {
   const int ui = uion(M, element, ion);
   const int ionstart = M.ion_coolingoffset[ui];
   const int nterms = M.ion_ncoolingterms[ui];
-  const double *contribs = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms) + ionstart;
+  const double *contribs = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms) + ionstart;
   const double rnd_process = rng_u24_value(u) * contribs[nterms - 1];
   const int ionoffset = upper_bound_d(contribs, nterms, rnd_process);
   const int ul = M.ion_uniquelevelindexstart[ui] + M.coolinglist_level[ionstart + ionoffset];
@@ -4774,8 +4774,8 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   ARTIS_STAT(env, ARTIS_STAT_INTERACTIONS);
   PROF_BEGIN();
   const int c = M.propcell_nonemptymgi[p.cellindex];
-  const double *ioncontribs = env.K.ion_cooling_contribs + ((int64_t)c * M.nions);
-  const uint16_t *guide = env.K.cool_guide + ((int64_t)c * M.nguide);  // (tables.h "COOLING GUIDES"; nguide == 0: none)
+  const double *ioncontribs = env.K.ion_cooling_contribs + (krow(env, c) * M.nions);
+  const uint16_t *guide = env.K.cool_guide + (krow(env, c) * M.nguide);  // (tables.h "COOLING GUIDES"; nguide == 0: none)
   const uint32_t u_ion = rng_u24(p);
   const double rndcool_ion = rng_u24_value(u_ion) * ioncontribs[M.nions - 1];  // (= rng_uniform(p) * ...)
   const int ui = (M.nguide > 0) ? guided_upper_bound(ioncontribs, M.nions, rndcool_ion, guide, M.guide_ion_shift, u_ion)
@@ -4790,7 +4790,7 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
   const int ion = ui - M.elem_uniqueionindexstart[element];
   const int ionstart = M.ion_coolingoffset[ui];
   const int nterms = M.ion_ncoolingterms[ui];
-  const double *cellcontrib = env.K.cooling_contrib + ((int64_t)c * M.ncoolingterms);
+  const double *cellcontrib = env.K.cooling_contrib + (krow(env, c) * M.ncoolingterms);
   const double *contribs = cellcontrib + ionstart;
   const uint32_t u_process = rng_u24(p);
   const double rnd_process = rng_u24_value(u_process) * contribs[nterms - 1];
@@ -4835,7 +4835,7 @@ AHD void do_kpkt(const Env &env, Pkt &p, int64_t pi) {
     if (nsearch > 0) {
       // (a cold level without a record in this cell: decided on the re-added sums like a draw the filter cannot decide)
       const int rslot = ma_resolve(env, c, lpk.rec_off);
-      const U4 *rec = (rslot >= 0) ? env.K.macache + ((int64_t)c * M.nmacache) + rslot : env.K.ma_pool + ((int64_t)(rslot < -1 ? -(rslot + 2) : 0) * MAPOOL_UNIT);
+      const U4 *rec = (rslot >= 0) ? env.K.macache + (krow(env, c) * M.nmacache) + rslot : env.K.ma_pool + ((int64_t)(rslot < -1 ? -(rslot + 2) : 0) * MAPOOL_UNIT);
       const double y = ((rnd_process - lo) / (hi - lo)) * MAFILT_SCALE;
       bool amb = env.ma_filters_off != 0 || rslot == MA_REC_NONE || !(y >= 0. && y < MAFILT_SCALE);
       const int yi = amb ? 0 : (int)y;

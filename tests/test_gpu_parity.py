@@ -421,6 +421,57 @@ def test_sparse_fills_do_not_cost_sweeps_and_vpkt_refuses_tiles(engine_mod, monk
     monkeypatch.delenv("ARTIS_AMD_CACHE_BUDGET_MB", raising=False)
 
 
+def test_tiles_as_sets_of_cells_give_identical_packets(engine_mod, monkeypatch):
+    """Round 6: a cache that does not fit has rows for a SET of cells at a time, addressed through a table (physics.h Env::krow_tab): a cell that is
+    resident and still wanted keeps its row, a fill of the new cells leaves the pool of on-demand records alone, and the engine picks the record tiers
+    that need the fewest tiles. Packet histories depend on none of it: every variant gives the untiled engine's packets and counters bit for bit --
+    the engine's own choice of tiers under the forced budget, a small pool (used up and emptied during the run), sets made of blocks of cells,
+    the fixed ranges of rounds 2-5, a pool emptied with every fill."""
+    model, cs, ts, aux = synth.build("small", ncoord=10)
+    pk0 = synth.make_packets(model, aux, 40000, kpkt_fraction=0.2, pellet_fraction=0.1)
+    n = model["npts_nonempty"]
+    names = ("ARTIS_AMD_CACHE_BUDGET_MB", "ARTIS_AMD_MA_HOTFRAC", "ARTIS_AMD_MA_POOLFRAC", "ARTIS_AMD_TILE_BLOCK", "ARTIS_AMD_TILE_ADAPT",
+             "ARTIS_AMD_POOL_KEEP")
+
+    def run(env):
+        for k in names:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = engine_mod.Engine(model)
+        tiles, tiers = eng.cache_tiles(), eng.record_tiers()
+        eng.set_cellstate(cs, ts)
+        p, e = pk0.copy(), abi.estimators_for(model, "classic")
+        eng.update_packets(p, e)
+        lt = eng.last_tiling()
+        eng.close()
+        return p, e, tiles, tiers, lt
+
+    p1, e1, t1, r1, _ = run({})
+    assert t1[0] == 1 and r1["ncold"] == 0
+    budget = str(t1[2] * (n // 3 + 1) / 1048576.0 + 0.01)  # a third of the cells' static rows
+    skip = abi.STAT_NAMES.index("UPDATECELL")
+    mask = np.arange(abi.NSTATS) != skip
+    seen = {}
+    for label, env in (("own tiers", {}), ("small pool", {"ARTIS_AMD_MA_HOTFRAC": "0.3", "ARTIS_AMD_MA_POOLFRAC": "0.1"}),
+                       ("blocks of cells", {"ARTIS_AMD_MA_HOTFRAC": "1", "ARTIS_AMD_TILE_BLOCK": "16"}),
+                       ("fixed ranges", {"ARTIS_AMD_MA_HOTFRAC": "1", "ARTIS_AMD_TILE_ADAPT": "0"}),
+                       ("pool emptied per fill", {"ARTIS_AMD_MA_HOTFRAC": "0.3", "ARTIS_AMD_MA_POOLFRAC": "0.1", "ARTIS_AMD_POOL_KEEP": "0"})):
+        p, e, tiles, tiers, lt = run({"ARTIS_AMD_CACHE_BUDGET_MB": budget, **env})
+        seen[label] = (tiles, tiers, lt)
+        assert tiles[0] > 1, (label, tiles)
+        parity.compare_packets(p, p1, 0.0, f"{label} vs untiled")
+        assert np.array_equal(e.stats[mask], e1.stats[mask]), label
+        parity.compare_estimators(e, e1, EST_RTOL, f"{label} vs untiled")
+    for k in names:
+        monkeypatch.delenv(k, raising=False)
+    # the engine's own choice: smaller rows, fewer tiles than static rows need under the same budget
+    assert seen["own tiers"][1]["ncold"] > 0 and seen["own tiers"][0][0] < seen["fixed ranges"][0][0], seen
+    # rows are kept: the adaptive run with static rows fills fewer cells than its fills x the rows there are
+    lt = seen["blocks of cells"][2]
+    assert lt["cells_filled"] < lt["tile_fills"] * seen["blocks of cells"][0][1], seen["blocks of cells"]
+
+
 def test_parked_visit_tails_give_identical_packets(engine_mod, monkeypatch):
     """Round 4: in a tiled run the last packets of a visit that began larger wait in the tile for its next visit (they run with the
     packets that return to it) instead of getting a long launch of their own. Packet histories do not depend on it."""
