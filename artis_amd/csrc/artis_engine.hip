@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,8 +42,8 @@ thread_local std::string g_last_error;
 constexpr int BLOCK = 256;
 
 // ------------------------------------------------------------------ populate kernels
-// The cells a fill works on: every cell of the resident tile, or -- a SPARSE fill (Env::fill_cells) -- the listed ones only
-// (the cells of the tile in which packets wait: the later sweeps of a tiled run bring a tile a few stragglers at a time).
+// The cells a fill works on: every cell (the whole cache at once, or a batch of it), or -- a tiled cache (Env::fill_cells) -- the listed ones: the cells
+// make_resident() gave rows to.
 __device__ inline int64_t fill_count(const Env &env) { return env.fill_cells ? env.nfill : (env.tile_hi - env.tile_lo); }
 __device__ inline int fill_cell(const Env &env, int64_t k) { return env.fill_cells ? env.fill_cells[k] : env.tile_lo + (int)k; }
 #ifndef ARTIS_MA_WAVE_FILL
@@ -1094,6 +1095,15 @@ inline int sort_lds_grid(int64_t n) {
 #define ARTIS_THERMAL_WAVES 4
 #endif
 constexpr int MAX_CHUNKS = 8192;  // >= 256 CUs x 4 waves/SIMD x 4 SIMDs, a multiple of 8
+// before a launch of the kernel of one kind: its own list's counter, the alternate counter and the chunk cursors start at zero
+__global__ void __launch_bounds__(BLOCK) k_launch_reset(int32_t *count, int kind, int32_t *cursors) {
+  for (int i = threadIdx.x; i < MAX_CHUNKS + 1; i += BLOCK) cursors[i] = 0;
+  if (threadIdx.x == 0) {
+    count[kind] = 0;
+    count[NEXT_NKINDS] = 0;
+  }
+}
+
 
 struct Puller {
   int chunk;           // current chunk
@@ -2374,7 +2384,8 @@ struct artis_amd_engine {
   int64_t est_ndoubles = 0;
   int64_t nvspec = 0, nvgrid = 0;  // doubles of the virtual-packet spectra / velocity-grid map at the end of the block
   unsigned long long *d_stats = nullptr;
-  int32_t *d_err = nullptr;
+  int32_t *d_err = nullptr;      // (the slot after the list counters: one copy brings both to the host)
+  int32_t *h_counts = nullptr;   // pinned: the host's copy of the list counters and the error flag after every launch
   // packets
   int64_t npackets = -1;           // -1: no resident population
   void *d_pkt = nullptr;           // the three record arrays of the resident population (tables.h PktStore)
@@ -3094,9 +3105,10 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
 #endif
   HIP_TRY(hipMalloc((void **)&e->d_stats, sizeof(unsigned long long) * ARTIS_NSTATS));
   HIP_TRY(hipMemset(e->d_stats, 0, sizeof(unsigned long long) * ARTIS_NSTATS));
-  HIP_TRY(hipMalloc((void **)&e->d_err, sizeof(int32_t)));
-  HIP_TRY(hipMemset(e->d_err, 0, sizeof(int32_t)));
-  HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * 2 * NEXT_NKINDS));
+  HIP_TRY(hipMalloc((void **)&e->d_count, sizeof(int32_t) * (2 * NEXT_NKINDS + 1)));
+  HIP_TRY(hipMemset(e->d_count, 0, sizeof(int32_t) * (2 * NEXT_NKINDS + 1)));
+  e->d_err = e->d_count + (2 * NEXT_NKINDS);
+  HIP_TRY(hipHostMalloc((void **)&e->h_counts, sizeof(int32_t) * (2 * NEXT_NKINDS + 1), hipHostMallocDefault));
   HIP_TRY(hipMalloc((void **)&e->d_cursors, sizeof(int32_t) * (MAX_CHUNKS + 1)));  // + the launch's "list used up" flag
   HIP_TRY(hipMalloc((void **)&e->d_fill_cells, sizeof(int32_t) * (size_t)(ncell_all > 0 ? ncell_all : 1)));
   if (e->ntiles > 1) {  // rows for a set of cells at a time: the table of rows, no cell resident yet
@@ -3203,7 +3215,8 @@ void artis_amd_engine_destroy(artis_amd_engine *e) {
   free_all(e->cell_allocs);
   free_all(e->cache_allocs);
   free_packet_buffers(e);
-  void *ptrs[] = {e->d_est, e->d_stats, e->d_err, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_krow, e->d_fill_cells, e->d_waiting,
+  if (e->h_counts) (void)hipHostFree(e->h_counts);
+  void *ptrs[] = {e->d_est, e->d_stats, e->d_aos, e->d_hist, e->d_tiles, e->d_count, e->d_cursors, e->d_krow, e->d_fill_cells, e->d_waiting,
                   e->d_bfrate_kept, e->d_collexc_terms, e->d_visit_counts};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -3764,10 +3777,20 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
     return L;
   };
   int32_t errflag = 0;
+  // (ARTIS_AMD_TRACE: where the host's time of the call goes -- waiting for the stream, submitting sorts, submitting launches)
+  using clk = std::chrono::steady_clock;
+  double wall_sync = 0., wall_sort = 0., wall_launch = 0.;
+  const clk::time_point wall_t0 = clk::now();
+  auto since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
   auto read_counts = [&]() -> int {
-    HIP_TRY(hipMemcpyAsync(cnt, e->d_count, sizeof(int32_t) * 2 * NEXT_NKINDS, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&errflag, e->d_err, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    // (one copy into pinned memory: counters and error flag are neighbours. Two copies into the stack -- pageable, staged by the runtime -- were a
+    // measurable share of the ~90 ms a headline step spends outside its kernels)
+    const clk::time_point t_sync = clk::now();
+    HIP_TRY(hipMemcpyAsync(e->h_counts, e->d_count, sizeof(int32_t) * (2 * NEXT_NKINDS + 1), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    wall_sync += since(t_sync);
+    std::memcpy(cnt, e->h_counts, sizeof(int32_t) * 2 * NEXT_NKINDS);
+    errflag = e->h_counts[2 * NEXT_NKINDS];
     HIP_TRY(hipGetLastError());
     if (errflag != 0) {
       g_last_error = "a kernel raised error flag " + std::to_string(errflag) + " (an assert_always of the reference would have fired)";
@@ -4029,6 +4052,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       if (nk <= 0) continue;
       const Lists next = lists_for(kind);
       const int32_t *lst = e->d_lists[kind][cur[kind]];
+      const clk::time_point t_sort = clk::now();
       if (kind == NEXT_RPKT || kind == NEXT_GAMMA || (kind == NEXT_MA && e->sort_ma)) {
         rc = sort_by_key(e, s, e->d_lists[kind][cur[kind]], e->d_keys[kind][cur[kind]], nk, &lst, kind == NEXT_RPKT ? r_nubins : (kind == NEXT_MA ? e->ma_bins : 1),
                          e->tile_cells, kind == NEXT_MA ? (env.cellest_n_t > 0 ? INT32_MAX : e->sort_maxpc_t)
@@ -4036,14 +4060,14 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
                          (kind == NEXT_RPKT && r_nubins > 1 && e->sort_numajor) ? r_ngroups * r_nubins : 0);
         if (rc != ARTIS_OK) return rc;
       }
+      wall_sort += since(t_sort);
+      const clk::time_point t_launch = clk::now();
       if (kind == NEXT_SLOW) {
         rc = reset_pool_if_due(env);
         if (rc != ARTIS_OK) return rc;
       }
       // the kernel starts with an empty current list of its own kind: everything it keeps goes to the alternate list
-      HIP_TRY(hipMemsetAsync(e->d_count + kind, 0, sizeof(int32_t), s));
-      HIP_TRY(hipMemsetAsync(e->d_count + NEXT_NKINDS, 0, sizeof(int32_t), s));
-      HIP_TRY(hipMemsetAsync(e->d_cursors, 0, sizeof(int32_t) * (MAX_CHUNKS + 1), s));
+      hipLaunchKernelGGL(k_launch_reset, dim3(1), dim3(BLOCK), 0, s, e->d_count, kind, e->d_cursors);  // (one command instead of three memsets)
       HIP_TRY(hipEventRecord(e->ev0, s));
       if (kind == NEXT_RPKT) {
         rc = launch_rpkt(s, lst, nk, next, e->d_cursors);
@@ -4071,6 +4095,7 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
       }
 #endif
       HIP_TRY(hipEventRecord(e->ev1, s));
+      wall_launch += since(t_launch);
       rc = read_counts();
       if (rc != ARTIS_OK) return rc;
       float ms = 0.f;
@@ -4099,6 +4124,9 @@ int artis_amd_update_packets_device(artis_amd_engine *e, void *hip_stream) {
   }  // sweeps
   for (int k = 1; k < NEXT_NKINDS; k++) e->last_propagate_ms += e->kms[k];
   e->last_propagate_ms += e->kms_tail;
+  if (e->trace)
+    fprintf(stderr, "[artis_amd] host time of the call: %.1f ms = %.1f waiting for the stream + %.1f submitting sorts + %.1f submitting launches + the rest; kernels by their events %.1f ms\n",
+            since(wall_t0), wall_sync, wall_sort, wall_launch, e->last_propagate_ms);
 #if ARTIS_OPT_DETAILED_BF_ESTIMATORS_ON
   if (env.bfrate_kept != nullptr && env.bfev != nullptr)
     hipLaunchKernelGGL(k_bfrate_expand, dim3(nblocks((int64_t)e->Mh.npts_nonempty * 64)), dim3(BLOCK), 0, s, env);

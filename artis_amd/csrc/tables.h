@@ -297,11 +297,12 @@ struct DevCells {
   const float *elem_meanweight;  // [cell][nelements] mean atomic weights (USE_CALCULATED_MEANATOMICWEIGHT builds), else null
 };
 
+// (every array [row][...]: the row of a cell is the cell while the whole cache is resident, else Env::krow_tab[cell] -- physics.h krow())
 struct DevCache {
   double *levelpops;             // [cell][nlevels]
   U4 *macache;                   // [cell][nmacache]: one record of filters + process rates per level (above; LevelPack::rec_off)
   // [cell][ncold] where a cold level's record is in the pool (units of MAPOOL_UNIT slots): -1 none yet, <= -3 being filled at unit -(v + 3), >= 0 ready;
-  // the pool ([resident cells x ma_pool_slots] slots, shared by all of them: NOT biased by the tile's first cell) and the units handed out
+  // the pool ([resident cells x ma_pool_slots] slots, shared by all of them: not indexed by row) and the units handed out
   int32_t *ma_rowtab;
   U4 *ma_pool;
   uint32_t *ma_pool_used;
