@@ -348,13 +348,14 @@ def _check_emission_aberration(backend, n):
     assert abs(energy) < 4 * np.sqrt(beta2.mean() / 3 / m) + 2 * beta2.mean(), (energy, beta2.mean())
 
 
-def _te_medium(T=11000., rho=3e-14, ncoord=4, width_frac=5e-4, lut_nsub=6):
+def _te_medium(T=11000., rho=3e-14, ncoord=4, width_frac=5e-4, lut_nsub=6, nphixspoints=None, phixsnuincrement=0.1):
     """every cell in strict thermodynamic equilibrium (synth.make_grid_and_cells uniform_te). A SHORT timestep: only a packet's
     last absorption and emission are recorded, and with dt/t = 2e-3 a tenth of the re-emitted packets meet another line before
     the step ends -- which ones depends on the emitting line, a bias of several per cent per pair (measured: chi2 246 over 118
     pairs); with 5e-4 the pairs are clean (53 over 70 at 8e6 packets)"""
     p = synth.PRESETS["small"]
-    atomic = synth.make_atomic(seed=3, elements=p[0], nlevels_per_ion=p[1], line_fraction=0.6, nphixspoints=p[3], lut_nsub=lut_nsub)
+    atomic = synth.make_atomic(seed=3, elements=p[0], nlevels_per_ion=p[1], line_fraction=0.6, nphixspoints=nphixspoints or p[3],
+                               phixsnuincrement=phixsnuincrement, lut_nsub=lut_nsub)
     grid, cells, aux = synth.make_grid_and_cells(atomic, ncoord=ncoord, uniform_te=dict(T=T, rho=rho))
     md = {k: v for k, v in atomic.items() if not k.startswith("_")}
     md.update(grid)
@@ -432,14 +433,16 @@ def _check_hubble_flow_energy(backend, n):
     assert abs(after / before - 1.) > 0. or n < 10
 
 
-def _check_te_channel_balance(backend, n):
+def _check_te_channel_balance(backend, n, nphixspoints=None, phixsnuincrement=0.1, only_thermal_pool=False):
     """law 12: the event counters of a run in the equilibrium medium, thick enough for plenty of events of every kind (the counters see them
     all: a photon emitted just above the dominant ion's edge is absorbed again at once, and counted again on both sides)"""
-    model, cs, ts, aux, T = _te_medium(T=25000., rho=1e-11, width_frac=1e-4)
+    model, cs, ts, aux, T = _te_medium(T=25000., rho=1e-11, width_frac=1e-4, nphixspoints=nphixspoints, phixsnuincrement=phixsnuincrement)
     rng = np.random.default_rng(33)
     pk = _planck_packets(model, aux, n, T, rng)
     est = backend(model, cs, ts, pk)
     st = est.stats_dict()
+    if only_thermal_pool:
+        return st["K_STAT_FROM_BF"], st["K_STAT_TO_R_FB"]
     pending = int(np.count_nonzero(pk["type"] != abi.TYPE_RPKT))  # absorbed, not emitted yet when the step ended
     pairs = {
         "bound-bound": (st["MA_STAT_ACTIVATION_BB"], st["MA_STAT_DEACTIVATION_BB"] + st["K_STAT_TO_R_BB"]),
@@ -462,19 +465,24 @@ def _check_te_channel_balance(backend, n):
         sigma = np.sqrt(max(fwd + bwd, 1))
         z = (fwd - bwd) / sigma
         if name == "bound-free, thermal pool":
-            # FINDING (round 6, engine and host emulation alike, i.e. the algorithm as restated): bound-free absorption makes 5-7 % more k-packets
-            # than free-bound cooling removes (8e6 packets on the GPU: 39 445 against 36 789, 9.6 sigma; 1.6e6 on the CPU: 7 942 against 7 562),
+            # FINDING (round 6, engine and host emulation alike, i.e. the algorithm as restated): bound-free absorption makes 5-8 % more k-packets
+            # than free-bound cooling removes (8e6 packets on the GPU: 39 445 against 36 789, 9.6 sigma; 1.6e7 on the CPU: 78 948 against 72 960),
             # made up by ~1 % more recombination emissions than photoionisations in the macro-atom half -- the two halves together balance.
             # What it is NOT: the RATES -- the continuous expectation of the heating, integrated over the cell's own populations and cross-
             # sections, is 0.996 of the cooling list's free-bound total; not the tables' quadrature (the same with lut_nsub = 200) nor the nu^-3
-            # tail beyond the tables (same with tables ten times as long). What it IS, as far as it was followed: the medium does not stay
-            # stationary in its optically thick continua. The path-length estimators of the same run (bfheatingestimator x n_level against
-            # ffheatingestimator) see 15 % more radiation above the dominant ion's ground edge (optical depth ~1e3 per step: a photon there is
-            # absorbed and re-emitted hundreds of times) than the Planck field the packets were drawn from: a net flow of ~1.6 % of the free-free
-            # absorptions through the thermal pool and collisional excitation into recombination photons, which a band holding 0.3 % of the
-            # packets turns into a 15 % excess -- and more photons above the edges are more bound-free heating events. Which pair of rates is
-            # 1 % off its inverse in this medium (collisional excitation / de-excitation against the Sobolev-escape radiative rates is the
-            # candidate) was not found. The pair is therefore held to 12 % here, not to its noise.
+            # tail beyond the tables (same with tables ten times as long).
+            # What it IS (found at the round's end): the reference draws the frequency of a free-bound photon UNIFORMLY within each of the
+            # NPHIXSPOINTS pieces of the continuum (select_continuum_nu, ratecoeff.cc:563-637: the tail integrals at the pieces' boundaries,
+            # interpolated linearly in between), and a piece is 0.1 nu_edge wide -- across which the emissivity sigma nu^3 exp(-h nu / kT) of a
+            # thick edge (h nu_edge = 14 kT here) falls by a factor of four. The photon is therefore emitted too blue on average, and when it is
+            # absorbed again (at once: optical depth ~1e3) its thermal share 1 - nu_edge / nu is 15 % larger than the share of the thermal
+            # pool in the emission (0.072 against 0.062 for the two thickest continua, which carry 10 % of the free-bound cooling); the excess
+            # heat leaves through collisional excitation and ionisation and comes back as recombination photons of the macro-atom half, and the
+            # path-length estimators see 15 % more radiation above those edges than Planck's (the photons sit where the opacity is lower).
+            # The imbalance is quadratic in the pieces' width: NPHIXSNUINCREMENT 0.1 / 0.05 / 0.025 / 0.0125 with as many more points (the same
+            # tables, 1.6e7 packets each) give 1.082 / 1.033 / 1.020 / 1.021 +- 0.005 -- test_thermal_pool_imbalance_is_the_free_bound_sampling
+            # below holds that. A floor of ~2 % (3.7 sigma) and the macro-atom half's 0.7 % do not depend on the width and are not explained.
+            # The pair is therefore held to 12 % here, not to its noise.
             assert abs(fwd - bwd) <= 0.12 * max(fwd, bwd) + 4.5 * sigma, (name, fwd, bwd)
             continue
         worst = max(worst, abs(z))
@@ -515,6 +523,17 @@ def _check_gamma_deposition(backend, n):
 
 def test_detailed_balance_channel_by_channel_kernel_bodies():
     _check_te_channel_balance(_backend_emu, 400_000)
+
+
+def test_thermal_pool_imbalance_is_the_free_bound_sampling():
+    """the open finding of law 12, explained (see _check_te_channel_balance): with the photoionisation tables four times as fine (the same cross-
+    sections, the same range) the excess of bound-free heating events over free-bound cooling events falls from ~6 % to ~1.5 % (4e6 packets:
+    1.064 and 1.014, +- 0.011 each) -- it is the uniform draw within a piece of select_continuum_nu(), not the kernels and not the rates"""
+    coarse = _check_te_channel_balance(_backend_emu, 4_000_000, only_thermal_pool=True)
+    fine = _check_te_channel_balance(_backend_emu, 4_000_000, nphixspoints=157, phixsnuincrement=0.025, only_thermal_pool=True)
+    r_coarse, r_fine = coarse[0] / coarse[1], fine[0] / fine[1]
+    assert min(coarse + fine) > 10_000, (coarse, fine)
+    assert r_coarse > 1.035 and r_fine < 1.035 and r_coarse - r_fine > 0.025, (coarse, fine)
 
 
 def test_gamma_deposition_estimator_and_analog_kernel_bodies():
