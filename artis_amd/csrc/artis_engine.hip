@@ -3355,7 +3355,8 @@ int populate_tile(artis_amd_engine *e, hipStream_t s, int64_t nfill = -1) {
   // The pool of on-demand records: a fill of the whole cache empties it. A fill of some cells of a tiled cache leaves it alone -- the cells that stay
   // resident keep their cold levels' records; the rows that are filled start without any (k_ma_reset below), and the units the cells before them held
   // stay handed out until the pool is used up and emptied (reset_pool_if_due() of the propagation loop), which costs fills, never an answer.
-  // ARTIS_AMD_POOL_KEEP=0: emptied with every fill (round 5).
+  // ARTIS_AMD_POOL_KEEP=0: emptied with every fill (round 5). (Emptying it only with the fills that replace half of the rows or more -- when most of what
+  // it holds belongs to cells that leave -- was measured too: no better, 1520 against 1498 ms at a quarter of the cache; profiles/r06/tiling.md.)
   if (h.ncold > 0 && (nfill < 0 || !e->pool_keep)) {
     HIP_TRY(hipMemsetAsync(e->K.ma_pool_used, 0, sizeof(uint32_t), s));
     if (nfill >= 0) HIP_TRY(hipMemsetAsync(e->K.ma_rowtab, 0xFF, sizeof(int32_t) * (size_t)(e->tile_cells * (int64_t)h.ncold), s));
