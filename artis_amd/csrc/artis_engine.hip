@@ -2913,8 +2913,10 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
       // records paid its fills again and again, 3.7 s against 3.0 s; now a fill leaves the pool and the rows of the cells that stay alone.)
       // (round 6: in steps of 0.05 below one half -- with the round-5 steps 0.5 / 0.3 / 0.2 / 0.1 a record that grew by a quarter, the fine bytes, sent
       // the 4e5-line set from 0.2 to 0.1 and doubled its fills)
-      int64_t best_nt = tiles_needed();
-      double best_h = 1., cur_h = 1.;
+      // (the fewest tiles among the shares >= 0.2: a tile saved by going lower costs more in cold levels filled on demand than the tile did -- at 11600 MB
+      // two tiles at hot 0.10 take 1750 ms, three at 0.5 1620; a cache that fits ONE tile at a lower share takes that: one tile beats any tiling)
+      int64_t best_nt = tiles_needed(), tiled_nt = best_nt;
+      double best_h = 1., cur_h = 1., tiled_h = 1.;
       for (const double h : {0.9, 0.8, 0.7, 0.6, 0.5, 0.45, 0.4, 0.35, 0.3, 0.25, 0.2, 0.15, 0.1, 0.05}) {
         if (best_nt <= 1) break;
         e->Mh = make_host_model_view(*model, e->own, h, pool);
@@ -2924,7 +2926,12 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
           best_nt = nt;
           best_h = h;
         }
+        if (h > 0.199 && nt < tiled_nt) {
+          tiled_nt = nt;
+          tiled_h = h;
+        }
       }
+      if (best_nt > 1) best_h = tiled_h;
       if (cur_h != best_h) e->Mh = make_host_model_view(*model, e->own, best_h, pool);
       e->ma_hotfrac = best_h;
     }
