@@ -1217,6 +1217,7 @@ def test_full_size_properties_50cubed_1e7_packets(engine_mod, options, npk, t_da
         parts = ea.arrays()[k] + eb.arrays()[k]
         scale = max(np.abs(whole).max(), 1e-300)
         assert np.abs(parts - whole).max() / scale < 1e-9, k
+    bytes_per_cell = eng.cache_tiles()[2]
     eng.close()
     if keep is not None:
         # (4) round 6: a second, FRESH engine (its own allocations, list buffers, pool and launch history) gives the same packets field by field and
@@ -1234,3 +1235,22 @@ def test_full_size_properties_50cubed_1e7_packets(engine_mod, options, npk, t_da
             assert np.array_equal(p3[f], keep[f], equal_nan=True), f"fresh engine: {f}"
         esc3 = p3["type"] == abi.TYPE_ESCAPE
         assert np.all(p3["prop_time"][~esc3] == t_end)   # no packet ends before the timestep does there either
+        # (5) round 6: a third engine that may use a QUARTER of the memory the cell cache takes -- rows for a set of cells at a time, addressed through
+        # a table, the record tiers of its own choice, the pool of on-demand records kept across fills -- gives the same packets and counters again
+        del p3
+        os.environ["ARTIS_AMD_CACHE_BUDGET_MB"] = str(bytes_per_cell * (n // 4 + 1) / 1048576.0)
+        try:
+            eng3 = engine_mod.Engine(model, preset=options)
+            tiles3, tiers3 = eng3.cache_tiles(), eng3.record_tiers()
+            eng3.set_cellstate(cs, ts)
+            p4 = pk0.copy()
+            e4 = abi.estimators_for(model, options)
+            eng3.update_packets(p4, e4)
+            lt = eng3.last_tiling()
+            eng3.close()
+        finally:
+            del os.environ["ARTIS_AMD_CACHE_BUDGET_MB"]
+        assert tiles3[0] > 1 and tiers3["ncold"] > 0 and lt["tile_fills"] > 1, (tiles3, tiers3, lt)
+        assert np.array_equal(e4.stats[mask], e1.stats[mask])
+        for f in abi.PACKET_DTYPE.names:
+            assert np.array_equal(p4[f], keep[f], equal_nan=True), f"tiled engine: {f}"
