@@ -502,10 +502,12 @@ int artis_amd_set_cellstate(artis_amd_engine *eng, const artis_cellstate *cells,
 int artis_amd_populate_cellcache(artis_amd_engine *eng, void *hip_stream);
 
 /* Cell-cache tiling. The cache of every non-empty cell is resident when it fits the budget (60 % of the free HBM at
- * engine creation, or ARTIS_AMD_CACHE_BUDGET_MB); otherwise the cells are cut into `*ntiles` ranges of `*cells_per_tile`
- * and artis_amd_update_packets*() sweeps over them (fill a range, advance the packets that sit in it until they leave it
- * or are done, next range, ... until no packet is left): the reference's single-slot cell cache (update_packets.cc:397-460,
- * :551-621) with a tile instead of a cell. Packet histories do not depend on the tiling. */
+ * engine creation, or ARTIS_AMD_CACHE_BUDGET_MB); otherwise there are rows for `*cells_per_tile` cells at a time
+ * (`*ntiles` = how many such sets cover the model) and artis_amd_update_packets*() visits sets of cells (make the cells in
+ * which most packets wait resident -- cells that are resident already keep their rows --, advance the packets that sit in
+ * them until they leave the set or are done, next set, ... until no packet is left): the reference's single-slot cell cache
+ * (update_packets.cc:397-460, :551-621) with a set of cells instead of one cell. With a cache that does not fit the engine also
+ * chooses macro-atom record tiers that need few tiles (artis_amd_record_tiers). Packet histories do not depend on any of it. */
 int artis_amd_cache_tiles(artis_amd_engine *eng, int32_t *ntiles, int64_t *cells_per_tile, int64_t *bytes_per_cell);
 
 /* Host-buffer form of update_packets() (update_packets.cc:530): every packet
