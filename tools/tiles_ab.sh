@@ -1,11 +1,11 @@
 #!/bin/bash
 # tiled cell cache (by default a quarter of the headline's cache) under variants of the environment:
-#   tools/tiles_ab.sh [budget MB] ["VAR=val VAR2=val" ...]   -> gpurun_out/tiles_ab.txt
+#   tools/tiles_ab.sh [budget MB] ["VAR=val VAR2=val" ...]   -> gpurun_out/tiles_ab_<budget>.txt (e.g. 13000 ARTIS_AMD_TILE_PARK_AT=524288 "ARTIS_AMD_MA_HOTFRAC=0.5 ARTIS_AMD_POOL_KEEP=0")
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
 cd $R
 MB=${1:-13000}
 shift
-out=gpurun_out/tiles_ab.txt
+out=gpurun_out/tiles_ab_$MB.txt
 mkdir -p gpurun_out
 : > $out
 line() {
