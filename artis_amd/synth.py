@@ -68,7 +68,7 @@ OPTION_TABLES = {"classic": (100, 3500.0, 140000.0), "kilonova_lte": (200, 500.0
 
 
 def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fraction: float = 0.4,
-                nphixspoints: int = 40, phixsnuincrement: float = 0.1, two_target_fraction: float = 0.25,
+                nphixspoints: int = 40, phixsnuincrement: float = 0.1, lut_linear_sigma: bool = False, two_target_fraction: float = 0.25,
                 forbidden_fraction: float = 0.2, collstr_fraction: float = 0.1, options: str = "classic", lut_nsub: int = 6) -> dict:
     """Build the atomic part of struct artis_model. `elements` = list of (Z, lowest_ionstage, nions).
     lut_nsub: sub-intervals per cross-section table cell of the quadrature behind the rate-coefficient tables (6: 1e-3 accurate, what every
@@ -318,6 +318,9 @@ def make_atomic(seed: int = 1, elements=None, nlevels_per_ion: int = 12, line_fr
                     x = (k + 0.5) / nsub * inc * nu_thr  # nu - nu_edge
                     dx = inc * nu_thr / nsub
                     sig = xs[np.minimum((k // nsub), NP - 1)]
+                    if lut_linear_sigma:  # the cross-section between two table points as the opacity interpolates it (rpkt.cc: linear in nu)
+                        cell = np.minimum(k // nsub, NP - 2)
+                        sig = xs[cell] + (xs[cell + 1] - xs[cell]) * (((k % nsub) + 0.5) / nsub)
                     nu = nu_thr + x
                     ex = np.exp(-H * x[None, :] / (KB * Tgrid[:, None]))
                     saha = SAHACONST * g_low / g_up * Tgrid**-1.5
