@@ -1250,8 +1250,24 @@ __global__ void __launch_bounds__(TB, ARTIS_RPKT_WGS) k_rpkt(Env env, const int3
   __shared__ ContPack lds_cont[CONT_LDS ? CONT_LDS_MAX : 1];
   __shared__ double lds_line_nu[LINE_LDS ? LINE_LDS_MAX : 1];
   __shared__ double lds_cellest[3 * ((CONT_LDS || LINE_LDS) ? RPKT_CELLEST_CAP : RPKT_CELLEST_CAP_NOCONT)];
+  constexpr int NEC = LINE_LDS ? 1 : ESTCACHE_SLOTS;       // (the line list in LDS leaves no room for the caches)
+  __shared__ double lds_estcache[(TB / 64) * NEC * 3];   // per wave: the accumulators of ESTCACHE_SLOTS cells (physics.h Env::estcache) ...
+  __shared__ int32_t lds_esttag[(TB / 64) * NEC * 2];    // ... whose cells they are, and the claims of an eviction
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   cellest_begin(env, lds_cellest, env.cellest_n_r, TB, env.E.J, env.E.nuJ, env.E.ffheatingestimator);
+  env.estcache = nullptr;
+  if (!LINE_LDS && env.estcache_on && env.cellest_n_r == 0) {  // many cells: the wave's own cache instead of the workgroup's array
+    const int w = threadIdx.x >> 6;
+    env.estcache = lds_estcache + (w * NEC * 3);
+    env.estcache_tag = lds_esttag + (w * NEC * 2);
+    for (int l = threadIdx.x & 63; l < NEC; l += 64) {
+      env.estcache_tag[l] = -1;
+      env.estcache_tag[NEC + l] = -1;
+      env.estcache[(l * 3) + 0] = 0.;
+      env.estcache[(l * 3) + 1] = 0.;
+      env.estcache[(l * 3) + 2] = 0.;
+    }
+  }
   if (LINE_LDS) {
     for (int i = threadIdx.x; i < env.M.nlines; i += TB) lds_line_nu[i] = env.M.line_nu[i];
     env.M.line_nu = lds_line_nu;
@@ -1332,6 +1348,16 @@ __global__ void __launch_bounds__(TB, ARTIS_RPKT_WGS) k_rpkt(Env env, const int3
     append_by_kind(kind, out_pi, p.cellindex, p.nu_cmf, next, (p.ma_element * 5 + p.ma_ion));
   }
   __syncthreads();
+  if (env.estcache != nullptr) {  // the wave's accumulators go to the cells' records: a lane per slot
+    for (int l = threadIdx.x & 63; l < NEC; l += 64) {
+      const int cell = env.estcache_tag[l];
+      if (cell < 0) continue;
+      const double s0 = env.estcache[(l * 3) + 0], s1 = env.estcache[(l * 3) + 1], s2 = env.estcache[(l * 3) + 2];
+      if (s0 != 0.) unsafeAtomicAdd(&env.E.J[(int64_t)cell * env.est_stride], s0);
+      if (s1 != 0.) unsafeAtomicAdd(&env.E.nuJ[(int64_t)cell * env.est_stride], s1);
+      if (s2 != 0.) unsafeAtomicAdd(&env.E.ffheatingestimator[(int64_t)cell * env.est_stride], s2);
+    }
+  }
   cellest_flush(env, CELLEST_J, env.E.J, TB);
   cellest_flush(env, CELLEST_NUJ, env.E.nuJ, TB);
   cellest_flush(env, CELLEST_FFHEAT, env.E.ffheatingestimator, TB);
@@ -2496,6 +2522,7 @@ struct artis_amd_engine {
   int dense_lpr = 32;           // k_bfest_dense: lanes per record (64 = a wave per record; ARTIS_AMD_DENSE_LPR)
   bool dense_cont_lds = true;   // k_bfest_dense reads the continuum table from LDS (nltenebular step 1917 -> 1882 ms); ARTIS_AMD_DENSE_CONTLDS=0
   bool cellest_in_lds = true;  // ARTIS_AMD_CELLEST_LDS=0: every estimator add is a global atomic
+  bool estcache = true;        // ARTIS_AMD_ESTCACHE=0: k_rpkt without its waves' caches of per-cell accumulators (physics.h Env::estcache)
   int sort_maxpc_r = 20000;
   int sort_maxpc_t = 600;
   // one list chunk per wave instead of one per XCD (artis_engine.hip pull): measured on MI355X, 1e7 packets: k_rpkt -4 %
@@ -2568,6 +2595,7 @@ Env make_env(const artis_amd_engine *e) {
     env.cellest_n_r = (e->cellest_in_lds && nc <= (e->rpkt_est_over_cont ? RPKT_CELLEST_CAP_NOCONT : RPKT_CELLEST_CAP)) ? nc : 0;
     env.cellest_n_g = (e->cellest_in_lds && nc <= GAMMA_CELLEST_CAP) ? nc : 0;
     env.scalars_in_lds = e->cellest_in_lds ? 1 : 0;
+    env.estcache_on = e->estcache ? 1 : 0;
     env.ma_filters_off = e->ma_filters ? 0 : 1;
   }
   env.S = e->S;
@@ -3166,6 +3194,7 @@ int engine_fill(artis_amd_engine *e, const artis_model *model) {
   if (const char *b = std::getenv("ARTIS_AMD_MAFILTERS")) e->ma_filters = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_DENSE_LPR")) e->dense_lpr = (std::atoi(b) == 64) ? 64 : (std::atoi(b) == 16 ? 16 : 32);
   if (const char *b = std::getenv("ARTIS_AMD_CELLEST_LDS")) e->cellest_in_lds = std::atoi(b) != 0;
+  if (const char *b = std::getenv("ARTIS_AMD_ESTCACHE")) e->estcache = std::atoi(b) != 0;
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_R")) e->sort_maxpc_r = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_SORT_MAXPC_T")) e->sort_maxpc_t = std::max(1, std::atoi(b));
   if (const char *b = std::getenv("ARTIS_AMD_WAVECHUNKS_R")) e->wave_chunks_r = std::atoi(b) != 0;

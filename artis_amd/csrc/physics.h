@@ -121,6 +121,51 @@ AHD void cellest_add(const EnvT &env, double *global_array, int kind, int c, dou
   ARTIS_EST_ADD(&global_array[(int64_t)c * env.est_stride], v);
 }
 
+#ifndef ESTCACHE_SLOTS
+#define ESTCACHE_SLOTS 128  // cells per wave in its cache of accumulators (a power of two; 28 bytes of LDS each)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// the wave's cache of per-cell accumulators (Env::estcache): J += a, nuJ += b, ffheating += f of non-empty cell c
+template <typename EnvT>
+__device__ inline void est_cache_add(const EnvT &env, int c, double a, double b, double f) {
+  typedef __attribute__((address_space(3))) int32_t lds_i32;
+  typedef __attribute__((address_space(3))) double lds_f64;
+  volatile lds_i32 *tags = (volatile lds_i32 *)env.estcache_tag;  // [64] the slots' cells, [64] claims
+  volatile lds_i32 *claim = tags + ESTCACHE_SLOTS;
+  volatile lds_f64 *vsums = (volatile lds_f64 *)env.estcache;
+  const int slot = c & (ESTCACHE_SLOTS - 1);
+  if (tags[slot] != c) {
+    // the lanes of this instruction that miss on one slot agree on one of them (the last store wins); it takes the slot for its cell
+    const int lane = (int)(threadIdx.x & 63);
+    claim[slot] = lane;
+    if (claim[slot] == lane) {
+      const int old = tags[slot];
+      if (old >= 0) {  // what the slot held goes to the cell's record in memory
+        const double s0 = vsums[(slot * 3) + 0], s1 = vsums[(slot * 3) + 1], s2 = vsums[(slot * 3) + 2];
+        if (s0 != 0.) ARTIS_EST_ADD(&env.E.J[(int64_t)old * env.est_stride], s0);
+        if (s1 != 0.) ARTIS_EST_ADD(&env.E.nuJ[(int64_t)old * env.est_stride], s1);
+        if (s2 != 0.) ARTIS_EST_ADD(&env.E.ffheatingestimator[(int64_t)old * env.est_stride], s2);
+      }
+      vsums[(slot * 3) + 0] = 0.;
+      vsums[(slot * 3) + 1] = 0.;
+      vsums[(slot * 3) + 2] = 0.;
+      tags[slot] = c;
+    }
+  }
+  // (read again by every lane: a lane whose cell held the slot a moment ago may have lost it to a lane of the same instruction)
+  if (tags[slot] == c) {
+    __attribute__((address_space(3))) double *sl = (__attribute__((address_space(3))) double *)(env.estcache + (slot * 3));
+    __hip_atomic_fetch_add(sl + 0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(sl + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (f != 0.) __hip_atomic_fetch_add(sl + 2, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    ARTIS_EST_ADD(&env.E.J[(int64_t)c * env.est_stride], a);
+    ARTIS_EST_ADD(&env.E.nuJ[(int64_t)c * env.est_stride], b);
+    if (f != 0.) ARTIS_EST_ADD(&env.E.ffheatingestimator[(int64_t)c * env.est_stride], f);
+  }
+}
+#endif
+
 template <typename EnvT>
 AHD void scalar_add(const EnvT &env, int idx, double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -174,6 +219,15 @@ struct Env {
   // k_thermal 2330 ms with its one atomic per walk on colheatingestimator[cell], 590 ms without it). A workgroup then
   // accumulates in LDS, cellest_lds[kind * cellest_n + cell] for cell < cellest_n, and adds its sums to the global
   // arrays once, when the kernel ends. cellest_n_t / _r / _g: set by the host for k_thermal / k_rpkt / k_gamma (0 = off).
+  // ... and of a model with MANY cells (round 6): the three additions of an r-packet step (J, nuJ, ffheating of the cell the packet crossed) cost k_rpkt 16 of
+  // its 224 ms as device-wide atomics -- 1.1e9 requests per step, carried out beyond the XCDs' L2s. A wave's packets sit in ~21 cells that change slowly
+  // (the work list is sorted by cell), so every WAVE keeps a small direct-mapped cache of accumulators in LDS: estcache_tag[slot] = the cell whose three
+  // sums estcache[slot * 3 ...] holds (-1: none), slot = cell & (ESTCACHE_SLOTS - 1). An addition whose cell holds the slot is an LDS addition; one that does not evicts the
+  // slot's cell (its sums go to the global record: three atomics for however many additions they stand for) or, where two cells of one instruction
+  // want one slot, goes to memory itself. The wave empties its cache when the kernel ends. Null: every addition is a global atomic (est_cache_add()).
+  double *estcache;
+  int32_t *estcache_tag;
+  int32_t estcache_on;  // host switch (ARTIS_AMD_ESTCACHE=0: off)
   double *cellest_lds;
   const double *cellest_owner[3];  // the global array each kind of the running kernel stands for (anything else: global add)
   int32_t cellest_n, cellest_n_t, cellest_n_r, cellest_n_g;
@@ -4517,7 +4571,13 @@ AHD void rpkt_event_continuum(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_
 // update_estimators rpkt.cc:502 + radfield::update_estimators radfield.cc:745
 AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double distance, int c, const Chi &x, bool thick, int64_t slot) {
   const double de = distance * e_cmf;
-  if (de != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const bool cached = env.estcache != nullptr;  // (k_rpkt on a model with many cells: the wave's cache of accumulators)
+  if (cached && de != 0) est_cache_add(env, c, de, de * nu_cmf, thick ? 0. : de * x.chi_freefree_heat);
+#else
+  const bool cached = false;
+#endif
+  if (de != 0 && !cached) {
     cellest_add(env, env.E.J, CELLEST_J, c, de);
     cellest_add(env, env.E.nuJ, CELLEST_NUJ, c, de * nu_cmf);
   }
@@ -4535,7 +4595,7 @@ AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double d
     }
   }
 #endif
-  cellest_add(env, env.E.ffheatingestimator, CELLEST_FFHEAT, c, de * x.chi_freefree_heat);
+  if (!cached) cellest_add(env, env.E.ffheatingestimator, CELLEST_FFHEAT, c, de * x.chi_freefree_heat);
 #if ARTIS_OPT_USE_LUT_PHOTOION || ARTIS_OPT_USE_ION_BFHEATING_ESTIMATORS
   // update_bfestimators rpkt.cc:519: the loop runs over the ground continua in rising nu_edge until nu_cmf <= nu_edge;
   // entries whose groundcont_gamma_contr is zero add nothing and are not in the packet's list
