@@ -2460,8 +2460,9 @@ struct artis_amd_engine {
   // ARTIS_AMD_TILE_PARK_AT: packets left of a larger visit at which it parks them (0 / <= tail_max: round 4's rule, at the tail kernel's
   // threshold). Measured on the headline at a quarter of its cache (4 tiles, adaptive windows; profiles/r06/tiling.md): 4096 / 32768 / 131072 /
   // 524288 / 2097152 -> 2395 / 2147 / 1971 / 1899 / 1868 ms per step (untiled 760); with this round's rows for sets of cells and record tiers (two tiles
-  // of rows with a quarter of the levels hot): 131072 / 524288 / 2097152 -> 1550 / 1532 / 1504 ms
-  int64_t park_at = 2097152;
+  // of rows with a quarter of the levels hot): 131072 / 524288 / 2097152 / 3145728 / 4194304 -> 1550 / 1532 / 1504 (1485 on the box of the last two) / 1448 / 1452 ms;
+  // three tiles at 11600 MB: 2097152 / 3145728 / 4194304 -> 1590 / 1573 / 1670 ms
+  int64_t park_at = 3145728;
   int64_t last_parked = 0;
   int64_t last_pool_resets = 0;  // times the pool of on-demand records was emptied because it was used up (this call)
   int64_t last_pool_used = 0, last_pool_cap = 0;  // units (128 B) of the pool in use at the end of the last call / the pool's size
