@@ -1256,8 +1256,10 @@ __global__ void __launch_bounds__(TB, ARTIS_RPKT_WGS) k_rpkt(Env env, const int3
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   cellest_begin(env, lds_cellest, env.cellest_n_r, TB, env.E.J, env.E.nuJ, env.E.ffheatingestimator);
   env.estcache = nullptr;
+  env.estcache_nv = 0;
   if (!LINE_LDS && env.estcache_on && env.cellest_n_r == 0) {  // many cells: the wave's own cache instead of the workgroup's array
     const int w = threadIdx.x >> 6;
+    env.estcache_nv = 3;
     env.estcache = lds_estcache + (w * NEC * 3);
     env.estcache_tag = lds_esttag + (w * NEC * 2);
     for (int l = threadIdx.x & 63; l < NEC; l += 64) {
@@ -1559,6 +1561,22 @@ __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_the
   __shared__ uint16_t lds_tlevel[TABLES_LDS == 1 ? MA_LDS_TRANS : 8];
   if (threadIdx.x < ARTIS_NSTATS) lstats[threadIdx.x] = 0;
   cellest_begin(env, lds_cellest, env.cellest_n_t, TB, env.E.colheatingestimator);
+  env.estcache = nullptr;
+  env.estcache_nv = 0;
+  // many cells: the workgroup's array is not in use; its LDS holds the waves' caches of per-cell sums instead (physics.h Env::estcache): per wave
+  // ESTCACHE_SLOTS doubles, then per wave 2 x ESTCACHE_SLOTS int32 (the slots' cells, the claims)
+  static_assert(TABLES_LDS == 2 || (TB / 64) * ESTCACHE_SLOTS * 2 <= THERMAL_CELLEST_CAP, "the waves' estimator caches take the few-cells array's LDS");
+  if (TABLES_LDS != 2 && env.estcache_on && env.cellest_n_t == 0) {
+    const int w = threadIdx.x >> 6;
+    env.estcache = lds_cellest + (w * ESTCACHE_SLOTS);
+    env.estcache_tag = (int32_t *)(lds_cellest + ((TB / 64) * ESTCACHE_SLOTS)) + (w * ESTCACHE_SLOTS * 2);
+    env.estcache_nv = 1;
+    for (int l = threadIdx.x & 63; l < ESTCACHE_SLOTS; l += 64) {
+      env.estcache[l] = 0.;
+      env.estcache_tag[l] = -1;
+      env.estcache_tag[ESTCACHE_SLOTS + l] = -1;
+    }
+  }
   if (TABLES_LDS) {
     for (int i = threadIdx.x; i < env.M.nlevels; i += TB) lds_levelpack[i] = env.M.level_pack[i];
     env.M.level_pack = lds_levelpack;
@@ -1691,6 +1709,13 @@ __global__ void __launch_bounds__(TB, (TABLES_LDS ? 1 : ARTIS_THERMAL_EU)) k_the
 #endif
   }
   __syncthreads();
+  if (env.estcache_nv == 1) {  // the wave's sums go to the cells' records
+    for (int l = threadIdx.x & 63; l < ESTCACHE_SLOTS; l += 64) {
+      const int cell = env.estcache_tag[l];
+      const double s0 = env.estcache[l];
+      if (cell >= 0 && s0 != 0.) unsafeAtomicAdd(&env.E.colheatingestimator[(int64_t)cell * env.est_stride], s0);
+    }
+  }
   cellest_flush(env, CELLEST_COLHEAT, env.E.colheatingestimator, TB);
   if (threadIdx.x < ARTIS_NSTATS && lstats[threadIdx.x] != 0) atomicAdd(&gstats[threadIdx.x], lstats[threadIdx.x]);
 }

@@ -166,6 +166,36 @@ __device__ inline void est_cache_add(const EnvT &env, int c, double a, double b,
 }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ... with one sum per cell (k_thermal: global_array = colheatingestimator); the same protocol
+template <typename EnvT>
+__device__ inline void est_cache_add_one(const EnvT &env, double *global_array, int c, double v) {
+  typedef __attribute__((address_space(3))) int32_t lds_i32;
+  typedef __attribute__((address_space(3))) double lds_f64;
+  volatile lds_i32 *tags = (volatile lds_i32 *)env.estcache_tag;
+  volatile lds_i32 *claim = tags + ESTCACHE_SLOTS;
+  volatile lds_f64 *vsums = (volatile lds_f64 *)env.estcache;
+  const int slot = c & (ESTCACHE_SLOTS - 1);
+  if (tags[slot] != c) {
+    const int lane = (int)(threadIdx.x & 63);
+    claim[slot] = lane;
+    if (claim[slot] == lane) {
+      const int old = tags[slot];
+      if (old >= 0) {
+        const double s0 = vsums[slot];
+        if (s0 != 0.) ARTIS_EST_ADD(&global_array[(int64_t)old * env.est_stride], s0);
+      }
+      vsums[slot] = 0.;
+      tags[slot] = c;
+    }
+  }
+  if (tags[slot] == c)
+    __hip_atomic_fetch_add((__attribute__((address_space(3))) double *)(env.estcache + slot), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    ARTIS_EST_ADD(&global_array[(int64_t)c * env.est_stride], v);
+}
+#endif
+
 template <typename EnvT>
 AHD void scalar_add(const EnvT &env, int idx, double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -225,8 +255,12 @@ struct Env {
   // sums estcache[slot * 3 ...] holds (-1: none), slot = cell & (ESTCACHE_SLOTS - 1). An addition whose cell holds the slot is an LDS addition; one that does not evicts the
   // slot's cell (its sums go to the global record: three atomics for however many additions they stand for) or, where two cells of one instruction
   // want one slot, goes to memory itself. The wave empties its cache when the kernel ends. Null: every addition is a global atomic (est_cache_add()).
+  // k_thermal keeps the one sum it adds per cell (colheatingestimator: one addition per collisional de-excitation / recombination of a macro-atom) the
+  // same way (estcache_nv = 1, est_cache_add_one(); in the LDS its workgroup array of a few-cells model would take): with 4e3 ... 2e4 cells -- above the
+  // few-cells caps, thousands of packets per cell -- its additions otherwise queue on a few addresses.
   double *estcache;
   int32_t *estcache_tag;
+  int32_t estcache_nv;  // sums per slot: 3 (k_rpkt) / 1 (k_thermal); 0: no cache in this kernel
   int32_t estcache_on;  // host switch (ARTIS_AMD_ESTCACHE=0: off)
   double *cellest_lds;
   const double *cellest_owner[3];  // the global array each kind of the running kernel stands for (anything else: global add)
@@ -4205,7 +4239,12 @@ AHD void ma_jump_exit(const Env &env, Pkt &p, int64_t pi, MACtx &k, const U4 *re
     ARTIS_STAT(env, action == ARTIS_MA_ACTION_COLDEEXC ? ARTIS_STAT_MA_DEACTIVATION_COLLDEEXC : ARTIS_STAT_MA_DEACTIVATION_COLLRECOMB);
     p.type = ARTIS_TYPE_KPKT;
 #if !ARTIS_OPT_DIRECT_COL_HEAT
-    cellest_add(env, env.E.colheatingestimator, CELLEST_COLHEAT, c, p.e_cmf);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (env.estcache_nv == 1)
+      est_cache_add_one(env, env.E.colheatingestimator, c, p.e_cmf);
+    else
+#endif
+      cellest_add(env, env.E.colheatingestimator, CELLEST_COLHEAT, c, p.e_cmf);
 #endif
     ma_finish(env, p, pi);
   } else if (action != MA_EXIT_FAILED) {
@@ -4572,7 +4611,7 @@ AHD void rpkt_event_continuum(const Env &env, Pkt &p, int64_t pi, Chi &x, int64_
 AHD void update_estimators(const Env &env, double e_cmf, double nu_cmf, double distance, int c, const Chi &x, bool thick, int64_t slot) {
   const double de = distance * e_cmf;
 #if defined(__HIP_DEVICE_COMPILE__)
-  const bool cached = env.estcache != nullptr;  // (k_rpkt on a model with many cells: the wave's cache of accumulators)
+  const bool cached = env.estcache_nv == 3;  // (k_rpkt on a model with many cells: the wave's cache of accumulators)
   if (cached && de != 0) est_cache_add(env, c, de, de * nu_cmf, thick ? 0. : de * x.chi_freefree_heat);
 #else
   const bool cached = false;
